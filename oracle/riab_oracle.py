@@ -1,0 +1,632 @@
+"""CPU oracle: a float64 NumPy restatement of RatInABox's per-step hot path.
+
+TEST INFRASTRUCTURE — NOT PRODUCT CODE.  Only `tests/`, `__graft_entry__.smoke()`
+and the `cpu_baseline` leg of `bench.py` may import this module; the product
+package `ratinabox_amd` never does (it fails loudly if the HIP library is missing).
+
+Every function restates, batched over agents/positions, the arithmetic of one
+reference function and cites it (paths relative to /root/reference).  The
+restatement is pinned against the reference itself: `tests/golden/make_golden.py`
+imports the reference in the build container, drives it with captured noise and
+stores input/output vectors under `tests/golden/*.npz`; `tests/test_oracle_golden.py`
+checks this module against those vectors (float64, rtol ~1e-12).  The reference's
+own test-suite holds no numeric assertion on this path (tests/test_agent.py and
+tests/test_neurons.py are empty), so these generated vectors are the pin.
+
+Conventions
+-----------
+* positions `pos` are `(P, 2)` float64, firing rates are `(n_cells, P)` like the
+  reference's `get_state(evaluate_at=None, pos=...)` (Neurons.py:943-949).
+* walls are `(N_w, 2, 2)` in `Environment.walls` order (Environment.py:128-163).
+* the reference's random geometric jitter (utils.py:64-69, 143-144) is NOT
+  applied (the golden vectors are generated with it patched to zero); divisions
+  by zero follow IEEE semantics exactly like the zero-jitter reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy import special as _sp
+
+TWO_PI = 2 * np.pi
+
+
+# --------------------------------------------------------------------------- #
+# small helpers (utils.py)
+# --------------------------------------------------------------------------- #
+def get_angle(vec):
+    """utils.get_angle (utils.py:231-273) for direction vectors `(..., 2)`:
+    `mod(arctan2(y, x + 1e-6), 2*pi)`."""
+    vec = np.asarray(vec, dtype=np.float64)
+    return np.mod(np.arctan2(vec[..., 1], vec[..., 0] + 1e-6), TWO_PI)
+
+
+def pi_domain(x):
+    """utils.pi_domain (utils.py:331-341): `x mod 2pi`, minus 2pi where > pi."""
+    x = np.asarray(x, dtype=np.float64) % TWO_PI
+    return np.where(x > np.pi, -TWO_PI + x, x)
+
+
+def ou_increment(x, dt, drift, noise_scale, coherence_time, z):
+    """utils.ornstein_uhlenbeck (utils.py:347-368) with the standard-normal draw
+    `z` made explicit: the reference draws `normal(scale=dt)` = `dt*z`."""
+    sigma = np.sqrt((2 * noise_scale**2) / (coherence_time * dt))
+    theta = 1 / coherence_time
+    return theta * (drift - x) * dt + sigma * (dt * z)
+
+
+def rayleigh_to_normal(x, sigma):
+    """utils.rayleigh_to_normal (utils.py:416-421); stats.norm.ppf == special.ndtri."""
+    u = 1 - np.exp(-(x**2) / (2 * sigma**2))
+    u = np.minimum(np.maximum(1e-6, u), 1 - 1e-6)
+    return _sp.ndtri(u)
+
+
+def normal_to_rayleigh(x, sigma):
+    """utils.normal_to_rayleigh (utils.py:409-413); stats.norm.cdf == special.ndtr."""
+    u = _sp.ndtr(x)
+    return sigma * np.sqrt(-2 * np.log(1 - u))
+
+
+def gaussian(x, mu, sigma):
+    """utils.gaussian(..., norm=1) (utils.py:424-438)."""
+    return np.exp(-((x - mu) ** 2) / (2 * sigma**2))
+
+
+def von_mises(theta, mu, sigma):
+    """utils.von_mises(..., norm=1) (utils.py:441-457): the reference evaluates
+    `exp(k cos) * (1/exp(k))`; restated as `exp(k (cos - 1))` (identical up to
+    rounding, and does not overflow for small sigma — SURVEY App. C-13)."""
+    kappa = 1 / (sigma**2)
+    return np.exp(kappa * (np.cos(theta - mu) - 1.0))
+
+
+# --------------------------------------------------------------------------- #
+# geometry (utils.py:30-184)
+# --------------------------------------------------------------------------- #
+def segment_intercepts(seg_a, seg_b):
+    """utils.vector_intercepts (utils.py:30-118) without the 1e-9 jitter.
+
+    seg_a `(Na,2,2)`, seg_b `(Nb,2,2)` -> `(l_a, l_b)` each `(Na,Nb)`: the line
+    parameters of the intersection of the infinite lines through each pair."""
+    seg_a = np.asarray(seg_a, dtype=np.float64).reshape(-1, 2, 2)
+    seg_b = np.asarray(seg_b, dtype=np.float64).reshape(-1, 2, 2)
+    d0 = seg_b[None, :, 0, :] - seg_a[:, None, 0, :]  # (Na,Nb,2)
+    sa = (seg_a[:, 1, :] - seg_a[:, 0, :])[:, None, :]  # (Na,1,2)
+    sb = (seg_b[:, 1, :] - seg_b[:, 0, :])[None, :, :]  # (1,Nb,2)
+    sa_p = np.stack((-sa[..., 1], sa[..., 0]), axis=-1)
+    sb_p = np.stack((-sb[..., 1], sb[..., 0]), axis=-1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        l_a = (d0[..., 0] * sb_p[..., 0] + d0[..., 1] * sb_p[..., 1]) / (
+            sa[..., 0] * sb_p[..., 0] + sa[..., 1] * sb_p[..., 1]
+        )
+        l_b = ((-d0[..., 0]) * sa_p[..., 0] + (-d0[..., 1]) * sa_p[..., 1]) / (
+            sb[..., 0] * sa_p[..., 0] + sb[..., 1] * sa_p[..., 1]
+        )
+    return l_a, l_b
+
+
+def segments_collide(seg_a, seg_b):
+    """`return_collisions=True` branch of utils.vector_intercepts (utils.py:99-106):
+    both parameters strictly inside (0, 1)."""
+    l_a, l_b = segment_intercepts(seg_a, seg_b)
+    return (l_a > 0) & (l_a < 1) & (l_b > 0) & (l_b < 1)
+
+
+def shortest_vectors_from_walls(pos, walls):
+    """utils.shortest_vectors_from_points_to_lines (utils.py:121-184) without the
+    1e-6 jitter.  pos `(P,2)`, walls `(Nw,2,2)` -> `(P,Nw,2)` vectors from the
+    nearest point of each wall segment to each position."""
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 2)
+    walls = np.asarray(walls, dtype=np.float64).reshape(-1, 2, 2)
+    d = pos[:, None, :] - walls[None, :, 0, :]
+    s = walls[:, 1, :] - walls[:, 0, :]
+    l_v = (d[..., 0] * s[:, 0] + d[..., 1] * s[:, 1]) / (s[:, 0] * s[:, 0] + s[:, 1] * s[:, 1])
+    l_v = np.where(l_v > 1, 1.0, l_v)
+    l_v = np.where(l_v < 0, 0.0, l_v)
+    return pos[:, None, :] - (walls[None, :, 0, :] + l_v[..., None] * s[None, :, :])
+
+
+# --------------------------------------------------------------------------- #
+# Environment queries (Environment.py)
+# --------------------------------------------------------------------------- #
+class EnvSpec:
+    """The subset of `Environment` state the hot path reads (Environment.py:65-191):
+    rectangular 2D box `[0, aspect*scale] x [0, scale]`, solid or periodic,
+    `walls` in reference order (4 boundary walls first when solid)."""
+
+    def __init__(self, scale=1.0, aspect=1.0, boundary_conditions="solid", walls=()):
+        self.scale = float(scale)
+        self.aspect = float(aspect)
+        self.boundary_conditions = boundary_conditions
+        b = [[0, 0], [aspect * scale, 0], [aspect * scale, scale], [0, scale]]
+        user = np.asarray(walls, dtype=np.float64).reshape(-1, 2, 2)
+        if boundary_conditions == "solid":
+            # Environment.py:137-144: wall i runs from b[i+1] to b[i]
+            bw = np.array([[b[(i + 1) % 4], b[i]] for i in range(4)], dtype=np.float64)
+            self.walls = np.vstack((bw, user))
+        else:
+            self.walls = user
+        self.extent = np.array([0.0, aspect * scale, 0.0, scale])
+
+    @property
+    def periodic(self):
+        return self.boundary_conditions == "periodic"
+
+
+def env_vectors_between(env, pos1, pos2):
+    """Environment.get_vectors_between___accounting_for_environment
+    (Environment.py:657-675): pairwise `pos1[i] - pos2[j]`, wrapped by `scale`
+    when periodic.  -> `(N1,N2,2)`."""
+    v = np.asarray(pos1, dtype=np.float64).reshape(-1, 1, 2) - np.asarray(pos2, dtype=np.float64).reshape(1, -1, 2)
+    if env.periodic:
+        flip = np.abs(v) > (env.scale / 2)
+        v = np.where(flip, -np.sign(v) * (env.scale - np.abs(v)), v)
+    return v
+
+
+def env_distances(env, pos1, pos2, wall_geometry="euclidean"):
+    """Environment.get_distances_between___accounting_for_environment
+    (Environment.py:677-779) for 2D: euclidean / line_of_sight / geodesic."""
+    pos1 = np.asarray(pos1, dtype=np.float64).reshape(-1, 2)
+    pos2 = np.asarray(pos2, dtype=np.float64).reshape(-1, 2)
+    vec = env_vectors_between(env, pos1, pos2)
+    dist = np.sqrt(vec[..., 0] ** 2 + vec[..., 1] ** 2)
+    if wall_geometry == "euclidean":
+        return dist
+    segs = np.stack(
+        (np.repeat(pos1[:, None, :], len(pos2), 1), np.repeat(pos2[None, :, :], len(pos1), 0)), axis=-2
+    ).reshape(-1, 2, 2)
+    if wall_geometry == "line_of_sight":
+        internal = env.walls[4:]  # Environment.py:715-717
+        if len(internal):
+            blocked = segments_collide(segs, internal).sum(axis=-1) != 0
+            dist = np.where(blocked.reshape(dist.shape), 1000.0, dist)
+        return dist
+    if wall_geometry == "geodesic":
+        assert len(env.walls) <= 5  # Environment.py:736-739
+        if len(env.walls) == 4:
+            return dist
+        wall = env.walls[4]
+        via = []
+        for e in wall:  # Environment.py:746-753: only endpoints strictly inside the env
+            if (e[0] > env.extent[0]) and (e[0] < env.extent[1]) and (e[1] > env.extent[2]) and (e[1] < env.extent[3]):
+                d1 = np.sqrt(((pos1 - e) ** 2).sum(-1))[:, None]
+                d2 = np.sqrt(((e - pos2) ** 2).sum(-1))[None, :]
+                via.append(d1 + d2)
+        blocked = segments_collide(segs, wall[None]).reshape(dist.shape)
+        if via:
+            dist = np.where(blocked, np.amin(np.array(via), axis=0), dist)
+        return dist
+    raise ValueError(wall_geometry)
+
+
+def env_is_inside(env, pos):
+    """Environment.check_if_position_is_in_environment (Environment.py:781-818)
+    for a rectangular box without holes: strict interior (shapely `contains`)."""
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 2)
+    e = env.extent
+    return (pos[:, 0] > e[0]) & (pos[:, 0] < e[1]) & (pos[:, 1] > e[2]) & (pos[:, 1] < e[3])
+
+
+def env_apply_boundary_conditions(env, pos):
+    """Environment.apply_boundary_conditions (Environment.py:855-894), rectangular:
+    solid -> clamp to [min+0.01, max-0.01]; periodic -> modulo the extent."""
+    pos = np.array(pos, dtype=np.float64).reshape(-1, 2)
+    e = env.extent
+    if env.periodic:
+        return np.stack((pos[:, 0] % e[1], pos[:, 1] % e[3]), axis=-1)
+    x = np.minimum(np.maximum(pos[:, 0], e[0] + 0.01), e[1] - 0.01)
+    y = np.minimum(np.maximum(pos[:, 1], e[2] + 0.01), e[3] - 0.01)
+    return np.stack((x, y), axis=-1)
+
+
+# --------------------------------------------------------------------------- #
+# Agent.update (Agent.py:160-242)
+# --------------------------------------------------------------------------- #
+DEFAULT_MOTION = dict(  # Agent.default_params (Agent.py:68-84)
+    speed_coherence_time=0.7,
+    speed_mean=0.08,
+    speed_std=0.08,
+    rotational_velocity_coherence_time=0.08,
+    rotational_velocity_std=120 * (np.pi / 180),
+    head_direction_smoothing_timescale=0.15,
+    thigmotaxis=0.5,
+    wall_repel_distance=0.1,
+    wall_repel_strength=1.0,
+)
+
+MAX_BOUNCES = 16  # the reference loops `while True` (Agent.py:426); bounded here and on the GPU
+
+
+def init_state(env, n_agents, speed_mean, rng):
+    """Agent.initialise_position_and_velocity (Agent.py:523-535) + Agent.__init__
+    (Agent.py:128-141), batched: uniform position, uniform heading."""
+    pos = np.stack(
+        (rng.uniform(env.extent[0], env.extent[1], n_agents), rng.uniform(env.extent[2], env.extent[3], n_agents)),
+        axis=-1,
+    )
+    direction = rng.uniform(0, TWO_PI, n_agents)
+    vel = speed_mean * np.stack((np.cos(direction), np.sin(direction)), axis=-1)
+    return dict(
+        pos=pos,
+        velocity=vel.copy(),
+        rotational_velocity=np.zeros(n_agents),
+        measured_velocity=vel.copy(),
+        measured_rotational_velocity=np.zeros(n_agents),
+        head_direction=vel / np.linalg.norm(vel, axis=-1, keepdims=True),
+        distance_travelled=np.zeros(n_agents),
+        distance_to_closest_wall=np.full(n_agents, np.inf),
+    )
+
+
+def agent_step(env, state, dt, z_rot, z_speed, params=None, drift_velocity=None,
+               drift_to_random_strength_ratio=1.0, z_zero=None, kwargs=None):
+    """One `Agent.update()` (Agent.py:160-242, random-motion branch, 2D) for B
+    independent agents.  `state` is a dict of `(B,...)` float64 arrays (see
+    `init_state`); `z_rot`, `z_speed` `(B,)` are the two standard-normal draws
+    the reference takes per update.  `params` are the Agent's
+    attributes, `kwargs` the per-call overrides `Agent.update(**kwargs)` forwards
+    to the sub-steps (Agent.py:280-285, 353-355) — note the reference reads some
+    quantities from the attribute even when a kwarg is given (speed_std==0 switch
+    :310, wall spring speed :375, bounce speed :439, drift tau :340).  Returns a
+    new state dict plus `n_bounces (B,)` and `bc_applied (B,)` diagnostics."""
+    p = dict(DEFAULT_MOTION)
+    if params:
+        p.update(params)
+    kw = dict(kwargs or {})
+    rotational_velocity_drift = kw.get("rotational_velocity_drift", 0.0)
+    pos = np.array(state["pos"], dtype=np.float64)
+    vel = np.array(state["velocity"], dtype=np.float64)
+    rot = np.array(state["rotational_velocity"], dtype=np.float64)
+    prev_mv = np.array(state["measured_velocity"], dtype=np.float64)
+    hd = np.array(state["head_direction"], dtype=np.float64)
+    dist_trav = np.array(state["distance_travelled"], dtype=np.float64)
+    dclose = np.array(state["distance_to_closest_wall"], dtype=np.float64)
+    B = pos.shape[0]
+    prev_pos = pos.copy()
+    speed_mean = p["speed_mean"]
+
+    # -- _stochastic_velocity_update (Agent.py:268-312)
+    rot = rot + ou_increment(rot, dt, rotational_velocity_drift,
+                             kw.get("rotational_velocity_std", p["rotational_velocity_std"]),
+                             kw.get("rotational_velocity_coherence_time", p["rotational_velocity_coherence_time"]),
+                             z_rot)
+    dtheta = rot * dt
+    c, s = np.cos(dtheta), np.sin(dtheta)
+    vel = np.stack((c * vel[:, 0] + (-s) * vel[:, 1], s * vel[:, 0] + c * vel[:, 1]), axis=-1)
+    speed = np.sqrt(vel[:, 0] * vel[:, 0] + vel[:, 1] * vel[:, 1])
+    zero = speed == 0
+    vel = np.where(zero[:, None], np.array([1e-8, 0.0]), vel)
+    speed = np.where(zero, 1e-8, speed)
+    sm_kw = kw.get("speed_mean", speed_mean)
+    nv = rayleigh_to_normal(speed, sm_kw)
+    nv = nv + ou_increment(nv, dt, 0.0, 1.0, kw.get("speed_coherence_time", p["speed_coherence_time"]), z_speed)
+    speed_new = normal_to_rayleigh(nv, sm_kw)
+    if p["speed_std"] == 0:
+        speed_new = np.full(B, float(sm_kw))
+    vel = (speed_new / speed)[:, None] * vel
+
+    # -- _drift_velocity_update (Agent.py:324-341)
+    if drift_velocity is not None:
+        dv = np.asarray(drift_velocity, dtype=np.float64).reshape(-1, 2)
+        tau = p["speed_coherence_time"] / drift_to_random_strength_ratio
+        vel = vel + (1 / tau) * (dv - vel) * dt
+
+    # -- _wall_velocity_update (Agent.py:343-415)
+    walls = env.walls
+    wall_repel_strength = kw.get("wall_repel_strength", p["wall_repel_strength"])
+    if wall_repel_strength != 0.0 and len(walls) > 0:
+        vw = shortest_vectors_from_walls(pos, walls)  # (B,Nw,2)
+        x = np.sqrt(vw[..., 0] ** 2 + vw[..., 1] ** 2)
+        dclose = x.min(axis=1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            nvec = vw / x[..., None]
+        d = kw.get("wall_repel_distance", p["wall_repel_distance"])
+        v0 = wall_repel_strength * speed_mean
+        k = v0**2 / d**2
+        near = x <= d
+        with np.errstate(invalid="ignore"):
+            acc = np.where(near, k * (d - x), 0.0)
+            spd = np.where(near, v0 * (1 - np.sqrt(1 - (d - x) ** 2 / d**2)), 0.0)
+        acc_sum = np.zeros((B, 2))
+        spd_sum = np.zeros((B, 2))
+        for w in range(len(walls)):  # sequential sum over walls, like ndarray.sum(axis=0)
+            acc_sum = acc_sum + acc[:, w, None] * nvec[:, w, :]
+            spd_sum = spd_sum + spd[:, w, None] * nvec[:, w, :]
+        g = kw.get("thigmotaxis", p["thigmotaxis"])
+        vel = vel + 3 * ((1 - g) ** 2) * (acc_sum * dt)
+        pos = pos + 6 * (g**2) * (spd_sum * dt)
+
+    # -- propose (Agent.py:216)
+    pos = pos + vel * dt
+
+    # -- _check_and_handle_wall_collisions (Agent.py:423-441)
+    n_bounces = np.zeros(B, dtype=np.int32)
+    if len(walls) > 0:
+        active = np.ones(B, dtype=bool)
+        for _ in range(MAX_BOUNCES):
+            idx = np.nonzero(active)[0]
+            if len(idx) == 0:
+                break
+            for i in idx:
+                step = np.array([prev_pos[i], pos[i]])
+                hits = segments_collide(walls, step[None]).reshape(-1)
+                if not hits.any():
+                    active[i] = False
+                    continue
+                w = walls[np.argmax(hits)]  # first colliding wall = lowest index
+                vel[i] = wall_bounce(vel[i], w)
+                vel[i] = (0.5 * speed_mean / np.sqrt(vel[i, 0] ** 2 + vel[i, 1] ** 2)) * vel[i]
+                pos[i] = prev_pos[i] + vel[i] * dt
+                n_bounces[i] += 1
+
+    # -- boundary safety net (Agent.py:221-222)
+    outside = ~env_is_inside(env, pos)
+    if outside.any():
+        pos = np.where(outside[:, None], env_apply_boundary_conditions(env, pos), pos)
+
+    # -- _measure_velocity_of_step_taken (Agent.py:444-472)
+    d_pos = pos - prev_pos
+    if env.periodic:
+        flip = np.abs(d_pos) > (env.scale / 2)
+        d_pos = np.where(flip, -np.sign(d_pos) * (env.scale - np.abs(d_pos)), d_pos)
+    mv = d_pos / dt
+    mv_norm = np.sqrt(mv[:, 0] ** 2 + mv[:, 1] ** 2)
+    still = mv_norm == 0
+    if still.any():
+        zz = np.zeros((B, 2)) if z_zero is None else np.asarray(z_zero, dtype=np.float64).reshape(B, 2)
+        mv = np.where(still[:, None], 1e-8 * zz, mv)
+        mv_norm = np.sqrt(mv[:, 0] ** 2 + mv[:, 1] ** 2)
+    mrv = pi_domain(get_angle(mv) - get_angle(prev_mv)) / dt
+
+    # -- _update_head_direction (Agent.py:474-500)
+    tau_h = p["head_direction_smoothing_timescale"]
+    imm = mv / mv_norm[:, None]
+    if tau_h <= dt:
+        hd = imm
+    else:
+        hd = hd * (1 - dt / tau_h) + dt / tau_h * imm
+        hd = hd / np.sqrt(hd[:, 0] ** 2 + hd[:, 1] ** 2)[:, None]
+
+    # -- _update_distance_travelled (Agent.py:502-507)
+    dist_trav = dist_trav + np.sqrt(d_pos[:, 0] ** 2 + d_pos[:, 1] ** 2)
+
+    return dict(
+        pos=pos,
+        velocity=vel,
+        rotational_velocity=rot,
+        measured_velocity=mv,
+        measured_rotational_velocity=mrv,
+        head_direction=hd,
+        distance_travelled=dist_trav,
+        distance_to_closest_wall=dclose,
+        n_bounces=n_bounces,
+        bc_applied=outside,
+    )
+
+
+def wall_bounce(v, wall):
+    """utils.wall_bounce (utils.py:304-328) for one velocity `(2,)` and wall `(2,2)`."""
+    par = wall[1] - wall[0]
+    perp = np.array([-par[1], par[0]])
+    if perp[0] * v[0] + perp[1] * v[1] <= 0:
+        perp = -perp
+    if par[0] * v[0] + par[1] * v[1] <= 0:
+        par = -par
+    par = par / np.sqrt(par[0] ** 2 + par[1] ** 2)
+    perp = perp / np.sqrt(perp[0] ** 2 + perp[1] ** 2)
+    return par * (v[0] * par[0] + v[1] * par[1]) - perp * (v[0] * perp[0] + v[1] * perp[1])
+
+
+# --------------------------------------------------------------------------- #
+# Neurons.get_state (Neurons.py)
+# --------------------------------------------------------------------------- #
+def place_cells(env, pos, centres, widths, description="gaussian", wall_geometry="euclidean",
+                min_fr=0.0, max_fr=1.0, widths_scalar=None):
+    """PlaceCells.get_state (Neurons.py:936-981) -> `(n, P)`."""
+    centres = np.asarray(centres, dtype=np.float64).reshape(-1, 2)
+    w = (np.asarray(widths, dtype=np.float64) * np.ones(len(centres)))[:, None]
+    dist = env_distances(env, centres, pos, wall_geometry)
+    if description == "gaussian":
+        fr = np.exp(-(dist**2) / (2 * (w**2)))
+    elif description == "gaussian_threshold":
+        fr = np.maximum(np.exp(-(dist**2) / (2 * (w**2))) - np.exp(-1 / 2), 0) / (1 - np.exp(-1 / 2))
+    elif description == "diff_of_gaussians":
+        ratio = 1.5
+        fr = np.exp(-(dist**2) / (2 * (w**2))) - (1 / ratio**2) * np.exp(-(dist**2) / (2 * ((ratio * w) ** 2)))
+        fr = fr * (ratio**2 / (ratio**2 - 1))
+    elif description == "one_hot":
+        closest = np.argmin(np.abs(dist), axis=0)
+        fr = np.eye(len(centres))[closest].T
+    elif description == "top_hat":
+        ws = w[0, 0] if widths_scalar is None else widths_scalar  # Neurons.py:976 uses the scalar `widths`
+        fr = 1.0 * (dist < ws)
+    else:
+        raise ValueError(description)
+    return fr * (max_fr - min_fr) + min_fr
+
+
+def grid_cell_w(orientations):
+    """GridCells.__init__ wave-vector construction (Neurons.py:1154-1161) -> `(n,3,2)`."""
+    def rot(v, th):
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        return R @ v
+    w = []
+    for th in np.asarray(orientations, dtype=np.float64):
+        w1 = rot(np.array([1, 0]), th)
+        w.append(np.array([w1, rot(w1, np.pi / 3), rot(w1, 2 * np.pi / 3)]))
+    return np.array(w)
+
+
+def grid_cells(pos, gridscales, phase_offsets, w, description="rectified_cosines",
+               width_ratio=4 / (3 * np.sqrt(3)), min_fr=0.0, max_fr=1.0):
+    """GridCells.get_state, 2D (Neurons.py:1172-1236) -> `(n, P)`."""
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 2)
+    gs = np.asarray(gridscales, dtype=np.float64)
+    origin = gs.reshape(-1, 1) * np.asarray(phase_offsets, dtype=np.float64) / (2 * np.pi)
+    vecs = origin[:, None, :] - pos[None, :, :]  # utils.get_vectors_between(origin, pos)
+    k = ((2 * np.pi) / gs)[:, None]
+    phi = [k * (vecs[..., 0] * w[:, i, 0][:, None] + vecs[..., 1] * w[:, i, 1][:, None]) for i in range(3)]
+    if description == "rectified_cosines":
+        fr = (1 / 3) * (np.cos(phi[0]) + np.cos(phi[1]) + np.cos(phi[2]))
+        f0 = (1 / 3) * (2 * np.cos(np.sqrt(3) * np.pi * width_ratio / 2) + 1)
+        fr = (fr - f0) / (1 - f0)
+        fr = np.where(fr < 0, 0.0, fr)
+    elif description == "shifted_cosines":
+        fr = (2 / 3) * ((1 / 3) * (np.cos(phi[0]) + np.cos(phi[1]) + np.cos(phi[2])) + (1 / 2))
+    else:
+        raise ValueError(description)
+    return fr * (max_fr - min_fr) + min_fr
+
+
+def bvc_test_angles(dtheta=2):
+    """BoundaryVectorCells.__init__ (Neurons.py:1584-1596): K = int(360/dtheta)
+    angles `[0] + [2*pi*i*dtheta/360 for i in range(K-1)]` (0 deg duplicated, the
+    last angle missing — SURVEY App. C-2) and unit directions `R(angle)(1,0)`."""
+    K = int(360 / dtheta)
+    angles = [0.0] + [2 * np.pi * i * dtheta / 360 for i in range(K - 1)]
+    angles = np.array(angles)
+    dirs = np.stack((np.cos(angles) * 1 + (-np.sin(angles)) * 0, np.sin(angles) * 1 + np.cos(angles) * 0), axis=-1)
+    dirs[0] = np.array([1.0, 0.0])
+    return angles, dirs
+
+
+def bvc_fr_norm(test_angles, sigma_angles):
+    """`cell_fr_norm` (Neurons.py:1598-1604): sum over test angles of von_mises(theta; 0, sigma)."""
+    return von_mises(test_angles.reshape(1, -1), 0.0, np.asarray(sigma_angles).reshape(-1, 1)).sum(axis=1)
+
+
+def bvc_ray_distances(pos, walls, test_dirs):
+    """Ray stage of BoundaryVectorCells.get_state (Neurons.py:1655-1684, 1746-1778):
+    for each position and test direction the line parameter (= distance, rays are
+    unit length) to the first wall hit.  -> `(P, K)`."""
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 2)
+    P, K = len(pos), len(test_dirs)
+    segs = np.empty((P, K, 2, 2))
+    segs[:, :, 0, :] = pos[:, None, :]
+    segs[:, :, 1, :] = pos[:, None, :] + test_dirs[None, :, :]
+    l_a, l_b = segment_intercepts(segs.reshape(-1, 2, 2), walls)
+    l_a = l_a.reshape(P, K, -1)
+    l_b = l_b.reshape(P, K, -1)
+    # boundary_vector_preference_function: np.piecewise, later conditions overwrite earlier
+    pref = np.zeros_like(l_a)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pref = np.where(l_a > 0, 1 / l_a, pref)
+    pref = np.where(l_a < 0, -1.0, pref)
+    pref = np.where(l_b < 0, -1.0, pref)
+    pref = np.where(l_b > 1, -1.0, pref)
+    first = np.argmax(pref, axis=-1)[..., None]
+    return np.take_along_axis(l_a, first, axis=-1)[..., 0]
+
+
+def bvc(pos, walls, tuning_distances, tuning_angles, sigma_distances, sigma_angles, dtheta=2,
+        head_direction=None, min_fr=0.0, max_fr=1.0):
+    """BoundaryVectorCells.get_state (Neurons.py:1617-1744) -> `(n, P)`.
+    `head_direction` `(P,2)` switches to the egocentric frame (test angles are
+    shifted by the head bearing, the rays themselves stay allocentric)."""
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 2)
+    angles, dirs = bvc_test_angles(dtheta)
+    d = bvc_ray_distances(pos, walls, dirs)  # (P,K)
+    th = np.broadcast_to(angles[None, :], d.shape)
+    if head_direction is not None:
+        hdir = np.asarray(head_direction, dtype=np.float64).reshape(-1, 2)
+        th = th - get_angle(hdir)[:, None]
+    mu_d = np.asarray(tuning_distances, dtype=np.float64)[:, None, None]
+    sg_d = np.asarray(sigma_distances, dtype=np.float64)[:, None, None]
+    mu_a = np.asarray(tuning_angles, dtype=np.float64)[:, None, None]
+    sg_a = np.asarray(sigma_angles, dtype=np.float64)[:, None, None]
+    out = np.empty((mu_d.shape[0], len(pos)))
+    norm = bvc_fr_norm(angles, np.asarray(sigma_angles, dtype=np.float64))
+    chunk = max(1, int(2_000_000 // max(1, d.shape[1] * mu_d.shape[0])))
+    for s in range(0, len(pos), chunk):
+        dd = d[None, s:s + chunk, :]
+        tt = th[None, s:s + chunk, :]
+        g = gaussian(dd, mu_d, sg_d) * von_mises(tt, mu_a, sg_a)
+        out[:, s:s + chunk] = g.sum(axis=-1)
+    out = out / norm[:, None]
+    return out * (max_fr - min_fr) + min_fr
+
+
+def head_direction_cells(head_direction, n, angular_spread_degrees=45.0, min_fr=0.0, max_fr=1.0):
+    """HeadDirectionCells.get_state, 2D (Neurons.py:2403-2409, 2466-2483) -> `(n, P)`."""
+    hd = np.asarray(head_direction, dtype=np.float64).reshape(-1, 2)
+    pref = np.linspace(0, 2 * np.pi, n + 1)[:-1]
+    sig = angular_spread_degrees * np.pi / 180
+    fr = von_mises(get_angle(hd)[None, :], pref[:, None], sig)
+    return fr * (max_fr - min_fr) + min_fr
+
+
+# --------------------------------------------------------------------------- #
+# Neurons.update noise + spikes (Neurons.py:145-171, 681-687)
+# --------------------------------------------------------------------------- #
+def spikes_ref(rates, u, dt):
+    """Neurons.save_to_history (Neurons.py:682-684), float64: `u < dt * firingrate`."""
+    return np.asarray(u) < (dt * np.asarray(rates))
+
+
+def spikes_f32(rates32, u32, dt):
+    """The product's exactly-specified spike rule: one fp32 multiply, one fp32
+    compare.  Bit-exact target for the HIP epilogue."""
+    r = np.asarray(rates32, dtype=np.float32)
+    return np.asarray(u32, dtype=np.float32) < (np.float32(dt) * r)
+
+
+# --------------------------------------------------------------------------- #
+# Counter-based RNG used by the product in production mode (new functionality:
+# the reference uses the global MT19937 stream).  Philox4x32-10,
+# Salmon et al. 2011; integer part bit-exact, restated here so tests can
+# regenerate the device's draws on the host.
+# --------------------------------------------------------------------------- #
+PHILOX_M0 = np.uint64(0xD2511F53)
+PHILOX_M1 = np.uint64(0xCD9E8D57)
+PHILOX_W0 = 0x9E3779B9
+PHILOX_W1 = 0xBB67AE85
+TAG_MOTION = 0x4D4F5449
+TAG_SPIKES = 0x53504B00
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10.  Counters are uint32 arrays (broadcastable),
+    key two python ints.  Returns four uint32 arrays."""
+    c = [np.asarray(x, dtype=np.uint64) & np.uint64(0xFFFFFFFF) for x in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0 = int(k0) & 0xFFFFFFFF
+    k1 = int(k1) & 0xFFFFFFFF
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = PHILOX_M0 * c[0]
+        p1 = PHILOX_M1 * c[2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & mask
+        hi1, lo1 = p1 >> np.uint64(32), p1 & mask
+        c = [hi1 ^ c[1] ^ np.uint64(k0), lo1, hi0 ^ c[3] ^ np.uint64(k1), lo0]
+        k0 = (k0 + PHILOX_W0) & 0xFFFFFFFF
+        k1 = (k1 + PHILOX_W1) & 0xFFFFFFFF
+    return tuple(x.astype(np.uint32) for x in c)
+
+
+def motion_normals(seed, step, agent_ids):
+    """The device's per-(step, agent) draws: Box-Muller on Philox words.
+    Returns z_rot, z_speed, z_zero0, z_zero1 (float64)."""
+    agent_ids = np.asarray(agent_ids, dtype=np.uint64)
+    x0, x1, x2, x3 = philox4x32_10(step & 0xFFFFFFFF, (step >> 32) & 0xFFFFFFFF, agent_ids, TAG_MOTION,
+                                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    def bm(a, b):
+        u1 = (a.astype(np.float64) + 0.5) * 2.0**-32
+        u2 = (b.astype(np.float64) + 0.5) * 2.0**-32
+        r = np.sqrt(-2.0 * np.log(u1))
+        return r * np.cos(TWO_PI * u2), r * np.sin(TWO_PI * u2)
+    z0, z1 = bm(x0, x1)
+    z2, z3 = bm(x2, x3)
+    return z0, z1, z2, z3
+
+
+def spike_uniforms(seed, step, pop_id, n_cells, n_agents, agent_id0=0):
+    """The device's per-(step, cell, agent) fp32 uniforms in [0,1): one Philox call
+    per (cell, group of 4 consecutive global agent ids); word j -> agent 4g+j;
+    `u = (word >> 8) * 2^-24`.  -> `(n_cells, n_agents)` float32."""
+    assert agent_id0 % 4 == 0 and n_agents % 4 == 0
+    g = (np.arange(n_agents // 4, dtype=np.uint64) + np.uint64(agent_id0 // 4))[None, :]
+    cell = np.arange(n_cells, dtype=np.uint64)[:, None]
+    xs = philox4x32_10(step & 0xFFFFFFFF, cell, g, TAG_SPIKES | (pop_id & 0xFF),
+                       seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = np.stack([(x >> np.uint32(8)).astype(np.float32) * np.float32(2.0**-24) for x in xs], axis=-1)
+    return u.reshape(n_cells, n_agents)

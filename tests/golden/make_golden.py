@@ -1,0 +1,366 @@
+"""Generate the golden vectors in tests/golden/*.npz by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference); the resulting .npz
+files are data (inputs + the reference's outputs) and are committed.  Nothing
+from the reference's source travels.
+
+    MPLBACKEND=Agg python tests/golden/make_golden.py
+
+How the reference is driven
+---------------------------
+* `shapely` is absent from the image; `oracle/ref_shims/shapely` (a strict
+  point-in-polygon stand-in) is put on sys.path so `import ratinabox` works.
+* `np.random.normal` is wrapped: draws with `scale` 1e-6 / 1e-9 (the reference's
+  geometric anti-degeneracy jitter, utils.py:64-69, 143-144) return zeros; every
+  other draw is a real draw from a private RandomState, recorded as a standard
+  normal (`value/scale`) so the same noise can be fed to the oracle / the GPU.
+* `np.random.uniform` is wrapped likewise to record the spike uniforms.
+"""
+import os
+import sys
+import warnings
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_shims"))
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+
+warnings.filterwarnings("ignore")
+np.seterr(all="ignore")
+
+import ratinabox  # noqa: E402
+from ratinabox.Environment import Environment  # noqa: E402
+from ratinabox.Agent import Agent  # noqa: E402
+from ratinabox.Neurons import (  # noqa: E402
+    PlaceCells, GridCells, BoundaryVectorCells, HeadDirectionCells)
+from ratinabox import utils as rutils  # noqa: E402
+
+_real = np.random.RandomState(12345)
+_rec = {"normal": [], "uniform": []}
+_orig_normal = np.random.normal
+_orig_uniform = np.random.uniform
+_capture = {"on": False}
+
+
+def _patched_normal(loc=0.0, scale=1.0, size=None):
+    if isinstance(scale, float) and scale in (1e-6, 1e-9):
+        return np.zeros(size) + loc
+    if not _capture["on"]:
+        return _orig_normal(loc=loc, scale=scale, size=size)
+    z = _real.standard_normal(size)
+    _rec["normal"].append((np.shape(z), np.array(z, dtype=np.float64)))
+    return loc + scale * z
+
+
+def _patched_uniform(low=0.0, high=1.0, size=None):
+    if not _capture["on"]:
+        return _orig_uniform(low, high, size)
+    u = _real.random_sample(size)
+    _rec["uniform"].append(np.array(u, dtype=np.float64))
+    return low + (high - low) * u
+
+
+np.random.normal = _patched_normal
+np.random.uniform = _patched_uniform
+
+MAZE_WALLS = [[[.2, 0], [.2, .4]], [[.4, 1], [.4, .6]], [[.6, 0], [.6, .4]],
+              [[.8, 1], [.8, .6]], [[.3, .5], [.7, .5]]]
+
+_bounces = {"n": 0}
+_orig_bounce = rutils.wall_bounce
+
+
+def _count_bounce(v, w):
+    _bounces["n"] += 1
+    return _orig_bounce(v, w)
+
+
+rutils.wall_bounce = _count_bounce
+_bc = {"n": 0}
+_orig_abc = Environment.apply_boundary_conditions
+
+
+def _count_abc(self, pos):
+    _bc["n"] += 1
+    return _orig_abc(self, pos)
+
+
+Environment.apply_boundary_conditions = _count_abc
+
+STATE_KEYS = ["pos", "velocity", "rotational_velocity", "measured_velocity", "head_direction",
+              "distance_travelled"]
+
+
+def _get_state(ag):
+    return [np.array(ag.pos, float), np.array(ag.velocity, float), float(ag.rotational_velocity),
+            np.array(ag.measured_velocity, float), np.array(ag.head_direction, float),
+            float(ag.distance_travelled)]
+
+
+def f32exact(x):
+    """Round to values exactly representable in fp32 (so the same vectors serve
+    the float64 oracle test and the fp32 GPU test)."""
+    return np.asarray(x, dtype=np.float32).astype(np.float64)
+
+
+# ------------------------------------------------------------------ G2 / G3 -- #
+def motion_records(name, env_params, agent_params, n_agents, n_steps, seed, drift=None, ratio=1.0,
+                   update_kwargs=None, keep=1500):
+    np.random.seed(seed)
+    Env = Environment(env_params)
+    agents = [Agent(Env, dict(agent_params)) for _ in range(n_agents)]
+    update_kwargs = update_kwargs or {}
+    pre, post, zs, nb, bc = [], [], [], [], []
+    traj = np.zeros((n_steps + 1, n_agents, 2))
+    traj[0] = [a.pos for a in agents]
+    zroll = np.zeros((n_steps, n_agents, 2))
+    state0 = [_get_state(a) for a in agents]
+    _capture["on"] = True
+    for t in range(n_steps):
+        for i, ag in enumerate(agents):
+            s0 = _get_state(ag)
+            _rec["normal"].clear()
+            _bounces["n"] = 0
+            _bc["n"] = 0
+            dv = None if drift is None else np.array(drift[(t + i) % len(drift)], float)
+            ag.update(drift_velocity=dv, drift_to_random_strength_ratio=ratio, **update_kwargs)
+            scal = [z for shp, z in _rec["normal"] if shp == ()]
+            assert len(scal) == 2, len(scal)
+            s1 = _get_state(ag)
+            pre.append(np.concatenate([np.ravel(x) for x in s0]))
+            post.append(np.concatenate([np.ravel(x) for x in s1] +
+                                       [[float(ag.measured_rotational_velocity)],
+                                        [float(ag.distance_to_closest_wall)]]))
+            zs.append([float(scal[0]), float(scal[1])])
+            nb.append(_bounces["n"])
+            bc.append(_bc["n"])
+            zroll[t, i] = zs[-1]
+            traj[t + 1, i] = ag.pos
+    _capture["on"] = False
+    pre, post, zs = np.array(pre), np.array(post), np.array(zs)
+    nb, bc = np.array(nb), np.array(bc)
+    # keep every "interesting" record plus a random subsample of the rest
+    interesting = np.nonzero((nb > 0) | (bc > 0))[0]
+    rest = np.setdiff1d(np.arange(len(pre)), interesting)
+    rs = np.random.RandomState(seed)
+    take = rs.choice(rest, size=min(len(rest), max(0, keep - len(interesting))), replace=False)
+    sel = np.sort(np.concatenate([interesting[:keep], take]))
+    drift_arr = np.zeros((0, 2))
+    if drift is not None:
+        idx = np.array([(t + i) % len(drift) for t in range(n_steps) for i in range(n_agents)])
+        drift_arr = np.array(drift, float)[idx][sel]
+    out = dict(
+        env_scale=float(Env.scale), env_aspect=float(Env.aspect),
+        env_bc=str(Env.boundary_conditions), user_walls=np.array(env_params.get("walls", []), float).reshape(-1, 2, 2),
+        ref_walls=np.array(Env.walls, float).reshape(-1, 2, 2),
+        dt=float(agents[0].dt),
+        params_keys=np.array(sorted(agent_params.keys())),
+        params_vals=np.array([float(agent_params[k]) for k in sorted(agent_params.keys())]),
+        kw_keys=np.array(sorted(update_kwargs.keys())),
+        kw_vals=np.array([float(update_kwargs[k]) for k in sorted(update_kwargs.keys())]),
+        pre=pre[sel], post=post[sel], z=zs[sel], n_bounces=nb[sel], bc_applied=bc[sel],
+        drift=drift_arr, drift_ratio=float(ratio),
+        # rollout (G3): first 16 agents, all steps
+        roll_state0=np.array([np.concatenate([np.ravel(x) for x in s]) for s in state0]),
+        roll_z=zroll, roll_pos=traj,
+        roll_final=np.array([np.concatenate([np.ravel(x) for x in _get_state(a)]) for a in agents]),
+    )
+    print(f"  {name}: {len(sel)} step records ({int((nb[sel] > 0).sum())} with bounces, "
+          f"{int((nb[sel] > 1).sum())} multi-bounce, {int((bc[sel] > 0).sum())} boundary-clamped)")
+    np.savez_compressed(os.path.join(HERE, f"motion_{name}.npz"), **out)
+
+
+def make_motion():
+    print("motion (G2 single steps + G3 rollouts)")
+    motion_records("open_dt10ms", {}, {"dt": 0.01}, 16, 400, seed=1)
+    motion_records("maze_dt10ms", {"walls": MAZE_WALLS}, {"dt": 0.01}, 16, 400, seed=2)
+    motion_records("maze_dt50ms", {"walls": MAZE_WALLS}, {"dt": 0.05, "thigmotaxis": 0.2}, 16, 300, seed=3)
+    motion_records("maze_fast", {"walls": MAZE_WALLS},
+                   {"dt": 0.1, "speed_mean": 0.6, "thigmotaxis": 0.9, "wall_repel_strength": 0.3}, 16, 250, seed=4)
+    motion_records("open_norepel_fast", {}, {"dt": 0.1, "speed_mean": 0.5, "wall_repel_strength": 0.0}, 8, 300, seed=5)
+    motion_records("open_drift", {"scale": 2.0, "aspect": 1.5}, {"dt": 0.02, "speed_std": 0.0}, 8, 200, seed=6,
+                   drift=[[0.3, 0.1], [-0.2, 0.25], [0.0, -0.4]], ratio=3.0)
+    motion_records("periodic_wall", {"boundary_conditions": "periodic", "walls": [[[.5, .2], [.5, .8]]]},
+                   {"dt": 0.05, "speed_mean": 0.3}, 8, 300, seed=7)
+    motion_records("open_kwargs", {}, {"dt": 0.01, "head_direction_smoothing_timescale": 0.005}, 8, 150, seed=8,
+                   update_kwargs={"thigmotaxis": 0.8, "wall_repel_distance": 0.2, "speed_mean": 0.12,
+                                  "rotational_velocity_std": 1.0, "speed_coherence_time": 0.3,
+                                  "rotational_velocity_coherence_time": 0.2, "wall_repel_strength": 1.5})
+
+
+# ----------------------------------------------------------------------- G1 -- #
+def test_positions(P, scale=1.0, aspect=1.0, seed=0):
+    rs = np.random.RandomState(seed)
+    pos = np.stack((rs.uniform(0, aspect * scale, P), rs.uniform(0, scale, P)), -1)
+    k = P // 8
+    # near the boundary and near the maze walls / their endpoints
+    pos[:k, 0] = rs.choice([1e-3, aspect * scale - 1e-3, 0.2 - 1e-3, 0.2 + 1e-3, 0.4 + 2e-3, 0.8 - 2e-3], k)
+    pos[k:2 * k, 1] = rs.choice([1e-3, scale - 1e-3, 0.5 + 1e-3, 0.5 - 1e-3, 0.4 + 1e-3, 0.6 - 1e-3], k)
+    return f32exact(pos)
+
+
+def make_rates():
+    print("rates (G1)")
+    np.random.seed(11)
+    out = {}
+    pos = test_positions(192, seed=3)
+    hd = np.random.RandomState(5).randn(192, 2)
+    hd = f32exact(hd / np.linalg.norm(hd, axis=1, keepdims=True))
+    out["pos"] = pos
+    out["hd"] = hd
+
+    # --- PlaceCells: all five descriptions, open box
+    Env = Environment()
+    Ag = Agent(Env)
+    for desc in ["gaussian", "gaussian_threshold", "diff_of_gaussians", "one_hot", "top_hat"]:
+        PCs = PlaceCells(Ag, {"n": 64, "description": desc, "widths": 0.2, "min_fr": 0.1, "max_fr": 2.0})
+        PCs.place_cell_centres = f32exact(PCs.place_cell_centres)
+        PCs.place_cell_widths = f32exact(np.linspace(0.1, 0.3, 64))
+        out[f"pc_{desc}_centres"] = PCs.place_cell_centres
+        out[f"pc_{desc}_widths"] = PCs.place_cell_widths
+        out[f"pc_{desc}_rates"] = PCs.get_state(evaluate_at=None, pos=pos)
+    # cfg-2 shape table (1024 cells default widths), fewer positions
+    PCs = PlaceCells(Ag, {"n": 1024})
+    PCs.place_cell_centres = f32exact(PCs.place_cell_centres)
+    out["pc_big_centres"] = PCs.place_cell_centres
+    out["pc_big_rates"] = PCs.get_state(evaluate_at=None, pos=pos[:64])
+    # --- PlaceCells: line_of_sight in the 9-wall maze; geodesic with one wall; periodic
+    EnvM = Environment({"walls": MAZE_WALLS})
+    AgM = Agent(EnvM)
+    PCs = PlaceCells(AgM, {"n": 64, "wall_geometry": "line_of_sight", "widths": 0.25})
+    PCs.place_cell_centres = f32exact(PCs.place_cell_centres)
+    out["pc_los_centres"] = PCs.place_cell_centres
+    out["pc_los_rates"] = PCs.get_state(evaluate_at=None, pos=pos)
+    out["maze_walls"] = np.array(EnvM.walls, float)
+    Env1 = Environment({"walls": [[[0.5, 0.0], [0.5, 0.6]]]})
+    Ag1 = Agent(Env1)
+    PCs = PlaceCells(Ag1, {"n": 49, "wall_geometry": "geodesic", "description": "gaussian_threshold"})
+    PCs.place_cell_centres = f32exact(PCs.place_cell_centres)
+    out["pc_geo_centres"] = PCs.place_cell_centres
+    out["pc_geo_rates"] = PCs.get_state(evaluate_at=None, pos=pos)
+    out["geo_walls"] = np.array(Env1.walls, float)
+    EnvP = Environment({"boundary_conditions": "periodic"})
+    AgP = Agent(EnvP)
+    PCs = PlaceCells(AgP, {"n": 36, "widths": 0.15})
+    PCs.place_cell_centres = f32exact(PCs.place_cell_centres)
+    out["pc_per_centres"] = PCs.place_cell_centres
+    out["pc_per_rates"] = PCs.get_state(evaluate_at=None, pos=pos)
+
+    # --- GridCells
+    for desc in ["rectified_cosines", "shifted_cosines"]:
+        GCs = GridCells(Ag, {"n": 60, "description": desc, "min_fr": 0.0, "max_fr": 1.5})
+        out[f"gc_{desc}_gridscales"] = np.array(GCs.gridscales, float)
+        out[f"gc_{desc}_phase_offsets"] = np.array(GCs.phase_offsets, float)
+        out[f"gc_{desc}_orientations"] = np.array(GCs.orientations, float)
+        out[f"gc_{desc}_w"] = np.array(GCs.w, float)
+        out[f"gc_{desc}_rates"] = GCs.get_state(evaluate_at=None, pos=pos)
+    GCs = GridCells(Ag, {"n": 40, "gridscale_distribution": "uniform", "gridscale": (0.2, 1.0),
+                         "orientation_distribution": "uniform", "orientation": (0, 2 * np.pi), "width_ratio": 0.5})
+    out["gc_rand_gridscales"] = np.array(GCs.gridscales, float)
+    out["gc_rand_phase_offsets"] = np.array(GCs.phase_offsets, float)
+    out["gc_rand_orientations"] = np.array(GCs.orientations, float)
+    out["gc_rand_w"] = np.array(GCs.w, float)
+    out["gc_rand_rates"] = GCs.get_state(evaluate_at=None, pos=pos)
+
+    # --- BVCs: allocentric open box / maze; egocentric maze (per-position head direction)
+    for tag, ag in [("open", Ag), ("maze", AgM)]:
+        B = BoundaryVectorCells(ag, {"n": 32, "min_fr": 0.0, "max_fr": 1.0})
+        for k in ["tuning_distances", "tuning_angles", "sigma_distances", "sigma_angles", "test_angles",
+                  "test_directions", "cell_fr_norm"]:
+            out[f"bvc_{tag}_{k}"] = np.array(getattr(B, k), float)
+        out[f"bvc_{tag}_rates"] = B.get_state(evaluate_at=None, pos=pos)
+    Be = BoundaryVectorCells(AgM, {"n": 24, "reference_frame": "egocentric", "max_fr": 3.0, "min_fr": 0.5})
+    for k in ["tuning_distances", "tuning_angles", "sigma_distances", "sigma_angles"]:
+        out[f"bvc_ego_{k}"] = np.array(getattr(Be, k), float)
+    # the reference's egocentric path takes ONE head direction per call; evaluate position by position
+    ego = np.zeros((Be.n, 48))
+    for j in range(48):
+        ego[:, j] = Be.get_state(evaluate_at=None, pos=pos[j:j + 1], head_direction=hd[j])[:, 0]
+    out["bvc_ego_rates"] = ego
+
+    # --- HeadDirectionCells
+    H = HeadDirectionCells(Ag, {"n": 24, "angular_spread_degrees": 30, "max_fr": 2.0, "min_fr": 0.25})
+    hdr = np.zeros((24, 192))
+    for j in range(192):
+        hdr[:, j] = H.get_state(evaluate_at=None, head_direction=hd[j], pos=pos[j:j + 1])[:, 0]
+    out["hdc_rates"] = hdr
+    np.savez_compressed(os.path.join(HERE, "rates.npz"), **out)
+    print("  rates.npz written:", len(out), "arrays")
+
+
+# ------------------------------------------------------------------ G4 / G5 -- #
+def make_update_and_init():
+    """Neurons.update() end-to-end (rates + noise OU + spikes) for a single agent,
+    and seeded init tables (host-side parameter sampling)."""
+    print("update/spikes (G4) + init tables (G5)")
+    out = {}
+    np.random.seed(21)
+    Env = Environment()
+    Ag = Agent(Env, {"dt": 0.01})
+    PCs = PlaceCells(Ag, {"n": 50, "max_fr": 40.0, "noise_std": 0.5, "noise_coherence_time": 0.2})
+    PCs.place_cell_centres = f32exact(PCs.place_cell_centres)
+    out["upd_centres"] = PCs.place_cell_centres
+    T = 120
+    pos_l, fr_l, spk_l, zn_l, u_l, noise_l = [], [], [], [], [], []
+    _capture["on"] = True
+    for t in range(T):
+        _rec["normal"].clear()
+        Ag.update()
+        Ag.pos = f32exact(Ag.pos)
+        _rec["normal"].clear()
+        _rec["uniform"].clear()
+        PCs.update()
+        zn = [z for shp, z in _rec["normal"] if shp == (50,)]
+        assert len(zn) == 1 and len(_rec["uniform"]) == 1
+        pos_l.append(Ag.pos.copy())
+        fr_l.append(PCs.firingrate.copy())
+        noise_l.append(PCs.noise.copy())
+        spk_l.append(np.array(PCs.history["spikes"][-1]))
+        zn_l.append(zn[0])
+        u_l.append(_rec["uniform"][0])
+    _capture["on"] = False
+    out.update(upd_dt=0.01, upd_pos=np.array(pos_l), upd_fr=np.array(fr_l), upd_noise=np.array(noise_l),
+               upd_spikes=np.array(spk_l), upd_z=np.array(zn_l), upd_u=np.array(u_l))
+    margin = np.abs(np.array(u_l) - 0.01 * np.array(fr_l)) / np.maximum(0.01 * np.abs(np.array(fr_l)), 1e-30)
+    out["upd_min_rel_margin"] = float(margin.min())
+    print(f"  spikes: {int(np.array(spk_l).sum())} spikes in {np.array(spk_l).size}, "
+          f"min relative margin {margin.min():.3e}")
+
+    # G5: seeded init tables
+    for seed in (0, 7):
+        np.random.seed(seed)
+        Env = Environment()
+        Ag = Agent(Env)
+        out[f"init{seed}_agent_pos"] = np.array(Ag.pos)
+        out[f"init{seed}_agent_vel"] = np.array(Ag.velocity)
+        P = PlaceCells(Ag, {"n": 100})
+        out[f"init{seed}_pc_centres"] = np.array(P.place_cell_centres)
+        P2 = PlaceCells(Ag, {"n": 37, "place_cell_centres": "random"})
+        out[f"init{seed}_pc_random_centres"] = np.array(P2.place_cell_centres)
+        G = GridCells(Ag, {"n": 32})
+        out[f"init{seed}_gc_gridscales"] = np.array(G.gridscales)
+        out[f"init{seed}_gc_phase"] = np.array(G.phase_offsets)
+        out[f"init{seed}_gc_orient"] = np.array(G.orientations)
+        Bv = BoundaryVectorCells(Ag, {"n": 20})
+        for k in ["tuning_distances", "tuning_angles", "sigma_distances", "sigma_angles"]:
+            out[f"init{seed}_bvc_{k}"] = np.array(getattr(Bv, k))
+        EnvW = Environment({"walls": MAZE_WALLS, "scale": 1.0})
+        out[f"init{seed}_maze_walls"] = np.array(EnvW.walls)
+        out[f"init{seed}_sample_uniform16"] = EnvW.sample_positions(16, "uniform")
+    np.savez_compressed(os.path.join(HERE, "update_init.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["motion", "rates", "update"]
+    if "motion" in which:
+        make_motion()
+    if "rates" in which:
+        make_rates()
+    if "update" in which:
+        make_update_and_init()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f"{f}: {os.path.getsize(os.path.join(HERE, f)) / 1024:.0f} KiB")

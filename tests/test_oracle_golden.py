@@ -1,0 +1,146 @@
+"""Pin the CPU oracle (oracle/riab_oracle.py) against golden vectors produced by
+the reference itself (tests/golden/make_golden.py).  float64 vs float64."""
+import numpy as np
+import pytest
+
+from oracle import riab_oracle as orc
+from tests import golden_util as gu
+
+RT = 1e-11
+
+
+@pytest.mark.parametrize("fname", gu.MOTION_FILES)
+def test_single_steps(fname):
+    g = gu.load(fname)
+    env = gu.env_from(g)
+    assert np.array_equal(env.walls, g["ref_walls"])
+    p, kw, dt = gu.params_from(g)
+    st = gu.state_from_rows(g["pre"])
+    drift = g["drift"] if g["drift"].shape[0] else None
+    out = orc.agent_step(env, st, dt, g["z"][:, 0], g["z"][:, 1], params=p, kwargs=kw, drift_velocity=drift,
+                         drift_to_random_strength_ratio=float(g["drift_ratio"]))
+    post = g["post"]
+    assert np.array_equal(out["n_bounces"], g["n_bounces"])
+    for k, s in gu.PRE_SLICES.items():
+        np.testing.assert_allclose(out[k], post[:, s], rtol=RT, atol=1e-13, err_msg=k)
+    # measured rotational velocity is an angle difference / dt: absolute tolerance
+    np.testing.assert_allclose(out["measured_rotational_velocity"], post[:, 10], rtol=1e-9, atol=1e-8)
+    fin = np.isfinite(post[:, 11])
+    np.testing.assert_allclose(out["distance_to_closest_wall"][fin], post[fin, 11], rtol=RT)
+
+
+@pytest.mark.parametrize("fname", gu.MOTION_FILES)
+def test_rollout(fname):
+    """G3: replay the reference's noise stream for every agent; the whole rollout
+    must track the reference (float64, same discrete decisions)."""
+    g = gu.load(fname)
+    if g["drift"].shape[0]:
+        pytest.skip("drift schedule is per (step, agent); covered by single steps")
+    env = gu.env_from(g)
+    p, kw, dt = gu.params_from(g)
+    st = gu.state_from_rows(g["roll_state0"])
+    T = g["roll_z"].shape[0]
+    for t in range(T):
+        st = orc.agent_step(env, st, dt, g["roll_z"][t, :, 0], g["roll_z"][t, :, 1], params=p, kwargs=kw)
+        np.testing.assert_allclose(st["pos"], g["roll_pos"][t + 1], rtol=1e-8, atol=1e-10, err_msg=f"step {t}")
+    np.testing.assert_allclose(st["head_direction"], g["roll_final"][:, 7:9], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(st["distance_travelled"], g["roll_final"][:, 9], rtol=1e-8)
+
+
+def _rates():
+    return gu.load("rates.npz")
+
+
+@pytest.mark.parametrize("desc", ["gaussian", "gaussian_threshold", "diff_of_gaussians", "one_hot", "top_hat"])
+def test_place_cells_descriptions(desc):
+    g = _rates()
+    env = orc.EnvSpec()
+    got = orc.place_cells(env, g["pos"], g[f"pc_{desc}_centres"], g[f"pc_{desc}_widths"], description=desc,
+                          min_fr=0.1, max_fr=2.0, widths_scalar=0.2)
+    np.testing.assert_allclose(got, g[f"pc_{desc}_rates"], rtol=1e-12, atol=1e-300)
+
+
+def test_place_cells_geometries():
+    g = _rates()
+    got = orc.place_cells(orc.EnvSpec(), g["pos"][:64], g["pc_big_centres"], 0.2)
+    np.testing.assert_allclose(got, g["pc_big_rates"], rtol=1e-12, atol=1e-300)
+    maze = orc.EnvSpec(walls=g["maze_walls"][4:])
+    got = orc.place_cells(maze, g["pos"], g["pc_los_centres"], 0.25, wall_geometry="line_of_sight")
+    np.testing.assert_allclose(got, g["pc_los_rates"], rtol=1e-12, atol=1e-300)
+    geo = orc.EnvSpec(walls=g["geo_walls"][4:])
+    got = orc.place_cells(geo, g["pos"], g["pc_geo_centres"], 0.2, description="gaussian_threshold",
+                          wall_geometry="geodesic")
+    np.testing.assert_allclose(got, g["pc_geo_rates"], rtol=1e-12, atol=1e-15)
+    per = orc.EnvSpec(boundary_conditions="periodic")
+    got = orc.place_cells(per, g["pos"], g["pc_per_centres"], 0.15)
+    np.testing.assert_allclose(got, g["pc_per_rates"], rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize("tag,kw", [("rectified_cosines", dict(description="rectified_cosines", max_fr=1.5)),
+                                    ("shifted_cosines", dict(description="shifted_cosines", max_fr=1.5)),
+                                    ("rand", dict(width_ratio=0.5))])
+def test_grid_cells(tag, kw):
+    g = _rates()
+    w = orc.grid_cell_w(g[f"gc_{tag}_orientations"])
+    np.testing.assert_allclose(w, g[f"gc_{tag}_w"], rtol=0, atol=1e-16)
+    got = orc.grid_cells(g["pos"], g[f"gc_{tag}_gridscales"], g[f"gc_{tag}_phase_offsets"], w, **kw)
+    np.testing.assert_allclose(got, g[f"gc_{tag}_rates"], rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("tag", ["open", "maze"])
+def test_bvc_allocentric(tag):
+    g = _rates()
+    angles, dirs = orc.bvc_test_angles(2)
+    assert np.array_equal(angles, g[f"bvc_{tag}_test_angles"])
+    np.testing.assert_allclose(dirs, g[f"bvc_{tag}_test_directions"], rtol=0, atol=1e-16)
+    np.testing.assert_allclose(orc.bvc_fr_norm(angles, g[f"bvc_{tag}_sigma_angles"]), g[f"bvc_{tag}_cell_fr_norm"],
+                               rtol=1e-12)
+    walls = orc.EnvSpec().walls if tag == "open" else g["maze_walls"]
+    got = orc.bvc(g["pos"], walls, g[f"bvc_{tag}_tuning_distances"], g[f"bvc_{tag}_tuning_angles"],
+                  g[f"bvc_{tag}_sigma_distances"], g[f"bvc_{tag}_sigma_angles"])
+    np.testing.assert_allclose(got, g[f"bvc_{tag}_rates"], rtol=1e-10, atol=1e-14)
+
+
+def test_bvc_egocentric():
+    g = _rates()
+    got = orc.bvc(g["pos"][:48], g["maze_walls"], g["bvc_ego_tuning_distances"], g["bvc_ego_tuning_angles"],
+                  g["bvc_ego_sigma_distances"], g["bvc_ego_sigma_angles"], head_direction=g["hd"][:48],
+                  min_fr=0.5, max_fr=3.0)
+    np.testing.assert_allclose(got, g["bvc_ego_rates"], rtol=1e-10, atol=1e-14)
+
+
+def test_head_direction_cells():
+    g = _rates()
+    got = orc.head_direction_cells(g["hd"], 24, angular_spread_degrees=30, min_fr=0.25, max_fr=2.0)
+    np.testing.assert_allclose(got, g["hdc_rates"], rtol=1e-12)
+
+
+def test_update_noise_and_spikes():
+    """Neurons.update end to end (Neurons.py:145-171, 681-687): rates + OU noise, spikes."""
+    g = gu.load("update_init.npz")
+    dt = float(g["upd_dt"])
+    noise = np.zeros(50)
+    env = orc.EnvSpec()
+    for t in range(g["upd_pos"].shape[0]):
+        noise = noise + orc.ou_increment(noise, dt, 0.0, 0.5, 0.2, g["upd_z"][t])
+        fr = orc.place_cells(env, g["upd_pos"][t][None], g["upd_centres"], 0.2, max_fr=40.0)[:, 0] + noise
+        np.testing.assert_allclose(noise, g["upd_noise"][t], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(fr, g["upd_fr"][t], rtol=1e-11, atol=1e-13)
+        assert np.array_equal(orc.spikes_ref(fr, g["upd_u"][t], dt), g["upd_spikes"][t])
+    # the fp32 spike rule agrees with the float64 reference wherever the margin is not razor thin
+    assert float(g["upd_min_rel_margin"]) > 1e-5
+    assert np.array_equal(orc.spikes_f32(g["upd_fr"].astype(np.float32), g["upd_u"].astype(np.float32), dt),
+                          g["upd_spikes"])
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for Philox4x32-10."""
+    assert [int(x) for x in orc.philox4x32_10(0, 0, 0, 0, 0, 0)] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    f = 0xFFFFFFFF
+    assert [int(x) for x in orc.philox4x32_10(f, f, f, f, f, f)] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    got = orc.philox4x32_10(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0)
+    assert [int(x) for x in got] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    z = np.concatenate(orc.motion_normals(1234, 7, np.arange(50000))[:2])
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    u = orc.spike_uniforms(1, 3, 0, 64, 1024)
+    assert u.dtype == np.float32 and u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.01
