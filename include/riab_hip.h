@@ -1,0 +1,235 @@
+/*
+ * riab_hip.h — C ABI of libriab_hip.so: the MI355X (gfx950) kernels behind the
+ * batched RatInABox hot path.
+ *
+ * The reference (RatInABox, pure Python/NumPy) has no FFI; this ABI is the
+ * drop-in boundary a maintainer would bind with ctypes.
+ * Each entry point names the reference code it replaces (paths relative to the
+ * reference checkout).
+ *
+ * Conventions
+ *  - every `const T*` / `T*` marked "device" is a device (HBM) pointer owned by
+ *    the caller (e.g. a PyTorch-ROCm tensor's data_ptr()); structs are host
+ *    memory, read before the call returns.
+ *  - nothing is allocated, copied host<->device or synchronised inside; kernels
+ *    are enqueued on `stream` (a hipStream_t) and the call returns immediately,
+ *    so every entry point is hipGraph-capturable.
+ *  - batch axis (agents / positions) is always the fastest-varying axis.
+ *    B must be a multiple of 4 and row pointers 16-byte aligned (the host layer
+ *    pads the agent axis); rows are `ld` elements apart where stated.
+ *  - return: 0 ok; negative = argument error detected before launch
+ *    (RIAB_E*); positive = hipError_t of the launch.
+ *  - re-entrant: no global state.
+ */
+#ifndef RIAB_HIP_H
+#define RIAB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RIAB_ABI_VERSION 1
+#define RIAB_MAX_WALLS 64     /* walls staged in LDS by the motion / BVC / line-of-sight kernels */
+#define RIAB_MAX_TEST_ANGLES 360
+#define RIAB_STATE_ROWS 12    /* rows of the agent state matrix, see below */
+#define RIAB_HIST_ROWS 8      /* rows of one trajectory-history record */
+#define RIAB_MAX_BOUNCES 16   /* bound on the reference's `while True` bounce loop (Agent.py:426) */
+
+enum {
+  RIAB_OK = 0,
+  RIAB_EINVAL = -1,       /* null pointer / negative size / bad enum */
+  RIAB_EALIGN = -2,       /* B % 4 != 0 or misaligned row pointer */
+  RIAB_ETOOBIG = -3,      /* more walls / test angles than the LDS staging allows */
+  RIAB_EUNSUPPORTED = -4  /* combination not implemented on device */
+};
+
+typedef void* riab_stream_t; /* hipStream_t */
+
+/* Rows of the agent state matrix `state[RIAB_STATE_ROWS][B]` (float64, device).
+ * Mirrors the attributes Agent.update mutates (Agent.py:193-242). */
+enum {
+  RIAB_S_POS_X = 0, RIAB_S_POS_Y = 1,
+  RIAB_S_VEL_X = 2, RIAB_S_VEL_Y = 3,          /* Agent.velocity */
+  RIAB_S_ROT_VEL = 4,                          /* Agent.rotational_velocity */
+  RIAB_S_MVEL_X = 5, RIAB_S_MVEL_Y = 6,        /* Agent.measured_velocity */
+  RIAB_S_MROT_VEL = 7,                         /* Agent.measured_rotational_velocity */
+  RIAB_S_HD_X = 8, RIAB_S_HD_Y = 9,            /* Agent.head_direction */
+  RIAB_S_DIST = 10,                            /* Agent.distance_travelled */
+  RIAB_S_DWALL = 11                            /* Agent.distance_to_closest_wall */
+};
+
+/* Rows of one history record `hist[t][RIAB_HIST_ROWS][B]` (float32, device):
+ * what Agent.save_to_history appends per step (Agent.py:509-521). */
+enum {
+  RIAB_H_POS_X = 0, RIAB_H_POS_Y = 1,
+  RIAB_H_VEL_X = 2, RIAB_H_VEL_Y = 3,          /* history["vel"] = measured velocity */
+  RIAB_H_HD_X = 4, RIAB_H_HD_Y = 5,
+  RIAB_H_ROT_VEL = 6,                          /* history["rot_vel"] = measured rotational velocity */
+  RIAB_H_DIST = 7                              /* history["distance_travelled"] */
+};
+
+/* Environment geometry read by the hot path (Environment.py:65-191, 657-894):
+ * rectangular 2D box, solid or periodic.  `walls` is Environment.walls
+ * flattened to [n_walls][4] = (ax, ay, bx, by), reference order (boundary walls
+ * first when solid). */
+typedef struct RiabEnv {
+  double extent[4];      /* left, right, bottom, top */
+  double scale;          /* Environment.scale (periodic wrap length, Environment.py:670-674) */
+  int32_t periodic;      /* boundary_conditions == "periodic" */
+  int32_t n_walls;
+  const double* walls;   /* device, float64 [n_walls][4] */
+} RiabEnv;
+
+/* Motion parameters of one Agent.update call, resolved on the host:
+ * `*_kw` are the values after per-call kwargs overrides (Agent.py:280-285,
+ * 353-355), plain names are the Agent attributes the reference reads
+ * regardless of kwargs (Agent.py:310, 340, 375, 439, 489). */
+typedef struct RiabMotion {
+  double dt;
+  double rot_theta_kw;        /* 1 / rotational_velocity_coherence_time */
+  double rot_sigma_kw;        /* sqrt(2 std^2 / (tau dt)), utils.py:365 */
+  double rot_drift_kw;        /* kwarg rotational_velocity_drift, default 0 */
+  double speed_theta_kw;      /* 1 / speed_coherence_time */
+  double speed_sigma_kw;      /* sqrt(2 / (tau dt)) */
+  double speed_mean_kw;       /* Rayleigh sigma in the stochastic update */
+  double speed_mean;          /* attribute: wall spring speed, bounce speed */
+  int32_t speed_std_is_zero;  /* attribute speed_std == 0 (Agent.py:310) */
+  int32_t has_drift;          /* drift_velocity given */
+  double drift_theta;         /* ratio / speed_coherence_time (attribute), Agent.py:340 */
+  double wall_repel_strength_kw;
+  double wall_repel_distance_kw;
+  double thigmotaxis_kw;
+  double hd_tau;              /* head_direction_smoothing_timescale (attribute) */
+} RiabMotion;
+
+/* T fused Agent.update() steps for B independent agents.
+ * Replaces Agent.update (Agent.py:160-242) = _stochastic_velocity_update
+ * (:268-322) + _drift_velocity_update (:324-341) + _wall_velocity_update
+ * (:343-421) + _check_and_handle_wall_collisions (:423-441) + boundary safety
+ * net (:221-222, Environment.py:781-894) + _measure_velocity_of_step_taken
+ * (:444-472) + _update_head_direction (:474-500) + _update_distance_travelled
+ * (:502-507) + save_to_history (:509-521), with utils.py:30-184, 231-368,
+ * 409-421 inlined.
+ *
+ *  state      device float64 [RIAB_STATE_ROWS][B], read and written
+ *  agent_id0  global id of agent 0 of this shard (keys the RNG; results do not
+ *             depend on how agents are sharded over GPUs)
+ *  drift      device float64 [2][B] or NULL (drift_velocity per agent)
+ *  z_in       device float64 [T][2][B] or NULL: the two standard normals the
+ *             reference draws per update (rotation OU, speed OU).  NULL =>
+ *             Philox4x32-10 keyed by (seed; step0+t, agent id)
+ *  z_out      device float64 [T][2][B] or NULL: records the normals used
+ *  hist       device float32 [T][RIAB_HIST_ROWS][B] or NULL
+ *  diag       device int32 [4] or NULL, atomically accumulated:
+ *             [0] bounces, [1] bounce-loop saturations, [2] boundary
+ *             conditions applied, [3] zero-displacement steps
+ *  precision  64 (float64 arithmetic, parity mode) or 32 (float32 arithmetic)
+ */
+int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
+                    int64_t agent_id0, const double* drift, const double* z_in, double* z_out,
+                    uint64_t seed, uint64_t step0, int32_t T, float* hist, int32_t* diag,
+                    int32_t precision, riab_stream_t stream);
+
+/* Where a firing-rate kernel reads positions and writes rates / spikes.
+ * Positions are T rows of B agents: row t of x starts at pos_x + t*pos_ld
+ * (so a trajectory history [T][8][B] is consumed in place with pos_ld = 8*B,
+ * and a plain list of P positions is T=1, B=P).  Output is rates[t][c][b]
+ * = Neurons.history["firingrate"][t][c] of agent b; for T=1 it is the
+ * reference's get_state() layout (n_cells, P) (Neurons.py:943-949). */
+typedef struct RiabRateIO {
+  const float* pos_x;    /* device */
+  const float* pos_y;    /* device */
+  const float* hd_x;     /* device or NULL: head direction rows (HDC, egocentric BVC) */
+  const float* hd_y;
+  int64_t pos_ld;        /* elements between consecutive time rows */
+  int64_t T, B;
+  float* rates;          /* device float32 [T][n][B] */
+  uint8_t* spikes;       /* device uint8 [T][n][B] or NULL (Neurons.py:681-687) */
+  const float* u_in;     /* device float32 [T][n][B] or NULL: explicit spike uniforms */
+  float dt;              /* Agent.dt for the spike rule `u < dt*rate` */
+  float min_fr, max_fr;  /* rates are scaled to [min_fr, max_fr] */
+  uint64_t seed;         /* Philox key for spikes when u_in == NULL */
+  uint64_t step0;        /* global index of time row 0 */
+  int64_t agent_id0;     /* global id of agent 0 (multiple of 4) */
+  int32_t pop_id;        /* distinguishes Neurons populations in the RNG stream */
+} RiabRateIO;
+
+enum { RIAB_PC_GAUSSIAN = 0, RIAB_PC_GAUSSIAN_THRESHOLD = 1, RIAB_PC_DIFF_OF_GAUSSIANS = 2,
+       RIAB_PC_ONE_HOT = 3, RIAB_PC_TOP_HAT = 4 };
+enum { RIAB_GEOM_EUCLIDEAN = 0, RIAB_GEOM_LINE_OF_SIGHT = 1, RIAB_GEOM_GEODESIC = 2 };
+
+/* PlaceCells.get_state (Neurons.py:936-981) with
+ * Environment.get_distances_between___accounting_for_environment
+ * (Environment.py:677-779).  cells device float32 [3][n]: row 0 centre x, row 1
+ * centre y, row 2 k = -log2(e)/(2 w^2) (host, float64, rounded once) so that
+ * the gaussian is exp2(d^2 * k).  top_hat_width is the scalar `widths`
+ * parameter the reference's top_hat compares against (Neurons.py:976).
+ * line_of_sight / geodesic read env->walls[4:] (Environment.py:715-717). */
+int riab_place_cells(const RiabEnv* env, const RiabRateIO* io, const float* cells, int32_t n,
+                     int32_t description, int32_t geometry, float top_hat_width,
+                     riab_stream_t stream);
+
+enum { RIAB_GC_RECTIFIED = 0, RIAB_GC_SHIFTED = 1 };
+
+/* GridCells.get_state, 2D (Neurons.py:1172-1236).  table device float32 [9][n]:
+ * rows 3i..3i+2 = (a_i, bx_i, by_i) with the phase of cosine i, in
+ * revolutions, phi_i/2pi = a_i - (x*bx_i + y*by_i); built on the host in
+ * float64 from gridscales, phase_offsets and w (Neurons.py:1154-1161, 1192-1203).
+ * f0 = firing_rate_at_full_width (Neurons.py:1211). */
+int riab_grid_cells(const RiabRateIO* io, const float* table, int32_t n, int32_t description,
+                    float f0, riab_stream_t stream);
+
+/* HeadDirectionCells.get_state, 2D (Neurons.py:2421-2485): von Mises of
+ * utils.get_angle(head_direction).  pref device float32 [n], kappa = 1/sigma^2
+ * device float32 [n].  Needs io->hd_x / hd_y. */
+int riab_head_direction_cells(const RiabRateIO* io, const float* pref, const float* kappa, int32_t n,
+                              riab_stream_t stream);
+
+/* BoundaryVectorCells.get_state (Neurons.py:1617-1778) with utils.vector_intercepts
+ * (utils.py:30-118), gaussian / von_mises (utils.py:424-457).
+ *  test_dirs  device float64 [K][2] unit test directions (Neurons.py:1584-1596)
+ *  cells      device float32 [4][n]: row 0 = a*mu_d, row 1 = a with
+ *             a = sqrt(log2(e)/2)/sigma_d (so the radial gaussian is
+ *             exp2(-(a d - a mu_d)^2)), row 2 = kappa*log2(e), row 3 unused
+ *  vm_table   device float32.  allocentric: [n][K] =
+ *             log2(e)*kappa_c*(cos(theta_k - mu_c) - 1).  egocentric: [2][n][K] =
+ *             cos(theta_k - mu_c), sin(theta_k - mu_c); the head bearing
+ *             utils.get_angle(head_direction) enters through its cosine / sine
+ *             (hx+1e-6, hy)/norm, so no per-term trigonometry is needed
+ *  inv_norm   device float32 [n]: 1 / cell_fr_norm (Neurons.py:1598-1604)
+ *  egocentric needs io->hd_x / hd_y
+ *  ray_out    device float32 [T][K][B] or NULL: the first-wall ray distances
+ *             (diagnostic / parity of the ray stage) */
+int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* io, const double* test_dirs,
+                               int32_t K, const float* cells, const float* vm_table,
+                               const float* inv_norm, int32_t n, int32_t egocentric,
+                               float* ray_out, riab_stream_t stream);
+
+/* Neurons.save_to_history spike rule (Neurons.py:681-687) on rates that already
+ * exist: spikes = u < dt*rate (one fp32 multiply, one fp32 compare).  count
+ * elements, u_in explicit uniforms or NULL => Philox as in the rate kernels
+ * (then n, B, T describe the [T][n][B] shape). */
+int riab_spikes(const RiabRateIO* io, int32_t n, riab_stream_t stream);
+
+/* Neurons.update noise (Neurons.py:153-168): noise += OU(noise; 0, noise_std,
+ * noise_coherence_time) for one step and rates[c][b] += noise[c][b].
+ * noise device float32 [n][B] read/written; z_in device float32 [n][B]
+ * standard normals or NULL => Philox. theta = 1/tau, sigma_dt = sigma*dt. */
+int riab_neuron_noise(float* noise, float* rates, const float* z_in, int32_t n, int64_t B,
+                      float theta_dt, float sigma_dt, uint64_t seed, uint64_t step, int32_t pop_id,
+                      int64_t agent_id0, riab_stream_t stream);
+
+/* Streaming-store calibration kernel: writes `bytes` bytes (multiple of 16) of
+ * a constant with the same 16-B/lane store pattern as the rate kernels.  Used
+ * to calibrate the WRITE_SIZE counter and to measure the store roofline. */
+int riab_fill(void* dst, int64_t bytes, float value, riab_stream_t stream);
+
+int riab_abi_version(void);
+const char* riab_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIAB_HIP_H */

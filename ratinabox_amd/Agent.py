@@ -1,0 +1,357 @@
+"""`Agent` — batched, device-resident drop-in for the reference's Agent on the
+random-motion path (reference ratinabox/Agent.py:17-1102).
+
+One `Agent` object holds `n_agents` INDEPENDENT agents (new: the reference has one
+agent per object and loops a Python list, README.md:236-241).  The public surface
+is the reference's: `Agent(Environment, params)`, `update(dt, drift_velocity,
+drift_to_random_strength_ratio, **kwargs)`, attributes `pos, velocity,
+rotational_velocity, measured_velocity, measured_rotational_velocity,
+head_direction, distance_travelled, distance_to_closest_wall, t, dt, history,
+Neurons`, `get_history_arrays()`, `reset_history()`.  With `n_agents == 1` the
+attribute shapes are the reference's (`pos (2,)`, ...); otherwise they carry a
+leading agent axis (`pos (B,2)`, `history["pos"] (T,B,2)`).
+
+All per-step arithmetic runs in the HIP kernel `riab_agent_step`
+(csrc/riab_agent.hip); this class owns the state tensor `[12, B]` (float64, HBM),
+the trajectory history chunks `[T, 8, B]` (float32, HBM) and resolves parameters.
+`simulate(T)` is the fused path: T steps per launch on one stream while the
+firing-rate kernels of the previous chunk run on another."""
+import copy
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib, utils
+from ._history import DeviceHistory, HistoryView
+
+_L = _lib
+
+
+class Agent:
+    default_params = {
+        "name": None,
+        "dt": 0.05,
+        "speed_coherence_time": 0.7,
+        "speed_mean": 0.08,
+        "speed_std": 0.08,
+        "rotational_velocity_coherence_time": 0.08,
+        "rotational_velocity_std": (120 * (np.pi / 180)),
+        "head_direction_smoothing_timescale": 0.15,
+        "thigmotaxis": 0.5,
+        "wall_repel_distance": 0.1,
+        "wall_repel_strength": 1.0,
+        "save_history": True,
+        # --- batched extension (not in the reference) ---
+        "n_agents": 1,        # independent agents held by this object
+        "device": "cuda",     # torch device of the state / history tensors
+        "seed": 0,            # Philox key of the in-kernel noise (production mode)
+        "precision": 64,      # arithmetic of the motion kernel: 64 (parity) or 32
+        "agent_id0": 0,       # global id of agent 0 (multi-GPU shards; keys the RNG)
+    }
+
+    def __init__(self, Environment, params={}):
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        utils.update_class_params(self, self.params, get_all_defaults=True)
+        utils.check_params(self, params.keys())
+
+        self.Environment = Environment
+        self.agent_idx = len(self.Environment.Agents)
+        if self.name is None:
+            self.name = f"agent_{self.agent_idx}"
+        self.Environment.add_agent(agent=self)
+
+        self.n_agents = int(self.n_agents)
+        assert self.n_agents >= 1
+        assert self.agent_id0 % 4 == 0, "agent_id0 must be a multiple of 4"
+        self._B = self.n_agents
+        self._Bp = (self.n_agents + 3) // 4 * 4  # kernels need a multiple of 4 on the agent axis
+        self._device = torch.device(self.device)
+
+        self.Neurons = []
+        self.prev_t = 0
+        self.t = 0
+        self.average_measured_speed = max(self.speed_mean, self.speed_std)
+        self.use_imported_trajectory = False
+        self._step_index = 0  # counts update() calls: the RNG counter
+        self._times = []
+        self._hist = DeviceHistory((_L.HIST_ROWS, self._Bp), torch.float32, self._device)
+        self._diag = torch.zeros(4, dtype=torch.int32, device=self._device)
+        self._streams = None
+
+        self._state = torch.zeros((_L.STATE_ROWS, self._Bp), dtype=torch.float64, device=self._device)
+        self.initialise_position_and_velocity()
+        # measured velocity starts as the velocity, head direction as its unit vector (Agent.py:137-141)
+        st = self._state
+        st[_L.S_MVEL_X:_L.S_MVEL_Y + 1] = st[_L.S_VEL_X:_L.S_VEL_Y + 1]
+        st[_L.S_MROT_VEL] = 0.0
+        nrm = torch.sqrt(st[_L.S_VEL_X] ** 2 + st[_L.S_VEL_Y] ** 2)
+        st[_L.S_HD_X] = st[_L.S_VEL_X] / nrm
+        st[_L.S_HD_Y] = st[_L.S_VEL_Y] / nrm
+        st[_L.S_DIST] = 0.0
+        st[_L.S_DWALL] = float("inf")
+        self.history = HistoryView(("t", "pos", "distance_travelled", "vel", "rot_vel", "head_direction"),
+                                   self._materialise_history, lambda: self._hist.version)
+
+    @classmethod
+    def get_all_default_params(cls, verbose=False):
+        all_params = utils.collect_all_params(cls, dict_name="default_params")
+        if verbose:
+            import pprint
+            pprint.pprint(all_params)
+        return all_params
+
+    # ---- initial state (Agent.py:523-535) ---------------------------------------------------
+    def initialise_position_and_velocity(self):
+        """Uniform positions in the box, uniform headings, speed = speed_mean.  Draws
+        from np.random per agent in the reference's order (position x, y, then heading)."""
+        B = self._B
+        pos = np.zeros((self._Bp, 2))
+        vel = np.zeros((self._Bp, 2))
+        for i in range(B):
+            pos[i] = self.Environment.sample_positions(n=1, method="random")[0]
+            direction = np.random.uniform(0, 2 * np.pi)
+            vel[i] = self.speed_mean * np.array([np.cos(direction), np.sin(direction)])
+        pos[B:], vel[B:] = pos[0], vel[0]  # padding agents shadow agent 0
+        self._upload(_L.S_POS_X, pos)
+        self._upload(_L.S_VEL_X, vel)
+        self._state[_L.S_ROT_VEL] = 0.0
+
+    # ---- attribute access -------------------------------------------------------------------
+    def _squeeze(self, a):
+        return a[0] if self._B == 1 else a
+
+    def _download(self, row, width):
+        a = self._state[row:row + width, :self._B].t().contiguous().cpu().numpy()
+        return self._squeeze(a if width > 1 else a[:, 0])
+
+    def _upload(self, row, value):
+        value = np.asarray(value, dtype=np.float64)
+        width = 2 if value.ndim >= 1 and value.shape[-1] == 2 and row in (
+            _L.S_POS_X, _L.S_VEL_X, _L.S_MVEL_X, _L.S_HD_X) else 1
+        if width == 2:
+            v = np.broadcast_to(value.reshape(-1, 2), (value.reshape(-1, 2).shape[0], 2))
+            full = np.empty((self._Bp, 2))
+            if v.shape[0] == 1:
+                full[:] = v[0]
+            else:
+                n = min(v.shape[0], self._Bp)
+                full[:n] = v[:n]
+                full[n:] = v[0]
+            self._state[row:row + 2] = torch.from_numpy(np.ascontiguousarray(full.T)).to(self._device)
+        else:
+            v = value.reshape(-1)
+            full = np.empty(self._Bp)
+            if v.shape[0] == 1:
+                full[:] = v[0]
+            else:
+                n = min(v.shape[0], self._Bp)
+                full[:n] = v[:n]
+                full[n:] = v[0]
+            self._state[row] = torch.from_numpy(full).to(self._device)
+
+    pos = property(lambda s: s._download(_L.S_POS_X, 2), lambda s, v: s._upload(_L.S_POS_X, v))
+    velocity = property(lambda s: s._download(_L.S_VEL_X, 2), lambda s, v: s._upload(_L.S_VEL_X, v))
+    rotational_velocity = property(lambda s: s._download(_L.S_ROT_VEL, 1), lambda s, v: s._upload(_L.S_ROT_VEL, v))
+    measured_velocity = property(lambda s: s._download(_L.S_MVEL_X, 2), lambda s, v: s._upload(_L.S_MVEL_X, v))
+    measured_rotational_velocity = property(lambda s: s._download(_L.S_MROT_VEL, 1),
+                                            lambda s, v: s._upload(_L.S_MROT_VEL, v))
+    head_direction = property(lambda s: s._download(_L.S_HD_X, 2), lambda s, v: s._upload(_L.S_HD_X, v))
+    distance_travelled = property(lambda s: s._download(_L.S_DIST, 1), lambda s, v: s._upload(_L.S_DIST, v))
+    distance_to_closest_wall = property(lambda s: s._download(_L.S_DWALL, 1))
+
+    @property
+    def state_tensor(self):
+        """Device state `[12, B_padded]` float64 (rows: include/riab_hip.h RIAB_S_*)."""
+        return self._state
+
+    @property
+    def diagnostics(self):
+        """Counters accumulated by the kernel: bounces, bounce-loop saturations,
+        boundary conditions applied, zero-displacement steps."""
+        d = self._diag.cpu().numpy()
+        return dict(bounces=int(d[0]), bounce_saturations=int(d[1]), boundary_conditions=int(d[2]),
+                    zero_displacement=int(d[3]))
+
+    # ---- parameter resolution ---------------------------------------------------------------
+    def _motion(self, dt, has_drift, ratio, kwargs):
+        """Resolve one update's parameters into the ABI struct, reproducing which values
+        the reference takes from kwargs and which from attributes (Agent.py:280-285,
+        310, 340, 353-355, 375, 439, 489)."""
+        g = kwargs.get
+        m = _L.RiabMotion()
+        rot_std = g("rotational_velocity_std", self.rotational_velocity_std)
+        rot_tau = g("rotational_velocity_coherence_time", self.rotational_velocity_coherence_time)
+        spd_tau = g("speed_coherence_time", self.speed_coherence_time)
+        m.dt = float(dt)
+        m.rot_theta_kw = 1 / rot_tau
+        m.rot_sigma_kw = float(np.sqrt((2 * rot_std ** 2) / (rot_tau * dt)))
+        m.rot_drift_kw = float(g("rotational_velocity_drift", 0))
+        m.speed_theta_kw = 1 / spd_tau
+        m.speed_sigma_kw = float(np.sqrt((2 * 1 ** 2) / (spd_tau * dt)))
+        m.speed_mean_kw = float(g("speed_mean", self.speed_mean))
+        m.speed_mean = float(self.speed_mean)
+        m.speed_std_is_zero = 1 if self.speed_std == 0 else 0
+        m.has_drift = 1 if has_drift else 0
+        m.drift_theta = 1 / (self.speed_coherence_time / ratio) if has_drift else 0.0
+        m.wall_repel_strength_kw = float(g("wall_repel_strength", self.wall_repel_strength))
+        m.wall_repel_distance_kw = float(g("wall_repel_distance", self.wall_repel_distance))
+        m.thigmotaxis_kw = float(g("thigmotaxis", self.thigmotaxis))
+        m.hd_tau = float(self.head_direction_smoothing_timescale)
+        return m
+
+    def _as_device_f64(self, x, rows):
+        """array-like `(B, rows)` / `(rows,)` / tensor `[rows, B]` -> device float64 `[rows, Bp]`."""
+        if torch.is_tensor(x):
+            t = x.to(self._device, torch.float64)
+            if t.shape == (rows, self._Bp):
+                return t.contiguous()
+            x = t.cpu().numpy()
+            if x.shape == (rows, self._B):
+                x = x.T
+        a = np.asarray(x, dtype=np.float64)
+        a = np.broadcast_to(a.reshape(-1, rows), (self._B, rows)) if a.size == rows else a.reshape(self._B, rows)
+        full = np.empty((rows, self._Bp))
+        full[:, :self._B] = a.T
+        full[:, self._B:] = a[0][:, None]
+        return torch.from_numpy(full).to(self._device)
+
+    # ---- one step -----------------------------------------------------------------------------
+    def update(self, dt=None, drift_velocity=None, drift_to_random_strength_ratio=1, **kwargs):
+        """One motion step for every agent (reference Agent.update, Agent.py:160-242).
+
+        kwargs: the reference's per-call overrides (speed_mean, thigmotaxis, ...), plus
+        `noise=` — explicit standard normals `(2, B)` / `(B, 2)` [rotation OU, speed OU]
+        instead of the in-kernel Philox draws (parity mode)."""
+        if self.use_imported_trajectory or kwargs.get("forced_next_position") is not None:
+            raise NotImplementedError("imported / forced trajectories are outside the accelerated path")
+        self._advance(1, dt, drift_velocity, drift_to_random_strength_ratio, kwargs)
+
+    def _advance(self, T, dt, drift_velocity, ratio, kwargs, hist_view=None, stream=None, z_out=None):
+        dt = dt or self.dt
+        self.dt = dt
+        noise = kwargs.pop("noise", None) if "noise" in kwargs else None
+        has_drift = drift_velocity is not None
+        m = self._motion(dt, has_drift, ratio, kwargs)
+        env, _walls = self.Environment.device_tables(self._device)
+        drift = self._as_device_f64(drift_velocity, 2) if has_drift else None
+        z = None
+        if noise is not None:
+            zt = noise if torch.is_tensor(noise) else torch.as_tensor(np.asarray(noise, dtype=np.float64))
+            zt = zt.to(self._device, torch.float64)
+            if T == 1 and zt.dim() == 2:
+                zt = zt.unsqueeze(0)
+            if zt.shape[-1] == 2 and zt.shape[-2] != 2:
+                zt = zt.transpose(-1, -2)
+            if zt.shape[-1] != self._Bp:  # pad agents
+                pad = zt[..., :1].expand(*zt.shape[:-1], self._Bp - zt.shape[-1])
+                zt = torch.cat((zt, pad), dim=-1)
+            z = zt.contiguous()
+            assert z.shape == (T, 2, self._Bp), f"noise must be (T,2,B), got {tuple(z.shape)}"
+        if hist_view is None and self.save_history:
+            hist_view = self._hist.reserve(T)
+        s = stream if stream is not None else _L.current_stream()
+        rc = _L.lib.riab_agent_step(env, m, _L.ptr(self._state), self._Bp, int(self.agent_id0), _L.ptr(drift),
+                                    _L.ptr(z), _L.ptr(z_out), int(self.seed), int(self._step_index), int(T),
+                                    _L.ptr(hist_view), _L.ptr(self._diag), int(self.precision), s)
+        _L.check(rc, "riab_agent_step")
+        self._keep = (drift, z, _walls, hist_view)  # keep operands alive until the stream is done
+        for _ in range(T):
+            self.prev_t = self.t
+            self.t += dt
+            if self.save_history:
+                self._times.append(self.t)
+        self._step_index += T
+        return hist_view
+
+    # ---- fused path ----------------------------------------------------------------------------
+    def simulate(self, n_steps, dt=None, drift_velocity=None, drift_to_random_strength_ratio=1, chunk=256,
+                 neurons=None, noise=None, **kwargs):
+        """`n_steps` x (Agent.update(); N.update() for N in neurons) without returning to
+        Python between steps (new; the open-loop workload of SURVEY §7.3-1).
+
+        The trajectory kernel advances `chunk` steps per launch on one HIP stream; the
+        firing-rate kernels of every Neurons population consume each finished chunk
+        `[chunk, 8, B]` in place on a second stream, overlapping the next trajectory
+        chunk.  Histories land in HBM (`save_history=True`) exactly as `n_steps` calls of
+        update() would have left them.  Returns the trajectory history tensor of this call
+        `[n_steps, 8, B_padded]` (device)."""
+        neurons = list(self.Neurons if neurons is None else neurons)
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(device=self._device), torch.cuda.Stream(device=self._device))
+        s_traj, s_rate = self._streams
+        cur = torch.cuda.current_stream(self._device)
+        n_steps = int(n_steps)
+        dt = dt or self.dt
+        if self.save_history:
+            traj = self._hist.reserve(n_steps)
+        else:
+            traj = torch.empty((n_steps, _L.HIST_ROWS, self._Bp), dtype=torch.float32, device=self._device)
+        outs = [N._reserve_rows(n_steps, ring=min(chunk, n_steps)) for N in neurons]
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        s_traj.wait_event(ready)
+        s_rate.wait_event(ready)
+        z_all = None
+        if noise is not None:
+            z_all = noise
+        step0 = self._step_index
+        t0 = 0
+        while t0 < n_steps:
+            tc = min(chunk, n_steps - t0)
+            view = traj[t0:t0 + tc]
+            kw = dict(kwargs)
+            if z_all is not None:
+                kw["noise"] = z_all[t0:t0 + tc]
+            with torch.cuda.stream(s_traj):
+                self._advance(tc, dt, drift_velocity, drift_to_random_strength_ratio, kw, hist_view=view,
+                              stream=_lib.C.c_void_p(s_traj.cuda_stream))
+                ev = torch.cuda.Event()
+                ev.record(s_traj)
+            s_rate.wait_event(ev)
+            with torch.cuda.stream(s_rate):
+                for N, out in zip(neurons, outs):
+                    N._rates_from_trajectory(view, out, t0, tc, step0 + t0, float(dt),
+                                             stream=_lib.C.c_void_p(s_rate.cuda_stream))
+            t0 += tc
+        done_a, done_b = torch.cuda.Event(), torch.cuda.Event()
+        done_a.record(s_traj)
+        done_b.record(s_rate)
+        cur.wait_event(done_a)
+        cur.wait_event(done_b)
+        for N, out in zip(neurons, outs):
+            N._finish_rows(out, n_steps, self._times[-n_steps:] if self.save_history else None)
+        return traj
+
+    # ---- history --------------------------------------------------------------------------------
+    def _materialise_history(self):
+        h = self._hist.stack()[:, :, :self._B].cpu().numpy()  # (T, 8, B)
+        sq = (lambda a: a[:, 0]) if self._B == 1 else (lambda a: a)
+        pair = lambda i: sq(np.stack((h[:, i], h[:, i + 1]), axis=-1))  # noqa: E731
+        return {
+            "t": np.array(self._times, dtype=float),
+            "pos": pair(_L.H_POS_X),
+            "distance_travelled": sq(h[:, _L.H_DIST]),
+            "vel": pair(_L.H_VEL_X),
+            "rot_vel": sq(h[:, _L.H_ROT_VEL]),
+            "head_direction": pair(_L.H_HD_X),
+        }
+
+    def get_history_arrays(self):
+        """history as a dict of NumPy arrays (reference Agent.py:1093-1102)."""
+        return dict(self.history.items())
+
+    def get_history_tensor(self):
+        """Trajectory history on device: float32 `[T, 8, B_padded]` (rows RIAB_H_*)."""
+        return self._hist.stack()
+
+    def reset_history(self):
+        self._hist.reset()
+        self._times = []
+
+    def save_to_history(self, **kwargs):
+        raise NotImplementedError("history rows are written by the motion kernel; there is no host-side append")
+
+    def import_trajectory(self, *a, **k):
+        raise NotImplementedError("imported trajectories are outside the accelerated path (SURVEY §8f)")

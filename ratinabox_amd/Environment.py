@@ -1,0 +1,183 @@
+"""`Environment` — host-side mirror of the reference's Environment class for the
+batched hot path (reference ratinabox/Environment.py:20-895).
+
+Same constructor / parameter dictionary / attributes that `Agent` and `Neurons`
+read: `walls (N_w,2,2)` in reference order, `extent`, `scale`, `aspect`, `D`,
+`dimensionality`, `boundary_conditions`, `Agents`, `flattened_discrete_coords`,
+`add_wall`, `sample_positions`, `discretise_environment`.  The geometry QUERIES
+of the reference (wall collisions, vectors from walls, distances accounting for
+walls, inside test, boundary conditions: Environment.py:657-894) are not Python
+here: they are inlined into the HIP kernels, which read the device copy of the
+wall table kept by `device_tables()`.
+
+In scope: rectangular 2D boxes, solid or periodic, with interior walls.
+Polygonal boundaries, holes, objects and 1D environments are outside the
+accelerated path and raise NotImplementedError."""
+import copy
+import warnings
+
+import numpy as np
+
+from . import utils
+
+
+class Environment:
+    default_params = {
+        "dimensionality": "2D",
+        "boundary_conditions": "solid",  # "solid" or "periodic"
+        "scale": 1,        # metres
+        "aspect": 1,       # width / height of the rectangular box
+        "dx": 0.01,        # discretisation used by evaluate_at="all"
+        "boundary": None,  # polygon boundary: not supported on the accelerated path
+        "walls": [],       # interior walls [[x0,y0],[x1,y1]]
+        "holes": [],       # not supported on the accelerated path
+        "objects": [],     # not supported on the accelerated path
+    }
+
+    def __init__(self, params={}):
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        utils.update_class_params(self, self.params, get_all_defaults=True)
+        utils.check_params(self, params.keys())
+
+        self.Agents = []
+        self.agents_dict = {}
+        if self.dimensionality != "2D":
+            raise NotImplementedError("ratinabox_amd accelerates 2D environments only")
+        if self.boundary is not None:
+            raise NotImplementedError("polygonal boundaries are outside the accelerated path (rectangular boxes only)")
+        if len(self.holes) > 0:
+            raise NotImplementedError("holes are outside the accelerated path")
+        if len(self.objects) > 0:
+            raise NotImplementedError("objects are outside the accelerated path")
+        if self.boundary_conditions not in ("solid", "periodic"):
+            raise ValueError("boundary_conditions must be 'solid' or 'periodic'")
+        self.D = 2
+        self.is_rectangular = True
+        self.has_holes = False
+        b = [[0, 0], [self.aspect * self.scale, 0], [self.aspect * self.scale, self.scale], [0, self.scale]]
+        self.boundary = b
+        self.walls = np.array(self.walls, dtype=float).reshape(-1, 2, 2)
+        if self.boundary_conditions == "solid":
+            # reference order (Environment.py:137-144): boundary wall i runs from corner i+1 to corner i
+            boundary_walls = np.array([[b[(i + 1) % 4], b[i]] for i in range(4)], dtype=float)
+            self.walls = np.vstack((boundary_walls, self.walls))
+        left, right = 0.0, float(self.aspect * self.scale)
+        bottom, top = 0.0, float(self.scale)
+        self.centre = np.array([(left + right) / 2, (top + bottom) / 2])
+        self.extent = np.array([left, right, bottom, top])
+        self.discrete_coords = self.discretise_environment(dx=self.dx)
+        self.flattened_discrete_coords = self.discrete_coords.reshape(-1, self.discrete_coords.shape[-1])
+        self._device_cache = {}
+
+    @classmethod
+    def get_all_default_params(cls, verbose=False):
+        all_params = utils.collect_all_params(cls, dict_name="default_params")
+        if verbose:
+            import pprint
+            pprint.pprint(all_params)
+        return all_params
+
+    # -- agents registry (Environment.py:250-330) ---------------------------------------
+    def add_agent(self, agent=None):
+        assert agent is not None, "agent must be an Agent"
+        if agent.name in self.agents_dict:
+            name = f"agent_{len(self.Agents)}"
+            if name in self.agents_dict:
+                raise ValueError(f"Agents named {agent.name} and {name} already exist; choose a unique name")
+            warnings.warn(f"An agent with the name {agent.name} already exists. Renaming to {name}")
+            agent.name = name
+        self.Agents.append(agent)
+        self.agents_dict[agent.name] = agent
+
+    def remove_agent(self, agent=None):
+        if isinstance(agent, str):
+            agent = self.agents_dict.get(agent)
+        if agent is None:
+            return None
+        self.Agents.remove(agent)
+        self.agents_dict.pop(agent.name)
+
+    # -- geometry edits -------------------------------------------------------------------
+    def add_wall(self, wall):
+        """Append one wall [[x1,y1],[x2,y2]] (Environment.py:330-342)."""
+        wall = np.asarray(wall, dtype=float).reshape(1, 2, 2)
+        self.walls = wall if len(self.walls) == 0 else np.concatenate((self.walls, wall), axis=0)
+        self._device_cache.clear()
+
+    def add_hole(self, hole):
+        raise NotImplementedError("holes are outside the accelerated path")
+
+    def add_object(self, object, type="new"):
+        raise NotImplementedError("objects are outside the accelerated path")
+
+    # -- sampling (Environment.py:560-633) ------------------------------------------------
+    def sample_positions(self, n=10, method="uniform_jitter"):
+        """n positions in the box: "random", "uniform" (a grid, x fastest) or
+        "uniform_jitter"; draws from the global np.random state in the reference's order."""
+        ex = self.extent
+        if method == "random":
+            positions = np.zeros((n, 2))
+            positions[:, 0] = np.random.uniform(ex[0], ex[1], size=n)
+            positions[:, 1] = np.random.uniform(ex[2], ex[3], size=n)
+            return positions
+        if method[:7] == "uniform":
+            area = (ex[1] - ex[0]) * (ex[3] - ex[2])
+            delta = np.sqrt(area / n)
+            x = np.linspace(ex[0] + delta / 2, ex[1] - delta / 2, int((ex[1] - ex[0]) / delta))
+            y = np.linspace(ex[2] + delta / 2, ex[3] - delta / 2, int((ex[3] - ex[2]) / delta))
+            positions = np.array(np.meshgrid(x, y)).reshape(2, -1).T
+            n_uniform = positions.shape[0]
+            if method[7:] == "_jitter":
+                positions = positions + np.random.uniform(-0.45 * delta, 0.45 * delta, positions.shape)
+            n_remaining = n - n_uniform
+            if n_remaining > 0:
+                pick = np.random.choice(range(len(positions)), n_remaining, replace=True)
+                extra = np.array([positions[i] for i in pick])
+                delta /= 2
+                extra = extra + np.random.uniform(-0.45 * delta, 0.45 * delta, extra.shape)
+                positions = np.vstack((positions, extra))
+            return positions
+        raise ValueError(f"unknown sampling method {method}")
+
+    def discretise_environment(self, dx=None):
+        """(Ny, Nx, 2) grid of positions, y descending (Environment.py:635-655)."""
+        dx = self.dx if dx is None else dx
+        minx, maxx, miny, maxy = [float(v) for v in self.extent]
+        self.x_array = np.arange(minx + dx / 2, maxx, dx)
+        self.y_array = np.arange(miny + dx / 2, maxy, dx)[::-1]
+        xm, ym = np.meshgrid(self.x_array, self.y_array)
+        return np.stack((xm, ym), axis=-1)
+
+    def check_if_position_is_in_environment(self, pos):
+        """Strict interior test (Environment.py:781-818), host-side convenience."""
+        pos = np.asarray(pos, dtype=float).reshape(-1)
+        e = self.extent
+        return bool((pos[0] > e[0]) and (pos[0] < e[1]) and (pos[1] > e[2]) and (pos[1] < e[3]))
+
+    # -- device tables --------------------------------------------------------------------
+    def device_tables(self, device):
+        """(RiabEnv struct, walls tensor): device copy of the wall table in the
+        layout include/riab_hip.h documents.  Rebuilt when `walls` changed."""
+        import torch
+        from . import _lib
+        walls = np.ascontiguousarray(np.asarray(self.walls, dtype=np.float64).reshape(-1, 4))
+        key = (str(device), walls.tobytes(), self.boundary_conditions, float(self.scale), float(self.aspect))
+        hit = self._device_cache.get("env")
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        if len(walls) > _lib.MAX_WALLS:
+            raise ValueError(f"at most {_lib.MAX_WALLS} walls are supported on device, got {len(walls)}")
+        wt = torch.from_numpy(walls if len(walls) else np.zeros((1, 4))).to(device)
+        env = _lib.RiabEnv()
+        for i in range(4):
+            env.extent[i] = float(self.extent[i])
+        env.scale = float(self.scale)
+        env.periodic = 1 if self.boundary_conditions == "periodic" else 0
+        env.n_walls = int(len(walls))
+        env.walls = wt.data_ptr()
+        self._device_cache["env"] = (key, env, wt)
+        return env, wt
+
+    def plot_environment(self, *a, **k):
+        raise NotImplementedError("plotting is outside the accelerated path; use the reference package for figures")

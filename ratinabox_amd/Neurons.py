@@ -1,0 +1,594 @@
+"""`Neurons`, `PlaceCells`, `GridCells`, `BoundaryVectorCells`,
+`HeadDirectionCells` — batched, device-resident drop-ins for the firing-rate
+path of the reference (reference ratinabox/Neurons.py).
+
+Surface kept from the reference: `Cells(Agent, params)`, `update(**kwargs)`,
+`get_state(evaluate_at="agent"|"all"|None, pos=..., head_direction=...)` returning
+`(n, P)`, attributes `firingrate, n, noise, history{"t","firingrate","spikes"}`,
+`get_history_arrays()`, `reset_history()`, `default_params` /
+`get_all_default_params()`, and the per-class tuning attributes users edit
+(`place_cell_centres`, `place_cell_widths`, `gridscales`, `phase_offsets`, `w`,
+`tuning_distances`, ..., `preferred_angles`).  Device tables are rebuilt whenever
+those attributes changed (content hash), so `PCs.place_cell_centres[-1] = ...`
+works as in the reference (tests/test_advanced.py:59).
+
+Every `get_state` evaluates on the GPU through the C ABI (include/riab_hip.h);
+init-time parameter sampling stays in NumPy with the reference's draw order.
+With `Agent.n_agents == B > 1`, `firingrate` is `(n, B)` and
+`history["firingrate"]` `(T, n, B)`."""
+import copy
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib, utils
+from ._history import DeviceHistory, HistoryView
+
+_L = _lib
+LOG2E = 1.4426950408889634
+
+
+def _pad4(n):
+    return (int(n) + 3) // 4 * 4
+
+
+class Neurons:
+    default_params = {
+        "n": 10,
+        "name": "Neurons",
+        "color": None,
+        "noise_std": 0,
+        "noise_coherence_time": 0.5,
+        "min_fr": 0.0,
+        "max_fr": 1.0,
+        "save_history": True,
+        # --- batched extension (not in the reference) ---
+        "save_spikes": True,  # False: skip the Poisson-spike draw and its history (rates only)
+    }
+
+    def __init__(self, Agent, params={}):
+        self.Agent = Agent
+        self.Agent.Neurons.append(self)
+        self.pop_id = len(self.Agent.Neurons) - 1  # keys this population's RNG stream
+
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        utils.update_class_params(self, self.params, get_all_defaults=True)
+        utils.check_params(self, params.keys())
+
+        self._device = Agent._device
+        self._B, self._Bp = Agent._B, Agent._Bp
+        self._table_cache = {}
+        self._alloc_state()
+
+    def _alloc_state(self):
+        n = int(self.n)
+        self._rates = torch.zeros((n, self._Bp), dtype=torch.float32, device=self._device)
+        self._noise = torch.zeros((n, self._Bp), dtype=torch.float32, device=self._device)
+        self._spikes_last = None
+        self._hist_fr = DeviceHistory((n, self._Bp), torch.float32, self._device)
+        self._hist_sp = DeviceHistory((n, self._Bp), torch.uint8, self._device)
+        self._times = []
+        self.history = HistoryView(("t", "firingrate", "spikes"), self._materialise_history,
+                                   lambda: self._hist_fr.version)
+
+    @classmethod
+    def get_all_default_params(cls, verbose=False):
+        all_params = utils.collect_all_params(cls, dict_name="default_params")
+        if verbose:
+            import pprint
+            pprint.pprint(all_params)
+        return all_params
+
+    # ---- attributes -----------------------------------------------------------------------------
+    @property
+    def firingrate(self):
+        a = self._rates[:, :self._B].cpu().numpy().astype(np.float64)
+        return a[:, 0] if self._B == 1 else a
+
+    @property
+    def noise(self):
+        a = self._noise[:, :self._B].cpu().numpy().astype(np.float64)
+        return a[:, 0] if self._B == 1 else a
+
+    @property
+    def firingrate_tensor(self):
+        """Device firing rates of the last update: float32 `[n, B_padded]`."""
+        return self._rates
+
+    # ---- the reference's per-step entry point (Neurons.py:145-171) ---------------------------
+    def update(self, **kwargs):
+        """firingrate = get_state() (+ OU noise when noise_std > 0); append t, rates and
+        Poisson spikes `U(0,1) < dt*rate` to the history.  kwargs: `spike_uniforms=`
+        `(n, B)` and `noise_normals=` `(n, B)` replace the in-kernel Philox draws."""
+        Ag = self.Agent
+        u = kwargs.pop("spike_uniforms", None)
+        zn = kwargs.pop("noise_normals", None)
+        save = bool(self.save_history)
+        need_noise = self.noise_std != 0
+        if save:
+            rates = self._hist_fr.reserve(1)
+            spikes = self._hist_sp.reserve(1) if self.save_spikes else None
+        else:
+            rates, spikes = self._rates.unsqueeze(0), None
+        u_t = None if u is None else self._as_rows(u, torch.float32).unsqueeze(0)
+        # spikes are drawn on the final rate: fuse them only when no noise is added afterwards
+        io_spikes = spikes if not need_noise else None
+        st = Ag._state
+        self._launch(st[_L.S_POS_X], st[_L.S_POS_Y], st[_L.S_HD_X], st[_L.S_HD_Y], pos_ld=self._Bp, T=1,
+                     B=self._Bp, rates=rates, spikes=io_spikes, u_in=u_t if not need_noise else None,
+                     dt=float(Ag.dt), step0=Ag._step_index, from_f64=True)
+        if need_noise:
+            tau = float(self.noise_coherence_time)
+            sigma = float(np.sqrt((2 * float(self.noise_std) ** 2) / (tau * Ag.dt)))
+            z_t = None if zn is None else self._as_rows(zn, torch.float32)
+            rc = _L.lib.riab_neuron_noise(_L.ptr(self._noise), _L.ptr(rates), _L.ptr(z_t), int(self.n), self._Bp,
+                                          float(Ag.dt / tau), float(sigma * Ag.dt), int(Ag.seed),
+                                          int(Ag._step_index), int(self.pop_id), int(Ag.agent_id0),
+                                          _L.current_stream())
+            _L.check(rc, "riab_neuron_noise")
+            if spikes is not None:
+                self._spike_pass(rates, spikes, u_t, float(Ag.dt), Ag._step_index)
+        self._rates = rates[0]
+        if save:
+            self._spikes_last = None if spikes is None else spikes[0]
+            self._times.append(Ag.t)
+
+    def _spike_pass(self, rates, spikes, u_t, dt, step0):
+        io = self._io(None, None, None, None, self._Bp, rates.shape[0], self._Bp, rates, spikes, u_t, dt, step0)
+        _L.check(_L.lib.riab_spikes(io, int(self.n), _L.current_stream()), "riab_spikes")
+
+    def _as_rows(self, x, dtype):
+        """array `(n, B)` -> device `[n, Bp]`."""
+        t = x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
+        t = t.to(self._device, dtype).reshape(int(self.n), -1)
+        if t.shape[1] != self._Bp:
+            pad = t[:, :1].expand(-1, self._Bp - t.shape[1])
+            t = torch.cat((t, pad), dim=1)
+        return t.contiguous()
+
+    # ---- evaluation at arbitrary positions (Neurons.py:943-949 etc.) ---------------------------
+    def get_state(self, evaluate_at="agent", **kwargs):
+        """Firing rates `(n, P)` float64 on the host (like the reference).  evaluate_at:
+        "agent" (current agent positions, P = n_agents), "all" (the environment's
+        discretised coordinates) or None with `pos=(P,2)` (+ `head_direction=(P,2)`)."""
+        return self.get_state_tensor(evaluate_at, **kwargs)[:, :self._last_P].cpu().numpy().astype(np.float64)
+
+    def get_state_tensor(self, evaluate_at="agent", **kwargs):
+        """As get_state but returns the device tensor float32 `[n, P_padded]`."""
+        Ag = self.Agent
+        if evaluate_at == "agent":
+            st = Ag._state
+            P = self._Bp
+            self._last_P = self._B
+            px, py, hx, hy = (st[_L.S_POS_X], st[_L.S_POS_Y], st[_L.S_HD_X], st[_L.S_HD_Y])
+            out = torch.empty((1, int(self.n), P), dtype=torch.float32, device=self._device)
+            self._launch(px, py, hx, hy, pos_ld=P, T=1, B=P, rates=out, spikes=None, u_in=None, dt=float(Ag.dt),
+                         step0=0, from_f64=True)
+            return out[0]
+        if evaluate_at == "all":
+            pos = Ag.Environment.flattened_discrete_coords
+        else:
+            pos = kwargs["pos"]
+        pos = np.asarray(pos, dtype=np.float64).reshape(-1, 2)
+        P = pos.shape[0]
+        Pp = _pad4(P)
+        self._last_P = P
+        buf = np.zeros((4, Pp), dtype=np.float32)
+        buf[0, :P], buf[1, :P] = pos[:, 0], pos[:, 1]
+        buf[0, P:], buf[1, P:] = pos[0, 0], pos[0, 1]
+        hd = kwargs.get("head_direction", kwargs.get("vel", None))
+        if hd is None:
+            buf[2], buf[3] = 1.0, 0.0  # the reference's default direction [1, 0]
+        else:
+            hd = np.asarray(hd, dtype=np.float64).reshape(-1, 2)
+            hd = np.broadcast_to(hd, (P, 2)) if hd.shape[0] == 1 else hd
+            buf[2, :P], buf[3, :P] = hd[:, 0], hd[:, 1]
+            buf[2, P:], buf[3, P:] = hd[0, 0], hd[0, 1]
+        d = torch.from_numpy(buf).to(self._device)
+        out = torch.empty((1, int(self.n), Pp), dtype=torch.float32, device=self._device)
+        self._launch(d[0], d[1], d[2], d[3], pos_ld=Pp, T=1, B=Pp, rates=out, spikes=None, u_in=None,
+                     dt=float(Ag.dt), step0=0, from_f64=False)
+        return out[0]
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def _io(self, px, py, hx, hy, pos_ld, T, B, rates, spikes, u_in, dt, step0):
+        io = _L.RiabRateIO()
+        io.pos_x = px.data_ptr() if px is not None else None
+        io.pos_y = py.data_ptr() if py is not None else None
+        io.hd_x = hx.data_ptr() if hx is not None else None
+        io.hd_y = hy.data_ptr() if hy is not None else None
+        io.pos_ld, io.T, io.B = int(pos_ld), int(T), int(B)
+        io.rates = rates.data_ptr()
+        io.spikes = spikes.data_ptr() if spikes is not None else None
+        io.u_in = u_in.data_ptr() if u_in is not None else None
+        io.dt = float(dt)
+        io.min_fr, io.max_fr = float(self.min_fr), float(self.max_fr)
+        io.seed = int(self.Agent.seed)
+        io.step0 = int(step0)
+        io.agent_id0 = int(self.Agent.agent_id0)
+        io.pop_id = int(self.pop_id)
+        return io
+
+    def _launch(self, px, py, hx, hy, pos_ld, T, B, rates, spikes, u_in, dt, step0, from_f64=False, stream=None):
+        """Run this population's rate kernel.  Positions are fp32 rows on device; the
+        agent state is float64, so `from_f64` first rounds the four rows to fp32."""
+        if from_f64:
+            f = torch.stack((px, py, hx, hy)).to(torch.float32)
+            px, py, hx, hy = f[0], f[1], f[2], f[3]
+            pos_ld = f.shape[1]
+        io = self._io(px, py, hx, hy, pos_ld, T, B, rates, spikes, u_in, dt, step0)
+        self._keep = (px, py, hx, hy, rates, spikes, u_in)
+        self._call(io, _L.current_stream() if stream is None else stream)
+
+    def _call(self, io, stream):
+        raise NotImplementedError("Neurons object needs a get_state() method")
+
+    def _tables(self, key_arrays, build):
+        """Device tables cached on the content of the host attributes they derive from."""
+        key = tuple(np.ascontiguousarray(a).tobytes() if isinstance(a, np.ndarray) else a for a in key_arrays)
+        hit = self._table_cache.get("t")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        tabs = build()
+        self._table_cache["t"] = (key, tabs)
+        return tabs
+
+    # ---- fused path hooks (called by Agent.simulate) ---------------------------------------------
+    def _reserve_rows(self, n_steps, ring):
+        n = int(self.n)
+        if self.noise_std != 0:
+            raise NotImplementedError("noise_std > 0 is supported by update(), not yet by the fused simulate() path")
+        if self.save_history:
+            return dict(fr=self._hist_fr.reserve(n_steps),
+                        sp=self._hist_sp.reserve(n_steps) if self.save_spikes else None, ring=None)
+        rows = min(n_steps, 2 * ring)
+        return dict(fr=torch.empty((rows, n, self._Bp), dtype=torch.float32, device=self._device), sp=None,
+                    ring=rows)
+
+    def _rates_from_trajectory(self, traj, out, t0, tc, step0, dt, stream):
+        """Rates (+ spikes) for trajectory rows `traj [tc, 8, Bp]`, written to rows
+        t0..t0+tc of the reserved output."""
+        Bp = self._Bp
+        if out["ring"] is None:
+            fr = out["fr"][t0:t0 + tc]
+            sp = None if out["sp"] is None else out["sp"][t0:t0 + tc]
+        else:
+            r0 = t0 % out["ring"]
+            if r0 + tc > out["ring"]:
+                r0 = 0
+            fr, sp = out["fr"][r0:r0 + tc], None
+            out["last"] = fr[tc - 1]
+        ld = _L.HIST_ROWS * Bp
+        hook = getattr(self.Agent, "_profile_hook", None)
+        if hook is not None:
+            hook(self, "begin", tc)
+        self._launch(traj[0, _L.H_POS_X], traj[0, _L.H_POS_Y], traj[0, _L.H_HD_X], traj[0, _L.H_HD_Y], pos_ld=ld,
+                     T=tc, B=Bp, rates=fr, spikes=sp, u_in=None, dt=dt, step0=step0 + 1, stream=stream)
+        if hook is not None:
+            hook(self, "end", tc)
+
+    def _finish_rows(self, out, n_steps, times):
+        if out["ring"] is None:
+            self._rates = out["fr"][n_steps - 1]
+            self._spikes_last = None if out["sp"] is None else out["sp"][n_steps - 1]
+            self._times.extend(times)
+        else:
+            self._rates = out["last"]
+
+    # ---- history ---------------------------------------------------------------------------------
+    def _materialise_history(self):
+        fr = self._hist_fr.stack()[:, :, :self._B].cpu().numpy()
+        sp = self._hist_sp.stack()[:, :, :self._B].cpu().numpy().astype(bool)
+        if len(sp) == 0:
+            sp = np.zeros((0,) + fr.shape[1:], dtype=bool)
+        if self._B == 1:
+            fr, sp = fr[:, :, 0], sp[:, :, 0]
+        return {"t": np.array(self._times, dtype=float), "firingrate": fr, "spikes": sp}
+
+    def get_history_arrays(self):
+        return dict(self.history.items())
+
+    def get_history_tensors(self):
+        """(firingrate float32 [T, n, Bp], spikes uint8 [T, n, Bp]) on device."""
+        return self._hist_fr.stack(), self._hist_sp.stack()
+
+    def reset_history(self):
+        self._hist_fr.reset()
+        self._hist_sp.reset()
+        self._times = []
+
+    def save_to_history(self):
+        raise NotImplementedError("history rows are written by the kernels; there is no host-side append")
+
+
+# ================================================================================================
+class PlaceCells(Neurons):
+    """Place cells: a function of the distance from the agent to each cell's centre
+    (reference Neurons.py:827-981).  descriptions: gaussian (default),
+    gaussian_threshold, diff_of_gaussians, top_hat, one_hot; wall geometries:
+    euclidean, line_of_sight, geodesic."""
+
+    default_params = {
+        "n": 10,
+        "name": "PlaceCells",
+        "description": "gaussian",
+        "widths": 0.20,
+        "place_cell_centres": None,
+        "wall_geometry": "geodesic",
+        "min_fr": 0,
+        "max_fr": 1,
+    }
+
+    def __init__(self, Agent, params={}):
+        self.Agent = Agent
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        pcc = self.params["place_cell_centres"]
+        if pcc is None:
+            self.params["place_cell_centres"] = Agent.Environment.sample_positions(
+                n=self.params["n"], method="uniform_jitter")
+        elif isinstance(pcc, str):
+            if pcc not in ("random", "uniform", "uniform_jitter"):
+                raise ValueError("self.params['place_cell_centres'] must be None, an array of locations or one of "
+                                 "the instructions ['random', 'uniform', 'uniform_jitter']")
+            self.params["place_cell_centres"] = Agent.Environment.sample_positions(n=self.params["n"], method=pcc)
+        else:
+            self.params["place_cell_centres"] = np.asarray(pcc, dtype=float)
+            self.params["n"] = self.params["place_cell_centres"].shape[0]
+        self.place_cell_widths = self.params["widths"] * np.ones(self.params["n"])
+        super().__init__(Agent, self.params)
+
+        Env = Agent.Environment
+        if self.wall_geometry in ("line_of_sight", "geodesic") and Env.boundary_conditions == "periodic":
+            print(f"{self.wall_geometry} wall geometry only possible in 2D when the boundary conditions are solid. "
+                  "Using 'euclidean' instead.")
+            self.wall_geometry = "euclidean"
+        if self.wall_geometry == "geodesic" and len(Env.walls) > 5:
+            print("'geodesic' wall geometry only supported for enivironments with 1 additional wall (4 bounding "
+                  "walls + 1 additional). Sorry. Using 'line_of_sight' instead.")
+            self.wall_geometry = "line_of_sight"
+
+    def _call(self, io, stream):
+        n = int(self.n)
+        centres = np.asarray(self.place_cell_centres, dtype=np.float64).reshape(-1, 2)
+        widths = np.asarray(self.place_cell_widths, dtype=np.float64) * np.ones(n)
+
+        def build():
+            tab = np.empty((3, n), dtype=np.float64)
+            tab[0], tab[1] = centres[:, 0], centres[:, 1]
+            tab[2] = -LOG2E / (2 * widths ** 2)
+            return torch.from_numpy(tab.astype(np.float32)).to(self._device)
+
+        tab = self._tables((centres, widths), build)
+        env, _w = self.Agent.Environment.device_tables(self._device)
+        geom = self.wall_geometry
+        if geom == "geodesic" and len(self.Agent.Environment.walls) <= 4:
+            geom = "euclidean"  # Environment.py:741-742
+        rc = _L.lib.riab_place_cells(env, io, _L.ptr(tab), n, _L.PC_DESCRIPTIONS[self.description],
+                                     _L.GEOMETRIES[geom], float(np.asarray(self.widths, dtype=float).reshape(-1)[0]), stream)
+        _L.check(rc, "riab_place_cells")
+
+    def remap(self):
+        self.place_cell_centres = self.Agent.Environment.sample_positions(n=self.n, method="uniform_jitter")
+        np.random.shuffle(self.place_cell_centres)
+
+
+# ================================================================================================
+class GridCells(Neurons):
+    """Grid cells: rectified or shifted sum of three cosines 60 degrees apart
+    (reference Neurons.py:1033-1256)."""
+
+    default_params = {
+        "n": 30,
+        "gridscale_distribution": "modules",
+        "gridscale": (0.3, 0.5, 0.8),
+        "orientation_distribution": "modules",
+        "orientation": (0, 0.1, 0.2),
+        "phase_offset_distribution": "uniform",
+        "phase_offset": (0, 2 * np.pi),
+        "description": "rectified_cosines",
+        "width_ratio": 4 / (3 * np.sqrt(3)),
+        "min_fr": 0,
+        "max_fr": 1,
+        "name": "GridCells",
+    }
+
+    def __init__(self, Agent, params={}):
+        self.Agent = Agent
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        p = self.params
+        if p["description"] in ("three_rectified_cosines", "three_shifted_cosines"):
+            p["description"] = p["description"][6:]
+            warnings.warn(f"the 'three_' prefix on the 'description' parameter is deprecated, in the future please "
+                          f"use '{p['description']}' instead")
+        if isinstance(p["gridscale"], (list, np.ndarray)):
+            self.gridscales = np.array(p["gridscale"])
+            p["n"] = len(self.gridscales)
+        else:
+            self.gridscales = utils.distribution_sampler(p["gridscale_distribution"], p["gridscale"], shape=(p["n"],))
+        super().__init__(Agent, p)
+        if isinstance(p["phase_offset"], (list, np.ndarray)) and np.array(p["phase_offset"]).ndim == 2:
+            self.phase_offsets = np.array(p["phase_offset"])
+            assert len(self.phase_offsets) == p["n"], "number of phase offsets supplied incompatible with number of neurons"
+        else:
+            self.phase_offsets = utils.distribution_sampler(p["phase_offset_distribution"], p["phase_offset"],
+                                                            shape=(p["n"], 2))
+        if isinstance(p["orientation"], (list, np.ndarray)):
+            self.orientations = np.array(p["orientation"])
+            assert len(self.orientations) == p["n"], "number of orientations supplied incompatible with number of neurons"
+        else:
+            self.orientations = utils.distribution_sampler(p["orientation_distribution"], p["orientation"],
+                                                           shape=(p["n"],))
+        w = []
+        for i in range(self.n):
+            w1 = utils.rotate(np.array([1, 0]), self.orientations[i])
+            w.append(np.array([w1, utils.rotate(w1, np.pi / 3), utils.rotate(w1, 2 * np.pi / 3)]))
+        self.w = np.array(w)
+        if self.description == "rectified_cosines":
+            assert 0 < self.width_ratio <= 1, "width_ratio must be between 0 and 1"
+
+    def _call(self, io, stream):
+        n = int(self.n)
+        gs = np.asarray(self.gridscales, dtype=np.float64)
+        ph = np.asarray(self.phase_offsets, dtype=np.float64)
+        w = np.asarray(self.w, dtype=np.float64)
+
+        def build():
+            # phase_i / 2pi = (origin - p) . w_i / lambda = a_i - (x bx_i + y by_i)   (Neurons.py:1192-1203)
+            origin = gs.reshape(-1, 1) * ph / (2 * np.pi)
+            tab = np.empty((9, n), dtype=np.float64)
+            for i in range(3):
+                a = (origin[:, 0] * w[:, i, 0] + origin[:, 1] * w[:, i, 1]) / gs
+                tab[3 * i] = a - np.floor(a)
+                tab[3 * i + 1] = w[:, i, 0] / gs
+                tab[3 * i + 2] = w[:, i, 1] / gs
+            return torch.from_numpy(tab.astype(np.float32)).to(self._device)
+
+        tab = self._tables((gs, ph, w), build)
+        f0 = (1 / 3) * (2 * np.cos(np.sqrt(3) * np.pi * self.width_ratio / 2) + 1)
+        rc = _L.lib.riab_grid_cells(io, _L.ptr(tab), n, _L.GC_DESCRIPTIONS[self.description], float(f0), stream)
+        _L.check(rc, "riab_grid_cells")
+
+
+# ================================================================================================
+class VectorCells(Neurons):
+    """Base of the vector-cell family: preferred distance / angle tuning per cell
+    (reference Neurons.py:1259-1437).  Only BoundaryVectorCells is accelerated."""
+
+    default_params = {
+        "n": 10,
+        "reference_frame": "allocentric",
+        "cell_arrangement": "random",
+        "tuning_distance_distribution": "uniform",
+        "tuning_distance": (0.05, 0.3),
+        "sigma_distance_distribution": "diverging",
+        "sigma_distance": (0.08, 12),
+        "tuning_angle_distribution": "uniform",
+        "tuning_angle": (0.0, 360),
+        "angular_spread_distribution": "uniform",
+        "angular_spread": (10, 30),
+    }
+
+    def __init__(self, Agent, params={}):
+        if type(self) is VectorCells:
+            raise RuntimeError("Cannot instantiate VectorCells on their own. Must be instantiated through one of the "
+                               "subclasses, e.g. BoundaryVectorCells")
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        super().__init__(Agent, self.params)
+        arr = self.cell_arrangement
+        if callable(arr):
+            mu_d, mu_t, sg_d, sg_t = arr(**self.params)
+        elif arr is None or arr[:6] == "random":
+            mu_d, mu_t, sg_d, sg_t = utils.create_random_assembly(**self.params)
+        else:
+            raise NotImplementedError("radial field-of-view manifolds are outside the accelerated path (SURVEY §8f)")
+        self.tuning_distances, self.tuning_angles = np.array(mu_d), np.array(mu_t)
+        self.sigma_distances, self.sigma_angles = np.array(sg_d), np.array(sg_t)
+        assert len(self.tuning_distances) == len(self.tuning_angles) == len(self.sigma_distances) == len(
+            self.sigma_angles), "All manifold tuning parameters must be of the same length"
+        if "n" in params and params["n"] is not None and params["n"] != len(self.tuning_distances):
+            warnings.warn(f"Ignoring 'n' parameter value ({params['n']}) that was passed, and setting number of "
+                          f"{self.name} neurons to {len(self.tuning_distances)}, inferred from the cell arrangement.")
+        self.n = len(self.tuning_distances)
+        self._alloc_state()
+
+
+class BoundaryVectorCells(VectorCells):
+    """Boundary vector cells (reference Neurons.py:1535-1778): for each of K test
+    directions the distance to the first wall, weighted by a gaussian in distance and
+    a von Mises in angle, summed over directions and normalised analytically."""
+
+    default_params = {
+        "n": 10,
+        "name": "BoundaryVectorCells",
+        "dtheta": 2,
+        "max_fr": 1.0,
+        "min_fr": 0.0,
+    }
+
+    def __init__(self, Agent, params={}):
+        self.Agent = Agent
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        super().__init__(Agent, self.params)
+        assert self.Agent.Environment.boundary_conditions == "solid", \
+            "boundary cells only possible with solid boundary conditions"
+        # K = int(360/dtheta) angles [0] + [2 pi i dtheta / 360, i = 0..K-2]: 0 is duplicated and the last
+        # angle missing, as in the reference (Neurons.py:1584-1596)
+        self.n_test_angles = int(360 / self.dtheta)
+        angles = [0.0] + [2 * np.pi * i * self.dtheta / 360 for i in range(self.n_test_angles - 1)]
+        self.test_angles = np.array(angles)
+        self.test_directions = np.array([utils.rotate(np.array([1, 0]), a) for a in angles])
+        self.test_directions[0] = np.array([1.0, 0.0])
+        kappa = 1 / np.asarray(self.sigma_angles, dtype=float).reshape(-1, 1) ** 2
+        self.cell_fr_norm = np.exp(kappa * (np.cos(self.test_angles.reshape(1, -1)) - 1)).sum(axis=1)
+
+    def _call(self, io, stream):
+        n, K = int(self.n), int(self.n_test_angles)
+        mu_d = np.asarray(self.tuning_distances, dtype=np.float64)
+        sg_d = np.asarray(self.sigma_distances, dtype=np.float64)
+        mu_t = np.asarray(self.tuning_angles, dtype=np.float64)
+        sg_t = np.asarray(self.sigma_angles, dtype=np.float64)
+        ang = np.asarray(self.test_angles, dtype=np.float64)
+        dirs = np.asarray(self.test_directions, dtype=np.float64)
+        norm = np.asarray(self.cell_fr_norm, dtype=np.float64)
+        ego = self.reference_frame == "egocentric"
+
+        def build():
+            a = np.sqrt(LOG2E / 2) / sg_d
+            kappa = 1 / sg_t ** 2
+            cells = np.zeros((4, n))
+            cells[0], cells[1], cells[2] = a * mu_d, a, kappa * LOG2E
+            diff = ang[None, :] - mu_t[:, None]
+            if ego:
+                vm = np.stack((np.cos(diff), np.sin(diff)))
+            else:
+                vm = LOG2E * kappa[:, None] * (np.cos(diff) - 1)
+            f32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self._device)  # noqa: E731
+            return (torch.from_numpy(np.ascontiguousarray(dirs)).to(self._device), f32(cells), f32(vm), f32(1 / norm))
+
+        dirs_t, cells_t, vm_t, inv_t = self._tables((mu_d, sg_d, mu_t, sg_t, ang, dirs, norm, ego), build)
+        env, _w = self.Agent.Environment.device_tables(self._device)
+        rc = _L.lib.riab_boundary_vector_cells(env, io, _L.ptr(dirs_t), K, _L.ptr(cells_t), _L.ptr(vm_t),
+                                               _L.ptr(inv_t), n, 1 if ego else 0, None, stream)
+        _L.check(rc, "riab_boundary_vector_cells")
+
+
+# ================================================================================================
+class HeadDirectionCells(Neurons):
+    """Head direction cells: von Mises tuning to the agent's head direction
+    (reference Neurons.py:2357-2485)."""
+
+    default_params = {
+        "min_fr": 0,
+        "max_fr": 1,
+        "n": 10,
+        "angular_spread_degrees": 45,
+        "name": "HeadDirectionCells",
+    }
+
+    def __init__(self, Agent, params={}):
+        self.Agent = Agent
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        self.n = self.params["n"]
+        self.preferred_angles = np.linspace(0, 2 * np.pi, self.n + 1)[:-1]
+        self.angular_tunings = np.array([self.params["angular_spread_degrees"] * np.pi / 180] * self.n)
+        super().__init__(Agent, self.params)
+
+    def _call(self, io, stream):
+        n = int(self.n)
+        pref = np.asarray(self.preferred_angles, dtype=np.float64)
+        sig = np.asarray(self.angular_tunings, dtype=np.float64)
+
+        def build():
+            f32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self._device)  # noqa: E731
+            return f32(pref), f32(LOG2E / sig ** 2)
+
+        pref_t, k2_t = self._tables((pref, sig), build)
+        rc = _L.lib.riab_head_direction_cells(io, _L.ptr(pref_t), _L.ptr(k2_t), n, stream)
+        _L.check(rc, "riab_head_direction_cells")

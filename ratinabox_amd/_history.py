@@ -1,0 +1,94 @@
+"""Device-resident history buffers.
+
+The reference appends Python lists per step (Agent.py:509-521, Neurons.py:681-687).
+Here a history is a list of preallocated device chunks `[T_chunk, rows..., B]`
+the kernels write in place; `stack()` returns the filled part as one tensor and
+host copies are made only on demand (`get_history_arrays`, `history[...]`)."""
+import torch
+
+
+class DeviceHistory:
+    def __init__(self, row_shape, dtype, device, chunk_bytes=1 << 30):
+        self.row_shape = tuple(int(x) for x in row_shape)
+        self.dtype = dtype
+        self.device = device
+        row_elems = 1
+        for x in self.row_shape:
+            row_elems *= x
+        self.row_bytes = max(1, row_elems * torch.empty((), dtype=dtype).element_size())
+        self.chunk_rows = int(max(1, min(4096, chunk_bytes // self.row_bytes)))
+        self.chunks = []   # tensors [rows, *row_shape]
+        self.filled = []   # rows used per chunk
+        self.version = 0
+
+    def __len__(self):
+        return sum(self.filled)
+
+    def reserve(self, T):
+        """A writable view `[T, *row_shape]` of fresh rows (contiguous).  A request
+        that does not fit the current chunk's free tail opens a new chunk of
+        exactly max(T, chunk_rows) rows."""
+        T = int(T)
+        self.version += 1
+        if self.chunks and self.chunks[-1].shape[0] - self.filled[-1] >= T:
+            s = self.filled[-1]
+            self.filled[-1] += T
+            return self.chunks[-1][s:s + T]
+        rows = max(T, self.chunk_rows) if T == 1 else T
+        self.chunks.append(torch.empty((rows, *self.row_shape), dtype=self.dtype, device=self.device))
+        self.filled.append(T)
+        return self.chunks[-1][:T]
+
+    def stack(self):
+        """All filled rows as one tensor `[T_total, *row_shape]`."""
+        parts = [c[:f] for c, f in zip(self.chunks, self.filled) if f]
+        if not parts:
+            return torch.empty((0, *self.row_shape), dtype=self.dtype, device=self.device)
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+
+    def last(self):
+        for c, f in zip(reversed(self.chunks), reversed(self.filled)):
+            if f:
+                return c[f - 1]
+        return None
+
+    def reset(self):
+        self.chunks, self.filled = [], []
+        self.version += 1
+
+
+class HistoryView:
+    """Read-only mapping over lazily materialised history arrays, cached until
+    the owner steps again.  `view[key]` is a NumPy array (time first)."""
+
+    def __init__(self, keys, materialise, version):
+        self._keys = tuple(keys)
+        self._materialise = materialise
+        self._version = version
+        self._cache = None
+        self._cache_version = None
+
+    def _get(self):
+        v = self._version()
+        if self._cache is None or self._cache_version != v:
+            self._cache = self._materialise()
+            self._cache_version = v
+        return self._cache
+
+    def __getitem__(self, key):
+        return self._get()[key]
+
+    def keys(self):
+        return self._keys
+
+    def items(self):
+        return self._get().items()
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def __contains__(self, key):
+        return key in self._keys
+
+    def __len__(self):
+        return len(self._keys)

@@ -1,0 +1,111 @@
+"""ctypes binding of libriab_hip.so (include/riab_hip.h).
+
+The library is the product's only compute path.  If it is missing it is built
+with hipcc; if that fails, importing this module RAISES — there is no CPU
+fallback (the CPU restatement under oracle/ is test infrastructure only)."""
+import ctypes as C
+import os
+
+from . import _build
+
+ABI_VERSION = 1
+MAX_WALLS = 64
+STATE_ROWS = 12
+HIST_ROWS = 8
+
+# row indices (mirror the enums in riab_hip.h)
+S_POS_X, S_POS_Y, S_VEL_X, S_VEL_Y, S_ROT_VEL, S_MVEL_X, S_MVEL_Y, S_MROT_VEL, S_HD_X, S_HD_Y, S_DIST, S_DWALL = range(12)
+H_POS_X, H_POS_Y, H_VEL_X, H_VEL_Y, H_HD_X, H_HD_Y, H_ROT_VEL, H_DIST = range(8)
+
+PC_DESCRIPTIONS = {"gaussian": 0, "gaussian_threshold": 1, "diff_of_gaussians": 2, "one_hot": 3, "top_hat": 4}
+GEOMETRIES = {"euclidean": 0, "line_of_sight": 1, "geodesic": 2}
+GC_DESCRIPTIONS = {"rectified_cosines": 0, "shifted_cosines": 1}
+
+
+class RiabEnv(C.Structure):
+    _fields_ = [("extent", C.c_double * 4), ("scale", C.c_double), ("periodic", C.c_int32),
+                ("n_walls", C.c_int32), ("walls", C.c_void_p)]
+
+
+class RiabMotion(C.Structure):
+    _fields_ = [("dt", C.c_double), ("rot_theta_kw", C.c_double), ("rot_sigma_kw", C.c_double),
+                ("rot_drift_kw", C.c_double), ("speed_theta_kw", C.c_double), ("speed_sigma_kw", C.c_double),
+                ("speed_mean_kw", C.c_double), ("speed_mean", C.c_double), ("speed_std_is_zero", C.c_int32),
+                ("has_drift", C.c_int32), ("drift_theta", C.c_double), ("wall_repel_strength_kw", C.c_double),
+                ("wall_repel_distance_kw", C.c_double), ("thigmotaxis_kw", C.c_double), ("hd_tau", C.c_double)]
+
+
+class RiabRateIO(C.Structure):
+    _fields_ = [("pos_x", C.c_void_p), ("pos_y", C.c_void_p), ("hd_x", C.c_void_p), ("hd_y", C.c_void_p),
+                ("pos_ld", C.c_int64), ("T", C.c_int64), ("B", C.c_int64), ("rates", C.c_void_p),
+                ("spikes", C.c_void_p), ("u_in", C.c_void_p), ("dt", C.c_float), ("min_fr", C.c_float),
+                ("max_fr", C.c_float), ("seed", C.c_uint64), ("step0", C.c_uint64), ("agent_id0", C.c_int64),
+                ("pop_id", C.c_int32)]
+
+
+# name -> (restype, argtypes): every symbol include/riab_hip.h declares
+PROTOTYPES = {
+    "riab_agent_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "riab_place_cells": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_float, C.c_void_p]),
+    "riab_grid_cells": (C.c_int, [C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "riab_head_direction_cells": (C.c_int, [C.POINTER(RiabRateIO), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "riab_boundary_vector_cells": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_int32,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                             C.c_void_p]),
+    "riab_spikes": (C.c_int, [C.POINTER(RiabRateIO), C.c_int32, C.c_void_p]),
+    "riab_neuron_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_float,
+                                    C.c_uint64, C.c_uint64, C.c_int32, C.c_int64, C.c_void_p]),
+    "riab_fill": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "riab_abi_version": (C.c_int, []),
+    "riab_strerror": (C.c_char_p, [C.c_int]),
+}
+
+
+class RiabError(RuntimeError):
+    pass
+
+
+def _load():
+    path = _build.LIB_PATH
+    if _build.is_stale():
+        try:
+            path = _build.build()
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(path):
+                raise ImportError(
+                    "ratinabox_amd: libriab_hip.so is missing and could not be built with hipcc "
+                    f"({e}). There is no CPU fallback; build it with `python -m ratinabox_amd._build`.") from e
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.riab_abi_version() != ABI_VERSION:
+        raise ImportError(f"libriab_hip.so ABI {lib.riab_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    return lib, path
+
+
+lib, LIB_PATH = _load()
+
+
+def strerror(code):
+    return lib.riab_strerror(int(code)).decode()
+
+
+def check(code, what):
+    """Raise on a non-zero return code of an ABI call."""
+    if code != 0:
+        raise RiabError(f"{what} failed with code {code}: {strerror(code)}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

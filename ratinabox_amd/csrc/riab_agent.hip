@@ -1,0 +1,398 @@
+// Agent.update() for B independent agents, T steps fused in one launch (gfx950).
+//
+// One lane = one agent; the whole recurrent state (12 values) lives in VGPRs for
+// the T steps, wall segments are staged once per workgroup in LDS (broadcast
+// reads: every lane walks the same wall list), the per-step output is one
+// coalesced row per history field.  The kernel is a latency-bound recurrence
+// (64 waves at B = 4096), not a bandwidth kernel: per step it moves 8 floats per
+// agent.  It runs on its own stream underneath the firing-rate kernels of the
+// previous chunk (see ratinabox_amd/Agent.py: simulate()).
+//
+// Arithmetic is templated on the real type R: R = double reproduces the
+// reference's float64 NumPy path to ~1e-12 per step, including the discrete
+// decisions (collision yes/no, which wall, boundary clamp); R = float is the
+// throughput variant.
+#include "riab_device.h"
+
+namespace riab {
+
+struct AgentArgs {
+  RiabMotion m;
+  double e0, e1, e2, e3;  // extent
+  double scale;
+  int periodic;
+  int n_walls;
+  const double* walls;  // device [n_walls][4]
+  double* state;        // [12][B]
+  int64_t B;
+  int64_t agent_id0;
+  const double* drift;  // [2][B] or null
+  const double* z_in;   // [T][2][B] or null
+  double* z_out;        // [T][2][B] or null
+  uint32_t k0, k1;
+  uint64_t step0;
+  int T;
+  float* hist;  // [T][8][B] or null
+  int* diag;
+};
+
+// ---- math wrappers ---------------------------------------------------------------------------
+__device__ __forceinline__ double r_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float r_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double r_exp(double x) { return exp(x); }
+__device__ __forceinline__ float r_exp(float x) { return expf(x); }
+__device__ __forceinline__ double r_log(double x) { return log(x); }
+__device__ __forceinline__ float r_log(float x) { return logf(x); }
+__device__ __forceinline__ double r_atan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float r_atan2(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ void r_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+__device__ __forceinline__ void r_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+__device__ __forceinline__ double r_ndtri(double u) { return normcdfinv(u); }
+__device__ __forceinline__ float r_ndtri(float u) { return normcdfinvf(u); }
+__device__ __forceinline__ double r_ndtr(double x) { return normcdf(x); }
+__device__ __forceinline__ float r_ndtr(float x) { return normcdff(x); }
+
+// np.mod(a, 2pi) for a in (-2pi, 2pi)
+template <class R>
+__device__ __forceinline__ R mod_2pi(R a) {
+  const R two_pi = (R)6.283185307179586476925286766559;
+  R r = a;
+  if (r >= two_pi) r -= two_pi;
+  if (r < (R)0) r += two_pi;
+  return r;
+}
+
+// utils.get_angle (reference utils.py:258-260): atan2(y, x + 1e-6) mod 2pi
+template <class R>
+__device__ __forceinline__ R get_angle(R x, R y) {
+  return mod_2pi(r_atan2(y, x + (R)1e-6));
+}
+
+template <class R>
+struct Wall {  // staged in LDS
+  R ax, ay, sx, sy;  // start point and direction (b - a)
+  R inv_ss;          // 1 / |s|^2
+  R inv_len;         // 1 / |s|
+};
+
+template <class R>
+__global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
+  __shared__ Wall<R> s_w[RIAB_MAX_WALLS];
+  for (int w = threadIdx.x; w < a.n_walls; w += 64) {
+    const double ax = a.walls[4 * w], ay = a.walls[4 * w + 1], bx = a.walls[4 * w + 2], by = a.walls[4 * w + 3];
+    const double sx = bx - ax, sy = by - ay;
+    const double ss = sx * sx + sy * sy;
+    s_w[w].ax = (R)ax;
+    s_w[w].ay = (R)ay;
+    s_w[w].sx = (R)sx;
+    s_w[w].sy = (R)sy;
+    s_w[w].inv_ss = (R)(1.0 / ss);
+    s_w[w].inv_len = (R)(1.0 / sqrt(ss));
+  }
+  __syncthreads();
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  const RiabMotion& m = a.m;
+  const int nw = a.n_walls;
+  const R dt = (R)m.dt;
+
+  double* st = a.state + b;
+  const int64_t B = a.B;
+  R px = (R)st[0 * B], py = (R)st[1 * B];
+  R vx = (R)st[2 * B], vy = (R)st[3 * B];
+  R rot = (R)st[4 * B];
+  R mvx = (R)st[5 * B], mvy = (R)st[6 * B];
+  R mrot = (R)st[7 * B];
+  R hx = (R)st[8 * B], hy = (R)st[9 * B];
+  R dist = (R)st[10 * B];
+  R dwall = (R)st[11 * B];
+
+  R drx = 0, dry = 0;
+  if (m.has_drift) {
+    drx = (R)a.drift[b];
+    dry = (R)a.drift[B + b];
+  }
+  // angle of the previous measured velocity: computed once, then carried (the reference
+  // recomputes get_angle(prev_measured_velocity) every step, Agent.py:466)
+  R ang_prev = get_angle(mvx, mvy);
+
+  int n_bounce = 0, n_sat = 0, n_bc = 0, n_still = 0;
+  const uint32_t aid = (uint32_t)(a.agent_id0 + b);
+
+  // constants of the step
+  const R sm_kw = (R)m.speed_mean_kw, sm = (R)m.speed_mean;
+  const R inv_2s2 = (R)1 / ((R)2 * sm_kw * sm_kw);
+  const R wd = (R)m.wall_repel_distance_kw;
+  const R v0 = (R)m.wall_repel_strength_kw * sm;
+  const R kspring = (v0 * v0) / (wd * wd);
+  const R g = (R)m.thigmotaxis_kw;
+  const R cvel = (R)3 * (((R)1 - g) * ((R)1 - g));
+  const R cpos = (R)6 * (g * g);
+  const bool repel = (m.wall_repel_strength_kw != 0.0) && nw > 0;
+  const R e0 = (R)a.e0, e1 = (R)a.e1, e2 = (R)a.e2, e3 = (R)a.e3;
+
+  for (int t = 0; t < a.T; ++t) {
+    // ---- the step's standard normals -------------------------------------------------------
+    R z_rot, z_spd, z_s0 = 0, z_s1 = 0;
+    if (a.z_in) {
+      z_rot = (R)a.z_in[((int64_t)t * 2 + 0) * B + b];
+      z_spd = (R)a.z_in[((int64_t)t * 2 + 1) * B + b];
+    } else {
+      const uint64_t step = a.step0 + (uint64_t)t;
+      const u32x4 w = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), aid, RIAB_TAG_MOTION, a.k0, a.k1);
+      // Box-Muller in float64 (oracle: motion_normals)
+      const double u1 = ((double)w.x + 0.5) * 0x1.0p-32, u2 = ((double)w.y + 0.5) * 0x1.0p-32;
+      const double rr = sqrt(-2.0 * log(u1));
+      double sn, cs;
+      sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+      z_rot = (R)(rr * cs);
+      z_spd = (R)(rr * sn);
+      const double u3 = ((double)w.z + 0.5) * 0x1.0p-32, u4 = ((double)w.w + 0.5) * 0x1.0p-32;
+      const double r2 = sqrt(-2.0 * log(u3));
+      sincos(6.283185307179586476925286766559 * u4, &sn, &cs);
+      z_s0 = (R)(r2 * cs);
+      z_s1 = (R)(r2 * sn);
+    }
+    if (a.z_out) {
+      a.z_out[((int64_t)t * 2 + 0) * B + b] = (double)z_rot;
+      a.z_out[((int64_t)t * 2 + 1) * B + b] = (double)z_spd;
+    }
+    const R ppx = px, ppy = py;  // prev_pos (Agent.py:199)
+
+    // ---- _stochastic_velocity_update (Agent.py:287-312) -----------------------------------
+    rot += (R)m.rot_theta_kw * ((R)m.rot_drift_kw - rot) * dt + (R)m.rot_sigma_kw * (dt * z_rot);
+    {
+      R sn, cs;
+      r_sincos(rot * dt, &sn, &cs);
+      const R nx = cs * vx + (-sn) * vy;
+      const R ny = sn * vx + cs * vy;
+      vx = nx;
+      vy = ny;
+    }
+    R speed = r_sqrt(vx * vx + vy * vy);
+    if (speed == (R)0) {
+      vx = (R)1e-8;
+      vy = (R)0;
+      speed = (R)1e-8;
+    }
+    {
+      // utils.rayleigh_to_normal / normal_to_rayleigh (utils.py:409-421), sigma = speed_mean
+      R u = (R)1 - r_exp(-(speed * speed) * inv_2s2);
+      u = (u < (R)1e-6) ? (R)1e-6 : u;
+      u = (u > (R)(1 - 1e-6)) ? (R)(1 - 1e-6) : u;
+      R nv = r_ndtri(u);
+      nv += (R)m.speed_theta_kw * ((R)0 - nv) * dt + (R)m.speed_sigma_kw * (dt * z_spd);
+      const R x = r_ndtr(nv);
+      R speed_new = sm_kw * r_sqrt((R)-2 * r_log((R)1 - x));
+      if (m.speed_std_is_zero) speed_new = sm_kw;
+      const R f = speed_new / speed;
+      vx *= f;
+      vy *= f;
+    }
+    // ---- _drift_velocity_update (Agent.py:331-341) ----------------------------------------
+    if (m.has_drift) {
+      vx += (R)m.drift_theta * (drx - vx) * dt;
+      vy += (R)m.drift_theta * (dry - vy) * dt;
+    }
+    // ---- _wall_velocity_update (Agent.py:357-415, utils.py:121-184) -----------------------
+    if (repel) {
+      R ax_ = 0, ay_ = 0, sx_ = 0, sy_ = 0, dmin = INFINITY;
+      for (int w = 0; w < nw; ++w) {
+        const Wall<R> W = s_w[w];
+        const R dxw = px - W.ax, dyw = py - W.ay;
+        R l = (dxw * W.sx + dyw * W.sy) * W.inv_ss;
+        l = (l > (R)1) ? (R)1 : l;
+        l = (l < (R)0) ? (R)0 : l;
+        const R qx = px - (W.ax + l * W.sx), qy = py - (W.ay + l * W.sy);
+        const R x = r_sqrt(qx * qx + qy * qy);
+        dmin = (x < dmin) ? x : dmin;
+        if (x <= wd) {
+          const R ix = (R)1 / x;
+          const R nx = qx * ix, ny = qy * ix;
+          const R acc = kspring * (wd - x);
+          const R spd = v0 * ((R)1 - r_sqrt((R)1 - ((wd - x) * (wd - x)) / (wd * wd)));
+          ax_ += acc * nx;
+          ay_ += acc * ny;
+          sx_ += spd * nx;
+          sy_ += spd * ny;
+        }
+      }
+      dwall = dmin;
+      vx += cvel * (ax_ * dt);
+      vy += cvel * (ay_ * dt);
+      px += cpos * (sx_ * dt);
+      py += cpos * (sy_ * dt);
+    }
+    // ---- propose (Agent.py:216) -----------------------------------------------------------
+    px += vx * dt;
+    py += vy * dt;
+    // ---- _check_and_handle_wall_collisions (Agent.py:426-441, utils.py:74-106, 304-328) ---
+    if (nw > 0) {
+      int it = 0;
+      for (; it < RIAB_MAX_BOUNCES; ++it) {
+        const R sbx = px - ppx, sby = py - ppy;  // the step (list b), walls are list a
+        int hit = -1;
+        for (int w = 0; w < nw; ++w) {
+          const Wall<R> W = s_w[w];
+          const R d0x = ppx - W.ax, d0y = ppy - W.ay;
+          const R den_a = W.sx * (-sby) + W.sy * sbx;
+          const R num_a = d0x * (-sby) + d0y * sbx;
+          const R den_b = sbx * (-W.sy) + sby * W.sx;
+          const R num_b = (-d0x) * (-W.sy) + (-d0y) * W.sx;
+          // 0 < num/den < 1 by sign logic (den == 0: +-inf / NaN in NumPy -> no hit)
+          const bool ia = (den_a > 0) ? (num_a > 0 && num_a < den_a) : (den_a < 0 ? (num_a < 0 && num_a > den_a) : false);
+          const bool ib = (den_b > 0) ? (num_b > 0 && num_b < den_b) : (den_b < 0 ? (num_b < 0 && num_b > den_b) : false);
+          if (ia && ib && hit < 0) hit = w;  // first colliding wall = lowest index
+        }
+        if (hit < 0) break;
+        const Wall<R> W = s_w[hit];
+        // utils.wall_bounce
+        R parx = W.sx * W.inv_len, pary = W.sy * W.inv_len;
+        R perx = -W.sy * W.inv_len, pery = W.sx * W.inv_len;
+        if ((-W.sy) * vx + W.sx * vy <= (R)0) {
+          perx = -perx;
+          pery = -pery;
+        }
+        if (W.sx * vx + W.sy * vy <= (R)0) {
+          parx = -parx;
+          pary = -pary;
+        }
+        const R vpar = vx * parx + vy * pary, vper = vx * perx + vy * pery;
+        R nvx = parx * vpar - perx * vper, nvy = pary * vpar - pery * vper;
+        const R f = ((R)0.5 * sm) / r_sqrt(nvx * nvx + nvy * nvy);
+        vx = f * nvx;
+        vy = f * nvy;
+        px = ppx + vx * dt;
+        py = ppy + vy * dt;
+        ++n_bounce;
+      }
+      if (it == RIAB_MAX_BOUNCES) ++n_sat;
+    }
+    // ---- boundary safety net (Agent.py:221-222, Environment.py:781-894) -------------------
+    if (!(px > e0 && px < e1 && py > e2 && py < e3)) {
+      ++n_bc;
+      if (a.periodic) {
+        px = px - e1 * floor(px / e1);  // np.mod(pos, extent)
+        py = py - e3 * floor(py / e3);
+      } else {
+        const R lo_x = e0 + (R)0.01, hi_x = e1 - (R)0.01, lo_y = e2 + (R)0.01, hi_y = e3 - (R)0.01;
+        px = (lo_x > px) ? lo_x : px;  // python max(pos, lo): NaN stays NaN
+        px = (hi_x < px) ? hi_x : px;
+        py = (lo_y > py) ? lo_y : py;
+        py = (hi_y < py) ? hi_y : py;
+      }
+    }
+    // ---- _measure_velocity_of_step_taken (Agent.py:456-471) -------------------------------
+    R dpx = px - ppx, dpy = py - ppy;
+    if (a.periodic) {
+      const R sc = (R)a.scale, hs = (R)(a.scale / 2);
+      if (fabs(dpx) > hs) dpx = -copysign(sc - fabs(dpx), dpx);
+      if (fabs(dpy) > hs) dpy = -copysign(sc - fabs(dpy), dpy);
+    }
+    mvx = dpx / dt;
+    mvy = dpy / dt;
+    R mvn = r_sqrt(mvx * mvx + mvy * mvy);
+    if (mvn == (R)0) {
+      mvx = (R)1e-8 * z_s0;
+      mvy = (R)1e-8 * z_s1;
+      mvn = r_sqrt(mvx * mvx + mvy * mvy);
+      ++n_still;
+    }
+    const R ang_now = get_angle(mvx, mvy);
+    {
+      // utils.pi_domain (utils.py:331-341)
+      R d = mod_2pi(ang_now - ang_prev);
+      if (d > (R)3.14159265358979323846) d = (R)-6.283185307179586476925286766559 + d;
+      mrot = d / dt;
+    }
+    ang_prev = ang_now;
+    // ---- _update_head_direction (Agent.py:488-500) ----------------------------------------
+    {
+      const R ix = mvx / mvn, iy = mvy / mvn;
+      const R tau = (R)m.hd_tau;
+      if (tau <= dt) {
+        hx = ix;
+        hy = iy;
+      } else {
+        const R nx = hx * ((R)1 - dt / tau) + dt / tau * ix;
+        const R ny = hy * ((R)1 - dt / tau) + dt / tau * iy;
+        const R nn = r_sqrt(nx * nx + ny * ny);
+        hx = nx / nn;
+        hy = ny / nn;
+      }
+    }
+    // ---- _update_distance_travelled (Agent.py:507) ----------------------------------------
+    dist += r_sqrt(dpx * dpx + dpy * dpy);
+    // ---- save_to_history (Agent.py:514-520) ------------------------------------------------
+    if (a.hist) {
+      float* h = a.hist + (int64_t)t * RIAB_HIST_ROWS * B + b;
+      h[0 * B] = (float)px;
+      h[1 * B] = (float)py;
+      h[2 * B] = (float)mvx;
+      h[3 * B] = (float)mvy;
+      h[4 * B] = (float)hx;
+      h[5 * B] = (float)hy;
+      h[6 * B] = (float)mrot;
+      h[7 * B] = (float)dist;
+    }
+  }
+  st[0 * B] = (double)px;
+  st[1 * B] = (double)py;
+  st[2 * B] = (double)vx;
+  st[3 * B] = (double)vy;
+  st[4 * B] = (double)rot;
+  st[5 * B] = (double)mvx;
+  st[6 * B] = (double)mvy;
+  st[7 * B] = (double)mrot;
+  st[8 * B] = (double)hx;
+  st[9 * B] = (double)hy;
+  st[10 * B] = (double)dist;
+  st[11 * B] = (double)dwall;
+  if (a.diag) {
+    if (n_bounce) atomicAdd(a.diag + 0, n_bounce);
+    if (n_sat) atomicAdd(a.diag + 1, n_sat);
+    if (n_bc) atomicAdd(a.diag + 2, n_bc);
+    if (n_still) atomicAdd(a.diag + 3, n_still);
+  }
+}
+
+}  // namespace riab
+
+using namespace riab;
+
+extern "C" int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
+                               int64_t agent_id0, const double* drift, const double* z_in, double* z_out,
+                               uint64_t seed, uint64_t step0, int32_t T, float* hist, int32_t* diag,
+                               int32_t precision, riab_stream_t stream) {
+  if (!env || !motion || !state || B <= 0 || T <= 0 || agent_id0 < 0) return RIAB_EINVAL;
+  if (env->n_walls < 0 || (env->n_walls > 0 && !env->walls)) return RIAB_EINVAL;
+  if (env->n_walls > RIAB_MAX_WALLS) return RIAB_ETOOBIG;
+  if (motion->has_drift && !drift) return RIAB_EINVAL;
+  if (precision != 64 && precision != 32) return RIAB_EINVAL;
+  AgentArgs a;
+  a.m = *motion;
+  a.e0 = env->extent[0];
+  a.e1 = env->extent[1];
+  a.e2 = env->extent[2];
+  a.e3 = env->extent[3];
+  a.scale = env->scale;
+  a.periodic = env->periodic;
+  a.n_walls = env->n_walls;
+  a.walls = env->walls;
+  a.state = state;
+  a.B = B;
+  a.agent_id0 = agent_id0;
+  a.drift = drift;
+  a.z_in = z_in;
+  a.z_out = z_out;
+  a.k0 = (uint32_t)seed;
+  a.k1 = (uint32_t)(seed >> 32);
+  a.step0 = step0;
+  a.T = T;
+  a.hist = hist;
+  a.diag = diag;
+  const dim3 grid((unsigned)((B + 63) / 64));
+  if (precision == 64) hipLaunchKernelGGL(agent_step_kernel<double>, grid, dim3(64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(agent_step_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,221 @@
+// BoundaryVectorCells.get_state for gfx950 (reference Neurons.py:1617-1778).
+//
+// rate[c][p] = (1/norm_c) * sum_k exp(-(d_k(p) - mu_c)^2 / 2 sigma_c^2) * exp(kappa_c (cos(theta_k - phi_c) - 1))
+// where d_k(p) is the distance from position p to the first wall along test direction k.
+// n*K exponentials per position (46 080 at n = 256, K = 180): the kernel is bound by
+// transcendental issue, not HBM, and has no contraction for MFMA (the summand depends on
+// all of c, k and p).
+//
+// Workgroup = 256 threads = 4 waves sharing one tile of 64 positions (lane = position):
+//   stage A  all 4 waves cast the K rays of the tile against the walls in float64 (the
+//            nearest-wall decision is discrete; walls + 1/denominator table staged in LDS)
+//            and leave d[k][lane] (fp32) in LDS;
+//   stage B  wave w owns the cells c = w (mod 4); per cell the K-loop reads d[k][lane]
+//            (conflict-free ds_read_b32) and the wave-uniform angular table entry (scalar
+//            load), one fused exponent per term: exp2(-(a d - a mu)^2 + T[c][k]).
+#include "riab_device.h"
+
+namespace riab {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct BvcArgs {
+  const float* pos_x;
+  const float* pos_y;
+  const float* hd_x;
+  const float* hd_y;
+  int64_t pos_ld;
+  int64_t P;     // T * B positions
+  int64_t B;
+  float* rates;  // [T][n][B]
+  uint8_t* spikes;
+  const float* u_in;
+  float dt, fr_scale, fr_min;
+  uint32_t k0, k1, step0, tag;
+  int64_t agent_id0;
+  int n, K, n_walls;
+  const double* walls;      // [n_walls][4]
+  const double* test_dirs;  // [K][2]
+  const float* cells;       // [4][n]
+  const float* vm;          // [n][K] or [2][n][K]
+  const float* inv_norm;    // [n]
+  float* ray_out;           // [T][K][B] or null
+};
+
+// LDS layout (dynamic): double wall[n_walls][4] (ax, ay, sx, sy) | double rden[K][n_walls] |
+// double dir[K][2] | float d[K][64]
+template <bool EGO>
+__global__ __launch_bounds__(256) void bvc_kernel(const BvcArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_wall = reinterpret_cast<double*>(smem);
+  double* s_rden = s_wall + 4 * a.n_walls;
+  double* s_dir = s_rden + (size_t)a.K * a.n_walls;
+  float* s_d = reinterpret_cast<float*>(s_dir + 2 * a.K);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nw = a.n_walls, K = a.K;
+
+  for (int i = tid; i < nw; i += 256) {
+    const double ax = a.walls[4 * i], ay = a.walls[4 * i + 1];
+    s_wall[4 * i] = ax;
+    s_wall[4 * i + 1] = ay;
+    s_wall[4 * i + 2] = a.walls[4 * i + 2] - ax;
+    s_wall[4 * i + 3] = a.walls[4 * i + 3] - ay;
+  }
+  for (int i = tid; i < 2 * K; i += 256) s_dir[i] = a.test_dirs[i];
+  for (int i = tid; i < K * nw; i += 256) {
+    const int k = i / nw, w = i - k * nw;
+    const double ux = a.test_dirs[2 * k], uy = a.test_dirs[2 * k + 1];
+    const double sx = a.walls[4 * w + 2] - a.walls[4 * w], sy = a.walls[4 * w + 3] - a.walls[4 * w + 1];
+    // utils.vector_intercepts (utils.py:96): l_a = (d0 . sb_p) / (sa . sb_p), sa = ray, sb = wall
+    s_rden[i] = 1.0 / (ux * (-sy) + uy * sx);
+  }
+  __syncthreads();
+
+  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = p < a.P;
+  const int64_t pc = live ? p : 0;
+  const int64_t t = pc / a.B;
+  const int64_t b = pc - t * a.B;
+  const float pxf = a.pos_x[t * a.pos_ld + b], pyf = a.pos_y[t * a.pos_ld + b];
+  const double px = pxf, py = pyf;
+
+  // ---- stage A: first-wall distance along each test direction (Neurons.py:1655-1684, 1746-1778)
+  for (int k = wave; k < K; k += 4) {
+    const double ux = s_dir[2 * k], uy = s_dir[2 * k + 1];
+    double best = INFINITY;  // smallest valid l_a == largest preference 1/l_a; first index wins ties
+    double fallback = 0.0;
+    bool have_fb = false;
+    for (int w = 0; w < nw; ++w) {
+      const double ax = s_wall[4 * w], ay = s_wall[4 * w + 1], sx = s_wall[4 * w + 2], sy = s_wall[4 * w + 3];
+      const double d0x = ax - px, d0y = ay - py;
+      const double rd = s_rden[k * nw + w];
+      const double la = (d0x * (-sy) + d0y * sx) * rd;
+      // l_b = (-d0 . sa_p) / (sb . sa_p) with sb . sa_p = -(sa . sb_p)
+      const double lb = ((-d0x) * (-uy) + (-d0y) * ux) * (-rd);
+      const bool valid = (la > 0.0) && !(lb < 0.0) && !(lb > 1.0);
+      if (valid && la < best) best = la;
+      if (w == 0 && !have_fb) {
+        fallback = la;  // argmax over all -1 preferences picks wall 0
+        have_fb = true;
+      }
+    }
+    const float d = (float)((best < INFINITY) ? best : fallback);
+    s_d[k * 64 + lane] = d;
+    if (a.ray_out && live) a.ray_out[(t * K + k) * a.B + b] = d;
+  }
+  __syncthreads();
+
+  // ---- stage B ------------------------------------------------------------------------------
+  float ch = 1.0f, sh = 0.0f;
+  if (EGO) {
+    // cos / sin of utils.get_angle(head_direction) = atan2(hy, hx + 1e-6)
+    const float hx = a.hd_x[t * a.pos_ld + b] + 1e-6f, hy = a.hd_y[t * a.pos_ld + b];
+    const float inv = 1.0f / sqrtf(hx * hx + hy * hy);
+    ch = hx * inv;
+    sh = hy * inv;
+  }
+  const int n = a.n;
+  for (int c = wave; c < n; c += 4) {
+    const float amu = a.cells[c], aa = a.cells[n + c], kap = a.cells[2 * n + c];
+    const float* vmc = a.vm + (int64_t)c * K;
+    const float* vms = a.vm + ((int64_t)n + c) * K;
+    float acc0 = 0.0f, acc1 = 0.0f;
+    int k = 0;
+    for (; k + 1 < K; k += 2) {
+      const float t0 = fmaf(s_d[k * 64 + lane], aa, -amu);
+      const float t1 = fmaf(s_d[(k + 1) * 64 + lane], aa, -amu);
+      float v0, v1;
+      if (EGO) {
+        v0 = kap * (fmaf(vmc[k], ch, vms[k] * sh) - 1.0f);
+        v1 = kap * (fmaf(vmc[k + 1], ch, vms[k + 1] * sh) - 1.0f);
+      } else {
+        v0 = vmc[k];
+        v1 = vmc[k + 1];
+      }
+      acc0 += __builtin_amdgcn_exp2f(fmaf(-t0, t0, v0));
+      acc1 += __builtin_amdgcn_exp2f(fmaf(-t1, t1, v1));
+    }
+    for (; k < K; ++k) {
+      const float t0 = fmaf(s_d[k * 64 + lane], aa, -amu);
+      const float v0 = EGO ? kap * (fmaf(vmc[k], ch, vms[k] * sh) - 1.0f) : vmc[k];
+      acc0 += __builtin_amdgcn_exp2f(fmaf(-t0, t0, v0));
+    }
+    float r = (acc0 + acc1) * a.inv_norm[c];
+    r = r * a.fr_scale + a.fr_min;
+    if (live) {
+      const int64_t off = (t * n + c) * a.B + b;
+      a.rates[off] = r;
+      if (a.spikes) {
+        float u;
+        if (a.u_in) {
+          u = a.u_in[off];
+        } else {
+          const uint64_t gid = (uint64_t)(a.agent_id0 + b);
+          const u32x4 w4 = philox4x32_10(a.step0 + (uint32_t)t, (uint32_t)c, (uint32_t)(gid >> 2), a.tag, a.k0, a.k1);
+          const uint32_t j = (uint32_t)gid & 3u;
+          const uint32_t word = j == 0 ? w4.x : (j == 1 ? w4.y : (j == 2 ? w4.z : w4.w));
+          u = u01_24(word);
+        }
+        a.spikes[off] = (u < a.dt * r) ? 1 : 0;
+      }
+    }
+  }
+}
+
+}  // namespace riab
+
+using namespace riab;
+
+extern "C" int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* io, const double* test_dirs, int32_t K,
+                                          const float* cells, const float* vm_table, const float* inv_norm,
+                                          int32_t n, int32_t egocentric, float* ray_out, riab_stream_t stream) {
+  if (!env || !io || !test_dirs || !cells || !vm_table || !inv_norm || n <= 0 || K <= 0) return RIAB_EINVAL;
+  if (io->T <= 0 || io->B <= 0 || !io->rates || !io->pos_x || !io->pos_y) return RIAB_EINVAL;
+  if (egocentric && (!io->hd_x || !io->hd_y)) return RIAB_EINVAL;
+  if (env->n_walls <= 0 || !env->walls) return RIAB_EINVAL;  // BVCs need solid boundaries (Neurons.py:1580-1582)
+  if (env->n_walls > RIAB_MAX_WALLS || K > RIAB_MAX_TEST_ANGLES) return RIAB_ETOOBIG;
+  if (io->u_in && !io->spikes) return RIAB_EINVAL;
+  BvcArgs a;
+  a.pos_x = io->pos_x;
+  a.pos_y = io->pos_y;
+  a.hd_x = io->hd_x;
+  a.hd_y = io->hd_y;
+  a.pos_ld = io->pos_ld;
+  a.P = io->T * io->B;
+  a.B = io->B;
+  a.rates = io->rates;
+  a.spikes = io->spikes;
+  a.u_in = io->u_in;
+  a.dt = io->dt;
+  a.fr_scale = io->max_fr - io->min_fr;
+  a.fr_min = io->min_fr;
+  a.k0 = (uint32_t)io->seed;
+  a.k1 = (uint32_t)(io->seed >> 32);
+  a.step0 = (uint32_t)io->step0;
+  a.tag = RIAB_TAG_SPIKES | ((uint32_t)io->pop_id & 0xFFu);
+  a.agent_id0 = io->agent_id0;
+  a.n = n;
+  a.K = K;
+  a.n_walls = env->n_walls;
+  a.walls = env->walls;
+  a.test_dirs = test_dirs;
+  a.cells = cells;
+  a.vm = vm_table;
+  a.inv_norm = inv_norm;
+  a.ray_out = ray_out;
+  const size_t lds = sizeof(double) * (4 * (size_t)env->n_walls + (size_t)K * env->n_walls + 2 * (size_t)K) +
+                     sizeof(float) * (size_t)K * 64;
+  if (lds > 160 * 1024) return RIAB_ETOOBIG;
+  const dim3 grid((unsigned)((a.P + 63) / 64));
+  hipStream_t s = (hipStream_t)stream;
+  if (egocentric) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)bvc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bvc_kernel<true>, grid, dim3(256), lds, s, a);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)bvc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bvc_kernel<false>, grid, dim3(256), lds, s, a);
+  }
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,587 @@
+// Firing-rate kernels for gfx950 (MI355X): PlaceCells, GridCells,
+// HeadDirectionCells, the Poisson-spike epilogue, neuron noise and the
+// streaming-store calibration kernel.
+//
+// Shape of the problem: out[t][c][b] = f(cell c, position of agent b at step t).
+// No contraction (nothing for MFMA); the only large traffic is the write of
+// `rates` (4 B per (cell, agent-step)) so the kernels are HBM-write bound.
+// Mapping:
+//   * a lane owns FOUR consecutive agents of one time row (one float4 of x and
+//     of y, loaded once) and walks a chunk of cells; every store is a 16-B
+//     float4, i.e. 1 KiB contiguous per wave-instruction, nontemporal;
+//   * the cell index is wave-uniform, so cell tables are read with scalar
+//     loads (SGPR operands) — no LDS round trip, no per-lane table traffic;
+//   * grid = (quads of agents over all T rows) x (cell chunks): >> 256
+//     workgroups for any trajectory chunk, so all 8 XCDs stream.
+#include "riab_device.h"
+
+namespace riab {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct RateArgs {
+  const float* pos_x;
+  const float* pos_y;
+  const float* hd_x;
+  const float* hd_y;
+  int64_t pos_ld;
+  int64_t nquads;  // T * (B/4)
+  int64_t qrow;    // B/4
+  int64_t B;
+  float* rates;
+  uint8_t* spikes;
+  const float* u_in;
+  float dt, fr_scale, fr_min;
+  uint32_t k0, k1;       // Philox key (seed)
+  uint32_t step0;
+  uint32_t tag;          // RIAB_TAG_SPIKES | pop_id
+  uint32_t group0;       // agent_id0 / 4
+  int32_t n;
+  int32_t cells_per_block;
+};
+
+struct PosQuad {
+  v4f x, y;
+};
+
+__device__ __forceinline__ v4f ldv4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
+
+// ---- spike epilogue: Neurons.save_to_history (reference Neurons.py:681-687) -------------
+template <bool EXPLICIT_U>
+__device__ __forceinline__ void spike_store(const RateArgs& a, v4f r, int64_t off, uint32_t step, uint32_t c,
+                                            uint32_t group) {
+  v4f u;
+  if (EXPLICIT_U) {
+    u = ldv4(a.u_in + off);
+  } else {
+    const u32x4 w = philox4x32_10(step, c, group, a.tag, a.k0, a.k1);
+    u = v4f{u01_24(w.x), u01_24(w.y), u01_24(w.z), u01_24(w.w)};
+  }
+  // one fp32 multiply, one fp32 compare: the exactly-specified spike rule
+  const uint32_t s = (u.x < a.dt * r.x ? 1u : 0u) | (u.y < a.dt * r.y ? 0x100u : 0u) |
+                     (u.z < a.dt * r.z ? 0x10000u : 0u) | (u.w < a.dt * r.w ? 0x1000000u : 0u);
+  __builtin_nontemporal_store(s, reinterpret_cast<uint32_t*>(a.spikes + off));
+}
+
+// ---- generic driver ----------------------------------------------------------------------
+// Cell tables are wave-uniform in the inner loop.  Each lane loads the parameters of ONE cell
+// of the current 64-cell group (coalesced, once), and the inner loop broadcasts cell j's
+// parameters with v_readlane_b32 into SGPRs: no memory latency and no LDS traffic inside the
+// store loop.
+// SPK: 0 none, 1 Philox uniforms, 2 explicit uniforms.
+template <class Cell, int SPK>
+__global__ __launch_bounds__(256) void rate_kernel(const RateArgs a, Cell cell) {
+  __shared__ double s_lds[Cell::LDS_DOUBLES];
+  cell.stage(s_lds);
+  const uint32_t p4 = blockIdx.x * 256u + threadIdx.x;
+  const bool live = p4 < a.nquads;
+  const uint32_t pc = live ? p4 : 0u;
+  const uint32_t t = pc / (uint32_t)a.qrow;
+  const uint32_t q = pc - t * (uint32_t)a.qrow;
+  const typename Cell::Pos P = cell.load(a, (int64_t)t * a.pos_ld + 4 * (int64_t)q);
+  const int c0 = blockIdx.y * a.cells_per_block;
+  const int c1 = min(a.n, c0 + a.cells_per_block);
+  int64_t off = ((int64_t)t * a.n + c0) * a.B + 4 * (int64_t)q;
+  const uint32_t step = a.step0 + t;
+  const uint32_t group = a.group0 + q;
+  const int lane = threadIdx.x & 63;
+  for (int cb = c0; cb < c1; cb += 64) {
+    float mine[Cell::NP];
+    cell.params(min(cb + lane, a.n - 1), mine);
+    const int cnt = min(64, c1 - cb);
+    for (int j = 0; j < cnt; ++j) {
+      float p[Cell::NP];
+#pragma unroll
+      for (int i = 0; i < Cell::NP; ++i) p[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine[i]), j));
+      v4f r = cell.eval(p, P);
+      r = r * a.fr_scale + a.fr_min;  // [0,1] -> [min_fr, max_fr]
+      if (live) {
+        __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(a.rates + off));
+        if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)(cb + j), group);
+        if (SPK == 2) spike_store<true>(a, r, off, step, (uint32_t)(cb + j), group);
+      }
+      off += a.B;
+    }
+  }
+}
+
+// ---- PlaceCells (reference Neurons.py:936-981, Environment.py:677-779) -------------------
+// Strict segment/segment intersection test of utils.vector_intercepts
+// (utils.py:74-106: 0 < l_a < 1 and 0 < l_b < 1), evaluated with sign logic on the
+// float64 cross products instead of the two divisions (equal up to the last ulp of
+// the quotient; parallel segments give den == 0 -> no hit, like +-inf/NaN in NumPy).
+__device__ __forceinline__ bool seg_hit(double p0x, double p0y, double p1x, double p1y, double ax, double ay,
+                                        double bx, double by) {
+  const double sax = p1x - p0x, say = p1y - p0y;  // list a = line of sight
+  const double sbx = bx - ax, sby = by - ay;      // list b = wall
+  const double d0x = ax - p0x, d0y = ay - p0y;
+  const double den_a = sax * (-sby) + say * sbx;
+  const double num_a = d0x * (-sby) + d0y * sbx;
+  const double den_b = sbx * (-say) + sby * sax;
+  const double num_b = (-d0x) * (-say) + (-d0y) * sax;
+  const bool ia = (den_a > 0) ? (num_a > 0 && num_a < den_a) : (den_a < 0 ? (num_a < 0 && num_a > den_a) : false);
+  const bool ib = (den_b > 0) ? (num_b > 0 && num_b < den_b) : (den_b < 0 ? (num_b < 0 && num_b > den_b) : false);
+  return ia && ib;
+}
+
+// GX: 0 euclidean, 1 line_of_sight, 2 geodesic, 3 euclidean + periodic wrap.
+template <int DESC, int GX>
+struct PlaceCell {
+  typedef PosQuad Pos;
+  static constexpr int LDS_DOUBLES = (GX == 1 || GX == 2) ? 4 * RIAB_MAX_WALLS + 8 : 1;
+  const float* cx;  // [n]
+  const float* cy;  // [n]
+  const float* k;   // [n] = -log2(e) / (2 w^2)
+  float scale, half_scale;  // periodic wrap (Environment.py:670-674)
+  float top_hat_w2;
+  const double* walls;  // device [n_walls][4]; internal walls = walls[4:] (Environment.py:715-717)
+  int n_internal;
+  double e0, e1, e2, e3;  // extent, for the geodesic "endpoint inside the env" test
+  const double* lds;      // set by stage()
+
+  __device__ __forceinline__ void stage(double* s) {
+    lds = s;
+    if (GX == 1 || GX == 2) {
+      for (int i = threadIdx.x; i < 4 * n_internal; i += 256) s[i] = walls[16 + i];
+      __syncthreads();
+    }
+  }
+  __device__ __forceinline__ Pos load(const RateArgs& a, int64_t off) const {
+    return Pos{ldv4(a.pos_x + off), ldv4(a.pos_y + off)};
+  }
+  __device__ __forceinline__ float wrap(float v) const {
+    const float av = fabsf(v);
+    return (av > half_scale) ? -copysignf(scale - av, v) : v;
+  }
+  __device__ __forceinline__ float dist2(float cxs, float cys, float px, float py) const {
+    float dx = cxs - px, dy = cys - py;
+    if (GX == 3) {
+      dx = wrap(dx);
+      dy = wrap(dy);
+    }
+    float d2 = fmaf(dy, dy, dx * dx);
+    if (GX == 1) {
+      bool blocked = false;
+      for (int w = 0; w < n_internal; ++w)
+        blocked |= seg_hit(cxs, cys, px, py, lds[4 * w], lds[4 * w + 1], lds[4 * w + 2], lds[4 * w + 3]);
+      if (blocked) d2 = 1.0e6f;  // distance 1000 (Environment.py:730)
+    }
+    if (GX == 2) {
+      if (n_internal > 0 && seg_hit(cxs, cys, px, py, lds[0], lds[1], lds[2], lds[3])) {
+        // Environment.py:744-774: shortest route via a wall endpoint strictly inside the env
+        float best = INFINITY;
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const double exd = lds[2 * e], eyd = lds[2 * e + 1];
+          if (exd > e0 && exd < e1 && eyd > e2 && eyd < e3) {
+            const float ex = (float)exd, ey = (float)eyd;
+            const float d1 = sqrtf(fmaf(cys - ey, cys - ey, (cxs - ex) * (cxs - ex)));
+            const float d2e = sqrtf(fmaf(ey - py, ey - py, (ex - px) * (ex - px)));
+            best = fminf(best, d1 + d2e);
+            any = true;
+          }
+        }
+        if (any) d2 = best * best;
+      }
+    }
+    return d2;
+  }
+  __device__ __forceinline__ float fr(float d2, float ks) const {
+    if (DESC == RIAB_PC_GAUSSIAN) return __builtin_amdgcn_exp2f(d2 * ks);
+    if (DESC == RIAB_PC_GAUSSIAN_THRESHOLD) {
+      const float e12 = 0.60653065971263342f;  // exp(-1/2)
+      return fmaxf(__builtin_amdgcn_exp2f(d2 * ks) - e12, 0.0f) * (1.0f / (1.0f - e12));
+    }
+    if (DESC == RIAB_PC_DIFF_OF_GAUSSIANS) {
+      const float g1 = __builtin_amdgcn_exp2f(d2 * ks);
+      const float g2 = __builtin_amdgcn_exp2f(d2 * ks * (1.0f / 2.25f));
+      return (g1 - (1.0f / 2.25f) * g2) * (2.25f / 1.25f);
+    }
+    if (DESC == RIAB_PC_TOP_HAT) return (d2 < top_hat_w2) ? 1.0f : 0.0f;
+    return 0.0f;
+  }
+  static constexpr int NP = 3;
+  __device__ __forceinline__ void params(int c, float* p) const {
+    p[0] = cx[c];
+    p[1] = cy[c];
+    p[2] = k[c];
+  }
+  __device__ __forceinline__ v4f eval(const float* p, const Pos& P) const {
+    const float cxs = p[0], cys = p[1], ks = p[2];
+    v4f r;
+    r.x = fr(dist2(cxs, cys, P.x.x, P.y.x), ks);
+    r.y = fr(dist2(cxs, cys, P.x.y, P.y.y), ks);
+    r.z = fr(dist2(cxs, cys, P.x.z, P.y.z), ks);
+    r.w = fr(dist2(cxs, cys, P.x.w, P.y.w), ks);
+    return r;
+  }
+  template <int D2>
+  __host__ PlaceCell<D2, GX> as() const {
+    PlaceCell<D2, GX> c;
+    c.cx = cx; c.cy = cy; c.k = k; c.scale = scale; c.half_scale = half_scale; c.top_hat_w2 = top_hat_w2;
+    c.walls = walls; c.n_internal = n_internal; c.e0 = e0; c.e1 = e1; c.e2 = e2; c.e3 = e3; c.lds = nullptr;
+    return c;
+  }
+};
+
+// one_hot (Neurons.py:971-973): 1 for argmin_c |dist|, first minimum wins.  Each lane scans
+// every cell for its four agents, then writes the one-hot columns.
+template <int GX>
+__global__ __launch_bounds__(256) void place_one_hot_kernel(const RateArgs a, PlaceCell<RIAB_PC_GAUSSIAN, GX> cell) {
+  __shared__ double s_lds[PlaceCell<RIAB_PC_GAUSSIAN, GX>::LDS_DOUBLES];
+  cell.stage(s_lds);
+  const uint32_t p4 = blockIdx.x * 256u + threadIdx.x;
+  if (p4 >= a.nquads) return;
+  const uint32_t t = p4 / (uint32_t)a.qrow;
+  const uint32_t q = p4 - t * (uint32_t)a.qrow;
+  const PosQuad P = cell.load(a, (int64_t)t * a.pos_ld + 4 * (int64_t)q);
+  float best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+  int arg[4] = {0, 0, 0, 0};
+  for (int c = 0; c < a.n; ++c) {
+    const float cxs = cell.cx[c], cys = cell.cy[c];
+    const float d[4] = {cell.dist2(cxs, cys, P.x.x, P.y.x), cell.dist2(cxs, cys, P.x.y, P.y.y),
+                        cell.dist2(cxs, cys, P.x.z, P.y.z), cell.dist2(cxs, cys, P.x.w, P.y.w)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (d[j] < best[j]) {
+        best[j] = d[j];
+        arg[j] = c;
+      }
+  }
+  int64_t off = ((int64_t)t * a.n) * a.B + 4 * (int64_t)q;
+  const uint32_t step = a.step0 + t;
+  const uint32_t group = a.group0 + q;
+  for (int c = 0; c < a.n; ++c) {
+    v4f r = {arg[0] == c ? 1.0f : 0.0f, arg[1] == c ? 1.0f : 0.0f, arg[2] == c ? 1.0f : 0.0f,
+             arg[3] == c ? 1.0f : 0.0f};
+    r = r * a.fr_scale + a.fr_min;
+    __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(a.rates + off));
+    if (a.spikes) {
+      if (a.u_in) spike_store<true>(a, r, off, step, (uint32_t)c, group);
+      else spike_store<false>(a, r, off, step, (uint32_t)c, group);
+    }
+    off += a.B;
+  }
+}
+
+// ---- GridCells (reference Neurons.py:1172-1236) -------------------------------------------
+// phase of cosine i in revolutions: a_i - (x*bx_i + y*by_i); v_cos_f32 takes revolutions.
+template <int DESC>
+struct GridCell {
+  typedef PosQuad Pos;
+  static constexpr int LDS_DOUBLES = 1;
+  __device__ __forceinline__ void stage(double*) {}
+  const float* tab;  // [9][n]
+  int n;
+  float f0, inv_1mf0;
+  __device__ __forceinline__ Pos load(const RateArgs& a, int64_t off) const {
+    return Pos{ldv4(a.pos_x + off), ldv4(a.pos_y + off)};
+  }
+  __device__ __forceinline__ float one(const float* p, float x, float y) const {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float rev = p[3 * i] - fmaf(x, p[3 * i + 1], y * p[3 * i + 2]);
+      rev -= floorf(rev);  // v_fract: keep the hardware cosine in its accurate range
+      s += __builtin_amdgcn_cosf(rev);
+    }
+    s *= (1.0f / 3.0f);
+    if (DESC == RIAB_GC_RECTIFIED) return fmaxf((s - f0) * inv_1mf0, 0.0f);
+    return (2.0f / 3.0f) * (s + 0.5f);
+  }
+  static constexpr int NP = 9;
+  __device__ __forceinline__ void params(int c, float* p) const {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p[i] = tab[(int64_t)i * n + c];
+  }
+  __device__ __forceinline__ v4f eval(const float* p, const Pos& P) const {
+    v4f r;
+    r.x = one(p, P.x.x, P.y.x);
+    r.y = one(p, P.x.y, P.y.y);
+    r.z = one(p, P.x.z, P.y.z);
+    r.w = one(p, P.x.w, P.y.w);
+    return r;
+  }
+};
+
+// ---- HeadDirectionCells (reference Neurons.py:2466-2483, utils.py:231-273, 441-457) --------
+struct HDCell {
+  struct Pos {
+    v4f ang;
+  };
+  static constexpr int LDS_DOUBLES = 1;
+  __device__ __forceinline__ void stage(double*) {}
+  const float* pref;    // [n]
+  const float* kappa2;  // [n] kappa * log2(e)
+  __device__ __forceinline__ Pos load(const RateArgs& a, int64_t off) const {
+    const v4f hx = ldv4(a.hd_x + off), hy = ldv4(a.hd_y + off);
+    Pos P;
+    // utils.get_angle: atan2(y, x + 1e-6); the mod 2pi is irrelevant under the cosine
+    P.ang.x = atan2f(hy.x, hx.x + 1e-6f);
+    P.ang.y = atan2f(hy.y, hx.y + 1e-6f);
+    P.ang.z = atan2f(hy.z, hx.z + 1e-6f);
+    P.ang.w = atan2f(hy.w, hx.w + 1e-6f);
+    return P;
+  }
+  __device__ __forceinline__ float one(float ang, float pr, float k2) const {
+    return __builtin_amdgcn_exp2f(k2 * (cosf(ang - pr) - 1.0f));
+  }
+  static constexpr int NP = 2;
+  __device__ __forceinline__ void params(int c, float* p) const {
+    p[0] = pref[c];
+    p[1] = kappa2[c];
+  }
+  __device__ __forceinline__ v4f eval(const float* p, const Pos& P) const {
+    const float pr = p[0], k2 = p[1];
+    return v4f{one(P.ang.x, pr, k2), one(P.ang.y, pr, k2), one(P.ang.z, pr, k2), one(P.ang.w, pr, k2)};
+  }
+};
+
+// ---- standalone spikes on existing rates ----------------------------------------------------
+template <bool EXPLICIT_U>
+__global__ __launch_bounds__(256) void spikes_kernel(const RateArgs a) {
+  const uint32_t p4 = blockIdx.x * 256u + threadIdx.x;
+  if (p4 >= a.nquads) return;
+  const uint32_t t = p4 / (uint32_t)a.qrow;
+  const uint32_t q = p4 - t * (uint32_t)a.qrow;
+  const int c0 = blockIdx.y * a.cells_per_block;
+  const int c1 = min(a.n, c0 + a.cells_per_block);
+  int64_t off = ((int64_t)t * a.n + c0) * a.B + 4 * (int64_t)q;
+  for (int c = c0; c < c1; ++c) {
+    const v4f r = ldv4(a.rates + off);
+    spike_store<EXPLICIT_U>(a, r, off, a.step0 + t, (uint32_t)c, a.group0 + q);
+    off += a.B;
+  }
+}
+
+// ---- Neurons.update noise (reference Neurons.py:153-168) -----------------------------------
+__global__ __launch_bounds__(256) void noise_kernel(float* noise, float* rates, const float* z_in, int n,
+                                                    int64_t qrow, float theta_dt, float sigma_dt, uint32_t k0,
+                                                    uint32_t k1, uint32_t step, uint32_t tag, uint32_t group0) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (q >= qrow) return;
+  const int64_t off = ((int64_t)c * qrow + q) * 4;
+  v4f z;
+  if (z_in) {
+    z = ldv4(z_in + off);
+  } else {
+    const u32x4 w = philox4x32_10(step, (uint32_t)c, group0 + (uint32_t)q, tag, k0, k1);
+    // two Box-Muller pairs in fp32
+    const float u0 = ((float)(w.x >> 8) + 0.5f) * 0x1.0p-24f, u1 = (float)(w.y >> 8) * 0x1.0p-24f;
+    const float u2 = ((float)(w.z >> 8) + 0.5f) * 0x1.0p-24f, u3 = (float)(w.w >> 8) * 0x1.0p-24f;
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    z = v4f{r0 * __builtin_amdgcn_cosf(u1), r0 * __builtin_amdgcn_sinf(u1), r1 * __builtin_amdgcn_cosf(u3),
+            r1 * __builtin_amdgcn_sinf(u3)};
+  }
+  v4f x = ldv4(noise + off);
+  // utils.ornstein_uhlenbeck with drift 0: dx = theta*(0 - x)*dt + sigma*(dt*z)
+  x = x + (-theta_dt) * x + sigma_dt * z;
+  *reinterpret_cast<v4f*>(noise + off) = x;
+  v4f r = ldv4(rates + off);
+  *reinterpret_cast<v4f*>(rates + off) = r + x;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* dst, int64_t n4, float value) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const v4f v = {value, value, value, value};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst) + i);
+}
+
+// ---- host side ------------------------------------------------------------------------------
+static int check_io(const RiabRateIO* io, int n, bool need_pos, bool need_hd) {
+  if (!io || n <= 0 || io->T <= 0 || io->B <= 0 || !io->rates) return RIAB_EINVAL;
+  if (need_pos && (!io->pos_x || !io->pos_y)) return RIAB_EINVAL;
+  if (need_hd && (!io->hd_x || !io->hd_y)) return RIAB_EINVAL;
+  if (io->B % 4 != 0 || io->pos_ld % 4 != 0 || io->agent_id0 % 4 != 0) return RIAB_EALIGN;
+  const uintptr_t m = (uintptr_t)io->rates | (uintptr_t)io->pos_x | (uintptr_t)io->pos_y | (uintptr_t)io->hd_x |
+                      (uintptr_t)io->hd_y | (uintptr_t)io->u_in;
+  if (m & 15) return RIAB_EALIGN;
+  if ((uintptr_t)io->spikes & 3) return RIAB_EALIGN;
+  if (io->u_in && !io->spikes) return RIAB_EINVAL;
+  if (io->T * (io->B / 4) >= ((int64_t)1 << 31)) return RIAB_ETOOBIG;  // 32-bit quad index in the kernels
+  return RIAB_OK;
+}
+
+static RateArgs make_args(const RiabRateIO* io, int n, dim3* grid) {
+  RateArgs a;
+  a.pos_x = io->pos_x;
+  a.pos_y = io->pos_y;
+  a.hd_x = io->hd_x;
+  a.hd_y = io->hd_y;
+  a.pos_ld = io->pos_ld;
+  a.qrow = io->B / 4;
+  a.nquads = io->T * a.qrow;
+  a.B = io->B;
+  a.rates = io->rates;
+  a.spikes = io->spikes;
+  a.u_in = io->u_in;
+  a.dt = io->dt;
+  a.fr_scale = io->max_fr - io->min_fr;
+  a.fr_min = io->min_fr;
+  a.k0 = (uint32_t)io->seed;
+  a.k1 = (uint32_t)(io->seed >> 32);
+  a.step0 = (uint32_t)io->step0;
+  a.tag = RIAB_TAG_SPIKES | ((uint32_t)io->pop_id & 0xFFu);
+  a.group0 = (uint32_t)(io->agent_id0 / 4);
+  a.n = n;
+  const int64_t pblocks = (a.nquads + 255) / 256;
+  // enough workgroups to fill 256 CUs x several waves, but keep >= 16 cells per lane so the
+  // position load and index arithmetic amortise
+  int chunks = (int)((4096 + pblocks - 1) / pblocks);
+  if (chunks < 1) chunks = 1;
+  int cpb = (n + chunks - 1) / chunks;
+  cpb = ((cpb + 63) / 64) * 64;  // whole 64-cell groups (one table register per lane)
+  a.cells_per_block = cpb;
+  *grid = dim3((unsigned)pblocks, (unsigned)((n + cpb - 1) / cpb), 1);
+  return a;
+}
+
+template <class Cell>
+static int launch_rate(const RiabRateIO* io, int n, const Cell& cell, hipStream_t s) {
+  dim3 grid;
+  const RateArgs a = make_args(io, n, &grid);
+  if (!io->spikes) hipLaunchKernelGGL((rate_kernel<Cell, 0>), grid, dim3(256), 0, s, a, cell);
+  else if (!io->u_in) hipLaunchKernelGGL((rate_kernel<Cell, 1>), grid, dim3(256), 0, s, a, cell);
+  else hipLaunchKernelGGL((rate_kernel<Cell, 2>), grid, dim3(256), 0, s, a, cell);
+  return (int)hipGetLastError();
+}
+
+template <int GX>
+static int launch_place(const RiabRateIO* io, int n, int desc, const PlaceCell<RIAB_PC_GAUSSIAN, GX>& base,
+                        hipStream_t s) {
+  switch (desc) {
+    case RIAB_PC_GAUSSIAN: return launch_rate(io, n, base, s);
+    case RIAB_PC_GAUSSIAN_THRESHOLD: return launch_rate(io, n, base.template as<RIAB_PC_GAUSSIAN_THRESHOLD>(), s);
+    case RIAB_PC_DIFF_OF_GAUSSIANS: return launch_rate(io, n, base.template as<RIAB_PC_DIFF_OF_GAUSSIANS>(), s);
+    case RIAB_PC_TOP_HAT: return launch_rate(io, n, base.template as<RIAB_PC_TOP_HAT>(), s);
+    case RIAB_PC_ONE_HOT: {
+      dim3 grid;
+      const RateArgs a = make_args(io, n, &grid);
+      grid.y = 1;
+      hipLaunchKernelGGL((place_one_hot_kernel<GX>), grid, dim3(256), 0, s, a, base);
+      return (int)hipGetLastError();
+    }
+    default: return RIAB_EINVAL;
+  }
+}
+
+template <int GX>
+static int place_dispatch(const RiabEnv* env, const RiabRateIO* io, const float* cells, int n, int desc, float thw,
+                          hipStream_t s) {
+  PlaceCell<RIAB_PC_GAUSSIAN, GX> c;
+  c.cx = cells;
+  c.cy = cells + n;
+  c.k = cells + 2 * (int64_t)n;
+  c.scale = (float)env->scale;
+  c.half_scale = (float)(env->scale / 2);
+  c.top_hat_w2 = thw * thw;
+  c.walls = env->walls;
+  c.n_internal = env->n_walls > 4 ? env->n_walls - 4 : 0;
+  if (GX == 2 && c.n_internal > 1) c.n_internal = 1;
+  c.e0 = env->extent[0]; c.e1 = env->extent[1]; c.e2 = env->extent[2]; c.e3 = env->extent[3];
+  c.lds = nullptr;
+  return launch_place<GX>(io, n, desc, c, s);
+}
+
+}  // namespace riab
+
+using namespace riab;
+
+extern "C" int riab_place_cells(const RiabEnv* env, const RiabRateIO* io, const float* cells, int32_t n,
+                                int32_t description, int32_t geometry, float top_hat_width, riab_stream_t stream) {
+  if (!env || !cells) return RIAB_EINVAL;
+  const int rc = check_io(io, n, true, false);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (env->periodic) {
+    if (geometry != RIAB_GEOM_EUCLIDEAN) return RIAB_EUNSUPPORTED;  // Neurons.py:908-921
+    return place_dispatch<3>(env, io, cells, n, description, top_hat_width, s);
+  }
+  if (geometry != RIAB_GEOM_EUCLIDEAN) {
+    if (env->n_walls > 4 && !env->walls) return RIAB_EINVAL;
+    if (env->n_walls - 4 > RIAB_MAX_WALLS) return RIAB_ETOOBIG;
+    if (geometry == RIAB_GEOM_GEODESIC && env->n_walls > 5) return RIAB_EUNSUPPORTED;  // Environment.py:736-739
+  }
+  switch (geometry) {
+    case RIAB_GEOM_EUCLIDEAN: return place_dispatch<0>(env, io, cells, n, description, top_hat_width, s);
+    case RIAB_GEOM_LINE_OF_SIGHT: return place_dispatch<1>(env, io, cells, n, description, top_hat_width, s);
+    case RIAB_GEOM_GEODESIC: return place_dispatch<2>(env, io, cells, n, description, top_hat_width, s);
+    default: return RIAB_EINVAL;
+  }
+}
+
+extern "C" int riab_grid_cells(const RiabRateIO* io, const float* table, int32_t n, int32_t description, float f0,
+                               riab_stream_t stream) {
+  if (!table) return RIAB_EINVAL;
+  const int rc = check_io(io, n, true, false);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (description == RIAB_GC_RECTIFIED) {
+    GridCell<RIAB_GC_RECTIFIED> c{table, n, f0, 1.0f / (1.0f - f0)};
+    return launch_rate(io, n, c, s);
+  }
+  if (description == RIAB_GC_SHIFTED) {
+    GridCell<RIAB_GC_SHIFTED> c{table, n, f0, 1.0f};
+    return launch_rate(io, n, c, s);
+  }
+  return RIAB_EINVAL;
+}
+
+extern "C" int riab_head_direction_cells(const RiabRateIO* io, const float* pref, const float* kappa2, int32_t n,
+                                         riab_stream_t stream) {
+  if (!pref || !kappa2) return RIAB_EINVAL;
+  const int rc = check_io(io, n, false, true);
+  if (rc) return rc;
+  HDCell c{pref, kappa2};
+  return launch_rate(io, n, c, (hipStream_t)stream);
+}
+
+extern "C" int riab_spikes(const RiabRateIO* io, int32_t n, riab_stream_t stream) {
+  const int rc = check_io(io, n, false, false);
+  if (rc) return rc;
+  if (!io->spikes) return RIAB_EINVAL;
+  dim3 grid;
+  const RateArgs a = make_args(io, n, &grid);
+  if (io->u_in) hipLaunchKernelGGL((spikes_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((spikes_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int riab_neuron_noise(float* noise, float* rates, const float* z_in, int32_t n, int64_t B, float theta_dt,
+                                 float sigma_dt, uint64_t seed, uint64_t step, int32_t pop_id, int64_t agent_id0,
+                                 riab_stream_t stream) {
+  if (!noise || !rates || n <= 0 || B <= 0) return RIAB_EINVAL;
+  if (B % 4 || agent_id0 % 4 || (((uintptr_t)noise | (uintptr_t)rates | (uintptr_t)z_in) & 15)) return RIAB_EALIGN;
+  const int64_t qrow = B / 4;
+  dim3 grid((unsigned)((qrow + 255) / 256), (unsigned)n, 1);
+  hipLaunchKernelGGL(noise_kernel, grid, dim3(256), 0, (hipStream_t)stream, noise, rates, z_in, n, qrow, theta_dt,
+                     sigma_dt, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step,
+                     RIAB_TAG_NOISE | ((uint32_t)pop_id & 0xFFu), (uint32_t)(agent_id0 / 4));
+  return (int)hipGetLastError();
+}
+
+extern "C" int riab_fill(void* dst, int64_t bytes, float value, riab_stream_t stream) {
+  if (!dst || bytes <= 0) return RIAB_EINVAL;
+  if ((bytes & 15) || ((uintptr_t)dst & 15)) return RIAB_EALIGN;
+  const int64_t n4 = bytes / 16;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float*)dst, n4, value);
+  return (int)hipGetLastError();
+}
+
+extern "C" int riab_abi_version(void) { return RIAB_ABI_VERSION; }
+
+extern "C" const char* riab_strerror(int code) {
+  switch (code) {
+    case RIAB_OK: return "ok";
+    case RIAB_EINVAL: return "invalid argument (null pointer, non-positive size or unknown enum)";
+    case RIAB_EALIGN: return "agent axis not a multiple of 4 or row pointer not 16-byte aligned";
+    case RIAB_ETOOBIG: return "too many walls / test angles for the LDS staging";
+    case RIAB_EUNSUPPORTED: return "combination not supported on device";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown riab error";
+  }
+}

@@ -1,0 +1,162 @@
+"""Host-side helpers of the batched hot path: the `default_params` protocol,
+init-time parameter samplers and a few scalar geometry helpers used while
+building device tables.  Nothing here runs per step.
+
+Reference interfaces mirrored (paths relative to the reference checkout):
+`utils.update_class_params / collect_all_params / check_params` (utils.py:804-916),
+`utils.distribution_sampler` (utils.py:460-538), `utils.create_random_assembly`
+(utils.py:1124-1220), `utils.rotate / get_angle / get_rayleigh_*` (utils.py:231-301, 395-406).
+Samplers draw from the global `np.random` state in the same order as the
+reference so that a seeded script builds identical cell tables (tests/golden:
+update_init.npz)."""
+import inspect
+import warnings
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------- #
+# default_params protocol
+# --------------------------------------------------------------------------- #
+def collect_all_params(obj_class, keys_only=False, dict_name="default_params"):
+    """Merge the `default_params` class attributes from the root of the class
+    hierarchy down to `obj_class` (children override parents)."""
+    if not inspect.isclass(obj_class):
+        raise ValueError("obj_class must be a class object.")
+    chain = [c for c in reversed(obj_class.__mro__) if dict_name in c.__dict__]
+    if dict_name not in obj_class.__dict__:
+        warnings.warn(f"{obj_class.__name__} has no class attribute '{dict_name}'; nothing to collect.")
+        return [] if keys_only else {}
+    merged = {}
+    for c in chain:
+        merged.update(getattr(c, dict_name))
+    return sorted(merged.keys()) if keys_only else merged
+
+
+def update_class_params(obj, params, get_all_defaults=False):
+    """Set every (key, value) of `params` as an attribute of `obj`; with
+    `get_all_defaults` the inherited defaults are filled in first."""
+    if get_all_defaults:
+        merged = collect_all_params(obj.__class__)
+        merged.update(params)
+        params = merged
+    for k, v in params.items():
+        setattr(obj, k, v)
+
+
+def check_params(obj, param_keys):
+    """Warn about keys that no class in the hierarchy declares in `default_params`."""
+    if inspect.isclass(obj):
+        raise ValueError("Obj must be an instance of a class, not a class object.")
+    cls = obj.__class__
+    if "default_params" not in cls.__dict__:
+        warnings.warn(f"{cls} has no 'default_params'; cannot check parameter keys.")
+        return
+    known = collect_all_params(cls, keys_only=True)
+    unexpected = [k for k in param_keys if k not in known]
+    if unexpected:
+        names = ", ".join(f"'{k}'" for k in unexpected)
+        warnings.warn(
+            f"Found {len(unexpected)} unexpected params key(s) while initializing {cls.__name__} object: {names}.\n"
+            f"If you intended to set this parameter, ignore this message. To see all default parameters for this "
+            f"class call {cls.__name__}.get_all_default_params().")
+    return unexpected
+
+
+# --------------------------------------------------------------------------- #
+# scalar geometry used at init time
+# --------------------------------------------------------------------------- #
+def rotate(vector, theta):
+    """Rotate a 2-vector anticlockwise by `theta` radians."""
+    c, s = np.cos(theta), np.sin(theta)
+    return np.matmul(np.array([[c, -s], [s, c]]), vector)
+
+
+def get_angle(vec):
+    """Angle of direction vectors `(..., 2)`, anticlockwise from the x-axis, in
+    [0, 2pi): `mod(arctan2(y, x + 1e-6), 2pi)` (the 1e-6 is the reference's)."""
+    vec = np.asarray(vec, dtype=float)
+    return np.mod(np.arctan2(vec[..., 1], vec[..., 0] + 1e-6), 2 * np.pi)
+
+
+def get_rayleigh_sigma(mean):
+    return mean / np.sqrt(np.pi / 2)
+
+
+def get_rayleigh_mean(sigma):
+    return sigma * np.sqrt(np.pi / 2)
+
+
+# --------------------------------------------------------------------------- #
+# init-time samplers
+# --------------------------------------------------------------------------- #
+def distribution_sampler(distribution_name="uniform", distribution_parameters=(1,), shape=(10,)):
+    """Sample an array of `shape` from a named distribution:
+    uniform (low, high)|(p -> 0.5p..1.5p), rayleigh (scale), normal (loc, scale),
+    logarithmic (low, high), delta (value), modules (v1, v2, ...), truncnorm
+    (low, high, loc, scale)."""
+    if isinstance(distribution_parameters, list):
+        distribution_parameters = tuple(distribution_parameters)
+    elif not isinstance(distribution_parameters, tuple):
+        distribution_parameters = (distribution_parameters,)
+    p = distribution_parameters
+    if distribution_name == "uniform":
+        low, high = (0.5 * p[0], 1.5 * p[0]) if len(p) == 1 else (p[0], p[1])
+        return np.random.uniform(low, high, size=shape)
+    if distribution_name == "rayleigh":
+        return np.random.rayleigh(scale=p[0], size=shape)
+    if distribution_name == "normal":
+        return np.random.normal(loc=p[0], scale=p[1], size=shape)
+    if distribution_name == "logarithmic":
+        assert len(shape) == 1, "Logarithmic distribution only works for 1D arrays"
+        return np.logspace(np.log10(p[0]), np.log10(p[1]), num=shape[0], base=10)
+    if distribution_name == "delta":
+        return p[0] * np.ones(shape)
+    if distribution_name == "modules":
+        assert len(shape) == 1, "Modules distribution only works for 1D arrays"
+        per = shape[0] // len(p)
+        out = p[-1] * np.ones(shape)  # the remainder joins the last module
+        for i, val in enumerate(p):
+            out[i * per:(i + 1) * per] = val
+        return out
+    if distribution_name == "truncnorm":
+        from scipy import stats
+        lower, upper, mu, sigma = p[0], p[1], p[2], p[3]
+        return stats.truncnorm.rvs((lower - mu) / sigma, (upper - mu) / sigma, scale=sigma, loc=mu, size=shape)
+    raise ValueError("This distribution is not recognised")
+
+
+def create_random_assembly(tuning_distance_distribution="uniform", tuning_distance=(0.02, 0.3),
+                           tuning_angle_distribution="uniform", tuning_angle=(0.0, 360.0),
+                           sigma_angle_distribution="uniform", sigma_angle=(10, 30),
+                           sigma_distance_distribution="diverging", sigma_distance=(0.08, 12), n=10, **kwargs):
+    """Tuning parameters of a random population of vector cells: returns
+    (tuning_distance, tuning_angle [rad], sigma_distance, sigma_angle [rad]).
+    Lists/arrays are taken verbatim (and fix n); tuples parameterise a
+    distribution.  "diverging" sigma_distance = xi + tuning_distance/beta."""
+    given = [p for p in (tuning_distance, tuning_angle, sigma_distance, sigma_angle)
+             if isinstance(p, (list, np.ndarray))]
+    if len(given) == 1:
+        n = len(given[0])
+    elif len(given) > 1:
+        lengths = {len(p) for p in given}
+        assert len(lengths) == 1, "If more than one parameter is passed as a list, they must all have the same length"
+        n = lengths.pop()
+
+    def draw(value, dist):
+        if isinstance(value, (list, np.ndarray)):
+            return np.array(value)
+        if isinstance(value, tuple):
+            return distribution_sampler(dist, value, shape=(n,))
+        return value
+
+    tuning_distance = np.abs(draw(tuning_distance, tuning_distance_distribution))
+    if isinstance(sigma_distance, tuple) and sigma_distance_distribution == "diverging":
+        sigma_distance = sigma_distance[0] + tuning_distance / sigma_distance[1]
+    else:
+        sigma_distance = draw(sigma_distance, sigma_distance_distribution)
+    tuning_angle = draw(tuning_angle, tuning_angle_distribution)
+    sigma_angle = draw(sigma_angle, sigma_angle_distribution)
+    tuning_angle = np.asarray(tuning_angle, dtype=float) * (np.pi / 180)
+    sigma_angle = np.asarray(sigma_angle, dtype=float) * (np.pi / 180)
+    return tuning_distance, tuning_angle, sigma_distance, sigma_angle

@@ -1,0 +1,348 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through
+the Python drop-in classes and hence the C ABI, against
+  (a) golden vectors produced by the reference itself (tests/golden/*.npz), and
+  (b) the float64 CPU oracle (oracle/riab_oracle.py) on seeded inputs.
+
+Tolerances (stated per test):
+  * firing rates: |gpu - ref| <= 1e-5 * |ref| (+ a floor of 1e-5 * (max_fr-min_fr)
+    only for the summed / rectified cells — GridCells, BVCs — where the rate passes
+    through zero; BASELINE.json north_star: "within 1e-5 relative fp32");
+  * motion (float64 arithmetic): 1e-9 relative per step;
+  * spikes, Philox words, discrete decisions: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import riab_oracle as orc
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def riab():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    import ratinabox_amd
+    return ratinabox_amd
+
+
+def assert_rates(got, ref, scale=1.0, floor=0.0):
+    """|got-ref| <= RTOL*|ref| + floor*RTOL*scale (+ fp32 underflow)."""
+    got, ref = np.asarray(got, float), np.asarray(ref, float)
+    assert got.shape == ref.shape
+    tol = RTOL * np.abs(ref) + floor * RTOL * scale + 1e-37
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), (f"{bad.sum()} / {bad.size} outside tolerance; worst rel err "
+                           f"{np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)):.3e}, "
+                           f"worst abs err {np.max(np.abs(got - ref)):.3e}")
+
+
+def make_env(riab, walls=(), **kw):
+    return riab.Environment(dict(walls=[np.asarray(w).tolist() for w in walls], **kw))
+
+
+# ----------------------------------------------------------------------------- rates vs reference
+@pytest.mark.parametrize("desc", ["gaussian", "gaussian_threshold", "diff_of_gaussians", "one_hot", "top_hat"])
+def test_place_cells_vs_reference(riab, desc):
+    g = gu.load("rates.npz")
+    Ag = riab.Agent(make_env(riab))
+    PCs = riab.PlaceCells(Ag, {"place_cell_centres": g[f"pc_{desc}_centres"], "description": desc, "widths": 0.2,
+                               "min_fr": 0.1, "max_fr": 2.0, "wall_geometry": "euclidean"})
+    PCs.place_cell_widths = g[f"pc_{desc}_widths"]
+    got = PCs.get_state(evaluate_at=None, pos=g["pos"])
+    ref = g[f"pc_{desc}_rates"]
+    if desc in ("one_hot", "top_hat"):
+        # discrete outputs: identical except where an fp32 distance comparison is a tie
+        assert (got != ref).mean() < 2e-4
+    else:
+        # thresholded / difference outputs pass through zero: floor on the 1.9 Hz range
+        assert_rates(got, ref, scale=1.9, floor=0.0 if desc == "gaussian" else 1.0)
+
+
+def test_place_cells_geometries_vs_reference(riab):
+    g = gu.load("rates.npz")
+    Ag = riab.Agent(make_env(riab))
+    PCs = riab.PlaceCells(Ag, {"place_cell_centres": g["pc_big_centres"], "wall_geometry": "euclidean"})
+    assert_rates(PCs.get_state(evaluate_at=None, pos=g["pos"][:64]), g["pc_big_rates"])
+    AgM = riab.Agent(make_env(riab, g["maze_walls"][4:]))
+    PCs = riab.PlaceCells(AgM, {"place_cell_centres": g["pc_los_centres"], "wall_geometry": "line_of_sight",
+                                "widths": 0.25})
+    assert_rates(PCs.get_state(evaluate_at=None, pos=g["pos"]), g["pc_los_rates"])
+    AgG = riab.Agent(make_env(riab, g["geo_walls"][4:]))
+    PCs = riab.PlaceCells(AgG, {"place_cell_centres": g["pc_geo_centres"], "wall_geometry": "geodesic",
+                                "description": "gaussian_threshold"})
+    assert_rates(PCs.get_state(evaluate_at=None, pos=g["pos"]), g["pc_geo_rates"], floor=1.0)
+    AgP = riab.Agent(make_env(riab, boundary_conditions="periodic"))
+    PCs = riab.PlaceCells(AgP, {"place_cell_centres": g["pc_per_centres"], "widths": 0.15})
+    assert_rates(PCs.get_state(evaluate_at=None, pos=g["pos"]), g["pc_per_rates"])
+
+
+@pytest.mark.parametrize("tag,kw", [("rectified_cosines", dict(description="rectified_cosines", max_fr=1.5)),
+                                    ("shifted_cosines", dict(description="shifted_cosines", max_fr=1.5)),
+                                    ("rand", dict(width_ratio=0.5))])
+def test_grid_cells_vs_reference(riab, tag, kw):
+    g = gu.load("rates.npz")
+    Ag = riab.Agent(make_env(riab))
+    GCs = riab.GridCells(Ag, dict(gridscale=list(g[f"gc_{tag}_gridscales"]),
+                                  orientation=list(g[f"gc_{tag}_orientations"]),
+                                  phase_offset=g[f"gc_{tag}_phase_offsets"], **kw))
+    got = GCs.get_state(evaluate_at=None, pos=g["pos"])
+    assert_rates(got, g[f"gc_{tag}_rates"], scale=kw.get("max_fr", 1.0), floor=1.0)
+
+
+def _bvc(riab, Ag, g, tag, **kw):
+    return riab.BoundaryVectorCells(Ag, dict(tuning_distance=list(g[f"bvc_{tag}_tuning_distances"]),
+                                             tuning_angle=list(np.degrees(g[f"bvc_{tag}_tuning_angles"])),
+                                             sigma_distance=list(g[f"bvc_{tag}_sigma_distances"]),
+                                             sigma_angle=list(np.degrees(g[f"bvc_{tag}_sigma_angles"])), **kw))
+
+
+@pytest.mark.parametrize("tag", ["open", "maze"])
+def test_bvc_allocentric_vs_reference(riab, tag):
+    g = gu.load("rates.npz")
+    Ag = riab.Agent(make_env(riab, g["maze_walls"][4:] if tag == "maze" else ()))
+    B = _bvc(riab, Ag, g, tag)
+    np.testing.assert_allclose(B.cell_fr_norm, g[f"bvc_{tag}_cell_fr_norm"], rtol=1e-12)
+    got = B.get_state(evaluate_at=None, pos=g["pos"])
+    assert_rates(got, g[f"bvc_{tag}_rates"], floor=1.0)
+
+
+def test_bvc_egocentric_vs_reference(riab):
+    g = gu.load("rates.npz")
+    Ag = riab.Agent(make_env(riab, g["maze_walls"][4:]))
+    B = _bvc(riab, Ag, g, "ego", reference_frame="egocentric", max_fr=3.0, min_fr=0.5)
+    got = B.get_state(evaluate_at=None, pos=g["pos"][:48], head_direction=g["hd"][:48])
+    assert_rates(got, g["bvc_ego_rates"], scale=2.5, floor=1.0)
+
+
+def test_head_direction_cells_vs_reference(riab):
+    g = gu.load("rates.npz")
+    Ag = riab.Agent(make_env(riab))
+    H = riab.HeadDirectionCells(Ag, {"n": 24, "angular_spread_degrees": 30, "max_fr": 2.0, "min_fr": 0.25})
+    got = H.get_state(evaluate_at=None, pos=g["pos"], head_direction=g["hd"])
+    assert_rates(got, g["hdc_rates"])
+
+
+# ----------------------------------------------------------------------------- motion vs reference
+def _agent_from_rows(riab, g, rows, precision=64):
+    p, kw, dt = gu.params_from(g)
+    env = make_env(riab, g["user_walls"], scale=float(g["env_scale"]), aspect=float(g["env_aspect"]),
+                   boundary_conditions=str(g["env_bc"]))
+    assert np.array_equal(env.walls, g["ref_walls"])
+    Ag = riab.Agent(env, dict(p, dt=dt, n_agents=len(rows), precision=precision))
+    for k, s in gu.PRE_SLICES.items():
+        setattr(Ag, k, rows[:, s])
+    return Ag, kw, dt
+
+
+@pytest.mark.parametrize("fname", gu.MOTION_FILES)
+def test_motion_single_steps_vs_reference(riab, fname):
+    """G2: every recorded (state, noise) pair of the reference, one HIP step each."""
+    g = gu.load(fname)
+    Ag, kw, dt = _agent_from_rows(riab, g, g["pre"])
+    drift = g["drift"] if g["drift"].shape[0] else None
+    Ag.update(drift_velocity=drift, drift_to_random_strength_ratio=float(g["drift_ratio"]), noise=g["z"].T, **kw)
+    post = g["post"]
+    for k, s in gu.PRE_SLICES.items():
+        np.testing.assert_allclose(getattr(Ag, k), post[:, s], rtol=1e-9, atol=1e-12, err_msg=k)
+    np.testing.assert_allclose(Ag.measured_rotational_velocity, post[:, 10], rtol=1e-7, atol=1e-6)
+    fin = np.isfinite(post[:, 11])
+    np.testing.assert_allclose(Ag.distance_to_closest_wall[fin], post[fin, 11], rtol=1e-9)
+    assert Ag.diagnostics["bounces"] == int(g["n_bounces"].sum())
+    assert Ag.diagnostics["bounce_saturations"] == 0
+
+
+@pytest.mark.parametrize("fname", [f for f in gu.MOTION_FILES if "drift" not in f])
+def test_motion_rollout_vs_reference(riab, fname):
+    """G3: the reference's whole noise stream replayed, per-step API and fused simulate()."""
+    g = gu.load(fname)
+    T = g["roll_z"].shape[0]
+    z = np.transpose(g["roll_z"], (0, 2, 1))  # (T, 2, B)
+    Ag, kw, dt = _agent_from_rows(riab, g, g["roll_state0"])
+    for t in range(T):
+        Ag.update(noise=z[t], **kw)
+    np.testing.assert_allclose(Ag.history["pos"], g["roll_pos"][1:], rtol=2e-6, atol=2e-7)  # fp32 history rows
+    np.testing.assert_allclose(Ag.pos, g["roll_pos"][-1], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(Ag.distance_travelled, g["roll_final"][:, 9], rtol=1e-7)
+    Ag2, kw, dt = _agent_from_rows(riab, g, g["roll_state0"])
+    Ag2.simulate(T, noise=torch.as_tensor(z), chunk=64, **kw)
+    assert np.array_equal(Ag2.pos, Ag.pos)  # same kernel, same inputs: bit-identical
+    assert np.array_equal(Ag2.history["pos"], Ag.history["pos"])
+    assert np.allclose(Ag2.history["t"], Ag.history["t"])
+
+
+def test_motion_fp32_variant_tracks_oracle(riab):
+    """precision=32: single steps agree with the float64 reference to fp32 accuracy."""
+    g = gu.load("motion_maze_dt10ms.npz")
+    Ag, kw, dt = _agent_from_rows(riab, g, g["pre"], precision=32)
+    Ag.update(noise=g["z"].T, **kw)
+    ok = g["n_bounces"] == 0
+    np.testing.assert_allclose(Ag.pos[ok], g["post"][ok, 0:2], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(Ag.velocity[ok], g["post"][ok, 2:4], rtol=2e-4, atol=2e-6)
+
+
+def test_production_rng_matches_host_philox(riab):
+    """In-kernel Philox + Box-Muller == oracle.motion_normals; the trajectory driven by it
+    equals the oracle driven by the same normals, and does not depend on sharding."""
+    env = make_env(riab)
+    B, T, seed = 64, 20, 987654321
+    np.random.seed(3)
+    Ag = riab.Agent(env, {"n_agents": B, "dt": 0.02, "seed": seed})
+    st0 = {k: np.array(getattr(Ag, k)) for k in gu.PRE_SLICES}
+    zout = torch.zeros((T, 2, B), dtype=torch.float64, device="cuda")
+    Ag._advance(T, None, None, 1, {}, z_out=zout)
+    torch.cuda.synchronize()
+    z = zout.cpu().numpy()
+    for t in range(T):
+        z0, z1, _, _ = orc.motion_normals(seed, t, np.arange(B))
+        np.testing.assert_allclose(z[t, 0], z0, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(z[t, 1], z1, rtol=1e-12, atol=1e-14)
+    st = dict(st0, measured_rotational_velocity=np.zeros(B), distance_to_closest_wall=np.full(B, np.inf))
+    oenv = orc.EnvSpec()
+    for t in range(T):
+        st = orc.agent_step(oenv, st, 0.02, z[t, 0], z[t, 1])
+    np.testing.assert_allclose(Ag.pos, st["pos"], rtol=1e-9, atol=1e-12)
+    # shard [32:64] run on its own with agent_id0=32 reproduces the same agents
+    np.random.seed(3)
+    Ag2 = riab.Agent(env, {"n_agents": 32, "dt": 0.02, "seed": seed, "agent_id0": 32})
+    for k in gu.PRE_SLICES:
+        setattr(Ag2, k, st0[k][32:])
+    Ag2.simulate(T)
+    assert np.array_equal(Ag2.pos, Ag.pos[32:])
+
+
+# ----------------------------------------------------------------------------- Neurons.update / spikes
+def test_update_noise_and_spikes_vs_reference(riab):
+    """G4: Neurons.update end to end for one agent with the reference's recorded noise
+    normals and spike uniforms: rates within 1e-5, spikes bit-exact."""
+    g = gu.load("update_init.npz")
+    dt = float(g["upd_dt"])
+    Ag = riab.Agent(make_env(riab), {"dt": dt})
+    PCs = riab.PlaceCells(Ag, {"place_cell_centres": g["upd_centres"], "max_fr": 40.0, "noise_std": 0.5,
+                               "noise_coherence_time": 0.2, "wall_geometry": "euclidean"})
+    for t in range(g["upd_pos"].shape[0]):
+        Ag.pos = g["upd_pos"][t]
+        Ag.t += dt
+        PCs.update(spike_uniforms=g["upd_u"][t][:, None], noise_normals=g["upd_z"][t][:, None])
+        np.testing.assert_allclose(PCs.firingrate, g["upd_fr"][t], rtol=2e-5, atol=2e-5)
+    assert np.array_equal(PCs.history["spikes"], g["upd_spikes"])
+    np.testing.assert_allclose(PCs.noise, g["upd_noise"][-1], rtol=1e-4, atol=1e-5)
+
+
+def test_philox_spikes_bit_exact(riab):
+    """Production mode: the kernel's spikes == the exactly-specified rule applied on the host
+    to the kernel's own fp32 rates and the host-regenerated Philox uniforms."""
+    np.random.seed(5)
+    B, n, T, seed = 256, 96, 6, 42
+    Ag = riab.Agent(make_env(riab), {"n_agents": B, "dt": 0.01, "seed": seed, "agent_id0": 1024})
+    PCs = riab.PlaceCells(Ag, {"n": n, "max_fr": 30.0})
+    HDs = riab.HeadDirectionCells(Ag, {"n": 12, "max_fr": 50.0})
+    for t in range(T):
+        Ag.update()
+        PCs.update()
+        HDs.update()
+    for pop in (PCs, HDs):
+        fr, sp = pop.get_history_tensors()
+        fr, sp = fr.cpu().numpy(), sp.cpu().numpy().astype(bool)
+        for t in range(T):
+            u = orc.spike_uniforms(seed, t + 1, pop.pop_id, pop.n, B, agent_id0=1024)
+            assert np.array_equal(sp[t], orc.spikes_f32(fr[t], u, 0.01)), (pop.name, t)
+        assert sp.sum() > 0
+    # fused path: same uniforms, same rule
+    np.random.seed(5)
+    Ag2 = riab.Agent(make_env(riab), {"n_agents": B, "dt": 0.01, "seed": seed, "agent_id0": 1024})
+    P2 = riab.PlaceCells(Ag2, {"place_cell_centres": PCs.place_cell_centres, "max_fr": 30.0})
+    H2 = riab.HeadDirectionCells(Ag2, {"n": 12, "max_fr": 50.0})
+    for k in gu.PRE_SLICES:
+        pass
+    Ag2.simulate(T, chunk=4)
+    torch.cuda.synchronize()
+    assert np.array_equal(Ag2.history["pos"], Ag.history["pos"])
+    assert np.array_equal(P2.history["firingrate"], PCs.history["firingrate"])
+    assert np.array_equal(P2.history["spikes"], PCs.history["spikes"])
+    assert np.array_equal(H2.history["spikes"], HDs.history["spikes"])
+
+
+# ----------------------------------------------------------------------------- oracle on seeded inputs, config shapes
+def test_config2_shape_vs_oracle(riab):
+    """BASELINE config 2 shape (4096 agents x 1024 gaussian PlaceCells, open box): rates of a
+    fused run against the oracle on the same fp32 trajectory rows (sampled steps), plus
+    size-independent properties on all of it."""
+    np.random.seed(0)
+    B, n, T = 4096, 1024, 24
+    Ag = riab.Agent(make_env(riab), {"n_agents": B, "dt": 0.01, "seed": 1234})
+    PCs = riab.PlaceCells(Ag, {"n": n})
+    traj = Ag.simulate(T, chunk=8)
+    torch.cuda.synchronize()
+    fr, sp = PCs.get_history_tensors()
+    assert fr.shape == (T, n, B) and sp.shape == (T, n, B)
+    assert torch.isfinite(fr).all() and float(fr.min()) >= 0 and float(fr.max()) <= 1
+    pos = traj[:, 0:2].cpu().numpy()  # (T, 2, B) fp32
+    assert (pos > 0).all() and (pos < 1).all()  # agents never leave the box
+    c = np.asarray(PCs.place_cell_centres)
+    for t in (0, T // 2, T - 1):
+        ref = orc.place_cells(orc.EnvSpec(), pos[t].T.astype(np.float64), c, 0.2)
+        assert_rates(fr[t].cpu().numpy(), ref)
+    # spikes only where the rate allows them; overall count matches sum(dt*rate) within 5 sigma
+    expected = float((0.01 * fr.double()).sum())
+    got = float(sp.sum())
+    assert abs(got - expected) < 5 * np.sqrt(expected) + 1
+
+
+def test_config3_shape_vs_oracle(riab):
+    """BASELINE config 3 shape: GridCells + BVCs in the 9-wall maze, against the oracle."""
+    np.random.seed(1)
+    B, T = 512, 6
+    env = make_env(riab, [[[.2, 0], [.2, .4]], [[.4, 1], [.4, .6]], [[.6, 0], [.6, .4]], [[.8, 1], [.8, .6]],
+                          [[.3, .5], [.7, .5]]])
+    Ag = riab.Agent(env, {"n_agents": B, "dt": 0.01})
+    GCs = riab.GridCells(Ag, {"n": 1024})
+    BVs = riab.BoundaryVectorCells(Ag, {"n": 256})
+    traj = Ag.simulate(T, chunk=4)
+    torch.cuda.synchronize()
+    pos = traj[T - 1, 0:2].cpu().numpy().T.astype(np.float64)
+    ref = orc.grid_cells(pos, GCs.gridscales, GCs.phase_offsets, GCs.w)
+    assert_rates(GCs.firingrate, ref, floor=1.0)
+    ref = orc.bvc(pos, env.walls, BVs.tuning_distances, BVs.tuning_angles, BVs.sigma_distances, BVs.sigma_angles)
+    assert_rates(BVs.firingrate, ref, floor=1.0)
+
+
+def test_edge_shapes(riab):
+    """Ragged / tiny shapes: a single agent, agent counts and position counts that are not
+    multiples of 4, a single cell."""
+    np.random.seed(2)
+    env = make_env(riab)
+    for B in (1, 3, 5, 66):
+        Ag = riab.Agent(env, {"n_agents": B, "dt": 0.05})
+        PCs = riab.PlaceCells(Ag, {"n": 1 if B == 1 else 7})
+        for _ in range(3):
+            Ag.update()
+            PCs.update()
+        assert np.asarray(Ag.pos).shape == ((2,) if B == 1 else (B, 2))
+        assert np.asarray(PCs.firingrate).shape == ((PCs.n,) if B == 1 else (PCs.n, B))
+        pos = np.asarray(Ag.pos, dtype=np.float32).astype(np.float64).reshape(-1, 2)
+        ref = orc.place_cells(orc.EnvSpec(), pos, PCs.place_cell_centres, 0.2)
+        assert_rates(np.asarray(PCs.firingrate).reshape(PCs.n, -1), ref, floor=0.01)
+        assert PCs.history["firingrate"].shape[0] == 3
+    PCs = riab.PlaceCells(Ag, {"n": 10})
+    for P in (1, 2, 7, 1001):
+        pos = np.random.RandomState(P).uniform(0, 1, (P, 2)).astype(np.float32).astype(np.float64)
+        got = PCs.get_state(evaluate_at=None, pos=pos)
+        assert got.shape == (10, P)
+        assert_rates(got, orc.place_cells(orc.EnvSpec(), pos, PCs.place_cell_centres, 0.2))
+    assert PCs.get_state(evaluate_at="all").shape == (10, env.flattened_discrete_coords.shape[0])
+
+
+def test_abi_rejects_bad_arguments(riab):
+    L = riab._lib
+    io = L.RiabRateIO()
+    assert L.lib.riab_place_cells(None, io, None, 4, 0, 0, 0.2, None) == -1
+    x = torch.zeros(64, device="cuda")
+    io.pos_x = io.pos_y = x.data_ptr()
+    io.rates = x.data_ptr()
+    io.T, io.B, io.pos_ld = 1, 6, 6
+    env, _ = make_env(riab).device_tables(torch.device("cuda"))
+    assert L.lib.riab_place_cells(env, io, L.ptr(x), 4, 0, 0, 0.2, None) == -2  # B % 4
+    assert "multiple of 4" in L.strerror(-2)
