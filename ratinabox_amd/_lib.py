@@ -6,6 +6,11 @@ fallback (the CPU restatement under oracle/ is test infrastructure only)."""
 import ctypes as C
 import os
 
+# torch must be imported BEFORE libriab_hip.so is loaded: torch bundles its own HIP runtime
+# (soname libamdhip64.so.7, requested by torch as "libamdhip64.so"); loading ours first would
+# put a second runtime in the process and the later one finds no device.
+import torch  # noqa: F401
+
 from . import _build
 
 ABI_VERSION = 1

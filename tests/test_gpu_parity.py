@@ -55,7 +55,7 @@ def test_place_cells_vs_reference(riab, desc):
     ref = g[f"pc_{desc}_rates"]
     if desc in ("one_hot", "top_hat"):
         # discrete outputs: identical except where an fp32 distance comparison is a tie
-        assert (got != ref).mean() < 2e-4
+        assert (~np.isclose(got, ref, rtol=1e-6)).mean() < 2e-4
     else:
         # thresholded / difference outputs pass through zero: floor on the 1.9 Hz range
         assert_rates(got, ref, scale=1.9, floor=0.0 if desc == "gaussian" else 1.0)
