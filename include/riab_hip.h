@@ -162,9 +162,9 @@ enum { RIAB_GEOM_EUCLIDEAN = 0, RIAB_GEOM_LINE_OF_SIGHT = 1, RIAB_GEOM_GEODESIC 
 
 /* PlaceCells.get_state (Neurons.py:936-981) with
  * Environment.get_distances_between___accounting_for_environment
- * (Environment.py:677-779).  cells device float32 [3][n]: row 0 centre x, row 1
- * centre y, row 2 k = -log2(e)/(2 w^2) (host, float64, rounded once) so that
- * the gaussian is exp2(d^2 * k).  top_hat_width is the scalar `widths`
+ * (Environment.py:677-779).  cells device float32 [n][3] = (centre x, centre y,
+ * k = -log2(e)/(2 w^2)) per cell (host, float64, rounded once) so that the
+ * gaussian is exp2(d^2 * k).  top_hat_width is the scalar `widths`
  * parameter the reference's top_hat compares against (Neurons.py:976).
  * line_of_sight / geodesic read env->walls[4:] (Environment.py:715-717). */
 int riab_place_cells(const RiabEnv* env, const RiabRateIO* io, const float* cells, int32_t n,
@@ -173,8 +173,8 @@ int riab_place_cells(const RiabEnv* env, const RiabRateIO* io, const float* cell
 
 enum { RIAB_GC_RECTIFIED = 0, RIAB_GC_SHIFTED = 1 };
 
-/* GridCells.get_state, 2D (Neurons.py:1172-1236).  table device float32 [9][n]:
- * rows 3i..3i+2 = (a_i, bx_i, by_i) with the phase of cosine i, in
+/* GridCells.get_state, 2D (Neurons.py:1172-1236).  table device float32 [n][9]:
+ * entries 3i..3i+2 of a cell = (a_i, bx_i, by_i) with the phase of cosine i, in
  * revolutions, phi_i/2pi = a_i - (x*bx_i + y*by_i); built on the host in
  * float64 from gridscales, phase_offsets and w (Neurons.py:1154-1161, 1192-1203).
  * f0 = firing_rate_at_full_width (Neurons.py:1211). */
@@ -182,9 +182,9 @@ int riab_grid_cells(const RiabRateIO* io, const float* table, int32_t n, int32_t
                     float f0, riab_stream_t stream);
 
 /* HeadDirectionCells.get_state, 2D (Neurons.py:2421-2485): von Mises of
- * utils.get_angle(head_direction).  pref device float32 [n], kappa = 1/sigma^2
- * device float32 [n].  Needs io->hd_x / hd_y. */
-int riab_head_direction_cells(const RiabRateIO* io, const float* pref, const float* kappa, int32_t n,
+ * utils.get_angle(head_direction).  table device float32 [n][2] = (preferred
+ * angle, log2(e)/sigma^2) per cell.  Needs io->hd_x / hd_y. */
+int riab_head_direction_cells(const RiabRateIO* io, const float* table, int32_t n,
                               riab_stream_t stream);
 
 /* BoundaryVectorCells.get_state (Neurons.py:1617-1778) with utils.vector_intercepts

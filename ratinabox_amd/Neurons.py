@@ -356,9 +356,9 @@ class PlaceCells(Neurons):
         widths = np.asarray(self.place_cell_widths, dtype=np.float64) * np.ones(n)
 
         def build():
-            tab = np.empty((3, n), dtype=np.float64)
-            tab[0], tab[1] = centres[:, 0], centres[:, 1]
-            tab[2] = -LOG2E / (2 * widths ** 2)
+            tab = np.empty((n, 3), dtype=np.float64)
+            tab[:, 0], tab[:, 1] = centres[:, 0], centres[:, 1]
+            tab[:, 2] = -LOG2E / (2 * widths ** 2)
             return torch.from_numpy(tab.astype(np.float32)).to(self._device)
 
         tab = self._tables((centres, widths), build)
@@ -439,12 +439,12 @@ class GridCells(Neurons):
         def build():
             # phase_i / 2pi = (origin - p) . w_i / lambda = a_i - (x bx_i + y by_i)   (Neurons.py:1192-1203)
             origin = gs.reshape(-1, 1) * ph / (2 * np.pi)
-            tab = np.empty((9, n), dtype=np.float64)
+            tab = np.empty((n, 9), dtype=np.float64)
             for i in range(3):
                 a = (origin[:, 0] * w[:, i, 0] + origin[:, 1] * w[:, i, 1]) / gs
-                tab[3 * i] = a - np.floor(a)
-                tab[3 * i + 1] = w[:, i, 0] / gs
-                tab[3 * i + 2] = w[:, i, 1] / gs
+                tab[:, 3 * i] = a - np.floor(a)
+                tab[:, 3 * i + 1] = w[:, i, 0] / gs
+                tab[:, 3 * i + 2] = w[:, i, 1] / gs
             return torch.from_numpy(tab.astype(np.float32)).to(self._device)
 
         tab = self._tables((gs, ph, w), build)
@@ -587,8 +587,8 @@ class HeadDirectionCells(Neurons):
 
         def build():
             f32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self._device)  # noqa: E731
-            return f32(pref), f32(LOG2E / sig ** 2)
+            return f32(np.stack((pref, LOG2E / sig ** 2), axis=-1))
 
-        pref_t, k2_t = self._tables((pref, sig), build)
-        rc = _L.lib.riab_head_direction_cells(io, _L.ptr(pref_t), _L.ptr(k2_t), n, stream)
+        tab = self._tables((pref, sig), build)
+        rc = _L.lib.riab_head_direction_cells(io, _L.ptr(tab), n, stream)
         _L.check(rc, "riab_head_direction_cells")

@@ -1,0 +1,101 @@
+"""Kernel-level microbenchmarks on one MI355X (HIP events on the launch stream).
+    python tools/microbench.py [agent] [fill] [rates]
+"""
+import sys
+import os
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ratinabox_amd as riab  # noqa: E402
+
+L = riab._lib
+
+
+def timeit(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts))
+
+
+MAZE = [[[.2, 0], [.2, .4]], [[.4, 1], [.4, .6]], [[.6, 0], [.6, .4]], [[.8, 1], [.8, .6]], [[.3, .5], [.7, .5]]]
+
+
+def agent():
+    T = 256
+    for B in (4096, 32768):
+        for walls, wname in (([], "open"), (MAZE, "maze")):
+            for prec in (64, 32):
+                for mode in ("philox", "z_in"):
+                    np.random.seed(0)
+                    env = riab.Environment({"walls": walls})
+                    ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "precision": prec, "save_history": True})
+                    z = torch.randn((T, 2, B), dtype=torch.float64, device="cuda") if mode == "z_in" else None
+                    hist = torch.empty((T, 8, B), dtype=torch.float32, device="cuda")
+
+                    def run():
+                        kw = {} if z is None else {"noise": z}
+                        ag._advance(T, None, None, 1, kw, hist_view=hist)
+                    ms = timeit(run)
+                    print(f"agent_step B={B} {wname} f{prec} {mode}: {ms / T * 1e3:.2f} us/step  "
+                          f"{B * T / ms / 1e6:.1f} M agent-steps/s", flush=True)
+
+
+def fill():
+    for gb in (0.25, 1, 4):
+        n = int(gb * (1 << 30))
+        buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ms = timeit(lambda: L.check(L.lib.riab_fill(L.ptr(buf), n, 1.0, L.current_stream()), "fill"))
+        print(f"riab_fill {gb} GiB: {ms:.3f} ms  {n / ms / 1e6:.0f} GB/s", flush=True)
+        ms = timeit(lambda: buf.fill_(1))
+        print(f"torch fill_ {gb} GiB: {ms:.3f} ms  {n / ms / 1e6:.0f} GB/s", flush=True)
+    a = torch.empty(1 << 30, dtype=torch.float32, device="cuda")
+    b = torch.empty(1 << 30, dtype=torch.float32, device="cuda")
+    ms = timeit(lambda: b.copy_(a))
+    print(f"torch copy 4 GiB -> 4 GiB: {ms:.3f} ms  {2 * 4 * (1 << 30) / ms / 1e6:.0f} GB/s (read+write)", flush=True)
+
+
+def rates():
+    B, T = 4096, 128
+    np.random.seed(0)
+    env = riab.Environment({"walls": MAZE})
+    ag = riab.Agent(env, {"n_agents": B, "dt": 0.01})
+    traj = ag.simulate(T)
+    torch.cuda.synchronize()
+    s = L.current_stream
+    for name, pop, spikes in (
+            ("PlaceCells 1024", riab.PlaceCells(ag, {"n": 1024, "wall_geometry": "euclidean"}), False),
+            ("PlaceCells 1024 +spikes", riab.PlaceCells(ag, {"n": 1024, "wall_geometry": "euclidean"}), True),
+            ("PlaceCells 4096", riab.PlaceCells(ag, {"n": 4096, "wall_geometry": "euclidean"}), False),
+            ("PlaceCells 1024 line_of_sight", riab.PlaceCells(ag, {"n": 1024, "wall_geometry": "line_of_sight"}), False),
+            ("GridCells 1024", riab.GridCells(ag, {"n": 1024}), False),
+            ("GridCells 1024 +spikes", riab.GridCells(ag, {"n": 1024}), True),
+            ("HeadDirectionCells 256", riab.HeadDirectionCells(ag, {"n": 256}), False),
+            ("BVC 256", riab.BoundaryVectorCells(ag, {"n": 256}), False),
+            ("BVC 256 egocentric", riab.BoundaryVectorCells(ag, {"n": 256, "reference_frame": "egocentric"}), False)):
+        n = pop.n
+        Tt = T if "BVC" not in name else 16
+        fr = torch.empty((Tt, n, B), dtype=torch.float32, device="cuda")
+        sp = torch.empty((Tt, n, B), dtype=torch.uint8, device="cuda") if spikes else None
+        out = dict(fr=fr, sp=sp, ring=None)
+        ms = timeit(lambda: pop._rates_from_trajectory(traj[:Tt], out, 0, Tt, 0, 0.01, stream=s()))
+        byt = Tt * B * n * (5 if spikes else 4)
+        print(f"{name}: {ms:.3f} ms for {Tt}x{B} positions  {Tt * B / ms / 1e3:.1f} M pos/s  "
+              f"{byt / ms / 1e6:.0f} GB/s written", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["agent", "fill", "rates"]
+    for w in which:
+        globals()[w]()
