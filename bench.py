@@ -172,6 +172,8 @@ def main():
 
     if not args.per_step:
         ag._profile_hook = hook
+    ag.preallocate_history(K)  # output buffers are allocated outside the timed region
+    torch.cuda.synchronize()
 
     barrier()
     torch.cuda.synchronize()

@@ -604,14 +604,18 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def motion_normals(seed, step, agent_ids):
-    """The device's per-(step, agent) draws: Box-Muller on Philox words.
+    """The device's per-(step, agent) motion draws: Box-Muller on the top 24 bits of
+    Philox words 0/1 (2/3 are the spare pair of the zero-displacement branch).  The
+    device evaluates log2 / sin / cos with the fp32 hardware approximations, so this
+    float64 restatement agrees to ~1e-6 (the Philox words themselves are bit-exact);
+    trajectories are compared through the `z_out` record of the kernel.
     Returns z_rot, z_speed, z_zero0, z_zero1 (float64)."""
     agent_ids = np.asarray(agent_ids, dtype=np.uint64)
     x0, x1, x2, x3 = philox4x32_10(step & 0xFFFFFFFF, (step >> 32) & 0xFFFFFFFF, agent_ids, TAG_MOTION,
                                    seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     def bm(a, b):
-        u1 = (a.astype(np.float64) + 0.5) * 2.0**-32
-        u2 = (b.astype(np.float64) + 0.5) * 2.0**-32
+        u1 = ((a >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0**-24
+        u2 = (b >> np.uint32(8)).astype(np.float64) * 2.0**-24
         r = np.sqrt(-2.0 * np.log(u1))
         return r * np.cos(TWO_PI * u2), r * np.sin(TWO_PI * u2)
     z0, z1 = bm(x0, x1)

@@ -324,6 +324,17 @@ class Agent:
             N._finish_rows(out, n_steps, self._times[-n_steps:] if self.save_history else None)
         return traj
 
+    def preallocate_history(self, n_steps):
+        """Allocate the HBM for `n_steps` more history rows of the agent and of every Neurons
+        population now, so that the stepping loop does not allocate (new; optional)."""
+        if self.save_history:
+            self._hist.preallocate(n_steps)
+        for N in self.Neurons:
+            if N.save_history:
+                N._hist_fr.preallocate(n_steps)
+                if N.save_spikes:
+                    N._hist_sp.preallocate(n_steps)
+
     # ---- history --------------------------------------------------------------------------------
     def _materialise_history(self):
         h = self._hist.stack()[:, :, :self._B].cpu().numpy()  # (T, 8, B)

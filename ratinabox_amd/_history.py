@@ -39,6 +39,15 @@ class DeviceHistory:
         self.filled.append(T)
         return self.chunks[-1][:T]
 
+    def preallocate(self, T):
+        """Make sure the next `reserve(T)` finds T free rows (allocation happens here, not
+        in the stepping loop)."""
+        T = int(T)
+        if self.chunks and self.chunks[-1].shape[0] - self.filled[-1] >= T:
+            return
+        self.chunks.append(torch.empty((T, *self.row_shape), dtype=self.dtype, device=self.device))
+        self.filled.append(0)
+
     def stack(self):
         """All filled rows as one tensor `[T_total, *row_shape]`."""
         parts = [c[:f] for c, f in zip(self.chunks, self.filled) if f]

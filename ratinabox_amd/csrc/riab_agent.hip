@@ -52,6 +52,34 @@ __device__ __forceinline__ float r_ndtri(float u) { return normcdfinvf(u); }
 __device__ __forceinline__ double r_ndtr(double x) { return normcdf(x); }
 __device__ __forceinline__ float r_ndtr(float x) { return normcdff(x); }
 
+// sin/cos of the per-step heading increment rot*dt (|x| is a few 1e-2): Taylor in x^2 for
+// |x| < 0.5 (truncation < 1e-18), the library routine otherwise.
+__device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
+  if (fabs(x) < 0.5) {
+    const double x2 = x * x;
+    double sp = -1.0 / 1307674368000.0;                // -1/15!
+    sp = fma(sp, x2, 1.0 / 6227020800.0);              //  1/13!
+    sp = fma(sp, x2, -1.0 / 39916800.0);               // -1/11!
+    sp = fma(sp, x2, 1.0 / 362880.0);                  //  1/9!
+    sp = fma(sp, x2, -1.0 / 5040.0);                   // -1/7!
+    sp = fma(sp, x2, 1.0 / 120.0);                     //  1/5!
+    sp = fma(sp, x2, -1.0 / 6.0);                      // -1/3!
+    *s = fma(sp * x2, x, x);
+    double cp = 1.0 / 20922789888000.0;                //  1/16!
+    cp = fma(cp, x2, -1.0 / 87178291200.0);            // -1/14!
+    cp = fma(cp, x2, 1.0 / 479001600.0);               //  1/12!
+    cp = fma(cp, x2, -1.0 / 3628800.0);                // -1/10!
+    cp = fma(cp, x2, 1.0 / 40320.0);                   //  1/8!
+    cp = fma(cp, x2, -1.0 / 720.0);                    // -1/6!
+    cp = fma(cp, x2, 1.0 / 24.0);                      //  1/4!
+    cp = fma(cp, x2, -0.5);
+    *c = fma(cp, x2, 1.0);
+  } else {
+    sincos(x, s, c);
+  }
+}
+__device__ __forceinline__ void sincos_small(float x, float* s, float* c) { sincosf(x, s, c); }
+
 // np.mod(a, 2pi) for a in (-2pi, 2pi)
 template <class R>
 __device__ __forceinline__ R mod_2pi(R a) {
@@ -130,28 +158,30 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   const R cpos = (R)6 * (g * g);
   const bool repel = (m.wall_repel_strength_kw != 0.0) && nw > 0;
   const R e0 = (R)a.e0, e1 = (R)a.e1, e2 = (R)a.e2, e3 = (R)a.e3;
+  // divisions by loop constants become multiplications (<= 1 ulp from the reference's quotient)
+  const R inv_dt = (R)(1.0 / m.dt);
+  const bool hd_instant = m.hd_tau <= m.dt;
+  const R hd_gain = (R)(m.dt / m.hd_tau), hd_keep = (R)(1.0 - m.dt / m.hd_tau);
 
   for (int t = 0; t < a.T; ++t) {
     // ---- the step's standard normals -------------------------------------------------------
-    R z_rot, z_spd, z_s0 = 0, z_s1 = 0;
+    R z_rot, z_spd;
+    uint32_t zw2 = 0x80000000u, zw3 = 0;
     if (a.z_in) {
       z_rot = (R)a.z_in[((int64_t)t * 2 + 0) * B + b];
       z_spd = (R)a.z_in[((int64_t)t * 2 + 1) * B + b];
     } else {
       const uint64_t step = a.step0 + (uint64_t)t;
       const u32x4 w = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), aid, RIAB_TAG_MOTION, a.k0, a.k1);
-      // Box-Muller in float64 (oracle: motion_normals)
-      const double u1 = ((double)w.x + 0.5) * 0x1.0p-32, u2 = ((double)w.y + 0.5) * 0x1.0p-32;
-      const double rr = sqrt(-2.0 * log(u1));
-      double sn, cs;
-      sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
-      z_rot = (R)(rr * cs);
-      z_spd = (R)(rr * sn);
-      const double u3 = ((double)w.z + 0.5) * 0x1.0p-32, u4 = ((double)w.w + 0.5) * 0x1.0p-32;
-      const double r2 = sqrt(-2.0 * log(u3));
-      sincos(6.283185307179586476925286766559 * u4, &sn, &cs);
-      z_s0 = (R)(r2 * cs);
-      z_s1 = (R)(r2 * sn);
+      // Box-Muller on the Philox words with the hardware log2 / sin / cos (the draws only need
+      // to be N(0,1) and a pure function of (seed, step, agent); `z_out` records them).  The
+      // second pair is only consumed by the zero-displacement branch.
+      const float u1 = ((float)(w.x >> 8) + 0.5f) * 0x1.0p-24f, u2 = (float)(w.y >> 8) * 0x1.0p-24f;
+      const float rr = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1)
+      z_rot = (R)(rr * __builtin_amdgcn_cosf(u2));
+      z_spd = (R)(rr * __builtin_amdgcn_sinf(u2));
+      zw2 = w.z;
+      zw3 = w.w;
     }
     if (a.z_out) {
       a.z_out[((int64_t)t * 2 + 0) * B + b] = (double)z_rot;
@@ -163,7 +193,7 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     rot += (R)m.rot_theta_kw * ((R)m.rot_drift_kw - rot) * dt + (R)m.rot_sigma_kw * (dt * z_rot);
     {
       R sn, cs;
-      r_sincos(rot * dt, &sn, &cs);
+      sincos_small(rot * dt, &sn, &cs);
       const R nx = cs * vx + (-sn) * vy;
       const R ny = sn * vx + cs * vy;
       vx = nx;
@@ -195,8 +225,12 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       vy += (R)m.drift_theta * (dry - vy) * dt;
     }
     // ---- _wall_velocity_update (Agent.py:357-415, utils.py:121-184) -----------------------
-    if (repel) {
-      R ax_ = 0, ay_ = 0, sx_ = 0, sy_ = 0, dmin = INFINITY;
+    // squared distances first: the sqrt / normalisation only for walls inside the repel
+    // distance, and ONE sqrt for distance_to_closest_wall (sqrt is monotone: same value)
+    R x2min = INFINITY;
+    if (nw > 0) {
+      R ax_ = 0, ay_ = 0, sx_ = 0, sy_ = 0;
+      const R wd2 = wd * wd;
       for (int w = 0; w < nw; ++w) {
         const Wall<R> W = s_w[w];
         const R dxw = px - W.ax, dyw = py - W.ay;
@@ -204,30 +238,38 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
         l = (l > (R)1) ? (R)1 : l;
         l = (l < (R)0) ? (R)0 : l;
         const R qx = px - (W.ax + l * W.sx), qy = py - (W.ay + l * W.sy);
-        const R x = r_sqrt(qx * qx + qy * qy);
-        dmin = (x < dmin) ? x : dmin;
-        if (x <= wd) {
-          const R ix = (R)1 / x;
-          const R nx = qx * ix, ny = qy * ix;
-          const R acc = kspring * (wd - x);
-          const R spd = v0 * ((R)1 - r_sqrt((R)1 - ((wd - x) * (wd - x)) / (wd * wd)));
-          ax_ += acc * nx;
-          ay_ += acc * ny;
-          sx_ += spd * nx;
-          sy_ += spd * ny;
+        const R x2 = qx * qx + qy * qy;
+        x2min = (x2 < x2min) ? x2 : x2min;
+        if (repel && x2 <= wd2 * (R)1.000001) {
+          const R x = r_sqrt(x2);
+          if (x <= wd) {
+            const R ix = (R)1 / x;
+            const R nx = qx * ix, ny = qy * ix;
+            const R acc = kspring * (wd - x);
+            const R spd = v0 * ((R)1 - r_sqrt((R)1 - ((wd - x) * (wd - x)) / wd2));
+            ax_ += acc * nx;
+            ay_ += acc * ny;
+            sx_ += spd * nx;
+            sy_ += spd * ny;
+          }
         }
       }
-      dwall = dmin;
-      vx += cvel * (ax_ * dt);
-      vy += cvel * (ay_ * dt);
-      px += cpos * (sx_ * dt);
-      py += cpos * (sy_ * dt);
+      if (repel) {
+        dwall = r_sqrt(x2min);
+        vx += cvel * (ax_ * dt);
+        vy += cvel * (ay_ * dt);
+        px += cpos * (sx_ * dt);
+        py += cpos * (sy_ * dt);
+      }
     }
     // ---- propose (Agent.py:216) -----------------------------------------------------------
     px += vx * dt;
     py += vy * dt;
     // ---- _check_and_handle_wall_collisions (Agent.py:426-441, utils.py:74-106, 304-328) ---
-    if (nw > 0) {
+    // A step shorter than the distance from prev_pos to the nearest wall cannot cross any wall:
+    // skip the per-wall segment tests (x2min was measured at prev_pos).
+    const R step2 = (px - ppx) * (px - ppx) + (py - ppy) * (py - ppy);
+    if (nw > 0 && !(step2 < (R)0.998 * x2min)) {
       int it = 0;
       for (; it < RIAB_MAX_BOUNCES; ++it) {
         const R sbx = px - ppx, sby = py - ppy;  // the step (list b), walls are list a
@@ -289,12 +331,15 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       if (fabs(dpx) > hs) dpx = -copysign(sc - fabs(dpx), dpx);
       if (fabs(dpy) > hs) dpy = -copysign(sc - fabs(dpy), dpy);
     }
-    mvx = dpx / dt;
-    mvy = dpy / dt;
+    mvx = dpx * inv_dt;
+    mvy = dpy * inv_dt;
     R mvn = r_sqrt(mvx * mvx + mvy * mvy);
     if (mvn == (R)0) {
-      mvx = (R)1e-8 * z_s0;
-      mvy = (R)1e-8 * z_s1;
+      // 1e-8 * randn(2) (Agent.py:459-460): never reached in practice; drawn from the spare words
+      const float u3 = ((float)(zw2 >> 8) + 0.5f) * 0x1.0p-24f, u4 = (float)(zw3 >> 8) * 0x1.0p-24f;
+      const float r2 = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u3));
+      mvx = (R)1e-8 * (R)(r2 * __builtin_amdgcn_cosf(u4));
+      mvy = (R)1e-8 * (R)(r2 * __builtin_amdgcn_sinf(u4));
       mvn = r_sqrt(mvx * mvx + mvy * mvy);
       ++n_still;
     }
@@ -303,22 +348,22 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       // utils.pi_domain (utils.py:331-341)
       R d = mod_2pi(ang_now - ang_prev);
       if (d > (R)3.14159265358979323846) d = (R)-6.283185307179586476925286766559 + d;
-      mrot = d / dt;
+      mrot = d * inv_dt;
     }
     ang_prev = ang_now;
     // ---- _update_head_direction (Agent.py:488-500) ----------------------------------------
     {
-      const R ix = mvx / mvn, iy = mvy / mvn;
-      const R tau = (R)m.hd_tau;
-      if (tau <= dt) {
+      const R imv = (R)1 / mvn;
+      const R ix = mvx * imv, iy = mvy * imv;
+      if (hd_instant) {
         hx = ix;
         hy = iy;
       } else {
-        const R nx = hx * ((R)1 - dt / tau) + dt / tau * ix;
-        const R ny = hy * ((R)1 - dt / tau) + dt / tau * iy;
-        const R nn = r_sqrt(nx * nx + ny * ny);
-        hx = nx / nn;
-        hy = ny / nn;
+        const R nx = hx * hd_keep + hd_gain * ix;
+        const R ny = hy * hd_keep + hd_gain * iy;
+        const R inn = (R)1 / r_sqrt(nx * nx + ny * ny);
+        hx = nx * inn;
+        hy = ny * inn;
       }
     }
     // ---- _update_distance_travelled (Agent.py:507) ----------------------------------------

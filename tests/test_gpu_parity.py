@@ -197,8 +197,9 @@ def test_production_rng_matches_host_philox(riab):
     z = zout.cpu().numpy()
     for t in range(T):
         z0, z1, _, _ = orc.motion_normals(seed, t, np.arange(B))
-        np.testing.assert_allclose(z[t, 0], z0, rtol=1e-12, atol=1e-14)
-        np.testing.assert_allclose(z[t, 1], z1, rtol=1e-12, atol=1e-14)
+        # Philox words bit-exact; log2/sin/cos are the fp32 hardware approximations
+        np.testing.assert_allclose(z[t, 0], z0, rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(z[t, 1], z1, rtol=1e-5, atol=2e-5)
     st = dict(st0, measured_rotational_velocity=np.zeros(B), distance_to_closest_wall=np.full(B, np.inf))
     oenv = orc.EnvSpec()
     for t in range(T):
