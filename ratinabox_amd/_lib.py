@@ -75,7 +75,10 @@ class RiabError(RuntimeError):
 
 def _load():
     path = _build.LIB_PATH
-    if _build.is_stale():
+    override = os.environ.get("RIAB_HIP_LIB")  # kernel experiments: load an alternative build
+    if override:
+        path = override
+    elif _build.is_stale():
         try:
             path = _build.build()
         except Exception as e:  # noqa: BLE001

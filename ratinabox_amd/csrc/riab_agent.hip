@@ -14,7 +14,50 @@
 // throughput variant.
 #include "riab_device.h"
 
+#define RIAB_TABLE_QUAL static __device__ const
+#include "riab_rayleigh_tables.h"
+
 namespace riab {
+
+// LDS row strides (in doubles), padded so that lanes reading the same coefficient index of
+// different segments spread over the banks
+#define RIAB_G_STRIDE (RIAB_G_DEG + 4)
+#define RIAB_H_STRIDE (RIAB_H_DEG + 4)
+
+// One Horner recurrence on per-lane coefficients: p(x), x = (arg - mid) * inv_halfwidth.
+template <int DEG>
+__device__ __forceinline__ double seg_poly(const double* row, double arg) {
+  const double x = (arg - row[0]) * row[1];
+  double p = row[2 + DEG];
+#pragma unroll
+  for (int k = DEG - 1; k >= 0; --k) p = fma(p, x, row[2 + k]);
+  return p;
+}
+
+// The speed update of Agent._stochastic_velocity_update (reference Agent.py:302-309 with
+// utils.rayleigh_to_normal / normal_to_rayleigh, utils.py:409-421), float64, table-driven:
+//   G(t) = Phi^-1(clip(1 - exp(-t^2/2), 1e-6, 1-1e-6)),  H(n) = sqrt(-2 ln(1 - Phi(n))),  t = speed/sigma
+// (tools/gen_rayleigh_tables.py; max error 1.6e-16 vs 50-digit arithmetic).  Every lane runs
+// the same instruction stream on its own segment's coefficients: no exp/log/erfc/ndtri and
+// no divergent range branches.  Arguments of H beyond the table use the library functions.
+struct RayleighLds {
+  const double* g;
+  const double* h;
+};
+__device__ __forceinline__ double rayleigh_G(const RayleighLds& L, double t) {
+  t = (t < RIAB_G_TLO) ? RIAB_G_TLO : t;
+  t = (t > RIAB_G_THI) ? RIAB_G_THI : t;
+  const int seg = (int)(((unsigned long long)__double_as_longlong(t) >> 49) - RIAB_G_KEY0);
+  return seg_poly<RIAB_G_DEG>(L.g + seg * RIAB_G_STRIDE, t);
+}
+__device__ __forceinline__ double rayleigh_H(const RayleighLds& L, double n) {
+  if (fabs(n) < RIAB_H_NMAX) {
+    int seg = (int)((n + RIAB_H_NMAX) * RIAB_H_INV_SEG);
+    seg = seg > RIAB_H_SEGS - 1 ? RIAB_H_SEGS - 1 : seg;
+    return seg_poly<RIAB_H_DEG>(L.h + seg * RIAB_H_STRIDE, n);
+  }
+  return sqrt(-2.0 * log(1.0 - normcdf(n)));
+}
 
 struct AgentArgs {
   RiabMotion m;
@@ -106,6 +149,15 @@ struct Wall {  // staged in LDS
 template <class R>
 __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   __shared__ Wall<R> s_w[RIAB_MAX_WALLS];
+  __shared__ double s_g[sizeof(R) == 8 ? RIAB_G_SEGS * RIAB_G_STRIDE : 1];
+  __shared__ double s_h[sizeof(R) == 8 ? RIAB_H_SEGS * RIAB_H_STRIDE : 1];
+  if (sizeof(R) == 8) {
+    for (int i = threadIdx.x; i < RIAB_G_SEGS * (RIAB_G_DEG + 3); i += 64)
+      s_g[(i / (RIAB_G_DEG + 3)) * RIAB_G_STRIDE + i % (RIAB_G_DEG + 3)] = (&riab_g_table[0][0])[i];
+    for (int i = threadIdx.x; i < RIAB_H_SEGS * (RIAB_H_DEG + 3); i += 64)
+      s_h[(i / (RIAB_H_DEG + 3)) * RIAB_H_STRIDE + i % (RIAB_H_DEG + 3)] = (&riab_h_table[0][0])[i];
+  }
+  const RayleighLds rl{s_g, s_h};
   for (int w = threadIdx.x; w < a.n_walls; w += 64) {
     const double ax = a.walls[4 * w], ay = a.walls[4 * w + 1], bx = a.walls[4 * w + 2], by = a.walls[4 * w + 3];
     const double sx = bx - ax, sy = by - ay;
@@ -150,6 +202,7 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   // constants of the step
   const R sm_kw = (R)m.speed_mean_kw, sm = (R)m.speed_mean;
   const R inv_2s2 = (R)1 / ((R)2 * sm_kw * sm_kw);
+  const double inv_sm = 1.0 / m.speed_mean_kw;
   const R wd = (R)m.wall_repel_distance_kw;
   const R v0 = (R)m.wall_repel_strength_kw * sm;
   const R kspring = (v0 * v0) / (wd * wd);
@@ -193,7 +246,11 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     rot += (R)m.rot_theta_kw * ((R)m.rot_drift_kw - rot) * dt + (R)m.rot_sigma_kw * (dt * z_rot);
     {
       R sn, cs;
+#ifdef RIAB_EXP_NO_SINCOS
+      sn = rot * dt; cs = (R)1 - (R)0.5 * sn * sn;
+#else
       sincos_small(rot * dt, &sn, &cs);
+#endif
       const R nx = cs * vx + (-sn) * vy;
       const R ny = sn * vx + cs * vy;
       vx = nx;
@@ -207,13 +264,20 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     }
     {
       // utils.rayleigh_to_normal / normal_to_rayleigh (utils.py:409-421), sigma = speed_mean
-      R u = (R)1 - r_exp(-(speed * speed) * inv_2s2);
-      u = (u < (R)1e-6) ? (R)1e-6 : u;
-      u = (u > (R)(1 - 1e-6)) ? (R)(1 - 1e-6) : u;
-      R nv = r_ndtri(u);
-      nv += (R)m.speed_theta_kw * ((R)0 - nv) * dt + (R)m.speed_sigma_kw * (dt * z_spd);
-      const R x = r_ndtr(nv);
-      R speed_new = sm_kw * r_sqrt((R)-2 * r_log((R)1 - x));
+      R speed_new;
+      if (sizeof(R) == 8) {
+        double nv = rayleigh_G(rl, (double)speed * inv_sm);
+        nv += m.speed_theta_kw * (0.0 - nv) * m.dt + m.speed_sigma_kw * (m.dt * (double)z_spd);
+        speed_new = (R)(m.speed_mean_kw * rayleigh_H(rl, nv));
+      } else {
+        R u = (R)1 - r_exp(-(speed * speed) * inv_2s2);
+        u = (u < (R)1e-6) ? (R)1e-6 : u;
+        u = (u > (R)(1 - 1e-6)) ? (R)(1 - 1e-6) : u;
+        R nv = r_ndtri(u);
+        nv += (R)m.speed_theta_kw * ((R)0 - nv) * dt + (R)m.speed_sigma_kw * (dt * z_spd);
+        const R x = r_ndtr(nv);
+        speed_new = sm_kw * r_sqrt((R)-2 * r_log((R)1 - x));
+      }
       if (m.speed_std_is_zero) speed_new = sm_kw;
       const R f = speed_new / speed;
       vx *= f;
@@ -343,7 +407,11 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       mvn = r_sqrt(mvx * mvx + mvy * mvy);
       ++n_still;
     }
+#ifdef RIAB_EXP_NO_ATAN
+    const R ang_now = mvx;
+#else
     const R ang_now = get_angle(mvx, mvy);
+#endif
     {
       // utils.pi_domain (utils.py:331-341)
       R d = mod_2pi(ang_now - ang_prev);
