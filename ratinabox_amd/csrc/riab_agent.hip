@@ -172,6 +172,9 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   __syncthreads();
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= a.B) return;
+  // a latency-bound recurrence sharing its CU with bandwidth-bound rate kernels: win the
+  // SIMD's issue arbitration whenever this wave is ready
+  __builtin_amdgcn_s_setprio(3);
   const RiabMotion& m = a.m;
   const int nw = a.n_walls;
   const R dt = (R)m.dt;
@@ -293,8 +296,14 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     // distance, and ONE sqrt for distance_to_closest_wall (sqrt is monotone: same value)
     R x2min = INFINITY;
     if (nw > 0) {
-      R ax_ = 0, ay_ = 0, sx_ = 0, sy_ = 0;
-      const R wd2 = wd * wd;
+      // pass 1 (cheap, every wall): squared distance to the nearest point of the wall; remember
+      // the first RIAB_NEAR walls inside the repel distance.  pass 2 (expensive: sqrt, 1/x, the
+      // spring / conveyor terms) runs only over those, in wall order, so the sums are the
+      // reference's sums (the skipped terms are exact zeros).
+      constexpr int RIAB_NEAR = 3;
+      int near_idx[RIAB_NEAR] = {0, 0, 0};
+      int n_near = 0;
+      const R wd2 = wd * wd * (R)1.000001;
       for (int w = 0; w < nw; ++w) {
         const Wall<R> W = s_w[w];
         const R dxw = px - W.ax, dyw = py - W.ay;
@@ -304,21 +313,36 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
         const R qx = px - (W.ax + l * W.sx), qy = py - (W.ay + l * W.sy);
         const R x2 = qx * qx + qy * qy;
         x2min = (x2 < x2min) ? x2 : x2min;
-        if (repel && x2 <= wd2 * (R)1.000001) {
-          const R x = r_sqrt(x2);
+        if (x2 <= wd2) {
+          if (n_near == 0) near_idx[0] = w;
+          if (n_near == 1) near_idx[1] = w;
+          if (n_near == 2) near_idx[2] = w;
+          ++n_near;
+        }
+      }
+      if (repel) {
+        R ax_ = 0, ay_ = 0, sx_ = 0, sy_ = 0;
+        const int cnt = (n_near <= RIAB_NEAR) ? n_near : nw;  // more than RIAB_NEAR near walls: walk them all
+        for (int k = 0; k < cnt; ++k) {
+          const int w = (n_near <= RIAB_NEAR) ? near_idx[k < RIAB_NEAR ? k : 0] : k;
+          const Wall<R> W = s_w[w];
+          const R dxw = px - W.ax, dyw = py - W.ay;
+          R l = (dxw * W.sx + dyw * W.sy) * W.inv_ss;
+          l = (l > (R)1) ? (R)1 : l;
+          l = (l < (R)0) ? (R)0 : l;
+          const R qx = px - (W.ax + l * W.sx), qy = py - (W.ay + l * W.sy);
+          const R x = r_sqrt(qx * qx + qy * qy);
           if (x <= wd) {
             const R ix = (R)1 / x;
             const R nx = qx * ix, ny = qy * ix;
             const R acc = kspring * (wd - x);
-            const R spd = v0 * ((R)1 - r_sqrt((R)1 - ((wd - x) * (wd - x)) / wd2));
+            const R spd = v0 * ((R)1 - r_sqrt((R)1 - ((wd - x) * (wd - x)) / (wd * wd)));
             ax_ += acc * nx;
             ay_ += acc * ny;
             sx_ += spd * nx;
             sy_ += spd * ny;
           }
         }
-      }
-      if (repel) {
         dwall = r_sqrt(x2min);
         vx += cvel * (ax_ * dt);
         vy += cvel * (ay_ * dt);
