@@ -207,7 +207,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                traffic = round(json.load(f).get("hbm_bytes_per_unit") * avg_units)  # PMC bytes/unit x units/launch
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": f"rate_kernel<{type(pops[0]).__name__}>", "launches": len(ms),
