@@ -15,8 +15,8 @@ def test_shard_ranges_cover_and_align():
     for n, w in ((4096, 8), (32768, 8), (10, 2), (7, 4), (65536, 3)):
         got = [parallel.shard_range(n, r, w) for r in range(w)]
         assert got[0][0] == 0 and sum(c for _, c in got) == n
-        for (a0, c), (b0, _) in zip(got[:-1], got[1:]):
-            assert a0 + c == b0
+        for (a0, c), (b0, d) in zip(got[:-1], got[1:]):
+            assert a0 + c == b0 or d == 0  # contiguous; empty trailing shards only keep the alignment
         assert all(a0 % 4 == 0 for a0, _ in got)
 
 
