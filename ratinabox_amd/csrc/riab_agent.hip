@@ -82,6 +82,8 @@ struct AgentArgs {
 // ---- math wrappers ---------------------------------------------------------------------------
 __device__ __forceinline__ double r_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ float r_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double r_rsqrt(double x) { return rsqrt(x); }
+__device__ __forceinline__ float r_rsqrt(float x) { return rsqrtf(x); }
 __device__ __forceinline__ double r_exp(double x) { return exp(x); }
 __device__ __forceinline__ float r_exp(float x) { return expf(x); }
 __device__ __forceinline__ double r_log(double x) { return log(x); }
@@ -195,9 +197,6 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     drx = (R)a.drift[b];
     dry = (R)a.drift[B + b];
   }
-  // angle of the previous measured velocity: computed once, then carried (the reference
-  // recomputes get_angle(prev_measured_velocity) every step, Agent.py:466)
-  R ang_prev = get_angle(mvx, mvy);
 
   int n_bounce = 0, n_sat = 0, n_bc = 0, n_still = 0;
   const uint32_t aid = (uint32_t)(a.agent_id0 + b);
@@ -259,12 +258,15 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       vx = nx;
       vy = ny;
     }
-    R speed = r_sqrt(vx * vx + vy * vy);
-    if (speed == (R)0) {
+    // |v| and 1/|v| from one reciprocal square root
+    R v2 = vx * vx + vy * vy;
+    if (v2 == (R)0) {
       vx = (R)1e-8;
       vy = (R)0;
-      speed = (R)1e-8;
+      v2 = (R)1e-16;
     }
+    const R ispeed = r_rsqrt(v2);
+    const R speed = v2 * ispeed;
     {
       // utils.rayleigh_to_normal / normal_to_rayleigh (utils.py:409-421), sigma = speed_mean
       R speed_new;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
         nv += m.speed_theta_kw * (0.0 - nv) * m.dt + m.speed_sigma_kw * (m.dt * (double)z_spd);
         speed_new = (R)(m.speed_mean_kw * rayleigh_H(rl, nv));
       } else {
-        R u = (R)1 - r_exp(-(speed * speed) * inv_2s2);
+        R u = (R)1 - r_exp(-v2 * inv_2s2);
         u = (u < (R)1e-6) ? (R)1e-6 : u;
         u = (u > (R)(1 - 1e-6)) ? (R)(1 - 1e-6) : u;
         R nv = r_ndtri(u);
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
         speed_new = sm_kw * r_sqrt((R)-2 * r_log((R)1 - x));
       }
       if (m.speed_std_is_zero) speed_new = sm_kw;
-      const R f = speed_new / speed;
+      const R f = speed_new * ispeed;
       vx *= f;
       vy *= f;
     }
@@ -419,33 +421,39 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       if (fabs(dpx) > hs) dpx = -copysign(sc - fabs(dpx), dpx);
       if (fabs(dpy) > hs) dpy = -copysign(sc - fabs(dpy), dpy);
     }
+    const R pmvx = mvx, pmvy = mvy;  // prev_measured_velocity (Agent.py:201)
     mvx = dpx * inv_dt;
     mvy = dpy * inv_dt;
-    R mvn = r_sqrt(mvx * mvx + mvy * mvy);
-    if (mvn == (R)0) {
+    R dp2 = dpx * dpx + dpy * dpy;
+    R idp = r_rsqrt(dp2);          // one reciprocal square root serves |d_pos|, |mv| and 1/|mv|
+    R dstep = dp2 * idp;
+    R imv = idp * dt;              // 1 / |mv|
+    if (dp2 == (R)0) {
       // 1e-8 * randn(2) (Agent.py:459-460): never reached in practice; drawn from the spare words
       const float u3 = ((float)(zw2 >> 8) + 0.5f) * 0x1.0p-24f, u4 = (float)(zw3 >> 8) * 0x1.0p-24f;
       const float r2 = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u3));
       mvx = (R)1e-8 * (R)(r2 * __builtin_amdgcn_cosf(u4));
       mvy = (R)1e-8 * (R)(r2 * __builtin_amdgcn_sinf(u4));
-      mvn = r_sqrt(mvx * mvx + mvy * mvy);
+      imv = r_rsqrt(mvx * mvx + mvy * mvy);
+      dstep = (R)0;
       ++n_still;
     }
-#ifdef RIAB_EXP_NO_ATAN
-    const R ang_now = mvx;
-#else
-    const R ang_now = get_angle(mvx, mvy);
-#endif
     {
-      // utils.pi_domain (utils.py:331-341)
-      R d = mod_2pi(ang_now - ang_prev);
-      if (d > (R)3.14159265358979323846) d = (R)-6.283185307179586476925286766559 + d;
-      mrot = d * inv_dt;
+      // measured rotational velocity (Agent.py:465-468): pi_domain(get_angle(mv) - get_angle(prev_mv)) / dt.
+      // The wrapped difference of the two angles IS the signed angle between the two vectors
+      // (x + 1e-6 is utils.get_angle's quirk), taken directly from their cross / dot products;
+      // the arctangent runs in fp32 on that DIFFERENCE (relative error 1e-7 of a small angle;
+      // the quantity is an output, it does not feed back into the motion).
+      const R ax_ = pmvx + (R)1e-6, bx_ = mvx + (R)1e-6;
+      const R crs = ax_ * mvy - pmvy * bx_, dotp = ax_ * bx_ + pmvy * mvy;
+#ifdef RIAB_EXP_NO_ATAN
+      mrot = crs * inv_dt;
+#else
+      mrot = (R)atan2f((float)crs, (float)dotp) * inv_dt;
+#endif
     }
-    ang_prev = ang_now;
     // ---- _update_head_direction (Agent.py:488-500) ----------------------------------------
     {
-      const R imv = (R)1 / mvn;
       const R ix = mvx * imv, iy = mvy * imv;
       if (hd_instant) {
         hx = ix;
@@ -453,13 +461,13 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       } else {
         const R nx = hx * hd_keep + hd_gain * ix;
         const R ny = hy * hd_keep + hd_gain * iy;
-        const R inn = (R)1 / r_sqrt(nx * nx + ny * ny);
+        const R inn = r_rsqrt(nx * nx + ny * ny);
         hx = nx * inn;
         hy = ny * inn;
       }
     }
     // ---- _update_distance_travelled (Agent.py:507) ----------------------------------------
-    dist += r_sqrt(dpx * dpx + dpy * dpy);
+    dist += dstep;
     // ---- save_to_history (Agent.py:514-520) ------------------------------------------------
     if (a.hist) {
       float* h = a.hist + (int64_t)t * RIAB_HIST_ROWS * B + b;
