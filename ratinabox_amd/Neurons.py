@@ -544,10 +544,14 @@ class BoundaryVectorCells(VectorCells):
             cells = np.zeros((4, n))
             cells[0], cells[1], cells[2] = a * mu_d, a, kappa * LOG2E
             diff = ang[None, :] - mu_t[:, None]
+            Kp = (K + 3) // 4 * 4  # table rows padded to a multiple of 4; pad terms are exp2(-inf) = 0
             if ego:
-                vm = np.stack((np.cos(diff), np.sin(diff)))
+                vm = np.zeros((2, n, Kp))
+                vm[0, :, :K], vm[1, :, :K] = np.cos(diff), np.sin(diff)
+                vm[0, :, K:] = -np.inf
             else:
-                vm = LOG2E * kappa[:, None] * (np.cos(diff) - 1)
+                vm = np.full((n, Kp), -np.inf)
+                vm[:, :K] = LOG2E * kappa[:, None] * (np.cos(diff) - 1)
             f32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self._device)  # noqa: E731
             return (torch.from_numpy(np.ascontiguousarray(dirs)).to(self._device), f32(cells), f32(vm), f32(1 / norm))
 

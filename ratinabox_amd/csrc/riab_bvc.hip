@@ -6,11 +6,11 @@
 // transcendental issue, not HBM, and has no contraction for MFMA (the summand depends on
 // all of c, k and p).
 //
-// Workgroup = 256 threads = 4 waves sharing one tile of 64 positions (lane = position):
-//   stage A  all 4 waves cast the K rays of the tile against the walls in float64 (the
+// Workgroup = 512 threads = 8 waves sharing one tile of 64 positions (lane = position):
+//   stage A  all 8 waves cast the K rays of the tile against the walls in float64 (the
 //            nearest-wall decision is discrete; walls + 1/denominator table staged in LDS)
 //            and leave d[k][lane] (fp32) in LDS;
-//   stage B  wave w owns the cells c = w (mod 4); per cell the K-loop reads d[k][lane]
+//   stage B  wave w owns the 4-cell groups g = w (mod 8); per group the K-loop reads d[k][lane]
 //            (conflict-free ds_read_b32) and the wave-uniform angular table entry (scalar
 //            load), one fused exponent per term: exp2(-(a d - a mu)^2 + T[c][k]).
 #include "riab_device.h"
@@ -33,7 +33,7 @@ struct BvcArgs {
   float dt, fr_scale, fr_min;
   uint32_t k0, k1, step0, tag;
   int64_t agent_id0;
-  int n, K, n_walls;
+  int n, K, Kp, n_walls;  // Kp = K rounded up to a multiple of 4 (table row stride, d-tile rows)
   const double* walls;      // [n_walls][4]
   const double* test_dirs;  // [K][2]
   const float* cells;       // [4][n]
@@ -45,24 +45,25 @@ struct BvcArgs {
 // LDS layout (dynamic): double wall[n_walls][4] (ax, ay, sx, sy) | double rden[K][n_walls] |
 // double dir[K][2] | float d[K][64]
 template <bool EGO>
-__global__ __launch_bounds__(256) void bvc_kernel(const BvcArgs a) {
+__global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   double* s_wall = reinterpret_cast<double*>(smem);
   double* s_rden = s_wall + 4 * a.n_walls;
   double* s_dir = s_rden + (size_t)a.K * a.n_walls;
   float* s_d = reinterpret_cast<float*>(s_dir + 2 * a.K);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: loop counters and table indices stay scalar
   const int nw = a.n_walls, K = a.K;
 
-  for (int i = tid; i < nw; i += 256) {
+  for (int i = tid; i < nw; i += 512) {
     const double ax = a.walls[4 * i], ay = a.walls[4 * i + 1];
     s_wall[4 * i] = ax;
     s_wall[4 * i + 1] = ay;
     s_wall[4 * i + 2] = a.walls[4 * i + 2] - ax;
     s_wall[4 * i + 3] = a.walls[4 * i + 3] - ay;
   }
-  for (int i = tid; i < 2 * K; i += 256) s_dir[i] = a.test_dirs[i];
-  for (int i = tid; i < K * nw; i += 256) {
+  for (int i = tid; i < 2 * K; i += 512) s_dir[i] = a.test_dirs[i];
+  for (int i = tid; i < K * nw; i += 512) {
     const int k = i / nw, w = i - k * nw;
     const double ux = a.test_dirs[2 * k], uy = a.test_dirs[2 * k + 1];
     const double sx = a.walls[4 * w + 2] - a.walls[4 * w], sy = a.walls[4 * w + 3] - a.walls[4 * w + 1];
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void bvc_kernel(const BvcArgs a) {
   const double px = pxf, py = pyf;
 
   // ---- stage A: first-wall distance along each test direction (Neurons.py:1655-1684, 1746-1778)
-  for (int k = wave; k < K; k += 4) {
+  for (int k = wave; k < K; k += 8) {
     const double ux = s_dir[2 * k], uy = s_dir[2 * k + 1];
     double best = INFINITY;  // smallest valid l_a == largest preference 1/l_a; first index wins ties
     double fallback = 0.0;
@@ -103,9 +104,13 @@ __global__ __launch_bounds__(256) void bvc_kernel(const BvcArgs a) {
     s_d[k * 64 + lane] = d;
     if (a.ray_out && live) a.ray_out[(t * K + k) * a.B + b] = d;
   }
+  for (int k = K + wave; k < a.Kp; k += 8) s_d[k * 64 + lane] = 0.0f;  // pad rows meet table entries of -inf
   __syncthreads();
 
   // ---- stage B ------------------------------------------------------------------------------
+  // wave w owns the 4-cell groups g = w (mod 8).  Per group the k-loop walks 4 test directions at
+  // a time: 4 ds_read_b32 of d (shared by the 4 cells), 4 s_load_dwordx4 of the angular table
+  // (wave-uniform -> SGPR operands), 16 fused exponents on 4 independent accumulators.
   float ch = 1.0f, sh = 0.0f;
   if (EGO) {
     // cos / sin of utils.get_angle(head_direction) = atan2(hy, hx + 1e-6)
@@ -114,49 +119,89 @@ __global__ __launch_bounds__(256) void bvc_kernel(const BvcArgs a) {
     ch = hx * inv;
     sh = hy * inv;
   }
-  const int n = a.n;
-  for (int c = wave; c < n; c += 4) {
-    const float amu = a.cells[c], aa = a.cells[n + c], kap = a.cells[2 * n + c];
-    const float* vmc = a.vm + (int64_t)c * K;
-    const float* vms = a.vm + ((int64_t)n + c) * K;
-    float acc0 = 0.0f, acc1 = 0.0f;
-    int k = 0;
-    for (; k + 1 < K; k += 2) {
-      const float t0 = fmaf(s_d[k * 64 + lane], aa, -amu);
-      const float t1 = fmaf(s_d[(k + 1) * 64 + lane], aa, -amu);
-      float v0, v1;
-      if (EGO) {
-        v0 = kap * (fmaf(vmc[k], ch, vms[k] * sh) - 1.0f);
-        v1 = kap * (fmaf(vmc[k + 1], ch, vms[k + 1] * sh) - 1.0f);
-      } else {
-        v0 = vmc[k];
-        v1 = vmc[k + 1];
+  const int n = a.n, Kp = a.Kp;
+  const int n_groups = (n + 3) >> 2;
+  for (int g = wave; g < n_groups; g += 8) {
+    float aa[4], nmu[4], kap[4];
+    const_f32_ptr tc[4];
+    const_f32_ptr ts[4];
+    const const_f32_ptr cells = as_const_table(a.cells);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = min(4 * g + j, n - 1);
+      nmu[j] = -cells[c];
+      aa[j] = cells[n + c];
+      kap[j] = cells[2 * n + c];
+      tc[j] = as_const_table(a.vm + (int64_t)c * Kp);
+      ts[j] = as_const_table(a.vm + ((int64_t)n + c) * Kp);
+    }
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // register double-buffering: the d values and table entries of step k+4 are requested before
+    // the 16 exponentials of step k are issued, so LDS / scalar-cache latency hides under them
+    float d[4], vc[4][4], vs[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = s_d[i * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vc[j][i] = tc[j][i];
+        if (EGO) vs[j][i] = ts[j][i];
       }
-      acc0 += __builtin_amdgcn_exp2f(fmaf(-t0, t0, v0));
-      acc1 += __builtin_amdgcn_exp2f(fmaf(-t1, t1, v1));
-    }
-    for (; k < K; ++k) {
-      const float t0 = fmaf(s_d[k * 64 + lane], aa, -amu);
-      const float v0 = EGO ? kap * (fmaf(vmc[k], ch, vms[k] * sh) - 1.0f) : vmc[k];
-      acc0 += __builtin_amdgcn_exp2f(fmaf(-t0, t0, v0));
-    }
-    float r = (acc0 + acc1) * a.inv_norm[c];
-    r = r * a.fr_scale + a.fr_min;
-    if (live) {
-      const int64_t off = (t * n + c) * a.B + b;
-      a.rates[off] = r;
-      if (a.spikes) {
-        float u;
-        if (a.u_in) {
-          u = a.u_in[off];
-        } else {
-          const uint64_t gid = (uint64_t)(a.agent_id0 + b);
-          const u32x4 w4 = philox4x32_10(a.step0 + (uint32_t)t, (uint32_t)c, (uint32_t)(gid >> 2), a.tag, a.k0, a.k1);
-          const uint32_t j = (uint32_t)gid & 3u;
-          const uint32_t word = j == 0 ? w4.x : (j == 1 ? w4.y : (j == 2 ? w4.z : w4.w));
-          u = u01_24(word);
+    for (int k = 0; k < Kp; k += 4) {
+      const int kn = (k + 4 < Kp) ? k + 4 : k;
+      float dn[4], vcn[4][4], vsn[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dn[i] = s_d[(kn + i) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          vcn[j][i] = tc[j][kn + i];
+          if (EGO) vsn[j][i] = ts[j][kn + i];
         }
-        a.spikes[off] = (u < a.dt * r) ? 1 : 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float tt = fmaf(d[i], aa[j], nmu[j]);
+          float v;
+          if (EGO) v = kap[j] * (fmaf(vc[j][i], ch, vs[j][i] * sh) - 1.0f);
+          else v = vc[j][i];
+          acc[j] += __builtin_amdgcn_exp2f(fmaf(-tt, tt, v));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d[i] = dn[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          vc[j][i] = vcn[j][i];
+          if (EGO) vs[j][i] = vsn[j][i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 4 * g + j;
+      if (c < n && live) {
+        float r = acc[j] * a.inv_norm[c];
+        r = r * a.fr_scale + a.fr_min;
+        const int64_t off = (t * n + c) * a.B + b;
+        a.rates[off] = r;
+        if (a.spikes) {
+          float u;
+          if (a.u_in) {
+            u = a.u_in[off];
+          } else {
+            const uint64_t gid = (uint64_t)(a.agent_id0 + b);
+            const u32x4 w4 = philox4x32_10(a.step0 + (uint32_t)t, (uint32_t)c, (uint32_t)(gid >> 2), a.tag, a.k0, a.k1);
+            const uint32_t jj = (uint32_t)gid & 3u;
+            const uint32_t word = jj == 0 ? w4.x : (jj == 1 ? w4.y : (jj == 2 ? w4.z : w4.w));
+            u = u01_24(word);
+          }
+          a.spikes[off] = (u < a.dt * r) ? 1 : 0;
+        }
       }
     }
   }
@@ -196,6 +241,7 @@ extern "C" int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* 
   a.agent_id0 = io->agent_id0;
   a.n = n;
   a.K = K;
+  a.Kp = (K + 3) / 4 * 4;
   a.n_walls = env->n_walls;
   a.walls = env->walls;
   a.test_dirs = test_dirs;
@@ -204,18 +250,18 @@ extern "C" int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* 
   a.inv_norm = inv_norm;
   a.ray_out = ray_out;
   const size_t lds = sizeof(double) * (4 * (size_t)env->n_walls + (size_t)K * env->n_walls + 2 * (size_t)K) +
-                     sizeof(float) * (size_t)K * 64;
+                     sizeof(float) * (size_t)((K + 3) / 4 * 4) * 64;
   if (lds > 160 * 1024) return RIAB_ETOOBIG;
   const dim3 grid((unsigned)((a.P + 63) / 64));
   hipStream_t s = (hipStream_t)stream;
   if (egocentric) {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)bvc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(bvc_kernel<true>, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(bvc_kernel<true>, grid, dim3(512), lds, s, a);
   } else {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)bvc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(bvc_kernel<false>, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(bvc_kernel<false>, grid, dim3(512), lds, s, a);
   }
   return (int)hipGetLastError();
 }

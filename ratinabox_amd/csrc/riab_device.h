@@ -37,6 +37,12 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
   return {c0, c1, c2, c3};
 }
 
+// Read-only, wave-uniform tables: a pointer in the constant address space tells the compiler the
+// memory is invariant, so uniform-index reads become scalar loads (s_load_dwordx4 -> SGPR operands)
+// instead of per-lane vector loads.
+typedef const __attribute__((address_space(4))) float* const_f32_ptr;
+__device__ __forceinline__ const_f32_ptr as_const_table(const float* p) { return (const_f32_ptr)(const void*)p; }
+
 // fp32 uniform in [0,1) with 24 random bits — exactly representable, so the
 // host can regenerate it bit for bit.
 __device__ __forceinline__ float u01_24(uint32_t w) { return (float)(w >> 8) * 0x1.0p-24f; }

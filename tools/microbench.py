@@ -83,6 +83,8 @@ def rates():
             ("GridCells 1024 +spikes", riab.GridCells(ag, {"n": 1024}), True),
             ("HeadDirectionCells 256", riab.HeadDirectionCells(ag, {"n": 256}), False),
             ("BVC 256", riab.BoundaryVectorCells(ag, {"n": 256}), False),
+            ("BVC 8 (ray stage dominated)", riab.BoundaryVectorCells(ag, {"n": 8}), False),
+            ("BVC 1024", riab.BoundaryVectorCells(ag, {"n": 1024}), False),
             ("BVC 256 egocentric", riab.BoundaryVectorCells(ag, {"n": 256, "reference_frame": "egocentric"}), False)):
         n = pop.n
         Tt = T if "BVC" not in name else 16
