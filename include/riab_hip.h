@@ -190,6 +190,9 @@ int riab_head_direction_cells(const RiabRateIO* io, const float* table, int32_t 
 /* BoundaryVectorCells.get_state (Neurons.py:1617-1778) with utils.vector_intercepts
  * (utils.py:30-118), gaussian / von_mises (utils.py:424-457).
  *  test_dirs  device float64 [K][2] unit test directions (Neurons.py:1584-1596)
+ *  ray_rden   device float64 [K][n_walls]: 1 / (u_k . s_w^perp) = 1 / (ux*(-sy) + uy*sx), the
+ *             position-independent denominator of utils.vector_intercepts (utils.py:96) for
+ *             ray k against wall w (inf for parallel pairs, like the zero-jitter reference)
  *  cells      device float32 [4][n]: row 0 = a*mu_d, row 1 = a with
  *             a = sqrt(log2(e)/2)/sigma_d (so the radial gaussian is
  *             exp2(-(a d - a mu_d)^2)), row 2 = kappa*log2(e), row 3 unused
@@ -204,7 +207,7 @@ int riab_head_direction_cells(const RiabRateIO* io, const float* table, int32_t 
  *  ray_out    device float32 [T][K][B] or NULL: the first-wall ray distances
  *             (diagnostic / parity of the ray stage) */
 int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* io, const double* test_dirs,
-                               int32_t K, const float* cells, const float* vm_table,
+                               const double* ray_rden, int32_t K, const float* cells, const float* vm_table,
                                const float* inv_norm, int32_t n, int32_t egocentric,
                                float* ray_out, riab_stream_t stream);
 

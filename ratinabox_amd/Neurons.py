@@ -553,11 +553,17 @@ class BoundaryVectorCells(VectorCells):
                 vm = np.full((n, Kp), -np.inf)
                 vm[:, :K] = LOG2E * kappa[:, None] * (np.cos(diff) - 1)
             f32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self._device)  # noqa: E731
-            return (torch.from_numpy(np.ascontiguousarray(dirs)).to(self._device), f32(cells), f32(vm), f32(1 / norm))
+            # position-independent denominators of the ray/wall intercepts (utils.py:96): sa . sb_p
+            s_w = walls[:, 1, :] - walls[:, 0, :]
+            with np.errstate(divide="ignore"):
+                rden = 1.0 / (dirs[:, None, 0] * (-s_w[None, :, 1]) + dirs[:, None, 1] * s_w[None, :, 0])
+            f64 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(self._device)  # noqa: E731
+            return (f64(dirs), f64(rden), f32(cells), f32(vm), f32(1 / norm))
 
-        dirs_t, cells_t, vm_t, inv_t = self._tables((mu_d, sg_d, mu_t, sg_t, ang, dirs, norm, ego), build)
+        walls = np.asarray(self.Agent.Environment.walls, dtype=np.float64).reshape(-1, 2, 2)
+        dirs_t, rden_t, cells_t, vm_t, inv_t = self._tables((mu_d, sg_d, mu_t, sg_t, ang, dirs, norm, ego, walls), build)
         env, _w = self.Agent.Environment.device_tables(self._device)
-        rc = _L.lib.riab_boundary_vector_cells(env, io, _L.ptr(dirs_t), K, _L.ptr(cells_t), _L.ptr(vm_t),
+        rc = _L.lib.riab_boundary_vector_cells(env, io, _L.ptr(dirs_t), _L.ptr(rden_t), K, _L.ptr(cells_t), _L.ptr(vm_t),
                                                _L.ptr(inv_t), n, 1 if ego else 0, None, stream)
         _L.check(rc, "riab_boundary_vector_cells")
 

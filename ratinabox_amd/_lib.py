@@ -57,7 +57,7 @@ PROTOTYPES = {
                                    C.c_int32, C.c_float, C.c_void_p]),
     "riab_grid_cells": (C.c_int, [C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "riab_head_direction_cells": (C.c_int, [C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_void_p]),
-    "riab_boundary_vector_cells": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_int32,
+    "riab_boundary_vector_cells": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                              C.c_void_p]),
     "riab_spikes": (C.c_int, [C.POINTER(RiabRateIO), C.c_int32, C.c_void_p]),

@@ -36,41 +36,27 @@ struct BvcArgs {
   int n, K, Kp, n_walls;  // Kp = K rounded up to a multiple of 4 (table row stride, d-tile rows)
   const double* walls;      // [n_walls][4]
   const double* test_dirs;  // [K][2]
+  const double* ray_rden;   // [K][n_walls] = 1 / (u_k x s_w)
   const float* cells;       // [4][n]
   const float* vm;          // [n][K] or [2][n][K]
   const float* inv_norm;    // [n]
   float* ray_out;           // [T][K][B] or null
 };
 
-// LDS layout (dynamic): double wall[n_walls][4] (ax, ay, sx, sy) | double rden[K][n_walls] |
-// double dir[K][2] | float d[K][64]
+typedef const __attribute__((address_space(4))) double* const_f64_ptr;
+
+// LDS (dynamic): float d[Kp][64] — the tile's first-wall distances.  Walls, test directions and the
+// 1/denominator table are wave-uniform: they are read from global memory with scalar loads.
 template <bool EGO>
 __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  double* s_wall = reinterpret_cast<double*>(smem);
-  double* s_rden = s_wall + 4 * a.n_walls;
-  double* s_dir = s_rden + (size_t)a.K * a.n_walls;
-  float* s_d = reinterpret_cast<float*>(s_dir + 2 * a.K);
+  float* s_d = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: loop counters and table indices stay scalar
   const int nw = a.n_walls, K = a.K;
-
-  for (int i = tid; i < nw; i += 512) {
-    const double ax = a.walls[4 * i], ay = a.walls[4 * i + 1];
-    s_wall[4 * i] = ax;
-    s_wall[4 * i + 1] = ay;
-    s_wall[4 * i + 2] = a.walls[4 * i + 2] - ax;
-    s_wall[4 * i + 3] = a.walls[4 * i + 3] - ay;
-  }
-  for (int i = tid; i < 2 * K; i += 512) s_dir[i] = a.test_dirs[i];
-  for (int i = tid; i < K * nw; i += 512) {
-    const int k = i / nw, w = i - k * nw;
-    const double ux = a.test_dirs[2 * k], uy = a.test_dirs[2 * k + 1];
-    const double sx = a.walls[4 * w + 2] - a.walls[4 * w], sy = a.walls[4 * w + 3] - a.walls[4 * w + 1];
-    // utils.vector_intercepts (utils.py:96): l_a = (d0 . sb_p) / (sa . sb_p), sa = ray, sb = wall
-    s_rden[i] = 1.0 / (ux * (-sy) + uy * sx);
-  }
-  __syncthreads();
+  const const_f64_ptr walls = (const_f64_ptr)(const void*)a.walls;
+  const const_f64_ptr dirs = (const_f64_ptr)(const void*)a.test_dirs;
+  const const_f64_ptr rden = (const_f64_ptr)(const void*)a.ray_rden;
 
   const int64_t p = (int64_t)blockIdx.x * 64 + lane;
   const bool live = p < a.P;
@@ -81,24 +67,22 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
   const double px = pxf, py = pyf;
 
   // ---- stage A: first-wall distance along each test direction (Neurons.py:1655-1684, 1746-1778)
+  // utils.vector_intercepts (utils.py:96-97) with sa = unit ray, sb = wall:
+  //   l_a = (d0 . sb_p) / (sa . sb_p),  l_b = (-d0 . sa_p) / (sb . sa_p),  sb . sa_p = -(sa . sb_p)
   for (int k = wave; k < K; k += 8) {
-    const double ux = s_dir[2 * k], uy = s_dir[2 * k + 1];
+    const double ux = dirs[2 * k], uy = dirs[2 * k + 1];
     double best = INFINITY;  // smallest valid l_a == largest preference 1/l_a; first index wins ties
     double fallback = 0.0;
-    bool have_fb = false;
     for (int w = 0; w < nw; ++w) {
-      const double ax = s_wall[4 * w], ay = s_wall[4 * w + 1], sx = s_wall[4 * w + 2], sy = s_wall[4 * w + 3];
+      const double ax = walls[4 * w], ay = walls[4 * w + 1];
+      const double sx = walls[4 * w + 2] - ax, sy = walls[4 * w + 3] - ay;
       const double d0x = ax - px, d0y = ay - py;
-      const double rd = s_rden[k * nw + w];
+      const double rd = rden[k * nw + w];
       const double la = (d0x * (-sy) + d0y * sx) * rd;
-      // l_b = (-d0 . sa_p) / (sb . sa_p) with sb . sa_p = -(sa . sb_p)
       const double lb = ((-d0x) * (-uy) + (-d0y) * ux) * (-rd);
       const bool valid = (la > 0.0) && !(lb < 0.0) && !(lb > 1.0);
       if (valid && la < best) best = la;
-      if (w == 0 && !have_fb) {
-        fallback = la;  // argmax over all -1 preferences picks wall 0
-        have_fb = true;
-      }
+      if (w == 0) fallback = la;  // argmax over all -1 preferences picks wall 0
     }
     const float d = (float)((best < INFINITY) ? best : fallback);
     s_d[k * 64 + lane] = d;
@@ -211,10 +195,10 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
 
 using namespace riab;
 
-extern "C" int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* io, const double* test_dirs, int32_t K,
-                                          const float* cells, const float* vm_table, const float* inv_norm,
+extern "C" int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* io, const double* test_dirs,
+                                          const double* ray_rden, int32_t K, const float* cells, const float* vm_table, const float* inv_norm,
                                           int32_t n, int32_t egocentric, float* ray_out, riab_stream_t stream) {
-  if (!env || !io || !test_dirs || !cells || !vm_table || !inv_norm || n <= 0 || K <= 0) return RIAB_EINVAL;
+  if (!env || !io || !test_dirs || !ray_rden || !cells || !vm_table || !inv_norm || n <= 0 || K <= 0) return RIAB_EINVAL;
   if (io->T <= 0 || io->B <= 0 || !io->rates || !io->pos_x || !io->pos_y) return RIAB_EINVAL;
   if (egocentric && (!io->hd_x || !io->hd_y)) return RIAB_EINVAL;
   if (env->n_walls <= 0 || !env->walls) return RIAB_EINVAL;  // BVCs need solid boundaries (Neurons.py:1580-1582)
@@ -245,12 +229,12 @@ extern "C" int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* 
   a.n_walls = env->n_walls;
   a.walls = env->walls;
   a.test_dirs = test_dirs;
+  a.ray_rden = ray_rden;
   a.cells = cells;
   a.vm = vm_table;
   a.inv_norm = inv_norm;
   a.ray_out = ray_out;
-  const size_t lds = sizeof(double) * (4 * (size_t)env->n_walls + (size_t)K * env->n_walls + 2 * (size_t)K) +
-                     sizeof(float) * (size_t)((K + 3) / 4 * 4) * 64;
+  const size_t lds = sizeof(float) * (size_t)((K + 3) / 4 * 4) * 64;
   if (lds > 160 * 1024) return RIAB_ETOOBIG;
   const dim3 grid((unsigned)((a.P + 63) / 64));
   hipStream_t s = (hipStream_t)stream;
