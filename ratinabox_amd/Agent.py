@@ -79,6 +79,8 @@ class Agent:
         self._hist = DeviceHistory((_L.HIST_ROWS, self._Bp), torch.float32, self._device)
         self._diag = torch.zeros(4, dtype=torch.int32, device=self._device)
         self._streams = None
+        self._scratch_row = None
+        self._last_row = None   # newest fp32 history row; None when the state was edited from the host
 
         self._state = torch.zeros((_L.STATE_ROWS, self._Bp), dtype=torch.float64, device=self._device)
         self.initialise_position_and_velocity()
@@ -127,6 +129,7 @@ class Agent:
         return self._squeeze(a if width > 1 else a[:, 0])
 
     def _upload(self, row, value):
+        self._last_row = None  # host edit: the fp32 row no longer mirrors the state
         value = np.asarray(value, dtype=np.float64)
         width = 2 if value.ndim >= 1 and value.shape[-1] == 2 and row in (
             _L.S_POS_X, _L.S_VEL_X, _L.S_MVEL_X, _L.S_HD_X) else 1
@@ -179,6 +182,14 @@ class Agent:
         """Resolve one update's parameters into the ABI struct, reproducing which values
         the reference takes from kwargs and which from attributes (Agent.py:280-285,
         310, 340, 353-355, 375, 439, 489)."""
+        key = None
+        if not kwargs:
+            key = (dt, has_drift, ratio, self.rotational_velocity_std, self.rotational_velocity_coherence_time,
+                   self.speed_coherence_time, self.speed_mean, self.speed_std, self.wall_repel_strength,
+                   self.wall_repel_distance, self.thigmotaxis, self.head_direction_smoothing_timescale)
+            hit = getattr(self, "_motion_cache", None)
+            if hit is not None and hit[0] == key:
+                return hit[1]
         g = kwargs.get
         m = _L.RiabMotion()
         rot_std = g("rotational_velocity_std", self.rotational_velocity_std)
@@ -199,6 +210,8 @@ class Agent:
         m.wall_repel_distance_kw = float(g("wall_repel_distance", self.wall_repel_distance))
         m.thigmotaxis_kw = float(g("thigmotaxis", self.thigmotaxis))
         m.hd_tau = float(self.head_direction_smoothing_timescale)
+        if key is not None:
+            self._motion_cache = (key, m)
         return m
 
     def _as_device_f64(self, x, rows):
@@ -251,12 +264,18 @@ class Agent:
             assert z.shape == (T, 2, self._Bp), f"noise must be (T,2,B), got {tuple(z.shape)}"
         if hist_view is None and self.save_history:
             hist_view = self._hist.reserve(T)
+        if hist_view is None:
+            # not saving: the kernel still leaves the step's fp32 row (what the rate kernels read)
+            if self._scratch_row is None or self._scratch_row.shape[0] < T:
+                self._scratch_row = torch.empty((T, _L.HIST_ROWS, self._Bp), dtype=torch.float32, device=self._device)
+            hist_view = self._scratch_row[:T]
         s = stream if stream is not None else _L.current_stream()
         rc = _L.lib.riab_agent_step(env, m, _L.ptr(self._state), self._Bp, int(self.agent_id0), _L.ptr(drift),
                                     _L.ptr(z), _L.ptr(z_out), int(self.seed), int(self._step_index), int(T),
                                     _L.ptr(hist_view), _L.ptr(self._diag), int(self.precision), s)
         _L.check(rc, "riab_agent_step")
         self._keep = (drift, z, _walls, hist_view)  # keep operands alive until the stream is done
+        self._last_row = hist_view[T - 1]            # fp32 [8, Bp]: positions / head directions of the newest step
         for _ in range(T):
             self.prev_t = self.t
             self.t += dt

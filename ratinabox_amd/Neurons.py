@@ -115,10 +115,17 @@ class Neurons:
         u_t = None if u is None else self._as_rows(u, torch.float32).unsqueeze(0)
         # spikes are drawn on the final rate: fuse them only when no noise is added afterwards
         io_spikes = spikes if not need_noise else None
-        st = Ag._state
-        self._launch(st[_L.S_POS_X], st[_L.S_POS_Y], st[_L.S_HD_X], st[_L.S_HD_Y], pos_ld=self._Bp, T=1,
-                     B=self._Bp, rates=rates, spikes=io_spikes, u_in=u_t if not need_noise else None,
-                     dt=float(Ag.dt), step0=Ag._step_index, from_f64=True)
+        row = Ag._last_row
+        if row is not None:
+            # the motion kernel already left this step's fp32 positions / head directions
+            self._launch(row[_L.H_POS_X], row[_L.H_POS_Y], row[_L.H_HD_X], row[_L.H_HD_Y], pos_ld=self._Bp, T=1,
+                         B=self._Bp, rates=rates, spikes=io_spikes, u_in=u_t if not need_noise else None,
+                         dt=float(Ag.dt), step0=Ag._step_index)
+        else:
+            st = Ag._state
+            self._launch(st[_L.S_POS_X], st[_L.S_POS_Y], st[_L.S_HD_X], st[_L.S_HD_Y], pos_ld=self._Bp, T=1,
+                         B=self._Bp, rates=rates, spikes=io_spikes, u_in=u_t if not need_noise else None,
+                         dt=float(Ag.dt), step0=Ag._step_index, from_f64=True)
         if need_noise:
             tau = float(self.noise_coherence_time)
             sigma = float(np.sqrt((2 * float(self.noise_std) ** 2) / (tau * Ag.dt)))
