@@ -217,11 +217,12 @@ int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* io, const d
  * (then n, B, T describe the [T][n][B] shape). */
 int riab_spikes(const RiabRateIO* io, int32_t n, riab_stream_t stream);
 
-/* Neurons.update noise (Neurons.py:153-168): noise += OU(noise; 0, noise_std,
- * noise_coherence_time) for one step and rates[c][b] += noise[c][b].
- * noise device float32 [n][B] read/written; z_in device float32 [n][B]
- * standard normals or NULL => Philox. theta = 1/tau, sigma_dt = sigma*dt. */
-int riab_neuron_noise(float* noise, float* rates, const float* z_in, int32_t n, int64_t B,
+/* Neurons.update noise (Neurons.py:153-168) for T consecutive steps: for each time row t,
+ * noise += OU(noise; 0, noise_std, noise_coherence_time) and rates[t][c][b] += noise[c][b].
+ * noise device float32 [n][B] read/written; rates device float32 [T][n][B]; z_in device
+ * float32 [T][n][B] standard normals or NULL => Philox keyed by (seed; step+t, cell, agent).
+ * theta_dt = dt/tau, sigma_dt = sqrt(2 std^2/(tau dt)) * dt (utils.py:361-368). */
+int riab_neuron_noise(float* noise, float* rates, const float* z_in, int32_t n, int64_t B, int32_t T,
                       float theta_dt, float sigma_dt, uint64_t seed, uint64_t step, int32_t pop_id,
                       int64_t agent_id0, riab_stream_t stream);
 

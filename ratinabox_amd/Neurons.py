@@ -130,7 +130,7 @@ class Neurons:
             tau = float(self.noise_coherence_time)
             sigma = float(np.sqrt((2 * float(self.noise_std) ** 2) / (tau * Ag.dt)))
             z_t = None if zn is None else self._as_rows(zn, torch.float32)
-            rc = _L.lib.riab_neuron_noise(_L.ptr(self._noise), _L.ptr(rates), _L.ptr(z_t), int(self.n), self._Bp,
+            rc = _L.lib.riab_neuron_noise(_L.ptr(self._noise), _L.ptr(rates), _L.ptr(z_t), int(self.n), self._Bp, 1,
                                           float(Ag.dt / tau), float(sigma * Ag.dt), int(Ag.seed),
                                           int(Ag._step_index), int(self.pop_id), int(Ag.agent_id0),
                                           _L.current_stream())
@@ -245,8 +245,6 @@ class Neurons:
     # ---- fused path hooks (called by Agent.simulate) ---------------------------------------------
     def _reserve_rows(self, n_steps, ring):
         n = int(self.n)
-        if self.noise_std != 0:
-            raise NotImplementedError("noise_std > 0 is supported by update(), not yet by the fused simulate() path")
         if self.save_history:
             return dict(fr=self._hist_fr.reserve(n_steps),
                         sp=self._hist_sp.reserve(n_steps) if self.save_spikes else None, ring=None)
@@ -271,10 +269,24 @@ class Neurons:
         hook = getattr(self.Agent, "_profile_hook", None)
         if hook is not None:
             hook(self, "begin", tc)
+        noisy = self.noise_std != 0
         self._launch(traj[0, _L.H_POS_X], traj[0, _L.H_POS_Y], traj[0, _L.H_HD_X], traj[0, _L.H_HD_Y], pos_ld=ld,
-                     T=tc, B=Bp, rates=fr, spikes=sp, u_in=None, dt=dt, step0=step0 + 1, stream=stream)
+                     T=tc, B=Bp, rates=fr, spikes=None if noisy else sp, u_in=None, dt=dt, step0=step0 + 1,
+                     stream=stream)
         if hook is not None:
             hook(self, "end", tc)
+        if noisy:
+            # rates -> + OU noise (sequential over the chunk's rows) -> spikes on the noisy rates
+            tau = float(self.noise_coherence_time)
+            sigma = float(np.sqrt((2 * float(self.noise_std) ** 2) / (tau * dt)))
+            Ag = self.Agent
+            rc = _L.lib.riab_neuron_noise(_L.ptr(self._noise), _L.ptr(fr), None, int(self.n), Bp, int(tc),
+                                          float(dt / tau), float(sigma * dt), int(Ag.seed), int(step0 + 1),
+                                          int(self.pop_id), int(Ag.agent_id0), stream)
+            _L.check(rc, "riab_neuron_noise")
+            if sp is not None:
+                io = self._io(None, None, None, None, Bp, tc, Bp, fr, sp, None, dt, step0 + 1)
+                _L.check(_L.lib.riab_spikes(io, int(self.n), stream), "riab_spikes")
 
     def _finish_rows(self, out, n_steps, times):
         if out["ring"] is None:

@@ -61,7 +61,7 @@ PROTOTYPES = {
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                              C.c_void_p]),
     "riab_spikes": (C.c_int, [C.POINTER(RiabRateIO), C.c_int32, C.c_void_p]),
-    "riab_neuron_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_float,
+    "riab_neuron_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float,
                                     C.c_uint64, C.c_uint64, C.c_int32, C.c_int64, C.c_void_p]),
     "riab_fill": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "riab_abi_version": (C.c_int, []),

@@ -386,30 +386,34 @@ __global__ __launch_bounds__(256) void spikes_kernel(const RateArgs a) {
 
 // ---- Neurons.update noise (reference Neurons.py:153-168) -----------------------------------
 __global__ __launch_bounds__(256) void noise_kernel(float* noise, float* rates, const float* z_in, int n,
-                                                    int64_t qrow, float theta_dt, float sigma_dt, uint32_t k0,
-                                                    uint32_t k1, uint32_t step, uint32_t tag, uint32_t group0) {
+                                                    int64_t qrow, int T, float theta_dt, float sigma_dt, uint32_t k0,
+                                                    uint32_t k1, uint32_t step0, uint32_t tag, uint32_t group0) {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y;
   if (q >= qrow) return;
   const int64_t off = ((int64_t)c * qrow + q) * 4;
-  v4f z;
-  if (z_in) {
-    z = ldv4(z_in + off);
-  } else {
-    const u32x4 w = philox4x32_10(step, (uint32_t)c, group0 + (uint32_t)q, tag, k0, k1);
-    // two Box-Muller pairs in fp32
-    const float u0 = ((float)(w.x >> 8) + 0.5f) * 0x1.0p-24f, u1 = (float)(w.y >> 8) * 0x1.0p-24f;
-    const float u2 = ((float)(w.z >> 8) + 0.5f) * 0x1.0p-24f, u3 = (float)(w.w >> 8) * 0x1.0p-24f;
-    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
-    z = v4f{r0 * __builtin_amdgcn_cosf(u1), r0 * __builtin_amdgcn_sinf(u1), r1 * __builtin_amdgcn_cosf(u3),
-            r1 * __builtin_amdgcn_sinf(u3)};
-  }
+  const int64_t row = (int64_t)n * qrow * 4;  // elements between consecutive time rows
   v4f x = ldv4(noise + off);
-  // utils.ornstein_uhlenbeck with drift 0: dx = theta*(0 - x)*dt + sigma*(dt*z)
-  x = x + (-theta_dt) * x + sigma_dt * z;
+  // the OU recurrence is sequential in time: one lane walks the T rows of its (cell, 4 agents)
+  for (int t = 0; t < T; ++t) {
+    v4f z;
+    if (z_in) {
+      z = ldv4(z_in + t * row + off);
+    } else {
+      const u32x4 w = philox4x32_10(step0 + (uint32_t)t, (uint32_t)c, group0 + (uint32_t)q, tag, k0, k1);
+      // two Box-Muller pairs in fp32
+      const float u0 = ((float)(w.x >> 8) + 0.5f) * 0x1.0p-24f, u1 = (float)(w.y >> 8) * 0x1.0p-24f;
+      const float u2 = ((float)(w.z >> 8) + 0.5f) * 0x1.0p-24f, u3 = (float)(w.w >> 8) * 0x1.0p-24f;
+      const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+      z = v4f{r0 * __builtin_amdgcn_cosf(u1), r0 * __builtin_amdgcn_sinf(u1), r1 * __builtin_amdgcn_cosf(u3),
+              r1 * __builtin_amdgcn_sinf(u3)};
+    }
+    // utils.ornstein_uhlenbeck with drift 0: dx = theta*(0 - x)*dt + sigma*(dt*z)
+    x = x + (-theta_dt) * x + sigma_dt * z;
+    const v4f r = ldv4(rates + t * row + off);
+    *reinterpret_cast<v4f*>(rates + t * row + off) = r + x;
+  }
   *reinterpret_cast<v4f*>(noise + off) = x;
-  v4f r = ldv4(rates + off);
-  *reinterpret_cast<v4f*>(rates + off) = r + x;
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float* dst, int64_t n4, float value) {
@@ -586,14 +590,14 @@ extern "C" int riab_spikes(const RiabRateIO* io, int32_t n, riab_stream_t stream
   return (int)hipGetLastError();
 }
 
-extern "C" int riab_neuron_noise(float* noise, float* rates, const float* z_in, int32_t n, int64_t B, float theta_dt,
-                                 float sigma_dt, uint64_t seed, uint64_t step, int32_t pop_id, int64_t agent_id0,
-                                 riab_stream_t stream) {
-  if (!noise || !rates || n <= 0 || B <= 0) return RIAB_EINVAL;
+extern "C" int riab_neuron_noise(float* noise, float* rates, const float* z_in, int32_t n, int64_t B, int32_t T,
+                                 float theta_dt, float sigma_dt, uint64_t seed, uint64_t step, int32_t pop_id,
+                                 int64_t agent_id0, riab_stream_t stream) {
+  if (!noise || !rates || n <= 0 || B <= 0 || T <= 0) return RIAB_EINVAL;
   if (B % 4 || agent_id0 % 4 || (((uintptr_t)noise | (uintptr_t)rates | (uintptr_t)z_in) & 15)) return RIAB_EALIGN;
   const int64_t qrow = B / 4;
   dim3 grid((unsigned)((qrow + 255) / 256), (unsigned)n, 1);
-  hipLaunchKernelGGL(noise_kernel, grid, dim3(256), 0, (hipStream_t)stream, noise, rates, z_in, n, qrow, theta_dt,
+  hipLaunchKernelGGL(noise_kernel, grid, dim3(256), 0, (hipStream_t)stream, noise, rates, z_in, n, qrow, T, theta_dt,
                      sigma_dt, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step,
                      RIAB_TAG_NOISE | ((uint32_t)pop_id & 0xFFu), (uint32_t)(agent_id0 / 4));
   return (int)hipGetLastError();

@@ -348,3 +348,78 @@ def test_abi_rejects_bad_arguments(riab):
     env, _ = make_env(riab).device_tables(torch.device("cuda"))
     assert L.lib.riab_place_cells(env, io, L.ptr(x), 4, 0, 0, 0.2, None) == -2  # B % 4
     assert "multiple of 4" in L.strerror(-2)
+
+
+def test_noise_fused_equals_per_step(riab):
+    """noise_std > 0: simulate() (rates -> OU noise over the chunk -> spikes) reproduces the
+    per-step update() path exactly (same Philox draws, same arithmetic)."""
+    def world():
+        np.random.seed(11)
+        Ag = riab.Agent(make_env(riab), {"n_agents": 128, "dt": 0.02, "seed": 5})
+        PCs = riab.PlaceCells(Ag, {"n": 20, "noise_std": 0.3, "noise_coherence_time": 0.1, "max_fr": 20.0})
+        return Ag, PCs
+    Ag, PCs = world()
+    for _ in range(12):
+        Ag.update()
+        PCs.update()
+    Ag2, P2 = world()
+    Ag2.simulate(12, chunk=5)
+    torch.cuda.synchronize()
+    assert np.array_equal(P2.history["firingrate"], PCs.history["firingrate"])
+    assert np.array_equal(P2.history["spikes"], PCs.history["spikes"])
+    assert np.array_equal(P2.noise, PCs.noise)
+    assert np.std(PCs.noise) > 0.05 and PCs.history["spikes"].sum() > 0
+
+
+def test_reference_style_scripts(riab):
+    """The flows of the reference's own smoke tests (reference tests/test_advanced.py:17-107,
+    demos/simple_example.ipynb) run unchanged apart from the import."""
+    Environment, Agent = riab.Environment, riab.Agent
+    PlaceCells, BoundaryVectorCells, GridCells = riab.PlaceCells, riab.BoundaryVectorCells, riab.GridCells
+    np.random.seed(0)
+    # test_simple
+    Env = Environment()
+    Ag = Agent(Env)
+    PCs = PlaceCells(Ag)
+    for i in range(int(6 / Ag.dt)):
+        Ag.update()
+        PCs.update()
+    assert np.asarray(Ag.history["pos"]).shape == (120, 2) and np.asarray(PCs.history["firingrate"]).shape == (120, 10)
+    assert np.isfinite(PCs.history["firingrate"]).all() and abs(Ag.t - 6.0) < 1e-9
+    # test_extensive: 2x1 box, two walls, thresholded line-of-sight place cells, BVCs, attribute edits
+    Env = Environment(params={"aspect": 2, "scale": 1})
+    Env.add_wall([[1, 0], [1, 0.35]])
+    Env.add_wall([[1, 0.65], [1, 1]])
+    Ag = Agent(Env)
+    Ag.pos = np.array([0.5, 0.5])
+    Ag.speed_mean = 0.2
+    PCs = PlaceCells(Ag, params={"n": 20, "description": "gaussian_threshold", "widths": 0.40,
+                                 "wall_geometry": "line_of_sight", "max_fr": 10, "min_fr": 0.1})
+    PCs.place_cell_centres[-1] = np.array([1.1, 0.5])
+    BVCs = BoundaryVectorCells(Ag, params={"n": 10})
+    dt = 50e-3
+    for i in range(int(10 / dt)):
+        Ag.update(dt=dt)
+        PCs.update()
+        BVCs.update()
+    pos = np.asarray(Ag.history["pos"])
+    assert pos.shape == (200, 2) and (pos[:, 0] > 0).all() and (pos[:, 0] < 2).all() and (pos[:, 1] < 1).all()
+    fr = np.asarray(PCs.history["firingrate"])
+    assert fr.min() >= 0.1 - 1e-6 and fr.max() <= 10 + 1e-4
+    # the edited centre is live: the last cell's rate map peaks at the new centre
+    rm = PCs.get_state(evaluate_at="all")
+    peak = Env.flattened_discrete_coords[np.argmax(rm[-1])]
+    assert np.linalg.norm(peak - np.array([1.1, 0.5])) < 0.03
+    assert np.asarray(BVCs.history["firingrate"]).shape == (200, 10)
+    h = PCs.get_history_arrays()
+    assert set(h) == {"t", "firingrate", "spikes"} and h["spikes"].dtype == bool
+    # decoding-style use: GridCells + training data arrays
+    GCs = GridCells(Ag, params={"n": 40, "gridscale": (0.8, 0.8), "gridscale_distribution": "uniform"})
+    for i in range(20):
+        Ag.update()
+        GCs.update()
+    t = np.asarray(GCs.history["t"])
+    assert len(t) == 20 and np.all(np.diff(t) > 0)
+    Ag.reset_history()
+    PCs.reset_history()
+    assert len(Ag.history["t"]) == 0 and PCs.history["firingrate"].shape[0] == 0
