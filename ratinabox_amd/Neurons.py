@@ -503,13 +503,18 @@ class VectorCells(Neurons):
             mu_d, mu_t, sg_d, sg_t = arr(**self.params)
         elif arr is None or arr[:6] == "random":
             mu_d, mu_t, sg_d, sg_t = utils.create_random_assembly(**self.params)
+        elif arr == "uniform_manifold":
+            mu_d, mu_t, sg_d, sg_t = utils.create_uniform_radial_assembly(**self.params)
+        elif arr == "diverging_manifold":
+            mu_d, mu_t, sg_d, sg_t = utils.create_diverging_radial_assembly(**self.params)
         else:
-            raise NotImplementedError("radial field-of-view manifolds are outside the accelerated path (SURVEY §8f)")
+            raise ValueError("cell_arrangement must be 'random', 'uniform_manifold', 'diverging_manifold' or a function")
         self.tuning_distances, self.tuning_angles = np.array(mu_d), np.array(mu_t)
         self.sigma_distances, self.sigma_angles = np.array(sg_d), np.array(sg_t)
         assert len(self.tuning_distances) == len(self.tuning_angles) == len(self.sigma_distances) == len(
             self.sigma_angles), "All manifold tuning parameters must be of the same length"
-        if "n" in params and params["n"] is not None and params["n"] != len(self.tuning_distances):
+        manifold = isinstance(arr, str) and arr.endswith("manifold")
+        if getattr(self, "_warn_if_n_changes", False) and (manifold or self.n != len(self.tuning_distances)):
             warnings.warn(f"Ignoring 'n' parameter value ({params['n']}) that was passed, and setting number of "
                           f"{self.name} neurons to {len(self.tuning_distances)}, inferred from the cell arrangement.")
         self.n = len(self.tuning_distances)
@@ -533,6 +538,8 @@ class BoundaryVectorCells(VectorCells):
         self.Agent = Agent
         self.params = copy.deepcopy(__class__.default_params)
         self.params.update(params)
+        if not hasattr(self, "_warn_if_n_changes"):  # warn only when the USER passed an n that gets overridden
+            self._warn_if_n_changes = "n" in params and params["n"] is not None
         super().__init__(Agent, self.params)
         assert self.Agent.Environment.boundary_conditions == "solid", \
             "boundary cells only possible with solid boundary conditions"
@@ -585,6 +592,30 @@ class BoundaryVectorCells(VectorCells):
         rc = _L.lib.riab_boundary_vector_cells(env, io, _L.ptr(dirs_t), _L.ptr(rden_t), K, _L.ptr(cells_t), _L.ptr(vm_t),
                                                _L.ptr(inv_t), n, 1 if ego else 0, None, stream)
         _L.check(rc, "riab_boundary_vector_cells")
+
+
+class FieldOfViewBVCs(BoundaryVectorCells):
+    """Egocentric boundary vector cells tiling the agent's field of view in concentric rows
+    (reference Neurons.py:1847-1888): a parameterisation of the egocentric BVC kernel.
+    `cell_arrangement`: "diverging_manifold" (field size grows with distance, default) or
+    "uniform_manifold"."""
+
+    default_params = {
+        "distance_range": [0.02, 0.4],
+        "angle_range": [0, 75],
+        "spatial_resolution": 0.02,
+        "cell_arrangement": "diverging_manifold",
+        "beta": 5,
+        "color": "darkgrey",
+    }
+
+    def __init__(self, Agent, params={}):
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        self.params["reference_frame"] = "egocentric"
+        assert self.params["cell_arrangement"] is not None, "cell_arrangement must be set for FoV Neurons"
+        self._warn_if_n_changes = "n" in params and params["n"] is not None
+        super().__init__(Agent, self.params)
 
 
 # ================================================================================================

@@ -160,3 +160,54 @@ def create_random_assembly(tuning_distance_distribution="uniform", tuning_distan
     tuning_angle = np.asarray(tuning_angle, dtype=float) * (np.pi / 180)
     sigma_angle = np.asarray(sigma_angle, dtype=float) * (np.pi / 180)
     return tuning_distance, tuning_angle, sigma_distance, sigma_angle
+
+
+# --------------------------------------------------------------------------- #
+# egocentric field-of-view manifolds (reference utils.py:1033-1121)
+# --------------------------------------------------------------------------- #
+def _fov_row_angles(first, last, step):
+    """Angles (radians) of one concentric row: cells every `step` from `first + step/2` up to
+    `last` on the right of the heading, mirrored on the left."""
+    right = np.arange(first + step / 2, last, step)
+    return np.concatenate((-right[::-1], right))
+
+
+def create_uniform_radial_assembly(distance_range=[0.0, 0.2], angle_range=[0, 90], spatial_resolution=0.04,
+                                   **kwargs):
+    """Concentric rows of receptive fields of constant size `spatial_resolution` tiling the
+    field of view: returns lists (mu_d, mu_theta [rad], sigma_d, sigma_theta [rad])."""
+    lo, hi = (a * np.pi / 180 for a in angle_range)
+    mu_d, mu_theta, sigma_d, sigma_theta = [], [], [], []
+    for radius in np.arange(max(0.01, distance_range[0]), distance_range[1], spatial_resolution):
+        for theta in _fov_row_angles(lo, hi, spatial_resolution / radius):
+            mu_d.append(radius)
+            mu_theta.append(theta)
+            sigma_d.append(spatial_resolution)
+            sigma_theta.append(spatial_resolution / radius)
+    return mu_d, mu_theta, sigma_d, sigma_theta
+
+
+def create_diverging_radial_assembly(distance_range=[0.01, 0.2], angle_range=[0, 90], spatial_resolution=0.04,
+                                     beta=5, **kwargs):
+    """As the uniform assembly but the field size grows with radius (Hartley et al. 2000):
+    size = xi + radius/beta with xi fixed by the innermost row having size `spatial_resolution`;
+    successive rows just touch: r_next = (2 r + size + xi) / (2 - 1/beta)."""
+    lo, hi = (a * np.pi / 180 for a in angle_range)
+    mu_d, mu_theta, sigma_d, sigma_theta = [], [], [], []
+    radius = max(0.01, distance_range[0])
+    xi = spatial_resolution - radius / beta
+    while radius < distance_range[1]:
+        size = xi + radius / beta
+        step = size / radius
+        if step / 2 > hi:
+            right = np.array([lo + step / 2])  # at least one cell per row
+            thetas = np.concatenate((-right[::-1], right))
+        else:
+            thetas = _fov_row_angles(lo, hi, step)
+        for theta in thetas:
+            mu_d.append(radius)
+            mu_theta.append(theta)
+            sigma_d.append(size)
+            sigma_theta.append(size / radius)
+        radius = (2 * radius + size + xi) / (2 - 1 / beta)
+    return mu_d, mu_theta, sigma_d, sigma_theta

@@ -35,7 +35,7 @@ import ratinabox  # noqa: E402
 from ratinabox.Environment import Environment  # noqa: E402
 from ratinabox.Agent import Agent  # noqa: E402
 from ratinabox.Neurons import (  # noqa: E402
-    PlaceCells, GridCells, BoundaryVectorCells, HeadDirectionCells)
+    PlaceCells, GridCells, BoundaryVectorCells, HeadDirectionCells, FieldOfViewBVCs)
 from ratinabox import utils as rutils  # noqa: E402
 
 _real = np.random.RandomState(12345)
@@ -287,6 +287,16 @@ def make_rates():
     for j in range(192):
         hdr[:, j] = H.get_state(evaluate_at=None, head_direction=hd[j], pos=pos[j:j + 1])[:, 0]
     out["hdc_rates"] = hdr
+    # --- FieldOfViewBVCs (egocentric radial manifolds; no random draws)
+    for tag, prm in (("div", {}), ("uni", {"cell_arrangement": "uniform_manifold", "distance_range": [0.05, 0.3],
+                                           "angle_range": [0, 120], "spatial_resolution": 0.05})):
+        F = FieldOfViewBVCs(AgM, dict(prm))
+        for k in ["tuning_distances", "tuning_angles", "sigma_distances", "sigma_angles"]:
+            out[f"fov_{tag}_{k}"] = np.array(getattr(F, k), float)
+        fr = np.zeros((F.n, 32))
+        for j in range(32):
+            fr[:, j] = F.get_state(evaluate_at=None, pos=pos[j:j + 1], head_direction=hd[j])[:, 0]
+        out[f"fov_{tag}_rates"] = fr
     np.savez_compressed(os.path.join(HERE, "rates.npz"), **out)
     print("  rates.npz written:", len(out), "arrays")
 

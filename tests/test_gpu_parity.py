@@ -117,6 +117,18 @@ def test_bvc_egocentric_vs_reference(riab):
     assert_rates(got, g["bvc_ego_rates"], scale=2.5, floor=1.0)
 
 
+@pytest.mark.parametrize("tag,prm", [("div", {}), ("uni", {"cell_arrangement": "uniform_manifold",
+                                                          "distance_range": [0.05, 0.3], "angle_range": [0, 120],
+                                                          "spatial_resolution": 0.05})])
+def test_field_of_view_bvcs_vs_reference(riab, tag, prm):
+    """FieldOfViewBVCs = the egocentric BVC kernel on a radial manifold."""
+    g = gu.load("rates.npz")
+    Ag = riab.Agent(make_env(riab, g["maze_walls"][4:]))
+    F = riab.FieldOfViewBVCs(Ag, dict(prm))
+    got = F.get_state(evaluate_at=None, pos=g["pos"][:32], head_direction=g["hd"][:32])
+    assert_rates(got, g[f"fov_{tag}_rates"], floor=1.0)
+
+
 def test_head_direction_cells_vs_reference(riab):
     g = gu.load("rates.npz")
     Ag = riab.Agent(make_env(riab))

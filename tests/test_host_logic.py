@@ -144,3 +144,20 @@ def test_samplers():
     d, a, sd, sa = riab.utils.create_random_assembly(tuning_distance=[0.1, 0.2], sigma_angle=(20, 20),
                                                      sigma_angle_distribution="delta")
     assert len(d) == 2 and np.allclose(sd, 0.08 + np.array([0.1, 0.2]) / 12) and np.allclose(sa, np.radians(20))
+
+
+def test_field_of_view_manifolds_match_reference():
+    g = gu.load("rates.npz")
+    env = riab.Environment({"walls": MAZE})
+    ag = riab.Agent(env, CPU)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # no spurious "ignoring n" / unknown-key warnings
+        div = riab.FieldOfViewBVCs(ag)
+        uni = riab.FieldOfViewBVCs(ag, {"cell_arrangement": "uniform_manifold", "distance_range": [0.05, 0.3],
+                                        "angle_range": [0, 120], "spatial_resolution": 0.05})
+    for tag, X in (("div", div), ("uni", uni)):
+        assert X.reference_frame == "egocentric" and X.n == len(g[f"fov_{tag}_tuning_distances"])
+        for k in ["tuning_distances", "tuning_angles", "sigma_distances", "sigma_angles"]:
+            assert np.array_equal(getattr(X, k), g[f"fov_{tag}_{k}"]), (tag, k)
+    with pytest.warns(UserWarning, match="Ignoring 'n'"):
+        riab.FieldOfViewBVCs(ag, {"n": 7})

@@ -144,3 +144,12 @@ def test_philox_known_answers():
     assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
     u = orc.spike_uniforms(1, 3, 0, 64, 1024)
     assert u.dtype == np.float32 and u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.01
+
+
+@pytest.mark.parametrize("tag", ["div", "uni"])
+def test_field_of_view_bvcs(tag):
+    """FieldOfViewBVCs (Neurons.py:1847-1888) = the egocentric BVC on a radial manifold."""
+    g = _rates()
+    got = orc.bvc(g["pos"][:32], g["maze_walls"], g[f"fov_{tag}_tuning_distances"], g[f"fov_{tag}_tuning_angles"],
+                  g[f"fov_{tag}_sigma_distances"], g[f"fov_{tag}_sigma_angles"], head_direction=g["hd"][:32])
+    np.testing.assert_allclose(got, g[f"fov_{tag}_rates"], rtol=1e-10, atol=1e-14)
