@@ -121,6 +121,11 @@ typedef struct RiabMotion {
  *             reference draws per update (rotation OU, speed OU).  NULL =>
  *             Philox4x32-10 keyed by (seed; step0+t, agent id)
  *  z_out      device float64 [T][2][B] or NULL: records the normals used
+ *  forced_pos device float64 [T][2][B] or NULL: imported / forced positions — the motion
+ *             model is skipped, the step is "moved to forced_pos[t]" and velocity /
+ *             rotational velocity are overwritten by the measured ones
+ *             (Agent._update_position_along_imported_trajectory / forced_next_position,
+ *             Agent.py:229-238, 244-266)
  *  hist       device float32 [T][RIAB_HIST_ROWS][B] or NULL
  *  diag       device int32 [4] or NULL, atomically accumulated:
  *             [0] bounces, [1] bounce-loop saturations, [2] boundary
@@ -129,7 +134,7 @@ typedef struct RiabMotion {
  */
 int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
                     int64_t agent_id0, const double* drift, const double* z_in, double* z_out,
-                    uint64_t seed, uint64_t step0, int32_t T, float* hist, int32_t* diag,
+                    const double* forced_pos, uint64_t seed, uint64_t step0, int32_t T, float* hist, int32_t* diag,
                     int32_t precision, riab_stream_t stream);
 
 /* Where a firing-rate kernel reads positions and writes rates / spikes.

@@ -260,7 +260,7 @@ def init_state(env, n_agents, speed_mean, rng):
 
 
 def agent_step(env, state, dt, z_rot, z_speed, params=None, drift_velocity=None,
-               drift_to_random_strength_ratio=1.0, z_zero=None, kwargs=None):
+               drift_to_random_strength_ratio=1.0, z_zero=None, kwargs=None, forced_pos=None):
     """One `Agent.update()` (Agent.py:160-242, random-motion branch, 2D) for B
     independent agents.  `state` is a dict of `(B,...)` float64 arrays (see
     `init_state`); `z_rot`, `z_speed` `(B,)` are the two standard-normal draws
@@ -269,7 +269,10 @@ def agent_step(env, state, dt, z_rot, z_speed, params=None, drift_velocity=None,
     to the sub-steps (Agent.py:280-285, 353-355) — note the reference reads some
     quantities from the attribute even when a kwarg is given (speed_std==0 switch
     :310, wall spring speed :375, bounce speed :439, drift tau :340).  Returns a
-    new state dict plus `n_bounces (B,)` and `bc_applied (B,)` diagnostics."""
+    new state dict plus `n_bounces (B,)` and `bc_applied (B,)` diagnostics.
+    `forced_pos (B,2)`: the imported / forced-trajectory branches (Agent.py:229-238): the motion
+    model is skipped, the agent is put at `forced_pos` and velocity / rotational velocity are
+    overwritten by the measured ones."""
     p = dict(DEFAULT_MOTION)
     if params:
         p.update(params)
@@ -285,6 +288,11 @@ def agent_step(env, state, dt, z_rot, z_speed, params=None, drift_velocity=None,
     B = pos.shape[0]
     prev_pos = pos.copy()
     speed_mean = p["speed_mean"]
+
+    if forced_pos is not None:
+        return _finish_step(env, p, dt, np.array(forced_pos, dtype=np.float64).reshape(B, 2), prev_pos, vel, rot,
+                            prev_mv, hd, dist_trav, dclose, np.zeros(B, dtype=np.int32), np.zeros(B, dtype=bool),
+                            z_zero, overwrite=True)
 
     # -- _stochastic_velocity_update (Agent.py:268-312)
     rot = rot + ou_increment(rot, dt, rotational_velocity_drift,
@@ -365,6 +373,15 @@ def agent_step(env, state, dt, z_rot, z_speed, params=None, drift_velocity=None,
     if outside.any():
         pos = np.where(outside[:, None], env_apply_boundary_conditions(env, pos), pos)
 
+    return _finish_step(env, p, dt, pos, prev_pos, vel, rot, prev_mv, hd, dist_trav, dclose, n_bounces, outside,
+                        z_zero, overwrite=False)
+
+
+def _finish_step(env, p, dt, pos, prev_pos, vel, rot, prev_mv, hd, dist_trav, dclose, n_bounces, outside, z_zero,
+                 overwrite):
+    """Common tail of Agent.update (Agent.py:224-242): measured velocities, head direction,
+    distance travelled."""
+    B = pos.shape[0]
     # -- _measure_velocity_of_step_taken (Agent.py:444-472)
     d_pos = pos - prev_pos
     if env.periodic:
@@ -378,6 +395,8 @@ def agent_step(env, state, dt, z_rot, z_speed, params=None, drift_velocity=None,
         mv = np.where(still[:, None], 1e-8 * zz, mv)
         mv_norm = np.sqrt(mv[:, 0] ** 2 + mv[:, 1] ** 2)
     mrv = pi_domain(get_angle(mv) - get_angle(prev_mv)) / dt
+    if overwrite:  # overwrite_velocity=True (Agent.py:461-462, 469-470)
+        vel, rot = mv.copy(), mrv.copy()
 
     # -- _update_head_direction (Agent.py:474-500)
     tau_h = p["head_direction_smoothing_timescale"]

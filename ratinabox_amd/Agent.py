@@ -237,11 +237,19 @@ class Agent:
         kwargs: the reference's per-call overrides (speed_mean, thigmotaxis, ...), plus
         `noise=` — explicit standard normals `(2, B)` / `(B, 2)` [rotation OU, speed OU]
         instead of the in-kernel Philox draws (parity mode)."""
-        if self.use_imported_trajectory or kwargs.get("forced_next_position") is not None:
-            raise NotImplementedError("imported / forced trajectories are outside the accelerated path")
-        self._advance(1, dt, drift_velocity, drift_to_random_strength_ratio, kwargs)
+        forced = kwargs.pop("forced_next_position", None)
+        if forced is not None:
+            # Agent._update_position_to_forced_next_position (Agent.py:244-253): overrides everything else
+            forced = np.asarray(forced, dtype=np.float64)
+            assert forced.shape in ((2,), (self._B, 2)), "forced_next_position must have shape (2,) or (n_agents, 2)"
+            self._advance(1, dt, None, 1, kwargs, forced=self._as_device_f64(forced, 2).unsqueeze(0))
+        elif self.use_imported_trajectory:
+            self._advance_imported(1, dt, kwargs)
+        else:
+            self._advance(1, dt, drift_velocity, drift_to_random_strength_ratio, kwargs)
 
-    def _advance(self, T, dt, drift_velocity, ratio, kwargs, hist_view=None, stream=None, z_out=None):
+    def _advance(self, T, dt, drift_velocity, ratio, kwargs, hist_view=None, stream=None, z_out=None,
+                 forced=None):
         dt = dt or self.dt
         self.dt = dt
         noise = kwargs.pop("noise", None) if "noise" in kwargs else None
@@ -271,10 +279,11 @@ class Agent:
             hist_view = self._scratch_row[:T]
         s = stream if stream is not None else _L.current_stream()
         rc = _L.lib.riab_agent_step(env, m, _L.ptr(self._state), self._Bp, int(self.agent_id0), _L.ptr(drift),
-                                    _L.ptr(z), _L.ptr(z_out), int(self.seed), int(self._step_index), int(T),
+                                    _L.ptr(z), _L.ptr(z_out), _L.ptr(forced), int(self.seed),
+                                    int(self._step_index), int(T),
                                     _L.ptr(hist_view), _L.ptr(self._diag), int(self.precision), s)
         _L.check(rc, "riab_agent_step")
-        self._keep = (drift, z, _walls, hist_view)  # keep operands alive until the stream is done
+        self._keep = (drift, z, _walls, hist_view, forced)  # keep operands alive until the stream is done
         self._last_row = hist_view[T - 1]            # fp32 [8, Bp]: positions / head directions of the newest step
         for _ in range(T):
             self.prev_t = self.t
@@ -324,8 +333,11 @@ class Agent:
             if z_all is not None:
                 kw["noise"] = z_all[t0:t0 + tc]
             with torch.cuda.stream(s_traj):
-                self._advance(tc, dt, drift_velocity, drift_to_random_strength_ratio, kw, hist_view=view,
-                              stream=_lib.C.c_void_p(s_traj.cuda_stream))
+                if self.use_imported_trajectory:
+                    self._advance_imported(tc, dt, kw, hist_view=view, stream=_lib.C.c_void_p(s_traj.cuda_stream))
+                else:
+                    self._advance(tc, dt, drift_velocity, drift_to_random_strength_ratio, kw, hist_view=view,
+                                  stream=_lib.C.c_void_p(s_traj.cuda_stream))
                 ev = torch.cuda.Event()
                 ev.record(s_traj)
             s_rate.wait_event(ev)
@@ -410,5 +422,61 @@ class Agent:
     def save_to_history(self, **kwargs):
         raise NotImplementedError("history rows are written by the motion kernel; there is no host-side append")
 
-    def import_trajectory(self, *a, **k):
-        raise NotImplementedError("imported trajectories are outside the accelerated path (SURVEY §8f)")
+    # ---- imported trajectories (reference Agent.py:543-659, 255-266) -----------------------------
+    def import_trajectory(self, times=None, positions=None, dataset=None, interpolate=True):
+        """Replace the random-motion model by playback of `positions (N,2)` sampled at `times (N,)`
+        (shared by all agents; `(N, n_agents, 2)` gives each agent its own), cubic-spline
+        interpolated on the host (`scipy.interpolate.interp1d`, like the reference) and looped.
+        `dataset`: path to an .npz with keys "t" and "pos" (the reference's data format).
+        Each update()/simulate() step then moves dt along the trajectory on the device
+        (`forced_pos` mode of riab_agent_step): measured velocity, head direction, distance and
+        history are computed exactly as for simulated motion."""
+        from scipy.interpolate import interp1d
+        assert self.Environment.boundary_conditions == "solid", "Only solid boundary conditions are supported"
+        if dataset is not None:
+            data = np.load(dataset if str(dataset).endswith(".npz") else str(dataset) + ".npz")
+            times, positions = data["t"], data["pos"]
+        assert times is not None and positions is not None, "provide 'times' and 'positions' (or 'dataset')"
+        times, positions = np.array(times, dtype=float), np.array(positions, dtype=float)
+        assert len(positions) == len(times), "time and position arrays must have same length"
+        times = times - min(times)
+        positions = positions.reshape(len(times), -1, 2)
+        assert positions.shape[1] in (1, self._B), "positions must be (N,2) or (N,n_agents,2)"
+        self.interpolate = interpolate
+        self.use_imported_trajectory = True
+        self.t_interp = times
+        if interpolate:
+            self.pos_interp = interp1d(times, positions, axis=0, kind="cubic", fill_value="extrapolate")
+            p0 = self.pos_interp(0)
+        else:
+            self.positions, self.times = positions, times
+            self.t = -self.dt
+            self.prev_t = -(times[1] - times[0])
+            self.imported_trajectory_id = 0
+            p0 = positions[0]
+        self.pos = np.broadcast_to(p0, (self._B, 2))
+
+    def _advance_imported(self, T, dt, kwargs, hist_view=None, stream=None):
+        """T steps along the imported trajectory (Agent._update_position_along_imported_trajectory)."""
+        dt = dt or self.dt
+        if self.interpolate:
+            ts = self.t + dt * np.arange(1, T + 1)
+            pos = self.pos_interp(ts % max(self.t_interp))            # (T, 1|B, 2)
+            pos = np.broadcast_to(pos, (T, self._B, 2))
+            full = np.empty((T, 2, self._Bp))
+            full[:, :, :self._B] = np.transpose(pos, (0, 2, 1))
+            full[:, :, self._B:] = full[:, :, :1]
+            self._advance(T, dt, None, 1, kwargs, hist_view=hist_view, stream=stream,
+                          forced=torch.from_numpy(full).to(self._device))
+        else:
+            assert T == 1 and stream is None, "interpolate=False trajectories advance one sample per update()"
+            i = self.imported_trajectory_id
+            t_new = float(self.times[i])
+            step_dt = t_new - self.t  # the reference resets dt to the sample spacing (Agent.py:262-263)
+            pos = np.broadcast_to(self.positions[i], (self._B, 2))
+            self.imported_trajectory_id = (i + 1) % len(self.times)
+            t_before = self.t
+            self._advance(1, step_dt, None, 1, kwargs, forced=self._as_device_f64(pos, 2).unsqueeze(0))
+            self.prev_t, self.t = t_before, t_new
+            if self.save_history:
+                self._times[-1] = self.t

@@ -51,7 +51,7 @@ class RiabRateIO(C.Structure):
 # name -> (restype, argtypes): every symbol include/riab_hip.h declares
 PROTOTYPES = {
     "riab_agent_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
-                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "riab_place_cells": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_float, C.c_void_p]),

@@ -72,6 +72,7 @@ struct AgentArgs {
   const double* drift;  // [2][B] or null
   const double* z_in;   // [T][2][B] or null
   double* z_out;        // [T][2][B] or null
+  const double* forced; // [T][2][B] or null: imported / forced positions (Agent.py:229-238)
   uint32_t k0, k1;
   uint64_t step0;
   int T;
@@ -243,6 +244,12 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       a.z_out[((int64_t)t * 2 + 1) * B + b] = (double)z_spd;
     }
     const R ppx = px, ppy = py;  // prev_pos (Agent.py:199)
+    if (a.forced) {
+      // imported / forced trajectory (Agent.py:229-238): the position is given, the motion
+      // model, wall handling and boundary conditions are skipped
+      px = (R)a.forced[((int64_t)t * 2 + 0) * B + b];
+      py = (R)a.forced[((int64_t)t * 2 + 1) * B + b];
+    } else {
 
     // ---- _stochastic_velocity_update (Agent.py:287-312) -----------------------------------
     rot += (R)m.rot_theta_kw * ((R)m.rot_drift_kw - rot) * dt + (R)m.rot_sigma_kw * (dt * z_rot);
@@ -414,6 +421,7 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
         py = (hi_y < py) ? hi_y : py;
       }
     }
+    }  // random-motion branch
     // ---- _measure_velocity_of_step_taken (Agent.py:456-471) -------------------------------
     R dpx = px - ppx, dpy = py - ppy;
     if (a.periodic) {
@@ -451,6 +459,11 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
 #else
       mrot = (R)atan2f((float)crs, (float)dotp) * inv_dt;
 #endif
+    }
+    if (a.forced) {  // overwrite_velocity=True (Agent.py:461-462, 469-470)
+      vx = mvx;
+      vy = mvy;
+      rot = mrot;
     }
     // ---- _update_head_direction (Agent.py:488-500) ----------------------------------------
     {
@@ -507,7 +520,7 @@ using namespace riab;
 
 extern "C" int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
                                int64_t agent_id0, const double* drift, const double* z_in, double* z_out,
-                               uint64_t seed, uint64_t step0, int32_t T, float* hist, int32_t* diag,
+                               const double* forced_pos, uint64_t seed, uint64_t step0, int32_t T, float* hist, int32_t* diag,
                                int32_t precision, riab_stream_t stream) {
   if (!env || !motion || !state || B <= 0 || T <= 0 || agent_id0 < 0) return RIAB_EINVAL;
   if (env->n_walls < 0 || (env->n_walls > 0 && !env->walls)) return RIAB_EINVAL;
@@ -530,6 +543,7 @@ extern "C" int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, dou
   a.drift = drift;
   a.z_in = z_in;
   a.z_out = z_out;
+  a.forced = forced_pos;
   a.k0 = (uint32_t)seed;
   a.k1 = (uint32_t)(seed >> 32);
   a.step0 = step0;

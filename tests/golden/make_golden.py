@@ -363,8 +363,53 @@ def make_update_and_init():
     np.savez_compressed(os.path.join(HERE, "update_init.npz"), **out)
 
 
+def make_imported():
+    """Imported (cubic-spline playback) and forced trajectories: Agent.py:229-266, 543-659."""
+    print("imported / forced trajectories")
+    out = {}
+    times = np.arange(0, 12.01, 0.4)
+    positions = np.stack((0.5 + 0.35 * np.sin(0.9 * times), 0.5 + 0.3 * np.cos(1.3 * times + 0.4)), axis=-1)
+    out["imp_times"], out["imp_positions"] = times, positions
+
+    def run(ag, n, **kw):
+        for _ in range(n):
+            ag.update(**kw)
+        h = ag.get_history_arrays()
+        return {k: np.array(h[k], float) for k in ("t", "pos", "vel", "rot_vel", "head_direction", "distance_travelled")}
+
+    np.random.seed(31)
+    Env = Environment()
+    Ag = Agent(Env, {"dt": 0.05})
+    Ag.import_trajectory(times=times, positions=positions)
+    out["imp_state0"] = np.concatenate([np.ravel(x) for x in _get_state(Ag)])
+    for k, v in run(Ag, 300).items():          # 15 s > 12 s of data: exercises the loop-around
+        out[f"imp_{k}"] = v
+    out["imp_final_velocity"] = np.array(Ag.velocity, float)
+    out["imp_final_rotvel"] = float(Ag.rotational_velocity)
+    # (interpolate=False raises AttributeError in the reference v1.15.3 — Agent.py:657 calls
+    #  self.pos_interp unconditionally — so there is nothing to record for that mode)
+    # forced_next_position
+    Ag3 = Agent(Env, {"dt": 0.02})
+    out["forced_state0"] = np.concatenate([np.ravel(x) for x in _get_state(Ag3)])
+    rs = np.random.RandomState(4)
+    p = np.array(Ag3.pos, float)
+    forced = []
+    for _ in range(60):
+        p = np.clip(p + 0.004 * rs.randn(2), 0.05, 0.95)
+        forced.append(p.copy())
+        Ag3.update(forced_next_position=p.copy())
+    out["forced_pos"] = np.array(forced)
+    h = Ag3.get_history_arrays()
+    for k in ("t", "pos", "vel", "rot_vel", "head_direction", "distance_travelled"):
+        out[f"forced_{k}"] = np.array(h[k], float)
+    out["forced_final_velocity"] = np.array(Ag3.velocity, float)
+    np.savez_compressed(os.path.join(HERE, "imported.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported"]
+    if "imported" in which:
+        make_imported()
     if "motion" in which:
         make_motion()
     if "rates" in which:

@@ -435,3 +435,46 @@ def test_reference_style_scripts(riab):
     Ag.reset_history()
     PCs.reset_history()
     assert len(Ag.history["t"]) == 0 and PCs.history["firingrate"].shape[0] == 0
+
+
+def test_forced_next_position_vs_reference(riab):
+    """Agent.update(forced_next_position=...) (Agent.py:229-238, 244-253)."""
+    g = gu.load("imported.npz")
+    Ag = riab.Agent(make_env(riab), {"dt": 0.02})
+    for k, s in gu.PRE_SLICES.items():
+        setattr(Ag, k, g["forced_state0"][None, s] if isinstance(s, slice) else g["forced_state0"][s])
+    for t in range(len(g["forced_pos"])):
+        Ag.update(forced_next_position=g["forced_pos"][t])
+        np.testing.assert_allclose(Ag.measured_velocity, g["forced_vel"][t], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(Ag.velocity, g["forced_final_velocity"], rtol=1e-9)
+    np.testing.assert_allclose(Ag.history["head_direction"], g["forced_head_direction"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(Ag.history["rot_vel"], g["forced_rot_vel"], rtol=5e-6, atol=5e-6)
+    np.testing.assert_allclose(Ag.distance_travelled, g["forced_distance_travelled"][-1], rtol=1e-9)
+    np.testing.assert_allclose(Ag.history["t"], g["forced_t"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_imported_trajectory_vs_reference(riab, fused):
+    """Agent.import_trajectory playback (Agent.py:543-659, 255-266), looping past the end of the data."""
+    g = gu.load("imported.npz")
+    Ag = riab.Agent(make_env(riab), {"dt": 0.05})
+    PCs = riab.PlaceCells(Ag, {"n": 16})
+    Ag.import_trajectory(times=g["imp_times"], positions=g["imp_positions"])
+    for k, s in gu.PRE_SLICES.items():  # the reference agent's (random) initial velocity / head direction
+        setattr(Ag, k, g["imp_state0"][None, s] if isinstance(s, slice) else g["imp_state0"][s])
+    if fused:
+        Ag.simulate(300, chunk=64)
+    else:
+        for _ in range(300):
+            Ag.update()
+            PCs.update()
+    h = Ag.history
+    np.testing.assert_allclose(h["pos"], g["imp_pos"], rtol=2e-6, atol=2e-7)  # fp32 history rows
+    np.testing.assert_allclose(h["vel"], g["imp_vel"], rtol=5e-6, atol=1e-6)
+    np.testing.assert_allclose(h["head_direction"], g["imp_head_direction"], rtol=5e-6, atol=1e-6)
+    np.testing.assert_allclose(h["rot_vel"], g["imp_rot_vel"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(h["distance_travelled"], g["imp_distance_travelled"], rtol=1e-6)
+    np.testing.assert_allclose(h["t"], g["imp_t"], rtol=1e-12)
+    np.testing.assert_allclose(Ag.velocity, g["imp_final_velocity"], rtol=1e-8)
+    np.testing.assert_allclose(Ag.rotational_velocity, g["imp_final_rotvel"], rtol=2e-6)
+    assert PCs.history["firingrate"].shape == (300, 16)

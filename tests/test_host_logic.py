@@ -98,8 +98,6 @@ def test_agent_attribute_shapes_and_setters():
     assert np.array_equal(many.rotational_velocity, np.arange(6.0))
     one.pos = [0.3, 0.4]
     assert one.pos.tolist() == [0.3, 0.4]
-    with pytest.raises(NotImplementedError):
-        one.update(forced_next_position=np.zeros(2))
 
 
 def test_motion_parameter_resolution():

@@ -153,3 +153,29 @@ def test_field_of_view_bvcs(tag):
     got = orc.bvc(g["pos"][:32], g["maze_walls"], g[f"fov_{tag}_tuning_distances"], g[f"fov_{tag}_tuning_angles"],
                   g[f"fov_{tag}_sigma_distances"], g[f"fov_{tag}_sigma_angles"], head_direction=g["hd"][:32])
     np.testing.assert_allclose(got, g[f"fov_{tag}_rates"], rtol=1e-10, atol=1e-14)
+
+
+def _replay_forced(g, prefix, positions, dt, state0):
+    st = state0
+    env = orc.EnvSpec()
+    for t in range(len(positions)):
+        st = orc.agent_step(env, st, dt, None, None, forced_pos=positions[t][None])
+        np.testing.assert_allclose(st["measured_velocity"][0], g[f"{prefix}_vel"][t], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(st["head_direction"][0], g[f"{prefix}_head_direction"][t], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(st["measured_rotational_velocity"][0], g[f"{prefix}_rot_vel"][t], rtol=1e-8, atol=1e-7)
+        np.testing.assert_allclose(st["distance_travelled"][0], g[f"{prefix}_distance_travelled"][t], rtol=1e-10)
+    return st
+
+
+def test_forced_and_imported_trajectories():
+    """forced_next_position and import_trajectory playback (Agent.py:229-266, 543-659)."""
+    from scipy.interpolate import interp1d
+    g = gu.load("imported.npz")
+    st0 = gu.state_from_rows(g["forced_state0"])
+    st = _replay_forced(g, "forced", g["forced_pos"], 0.02, st0)
+    np.testing.assert_allclose(st["velocity"][0], g["forced_final_velocity"], rtol=1e-9)  # overwritten by measured
+    # imported: the reference interpolates with a cubic spline at t % max(t) and starts at pos_interp(0)
+    f = interp1d(g["imp_times"], g["imp_positions"], axis=0, kind="cubic", fill_value="extrapolate")
+    ts = 0.05 * np.arange(1, 301)
+    pos = f(ts % g["imp_times"].max())
+    np.testing.assert_allclose(pos, g["imp_pos"], rtol=1e-9, atol=1e-12)
