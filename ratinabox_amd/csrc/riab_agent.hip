@@ -24,14 +24,20 @@ namespace riab {
 #define RIAB_G_STRIDE (RIAB_G_DEG + 4)
 #define RIAB_H_STRIDE (RIAB_H_DEG + 4)
 
-// One Horner recurrence on per-lane coefficients: p(x), x = (arg - mid) * inv_halfwidth.
+// p(x) on per-lane coefficients, x = (arg - mid) * inv_halfwidth, split into its even and odd
+// parts p = E(x^2) + x O(x^2): two independent Horner recurrences of half the length (the wave
+// is alone on its SIMD, so the dependent-chain depth is what costs).
 template <int DEG>
 __device__ __forceinline__ double seg_poly(const double* row, double arg) {
   const double x = (arg - row[0]) * row[1];
-  double p = row[2 + DEG];
+  const double x2 = x * x;
+  constexpr int KE = DEG & ~1, KO = (DEG - 1) | 1;  // highest even / odd power
+  double pe = row[2 + KE], po = row[2 + KO];
 #pragma unroll
-  for (int k = DEG - 1; k >= 0; --k) p = fma(p, x, row[2 + k]);
-  return p;
+  for (int k = KE - 2; k >= 0; k -= 2) pe = fma(pe, x2, row[2 + k]);
+#pragma unroll
+  for (int k = KO - 2; k >= 1; k -= 2) po = fma(po, x2, row[2 + k]);
+  return fma(po, x, pe);
 }
 
 // The speed update of Agent._stochastic_velocity_update (reference Agent.py:302-309 with
@@ -149,7 +155,11 @@ struct Wall {  // staged in LDS
   R inv_len;         // 1 / |s|
 };
 
-template <class R>
+// IN: 0 = in-kernel Philox noise, 1 = explicit normals z_in, 2 = forced positions.  The Philox
+// variant has NO global load inside the step loop, so no s_waitcnt vmcnt(0) ever makes a step
+// wait for the previous step's history stores to land (measured: 37 % of the wave's cycles were
+// spent in such waits when all modes shared one kernel).
+template <class R, int IN>
 __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   __shared__ Wall<R> s_w[RIAB_MAX_WALLS];
   __shared__ double s_g[sizeof(R) == 8 ? RIAB_G_SEGS * RIAB_G_STRIDE : 1];
@@ -223,9 +233,12 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     // ---- the step's standard normals -------------------------------------------------------
     R z_rot, z_spd;
     uint32_t zw2 = 0x80000000u, zw3 = 0;
-    if (a.z_in) {
+    if (IN == 1) {
       z_rot = (R)a.z_in[((int64_t)t * 2 + 0) * B + b];
       z_spd = (R)a.z_in[((int64_t)t * 2 + 1) * B + b];
+    } else if (IN == 2) {
+      z_rot = (R)0;
+      z_spd = (R)0;
     } else {
       const uint64_t step = a.step0 + (uint64_t)t;
       const u32x4 w = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), aid, RIAB_TAG_MOTION, a.k0, a.k1);
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       a.z_out[((int64_t)t * 2 + 1) * B + b] = (double)z_spd;
     }
     const R ppx = px, ppy = py;  // prev_pos (Agent.py:199)
-    if (a.forced) {
+    if (IN == 2) {
       // imported / forced trajectory (Agent.py:229-238): the position is given, the motion
       // model, wall handling and boundary conditions are skipped
       px = (R)a.forced[((int64_t)t * 2 + 0) * B + b];
@@ -460,7 +473,7 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       mrot = (R)atan2f((float)crs, (float)dotp) * inv_dt;
 #endif
     }
-    if (a.forced) {  // overwrite_velocity=True (Agent.py:461-462, 469-470)
+    if (IN == 2) {  // overwrite_velocity=True (Agent.py:461-462, 469-470)
       vx = mvx;
       vy = mvy;
       rot = mrot;
@@ -551,7 +564,16 @@ extern "C" int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, dou
   a.hist = hist;
   a.diag = diag;
   const dim3 grid((unsigned)((B + 63) / 64));
-  if (precision == 64) hipLaunchKernelGGL(agent_step_kernel<double>, grid, dim3(64), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(agent_step_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, a);
+  hipStream_t s = (hipStream_t)stream;
+  const int in = forced_pos ? 2 : (z_in ? 1 : 0);
+  if (precision == 64) {
+    if (in == 0) hipLaunchKernelGGL((agent_step_kernel<double, 0>), grid, dim3(64), 0, s, a);
+    else if (in == 1) hipLaunchKernelGGL((agent_step_kernel<double, 1>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((agent_step_kernel<double, 2>), grid, dim3(64), 0, s, a);
+  } else {
+    if (in == 0) hipLaunchKernelGGL((agent_step_kernel<float, 0>), grid, dim3(64), 0, s, a);
+    else if (in == 1) hipLaunchKernelGGL((agent_step_kernel<float, 1>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((agent_step_kernel<float, 2>), grid, dim3(64), 0, s, a);
+  }
   return (int)hipGetLastError();
 }
