@@ -50,6 +50,45 @@ struct RayleighLds {
   const double* g;
   const double* h;
 };
+// lookup (issue the per-lane LDS reads of one segment's row) and evaluation are split so that
+// independent work can be placed between them: the wave is alone on its SIMD, nothing else hides
+// the LDS latency.
+template <int DEG>
+struct SegRow {
+  double c[DEG + 3];
+};
+template <int DEG>
+__device__ __forceinline__ SegRow<DEG> seg_fetch(const double* row) {
+  SegRow<DEG> r;
+#pragma unroll
+  for (int i = 0; i < DEG + 3; ++i) r.c[i] = row[i];
+  return r;
+}
+template <int DEG>
+__device__ __forceinline__ double seg_eval(const SegRow<DEG>& r, double arg) {
+  const double x = (arg - r.c[0]) * r.c[1];
+  const double x2 = x * x;
+  constexpr int KE = DEG & ~1, KO = (DEG - 1) | 1;  // highest even / odd power
+  double pe = r.c[2 + KE], po = r.c[2 + KO];
+#pragma unroll
+  for (int k = KE - 2; k >= 0; k -= 2) pe = fma(pe, x2, r.c[2 + k]);
+#pragma unroll
+  for (int k = KO - 2; k >= 1; k -= 2) po = fma(po, x2, r.c[2 + k]);
+  return fma(po, x, pe);
+}
+__device__ __forceinline__ double clamp_G_arg(double t) {
+  t = (t < RIAB_G_TLO) ? RIAB_G_TLO : t;
+  return (t > RIAB_G_THI) ? RIAB_G_THI : t;
+}
+__device__ __forceinline__ const double* row_G(const RayleighLds& L, double t_clamped) {
+  const int seg = (int)(((unsigned long long)__double_as_longlong(t_clamped) >> 49) - RIAB_G_KEY0);
+  return L.g + seg * RIAB_G_STRIDE;
+}
+__device__ __forceinline__ const double* row_H(const RayleighLds& L, double n) {
+  int seg = (int)((n + RIAB_H_NMAX) * RIAB_H_INV_SEG);
+  seg = seg < 0 ? 0 : (seg > RIAB_H_SEGS - 1 ? RIAB_H_SEGS - 1 : seg);
+  return L.h + seg * RIAB_H_STRIDE;
+}
 __device__ __forceinline__ double rayleigh_G(const RayleighLds& L, double t) {
   t = (t < RIAB_G_TLO) ? RIAB_G_TLO : t;
   t = (t > RIAB_G_THI) ? RIAB_G_THI : t;
@@ -229,6 +268,10 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   const bool hd_instant = m.hd_tau <= m.dt;
   const R hd_gain = (R)(m.dt / m.hd_tau), hd_keep = (R)(1.0 - m.dt / m.hd_tau);
 
+  Wall<R> w4[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) w4[w] = s_w[w < nw ? w : 0];
+
   for (int t = 0; t < a.T; ++t) {
     // ---- the step's standard normals -------------------------------------------------------
     R z_rot, z_spd;
@@ -265,6 +308,20 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     } else {
 
     // ---- _stochastic_velocity_update (Agent.py:287-312) -----------------------------------
+    // float64 path, ordered for latency: the rotation does not change |v|, so the speed and the
+    // LDS fetch of its G-segment come first; the H-segment fetch is followed by wall pass 1
+    // (which only needs the position) before the H polynomial is evaluated.
+    R v2 = vx * vx + vy * vy;
+    const bool zero_v = (v2 == (R)0);
+    if (zero_v) v2 = (R)1e-16;  // the reference replaces a zero velocity by (1e-8, 0) (Agent.py:299-300)
+    const R ispeed = r_rsqrt(v2);
+    const R speed = v2 * ispeed;
+    SegRow<RIAB_G_DEG> grow;
+    double tG = 0.0;
+    if (sizeof(R) == 8) {
+      tG = clamp_G_arg((double)speed * inv_sm);
+      grow = seg_fetch<RIAB_G_DEG>(row_G(rl, tG));
+    }
     rot += (R)m.rot_theta_kw * ((R)m.rot_drift_kw - rot) * dt + (R)m.rot_sigma_kw * (dt * z_rot);
     {
       R sn, cs;
@@ -275,59 +332,42 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
 #endif
       const R nx = cs * vx + (-sn) * vy;
       const R ny = sn * vx + cs * vy;
-      vx = nx;
-      vy = ny;
+      vx = zero_v ? (R)1e-8 : nx;
+      vy = zero_v ? (R)0 : ny;
     }
-    // |v| and 1/|v| from one reciprocal square root
-    R v2 = vx * vx + vy * vy;
-    if (v2 == (R)0) {
-      vx = (R)1e-8;
-      vy = (R)0;
-      v2 = (R)1e-16;
+    // utils.rayleigh_to_normal / normal_to_rayleigh (utils.py:409-421), sigma = speed_mean
+    R speed_new = sm_kw;
+    SegRow<RIAB_H_DEG> hrow;
+    double nv64 = 0.0;
+    bool h_in_table = true;
+    if (sizeof(R) == 8) {
+      nv64 = seg_eval<RIAB_G_DEG>(grow, tG);
+      nv64 += m.speed_theta_kw * (0.0 - nv64) * m.dt + m.speed_sigma_kw * (m.dt * (double)z_spd);
+      h_in_table = fabs(nv64) < RIAB_H_NMAX;
+      hrow = seg_fetch<RIAB_H_DEG>(row_H(rl, nv64));
+    } else {
+      R u = (R)1 - r_exp(-v2 * inv_2s2);
+      u = (u < (R)1e-6) ? (R)1e-6 : u;
+      u = (u > (R)(1 - 1e-6)) ? (R)(1 - 1e-6) : u;
+      R nv = r_ndtri(u);
+      nv += (R)m.speed_theta_kw * ((R)0 - nv) * dt + (R)m.speed_sigma_kw * (dt * z_spd);
+      const R x = r_ndtr(nv);
+      speed_new = sm_kw * r_sqrt((R)-2 * r_log((R)1 - x));
     }
-    const R ispeed = r_rsqrt(v2);
-    const R speed = v2 * ispeed;
-    {
-      // utils.rayleigh_to_normal / normal_to_rayleigh (utils.py:409-421), sigma = speed_mean
-      R speed_new;
-      if (sizeof(R) == 8) {
-        double nv = rayleigh_G(rl, (double)speed * inv_sm);
-        nv += m.speed_theta_kw * (0.0 - nv) * m.dt + m.speed_sigma_kw * (m.dt * (double)z_spd);
-        speed_new = (R)(m.speed_mean_kw * rayleigh_H(rl, nv));
-      } else {
-        R u = (R)1 - r_exp(-v2 * inv_2s2);
-        u = (u < (R)1e-6) ? (R)1e-6 : u;
-        u = (u > (R)(1 - 1e-6)) ? (R)(1 - 1e-6) : u;
-        R nv = r_ndtri(u);
-        nv += (R)m.speed_theta_kw * ((R)0 - nv) * dt + (R)m.speed_sigma_kw * (dt * z_spd);
-        const R x = r_ndtr(nv);
-        speed_new = sm_kw * r_sqrt((R)-2 * r_log((R)1 - x));
-      }
-      if (m.speed_std_is_zero) speed_new = sm_kw;
-      const R f = speed_new * ispeed;
-      vx *= f;
-      vy *= f;
-    }
-    // ---- _drift_velocity_update (Agent.py:331-341) ----------------------------------------
-    if (m.has_drift) {
-      vx += (R)m.drift_theta * (drx - vx) * dt;
-      vy += (R)m.drift_theta * (dry - vy) * dt;
-    }
-    // ---- _wall_velocity_update (Agent.py:357-415, utils.py:121-184) -----------------------
+    // ---- _wall_velocity_update, pass 1 (Agent.py:357-415, utils.py:121-184) ---------------
     // squared distances first: the sqrt / normalisation only for walls inside the repel
     // distance, and ONE sqrt for distance_to_closest_wall (sqrt is monotone: same value)
     R x2min = INFINITY;
+    constexpr int RIAB_NEAR = 3;
+    int near_idx[RIAB_NEAR] = {0, 0, 0};
+    int n_near = 0;
+    const R wd2 = wd * wd * (R)1.000001;
     if (nw > 0) {
       // pass 1 (cheap, every wall): squared distance to the nearest point of the wall; remember
       // the first RIAB_NEAR walls inside the repel distance.  pass 2 (expensive: sqrt, 1/x, the
       // spring / conveyor terms) runs only over those, in wall order, so the sums are the
       // reference's sums (the skipped terms are exact zeros).
-      constexpr int RIAB_NEAR = 3;
-      int near_idx[RIAB_NEAR] = {0, 0, 0};
-      int n_near = 0;
-      const R wd2 = wd * wd * (R)1.000001;
-      for (int w = 0; w < nw; ++w) {
-        const Wall<R> W = s_w[w];
+      auto pass1 = [&](const Wall<R>& W, int w) {
         const R dxw = px - W.ax, dyw = py - W.ay;
         R l = (dxw * W.sx + dyw * W.sy) * W.inv_ss;
         l = (l > (R)1) ? (R)1 : l;
@@ -341,7 +381,32 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
           if (n_near == 2) near_idx[2] = w;
           ++n_near;
         }
-      }
+      };
+      // the first four walls (the box itself when boundaries are solid) live in registers for the
+      // whole launch: no LDS round trip per step for the common open-box case
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (w < nw) pass1(w4[w], w);
+      for (int w = 4; w < nw; ++w) pass1(s_w[w], w);
+    }
+    // ---- finish the speed update ---------------------------------------------------------------
+    if (sizeof(R) == 8) {
+      const double tnew = h_in_table ? seg_eval<RIAB_H_DEG>(hrow, nv64) : sqrt(-2.0 * log(1.0 - normcdf(nv64)));
+      speed_new = (R)(m.speed_mean_kw * tnew);
+    }
+    if (m.speed_std_is_zero) speed_new = sm_kw;
+    {
+      const R f = speed_new * ispeed;
+      vx *= f;
+      vy *= f;
+    }
+    // ---- _drift_velocity_update (Agent.py:331-341) ----------------------------------------
+    if (m.has_drift) {
+      vx += (R)m.drift_theta * (drx - vx) * dt;
+      vy += (R)m.drift_theta * (dry - vy) * dt;
+    }
+    // ---- _wall_velocity_update, pass 2 -----------------------------------------------------
+    if (nw > 0) {
       if (repel) {
         R ax_ = 0, ay_ = 0, sx_ = 0, sy_ = 0;
         const int cnt = (n_near <= RIAB_NEAR) ? n_near : nw;  // more than RIAB_NEAR near walls: walk them all
