@@ -356,31 +356,11 @@ class Agent:
         return traj
 
     def _make_streams(self):
-        """Two HIP streams: trajectory kernel / firing-rate kernels.  With `cu_split = k > 0`
-        (param or env RIAB_CU_SPLIT) the streams are created with complementary CU masks
-        (hipExtStreamCreateWithCUMask): every k-th CU runs only the latency-bound trajectory
-        kernel, the rest only the bandwidth-bound rate kernels, so the two never share a SIMD."""
-        import ctypes
-        import os
-        k = int(os.environ.get("RIAB_CU_SPLIT", getattr(self, "cu_split", 0)) or 0)
-        if k <= 1:
-            return (torch.cuda.Stream(device=self._device), torch.cuda.Stream(device=self._device))
-        n_cu = torch.cuda.get_device_properties(self._device).multi_processor_count
-        words = (n_cu + 31) // 32
-        m_traj = [0] * words
-        m_rate = [0] * words
-        for i in range(n_cu):
-            (m_traj if i % k == 0 else m_rate)[i // 32] |= (1 << (i % 32))
-        hip = ctypes.CDLL("libamdhip64.so")  # already resident (torch's runtime)
-        out = []
-        for mask in (m_traj, m_rate):
-            arr = (ctypes.c_uint32 * words)(*mask)
-            h = ctypes.c_void_p()
-            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), arr)
-            if rc != 0:
-                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
-            out.append(torch.cuda.ExternalStream(h.value, device=self._device))
-        return tuple(out)
+        """Two HIP streams: trajectory kernel / firing-rate kernels.  (CU-masked streams,
+        hipExtStreamCreateWithCUMask, were tried to keep the two kernels off each other's SIMDs:
+        the mask is accepted but has no effect on this ROCm 7.2 stack — a 16-CU mask still fills
+        at 4.2 TB/s — so plain streams are used.)"""
+        return (torch.cuda.Stream(device=self._device), torch.cuda.Stream(device=self._device))
 
     def preallocate_history(self, n_steps):
         """Allocate the HBM for `n_steps` more history rows of the agent and of every Neurons
