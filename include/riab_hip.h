@@ -231,6 +231,28 @@ int riab_neuron_noise(float* noise, float* rates, const float* z_in, int32_t n, 
                       float theta_dt, float sigma_dt, uint64_t seed, uint64_t step, int32_t pop_id,
                       int64_t agent_id0, riab_stream_t stream);
 
+/* One input layer of a FeedForwardLayer: its firing rates and its weights. */
+typedef struct RiabFFInput {
+  const float* rates;  /* device float32 [T][n_in][B]: the input layer's rates for the same rows */
+  const float* wt;     /* device float32 [n_in][Mp]: the weight matrix TRANSPOSED (w[m][k] -> wt[k][m]),
+                          rows padded with zeros to Mp = n_out rounded up to a multiple of 32 */
+  int32_t n_in;
+} RiabFFInput;
+
+enum { RIAB_ACT_LINEAR = 0, RIAB_ACT_SIGMOID = 1, RIAB_ACT_RELU = 2, RIAB_ACT_TANH = 3,
+       RIAB_ACT_RETANH = 4, RIAB_ACT_SOFTMAX = 5 };
+
+/* FeedForwardLayer.get_state (Neurons.py:2797-2847) with utils.activate (utils.py:919-1026):
+ * out[t][m][b] = act(sum_l sum_k w_l[m][k] * rates_l[t][k][b] + bias[m]) on the fp32 matrix
+ * cores (v_mfma_f32_32x32x2_f32, exact fp32 accumulation).  Up to 8 input layers.
+ * act_params[4]: sigmoid (max_fr, min_fr, mid_x, beta = ln(19)/(width_x/2)); relu / tanh /
+ * retanh / softmax (gain, threshold, -, -); linear ignores them.
+ * out_prime (or NULL) receives the derivative of the activation at the same pre-activation
+ * (FeedForwardLayer.firingrate_prime, Neurons.py:2839-2845). */
+int riab_feedforward(const RiabFFInput* inputs, int32_t n_inputs, const float* bias, int32_t n_out,
+                     int64_t T, int64_t B, int32_t activation, const float* act_params, float* out,
+                     float* out_prime, riab_stream_t stream);
+
 /* Streaming-store calibration kernel: writes `bytes` bytes (multiple of 16) of
  * a constant with the same 16-B/lane store pattern as the rate kernels.  Used
  * to calibrate the WRITE_SIZE counter and to measure the store roofline. */

@@ -575,6 +575,42 @@ def head_direction_cells(head_direction, n, angular_spread_degrees=45.0, min_fr=
     return fr * (max_fr - min_fr) + min_fr
 
 
+def activate(x, spec):
+    """utils.activate (utils.py:919-1026) for the named activations -> (f(x), df/dx)."""
+    name = spec.get("activation", "sigmoid")
+    x = np.asarray(x, dtype=np.float64)
+    if name == "linear":
+        return x, np.ones(x.shape)
+    if name == "sigmoid":
+        d = {"max_fr": 1, "min_fr": 0, "mid_x": 1, "width_x": 2}
+        d.update(spec)
+        beta = np.log((1 - 0.05) / 0.05) / (0.5 * d["width_x"])
+        f = ((d["max_fr"] - d["min_fr"]) / (1 + np.exp(-beta * (x - d["mid_x"])))) + d["min_fr"]
+        return f, beta * (f - d["min_fr"]) * (1 - (f - d["min_fr"]) / (d["max_fr"] - d["min_fr"]))
+    d = {"gain": 1, "threshold": 0}
+    d.update(spec)
+    g, th = d["gain"], d["threshold"]
+    if name == "relu":
+        return g * np.maximum(0, x - th), g * ((x - th) > 0)
+    if name == "tanh":  # the reference's derivative ignores the threshold (utils.py:998)
+        return g * np.tanh(x - th), g * (1 - np.tanh(x) ** 2)
+    if name == "retanh":
+        return g * np.maximum(0, np.tanh(x - th)), g * (1 - np.tanh(x) ** 2) * ((x - th) > 0)
+    if name == "softmax":
+        return g * np.log(1 + np.exp(x - th)), g / (1 + np.exp(-(x - th)))
+    raise ValueError(name)
+
+
+def feedforward(inputs, weights, biases, spec):
+    """FeedForwardLayer.get_state (Neurons.py:2797-2847): inputs list of `(n_in, P)` rates,
+    weights list of `(n, n_in)` -> (rates `(n, P)`, activation derivative `(n, P)`)."""
+    V = np.zeros((weights[0].shape[0], np.asarray(inputs[0]).shape[1]))
+    for w, I in zip(weights, inputs):
+        V = V + np.matmul(np.asarray(w, dtype=np.float64), np.asarray(I, dtype=np.float64))
+    V = V + np.asarray(biases, dtype=np.float64).reshape(-1, 1)
+    return activate(V, spec)
+
+
 # --------------------------------------------------------------------------- #
 # Neurons.update noise + spikes (Neurons.py:145-171, 681-687)
 # --------------------------------------------------------------------------- #

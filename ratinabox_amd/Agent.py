@@ -317,6 +317,7 @@ class Agent:
         else:
             traj = torch.empty((n_steps, _L.HIST_ROWS, self._Bp), dtype=torch.float32, device=self._device)
         outs = [N._reserve_rows(n_steps, ring=min(chunk, n_steps)) for N in neurons]
+        self._sim_outs = dict(zip(neurons, outs))  # FeedForwardLayers read their inputs' rows of the same chunk
         ready = torch.cuda.Event()
         ready.record(cur)
         s_traj.wait_event(ready)

@@ -256,15 +256,7 @@ class Neurons:
         """Rates (+ spikes) for trajectory rows `traj [tc, 8, Bp]`, written to rows
         t0..t0+tc of the reserved output."""
         Bp = self._Bp
-        if out["ring"] is None:
-            fr = out["fr"][t0:t0 + tc]
-            sp = None if out["sp"] is None else out["sp"][t0:t0 + tc]
-        else:
-            r0 = t0 % out["ring"]
-            if r0 + tc > out["ring"]:
-                r0 = 0
-            fr, sp = out["fr"][r0:r0 + tc], None
-            out["last"] = fr[tc - 1]
+        fr, sp = self._chunk_view(out, t0, tc)
         ld = _L.HIST_ROWS * Bp
         hook = getattr(self.Agent, "_profile_hook", None)
         if hook is not None:
@@ -287,6 +279,17 @@ class Neurons:
             if sp is not None:
                 io = self._io(None, None, None, None, Bp, tc, Bp, fr, sp, None, dt, step0 + 1)
                 _L.check(_L.lib.riab_spikes(io, int(self.n), stream), "riab_spikes")
+
+    def _chunk_view(self, out, t0, tc):
+        """(rates, spikes) rows of the chunk [t0, t0+tc) inside a reserved output."""
+        if out["ring"] is None:
+            return out["fr"][t0:t0 + tc], (None if out["sp"] is None else out["sp"][t0:t0 + tc])
+        r0 = t0 % out["ring"]
+        if r0 + tc > out["ring"]:
+            r0 = 0
+        fr = out["fr"][r0:r0 + tc]
+        out["last"] = fr[tc - 1]
+        return fr, None
 
     def _finish_rows(self, out, n_steps, times):
         if out["ring"] is None:
@@ -652,3 +655,173 @@ class HeadDirectionCells(Neurons):
         tab = self._tables((pref, sig), build)
         rc = _L.lib.riab_head_direction_cells(io, _L.ptr(tab), n, stream)
         _L.check(rc, "riab_head_direction_cells")
+
+
+# ================================================================================================
+class FeedForwardLayer(Neurons):
+    """A layer whose firing rates are an activated linear combination of the rates of its input
+    layers (reference Neurons.py:2654-2860): `firingrate = act(sum_l W_l @ I_l + biases)`.
+
+    `inputs[name]` keeps the reference's dictionary (`"layer"`, `"w"` (n, n_in) NumPy — edit it
+    freely, e.g. in a learning rule; the device copy is refreshed when it changes —, `"w_init"`,
+    `"I"`, `"n"`, `"recurrent"`).  The contraction runs on the fp32 matrix cores
+    (`riab_feedforward`, csrc/riab_ff.hip) directly on the input layers' device-resident rates;
+    `firingrate_prime` holds the activation derivative like the reference.  Activation functions:
+    the reference's named ones (linear, sigmoid, relu, tanh, retanh, softmax); a Python callable
+    cannot run inside the kernel and raises NotImplementedError."""
+
+    default_params = {
+        "n": 10,
+        "input_layers": [],
+        "activation_function": {"activation": "linear"},
+        "name": "FeedForwardLayer",
+        "biases": None,
+    }
+
+    def __init__(self, Agent, params={}):
+        self.Agent = Agent
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        if "activation_params" in self.params:
+            warnings.warn("The parameter 'activation_params' is deprecated. Use 'activation_function' instead.")
+            self.params["activation_function"] = self.params["activation_params"]
+        super().__init__(Agent, self.params)
+        assert isinstance(self.input_layers, list), "param['input_layers'] must be a list."
+        if len(self.input_layers) == 0:
+            warnings.warn("No input layers have been provided. Either hand them in in the params dictionary "
+                          "params['input_layers']=[list,of,inputs] or use self.add_input_layer() to add them manually.")
+        if not isinstance(self.activation_function, dict):
+            raise NotImplementedError("a Python callable activation cannot run inside the HIP kernel; use one of "
+                                      "the named activations {'activation': 'linear'|'sigmoid'|'relu'|'tanh'|"
+                                      "'retanh'|'softmax', ...}")
+        self.inputs = {}
+        for layer in self.input_layers:
+            self.add_input(layer)
+        if self.biases is None:
+            self.biases = np.zeros(self.n)
+        self._rates_prime = torch.zeros((int(self.n), self._Bp), dtype=torch.float32, device=self._device)
+
+    def add_input(self, input_layer, w=None, w_init_scale=1, recurrent=False, **kwargs):
+        """Add an input layer with weights `w` (n, n_in); None draws N(0, w_init_scale/sqrt(n_in))."""
+        n_in, name = input_layer.n, input_layer.name
+        if w is None:
+            w = np.random.normal(loc=0, scale=w_init_scale / np.sqrt(n_in), size=(self.n, n_in))
+        self.inputs[name] = {"layer": input_layer, "w": w, "w_init": w.copy(), "I": np.zeros(n_in), "n": n_in,
+                             "recurrent": recurrent}
+        self.inputs[name].update(kwargs)
+
+    add_input_layer = add_input
+
+    @property
+    def firingrate_prime(self):
+        a = self._rates_prime[:, :self._B].cpu().numpy().astype(np.float64)
+        return a[:, 0] if self._B == 1 else a
+
+    # ---- activation parameters -> the kernel's 4 floats (utils.activate, utils.py:919-1026) -----
+    def _activation(self):
+        spec = dict(self.activation_function)
+        name = spec.get("activation", "sigmoid")
+        if "function" in spec:
+            raise NotImplementedError("bespoke Python activation functions cannot run inside the HIP kernel")
+        assert name in _L.ACTIVATIONS, f"unknown activation {name}"
+        if name == "sigmoid":
+            d = {"max_fr": 1, "min_fr": 0, "mid_x": 1, "width_x": 2}
+            d.update(spec)
+            beta = np.log((1 - 0.05) / 0.05) / (0.5 * d["width_x"])
+            p = (d["max_fr"], d["min_fr"], d["mid_x"], beta)
+        elif name == "linear":
+            p = (0, 0, 0, 0)
+        else:
+            d = {"gain": 1, "threshold": 0}
+            d.update(spec)
+            p = (d["gain"], d["threshold"], 0, 0)
+        return _L.ACTIVATIONS[name], (_L.C.c_float * 4)(*[float(x) for x in p])
+
+    def _device_weights(self, entry):
+        """W^T padded to a multiple of 32 outputs, float32 on device; refreshed when `w` changes."""
+        w = np.ascontiguousarray(np.asarray(entry["w"], dtype=np.float64))
+        key = w.tobytes()
+        hit = entry.get("_dev")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        n, n_in = w.shape
+        Mp = (n + 31) // 32 * 32
+        wt = np.zeros((n_in, Mp), dtype=np.float32)
+        wt[:, :n] = w.T
+        t = torch.from_numpy(wt).to(self._device)
+        entry["_dev"] = (key, t)
+        return t
+
+    def _gemm(self, input_tensors, T, B, out, out_prime, stream):
+        """out[T][n][B] = act(sum_l W_l @ input_tensors[l] + biases); input tensors [T][n_in][B]."""
+        entries = list(self.inputs.values())
+        arr = (_L.RiabFFInput * len(entries))()
+        keep = []
+        for i, (e, x) in enumerate(zip(entries, input_tensors)):
+            wt = self._device_weights(e)
+            arr[i].rates, arr[i].wt, arr[i].n_in = x.data_ptr(), wt.data_ptr(), int(e["n"])
+            keep.append((wt, x))
+        bias = np.asarray(self.biases, dtype=np.float32).reshape(-1)
+        bias_t = self._tables((bias,), lambda: torch.from_numpy(bias.copy()).to(self._device))
+        act, pars = self._activation()
+        rc = _L.lib.riab_feedforward(arr, len(entries), _L.ptr(bias_t), int(self.n), int(T), int(B), act, pars,
+                                     _L.ptr(out), _L.ptr(out_prime), stream)
+        _L.check(rc, "riab_feedforward")
+        self._keep = (keep, bias_t, out, out_prime)
+
+    # ---- Neurons plumbing ------------------------------------------------------------------------
+    def _launch(self, px, py, hx, hy, pos_ld, T, B, rates, spikes, u_in, dt, step0, from_f64=False, stream=None):
+        """update() path: inputs are the input layers' LAST firing rates (evaluate_at='last')."""
+        stream = _L.current_stream() if stream is None else stream
+        xs = []
+        for e in self.inputs.values():
+            x = e["layer"]._rates
+            xs.append(x.reshape(1, *x.shape))
+        self._gemm(xs, 1, self._Bp, rates, self._rates_prime, stream)
+        if spikes is not None:
+            io = self._io(None, None, None, None, self._Bp, 1, self._Bp, rates, spikes, u_in, dt, step0)
+            _L.check(_L.lib.riab_spikes(io, int(self.n), stream), "riab_spikes")
+
+    def get_state_tensor(self, evaluate_at="last", max_recurrence=None, **kwargs):
+        if evaluate_at in ("last", "agent"):
+            out = torch.empty((1, int(self.n), self._Bp), dtype=torch.float32, device=self._device)
+            xs = [e["layer"]._rates.reshape(1, *e["layer"]._rates.shape) for e in self.inputs.values()]
+            self._last_P = self._B
+            self._gemm(xs, 1, self._Bp, out, self._rates_prime, _L.current_stream())
+            return out[0]
+        xs, P = [], None
+        for e in self.inputs.values():
+            kw = dict(kwargs)
+            if isinstance(e["layer"], FeedForwardLayer):
+                nxt = max_recurrence
+                if max_recurrence is not None and e["recurrent"]:
+                    if max_recurrence <= 0:
+                        continue
+                    nxt = max_recurrence - 1
+                kw["max_recurrence"] = nxt
+            x = e["layer"].get_state_tensor(evaluate_at, **kw)
+            P = e["layer"]._last_P
+            xs.append(x.reshape(1, *x.shape))
+        Pp = xs[0].shape[-1]
+        self._last_P = P
+        out = torch.empty((1, int(self.n), Pp), dtype=torch.float32, device=self._device)
+        self._gemm(xs, 1, Pp, out, None, _L.current_stream())
+        return out[0]
+
+    def get_state(self, evaluate_at="last", max_recurrence=None, **kwargs):
+        t = self.get_state_tensor(evaluate_at, max_recurrence=max_recurrence, **kwargs)
+        return t[:, :self._last_P].cpu().numpy().astype(np.float64)
+
+    def _rates_from_trajectory(self, traj, out, t0, tc, step0, dt, stream):
+        """Fused path: the input layers' rows of the same chunk feed the GEMM in place."""
+        outs = self.Agent._sim_outs
+        xs = []
+        for e in self.inputs.values():
+            if e["recurrent"] or e["layer"] is self:
+                raise NotImplementedError("recurrent inputs need one step per launch: use update(), not simulate()")
+            xs.append(e["layer"]._chunk_view(outs[e["layer"]], t0, tc)[0])
+        fr, sp = self._chunk_view(out, t0, tc)
+        self._gemm(xs, tc, self._Bp, fr, None, stream)
+        if sp is not None:
+            io = self._io(None, None, None, None, self._Bp, tc, self._Bp, fr, sp, None, dt, step0 + 1)
+            _L.check(_L.lib.riab_spikes(io, int(self.n), stream), "riab_spikes")

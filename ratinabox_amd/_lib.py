@@ -48,6 +48,12 @@ class RiabRateIO(C.Structure):
                 ("pop_id", C.c_int32)]
 
 
+class RiabFFInput(C.Structure):
+    _fields_ = [("rates", C.c_void_p), ("wt", C.c_void_p), ("n_in", C.c_int32)]
+
+
+ACTIVATIONS = {"linear": 0, "sigmoid": 1, "relu": 2, "tanh": 3, "retanh": 4, "softmax": 5}
+
 # name -> (restype, argtypes): every symbol include/riab_hip.h declares
 PROTOTYPES = {
     "riab_agent_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
@@ -63,6 +69,8 @@ PROTOTYPES = {
     "riab_spikes": (C.c_int, [C.POINTER(RiabRateIO), C.c_int32, C.c_void_p]),
     "riab_neuron_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float,
                                     C.c_uint64, C.c_uint64, C.c_int32, C.c_int64, C.c_void_p]),
+    "riab_feedforward": (C.c_int, [C.POINTER(RiabFFInput), C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
+                                   C.c_int32, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_fill": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "riab_abi_version": (C.c_int, []),
     "riab_strerror": (C.c_char_p, [C.c_int]),

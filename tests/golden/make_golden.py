@@ -406,8 +406,60 @@ def make_imported():
     np.savez_compressed(os.path.join(HERE, "imported.npz"), **out)
 
 
+def make_feedforward():
+    """FeedForwardLayer (Neurons.py:2654-2860) over PlaceCells + GridCells, every named activation."""
+    from ratinabox.Neurons import FeedForwardLayer
+    print("feedforward")
+    out = {}
+    np.random.seed(41)
+    Env = Environment()
+    Ag = Agent(Env, {"dt": 0.05})
+    PCs = PlaceCells(Ag, {"n": 70, "name": "PCs"})
+    PCs.place_cell_centres = f32exact(PCs.place_cell_centres)
+    GCs = GridCells(Ag, {"n": 45, "name": "GCs"})
+    out["pc_centres"] = PCs.place_cell_centres
+    out["gc_gridscales"], out["gc_phase"], out["gc_orient"] = GCs.gridscales, GCs.phase_offsets, GCs.orientations
+    pos = test_positions(96, seed=9)
+    out["pos"] = pos
+    w_pc = np.random.RandomState(1).randn(37, 70) / np.sqrt(70)
+    w_gc = np.random.RandomState(2).randn(37, 45) / np.sqrt(45)
+    bias = np.random.RandomState(3).randn(37) * 0.1
+    out["w_pc"], out["w_gc"], out["bias"] = w_pc, w_gc, bias
+    acts = {"linear": {"activation": "linear"},
+            "sigmoid": {"activation": "sigmoid", "max_fr": 5, "min_fr": 0.5, "mid_x": 0.2, "width_x": 1.5},
+            "relu": {"activation": "relu", "gain": 2.0, "threshold": 0.1},
+            "tanh": {"activation": "tanh", "gain": 1.5, "threshold": -0.2},
+            "retanh": {"activation": "retanh", "gain": 1.2, "threshold": 0.05},
+            "softmax": {"activation": "softmax", "gain": 0.7, "threshold": 0.3}}
+    Ag.pos = f32exact(np.array([0.37, 0.61]))
+    PCs.update()
+    GCs.update()
+    out["agent_pos"] = np.array(Ag.pos)
+    for name, spec in acts.items():
+        F = FeedForwardLayer(Ag, {"n": 37, "input_layers": [PCs, GCs], "activation_function": dict(spec),
+                                  "biases": bias.copy(), "name": "FF_" + name})
+        F.inputs["PCs"]["w"] = w_pc.copy()
+        F.inputs["GCs"]["w"] = w_gc.copy()
+        out[f"ff_{name}_rates"] = F.get_state(evaluate_at=None, pos=pos)
+        F.update()
+        out[f"ff_{name}_last"] = np.array(F.firingrate)
+        out[f"ff_{name}_prime"] = np.array(F.firingrate_prime)
+    # two-layer stack: FF2(FF1(PCs, GCs))
+    F1 = FeedForwardLayer(Ag, {"n": 37, "input_layers": [PCs, GCs], "activation_function": acts["relu"],
+                               "biases": bias.copy(), "name": "F1"})
+    F1.inputs["PCs"]["w"], F1.inputs["GCs"]["w"] = w_pc.copy(), w_gc.copy()
+    w2 = np.random.RandomState(4).randn(5, 37) / np.sqrt(37)
+    F2 = FeedForwardLayer(Ag, {"n": 5, "input_layers": [F1], "activation_function": acts["tanh"], "name": "F2"})
+    F2.inputs["F1"]["w"] = w2.copy()
+    out["w2"] = w2
+    out["ff_stack_rates"] = F2.get_state(evaluate_at=None, pos=pos)
+    np.savez_compressed(os.path.join(HERE, "feedforward.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward"]
+    if "feedforward" in which:
+        make_feedforward()
     if "imported" in which:
         make_imported()
     if "motion" in which:

@@ -38,3 +38,10 @@ def state_from_rows(rows):
     st["measured_rotational_velocity"] = np.zeros(B)
     st["distance_to_closest_wall"] = np.full(B, np.inf)
     return st
+
+FF_ACTS = {"linear": {"activation": "linear"},
+           "sigmoid": {"activation": "sigmoid", "max_fr": 5, "min_fr": 0.5, "mid_x": 0.2, "width_x": 1.5},
+           "relu": {"activation": "relu", "gain": 2.0, "threshold": 0.1},
+           "tanh": {"activation": "tanh", "gain": 1.5, "threshold": -0.2},
+           "retanh": {"activation": "retanh", "gain": 1.2, "threshold": 0.05},
+           "softmax": {"activation": "softmax", "gain": 0.7, "threshold": 0.3}}

@@ -478,3 +478,73 @@ def test_imported_trajectory_vs_reference(riab, fused):
     np.testing.assert_allclose(Ag.velocity, g["imp_final_velocity"], rtol=1e-8)
     np.testing.assert_allclose(Ag.rotational_velocity, g["imp_final_rotvel"], rtol=2e-6)
     assert PCs.history["firingrate"].shape == (300, 16)
+
+
+def _ff_world(riab, g, n_agents=1):
+    Ag = riab.Agent(make_env(riab), {"dt": 0.05, "n_agents": n_agents})
+    PCs = riab.PlaceCells(Ag, {"place_cell_centres": g["pc_centres"], "name": "PCs", "wall_geometry": "euclidean"})
+    GCs = riab.GridCells(Ag, {"gridscale": list(g["gc_gridscales"]), "orientation": list(g["gc_orient"]),
+                              "phase_offset": g["gc_phase"], "name": "GCs"})
+    return Ag, PCs, GCs
+
+
+def _ff_tol(g, act):
+    """fp32 accumulation: |err| <= 1e-5 * (sum |w||I| + |b|) * max|act'| (I in [0,1])."""
+    spec = gu.FF_ACTS[act]
+    cond = np.abs(g["w_pc"]).sum(1) + np.abs(g["w_gc"]).sum(1) + np.abs(g["bias"])
+    lip = {"linear": 1, "sigmoid": (5 - 0.5) * np.log(19) / 0.75 / 4, "relu": 2.0, "tanh": 1.5, "retanh": 1.2,
+           "softmax": 0.7}[act]
+    return 1e-5 * cond[:, None] * lip
+
+
+@pytest.mark.parametrize("act", sorted(gu.FF_ACTS))
+def test_feedforward_layer_vs_reference(riab, act):
+    """FeedForwardLayer on the fp32 matrix cores vs the reference."""
+    g = gu.load("feedforward.npz")
+    Ag, PCs, GCs = _ff_world(riab, g)
+    F = riab.FeedForwardLayer(Ag, {"n": 37, "input_layers": [PCs, GCs], "activation_function": gu.FF_ACTS[act],
+                                   "biases": g["bias"].copy(), "name": "FF"})
+    F.inputs["PCs"]["w"] = g["w_pc"].copy()
+    F.inputs["GCs"]["w"] = g["w_gc"].copy()
+    got = F.get_state(evaluate_at=None, pos=g["pos"])
+    ref = g[f"ff_{act}_rates"]
+    assert got.shape == ref.shape
+    assert (np.abs(got - ref) <= _ff_tol(g, act) + 1e-5 * np.abs(ref)).all(), np.abs(got - ref).max()
+    Ag.pos = g["agent_pos"]
+    PCs.update(); GCs.update(); F.update()
+    assert (np.abs(F.firingrate - g[f"ff_{act}_last"]) <= _ff_tol(g, act)[:, 0] + 1e-5 * np.abs(g[f"ff_{act}_last"])).all()
+    np.testing.assert_allclose(F.firingrate_prime, g[f"ff_{act}_prime"], rtol=2e-4, atol=2e-5)
+    assert F.history["firingrate"].shape == (1, 37)
+
+
+def test_feedforward_stack_batched_and_fused(riab):
+    """Two stacked layers; weights edited between steps; per-step == fused; 300 agents (ragged tile)."""
+    g = gu.load("feedforward.npz")
+    Ag, PCs, GCs = _ff_world(riab, g)
+    F1 = riab.FeedForwardLayer(Ag, {"n": 37, "input_layers": [PCs, GCs], "activation_function": gu.FF_ACTS["relu"],
+                                    "biases": g["bias"].copy(), "name": "F1"})
+    F1.inputs["PCs"]["w"], F1.inputs["GCs"]["w"] = g["w_pc"].copy(), g["w_gc"].copy()
+    F2 = riab.FeedForwardLayer(Ag, {"n": 5, "input_layers": [F1], "activation_function": gu.FF_ACTS["tanh"], "name": "F2"})
+    F2.inputs["F1"]["w"] = g["w2"].copy()
+    got = F2.get_state(evaluate_at=None, pos=g["pos"])
+    np.testing.assert_allclose(got, g["ff_stack_rates"], rtol=2e-5, atol=2e-5)
+    F2.inputs["F1"]["w"][0, :] = 0.0  # in-place edit is picked up
+    np.testing.assert_allclose(F2.get_state(evaluate_at=None, pos=g["pos"])[0], 1.5 * np.tanh(0.2), rtol=1e-6)
+
+    def world():
+        np.random.seed(3)
+        Ag, PCs, GCs = _ff_world(riab, g, n_agents=300)
+        F = riab.FeedForwardLayer(Ag, {"n": 150, "input_layers": [PCs, GCs], "name": "F",
+                                       "activation_function": gu.FF_ACTS["sigmoid"]})
+        return Ag, PCs, GCs, F
+    Ag, PCs, GCs, F = world()
+    for _ in range(9):
+        Ag.update(); PCs.update(); GCs.update(); F.update()
+    Ag2, P2, G2, F_2 = world()
+    Ag2.simulate(9, chunk=4)
+    torch.cuda.synchronize()
+    assert np.array_equal(F_2.history["firingrate"], F.history["firingrate"])
+    assert np.array_equal(F_2.history["spikes"], F.history["spikes"])
+    w = [F.inputs["PCs"]["w"], F.inputs["GCs"]["w"]]
+    ref, _ = orc.feedforward([PCs.firingrate, GCs.firingrate], w, F.biases, gu.FF_ACTS["sigmoid"])
+    np.testing.assert_allclose(F.firingrate, ref, rtol=2e-5, atol=2e-5)

@@ -179,3 +179,25 @@ def test_forced_and_imported_trajectories():
     ts = 0.05 * np.arange(1, 301)
     pos = f(ts % g["imp_times"].max())
     np.testing.assert_allclose(pos, g["imp_pos"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("act", sorted(gu.FF_ACTS))
+def test_feedforward_layer(act):
+    """FeedForwardLayer over PlaceCells + GridCells (Neurons.py:2797-2847, utils.py:919-1026)."""
+    g = gu.load("feedforward.npz")
+    env = orc.EnvSpec()
+    pc = orc.place_cells(env, g["pos"], g["pc_centres"], 0.2)
+    gc = orc.grid_cells(g["pos"], g["gc_gridscales"], g["gc_phase"], orc.grid_cell_w(g["gc_orient"]))
+    f, _ = orc.feedforward([pc, gc], [g["w_pc"], g["w_gc"]], g["bias"], gu.FF_ACTS[act])
+    np.testing.assert_allclose(f, g[f"ff_{act}_rates"], rtol=1e-11, atol=1e-13)
+    p1 = g["agent_pos"][None]
+    pc1 = orc.place_cells(env, p1, g["pc_centres"], 0.2)
+    gc1 = orc.grid_cells(p1, g["gc_gridscales"], g["gc_phase"], orc.grid_cell_w(g["gc_orient"]))
+    f, d = orc.feedforward([pc1, gc1], [g["w_pc"], g["w_gc"]], g["bias"], gu.FF_ACTS[act])
+    np.testing.assert_allclose(f[:, 0], g[f"ff_{act}_last"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(d[:, 0], g[f"ff_{act}_prime"], rtol=1e-11, atol=1e-13)
+    if act == "relu":
+        f2, _ = orc.feedforward([orc.feedforward([pc, gc], [g["w_pc"], g["w_gc"]], g["bias"], gu.FF_ACTS["relu"])[0]],
+                                [g["w2"]], np.zeros(5), gu.FF_ACTS["tanh"])
+        pcs = orc.place_cells(env, g["pos"], g["pc_centres"], 0.2)
+        np.testing.assert_allclose(f2, g["ff_stack_rates"], rtol=1e-11, atol=1e-13)
