@@ -97,6 +97,25 @@ def rates():
               f"{byt / ms / 1e6:.0f} GB/s written", flush=True)
 
 
+def ff():
+    """FeedForwardLayer GEMM on the fp32 matrix cores: PlaceCells(1024) -> n_out, 128 x 4096 positions."""
+    B, T = 4096, 128
+    np.random.seed(0)
+    ag = riab.Agent(riab.Environment(), {"n_agents": B, "dt": 0.01})
+    pcs = riab.PlaceCells(ag, {"n": 1024, "wall_geometry": "euclidean", "save_spikes": False})
+    ag.simulate(T)
+    torch.cuda.synchronize()
+    x = pcs.get_history_tensors()[0]  # [T, 1024, B]
+    for n_out in (32, 128, 512):
+        F = riab.FeedForwardLayer(ag, {"n": n_out, "input_layers": [pcs], "name": f"F{n_out}",
+                                       "activation_function": {"activation": "relu"}})
+        out = torch.empty((T, n_out, B), dtype=torch.float32, device="cuda")
+        ms = timeit(lambda: F._gemm([x], T, B, out, None, L.current_stream()))
+        fl = 2.0 * 1024 * n_out * T * B
+        print(f"feedforward 1024 -> {n_out}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  "
+              f"(reads {x.numel() * 4 / ms / 1e6:.0f} GB/s of rates)", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["agent", "fill", "rates"]
     for w in which:
