@@ -24,22 +24,6 @@ namespace riab {
 #define RIAB_G_STRIDE (RIAB_G_DEG + 4)
 #define RIAB_H_STRIDE (RIAB_H_DEG + 4)
 
-// p(x) on per-lane coefficients, x = (arg - mid) * inv_halfwidth, split into its even and odd
-// parts p = E(x^2) + x O(x^2): two independent Horner recurrences of half the length (the wave
-// is alone on its SIMD, so the dependent-chain depth is what costs).
-template <int DEG>
-__device__ __forceinline__ double seg_poly(const double* row, double arg) {
-  const double x = (arg - row[0]) * row[1];
-  const double x2 = x * x;
-  constexpr int KE = DEG & ~1, KO = (DEG - 1) | 1;  // highest even / odd power
-  double pe = row[2 + KE], po = row[2 + KO];
-#pragma unroll
-  for (int k = KE - 2; k >= 0; k -= 2) pe = fma(pe, x2, row[2 + k]);
-#pragma unroll
-  for (int k = KO - 2; k >= 1; k -= 2) po = fma(po, x2, row[2 + k]);
-  return fma(po, x, pe);
-}
-
 // The speed update of Agent._stochastic_velocity_update (reference Agent.py:302-309 with
 // utils.rayleigh_to_normal / normal_to_rayleigh, utils.py:409-421), float64, table-driven:
 //   G(t) = Phi^-1(clip(1 - exp(-t^2/2), 1e-6, 1-1e-6)),  H(n) = sqrt(-2 ln(1 - Phi(n))),  t = speed/sigma
@@ -64,6 +48,8 @@ __device__ __forceinline__ SegRow<DEG> seg_fetch(const double* row) {
   for (int i = 0; i < DEG + 3; ++i) r.c[i] = row[i];
   return r;
 }
+// p(x), x = (arg - mid) * inv_halfwidth, split into even and odd parts p = E(x^2) + x O(x^2): two
+// independent Horner recurrences of half the length (dependent-chain depth is what costs here).
 template <int DEG>
 __device__ __forceinline__ double seg_eval(const SegRow<DEG>& r, double arg) {
   const double x = (arg - r.c[0]) * r.c[1];
@@ -88,20 +74,6 @@ __device__ __forceinline__ const double* row_H(const RayleighLds& L, double n) {
   int seg = (int)((n + RIAB_H_NMAX) * RIAB_H_INV_SEG);
   seg = seg < 0 ? 0 : (seg > RIAB_H_SEGS - 1 ? RIAB_H_SEGS - 1 : seg);
   return L.h + seg * RIAB_H_STRIDE;
-}
-__device__ __forceinline__ double rayleigh_G(const RayleighLds& L, double t) {
-  t = (t < RIAB_G_TLO) ? RIAB_G_TLO : t;
-  t = (t > RIAB_G_THI) ? RIAB_G_THI : t;
-  const int seg = (int)(((unsigned long long)__double_as_longlong(t) >> 49) - RIAB_G_KEY0);
-  return seg_poly<RIAB_G_DEG>(L.g + seg * RIAB_G_STRIDE, t);
-}
-__device__ __forceinline__ double rayleigh_H(const RayleighLds& L, double n) {
-  if (fabs(n) < RIAB_H_NMAX) {
-    int seg = (int)((n + RIAB_H_NMAX) * RIAB_H_INV_SEG);
-    seg = seg > RIAB_H_SEGS - 1 ? RIAB_H_SEGS - 1 : seg;
-    return seg_poly<RIAB_H_DEG>(L.h + seg * RIAB_H_STRIDE, n);
-  }
-  return sqrt(-2.0 * log(1.0 - normcdf(n)));
 }
 
 struct AgentArgs {
@@ -134,10 +106,6 @@ __device__ __forceinline__ double r_exp(double x) { return exp(x); }
 __device__ __forceinline__ float r_exp(float x) { return expf(x); }
 __device__ __forceinline__ double r_log(double x) { return log(x); }
 __device__ __forceinline__ float r_log(float x) { return logf(x); }
-__device__ __forceinline__ double r_atan2(double y, double x) { return atan2(y, x); }
-__device__ __forceinline__ float r_atan2(float y, float x) { return atan2f(y, x); }
-__device__ __forceinline__ void r_sincos(double x, double* s, double* c) { sincos(x, s, c); }
-__device__ __forceinline__ void r_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
 __device__ __forceinline__ double r_ndtri(double u) { return normcdfinv(u); }
 __device__ __forceinline__ float r_ndtri(float u) { return normcdfinvf(u); }
 __device__ __forceinline__ double r_ndtr(double x) { return normcdf(x); }
@@ -170,22 +138,6 @@ __device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
   }
 }
 __device__ __forceinline__ void sincos_small(float x, float* s, float* c) { sincosf(x, s, c); }
-
-// np.mod(a, 2pi) for a in (-2pi, 2pi)
-template <class R>
-__device__ __forceinline__ R mod_2pi(R a) {
-  const R two_pi = (R)6.283185307179586476925286766559;
-  R r = a;
-  if (r >= two_pi) r -= two_pi;
-  if (r < (R)0) r += two_pi;
-  return r;
-}
-
-// utils.get_angle (reference utils.py:258-260): atan2(y, x + 1e-6) mod 2pi
-template <class R>
-__device__ __forceinline__ R get_angle(R x, R y) {
-  return mod_2pi(r_atan2(y, x + (R)1e-6));
-}
 
 template <class R>
 struct Wall {  // staged in LDS
