@@ -216,6 +216,19 @@ int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* io, const d
                                const float* inv_norm, int32_t n, int32_t egocentric,
                                float* ray_out, riab_stream_t stream);
 
+/* ObjectVectorCells.get_state (Neurons.py:1991-2116; FieldOfViewOVCs Neurons.py:2119-2150 is
+ * the same on a radial manifold) with Environment.get_distances_between___accounting_for_
+ * environment(..., return_vectors=True) (Environment.py:677-730).
+ *  objects       device float32 [n_objects][2] (Environment.objects["objects"])
+ *  object_types  device int32 [n_objects]
+ *  cells         device float32 [n][6] = (a*mu_d, a, cos(mu_theta), sin(mu_theta), kappa*log2(e),
+ *                tuning type), a = sqrt(log2(e)/2)/sigma_d
+ *  walls_occlude line_of_sight geometry: an object behind an internal wall (env->walls[4:]) is
+ *                at distance 1000 (Neurons.py:1938-1941); egocentric needs io->hd_x / hd_y */
+int riab_object_vector_cells(const RiabEnv* env, const RiabRateIO* io, const float* objects,
+                             const int32_t* object_types, int32_t n_objects, const float* cells, int32_t n,
+                             int32_t walls_occlude, int32_t egocentric, riab_stream_t stream);
+
 /* Neurons.save_to_history spike rule (Neurons.py:681-687) on rates that already
  * exist: spikes = u < dt*rate (one fp32 multiply, one fp32 compare).  count
  * elements, u_in explicit uniforms or NULL => Philox as in the rate kernels

@@ -575,6 +575,28 @@ def head_direction_cells(head_direction, n, angular_spread_degrees=45.0, min_fr=
     return fr * (max_fr - min_fr) + min_fr
 
 
+def object_vector_cells(env, pos, objects, object_types, tuning_distances, tuning_angles, sigma_distances,
+                        sigma_angles, tuning_types, walls_occlude=True, head_direction=None, min_fr=0.0, max_fr=1.0):
+    """ObjectVectorCells.get_state (Neurons.py:1991-2116) -> `(n, P)`.  `head_direction (P,2)`
+    switches to the egocentric frame."""
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 2)
+    objects = np.asarray(objects, dtype=np.float64).reshape(-1, 2)
+    geom = "line_of_sight" if walls_occlude else "euclidean"
+    dist = env_distances(env, pos, objects, geom)           # (P, M)
+    vec = -1 * env_vectors_between(env, pos, objects)        # object - position, (P, M, 2)
+    bearing = get_angle(vec.reshape(-1, 2)).reshape(dist.shape)
+    if head_direction is not None:
+        bearing = bearing - get_angle(np.asarray(head_direction, dtype=np.float64).reshape(-1, 2))[:, None]
+    mu_d = np.asarray(tuning_distances, dtype=np.float64)[None, None, :]
+    sg_d = np.asarray(sigma_distances, dtype=np.float64)[None, None, :]
+    mu_a = np.asarray(tuning_angles, dtype=np.float64)[None, None, :]
+    sg_a = np.asarray(sigma_angles, dtype=np.float64)[None, None, :]
+    fr = gaussian(dist[:, :, None], mu_d, sg_d) * von_mises(bearing[:, :, None], mu_a, sg_a)  # (P, M, n)
+    mask = (np.asarray(object_types)[:, None] == np.asarray(tuning_types)[None, :]).astype(int)[None]
+    fr = (fr * mask).sum(axis=1).T
+    return fr * (max_fr - min_fr) + min_fr
+
+
 def activate(x, spec):
     """utils.activate (utils.py:919-1026) for the named activations -> (f(x), df/dx)."""
     name = spec.get("activation", "sigmoid")

@@ -11,7 +11,7 @@ here: they are inlined into the HIP kernels, which read the device copy of the
 wall table kept by `device_tables()`.
 
 In scope: rectangular 2D boxes, solid or periodic, with interior walls.
-Polygonal boundaries, holes, objects and 1D environments are outside the
+Polygonal boundaries, holes and 1D environments are outside the
 accelerated path and raise NotImplementedError."""
 import copy
 import warnings
@@ -31,7 +31,7 @@ class Environment:
         "boundary": None,  # polygon boundary: not supported on the accelerated path
         "walls": [],       # interior walls [[x0,y0],[x1,y1]]
         "holes": [],       # not supported on the accelerated path
-        "objects": [],     # not supported on the accelerated path
+        "objects": [],     # object positions [[x0,y0],...] (all type 0); or use add_object
     }
 
     def __init__(self, params={}):
@@ -48,8 +48,6 @@ class Environment:
             raise NotImplementedError("polygonal boundaries are outside the accelerated path (rectangular boxes only)")
         if len(self.holes) > 0:
             raise NotImplementedError("holes are outside the accelerated path")
-        if len(self.objects) > 0:
-            raise NotImplementedError("objects are outside the accelerated path")
         if self.boundary_conditions not in ("solid", "periodic"):
             raise ValueError("boundary_conditions must be 'solid' or 'periodic'")
         self.D = 2
@@ -66,6 +64,12 @@ class Environment:
         bottom, top = 0.0, float(self.scale)
         self.centre = np.array([(left + right) / 2, (top + bottom) / 2])
         self.extent = np.array([left, right, bottom, top])
+        # objects seen by ObjectVectorCells (Environment.py:166-176)
+        self.passed_in_objects = copy.deepcopy(self.objects)
+        self.objects = {"objects": np.empty((0, self.D)), "object_types": np.empty(0, int)}
+        self.n_object_types = 0
+        for o in self.passed_in_objects:
+            self.add_object(o, type=0)
         self.discrete_coords = self.discretise_environment(dx=self.dx)
         self.flattened_discrete_coords = self.discrete_coords.reshape(-1, self.discrete_coords.shape[-1])
         self._device_cache = {}
@@ -109,7 +113,20 @@ class Environment:
         raise NotImplementedError("holes are outside the accelerated path")
 
     def add_object(self, object, type="new"):
-        raise NotImplementedError("objects are outside the accelerated path")
+        """Add an object at `object` (x, y).  type: "new" (a new type id), "same" (the last
+        object's type) or an existing / the next integer type (Environment.py:366-395)."""
+        object = np.array(object, dtype=float).reshape(1, -1)
+        assert object.shape[1] == self.D
+        if type == "new":
+            type = self.n_object_types
+        elif type == "same":
+            type = 0 if len(self.objects["object_types"]) == 0 else self.objects["object_types"][-1]
+        else:
+            assert type <= self.n_object_types, (f"Newly added object must be one of the existing types or the next "
+                                                  f"one along ({self.n_object_types}), not {type}")
+        self.objects["objects"] = np.append(self.objects["objects"], object, axis=0)
+        self.objects["object_types"] = np.append(self.objects["object_types"], np.array([type], int), axis=0)
+        self.n_object_types = len(np.unique(self.objects["object_types"]))
 
     # -- sampling (Environment.py:560-633) ------------------------------------------------
     def sample_positions(self, n=10, method="uniform_jitter"):

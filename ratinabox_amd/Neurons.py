@@ -621,6 +621,103 @@ class FieldOfViewBVCs(BoundaryVectorCells):
         super().__init__(Agent, self.params)
 
 
+class ObjectVectorCells(VectorCells):
+    """Object vector cells (reference Neurons.py:1892-2116): gaussian in the distance and von
+    Mises in the bearing to the objects of the cell's preferred type, summed over those objects;
+    with `walls_occlude` an object behind a wall is not seen (line_of_sight geometry)."""
+
+    default_params = {
+        "n": 10,
+        "name": "ObjectVectorCell",
+        "walls_occlude": True,
+        "object_tuning_type": "random",  # "random", an int, or a list / array of n ints
+    }
+
+    def __init__(self, Agent, params={}):
+        self.Agent = Agent
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        if not hasattr(self, "_warn_if_n_changes"):
+            self._warn_if_n_changes = "n" in params and params["n"] is not None
+        super().__init__(Agent, self.params)
+        self.object_locations = self.Agent.Environment.objects["objects"]
+        if len(self.object_locations) == 0:
+            raise RuntimeError(f"Cannot initialize {self.params['name']}, as there are no objects in the environment.")
+        self.tuning_types = None
+        self.set_tuning_types(self.object_tuning_type)
+        self.wall_geometry = "line_of_sight" if self.walls_occlude else "euclidean"
+
+    def set_tuning_types(self, tuning_types=None):
+        """Preferred object type of every cell ("random": drawn from the types present)."""
+        if isinstance(tuning_types, str) and tuning_types == "random":
+            self.object_types = self.Agent.Environment.objects["object_types"]
+            self.tuning_types = np.random.choice(np.unique(self.object_types), replace=True, size=(self.n,))
+            return
+        if isinstance(tuning_types, (int, np.integer)):
+            tuning_types = np.repeat(tuning_types, self.n)
+        elif isinstance(tuning_types, list):
+            tuning_types = np.array(tuning_types)
+        assert isinstance(tuning_types, np.ndarray), "tuning_types must be an integer, list or numpy array"
+        assert tuning_types.shape[0] == self.n, f"Tuning types must be a vector of length ({self.n},)"
+        self.tuning_types = tuning_types
+
+    def _call(self, io, stream):
+        n = int(self.n)
+        Env = self.Agent.Environment
+        objs = np.asarray(Env.objects["objects"], dtype=np.float64).reshape(-1, 2)
+        otypes = np.asarray(Env.objects["object_types"], dtype=np.int64)
+        mu_d = np.asarray(self.tuning_distances, dtype=np.float64)
+        sg_d = np.asarray(self.sigma_distances, dtype=np.float64)
+        mu_t = np.asarray(self.tuning_angles, dtype=np.float64)
+        sg_t = np.asarray(self.sigma_angles, dtype=np.float64)
+        ttypes = np.asarray(self.tuning_types, dtype=np.int64)
+        occlude = self.wall_geometry == "line_of_sight"
+        if occlude:
+            assert Env.boundary_conditions == "solid", \
+                "line of sight geometry not available for periodic boundary conditions"
+
+        def build():
+            a = np.sqrt(LOG2E / 2) / sg_d
+            cells = np.stack((a * mu_d, a, np.cos(mu_t), np.sin(mu_t), LOG2E / sg_t ** 2, ttypes.astype(float)), axis=-1)
+            return (torch.from_numpy(np.ascontiguousarray(objs, dtype=np.float32)).to(self._device),
+                    torch.from_numpy(np.ascontiguousarray(otypes, dtype=np.int32)).to(self._device),
+                    torch.from_numpy(np.ascontiguousarray(cells, dtype=np.float32)).to(self._device))
+
+        objs_t, types_t, cells_t = self._tables((objs, otypes, mu_d, sg_d, mu_t, sg_t, ttypes), build)
+        env, _w = Env.device_tables(self._device)
+        rc = _L.lib.riab_object_vector_cells(env, io, _L.ptr(objs_t), _L.ptr(types_t), int(len(objs)), _L.ptr(cells_t),
+                                             n, 1 if occlude else 0, 1 if self.reference_frame == "egocentric" else 0,
+                                             stream)
+        _L.check(rc, "riab_object_vector_cells")
+
+
+class FieldOfViewOVCs(ObjectVectorCells):
+    """Egocentric object vector cells tiling the agent's field of view (reference
+    Neurons.py:2119-2150)."""
+
+    default_params = {
+        "distance_range": [0.02, 0.4],
+        "angle_range": [0, 75],
+        "spatial_resolution": 0.02,
+        "beta": 5,
+        "cell_arrangement": "diverging_manifold",
+        "object_tuning_type": None,
+    }
+
+    def __init__(self, Agent, params={}):
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        if self.params["object_tuning_type"] is None:
+            warnings.warn("For FieldOfViewOVCs you must specify the object type they are selective for with the "
+                          "'object_tuning_type' parameter ('random' or an integer). For now defaulting to "
+                          "params['object_tuning_type'] = 0.")
+            self.params["object_tuning_type"] = 0
+        self.params["reference_frame"] = "egocentric"
+        assert self.params["cell_arrangement"] is not None, "cell_arrangement must be set for FOV Neurons"
+        self._warn_if_n_changes = "n" in params and params["n"] is not None
+        super().__init__(Agent, self.params)
+
+
 # ================================================================================================
 class HeadDirectionCells(Neurons):
     """Head direction cells: von Mises tuning to the agent's head direction

@@ -12,7 +12,8 @@ from . import utils  # noqa: E402,F401
 from .Environment import Environment  # noqa: E402,F401
 from .Agent import Agent  # noqa: E402,F401
 from .Neurons import (  # noqa: E402,F401
-    Neurons, PlaceCells, GridCells, VectorCells, BoundaryVectorCells, FieldOfViewBVCs, HeadDirectionCells, FeedForwardLayer)
+    Neurons, PlaceCells, GridCells, VectorCells, BoundaryVectorCells, FieldOfViewBVCs, ObjectVectorCells,
+    FieldOfViewOVCs, HeadDirectionCells, FeedForwardLayer)
 
 __all__ = ["Environment", "Agent", "Neurons", "PlaceCells", "GridCells", "VectorCells", "BoundaryVectorCells",
-           "FieldOfViewBVCs", "HeadDirectionCells", "FeedForwardLayer", "utils"]
+           "FieldOfViewBVCs", "ObjectVectorCells", "FieldOfViewOVCs", "HeadDirectionCells", "FeedForwardLayer", "utils"]

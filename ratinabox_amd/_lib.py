@@ -66,6 +66,8 @@ PROTOTYPES = {
     "riab_boundary_vector_cells": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                              C.c_void_p]),
+    "riab_object_vector_cells": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "riab_spikes": (C.c_int, [C.POINTER(RiabRateIO), C.c_int32, C.c_void_p]),
     "riab_neuron_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float,
                                     C.c_uint64, C.c_uint64, C.c_int32, C.c_int64, C.c_void_p]),

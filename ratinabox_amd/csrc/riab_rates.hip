@@ -149,24 +149,6 @@ __global__ __launch_bounds__(256) void rate_kernel_generic(const RateArgs a, Cel
 }
 
 // ---- PlaceCells (reference Neurons.py:936-981, Environment.py:677-779) -------------------
-// Strict segment/segment intersection test of utils.vector_intercepts
-// (utils.py:74-106: 0 < l_a < 1 and 0 < l_b < 1), evaluated with sign logic on the
-// float64 cross products instead of the two divisions (equal up to the last ulp of
-// the quotient; parallel segments give den == 0 -> no hit, like +-inf/NaN in NumPy).
-__device__ __forceinline__ bool seg_hit(double p0x, double p0y, double p1x, double p1y, double ax, double ay,
-                                        double bx, double by) {
-  const double sax = p1x - p0x, say = p1y - p0y;  // list a = line of sight
-  const double sbx = bx - ax, sby = by - ay;      // list b = wall
-  const double d0x = ax - p0x, d0y = ay - p0y;
-  const double den_a = sax * (-sby) + say * sbx;
-  const double num_a = d0x * (-sby) + d0y * sbx;
-  const double den_b = sbx * (-say) + sby * sax;
-  const double num_b = (-d0x) * (-say) + (-d0y) * sax;
-  const bool ia = (den_a > 0) ? (num_a > 0 && num_a < den_a) : (den_a < 0 ? (num_a < 0 && num_a > den_a) : false);
-  const bool ib = (den_b > 0) ? (num_b > 0 && num_b < den_b) : (den_b < 0 ? (num_b < 0 && num_b > den_b) : false);
-  return ia && ib;
-}
-
 // GX: 0 euclidean, 1 line_of_sight, 2 geodesic, 3 euclidean + periodic wrap.
 template <int DESC, int GX>
 struct PlaceCell {

@@ -456,8 +456,46 @@ def make_feedforward():
     np.savez_compressed(os.path.join(HERE, "feedforward.npz"), **out)
 
 
+def make_ovc():
+    """ObjectVectorCells / FieldOfViewOVCs (Neurons.py:1892-2150) with occluding walls."""
+    from ratinabox.Neurons import ObjectVectorCells, FieldOfViewOVCs
+    print("object vector cells")
+    out = {}
+    np.random.seed(51)
+    Env = Environment({"walls": [[[0.5, 0.0], [0.5, 0.55]], [[0.2, 0.8], [0.6, 0.8]]]})
+    rs = np.random.RandomState(6)
+    objs = f32exact(rs.uniform(0.05, 0.95, (9, 2)))
+    types = [0, 0, 1, 2, 1, 0, 2, 2, 1]
+    for o, ty in zip(objs, types):
+        Env.add_object(o, type=ty)
+    out["objects"], out["object_types"] = np.array(Env.objects["objects"]), np.array(Env.objects["object_types"])
+    out["walls"] = np.array(Env.walls, float)
+    Ag = Agent(Env)
+    pos = test_positions(64, seed=13)
+    hd = np.random.RandomState(14).randn(64, 2)
+    hd = f32exact(hd / np.linalg.norm(hd, axis=1, keepdims=True))
+    out["pos"], out["hd"] = pos, hd
+    for tag, cls, prm in (("allo", ObjectVectorCells, {"n": 30}),
+                          ("allo_nowalls", ObjectVectorCells, {"n": 12, "walls_occlude": False, "object_tuning_type": 1}),
+                          ("ego", ObjectVectorCells, {"n": 20, "reference_frame": "egocentric", "max_fr": 4.0, "min_fr": 0.2}),
+                          ("fov", FieldOfViewOVCs, {"object_tuning_type": "random", "angle_range": [0, 100]})):
+        O = cls(Ag, dict(prm))
+        for k in ["tuning_distances", "tuning_angles", "sigma_distances", "sigma_angles", "tuning_types"]:
+            out[f"ovc_{tag}_{k}"] = np.array(getattr(O, k), float)
+        if O.reference_frame == "egocentric":
+            fr = np.zeros((O.n, 64))
+            for j in range(64):
+                fr[:, j] = O.get_state(evaluate_at=None, pos=pos[j:j + 1], head_direction=hd[j])[:, 0]
+        else:
+            fr = O.get_state(evaluate_at=None, pos=pos)
+        out[f"ovc_{tag}_rates"] = fr
+    np.savez_compressed(os.path.join(HERE, "ovc.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc"]
+    if "ovc" in which:
+        make_ovc()
     if "feedforward" in which:
         make_feedforward()
     if "imported" in which:

@@ -548,3 +548,42 @@ def test_feedforward_stack_batched_and_fused(riab):
     w = [F.inputs["PCs"]["w"], F.inputs["GCs"]["w"]]
     ref, _ = orc.feedforward([PCs.firingrate, GCs.firingrate], w, F.biases, gu.FF_ACTS["sigmoid"])
     np.testing.assert_allclose(F.firingrate, ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["allo", "allo_nowalls", "ego", "fov"])
+def test_object_vector_cells_vs_reference(riab, tag):
+    """SURVEY §8f rank 1 (second half): ObjectVectorCells / FieldOfViewOVCs vs the reference."""
+    g = gu.load("ovc.npz")
+    env = make_env(riab, g["walls"][4:])
+    for o, ty in zip(g["objects"], g["object_types"]):
+        env.add_object(o, type=int(ty))
+    assert np.array_equal(env.objects["object_types"], g["object_types"]) and env.n_object_types == 3
+    Ag = riab.Agent(env)
+    tun = dict(tuning_distance=list(g[f"ovc_{tag}_tuning_distances"]),
+               tuning_angle=list(np.degrees(g[f"ovc_{tag}_tuning_angles"])),
+               sigma_distance=list(g[f"ovc_{tag}_sigma_distances"]),
+               sigma_angle=list(np.degrees(g[f"ovc_{tag}_sigma_angles"])),
+               object_tuning_type=[int(x) for x in g[f"ovc_{tag}_tuning_types"]])
+    if tag == "fov":
+        O = riab.FieldOfViewOVCs(Ag, {"object_tuning_type": [int(x) for x in g["ovc_fov_tuning_types"]],
+                                      "angle_range": [0, 100]})
+        np.testing.assert_allclose(O.tuning_distances, g["ovc_fov_tuning_distances"], rtol=1e-15)
+        np.testing.assert_allclose(O.sigma_angles, g["ovc_fov_sigma_angles"], rtol=1e-15)
+    elif tag == "ego":
+        O = riab.ObjectVectorCells(Ag, dict(tun, reference_frame="egocentric", max_fr=4.0, min_fr=0.2))
+    else:
+        O = riab.ObjectVectorCells(Ag, dict(tun, walls_occlude=(tag == "allo")))
+    kw = dict(head_direction=g["hd"]) if tag in ("ego", "fov") else {}
+    got = O.get_state(evaluate_at=None, pos=g["pos"], **kw)
+    assert_rates(got, g[f"ovc_{tag}_rates"], scale=3.8 if tag == "ego" else 1.0, floor=1.0)
+    # batched per-step and fused use agree with the oracle on the agents' own positions
+    np.random.seed(8)
+    Ag2 = riab.Agent(env, {"n_agents": 70, "dt": 0.02})
+    O2 = riab.ObjectVectorCells(Ag2, {"n": 9})
+    Ag2.simulate(5)
+    torch.cuda.synchronize()
+    traj = Ag2.get_history_tensor()[-1].cpu().numpy()
+    ref = orc.object_vector_cells(orc.EnvSpec(walls=g["walls"][4:]), traj[0:2, :70].T.astype(np.float64), g["objects"],
+                                  g["object_types"], O2.tuning_distances, O2.tuning_angles, O2.sigma_distances,
+                                  O2.sigma_angles, O2.tuning_types)
+    assert_rates(O2.firingrate, ref, floor=1.0)

@@ -201,3 +201,19 @@ def test_feedforward_layer(act):
                                 [g["w2"]], np.zeros(5), gu.FF_ACTS["tanh"])
         pcs = orc.place_cells(env, g["pos"], g["pc_centres"], 0.2)
         np.testing.assert_allclose(f2, g["ff_stack_rates"], rtol=1e-11, atol=1e-13)
+
+
+OVC_CASES = [("allo", dict(walls_occlude=True), False), ("allo_nowalls", dict(walls_occlude=False), False),
+             ("ego", dict(walls_occlude=True, min_fr=0.2, max_fr=4.0), True), ("fov", dict(walls_occlude=True), True)]
+
+
+@pytest.mark.parametrize("tag,kw,ego", OVC_CASES)
+def test_object_vector_cells(tag, kw, ego):
+    """ObjectVectorCells / FieldOfViewOVCs (Neurons.py:1892-2150)."""
+    g = gu.load("ovc.npz")
+    env = orc.EnvSpec(walls=g["walls"][4:])
+    got = orc.object_vector_cells(env, g["pos"], g["objects"], g["object_types"], g[f"ovc_{tag}_tuning_distances"],
+                                  g[f"ovc_{tag}_tuning_angles"], g[f"ovc_{tag}_sigma_distances"],
+                                  g[f"ovc_{tag}_sigma_angles"], g[f"ovc_{tag}_tuning_types"],
+                                  head_direction=g["hd"] if ego else None, **kw)
+    np.testing.assert_allclose(got, g[f"ovc_{tag}_rates"], rtol=1e-10, atol=1e-14)
