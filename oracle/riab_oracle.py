@@ -681,22 +681,25 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def motion_normals(seed, step, agent_ids):
-    """The device's per-(step, agent) motion draws: Box-Muller on the top 24 bits of
-    Philox words 0/1 (2/3 are the spare pair of the zero-displacement branch).  The
+    """The device's per-(step, agent) motion draws: Box-Muller on the top 24 bits of two
+    Philox words.  The
     device evaluates log2 / sin / cos with the fp32 hardware approximations, so this
     float64 restatement agrees to ~1e-6 (the Philox words themselves are bit-exact);
     trajectories are compared through the `z_out` record of the kernel.
     Returns z_rot, z_speed, z_zero0, z_zero1 (float64)."""
     agent_ids = np.asarray(agent_ids, dtype=np.uint64)
-    x0, x1, x2, x3 = philox4x32_10(step & 0xFFFFFFFF, (step >> 32) & 0xFFFFFFFF, agent_ids, TAG_MOTION,
-                                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    pair = step >> 1  # one Philox call serves two steps: words (0,1) on even steps, (2,3) on odd ones
+    x = philox4x32_10(pair & 0xFFFFFFFF, (pair >> 32) & 0xFFFFFFFF, agent_ids, TAG_MOTION,
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    y = philox4x32_10(step & 0xFFFFFFFF, (step >> 32) & 0xFFFFFFFF, agent_ids, TAG_MOTION ^ 1,
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)  # the zero-displacement branch's stream
     def bm(a, b):
         u1 = ((a >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0**-24
         u2 = (b >> np.uint32(8)).astype(np.float64) * 2.0**-24
         r = np.sqrt(-2.0 * np.log(u1))
         return r * np.cos(TWO_PI * u2), r * np.sin(TWO_PI * u2)
-    z0, z1 = bm(x0, x1)
-    z2, z3 = bm(x2, x3)
+    z0, z1 = bm(x[2], x[3]) if (step & 1) else bm(x[0], x[1])
+    z2, z3 = bm(y[0], y[1])
     return z0, z1, z2, z3
 
 

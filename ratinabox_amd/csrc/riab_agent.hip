@@ -210,6 +210,7 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   const R wd = (R)m.wall_repel_distance_kw;
   const R v0 = (R)m.wall_repel_strength_kw * sm;
   const R kspring = (v0 * v0) / (wd * wd);
+  const R inv_wd2 = (R)1 / (wd * wd);
   const R g = (R)m.thigmotaxis_kw;
   const R cvel = (R)3 * (((R)1 - g) * ((R)1 - g));
   const R cpos = (R)6 * (g * g);
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   const bool hd_instant = m.hd_tau <= m.dt;
   const R hd_gain = (R)(m.dt / m.hd_tau), hd_keep = (R)(1.0 - m.dt / m.hd_tau);
 
+  u32x4 pw = {0u, 0u, 0u, 0u};
   Wall<R> w4[4];
 #pragma unroll
   for (int w = 0; w < 4; ++w) w4[w] = s_w[w < nw ? w : 0];
@@ -227,7 +229,6 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   for (int t = 0; t < a.T; ++t) {
     // ---- the step's standard normals -------------------------------------------------------
     R z_rot, z_spd;
-    uint32_t zw2 = 0x80000000u, zw3 = 0;
     if (IN == 1) {
       z_rot = (R)a.z_in[((int64_t)t * 2 + 0) * B + b];
       z_spd = (R)a.z_in[((int64_t)t * 2 + 1) * B + b];
@@ -235,17 +236,20 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       z_rot = (R)0;
       z_spd = (R)0;
     } else {
+      // one Philox4x32-10 call serves TWO steps: counter = step >> 1, words (x, y) on even steps
+      // and (z, w) on odd ones
       const uint64_t step = a.step0 + (uint64_t)t;
-      const u32x4 w = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), aid, RIAB_TAG_MOTION, a.k0, a.k1);
+      if (t == 0 || (step & 1) == 0) {
+        const uint64_t pair = step >> 1;
+        pw = philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), aid, RIAB_TAG_MOTION, a.k0, a.k1);
+      }
+      const uint32_t wa = (step & 1) ? pw.z : pw.x, wb = (step & 1) ? pw.w : pw.y;
       // Box-Muller on the Philox words with the hardware log2 / sin / cos (the draws only need
-      // to be N(0,1) and a pure function of (seed, step, agent); `z_out` records them).  The
-      // second pair is only consumed by the zero-displacement branch.
-      const float u1 = ((float)(w.x >> 8) + 0.5f) * 0x1.0p-24f, u2 = (float)(w.y >> 8) * 0x1.0p-24f;
+      // to be N(0,1) and a pure function of (seed, step, agent); `z_out` records them).
+      const float u1 = ((float)(wa >> 8) + 0.5f) * 0x1.0p-24f, u2 = (float)(wb >> 8) * 0x1.0p-24f;
       const float rr = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1)
       z_rot = (R)(rr * __builtin_amdgcn_cosf(u2));
       z_spd = (R)(rr * __builtin_amdgcn_sinf(u2));
-      zw2 = w.z;
-      zw3 = w.w;
     }
     if (a.z_out) {
       a.z_out[((int64_t)t * 2 + 0) * B + b] = (double)z_rot;
@@ -370,12 +374,13 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
           l = (l > (R)1) ? (R)1 : l;
           l = (l < (R)0) ? (R)0 : l;
           const R qx = px - (W.ax + l * W.sx), qy = py - (W.ay + l * W.sy);
-          const R x = r_sqrt(qx * qx + qy * qy);
+          const R xx = qx * qx + qy * qy;
+          const R ix = r_rsqrt(xx);  // 1/x and x from one reciprocal square root
+          const R x = xx * ix;
           if (x <= wd) {
-            const R ix = (R)1 / x;
             const R nx = qx * ix, ny = qy * ix;
             const R acc = kspring * (wd - x);
-            const R spd = v0 * ((R)1 - r_sqrt((R)1 - ((wd - x) * (wd - x)) / (wd * wd)));
+            const R spd = v0 * ((R)1 - r_sqrt((R)1 - ((wd - x) * (wd - x)) * inv_wd2));
             ax_ += acc * nx;
             ay_ += acc * ny;
             sx_ += spd * nx;
@@ -467,8 +472,10 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     R dstep = dp2 * idp;
     R imv = idp * dt;              // 1 / |mv|
     if (dp2 == (R)0) {
-      // 1e-8 * randn(2) (Agent.py:459-460): never reached in practice; drawn from the spare words
-      const float u3 = ((float)(zw2 >> 8) + 0.5f) * 0x1.0p-24f, u4 = (float)(zw3 >> 8) * 0x1.0p-24f;
+      // 1e-8 * randn(2) (Agent.py:459-460): never reached in practice; its own Philox stream
+      const uint64_t stp = a.step0 + (uint64_t)t;
+      const u32x4 zw = philox4x32_10((uint32_t)stp, (uint32_t)(stp >> 32), aid, RIAB_TAG_MOTION ^ 1u, a.k0, a.k1);
+      const float u3 = ((float)(zw.x >> 8) + 0.5f) * 0x1.0p-24f, u4 = (float)(zw.y >> 8) * 0x1.0p-24f;
       const float r2 = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u3));
       mvx = (R)1e-8 * (R)(r2 * __builtin_amdgcn_cosf(u4));
       mvy = (R)1e-8 * (R)(r2 * __builtin_amdgcn_sinf(u4));
