@@ -33,23 +33,38 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libriab_hip.so."""
+    """Compile every HIP source for gfx950 and link libriab_hip.so.  Safe when several ranks
+    import the package at once: one process builds under a file lock, into a private directory,
+    and the library is moved into place atomically."""
+    import fcntl
+    import tempfile
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    hipcc = _hipcc()
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-I", INCLUDE, "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
-        objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():  # another rank built it while we waited
+                return LIB_PATH
+            hipcc = _hipcc()
+            work = tempfile.mkdtemp(prefix="build_", dir=LIB_DIR)
+            objs = []
+            for src in SOURCES:
+                obj = os.path.join(work, src.replace(".hip", ".o"))
+                cmd = [hipcc, *FLAGS, "-I", INCLUDE, "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                subprocess.run(cmd, check=True)
+                objs.append(obj)
+            tmp_lib = os.path.join(work, "libriab_hip.so")
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib, *objs]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            os.replace(tmp_lib, LIB_PATH)
+            shutil.rmtree(work, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
