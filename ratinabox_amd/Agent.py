@@ -216,13 +216,18 @@ class Agent:
 
     def _as_device_f64(self, x, rows):
         """array-like `(B, rows)` / `(rows,)` / tensor `[rows, B]` -> device float64 `[rows, Bp]`."""
-        if torch.is_tensor(x):
+        if torch.is_tensor(x):  # stays on the device: closed-loop callers pass policy outputs directly
             t = x.to(self._device, torch.float64)
             if t.shape == (rows, self._Bp):
                 return t.contiguous()
-            x = t.cpu().numpy()
-            if x.shape == (rows, self._B):
-                x = x.T
+            if t.shape == (rows,):
+                return t.reshape(rows, 1).expand(rows, self._Bp).contiguous()
+            if t.shape == (self._B, rows):
+                t = t.t()
+            assert t.shape == (rows, self._B), f"expected ({self._B},{rows}) or ({rows},{self._B}), got {tuple(x.shape)}"
+            if self._Bp != self._B:
+                t = torch.cat((t, t[:, :1].expand(rows, self._Bp - self._B)), dim=1)
+            return t.contiguous()
         a = np.asarray(x, dtype=np.float64)
         a = np.broadcast_to(a.reshape(-1, rows), (self._B, rows)) if a.size == rows else a.reshape(self._B, rows)
         full = np.empty((rows, self._Bp))

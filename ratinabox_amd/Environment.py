@@ -178,11 +178,15 @@ class Environment:
         layout include/riab_hip.h documents.  Rebuilt when `walls` changed."""
         import torch
         from . import _lib
-        walls = np.ascontiguousarray(np.asarray(self.walls, dtype=np.float64).reshape(-1, 4))
-        key = (str(device), walls.tobytes(), self.boundary_conditions, float(self.scale), float(self.aspect))
         hit = self._device_cache.get("env")
-        if hit is not None and hit[0] == key:
-            return hit[1], hit[2]
+        if hit is not None:
+            (dev, src, bc, sc, asp), env, wt = hit
+            # fast path (every step): same device, same geometry, wall array unchanged
+            if (dev == str(device) and bc == self.boundary_conditions and sc == self.scale and asp == self.aspect
+                    and src.shape == np.shape(self.walls) and np.array_equal(src, self.walls)):
+                return env, wt
+        walls = np.ascontiguousarray(np.asarray(self.walls, dtype=np.float64).reshape(-1, 4))
+        key = (str(device), np.array(self.walls, dtype=np.float64), self.boundary_conditions, self.scale, self.aspect)
         if len(walls) > _lib.MAX_WALLS:
             raise ValueError(f"at most {_lib.MAX_WALLS} walls are supported on device, got {len(walls)}")
         wt = torch.from_numpy(walls if len(walls) else np.zeros((1, 4))).to(device)

@@ -201,21 +201,25 @@ class Neurons:
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _io(self, px, py, hx, hy, pos_ld, T, B, rates, spikes, u_in, dt, step0):
-        io = _L.RiabRateIO()
+        """Fill the ABI's RiabRateIO (one persistent struct per population; the library reads it
+        before the call returns)."""
+        io = self.__dict__.get("_io_struct")
+        if io is None:
+            io = self.__dict__["_io_struct"] = _L.RiabRateIO()
         io.pos_x = px.data_ptr() if px is not None else None
         io.pos_y = py.data_ptr() if py is not None else None
         io.hd_x = hx.data_ptr() if hx is not None else None
         io.hd_y = hy.data_ptr() if hy is not None else None
-        io.pos_ld, io.T, io.B = int(pos_ld), int(T), int(B)
+        io.pos_ld, io.T, io.B = pos_ld, T, B
         io.rates = rates.data_ptr()
         io.spikes = spikes.data_ptr() if spikes is not None else None
         io.u_in = u_in.data_ptr() if u_in is not None else None
-        io.dt = float(dt)
-        io.min_fr, io.max_fr = float(self.min_fr), float(self.max_fr)
-        io.seed = int(self.Agent.seed)
-        io.step0 = int(step0)
-        io.agent_id0 = int(self.Agent.agent_id0)
-        io.pop_id = int(self.pop_id)
+        io.dt = dt
+        io.min_fr, io.max_fr = self.min_fr, self.max_fr
+        io.seed = self.Agent.seed
+        io.step0 = step0
+        io.agent_id0 = self.Agent.agent_id0
+        io.pop_id = self.pop_id
         return io
 
     def _launch(self, px, py, hx, hy, pos_ld, T, B, rates, spikes, u_in, dt, step0, from_f64=False, stream=None):

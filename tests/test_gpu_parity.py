@@ -587,3 +587,21 @@ def test_object_vector_cells_vs_reference(riab, tag):
                                   g["object_types"], O2.tuning_distances, O2.tuning_angles, O2.sigma_distances,
                                   O2.sigma_angles, O2.tuning_types)
     assert_rates(O2.firingrate, ref, floor=1.0)
+
+
+def test_device_drift_velocity_closed_loop(riab):
+    """drift_velocity as a device tensor (B,2) (policy in the loop) == the same values from the host."""
+    np.random.seed(4)
+    env = make_env(riab)
+    A1 = riab.Agent(env, {"n_agents": 10, "dt": 0.05, "seed": 3})
+    np.random.seed(4)
+    A2 = riab.Agent(env, {"n_agents": 10, "dt": 0.05, "seed": 3})
+    target = np.array([0.5, 0.5])
+    for _ in range(40):
+        d_host = 0.3 * (target - A1.pos)
+        A1.update(drift_velocity=d_host, drift_to_random_strength_ratio=5.0)
+        pos_dev = A2.state_tensor[0:2, :10].t()
+        d_dev = 0.3 * (torch.as_tensor(target, device="cuda") - pos_dev)
+        A2.update(drift_velocity=d_dev, drift_to_random_strength_ratio=5.0)
+    assert np.array_equal(A1.pos, A2.pos)
+    assert np.linalg.norm(A1.pos - target, axis=1).mean() < 0.25  # the drift pulls the agents to the target
