@@ -136,6 +136,13 @@ def main():
     import ratinabox_amd as riab
     cfg = CONFIGS[args.config]
     env, ag, pops = build_world(riab, cfg, rank, args.precision)
+    # the full rate history of K steps must fit in HBM next to the warmup's; otherwise stream
+    # through ring buffers (every byte is still written, the oldest rows are overwritten)
+    n_cells = sum(int(p.n) for p in pops)
+    need = (args.steps + args.warmup) * cfg["agents"] * (n_cells * (5 if cfg["spikes"] else 4) + 32)
+    free_b, _total_b = torch.cuda.mem_get_info()
+    if need > 0.6 * free_b:
+        args.no_history = True
     if args.no_history:
         ag.save_history = False
         for p in pops:

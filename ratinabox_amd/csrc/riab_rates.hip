@@ -50,6 +50,17 @@ struct PosQuad {
 
 __device__ __forceinline__ v4f ldv4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
 
+// Neurons.update returns zeros while the agent's position is NaN (reference Neurons.py:163-164)
+__device__ __forceinline__ v4f nan_pos_to_zero(v4f r, const PosQuad& P) {
+  r.x = (P.x.x == P.x.x) ? r.x : 0.0f;
+  r.y = (P.x.y == P.x.y) ? r.y : 0.0f;
+  r.z = (P.x.z == P.x.z) ? r.z : 0.0f;
+  r.w = (P.x.w == P.x.w) ? r.w : 0.0f;
+  return r;
+}
+template <class P_>
+__device__ __forceinline__ v4f nan_pos_to_zero(v4f r, const P_&) { return r; }
+
 // ---- spike epilogue: Neurons.save_to_history (reference Neurons.py:681-687) -------------
 template <bool EXPLICIT_U>
 __device__ __forceinline__ void spike_store(const RateArgs& a, v4f r, int64_t off, uint32_t step, uint32_t c,
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(256) void rate_kernel_wide(const RateArgs a, Cell c
       for (int i = 0; i < NP; ++i)
         p[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), j * NP + i));
       v4f r = cell.eval(p, P);
-      r = r * a.fr_scale + a.fr_min;  // [0,1] -> [min_fr, max_fr]
+      r = nan_pos_to_zero(r * a.fr_scale + a.fr_min, P);  // [0,1] -> [min_fr, max_fr]
       if (live) {
         *reinterpret_cast<v4f*>(a.rates + off) = r;
         if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)(c0 + j), group);
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(256) void rate_kernel_generic(const RateArgs a, Cel
       for (int i = 0; i < NP; ++i)
         p[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine[i]), j));
       v4f r = cell.eval(p, P);
-      r = r * a.fr_scale + a.fr_min;
+      r = nan_pos_to_zero(r * a.fr_scale + a.fr_min, P);
       if (live) {
         __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(a.rates + off));
         if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)(cb + j), group);

@@ -606,3 +606,17 @@ def test_device_drift_velocity_closed_loop(riab):
         A2.update(drift_velocity=d_dev, drift_to_random_strength_ratio=5.0)
     assert np.array_equal(A1.pos, A2.pos)
     assert np.linalg.norm(A1.pos - target, axis=1).mean() < d0  # the drift pulls the agents towards the target
+
+
+def test_nan_position_gives_zero_rates(riab):
+    """Neurons.update returns zeros while Agent.pos is NaN (Neurons.py:163-164)."""
+    Ag = riab.Agent(make_env(riab), {"n_agents": 8})
+    PCs = riab.PlaceCells(Ag, {"n": 5, "min_fr": 0.3, "max_fr": 2.0})
+    GCs = riab.GridCells(Ag, {"n": 6})
+    pos = np.array(Ag.pos)
+    pos[2] = np.nan
+    Ag.pos = pos
+    PCs.update(); GCs.update()
+    assert (PCs.firingrate[:, 2] == 0).all() and (GCs.firingrate[:, 2] == 0).all()
+    ok = [0, 1, 3, 4, 5, 6, 7]
+    assert np.isfinite(PCs.firingrate[:, ok]).all() and (PCs.firingrate[:, ok] >= 0.3 - 1e-6).all()
