@@ -744,6 +744,25 @@ class HeadDirectionCells(Neurons):
         self.angular_tunings = np.array([self.params["angular_spread_degrees"] * np.pi / 180] * self.n)
         super().__init__(Agent, self.params)
 
+    def get_state_tensor(self, evaluate_at="agent", use_velocity=False, **kwargs):
+        """`use_velocity=True` tunes to the direction of the agent's velocity (or the `velocity=`
+        kwarg) instead of its head direction (reference Neurons.py:2421-2461)."""
+        if not use_velocity:
+            return super().get_state_tensor(evaluate_at, **kwargs)
+        if evaluate_at == "agent":
+            vel = np.asarray(self.Agent.velocity, dtype=np.float64).reshape(-1, 2)
+            pos = np.asarray(self.Agent.pos, dtype=np.float64).reshape(-1, 2)
+        else:
+            vel = np.asarray(kwargs.get("velocity", [1.0, 0.0]), dtype=np.float64).reshape(-1, 2)
+            pos = (self.Agent.Environment.flattened_discrete_coords if evaluate_at == "all"
+                   else np.asarray(kwargs.get("pos", np.zeros((len(vel), 2))), dtype=np.float64).reshape(-1, 2))
+        direction = vel / np.linalg.norm(vel, axis=-1, keepdims=True)
+        return super().get_state_tensor(None, pos=pos, head_direction=direction)
+
+    def get_state(self, evaluate_at="agent", use_velocity=False, **kwargs):
+        t = self.get_state_tensor(evaluate_at, use_velocity=use_velocity, **kwargs)
+        return t[:, :self._last_P].cpu().numpy().astype(np.float64)
+
     def _call(self, io, stream):
         n = int(self.n)
         pref = np.asarray(self.preferred_angles, dtype=np.float64)

@@ -620,3 +620,18 @@ def test_nan_position_gives_zero_rates(riab):
     assert (PCs.firingrate[:, 2] == 0).all() and (GCs.firingrate[:, 2] == 0).all()
     ok = [0, 1, 3, 4, 5, 6, 7]
     assert np.isfinite(PCs.firingrate[:, ok]).all() and (PCs.firingrate[:, ok] >= 0.3 - 1e-6).all()
+
+
+def test_hdc_use_velocity(riab):
+    """HeadDirectionCells.get_state(use_velocity=True) (Neurons.py:2440-2461)."""
+    np.random.seed(9)
+    Ag = riab.Agent(make_env(riab), {"n_agents": 6})
+    H = riab.HeadDirectionCells(Ag, {"n": 12})
+    for _ in range(5):
+        Ag.update()
+    got = H.get_state(use_velocity=True)
+    v = np.asarray(Ag.velocity)
+    ref = orc.head_direction_cells(v / np.linalg.norm(v, axis=1, keepdims=True), 12)
+    assert_rates(got, ref)
+    got = H.get_state(evaluate_at=None, use_velocity=True, velocity=np.array([0.0, 2.0]), pos=np.zeros((1, 2)))
+    assert_rates(got, orc.head_direction_cells(np.array([[0.0, 1.0]]), 12))
