@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=128, help="steps per kernel launch in the fused path")
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64), help="motion-kernel arithmetic")
     ap.add_argument("--per-step", action="store_true", help="time the drop-in per-step API instead of simulate()")
+    ap.add_argument("--plan", action="store_true", help="time the closed-loop path through a native step plan")
+    ap.add_argument("--plan-batch", type=int, default=1, help="steps per riab_plan_step call (1 = closed loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-history", action="store_true", help="ring buffers instead of a full T-long history")
     args = ap.parse_args()
@@ -150,8 +152,18 @@ def main():
     B = cfg["agents"]
     K, W = args.steps, args.warmup
 
+    plan = {"p": None}
+
     def run(n_steps):
-        if args.per_step:
+        if args.plan:
+            if plan["p"] is None or ag._plan is not plan["p"]:
+                plan["p"] = ag.make_step_plan(capacity=max(K, W))
+            nb = args.plan_batch
+            for _ in range(n_steps // nb):
+                plan["p"].step(nb)
+            if n_steps % nb:
+                plan["p"].step(n_steps % nb)
+        elif args.per_step:
             for _ in range(n_steps):
                 ag.update()
                 for p in pops:
@@ -183,7 +195,7 @@ def main():
         else:
             spans[-1][1] = ev
 
-    if not args.per_step:
+    if not (args.per_step or args.plan):
         ag._profile_hook = hook
     ag.preallocate_history(K)  # output buffers are allocated outside the timed region
     torch.cuda.synchronize()
@@ -237,7 +249,8 @@ def main():
             "config": {"workload": args.config + ": " + cfg["desc"], "agents_per_gpu": B,
                        "cells": {k: cfg[k] for k in ("place", "grid", "bvc", "hdc")},
                        "parallelism": f"agent-sharded x{world}, no step-path collective",
-                       "api": "per-step update()" if args.per_step else f"simulate(), {args.chunk} steps/launch",
+                       "api": ("step plan (one native call per step)" if args.plan else "per-step update()"
+                               if args.per_step else f"simulate(), {args.chunk} steps/launch"),
                        "history": "ring" if args.no_history else "full", "spikes": cfg["spikes"],
                        "bytes_per_agent_step": bpu},
             "hbm_GBps_whole_path": round(value / world * bpu / 1e9, 1),

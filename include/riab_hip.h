@@ -42,7 +42,8 @@ enum {
   RIAB_EINVAL = -1,       /* null pointer / negative size / bad enum */
   RIAB_EALIGN = -2,       /* B % 4 != 0 or misaligned row pointer */
   RIAB_ETOOBIG = -3,      /* more walls / test angles than the LDS staging allows */
-  RIAB_EUNSUPPORTED = -4  /* combination not implemented on device */
+  RIAB_EUNSUPPORTED = -4, /* combination not implemented on device */
+  RIAB_EFULL = -5         /* a step plan's history chunk has no free row left */
 };
 
 typedef void* riab_stream_t; /* hipStream_t */
@@ -265,6 +266,56 @@ enum { RIAB_ACT_LINEAR = 0, RIAB_ACT_SIGMOID = 1, RIAB_ACT_RELU = 2, RIAB_ACT_TA
 int riab_feedforward(const RiabFFInput* inputs, int32_t n_inputs, const float* bias, int32_t n_out,
                      int64_t T, int64_t B, int32_t activation, const float* act_params, float* out,
                      float* out_prime, riab_stream_t stream);
+
+/* ---- step plans: the closed-loop per-step path as one native call -----------------------------
+ * `for each step: Agent.update(); N.update() for N in Agent.Neurons` (demos/simple_example.ipynb
+ * cell 4; contribs/TaskEnvironment.py:399-408) recorded once, then advanced by riab_plan_step:
+ * row cursors, RNG counters and pointers are kept in C++, every kernel of every step is enqueued on
+ * `stream`, nothing is allocated or synchronised. */
+enum { RIAB_POP_PLACE = 0, RIAB_POP_GRID = 1, RIAB_POP_HDC = 2, RIAB_POP_BVC = 3, RIAB_POP_OVC = 4 };
+
+typedef struct RiabPopulation {
+  int32_t kind;              /* RIAB_POP_* */
+  int32_t n;                 /* cells */
+  RiabRateIO io;             /* min_fr, max_fr, pop_id are used; pointers / steps are filled per step */
+  float* rates_base;         /* device float32 [capacity_rows][n][B] history chunk */
+  uint8_t* spikes_base;      /* device uint8 [capacity_rows][n][B] or NULL */
+  int64_t capacity_rows;     /* 0: rates_base is a single row overwritten every step */
+  const float* table;        /* the population's cell table (as in its own entry point) */
+  int32_t description;       /* place / grid */
+  int32_t geometry;          /* place */
+  float top_hat_width;       /* place */
+  float f0;                  /* grid */
+  const double* test_dirs;   /* bvc */
+  const double* ray_rden;    /* bvc */
+  int32_t K;                 /* bvc */
+  int32_t egocentric;        /* bvc / ovc */
+  const float* vm_table;     /* bvc */
+  const float* inv_norm;     /* bvc */
+  const float* objects;      /* ovc */
+  const int32_t* object_types; /* ovc */
+  int32_t n_objects;         /* ovc */
+  int32_t walls_occlude;     /* ovc */
+} RiabPopulation;
+
+typedef struct RiabPlan RiabPlan;
+
+/* state / diag / row_scratch as in riab_agent_step (row_scratch: device float32 [8][B], receives the
+ * newest history row when no agent history chunk is attached); step = Agent updates taken so far. */
+RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
+                           int64_t agent_id0, uint64_t seed, uint64_t step, int32_t precision,
+                           float* row_scratch, int32_t* diag);
+void riab_plan_destroy(RiabPlan* plan);
+int riab_plan_set_motion(RiabPlan* plan, const RiabMotion* motion, const double* drift);
+int riab_plan_set_agent_history(RiabPlan* plan, float* hist_base, int64_t capacity_rows);
+int riab_plan_add(RiabPlan* plan, const RiabPopulation* pop);  /* returns the population's index */
+int riab_plan_set_population_history(RiabPlan* plan, int32_t index, float* rates_base, uint8_t* spikes_base,
+                                     int64_t capacity_rows);
+int64_t riab_plan_rows_free(const RiabPlan* plan);
+uint64_t riab_plan_step_index(const RiabPlan* plan);
+/* n_steps x (Agent.update(); every population's update()); RIAB_EFULL (nothing launched) when a
+ * history chunk has fewer than n_steps free rows. */
+int riab_plan_step(RiabPlan* plan, int32_t n_steps, riab_stream_t stream);
 
 /* Streaming-store calibration kernel: writes `bytes` bytes (multiple of 16) of
  * a constant with the same 16-B/lane store pattern as the rate kernels.  Used

@@ -81,6 +81,7 @@ class Agent:
         self._streams = None
         self._scratch_row = None
         self._last_row = None   # newest fp32 history row; None when the state was edited from the host
+        self._plan = None       # an active StepPlan (plan.py), if any
 
         self._state = torch.zeros((_L.STATE_ROWS, self._Bp), dtype=torch.float64, device=self._device)
         self.initialise_position_and_velocity()
@@ -255,6 +256,8 @@ class Agent:
 
     def _advance(self, T, dt, drift_velocity, ratio, kwargs, hist_view=None, stream=None, z_out=None,
                  forced=None):
+        if self._plan is not None:
+            self._plan.close()  # eager stepping resumes: the plan's cursors would go stale
         dt = dt or self.dt
         self.dt = dt
         noise = kwargs.pop("noise", None) if "noise" in kwargs else None
@@ -380,7 +383,18 @@ class Agent:
                     N._hist_sp.preallocate(n_steps)
 
     # ---- history --------------------------------------------------------------------------------
+    def _sync_plan(self):
+        if self._plan is not None:
+            self._plan.sync()
+
+    def make_step_plan(self, neurons=None, capacity=1024):
+        """A `StepPlan` (plan.py): `plan.step()` == `Agent.update(); N.update() for N in neurons` with the
+        per-step host work done in one native call."""
+        from .plan import StepPlan
+        return StepPlan(self, neurons, capacity)
+
     def _materialise_history(self):
+        self._sync_plan()
         h = self._hist.stack()[:, :, :self._B].cpu().numpy()  # (T, 8, B)
         sq = (lambda a: a[:, 0]) if self._B == 1 else (lambda a: a)
         pair = lambda i: sq(np.stack((h[:, i], h[:, i + 1]), axis=-1))  # noqa: E731
@@ -399,9 +413,12 @@ class Agent:
 
     def get_history_tensor(self):
         """Trajectory history on device: float32 `[T, 8, B_padded]` (rows RIAB_H_*)."""
+        self._sync_plan()
         return self._hist.stack()
 
     def reset_history(self):
+        if self._plan is not None:
+            self._plan.close()
         self._hist.reset()
         self._times = []
 

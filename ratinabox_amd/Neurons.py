@@ -81,9 +81,25 @@ class Neurons:
             pprint.pprint(all_params)
         return all_params
 
+    def _population(self):
+        """This population as the ABI's RiabPopulation (for a step plan); keeps its tables alive."""
+        if self.noise_std != 0 or isinstance(self, FeedForwardLayer):
+            raise NotImplementedError("step plans cover the position-driven populations without noise; "
+                                      "use update() for noise_std > 0 and FeedForwardLayers")
+        f = self._call(None, None)
+        pop = _L.RiabPopulation()
+        pop.kind, pop.n = f["kind"], int(self.n)
+        pop.io.min_fr, pop.io.max_fr, pop.io.pop_id = float(self.min_fr), float(self.max_fr), int(self.pop_id)
+        self._plan_tables = [v for v in f.values() if torch.is_tensor(v)]
+        for k, v in f.items():
+            if k != "kind":
+                setattr(pop, k, v.data_ptr() if torch.is_tensor(v) else v)
+        return pop
+
     # ---- attributes -----------------------------------------------------------------------------
     @property
     def firingrate(self):
+        self.Agent._sync_plan()
         a = self._rates[:, :self._B].cpu().numpy().astype(np.float64)
         return a[:, 0] if self._B == 1 else a
 
@@ -95,6 +111,7 @@ class Neurons:
     @property
     def firingrate_tensor(self):
         """Device firing rates of the last update: float32 `[n, B_padded]`."""
+        self.Agent._sync_plan()
         return self._rates
 
     # ---- the reference's per-step entry point (Neurons.py:145-171) ---------------------------
@@ -103,6 +120,7 @@ class Neurons:
         Poisson spikes `U(0,1) < dt*rate` to the history.  kwargs: `spike_uniforms=`
         `(n, B)` and `noise_normals=` `(n, B)` replace the in-kernel Philox draws."""
         Ag = self.Agent
+        Ag._sync_plan()
         u = kwargs.pop("spike_uniforms", None)
         zn = kwargs.pop("noise_normals", None)
         save = bool(self.save_history)
@@ -305,6 +323,7 @@ class Neurons:
 
     # ---- history ---------------------------------------------------------------------------------
     def _materialise_history(self):
+        self.Agent._sync_plan()
         fr = self._hist_fr.stack()[:, :, :self._B].cpu().numpy()
         sp = self._hist_sp.stack()[:, :, :self._B].cpu().numpy().astype(bool)
         if len(sp) == 0:
@@ -318,6 +337,7 @@ class Neurons:
 
     def get_history_tensors(self):
         """(firingrate float32 [T, n, Bp], spikes uint8 [T, n, Bp]) on device."""
+        self.Agent._sync_plan()
         return self._hist_fr.stack(), self._hist_sp.stack()
 
     def reset_history(self):
@@ -388,12 +408,16 @@ class PlaceCells(Neurons):
             return torch.from_numpy(tab.astype(np.float32)).to(self._device)
 
         tab = self._tables((centres, widths), build)
-        env, _w = self.Agent.Environment.device_tables(self._device)
         geom = self.wall_geometry
         if geom == "geodesic" and len(self.Agent.Environment.walls) <= 4:
             geom = "euclidean"  # Environment.py:741-742
+        thw = float(np.asarray(self.widths, dtype=float).reshape(-1)[0])
+        if io is None:  # descriptor for a step plan
+            return dict(kind=_L.POP_KINDS["place"], table=tab, description=_L.PC_DESCRIPTIONS[self.description],
+                        geometry=_L.GEOMETRIES[geom], top_hat_width=thw)
+        env, _w = self.Agent.Environment.device_tables(self._device)
         rc = _L.lib.riab_place_cells(env, io, _L.ptr(tab), n, _L.PC_DESCRIPTIONS[self.description],
-                                     _L.GEOMETRIES[geom], float(np.asarray(self.widths, dtype=float).reshape(-1)[0]), stream)
+                                     _L.GEOMETRIES[geom], thw, stream)
         _L.check(rc, "riab_place_cells")
 
     def remap(self):
@@ -475,6 +499,9 @@ class GridCells(Neurons):
 
         tab = self._tables((gs, ph, w), build)
         f0 = (1 / 3) * (2 * np.cos(np.sqrt(3) * np.pi * self.width_ratio / 2) + 1)
+        if io is None:
+            return dict(kind=_L.POP_KINDS["grid"], table=tab, description=_L.GC_DESCRIPTIONS[self.description],
+                        f0=float(f0))
         rc = _L.lib.riab_grid_cells(io, _L.ptr(tab), n, _L.GC_DESCRIPTIONS[self.description], float(f0), stream)
         _L.check(rc, "riab_grid_cells")
 
@@ -595,6 +622,9 @@ class BoundaryVectorCells(VectorCells):
 
         walls = np.asarray(self.Agent.Environment.walls, dtype=np.float64).reshape(-1, 2, 2)
         dirs_t, rden_t, cells_t, vm_t, inv_t = self._tables((mu_d, sg_d, mu_t, sg_t, ang, dirs, norm, ego, walls), build)
+        if io is None:
+            return dict(kind=_L.POP_KINDS["bvc"], table=cells_t, test_dirs=dirs_t, ray_rden=rden_t, K=K, vm_table=vm_t,
+                        inv_norm=inv_t, egocentric=1 if ego else 0)
         env, _w = self.Agent.Environment.device_tables(self._device)
         rc = _L.lib.riab_boundary_vector_cells(env, io, _L.ptr(dirs_t), _L.ptr(rden_t), K, _L.ptr(cells_t), _L.ptr(vm_t),
                                                _L.ptr(inv_t), n, 1 if ego else 0, None, stream)
@@ -688,6 +718,10 @@ class ObjectVectorCells(VectorCells):
                     torch.from_numpy(np.ascontiguousarray(cells, dtype=np.float32)).to(self._device))
 
         objs_t, types_t, cells_t = self._tables((objs, otypes, mu_d, sg_d, mu_t, sg_t, ttypes), build)
+        if io is None:
+            return dict(kind=_L.POP_KINDS["ovc"], table=cells_t, objects=objs_t, object_types=types_t,
+                        n_objects=int(len(objs)), walls_occlude=1 if occlude else 0,
+                        egocentric=1 if self.reference_frame == "egocentric" else 0)
         env, _w = Env.device_tables(self._device)
         rc = _L.lib.riab_object_vector_cells(env, io, _L.ptr(objs_t), _L.ptr(types_t), int(len(objs)), _L.ptr(cells_t),
                                              n, 1 if occlude else 0, 1 if self.reference_frame == "egocentric" else 0,
@@ -773,6 +807,8 @@ class HeadDirectionCells(Neurons):
             return f32(np.stack((pref, LOG2E / sig ** 2), axis=-1))
 
         tab = self._tables((pref, sig), build)
+        if io is None:
+            return dict(kind=_L.POP_KINDS["hdc"], table=tab)
         rc = _L.lib.riab_head_direction_cells(io, _L.ptr(tab), n, stream)
         _L.check(rc, "riab_head_direction_cells")
 

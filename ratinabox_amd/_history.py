@@ -48,6 +48,19 @@ class DeviceHistory:
         self.chunks.append(torch.empty((T, *self.row_shape), dtype=self.dtype, device=self.device))
         self.filled.append(0)
 
+    def open_rows(self, T):
+        """A writable view of T free rows that are NOT yet counted as history (a step plan writes
+        them one by one); `commit(n)` then publishes the first n of them."""
+        self.preallocate(T)
+        s = self.filled[-1]
+        return self.chunks[-1][s:s + int(T)]
+
+    def commit(self, n):
+        if n:
+            self.filled[-1] += int(n)
+            assert self.filled[-1] <= self.chunks[-1].shape[0]
+            self.version += 1
+
     def stack(self):
         """All filled rows as one tensor `[T_total, *row_shape]`."""
         parts = [c[:f] for c, f in zip(self.chunks, self.filled) if f]

@@ -52,6 +52,18 @@ class RiabFFInput(C.Structure):
     _fields_ = [("rates", C.c_void_p), ("wt", C.c_void_p), ("n_in", C.c_int32)]
 
 
+class RiabPopulation(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("io", RiabRateIO), ("rates_base", C.c_void_p),
+                ("spikes_base", C.c_void_p), ("capacity_rows", C.c_int64), ("table", C.c_void_p),
+                ("description", C.c_int32), ("geometry", C.c_int32), ("top_hat_width", C.c_float), ("f0", C.c_float),
+                ("test_dirs", C.c_void_p), ("ray_rden", C.c_void_p), ("K", C.c_int32), ("egocentric", C.c_int32),
+                ("vm_table", C.c_void_p), ("inv_norm", C.c_void_p), ("objects", C.c_void_p),
+                ("object_types", C.c_void_p), ("n_objects", C.c_int32), ("walls_occlude", C.c_int32)]
+
+
+POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4}
+EFULL = -5
+
 ACTIVATIONS = {"linear": 0, "sigmoid": 1, "relu": 2, "tanh": 3, "retanh": 4, "softmax": 5}
 
 # name -> (restype, argtypes): every symbol include/riab_hip.h declares
@@ -74,6 +86,16 @@ PROTOTYPES = {
     "riab_feedforward": (C.c_int, [C.POINTER(RiabFFInput), C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
                                    C.c_int32, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_fill": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "riab_plan_create": (C.c_void_p, [C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
+                                      C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "riab_plan_destroy": (None, [C.c_void_p]),
+    "riab_plan_set_motion": (C.c_int, [C.c_void_p, C.POINTER(RiabMotion), C.c_void_p]),
+    "riab_plan_set_agent_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "riab_plan_add": (C.c_int, [C.c_void_p, C.POINTER(RiabPopulation)]),
+    "riab_plan_set_population_history": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
+    "riab_plan_rows_free": (C.c_int64, [C.c_void_p]),
+    "riab_plan_step_index": (C.c_uint64, [C.c_void_p]),
+    "riab_plan_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "riab_abi_version": (C.c_int, []),
     "riab_strerror": (C.c_char_p, [C.c_int]),
 }

@@ -1,0 +1,159 @@
+// Step plans: the per-step (closed-loop) path as ONE native call.
+//
+// `Agent.update(); N.update() for N in neurons` costs, from Python, one ctypes transition,
+// struct filling and history bookkeeping per kernel — 30+ us per step at cfg 2 against ~9 us of
+// GPU time.  A plan records the agent and its populations once (the same arguments the
+// per-kernel entry points take); riab_plan_step then advances the row cursors, RNG counters and
+// pointers in C++ and enqueues the motion kernel and every population's rate kernel for each
+// requested step.  No allocation, no synchronisation: histories are chunks handed in by the
+// caller, and the call reports RIAB_EFULL (before launching anything) when a chunk is exhausted.
+#include <new>
+#include <vector>
+
+#include "riab_device.h"
+
+struct RiabPlan {
+  RiabEnv env;
+  RiabMotion motion;
+  double* state;
+  int64_t B;
+  int64_t agent_id0;
+  uint64_t seed;
+  uint64_t step;  // number of Agent.update() steps taken so far (the RNG counter)
+  int32_t precision;
+  const double* drift;
+  float* hist_base;     // [cap][8][B]
+  int64_t hist_cap, hist_fill;
+  float* row_scratch;   // [8][B] used when no history chunk is attached
+  int32_t* diag;
+  std::vector<RiabPopulation> pops;
+  std::vector<int64_t> pop_fill;
+};
+
+extern "C" RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
+                                      int64_t agent_id0, uint64_t seed, uint64_t step, int32_t precision,
+                                      float* row_scratch, int32_t* diag) {
+  if (!env || !motion || !state || B <= 0 || !row_scratch) return nullptr;
+  RiabPlan* p = new (std::nothrow) RiabPlan();
+  if (!p) return nullptr;
+  p->env = *env;
+  p->motion = *motion;
+  p->state = state;
+  p->B = B;
+  p->agent_id0 = agent_id0;
+  p->seed = seed;
+  p->step = step;
+  p->precision = precision;
+  p->drift = nullptr;
+  p->hist_base = nullptr;
+  p->hist_cap = p->hist_fill = 0;
+  p->row_scratch = row_scratch;
+  p->diag = diag;
+  return p;
+}
+
+extern "C" void riab_plan_destroy(RiabPlan* p) { delete p; }
+
+extern "C" int riab_plan_set_motion(RiabPlan* p, const RiabMotion* motion, const double* drift) {
+  if (!p || !motion) return RIAB_EINVAL;
+  if (motion->has_drift && !drift) return RIAB_EINVAL;
+  p->motion = *motion;
+  p->drift = drift;
+  return RIAB_OK;
+}
+
+extern "C" int riab_plan_set_agent_history(RiabPlan* p, float* hist_base, int64_t capacity_rows) {
+  if (!p || capacity_rows < 0 || (capacity_rows > 0 && !hist_base)) return RIAB_EINVAL;
+  p->hist_base = hist_base;
+  p->hist_cap = capacity_rows;
+  p->hist_fill = 0;
+  return RIAB_OK;
+}
+
+extern "C" int riab_plan_add(RiabPlan* p, const RiabPopulation* pop) {
+  if (!p || !pop || pop->n <= 0 || pop->kind < RIAB_POP_PLACE || pop->kind > RIAB_POP_OVC) return RIAB_EINVAL;
+  p->pops.push_back(*pop);
+  p->pop_fill.push_back(0);
+  return (int)p->pops.size() - 1;
+}
+
+extern "C" int riab_plan_set_population_history(RiabPlan* p, int32_t index, float* rates_base, uint8_t* spikes_base,
+                                                int64_t capacity_rows) {
+  if (!p || index < 0 || index >= (int)p->pops.size() || capacity_rows < 0) return RIAB_EINVAL;
+  if (!rates_base) return RIAB_EINVAL;  // capacity 0 = a single-row scratch that is overwritten every step
+  RiabPopulation& q = p->pops[index];
+  q.rates_base = rates_base;
+  q.spikes_base = spikes_base;
+  q.capacity_rows = capacity_rows;
+  p->pop_fill[index] = 0;
+  return RIAB_OK;
+}
+
+extern "C" int64_t riab_plan_rows_free(const RiabPlan* p) {
+  if (!p) return 0;
+  int64_t free_rows = p->hist_base ? p->hist_cap - p->hist_fill : INT64_MAX;
+  for (size_t i = 0; i < p->pops.size(); ++i) {
+    if (p->pops[i].capacity_rows == 0) continue;  // single-row scratch (no history kept)
+    const int64_t f = p->pops[i].capacity_rows - p->pop_fill[i];
+    free_rows = f < free_rows ? f : free_rows;
+  }
+  return free_rows;
+}
+
+extern "C" uint64_t riab_plan_step_index(const RiabPlan* p) { return p ? p->step : 0; }
+
+static int launch_population(RiabPlan* p, size_t i, const float* row, hipStream_t s) {
+  RiabPopulation& q = p->pops[i];
+  const int64_t B = p->B;
+  RiabRateIO io = q.io;
+  io.pos_x = row + RIAB_H_POS_X * B;
+  io.pos_y = row + RIAB_H_POS_Y * B;
+  io.hd_x = row + RIAB_H_HD_X * B;
+  io.hd_y = row + RIAB_H_HD_Y * B;
+  io.pos_ld = B;
+  io.T = 1;
+  io.B = B;
+  const int64_t r = p->pop_fill[i];
+  io.rates = q.rates_base + r * (int64_t)q.n * B;
+  io.spikes = q.spikes_base ? q.spikes_base + r * (int64_t)q.n * B : nullptr;
+  io.u_in = nullptr;
+  io.dt = (float)p->motion.dt;
+  io.seed = p->seed;
+  io.step0 = p->step;  // Neurons.update after the p->step-th Agent.update (the cursor was already advanced)
+  io.agent_id0 = p->agent_id0;
+  switch (q.kind) {
+    case RIAB_POP_PLACE:
+      return riab_place_cells(&p->env, &io, q.table, q.n, q.description, q.geometry, q.top_hat_width, s);
+    case RIAB_POP_GRID:
+      return riab_grid_cells(&io, q.table, q.n, q.description, q.f0, s);
+    case RIAB_POP_HDC:
+      return riab_head_direction_cells(&io, q.table, q.n, s);
+    case RIAB_POP_BVC:
+      return riab_boundary_vector_cells(&p->env, &io, q.test_dirs, q.ray_rden, q.K, q.table, q.vm_table, q.inv_norm,
+                                        q.n, q.egocentric, nullptr, s);
+    case RIAB_POP_OVC:
+      return riab_object_vector_cells(&p->env, &io, q.objects, q.object_types, q.n_objects, q.table, q.n,
+                                      q.walls_occlude, q.egocentric, s);
+  }
+  return RIAB_EINVAL;
+}
+
+extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream) {
+  if (!p || n_steps <= 0) return RIAB_EINVAL;
+  if (riab_plan_rows_free(p) < n_steps) return RIAB_EFULL;
+  hipStream_t s = (hipStream_t)stream;
+  for (int32_t k = 0; k < n_steps; ++k) {
+    float* row = p->hist_base ? p->hist_base + p->hist_fill * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
+    int rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr,
+                             p->seed, p->step, 1, row, p->diag, p->precision, s);
+    if (rc) return rc;
+    p->step += 1;
+    if (p->hist_base) p->hist_fill += 1;
+    for (size_t i = 0; i < p->pops.size(); ++i) {
+      rc = launch_population(p, i, row, s);
+      if (rc) return rc;
+      if (p->pops[i].capacity_rows > 0) p->pop_fill[i] += 1;
+    }
+  }
+  return RIAB_OK;
+}

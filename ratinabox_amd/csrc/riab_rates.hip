@@ -615,6 +615,7 @@ extern "C" const char* riab_strerror(int code) {
     case RIAB_EALIGN: return "agent axis not a multiple of 4 or row pointer not 16-byte aligned";
     case RIAB_ETOOBIG: return "too many walls / test angles for the LDS staging";
     case RIAB_EUNSUPPORTED: return "combination not supported on device";
+    case RIAB_EFULL: return "a step plan's history chunk is full: attach a new chunk";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown riab error";
   }
 }

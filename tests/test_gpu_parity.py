@@ -635,3 +635,53 @@ def test_hdc_use_velocity(riab):
     assert_rates(got, ref)
     got = H.get_state(evaluate_at=None, use_velocity=True, velocity=np.array([0.0, 2.0]), pos=np.zeros((1, 2)))
     assert_rates(got, orc.head_direction_cells(np.array([[0.0, 1.0]]), 12))
+
+
+@pytest.mark.parametrize("save", [True, False])
+def test_step_plan_equals_eager_loop(riab, save):
+    """StepPlan.step() == Agent.update(); N.update() ... (same kernels, arguments and RNG counters),
+    across history-chunk rollovers, with a device drift tensor, then back to eager stepping."""
+    walls = [[[0.5, 0.0], [0.5, 0.5]]]
+
+    def world():
+        np.random.seed(21)
+        env = make_env(riab, walls)
+        env.add_object([0.3, 0.7])
+        Ag = riab.Agent(env, {"n_agents": 36, "dt": 0.02, "seed": 11, "save_history": save})
+        pops = [riab.PlaceCells(Ag, {"n": 20, "max_fr": 30, "save_history": save}),
+                riab.GridCells(Ag, {"n": 9, "save_history": save, "save_spikes": False}),
+                riab.BoundaryVectorCells(Ag, {"n": 8, "save_history": save}),
+                riab.HeadDirectionCells(Ag, {"n": 6, "save_history": save}),
+                riab.ObjectVectorCells(Ag, {"n": 5, "save_history": save})]
+        return Ag, pops
+    drift = torch.tensor([0.1, -0.05], device="cuda", dtype=torch.float64)
+    A1, P1 = world()
+    for i in range(13):
+        A1.update(drift_velocity=drift if i >= 6 else None, drift_to_random_strength_ratio=2.0)
+        for p in P1:
+            p.update()
+    A2, P2 = world()
+    plan = A2.make_step_plan(capacity=5)  # forces two chunk rollovers
+    for i in range(13):
+        plan.step(drift_velocity=drift if i >= 6 else None, drift_to_random_strength_ratio=2.0)
+    assert abs(A2.t - A1.t) < 1e-12 and A2._step_index == 13
+    assert np.array_equal(A2.pos, A1.pos) and np.array_equal(A2.velocity, A1.velocity)
+    for a, b in zip(P1, P2):
+        assert np.array_equal(a.firingrate, b.firingrate), a.name
+    if save:
+        assert np.array_equal(A2.history["pos"], A1.history["pos"])
+        np.testing.assert_allclose(A2.history["t"], A1.history["t"], rtol=0, atol=0)
+        for a, b in zip(P1, P2):
+            assert np.array_equal(a.history["firingrate"], b.history["firingrate"]), a.name
+            assert np.array_equal(a.history["spikes"], b.history["spikes"]), a.name
+            assert len(b.history["t"]) == 13
+    # eager stepping after a plan: the plan closes itself and the histories continue seamlessly
+    A1.update(); A2.update()
+    for p in P1 + P2:
+        p.update()
+    assert A2._plan is None and np.array_equal(A2.pos, A1.pos)
+    assert np.array_equal(P1[0].firingrate, P2[0].firingrate)
+    if save:
+        assert A2.history["pos"].shape[0] == 14 and np.array_equal(A2.history["pos"], A1.history["pos"])
+    with pytest.raises(RuntimeError):
+        plan.step()
