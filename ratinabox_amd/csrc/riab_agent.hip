@@ -33,6 +33,7 @@ namespace riab {
 struct RayleighLds {
   const double* g;
   const double* h;
+  int g_stride, h_stride;  // doubles between consecutive segment rows
 };
 // lookup (issue the per-lane LDS reads of one segment's row) and evaluation are split so that
 // independent work can be placed between them: the wave is alone on its SIMD, nothing else hides
@@ -68,12 +69,12 @@ __device__ __forceinline__ double clamp_G_arg(double t) {
 }
 __device__ __forceinline__ const double* row_G(const RayleighLds& L, double t_clamped) {
   const int seg = (int)(((unsigned long long)__double_as_longlong(t_clamped) >> 49) - RIAB_G_KEY0);
-  return L.g + seg * RIAB_G_STRIDE;
+  return L.g + seg * L.g_stride;
 }
 __device__ __forceinline__ const double* row_H(const RayleighLds& L, double n) {
   int seg = (int)((n + RIAB_H_NMAX) * RIAB_H_INV_SEG);
   seg = seg < 0 ? 0 : (seg > RIAB_H_SEGS - 1 ? RIAB_H_SEGS - 1 : seg);
-  return L.h + seg * RIAB_H_STRIDE;
+  return L.h + seg * L.h_stride;
 }
 
 struct AgentArgs {
@@ -155,13 +156,18 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   __shared__ Wall<R> s_w[RIAB_MAX_WALLS];
   __shared__ double s_g[sizeof(R) == 8 ? RIAB_G_SEGS * RIAB_G_STRIDE : 1];
   __shared__ double s_h[sizeof(R) == 8 ? RIAB_H_SEGS * RIAB_H_STRIDE : 1];
-  if (sizeof(R) == 8) {
+  // Long launches stage the tables in LDS (per-lane gathers every step); a launch of a few steps
+  // (the closed-loop path, T = 1) reads its two rows per step straight from the L2-resident
+  // global tables instead of paying the 19 KB staging each time.
+  const bool use_lds = sizeof(R) == 8 && a.T >= 16;
+  if (use_lds) {
     for (int i = threadIdx.x; i < RIAB_G_SEGS * (RIAB_G_DEG + 3); i += 64)
       s_g[(i / (RIAB_G_DEG + 3)) * RIAB_G_STRIDE + i % (RIAB_G_DEG + 3)] = (&riab_g_table[0][0])[i];
     for (int i = threadIdx.x; i < RIAB_H_SEGS * (RIAB_H_DEG + 3); i += 64)
       s_h[(i / (RIAB_H_DEG + 3)) * RIAB_H_STRIDE + i % (RIAB_H_DEG + 3)] = (&riab_h_table[0][0])[i];
   }
-  const RayleighLds rl{s_g, s_h};
+  const RayleighLds rl = use_lds ? RayleighLds{s_g, s_h, RIAB_G_STRIDE, RIAB_H_STRIDE}
+                                 : RayleighLds{&riab_g_table[0][0], &riab_h_table[0][0], RIAB_G_DEG + 3, RIAB_H_DEG + 3};
   for (int w = threadIdx.x; w < a.n_walls; w += 64) {
     const double ax = a.walls[4 * w], ay = a.walls[4 * w + 1], bx = a.walls[4 * w + 2], by = a.walls[4 * w + 3];
     const double sx = bx - ax, sy = by - ay;
