@@ -82,3 +82,27 @@ def test_no_cpu_fallback_in_product():
             src = open(os.path.join(pkg, f)).read()
             assert "oracle" not in src.replace("the oracle", "").replace("oracle/", "") or f == "_lib.py" or True
             assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_step_plan_validation_without_gpu(L):
+    """riab_plan_*: argument validation and the 'history chunk full' report happen before any launch."""
+    env, m = L.RiabEnv(), L.RiabMotion()
+    assert not L.lib.riab_plan_create(None, m, C.c_void_p(16), 4, 0, 0, 0, 64, C.c_void_p(16), None)
+    assert not L.lib.riab_plan_create(env, m, None, 4, 0, 0, 0, 64, C.c_void_p(16), None)
+    h = L.lib.riab_plan_create(env, m, C.c_void_p(16), 4, 0, 7, 5, 64, C.c_void_p(16), None)
+    assert h and L.lib.riab_plan_step_index(h) == 5
+    assert L.lib.riab_plan_step(h, 0, None) == -1
+    pop = L.RiabPopulation()
+    pop.kind, pop.n = 99, 4
+    assert L.lib.riab_plan_add(h, pop) == -1
+    pop.kind = L.POP_KINDS["place"]
+    assert L.lib.riab_plan_add(h, pop) == 0
+    assert L.lib.riab_plan_set_population_history(h, 3, C.c_void_p(16), None, 4) == -1
+    assert L.lib.riab_plan_set_population_history(h, 0, C.c_void_p(16), None, 2) == 0
+    assert L.lib.riab_plan_set_agent_history(h, C.c_void_p(16), 8) == 0
+    assert L.lib.riab_plan_rows_free(h) == 2
+    assert L.lib.riab_plan_step(h, 3, None) == L.EFULL  # nothing launched
+    assert "full" in L.strerror(L.EFULL)
+    m.has_drift = 1
+    assert L.lib.riab_plan_set_motion(h, m, None) == -1
+    L.lib.riab_plan_destroy(h)
