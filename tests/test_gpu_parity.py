@@ -685,3 +685,39 @@ def test_step_plan_equals_eager_loop(riab, save):
         assert A2.history["pos"].shape[0] == 14 and np.array_equal(A2.history["pos"], A1.history["pos"])
     with pytest.raises(RuntimeError):
         plan.step()
+
+
+def test_config5_shape_mixed_population_with_spikes(riab):
+    """BASELINE config 5 shard shape: 8192 agents x (1024 PC + 512 GC + 256 BVC + 256 HDC) with Poisson
+    spikes, fused.  Rates of a sample of agents against the oracle; spikes bit-exact against the
+    exactly-specified rule on the kernel's own rates and host-regenerated Philox uniforms."""
+    np.random.seed(5)
+    B, T, seed = 8192, 3, 77
+    env = make_env(riab)
+    Ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "seed": seed})
+    PCs = riab.PlaceCells(Ag, {"n": 1024, "max_fr": 20.0})
+    GCs = riab.GridCells(Ag, {"n": 512, "max_fr": 20.0})
+    BVs = riab.BoundaryVectorCells(Ag, {"n": 256, "max_fr": 20.0})
+    HDs = riab.HeadDirectionCells(Ag, {"n": 256, "max_fr": 20.0})
+    traj = Ag.simulate(T, chunk=2)
+    torch.cuda.synchronize()
+    sel = np.arange(0, B, 257)  # 32 agents spread over the batch
+    row = traj[T - 1].cpu().numpy()
+    pos = row[0:2, sel].T.astype(np.float64)
+    hd = row[4:6, sel].T.astype(np.float64)
+    oenv = orc.EnvSpec()
+    refs = {PCs: orc.place_cells(oenv, pos, PCs.place_cell_centres, 0.2, max_fr=20.0),
+            GCs: orc.grid_cells(pos, GCs.gridscales, GCs.phase_offsets, GCs.w, max_fr=20.0),
+            BVs: orc.bvc(pos, env.walls, BVs.tuning_distances, BVs.tuning_angles, BVs.sigma_distances,
+                         BVs.sigma_angles, max_fr=20.0),
+            HDs: orc.head_direction_cells(hd, 256, max_fr=20.0)}
+    total_spikes = 0
+    for pop, ref in refs.items():
+        fr, sp = pop.get_history_tensors()
+        assert fr.shape == (T, pop.n, B) and sp.shape == (T, pop.n, B)
+        assert_rates(fr[T - 1][:, sel].cpu().numpy(), ref, scale=20.0, floor=1.0)
+        fr_np, sp_np = fr[T - 1].cpu().numpy(), sp[T - 1].cpu().numpy().astype(bool)
+        u = orc.spike_uniforms(seed, T, pop.pop_id, pop.n, B)
+        assert np.array_equal(sp_np, orc.spikes_f32(fr_np, u, 0.01)), pop.name
+        total_spikes += int(sp_np.sum())
+    assert total_spikes > 1000
