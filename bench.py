@@ -240,6 +240,26 @@ def main():
                     "bytes_per_unit": unit_bytes, "kernel_own_bytes_per_unit": 4 * n0 + 8,
                     "frac_of_measured_copy_bw_6290": round(achieved / 6290.0, 4)}
 
+    # the chip's measured store ceiling in this same process (riab_fill: one float4 per thread,
+    # address-ordered), for context next to the spec peak
+    store_ceiling = None
+    if rank == 0 and roofline is not None:
+        L = riab._lib
+        nbytes = 1 << 30
+        buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        for _ in range(2):
+            L.lib.riab_fill(L.ptr(buf), nbytes, 1.0, L.current_stream())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            L.lib.riab_fill(L.ptr(buf), nbytes, 1.0, L.current_stream())
+        e1.record()
+        torch.cuda.synchronize()
+        store_ceiling = 5 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        roofline["measured_store_ceiling_GBps"] = round(store_ceiling, 1)
+        roofline["frac_of_measured_store_ceiling"] = round(roofline["achieved"] / store_ceiling, 4)
+        del buf
+
     if rank == 0:
         out = {
             "metric": "agent-steps/sec (whole node) at 4096 agents x 1024 PlaceCells",

@@ -409,11 +409,11 @@ __global__ __launch_bounds__(256) void noise_kernel(float* noise, float* rates, 
   *reinterpret_cast<v4f*>(noise + off) = x;
 }
 
+// one float4 per thread, workgroups in address order: the store roofline of the chip (6.9 TB/s
+// measured on MI355X) and the calibration kernel for the WRITE_SIZE counter
 __global__ __launch_bounds__(256) void fill_kernel(float* dst, int64_t n4, float value) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  const v4f v = {value, value, value, value};
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
-    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(dst) + i);
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) reinterpret_cast<v4f*>(dst)[i] = v4f{value, value, value, value};
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -600,8 +600,8 @@ extern "C" int riab_fill(void* dst, int64_t bytes, float value, riab_stream_t st
   if (!dst || bytes <= 0) return RIAB_EINVAL;
   if ((bytes & 15) || ((uintptr_t)dst & 15)) return RIAB_EALIGN;
   const int64_t n4 = bytes / 16;
-  int64_t blocks = (n4 + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  const int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 0x7fffffffLL) return RIAB_ETOOBIG;
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float*)dst, n4, value);
   return (int)hipGetLastError();
 }
