@@ -8,13 +8,16 @@
 // input rates and the output).  It runs on the fp32-input matrix cores,
 // v_mfma_f32_32x32x2_f32: exact fp32 (a k-ordered fmaf chain), 64 FLOP/clk/SIMD.
 //
-// Workgroup = 4 waves; block tile = up to 128 outputs x 128 positions; wave w owns positions
-// [32w, 32w+32) and all (<= 4) 32-row output tiles, so a B fragment read from LDS feeds 4 MFMAs.
-// K is walked in slabs of 32: the slab of W^T ([k][m], prepared on the host so that both
+// Workgroup = 4 waves; block tile = 32*MT outputs x 128 positions (MT = 4, 2 or 1 by layer width);
+// wave w owns positions [32w, 32w+32) and all MT 32-row output tiles, so a B fragment read from
+// LDS feeds MT MFMAs.
+// K is walked in double-buffered slabs of 16: the slab of W^T ([k][m], prepared on the host so that both
 // operands are read with unit stride) and of the input rates are staged in LDS by coalesced
 // 16-B loads.  Fragment layout (lane l): A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
 // C/D: column = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 // Epilogue: bias + activation (+ optional derivative) fused, 128-B row segments stored.
+#include <type_traits>
+
 #include "riab_device.h"
 
 namespace riab {
@@ -23,9 +26,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int FF_MAX_LAYERS = 8;
-constexpr int FF_KT = 32;    // K slab
+constexpr int FF_KT = 16;    // K slab
 constexpr int FF_NB = 128;   // positions per block
-constexpr int FF_MB = 128;   // outputs per block (4 MFMA row tiles)
 
 struct FFArgs {
   const float* rates[FF_MAX_LAYERS];  // [T][n_in][B]
@@ -42,114 +44,169 @@ struct FFArgs {
   float* out_prime;      // or null
 };
 
-// utils.activate (reference utils.py:919-1026); returns f(x), writes df/dx.
-__device__ __forceinline__ float activate(int act, float x, float p0, float p1, float p2, float p3, float* d) {
-  switch (act) {
-    case RIAB_ACT_LINEAR: *d = 1.0f; return x;
-    case RIAB_ACT_SIGMOID: {  // p0 max_fr, p1 min_fr, p2 mid_x, p3 beta = ln(19)/(width_x/2)
-      const float s = 1.0f / (1.0f + expf(-p3 * (x - p2)));
-      const float f = (p0 - p1) * s + p1;
-      *d = p3 * (f - p1) * (1.0f - (f - p1) / (p0 - p1));
-      return f;
-    }
-    case RIAB_ACT_RELU: {  // p0 gain, p1 threshold
-      *d = p0 * ((x - p1) > 0.0f ? 1.0f : 0.0f);
-      return p0 * fmaxf(0.0f, x - p1);
-    }
-    case RIAB_ACT_TANH: {  // the reference's derivative ignores the threshold (utils.py:998)
-      const float th = tanhf(x);
-      *d = p0 * (1.0f - th * th);
-      return p0 * tanhf(x - p1);
-    }
-    case RIAB_ACT_RETANH: {
-      const float th = tanhf(x);
-      *d = p0 * (1.0f - th * th) * ((x - p1) > 0.0f ? 1.0f : 0.0f);
-      return p0 * fmaxf(0.0f, tanhf(x - p1));
-    }
-    case RIAB_ACT_SOFTMAX: {  // "softmax" in the reference is softplus: gain*log(1+exp(x-thr))
-      const float z = x - p1;
-      *d = p0 / (1.0f + expf(-z));
-      return p0 * (z > 20.0f ? z : log1pf(expf(z)));
-    }
+// utils.activate (reference utils.py:919-1026); returns f(x), writes df/dx.  ACT is a template
+// parameter so that the 64-element epilogue of a lane is straight-line code.
+template <int ACT>
+__device__ __forceinline__ float activate(float x, float p0, float p1, float p2, float p3, float* d) {
+  if constexpr (ACT == RIAB_ACT_LINEAR) {
+    *d = 1.0f;
+    return x;
+  } else if constexpr (ACT == RIAB_ACT_SIGMOID) {  // p0 max_fr, p1 min_fr, p2 mid_x, p3 beta = ln(19)/(width_x/2)
+    const float s = 1.0f / (1.0f + expf(-p3 * (x - p2)));
+    const float f = (p0 - p1) * s + p1;
+    *d = p3 * (f - p1) * (1.0f - (f - p1) / (p0 - p1));
+    return f;
+  } else if constexpr (ACT == RIAB_ACT_RELU) {  // p0 gain, p1 threshold
+    *d = p0 * ((x - p1) > 0.0f ? 1.0f : 0.0f);
+    return p0 * fmaxf(0.0f, x - p1);
+  } else if constexpr (ACT == RIAB_ACT_TANH) {  // the reference's derivative ignores the threshold (utils.py:998)
+    const float th = tanhf(x);
+    *d = p0 * (1.0f - th * th);
+    return p0 * tanhf(x - p1);
+  } else if constexpr (ACT == RIAB_ACT_RETANH) {
+    const float th = tanhf(x);
+    *d = p0 * (1.0f - th * th) * ((x - p1) > 0.0f ? 1.0f : 0.0f);
+    return p0 * fmaxf(0.0f, tanhf(x - p1));
+  } else {  // RIAB_ACT_SOFTMAX: "softmax" in the reference is softplus, gain*log(1+exp(x-thr))
+    const float z = x - p1;
+    *d = p0 / (1.0f + expf(-z));
+    return p0 * (z > 20.0f ? z : log1pf(expf(z)));
   }
-  *d = 0.0f;
-  return 0.0f;
 }
 
+// One thread's share of a K slab: waves 0-1 fetch W^T, waves 2-3 the rates; a thread takes rows
+// k0 + 8g + 2s + kh (s = 0..3) x 4 consecutive columns.  Out-of-range rows / columns read a clamped
+// address (zeroed by the stash), so the fetch is branch-free (B and Mp are multiples of 4: a
+// float4 is either wholly inside or outside).
+struct FFSlab {
+  v4f v[4];
+};
+
+__device__ __forceinline__ FFSlab ff_fetch(const float* src, int64_t ld, int64_t col, int K, int kbase) {
+  FFSlab f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = kbase + 2 * s;
+    const int kc = k < K ? k : K - 1;
+    f.v[s] = *reinterpret_cast<const v4f*>(src + (int64_t)kc * ld + col);
+  }
+  return f;
+}
+
+// LDS slab layout [g][kh][column][s] (k = 8g + 2s + kh): the four k-steps a lane needs for one
+// column are one 16-B read, so a group of 4*MT MFMAs is fed by 1 + MT ds_read_b128.  Slabs are
+// double-buffered: the global loads of slab i+1 are in flight while slab i feeds the MFMAs.
+// 32 KB of LDS and < 170 registers per wave keep 3 workgroups (12 waves) on a CU, which is what hides
+// the stash / barrier of one workgroup and the store epilogue of another behind the MFMAs of the third.
+template <int MT>
 __global__ __launch_bounds__(256) void ff_kernel(const FFArgs a) {
-  __shared__ __align__(16) float s_a[FF_KT][FF_MB];  // W^T slab  [k][m]
-  __shared__ __align__(16) float s_b[FF_KT][FF_NB];  // rates slab [k][position]
+  __shared__ __align__(16) float s_a[2][FF_KT / 4][MT * 32][4];  // W^T slab, index [2g + kh]
+  __shared__ __align__(16) float s_b[2][FF_KT / 4][FF_NB][4];    // rates slab
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t b0 = (int64_t)blockIdx.x * FF_NB;  // first agent of the block's position tile
-  const int m0 = blockIdx.y * FF_MB;               // first output of the block
+  const int m0 = blockIdx.y * (MT * 32);           // first output of the block
   const int t = blockIdx.z;
-  const int mt_count = min(4, (a.Mp - m0) >> 5);   // 32-row output tiles in this block
-  v16f acc[4];
+  // bias rows of this block, read back through LDS in the epilogue: a global load there would make
+  // every s_waitcnt vmcnt also wait for the stores issued before it (one write round trip per row)
+  __shared__ float s_bias[MT * 32];
+  if (tid < MT * 32) s_bias[tid] = m0 + tid < a.n_out ? a.bias[m0 + tid] : 0.0f;
+  v16f acc[MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
+  // fetch role of this thread
+  const bool is_b = wave >= 2;                       // wave-uniform
+  const int c4 = (tid & 31) * 4, rg = (tid >> 5) & 3;  // rg = 2g + kh
+  const int krow = (rg >> 1) * 8 + (rg & 1);
+  const bool col_ok = is_b ? (b0 + c4 < a.B) : (c4 < MT * 32 && m0 + c4 < a.Mp);
+  const int64_t col = col_ok ? (is_b ? b0 + c4 : (int64_t)m0 + c4) : 0;
+  const int64_t ld = is_b ? a.B : (int64_t)a.Mp;
+  // columns are XOR-swizzled in LDS (physical = col ^ ((col >> 3) & 7)): the transposed 16-B writes of
+  // lanes 4 columns apart and the fragment reads of consecutive columns are both bank-conflict free
+  const int sw = (c4 >> 3) & 7;
+  float* const s_dst = is_b ? &s_b[0][rg][0][0] : &s_a[0][rg][0][0];
+  const int buf_stride = is_b ? (FF_KT / 4) * FF_NB * 4 : (FF_KT / 4) * MT * 32 * 4;
+  // 4x4 register transpose [s][column] -> [column][s]; rows >= K and columns outside the problem become 0
+  auto stash = [&](const FFSlab& f, int buf, int K, int k0) {
+    if (!is_b && c4 >= MT * 32) return;
+    v4f v[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = (col_ok && k0 + krow + 2 * s < K) ? f.v[s] : v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<v4f*>(s_dst + buf * buf_stride + ((c4 + i) ^ sw) * 4) = v4f{v[0][i], v[1][i], v[2][i], v[3][i]};
+  };
+  const int kh = lane >> 5, j = lane & 31;
+  const int jb = (wave * 32 + j) ^ (((wave * 32 + j) >> 3) & 7);
+  int ja[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) ja[mt] = (mt * 32 + j) ^ (((mt * 32 + j) >> 3) & 7);
+  int buf = 0;
   for (int l = 0; l < a.n_layers; ++l) {
     const int K = a.n_in[l];
-    const float* rates = a.rates[l] + (int64_t)t * K * a.B;
-    const float* wt = a.wt[l];
+    const float* src = is_b ? a.rates[l] + (int64_t)t * K * a.B : a.wt[l];
+    __syncthreads();  // the previous layer's last slab has been consumed
+    stash(ff_fetch(src, ld, col, K, krow), buf, K, 0);
+    __syncthreads();
     for (int k0 = 0; k0 < K; k0 += FF_KT) {
-      __syncthreads();
-      // stage: 32 x 128 floats each = 1024 float4; 256 threads x 4 passes
+      const bool more = k0 + FF_KT < K;  // block-uniform
+      FFSlab nxt;
+      if (more) nxt = ff_fetch(src, ld, col, K, k0 + FF_KT + krow);
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int idx = pass * 256 + tid;  // float4 index
-        const int kk = idx >> 5, c4 = (idx & 31) * 4;
-        const int k = k0 + kk;
-        v4f va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-        if (k < K) {
-          if (m0 + c4 < a.Mp) va = *reinterpret_cast<const v4f*>(wt + (int64_t)k * a.Mp + m0 + c4);
-          const int64_t b = b0 + c4;
-          if (b + 3 < a.B) vb = *reinterpret_cast<const v4f*>(rates + (int64_t)k * a.B + b);
-          else if (b < a.B) {
-            vb.x = rates[(int64_t)k * a.B + b];
-            if (b + 1 < a.B) vb.y = rates[(int64_t)k * a.B + b + 1];
-            if (b + 2 < a.B) vb.z = rates[(int64_t)k * a.B + b + 2];
-          }
-        }
-        *reinterpret_cast<v4f*>(&s_a[kk][c4]) = va;
-        *reinterpret_cast<v4f*>(&s_b[kk][c4]) = vb;
+      for (int g = 0; g < FF_KT / 8; ++g) {
+        const v4f bq = *reinterpret_cast<const v4f*>(&s_b[buf][2 * g + kh][jb][0]);
+        v4f aq[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) aq[mt] = *reinterpret_cast<const v4f*>(&s_a[buf][2 * g + kh][ja[mt]][0]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[mt][s], bq[s], acc[mt], 0, 0, 0);
       }
-      __syncthreads();
-      const int kh = lane >> 5, j = lane & 31;
-#pragma unroll 4
-      for (int kk = 0; kk < FF_KT; kk += 2) {
-        const float bf = s_b[kk + kh][wave * 32 + j];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          if (mt < mt_count) {  // wave-uniform
-            const float af = s_a[kk + kh][mt * 32 + j];
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[mt], 0, 0, 0);
-          }
-        }
+      if (more) {
+        stash(nxt, buf ^ 1, K, k0 + FF_KT);  // the other buffer was last read one iteration ago (barrier below)
+        __syncthreads();
+        buf ^= 1;
       }
     }
   }
   // ---- epilogue: bias + activation, C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int64_t b = b0 + wave * 32 + (lane & 31);
   if (b < a.B) {
+    const int row0 = 4 * (lane >> 5);
+    const int64_t off0 = ((int64_t)t * a.n_out + m0 + row0) * a.B + b;
+    const int rows_left = a.n_out - m0 - row0;  // rows ml (relative to row0) < rows_left are real outputs
+    auto store_tiles = [&](auto act_tag, auto prime_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
+      constexpr bool PRIME = decltype(prime_tag)::value;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      if (mt < mt_count) {
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < a.n_out) {
+          const int ml = mt * 32 + (r & 3) + 8 * (r >> 2);  // compile-time
+          if (ml < rows_left) {
             float d;
-            const float f = activate(a.act, acc[mt][r] + a.bias[m], a.p0, a.p1, a.p2, a.p3, &d);
-            const int64_t off = ((int64_t)t * a.n_out + m) * a.B + b;
-            a.out[off] = f;
-            if (a.out_prime) a.out_prime[off] = d;
+            const float f = activate<ACT>(acc[mt][r] + s_bias[ml + row0], a.p0, a.p1, a.p2, a.p3, &d);
+            a.out[off0 + (int64_t)ml * a.B] = f;
+            if (PRIME) a.out_prime[off0 + (int64_t)ml * a.B] = d;
           }
         }
       }
+    };
+    auto with_act = [&](auto act_tag) {
+      if (a.out_prime) store_tiles(act_tag, std::true_type{});
+      else store_tiles(act_tag, std::false_type{});
+    };
+    switch (a.act) {  // block-uniform
+      case RIAB_ACT_LINEAR: with_act(std::integral_constant<int, RIAB_ACT_LINEAR>{}); break;
+      case RIAB_ACT_SIGMOID: with_act(std::integral_constant<int, RIAB_ACT_SIGMOID>{}); break;
+      case RIAB_ACT_RELU: with_act(std::integral_constant<int, RIAB_ACT_RELU>{}); break;
+      case RIAB_ACT_TANH: with_act(std::integral_constant<int, RIAB_ACT_TANH>{}); break;
+      case RIAB_ACT_RETANH: with_act(std::integral_constant<int, RIAB_ACT_RETANH>{}); break;
+      default: with_act(std::integral_constant<int, RIAB_ACT_SOFTMAX>{}); break;
     }
   }
 }
@@ -186,7 +243,11 @@ extern "C" int riab_feedforward(const RiabFFInput* inputs, int32_t n_inputs, con
   a.p3 = act_params[3];
   a.out = out;
   a.out_prime = out_prime;
-  const dim3 grid((unsigned)((B + FF_NB - 1) / FF_NB), (unsigned)((a.Mp + FF_MB - 1) / FF_MB), (unsigned)T);
-  hipLaunchKernelGGL(ff_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  // outputs per block: 128 (4 MFMA row tiles), 64 or 32 for narrow layers
+  const int mt = a.Mp >= 128 ? 4 : (a.Mp >= 64 ? 2 : 1);
+  const dim3 grid((unsigned)((B + FF_NB - 1) / FF_NB), (unsigned)((a.Mp + mt * 32 - 1) / (mt * 32)), (unsigned)T);
+  if (mt == 4) hipLaunchKernelGGL(ff_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (mt == 2) hipLaunchKernelGGL(ff_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(ff_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
