@@ -317,6 +317,90 @@ uint64_t riab_plan_step_index(const RiabPlan* plan);
  * history chunk has fewer than n_steps free rows. */
 int riab_plan_step(RiabPlan* plan, int32_t n_steps, riab_stream_t stream);
 
+/* ---- batched TaskEnvironment (contribs/TaskEnvironment.py) ------------------------------------
+ * The closed-loop caller of the path: `TaskEnvironment.step(actions)` = Agent.update(drift_velocity
+ * = action) [riab_agent_step / riab_plan_step], then the task bookkeeping of
+ * contribs/TaskEnvironment.py:410-449: reward caches decay (RewardCache.update :913-927,
+ * Reward.update :804-821), the clock advances (:358), goals are checked and consumed
+ * (GoalCache.check :1076-1152, SpatialGoal.check :1337-1360 with the line-of-sight distance of
+ * Environment.py:677-779, TimeElapsedGoal.check :1271-1278), the termination delay is appended
+ * (:420-434) and rewards are totalled (RewardCache.get_total :929-939).
+ *
+ * Batched semantics: every lane (agent of the batch) is an independent single-agent replica of the
+ * reference's TaskEnvironment sharing one goal pool and one clock; lanes shard over GPUs like agents
+ * do.  riab_task_step is that bookkeeping for all lanes in one launch; riab_task_reset is
+ * TaskEnvironment.reset (:307-351, GoalCache.reset :1218-1252) for the lanes selected by a mask.
+ *
+ * Per-lane task state: device float64 [RIAB_TS_ROWS][B], lane axis fastest (small integers are
+ * stored as doubles so that the whole state is one tensor). */
+#define RIAB_TASK_MAX_GOALS 16   /* goals in one episode's list, incl. the termination-delay goal */
+#define RIAB_TASK_MAX_REWARDS 16 /* simultaneously active rewards of one lane */
+#define RIAB_TASK_MAX_POOL 64    /* goals in the pool the episodes draw from */
+enum {
+  RIAB_TS_N_GOALS = 0,        /* length of the lane's goal list */
+  RIAB_TS_DELAYED = 1,        /* episode_state["delayed_term"] */
+  RIAB_TS_PAD_START = 2,      /* TimeElapsedGoal.start_time of the termination-delay goal */
+  RIAB_TS_N_REWARDS = 3,      /* length of the lane's RewardCache.cache */
+  RIAB_TS_EPISODE = 4,        /* TaskEnvironment.episode */
+  RIAB_TS_EP_START = 5,       /* episodes["start"][-1] */
+  RIAB_TS_EP_ANY_ENDED = 6,   /* an episode of non-zero duration has ended before */
+  RIAB_TS_STEPS_ACTIVE = 7,   /* RewardCache.stats total_steps_active / total_steps_inactive, max, min */
+  RIAB_TS_STEPS_INACTIVE = 8,
+  RIAB_TS_R_MAX = 9,
+  RIAB_TS_R_MIN = 10,
+  RIAB_TS_STARTED = 11,       /* len(episodes["start"]) > 0 */
+  RIAB_TS_GOAL_LIST = 12,     /* [MAX_GOALS] pool index of list entry i; RIAB_GOAL_TIME_ELAPSED = delay goal */
+  RIAB_TS_RW_STATE = 28,      /* [MAX_REWARDS] Reward.state, in cache (append) order */
+  RIAB_TS_RW_EXPIRE = 44,     /* [MAX_REWARDS] Reward.expire_clock */
+  RIAB_TS_RW_SRC = 60,        /* [MAX_REWARDS] pool index of the goal that gave it (decay parameters) */
+  RIAB_TS_ROWS = 76
+};
+#define RIAB_GOAL_TIME_ELAPSED (-2)
+/* goal pool row (float64 x 8): x, y, radius, then the goal's Reward: init_state, dt, expire_clock,
+ * decay preset (RIAB_DECAY_*), decay knob (Reward.decay_preset / decay_knobs_preset, :732-743) */
+#define RIAB_GOAL_COLS 8
+enum { RIAB_DECAY_CONSTANT = 0, RIAB_DECAY_LINEAR = 1, RIAB_DECAY_EXPONENTIAL = 2, RIAB_DECAY_NONE = 3 };
+enum { RIAB_GOALORDER_NONSEQUENTIAL = 0, RIAB_GOALORDER_SEQUENTIAL = 1 };
+/* task diagnostics (int32 counters, device, [4]) */
+enum { RIAB_TD_REWARD_OVERFLOW = 0, RIAB_TD_LATE_COMPLETIONS = 1, RIAB_TD_EPLOG_OVERFLOW = 2, RIAB_TD_RESETS = 3 };
+
+typedef struct RiabTask {
+  const double* goals;         /* device float64 [n_pool][RIAB_GOAL_COLS] */
+  int32_t n_pool;
+  int32_t goalorder;           /* RIAB_GOALORDER_* (GoalCache.goalorder) */
+  double terminate_delay;      /* episode_terminate_delay (seconds; 0 = none) */
+  double pad_reward[5];        /* no_reward_default (:949-951): init_state, dt, expire_clock, preset, knob */
+  double default_reward_level; /* RewardCache.default_reward_level */
+} RiabTask;
+
+/* One TaskEnvironment.step after the agents have moved.  pos_x / pos_y: device float64 [B] (rows
+ * RIAB_S_POS_X / RIAB_S_POS_Y of the agent state); t_env: the clock AFTER `self.t += self.dt`.
+ * reward_out float64 [B] = RewardCache.get_total(); terminal_out uint8 [B].  Each lane runs the
+ * goal check passes of one reference step (two, three when the termination delay is appended) with
+ * the reference's list semantics (index skipped after a pop, :1130-1141; reward skipped after an
+ * expiry, :919-922).  terminal_out is "no goals left" after the last pass; the reference returns
+ * the value after the first (it differs only when a later pass of the same step completes further
+ * goals — counted in diag[RIAB_TD_LATE_COMPLETIONS]; the reference then errors on its next step). */
+int riab_task_step(const RiabEnv* env, const RiabTask* task, double* task_state, const double* pos_x,
+                   const double* pos_y, int64_t B, double t_env, double* reward_out, uint8_t* terminal_out,
+                   int32_t* diag, riab_stream_t stream);
+
+/* TaskEnvironment.reset for the lanes with mask[b] != 0 (mask NULL = every lane): the running
+ * episode is closed (appended to ep_log when given: float64 [cap][5] = global lane id, episode,
+ * start, end, duration; ep_count int32 device counter), the episode counter advances unless the
+ * closed episode had zero duration (:333-337), the goal list is refilled with n_select goals of
+ * the pool — the first n_select when `ordered` (reset_orders_goal), otherwise a uniform sample
+ * without replacement from Philox(seed; counter, global lane id) — and, when `teleport`, the
+ * lane's position (pos_x / pos_y: rows RIAB_S_POS_X / _Y of the agent state; hist_x / hist_y: rows
+ * RIAB_H_POS_X / _Y of the newest float32 history record, or NULL) is set to (new_x, new_y)[b] or,
+ * when those are NULL, drawn as Environment.sample_positions(1) does for a square box: centre +
+ * U(-0.45, 0.45) * scale per axis (Environment.py:560-633).  All per-lane arrays hold B entries. */
+int riab_task_reset(const RiabEnv* env, const RiabTask* task, double* task_state, const uint8_t* mask, int64_t B,
+                    int64_t agent_id0, double t_env, int32_t n_select, int32_t ordered, uint64_t seed,
+                    uint64_t counter, int32_t teleport, const double* new_x, const double* new_y, double* pos_x,
+                    double* pos_y, float* hist_x, float* hist_y, double* ep_log, int64_t ep_log_cap,
+                    int32_t* ep_count, int32_t* diag, riab_stream_t stream);
+
 /* Streaming-store calibration kernel: writes `bytes` bytes (multiple of 16) of
  * a constant with the same 16-B/lane store pattern as the rate kernels.  Used
  * to calibrate the WRITE_SIZE counter and to measure the store roofline. */

@@ -714,3 +714,161 @@ def spike_uniforms(seed, step, pop_id, n_cells, n_agents, agent_id0=0):
                        seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     u = np.stack([(x >> np.uint32(8)).astype(np.float32) * np.float32(2.0**-24) for x in xs], axis=-1)
     return u.reshape(n_cells, n_agents)
+
+
+# --------------------------------------------------------------------------------------------------
+# TaskEnvironment bookkeeping (reference contribs/TaskEnvironment.py), one single-agent replica
+# --------------------------------------------------------------------------------------------------
+DECAY_CONSTANT, DECAY_LINEAR, DECAY_EXPONENTIAL, DECAY_NONE = 0, 1, 2, 3
+GOAL_TIME_ELAPSED = -2
+# no_reward_default (TaskEnvironment.py:949-951): (init_state, dt, expire_clock, preset, knob)
+PAD_REWARD = (0.0, 0.01, 0.1, DECAY_NONE, 0.0)
+
+
+def reward_delta(preset, knob, state):
+    """Reward.get_delta without external drive (TaskEnvironment.py:823-832) for the decay presets
+    of :732-737 (`partial(preset, *knobs)`: the knob is the first argument, the state the second)."""
+    if preset == DECAY_CONSTANT:
+        return -knob
+    if preset == DECAY_LINEAR:
+        return -(knob * state)
+    if preset == DECAY_EXPONENTIAL:
+        return -(knob * np.exp(state))
+    return -0.0
+
+
+class TaskLane:
+    """One agent's view of a TaskEnvironment in which it is the only agent: goal list, reward
+    cache and episode counters, stepped exactly as TaskEnvironment.step does after Agent.update
+    (TaskEnvironment.py:410-449).  `goals`: rows (x, y, radius, reward init_state, reward dt,
+    reward expire_clock, decay preset, decay knob)."""
+
+    def __init__(self, env, goals, goalorder="nonsequential", terminate_delay=0.0, default_reward_level=0.0):
+        self.env = env
+        self.goals = np.asarray(goals, dtype=np.float64).reshape(-1, 8)
+        self.sequential = goalorder == "sequential"
+        self.terminate_delay = float(terminate_delay)
+        self.default_level = float(default_reward_level)
+        self.goal_list = []          # pool indices (GOAL_TIME_ELAPSED = the termination-delay goal)
+        self.pad_start = 0.0
+        self.delayed = False
+        self.rewards = []            # [state, expire_clock, source goal], in append order
+        self.episode = 0
+        self.ep_start = 0.0
+        self.started = False
+        self.any_ended = False
+        self.finished = []           # (episode, start, end, duration)
+        self.late_completions = 0
+
+    def _reward_template(self, src):
+        return PAD_REWARD if src == GOAL_TIME_ELAPSED else tuple(self.goals[src, 3:8])
+
+    def _met(self, src, pos, t_env):
+        if src == GOAL_TIME_ELAPSED:  # TimeElapsedGoal.check (:1271-1278)
+            return t_env - self.pad_start >= self.terminate_delay
+        g = self.goals[src]           # SpatialGoal._in_goal_radius (:1319-1332)
+        d = env_distances(self.env, np.asarray(pos, float).reshape(1, 2), g[None, 0:2], "line_of_sight")
+        return bool((d < g[2]).all())
+
+    def _award(self, src):            # RewardCache.append (:902-911): a copy of the goal's reward
+        tpl = self._reward_template(src)
+        self.rewards.append([float(tpl[0]), float(tpl[2]), src])
+
+    def _check_pass(self, pos, t_env):
+        """GoalCache.check(remove_finished=True) (:1076-1152) for the lane; returns goals consumed."""
+        done = 0
+        if not self.goal_list:
+            return 0
+        if self.sequential:           # `this` is always the head: pop() rewinds the marker (:1161-1163)
+            if self._met(self.goal_list[0], pos, t_env):
+                self._award(self.goal_list[0])
+                del self.goal_list[0]
+                done = 1
+            return done
+        g = 0
+        while g < len(self.goal_list):
+            if self._met(self.goal_list[g], pos, t_env):
+                self._award(self.goal_list[g])
+                del self.goal_list[g]
+                done += 1
+            g += 1                    # also after a pop (:1141): the goal that slid into slot g waits
+        return done
+
+    def step(self, pos, t_env):
+        """-> (reward total, terminal).  `t_env` is the clock after `self.t += self.dt`."""
+        # RewardCache.update (:913-927) with the remove-while-iterating skip
+        i = 0
+        while i < len(self.rewards):
+            state, expire, src = self.rewards[i]
+            tpl = self._reward_template(src)
+            rdt = float(tpl[1])
+            state = state + reward_delta(int(tpl[3]), float(tpl[4]), state) * rdt
+            expire = expire - rdt
+            if expire <= 0:
+                del self.rewards[i]
+            else:
+                self.rewards[i] = [state, expire, src]
+            i += 1
+        self._check_pass(pos, t_env)
+        terminal = len(self.goal_list) == 0
+        if terminal and self.terminate_delay and not self.delayed:  # :421-434
+            self.delayed = True
+            self.pad_start = t_env
+            self.goal_list.append(GOAL_TIME_ELAPSED)
+            self._check_pass(pos, t_env)
+            terminal = len(self.goal_list) == 0
+        late = self._check_pass(pos, t_env)                            # :438
+        terminal_last = len(self.goal_list) == 0
+        if late and terminal_last and not terminal:
+            self.late_completions += 1
+        total = 0.0
+        for r in self.rewards:        # python sum(), left to right from 0 (:933)
+            total = total + r[0]
+        total = total + self.default_level
+        return total, terminal_last
+
+    def reset(self, t_env, selected):
+        """TaskEnvironment.reset (:307-351) with the goal selection given (`selected` pool indices)."""
+        zero = False
+        if self.started:
+            duration = t_env - self.ep_start
+            zero = duration == 0
+            if not zero:
+                self.any_ended = True
+                self.finished.append((self.episode, self.ep_start, t_env, duration))
+        if not zero:
+            self.episode += 1
+        self.started = True
+        self.ep_start = t_env if self.any_ended else 0.0
+        self.goal_list = [int(s) for s in selected]
+        self.delayed = False
+
+
+def task_reset_draws(seed, counter, lane_id, n_pool, n_select):
+    """The production goal selection of riab_task_reset: partial Fisher-Yates driven by Philox
+    (draw i = word i%4 of block 1 + i//4, j = i + floor(w * (n_pool - i) / 2^32))."""
+    TAG = 0x5441534B
+    perm = list(range(n_pool))
+    out = []
+    words = None
+    for i in range(min(n_select, n_pool)):
+        if i % 4 == 0:
+            words = philox4x32_10(counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF, lane_id & 0xFFFFFFFF,
+                                  (TAG + 1 + i // 4) & 0xFFFFFFFF, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        w = int(words[i % 4])
+        j = i + ((w * (n_pool - i)) >> 32)
+        perm[i], perm[j] = perm[j], perm[i]
+        out.append(perm[i])
+    return out
+
+
+def task_teleport_draw(seed, counter, lane_id, env):
+    """Teleport position of riab_task_reset (block 0 of the same Philox stream)."""
+    TAG = 0x5441534B
+    w = philox4x32_10(counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF, lane_id & 0xFFFFFFFF, TAG,
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    e = env.extent
+    cx, cy = 0.5 * (e[0] + e[1]), 0.5 * (e[2] + e[3])
+    half = 0.45 * np.sqrt((e[1] - e[0]) * (e[3] - e[2]))
+    ux, uy = (int(w[0]) + 0.5) * 2.0 ** -32, (int(w[1]) + 0.5) * 2.0 ** -32
+    return np.array([cx + (2 * ux - 1) * half, cy + (2 * uy - 1) * half])

@@ -61,6 +61,21 @@ class RiabPopulation(C.Structure):
                 ("object_types", C.c_void_p), ("n_objects", C.c_int32), ("walls_occlude", C.c_int32)]
 
 
+class RiabTask(C.Structure):
+    _fields_ = [("goals", C.c_void_p), ("n_pool", C.c_int32), ("goalorder", C.c_int32), ("terminate_delay", C.c_double),
+                ("pad_reward", C.c_double * 5), ("default_reward_level", C.c_double)]
+
+
+# rows of the per-lane task state tensor (include/riab_hip.h RIAB_TS_*)
+TS_N_GOALS, TS_DELAYED, TS_PAD_START, TS_N_REWARDS, TS_EPISODE, TS_EP_START, TS_EP_ANY_ENDED = range(7)
+TS_STEPS_ACTIVE, TS_STEPS_INACTIVE, TS_R_MAX, TS_R_MIN, TS_STARTED = 7, 8, 9, 10, 11
+TS_GOAL_LIST, TS_RW_STATE, TS_RW_EXPIRE, TS_RW_SRC, TS_ROWS = 12, 28, 44, 60, 76
+TASK_MAX_GOALS, TASK_MAX_REWARDS, TASK_MAX_POOL = 16, 16, 64
+GOAL_TIME_ELAPSED = -2
+DECAYS = {"constant": 0, "linear": 1, "exponential": 2, "none": 3}
+GOALORDERS = {"nonsequential": 0, "sequential": 1}
+TD_REWARD_OVERFLOW, TD_LATE_COMPLETIONS, TD_EPLOG_OVERFLOW, TD_RESETS = range(4)
+
 POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4}
 EFULL = -5
 
@@ -96,6 +111,12 @@ PROTOTYPES = {
     "riab_plan_rows_free": (C.c_int64, [C.c_void_p]),
     "riab_plan_step_index": (C.c_uint64, [C.c_void_p]),
     "riab_plan_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "riab_task_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "riab_task_reset": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                  C.c_double, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_abi_version": (C.c_int, []),
     "riab_strerror": (C.c_char_p, [C.c_int]),
 }

@@ -492,8 +492,120 @@ def make_ovc():
     np.savez_compressed(os.path.join(HERE, "ovc.npz"), **out)
 
 
+def make_task():
+    """TaskEnvironment.step / reset (contribs/TaskEnvironment.py): single-agent replicas of a
+    SpatialGoalEnvironment, one per lane, driven towards their goals; per step the action, the two
+    OU normals, the resulting position, reward total, terminal flag and goal / reward cache sizes."""
+    from ratinabox.contribs.TaskEnvironment import (SpatialGoalEnvironment, SpatialGoal, Reward, get_goal_vector)
+    print("task environment")
+    presets = {"constant": 0, "linear": 1, "exponential": 2, "none": 3}
+    scenarios = {
+        # name: (env params, goal positions, radius, rewards per goal (None = reward_default), goalcachekws,
+        #        terminate delay, teleport, n lanes, n steps, speed factor)
+        "open_nonseq": ({}, [[0.2, 0.25], [0.8, 0.7], [0.5, 0.1]], None, None,
+                        dict(reset_n_goals=2, reset_orders_goal=True, goalorder="nonsequential", agentmode="noninteract"),
+                        0.0, False, 8, 500, 11.0),
+        # the first goal sits behind a wall for lanes that start on the right: inside the radius, no line of sight
+        "wall_seq_delay": ({"walls": [[[0.5, 0.0], [0.5, 0.6]]]}, [[0.45, 0.3], [0.25, 0.8], [0.75, 0.8]], 0.12,
+                           [dict(init_state=2.0, expire_clock=0.3, decay="constant", decay_knobs=[0.5]),
+                            dict(init_state=1.0, expire_clock=0.5, decay="exponential", decay_knobs=[0.2]),
+                            dict(init_state=-1.0, expire_clock=0.5, decay="linear", decay_knobs=[6], dt=0.02)],
+                           dict(reset_n_goals=3, reset_orders_goal=True, goalorder="sequential", agentmode="interact"),
+                           0.05, False, 10, 700, 11.0),
+        # two goals met on the same step: the second is consumed by the second pass of that step
+        "overlap_pair": ({}, [[0.5, 0.5], [0.52, 0.5]], 0.12, None,
+                         dict(reset_n_goals=2, reset_orders_goal=True, goalorder="nonsequential", agentmode="noninteract"),
+                         0.0, True, 4, 300, 11.0),
+        # overlapping goals: several are met on the same step (list-index skip, late completions)
+        "overlap_teleport": ({}, [[0.5, 0.5], [0.52, 0.5], [0.5, 0.53], [0.2, 0.8]], 0.12, None,
+                             dict(reset_n_goals=4, reset_orders_goal=True, goalorder="nonsequential", agentmode="interact"),
+                             0.03, True, 8, 400, 14.0),
+    }
+    for name, (envp, gpos, radius, rewards, gckws, delay, teleport, n_lanes, n_steps, speed) in scenarios.items():
+        rec = {k: [] for k in ("action", "z", "pos", "reward", "terminal", "goals_left", "n_rewards", "reset",
+                               "teleport_pos", "pos0", "state0", "late", "episodes")}
+        goal_table = None
+        for lane in range(n_lanes):
+            np.random.seed(1000 + 17 * lane)
+            env = SpatialGoalEnvironment(params=dict(envp), possible_goal_positions=np.array(gpos), render_mode="none",
+                                         goalcachekws=dict(gckws), episode_terminate_delay=delay,
+                                         teleport_on_reset=teleport, goalkws=({} if radius is None else {"goal_radius": radius}))
+            pool = env.goal_cache.reset_goals
+            if rewards is not None:
+                for g, rw in zip(pool, rewards):
+                    if rw is not None:
+                        g.reward = Reward(**dict({"dt": 0.01}, **rw))
+                        g.reward.goal = g
+            goal_table = np.array([[g.pos[0], g.pos[1], g.radius, g.reward.state, g.reward.dt, g.reward.expire_clock,
+                                    presets[g.reward.preset], g.reward.decay_knobs[0]] for g in pool], float)
+            Ag = Agent(env, {"dt": 0.01})
+            env.add_agents(Ag)
+            rec["state0"].append(np.concatenate([np.ravel(x) for x in _get_state(Ag)]))
+            L = {k: [] for k in ("action", "z", "pos", "reward", "terminal", "goals_left", "n_rewards", "reset",
+                                 "teleport_pos", "late")}
+            _capture["on"] = True
+            for t in range(n_steps):
+                # policy (input data only): head for the first pending goal (sequential) / the nearest one
+                pend = [g.pos for g in env.goal_cache.goals[Ag.name] if isinstance(g, SpatialGoal)]
+                if not pend:
+                    v = np.zeros(2)
+                elif gckws["goalorder"] == "sequential":
+                    v = pend[0] - Ag.pos
+                else:
+                    v = min((p_ - Ag.pos for p_ in pend), key=np.linalg.norm)
+                nv = np.linalg.norm(v)
+                action = speed * Ag.speed_mean * (v / nv) if nv > 0 else np.array([np.nan, np.nan])
+                _rec["normal"].clear()
+                active_before = len(env.agents) > 0
+                if not active_before:  # the reference would raise (TaskEnvironment.py:384-391)
+                    raise RuntimeError("inactive agent stepped")
+                obs, rew, term, trunc, info = env.step({Ag.name: np.array(action)})
+                scal = [z for shp, z in _rec["normal"] if shp == ()]
+                assert len(scal) == 2, len(scal)
+                left = len(env.goal_cache.goals[Ag.name])
+                late = (left == 0) and not term[Ag.name]
+                L["action"].append(action)
+                L["z"].append([float(scal[0]), float(scal[1])])
+                L["pos"].append(np.array(Ag.pos, float))
+                L["reward"].append(float(rew[Ag.name]))
+                L["terminal"].append(bool(term[Ag.name]))
+                L["goals_left"].append(left)
+                L["n_rewards"].append(len(Ag.reward.cache))
+                L["late"].append(bool(late))
+                if left == 0:  # (reset also after a late completion: the reference's next step would raise)
+                    _capture["on"] = False
+                    env.reset()
+                    _capture["on"] = True
+                    L["reset"].append(True)
+                    L["teleport_pos"].append(np.array(Ag.pos, float))
+                else:
+                    L["reset"].append(False)
+                    L["teleport_pos"].append(np.array([np.nan, np.nan]))
+            _capture["on"] = False
+            for k in L:
+                rec[k].append(np.array(L[k]))
+            ep = env.episodes
+            rec["episodes"].append(np.array([[e, s, en, d] for e, s, en, d in
+                                             zip(ep["episode"], ep["start"], ep["end"], ep["duration"])], float).reshape(-1, 4))
+            rec["pos0"].append(rec["state0"][-1][0:2])
+        out = {k: np.array(v) for k, v in rec.items() if k != "episodes"}
+        n_ep = max(len(e) for e in rec["episodes"])
+        eps = np.full((n_lanes, n_ep, 4), np.nan)
+        for i, e in enumerate(rec["episodes"]):
+            eps[i, :len(e)] = e
+        out.update(episodes=eps, goal_table=goal_table, user_walls=np.array(envp.get("walls", []), float).reshape(-1, 2, 2),
+                   env_bc=str(envp.get("boundary_conditions", "solid")), goalorder=str(gckws["goalorder"]),
+                   reset_n_goals=int(gckws["reset_n_goals"]), terminate_delay=float(delay), teleport=bool(teleport),
+                   dt=0.01, final_episode=np.array([0]))
+        print(f"  {name}: {n_lanes} lanes x {n_steps} steps, resets {int(out['reset'].sum())}, "
+              f"late completions {int(out['late'].sum())}, max rewards in cache {int(out['n_rewards'].max())}")
+        np.savez_compressed(os.path.join(HERE, f"task_{name}.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "task"]
+    if "task" in which:
+        make_task()
     if "ovc" in which:
         make_ovc()
     if "feedforward" in which:

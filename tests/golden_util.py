@@ -45,3 +45,5 @@ FF_ACTS = {"linear": {"activation": "linear"},
            "tanh": {"activation": "tanh", "gain": 1.5, "threshold": -0.2},
            "retanh": {"activation": "retanh", "gain": 1.2, "threshold": 0.05},
            "softmax": {"activation": "softmax", "gain": 0.7, "threshold": 0.3}}
+
+TASK_FILES = sorted(f for f in os.listdir(GOLDEN) if f.startswith("task_") and f.endswith(".npz"))

@@ -1,0 +1,198 @@
+"""GPU parity tests of the batched TaskEnvironment (run with `-m gpu`): `step` / `reset` through the
+Python classes and hence riab_task_step / riab_task_reset, against golden vectors produced by the
+reference's own TaskEnvironment (one single-agent reference run per lane; tests/golden/task_*.npz)
+and against the oracle's TaskLane restatement.
+
+Tolerances: positions 1e-9 relative (float64 motion); reward totals bit-exact (float64 recursions
+with the reference's operation order) except the "exponential" decay preset, which goes through the
+device exp (<= 1 ulp: 1e-14 relative); terminal flags, goal counts, reward-cache sizes, episode
+tables: exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import riab_oracle as orc
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def riab():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    import ratinabox_amd
+    return ratinabox_amd
+
+
+def _build(riab, g, n_agents=None, teleport=None, **envkw):
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment, SpatialGoal, Reward
+    presets = {v: k for k, v in riab._lib.DECAYS.items()}
+    env = SpatialGoalEnvironment(params={"walls": g["user_walls"].tolist()}, possible_goals=[], render_mode="none",
+                                 goalcachekws=dict(reset_n_goals=int(g["reset_n_goals"]), reset_orders_goal=True,
+                                                   goalorder=str(g["goalorder"])),
+                                 episode_terminate_delay=float(g["terminate_delay"]),
+                                 teleport_on_reset=bool(g["teleport"]) if teleport is None else teleport, **envkw)
+    env.goal_cache.reset_goals = [
+        SpatialGoal(env, pos=row[0:2], goal_radius=row[2],
+                    reward=Reward(row[3], dt=row[4], expire_clock=float(row[5]), decay=presets[int(row[6])], decay_knobs=[row[7]]))
+        for row in g["goal_table"]]
+    B = g["pos"].shape[0] if n_agents is None else n_agents
+    Ag = riab.Agent(env, {"dt": float(g["dt"]), "n_agents": B})
+    return env, Ag
+
+
+@pytest.mark.parametrize("fname", gu.TASK_FILES)
+def test_task_environment_vs_reference(riab, fname):
+    """Closed loop, every lane = one reference run: same actions and OU normals in, positions,
+    rewards, terminal flags, cache sizes and episodes out."""
+    g = gu.load(fname)
+    env, Ag = _build(riab, g)
+    B, T = g["pos"].shape[:2]
+    env.add_agents(Ag)          # (resets, and teleports when teleport_on_reset: the recorded state is from after it)
+    for k, s in gu.PRE_SLICES.items():
+        setattr(Ag, k, g["state0"][:, s])
+    L = riab._lib
+    exact = not np.any(g["goal_table"][:, 6] == L.DECAYS["exponential"])
+    for k in range(T):
+        obs, rew, term, trunc, info = env.step(g["action"][:, k], agent_kwargs={"noise": g["z"][:, k].T})
+        np.testing.assert_allclose(obs.cpu().numpy(), g["pos"][:, k], rtol=1e-9, atol=1e-12, err_msg=f"step {k}")
+        r = rew.cpu().numpy()
+        if exact:
+            assert np.array_equal(r, g["reward"][:, k]), (k, r, g["reward"][:, k])
+        else:
+            np.testing.assert_allclose(r, g["reward"][:, k], rtol=1e-14, atol=0)
+        term = term.cpu().numpy()
+        assert np.array_equal(term, g["goals_left"][:, k] == 0), k
+        ok = ~g["late"][:, k]
+        assert np.array_equal(term[ok], g["terminal"][ok, k]), k  # where the reference's first-pass flag applies
+        assert np.array_equal(env.goals_left.cpu().numpy(), g["goals_left"][:, k]), k
+        assert np.array_equal(Ag.reward.active()[2].cpu().numpy(), g["n_rewards"][:, k]), k
+        assert not trunc.any()
+        if g["reset"][:, k].any():
+            assert np.array_equal(g["reset"][:, k], term)
+            env.reset(mask=term, positions=np.nan_to_num(g["teleport_pos"][:, k]) if bool(g["teleport"]) else None)
+    d = env.diagnostics
+    assert d["reward_overflow"] == 0 and d["episode_log_overflow"] == 0
+    assert d["late_completions"] == int(g["late"].sum())
+    ep = env.episodes
+    for lane in range(B):
+        ref = g["episodes"][lane]
+        ref = ref[~np.isnan(ref[:, 3])]
+        mine = np.array([[e, s, en, du] for ln, e, s, en, du in zip(ep["lane"], ep["episode"], ep["start"], ep["end"], ep["duration"])
+                         if ln == lane]).reshape(-1, 4)
+        np.testing.assert_allclose(mine, ref[:len(mine)], rtol=0, atol=1e-12)
+        assert len(mine) == int(g["reset"][lane].sum())
+    # RewardCache.stats: every step is either active or inactive
+    st = Ag.reward.stats
+    assert np.array_equal((st["total_steps_active"] + st["total_steps_inactive"]).cpu().numpy(), np.full(B, T))
+    assert np.allclose(st["max"].cpu().numpy(), g["reward"].max(axis=1), rtol=1e-14)
+
+
+def test_task_production_reset_matches_host_philox(riab):
+    """Unordered goal selection and teleports of riab_task_reset == the oracle's Philox restatement;
+    selections are prefixes of permutations; masked lanes are untouched."""
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
+    np.random.seed(0)
+    B = 300
+    env = SpatialGoalEnvironment(possible_goal_positions="random_9", goalcachekws=dict(reset_n_goals=5), seed=77,
+                                 teleport_on_reset=True)
+    Ag = riab.Agent(env, {"dt": 0.01, "n_agents": B, "agent_id0": 64})
+    env.add_agents(Ag)                      # reset #1
+    lists = env.goal_cache.goal_lists()
+    ospec = orc.EnvSpec()
+    for lane in (0, 1, 17, 299):
+        assert list(lists[lane, :5]) == orc.task_reset_draws(77, 1, 64 + lane, 9, 5)
+        np.testing.assert_allclose(Ag.pos[lane], orc.task_teleport_draw(77, 1, 64 + lane, ospec), rtol=1e-15)
+    assert all(len(set(r[:5])) == 5 and (r[5:] == -1).all() for r in lists)
+    assert np.all((Ag.pos > 0.05 - 1e-12) & (Ag.pos < 0.95 + 1e-12))       # centre +- 0.45 * scale
+    before, pos_before = lists.copy(), Ag.pos.copy()
+    mask = np.arange(B) % 3 == 0
+    env.reset(mask=mask)                    # reset #2, a third of the lanes
+    after = env.goal_cache.goal_lists()
+    assert np.array_equal(after[~mask], before[~mask]) and np.array_equal(Ag.pos[~mask], pos_before[~mask])
+    assert list(after[3, :5]) == orc.task_reset_draws(77, 2, 64 + 3, 9, 5)
+    assert env.diagnostics["resets"] == B + int(mask.sum())
+    # no time has passed: the zero-duration episodes were dropped again (TaskEnvironment.py:333-337)
+    assert env.episodes["episode"] == [] and np.all(env.episode.cpu().numpy() == 1)
+
+
+def test_agents_reach_their_goals_closed_loop(riab):
+    """The reference's own test (tests/test_taskenv.py::test_agent_can_reach_goal): driven along
+    get_goal_vector every lane terminates; here with 2048 lanes, the policy on the device, in-kernel
+    noise, per-lane auto-reset, and the oracle's TaskLane replaying a few lanes from the observations."""
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment, get_goal_vector
+    np.random.seed(1)
+    B, T = 2048, 400
+    goals = [[0.2, 0.25], [0.8, 0.7], [0.5, 0.1], [0.15, 0.85]]
+    env = SpatialGoalEnvironment(params={"walls": [[[0.5, 0.3], [0.5, 0.7]]]}, possible_goal_positions=goals,
+                                 goalcachekws=dict(reset_n_goals=2, goalorder="nonsequential"),
+                                 episode_terminate_delay=0.05, seed=5)
+    Ag = riab.Agent(env, {"dt": 0.01, "n_agents": B, "seed": 9})
+    env.add_agents(Ag)
+    probe = [0, 1, 500, 2047]
+    table = np.array([[g.pos[0], g.pos[1], g.radius] + g.reward.row() for g in env.goal_cache.get_goals()])
+    lanes = {}
+    for b in probe:
+        lanes[b] = orc.TaskLane(orc.EnvSpec(walls=[[[0.5, 0.3], [0.5, 0.7]]]), table, "nonsequential", 0.05)
+        lanes[b].reset(0.0, env.goal_cache.goal_lists()[b, :2])
+    done = torch.zeros(B, dtype=torch.long, device="cuda")
+    t = 0.0
+    for k in range(T):
+        v = get_goal_vector(Ag)
+        a = 11.0 * Ag.speed_mean * v / torch.linalg.norm(v, dim=1, keepdim=True)      # NaN where no goal is pending
+        obs, rew, term, trunc, info = env.step(a)
+        done += term
+        t = t + 0.01
+        o, r, tm = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+        for b in probe:
+            total, terminal = lanes[b].step(o[b], t)
+            assert total == r[b] and terminal == tm[b], (k, b)
+        if term.any():
+            env.reset(mask=term)
+            sel = env.goal_cache.goal_lists()
+            for b in probe:
+                if tm[b]:
+                    lanes[b].reset(t, sel[b, :2])
+    assert (done > 0).float().mean().item() > 0.6            # most lanes finished an episode within 4 s
+    ep = env.episodes
+    assert len(ep["episode"]) == int(done.sum().item()) and min(ep["duration"]) > 0
+    assert env.diagnostics["reward_overflow"] == 0
+
+
+def test_task_edge_cases(riab):
+    from ratinabox_amd.contribs.TaskEnvironment import (SpatialGoalEnvironment, TaskEnvironment, SpatialGoal, Reward,
+                                                        TimeElapsedGoal)
+    # B = 1: reference-shaped single agent, step1 returns python values
+    env = SpatialGoalEnvironment(possible_goal_positions=[[0.5, 0.5]], goalkws={"goal_radius": 2.0})
+    Ag = riab.Agent(env, {"dt": 0.01})
+    env.add_agents(Ag)
+    obs, r, term, trunc, info = env.step1(np.array([0.1, 0.0]))
+    assert obs.shape == (2,) and r == 1.0 and term is True and env.episode == 1
+    env.reset()
+    assert env.episode == 2 and env.episodes["duration"] == [pytest.approx(0.01)]
+    # pool smaller than reset_n_goals: warns and uses the whole pool (:1231-1239)
+    env = SpatialGoalEnvironment(possible_goal_positions=[[0.5, 0.5]], goalcachekws=dict(reset_n_goals=3))
+    Ag = riab.Agent(env, {"dt": 0.01, "n_agents": 6})
+    with pytest.warns(UserWarning):
+        env.add_agents(Ag)
+    assert np.array_equal(env.goals_left.cpu().numpy(), np.ones(6))
+    # no goals at all: every lane is terminal at once; random motion with actions=None
+    env = TaskEnvironment()
+    Ag = riab.Agent(env, {"dt": 0.01, "n_agents": 5})
+    env.add_agents(Ag)
+    obs, r, term, trunc, info = env.step()
+    assert term.all() and (r == 0).all()
+    # unsupported configurations fail loudly
+    env = TaskEnvironment(goals=[TimeElapsedGoal(None, reward=Reward(1, decay="none"))])
+    Ag = riab.Agent(env, {"dt": 0.01})
+    with pytest.raises(NotImplementedError):
+        env.add_agents(Ag)
+    env = SpatialGoalEnvironment(params={"boundary_conditions": "periodic"}, possible_goal_positions=[[0.5, 0.5]])
+    Ag = riab.Agent(env, {"dt": 0.01})
+    with pytest.raises(AssertionError):
+        env.add_agents(Ag)
+    env = SpatialGoalEnvironment(possible_goal_positions=[[0.5, 0.5]])
+    with pytest.raises(NotImplementedError):
+        env.add_agents(riab.Agent(env, {"dt": 0.05}))       # agent dt != environment dt
+    with pytest.raises(NotImplementedError):
+        env.add_agents([riab.Agent(env, {"dt": 0.01}), riab.Agent(env, {"dt": 0.01})])

@@ -1,0 +1,109 @@
+"""No-GPU checks of the task layer: the oracle's TaskLane restatement against the golden vectors
+generated from the reference's TaskEnvironment, and the host-side descriptions (Reward, goals,
+GoalCache validation, C-ABI argument checks)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import golden_util as gu
+from oracle import riab_oracle as orc
+
+
+@pytest.mark.parametrize("fname", gu.TASK_FILES)
+def test_task_lane_oracle_vs_reference(fname):
+    """Reward totals (bit-exact), terminal flags, goal / reward cache sizes and the episode table of
+    every lane of the reference runs, replayed from the recorded positions."""
+    g = gu.load(fname)
+    env = orc.EnvSpec(walls=g["user_walls"])
+    n = int(g["reset_n_goals"])
+    late = 0
+    for lane in range(g["pos"].shape[0]):
+        L = orc.TaskLane(env, g["goal_table"], str(g["goalorder"]), float(g["terminate_delay"]))
+        L.reset(0.0, range(n))
+        t = 0.0
+        for k in range(g["pos"].shape[1]):
+            t = t + float(g["dt"])
+            total, term = L.step(g["pos"][lane, k], t)
+            assert total == g["reward"][lane, k], (lane, k)
+            assert len(L.goal_list) == g["goals_left"][lane, k] and len(L.rewards) == g["n_rewards"][lane, k], (lane, k)
+            assert term == (g["goals_left"][lane, k] == 0)
+            if not g["late"][lane, k]:  # the reference reports the flag of its FIRST check pass
+                assert term == bool(g["terminal"][lane, k]), (lane, k)
+            if g["reset"][lane, k]:
+                L.reset(t, range(n))
+        ep = g["episodes"][lane]
+        ep = ep[~np.isnan(ep[:, 0])]
+        mine = np.array(L.finished).reshape(-1, 4)
+        assert len(mine) >= 1 or len(ep) <= 1
+        np.testing.assert_allclose(mine, ep[:len(mine)], rtol=0, atol=0)
+        late += L.late_completions
+    assert late == int(g["late"].sum())
+
+
+def test_reset_draws_are_permutation_prefixes():
+    for lane in range(50):
+        d = orc.task_reset_draws(seed=7, counter=3, lane_id=lane, n_pool=9, n_select=6)
+        assert len(set(d)) == 6 and all(0 <= x < 9 for x in d)
+    allsel = np.array([orc.task_reset_draws(1, 1, lane, 5, 1)[0] for lane in range(4000)])
+    assert np.all(np.abs(np.bincount(allsel, minlength=5) / 4000 - 0.2) < 0.03)  # uniform over the pool
+
+
+def test_reward_descriptions():
+    from ratinabox_amd.contribs.TaskEnvironment import Reward, reward_default, no_reward_default
+    assert reward_default.row() == [1.0, 0.01, 1.0, 1.0, 1.0]
+    assert no_reward_default.row() == [0.0, 0.01, 0.1, 3.0, 0.0] == list(orc.PAD_REWARD)
+    r = Reward(2, dt=0.02, expire_clock=0.5, decay="exponential")
+    assert r.row() == [2.0, 0.02, 0.5, 2.0, 2.0] and r.get_delta() == -2 * np.exp(2)
+    assert Reward(1, decay="constant", expire_clock=None).expire_clock == 0.01  # falls back to dt (:780-782)
+    with pytest.raises(NotImplementedError):
+        Reward(1)  # the reference's default (decay=None) cannot be stepped either (TypeError in its update)
+    with pytest.raises(NotImplementedError):
+        Reward(1, decay="linear", external_drive=lambda: 1.0)
+
+
+def test_goal_cache_validation_and_pool():
+    from ratinabox_amd.contribs.TaskEnvironment import GoalCache, SpatialGoalEnvironment, SpatialGoal
+    with pytest.raises(ValueError):
+        GoalCache(None, goalorder="sometimes")
+    with pytest.raises(ValueError):
+        GoalCache(None, agentmode="compete")
+    with pytest.raises(ValueError):
+        GoalCache(None, reset_n_goals=0)
+    with pytest.raises(NotImplementedError):
+        GoalCache(None, goalorder="custom")
+    np.random.seed(3)
+    env = SpatialGoalEnvironment(possible_goal_positions="random_4", goalkws={"goal_radius": 0.07})
+    pool = env.goal_cache.get_goals()
+    assert len(pool) == 4 and all(isinstance(g, SpatialGoal) and g.radius == 0.07 for g in pool)
+    assert env.get_goal_positions().shape == (4, 2)
+    env2 = SpatialGoalEnvironment(possible_goal_positions=[[0.1, 0.2], [0.3, 0.4]])
+    assert env2.goal_cache.get_goals()[0].radius == pytest.approx(0.1)  # min(dx*10, ptp(extent)/10)
+    assert env2.goal_cache.get_goals()[1] == [0.3, 0.4]
+    with pytest.raises(ValueError):
+        SpatialGoalEnvironment(possible_goal_positions="grid_4")
+    with pytest.raises(NotImplementedError):
+        env2.render()
+
+
+def test_task_abi_argument_errors():
+    from ratinabox_amd import _lib as L
+    env, task = L.RiabEnv(), L.RiabTask()
+    p = C.c_void_p(64)
+    assert L.lib.riab_task_step(None, task, p, p, p, 4, 0.0, p, p, p, None) == -1
+    assert L.lib.riab_task_step(env, task, p, p, p, 0, 0.0, p, p, p, None) == -1
+    assert L.lib.riab_task_step(env, task, p, None, p, 4, 0.0, p, p, p, None) == -1
+    task.n_pool = 65
+    assert L.lib.riab_task_step(env, task, p, p, p, 4, 0.0, p, p, p, None) == -3      # RIAB_ETOOBIG
+    task.n_pool = 2
+    assert L.lib.riab_task_step(env, task, p, p, p, 4, 0.0, p, p, p, None) == -1      # goals pointer missing
+    task.goals = 64
+    env.periodic = 1
+    assert L.lib.riab_task_step(env, task, p, p, p, 4, 0.0, p, p, p, None) == -4      # line of sight needs solid walls
+    env.periodic = 0
+    task.goalorder = 7
+    assert L.lib.riab_task_step(env, task, p, p, p, 4, 0.0, p, p, p, None) == -4
+    task.goalorder = 0
+    assert L.lib.riab_task_reset(env, task, p, None, 4, 0, 0.0, 16, 1, 0, 0, 0, None, None, None, None, None, None, None, 0, None, p, None) == -3
+    assert L.lib.riab_task_reset(env, task, p, None, 4, 0, 0.0, 2, 1, 0, 0, 1, None, None, None, None, None, None, None, 0, None, p, None) == -1
+    assert C.sizeof(L.RiabTask) == 8 + 4 + 4 + 8 + 5 * 8 + 8
