@@ -53,9 +53,15 @@ def bytes_per_agent_step(cfg):
     return 4 * n + (n if cfg["spikes"] else 0) + 112
 
 
-def build_world(riab, cfg, rank, precision, seed=1234):
+def build_world(riab, cfg, rank, precision, seed=1234, task=False):
     np.random.seed(1000 + rank)
-    env = riab.Environment({"walls": cfg["walls"]})
+    if task:  # the same world inside a goal-directed task (closed loop: contribs/TaskEnvironment.py)
+        from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
+        env = SpatialGoalEnvironment(params={"walls": cfg["walls"]}, possible_goal_positions="random_8",
+                                     goalcachekws=dict(reset_n_goals=2), teleport_on_reset=True,
+                                     episode_terminate_delay=0.05, seed=seed)
+    else:
+        env = riab.Environment({"walls": cfg["walls"]})
     B = cfg["agents"]
     ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "seed": seed, "agent_id0": rank * B, "precision": precision})
     pops = []
@@ -69,6 +75,8 @@ def build_world(riab, cfg, rank, precision, seed=1234):
         pops.append(riab.BoundaryVectorCells(ag, dict(common, n=cfg["bvc"])))
     if cfg["hdc"]:
         pops.append(riab.HeadDirectionCells(ag, dict(common, n=cfg["hdc"])))
+    if task:
+        env.add_agents(ag)
     return env, ag, pops
 
 
@@ -113,6 +121,9 @@ def main():
     ap.add_argument("--per-step", action="store_true", help="time the drop-in per-step API instead of simulate()")
     ap.add_argument("--plan", action="store_true", help="time the closed-loop path through a native step plan")
     ap.add_argument("--plan-batch", type=int, default=1, help="steps per riab_plan_step call (1 = closed loop)")
+    ap.add_argument("--task", action="store_true",
+                    help="closed loop through the batched TaskEnvironment: goal-seeking actions, rewards, goal checks "
+                         "and per-lane auto-reset every step (implies --plan)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-history", action="store_true", help="ring buffers instead of a full T-long history")
     args = ap.parse_args()
@@ -137,7 +148,8 @@ def main():
 
     import ratinabox_amd as riab
     cfg = CONFIGS[args.config]
-    env, ag, pops = build_world(riab, cfg, rank, args.precision)
+    args.plan = args.plan or args.task
+    env, ag, pops = build_world(riab, cfg, rank, args.precision, task=args.task)
     # the full rate history of K steps must fit in HBM next to the warmup's; otherwise stream
     # through ring buffers (every byte is still written, the oldest rows are overwritten)
     n_cells = sum(int(p.n) for p in pops)
@@ -157,7 +169,10 @@ def main():
     def run(n_steps):
         if args.plan:
             if plan["p"] is None or ag._plan is not plan["p"]:
-                plan["p"] = ag.make_step_plan(capacity=max(K, W))
+                if args.task:
+                    plan["p"] = env.make_step_plan(capacity=max(K, W), auto_reset=True, scripted_speed=11 * ag.speed_mean)
+                else:
+                    plan["p"] = ag.make_step_plan(capacity=max(K, W))
             nb = args.plan_batch
             for _ in range(n_steps // nb):
                 plan["p"].step(nb)
@@ -269,7 +284,9 @@ def main():
             "config": {"workload": args.config + ": " + cfg["desc"], "agents_per_gpu": B,
                        "cells": {k: cfg[k] for k in ("place", "grid", "bvc", "hdc")},
                        "parallelism": f"agent-sharded x{world}, no step-path collective",
-                       "api": ("step plan (one native call per step)" if args.plan else "per-step update()"
+                       "api": ("TaskEnvironment step plan: action, Agent.update, rewards/goals, auto-reset, rates; one "
+                               "native call per step" if args.task else
+                               "step plan (one native call per step)" if args.plan else "per-step update()"
                                if args.per_step else f"simulate(), {args.chunk} steps/launch"),
                        "history": "ring" if args.no_history else "full", "spikes": cfg["spikes"],
                        "bytes_per_agent_step": bpu},
@@ -279,6 +296,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         diag = ag.diagnostics
+        if args.task:
+            diag = dict(diag, **env.diagnostics, episodes_finished=len(env.episodes["episode"]))
         out["diagnostics"] = diag
         print(json.dumps(out), flush=True)
     if dist is not None:

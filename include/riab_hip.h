@@ -385,6 +385,14 @@ int riab_task_step(const RiabEnv* env, const RiabTask* task, double* task_state,
                    const double* pos_y, int64_t B, double t_env, double* reward_out, uint8_t* terminal_out,
                    int32_t* diag, riab_stream_t stream);
 
+/* get_goal_vector (contribs/TaskEnvironment.py:1555-1584): out = goal - position for the head of the
+ * lane's list (sequential) or its nearest pending spatial goal, (0,0) when none is pending.
+ * scale > 0 writes scale * unit vector instead (0 where there is no goal): the scripted
+ * goal-seeking action of the reference's test loop (:1599-1605). */
+int riab_task_goal_vector(const RiabEnv* env, const RiabTask* task, double* task_state, const double* pos_x,
+                          const double* pos_y, int64_t B, double scale, double* out_x, double* out_y,
+                          riab_stream_t stream);
+
 /* TaskEnvironment.reset for the lanes with mask[b] != 0 (mask NULL = every lane): the running
  * episode is closed (appended to ep_log when given: float64 [cap][5] = global lane id, episode,
  * start, end, duration; ep_count int32 device counter), the episode counter advances unless the
@@ -400,6 +408,19 @@ int riab_task_reset(const RiabEnv* env, const RiabTask* task, double* task_state
                     uint64_t counter, int32_t teleport, const double* new_x, const double* new_y, double* pos_x,
                     double* pos_y, float* hist_x, float* hist_y, double* ep_log, int64_t ep_log_cap,
                     int32_t* ep_count, int32_t* diag, riab_stream_t stream);
+
+/* Attach a task (riab_task_*) to the plan: every plan step then is one TaskEnvironment.step —
+ * [scripted_speed > 0: drift <- scripted_speed * unit goal vector, written to the plan's drift buffer]
+ * Agent.update, clock += dt_env, riab_task_step, [auto_reset: riab_task_reset(mask = terminal_out) with
+ * the reset counter advanced every step], then the populations (which therefore see teleported
+ * positions).  Task arrays hold task_B lanes (the agents of the batch, without the padding of the
+ * plan's B).  task == NULL detaches. */
+int riab_plan_set_task(RiabPlan* plan, const RiabTask* task, double* task_state, int64_t task_B, double t_env,
+                       double dt_env, double* reward_out, uint8_t* terminal_out, int32_t* task_diag,
+                       int32_t auto_reset, int32_t n_select, int32_t ordered, uint64_t task_seed,
+                       uint64_t reset_counter, int32_t teleport, double* ep_log, int64_t ep_log_cap,
+                       int32_t* ep_count, double scripted_speed);
+double riab_plan_task_clock(const RiabPlan* plan);
 
 /* Streaming-store calibration kernel: writes `bytes` bytes (multiple of 16) of
  * a constant with the same 16-B/lane store pattern as the rate kernels.  Used

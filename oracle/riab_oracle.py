@@ -845,10 +845,11 @@ class TaskLane:
 
 
 def task_reset_draws(seed, counter, lane_id, n_pool, n_select):
-    """The production goal selection of riab_task_reset: partial Fisher-Yates driven by Philox
-    (draw i = word i%4 of block 1 + i//4, j = i + floor(w * (n_pool - i) / 2^32))."""
+    """The production goal selection of riab_task_reset: uniform sample without replacement driven
+    by Philox — draw i picks the j-th goal still in the pool (ascending order),
+    j = floor(w_i * (n_pool - i) / 2^32), w_i = word i%4 of block 1 + i//4."""
     TAG = 0x5441534B
-    perm = list(range(n_pool))
+    remaining = list(range(n_pool))
     out = []
     words = None
     for i in range(min(n_select, n_pool)):
@@ -856,9 +857,8 @@ def task_reset_draws(seed, counter, lane_id, n_pool, n_select):
             words = philox4x32_10(counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF, lane_id & 0xFFFFFFFF,
                                   (TAG + 1 + i // 4) & 0xFFFFFFFF, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
         w = int(words[i % 4])
-        j = i + ((w * (n_pool - i)) >> 32)
-        perm[i], perm[j] = perm[j], perm[i]
-        out.append(perm[i])
+        j = (w * (n_pool - i)) >> 32
+        out.append(remaining.pop(j))
     return out
 
 

@@ -113,6 +113,12 @@ PROTOTYPES = {
     "riab_plan_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "riab_task_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "riab_task_goal_vector": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "riab_plan_set_task": (C.c_int, [C.c_void_p, C.POINTER(RiabTask), C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
+                                     C.c_uint64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_double]),
+    "riab_plan_task_clock": (C.c_double, [C.c_void_p]),
     "riab_task_reset": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_double, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

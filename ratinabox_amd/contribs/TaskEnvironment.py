@@ -316,7 +316,11 @@ class TaskEnvironment(Environment):
         return {name: V for name in self.agent_names}
 
     # ---- goal pool -> device ------------------------------------------------------------------------
-    def _task_struct(self):
+    def _task_struct(self, refresh=False):
+        """RiabTask for the kernels.  The goal pool is read at reset() time (refresh=True); between
+        resets the cached table is used (edits to goals take effect at the next reset)."""
+        if not refresh and getattr(self, "_task_cached", None) is not None:
+            return self._task_cached
         pool = self.goal_cache.reset_goals
         if len(pool) > _L.TASK_MAX_POOL:
             raise ValueError(f"at most {_L.TASK_MAX_POOL} goals in the pool, got {len(pool)}")
@@ -338,6 +342,7 @@ class TaskEnvironment(Environment):
         for i, v in enumerate(no_reward_default.row()):
             t.pad_reward[i] = v
         t.default_reward_level = float(self.reward_caches[self.agent_names[0]].default_reward_level)
+        self._task_cached = t
         return t
 
     # ---- episode control --------------------------------------------------------------------------
@@ -362,7 +367,7 @@ class TaskEnvironment(Environment):
             return self.get_observation(), self.infos
         ag = self._agent
         dev = ag.state_tensor.device
-        task = self._task_struct()
+        task = self._task_struct(refresh=True)
         if getattr(self, "_pool_changed", False):
             if mask is not None and self._reset_counter > 0:
                 raise ValueError("the goal pool changed: reset every lane (mask=None) so that no lane keeps stale goals")
@@ -452,6 +457,18 @@ class TaskEnvironment(Environment):
         self._keep_step = (walls, task)
         return (self.get_observation(), self._reward, self._terminal.bool(), self._truncated, self.infos)
 
+    def make_step_plan(self, neurons=None, capacity=1024, auto_reset=True, scripted_speed=None):
+        """The whole closed-loop step as ONE native call (plan.py, riab_plan_*): `plan.step(1, drift_velocity=
+        actions)` == `env.step(actions)` + `Neurons.update()` of every population (+ `env.reset(mask=terminal)`
+        when `auto_reset`).  Read `env.get_reward()`, `env.terminal`, `env.get_observation()` afterwards."""
+        plan = self._agent.make_step_plan(neurons, capacity)
+        return plan.attach_task(self, auto_reset=auto_reset, scripted_speed=scripted_speed)
+
+    @property
+    def terminal(self):
+        """Terminal flag of every lane as of the last step (device bool (B,))."""
+        return self._terminal.bool()
+
     def step1(self, action=None, *pos, **kws):
         """Single-lane shortcut returning python values (reference step1, TaskEnvironment.py:455-462)."""
         assert self._B == 1, "step1 is for a single agent"
@@ -490,6 +507,17 @@ class TaskEnvironment(Environment):
         """Episode counter per lane (device int tensor); the reference's scalar when B == 1."""
         e = self.task_state[_L.TS_EPISODE, :self._B].long()
         return int(e[0].item()) if self._B == 1 else e
+
+    def _goal_vector(self, scale):
+        st = self._agent.state_tensor
+        out = torch.empty((2, self._B), dtype=torch.float64, device=st.device)
+        env_s, walls = self.device_tables(st.device)
+        task = self._task_struct()
+        rc = _L.lib.riab_task_goal_vector(env_s, task, _L.ptr(self.task_state), _L.ptr(st[0]), _L.ptr(st[1]), self._B,
+                                          float(scale), _L.ptr(out[0]), _L.ptr(out[1]), _L.current_stream())
+        _L.check(rc, "riab_task_goal_vector")
+        self._keep_gv = (walls, task)
+        return out.t()
 
     def _goal_lists(self):
         ts = self.task_state[:, :self._B].cpu().numpy()
@@ -589,19 +617,4 @@ def get_goal_vector(Ag=None):
     if not isinstance(Ag, Agent):
         raise TypeError("Unknown input type")
     env = Ag.Environment
-    B = env._B
-    ts = env.task_state
-    pos = Ag.state_tensor[0:2, :B].t()                                               # (B,2)
-    idx = ts[_L.TS_GOAL_LIST:_L.TS_GOAL_LIST + _L.TASK_MAX_GOALS, :B].long()       # (16,B)
-    n = ts[_L.TS_N_GOALS, :B].long()
-    valid = (torch.arange(_L.TASK_MAX_GOALS, device=ts.device).unsqueeze(1) < n.unsqueeze(0)) & (idx >= 0)
-    goals = env._pool_dev[:, 0:2][idx.clamp(min=0)]                                  # (16,B,2)
-    vec = goals - pos.unsqueeze(0)
-    if env.goal_cache.goalorder == "sequential":
-        pick = torch.zeros(B, dtype=torch.long, device=ts.device)
-    else:
-        dist = torch.linalg.norm(vec, dim=2).masked_fill(~valid, float("inf"))
-        pick = dist.argmin(dim=0)
-    lanes = torch.arange(B, device=ts.device)
-    out = vec[pick, lanes]
-    return torch.where(valid[pick, lanes].unsqueeze(1), out, torch.zeros_like(out))
+    return env._goal_vector(0.0)

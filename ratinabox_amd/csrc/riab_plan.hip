@@ -12,6 +12,14 @@
 
 #include "riab_device.h"
 
+namespace riab {
+int launch_task_fused(const RiabEnv* env, const RiabTask* task, double* task_state, double* pos_x, double* pos_y, int64_t B,
+                      double t_env, double* reward_out, uint8_t* terminal_out, int32_t* diag, bool auto_reset,
+                      int64_t agent_id0, int32_t n_select, int32_t ordered, uint64_t seed, uint64_t counter,
+                      int32_t teleport, float* hist_x, float* hist_y, double* ep_log, int64_t ep_log_cap,
+                      int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y, hipStream_t s);
+}
+
 struct RiabPlan {
   RiabEnv env;
   RiabMotion motion;
@@ -28,6 +36,22 @@ struct RiabPlan {
   int32_t* diag;
   std::vector<RiabPopulation> pops;
   std::vector<int64_t> pop_fill;
+  // attached task (riab_plan_set_task)
+  bool has_task;
+  RiabTask task;
+  double* task_state;
+  int64_t task_B;
+  double t_env, dt_env;
+  double* reward_out;
+  uint8_t* terminal_out;
+  int32_t* task_diag;
+  int32_t auto_reset, n_select, ordered, teleport;
+  uint64_t task_seed, reset_counter;
+  double* ep_log;
+  int64_t ep_log_cap;
+  int32_t* ep_count;
+  double scripted_speed;
+  bool action_ready;  // the drift buffer holds the scripted action of the coming step
 };
 
 extern "C" RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
@@ -49,6 +73,8 @@ extern "C" RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* moti
   p->hist_cap = p->hist_fill = 0;
   p->row_scratch = row_scratch;
   p->diag = diag;
+  p->has_task = false;
+  p->action_ready = false;
   return p;
 }
 
@@ -59,6 +85,7 @@ extern "C" int riab_plan_set_motion(RiabPlan* p, const RiabMotion* motion, const
   if (motion->has_drift && !drift) return RIAB_EINVAL;
   p->motion = *motion;
   p->drift = drift;
+  p->action_ready = false;
   return RIAB_OK;
 }
 
@@ -88,6 +115,44 @@ extern "C" int riab_plan_set_population_history(RiabPlan* p, int32_t index, floa
   p->pop_fill[index] = 0;
   return RIAB_OK;
 }
+
+extern "C" int riab_plan_set_task(RiabPlan* p, const RiabTask* task, double* task_state, int64_t task_B, double t_env,
+                                  double dt_env, double* reward_out, uint8_t* terminal_out, int32_t* task_diag,
+                                  int32_t auto_reset, int32_t n_select, int32_t ordered, uint64_t task_seed,
+                                  uint64_t reset_counter, int32_t teleport, double* ep_log, int64_t ep_log_cap,
+                                  int32_t* ep_count, double scripted_speed) {
+  if (!p) return RIAB_EINVAL;
+  if (!task) {
+    p->has_task = false;
+    return RIAB_OK;
+  }
+  if (!task_state || task_B <= 0 || task_B > p->B || !reward_out || !terminal_out || !task_diag) return RIAB_EINVAL;
+  if (n_select < 0 || n_select > RIAB_TASK_MAX_GOALS - 1) return RIAB_ETOOBIG;
+  if (ep_log && (!ep_count || ep_log_cap <= 0)) return RIAB_EINVAL;
+  p->has_task = true;
+  p->task = *task;
+  p->task_state = task_state;
+  p->task_B = task_B;
+  p->t_env = t_env;
+  p->dt_env = dt_env;
+  p->reward_out = reward_out;
+  p->terminal_out = terminal_out;
+  p->task_diag = task_diag;
+  p->auto_reset = auto_reset;
+  p->n_select = n_select;
+  p->ordered = ordered;
+  p->task_seed = task_seed;
+  p->reset_counter = reset_counter;
+  p->teleport = teleport;
+  p->ep_log = ep_log;
+  p->ep_log_cap = ep_log_cap;
+  p->ep_count = ep_count;
+  p->scripted_speed = scripted_speed;
+  p->action_ready = false;
+  return RIAB_OK;
+}
+
+extern "C" double riab_plan_task_clock(const RiabPlan* p) { return p && p->has_task ? p->t_env : 0.0; }
 
 extern "C" int64_t riab_plan_rows_free(const RiabPlan* p) {
   if (!p) return 0;
@@ -144,11 +209,35 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
   hipStream_t s = (hipStream_t)stream;
   for (int32_t k = 0; k < n_steps; ++k) {
     float* row = p->hist_base ? p->hist_base + p->hist_fill * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
-    int rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr,
+    double* pos_x = p->state + (int64_t)RIAB_S_POS_X * p->B;
+    double* pos_y = p->state + (int64_t)RIAB_S_POS_Y * p->B;
+    int rc;
+    const bool scripted = p->has_task && p->scripted_speed > 0.0;
+    double* act = const_cast<double*>(p->drift);
+    if (scripted) {
+      if (!act || !p->motion.has_drift) return RIAB_EINVAL;
+      if (!p->action_ready) {  // first step: later ones get their action from the previous step's fused task kernel
+        rc = riab_task_goal_vector(&p->env, &p->task, p->task_state, pos_x, pos_y, p->task_B, p->scripted_speed, act,
+                                   act + p->B, s);
+        if (rc) return rc;
+      }
+    }
+    rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr,
                              p->seed, p->step, 1, row, p->diag, p->precision, s);
     if (rc) return rc;
     p->step += 1;
     if (p->hist_base) p->hist_fill += 1;
+    if (p->has_task) {  // the rest of TaskEnvironment.step (+ the caller's `if terminal: reset()`)
+      p->t_env += p->dt_env;
+      if (p->auto_reset) p->reset_counter += 1;
+      rc = riab::launch_task_fused(&p->env, &p->task, p->task_state, pos_x, pos_y, p->task_B, p->t_env, p->reward_out,
+                                   p->terminal_out, p->task_diag, p->auto_reset != 0, p->agent_id0, p->n_select, p->ordered,
+                                   p->task_seed, p->reset_counter, p->teleport, row + (int64_t)RIAB_H_POS_X * p->B,
+                                   row + (int64_t)RIAB_H_POS_Y * p->B, p->ep_log, p->ep_log_cap, p->ep_count,
+                                   p->scripted_speed, scripted ? act : nullptr, scripted ? act + p->B : nullptr, s);
+      if (rc) return rc;
+      p->action_ready = scripted;
+    }
     for (size_t i = 0; i < p->pops.size(); ++i) {
       rc = launch_population(p, i, row, s);
       if (rc) return rc;

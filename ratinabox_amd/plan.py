@@ -55,6 +55,10 @@ class StepPlan:
         self._agent_rows = None
         self._pop_rows = [None] * len(self.neurons)
         self._scratch_rates = [None] * len(self.neurons)
+        self._task_env = None    # TaskEnvironment attached by attach_task()
+        self._actions = None     # persistent drift buffer [2, Bp] the plan reads when a task is attached
+        self._auto_reset = False
+        self._scripted = False
         agent._plan = self
         self._attach()
 
@@ -85,19 +89,57 @@ class StepPlan:
         self._rows_open = cap
         self._chunk_rows_done = 0
 
+    # ---- task ------------------------------------------------------------------------------------
+    def attach_task(self, env, auto_reset=True, scripted_speed=None):
+        """Make every plan step one `TaskEnvironment.step` (contribs/TaskEnvironment.py): after the motion
+        kernel the task kernel updates rewards / goals of all lanes; with `auto_reset` the lanes that
+        became terminal are reset right away (the caller's `if terminal: env.reset()`), before the
+        populations are evaluated.  `scripted_speed`: the action of every step is
+        `scripted_speed * unit goal vector`, computed on the device (no policy on the host)."""
+        ag = self.agent
+        assert env._agent is ag, "the plan's agent is not the one added to this TaskEnvironment"
+        task = env._task_struct()
+        n_sel = min(env.goal_cache.reset_n_goals, task.n_pool)
+        self._task_env, self._task_struct_keep = env, task
+        self._auto_reset, self._scripted = bool(auto_reset), bool(scripted_speed)
+        self._actions = torch.zeros((2, ag._Bp), dtype=torch.float64, device=ag._device)
+        rc = _L.lib.riab_plan_set_task(self._h, task, _L.ptr(env.task_state), env._B, float(env.t), float(env.dt),
+                                       _L.ptr(env._reward), _L.ptr(env._terminal), _L.ptr(env._diag), int(self._auto_reset),
+                                       int(n_sel), int(bool(env.goal_cache.reset_orders_goal)), env._task_seed,
+                                       env._reset_counter, int(bool(env.teleport_on_reset)), _L.ptr(env._ep_log), env._ep_cap,
+                                       _L.ptr(env._ep_count), float(scripted_speed or 0.0))
+        _L.check(rc, "riab_plan_set_task")
+        self._drift_key = None
+        return self
+
     # ---- stepping --------------------------------------------------------------------------------
     def step(self, n_steps=1, drift_velocity=None, drift_to_random_strength_ratio=1, dt=None):
         ag = self.agent
         if ag._plan is not self:
             raise RuntimeError("this plan was closed (the agent was stepped eagerly or its history reset)")
         dt = dt or ag.dt
-        key = (dt, drift_velocity is not None, drift_to_random_strength_ratio)
-        if key != self._drift_key or drift_velocity is not None:
-            drift = ag._as_device_f64(drift_velocity, 2) if drift_velocity is not None else None
-            motion = ag._motion(dt, drift is not None, drift_to_random_strength_ratio, {})
-            _L.check(_L.lib.riab_plan_set_motion(self._h, motion, _L.ptr(drift)), "riab_plan_set_motion")
-            self._drift_t, self._drift_key = drift, key
-            ag.dt = dt
+        if self._task_env is not None:
+            # actions land in the plan's persistent drift buffer: no per-step parameter resolution
+            has_drift = drift_velocity is not None or self._scripted
+            if drift_velocity is not None:
+                a = drift_velocity if torch.is_tensor(drift_velocity) else torch.as_tensor(np.asarray(drift_velocity, dtype=np.float64))
+                a = torch.nan_to_num(a.to(ag._device, torch.float64), nan=0.0)   # TaskEnvironment.py:403-404
+                self._actions[:, :ag._B].copy_(a.reshape(-1, 2).t() if a.numel() > 2 else a.reshape(2, 1))
+            key = (dt, has_drift, drift_to_random_strength_ratio, "task")
+            if key != self._drift_key:
+                motion = ag._motion(dt, has_drift, drift_to_random_strength_ratio, {})
+                _L.check(_L.lib.riab_plan_set_motion(self._h, motion, _L.ptr(self._actions) if has_drift else None),
+                         "riab_plan_set_motion")
+                self._drift_key = key
+                ag.dt = dt
+        else:
+            key = (dt, drift_velocity is not None, drift_to_random_strength_ratio)
+            if key != self._drift_key or drift_velocity is not None:
+                drift = ag._as_device_f64(drift_velocity, 2) if drift_velocity is not None else None
+                motion = ag._motion(dt, drift is not None, drift_to_random_strength_ratio, {})
+                _L.check(_L.lib.riab_plan_set_motion(self._h, motion, _L.ptr(drift)), "riab_plan_set_motion")
+                self._drift_t, self._drift_key = drift, key
+                ag.dt = dt
         if n_steps > self._rows_open:
             if n_steps > self.capacity:
                 raise ValueError(f"n_steps {n_steps} exceeds the plan's chunk capacity {self.capacity}")
@@ -111,6 +153,12 @@ class StepPlan:
             ag.t += dt
             self._times_pending.append(ag.t)
         ag._step_index += n_steps
+        env = self._task_env
+        if env is not None:
+            for _ in range(n_steps):
+                env.update()               # the clock (the native plan advances its copy the same way)
+            if self._auto_reset:
+                env._reset_counter += n_steps
 
     def sync(self):
         """Publish the rows written since the last sync to the Python-side mirrors."""

@@ -196,3 +196,59 @@ def test_task_edge_cases(riab):
         env.add_agents(riab.Agent(env, {"dt": 0.05}))       # agent dt != environment dt
     with pytest.raises(NotImplementedError):
         env.add_agents([riab.Agent(env, {"dt": 0.01}), riab.Agent(env, {"dt": 0.01})])
+
+
+def test_task_step_plan_equals_eager_loop(riab):
+    """env.make_step_plan(auto_reset, scripted_speed): one native call per step == the eager loop
+    `a = speed * goal direction; env.step(a); env.reset(mask=terminal); PCs.update()` bit for bit."""
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment, get_goal_vector
+    B, T, speed = 257, 150, 11.0 * 0.08
+
+    def build():
+        np.random.seed(2)
+        env = SpatialGoalEnvironment(params={"walls": [[[0.5, 0.3], [0.5, 0.7]]]},
+                                     possible_goal_positions=[[0.2, 0.25], [0.8, 0.7], [0.5, 0.1]],
+                                     goalcachekws=dict(reset_n_goals=2, goalorder="sequential"),
+                                     episode_terminate_delay=0.03, teleport_on_reset=True, seed=11)
+        Ag = riab.Agent(env, {"dt": 0.01, "n_agents": B, "seed": 4})
+        PCs = riab.PlaceCells(Ag, {"n": 40})
+        env.add_agents(Ag)
+        return env, Ag, PCs
+
+    e1, A1, P1 = build()
+    e2, A2, P2 = build()
+    plan = e2.make_step_plan(auto_reset=True, scripted_speed=speed)
+    rews, terms = [], []
+    for k in range(T):
+        a = e1._goal_vector(speed)
+        obs, rew, term, trunc, info = e1.step(a)
+        rews.append(rew.clone())
+        terms.append(term.clone())
+        e1.reset(mask=term)
+        P1.update()
+        plan.step(1)
+        assert torch.equal(e2.get_reward(), rews[-1]) and torch.equal(e2.terminal, terms[-1]), k
+    assert np.array_equal(A1.pos, A2.pos) and np.array_equal(P1.firingrate, P2.firingrate)
+    assert torch.equal(e1.task_state, e2.task_state)
+    assert e1.episodes == e2.episodes and len(e1.episodes["episode"]) > 5
+    assert e1.t == e2.t and e1.diagnostics == e2.diagnostics
+    assert np.array_equal(A1.history["pos"], A2.history["pos"])
+    assert np.array_equal(P1.history["firingrate"], P2.history["firingrate"])
+    # teleports are visible in the stored trajectory (agent.history["pos"][-1] = agent.pos) and in the rates
+    assert torch.stack(terms).any()
+    # user-provided actions through the plan == eager step with the same actions
+    plan2 = e2.make_step_plan(auto_reset=False)
+    act = torch.randn(B, 2, dtype=torch.float64, device="cuda") * 0.2
+    act[3] = float("nan")
+    o1, r1, t1, _, _ = e1.step(act)
+    P1.update()
+    plan2.step(1, drift_velocity=act)
+    assert np.array_equal(A1.pos, A2.pos) and torch.equal(e2.get_reward(), r1) and torch.equal(e2.terminal, t1)
+    # get_goal_vector: raw vectors point at a pending goal of the lane
+    v = get_goal_vector(A1).cpu().numpy()
+    lists, pool = e1.goal_cache.goal_lists(), e1.get_goal_positions()
+    for b in range(0, B, 37):
+        if lists[b, 0] >= 0:
+            np.testing.assert_allclose(v[b], pool[lists[b, 0]] - A1.pos[b], rtol=0, atol=1e-15)  # sequential: the head
+        else:
+            assert np.all(v[b] == 0)

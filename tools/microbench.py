@@ -116,6 +116,43 @@ def ff():
               f"(reads {x.numel() * 4 / ms / 1e6:.0f} GB/s of rates)", flush=True)
 
 
+def task():
+    """Closed-loop TaskEnvironment steps/s: 4096 lanes, 1024 PlaceCells as observation, scripted
+    goal-seeking policy, auto-reset; eager Python loop vs one native plan call per step."""
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
+    B, K = 4096, 400
+    for mode in ("eager", "plan", "plan x16"):
+        np.random.seed(0)
+        env = SpatialGoalEnvironment(possible_goal_positions="random_8", goalcachekws=dict(reset_n_goals=2),
+                                     teleport_on_reset=True, episode_terminate_delay=0.05)
+        ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "save_history": False})
+        pcs = riab.PlaceCells(ag, {"n": 1024, "save_history": False, "save_spikes": False})
+        env.add_agents(ag)
+        speed = 11 * ag.speed_mean
+        if mode == "eager":
+            def run(n):
+                for _ in range(n):
+                    a = env._goal_vector(speed)
+                    obs, rew, term, _, _ = env.step(a)
+                    env.reset(mask=term)
+                    pcs.update()
+        else:
+            plan = env.make_step_plan(auto_reset=True, scripted_speed=speed)
+            chunk = 16 if "x16" in mode else 1
+
+            def run(n):
+                for _ in range(n // chunk):
+                    plan.step(chunk)
+        run(64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(K)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"task loop [{mode}]: {dt / K * 1e6:.1f} us/step  {B * K / dt / 1e6:.1f} M agent-steps/s  "
+              f"episodes finished {len(env.episodes['episode'])}", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["agent", "fill", "rates"]
     for w in which:
