@@ -335,8 +335,7 @@ class Agent:
             z_all = noise
         step0 = self._step_index
         t0 = 0
-        while t0 < n_steps:
-            tc = min(chunk, n_steps - t0)
+        for tc in self._chunk_schedule(n_steps, chunk):
             view = traj[t0:t0 + tc]
             kw = dict(kwargs)
             if z_all is not None:
@@ -363,6 +362,26 @@ class Agent:
         for N, out in zip(neurons, outs):
             N._finish_rows(out, n_steps, self._times[-n_steps:] if self.save_history else None)
         return traj
+
+    @staticmethod
+    def _chunk_schedule(n_steps, chunk):
+        """Steps per trajectory launch: `chunk`, with the last chunk tapered (1/2, 1/4, ... down to 16
+        steps).  The rate kernels trail the trajectory kernel by one chunk, so after the last trajectory
+        launch a whole chunk of rates is still to be computed with nothing to overlap; tapering makes
+        that drain the rates of 16 steps instead of `chunk` (+3 % at cfg 2, K = 1024).  A taper at the
+        head, or larger chunks, do not help: the two stages take about the same time per step."""
+        n_steps, chunk = int(n_steps), max(int(chunk), 1)
+        sched = [chunk] * (n_steps // chunk)
+        tail = n_steps - chunk * len(sched)
+        if tail == 0 and sched:
+            tail = sched.pop()
+        while tail > 16:
+            piece = max(16, (tail // 2) // 16 * 16)
+            sched.append(piece)
+            tail -= piece
+        if tail:
+            sched.append(tail)
+        return sched
 
     def _make_streams(self):
         """Two HIP streams: trajectory kernel / firing-rate kernels.  (CU-masked streams,

@@ -52,6 +52,17 @@ def agent():
                           f"{B * T / ms / 1e6:.1f} M agent-steps/s", flush=True)
 
 
+def agent_t():
+    """Launch duration of the motion kernel vs steps per launch (B = 4096, open box, f64, Philox)."""
+    B = 4096
+    np.random.seed(0)
+    ag = riab.Agent(riab.Environment(), {"n_agents": B, "dt": 0.01, "save_history": True})
+    hist = torch.empty((256, 8, B), dtype=torch.float32, device="cuda")
+    for T in (1, 4, 15, 16, 32, 64, 128, 256):
+        ms = timeit(lambda: ag._advance(T, None, None, 1, {}, hist_view=hist[:T]))
+        print(f"agent_step T={T}: {ms * 1e3:.1f} us/launch  {ms / T * 1e3:.2f} us/step", flush=True)
+
+
 def fill():
     for gb in (0.25, 1, 4):
         n = int(gb * (1 << 30))
