@@ -63,6 +63,25 @@ def agent_t():
         print(f"agent_step T={T}: {ms * 1e3:.1f} us/launch  {ms / T * 1e3:.2f} us/step", flush=True)
 
 
+def hostio():
+    """The host-buffer form of the boundary: get_state(pos=host array) -> host float64 array (upload of the
+    positions, kernel, download + widening of the (n, P) rates) against the device-resident form."""
+    np.random.seed(0)
+    ag = riab.Agent(riab.Environment(), {"n_agents": 4, "dt": 0.01})
+    pcs = riab.PlaceCells(ag, {"n": 1024, "wall_geometry": "euclidean"})
+    P = 4096
+    pos = np.random.rand(P, 2)
+    for _ in range(3):
+        out = pcs.get_state(evaluate_at=None, pos=pos)
+    t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        out = pcs.get_state(evaluate_at=None, pos=pos)
+    dt = (time.perf_counter() - t0) / reps
+    print(f"get_state host->host, {P} positions x 1024 PlaceCells: {dt * 1e3:.2f} ms  {P / dt / 1e6:.2f} M positions/s "
+          f"({out.nbytes / 2 / dt / 1e9:.2f} GB/s of fp32 rates over PCIe incl. fp64 widening on the host)", flush=True)
+
+
 def fill():
     for gb in (0.25, 1, 4):
         n = int(gb * (1 << 30))
