@@ -18,6 +18,7 @@
 namespace riab {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct BvcArgs {
   const float* pos_x;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
       tc[j] = as_const_table(a.vm + (int64_t)c * Kp);
       ts[j] = as_const_table(a.vm + ((int64_t)n + c) * Kp);
     }
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    v2f acc2[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
     // register double-buffering: the d values and table entries of step k+4 are requested before
     // the 16 exponentials of step k are issued, so LDS / scalar-cache latency hides under them
     float d[4], vc[4][4], vs[4][4];
@@ -144,15 +145,24 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
           vcn[j][i] = tc[j][kn + i];
           if (EGO) vsn[j][i] = ts[j][kn + i];
         }
+      // the three non-transcendental operations of a term are issued as packed fp32 (v_pk_fma_f32,
+      // v_pk_add_f32: two terms per instruction); only the exp2 itself stays one per term
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float tt = fmaf(d[i], aa[j], nmu[j]);
-          float v;
-          if (EGO) v = kap[j] * (fmaf(vc[j][i], ch, vs[j][i] * sh) - 1.0f);
-          else v = vc[j][i];
-          acc[j] += __builtin_amdgcn_exp2f(fmaf(-tt, tt, v));
+        for (int i = 0; i < 4; i += 2) {
+          const v2f dd = {d[i], d[i + 1]};
+          const v2f tt = __builtin_elementwise_fma(dd, v2f{aa[j], aa[j]}, v2f{nmu[j], nmu[j]});
+          v2f v;
+          if (EGO) {
+            const v2f c2 = {vc[j][i], vc[j][i + 1]}, s2 = {vs[j][i], vs[j][i + 1]};
+            const v2f rot = __builtin_elementwise_fma(c2, v2f{ch, ch}, s2 * v2f{sh, sh});
+            v = v2f{kap[j], kap[j]} * (rot - v2f{1.0f, 1.0f});
+          } else {
+            v = v2f{vc[j][i], vc[j][i + 1]};
+          }
+          const v2f e = __builtin_elementwise_fma(-tt, tt, v);
+          acc2[j] += v2f{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
         }
       }
 #pragma unroll
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
     for (int j = 0; j < 4; ++j) {
       const int c = 4 * g + j;
       if (c < n && live) {
-        float r = acc[j] * a.inv_norm[c];
+        float r = (acc2[j].x + acc2[j].y) * a.inv_norm[c];
         r = r * a.fr_scale + a.fr_min;
         const int64_t off = (t * n + c) * a.B + b;
         a.rates[off] = r;
