@@ -123,28 +123,28 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
     v2f acc2[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
     // register double-buffering: the d values and table entries of step k+4 are requested before
     // the 16 exponentials of step k are issued, so LDS / scalar-cache latency hides under them
-    float d[4], vc[4][4], vs[4][4];
+    // (table rows are read four directions at a time: one s_load_dwordx4 per cell and iteration)
+    typedef const __attribute__((address_space(4))) v4f* const_v4f_ptr;
+    float d[4];
+    v4f vc[4], vs[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) d[i] = s_d[i * 64 + lane];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        vc[j][i] = tc[j][i];
-        if (EGO) vs[j][i] = ts[j][i];
-      }
+    for (int j = 0; j < 4; ++j) {
+      vc[j] = *(const_v4f_ptr)(tc[j]);
+      if (EGO) vs[j] = *(const_v4f_ptr)(ts[j]);
+    }
     for (int k = 0; k < Kp; k += 4) {
       const int kn = (k + 4 < Kp) ? k + 4 : k;
-      float dn[4], vcn[4][4], vsn[4][4];
+      float dn[4];
+      v4f vcn[4], vsn[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) dn[i] = s_d[(kn + i) * 64 + lane];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          vcn[j][i] = tc[j][kn + i];
-          if (EGO) vsn[j][i] = ts[j][kn + i];
-        }
+      for (int j = 0; j < 4; ++j) {
+        vcn[j] = *(const_v4f_ptr)(tc[j] + kn);
+        if (EGO) vsn[j] = *(const_v4f_ptr)(ts[j] + kn);
+      }
       // the three non-transcendental operations of a term are issued as packed fp32 (v_pk_fma_f32,
       // v_pk_add_f32: two terms per instruction); only the exp2 itself stays one per term
 #pragma unroll
@@ -168,12 +168,10 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) d[i] = dn[i];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          vc[j][i] = vcn[j][i];
-          if (EGO) vs[j][i] = vsn[j][i];
-        }
+      for (int j = 0; j < 4; ++j) {
+        vc[j] = vcn[j];
+        if (EGO) vs[j] = vsn[j];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
