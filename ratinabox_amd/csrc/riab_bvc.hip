@@ -70,24 +70,44 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
   // ---- stage A: first-wall distance along each test direction (Neurons.py:1655-1684, 1746-1778)
   // utils.vector_intercepts (utils.py:96-97) with sa = unit ray, sb = wall:
   //   l_a = (d0 . sb_p) / (sa . sb_p),  l_b = (-d0 . sa_p) / (sb . sa_p),  sb . sa_p = -(sa . sb_p)
-  for (int k = wave; k < K; k += 8) {
-    const double ux = dirs[2 * k], uy = dirs[2 * k + 1];
-    double best = INFINITY;  // smallest valid l_a == largest preference 1/l_a; first index wins ties
-    double fallback = 0.0;
+  // Four test directions per pass over the walls: the wall-only quantities (d0, its cross product
+  // with the wall) are computed once per wall and pass, leaving 1 + 3 multiply-adds per (ray, wall).
+  constexpr int KB = 4;
+  for (int k0 = wave; k0 < K; k0 += 8 * KB) {
+    double ux[KB], uy[KB], best[KB], fallback[KB];
+    int kk[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      kk[i] = min(k0 + 8 * i, K - 1);  // (wave-uniform; a clamped duplicate is computed but not stored)
+      ux[i] = dirs[2 * kk[i]];
+      uy[i] = dirs[2 * kk[i] + 1];
+      best[i] = INFINITY;  // smallest valid l_a == largest preference 1/l_a; first index wins ties
+      fallback[i] = 0.0;
+    }
     for (int w = 0; w < nw; ++w) {
       const double ax = walls[4 * w], ay = walls[4 * w + 1];
       const double sx = walls[4 * w + 2] - ax, sy = walls[4 * w + 3] - ay;
       const double d0x = ax - px, d0y = ay - py;
-      const double rd = rden[k * nw + w];
-      const double la = (d0x * (-sy) + d0y * sx) * rd;
-      const double lb = ((-d0x) * (-uy) + (-d0y) * ux) * (-rd);
-      const bool valid = (la > 0.0) && !(lb < 0.0) && !(lb > 1.0);
-      if (valid && la < best) best = la;
-      if (w == 0) fallback = la;  // argmax over all -1 preferences picks wall 0
+      const double num_a = d0x * (-sy) + d0y * sx;
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        const double rd = rden[kk[i] * nw + w];
+        const double la = num_a * rd;
+        const double lb = ((-d0x) * (-uy[i]) + (-d0y) * ux[i]) * (-rd);
+        const bool valid = (la > 0.0) && !(lb < 0.0) && !(lb > 1.0);
+        if (valid && la < best[i]) best[i] = la;
+        if (w == 0) fallback[i] = la;  // argmax over all -1 preferences picks wall 0
+      }
     }
-    const float d = (float)((best < INFINITY) ? best : fallback);
-    s_d[k * 64 + lane] = d;
-    if (a.ray_out && live) a.ray_out[(t * K + k) * a.B + b] = d;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const int k = k0 + 8 * i;
+      if (k < K) {
+        const float d = (float)((best[i] < INFINITY) ? best[i] : fallback[i]);
+        s_d[k * 64 + lane] = d;
+        if (a.ray_out && live) a.ray_out[(t * K + k) * a.B + b] = d;
+      }
+    }
   }
   for (int k = K + wave; k < a.Kp; k += 8) s_d[k * 64 + lane] = 0.0f;  // pad rows meet table entries of -inf
   __syncthreads();
