@@ -29,6 +29,10 @@
 namespace riab {
 
 typedef unsigned __int128 u128;
+// the staged goal pool is read with LDS instructions proper (ds_read): a generic pointer would compile
+// to flat loads, whose completion is tracked by vmcnt as well — every goal-row read would then also
+// wait for the reward rows stored just before it
+typedef const __attribute__((address_space(3))) double* lds_f64_ptr;
 
 struct TaskArgs {
   const double* walls;  // [n_walls][4]
@@ -113,15 +117,21 @@ __device__ __forceinline__ double reward_delta(int preset, double knob, double s
 }
 
 // the Reward template (init_state, dt, expire_clock, preset, knob) a goal hands out
-__device__ __forceinline__ const double* reward_of(const TaskArgs& a, int src) {
-  return src == RIAB_GOAL_TIME_ELAPSED ? a.pad_reward : a.goals + (int64_t)src * RIAB_GOAL_COLS + 3;
+struct RewardTpl {
+  double init, dt, expire, knob;
+  int preset;
+};
+__device__ __forceinline__ RewardTpl reward_of(const TaskArgs& a, lds_f64_ptr goals, int src) {
+  if (src == RIAB_GOAL_TIME_ELAPSED) return {a.pad_reward[0], a.pad_reward[1], a.pad_reward[2], a.pad_reward[4], (int)a.pad_reward[3]};
+  const lds_f64_ptr r = goals + src * RIAB_GOAL_COLS + 3;
+  return {r[0], r[1], r[2], r[4], (int)r[3]};
 }
 
 // SpatialGoal._in_goal_radius (:1319-1332): line_of_sight distance < radius, i.e. the euclidean
 // distance unless a wall of walls[4:] crosses the segment agent -> goal (Environment.py:715-722: the
 // distance becomes 1000, which no radius reaches in practice but is compared all the same).  The
 // reference asserts solid boundaries for this geometry (Environment.py:710-713); so does the host.
-__device__ bool in_goal_radius(const TaskArgs& a, double px, double py, const double* g) {
+__device__ bool in_goal_radius(const TaskArgs& a, double px, double py, lds_f64_ptr g) {
   const double gx = g[0], gy = g[1], radius = g[2];
   const double vx = px - gx, vy = py - gy;
   double dist = sqrt(vx * vx + vy * vy);
@@ -137,34 +147,34 @@ __device__ bool in_goal_radius(const TaskArgs& a, double px, double py, const do
 }
 
 // RewardCache.append (:902-911): a copy of the goal's reward joins the end of the cache
-__device__ void award(const TaskArgs& a, int64_t b, Lane& L, int src, int32_t* diag) {
+__device__ void award(const TaskArgs& a, lds_f64_ptr goals, int64_t b, Lane& L, int src, int32_t* diag) {
   if (L.n_rw >= RIAB_TASK_MAX_REWARDS) {
     atomicAdd(diag + RIAB_TD_REWARD_OVERFLOW, 1);
     return;
   }
-  const double* r = reward_of(a, src);
-  ts_at(a, RIAB_TS_RW_STATE + L.n_rw, b) = r[0];
-  ts_at(a, RIAB_TS_RW_EXPIRE + L.n_rw, b) = r[2];
+  const RewardTpl r = reward_of(a, goals, src);
+  ts_at(a, RIAB_TS_RW_STATE + L.n_rw, b) = r.init;
+  ts_at(a, RIAB_TS_RW_EXPIRE + L.n_rw, b) = r.expire;
   ts_at(a, RIAB_TS_RW_SRC + L.n_rw, b) = (double)src;
   L.n_rw += 1;
-  L.new_total = L.new_total + r[0];
+  L.new_total = L.new_total + r.init;
 }
 
-__device__ bool goal_met(const TaskArgs& a, const Lane& L, int src, double t_env) {
+__device__ bool goal_met(const TaskArgs& a, lds_f64_ptr goals, const Lane& L, int src, double t_env) {
   if (src == RIAB_GOAL_TIME_ELAPSED)  // TimeElapsedGoal.check (:1271-1278)
     return t_env - L.pad_start >= a.terminate_delay;
-  return in_goal_radius(a, L.px, L.py, a.goals + (int64_t)src * RIAB_GOAL_COLS);
+  return in_goal_radius(a, L.px, L.py, goals + src * RIAB_GOAL_COLS);
 }
 
 // One GoalCache.check(remove_finished=True) for the lane (:1076-1152); returns goals consumed.
-__device__ int check_pass(const TaskArgs& a, int64_t b, Lane& L, double t_env, int32_t* diag) {
+__device__ int check_pass(const TaskArgs& a, lds_f64_ptr goals, int64_t b, Lane& L, double t_env, int32_t* diag) {
   int done = 0;
   if (L.n_goals == 0) return 0;
   if (a.goalorder == RIAB_GOALORDER_SEQUENTIAL) {
     // `this` = last achieved + 1 is always the head of the list: pop() rewinds the marker (:1161-1163)
     const int src = list_get(L.list, 0);
-    if (goal_met(a, L, src, t_env)) {
-      award(a, b, L, src, diag);
+    if (goal_met(a, goals, L, src, t_env)) {
+      award(a, goals, b, L, src, diag);
       L.list = list_pop(L.list, 0);
       L.n_goals -= 1;
       L.list_dirty = true;
@@ -175,8 +185,8 @@ __device__ int check_pass(const TaskArgs& a, int64_t b, Lane& L, double t_env, i
   int g = 0;
   while (g < L.n_goals) {  // :1130-1141: g advances after a pop too, so the goal that slid into slot g waits a pass
     const int src = list_get(L.list, g);
-    if (goal_met(a, L, src, t_env)) {
-      award(a, b, L, src, diag);
+    if (goal_met(a, goals, L, src, t_env)) {
+      award(a, goals, b, L, src, diag);
       L.list = list_pop(L.list, g);
       L.n_goals -= 1;
       L.list_dirty = true;
@@ -189,38 +199,57 @@ __device__ int check_pass(const TaskArgs& a, int64_t b, Lane& L, double t_env, i
 
 // RewardCache.update (:913-927) as an out-of-place compaction; returns the python sum() of the
 // surviving states (left to right from 0).  `cache.remove` while iterating makes the iterator skip
-// the reward after an expired one: it is carried over untouched.
-__device__ double rewards_update(const TaskArgs& a, int64_t b, Lane& L) {
+// the reward after an expired one: it is carried over untouched.  The first RW_PRE entries were
+// fetched with the lane's first batch of loads (`pre`): walking the cache costs no further global
+// round trips unless more than RW_PRE rewards are active.
+constexpr int RW_PRE = 4;
+struct RewardRows {
+  double state[RW_PRE], expire[RW_PRE], src[RW_PRE];
+};
+
+__device__ __forceinline__ void load_rewards(const TaskArgs& a, int64_t b, RewardRows& pre) {
+#pragma unroll
+  for (int i = 0; i < RW_PRE; ++i) {
+    pre.state[i] = ts_at(a, RIAB_TS_RW_STATE + i, b);
+    pre.expire[i] = ts_at(a, RIAB_TS_RW_EXPIRE + i, b);
+    pre.src[i] = ts_at(a, RIAB_TS_RW_SRC + i, b);
+  }
+}
+
+__device__ double rewards_update(const TaskArgs& a, lds_f64_ptr goals, int64_t b, Lane& L, const RewardRows& pre) {
   double total = 0.0;
-  int w = 0, i = 0;
+  int w = 0;
+  bool skip = false;  // the previous reward expired: this one is carried over untouched
   const int nr = L.n_rw;
-  while (i < nr) {
-    const int src = (int)ts_at(a, RIAB_TS_RW_SRC + i, b);
-    double state = ts_at(a, RIAB_TS_RW_STATE + i, b);
-    double expire = ts_at(a, RIAB_TS_RW_EXPIRE + i, b);
-    const double* r = reward_of(a, src);
-    const double rdt = r[1];
-    state = state + reward_delta((int)r[3], r[4], state) * rdt;  // Reward.update (:817-821)
+  auto visit = [&](int i, double state, double expire, double srcd) {
+    if (skip) {
+      ts_at(a, RIAB_TS_RW_STATE + w, b) = state;
+      ts_at(a, RIAB_TS_RW_EXPIRE + w, b) = expire;
+      ts_at(a, RIAB_TS_RW_SRC + w, b) = srcd;
+      total = total + state;
+      w += 1;
+      skip = false;
+      return;
+    }
+    const RewardTpl r = reward_of(a, goals, (int)srcd);
+    const double rdt = r.dt;
+    state = state + reward_delta(r.preset, r.knob, state) * rdt;  // Reward.update (:817-821)
     expire -= rdt;
     if (expire <= 0.0) {
-      if (i + 1 < nr) {
-        const double s2 = ts_at(a, RIAB_TS_RW_STATE + i + 1, b);
-        ts_at(a, RIAB_TS_RW_STATE + w, b) = s2;
-        ts_at(a, RIAB_TS_RW_EXPIRE + w, b) = ts_at(a, RIAB_TS_RW_EXPIRE + i + 1, b);
-        ts_at(a, RIAB_TS_RW_SRC + w, b) = ts_at(a, RIAB_TS_RW_SRC + i + 1, b);
-        total = total + s2;
-        w += 1;
-      }
-      i += 2;
+      skip = true;
     } else {
       ts_at(a, RIAB_TS_RW_STATE + w, b) = state;
       ts_at(a, RIAB_TS_RW_EXPIRE + w, b) = expire;
-      if (w != i) ts_at(a, RIAB_TS_RW_SRC + w, b) = (double)src;
+      if (w != i) ts_at(a, RIAB_TS_RW_SRC + w, b) = srcd;
       total = total + state;
       w += 1;
-      i += 1;
     }
-  }
+  };
+#pragma unroll
+  for (int i = 0; i < RW_PRE; ++i)
+    if (i < nr) visit(i, pre.state[i], pre.expire[i], pre.src[i]);
+  for (int i = RW_PRE; i < nr; ++i)
+    visit(i, ts_at(a, RIAB_TS_RW_STATE + i, b), ts_at(a, RIAB_TS_RW_EXPIRE + i, b), ts_at(a, RIAB_TS_RW_SRC + i, b));
   L.n_rw = w;
   return total;
 }
@@ -317,7 +346,7 @@ __device__ void reset_lane(const TaskArgs& a, const ResetArgs& r, int64_t b, Lan
 // get_goal_vector (:1555-1584): goal - position for the head of the list (sequential) or the nearest
 // pending spatial goal; (0,0) when none is pending.  scale > 0: scale * unit vector instead (the
 // scripted policy of the reference's test loop, :1599-1605, with its NaN -> 0 of :403-404).
-__device__ void goal_vector(const TaskArgs& a, const Lane& L, double scale, double* vx_out, double* vy_out) {
+__device__ void goal_vector(const TaskArgs& a, lds_f64_ptr goals, const Lane& L, double scale, double* vx_out, double* vy_out) {
   double vx = 0.0, vy = 0.0, best = INFINITY;
   for (int g = 0; g < L.n_goals; ++g) {
     const int src = list_get(L.list, g);
@@ -325,7 +354,7 @@ __device__ void goal_vector(const TaskArgs& a, const Lane& L, double scale, doub
       if (a.goalorder == RIAB_GOALORDER_SEQUENTIAL) break;
       continue;
     }
-    const double* gl = a.goals + (int64_t)src * RIAB_GOAL_COLS;
+    const lds_f64_ptr gl = goals + src * RIAB_GOAL_COLS;
     const double dx = gl[0] - L.px, dy = gl[1] - L.py;
     const double d = sqrt(dx * dx + dy * dy);
     if (d < best) {  // strict: the first of equidistant goals, like argmin
@@ -372,8 +401,10 @@ __global__ __launch_bounds__(64) void task_kernel(TaskArgs a, ResetArgs r, const
   L.py = pos_y[b];
   L.new_total = 0.0;
   load_list(a, b, L);
+  RewardRows pre;
+  if (STEP) load_rewards(a, b, pre);
   __syncthreads();
-  a.goals = s_goals;  // (generic pointer to LDS: every later a.goals[...] reads the staged copy)
+  const lds_f64_ptr goals = (lds_f64_ptr)s_goals;
   const int n_goals0 = L.n_goals, n_rw0 = L.n_rw;
   const bool delayed0 = L.delayed;
   bool terminal_last = false;
@@ -382,11 +413,11 @@ __global__ __launch_bounds__(64) void task_kernel(TaskArgs a, ResetArgs r, const
     const double steps_active = ts_at(a, RIAB_TS_STEPS_ACTIVE, b), steps_inactive = ts_at(a, RIAB_TS_STEPS_INACTIVE, b);
     // ---- RewardCache.update (:913-927)
     double total = 0.0;
-    if (n_rw0 > 0) total = rewards_update(a, b, L);
+    if (n_rw0 > 0) total = rewards_update(a, goals, b, L, pre);
     if (n_rw0 > 0) ts_at(a, RIAB_TS_STEPS_ACTIVE, b) = steps_active + 1.0;
     else ts_at(a, RIAB_TS_STEPS_INACTIVE, b) = steps_inactive + 1.0;
     // ---- goals: _is_terminal_state (:278-290) as step() calls it (:418-440)
-    check_pass(a, b, L, t_env, diag);
+    check_pass(a, goals, b, L, t_env, diag);
     bool terminal = L.n_goals == 0;
     if (terminal && a.terminate_delay != 0.0 && !L.delayed) {
       // :421-434: one unrewarded TimeElapsedGoal pads the episode
@@ -395,10 +426,10 @@ __global__ __launch_bounds__(64) void task_kernel(TaskArgs a, ResetArgs r, const
       L.list = list_set(L.list, 0, RIAB_GOAL_TIME_ELAPSED);
       L.n_goals = 1;
       L.list_dirty = true;
-      check_pass(a, b, L, t_env, diag);
+      check_pass(a, goals, b, L, t_env, diag);
       terminal = L.n_goals == 0;
     }
-    const int late = check_pass(a, b, L, t_env, diag);  // the pass of the `for agent, term in ...` loop (:438)
+    const int late = check_pass(a, goals, b, L, t_env, diag);  // the pass of the `for agent, term in ...` loop (:438)
     terminal_last = L.n_goals == 0;
     if (late > 0 && terminal_last && !terminal) atomicAdd(diag + RIAB_TD_LATE_COMPLETIONS, 1);
     // ---- RewardCache.get_total (:929-939): survivors, then this step's awards, then the default level
@@ -410,7 +441,7 @@ __global__ __launch_bounds__(64) void task_kernel(TaskArgs a, ResetArgs r, const
     terminal_out[b] = terminal_last ? 1 : 0;
   }
   if (RESET && (STEP ? terminal_last : true)) reset_lane(a, r, b, L, t_env, diag);
-  if (GOALVEC) goal_vector(a, L, gv_scale, gv_x + b, gv_y + b);
+  if (GOALVEC) goal_vector(a, goals, L, gv_scale, gv_x + b, gv_y + b);
   // ---- write back what changed
   if (STEP || RESET) {
     if (L.n_goals != n_goals0) ts_at(a, RIAB_TS_N_GOALS, b) = (double)L.n_goals;
