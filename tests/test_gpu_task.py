@@ -252,3 +252,52 @@ def test_task_step_plan_equals_eager_loop(riab):
             np.testing.assert_allclose(v[b], pool[lists[b, 0]] - A1.pos[b], rtol=0, atol=1e-15)  # sequential: the head
         else:
             assert np.all(v[b] == 0)
+
+
+@pytest.mark.parametrize("goalorder", ["nonsequential", "sequential"])
+def test_task_maximum_sizes(riab, goalorder):
+    """64 goals in the pool, 15 per episode (+ the termination-delay goal = all 16 list slots), large
+    radii so that several goals are consumed per step at every list position: the packed 16-byte goal
+    list, Philox sampling and reward cache against the oracle's TaskLane for a handful of lanes."""
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment, Reward
+    np.random.seed(8)
+    B, T = 130, 400
+    pool = np.random.rand(64, 2) * 0.9 + 0.05
+    env = SpatialGoalEnvironment(possible_goal_positions=pool,
+                                 goalkws=dict(goal_radius=0.22, reward=Reward(0.5, dt=0.01, expire_clock=0.04, decay="constant",
+                                                                              decay_knobs=[0.3])),
+                                 goalcachekws=dict(reset_n_goals=15, goalorder=goalorder),
+                                 episode_terminate_delay=0.02, teleport_on_reset=True, seed=21)
+    Ag = riab.Agent(env, {"dt": 0.01, "n_agents": B, "seed": 2})
+    env.add_agents(Ag)
+    lists = env.goal_cache.goal_lists()
+    assert lists.shape == (B, 16) and (lists[:, :15] >= 0).all() and (lists[:, 15] == -1).all()
+    assert all(len(set(r[:15])) == 15 for r in lists)
+    table = np.array([[g.pos[0], g.pos[1], g.radius] + g.reward.row() for g in env.goal_cache.get_goals()])
+    probe = [0, 63, 64, 129]
+    lanes = {b: orc.TaskLane(orc.EnvSpec(), table, goalorder, 0.02) for b in probe}
+    for b in probe:
+        assert list(lists[b, :15]) == orc.task_reset_draws(21, 1, b, 64, 15)
+        lanes[b].reset(0.0, lists[b, :15])
+    t, max_rw, resets = 0.0, 0, 0
+    for k in range(T):
+        a = env._goal_vector(30 * 0.08)
+        obs, rew, term, _, _ = env.step(a, drift_to_random_strength_ratio=4)
+        t = t + 0.01
+        o, r, tm = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+        nrw = Ag.reward.active()[2].cpu().numpy()
+        max_rw = max(max_rw, int(nrw.max()))
+        for b in probe:
+            total, terminal = lanes[b].step(o[b], t)
+            assert total == r[b] and terminal == tm[b] and len(lanes[b].rewards) == nrw[b], (k, b)
+        env.reset(mask=term)
+        sel = env.goal_cache.goal_lists()
+        for b in probe:
+            if tm[b]:
+                resets += 1
+                assert list(sel[b, :15]) == orc.task_reset_draws(21, env._reset_counter, b, 64, 15)
+                lanes[b].reset(t, sel[b, :15])
+            want = lanes[b].goal_list
+            assert list(sel[b, :len(want)]) == [g if g >= 0 else -2 for g in want], (k, b)
+    assert env.diagnostics["resets"] > B and max_rw >= 4   # episodes of 15 goals were completed
+    assert env.diagnostics["reward_overflow"] == 0
