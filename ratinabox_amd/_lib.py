@@ -174,5 +174,10 @@ def ptr(t):
 
 
 def current_stream():
+    """hipStream_t of torch's current stream on the current device (the raw handle straight from the C
+    API: torch.cuda.current_stream() costs ~8 us of Python per call, this ~0.5 us)."""
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return C.c_void_p(raw(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
