@@ -22,6 +22,7 @@
 namespace riab {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct RateArgs {
   const float* pos_x;
@@ -307,27 +308,31 @@ struct GridCell {
   __device__ __forceinline__ Pos load(const RateArgs& a, int64_t off) const {
     return Pos{ldv4(a.pos_x + off), ldv4(a.pos_y + off)};
   }
-  __device__ __forceinline__ float one(const float* p, float x, float y) const {
-    float s = 0.0f;
+  // two agents per instruction: the phase arithmetic and the final affine map are packed fp32
+  // (v_pk_mul / v_pk_fma / v_pk_add); v_fract and v_cos stay one per term
+  __device__ __forceinline__ v2f two(const float* p, v2f x, v2f y) const {
+    v2f s = {0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      float rev = p[3 * i] - fmaf(x, p[3 * i + 1], y * p[3 * i + 2]);
-      rev -= floorf(rev);  // v_fract: keep the hardware cosine in its accurate range
-      s += __builtin_amdgcn_cosf(rev);
+      const v2f p0 = {p[3 * i], p[3 * i]}, p1 = {p[3 * i + 1], p[3 * i + 1]}, p2 = {p[3 * i + 2], p[3 * i + 2]};
+      v2f rev = p0 - __builtin_elementwise_fma(x, p1, y * p2);
+      rev.x -= floorf(rev.x);  // v_fract: keep the hardware cosine in its accurate range
+      rev.y -= floorf(rev.y);
+      s += v2f{__builtin_amdgcn_cosf(rev.x), __builtin_amdgcn_cosf(rev.y)};
     }
-    s *= (1.0f / 3.0f);
-    if (DESC == RIAB_GC_RECTIFIED) return fmaxf((s - f0) * inv_1mf0, 0.0f);
-    return (2.0f / 3.0f) * (s + 0.5f);
+    s *= v2f{1.0f / 3.0f, 1.0f / 3.0f};
+    if (DESC == RIAB_GC_RECTIFIED) {
+      const v2f r = (s - v2f{f0, f0}) * v2f{inv_1mf0, inv_1mf0};
+      return v2f{fmaxf(r.x, 0.0f), fmaxf(r.y, 0.0f)};
+    }
+    return v2f{2.0f / 3.0f, 2.0f / 3.0f} * (s + v2f{0.5f, 0.5f});
   }
   static constexpr int NP = 9;
   static constexpr int CPB = 4;
   __device__ __forceinline__ v4f eval(const float* p, const Pos& P) const {
-    v4f r;
-    r.x = one(p, P.x.x, P.y.x);
-    r.y = one(p, P.x.y, P.y.y);
-    r.z = one(p, P.x.z, P.y.z);
-    r.w = one(p, P.x.w, P.y.w);
-    return r;
+    const v2f lo = two(p, v2f{P.x.x, P.x.y}, v2f{P.y.x, P.y.y});
+    const v2f hi = two(p, v2f{P.x.z, P.x.w}, v2f{P.y.z, P.y.w});
+    return v4f{lo.x, lo.y, hi.x, hi.y};
   }
 };
 
