@@ -272,7 +272,8 @@ int riab_feedforward(const RiabFFInput* inputs, int32_t n_inputs, const float* b
  * cell 4; contribs/TaskEnvironment.py:399-408) recorded once, then advanced by riab_plan_step:
  * row cursors, RNG counters and pointers are kept in C++, every kernel of every step is enqueued on
  * `stream`, nothing is allocated or synchronised. */
-enum { RIAB_POP_PLACE = 0, RIAB_POP_GRID = 1, RIAB_POP_HDC = 2, RIAB_POP_BVC = 3, RIAB_POP_OVC = 4 };
+enum { RIAB_POP_PLACE = 0, RIAB_POP_GRID = 1, RIAB_POP_HDC = 2, RIAB_POP_BVC = 3, RIAB_POP_OVC = 4, RIAB_POP_FF = 5 };
+#define RIAB_FF_MAX_INPUTS 8
 
 typedef struct RiabPopulation {
   int32_t kind;              /* RIAB_POP_* */
@@ -296,6 +297,19 @@ typedef struct RiabPopulation {
   const int32_t* object_types; /* ovc */
   int32_t n_objects;         /* ovc */
   int32_t walls_occlude;     /* ovc */
+  /* additive OU noise of Neurons.update (Neurons.py:153-168, riab_neuron_noise); NULL = none */
+  float* noise_state;        /* device float32 [n][B] */
+  float noise_theta_dt;      /* dt / noise_coherence_time */
+  float noise_sigma_dt;      /* sqrt(2 std^2 / (tau dt)) * dt */
+  /* RIAB_POP_FF (FeedForwardLayer, riab_feedforward): the inputs are populations added to the plan
+   * BEFORE this one; each step reads the rows they have just written */
+  int32_t n_inputs;
+  int32_t input_index[RIAB_FF_MAX_INPUTS];      /* plan indices of the input populations */
+  const float* input_wt[RIAB_FF_MAX_INPUTS];    /* their W^T tables (RiabFFInput.wt) */
+  const float* bias;         /* [n] */
+  int32_t activation;        /* RIAB_ACT_* */
+  float act_params[4];
+  float* rates_prime;        /* device float32 [n][B] activation derivative, or NULL */
 } RiabPopulation;
 
 typedef struct RiabPlan RiabPlan;

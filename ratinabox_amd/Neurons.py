@@ -81,19 +81,45 @@ class Neurons:
             pprint.pprint(all_params)
         return all_params
 
-    def _population(self):
-        """This population as the ABI's RiabPopulation (for a step plan); keeps its tables alive."""
-        if self.noise_std != 0 or isinstance(self, FeedForwardLayer):
-            raise NotImplementedError("step plans cover the position-driven populations without noise; "
-                                      "use update() for noise_std > 0 and FeedForwardLayers")
-        f = self._call(None, None)
+    def _population(self, plan_index=None):
+        """This population as the ABI's RiabPopulation (for a step plan); keeps its tables alive.
+        `plan_index`: {Neurons object: index in the plan} of the populations recorded before this one
+        (what a FeedForwardLayer's inputs are looked up in)."""
         pop = _L.RiabPopulation()
-        pop.kind, pop.n = f["kind"], int(self.n)
+        pop.n = int(self.n)
         pop.io.min_fr, pop.io.max_fr, pop.io.pop_id = float(self.min_fr), float(self.max_fr), int(self.pop_id)
-        self._plan_tables = [v for v in f.values() if torch.is_tensor(v)]
-        for k, v in f.items():
-            if k != "kind":
-                setattr(pop, k, v.data_ptr() if torch.is_tensor(v) else v)
+        if isinstance(self, FeedForwardLayer):
+            entries = list(self.inputs.values())
+            if len(entries) > 8:
+                raise ValueError("a FeedForwardLayer in a step plan takes at most 8 input layers")
+            pop.kind, pop.n_inputs = _L.POP_KINDS["ff"], len(entries)
+            keep = []
+            for l, e in enumerate(entries):
+                if plan_index is None or e["layer"] not in plan_index:
+                    raise NotImplementedError(f"input layer {e['layer'].name} must be recorded in the plan before "
+                                              f"{self.name} (recurrent inputs advance through update())")
+                wt = self._device_weights(e)
+                pop.input_index[l], pop.input_wt[l] = plan_index[e["layer"]], wt.data_ptr()
+                keep.append(wt)
+            bias = np.asarray(self.biases, dtype=np.float32).reshape(-1)
+            bias_t = self._tables((bias,), lambda: torch.from_numpy(bias.copy()).to(self._device))
+            act, pars = self._activation()
+            pop.bias, pop.activation, pop.rates_prime = bias_t.data_ptr(), act, self._rates_prime.data_ptr()
+            for i in range(4):
+                pop.act_params[i] = pars[i]
+            self._plan_tables = keep + [bias_t]
+        else:
+            f = self._call(None, None)
+            pop.kind = f["kind"]
+            self._plan_tables = [v for v in f.values() if torch.is_tensor(v)]
+            for k, v in f.items():
+                if k != "kind":
+                    setattr(pop, k, v.data_ptr() if torch.is_tensor(v) else v)
+        if self.noise_std != 0:  # the OU parameters of update() (Neurons.py:153-168), fixed for the plan's dt
+            tau, dt = float(self.noise_coherence_time), float(self.Agent.dt)
+            pop.noise_state = self._noise.data_ptr()
+            pop.noise_theta_dt = dt / tau
+            pop.noise_sigma_dt = float(np.sqrt((2 * float(self.noise_std) ** 2) / (tau * dt))) * dt
         return pop
 
     # ---- attributes -----------------------------------------------------------------------------

@@ -58,7 +58,11 @@ class RiabPopulation(C.Structure):
                 ("description", C.c_int32), ("geometry", C.c_int32), ("top_hat_width", C.c_float), ("f0", C.c_float),
                 ("test_dirs", C.c_void_p), ("ray_rden", C.c_void_p), ("K", C.c_int32), ("egocentric", C.c_int32),
                 ("vm_table", C.c_void_p), ("inv_norm", C.c_void_p), ("objects", C.c_void_p),
-                ("object_types", C.c_void_p), ("n_objects", C.c_int32), ("walls_occlude", C.c_int32)]
+                ("object_types", C.c_void_p), ("n_objects", C.c_int32), ("walls_occlude", C.c_int32),
+                ("noise_state", C.c_void_p), ("noise_theta_dt", C.c_float), ("noise_sigma_dt", C.c_float),
+                ("n_inputs", C.c_int32), ("input_index", C.c_int32 * 8), ("input_wt", C.c_void_p * 8),
+                ("bias", C.c_void_p), ("activation", C.c_int32), ("act_params", C.c_float * 4),
+                ("rates_prime", C.c_void_p)]
 
 
 class RiabTask(C.Structure):
@@ -76,7 +80,7 @@ DECAYS = {"constant": 0, "linear": 1, "exponential": 2, "none": 3}
 GOALORDERS = {"nonsequential": 0, "sequential": 1}
 TD_REWARD_OVERFLOW, TD_LATE_COMPLETIONS, TD_EPLOG_OVERFLOW, TD_RESETS = range(4)
 
-POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4}
+POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4, "ff": 5}
 EFULL = -5
 
 ACTIVATIONS = {"linear": 0, "sigmoid": 1, "relu": 2, "tanh": 3, "retanh": 4, "softmax": 5}

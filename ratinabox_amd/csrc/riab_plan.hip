@@ -98,7 +98,12 @@ extern "C" int riab_plan_set_agent_history(RiabPlan* p, float* hist_base, int64_
 }
 
 extern "C" int riab_plan_add(RiabPlan* p, const RiabPopulation* pop) {
-  if (!p || !pop || pop->n <= 0 || pop->kind < RIAB_POP_PLACE || pop->kind > RIAB_POP_OVC) return RIAB_EINVAL;
+  if (!p || !pop || pop->n <= 0 || pop->kind < RIAB_POP_PLACE || pop->kind > RIAB_POP_FF) return RIAB_EINVAL;
+  if (pop->kind == RIAB_POP_FF) {
+    if (pop->n_inputs <= 0 || pop->n_inputs > RIAB_FF_MAX_INPUTS || !pop->bias) return RIAB_EINVAL;
+    for (int l = 0; l < pop->n_inputs; ++l)  // feed-forward only: an input must already be in the plan
+      if (pop->input_index[l] < 0 || pop->input_index[l] >= (int)p->pops.size() || !pop->input_wt[l]) return RIAB_EINVAL;
+  }
   p->pops.push_back(*pop);
   p->pop_fill.push_back(0);
   return (int)p->pops.size() - 1;
@@ -186,21 +191,55 @@ static int launch_population(RiabPlan* p, size_t i, const float* row, hipStream_
   io.seed = p->seed;
   io.step0 = p->step;  // Neurons.update after the p->step-th Agent.update (the cursor was already advanced)
   io.agent_id0 = p->agent_id0;
+  const bool noisy = q.noise_state != nullptr;
+  uint8_t* const spikes = io.spikes;
+  if (noisy) io.spikes = nullptr;  // spikes are drawn on the final rate, after the noise has been added
+  int rc = RIAB_EINVAL;
   switch (q.kind) {
     case RIAB_POP_PLACE:
-      return riab_place_cells(&p->env, &io, q.table, q.n, q.description, q.geometry, q.top_hat_width, s);
+      rc = riab_place_cells(&p->env, &io, q.table, q.n, q.description, q.geometry, q.top_hat_width, s);
+      break;
     case RIAB_POP_GRID:
-      return riab_grid_cells(&io, q.table, q.n, q.description, q.f0, s);
+      rc = riab_grid_cells(&io, q.table, q.n, q.description, q.f0, s);
+      break;
     case RIAB_POP_HDC:
-      return riab_head_direction_cells(&io, q.table, q.n, s);
+      rc = riab_head_direction_cells(&io, q.table, q.n, s);
+      break;
     case RIAB_POP_BVC:
-      return riab_boundary_vector_cells(&p->env, &io, q.test_dirs, q.ray_rden, q.K, q.table, q.vm_table, q.inv_norm,
-                                        q.n, q.egocentric, nullptr, s);
+      rc = riab_boundary_vector_cells(&p->env, &io, q.test_dirs, q.ray_rden, q.K, q.table, q.vm_table, q.inv_norm, q.n,
+                                      q.egocentric, nullptr, s);
+      break;
     case RIAB_POP_OVC:
-      return riab_object_vector_cells(&p->env, &io, q.objects, q.object_types, q.n_objects, q.table, q.n,
-                                      q.walls_occlude, q.egocentric, s);
+      rc = riab_object_vector_cells(&p->env, &io, q.objects, q.object_types, q.n_objects, q.table, q.n, q.walls_occlude,
+                                    q.egocentric, s);
+      break;
+    case RIAB_POP_FF: {
+      RiabFFInput in[RIAB_FF_MAX_INPUTS];
+      for (int l = 0; l < q.n_inputs; ++l) {
+        const int j = q.input_index[l];
+        const RiabPopulation& src = p->pops[j];
+        // population j < i has been launched this step already: its cursor points past the row it wrote
+        const int64_t row_j = src.capacity_rows > 0 ? p->pop_fill[j] - 1 : 0;
+        in[l].rates = src.rates_base + row_j * (int64_t)src.n * B;
+        in[l].wt = q.input_wt[l];
+        in[l].n_in = src.n;
+      }
+      rc = riab_feedforward(in, q.n_inputs, q.bias, q.n, 1, B, q.activation, q.act_params, io.rates, q.rates_prime, s);
+      if (rc == RIAB_OK && io.spikes) rc = riab_spikes(&io, q.n, s);
+      break;
+    }
   }
-  return RIAB_EINVAL;
+  if (rc) return rc;
+  if (noisy) {
+    rc = riab_neuron_noise(q.noise_state, io.rates, nullptr, q.n, B, 1, q.noise_theta_dt, q.noise_sigma_dt, p->seed, p->step,
+                           q.io.pop_id, p->agent_id0, s);
+    if (rc) return rc;
+    if (spikes) {
+      io.spikes = spikes;
+      rc = riab_spikes(&io, q.n, s);
+    }
+  }
+  return rc;
 }
 
 extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream) {

@@ -9,8 +9,10 @@
 (csrc/riab_plan.hip).  Histories are written into rows opened in the same device chunks the eager
 path uses; the Python mirrors (`history`, `firingrate`, `_times`) are brought up to date lazily by
 `sync()` (called automatically by the accessors).  Results are identical to the eager loop: same
-kernels, same arguments, same RNG counters.  Populations with `noise_std > 0` and
-FeedForwardLayers are not covered (use `update()`)."""
+kernels, same arguments, same RNG counters.  Populations with `noise_std > 0` are covered (their OU
+parameters are fixed at the plan's dt), FeedForwardLayers too as long as their input layers are
+recorded before them (weights are read from the device copies made when the plan is built:
+rebuild the plan after editing `inputs[...]["w"]`)."""
 import numpy as np
 import torch
 
@@ -42,8 +44,10 @@ class StepPlan:
         if not self._h:
             raise _L.RiabError("riab_plan_create failed")
         self._pops = []
+        index = {}
         for N in self.neurons:
-            pop = N._population()
+            pop = N._population(index)
+            index[N] = len(index)
             idx = _L.lib.riab_plan_add(self._h, pop)
             if idx < 0:
                 raise _L.RiabError(f"riab_plan_add failed: {_L.strerror(idx)}")

@@ -687,6 +687,47 @@ def test_step_plan_equals_eager_loop(riab, save):
         plan.step()
 
 
+@pytest.mark.parametrize("save", [True, False])
+def test_step_plan_with_noise_and_feedforward_layers(riab, save):
+    """Populations with OU noise (+ spikes drawn on the noisy rate) and a two-level FeedForwardLayer stack
+    recorded in a step plan == the eager update() loop, bit for bit."""
+    def world():
+        np.random.seed(31)
+        env = make_env(riab, [[[0.5, 0.0], [0.5, 0.5]]])
+        Ag = riab.Agent(env, {"n_agents": 70, "dt": 0.02, "seed": 5, "save_history": save})
+        pcs = riab.PlaceCells(Ag, {"n": 33, "noise_std": 0.2, "noise_coherence_time": 0.3, "save_history": save, "max_fr": 10})
+        hdc = riab.HeadDirectionCells(Ag, {"n": 7, "save_history": save, "save_spikes": False})
+        ff1 = riab.FeedForwardLayer(Ag, {"n": 40, "input_layers": [pcs, hdc], "name": "hidden", "save_history": save,
+                                         "activation_function": {"activation": "tanh", "gain": 1.5, "threshold": 0.1},
+                                         "noise_std": 0.05, "max_fr": 5})
+        ff2 = riab.FeedForwardLayer(Ag, {"n": 3, "input_layers": [ff1], "name": "readout", "save_history": save,
+                                         "activation_function": {"activation": "sigmoid", "max_fr": 4, "mid_x": 0.5, "width_x": 2},
+                                         "biases": np.array([0.1, -0.2, 0.3]), "save_spikes": False})
+        return Ag, [pcs, hdc, ff1, ff2]
+    A1, P1 = world()
+    for i in range(11):
+        A1.update()
+        for p in P1:
+            p.update()
+    A2, P2 = world()
+    plan = A2.make_step_plan(capacity=4)
+    for i in range(11):
+        plan.step()
+    assert np.array_equal(A2.pos, A1.pos)
+    for a, b in zip(P1, P2):
+        assert np.array_equal(a.firingrate, b.firingrate), a.name
+        assert np.array_equal(a.noise, b.noise), a.name
+    assert np.array_equal(P1[2].firingrate_prime, P2[2].firingrate_prime)
+    assert np.abs(P1[0].noise).max() > 0 and np.abs(P1[3].firingrate).max() > 0
+    if save:
+        for a, b in zip(P1, P2):
+            assert np.array_equal(a.history["firingrate"], b.history["firingrate"]), a.name
+            assert np.array_equal(a.history["spikes"], b.history["spikes"]), a.name
+    # a layer whose input is not in the plan (or comes after it) cannot be recorded
+    with pytest.raises(NotImplementedError):
+        A2.make_step_plan(neurons=[P2[2], P2[0], P2[1]])
+
+
 def test_config5_shape_mixed_population_with_spikes(riab):
     """BASELINE config 5 shard shape: 8192 agents x (1024 PC + 512 GC + 256 BVC + 256 HDC) with Poisson
     spikes, fused.  Rates of a sample of agents against the oracle; spikes bit-exact against the
