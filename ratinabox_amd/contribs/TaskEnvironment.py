@@ -366,6 +366,7 @@ class TaskEnvironment(Environment):
             self.agents = copy.copy(self.agent_names)
             return self.get_observation(), self.infos
         ag = self._agent
+        ag._sync_plan()  # (a step plan may have advanced the newest history row since the last host-side look)
         dev = ag.state_tensor.device
         task = self._task_struct(refresh=True)
         if getattr(self, "_pool_changed", False):

@@ -301,3 +301,37 @@ def test_task_maximum_sizes(riab, goalorder):
             assert list(sel[b, :len(want)]) == [g if g >= 0 else -2 for g in want], (k, b)
     assert env.diagnostics["resets"] > B and max_rw >= 4   # episodes of 15 goals were completed
     assert env.diagnostics["reward_overflow"] == 0
+
+
+def test_task_plan_with_manual_resets(riab):
+    """A task plan without auto-reset, the caller resetting terminal lanes itself between plan steps
+    (teleports patch the newest history row the plan wrote) == the eager loop."""
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
+    B, T, speed = 48, 120, 12 * 0.08
+
+    def build():
+        np.random.seed(6)
+        env = SpatialGoalEnvironment(possible_goal_positions=[[0.3, 0.3], [0.7, 0.6]], goalkws=dict(goal_radius=0.15),
+                                     goalcachekws=dict(reset_n_goals=1), teleport_on_reset=True, seed=3)
+        Ag = riab.Agent(env, {"dt": 0.01, "n_agents": B, "seed": 8})
+        PCs = riab.PlaceCells(Ag, {"n": 12})
+        env.add_agents(Ag)
+        return env, Ag, PCs
+
+    e1, A1, P1 = build()
+    e2, A2, P2 = build()
+    plan = e2.make_step_plan(auto_reset=False)
+    n_term = 0
+    for k in range(T):
+        a = e1._goal_vector(speed)
+        _, r1, t1, _, _ = e1.step(a)
+        P1.update()
+        e1.reset(mask=t1)
+        plan.step(1, drift_velocity=e2._goal_vector(speed))
+        assert torch.equal(e2.get_reward(), r1) and torch.equal(e2.terminal, t1), k
+        e2.reset(mask=e2.terminal)
+        n_term += int(t1.sum().item())
+    assert n_term > 10
+    assert np.array_equal(A1.pos, A2.pos) and torch.equal(e1.task_state, e2.task_state)
+    assert np.array_equal(A1.history["pos"], A2.history["pos"]) and e1.episodes == e2.episodes
+    assert np.array_equal(P1.history["firingrate"], P2.history["firingrate"])
