@@ -30,11 +30,6 @@ namespace riab {
 // (tools/gen_rayleigh_tables.py; max error 1.6e-16 vs 50-digit arithmetic).  Every lane runs
 // the same instruction stream on its own segment's coefficients: no exp/log/erfc/ndtri and
 // no divergent range branches.  Arguments of H beyond the table use the library functions.
-struct RayleighLds {
-  const double* g;
-  const double* h;
-  int g_stride, h_stride;  // doubles between consecutive segment rows
-};
 // lookup (issue the per-lane LDS reads of one segment's row) and evaluation are split so that
 // independent work can be placed between them: the wave is alone on its SIMD, nothing else hides
 // the LDS latency.
@@ -42,8 +37,14 @@ template <int DEG>
 struct SegRow {
   double c[DEG + 3];
 };
-template <int DEG>
-__device__ __forceinline__ SegRow<DEG> seg_fetch(const double* row) {
+// The row pointer carries its address space: LDS rows are read with ds_read (lgkmcnt), rows of the
+// global tables with global_load.  A generic pointer would make these flat loads, whose completion
+// is tracked by vmcnt as well — each step would then wait for the previous step's history stores
+// to be acknowledged before its polynomial could start.
+typedef const __attribute__((address_space(3))) double* lds_cf64_ptr;
+typedef const __attribute__((address_space(1))) double* glb_cf64_ptr;
+template <int DEG, class Ptr>
+__device__ __forceinline__ SegRow<DEG> seg_fetch(Ptr row) {
   SegRow<DEG> r;
 #pragma unroll
   for (int i = 0; i < DEG + 3; ++i) r.c[i] = row[i];
@@ -67,14 +68,12 @@ __device__ __forceinline__ double clamp_G_arg(double t) {
   t = (t < RIAB_G_TLO) ? RIAB_G_TLO : t;
   return (t > RIAB_G_THI) ? RIAB_G_THI : t;
 }
-__device__ __forceinline__ const double* row_G(const RayleighLds& L, double t_clamped) {
-  const int seg = (int)(((unsigned long long)__double_as_longlong(t_clamped) >> 49) - RIAB_G_KEY0);
-  return L.g + seg * L.g_stride;
+__device__ __forceinline__ int seg_G(double t_clamped) {
+  return (int)(((unsigned long long)__double_as_longlong(t_clamped) >> 49) - RIAB_G_KEY0);
 }
-__device__ __forceinline__ const double* row_H(const RayleighLds& L, double n) {
-  int seg = (int)((n + RIAB_H_NMAX) * RIAB_H_INV_SEG);
-  seg = seg < 0 ? 0 : (seg > RIAB_H_SEGS - 1 ? RIAB_H_SEGS - 1 : seg);
-  return L.h + seg * L.h_stride;
+__device__ __forceinline__ int seg_H(double n) {
+  const int seg = (int)((n + RIAB_H_NMAX) * RIAB_H_INV_SEG);
+  return seg < 0 ? 0 : (seg > RIAB_H_SEGS - 1 ? RIAB_H_SEGS - 1 : seg);
 }
 
 struct AgentArgs {
@@ -111,6 +110,37 @@ __device__ __forceinline__ double r_ndtri(double u) { return normcdfinv(u); }
 __device__ __forceinline__ float r_ndtri(float u) { return normcdfinvf(u); }
 __device__ __forceinline__ double r_ndtr(double x) { return normcdf(x); }
 __device__ __forceinline__ float r_ndtr(float x) { return normcdff(x); }
+
+// clamp to [0, 1] / minimum as single v_max / v_min instructions.  A NaN argument (NaN position)
+// comes out as a number where the reference's comparisons keep the NaN; the position stays NaN
+// through `px - (...)` regardless, so nothing downstream differs.
+__device__ __forceinline__ double r_clamp01(double l) { return fmin(fmax(l, 0.0), 1.0); }
+__device__ __forceinline__ float r_clamp01(float l) { return fminf(fmaxf(l, 0.0f), 1.0f); }
+__device__ __forceinline__ double r_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float r_min(float a, float b) { return fminf(a, b); }
+
+// atan2 in fp32 for the measured rotational velocity (an output: it does not feed back into the
+// motion): Cephes-style argument reduction to [0, tan(pi/8)] and a degree-9 odd polynomial (~2 ulp),
+// about half the instructions of the library routine, which also handles infinities.
+__device__ __forceinline__ float atan2_fast(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float t = mn * __builtin_amdgcn_rcpf(mx);          // in [0, 1]; 0/0 -> NaN, fixed below
+  const bool hi = t > 0.4142135623730950f;            // tan(pi/8)
+  const float tr = (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f);
+  t = hi ? tr : t;
+  const float z = t * t;
+  float p = 8.05374449538e-2f;
+  p = fmaf(p, z, -1.38776856032e-1f);
+  p = fmaf(p, z, 1.99777106478e-1f);
+  p = fmaf(p, z, -3.33329491539e-1f);
+  float r = fmaf(p * z, t, t);
+  r = hi ? r + 0.78539816339744831f : r;
+  r = (ay > ax) ? 1.57079632679489662f - r : r;
+  r = (x < 0.0f) ? 3.14159265358979324f - r : r;
+  r = (mx == 0.0f) ? 0.0f : r;
+  return copysignf(r, y);
+}
 
 // sin/cos of the per-step heading increment rot*dt (|x| is a few 1e-2): Taylor in x^2 for
 // |x| < 0.5 (truncation < 1e-18), the library routine otherwise.
@@ -187,8 +217,8 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       if (i < HN) s_h[(i / (RIAB_H_DEG + 3)) * RIAB_H_STRIDE + i % (RIAB_H_DEG + 3)] = hv[k];
     }
   }
-  const RayleighLds rl = use_lds ? RayleighLds{s_g, s_h, RIAB_G_STRIDE, RIAB_H_STRIDE}
-                                 : RayleighLds{&riab_g_table[0][0], &riab_h_table[0][0], RIAB_G_DEG + 3, RIAB_H_DEG + 3};
+  const lds_cf64_ptr lds_g = (lds_cf64_ptr)s_g, lds_h = (lds_cf64_ptr)s_h;
+  const glb_cf64_ptr glb_g = (glb_cf64_ptr)&riab_g_table[0][0], glb_h = (glb_cf64_ptr)&riab_h_table[0][0];
   for (int w = threadIdx.x; w < a.n_walls; w += 64) {
     const double ax = a.walls[4 * w], ay = a.walls[4 * w + 1], bx = a.walls[4 * w + 2], by = a.walls[4 * w + 3];
     const double sx = bx - ax, sy = by - ay;
@@ -303,7 +333,8 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     double tG = 0.0;
     if (sizeof(R) == 8) {
       tG = clamp_G_arg((double)speed * inv_sm);
-      grow = seg_fetch<RIAB_G_DEG>(row_G(rl, tG));
+      const int sg = seg_G(tG);
+      grow = use_lds ? seg_fetch<RIAB_G_DEG>(lds_g + sg * RIAB_G_STRIDE) : seg_fetch<RIAB_G_DEG>(glb_g + sg * (RIAB_G_DEG + 3));
     }
     rot += (R)m.rot_theta_kw * ((R)m.rot_drift_kw - rot) * dt + (R)m.rot_sigma_kw * (dt * z_rot);
     {
@@ -327,7 +358,8 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       nv64 = seg_eval<RIAB_G_DEG>(grow, tG);
       nv64 += m.speed_theta_kw * (0.0 - nv64) * m.dt + m.speed_sigma_kw * (m.dt * (double)z_spd);
       h_in_table = fabs(nv64) < RIAB_H_NMAX;
-      hrow = seg_fetch<RIAB_H_DEG>(row_H(rl, nv64));
+      const int sh = seg_H(nv64);
+      hrow = use_lds ? seg_fetch<RIAB_H_DEG>(lds_h + sh * RIAB_H_STRIDE) : seg_fetch<RIAB_H_DEG>(glb_h + sh * (RIAB_H_DEG + 3));
     } else {
       R u = (R)1 - r_exp(-v2 * inv_2s2);
       u = (u < (R)1e-6) ? (R)1e-6 : u;
@@ -341,29 +373,22 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     // squared distances first: the sqrt / normalisation only for walls inside the repel
     // distance, and ONE sqrt for distance_to_closest_wall (sqrt is monotone: same value)
     R x2min = INFINITY;
-    constexpr int RIAB_NEAR = 3;
-    int near_idx[RIAB_NEAR] = {0, 0, 0};
-    int n_near = 0;
+    uint64_t near_mask = 0;  // bit w: wall w is within the repel distance (pass 2 walks the set bits in order)
     const R wd2 = wd * wd * (R)1.000001;
     if (nw > 0) {
-      // pass 1 (cheap, every wall): squared distance to the nearest point of the wall; remember
-      // the first RIAB_NEAR walls inside the repel distance.  pass 2 (expensive: sqrt, 1/x, the
-      // spring / conveyor terms) runs only over those, in wall order, so the sums are the
-      // reference's sums (the skipped terms are exact zeros).
+      // pass 1 (cheap, every wall): squared distance to the nearest point of the wall; remember the
+      // walls inside the repel distance.  pass 2 (expensive: sqrt, 1/x, the spring / conveyor terms)
+      // runs only over those, in wall order, so the sums are the reference's sums (the skipped terms
+      // are exact zeros).  Instruction count matters here (one wave per SIMD issues an fp64
+      // instruction every 7.5 cycles): the clamps are v_min / v_max, the near set is a bit mask.
       auto pass1 = [&](const Wall<R>& W, int w) {
         const R dxw = px - W.ax, dyw = py - W.ay;
         R l = (dxw * W.sx + dyw * W.sy) * W.inv_ss;
-        l = (l > (R)1) ? (R)1 : l;
-        l = (l < (R)0) ? (R)0 : l;
+        l = r_clamp01(l);
         const R qx = px - (W.ax + l * W.sx), qy = py - (W.ay + l * W.sy);
         const R x2 = qx * qx + qy * qy;
-        x2min = (x2 < x2min) ? x2 : x2min;
-        if (x2 <= wd2) {
-          if (n_near == 0) near_idx[0] = w;
-          if (n_near == 1) near_idx[1] = w;
-          if (n_near == 2) near_idx[2] = w;
-          ++n_near;
-        }
+        x2min = r_min(x2, x2min);
+        near_mask |= (uint64_t)(x2 <= wd2) << w;
       };
       // the first four walls (the box itself when boundaries are solid) live in registers for the
       // whole launch: no LDS round trip per step for the common open-box case
@@ -392,14 +417,12 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     if (nw > 0) {
       if (repel) {
         R ax_ = 0, ay_ = 0, sx_ = 0, sy_ = 0;
-        const int cnt = (n_near <= RIAB_NEAR) ? n_near : nw;  // more than RIAB_NEAR near walls: walk them all
-        for (int k = 0; k < cnt; ++k) {
-          const int w = (n_near <= RIAB_NEAR) ? near_idx[k < RIAB_NEAR ? k : 0] : k;
+        for (uint64_t rest = near_mask; rest; rest &= rest - 1) {
+          const int w = __ffsll((long long)rest) - 1;
           const Wall<R> W = s_w[w];
           const R dxw = px - W.ax, dyw = py - W.ay;
           R l = (dxw * W.sx + dyw * W.sy) * W.inv_ss;
-          l = (l > (R)1) ? (R)1 : l;
-          l = (l < (R)0) ? (R)0 : l;
+          l = r_clamp01(l);
           const R qx = px - (W.ax + l * W.sx), qy = py - (W.ay + l * W.sy);
           const R xx = qx * qx + qy * qy;
           const R ix = r_rsqrt(xx);  // 1/x and x from one reciprocal square root
@@ -521,7 +544,7 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
 #ifdef RIAB_EXP_NO_ATAN
       mrot = crs * inv_dt;
 #else
-      mrot = (R)atan2f((float)crs, (float)dotp) * inv_dt;
+      mrot = (R)atan2_fast((float)crs, (float)dotp) * inv_dt;
 #endif
     }
     if (IN == 2) {  // overwrite_velocity=True (Agent.py:461-462, 469-470)
