@@ -142,10 +142,27 @@ __device__ __forceinline__ float atan2_fast(float y, float x) {
   return copysignf(r, y);
 }
 
-// sin/cos of the per-step heading increment rot*dt (|x| is a few 1e-2): Taylor in x^2 for
-// |x| < 0.5 (truncation < 1e-18), the library routine otherwise.
+// sin/cos of the per-step heading increment rot*dt (|x| is a few 1e-2): Taylor in x^2, the library
+// routine for |x| >= 0.5.
 __device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
-  if (fabs(x) < 0.5) {
+  // the branch is wave-uniform (ballot): a wave runs exactly one of the three variants.  Each Taylor
+  // coefficient costs two instructions here (the loop-invariant constant has to be copied into the
+  // accumulator of a v_fmac), so the common case gets the shortest series that is exact to 1e-17.
+  const double ax = fabs(x);
+  if (__builtin_amdgcn_ballot_w64(ax >= 0.125) == 0) {  // |x| < 1/8: truncation < 3e-17 (sin), 3e-20 (cos)
+    const double x2 = x * x;
+    double sp = 1.0 / 362880.0;                        //  1/9!
+    sp = fma(sp, x2, -1.0 / 5040.0);                   // -1/7!
+    sp = fma(sp, x2, 1.0 / 120.0);                     //  1/5!
+    sp = fma(sp, x2, -1.0 / 6.0);                      // -1/3!
+    *s = fma(sp * x2, x, x);
+    double cp = -1.0 / 3628800.0;                      // -1/10!
+    cp = fma(cp, x2, 1.0 / 40320.0);                   //  1/8!
+    cp = fma(cp, x2, -1.0 / 720.0);                    // -1/6!
+    cp = fma(cp, x2, 1.0 / 24.0);                      //  1/4!
+    cp = fma(cp, x2, -0.5);
+    *c = fma(cp, x2, 1.0);
+  } else if (__builtin_amdgcn_ballot_w64(ax >= 0.5) == 0) {
     const double x2 = x * x;
     double sp = -1.0 / 1307674368000.0;                // -1/15!
     sp = fma(sp, x2, 1.0 / 6227020800.0);              //  1/13!
@@ -298,13 +315,17 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       const uint64_t step = a.step0 + (uint64_t)t;
       if (t == 0 || (step & 1) == 0) {
         const uint64_t pair = step >> 1;
-        pw = philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), aid, RIAB_TAG_MOTION, a.k0, a.k1);
+        // (the key is made opaque per call: otherwise the ten round keys are hoisted out of the step
+        // loop as 20 loop-invariant SGPRs, spilled to VGPR lanes, and read back with a v_readlane each)
+        uint32_t kk0 = a.k0, kk1 = a.k1;
+        asm volatile("" : "+s"(kk0), "+s"(kk1));
+        pw = philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), aid, RIAB_TAG_MOTION, kk0, kk1);
       }
       const uint32_t wa = (step & 1) ? pw.z : pw.x, wb = (step & 1) ? pw.w : pw.y;
       // Box-Muller on the Philox words with the hardware log2 / sin / cos (the draws only need
       // to be N(0,1) and a pure function of (seed, step, agent); `z_out` records them).
       const float u1 = ((float)(wa >> 8) + 0.5f) * 0x1.0p-24f, u2 = (float)(wb >> 8) * 0x1.0p-24f;
-      const float rr = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1)
+      const float rr = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1), hardware sqrt
       z_rot = (R)(rr * __builtin_amdgcn_cosf(u2));
       z_spd = (R)(rr * __builtin_amdgcn_sinf(u2));
     }
