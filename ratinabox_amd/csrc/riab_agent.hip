@@ -413,10 +413,13 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       };
       // the first four walls (the box itself when boundaries are solid) live in registers for the
       // whole launch: no LDS round trip per step for the common open-box case
+      if (nw >= 4) {  // one uniform test instead of four (each a spilled 64-bit mask read back per step)
 #pragma unroll
-      for (int w = 0; w < 4; ++w)
-        if (w < nw) pass1(w4[w], w);
-      for (int w = 4; w < nw; ++w) pass1(s_w[w], w);
+        for (int w = 0; w < 4; ++w) pass1(w4[w], w);
+        for (int w = 4; w < nw; ++w) pass1(s_w[w], w);
+      } else {
+        for (int w = 0; w < nw; ++w) pass1(s_w[w], w);
+      }
     }
     // ---- finish the speed update ---------------------------------------------------------------
     if (sizeof(R) == 8) {
