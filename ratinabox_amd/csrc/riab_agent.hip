@@ -100,7 +100,14 @@ struct AgentArgs {
 // ---- math wrappers ---------------------------------------------------------------------------
 __device__ __forceinline__ double r_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ float r_sqrt(float x) { return sqrtf(x); }
-__device__ __forceinline__ double r_rsqrt(double x) { return rsqrt(x); }
+// 1/sqrt(x) for positive finite x: the hardware estimate (v_rsq_f64, ~26 bits) and one third-order
+// correction — the library routine's arithmetic without its special-case selects (x = 0 or inf
+// only occur on paths whose result is discarded or replaced, see the call sites).
+__device__ __forceinline__ double r_rsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y, y, 1.0);
+  return fma(y * e, fma(e, 0.375, 0.5), y);
+}
 __device__ __forceinline__ float r_rsqrt(float x) { return rsqrtf(x); }
 __device__ __forceinline__ double r_exp(double x) { return exp(x); }
 __device__ __forceinline__ float r_exp(float x) { return expf(x); }
