@@ -253,8 +253,7 @@ def main():
                     "kernel": f"rate_kernel<{type(pops[0]).__name__}>", "launches": len(ms),
                     "avg_launch_ms": round(avg_ms, 4), "units_per_launch": int(avg_units),
                     "bytes_per_unit": unit_bytes, "kernel_own_bytes_per_unit": 4 * n0 + 8,
-                    # simulate() tapers the last chunk (64, 32, 16, 16 steps) to shorten the pipeline drain;
-                    # the averages above are over ALL launches (what rocprofv3 --stats averages too)
+                    # the averages above are over ALL timed launches (what rocprofv3 --stats averages too)
                     "full_chunk_launch_ms": round(float(np.mean([m for m, u in zip(ms, units) if u == max(units)])), 4),
                     "frac_of_measured_copy_bw_6290": round(achieved / 6290.0, 4)}
 

@@ -365,22 +365,13 @@ class Agent:
 
     @staticmethod
     def _chunk_schedule(n_steps, chunk):
-        """Steps per trajectory launch: `chunk`, with the last chunk tapered (1/2, 1/4, ... down to 16
-        steps).  The rate kernels trail the trajectory kernel by one chunk, so after the last trajectory
-        launch a whole chunk of rates is still to be computed with nothing to overlap; tapering makes
-        that drain the rates of 16 steps instead of `chunk` (+3 % at cfg 2, K = 1024).  A taper at the
-        head, or larger chunks, do not help: the two stages take about the same time per step."""
+        """Steps per trajectory launch: uniform chunks.  (Tapering the last chunk to shorten the pipeline
+        drain paid +3 % while the trajectory kernel was the slower stage; with the two stages level at
+        cfg 2 it is neutral — small rate launches lose what the shorter drain saves — and was dropped.)"""
         n_steps, chunk = int(n_steps), max(int(chunk), 1)
         sched = [chunk] * (n_steps // chunk)
-        tail = n_steps - chunk * len(sched)
-        if tail == 0 and sched:
-            tail = sched.pop()
-        while tail > 16:
-            piece = max(16, (tail // 2) // 16 * 16)
-            sched.append(piece)
-            tail -= piece
-        if tail:
-            sched.append(tail)
+        if n_steps % chunk:
+            sched.append(n_steps % chunk)
         return sched
 
     def _make_streams(self):
