@@ -19,6 +19,8 @@
 
 namespace riab {
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 // LDS row strides (in doubles), padded so that lanes reading the same coefficient index of
 // different segments spread over the banks
 #define RIAB_G_STRIDE (RIAB_G_DEG + 4)
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   __shared__ Wall<R> s_w[RIAB_MAX_WALLS];
   __shared__ double s_g[sizeof(R) == 8 ? RIAB_G_SEGS * RIAB_G_STRIDE : 1];
   __shared__ double s_h[sizeof(R) == 8 ? RIAB_H_SEGS * RIAB_H_STRIDE : 1];
+  __shared__ __align__(16) float s_hist[4][RIAB_HIST_ROWS][64];  // four steps of history rows of this wave
   // Long launches stage the tables in LDS (per-lane gathers every step); a launch of a few steps
   // (the closed-loop path, T = 1) reads its two rows per step straight from the L2-resident
   // global tables instead of paying the 19 KB staging each time.
@@ -257,6 +260,8 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   __syncthreads();
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= a.B) return;
+  // full wave and a multi-step launch: history rows go through LDS (below); single steps store directly
+  const bool hist_staged = a.hist && a.T >= 4 && ((int64_t)blockIdx.x * 64 + 64 <= a.B);
   // a latency-bound recurrence sharing its CU with bandwidth-bound rate kernels: win the
   // SIMD's issue arbitration whenever this wave is ready
   __builtin_amdgcn_s_setprio(3);
@@ -600,7 +605,32 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     // ---- _update_distance_travelled (Agent.py:507) ----------------------------------------
     dist += dstep;
     // ---- save_to_history (Agent.py:514-520) ------------------------------------------------
-    if (a.hist) {
+    if (hist_staged) {
+      // Eight dword stores per step are eight places to queue behind the rate kernels' store stream.
+      // The rows of four steps are parked in LDS (the wave is the only user) and written out as
+      // float4 rows: eight store instructions per FOUR steps, each covering four (step, row) pairs.
+      float* sh = &s_hist[t & 3][0][threadIdx.x];
+      sh[0 * 64] = (float)px;
+      sh[1 * 64] = (float)py;
+      sh[2 * 64] = (float)mvx;
+      sh[3 * 64] = (float)mvy;
+      sh[4 * 64] = (float)hx;
+      sh[5 * 64] = (float)hy;
+      sh[6 * 64] = (float)mrot;
+      sh[7 * 64] = (float)dist;
+      if ((t & 3) == 3 || t == a.T - 1) {
+        __builtin_amdgcn_wave_barrier();  // (LDS serves a wave's requests in order: the reads below see the writes)
+        const int n = (t & 3) + 1, t0 = t - (t & 3);
+        for (int j = 0; j < 2 * n; ++j) {
+          const int idx = j * 64 + threadIdx.x;
+          const int pair = idx >> 4, q = idx & 15;  // pair = (step, row) of the group, q = agent quad
+          const v4f v = *reinterpret_cast<const v4f*>(&s_hist[pair >> 3][pair & 7][q * 4]);
+          *reinterpret_cast<v4f*>(a.hist + ((int64_t)(t0 + (pair >> 3)) * RIAB_HIST_ROWS + (pair & 7)) * B +
+                                  (int64_t)blockIdx.x * 64 + q * 4) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else if (a.hist) {
       float* h = a.hist + (int64_t)t * RIAB_HIST_ROWS * B + b;
       h[0 * B] = (float)px;
       h[1 * B] = (float)py;
