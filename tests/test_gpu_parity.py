@@ -728,6 +728,25 @@ def test_step_plan_with_noise_and_feedforward_layers(riab, save):
         A2.make_step_plan(neurons=[P2[2], P2[0], P2[1]])
 
 
+def test_history_rows_staged_and_direct_agree(riab):
+    """Multi-step launches park four steps of history rows in LDS and write float4 rows (full 64-agent
+    waves only); single steps and ragged waves store directly.  Chunk lengths that are not multiples of
+    four, three full waves plus a ragged one: fused == per-step, bit for bit, state and history."""
+    def world():
+        np.random.seed(17)
+        env = make_env(riab, [[[0.4, 0.0], [0.4, 0.6]]])
+        return riab.Agent(env, {"n_agents": 200, "dt": 0.02, "seed": 23})
+    A1, A2, A3 = world(), world(), world()
+    for _ in range(23):
+        A1.update()
+    A2.simulate(23, chunk=10)       # launches of 10, 10 and 3 steps
+    A3.simulate(23, chunk=23)       # one launch: five full groups of four and a tail of three
+    for A in (A2, A3):
+        assert np.array_equal(A.pos, A1.pos) and np.array_equal(A.head_direction, A1.head_direction)
+        for key in ("pos", "vel", "head_direction", "rot_vel", "distance_travelled"):
+            assert np.array_equal(A.history[key], A1.history[key]), key
+
+
 def test_config5_shape_mixed_population_with_spikes(riab):
     """BASELINE config 5 shard shape: 8192 agents x (1024 PC + 512 GC + 256 BVC + 256 HDC) with Poisson
     spikes, fused.  Rates of a sample of agents against the oracle; spikes bit-exact against the
