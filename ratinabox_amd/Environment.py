@@ -178,15 +178,16 @@ class Environment:
         layout include/riab_hip.h documents.  Rebuilt when `walls` changed."""
         import torch
         from . import _lib
-        hit = self._device_cache.get("env")
+        slot = ("env", str(device))  # ("cuda" and "cuda:0" name the same device but are cached separately)
+        hit = self._device_cache.get(slot)
         if hit is not None:
-            (dev, src, bc, sc, asp), env, wt = hit
-            # fast path (every step): same device, same geometry, wall array unchanged
-            if (dev == str(device) and bc == self.boundary_conditions and sc == self.scale and asp == self.aspect
+            (src, bc, sc, asp), env, wt = hit
+            # fast path (every step): same geometry, wall array unchanged
+            if (bc == self.boundary_conditions and sc == self.scale and asp == self.aspect
                     and src.shape == np.shape(self.walls) and np.array_equal(src, self.walls)):
                 return env, wt
         walls = np.ascontiguousarray(np.asarray(self.walls, dtype=np.float64).reshape(-1, 4))
-        key = (str(device), np.array(self.walls, dtype=np.float64), self.boundary_conditions, self.scale, self.aspect)
+        key = (np.array(self.walls, dtype=np.float64), self.boundary_conditions, self.scale, self.aspect)
         if len(walls) > _lib.MAX_WALLS:
             raise ValueError(f"at most {_lib.MAX_WALLS} walls are supported on device, got {len(walls)}")
         wt = torch.from_numpy(walls if len(walls) else np.zeros((1, 4))).to(device)
@@ -197,7 +198,7 @@ class Environment:
         env.periodic = 1 if self.boundary_conditions == "periodic" else 0
         env.n_walls = int(len(walls))
         env.walls = wt.data_ptr()
-        self._device_cache["env"] = (key, env, wt)
+        self._device_cache[slot] = (key, env, wt)
         return env, wt
 
     def plot_environment(self, *a, **k):
