@@ -602,8 +602,44 @@ def make_task():
         np.savez_compressed(os.path.join(HERE, f"task_{name}.npz"), **out)
 
 
+def make_stats():
+    """G6: long-run statistics of the reference's own motion model (its own NumPy RNG), for validating the
+    production (in-kernel Philox) mode, which cannot be compared draw by draw."""
+    print("long-run statistics (this takes a few minutes)")
+    out = {}
+    for name, envp in (("open", {}), ("wall", {"walls": [[[0.5, 0.0], [0.5, 0.6]]]})):
+        np.random.seed(77)
+        Env = Environment(dict(envp))
+        n_agents, n_steps, burn = 40, 4000, 250
+        agents = [Agent(Env, {"dt": 0.02}) for _ in range(n_agents)]
+        speed, rot, dwall, pos = [], [], [], []
+        for t in range(n_steps):
+            for ag in agents:
+                ag.update()
+            if t >= burn:
+                speed.append([np.linalg.norm(a.velocity) for a in agents])
+                rot.append([a.rotational_velocity for a in agents])
+                dwall.append([a.distance_to_closest_wall for a in agents])
+                pos.append([a.pos for a in agents])
+        speed, rot, dwall, pos = map(np.array, (speed, rot, dwall, pos))
+        out[f"{name}_speed_mean"] = speed.mean()
+        out[f"{name}_speed_std"] = speed.std()
+        out[f"{name}_speed_q"] = np.quantile(speed, [0.1, 0.5, 0.9])
+        out[f"{name}_rot_std"] = rot.std()
+        out[f"{name}_dwall_hist"] = np.histogram(dwall, bins=10, range=(0, 0.5))[0] / dwall.size
+        out[f"{name}_pos_hist"] = np.histogram2d(pos[..., 0].ravel(), pos[..., 1].ravel(), bins=4, range=[[0, 1], [0, 1]])[0] / (pos.size / 2)
+        out[f"{name}_walls"] = np.array(envp.get("walls", []), float).reshape(-1, 2, 2)
+        # the per-agent means give the standard error the tests use
+        out[f"{name}_speed_agent_means"] = speed.mean(axis=0)
+        print(f"  {name}: speed {speed.mean():.4f} +- {speed.mean(axis=0).std() / np.sqrt(n_agents):.4f}, rot std {rot.std():.3f}")
+    out["dt"], out["n_steps"], out["burn"] = 0.02, 4000, 250
+    np.savez_compressed(os.path.join(HERE, "stats.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "task"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "task", "stats"]
+    if "stats" in which:
+        make_stats()
     if "task" in which:
         make_task()
     if "ovc" in which:

@@ -781,3 +781,26 @@ def test_config5_shape_mixed_population_with_spikes(riab):
         assert np.array_equal(sp_np, orc.spikes_f32(fr_np, u, 0.01)), pop.name
         total_spikes += int(sp_np.sum())
     assert total_spikes > 1000
+
+
+@pytest.mark.parametrize("name", ["open", "wall"])
+def test_production_mode_long_run_statistics_vs_reference(riab, name):
+    """G6: 4096 agents x 3000 steps driven by the in-kernel Philox noise reproduce the stationary statistics
+    of the reference's own motion model (tests/golden/stats.npz, generated by running the reference):
+    speed distribution, rotational-velocity spread, distance-to-wall and occupancy histograms."""
+    from tests.test_oracle_golden import assert_long_run_stats, _long_run_stats
+    g = gu.load("stats.npz")
+    np.random.seed(9)
+    env = make_env(riab, g[f"{name}_walls"])
+    Ag = riab.Agent(env, {"n_agents": 4096, "dt": float(g["dt"]), "seed": 2024, "save_history": False})
+    Ag.simulate(250, chunk=125)          # burn-in
+    speed, rot, dwall, pos = [], [], [], []
+    for _ in range(55):
+        Ag.simulate(50, chunk=50)
+        speed.append(np.linalg.norm(Ag.velocity, axis=1))
+        rot.append(Ag.rotational_velocity)
+        dwall.append(Ag.distance_to_closest_wall)
+        pos.append(Ag.pos)
+    assert_long_run_stats(_long_run_stats(*map(np.array, (speed, rot, dwall, pos))), g, name)
+    d = Ag.diagnostics
+    assert d["bounce_saturations"] == 0 and d["zero_displacement"] == 0

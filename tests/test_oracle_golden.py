@@ -217,3 +217,45 @@ def test_object_vector_cells(tag, kw, ego):
                                   g[f"ovc_{tag}_sigma_angles"], g[f"ovc_{tag}_tuning_types"],
                                   head_direction=g["hd"] if ego else None, **kw)
     np.testing.assert_allclose(got, g[f"ovc_{tag}_rates"], rtol=1e-10, atol=1e-14)
+
+
+def _long_run_stats(speed, rot, dwall, pos):
+    return dict(speed_mean=speed.mean(), speed_std=speed.std(), speed_q=np.quantile(speed, [0.1, 0.5, 0.9]),
+                rot_std=rot.std(), dwall_hist=np.histogram(dwall, bins=10, range=(0, 0.5))[0] / dwall.size,
+                pos_hist=np.histogram2d(pos[..., 0].ravel(), pos[..., 1].ravel(), bins=4, range=[[0, 1], [0, 1]])[0]
+                / (pos.size / 2))
+
+
+def assert_long_run_stats(got, g, name):
+    """Stationary statistics against the reference's (tests/golden/stats.npz): the tolerance on the mean
+    speed is 4 standard errors of the reference's own estimate (from its per-agent means) + 1 %."""
+    se = g[f"{name}_speed_agent_means"].std() / np.sqrt(len(g[f"{name}_speed_agent_means"]))
+    ref_mean = float(g[f"{name}_speed_mean"])
+    assert abs(got["speed_mean"] - ref_mean) < 4 * se + 0.01 * ref_mean, (got["speed_mean"], ref_mean, se)
+    np.testing.assert_allclose(got["speed_std"], g[f"{name}_speed_std"], rtol=0.06)
+    np.testing.assert_allclose(got["speed_q"], g[f"{name}_speed_q"], rtol=0.08)
+    np.testing.assert_allclose(got["rot_std"], g[f"{name}_rot_std"], rtol=0.04)
+    np.testing.assert_allclose(got["dwall_hist"], g[f"{name}_dwall_hist"], atol=0.025)
+    # (occupancy of a 4x4 grid mixes slowly: 40 reference agents x 75 s leave +-0.02 of sampling noise per cell)
+    np.testing.assert_allclose(got["pos_hist"], g[f"{name}_pos_hist"], atol=0.045)
+
+
+@pytest.mark.parametrize("name", ["open", "wall"])
+def test_long_run_statistics_vs_reference(name):
+    """G6: the oracle driven by its own NumPy normals reproduces the reference's stationary statistics
+    (speed distribution, rotational-velocity spread, distance-to-wall and occupancy histograms)."""
+    g = gu.load("stats.npz")
+    rs = np.random.RandomState(5)
+    env = orc.EnvSpec(walls=g[f"{name}_walls"])
+    B, T, burn, dt = 160, 1500, 250, float(g["dt"])
+    st = orc.init_state(env, B, 0.08, rs)
+    speed, rot, dwall, pos = [], [], [], []
+    for t in range(T):
+        z = rs.standard_normal((2, B))
+        st = orc.agent_step(env, st, dt, z[0], z[1])
+        if t >= burn and t % 5 == 0:
+            speed.append(np.linalg.norm(st["velocity"], axis=1))
+            rot.append(st["rotational_velocity"].copy())
+            dwall.append(st["distance_to_closest_wall"].copy())
+            pos.append(st["pos"].copy())
+    assert_long_run_stats(_long_run_stats(*map(np.array, (speed, rot, dwall, pos))), g, name)
