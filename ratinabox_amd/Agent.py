@@ -130,30 +130,14 @@ class Agent:
         return self._squeeze(a if width > 1 else a[:, 0])
 
     def _upload(self, row, value):
-        self._last_row = None  # host edit: the fp32 row no longer mirrors the state
-        value = np.asarray(value, dtype=np.float64)
-        width = 2 if value.ndim >= 1 and value.shape[-1] == 2 and row in (
-            _L.S_POS_X, _L.S_VEL_X, _L.S_MVEL_X, _L.S_HD_X) else 1
-        if width == 2:
-            v = np.broadcast_to(value.reshape(-1, 2), (value.reshape(-1, 2).shape[0], 2))
-            full = np.empty((self._Bp, 2))
-            if v.shape[0] == 1:
-                full[:] = v[0]
-            else:
-                n = min(v.shape[0], self._Bp)
-                full[:n] = v[:n]
-                full[n:] = v[0]
-            self._state[row:row + 2] = torch.from_numpy(np.ascontiguousarray(full.T)).to(self._device)
-        else:
-            v = value.reshape(-1)
-            full = np.empty(self._Bp)
-            if v.shape[0] == 1:
-                full[:] = v[0]
-            else:
-                n = min(v.shape[0], self._Bp)
-                full[:n] = v[:n]
-                full[n:] = v[0]
-            self._state[row] = torch.from_numpy(full).to(self._device)
+        """Host edit of a state attribute: one value (broadcast to every agent) or one row per agent."""
+        self._last_row = None  # the fp32 row the rate kernels read no longer mirrors the state
+        width = 2 if row in (_L.S_POS_X, _L.S_VEL_X, _L.S_MVEL_X, _L.S_HD_X) else 1
+        v = np.asarray(value, dtype=np.float64).reshape(-1, width)
+        full = np.broadcast_to(v[:1], (self._Bp, width)).copy()  # (padding lanes repeat agent 0)
+        n = min(len(v), self._Bp)
+        full[:n] = v[:n]
+        self._state[row:row + width] = torch.from_numpy(np.ascontiguousarray(full.T)).to(self._device)
 
     pos = property(lambda s: s._download(_L.S_POS_X, 2), lambda s, v: s._upload(_L.S_POS_X, v))
     velocity = property(lambda s: s._download(_L.S_VEL_X, 2), lambda s, v: s._upload(_L.S_VEL_X, v))
