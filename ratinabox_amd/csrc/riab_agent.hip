@@ -262,6 +262,8 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
   if (b >= a.B) return;
   // full wave and a multi-step launch: history rows go through LDS (below); single steps store directly
   const bool hist_staged = a.hist && a.T >= 4 && ((int64_t)blockIdx.x * 64 + 64 <= a.B);
+  const int hist_lds_lane = (int)(threadIdx.x >> 4) * 64 + (int)(threadIdx.x & 15) * 4;                    // floats
+  const uint32_t hist_glb_lane = (uint32_t)(((int64_t)(threadIdx.x >> 4) * a.B + (threadIdx.x & 15) * 4) * 4);  // bytes
   // a latency-bound recurrence sharing its CU with bandwidth-bound rate kernels: win the
   // SIMD's issue arbitration whenever this wave is ready
   __builtin_amdgcn_s_setprio(3);
@@ -620,13 +622,18 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       sh[7 * 64] = (float)dist;
       if ((t & 3) == 3 || t == a.T - 1) {
         __builtin_amdgcn_wave_barrier();  // (LDS serves a wave's requests in order: the reads below see the writes)
-        const int n = (t & 3) + 1, t0 = t - (t & 3);
-        for (int j = 0; j < 2 * n; ++j) {
-          const int idx = j * 64 + threadIdx.x;
-          const int pair = idx >> 4, q = idx & 15;  // pair = (step, row) of the group, q = agent quad
-          const v4f v = *reinterpret_cast<const v4f*>(&s_hist[pair >> 3][pair & 7][q * 4]);
-          *reinterpret_cast<v4f*>(a.hist + ((int64_t)(t0 + (pair >> 3)) * RIAB_HIST_ROWS + (pair & 7)) * B +
-                                  (int64_t)blockIdx.x * 64 + q * 4) = v;
+        // store j covers the (step, row) pairs 4j .. 4j+3: step j/2, rows 4(j&1) + lane/16, agents 4(lane&15)..+3.
+        // Everything that depends on j or t is wave-uniform (scalar registers); the lane's share of the
+        // addresses was computed once before the step loop.
+        const int n2 = 2 * ((t & 3) + 1);
+        float* const g0 = a.hist + (int64_t)(t - (t & 3)) * RIAB_HIST_ROWS * B + (int64_t)blockIdx.x * 64;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (j < n2) {
+            const v4f v = *reinterpret_cast<const v4f*>(&s_hist[j >> 1][(j & 1) * 4][0] + hist_lds_lane);
+            char* const gj = reinterpret_cast<char*>(g0 + (int64_t)((j >> 1) * RIAB_HIST_ROWS + (j & 1) * 4) * B);
+            *reinterpret_cast<v4f*>(gj + hist_glb_lane) = v;
+          }
         }
         __builtin_amdgcn_wave_barrier();
       }
