@@ -286,7 +286,7 @@ class Agent:
         return hist_view
 
     # ---- fused path ----------------------------------------------------------------------------
-    def simulate(self, n_steps, dt=None, drift_velocity=None, drift_to_random_strength_ratio=1, chunk=256,
+    def simulate(self, n_steps, dt=None, drift_velocity=None, drift_to_random_strength_ratio=1, chunk=128,
                  neurons=None, noise=None, **kwargs):
         """`n_steps` x (Agent.update(); N.update() for N in neurons) without returning to
         Python between steps (new; the open-loop workload of SURVEY §7.3-1).
