@@ -401,6 +401,17 @@ class Agent:
             "head_direction": pair(_L.H_HD_X),
         }
 
+    def get_history_slice(self, t_start=None, t_end=None, framerate=None):
+        """A python slice over the history between t_start and t_end at `framerate` frames per second
+        (reference Agent.py:1068-1091)."""
+        t = self.history["t"]
+        t_start = t_start or t[0]
+        startid = np.nanargmin(np.abs(t - t_start))
+        t_end = t_end or t[-1]
+        endid = np.nanargmin(np.abs(t - t_end))
+        skiprate = 1 if framerate is None else max(1, int((1 / framerate) / self.dt))
+        return slice(startid, endid, skiprate)
+
     def get_history_arrays(self):
         """history as a dict of NumPy arrays (reference Agent.py:1093-1102)."""
         return dict(self.history.items())

@@ -122,6 +122,24 @@ class Neurons:
             pop.noise_sigma_dt = float(np.sqrt((2 * float(self.noise_std) ** 2) / (tau * dt))) * dt
         return pop
 
+    def return_list_of_neurons(self, chosen_neurons="all"):
+        """Indices of a selection of cells: "all", an int or digit string (that many, evenly spread),
+        "<k>rand" (k at random), or an explicit list / array (reference Neurons.py:779-810)."""
+        if isinstance(chosen_neurons, str):
+            if chosen_neurons == "all":
+                chosen_neurons = np.arange(self.n)
+            elif chosen_neurons.isdigit():
+                chosen_neurons = np.linspace(0, self.n - 1, min(self.n, int(chosen_neurons))).astype(int)
+            elif chosen_neurons[-4:] == "rand":
+                chosen_neurons = np.random.choice(np.arange(self.n), size=int(chosen_neurons[:-4]), replace=False)
+        if type(chosen_neurons) is int:
+            chosen_neurons = np.linspace(0, self.n - 1, min(self.n, chosen_neurons))
+        if isinstance(chosen_neurons, list):
+            chosen_neurons = list(np.array(chosen_neurons).astype(int))
+        if isinstance(chosen_neurons, np.ndarray):
+            chosen_neurons = list(chosen_neurons.astype(int))
+        return chosen_neurons
+
     # ---- attributes -----------------------------------------------------------------------------
     @property
     def firingrate(self):
@@ -489,6 +507,8 @@ class GridCells(Neurons):
         if isinstance(p["phase_offset"], (list, np.ndarray)) and np.array(p["phase_offset"]).ndim == 2:
             self.phase_offsets = np.array(p["phase_offset"])
             assert len(self.phase_offsets) == p["n"], "number of phase offsets supplied incompatible with number of neurons"
+        elif p["phase_offset_distribution"] == "grid":
+            self.phase_offsets = self.set_phase_offsets_on_grid()
         else:
             self.phase_offsets = utils.distribution_sampler(p["phase_offset_distribution"], p["phase_offset"],
                                                             shape=(p["n"], 2))
@@ -505,6 +525,18 @@ class GridCells(Neurons):
         self.w = np.array(w)
         if self.description == "rectified_cosines":
             assert 0 < self.width_ratio <= 1, "width_ratio must be between 0 and 1"
+
+    def set_phase_offsets_on_grid(self):
+        """Phase offsets tiling [0, 2pi)^2 on an n_x x n_y grid, the remaining cells uniform at random
+        (reference Neurons.py:1238-1256)."""
+        n_x = int(np.sqrt(self.n))
+        n_y = self.n // n_x
+        n_remaining = self.n - n_x * n_y
+        dx, dy = 2 * np.pi / n_x, 2 * np.pi / n_y
+        grid = np.mgrid[(0 + dx / 2):(2 * np.pi - dx / 2):(n_x * 1j), (0 + dy / 2):(2 * np.pi - dy / 2):(n_y * 1j)]
+        grid = grid.reshape(2, -1).T
+        remaining = np.random.uniform(0, 2 * np.pi, size=(n_remaining, 2))
+        return np.vstack([grid, remaining])
 
     def _call(self, io, stream):
         n = int(self.n)

@@ -170,3 +170,21 @@ def test_simulate_chunk_schedule():
     assert Agent._chunk_schedule(1024, 128) == [128] * 8
     assert Agent._chunk_schedule(300, 128) == [128, 128, 44]
     assert Agent._chunk_schedule(0, 128) == []
+
+
+def test_small_api_helpers_match_reference():
+    """return_list_of_neurons, GridCells grid phase offsets (reference Neurons.py:779-810, 1238-1256)."""
+    np.random.seed(0)
+    env = riab.Environment()
+    Ag = riab.Agent(env, dict(CPU))
+    np.random.seed(4)
+    GCs = riab.GridCells(Ag, {"n": 11, "phase_offset_distribution": "grid"})
+    assert GCs.phase_offsets.shape == (11, 2)
+    dx = 2 * np.pi / 3
+    assert np.allclose(GCs.phase_offsets[:9, 0], np.repeat([dx / 2, 3 * dx / 2, 5 * dx / 2], 3))
+    assert np.allclose(GCs.phase_offsets[:9, 1], np.tile([dx / 2, 3 * dx / 2, 5 * dx / 2], 3))
+    assert np.all((GCs.phase_offsets[9:] >= 0) & (GCs.phase_offsets[9:] < 2 * np.pi))
+    assert GCs.return_list_of_neurons("all") == list(range(11)) or list(GCs.return_list_of_neurons("all")) == list(range(11))
+    assert list(GCs.return_list_of_neurons("3")) == [0, 5, 10]
+    assert GCs.return_list_of_neurons([1.0, 4.0]) == [1, 4]
+    assert len(set(GCs.return_list_of_neurons("4rand"))) == 4
