@@ -224,6 +224,19 @@ class Neurons:
         discretised coordinates) or None with `pos=(P,2)` (+ `head_direction=(P,2)`)."""
         return self.get_state_tensor(evaluate_at, **kwargs)[:, :self._last_P].cpu().numpy().astype(np.float64)
 
+    def get_head_direction_averaged_state(self, evaluate_at="agent", angular_resolution_degrees=10, **kwargs):
+        """get_state() averaged over head directions 0..2pi (reference Neurons.py:176-192); only differs
+        from get_state() for cells tuned to the head direction (HeadDirectionCells, egocentric cells)."""
+        if evaluate_at == "agent":  # evaluate at the agents' positions, but with the head directions imposed
+            kwargs = dict(kwargs, pos=np.asarray(self.Agent.pos, dtype=np.float64).reshape(-1, 2))
+            evaluate_at = None
+        n_angles = int(360 / angular_resolution_degrees)
+        total = None
+        for ang in np.linspace(0, 2 * np.pi, n_angles):
+            fr = self.get_state(evaluate_at=evaluate_at, **dict(kwargs, head_direction=np.array([np.cos(ang), np.sin(ang)])))
+            total = fr if total is None else total + fr
+        return total / n_angles
+
     def get_state_tensor(self, evaluate_at="agent", **kwargs):
         """As get_state but returns the device tensor float32 `[n, P_padded]`."""
         Ag = self.Agent

@@ -804,3 +804,21 @@ def test_production_mode_long_run_statistics_vs_reference(riab, name):
     assert_long_run_stats(_long_run_stats(*map(np.array, (speed, rot, dwall, pos))), g, name)
     d = Ag.diagnostics
     assert d["bounce_saturations"] == 0 and d["zero_displacement"] == 0
+
+
+def test_head_direction_averaged_state(riab):
+    """get_head_direction_averaged_state == the mean of get_state over the 36 head directions the
+    reference uses (Neurons.py:176-192): flat for HeadDirectionCells, equal to get_state for PlaceCells."""
+    np.random.seed(2)
+    env = make_env(riab)
+    Ag = riab.Agent(env, {"n_agents": 3})
+    HDCs = riab.HeadDirectionCells(Ag, {"n": 8})
+    PCs = riab.PlaceCells(Ag, {"n": 5})
+    pos = np.random.rand(7, 2)
+    avg = HDCs.get_head_direction_averaged_state(evaluate_at=None, pos=pos)
+    angles = np.linspace(0, 2 * np.pi, 36)
+    ref = np.mean([orc.head_direction_cells(np.tile([np.cos(a), np.sin(a)], (7, 1)), 8) for a in angles], axis=0)
+    np.testing.assert_allclose(avg, ref, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(PCs.get_head_direction_averaged_state(evaluate_at=None, pos=pos),
+                               PCs.get_state(evaluate_at=None, pos=pos), rtol=1e-6)
+    assert HDCs.get_head_direction_averaged_state().shape == (8, 3)
