@@ -43,3 +43,24 @@ for name, (envp, agp, drift) in cases.items():
           f"|hd|-1 max {float((hd_norm - 1).abs().max()):.1e} speed mean {float(torch.sqrt(st[2] ** 2 + st[3] ** 2).mean()):.4f} {d}",
           flush=True)
     assert ok_finite and inside and d["bounce_saturations"] == 0
+
+# ---- closed loop inside a TaskEnvironment (scripted policy, auto-reset): rewards finite, caches within bounds
+from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment  # noqa: E402
+
+np.random.seed(3)
+env = SpatialGoalEnvironment(possible_goal_positions="random_12",
+                             goalcachekws=dict(reset_n_goals=3), teleport_on_reset=True, episode_terminate_delay=0.05,
+                             episode_log_capacity=1 << 22)
+ag = riab.Agent(env, {"n_agents": 4096, "dt": 0.01, "save_history": False})
+env.add_agents(ag)
+plan = env.make_step_plan(neurons=[], auto_reset=True, scripted_speed=11 * ag.speed_mean)
+n_task = min(steps, 200_000)
+t0 = time.perf_counter()
+for _ in range(n_task // 100):
+    plan.step(100)
+torch.cuda.synchronize()
+r = env.get_reward()
+d = env.diagnostics
+print(f"task loop: {n_task} steps x 4096 lanes in {time.perf_counter() - t0:.1f} s: rewards finite={bool(torch.isfinite(r).all())} "
+      f"max active rewards {int(ag.reward.active()[2].max())} episodes {int(env._ep_count.item())} {d}", flush=True)
+assert torch.isfinite(r).all() and d["reward_overflow"] == 0
