@@ -203,9 +203,10 @@ int riab_head_direction_cells(const RiabRateIO* io, const float* table, int32_t 
  *             a = sqrt(log2(e)/2)/sigma_d (so the radial gaussian is
  *             exp2(-(a d - a mu_d)^2)), row 2 = kappa*log2(e), row 3 unused
  *  vm_table   device float32, rows padded to Kp = K rounded up to a multiple of 4.
- *             allocentric: [n][Kp] = log2(e)*kappa_c*(cos(theta_k - mu_c) - 1), pad
- *             entries -inf.  egocentric: [2][n][Kp] = cos(theta_k - mu_c),
- *             sin(theta_k - mu_c), pad entries -inf / 0; the head bearing
+ *             allocentric: [n][Kp] = log2(e)*kappa_c*(cos(theta_k - mu_c) - 1).
+ *             egocentric: [2][n][Kp] = cos(theta_k - mu_c), sin(theta_k - mu_c).
+ *             Pad entries (k >= K): any finite value or -inf (the kernel gives the
+ *             pad directions an infinite distance, so their terms vanish); the head bearing
  *             utils.get_angle(head_direction) enters through its cosine / sine
  *             (hx+1e-6, hy)/norm, so no per-term trigonometry is needed
  *  inv_norm   device float32 [n]: 1 / cell_fr_norm (Neurons.py:1598-1604)

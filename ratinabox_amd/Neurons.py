@@ -675,11 +675,13 @@ class BoundaryVectorCells(VectorCells):
             cells = np.zeros((4, n))
             cells[0], cells[1], cells[2] = a * mu_d, a, kappa * LOG2E
             diff = ang[None, :] - mu_t[:, None]
-            Kp = (K + 3) // 4 * 4  # table rows padded to a multiple of 4; pad terms are exp2(-inf) = 0
+            # table rows padded to a multiple of 4.  The kernel gives the pad directions an infinite distance,
+            # so their terms are exp2(-inf) = 0 whatever the table holds (an -inf COSINE entry times a negative
+            # cos(head bearing) would be +inf: the egocentric pads are zeros)
+            Kp = (K + 3) // 4 * 4
             if ego:
                 vm = np.zeros((2, n, Kp))
                 vm[0, :, :K], vm[1, :, :K] = np.cos(diff), np.sin(diff)
-                vm[0, :, K:] = -np.inf
             else:
                 vm = np.full((n, Kp), -np.inf)
                 vm[:, :K] = LOG2E * kappa[:, None] * (np.cos(diff) - 1)

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
       }
     }
   }
-  for (int k = K + wave; k < a.Kp; k += 8) s_d[k * 64 + lane] = 0.0f;  // pad rows meet table entries of -inf
+  // pad rows: an infinite distance makes the term exp2(-inf) = 0 for any (finite or -inf) table entry
+  for (int k = K + wave; k < a.Kp; k += 8) s_d[k * 64 + lane] = INFINITY;
   __syncthreads();
 
   // ---- stage B ------------------------------------------------------------------------------

@@ -822,3 +822,24 @@ def test_head_direction_averaged_state(riab):
     np.testing.assert_allclose(PCs.get_head_direction_averaged_state(evaluate_at=None, pos=pos),
                                PCs.get_state(evaluate_at=None, pos=pos), rtol=1e-6)
     assert HDCs.get_head_direction_averaged_state().shape == (8, 3)
+
+
+@pytest.mark.parametrize("dtheta", [7, 5, 1])
+def test_bvc_other_angular_resolutions_vs_oracle(riab, dtheta):
+    """K = 360 / dtheta test directions other than the default 180: 51 (not a multiple of the kernel's
+    4-direction blocks, exercising the -inf padded table rows and the clamped ray blocks), 72 and the
+    maximum 360; allocentric and egocentric, 9 walls."""
+    g = gu.load("rates.npz")
+    np.random.seed(12)
+    env = make_env(riab, g["maze_walls"][4:])
+    Ag = riab.Agent(env, {"n_agents": 2})
+    pos = g["pos"][:48]
+    hd = np.random.randn(48, 2)
+    hd /= np.linalg.norm(hd, axis=1, keepdims=True)
+    hd = hd.astype(np.float32).astype(np.float64)
+    for frame in ("allocentric", "egocentric"):
+        B = riab.BoundaryVectorCells(Ag, {"n": 13, "dtheta": dtheta, "reference_frame": frame})
+        ref = orc.bvc(pos, g["maze_walls"], B.tuning_distances, B.tuning_angles, B.sigma_distances, B.sigma_angles,
+                      dtheta=dtheta, head_direction=hd if frame == "egocentric" else None)
+        got = B.get_state(evaluate_at=None, pos=pos, head_direction=hd)
+        assert_rates(got, ref, floor=1.0)
