@@ -843,3 +843,56 @@ def test_bvc_other_angular_resolutions_vs_oracle(riab, dtheta):
                       dtheta=dtheta, head_direction=hd if frame == "egocentric" else None)
         got = B.get_state(evaluate_at=None, pos=pos, head_direction=hd)
         assert_rates(got, ref, floor=1.0)
+
+
+def _rollout_vs_oracle(riab, env_kw, walls, params, T, B=96, seed=77):
+    """Production-RNG rollout with the normals captured, replayed through the oracle."""
+    env = make_env(riab, walls, **env_kw)
+    np.random.seed(seed)
+    Ag = riab.Agent(env, dict(params, n_agents=B, seed=seed))
+    st0 = {k: np.array(getattr(Ag, k)) for k in gu.PRE_SLICES}
+    zout = torch.zeros((T, 2, B), dtype=torch.float64, device="cuda")
+    Ag._advance(T, None, None, 1, {}, z_out=zout)
+    torch.cuda.synchronize()
+    z = zout.cpu().numpy()
+    st = dict(st0, measured_rotational_velocity=np.zeros(B), distance_to_closest_wall=np.full(B, np.inf))
+    oenv = orc.EnvSpec(walls=walls, **env_kw)
+    prm = {k: v for k, v in params.items() if k != "dt"}
+    bounces = 0
+    for t in range(T):
+        st = orc.agent_step(oenv, st, params["dt"], z[t, 0], z[t, 1], params=prm)
+        bounces += int(st["n_bounces"].sum())
+    return Ag, st, bounces
+
+
+@pytest.mark.parametrize("case", ["large_dt", "many_walls", "periodic_walls", "wide_box"])
+def test_motion_stress_shapes_vs_oracle(riab, case):
+    """Corners of the parameter space the reference goldens do not reach, against the oracle on
+    the captured normals: dt so large that rotational_velocity*dt leaves the small-angle tiers,
+    the maximum wall count (60 interior + 4 boundary), interior walls in a periodic box, and a
+    non-unit scale / aspect."""
+    rs = np.random.RandomState(5)
+    if case == "large_dt":
+        env_kw, walls, T = {}, [[[.5, .2], [.5, .8]]], 60
+        # coherence time > dt keeps the Ornstein-Uhlenbeck update contractive (dt/tau = 5 would diverge)
+        params = {"dt": 0.4, "rotational_velocity_std": 4.0, "rotational_velocity_coherence_time": 0.9,
+                  "speed_mean": 0.05}
+    elif case == "many_walls":
+        a = rs.uniform(0.05, 0.95, (60, 2))
+        th = rs.uniform(0, np.pi, 60)
+        d = 0.04 * np.stack((np.cos(th), np.sin(th)), -1)
+        env_kw, walls, T = {}, np.stack((a - d, a + d), 1).tolist(), 150
+        params = {"dt": 0.02, "speed_mean": 0.2}
+    elif case == "periodic_walls":
+        env_kw, walls, T = {"boundary_conditions": "periodic"}, [[[.3, .3], [.7, .3]], [[.5, .5], [.5, .9]]], 150
+        params = {"dt": 0.03, "speed_mean": 0.25}
+    else:
+        env_kw, walls, T = {"scale": 2.5, "aspect": 1.6}, [[[1.0, 0.5], [3.0, 0.5]], [[2.0, 1.0], [2.0, 2.5]]], 150
+        params = {"dt": 0.05, "speed_mean": 0.4, "thigmotaxis": 0.8}
+    Ag, st, bounces = _rollout_vs_oracle(riab, env_kw, walls, params, T)
+    np.testing.assert_allclose(Ag.pos, st["pos"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(Ag.velocity, st["velocity"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(Ag.head_direction, st["head_direction"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(Ag.distance_travelled, st["distance_travelled"], rtol=1e-9)
+    if case != "large_dt":
+        assert bounces > 0  # the collision branch was exercised
