@@ -896,3 +896,34 @@ def test_motion_stress_shapes_vs_oracle(riab, case):
     np.testing.assert_allclose(Ag.distance_travelled, st["distance_travelled"], rtol=1e-9)
     if case != "large_dt":
         assert bounces > 0  # the collision branch was exercised
+
+
+@pytest.mark.parametrize("geometry", ["euclidean", "line_of_sight", "geodesic"])
+def test_rates_stress_shapes_vs_oracle(riab, geometry):
+    """PlaceCells (every wall geometry the environment allows) and BoundaryVectorCells in a box
+    with the maximum wall count and a non-unit scale / aspect, ragged cell and position counts."""
+    rs = np.random.RandomState(11)
+    scale, aspect = 1.7, 1.3
+    n_walls = 60 if geometry != "geodesic" else 1  # the reference's geodesic distance handles one wall
+    a = np.stack((rs.uniform(0.1, aspect * scale - 0.1, n_walls), rs.uniform(0.1, scale - 0.1, n_walls)), -1)
+    th = rs.uniform(0, np.pi, n_walls)
+    d = 0.08 * np.stack((np.cos(th), np.sin(th)), -1)
+    walls = np.stack((a - d, a + d), 1).tolist()
+    env = make_env(riab, walls, scale=scale, aspect=aspect)
+    oenv = orc.EnvSpec(scale=scale, aspect=aspect, walls=walls)
+    Ag = riab.Agent(env)
+    P, n = 333, 37
+    pos = np.stack((rs.uniform(0, aspect * scale, P), rs.uniform(0, scale, P)), -1).astype(np.float32).astype(np.float64)
+    centres = np.stack((rs.uniform(0, aspect * scale, n), rs.uniform(0, scale, n)), -1)
+    widths = rs.uniform(0.1, 0.5, n)
+    PCs = riab.PlaceCells(Ag, {"place_cell_centres": centres, "widths": 0.2, "wall_geometry": geometry,
+                               "description": "gaussian", "max_fr": 3.0, "min_fr": 0.5})
+    PCs.place_cell_widths = widths
+    got = PCs.get_state(evaluate_at=None, pos=pos)
+    ref = orc.place_cells(oenv, pos, centres, widths, wall_geometry=geometry, min_fr=0.5, max_fr=3.0)
+    assert_rates(got, ref, scale=2.5)
+    if geometry == "euclidean":
+        BVs = riab.BoundaryVectorCells(Ag, {"n": 29})
+        got = BVs.get_state(evaluate_at=None, pos=pos)
+        ref = orc.bvc(pos, env.walls, BVs.tuning_distances, BVs.tuning_angles, BVs.sigma_distances, BVs.sigma_angles)
+        assert_rates(got, ref, floor=1.0)
