@@ -193,6 +193,20 @@ int riab_grid_cells(const RiabRateIO* io, const float* table, int32_t n, int32_t
 int riab_head_direction_cells(const RiabRateIO* io, const float* table, int32_t n,
                               riab_stream_t stream);
 
+/* VelocityCells.get_state (Neurons.py:2577-2583): the HeadDirectionCells tuning of the NORMALISED
+ * velocity, scaled to [min_fr, max_fr] and then multiplied by |v| / one_sigma_speed
+ * (one_sigma_speed = Agent.speed_mean + Agent.speed_std at construction, Neurons.py:2567).
+ * The velocity is read from vel_x / vel_y: device float64 [B], rows RIAB_S_VEL_X / _Y of the agent
+ * state (what `evaluate_at="agent"` reads: Agent.velocity, not the measured velocity; T must be 1),
+ * or, when they are NULL, from the float32 rows io->hd_x / hd_y (any T). */
+int riab_velocity_cells(const RiabRateIO* io, const float* table, int32_t n, float one_sigma_speed,
+                        const double* vel_x, const double* vel_y, riab_stream_t stream);
+
+/* SpeedCell.get_state (Neurons.py:2632-2651): one cell, |v| / one_sigma_speed scaled to
+ * [min_fr, max_fr]; v = the float32 rows io->hd_x / hd_y (the newest history["vel"] = measured
+ * velocity at the agent: rows RIAB_H_VEL_X / _Y).  rates is [T][1][B]. */
+int riab_speed_cell(const RiabRateIO* io, float one_sigma_speed, riab_stream_t stream);
+
 /* BoundaryVectorCells.get_state (Neurons.py:1617-1778) with utils.vector_intercepts
  * (utils.py:30-118), gaussian / von_mises (utils.py:424-457).
  *  test_dirs  device float64 [K][2] unit test directions (Neurons.py:1584-1596)
@@ -273,7 +287,8 @@ int riab_feedforward(const RiabFFInput* inputs, int32_t n_inputs, const float* b
  * cell 4; contribs/TaskEnvironment.py:399-408) recorded once, then advanced by riab_plan_step:
  * row cursors, RNG counters and pointers are kept in C++, every kernel of every step is enqueued on
  * `stream`, nothing is allocated or synchronised. */
-enum { RIAB_POP_PLACE = 0, RIAB_POP_GRID = 1, RIAB_POP_HDC = 2, RIAB_POP_BVC = 3, RIAB_POP_OVC = 4, RIAB_POP_FF = 5 };
+enum { RIAB_POP_PLACE = 0, RIAB_POP_GRID = 1, RIAB_POP_HDC = 2, RIAB_POP_BVC = 3, RIAB_POP_OVC = 4, RIAB_POP_FF = 5,
+       RIAB_POP_VELOCITY = 6, RIAB_POP_SPEED = 7 };
 #define RIAB_FF_MAX_INPUTS 8
 
 typedef struct RiabPopulation {
@@ -298,6 +313,7 @@ typedef struct RiabPopulation {
   const int32_t* object_types; /* ovc */
   int32_t n_objects;         /* ovc */
   int32_t walls_occlude;     /* ovc */
+  float one_sigma_speed;     /* velocity / speed */
   /* additive OU noise of Neurons.update (Neurons.py:153-168, riab_neuron_noise); NULL = none */
   float* noise_state;        /* device float32 [n][B] */
   float noise_theta_dt;      /* dt / noise_coherence_time */

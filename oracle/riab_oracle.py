@@ -575,6 +575,24 @@ def head_direction_cells(head_direction, n, angular_spread_degrees=45.0, min_fr=
     return fr * (max_fr - min_fr) + min_fr
 
 
+def velocity_cells(velocity, n, one_sigma_speed, angular_spread_degrees=45.0, min_fr=0.0, max_fr=1.0,
+                   scale_velocity=None):
+    """VelocityCells.get_state (Neurons.py:2577-2583): HeadDirectionCells tuned to `velocity / |velocity|`
+    (Neurons.py:2446-2461), scaled to [min_fr, max_fr], THEN multiplied by `|v| / one_sigma_speed` where v
+    is the agent's velocity (`scale_velocity`; the reference uses Agent.velocity for the scale even when a
+    `velocity=` kwarg gives the direction, :2581) -> `(n, P)`."""
+    v = np.asarray(velocity, dtype=np.float64).reshape(-1, 2)
+    fr = head_direction_cells(v / np.linalg.norm(v, axis=-1, keepdims=True), n, angular_spread_degrees, min_fr, max_fr)
+    sv = v if scale_velocity is None else np.asarray(scale_velocity, dtype=np.float64).reshape(-1, 2)
+    return fr * (np.linalg.norm(sv, axis=-1) / one_sigma_speed)[None, :]
+
+
+def speed_cell(vel, one_sigma_speed, min_fr=0.0, max_fr=1.0):
+    """SpeedCell.get_state (Neurons.py:2632-2651) -> `(1, P)`."""
+    v = np.asarray(vel, dtype=np.float64).reshape(-1, 2)
+    return (np.linalg.norm(v, axis=-1) / one_sigma_speed * (max_fr - min_fr) + min_fr)[None, :]
+
+
 def object_vector_cells(env, pos, objects, object_types, tuning_distances, tuning_angles, sigma_distances,
                         sigma_angles, tuning_types, walls_occlude=True, head_direction=None, min_fr=0.0, max_fr=1.0):
     """ObjectVectorCells.get_state (Neurons.py:1991-2116) -> `(n, P)`.  `head_direction (P,2)`

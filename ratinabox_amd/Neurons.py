@@ -47,6 +47,10 @@ class Neurons:
         "save_spikes": True,  # False: skip the Poisson-spike draw and its history (rates only)
     }
 
+    # which per-agent direction rows feed io.hd_x / hd_y: (history-record rows, float64 state rows)
+    _H_DIR = (_L.H_HD_X, _L.H_HD_Y)
+    _S_DIR = (_L.S_HD_X, _L.S_HD_Y)
+
     def __init__(self, Agent, params={}):
         self.Agent = Agent
         self.Agent.Neurons.append(self)
@@ -180,12 +184,12 @@ class Neurons:
         row = Ag._last_row
         if row is not None:
             # the motion kernel already left this step's fp32 positions / head directions
-            self._launch(row[_L.H_POS_X], row[_L.H_POS_Y], row[_L.H_HD_X], row[_L.H_HD_Y], pos_ld=self._Bp, T=1,
+            self._launch(row[_L.H_POS_X], row[_L.H_POS_Y], row[self._H_DIR[0]], row[self._H_DIR[1]], pos_ld=self._Bp, T=1,
                          B=self._Bp, rates=rates, spikes=io_spikes, u_in=u_t if not need_noise else None,
                          dt=float(Ag.dt), step0=Ag._step_index)
         else:
             st = Ag._state
-            self._launch(st[_L.S_POS_X], st[_L.S_POS_Y], st[_L.S_HD_X], st[_L.S_HD_Y], pos_ld=self._Bp, T=1,
+            self._launch(st[_L.S_POS_X], st[_L.S_POS_Y], st[self._S_DIR[0]], st[self._S_DIR[1]], pos_ld=self._Bp, T=1,
                          B=self._Bp, rates=rates, spikes=io_spikes, u_in=u_t if not need_noise else None,
                          dt=float(Ag.dt), step0=Ag._step_index, from_f64=True)
         if need_noise:
@@ -244,7 +248,7 @@ class Neurons:
             st = Ag._state
             P = self._Bp
             self._last_P = self._B
-            px, py, hx, hy = (st[_L.S_POS_X], st[_L.S_POS_Y], st[_L.S_HD_X], st[_L.S_HD_Y])
+            px, py, hx, hy = (st[_L.S_POS_X], st[_L.S_POS_Y], st[self._S_DIR[0]], st[self._S_DIR[1]])
             out = torch.empty((1, int(self.n), P), dtype=torch.float32, device=self._device)
             self._launch(px, py, hx, hy, pos_ld=P, T=1, B=P, rates=out, spikes=None, u_in=None, dt=float(Ag.dt),
                          step0=0, from_f64=True)
@@ -341,7 +345,7 @@ class Neurons:
         if hook is not None:
             hook(self, "begin", tc)
         noisy = self.noise_std != 0
-        self._launch(traj[0, _L.H_POS_X], traj[0, _L.H_POS_Y], traj[0, _L.H_HD_X], traj[0, _L.H_HD_Y], pos_ld=ld,
+        self._launch(traj[0, _L.H_POS_X], traj[0, _L.H_POS_Y], traj[0, self._H_DIR[0]], traj[0, self._H_DIR[1]], pos_ld=ld,
                      T=tc, B=Bp, rates=fr, spikes=None if noisy else sp, u_in=None, dt=dt, step0=step0 + 1,
                      stream=stream)
         if hook is not None:
@@ -884,6 +888,122 @@ class HeadDirectionCells(Neurons):
             return dict(kind=_L.POP_KINDS["hdc"], table=tab)
         rc = _L.lib.riab_head_direction_cells(io, _L.ptr(tab), n, stream)
         _L.check(rc, "riab_head_direction_cells")
+
+
+# ================================================================================================
+class VelocityCells(HeadDirectionCells):
+    """HeadDirectionCells tuned to the direction of the agent's velocity, scaled by
+    `|velocity| / one_sigma_speed`, one_sigma_speed = speed_mean + speed_std when the cells are made
+    (reference Neurons.py:2534-2583).  At the agent the reference reads `Agent.velocity` (the state of
+    the motion model, not the measured velocity the history keeps), which lives in the float64 agent
+    state only: `update()`, `get_state()` and step plans read it there; `Agent.simulate()` cannot
+    (its rate stage runs on the float32 history records) and raises."""
+
+    default_params = {
+        "min_fr": 0,
+        "max_fr": 1,
+        "name": "VelocityCells",
+    }
+
+    def __init__(self, Agent, params={}):
+        self.Agent = Agent
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        self.one_sigma_speed = float(self.Agent.speed_mean + self.Agent.speed_std)
+        self._vel_from_state = False
+        super().__init__(Agent, self.params)
+
+    def update(self, **kwargs):
+        self._vel_from_state = True
+        try:
+            super().update(**kwargs)
+        finally:
+            self._vel_from_state = False
+
+    def get_state_tensor(self, evaluate_at="agent", **kwargs):
+        if evaluate_at == "agent":
+            self._vel_from_state = True
+            try:
+                return Neurons.get_state_tensor(self, "agent")
+            finally:
+                self._vel_from_state = False
+        # away from the agent the reference tunes to the given `velocity=` but still scales by the
+        # AGENT's speed (Neurons.py:2581): the direction tuning runs as HeadDirectionCells, the scale
+        # is one factor per agent
+        vel = np.asarray(kwargs.get("velocity", [1.0, 0.0]), dtype=np.float64).reshape(-1, 2)
+        pos = (self.Agent.Environment.flattened_discrete_coords if evaluate_at == "all"
+               else np.asarray(kwargs.get("pos", np.zeros((len(vel), 2))), dtype=np.float64).reshape(-1, 2))
+        direction = vel / np.linalg.norm(vel, axis=-1, keepdims=True)
+        self._as_hdc = True
+        try:
+            out = Neurons.get_state_tensor(self, None, pos=pos, head_direction=direction)
+        finally:
+            self._as_hdc = False
+        speed = torch.linalg.vector_norm(self.Agent._state[_L.S_VEL_X:_L.S_VEL_Y + 1, :self._B], dim=0)
+        if self._B == 1:
+            return out * (speed[0] / self.one_sigma_speed).to(torch.float32)
+        if self._last_P != self._B:
+            raise ValueError("VelocityCells.get_state away from the agents scales by each agent's own speed: "
+                             "pass one velocity per agent")
+        scale = torch.ones(out.shape[1], dtype=torch.float32, device=out.device)
+        scale[:self._B] = (speed / self.one_sigma_speed).to(torch.float32)
+        return out * scale
+
+    def get_state(self, evaluate_at="agent", **kwargs):
+        t = self.get_state_tensor(evaluate_at, **kwargs)
+        return t[:, :self._last_P].cpu().numpy().astype(np.float64)
+
+    def _rates_from_trajectory(self, traj, out, t0, tc, step0, dt, stream):
+        raise NotImplementedError("VelocityCells read Agent.velocity, which the fused simulate() pipeline does not "
+                                  "keep per step; advance them with update() or a step plan")
+
+    def _call(self, io, stream):
+        if getattr(self, "_as_hdc", False):
+            return super()._call(io, stream)
+        f = super()._call(None, None)
+        if io is None:
+            return dict(kind=_L.POP_KINDS["velocity"], table=f["table"], one_sigma_speed=float(self.one_sigma_speed))
+        st = self.Agent._state
+        vx, vy = (_L.ptr(st[_L.S_VEL_X]), _L.ptr(st[_L.S_VEL_Y])) if self._vel_from_state else (None, None)
+        rc = _L.lib.riab_velocity_cells(io, _L.ptr(f["table"]), int(self.n), float(self.one_sigma_speed), vx, vy, stream)
+        _L.check(rc, "riab_velocity_cells")
+
+
+class SpeedCell(Neurons):
+    """One cell whose rate is `|measured velocity| / one_sigma_speed` scaled to [min_fr, max_fr]
+    (reference Neurons.py:2586-2651; `evaluate_at="agent"` reads `Agent.history["vel"][-1]`, the
+    measured velocity of the newest step; otherwise pass `vel=`)."""
+
+    default_params = {
+        "min_fr": 0,
+        "max_fr": 1,
+        "name": "SpeedCell",
+    }
+    _H_DIR = (_L.H_VEL_X, _L.H_VEL_Y)
+    _S_DIR = (_L.S_MVEL_X, _L.S_MVEL_Y)
+
+    def __init__(self, Agent, params={}):
+        self.Agent = Agent
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        if "n" in params and params["n"] != 1:
+            warnings.warn(f"Ignoring 'n' parameter value ({params['n']}) that was passed for "
+                          f"{self.params['name']}. Only 1 speed cell is needed.")
+        self.params["n"] = 1
+        self.one_sigma_speed = float(self.Agent.speed_mean + self.Agent.speed_std)
+        super().__init__(Agent, self.params)
+        self.n = 1
+
+    def get_state_tensor(self, evaluate_at="agent", **kwargs):
+        if evaluate_at == "agent":
+            return super().get_state_tensor("agent")
+        vel = np.asarray(kwargs["vel"], dtype=np.float64).reshape(-1, 2)
+        return super().get_state_tensor(None, pos=np.zeros((len(vel), 2)), head_direction=vel)
+
+    def _call(self, io, stream):
+        if io is None:
+            return dict(kind=_L.POP_KINDS["speed"], one_sigma_speed=float(self.one_sigma_speed))
+        _L.check(_L.lib.riab_speed_cell(io, float(self.one_sigma_speed), stream), "riab_speed_cell")
 
 
 # ================================================================================================

@@ -13,7 +13,8 @@ from .Environment import Environment  # noqa: E402,F401
 from .Agent import Agent  # noqa: E402,F401
 from .Neurons import (  # noqa: E402,F401
     Neurons, PlaceCells, GridCells, VectorCells, BoundaryVectorCells, FieldOfViewBVCs, ObjectVectorCells,
-    FieldOfViewOVCs, HeadDirectionCells, FeedForwardLayer)
+    FieldOfViewOVCs, HeadDirectionCells, VelocityCells, SpeedCell, FeedForwardLayer)
 
 __all__ = ["Environment", "Agent", "Neurons", "PlaceCells", "GridCells", "VectorCells", "BoundaryVectorCells",
-           "FieldOfViewBVCs", "ObjectVectorCells", "FieldOfViewOVCs", "HeadDirectionCells", "FeedForwardLayer", "utils"]
+           "FieldOfViewBVCs", "ObjectVectorCells", "FieldOfViewOVCs", "HeadDirectionCells", "VelocityCells", "SpeedCell",
+           "FeedForwardLayer", "utils"]

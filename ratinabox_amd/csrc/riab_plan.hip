@@ -98,7 +98,7 @@ extern "C" int riab_plan_set_agent_history(RiabPlan* p, float* hist_base, int64_
 }
 
 extern "C" int riab_plan_add(RiabPlan* p, const RiabPopulation* pop) {
-  if (!p || !pop || pop->n <= 0 || pop->kind < RIAB_POP_PLACE || pop->kind > RIAB_POP_FF) return RIAB_EINVAL;
+  if (!p || !pop || pop->n <= 0 || pop->kind < RIAB_POP_PLACE || pop->kind > RIAB_POP_SPEED) return RIAB_EINVAL;
   if (pop->kind == RIAB_POP_FF) {
     if (pop->n_inputs <= 0 || pop->n_inputs > RIAB_FF_MAX_INPUTS || !pop->bias) return RIAB_EINVAL;
     for (int l = 0; l < pop->n_inputs; ++l)  // feed-forward only: an input must already be in the plan
@@ -204,6 +204,15 @@ static int launch_population(RiabPlan* p, size_t i, const float* row, hipStream_
       break;
     case RIAB_POP_HDC:
       rc = riab_head_direction_cells(&io, q.table, q.n, s);
+      break;
+    case RIAB_POP_VELOCITY:  // Agent.velocity: rows of the float64 state, not of the history record
+      rc = riab_velocity_cells(&io, q.table, q.n, q.one_sigma_speed, p->state + RIAB_S_VEL_X * B,
+                               p->state + RIAB_S_VEL_Y * B, s);
+      break;
+    case RIAB_POP_SPEED:  // history["vel"][-1]: the measured velocity of the step just taken
+      io.hd_x = row + RIAB_H_VEL_X * B;
+      io.hd_y = row + RIAB_H_VEL_Y * B;
+      rc = riab_speed_cell(&io, q.one_sigma_speed, s);
       break;
     case RIAB_POP_BVC:
       rc = riab_boundary_vector_cells(&p->env, &io, q.test_dirs, q.ray_rden, q.K, q.table, q.vm_table, q.inv_norm, q.n,

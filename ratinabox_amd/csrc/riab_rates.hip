@@ -51,8 +51,9 @@ struct PosQuad {
 
 __device__ __forceinline__ v4f ldv4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
 
+// finish_rate: per-position epilogue on the rate already scaled to [min_fr, max_fr].
 // Neurons.update returns zeros while the agent's position is NaN (reference Neurons.py:163-164)
-__device__ __forceinline__ v4f nan_pos_to_zero(v4f r, const PosQuad& P) {
+__device__ __forceinline__ v4f finish_rate(v4f r, const PosQuad& P) {
   r.x = (P.x.x == P.x.x) ? r.x : 0.0f;
   r.y = (P.x.y == P.x.y) ? r.y : 0.0f;
   r.z = (P.x.z == P.x.z) ? r.z : 0.0f;
@@ -60,7 +61,7 @@ __device__ __forceinline__ v4f nan_pos_to_zero(v4f r, const PosQuad& P) {
   return r;
 }
 template <class P_>
-__device__ __forceinline__ v4f nan_pos_to_zero(v4f r, const P_&) { return r; }
+__device__ __forceinline__ v4f finish_rate(v4f r, const P_&) { return r; }
 
 // ---- spike epilogue: Neurons.save_to_history (reference Neurons.py:681-687) -------------
 template <bool EXPLICIT_U>
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void rate_kernel_wide(const RateArgs a, Cell c
       for (int i = 0; i < NP; ++i)
         p[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), j * NP + i));
       v4f r = cell.eval(p, P);
-      r = nan_pos_to_zero(r * a.fr_scale + a.fr_min, P);  // [0,1] -> [min_fr, max_fr]
+      r = finish_rate(r * a.fr_scale + a.fr_min, P);  // [0,1] -> [min_fr, max_fr]
       if (live) {
         *reinterpret_cast<v4f*>(a.rates + off) = r;
         if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)(c0 + j), group);
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void rate_kernel_generic(const RateArgs a, Cel
       for (int i = 0; i < NP; ++i)
         p[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine[i]), j));
       v4f r = cell.eval(p, P);
-      r = nan_pos_to_zero(r * a.fr_scale + a.fr_min, P);
+      r = finish_rate(r * a.fr_scale + a.fr_min, P);
       if (live) {
         __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(a.rates + off));
         if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)(cb + j), group);
@@ -336,17 +337,46 @@ struct GridCell {
   }
 };
 
-// ---- HeadDirectionCells (reference Neurons.py:2466-2483, utils.py:231-273, 441-457) --------
+// ---- HeadDirectionCells / VelocityCells / SpeedCell ------------------------------------------
+// (reference Neurons.py:2466-2483, 2577-2583, 2632-2651; utils.py:231-273, 441-457)
+// MODE 0: von Mises of utils.get_angle(head direction).
+// MODE 1: the same of the NORMALISED velocity, times |v| / one_sigma_speed after the [min_fr, max_fr] scaling.
+// MODE 2: one cell, |v| / one_sigma_speed.
+template <int MODE>
 struct HDCell {
   struct Pos {
     v4f ang;
+    v4f speed;  // |v| / one_sigma_speed (MODE >= 1)
   };
   static constexpr int LDS_DOUBLES = 1;
   __device__ __forceinline__ void stage(double*) {}
   const float* tab;  // [n][2] = (preferred angle, kappa * log2(e))
+  float speed_inv;   // 1 / one_sigma_speed
+  const double* vx64;  // MODE 1 at the agent: rows RIAB_S_VEL_X / _Y of the float64 state (T = 1), or NULL
+  const double* vy64;
   __device__ __forceinline__ Pos load(const RateArgs& a, int64_t off) const {
-    const v4f hx = ldv4(a.hd_x + off), hy = ldv4(a.hd_y + off);
+    v4f hx, hy;
+    if (MODE == 1 && vx64) {
+      const double* px = vx64 + off;
+      const double* py = vy64 + off;
+      hx = v4f{(float)px[0], (float)px[1], (float)px[2], (float)px[3]};
+      hy = v4f{(float)py[0], (float)py[1], (float)py[2], (float)py[3]};
+    } else {
+      hx = ldv4(a.hd_x + off);
+      hy = ldv4(a.hd_y + off);
+    }
     Pos P;
+    if (MODE >= 1) {
+      const v4f sp{sqrtf(fmaf(hy.x, hy.x, hx.x * hx.x)), sqrtf(fmaf(hy.y, hy.y, hx.y * hx.y)),
+                   sqrtf(fmaf(hy.z, hy.z, hx.z * hx.z)), sqrtf(fmaf(hy.w, hy.w, hx.w * hx.w))};
+      P.speed = sp * speed_inv;
+      if (MODE == 1) {  // direction = vel / |vel| before the 1e-6 of get_angle
+        hx = hx / sp;
+        hy = hy / sp;
+      }
+    } else {
+      P.speed = v4f{1.0f, 1.0f, 1.0f, 1.0f};
+    }
     // utils.get_angle: atan2(y, x + 1e-6); the mod 2pi is irrelevant under the cosine
     P.ang.x = atan2f(hy.x, hx.x + 1e-6f);
     P.ang.y = atan2f(hy.y, hx.y + 1e-6f);
@@ -360,10 +390,14 @@ struct HDCell {
   static constexpr int NP = 2;
   static constexpr int CPB = 32;  // amortise the per-position atan2 over many cells
   __device__ __forceinline__ v4f eval(const float* p, const Pos& P) const {
+    if (MODE == 2) return P.speed;
     const float pr = p[0], k2 = p[1];
     return v4f{one(P.ang.x, pr, k2), one(P.ang.y, pr, k2), one(P.ang.z, pr, k2), one(P.ang.w, pr, k2)};
   }
 };
+
+// VelocityCells: HDC_firingrates * speed_scale, AFTER the scaling to [min_fr, max_fr] (Neurons.py:2580-2582)
+__device__ __forceinline__ v4f finish_rate(v4f r, const HDCell<1>::Pos& P) { return r * P.speed; }
 
 // ---- standalone spikes on existing rates ----------------------------------------------------
 template <bool EXPLICIT_U>
@@ -573,8 +607,28 @@ extern "C" int riab_head_direction_cells(const RiabRateIO* io, const float* tabl
   if (!table) return RIAB_EINVAL;
   const int rc = check_io(io, n, false, true);
   if (rc) return rc;
-  HDCell c{table};
+  HDCell<0> c{table, 0.0f, nullptr, nullptr};
   return launch_rate(io, n, c, (hipStream_t)stream);
+}
+
+extern "C" int riab_velocity_cells(const RiabRateIO* io, const float* table, int32_t n, float one_sigma_speed,
+                                   const double* vel_x, const double* vel_y, riab_stream_t stream) {
+  if (!table || !(one_sigma_speed > 0.0f) || (vel_x == nullptr) != (vel_y == nullptr)) return RIAB_EINVAL;
+  const int rc = check_io(io, n, false, vel_x == nullptr);
+  if (rc) return rc;
+  if (vel_x && io->T != 1) return RIAB_EINVAL;  // the state holds the current step only
+  if (((uintptr_t)vel_x | (uintptr_t)vel_y) & 31) return RIAB_EALIGN;
+  HDCell<1> c{table, 1.0f / one_sigma_speed, vel_x, vel_y};
+  return launch_rate(io, n, c, (hipStream_t)stream);
+}
+
+extern "C" int riab_speed_cell(const RiabRateIO* io, float one_sigma_speed, riab_stream_t stream) {
+  if (!(one_sigma_speed > 0.0f)) return RIAB_EINVAL;
+  const int rc = check_io(io, 1, false, true);
+  if (rc) return rc;
+  // the single cell has no parameters; the table pointer only has to be readable (two floats)
+  HDCell<2> c{io->hd_x, 1.0f / one_sigma_speed, nullptr, nullptr};
+  return launch_rate(io, 1, c, (hipStream_t)stream);
 }
 
 extern "C" int riab_spikes(const RiabRateIO* io, int32_t n, riab_stream_t stream) {

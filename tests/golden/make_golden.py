@@ -492,6 +492,41 @@ def make_ovc():
     np.savez_compressed(os.path.join(HERE, "ovc.npz"), **out)
 
 
+def make_velocity():
+    """VelocityCells / SpeedCell (Neurons.py:2534-2651) along the reference's own run in the maze: per step
+    the velocity state (what VelocityCells read), the measured velocity (history["vel"][-1], what the
+    SpeedCell reads) and both populations' rates after update(); plus get_state on given velocities."""
+    from ratinabox.Neurons import VelocityCells, SpeedCell
+    print("velocity / speed cells")
+    np.random.seed(41)
+    out = {}
+    Env = Environment({"walls": MAZE_WALLS})
+    Ag = Agent(Env, {"dt": 0.02, "speed_mean": 0.15})
+    VCs = VelocityCells(Ag, {"n": 12, "angular_spread_degrees": 30, "min_fr": 0.2, "max_fr": 3.0})
+    SC = SpeedCell(Ag, {"min_fr": 0.5, "max_fr": 2.0})
+    vel, mvel, vr, sr = [], [], [], []
+    for t in range(400):
+        Ag.update()
+        VCs.update()
+        SC.update()
+        vel.append(np.array(Ag.velocity))
+        mvel.append(np.array(Ag.history["vel"][-1]))
+        vr.append(VCs.firingrate.copy())
+        sr.append(SC.firingrate.copy())
+    out.update(vel=np.array(vel), mvel=np.array(mvel), vc_rates=np.array(vr), sc_rates=np.array(sr),
+               one_sigma_speed=VCs.one_sigma_speed, n=12, spread=30.0, vc_min=0.2, vc_max=3.0, sc_min=0.5, sc_max=2.0)
+    differs = np.abs(np.array(vel) - np.array(mvel)).max(axis=1) > 1e-9
+    print(f"  velocity != measured velocity on {int(differs.sum())} of 400 steps")
+    # get_state away from the agent: the scale still uses the AGENT's speed (Neurons.py:2581)
+    rs = np.random.RandomState(3)
+    v = f32exact(rs.normal(0, 0.2, (64, 2)))
+    out["gs_vel"] = v
+    out["gs_agent_vel"] = np.array(Ag.velocity)
+    out["gs_vc"] = np.stack([VCs.get_state(evaluate_at=None, velocity=v[i])[:, 0] for i in range(64)], axis=1)
+    out["gs_sc"] = np.stack([SC.get_state(evaluate_at=None, vel=v[i]) for i in range(64)], axis=1)
+    np.savez_compressed(os.path.join(HERE, "velocity.npz"), **out)
+
+
 def make_task():
     """TaskEnvironment.step / reset (contribs/TaskEnvironment.py): single-agent replicas of a
     SpatialGoalEnvironment, one per lane, driven towards their goals; per step the action, the two
@@ -637,11 +672,13 @@ def make_stats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "task", "stats"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "velocity", "task", "stats"]
     if "stats" in which:
         make_stats()
     if "task" in which:
         make_task()
+    if "velocity" in which:
+        make_velocity()
     if "ovc" in which:
         make_ovc()
     if "feedforward" in which:

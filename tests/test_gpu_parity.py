@@ -927,3 +927,86 @@ def test_rates_stress_shapes_vs_oracle(riab, geometry):
         got = BVs.get_state(evaluate_at=None, pos=pos)
         ref = orc.bvc(pos, env.walls, BVs.tuning_distances, BVs.tuning_angles, BVs.sigma_distances, BVs.sigma_angles)
         assert_rates(got, ref, floor=1.0)
+
+
+def test_velocity_and_speed_cells_vs_reference(riab):
+    """VelocityCells / SpeedCell (reference Neurons.py:2534-2651) on the velocity states and measured
+    velocities of the reference's own run, one lane per recorded step; get_state away from the agent."""
+    g = gu.load("velocity.npz")
+    T = len(g["vel"])
+    Ag = riab.Agent(make_env(riab), {"n_agents": T, "dt": 0.02, "speed_mean": 0.15})
+    prm = dict(n=int(g["n"]), angular_spread_degrees=float(g["spread"]), min_fr=float(g["vc_min"]),
+               max_fr=float(g["vc_max"]))
+    VCs = riab.VelocityCells(Ag, prm)
+    SC = riab.SpeedCell(Ag, {"min_fr": float(g["sc_min"]), "max_fr": float(g["sc_max"])})
+    assert np.isclose(VCs.one_sigma_speed, float(g["one_sigma_speed"])) and SC.n == 1
+    Ag.velocity = g["vel"]
+    Ag.measured_velocity = g["mvel"]
+    VCs.update()
+    SC.update()
+    assert_rates(VCs.firingrate, g["vc_rates"].T)
+    assert_rates(SC.firingrate, g["sc_rates"][:, :1].T)
+    assert_rates(VCs.get_state(), g["vc_rates"].T)
+    # one agent, many velocities: tuned to the kwarg, scaled by the agent's own speed (Neurons.py:2581)
+    Ag1 = riab.Agent(make_env(riab), {"dt": 0.02, "speed_mean": 0.15})
+    VC1 = riab.VelocityCells(Ag1, prm)
+    SC1 = riab.SpeedCell(Ag1, {"min_fr": float(g["sc_min"]), "max_fr": float(g["sc_max"])})
+    Ag1.velocity = g["gs_agent_vel"]
+    assert_rates(VC1.get_state(evaluate_at=None, velocity=g["gs_vel"]), g["gs_vc"])
+    assert_rates(SC1.get_state(evaluate_at=None, vel=g["gs_vel"]), g["gs_sc"])
+    with pytest.warns(UserWarning):
+        assert riab.SpeedCell(Ag1, {"n": 5}).n == 1
+
+
+def test_velocity_and_speed_cells_closed_loop(riab):
+    """VelocityCells + SpeedCell feeding a FeedForwardLayer while the agents move through the maze: the
+    eager loop against the oracle on each step's Agent.velocity / history["vel"][-1]; a step plan
+    reproduces the eager loop; float32 velocity rows through the C ABI; simulate() refuses VelocityCells."""
+    walls = [[[.2, 0], [.2, .4]], [[.6, 1], [.6, .5]]]
+
+    def world():
+        np.random.seed(9)
+        Ag = riab.Agent(make_env(riab, walls), {"n_agents": 70, "dt": 0.05, "speed_mean": 0.3, "seed": 5})
+        VCs = riab.VelocityCells(Ag, {"n": 6, "max_fr": 2.0})
+        SC = riab.SpeedCell(Ag, {"max_fr": 4.0})
+        FF = riab.FeedForwardLayer(Ag, {"n": 5, "activation_function": {"activation": "tanh"}})
+        FF.add_input(VCs)
+        FF.add_input(SC)
+        return Ag, VCs, SC, FF
+
+    Ag, VCs, SC, FF = world()
+    T = 40
+    differs = 0
+    for _ in range(T):
+        Ag.update()
+        for N in (VCs, SC, FF):
+            N.update()
+        v, mv = np.asarray(Ag.velocity), np.asarray(Ag.history["vel"][-1])
+        differs += int((np.abs(v - mv).max(axis=-1) > 1e-9).sum())
+        assert_rates(VCs.firingrate, orc.velocity_cells(v, 6, VCs.one_sigma_speed, max_fr=2.0))
+        assert_rates(SC.firingrate, orc.speed_cell(mv.astype(np.float32), SC.one_sigma_speed, max_fr=4.0))
+    assert differs > 0  # velocity state and measured velocity do part company near walls
+    ref = {N.name + str(i): np.array(N.history["firingrate"]) for i, N in enumerate((VCs, SC, FF))}
+    pos = np.asarray(Ag.pos)
+    Ag, VCs, SC, FF = world()
+    plan = Ag.make_step_plan(capacity=T)
+    for _ in range(T):
+        plan.step()
+    assert np.array_equal(np.asarray(Ag.pos), pos)
+    for i, N in enumerate((VCs, SC, FF)):
+        assert np.array_equal(np.array(N.history["firingrate"]), ref[N.name + str(i)])
+    # C ABI: velocity read from float32 rows (vel_x == NULL), T rows at once
+    L = riab._lib
+    rs = np.random.RandomState(2)
+    vel = rs.normal(0, 0.3, (3, 2, 64)).astype(np.float32)
+    d = torch.from_numpy(vel).cuda()
+    out = torch.empty((3, 6, 64), dtype=torch.float32, device="cuda")
+    io = VCs._io(None, None, d[0, 0], d[0, 1], 2 * 64, 3, 64, out, None, None, 0.05, 0)
+    tab = VCs._call(None, None)["table"]
+    L.check(L.lib.riab_velocity_cells(io, L.ptr(tab), 6, float(VCs.one_sigma_speed), None, None, L.current_stream()),
+            "riab_velocity_cells")
+    for t in range(3):
+        assert_rates(out[t].cpu().numpy(), orc.velocity_cells(vel[t].T.astype(np.float64), 6, VCs.one_sigma_speed,
+                                                              max_fr=2.0))
+    with pytest.raises(NotImplementedError):
+        Ag.simulate(4)

@@ -259,3 +259,22 @@ def test_long_run_statistics_vs_reference(name):
             dwall.append(st["distance_to_closest_wall"].copy())
             pos.append(st["pos"].copy())
     assert_long_run_stats(_long_run_stats(*map(np.array, (speed, rot, dwall, pos))), g, name)
+
+
+def test_velocity_and_speed_cells():
+    """VelocityCells / SpeedCell (Neurons.py:2534-2651) along the reference's own run."""
+    g = gu.load("velocity.npz")
+    oss = float(g["one_sigma_speed"])
+    got = orc.velocity_cells(g["vel"], int(g["n"]), oss, float(g["spread"]), float(g["vc_min"]), float(g["vc_max"]))
+    np.testing.assert_allclose(got, g["vc_rates"].T, rtol=1e-12)
+    got = orc.speed_cell(g["mvel"], oss, float(g["sc_min"]), float(g["sc_max"]))
+    # the reference's SpeedCell keeps firingrate at the base class's default length 10 (n is set to 1 only
+    # after Neurons.__init__ sized the arrays): ten copies of the one rate
+    assert (g["sc_rates"] == g["sc_rates"][:, :1]).all()
+    np.testing.assert_allclose(got[0], g["sc_rates"][:, 0], rtol=1e-12)
+    # away from the agent: direction from the kwarg, scale from the agent's own velocity
+    got = orc.velocity_cells(g["gs_vel"], int(g["n"]), oss, float(g["spread"]), float(g["vc_min"]), float(g["vc_max"]),
+                             scale_velocity=np.broadcast_to(g["gs_agent_vel"], g["gs_vel"].shape))
+    np.testing.assert_allclose(got, g["gs_vc"], rtol=1e-12)
+    np.testing.assert_allclose(orc.speed_cell(g["gs_vel"], oss, float(g["sc_min"]), float(g["sc_max"])), g["gs_sc"],
+                               rtol=1e-12)
