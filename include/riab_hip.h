@@ -138,6 +138,40 @@ int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, double* state,
                     const double* forced_pos, uint64_t seed, uint64_t step0, int32_t T, float* hist, int32_t* diag,
                     int32_t precision, riab_stream_t stream);
 
+/* ---- Environment geometry queries ---------------------------------------------------------
+ * The stand-alone forms of the helpers riab_agent_step / riab_place_cells inline, for callers of
+ * the reference's Environment API.  float64 like the reference's functions; device pointers;
+ * `geometry` is RIAB_GEOM_* (declared below). */
+
+/* Environment.get_vectors_between___accounting_for_environment (Environment.py:657-675) and
+ * get_distances_between___accounting_for_environment (Environment.py:677-779) for all pairs
+ * (pos1[i], pos2[j]): vec = pos1[i] - pos2[j], wrapped when periodic; dist = |vec|, 1000 where
+ * an internal wall (walls[4:]) blocks the line of sight (line_of_sight), or the route round the
+ * single internal wall (geodesic).  x1,y1 [N1]; x2,y2 [N2]; dist / vec_x / vec_y [N1][N2], each
+ * may be NULL (not all). */
+int riab_env_pairwise(const RiabEnv* env, const double* x1, const double* y1, int64_t N1, const double* x2,
+                      const double* y2, int64_t N2, int32_t geometry, double* dist, double* vec_x, double* vec_y,
+                      riab_stream_t stream);
+
+/* Environment.vectors_from_walls (Environment.py:843-853) = utils.shortest_vectors_from_points_to_lines
+ * (utils.py:121-184) for P positions: out [n_walls][2][P], the vector from the nearest point of
+ * wall w to position p. */
+int riab_env_vectors_from_walls(const RiabEnv* env, const double* pos_x, const double* pos_y, int64_t P,
+                                double* out, riab_stream_t stream);
+
+/* Environment.check_wall_collisions (Environment.py:820-841; utils.vector_intercepts with
+ * return_collisions=True, utils.py:74-106) for P proposed steps (x0,y0)->(x1,y1):
+ * out uint8 [n_walls][P], 1 where the step strictly crosses the wall. */
+int riab_env_check_wall_collisions(const RiabEnv* env, const double* x0, const double* y0, const double* x1,
+                                   const double* y1, int64_t P, uint8_t* out, riab_stream_t stream);
+
+/* Environment.check_if_position_is_in_environment (Environment.py:781-818, rectangular box: strict
+ * interior) -> inside_out uint8 [P] (or NULL), and, when `apply`, Environment.apply_boundary_conditions
+ * (Environment.py:855-894) in place: positions outside are clamped to [min+0.01, max-0.01] (solid)
+ * or wrapped modulo the extent (periodic). */
+int riab_env_boundary_conditions(const RiabEnv* env, double* pos_x, double* pos_y, int64_t P, uint8_t* inside_out,
+                                 int32_t apply, riab_stream_t stream);
+
 /* Where a firing-rate kernel reads positions and writes rates / spikes.
  * Positions are T rows of B agents: row t of x starts at pos_x + t*pos_ld
  * (so a trajectory history [T][8][B] is consumed in place with pos_ld = 8*B,

@@ -73,6 +73,7 @@ class Environment:
         self.discrete_coords = self.discretise_environment(dx=self.dx)
         self.flattened_discrete_coords = self.discrete_coords.reshape(-1, self.discrete_coords.shape[-1])
         self._device_cache = {}
+        self.query_device = "cuda"  # where the geometry queries (get_distances_between... etc.) run
 
     @classmethod
     def get_all_default_params(cls, verbose=False):
@@ -171,6 +172,98 @@ class Environment:
         pos = np.asarray(pos, dtype=float).reshape(-1)
         e = self.extent
         return bool((pos[0] > e[0]) and (pos[0] < e[1]) and (pos[1] > e[2]) and (pos[1] < e[3]))
+
+    # -- geometry queries on device (the stand-alone forms of what the kernels inline) ----------
+    def _query_rows(self, pos):
+        """(P,2) host positions -> device float64 rows x [P], y [P]."""
+        import torch
+        a = np.ascontiguousarray(np.asarray(pos, dtype=np.float64).reshape(-1, 2).T)
+        t = torch.from_numpy(a).to(self.query_device)
+        return t[0], t[1]
+
+    def get_vectors_between___accounting_for_environment(self, pos1=None, pos2=None, line_segments=None):
+        """Pairwise vectors `pos1[i] - pos2[j]` `(N1, N2, 2)`, wrapped round a periodic box
+        (reference Environment.py:657-675).  `line_segments (N1, N2, 2, 2)` as in the reference:
+        [..., 0, :] = pos1[i], [..., 1, :] = pos2[j]."""
+        return self._pairwise(pos1, pos2, line_segments, "euclidean", want_dist=False)
+
+    def get_distances_between___accounting_for_environment(self, pos1, pos2, wall_geometry="euclidean",
+                                                           return_vectors=False):
+        """Pairwise distances `(N1, N2)` under the wall geometry ("euclidean", "line_of_sight": 1000
+        where an internal wall blocks the view, "geodesic": round the single internal wall)
+        (reference Environment.py:677-779)."""
+        if wall_geometry != "euclidean":
+            assert self.boundary_conditions == "solid", f"{wall_geometry} geometry is only possible with solid boundaries"
+        if wall_geometry == "geodesic":
+            assert len(self.walls) <= 5, "unfortunately geodesic geometry is only defined in closed rooms with one additional wall"
+        d, v = self._pairwise(pos1, pos2, None, wall_geometry, want_dist=True)
+        return (d, v) if return_vectors else d
+
+    def _pairwise(self, pos1, pos2, line_segments, wall_geometry, want_dist):
+        import torch
+        from . import _lib as L
+        if line_segments is not None:
+            seg = np.asarray(line_segments, dtype=np.float64)
+            pos1, pos2 = seg[:, 0, 0, :], seg[0, :, 1, :]
+        x1, y1 = self._query_rows(pos1)
+        x2, y2 = self._query_rows(pos2)
+        n1, n2 = x1.numel(), x2.numel()
+        env, _keep = self.device_tables(self.query_device)
+        vec = torch.empty((2, n1, n2), dtype=torch.float64, device=x1.device)
+        dist = torch.empty((n1, n2), dtype=torch.float64, device=x1.device) if want_dist else None
+        rc = L.lib.riab_env_pairwise(env, L.ptr(x1), L.ptr(y1), n1, L.ptr(x2), L.ptr(y2), n2, L.GEOMETRIES[wall_geometry],
+                                     L.ptr(dist), L.ptr(vec[0]), L.ptr(vec[1]), L.current_stream())
+        L.check(rc, "riab_env_pairwise")
+        v = vec.permute(1, 2, 0).cpu().numpy()
+        return (dist.cpu().numpy(), v) if want_dist else v
+
+    def vectors_from_walls(self, pos):
+        """Shortest vectors from every wall to `pos`: `(N_walls, 2)` for one position (reference
+        Environment.py:843-853), `(P, N_walls, 2)` for `(P, 2)` positions (batched extension)."""
+        import torch
+        from . import _lib as L
+        single = np.ndim(pos) == 1
+        x, y = self._query_rows(pos)
+        env, _keep = self.device_tables(self.query_device)
+        out = torch.empty((max(int(env.n_walls), 1), 2, x.numel()), dtype=torch.float64, device=x.device)
+        L.check(L.lib.riab_env_vectors_from_walls(env, L.ptr(x), L.ptr(y), x.numel(), L.ptr(out), L.current_stream()),
+                "riab_env_vectors_from_walls")
+        v = out[:int(env.n_walls)].permute(2, 0, 1).cpu().numpy()
+        return v[0] if single else v
+
+    def check_wall_collisions(self, proposed_step):
+        """(walls, collisions): does the step `[[x0, y0], [x1, y1]]` strictly cross each wall?
+        `(N_walls,)` bools for one step (reference Environment.py:820-841), `(P, N_walls)` for
+        `(P, 2, 2)` steps (batched extension)."""
+        import torch
+        from . import _lib as L
+        if self.walls is None or len(self.walls) == 0:
+            return (None, None)
+        step = np.asarray(proposed_step, dtype=np.float64)
+        single = step.ndim == 2
+        step = step.reshape(-1, 2, 2)
+        x0, y0 = self._query_rows(step[:, 0])
+        x1, y1 = self._query_rows(step[:, 1])
+        env, _keep = self.device_tables(self.query_device)
+        out = torch.empty((int(env.n_walls), x0.numel()), dtype=torch.uint8, device=x0.device)
+        L.check(L.lib.riab_env_check_wall_collisions(env, L.ptr(x0), L.ptr(y0), L.ptr(x1), L.ptr(y1), x0.numel(),
+                                                     L.ptr(out), L.current_stream()), "riab_env_check_wall_collisions")
+        hit = out.t().cpu().numpy().astype(bool)
+        return (self.walls, hit[0] if single else hit)
+
+    def apply_boundary_conditions(self, pos):
+        """Positions outside the box are clamped 1 cm inside it (solid) or wrapped (periodic); positions
+        inside are returned unchanged (reference Environment.py:855-894).  `(2,)` or `(P, 2)`."""
+        import torch
+        from . import _lib as L
+        single = np.ndim(pos) == 1
+        x, y = self._query_rows(pos)
+        xy = torch.stack((x, y)).contiguous()
+        env, _keep = self.device_tables(self.query_device)
+        L.check(L.lib.riab_env_boundary_conditions(env, L.ptr(xy[0]), L.ptr(xy[1]), x.numel(), None, 1,
+                                                   L.current_stream()), "riab_env_boundary_conditions")
+        out = xy.t().cpu().numpy()
+        return out[0] if single else out
 
     # -- device tables --------------------------------------------------------------------
     def device_tables(self, device):

@@ -95,6 +95,14 @@ PROTOTYPES = {
                                    C.c_int32, C.c_float, C.c_void_p]),
     "riab_grid_cells": (C.c_int, [C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "riab_head_direction_cells": (C.c_int, [C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_void_p]),
+    "riab_env_pairwise": (C.c_int, [C.POINTER(RiabEnv), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "riab_env_vectors_from_walls": (C.c_int, [C.POINTER(RiabEnv), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                              C.c_void_p]),
+    "riab_env_check_wall_collisions": (C.c_int, [C.POINTER(RiabEnv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_int64, C.c_void_p, C.c_void_p]),
+    "riab_env_boundary_conditions": (C.c_int, [C.POINTER(RiabEnv), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                               C.c_int32, C.c_void_p]),
     "riab_velocity_cells": (C.c_int, [C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "riab_speed_cell": (C.c_int, [C.POINTER(RiabRateIO), C.c_float, C.c_void_p]),

@@ -527,6 +527,43 @@ def make_velocity():
     np.savez_compressed(os.path.join(HERE, "velocity.npz"), **out)
 
 
+def make_env_queries():
+    """Environment geometry queries called directly (Environment.py:657-894): pairwise vectors / distances
+    under each wall geometry, vectors_from_walls, check_wall_collisions, apply_boundary_conditions."""
+    print("environment queries")
+    rs = np.random.RandomState(17)
+    out = {}
+    p1, p2 = f32exact(rs.uniform(0, 1, (40, 2))), f32exact(rs.uniform(0, 1, (50, 2)))
+    out["p1"], out["p2"] = p1, p2
+    maze = Environment({"walls": MAZE_WALLS})
+    out["maze_walls"] = np.array(maze.walls)
+    out["maze_vec"] = maze.get_vectors_between___accounting_for_environment(p1, p2)
+    out["maze_euclid"] = maze.get_distances_between___accounting_for_environment(p1, p2, wall_geometry="euclidean")
+    out["maze_los"] = maze.get_distances_between___accounting_for_environment(p1, p2, wall_geometry="line_of_sight")
+    one = Environment({"walls": [[[0.5, 0.0], [0.5, 0.6]]]})
+    out["one_walls"] = np.array(one.walls)
+    out["one_geo"] = one.get_distances_between___accounting_for_environment(p1, p2, wall_geometry="geodesic")
+    per = Environment({"boundary_conditions": "periodic"})
+    d, v = per.get_distances_between___accounting_for_environment(p1, p2, return_vectors=True)
+    out["per_dist"], out["per_vec"] = d, v
+    # single-position / single-step queries, as Agent.update makes them
+    pts = f32exact(np.concatenate((rs.uniform(0, 1, (60, 2)), rs.uniform(-0.3, 1.3, (20, 2)))))
+    out["pts"] = pts
+    out["maze_vfw"] = np.array([maze.vectors_from_walls(p.copy()) for p in pts])
+    steps = f32exact(np.stack((rs.uniform(0, 1, (300, 2)), rs.uniform(0, 1, (300, 2))), axis=1))
+    steps[:, 1] = f32exact(steps[:, 0] + 0.3 * (steps[:, 1] - 0.5))
+    out["steps"] = steps
+    out["maze_coll"] = np.array([maze.check_wall_collisions(s.copy())[1] for s in steps])
+    print(f"  {int(out['maze_coll'].sum())} wall crossings in 300 steps, "
+          f"{int((out['maze_los'] == 1000).sum())} of {out['maze_los'].size} pairs without line of sight")
+    far = f32exact(rs.uniform(-0.5, 1.5, (80, 2)))
+    out["far"] = far
+    out["solid_bc"] = np.array([maze.apply_boundary_conditions(p.copy()) for p in far])
+    out["per_bc"] = np.array([per.apply_boundary_conditions(p.copy()) for p in far])
+    out["solid_inside"] = np.array([maze.check_if_position_is_in_environment(p) for p in far])
+    np.savez_compressed(os.path.join(HERE, "env_queries.npz"), **out)
+
+
 def make_task():
     """TaskEnvironment.step / reset (contribs/TaskEnvironment.py): single-agent replicas of a
     SpatialGoalEnvironment, one per lane, driven towards their goals; per step the action, the two
@@ -672,11 +709,13 @@ def make_stats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "velocity", "task", "stats"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "velocity", "env", "task", "stats"]
     if "stats" in which:
         make_stats()
     if "task" in which:
         make_task()
+    if "env" in which:
+        make_env_queries()
     if "velocity" in which:
         make_velocity()
     if "ovc" in which:

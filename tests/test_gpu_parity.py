@@ -1010,3 +1010,51 @@ def test_velocity_and_speed_cells_closed_loop(riab):
                                                               max_fr=2.0))
     with pytest.raises(NotImplementedError):
         Ag.simulate(4)
+
+
+def test_environment_queries_vs_reference(riab):
+    """The Environment API's geometry queries (reference Environment.py:657-894) through riab_env_*:
+    against the reference's outputs, single calls and batched."""
+    g = gu.load("env_queries.npz")
+    p1, p2 = g["p1"], g["p2"]
+    maze = make_env(riab, g["maze_walls"][4:])
+    np.testing.assert_allclose(maze.get_vectors_between___accounting_for_environment(p1, p2), g["maze_vec"], rtol=0,
+                               atol=1e-15)
+    np.testing.assert_allclose(maze.get_distances_between___accounting_for_environment(p1, p2), g["maze_euclid"],
+                               rtol=1e-14)
+    d, v = maze.get_distances_between___accounting_for_environment(p1, p2, wall_geometry="line_of_sight",
+                                                                   return_vectors=True)
+    np.testing.assert_allclose(d, g["maze_los"], rtol=1e-14)
+    np.testing.assert_allclose(v, g["maze_vec"], rtol=0, atol=1e-15)
+    one = make_env(riab, g["one_walls"][4:])
+    np.testing.assert_allclose(one.get_distances_between___accounting_for_environment(p1, p2, wall_geometry="geodesic"),
+                               g["one_geo"], rtol=1e-14)
+    per = make_env(riab, boundary_conditions="periodic")
+    d, v = per.get_distances_between___accounting_for_environment(p1, p2, return_vectors=True)
+    np.testing.assert_allclose(d, g["per_dist"], rtol=1e-14)
+    np.testing.assert_allclose(v, g["per_vec"], rtol=0, atol=1e-15)
+    with pytest.raises(AssertionError):
+        per.get_distances_between___accounting_for_environment(p1, p2, wall_geometry="line_of_sight")
+    with pytest.raises(AssertionError):
+        maze.get_distances_between___accounting_for_environment(p1, p2, wall_geometry="geodesic")
+    # line segments in place of the two position lists (Environment.py:665-667)
+    seg = np.stack((np.repeat(p1[:, None], len(p2), 1), np.repeat(p2[None], len(p1), 0)), axis=2)
+    np.testing.assert_allclose(per.get_vectors_between___accounting_for_environment(line_segments=seg), g["per_vec"],
+                               rtol=0, atol=1e-15)
+    # batched and single-position forms
+    np.testing.assert_allclose(maze.vectors_from_walls(g["pts"]), g["maze_vfw"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(maze.vectors_from_walls(g["pts"][3]), g["maze_vfw"][3], rtol=1e-12, atol=1e-15)
+    walls, hit = maze.check_wall_collisions(g["steps"])
+    assert np.array_equal(walls, g["maze_walls"]) and np.array_equal(hit, g["maze_coll"])
+    assert np.array_equal(maze.check_wall_collisions(g["steps"][5])[1], g["maze_coll"][5])
+    np.testing.assert_allclose(maze.apply_boundary_conditions(g["far"]), g["solid_bc"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(per.apply_boundary_conditions(g["far"]), g["per_bc"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(maze.apply_boundary_conditions(g["far"][0]), g["solid_bc"][0], rtol=0, atol=1e-15)
+    # larger than one workgroup row / the grid's y range, against the oracle
+    rs = np.random.RandomState(4)
+    a, b = rs.uniform(0, 1, (70000, 2)), rs.uniform(0, 1, (3, 2))
+    ref = orc.env_distances(orc.EnvSpec(walls=g["maze_walls"][4:]), a, b, "line_of_sight")
+    np.testing.assert_allclose(maze.get_distances_between___accounting_for_environment(a, b, "line_of_sight"), ref,
+                               rtol=1e-14)
+    np.testing.assert_allclose(maze.get_distances_between___accounting_for_environment(b, a, "line_of_sight"), ref.T,
+                               rtol=1e-14)

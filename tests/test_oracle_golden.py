@@ -278,3 +278,29 @@ def test_velocity_and_speed_cells():
     np.testing.assert_allclose(got, g["gs_vc"], rtol=1e-12)
     np.testing.assert_allclose(orc.speed_cell(g["gs_vel"], oss, float(g["sc_min"]), float(g["sc_max"])), g["gs_sc"],
                                rtol=1e-12)
+
+
+def test_environment_queries():
+    """Environment.get_vectors/distances_between___accounting_for_environment, vectors_from_walls,
+    check_wall_collisions, apply_boundary_conditions, called directly (Environment.py:657-894)."""
+    g = gu.load("env_queries.npz")
+    p1, p2 = g["p1"], g["p2"]
+    maze = orc.EnvSpec(walls=g["maze_walls"][4:])
+    np.testing.assert_allclose(orc.env_vectors_between(maze, p1, p2), g["maze_vec"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(orc.env_distances(maze, p1, p2), g["maze_euclid"], rtol=1e-14)
+    np.testing.assert_allclose(orc.env_distances(maze, p1, p2, "line_of_sight"), g["maze_los"], rtol=1e-14)
+    one = orc.EnvSpec(walls=g["one_walls"][4:])
+    np.testing.assert_allclose(orc.env_distances(one, p1, p2, "geodesic"), g["one_geo"], rtol=1e-14)
+    per = orc.EnvSpec(boundary_conditions="periodic")
+    np.testing.assert_allclose(orc.env_vectors_between(per, p1, p2), g["per_vec"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(orc.env_distances(per, p1, p2), g["per_dist"], rtol=1e-14)
+    np.testing.assert_allclose(orc.shortest_vectors_from_walls(g["pts"], g["maze_walls"]), g["maze_vfw"], rtol=1e-12,
+                               atol=1e-15)
+    steps = g["steps"]
+    assert np.array_equal(orc.segments_collide(steps, g["maze_walls"]), g["maze_coll"])
+    inside = orc.env_is_inside(maze, g["far"])
+    assert np.array_equal(inside, g["solid_inside"])
+    bc = np.where(inside[:, None], g["far"], orc.env_apply_boundary_conditions(maze, g["far"]))
+    np.testing.assert_allclose(bc, g["solid_bc"], rtol=0, atol=1e-15)
+    bc = np.where(inside[:, None], g["far"], orc.env_apply_boundary_conditions(per, g["far"]))
+    np.testing.assert_allclose(bc, g["per_bc"], rtol=0, atol=1e-15)
