@@ -211,6 +211,15 @@ int riab_place_cells(const RiabEnv* env, const RiabRateIO* io, const float* cell
                      int32_t description, int32_t geometry, float top_hat_width,
                      riab_stream_t stream);
 
+/* RandomSpatialNeurons.get_state (Neurons.py:2916-2960): the kernel-weighted local average of the
+ * sampled targets, rate[c][p] = sum_m k(p, X_m) targets[m][c] / sum_m k(p, X_m) with
+ * k = exp(-d^2 / (2 lengthscale^2)) and d the environment distance of riab_place_cells.
+ *  anchors device float32 [M][3] = (X_m x, X_m y, -log2(e) / (2 lengthscale^2))
+ *  targets device float32 [M][n], already squashed into [min_fr, max_fr] (Neurons.py:2911-2912);
+ *          io->min_fr / max_fr are not applied again. */
+int riab_random_spatial_neurons(const RiabEnv* env, const RiabRateIO* io, const float* anchors, int32_t M,
+                                const float* targets, int32_t n, int32_t geometry, riab_stream_t stream);
+
 enum { RIAB_GC_RECTIFIED = 0, RIAB_GC_SHIFTED = 1 };
 
 /* GridCells.get_state, 2D (Neurons.py:1172-1236).  table device float32 [n][9]:
@@ -322,7 +331,7 @@ int riab_feedforward(const RiabFFInput* inputs, int32_t n_inputs, const float* b
  * row cursors, RNG counters and pointers are kept in C++, every kernel of every step is enqueued on
  * `stream`, nothing is allocated or synchronised. */
 enum { RIAB_POP_PLACE = 0, RIAB_POP_GRID = 1, RIAB_POP_HDC = 2, RIAB_POP_BVC = 3, RIAB_POP_OVC = 4, RIAB_POP_FF = 5,
-       RIAB_POP_VELOCITY = 6, RIAB_POP_SPEED = 7 };
+       RIAB_POP_VELOCITY = 6, RIAB_POP_SPEED = 7, RIAB_POP_RANDOM_SPATIAL = 8 };
 #define RIAB_FF_MAX_INPUTS 8
 
 typedef struct RiabPopulation {
@@ -348,6 +357,8 @@ typedef struct RiabPopulation {
   int32_t n_objects;         /* ovc */
   int32_t walls_occlude;     /* ovc */
   float one_sigma_speed;     /* velocity / speed */
+  const float* targets;      /* random spatial: [n_anchors][n]; `table` holds the anchors */
+  int32_t n_anchors;         /* random spatial */
   /* additive OU noise of Neurons.update (Neurons.py:153-168, riab_neuron_noise); NULL = none */
   float* noise_state;        /* device float32 [n][B] */
   float noise_theta_dt;      /* dt / noise_coherence_time */

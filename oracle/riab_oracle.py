@@ -593,6 +593,16 @@ def speed_cell(vel, one_sigma_speed, min_fr=0.0, max_fr=1.0):
     return (np.linalg.norm(v, axis=-1) / one_sigma_speed * (max_fr - min_fr) + min_fr)[None, :]
 
 
+def random_spatial_neurons(env, pos, X, targets, lengthscale, wall_geometry="euclidean"):
+    """RandomSpatialNeurons.get_state (Neurons.py:2916-2942) with kernel() (:2944-2956): the
+    kernel-weighted local average of the anchor targets `(M, n)` -> `(n, P)`."""
+    d = env_distances(env, pos, X, wall_geometry)
+    k = np.exp(-(d ** 2) / (2 * lengthscale ** 2))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        k = k / np.sum(k, axis=1, keepdims=True)
+        return (k @ np.asarray(targets, dtype=np.float64)).T
+
+
 def object_vector_cells(env, pos, objects, object_types, tuning_distances, tuning_angles, sigma_distances,
                         sigma_angles, tuning_types, walls_occlude=True, head_direction=None, min_fr=0.0, max_fr=1.0):
     """ObjectVectorCells.get_state (Neurons.py:1991-2116) -> `(n, P)`.  `head_direction (P,2)`

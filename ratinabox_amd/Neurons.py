@@ -1007,6 +1007,75 @@ class SpeedCell(Neurons):
 
 
 # ================================================================================================
+class RandomSpatialNeurons(Neurons):
+    """Neurons with smooth random spatial tuning: per neuron a function sampled from a Gaussian-process
+    prior (squared-exponential kernel of the environment distance, `lengthscale`) on a grid of anchor
+    points, squashed by a sigmoid into [min_fr, max_fr]; anywhere else the rate is the kernel-weighted
+    local average of the anchors' targets (reference Neurons.py:2865-2960).  The sampling is host NumPy
+    at construction (same `np.random` call as the reference); the local average runs on device."""
+
+    default_params = {
+        "lengthscale": 0.1,
+        "max_fr": 1,
+        "min_fr": 0,
+        "n": 10,
+        "wall_geometry": "geodesic",
+        "name": "RandomSpatialNeurons",
+    }
+
+    def __init__(self, Agent, params={}):
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        super().__init__(Agent, self.params)
+        Env = self.Agent.Environment
+        if self.wall_geometry == "geodesic" and len(Env.walls) > 5:
+            print("Geodesic wall geometry only possible in environments with one or no additional walls. Using "
+                  "'line_of_sight' instead. If this is slow, consider trying 'euclidean'")
+            self.wall_geometry = "line_of_sight"
+        assert self.lengthscale >= 0.02, "lengthscale must be greater than 0.02 m"
+        # Neurons.py:2899-2912: anchors at least as dense as the lengthscale, one draw of n functions
+        self.X = Env.discretise_environment(dx=min(0.05, self.lengthscale))
+        self.X = self.X.reshape(-1, self.X.shape[-1])
+        self.Q = self.kernel(self.X, self.X)
+        warnings.filterwarnings("ignore", category=RuntimeWarning)
+        self.targets = np.random.multivariate_normal(mean=np.zeros(self.Q.shape[0]), cov=self.Q, size=self.n).T
+        warnings.filterwarnings("default", category=RuntimeWarning)
+        # utils.activate(..., "sigmoid", mid_x=0, width_x=2) (utils.py:962-975)
+        beta = np.log((1 - 0.05) / 0.05) / (0.5 * 2)
+        self.targets = (self.max_fr - self.min_fr) / (1 + np.exp(-beta * self.targets)) + self.min_fr
+
+    def kernel(self, x1, x2):
+        """Squared-exponential covariance `(len(x1), len(x2))` of the environment distance (Neurons.py:2944-2956)."""
+        d = self.Agent.Environment.get_distances_between___accounting_for_environment(
+            x1, x2, wall_geometry=self.wall_geometry)
+        return np.exp(-(d ** 2) / (2 * self.lengthscale ** 2))
+
+    def _call(self, io, stream):
+        X = np.asarray(self.X, dtype=np.float64).reshape(-1, 2)
+        targets = np.asarray(self.targets, dtype=np.float64)
+        ell = float(self.lengthscale)
+
+        def build():
+            tab = np.empty((len(X), 3), dtype=np.float64)
+            tab[:, 0], tab[:, 1] = X[:, 0], X[:, 1]
+            tab[:, 2] = -LOG2E / (2 * ell ** 2)
+            f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self._device)  # noqa: E731
+            return f32(tab), f32(targets)
+
+        anchors, tg = self._tables((X, targets, ell), build)
+        geom = self.wall_geometry
+        if geom == "geodesic" and len(self.Agent.Environment.walls) <= 4:
+            geom = "euclidean"  # Environment.py:741-742
+        if io is None:
+            return dict(kind=_L.POP_KINDS["random_spatial"], table=anchors, targets=tg, n_anchors=len(X),
+                        geometry=_L.GEOMETRIES[geom])
+        env, _w = self.Agent.Environment.device_tables(self._device)
+        rc = _L.lib.riab_random_spatial_neurons(env, io, _L.ptr(anchors), len(X), _L.ptr(tg), int(self.n),
+                                                _L.GEOMETRIES[geom], stream)
+        _L.check(rc, "riab_random_spatial_neurons")
+
+
+# ================================================================================================
 class FeedForwardLayer(Neurons):
     """A layer whose firing rates are an activated linear combination of the rates of its input
     layers (reference Neurons.py:2654-2860): `firingrate = act(sum_l W_l @ I_l + biases)`.

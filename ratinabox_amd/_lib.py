@@ -59,7 +59,7 @@ class RiabPopulation(C.Structure):
                 ("test_dirs", C.c_void_p), ("ray_rden", C.c_void_p), ("K", C.c_int32), ("egocentric", C.c_int32),
                 ("vm_table", C.c_void_p), ("inv_norm", C.c_void_p), ("objects", C.c_void_p),
                 ("object_types", C.c_void_p), ("n_objects", C.c_int32), ("walls_occlude", C.c_int32),
-                ("one_sigma_speed", C.c_float),
+                ("one_sigma_speed", C.c_float), ("targets", C.c_void_p), ("n_anchors", C.c_int32),
                 ("noise_state", C.c_void_p), ("noise_theta_dt", C.c_float), ("noise_sigma_dt", C.c_float),
                 ("n_inputs", C.c_int32), ("input_index", C.c_int32 * 8), ("input_wt", C.c_void_p * 8),
                 ("bias", C.c_void_p), ("activation", C.c_int32), ("act_params", C.c_float * 4),
@@ -81,7 +81,7 @@ DECAYS = {"constant": 0, "linear": 1, "exponential": 2, "none": 3}
 GOALORDERS = {"nonsequential": 0, "sequential": 1}
 TD_REWARD_OVERFLOW, TD_LATE_COMPLETIONS, TD_EPLOG_OVERFLOW, TD_RESETS = range(4)
 
-POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4, "ff": 5, "velocity": 6, "speed": 7}
+POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4, "ff": 5, "velocity": 6, "speed": 7, "random_spatial": 8}
 EFULL = -5
 
 ACTIVATIONS = {"linear": 0, "sigmoid": 1, "relu": 2, "tanh": 3, "retanh": 4, "softmax": 5}
@@ -103,6 +103,8 @@ PROTOTYPES = {
                                                  C.c_int64, C.c_void_p, C.c_void_p]),
     "riab_env_boundary_conditions": (C.c_int, [C.POINTER(RiabEnv), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                                C.c_int32, C.c_void_p]),
+    "riab_random_spatial_neurons": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_int32,
+                                              C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "riab_velocity_cells": (C.c_int, [C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "riab_speed_cell": (C.c_int, [C.POINTER(RiabRateIO), C.c_float, C.c_void_p]),

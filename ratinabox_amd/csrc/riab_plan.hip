@@ -98,7 +98,7 @@ extern "C" int riab_plan_set_agent_history(RiabPlan* p, float* hist_base, int64_
 }
 
 extern "C" int riab_plan_add(RiabPlan* p, const RiabPopulation* pop) {
-  if (!p || !pop || pop->n <= 0 || pop->kind < RIAB_POP_PLACE || pop->kind > RIAB_POP_SPEED) return RIAB_EINVAL;
+  if (!p || !pop || pop->n <= 0 || pop->kind < RIAB_POP_PLACE || pop->kind > RIAB_POP_RANDOM_SPATIAL) return RIAB_EINVAL;
   if (pop->kind == RIAB_POP_FF) {
     if (pop->n_inputs <= 0 || pop->n_inputs > RIAB_FF_MAX_INPUTS || !pop->bias) return RIAB_EINVAL;
     for (int l = 0; l < pop->n_inputs; ++l)  // feed-forward only: an input must already be in the plan
@@ -213,6 +213,9 @@ static int launch_population(RiabPlan* p, size_t i, const float* row, hipStream_
       io.hd_x = row + RIAB_H_VEL_X * B;
       io.hd_y = row + RIAB_H_VEL_Y * B;
       rc = riab_speed_cell(&io, q.one_sigma_speed, s);
+      break;
+    case RIAB_POP_RANDOM_SPATIAL:
+      rc = riab_random_spatial_neurons(&p->env, &io, q.table, q.n_anchors, q.targets, q.n, q.geometry, s);
       break;
     case RIAB_POP_BVC:
       rc = riab_boundary_vector_cells(&p->env, &io, q.test_dirs, q.ray_rden, q.K, q.table, q.vm_table, q.inv_norm, q.n,

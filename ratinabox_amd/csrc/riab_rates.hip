@@ -297,6 +297,58 @@ __global__ __launch_bounds__(256) void place_one_hot_kernel(const RateArgs a, Pl
   }
 }
 
+// ---- RandomSpatialNeurons (reference Neurons.py:2916-2960) ------------------------------------
+// rate[c][p] = sum_m k(p, X_m) targets[m][c] / sum_m k(p, X_m), k = exp(-d_env(p, X_m)^2 / (2 l^2)):
+// the "local average of targets" over the M anchor points X the smooth random functions were sampled
+// on.  A lane owns four positions; blockIdx.y picks a chunk of RS_CH cells whose sums stay in
+// registers; anchors and target rows are wave-uniform loads.
+constexpr int RS_CH = 8;
+template <int GX>
+__global__ __launch_bounds__(256) void random_spatial_kernel(const RateArgs a, PlaceCell<RIAB_PC_GAUSSIAN, GX> cell,
+                                                             const float* __restrict__ targets, int M) {
+  __shared__ double s_lds[PlaceCell<RIAB_PC_GAUSSIAN, GX>::LDS_DOUBLES];
+  cell.stage(s_lds);
+  const uint32_t p4 = blockIdx.x * 256u + threadIdx.x;
+  if (p4 >= a.nquads) return;
+  const uint32_t t = p4 / (uint32_t)a.qrow;
+  const uint32_t q = p4 - t * (uint32_t)a.qrow;
+  const PosQuad P = cell.load(a, (int64_t)t * a.pos_ld + 4 * (int64_t)q);
+  const int c0 = blockIdx.y * RS_CH;
+  v4f den = {0.0f, 0.0f, 0.0f, 0.0f};
+  v4f acc[RS_CH];
+#pragma unroll
+  for (int j = 0; j < RS_CH; ++j) acc[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int m = 0; m < M; ++m) {
+    const float cxs = cell.tab[3 * m], cys = cell.tab[3 * m + 1], k = cell.tab[3 * m + 2];
+    const v4f kv = {__builtin_amdgcn_exp2f(cell.dist2(cxs, cys, P.x.x, P.y.x) * k),
+                    __builtin_amdgcn_exp2f(cell.dist2(cxs, cys, P.x.y, P.y.y) * k),
+                    __builtin_amdgcn_exp2f(cell.dist2(cxs, cys, P.x.z, P.y.z) * k),
+                    __builtin_amdgcn_exp2f(cell.dist2(cxs, cys, P.x.w, P.y.w) * k)};
+    den += kv;
+    const float* tr = targets + (int64_t)m * a.n;
+#pragma unroll
+    for (int j = 0; j < RS_CH; ++j) {
+      const int c = (c0 + j < a.n) ? c0 + j : a.n - 1;  // wave-uniform clamp; surplus sums are not stored
+      acc[j] += kv * tr[c];
+    }
+  }
+  int64_t off = ((int64_t)t * a.n + c0) * a.B + 4 * (int64_t)q;
+  const uint32_t step = a.step0 + t;
+  const uint32_t group = a.group0 + q;
+#pragma unroll
+  for (int j = 0; j < RS_CH; ++j) {
+    if (c0 + j < a.n) {
+      const v4f r = acc[j] / den;  // no position in range of any anchor: 0/0 = NaN, like the reference
+      __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(a.rates + off));
+      if (a.spikes) {
+        if (a.u_in) spike_store<true>(a, r, off, step, (uint32_t)(c0 + j), group);
+        else spike_store<false>(a, r, off, step, (uint32_t)(c0 + j), group);
+      }
+      off += a.B;
+    }
+  }
+}
+
 // ---- GridCells (reference Neurons.py:1172-1236) -------------------------------------------
 // phase of cosine i in revolutions: a_i - (x*bx_i + y*by_i); v_cos_f32 takes revolutions.
 template <int DESC>
@@ -581,6 +633,52 @@ extern "C" int riab_place_cells(const RiabEnv* env, const RiabRateIO* io, const 
     case RIAB_GEOM_EUCLIDEAN: return place_dispatch<0>(env, io, cells, n, description, top_hat_width, s);
     case RIAB_GEOM_LINE_OF_SIGHT: return place_dispatch<1>(env, io, cells, n, description, top_hat_width, s);
     case RIAB_GEOM_GEODESIC: return place_dispatch<2>(env, io, cells, n, description, top_hat_width, s);
+    default: return RIAB_EINVAL;
+  }
+}
+
+template <int GX>
+static int random_spatial_dispatch(const RiabEnv* env, const RiabRateIO* io, const float* anchors, int M,
+                                   const float* targets, int n, hipStream_t s) {
+  PlaceCell<RIAB_PC_GAUSSIAN, GX> c;
+  c.tab = anchors;
+  c.scale = (float)env->scale;
+  c.half_scale = (float)(env->scale / 2);
+  c.top_hat_w2 = 0.0f;
+  c.walls = env->walls;
+  c.n_internal = env->n_walls > 4 ? env->n_walls - 4 : 0;
+  if (GX == 2 && c.n_internal > 1) c.n_internal = 1;
+  c.e0 = env->extent[0]; c.e1 = env->extent[1]; c.e2 = env->extent[2]; c.e3 = env->extent[3];
+  c.lds = nullptr;
+  dim3 grid;
+  RateArgs a = make_args(io, n, &grid);
+  a.fr_scale = 1.0f;  // the targets already lie in [min_fr, max_fr] (Neurons.py:2911-2912)
+  a.fr_min = 0.0f;
+  grid.y = (unsigned)((n + RS_CH - 1) / RS_CH);
+  hipLaunchKernelGGL((random_spatial_kernel<GX>), grid, dim3(256), 0, s, a, c, targets, M);
+  return (int)hipGetLastError();
+}
+
+extern "C" int riab_random_spatial_neurons(const RiabEnv* env, const RiabRateIO* io, const float* anchors, int32_t M,
+                                           const float* targets, int32_t n, int32_t geometry, riab_stream_t stream) {
+  if (!env || !anchors || !targets || M <= 0) return RIAB_EINVAL;
+  const int rc = check_io(io, n, true, false);
+  if (rc) return rc;
+  if ((n + RS_CH - 1) / RS_CH > 65535) return RIAB_ETOOBIG;
+  hipStream_t s = (hipStream_t)stream;
+  if (env->periodic) {
+    if (geometry != RIAB_GEOM_EUCLIDEAN) return RIAB_EUNSUPPORTED;
+    return random_spatial_dispatch<3>(env, io, anchors, M, targets, n, s);
+  }
+  if (geometry != RIAB_GEOM_EUCLIDEAN) {
+    if (env->n_walls > 4 && !env->walls) return RIAB_EINVAL;
+    if (env->n_walls - 4 > RIAB_MAX_WALLS) return RIAB_ETOOBIG;
+    if (geometry == RIAB_GEOM_GEODESIC && env->n_walls > 5) return RIAB_EUNSUPPORTED;
+  }
+  switch (geometry) {
+    case RIAB_GEOM_EUCLIDEAN: return random_spatial_dispatch<0>(env, io, anchors, M, targets, n, s);
+    case RIAB_GEOM_LINE_OF_SIGHT: return random_spatial_dispatch<1>(env, io, anchors, M, targets, n, s);
+    case RIAB_GEOM_GEODESIC: return random_spatial_dispatch<2>(env, io, anchors, M, targets, n, s);
     default: return RIAB_EINVAL;
   }
 }

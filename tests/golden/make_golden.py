@@ -564,6 +564,32 @@ def make_env_queries():
     np.savez_compressed(os.path.join(HERE, "env_queries.npz"), **out)
 
 
+def make_random_spatial():
+    """RandomSpatialNeurons (Neurons.py:2865-2960): seeded targets (one multivariate-normal draw over the
+    anchor grid) and get_state at given positions, for each wall geometry."""
+    from ratinabox.Neurons import RandomSpatialNeurons
+    print("random spatial neurons")
+    out = {}
+    rs = np.random.RandomState(8)
+    pos = f32exact(rs.uniform(0, 1, (150, 2)))
+    out["pos"] = pos
+    cases = {"open": ({}, "euclidean", 0.1), "one": ({"walls": [[[0.5, 0.0], [0.5, 0.6]]]}, "geodesic", 0.12),
+             "maze": ({"walls": MAZE_WALLS}, "geodesic", 0.08), "per": ({"boundary_conditions": "periodic"}, "euclidean", 0.15)}
+    for name, (envp, geom, ell) in cases.items():
+        np.random.seed(33)
+        Env = Environment(envp)
+        Ag = Agent(Env)
+        N = RandomSpatialNeurons(Ag, {"n": 7, "lengthscale": ell, "wall_geometry": geom, "min_fr": 0.5, "max_fr": 4.0})
+        out[f"{name}_geometry"] = N.wall_geometry
+        out[f"{name}_lengthscale"] = ell
+        out[f"{name}_X"] = np.array(N.X)
+        out[f"{name}_targets"] = np.array(N.targets)
+        out[f"{name}_rates"] = N.get_state(evaluate_at=None, pos=pos)
+        out[f"{name}_walls"] = np.array(envp.get("walls", []), float).reshape(-1, 2, 2)
+        print(f"  {name}: {N.wall_geometry}, {N.X.shape[0]} anchors, nan rates {int(np.isnan(out[f'{name}_rates']).sum())}")
+    np.savez_compressed(os.path.join(HERE, "random_spatial.npz"), **out)
+
+
 def make_task():
     """TaskEnvironment.step / reset (contribs/TaskEnvironment.py): single-agent replicas of a
     SpatialGoalEnvironment, one per lane, driven towards their goals; per step the action, the two
@@ -709,11 +735,13 @@ def make_stats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "velocity", "env", "task", "stats"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "velocity", "env", "random_spatial", "task", "stats"]
     if "stats" in which:
         make_stats()
     if "task" in which:
         make_task()
+    if "random_spatial" in which:
+        make_random_spatial()
     if "env" in which:
         make_env_queries()
     if "velocity" in which:

@@ -304,3 +304,18 @@ def test_environment_queries():
     np.testing.assert_allclose(bc, g["solid_bc"], rtol=0, atol=1e-15)
     bc = np.where(inside[:, None], g["far"], orc.env_apply_boundary_conditions(per, g["far"]))
     np.testing.assert_allclose(bc, g["per_bc"], rtol=0, atol=1e-15)
+
+
+RS_CASES = {"open": {}, "one": {}, "maze": {}, "per": {"boundary_conditions": "periodic"}}
+
+
+@pytest.mark.parametrize("name", sorted(RS_CASES))
+def test_random_spatial_neurons(name):
+    g = gu.load("random_spatial.npz")
+    env = orc.EnvSpec(walls=g[f"{name}_walls"], **RS_CASES[name])
+    geom = str(g[f"{name}_geometry"])
+    if geom == "geodesic" and len(env.walls) <= 4:
+        geom = "euclidean"
+    got = orc.random_spatial_neurons(env, g["pos"], g[f"{name}_X"], g[f"{name}_targets"], float(g[f"{name}_lengthscale"]),
+                                     geom)
+    np.testing.assert_allclose(got, g[f"{name}_rates"], rtol=1e-11)
