@@ -288,6 +288,14 @@ int riab_object_vector_cells(const RiabEnv* env, const RiabRateIO* io, const flo
                              const int32_t* object_types, int32_t n_objects, const float* cells, int32_t n,
                              int32_t walls_occlude, int32_t egocentric, riab_stream_t stream);
 
+/* AgentVectorCells.get_state (+ FieldOfViewAVCs), Neurons.py:2204-2355: ObjectVectorCells whose one
+ * object is ANOTHER AGENT, i.e. a different point for every lane: other_x / other_y are float32 rows
+ * laid out like io->pos_x / pos_y (element [t*other_ld + b]; other_ld = 0 repeats one row for every t).
+ * cells as for riab_object_vector_cells (the type column is ignored: every cell responds to the agent). */
+int riab_agent_vector_cells(const RiabEnv* env, const RiabRateIO* io, const float* other_x, const float* other_y,
+                            int64_t other_ld, const float* cells, int32_t n, int32_t walls_occlude,
+                            int32_t egocentric, riab_stream_t stream);
+
 /* Neurons.save_to_history spike rule (Neurons.py:681-687) on rates that already
  * exist: spikes = u < dt*rate (one fp32 multiply, one fp32 compare).  count
  * elements, u_in explicit uniforms or NULL => Philox as in the rate kernels

@@ -625,6 +625,23 @@ def object_vector_cells(env, pos, objects, object_types, tuning_distances, tunin
     return fr * (max_fr - min_fr) + min_fr
 
 
+def agent_vector_cells(env, pos, other_pos, tuning_distances, tuning_angles, sigma_distances, sigma_angles,
+                       walls_occlude=True, head_direction=None, min_fr=0.0, max_fr=1.0):
+    """AgentVectorCells.get_state (Neurons.py:2204-2320) -> `(n, P)`: ObjectVectorCells with one object,
+    the other agent, whose position `other_pos (P,2)` is given per observer position (the reference
+    has one observer and one other agent per call)."""
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 2)
+    other = np.broadcast_to(np.asarray(other_pos, dtype=np.float64).reshape(-1, 2), pos.shape)
+    n = len(np.asarray(tuning_distances))
+    out = np.empty((n, len(pos)))
+    for i in range(len(pos)):
+        hd = None if head_direction is None else np.asarray(head_direction, dtype=np.float64).reshape(-1, 2)[i:i + 1]
+        out[:, i] = object_vector_cells(env, pos[i:i + 1], other[i:i + 1], [0], tuning_distances, tuning_angles,
+                                        sigma_distances, sigma_angles, np.zeros(n, dtype=int), walls_occlude, hd,
+                                        min_fr, max_fr)[:, 0]
+    return out
+
+
 def activate(x, spec):
     """utils.activate (utils.py:919-1026) for the named activations -> (f(x), df/dx)."""
     name = spec.get("activation", "sigmoid")

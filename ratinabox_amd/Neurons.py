@@ -833,6 +833,103 @@ class FieldOfViewOVCs(ObjectVectorCells):
         super().__init__(Agent, self.params)
 
 
+class AgentVectorCells(VectorCells):
+    """Vector cells tuned to ANOTHER AGENT: ObjectVectorCells whose single object is `Other_Agent`'s
+    position (reference Neurons.py:2151-2320).  Batched: lane b of `Agent` sees lane b of `Other_Agent`
+    (equal `n_agents`), or every lane sees the one agent of a single-agent `Other_Agent`.  The other
+    agent's position is read where it stands when `update()` / `get_state()` is called, as in the
+    reference's interleaved `for Ag in Env.Agents: Ag.update(); ...` loops; `Agent.simulate()` and step
+    plans advance one Agent object on its own and refuse these cells."""
+
+    default_params = {
+        "name": "AgentVectorCell",
+        "walls_occlude": True,
+    }
+
+    def __init__(self, Agent, Other_Agent, params={}):
+        self.Agent = Agent
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        if not hasattr(self, "_warn_if_n_changes"):
+            self._warn_if_n_changes = "n" in params and params["n"] is not None
+        super().__init__(Agent, self.params)
+        self.tuning_type_agent = Other_Agent
+        self.wall_geometry = "line_of_sight" if self.walls_occlude else "euclidean"
+        if Other_Agent is not None and Other_Agent._B not in (1, self._B):
+            raise ValueError(f"Other_Agent has {Other_Agent._B} agents; expected 1 or {self._B} (one per lane)")
+
+    def _other_rows(self, width):
+        """float32 [2, width] device rows of the other agent's position, one per lane of this launch."""
+        Other = self.tuning_type_agent
+        Other._sync_plan()
+        xy = Other._state[_L.S_POS_X:_L.S_POS_Y + 1].to(torch.float32)
+        if Other._B == 1:
+            return xy[:, :1].expand(2, width).contiguous()
+        if xy.shape[1] != width:
+            raise ValueError("AgentVectorCells away from the agents need a single-agent Other_Agent, or one position "
+                             "per lane")
+        return xy.contiguous()
+
+    def get_state_tensor(self, evaluate_at="agent", **kwargs):
+        if self.tuning_type_agent is None:
+            self._last_P = self._B
+            return torch.zeros((int(self.n), self._Bp), dtype=torch.float32, device=self._device)
+        return super().get_state_tensor(evaluate_at, **kwargs)
+
+    def _rates_from_trajectory(self, traj, out, t0, tc, step0, dt, stream):
+        raise NotImplementedError("AgentVectorCells follow another Agent object step by step: advance both agents "
+                                  "with update() (simulate() runs one Agent on its own)")
+
+    def _call(self, io, stream):
+        if io is None:
+            raise NotImplementedError("AgentVectorCells cannot be recorded in a step plan (a plan steps one Agent "
+                                      "object); advance them with update()")
+        n = int(self.n)
+        Env = self.Agent.Environment
+        mu_d = np.asarray(self.tuning_distances, dtype=np.float64)
+        sg_d = np.asarray(self.sigma_distances, dtype=np.float64)
+        mu_t = np.asarray(self.tuning_angles, dtype=np.float64)
+        sg_t = np.asarray(self.sigma_angles, dtype=np.float64)
+        occlude = self.wall_geometry == "line_of_sight"
+        if occlude:
+            assert Env.boundary_conditions == "solid", \
+                "line of sight geometry not available for periodic boundary conditions"
+
+        def build():
+            a = np.sqrt(LOG2E / 2) / sg_d
+            cells = np.stack((a * mu_d, a, np.cos(mu_t), np.sin(mu_t), LOG2E / sg_t ** 2, np.zeros(n)), axis=-1)
+            return torch.from_numpy(np.ascontiguousarray(cells, dtype=np.float32)).to(self._device)
+
+        cells_t = self._tables((mu_d, sg_d, mu_t, sg_t), build)
+        other = self._other_rows(int(io.B))
+        self._keep_other = other
+        env, _w = Env.device_tables(self._device)
+        rc = _L.lib.riab_agent_vector_cells(env, io, _L.ptr(other[0]), _L.ptr(other[1]), 0, _L.ptr(cells_t), n,
+                                            1 if occlude else 0, 1 if self.reference_frame == "egocentric" else 0,
+                                            stream)
+        _L.check(rc, "riab_agent_vector_cells")
+
+
+class FieldOfViewAVCs(AgentVectorCells):
+    """Egocentric agent vector cells tiling the agent's field of view (reference Neurons.py:2323-2355)."""
+
+    default_params = {
+        "distance_range": [0.02, 0.4],
+        "angle_range": [0, 75],
+        "spatial_resolution": 0.02,
+        "beta": 5,
+        "cell_arrangement": "diverging_manifold",
+    }
+
+    def __init__(self, Agent, Other_Agent, params={}):
+        self.params = copy.deepcopy(__class__.default_params)
+        self.params.update(params)
+        self.params["reference_frame"] = "egocentric"
+        assert self.params["cell_arrangement"] is not None, "cell_arrangement must be set for FOV Neurons"
+        self._warn_if_n_changes = "n" in params and params["n"] is not None
+        super().__init__(Agent, Other_Agent, self.params)
+
+
 # ================================================================================================
 class HeadDirectionCells(Neurons):
     """Head direction cells: von Mises tuning to the agent's head direction

@@ -13,9 +13,9 @@ from .Environment import Environment  # noqa: E402,F401
 from .Agent import Agent  # noqa: E402,F401
 from .Neurons import (  # noqa: E402,F401
     Neurons, PlaceCells, GridCells, VectorCells, BoundaryVectorCells, FieldOfViewBVCs, ObjectVectorCells,
-    FieldOfViewOVCs, HeadDirectionCells, VelocityCells, SpeedCell,
+    FieldOfViewOVCs, AgentVectorCells, FieldOfViewAVCs, HeadDirectionCells, VelocityCells, SpeedCell,
     RandomSpatialNeurons, FeedForwardLayer)
 
 __all__ = ["Environment", "Agent", "Neurons", "PlaceCells", "GridCells", "VectorCells", "BoundaryVectorCells",
-           "FieldOfViewBVCs", "ObjectVectorCells", "FieldOfViewOVCs", "HeadDirectionCells", "VelocityCells", "SpeedCell", "RandomSpatialNeurons",
-           "FeedForwardLayer", "utils"]
+           "FieldOfViewBVCs", "ObjectVectorCells", "FieldOfViewOVCs", "AgentVectorCells", "FieldOfViewAVCs",
+           "HeadDirectionCells", "VelocityCells", "SpeedCell", "RandomSpatialNeurons", "FeedForwardLayer", "utils"]

@@ -105,6 +105,8 @@ PROTOTYPES = {
                                                C.c_int32, C.c_void_p]),
     "riab_random_spatial_neurons": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_int32,
                                               C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "riab_agent_vector_cells": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "riab_velocity_cells": (C.c_int, [C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "riab_speed_cell": (C.c_int, [C.POINTER(RiabRateIO), C.c_float, C.c_void_p]),

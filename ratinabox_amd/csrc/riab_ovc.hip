@@ -34,6 +34,11 @@ struct OvcArgs {
   const float* objects;   // [M][2]
   const int* types;       // [M]
   const float* cells;     // [n][6] = a*mu_d, a, cos(phi), sin(phi), kappa*log2(e), type
+  // AgentVectorCells (Neurons.py:2204-2320): the one "object" is another agent, a different point for
+  // every lane: rows like pos_x / pos_y; objects / types are unused (every cell responds to it)
+  const float* other_x;
+  const float* other_y;
+  int64_t other_ld;
 };
 
 __global__ __launch_bounds__(256) void ovc_kernel(const OvcArgs a) {
@@ -60,7 +65,8 @@ __global__ __launch_bounds__(256) void ovc_kernel(const OvcArgs a) {
   const cf64 walls = (cf64)(const void*)a.walls;
   // ---- stage A ---------------------------------------------------------------------------------
   for (int m = wave; m < a.M; m += 4) {
-    const float ox = objs[2 * m], oy = objs[2 * m + 1];
+    const float ox = a.other_x ? a.other_x[t * a.other_ld + b] : objs[2 * m];
+    const float oy = a.other_x ? a.other_y[t * a.other_ld + b] : objs[2 * m + 1];
     float vx = ox - px, vy = oy - py;  // object - position (Neurons.py:2038-2040)
     if (a.periodic) {                  // Environment.py:670-674
       if (fabsf(vx) > a.half_scale) vx = -copysignf(a.scale - fabsf(vx), vx);
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(256) void ovc_kernel(const OvcArgs a) {
     const int ctype = (int)cells[6 * c + 5];
     float acc = 0.0f;
     for (int m = 0; m < a.M; ++m) {
-      if (types[m] != ctype) continue;  // wave-uniform
+      if (!a.other_x && types[m] != ctype) continue;  // wave-uniform
       const float tt = fmaf(s_d[m * 64 + lane], aa, -amu);
       const float cosd = fmaf(s_c[m * 64 + lane], cphi, s_s[m * 64 + lane] * sphi);  // cos(bearing - phi)
       acc += __builtin_amdgcn_exp2f(fmaf(-tt, tt, kap * (cosd - 1.0f)));
@@ -123,10 +129,9 @@ __global__ __launch_bounds__(256) void ovc_kernel(const OvcArgs a) {
 
 using namespace riab;
 
-extern "C" int riab_object_vector_cells(const RiabEnv* env, const RiabRateIO* io, const float* objects,
-                                        const int32_t* object_types, int32_t n_objects, const float* cells, int32_t n,
-                                        int32_t walls_occlude, int32_t egocentric, riab_stream_t stream) {
-  if (!env || !io || !objects || !object_types || !cells || n <= 0 || n_objects <= 0) return RIAB_EINVAL;
+static int launch_ovc(const RiabEnv* env, const RiabRateIO* io, const float* objects, const int32_t* object_types,
+                      int32_t n_objects, const float* other_x, const float* other_y, int64_t other_ld,
+                      const float* cells, int32_t n, int32_t walls_occlude, int32_t egocentric, hipStream_t stream) {
   if (io->T <= 0 || io->B <= 0 || !io->rates || !io->pos_x || !io->pos_y) return RIAB_EINVAL;
   if (egocentric && (!io->hd_x || !io->hd_y)) return RIAB_EINVAL;
   if (io->u_in && !io->spikes) return RIAB_EINVAL;
@@ -146,8 +151,25 @@ extern "C" int riab_object_vector_cells(const RiabEnv* env, const RiabRateIO* io
   a.periodic = env->periodic; a.occlude = walls_occlude ? 1 : 0; a.ego = egocentric ? 1 : 0;
   a.scale = (float)env->scale; a.half_scale = (float)(env->scale / 2);
   a.walls = env->walls; a.objects = objects; a.types = object_types; a.cells = cells;
+  a.other_x = other_x; a.other_y = other_y; a.other_ld = other_ld;
   const size_t lds = sizeof(float) * 3 * 64 * (size_t)n_objects;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)ovc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(ovc_kernel, dim3((unsigned)((a.P + 63) / 64)), dim3(256), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ovc_kernel, dim3((unsigned)((a.P + 63) / 64)), dim3(256), lds, stream, a);
   return (int)hipGetLastError();
+}
+
+extern "C" int riab_object_vector_cells(const RiabEnv* env, const RiabRateIO* io, const float* objects,
+                                        const int32_t* object_types, int32_t n_objects, const float* cells, int32_t n,
+                                        int32_t walls_occlude, int32_t egocentric, riab_stream_t stream) {
+  if (!env || !io || !objects || !object_types || !cells || n <= 0 || n_objects <= 0) return RIAB_EINVAL;
+  return launch_ovc(env, io, objects, object_types, n_objects, nullptr, nullptr, 0, cells, n, walls_occlude, egocentric,
+                    (hipStream_t)stream);
+}
+
+extern "C" int riab_agent_vector_cells(const RiabEnv* env, const RiabRateIO* io, const float* other_x,
+                                       const float* other_y, int64_t other_ld, const float* cells, int32_t n,
+                                       int32_t walls_occlude, int32_t egocentric, riab_stream_t stream) {
+  if (!env || !io || !other_x || !other_y || !cells || n <= 0 || other_ld < 0) return RIAB_EINVAL;
+  return launch_ovc(env, io, nullptr, nullptr, 1, other_x, other_y, other_ld, cells, n, walls_occlude, egocentric,
+                    (hipStream_t)stream);
 }

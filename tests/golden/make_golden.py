@@ -492,6 +492,43 @@ def make_ovc():
     np.savez_compressed(os.path.join(HERE, "ovc.npz"), **out)
 
 
+def make_avc():
+    """AgentVectorCells / FieldOfViewAVCs (Neurons.py:2151-2355): two agents in a walled box updated in
+    turn; per step both positions, the observer's head direction and the rates of its cells."""
+    from ratinabox.Neurons import AgentVectorCells, FieldOfViewAVCs
+    print("agent vector cells")
+    out = {}
+    np.random.seed(61)
+    Env = Environment({"walls": [[[0.5, 0.0], [0.5, 0.55]], [[0.2, 0.8], [0.6, 0.8]]]})
+    out["walls"] = np.array(Env.walls, float)
+    Ag1 = Agent(Env, {"dt": 0.05, "speed_mean": 0.2})
+    Ag2 = Agent(Env, {"dt": 0.05, "speed_mean": 0.2})
+    pops = {"allo": AgentVectorCells(Ag1, Ag2, {"n": 12, "max_fr": 3.0, "min_fr": 0.1}),
+            "nowalls": AgentVectorCells(Ag1, Ag2, {"n": 8, "walls_occlude": False}),
+            "ego": AgentVectorCells(Ag1, Ag2, {"n": 10, "reference_frame": "egocentric"}),
+            "fov": FieldOfViewAVCs(Ag1, Ag2, {"angle_range": [0, 120], "distance_range": [0.05, 0.6],
+                                              "spatial_resolution": 0.08})}
+    for tag, N in pops.items():
+        for k in ["tuning_distances", "tuning_angles", "sigma_distances", "sigma_angles"]:
+            out[f"{tag}_{k}"] = np.array(getattr(N, k), float)
+    p1, p2, hd, rates = [], [], [], {t: [] for t in pops}
+    for t in range(300):
+        Ag1.update()
+        Ag2.update()
+        Ag1.pos, Ag2.pos = f32exact(Ag1.pos), f32exact(Ag2.pos)
+        Ag1.head_direction = f32exact(Ag1.head_direction)
+        for tag, N in pops.items():
+            N.update()
+            rates[tag].append(N.firingrate.copy())
+        p1.append(Ag1.pos.copy()); p2.append(Ag2.pos.copy()); hd.append(Ag1.head_direction.copy())
+    out["p1"], out["p2"], out["hd"] = np.array(p1), np.array(p2), np.array(hd)
+    for tag in pops:
+        out[f"{tag}_rates"] = np.array(rates[tag])
+    occl = (out["allo_rates"] <= 0.1 + 1e-12).all(axis=1).sum()
+    print(f"  other agent out of sight on {int(occl)} of 300 steps; fov cells: {pops['fov'].n}")
+    np.savez_compressed(os.path.join(HERE, "avc.npz"), **out)
+
+
 def make_velocity():
     """VelocityCells / SpeedCell (Neurons.py:2534-2651) along the reference's own run in the maze: per step
     the velocity state (what VelocityCells read), the measured velocity (history["vel"][-1], what the
@@ -735,7 +772,7 @@ def make_stats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "velocity", "env", "random_spatial", "task", "stats"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task", "stats"]
     if "stats" in which:
         make_stats()
     if "task" in which:
@@ -746,6 +783,8 @@ if __name__ == "__main__":
         make_env_queries()
     if "velocity" in which:
         make_velocity()
+    if "avc" in which:
+        make_avc()
     if "ovc" in which:
         make_ovc()
     if "feedforward" in which:

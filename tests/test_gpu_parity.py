@@ -1115,3 +1115,65 @@ def test_random_spatial_neurons_vs_reference(riab, name, env_kw):
     for _ in range(5):
         plan.step()
     assert np.array_equal(np.array(N.history["firingrate"]), ref)
+
+
+def test_agent_vector_cells_vs_reference(riab):
+    """AgentVectorCells / FieldOfViewAVCs (reference Neurons.py:2151-2355): the reference's two-agent run,
+    one lane per recorded step (lane b of the observer sees lane b of the other agent); then two batched
+    agents moving in turn against the oracle; a single-agent Other_Agent is seen by every lane."""
+    g = gu.load("avc.npz")
+    T = len(g["p1"])
+    env = make_env(riab, g["walls"][4:])
+    np.random.seed(0)
+    Ag1 = riab.Agent(env, {"n_agents": T, "dt": 0.05})
+    Ag2 = riab.Agent(env, {"n_agents": T, "dt": 0.05})
+    assert env.Agents == [Ag1, Ag2]
+    pops = {"allo": riab.AgentVectorCells(Ag1, Ag2, {"n": 12, "max_fr": 3.0, "min_fr": 0.1}),
+            "nowalls": riab.AgentVectorCells(Ag1, Ag2, {"n": 8, "walls_occlude": False}),
+            "ego": riab.AgentVectorCells(Ag1, Ag2, {"n": 10, "reference_frame": "egocentric"}),
+            "fov": riab.FieldOfViewAVCs(Ag1, Ag2, {"angle_range": [0, 120], "distance_range": [0.05, 0.6],
+                                                   "spatial_resolution": 0.08})}
+    Ag1.pos, Ag2.pos, Ag1.head_direction = g["p1"], g["p2"], g["hd"]
+    for tag, N in pops.items():
+        for k in ["tuning_distances", "tuning_angles", "sigma_distances", "sigma_angles"]:
+            if tag != "fov":
+                setattr(N, k, g[f"{tag}_{k}"])
+            else:  # the manifold is deterministic: same cells as the reference's
+                np.testing.assert_allclose(getattr(N, k), g[f"{tag}_{k}"], rtol=1e-12)
+        N.update()
+        assert_rates(N.firingrate, g[f"{tag}_rates"].T, scale=2.9 if tag == "allo" else 1.0, floor=1.0)
+    # two batched agents taking turns, as in the reference's multi-agent loops
+    np.random.seed(1)
+    A = riab.Agent(env, {"n_agents": 130, "dt": 0.05, "speed_mean": 0.2, "seed": 3})
+    Bg = riab.Agent(env, {"n_agents": 130, "dt": 0.05, "speed_mean": 0.2, "seed": 4})
+    N = riab.AgentVectorCells(A, Bg, {"n": 9, "reference_frame": "egocentric"})
+    oenv = orc.EnvSpec(walls=g["walls"][4:])
+    seen = 0
+    for _ in range(25):
+        A.update()
+        Bg.update()
+        N.update()
+        f32 = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)  # noqa: E731
+        ref = orc.agent_vector_cells(oenv, f32(A.pos), f32(Bg.pos), N.tuning_distances, N.tuning_angles,
+                                     N.sigma_distances, N.sigma_angles, head_direction=f32(A.head_direction))
+        assert_rates(N.firingrate, ref, floor=1.0)
+        seen += int((ref > 1e-3).any(axis=0).sum())
+    assert seen > 0
+    # a single other agent is seen by every lane; away from the agents one position per call
+    C = riab.Agent(env, {"dt": 0.05})
+    N1 = riab.AgentVectorCells(A, C, {"n": 5, "walls_occlude": False})
+    N1.update()
+    ref = orc.agent_vector_cells(oenv, f32(A.pos), np.broadcast_to(f32(C.pos), (130, 2)), N1.tuning_distances,
+                                 N1.tuning_angles, N1.sigma_distances, N1.sigma_angles, walls_occlude=False)
+    assert_rates(N1.firingrate, ref, floor=1.0)
+    pts = g["p1"][:40]
+    got = N1.get_state(evaluate_at=None, pos=pts)
+    ref = orc.agent_vector_cells(oenv, pts, np.broadcast_to(f32(C.pos), (40, 2)), N1.tuning_distances, N1.tuning_angles,
+                                 N1.sigma_distances, N1.sigma_angles, walls_occlude=False)
+    assert_rates(got, ref, floor=1.0)
+    with pytest.raises(NotImplementedError):
+        A.simulate(3)
+    with pytest.raises(NotImplementedError):
+        A.make_step_plan()
+    with pytest.raises(ValueError):
+        riab.AgentVectorCells(A, Ag1)

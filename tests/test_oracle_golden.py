@@ -319,3 +319,18 @@ def test_random_spatial_neurons(name):
     got = orc.random_spatial_neurons(env, g["pos"], g[f"{name}_X"], g[f"{name}_targets"], float(g[f"{name}_lengthscale"]),
                                      geom)
     np.testing.assert_allclose(got, g[f"{name}_rates"], rtol=1e-11)
+
+
+AVC_CASES = {"allo": dict(min_fr=0.1, max_fr=3.0), "nowalls": dict(walls_occlude=False), "ego": dict(ego=True),
+             "fov": dict(ego=True)}
+
+
+@pytest.mark.parametrize("tag", sorted(AVC_CASES))
+def test_agent_vector_cells(tag):
+    g = gu.load("avc.npz")
+    kw = dict(AVC_CASES[tag])
+    hd = g["hd"] if kw.pop("ego", False) else None
+    env = orc.EnvSpec(walls=g["walls"][4:])
+    got = orc.agent_vector_cells(env, g["p1"], g["p2"], g[f"{tag}_tuning_distances"], g[f"{tag}_tuning_angles"],
+                                 g[f"{tag}_sigma_distances"], g[f"{tag}_sigma_angles"], head_direction=hd, **kw)
+    np.testing.assert_allclose(got, g[f"{tag}_rates"].T, rtol=1e-10, atol=1e-14)
