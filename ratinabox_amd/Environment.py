@@ -95,9 +95,30 @@ class Environment:
         self.Agents.append(agent)
         self.agents_dict[agent.name] = agent
 
+    def agent_lookup(self, agent_names=None):
+        """Agents by name: a name or a list of names -> list of Agents (None -> None); unknown names
+        raise ValueError (Environment.py:220-276)."""
+        if agent_names is None:
+            return None
+        if isinstance(agent_names, str):
+            agent_names = [agent_names]
+        return [self._agent_lookup(name) for name in agent_names]
+
+    def _agent_lookup(self, agent_name):
+        if agent_name is None:
+            return None
+        if agent_name in self.agents_dict:
+            return self.agents_dict[agent_name]
+        for agent in self.Agents:
+            if agent.name == agent_name:
+                self.agents_dict[agent_name] = agent
+                return agent
+        raise ValueError("Agent name not found in Environment.agents list. Make sure the there no typos. agent name is "
+                         "case sensitive")
+
     def remove_agent(self, agent=None):
         if isinstance(agent, str):
-            agent = self.agents_dict.get(agent)
+            agent = self._agent_lookup(agent)
         if agent is None:
             return None
         self.Agents.remove(agent)

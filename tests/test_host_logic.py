@@ -188,3 +188,21 @@ def test_small_api_helpers_match_reference():
     assert list(GCs.return_list_of_neurons("3")) == [0, 5, 10]
     assert GCs.return_list_of_neurons([1.0, 4.0]) == [1, 4]
     assert len(set(GCs.return_list_of_neurons("4rand"))) == 4
+
+
+def test_agent_registry_lookup():
+    """Environment.Agents / agents_dict / agent_lookup / remove_agent (reference Environment.py:220-328)."""
+    np.random.seed(0)
+    env = riab.Environment()
+    a = riab.Agent(env, dict(CPU))
+    b = riab.Agent(env, dict(CPU, name="rat"))
+    assert [x.name for x in env.Agents] == ["agent_0", "rat"] and (a.agent_idx, b.agent_idx) == (0, 1)
+    assert env.agent_lookup("rat") == [b] and env.agent_lookup(["rat", "agent_0"]) == [b, a]
+    assert env.agent_lookup(None) is None
+    with pytest.raises(ValueError):
+        env.agent_lookup("mouse")
+    with pytest.warns(UserWarning):
+        c = riab.Agent(env, dict(CPU, name="rat"))
+    assert c.name == "agent_2"
+    env.remove_agent("rat")
+    assert env.Agents == [a, c] and "rat" not in env.agents_dict
