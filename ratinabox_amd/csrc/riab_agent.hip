@@ -12,6 +12,7 @@
 // reference's float64 NumPy path to ~1e-12 per step, including the discrete
 // decisions (collision yes/no, which wall, boundary clamp); R = float is the
 // throughput variant.
+#include <cstdlib>
 #include "riab_device.h"
 
 #define RIAB_TABLE_QUAL static __device__ const
@@ -207,12 +208,102 @@ struct Wall {  // staged in LDS
 // variant has NO global load inside the step loop, so no s_waitcnt vmcnt(0) ever makes a step
 // wait for the previous step's history stores to land (measured: 37 % of the wave's cycles were
 // spent in such waits when all modes shared one kernel).
-template <class R, int IN>
-__global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
+//
+// PC (helper wave, Philox mode only): the workgroup has a SECOND wave that takes everything off the stepping
+// wave that is not part of the recurrence:
+//   * it draws the normals — Philox + Box-Muller are the one part of a step that does not depend on the
+//     state — a batch of RIAB_Z_BATCH steps ahead into a double-buffered LDS tile (the stepping wave reads
+//     two floats per step instead of issuing ~70 of its ~650 instructions at the lone-wave issue rate);
+//   * it writes the history rows to HBM: the stepping wave parks the rows of four steps in LDS (also
+//     double-buffered) and never issues a global store inside the step loop, so it never queues behind the
+//     rate kernels' store stream.
+// The waves meet at one workgroup barrier per four steps.  Values are bit-identical to the single-wave
+// kernel (the same float products, parked in LDS before the widening conversion).
+#define RIAB_Z_BATCH 16
+
+// the two standard normals of `step` for agent `aid` as floats; `pw` carries the Philox block that
+// serves an (even, odd) pair of steps
+struct MotionDraw {
+  u32x4 pw;
+  float z_rot, z_spd;
+};
+__device__ __forceinline__ MotionDraw motion_normals(uint64_t step, bool first, uint32_t aid, uint32_t k0, uint32_t k1,
+                                                     u32x4 pw) {
+  // one Philox4x32-10 call serves TWO steps: counter = step >> 1, words (x, y) on even steps
+  // and (z, w) on odd ones
+  if (first || (step & 1) == 0) {
+    const uint64_t pair = step >> 1;
+    // (the key is made opaque per call: otherwise the ten round keys are hoisted out of the step
+    // loop as 20 loop-invariant SGPRs, spilled to VGPR lanes, and read back with a v_readlane each)
+    uint32_t kk0 = k0, kk1 = k1;
+    asm volatile("" : "+s"(kk0), "+s"(kk1));
+    pw = philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), aid, RIAB_TAG_MOTION, kk0, kk1);
+  }
+  const uint32_t wa = (step & 1) ? pw.z : pw.x, wb = (step & 1) ? pw.w : pw.y;
+  // Box-Muller on the Philox words with the hardware log2 / sin / cos (the draws only need
+  // to be N(0,1) and a pure function of (seed, step, agent); `z_out` records them).
+  const float u1 = ((float)(wa >> 8) + 0.5f) * 0x1.0p-24f, u2 = (float)(wb >> 8) * 0x1.0p-24f;
+  const float rr = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1), hardware sqrt
+  return MotionDraw{pw, rr * __builtin_amdgcn_cosf(u2), rr * __builtin_amdgcn_sinf(u2)};
+}
+
+template <class R, int IN, bool PC>
+__global__ __launch_bounds__(PC ? 128 : 64) void agent_step_kernel(const AgentArgs a) {
+  static_assert(!PC || IN == 0, "the producer wave only exists in Philox mode");
+  const int lane = (int)(threadIdx.x & 63);
+  const int wave = PC ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  __shared__ float s_z[PC ? 2 : 1][PC ? RIAB_Z_BATCH : 1][2][PC ? 64 : 1];
+  // history rows of four steps of this workgroup's 64 agents (two such blocks with the helper wave)
+  __shared__ __align__(16) float s_hist[PC ? 2 : 1][4][RIAB_HIST_ROWS][64];
+  const int hist_lds_lane = (lane >> 4) * 64 + (lane & 15) * 4;                    // floats
+  const uint32_t hist_glb_lane = (uint32_t)(((int64_t)(lane >> 4) * a.B + (lane & 15) * 4) * 4);  // bytes
+  // rows of the four-step block that starts at step t0 (n_steps of them), LDS -> HBM as float4 rows:
+  // store j covers the (step, row) pairs 4j .. 4j+3: step j/2, rows 4(j&1) + lane/16, agents 4(lane&15)..+3.
+  // Everything that depends on j or t0 is wave-uniform (scalar registers).
+  auto flush_hist = [&](int buf, int t0, int n_steps) {
+    const int n2 = 2 * n_steps;
+    float* const g0 = a.hist + (int64_t)t0 * RIAB_HIST_ROWS * a.B + (int64_t)blockIdx.x * 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < n2) {
+        const v4f v = *reinterpret_cast<const v4f*>(&s_hist[buf][j >> 1][(j & 1) * 4][0] + hist_lds_lane);
+        char* const gj = reinterpret_cast<char*>(g0 + (int64_t)((j >> 1) * RIAB_HIST_ROWS + (j & 1) * 4) * a.B);
+        *reinterpret_cast<v4f*>(gj + hist_glb_lane) = v;
+      }
+    }
+  };
+  if (PC && wave == 1) {
+    // ---- helper wave.  Barrier schedule (both waves): staging, "noise batch 0 ready", then one barrier
+    // after every four-step block k.  While the stepping wave computes block k the helper (a) draws noise
+    // batch k/4 + 1 when k is a multiple of 4 — into the buffer the stepping wave left at the previous
+    // barrier — and (b) writes out history block k - 1 — the stepping wave fills the other buffer.
+    const uint32_t aid = (uint32_t)(a.agent_id0 + (int64_t)blockIdx.x * 64 + lane);
+    u32x4 pw = {0u, 0u, 0u, 0u};
+    auto draw_batch = [&](int batch) {
+      const int t0 = batch * RIAB_Z_BATCH;
+      const int tn = min(RIAB_Z_BATCH, a.T - t0);
+      for (int tl = 0; tl < tn; ++tl) {
+        const MotionDraw d = motion_normals(a.step0 + (uint64_t)(t0 + tl), t0 + tl == 0, aid, a.k0, a.k1, pw);
+        pw = d.pw;
+        s_z[batch & 1][tl][0][lane] = d.z_rot;
+        s_z[batch & 1][tl][1][lane] = d.z_spd;
+      }
+    };
+    __syncthreads();  // (the table-staging barrier of the stepping wave)
+    draw_batch(0);
+    __syncthreads();  // noise batch 0 ready
+    const int n_blocks = (a.T + 3) >> 2;
+    for (int k = 0; k < n_blocks; ++k) {
+      if ((k & 3) == 0 && (k / 4 + 1) * RIAB_Z_BATCH < a.T) draw_batch(k / 4 + 1);
+      if (k > 0 && a.hist) flush_hist((k - 1) & 1, 4 * (k - 1), 4);
+      __syncthreads();  // block k is in LDS; noise for block k + 1 is ready
+    }
+    if (a.hist) flush_hist((n_blocks - 1) & 1, 4 * (n_blocks - 1), a.T - 4 * (n_blocks - 1));
+    return;
+  }
   __shared__ Wall<R> s_w[RIAB_MAX_WALLS];
   __shared__ double s_g[sizeof(R) == 8 ? RIAB_G_SEGS * RIAB_G_STRIDE : 1];
   __shared__ double s_h[sizeof(R) == 8 ? RIAB_H_SEGS * RIAB_H_STRIDE : 1];
-  __shared__ __align__(16) float s_hist[4][RIAB_HIST_ROWS][64];  // four steps of history rows of this wave
   // Long launches stage the tables in LDS (per-lane gathers every step); a launch of a few steps
   // (the closed-loop path, T = 1) reads its two rows per step straight from the L2-resident
   // global tables instead of paying the 19 KB staging each time.
@@ -225,28 +316,28 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     double gv[GI], hv[HI];
 #pragma unroll
     for (int k = 0; k < GI; ++k) {
-      const int i = k * 64 + threadIdx.x;
+      const int i = k * 64 + lane;
       gv[k] = i < GN ? (&riab_g_table[0][0])[i] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < HI; ++k) {
-      const int i = k * 64 + threadIdx.x;
+      const int i = k * 64 + lane;
       hv[k] = i < HN ? (&riab_h_table[0][0])[i] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < GI; ++k) {
-      const int i = k * 64 + threadIdx.x;
+      const int i = k * 64 + lane;
       if (i < GN) s_g[(i / (RIAB_G_DEG + 3)) * RIAB_G_STRIDE + i % (RIAB_G_DEG + 3)] = gv[k];
     }
 #pragma unroll
     for (int k = 0; k < HI; ++k) {
-      const int i = k * 64 + threadIdx.x;
+      const int i = k * 64 + lane;
       if (i < HN) s_h[(i / (RIAB_H_DEG + 3)) * RIAB_H_STRIDE + i % (RIAB_H_DEG + 3)] = hv[k];
     }
   }
   const lds_cf64_ptr lds_g = (lds_cf64_ptr)s_g, lds_h = (lds_cf64_ptr)s_h;
   const glb_cf64_ptr glb_g = (glb_cf64_ptr)&riab_g_table[0][0], glb_h = (glb_cf64_ptr)&riab_h_table[0][0];
-  for (int w = threadIdx.x; w < a.n_walls; w += 64) {
+  for (int w = lane; w < a.n_walls; w += 64) {
     const double ax = a.walls[4 * w], ay = a.walls[4 * w + 1], bx = a.walls[4 * w + 2], by = a.walls[4 * w + 3];
     const double sx = bx - ax, sy = by - ay;
     const double ss = sx * sx + sy * sy;
@@ -258,12 +349,10 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     s_w[w].inv_len = (R)(1.0 / sqrt(ss));
   }
   __syncthreads();
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x * 64 + lane;
   if (b >= a.B) return;
   // full wave and a multi-step launch: history rows go through LDS (below); single steps store directly
   const bool hist_staged = a.hist && a.T >= 4 && ((int64_t)blockIdx.x * 64 + 64 <= a.B);
-  const int hist_lds_lane = (int)(threadIdx.x >> 4) * 64 + (int)(threadIdx.x & 15) * 4;                    // floats
-  const uint32_t hist_glb_lane = (uint32_t)(((int64_t)(threadIdx.x >> 4) * a.B + (threadIdx.x & 15) * 4) * 4);  // bytes
   // a latency-bound recurrence sharing its CU with bandwidth-bound rate kernels: win the
   // SIMD's issue arbitration whenever this wave is ready
   __builtin_amdgcn_s_setprio(3);
@@ -324,24 +413,19 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
       z_rot = (R)0;
       z_spd = (R)0;
     } else {
-      // one Philox4x32-10 call serves TWO steps: counter = step >> 1, words (x, y) on even steps
-      // and (z, w) on odd ones
-      const uint64_t step = a.step0 + (uint64_t)t;
-      if (t == 0 || (step & 1) == 0) {
-        const uint64_t pair = step >> 1;
-        // (the key is made opaque per call: otherwise the ten round keys are hoisted out of the step
-        // loop as 20 loop-invariant SGPRs, spilled to VGPR lanes, and read back with a v_readlane each)
-        uint32_t kk0 = a.k0, kk1 = a.k1;
-        asm volatile("" : "+s"(kk0), "+s"(kk1));
-        pw = philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), aid, RIAB_TAG_MOTION, kk0, kk1);
+      float zr, zs;
+      if (PC) {
+        if (t == 0) __syncthreads();  // noise batch 0 is ready (later batches: the barrier that ends a block)
+        zr = s_z[(t / RIAB_Z_BATCH) & 1][t % RIAB_Z_BATCH][0][lane];
+        zs = s_z[(t / RIAB_Z_BATCH) & 1][t % RIAB_Z_BATCH][1][lane];
+      } else {
+        const MotionDraw d = motion_normals(a.step0 + (uint64_t)t, t == 0, aid, a.k0, a.k1, pw);
+        pw = d.pw;
+        zr = d.z_rot;
+        zs = d.z_spd;
       }
-      const uint32_t wa = (step & 1) ? pw.z : pw.x, wb = (step & 1) ? pw.w : pw.y;
-      // Box-Muller on the Philox words with the hardware log2 / sin / cos (the draws only need
-      // to be N(0,1) and a pure function of (seed, step, agent); `z_out` records them).
-      const float u1 = ((float)(wa >> 8) + 0.5f) * 0x1.0p-24f, u2 = (float)(wb >> 8) * 0x1.0p-24f;
-      const float rr = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1), hardware sqrt
-      z_rot = (R)(rr * __builtin_amdgcn_cosf(u2));
-      z_spd = (R)(rr * __builtin_amdgcn_sinf(u2));
+      z_rot = (R)zr;
+      z_spd = (R)zs;
     }
     if (a.z_out) {
       a.z_out[((int64_t)t * 2 + 0) * B + b] = (double)z_rot;
@@ -607,35 +691,29 @@ __global__ __launch_bounds__(64) void agent_step_kernel(const AgentArgs a) {
     // ---- _update_distance_travelled (Agent.py:507) ----------------------------------------
     dist += dstep;
     // ---- save_to_history (Agent.py:514-520) ------------------------------------------------
-    if (hist_staged) {
+    if (PC || hist_staged) {
       // Eight dword stores per step are eight places to queue behind the rate kernels' store stream.
-      // The rows of four steps are parked in LDS (the wave is the only user) and written out as
-      // float4 rows: eight store instructions per FOUR steps, each covering four (step, row) pairs.
-      float* sh = &s_hist[t & 3][0][threadIdx.x];
-      sh[0 * 64] = (float)px;
-      sh[1 * 64] = (float)py;
-      sh[2 * 64] = (float)mvx;
-      sh[3 * 64] = (float)mvy;
-      sh[4 * 64] = (float)hx;
-      sh[5 * 64] = (float)hy;
-      sh[6 * 64] = (float)mrot;
-      sh[7 * 64] = (float)dist;
+      // The rows of four steps are parked in LDS and written out as float4 rows: eight store instructions
+      // per FOUR steps, each covering four (step, row) pairs — by the helper wave when there is one.
+      if (!PC || a.hist) {
+        float* sh = &s_hist[PC ? (t >> 2) & 1 : 0][t & 3][0][lane];
+        sh[0 * 64] = (float)px;
+        sh[1 * 64] = (float)py;
+        sh[2 * 64] = (float)mvx;
+        sh[3 * 64] = (float)mvy;
+        sh[4 * 64] = (float)hx;
+        sh[5 * 64] = (float)hy;
+        sh[6 * 64] = (float)mrot;
+        sh[7 * 64] = (float)dist;
+      }
       if ((t & 3) == 3 || t == a.T - 1) {
-        __builtin_amdgcn_wave_barrier();  // (LDS serves a wave's requests in order: the reads below see the writes)
-        // store j covers the (step, row) pairs 4j .. 4j+3: step j/2, rows 4(j&1) + lane/16, agents 4(lane&15)..+3.
-        // Everything that depends on j or t is wave-uniform (scalar registers); the lane's share of the
-        // addresses was computed once before the step loop.
-        const int n2 = 2 * ((t & 3) + 1);
-        float* const g0 = a.hist + (int64_t)(t - (t & 3)) * RIAB_HIST_ROWS * B + (int64_t)blockIdx.x * 64;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (j < n2) {
-            const v4f v = *reinterpret_cast<const v4f*>(&s_hist[j >> 1][(j & 1) * 4][0] + hist_lds_lane);
-            char* const gj = reinterpret_cast<char*>(g0 + (int64_t)((j >> 1) * RIAB_HIST_ROWS + (j & 1) * 4) * B);
-            *reinterpret_cast<v4f*>(gj + hist_glb_lane) = v;
-          }
+        if (PC) {
+          __syncthreads();  // hand the block to the helper wave; the next noise batch is ready
+        } else {
+          __builtin_amdgcn_wave_barrier();  // (LDS serves a wave's requests in order: the reads below see the writes)
+          flush_hist(0, t - (t & 3), (t & 3) + 1);
+          __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
       }
     } else if (a.hist) {
       float* h = a.hist + (int64_t)t * RIAB_HIST_ROWS * B + b;
@@ -708,14 +786,18 @@ extern "C" int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, dou
   const dim3 grid((unsigned)((B + 63) / 64));
   hipStream_t s = (hipStream_t)stream;
   const int in = forced_pos ? 2 : (z_in ? 1 : 0);
+  // long Philox launches of whole waves get the noise-producer wave (no lane may leave before the
+  // workgroup barriers, and z_out is written by the stepping wave of the single-wave kernel only)
+  const bool pc = in == 0 && precision == 64 && T >= 2 * RIAB_Z_BATCH && B % 64 == 0 && !z_out && !getenv("RIAB_NO_PC");
   if (precision == 64) {
-    if (in == 0) hipLaunchKernelGGL((agent_step_kernel<double, 0>), grid, dim3(64), 0, s, a);
-    else if (in == 1) hipLaunchKernelGGL((agent_step_kernel<double, 1>), grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((agent_step_kernel<double, 2>), grid, dim3(64), 0, s, a);
+    if (pc) hipLaunchKernelGGL((agent_step_kernel<double, 0, true>), grid, dim3(128), 0, s, a);
+    else if (in == 0) hipLaunchKernelGGL((agent_step_kernel<double, 0, false>), grid, dim3(64), 0, s, a);
+    else if (in == 1) hipLaunchKernelGGL((agent_step_kernel<double, 1, false>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((agent_step_kernel<double, 2, false>), grid, dim3(64), 0, s, a);
   } else {
-    if (in == 0) hipLaunchKernelGGL((agent_step_kernel<float, 0>), grid, dim3(64), 0, s, a);
-    else if (in == 1) hipLaunchKernelGGL((agent_step_kernel<float, 1>), grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((agent_step_kernel<float, 2>), grid, dim3(64), 0, s, a);
+    if (in == 0) hipLaunchKernelGGL((agent_step_kernel<float, 0, false>), grid, dim3(64), 0, s, a);
+    else if (in == 1) hipLaunchKernelGGL((agent_step_kernel<float, 1, false>), grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((agent_step_kernel<float, 2, false>), grid, dim3(64), 0, s, a);
   }
   return (int)hipGetLastError();
 }

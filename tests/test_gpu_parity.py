@@ -1177,3 +1177,28 @@ def test_agent_vector_cells_vs_reference(riab):
         A.make_step_plan()
     with pytest.raises(ValueError):
         riab.AgentVectorCells(A, Ag1)
+
+
+@pytest.mark.parametrize("B", [64, 192, 4096])
+def test_noise_producer_wave_is_bit_identical(riab, B, monkeypatch):
+    """Long Philox launches of whole waves run with a second wave that draws the normals ahead into LDS
+    (riab_agent.hip, PC variant).  Same state, history rows and diagnostics as the single-wave kernel
+    (RIAB_NO_PC=1), for step counts around the batch size of 16 and in the maze."""
+    walls = [[[.2, 0], [.2, .4]], [[.4, 1], [.4, .6]], [[.3, .5], [.7, .5]]]
+
+    def run(T, no_pc):
+        if no_pc:
+            monkeypatch.setenv("RIAB_NO_PC", "1")
+        else:
+            monkeypatch.delenv("RIAB_NO_PC", raising=False)
+        np.random.seed(5)
+        Ag = riab.Agent(make_env(riab, walls), {"n_agents": B, "dt": 0.05, "speed_mean": 0.3, "seed": 11})
+        traj = Ag.simulate(T, chunk=T)
+        torch.cuda.synchronize()
+        return Ag.state_tensor.clone(), traj.clone(), Ag.diagnostics
+
+    for T in (32, 33, 47, 48, 125, 256):
+        s1, h1, d1 = run(T, False)
+        s0, h0, d0 = run(T, True)
+        assert torch.equal(s1, s0) and torch.equal(h1, h0) and d1 == d0, T
+    monkeypatch.delenv("RIAB_NO_PC", raising=False)
