@@ -349,9 +349,12 @@ class Agent:
 
     @staticmethod
     def _chunk_schedule(n_steps, chunk):
-        """Steps per trajectory launch: uniform chunks.  (Tapering the last chunk to shorten the pipeline
-        drain paid +3 % while the trajectory kernel was the slower stage; with the two stages level at
-        cfg 2 it is neutral — small rate launches lose what the shorter drain saves — and was dropped.)"""
+        """Steps per trajectory launch: uniform chunks.  The pipeline is bound by the rate stage (rocprofv3
+        trace: its launches run back to back, 17 us apart); what the trajectory stage adds is the fill, the first
+        launch with nothing to overlap.  Measured at cfg 2 / K = 1024 and within the run-to-run spread, so not
+        adopted: ramping the first launches (chunk/4, chunk/4, chunk/2, chunk/2) +2 %, but the rate kernel loses
+        its large-launch efficiency on those chunks; alternating the rate launches over two streams to hide
+        the 17 us: 0 %; tapering the tail: 0 %."""
         n_steps, chunk = int(n_steps), max(int(chunk), 1)
         sched = [chunk] * (n_steps // chunk)
         if n_steps % chunk:

@@ -223,6 +223,72 @@ struct Wall {  // staged in LDS
 
 // the two standard normals of `step` for agent `aid` as floats; `pw` carries the Philox block that
 // serves an (even, odd) pair of steps
+// The part of a step that only produces OUTPUTS (measured velocity, measured rotational velocity, head
+// direction, distance travelled: Agent.py:456-507): nothing in it feeds the next step's motion, so the helper
+// wave can run it (PC variant) — from the step's displacement alone.
+template <class R>
+struct StepTail {
+  R mvx, mvy, mrot, hx, hy, dist;
+  int n_still;
+};
+template <class R>
+struct TailConst {
+  R dt, inv_dt, hd_keep, hd_gain;
+  bool hd_instant;
+};
+template <class R>
+__device__ __forceinline__ StepTail<R> step_tail(StepTail<R> s, R dpx, R dpy, const TailConst<R> c, uint64_t stp,
+                                                 uint32_t aid, uint32_t k0, uint32_t k1) {
+  // ---- _measure_velocity_of_step_taken (Agent.py:456-471) -------------------------------
+  const R pmvx = s.mvx, pmvy = s.mvy;  // prev_measured_velocity (Agent.py:201)
+  R mvx = dpx * c.inv_dt;
+  R mvy = dpy * c.inv_dt;
+  R dp2 = dpx * dpx + dpy * dpy;
+  R idp = r_rsqrt(dp2);          // one reciprocal square root serves |d_pos|, |mv| and 1/|mv|
+  R dstep = dp2 * idp;
+  R imv = idp * c.dt;            // 1 / |mv|
+  if (dp2 == (R)0) {
+    // 1e-8 * randn(2) (Agent.py:459-460): never reached in practice; its own Philox stream
+    const u32x4 zw = philox4x32_10((uint32_t)stp, (uint32_t)(stp >> 32), aid, RIAB_TAG_MOTION ^ 1u, k0, k1);
+    const float u3 = ((float)(zw.x >> 8) + 0.5f) * 0x1.0p-24f, u4 = (float)(zw.y >> 8) * 0x1.0p-24f;
+    const float r2 = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u3));
+    mvx = (R)1e-8 * (R)(r2 * __builtin_amdgcn_cosf(u4));
+    mvy = (R)1e-8 * (R)(r2 * __builtin_amdgcn_sinf(u4));
+    imv = r_rsqrt(mvx * mvx + mvy * mvy);
+    dstep = (R)0;
+    ++s.n_still;
+  }
+  {
+    // measured rotational velocity (Agent.py:465-468): pi_domain(get_angle(mv) - get_angle(prev_mv)) / dt.
+    // The wrapped difference of the two angles IS the signed angle between the two vectors
+    // (x + 1e-6 is utils.get_angle's quirk), taken directly from their cross / dot products;
+    // the arctangent runs in fp32 on that DIFFERENCE (relative error 1e-7 of a small angle;
+    // the quantity is an output, it does not feed back into the motion).
+    const R ax_ = pmvx + (R)1e-6, bx_ = mvx + (R)1e-6;
+    const R crs = ax_ * mvy - pmvy * bx_, dotp = ax_ * bx_ + pmvy * mvy;
+    s.mrot = (R)atan2_fast((float)crs, (float)dotp) * c.inv_dt;
+  }
+  s.mvx = mvx;
+  s.mvy = mvy;
+  // ---- _update_head_direction (Agent.py:488-500) ----------------------------------------
+  {
+    const R ix = mvx * imv, iy = mvy * imv;
+    if (c.hd_instant) {
+      s.hx = ix;
+      s.hy = iy;
+    } else {
+      const R nx = s.hx * c.hd_keep + c.hd_gain * ix;
+      const R ny = s.hy * c.hd_keep + c.hd_gain * iy;
+      const R inn = r_rsqrt(nx * nx + ny * ny);
+      s.hx = nx * inn;
+      s.hy = ny * inn;
+    }
+  }
+  // ---- _update_distance_travelled (Agent.py:507) ----------------------------------------
+  s.dist += dstep;
+  return s;
+}
+
 struct MotionDraw {
   u32x4 pw;
   float z_rot, z_spd;
@@ -253,8 +319,8 @@ __global__ __launch_bounds__(PC ? 128 : 64) void agent_step_kernel(const AgentAr
   const int lane = (int)(threadIdx.x & 63);
   const int wave = PC ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   __shared__ float s_z[PC ? 2 : 1][PC ? RIAB_Z_BATCH : 1][2][PC ? 64 : 1];
-  // history rows of four steps of this workgroup's 64 agents (two such blocks with the helper wave)
-  __shared__ __align__(16) float s_hist[PC ? 2 : 1][4][RIAB_HIST_ROWS][64];
+  // history rows of four steps of this workgroup's 64 agents (written by whichever wave stores them)
+  __shared__ __align__(16) float s_hist[1][4][RIAB_HIST_ROWS][64];
   const int hist_lds_lane = (lane >> 4) * 64 + (lane & 15) * 4;                    // floats
   const uint32_t hist_glb_lane = (uint32_t)(((int64_t)(lane >> 4) * a.B + (lane & 15) * 4) * 4);  // bytes
   // rows of the four-step block that starts at step t0 (n_steps of them), LDS -> HBM as float4 rows:
@@ -272,21 +338,55 @@ __global__ __launch_bounds__(PC ? 128 : 64) void agent_step_kernel(const AgentAr
       }
     }
   };
+  // what the stepping wave hands over per step in the PC variant: the displacement (float64: the tail is
+  // float64 arithmetic) and the position as the history keeps it; two four-step blocks
+  __shared__ double s_dp[PC ? 2 : 1][PC ? 4 : 1][2][PC ? 64 : 1];
+  __shared__ float s_pp[PC ? 2 : 1][PC ? 4 : 1][2][PC ? 64 : 1];
   if (PC && wave == 1) {
     // ---- helper wave.  Barrier schedule (both waves): staging, "noise batch 0 ready", then one barrier
     // after every four-step block k.  While the stepping wave computes block k the helper (a) draws noise
     // batch k/4 + 1 when k is a multiple of 4 — into the buffer the stepping wave left at the previous
-    // barrier — and (b) writes out history block k - 1 — the stepping wave fills the other buffer.
-    const uint32_t aid = (uint32_t)(a.agent_id0 + (int64_t)blockIdx.x * 64 + lane);
+    // barrier — and (b) finishes block k - 1: measured velocities, head direction, distance and the
+    // history rows of its four steps — the stepping wave fills the other hand-over buffer.
+    const int64_t b = (int64_t)blockIdx.x * 64 + lane;
+    const uint32_t aid = (uint32_t)(a.agent_id0 + b);
+    const RiabMotion& m = a.m;
+    const TailConst<R> tail_c = {(R)m.dt, (R)(1.0 / m.dt), (R)(1.0 - m.dt / m.hd_tau), (R)(m.dt / m.hd_tau),
+                                 m.hd_tau <= m.dt};
+    double* st = a.state + b;
+    const int64_t B = a.B;
+    StepTail<R> tl{(R)st[5 * B], (R)st[6 * B], (R)st[7 * B], (R)st[8 * B], (R)st[9 * B], (R)st[10 * B], 0};
     u32x4 pw = {0u, 0u, 0u, 0u};
     auto draw_batch = [&](int batch) {
       const int t0 = batch * RIAB_Z_BATCH;
       const int tn = min(RIAB_Z_BATCH, a.T - t0);
-      for (int tl = 0; tl < tn; ++tl) {
-        const MotionDraw d = motion_normals(a.step0 + (uint64_t)(t0 + tl), t0 + tl == 0, aid, a.k0, a.k1, pw);
+      for (int i = 0; i < tn; ++i) {
+        const MotionDraw d = motion_normals(a.step0 + (uint64_t)(t0 + i), t0 + i == 0, aid, a.k0, a.k1, pw);
         pw = d.pw;
-        s_z[batch & 1][tl][0][lane] = d.z_rot;
-        s_z[batch & 1][tl][1][lane] = d.z_spd;
+        s_z[batch & 1][i][0][lane] = d.z_rot;
+        s_z[batch & 1][i][1][lane] = d.z_spd;
+      }
+    };
+    auto finish_block = [&](int buf, int t0, int n_steps) {
+      for (int i = 0; i < n_steps; ++i) {
+        tl = step_tail<R>(tl, (R)s_dp[buf][i][0][lane], (R)s_dp[buf][i][1][lane], tail_c, a.step0 + (uint64_t)(t0 + i),
+                          aid, a.k0, a.k1);
+        if (a.hist) {
+          float* sh = &s_hist[0][i][0][lane];
+          sh[0 * 64] = s_pp[buf][i][0][lane];
+          sh[1 * 64] = s_pp[buf][i][1][lane];
+          sh[2 * 64] = (float)tl.mvx;
+          sh[3 * 64] = (float)tl.mvy;
+          sh[4 * 64] = (float)tl.hx;
+          sh[5 * 64] = (float)tl.hy;
+          sh[6 * 64] = (float)tl.mrot;
+          sh[7 * 64] = (float)tl.dist;
+        }
+      }
+      if (a.hist) {
+        __builtin_amdgcn_wave_barrier();  // (LDS serves a wave's requests in order: the reads below see the writes)
+        flush_hist(0, t0, n_steps);
+        __builtin_amdgcn_wave_barrier();
       }
     };
     __syncthreads();  // (the table-staging barrier of the stepping wave)
@@ -295,10 +395,17 @@ __global__ __launch_bounds__(PC ? 128 : 64) void agent_step_kernel(const AgentAr
     const int n_blocks = (a.T + 3) >> 2;
     for (int k = 0; k < n_blocks; ++k) {
       if ((k & 3) == 0 && (k / 4 + 1) * RIAB_Z_BATCH < a.T) draw_batch(k / 4 + 1);
-      if (k > 0 && a.hist) flush_hist((k - 1) & 1, 4 * (k - 1), 4);
-      __syncthreads();  // block k is in LDS; noise for block k + 1 is ready
+      if (k > 0) finish_block((k - 1) & 1, 4 * (k - 1), 4);
+      __syncthreads();  // block k is handed over; noise for block k + 1 is ready
     }
-    if (a.hist) flush_hist((n_blocks - 1) & 1, 4 * (n_blocks - 1), a.T - 4 * (n_blocks - 1));
+    finish_block((n_blocks - 1) & 1, 4 * (n_blocks - 1), a.T - 4 * (n_blocks - 1));
+    st[5 * B] = (double)tl.mvx;
+    st[6 * B] = (double)tl.mvy;
+    st[7 * B] = (double)tl.mrot;
+    st[8 * B] = (double)tl.hx;
+    st[9 * B] = (double)tl.hy;
+    st[10 * B] = (double)tl.dist;
+    if (a.diag && tl.n_still) atomicAdd(a.diag + 3, tl.n_still);
     return;
   }
   __shared__ Wall<R> s_w[RIAB_MAX_WALLS];
@@ -395,8 +502,7 @@ __global__ __launch_bounds__(PC ? 128 : 64) void agent_step_kernel(const AgentAr
   const R e0 = (R)a.e0, e1 = (R)a.e1, e2 = (R)a.e2, e3 = (R)a.e3;
   // divisions by loop constants become multiplications (<= 1 ulp from the reference's quotient)
   const R inv_dt = (R)(1.0 / m.dt);
-  const bool hd_instant = m.hd_tau <= m.dt;
-  const R hd_gain = (R)(m.dt / m.hd_tau), hd_keep = (R)(1.0 - m.dt / m.hd_tau);
+  const TailConst<R> tail_c = {dt, inv_dt, (R)(1.0 - m.dt / m.hd_tau), (R)(m.dt / m.hd_tau), m.hd_tau <= m.dt};
 
   u32x4 pw = {0u, 0u, 0u, 0u};
   Wall<R> w4[4];
@@ -636,84 +742,43 @@ __global__ __launch_bounds__(PC ? 128 : 64) void agent_step_kernel(const AgentAr
       if (fabs(dpx) > hs) dpx = -copysign(sc - fabs(dpx), dpx);
       if (fabs(dpy) > hs) dpy = -copysign(sc - fabs(dpy), dpy);
     }
-    const R pmvx = mvx, pmvy = mvy;  // prev_measured_velocity (Agent.py:201)
-    mvx = dpx * inv_dt;
-    mvy = dpy * inv_dt;
-    R dp2 = dpx * dpx + dpy * dpy;
-    R idp = r_rsqrt(dp2);          // one reciprocal square root serves |d_pos|, |mv| and 1/|mv|
-    R dstep = dp2 * idp;
-    R imv = idp * dt;              // 1 / |mv|
-    if (dp2 == (R)0) {
-      // 1e-8 * randn(2) (Agent.py:459-460): never reached in practice; its own Philox stream
-      const uint64_t stp = a.step0 + (uint64_t)t;
-      const u32x4 zw = philox4x32_10((uint32_t)stp, (uint32_t)(stp >> 32), aid, RIAB_TAG_MOTION ^ 1u, a.k0, a.k1);
-      const float u3 = ((float)(zw.x >> 8) + 0.5f) * 0x1.0p-24f, u4 = (float)(zw.y >> 8) * 0x1.0p-24f;
-      const float r2 = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u3));
-      mvx = (R)1e-8 * (R)(r2 * __builtin_amdgcn_cosf(u4));
-      mvy = (R)1e-8 * (R)(r2 * __builtin_amdgcn_sinf(u4));
-      imv = r_rsqrt(mvx * mvx + mvy * mvy);
-      dstep = (R)0;
-      ++n_still;
+    if (PC) {
+      // the rest of the step only produces outputs: the helper wave computes it from the displacement
+      s_dp[(t >> 2) & 1][t & 3][0][lane] = (double)dpx;
+      s_dp[(t >> 2) & 1][t & 3][1][lane] = (double)dpy;
+      s_pp[(t >> 2) & 1][t & 3][0][lane] = (float)px;
+      s_pp[(t >> 2) & 1][t & 3][1][lane] = (float)py;
+      if ((t & 3) == 3 || t == a.T - 1) __syncthreads();  // hand the block over; the next noise batch is ready
+      continue;
     }
     {
-      // measured rotational velocity (Agent.py:465-468): pi_domain(get_angle(mv) - get_angle(prev_mv)) / dt.
-      // The wrapped difference of the two angles IS the signed angle between the two vectors
-      // (x + 1e-6 is utils.get_angle's quirk), taken directly from their cross / dot products;
-      // the arctangent runs in fp32 on that DIFFERENCE (relative error 1e-7 of a small angle;
-      // the quantity is an output, it does not feed back into the motion).
-      const R ax_ = pmvx + (R)1e-6, bx_ = mvx + (R)1e-6;
-      const R crs = ax_ * mvy - pmvy * bx_, dotp = ax_ * bx_ + pmvy * mvy;
-#ifdef RIAB_EXP_NO_ATAN
-      mrot = crs * inv_dt;
-#else
-      mrot = (R)atan2_fast((float)crs, (float)dotp) * inv_dt;
-#endif
+      StepTail<R> tl{mvx, mvy, mrot, hx, hy, dist, n_still};
+      tl = step_tail<R>(tl, dpx, dpy, tail_c, a.step0 + (uint64_t)t, aid, a.k0, a.k1);
+      mvx = tl.mvx; mvy = tl.mvy; mrot = tl.mrot; hx = tl.hx; hy = tl.hy; dist = tl.dist; n_still = tl.n_still;
     }
     if (IN == 2) {  // overwrite_velocity=True (Agent.py:461-462, 469-470)
       vx = mvx;
       vy = mvy;
       rot = mrot;
     }
-    // ---- _update_head_direction (Agent.py:488-500) ----------------------------------------
-    {
-      const R ix = mvx * imv, iy = mvy * imv;
-      if (hd_instant) {
-        hx = ix;
-        hy = iy;
-      } else {
-        const R nx = hx * hd_keep + hd_gain * ix;
-        const R ny = hy * hd_keep + hd_gain * iy;
-        const R inn = r_rsqrt(nx * nx + ny * ny);
-        hx = nx * inn;
-        hy = ny * inn;
-      }
-    }
-    // ---- _update_distance_travelled (Agent.py:507) ----------------------------------------
-    dist += dstep;
     // ---- save_to_history (Agent.py:514-520) ------------------------------------------------
-    if (PC || hist_staged) {
+    if (hist_staged) {
       // Eight dword stores per step are eight places to queue behind the rate kernels' store stream.
       // The rows of four steps are parked in LDS and written out as float4 rows: eight store instructions
-      // per FOUR steps, each covering four (step, row) pairs — by the helper wave when there is one.
-      if (!PC || a.hist) {
-        float* sh = &s_hist[PC ? (t >> 2) & 1 : 0][t & 3][0][lane];
-        sh[0 * 64] = (float)px;
-        sh[1 * 64] = (float)py;
-        sh[2 * 64] = (float)mvx;
-        sh[3 * 64] = (float)mvy;
-        sh[4 * 64] = (float)hx;
-        sh[5 * 64] = (float)hy;
-        sh[6 * 64] = (float)mrot;
-        sh[7 * 64] = (float)dist;
-      }
+      // per FOUR steps, each covering four (step, row) pairs.
+      float* sh = &s_hist[0][t & 3][0][lane];
+      sh[0 * 64] = (float)px;
+      sh[1 * 64] = (float)py;
+      sh[2 * 64] = (float)mvx;
+      sh[3 * 64] = (float)mvy;
+      sh[4 * 64] = (float)hx;
+      sh[5 * 64] = (float)hy;
+      sh[6 * 64] = (float)mrot;
+      sh[7 * 64] = (float)dist;
       if ((t & 3) == 3 || t == a.T - 1) {
-        if (PC) {
-          __syncthreads();  // hand the block to the helper wave; the next noise batch is ready
-        } else {
-          __builtin_amdgcn_wave_barrier();  // (LDS serves a wave's requests in order: the reads below see the writes)
-          flush_hist(0, t - (t & 3), (t & 3) + 1);
-          __builtin_amdgcn_wave_barrier();
-        }
+        __builtin_amdgcn_wave_barrier();  // (LDS serves a wave's requests in order: the reads below see the writes)
+        flush_hist(0, t - (t & 3), (t & 3) + 1);
+        __builtin_amdgcn_wave_barrier();
       }
     } else if (a.hist) {
       float* h = a.hist + (int64_t)t * RIAB_HIST_ROWS * B + b;
@@ -732,12 +797,14 @@ __global__ __launch_bounds__(PC ? 128 : 64) void agent_step_kernel(const AgentAr
   st[2 * B] = (double)vx;
   st[3 * B] = (double)vy;
   st[4 * B] = (double)rot;
-  st[5 * B] = (double)mvx;
-  st[6 * B] = (double)mvy;
-  st[7 * B] = (double)mrot;
-  st[8 * B] = (double)hx;
-  st[9 * B] = (double)hy;
-  st[10 * B] = (double)dist;
+  if (!PC) {  // (the helper wave owns these rows)
+    st[5 * B] = (double)mvx;
+    st[6 * B] = (double)mvy;
+    st[7 * B] = (double)mrot;
+    st[8 * B] = (double)hx;
+    st[9 * B] = (double)hy;
+    st[10 * B] = (double)dist;
+  }
   st[11 * B] = (double)dwall;
   if (a.diag) {
     if (n_bounce) atomicAdd(a.diag + 0, n_bounce);
