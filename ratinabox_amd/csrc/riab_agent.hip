@@ -211,14 +211,14 @@ struct Wall {  // staged in LDS
 //
 // PC (helper wave, Philox mode only): the workgroup has a SECOND wave that takes everything off the stepping
 // wave that is not part of the recurrence:
-//   * it draws the normals — Philox + Box-Muller are the one part of a step that does not depend on the
-//     state — a batch of RIAB_Z_BATCH steps ahead into a double-buffered LDS tile (the stepping wave reads
-//     two floats per step instead of issuing ~70 of its ~650 instructions at the lone-wave issue rate);
-//   * it writes the history rows to HBM: the stepping wave parks the rows of four steps in LDS (also
-//     double-buffered) and never issues a global store inside the step loop, so it never queues behind the
-//     rate kernels' store stream.
+//   * it draws the normals — Philox + Box-Muller do not depend on the state — a batch of RIAB_Z_BATCH steps
+//     ahead into a double-buffered LDS tile (the stepping wave reads two floats per step);
+//   * it computes the output-only tail of every step (step_tail: measured velocities, head direction, distance)
+//     from the displacement the stepping wave hands over in LDS, and owns those state rows;
+//   * it writes the history rows to HBM, so the stepping wave never issues a global store inside the step
+//     loop and never queues behind the rate kernels' store stream.
 // The waves meet at one workgroup barrier per four steps.  Values are bit-identical to the single-wave
-// kernel (the same float products, parked in LDS before the widening conversion).
+// kernel (the same inlined functions on the same operands).
 #define RIAB_Z_BATCH 16
 
 // the two standard normals of `step` for agent `aid` as floats; `pw` carries the Philox block that
