@@ -1,817 +1,50 @@
-// Agent.update() for B independent agents, T steps fused in one launch (gfx950).
-//
-// One lane = one agent; the whole recurrent state (12 values) lives in VGPRs for
-// the T steps, wall segments are staged once per workgroup in LDS (broadcast
-// reads: every lane walks the same wall list), the per-step output is one
-// coalesced row per history field.  The kernel is a latency-bound recurrence
-// (64 waves at B = 4096), not a bandwidth kernel: per step it moves 8 floats per
-// agent.  It runs on its own stream underneath the firing-rate kernels of the
-// previous chunk (see ratinabox_amd/Agent.py: simulate()).
-//
-// Arithmetic is templated on the real type R: R = double reproduces the
-// reference's float64 NumPy path to ~1e-12 per step, including the discrete
-// decisions (collision yes/no, which wall, boundary clamp); R = float is the
-// throughput variant.
-#include <cstdlib>
-#include "riab_device.h"
-
-#define RIAB_TABLE_QUAL static __device__ const
-#include "riab_rayleigh_tables.h"
+// Agent.update on gfx950: the C ABI entry point of the motion kernel (riab_agent_kernel.h) and the step
+// plan's fused motion + task launch.
+#include "riab_agent_kernel.h"
+#include "riab_task_kernel.h"  // (after the motion kernel: this header turns fp contraction off for its own code)
 
 namespace riab {
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// LDS row strides (in doubles), padded so that lanes reading the same coefficient index of
-// different segments spread over the banks
-#define RIAB_G_STRIDE (RIAB_G_DEG + 4)
-#define RIAB_H_STRIDE (RIAB_H_DEG + 4)
-
-// The speed update of Agent._stochastic_velocity_update (reference Agent.py:302-309 with
-// utils.rayleigh_to_normal / normal_to_rayleigh, utils.py:409-421), float64, table-driven:
-//   G(t) = Phi^-1(clip(1 - exp(-t^2/2), 1e-6, 1-1e-6)),  H(n) = sqrt(-2 ln(1 - Phi(n))),  t = speed/sigma
-// (tools/gen_rayleigh_tables.py; max error 1.6e-16 vs 50-digit arithmetic).  Every lane runs
-// the same instruction stream on its own segment's coefficients: no exp/log/erfc/ndtri and
-// no divergent range branches.  Arguments of H beyond the table use the library functions.
-// lookup (issue the per-lane LDS reads of one segment's row) and evaluation are split so that
-// independent work can be placed between them: the wave is alone on its SIMD, nothing else hides
-// the LDS latency.
-template <int DEG>
-struct SegRow {
-  double c[DEG + 3];
-};
-// The row pointer carries its address space: LDS rows are read with ds_read (lgkmcnt), rows of the
-// global tables with global_load.  A generic pointer would make these flat loads, whose completion
-// is tracked by vmcnt as well — each step would then wait for the previous step's history stores
-// to be acknowledged before its polynomial could start.
-typedef const __attribute__((address_space(3))) double* lds_cf64_ptr;
-typedef const __attribute__((address_space(1))) double* glb_cf64_ptr;
-template <int DEG, class Ptr>
-__device__ __forceinline__ SegRow<DEG> seg_fetch(Ptr row) {
-  SegRow<DEG> r;
-#pragma unroll
-  for (int i = 0; i < DEG + 3; ++i) r.c[i] = row[i];
-  return r;
-}
-// p(x), x = (arg - mid) * inv_halfwidth, split into even and odd parts p = E(x^2) + x O(x^2): two
-// independent Horner recurrences of half the length (dependent-chain depth is what costs here).
-template <int DEG>
-__device__ __forceinline__ double seg_eval(const SegRow<DEG>& r, double arg) {
-  const double x = (arg - r.c[0]) * r.c[1];
-  const double x2 = x * x;
-  constexpr int KE = DEG & ~1, KO = (DEG - 1) | 1;  // highest even / odd power
-  double pe = r.c[2 + KE], po = r.c[2 + KO];
-#pragma unroll
-  for (int k = KE - 2; k >= 0; k -= 2) pe = fma(pe, x2, r.c[2 + k]);
-#pragma unroll
-  for (int k = KO - 2; k >= 1; k -= 2) po = fma(po, x2, r.c[2 + k]);
-  return fma(po, x, pe);
-}
-__device__ __forceinline__ double clamp_G_arg(double t) {
-  t = (t < RIAB_G_TLO) ? RIAB_G_TLO : t;
-  return (t > RIAB_G_THI) ? RIAB_G_THI : t;
-}
-__device__ __forceinline__ int seg_G(double t_clamped) {
-  return (int)(((unsigned long long)__double_as_longlong(t_clamped) >> 49) - RIAB_G_KEY0);
-}
-__device__ __forceinline__ int seg_H(double n) {
-  const int seg = (int)((n + RIAB_H_NMAX) * RIAB_H_INV_SEG);
-  return seg < 0 ? 0 : (seg > RIAB_H_SEGS - 1 ? RIAB_H_SEGS - 1 : seg);
+// One closed-loop step of a TaskEnvironment in ONE launch: Agent.update for this lane (a one-step,
+// single-wave motion launch), then — the lane reads back the position it has just written — the task
+// kernel's step + auto-reset + next scripted action.  Both are the device bodies of the stand-alone
+// kernels; what is saved is one dependent dispatch per step (the closed loop is bound by dispatch
+// latency, not by work).
+template <int MODE>
+__global__ __launch_bounds__(64) void motion_task_kernel(const AgentArgs ma, const TaskArgs a, const ResetArgs r,
+                                                         const double* pos_x, const double* pos_y, double t_env,
+                                                         double* reward_out, uint8_t* terminal_out, double gv_scale,
+                                                         double* gv_x, double* gv_y, int32_t* diag) {
+  agent_step_body<double, 0, false>(ma);
+  task_body<MODE>(a, r, pos_x, pos_y, t_env, reward_out, terminal_out, nullptr, gv_scale, gv_x, gv_y, diag);
 }
 
-struct AgentArgs {
-  RiabMotion m;
-  double e0, e1, e2, e3;  // extent
-  double scale;
-  int periodic;
-  int n_walls;
-  const double* walls;  // device [n_walls][4]
-  double* state;        // [12][B]
-  int64_t B;
-  int64_t agent_id0;
-  const double* drift;  // [2][B] or null
-  const double* z_in;   // [T][2][B] or null
-  double* z_out;        // [T][2][B] or null
-  const double* forced; // [T][2][B] or null: imported / forced positions (Agent.py:229-238)
-  uint32_t k0, k1;
-  uint64_t step0;
-  int T;
-  float* hist;  // [T][8][B] or null
-  int* diag;
-};
-
-// ---- math wrappers ---------------------------------------------------------------------------
-__device__ __forceinline__ double r_sqrt(double x) { return sqrt(x); }
-__device__ __forceinline__ float r_sqrt(float x) { return sqrtf(x); }
-// 1/sqrt(x) for positive finite x: the hardware estimate (v_rsq_f64, ~26 bits) and one third-order
-// correction — the library routine's arithmetic without its special-case selects (x = 0 or inf
-// only occur on paths whose result is discarded or replaced, see the call sites).
-__device__ __forceinline__ double r_rsqrt(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  const double e = fma(-x * y, y, 1.0);
-  return fma(y * e, fma(e, 0.375, 0.5), y);
-}
-__device__ __forceinline__ float r_rsqrt(float x) { return rsqrtf(x); }
-__device__ __forceinline__ double r_exp(double x) { return exp(x); }
-__device__ __forceinline__ float r_exp(float x) { return expf(x); }
-__device__ __forceinline__ double r_log(double x) { return log(x); }
-__device__ __forceinline__ float r_log(float x) { return logf(x); }
-__device__ __forceinline__ double r_ndtri(double u) { return normcdfinv(u); }
-__device__ __forceinline__ float r_ndtri(float u) { return normcdfinvf(u); }
-__device__ __forceinline__ double r_ndtr(double x) { return normcdf(x); }
-__device__ __forceinline__ float r_ndtr(float x) { return normcdff(x); }
-
-// clamp to [0, 1] / minimum as single v_max / v_min instructions.  A NaN argument (NaN position)
-// comes out as a number where the reference's comparisons keep the NaN; the position stays NaN
-// through `px - (...)` regardless, so nothing downstream differs.
-__device__ __forceinline__ double r_clamp01(double l) { return fmin(fmax(l, 0.0), 1.0); }
-__device__ __forceinline__ float r_clamp01(float l) { return fminf(fmaxf(l, 0.0f), 1.0f); }
-__device__ __forceinline__ double r_min(double a, double b) { return fmin(a, b); }
-__device__ __forceinline__ float r_min(float a, float b) { return fminf(a, b); }
-
-// atan2 in fp32 for the measured rotational velocity (an output: it does not feed back into the
-// motion): Cephes-style argument reduction to [0, tan(pi/8)] and a degree-9 odd polynomial (~2 ulp),
-// about half the instructions of the library routine, which also handles infinities.
-__device__ __forceinline__ float atan2_fast(float y, float x) {
-  const float ax = fabsf(x), ay = fabsf(y);
-  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-  float t = mn * __builtin_amdgcn_rcpf(mx);          // in [0, 1]; 0/0 -> NaN, fixed below
-  const bool hi = t > 0.4142135623730950f;            // tan(pi/8)
-  const float tr = (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f);
-  t = hi ? tr : t;
-  const float z = t * t;
-  float p = 8.05374449538e-2f;
-  p = fmaf(p, z, -1.38776856032e-1f);
-  p = fmaf(p, z, 1.99777106478e-1f);
-  p = fmaf(p, z, -3.33329491539e-1f);
-  float r = fmaf(p * z, t, t);
-  r = hi ? r + 0.78539816339744831f : r;
-  r = (ay > ax) ? 1.57079632679489662f - r : r;
-  r = (x < 0.0f) ? 3.14159265358979324f - r : r;
-  r = (mx == 0.0f) ? 0.0f : r;
-  return copysignf(r, y);
-}
-
-// sin/cos of the per-step heading increment rot*dt (|x| is a few 1e-2): Taylor in x^2, the library
-// routine for |x| >= 0.5.
-__device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
-  // the branch is wave-uniform (ballot): a wave runs exactly one of the three variants.  Each Taylor
-  // coefficient costs two instructions here (the loop-invariant constant has to be copied into the
-  // accumulator of a v_fmac), so the common case gets the shortest series that is exact to 1e-17.
-  const double ax = fabs(x);
-  if (__builtin_amdgcn_ballot_w64(ax >= 0.125) == 0) {  // |x| < 1/8: truncation < 3e-17 (sin), 3e-20 (cos)
-    const double x2 = x * x;
-    double sp = 1.0 / 362880.0;                        //  1/9!
-    sp = fma(sp, x2, -1.0 / 5040.0);                   // -1/7!
-    sp = fma(sp, x2, 1.0 / 120.0);                     //  1/5!
-    sp = fma(sp, x2, -1.0 / 6.0);                      // -1/3!
-    *s = fma(sp * x2, x, x);
-    double cp = -1.0 / 3628800.0;                      // -1/10!
-    cp = fma(cp, x2, 1.0 / 40320.0);                   //  1/8!
-    cp = fma(cp, x2, -1.0 / 720.0);                    // -1/6!
-    cp = fma(cp, x2, 1.0 / 24.0);                      //  1/4!
-    cp = fma(cp, x2, -0.5);
-    *c = fma(cp, x2, 1.0);
-  } else if (__builtin_amdgcn_ballot_w64(ax >= 0.5) == 0) {
-    const double x2 = x * x;
-    double sp = -1.0 / 1307674368000.0;                // -1/15!
-    sp = fma(sp, x2, 1.0 / 6227020800.0);              //  1/13!
-    sp = fma(sp, x2, -1.0 / 39916800.0);               // -1/11!
-    sp = fma(sp, x2, 1.0 / 362880.0);                  //  1/9!
-    sp = fma(sp, x2, -1.0 / 5040.0);                   // -1/7!
-    sp = fma(sp, x2, 1.0 / 120.0);                     //  1/5!
-    sp = fma(sp, x2, -1.0 / 6.0);                      // -1/3!
-    *s = fma(sp * x2, x, x);
-    double cp = 1.0 / 20922789888000.0;                //  1/16!
-    cp = fma(cp, x2, -1.0 / 87178291200.0);            // -1/14!
-    cp = fma(cp, x2, 1.0 / 479001600.0);               //  1/12!
-    cp = fma(cp, x2, -1.0 / 3628800.0);                // -1/10!
-    cp = fma(cp, x2, 1.0 / 40320.0);                   //  1/8!
-    cp = fma(cp, x2, -1.0 / 720.0);                    // -1/6!
-    cp = fma(cp, x2, 1.0 / 24.0);                      //  1/4!
-    cp = fma(cp, x2, -0.5);
-    *c = fma(cp, x2, 1.0);
-  } else {
-    sincos(x, s, c);
+int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* task, double* task_state, double* pos_x,
+                       double* pos_y, int64_t task_B, double t_env, double* reward_out, uint8_t* terminal_out,
+                       int32_t* diag, bool auto_reset, int64_t agent_id0, int32_t n_select, int32_t ordered, uint64_t seed,
+                       uint64_t counter, int32_t teleport, float* hist_x, float* hist_y, double* ep_log,
+                       int64_t ep_log_cap, int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y, hipStream_t s) {
+  TaskArgs a;
+  int rc = fill_args(a, env, task, task_state, task_B);
+  if (rc) return rc;
+  if (!pos_x || !pos_y || !reward_out || !terminal_out || !diag) return RIAB_EINVAL;
+  ResetArgs r = {};
+  if (auto_reset) {
+    rc = fill_reset(r, env, agent_id0, n_select, ordered, seed, counter, teleport, nullptr, nullptr, pos_x, pos_y, hist_x,
+                    hist_y, ep_log, ep_log_cap, ep_count);
+    if (rc) return rc;
   }
-}
-__device__ __forceinline__ void sincos_small(float x, float* s, float* c) { sincosf(x, s, c); }
-
-template <class R>
-struct Wall {  // staged in LDS
-  R ax, ay, sx, sy;  // start point and direction (b - a)
-  R inv_ss;          // 1 / |s|^2
-  R inv_len;         // 1 / |s|
-};
-
-// IN: 0 = in-kernel Philox noise, 1 = explicit normals z_in, 2 = forced positions.  The Philox
-// variant has NO global load inside the step loop, so no s_waitcnt vmcnt(0) ever makes a step
-// wait for the previous step's history stores to land (measured: 37 % of the wave's cycles were
-// spent in such waits when all modes shared one kernel).
-//
-// PC (helper wave, Philox mode only): the workgroup has a SECOND wave that takes everything off the stepping
-// wave that is not part of the recurrence:
-//   * it draws the normals — Philox + Box-Muller do not depend on the state — a batch of RIAB_Z_BATCH steps
-//     ahead into a double-buffered LDS tile (the stepping wave reads two floats per step);
-//   * it computes the output-only tail of every step (step_tail: measured velocities, head direction, distance)
-//     from the displacement the stepping wave hands over in LDS, and owns those state rows;
-//   * it writes the history rows to HBM, so the stepping wave never issues a global store inside the step
-//     loop and never queues behind the rate kernels' store stream.
-// The waves meet at one workgroup barrier per four steps.  Values are bit-identical to the single-wave
-// kernel (the same inlined functions on the same operands).
-#define RIAB_Z_BATCH 16
-
-// the two standard normals of `step` for agent `aid` as floats; `pw` carries the Philox block that
-// serves an (even, odd) pair of steps
-// The part of a step that only produces OUTPUTS (measured velocity, measured rotational velocity, head
-// direction, distance travelled: Agent.py:456-507): nothing in it feeds the next step's motion, so the helper
-// wave can run it (PC variant) — from the step's displacement alone.
-template <class R>
-struct StepTail {
-  R mvx, mvy, mrot, hx, hy, dist;
-  int n_still;
-};
-template <class R>
-struct TailConst {
-  R dt, inv_dt, hd_keep, hd_gain;
-  bool hd_instant;
-};
-template <class R>
-__device__ __forceinline__ StepTail<R> step_tail(StepTail<R> s, R dpx, R dpy, const TailConst<R> c, uint64_t stp,
-                                                 uint32_t aid, uint32_t k0, uint32_t k1) {
-  // ---- _measure_velocity_of_step_taken (Agent.py:456-471) -------------------------------
-  const R pmvx = s.mvx, pmvy = s.mvy;  // prev_measured_velocity (Agent.py:201)
-  R mvx = dpx * c.inv_dt;
-  R mvy = dpy * c.inv_dt;
-  R dp2 = dpx * dpx + dpy * dpy;
-  R idp = r_rsqrt(dp2);          // one reciprocal square root serves |d_pos|, |mv| and 1/|mv|
-  R dstep = dp2 * idp;
-  R imv = idp * c.dt;            // 1 / |mv|
-  if (dp2 == (R)0) {
-    // 1e-8 * randn(2) (Agent.py:459-460): never reached in practice; its own Philox stream
-    const u32x4 zw = philox4x32_10((uint32_t)stp, (uint32_t)(stp >> 32), aid, RIAB_TAG_MOTION ^ 1u, k0, k1);
-    const float u3 = ((float)(zw.x >> 8) + 0.5f) * 0x1.0p-24f, u4 = (float)(zw.y >> 8) * 0x1.0p-24f;
-    const float r2 = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u3));
-    mvx = (R)1e-8 * (R)(r2 * __builtin_amdgcn_cosf(u4));
-    mvy = (R)1e-8 * (R)(r2 * __builtin_amdgcn_sinf(u4));
-    imv = r_rsqrt(mvx * mvx + mvy * mvy);
-    dstep = (R)0;
-    ++s.n_still;
-  }
-  {
-    // measured rotational velocity (Agent.py:465-468): pi_domain(get_angle(mv) - get_angle(prev_mv)) / dt.
-    // The wrapped difference of the two angles IS the signed angle between the two vectors
-    // (x + 1e-6 is utils.get_angle's quirk), taken directly from their cross / dot products;
-    // the arctangent runs in fp32 on that DIFFERENCE (relative error 1e-7 of a small angle;
-    // the quantity is an output, it does not feed back into the motion).
-    const R ax_ = pmvx + (R)1e-6, bx_ = mvx + (R)1e-6;
-    const R crs = ax_ * mvy - pmvy * bx_, dotp = ax_ * bx_ + pmvy * mvy;
-    s.mrot = (R)atan2_fast((float)crs, (float)dotp) * c.inv_dt;
-  }
-  s.mvx = mvx;
-  s.mvy = mvy;
-  // ---- _update_head_direction (Agent.py:488-500) ----------------------------------------
-  {
-    const R ix = mvx * imv, iy = mvy * imv;
-    if (c.hd_instant) {
-      s.hx = ix;
-      s.hy = iy;
-    } else {
-      const R nx = s.hx * c.hd_keep + c.hd_gain * ix;
-      const R ny = s.hy * c.hd_keep + c.hd_gain * iy;
-      const R inn = r_rsqrt(nx * nx + ny * ny);
-      s.hx = nx * inn;
-      s.hy = ny * inn;
-    }
-  }
-  // ---- _update_distance_travelled (Agent.py:507) ----------------------------------------
-  s.dist += dstep;
-  return s;
-}
-
-struct MotionDraw {
-  u32x4 pw;
-  float z_rot, z_spd;
-};
-__device__ __forceinline__ MotionDraw motion_normals(uint64_t step, bool first, uint32_t aid, uint32_t k0, uint32_t k1,
-                                                     u32x4 pw) {
-  // one Philox4x32-10 call serves TWO steps: counter = step >> 1, words (x, y) on even steps
-  // and (z, w) on odd ones
-  if (first || (step & 1) == 0) {
-    const uint64_t pair = step >> 1;
-    // (the key is made opaque per call: otherwise the ten round keys are hoisted out of the step
-    // loop as 20 loop-invariant SGPRs, spilled to VGPR lanes, and read back with a v_readlane each)
-    uint32_t kk0 = k0, kk1 = k1;
-    asm volatile("" : "+s"(kk0), "+s"(kk1));
-    pw = philox4x32_10((uint32_t)pair, (uint32_t)(pair >> 32), aid, RIAB_TAG_MOTION, kk0, kk1);
-  }
-  const uint32_t wa = (step & 1) ? pw.z : pw.x, wb = (step & 1) ? pw.w : pw.y;
-  // Box-Muller on the Philox words with the hardware log2 / sin / cos (the draws only need
-  // to be N(0,1) and a pure function of (seed, step, agent); `z_out` records them).
-  const float u1 = ((float)(wa >> 8) + 0.5f) * 0x1.0p-24f, u2 = (float)(wb >> 8) * 0x1.0p-24f;
-  const float rr = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1), hardware sqrt
-  return MotionDraw{pw, rr * __builtin_amdgcn_cosf(u2), rr * __builtin_amdgcn_sinf(u2)};
-}
-
-template <class R, int IN, bool PC>
-__global__ __launch_bounds__(PC ? 128 : 64) void agent_step_kernel(const AgentArgs a) {
-  static_assert(!PC || IN == 0, "the producer wave only exists in Philox mode");
-  const int lane = (int)(threadIdx.x & 63);
-  const int wave = PC ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-  __shared__ float s_z[PC ? 2 : 1][PC ? RIAB_Z_BATCH : 1][2][PC ? 64 : 1];
-  // history rows of four steps of this workgroup's 64 agents (written by whichever wave stores them)
-  __shared__ __align__(16) float s_hist[1][4][RIAB_HIST_ROWS][64];
-  const int hist_lds_lane = (lane >> 4) * 64 + (lane & 15) * 4;                    // floats
-  const uint32_t hist_glb_lane = (uint32_t)(((int64_t)(lane >> 4) * a.B + (lane & 15) * 4) * 4);  // bytes
-  // rows of the four-step block that starts at step t0 (n_steps of them), LDS -> HBM as float4 rows:
-  // store j covers the (step, row) pairs 4j .. 4j+3: step j/2, rows 4(j&1) + lane/16, agents 4(lane&15)..+3.
-  // Everything that depends on j or t0 is wave-uniform (scalar registers).
-  auto flush_hist = [&](int buf, int t0, int n_steps) {
-    const int n2 = 2 * n_steps;
-    float* const g0 = a.hist + (int64_t)t0 * RIAB_HIST_ROWS * a.B + (int64_t)blockIdx.x * 64;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j < n2) {
-        const v4f v = *reinterpret_cast<const v4f*>(&s_hist[buf][j >> 1][(j & 1) * 4][0] + hist_lds_lane);
-        char* const gj = reinterpret_cast<char*>(g0 + (int64_t)((j >> 1) * RIAB_HIST_ROWS + (j & 1) * 4) * a.B);
-        *reinterpret_cast<v4f*>(gj + hist_glb_lane) = v;
-      }
-    }
-  };
-  // what the stepping wave hands over per step in the PC variant: the displacement (float64: the tail is
-  // float64 arithmetic) and the position as the history keeps it; two four-step blocks
-  __shared__ double s_dp[PC ? 2 : 1][PC ? 4 : 1][2][PC ? 64 : 1];
-  __shared__ float s_pp[PC ? 2 : 1][PC ? 4 : 1][2][PC ? 64 : 1];
-  if (PC && wave == 1) {
-    // ---- helper wave.  Barrier schedule (both waves): staging, "noise batch 0 ready", then one barrier
-    // after every four-step block k.  While the stepping wave computes block k the helper (a) draws noise
-    // batch k/4 + 1 when k is a multiple of 4 — into the buffer the stepping wave left at the previous
-    // barrier — and (b) finishes block k - 1: measured velocities, head direction, distance and the
-    // history rows of its four steps — the stepping wave fills the other hand-over buffer.
-    const int64_t b = (int64_t)blockIdx.x * 64 + lane;
-    const uint32_t aid = (uint32_t)(a.agent_id0 + b);
-    const RiabMotion& m = a.m;
-    const TailConst<R> tail_c = {(R)m.dt, (R)(1.0 / m.dt), (R)(1.0 - m.dt / m.hd_tau), (R)(m.dt / m.hd_tau),
-                                 m.hd_tau <= m.dt};
-    double* st = a.state + b;
-    const int64_t B = a.B;
-    StepTail<R> tl{(R)st[5 * B], (R)st[6 * B], (R)st[7 * B], (R)st[8 * B], (R)st[9 * B], (R)st[10 * B], 0};
-    u32x4 pw = {0u, 0u, 0u, 0u};
-    auto draw_batch = [&](int batch) {
-      const int t0 = batch * RIAB_Z_BATCH;
-      const int tn = min(RIAB_Z_BATCH, a.T - t0);
-      for (int i = 0; i < tn; ++i) {
-        const MotionDraw d = motion_normals(a.step0 + (uint64_t)(t0 + i), t0 + i == 0, aid, a.k0, a.k1, pw);
-        pw = d.pw;
-        s_z[batch & 1][i][0][lane] = d.z_rot;
-        s_z[batch & 1][i][1][lane] = d.z_spd;
-      }
-    };
-    auto finish_block = [&](int buf, int t0, int n_steps) {
-      for (int i = 0; i < n_steps; ++i) {
-        tl = step_tail<R>(tl, (R)s_dp[buf][i][0][lane], (R)s_dp[buf][i][1][lane], tail_c, a.step0 + (uint64_t)(t0 + i),
-                          aid, a.k0, a.k1);
-        if (a.hist) {
-          float* sh = &s_hist[0][i][0][lane];
-          sh[0 * 64] = s_pp[buf][i][0][lane];
-          sh[1 * 64] = s_pp[buf][i][1][lane];
-          sh[2 * 64] = (float)tl.mvx;
-          sh[3 * 64] = (float)tl.mvy;
-          sh[4 * 64] = (float)tl.hx;
-          sh[5 * 64] = (float)tl.hy;
-          sh[6 * 64] = (float)tl.mrot;
-          sh[7 * 64] = (float)tl.dist;
-        }
-      }
-      if (a.hist) {
-        __builtin_amdgcn_wave_barrier();  // (LDS serves a wave's requests in order: the reads below see the writes)
-        flush_hist(0, t0, n_steps);
-        __builtin_amdgcn_wave_barrier();
-      }
-    };
-    __syncthreads();  // (the table-staging barrier of the stepping wave)
-    draw_batch(0);
-    __syncthreads();  // noise batch 0 ready
-    const int n_blocks = (a.T + 3) >> 2;
-    for (int k = 0; k < n_blocks; ++k) {
-      if ((k & 3) == 0 && (k / 4 + 1) * RIAB_Z_BATCH < a.T) draw_batch(k / 4 + 1);
-      if (k > 0) finish_block((k - 1) & 1, 4 * (k - 1), 4);
-      __syncthreads();  // block k is handed over; noise for block k + 1 is ready
-    }
-    finish_block((n_blocks - 1) & 1, 4 * (n_blocks - 1), a.T - 4 * (n_blocks - 1));
-    st[5 * B] = (double)tl.mvx;
-    st[6 * B] = (double)tl.mvy;
-    st[7 * B] = (double)tl.mrot;
-    st[8 * B] = (double)tl.hx;
-    st[9 * B] = (double)tl.hy;
-    st[10 * B] = (double)tl.dist;
-    if (a.diag && tl.n_still) atomicAdd(a.diag + 3, tl.n_still);
-    return;
-  }
-  __shared__ Wall<R> s_w[RIAB_MAX_WALLS];
-  __shared__ double s_g[sizeof(R) == 8 ? RIAB_G_SEGS * RIAB_G_STRIDE : 1];
-  __shared__ double s_h[sizeof(R) == 8 ? RIAB_H_SEGS * RIAB_H_STRIDE : 1];
-  // Long launches stage the tables in LDS (per-lane gathers every step); a launch of a few steps
-  // (the closed-loop path, T = 1) reads its two rows per step straight from the L2-resident
-  // global tables instead of paying the 19 KB staging each time.
-  const bool use_lds = sizeof(R) == 8 && a.T >= 16;
-  if (use_lds) {
-    // all of a thread's table loads are issued before the first LDS write (one memory round trip for
-    // the whole staging; a load -> store loop serialises ~36 of them, 37 us per launch)
-    constexpr int GN = RIAB_G_SEGS * (RIAB_G_DEG + 3), HN = RIAB_H_SEGS * (RIAB_H_DEG + 3);
-    constexpr int GI = (GN + 63) / 64, HI = (HN + 63) / 64;
-    double gv[GI], hv[HI];
-#pragma unroll
-    for (int k = 0; k < GI; ++k) {
-      const int i = k * 64 + lane;
-      gv[k] = i < GN ? (&riab_g_table[0][0])[i] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < HI; ++k) {
-      const int i = k * 64 + lane;
-      hv[k] = i < HN ? (&riab_h_table[0][0])[i] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < GI; ++k) {
-      const int i = k * 64 + lane;
-      if (i < GN) s_g[(i / (RIAB_G_DEG + 3)) * RIAB_G_STRIDE + i % (RIAB_G_DEG + 3)] = gv[k];
-    }
-#pragma unroll
-    for (int k = 0; k < HI; ++k) {
-      const int i = k * 64 + lane;
-      if (i < HN) s_h[(i / (RIAB_H_DEG + 3)) * RIAB_H_STRIDE + i % (RIAB_H_DEG + 3)] = hv[k];
-    }
-  }
-  const lds_cf64_ptr lds_g = (lds_cf64_ptr)s_g, lds_h = (lds_cf64_ptr)s_h;
-  const glb_cf64_ptr glb_g = (glb_cf64_ptr)&riab_g_table[0][0], glb_h = (glb_cf64_ptr)&riab_h_table[0][0];
-  for (int w = lane; w < a.n_walls; w += 64) {
-    const double ax = a.walls[4 * w], ay = a.walls[4 * w + 1], bx = a.walls[4 * w + 2], by = a.walls[4 * w + 3];
-    const double sx = bx - ax, sy = by - ay;
-    const double ss = sx * sx + sy * sy;
-    s_w[w].ax = (R)ax;
-    s_w[w].ay = (R)ay;
-    s_w[w].sx = (R)sx;
-    s_w[w].sy = (R)sy;
-    s_w[w].inv_ss = (R)(1.0 / ss);
-    s_w[w].inv_len = (R)(1.0 / sqrt(ss));
-  }
-  __syncthreads();
-  const int64_t b = (int64_t)blockIdx.x * 64 + lane;
-  if (b >= a.B) return;
-  // full wave and a multi-step launch: history rows go through LDS (below); single steps store directly
-  const bool hist_staged = a.hist && a.T >= 4 && ((int64_t)blockIdx.x * 64 + 64 <= a.B);
-  // a latency-bound recurrence sharing its CU with bandwidth-bound rate kernels: win the
-  // SIMD's issue arbitration whenever this wave is ready
-  __builtin_amdgcn_s_setprio(3);
-  const RiabMotion& m = a.m;
-  const int nw = a.n_walls;
-  const R dt = (R)m.dt;
-
-  double* st = a.state + b;
-  const int64_t B = a.B;
-  R px = (R)st[0 * B], py = (R)st[1 * B];
-  R vx = (R)st[2 * B], vy = (R)st[3 * B];
-  R rot = (R)st[4 * B];
-  R mvx = (R)st[5 * B], mvy = (R)st[6 * B];
-  R mrot = (R)st[7 * B];
-  R hx = (R)st[8 * B], hy = (R)st[9 * B];
-  R dist = (R)st[10 * B];
-  R dwall = (R)st[11 * B];
-
-  R drx = 0, dry = 0;
-  if (m.has_drift) {
-    drx = (R)a.drift[b];
-    dry = (R)a.drift[B + b];
-  }
-
-  int n_bounce = 0, n_sat = 0, n_bc = 0, n_still = 0;
-  const uint32_t aid = (uint32_t)(a.agent_id0 + b);
-
-  // constants of the step
-  const R sm_kw = (R)m.speed_mean_kw, sm = (R)m.speed_mean;
-  const R inv_2s2 = (R)1 / ((R)2 * sm_kw * sm_kw);
-  const double inv_sm = 1.0 / m.speed_mean_kw;
-  const R wd = (R)m.wall_repel_distance_kw;
-  const R v0 = (R)m.wall_repel_strength_kw * sm;
-  const R kspring = (v0 * v0) / (wd * wd);
-  const R inv_wd2 = (R)1 / (wd * wd);
-  const R g = (R)m.thigmotaxis_kw;
-  const R cvel = (R)3 * (((R)1 - g) * ((R)1 - g));
-  const R cpos = (R)6 * (g * g);
-  const bool repel = (m.wall_repel_strength_kw != 0.0) && nw > 0;
-  const R e0 = (R)a.e0, e1 = (R)a.e1, e2 = (R)a.e2, e3 = (R)a.e3;
-  // divisions by loop constants become multiplications (<= 1 ulp from the reference's quotient)
-  const R inv_dt = (R)(1.0 / m.dt);
-  const TailConst<R> tail_c = {dt, inv_dt, (R)(1.0 - m.dt / m.hd_tau), (R)(m.dt / m.hd_tau), m.hd_tau <= m.dt};
-
-  u32x4 pw = {0u, 0u, 0u, 0u};
-  Wall<R> w4[4];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) w4[w] = s_w[w < nw ? w : 0];
-
-  for (int t = 0; t < a.T; ++t) {
-    // ---- the step's standard normals -------------------------------------------------------
-    R z_rot, z_spd;
-    if (IN == 1) {
-      z_rot = (R)a.z_in[((int64_t)t * 2 + 0) * B + b];
-      z_spd = (R)a.z_in[((int64_t)t * 2 + 1) * B + b];
-    } else if (IN == 2) {
-      z_rot = (R)0;
-      z_spd = (R)0;
-    } else {
-      float zr, zs;
-      if (PC) {
-        if (t == 0) __syncthreads();  // noise batch 0 is ready (later batches: the barrier that ends a block)
-        zr = s_z[(t / RIAB_Z_BATCH) & 1][t % RIAB_Z_BATCH][0][lane];
-        zs = s_z[(t / RIAB_Z_BATCH) & 1][t % RIAB_Z_BATCH][1][lane];
-      } else {
-        const MotionDraw d = motion_normals(a.step0 + (uint64_t)t, t == 0, aid, a.k0, a.k1, pw);
-        pw = d.pw;
-        zr = d.z_rot;
-        zs = d.z_spd;
-      }
-      z_rot = (R)zr;
-      z_spd = (R)zs;
-    }
-    if (a.z_out) {
-      a.z_out[((int64_t)t * 2 + 0) * B + b] = (double)z_rot;
-      a.z_out[((int64_t)t * 2 + 1) * B + b] = (double)z_spd;
-    }
-    const R ppx = px, ppy = py;  // prev_pos (Agent.py:199)
-    if (IN == 2) {
-      // imported / forced trajectory (Agent.py:229-238): the position is given, the motion
-      // model, wall handling and boundary conditions are skipped
-      px = (R)a.forced[((int64_t)t * 2 + 0) * B + b];
-      py = (R)a.forced[((int64_t)t * 2 + 1) * B + b];
-    } else {
-
-    // ---- _stochastic_velocity_update (Agent.py:287-312) -----------------------------------
-    // float64 path, ordered for latency: the rotation does not change |v|, so the speed and the
-    // LDS fetch of its G-segment come first; the H-segment fetch is followed by wall pass 1
-    // (which only needs the position) before the H polynomial is evaluated.
-    R v2 = vx * vx + vy * vy;
-    const bool zero_v = (v2 == (R)0);
-    if (zero_v) v2 = (R)1e-16;  // the reference replaces a zero velocity by (1e-8, 0) (Agent.py:299-300)
-    const R ispeed = r_rsqrt(v2);
-    const R speed = v2 * ispeed;
-    SegRow<RIAB_G_DEG> grow;
-    double tG = 0.0;
-    if (sizeof(R) == 8) {
-      tG = clamp_G_arg((double)speed * inv_sm);
-      const int sg = seg_G(tG);
-      grow = use_lds ? seg_fetch<RIAB_G_DEG>(lds_g + sg * RIAB_G_STRIDE) : seg_fetch<RIAB_G_DEG>(glb_g + sg * (RIAB_G_DEG + 3));
-    }
-    rot += (R)m.rot_theta_kw * ((R)m.rot_drift_kw - rot) * dt + (R)m.rot_sigma_kw * (dt * z_rot);
-    {
-      R sn, cs;
-#ifdef RIAB_EXP_NO_SINCOS
-      sn = rot * dt; cs = (R)1 - (R)0.5 * sn * sn;
-#else
-      sincos_small(rot * dt, &sn, &cs);
-#endif
-      const R nx = cs * vx + (-sn) * vy;
-      const R ny = sn * vx + cs * vy;
-      vx = zero_v ? (R)1e-8 : nx;
-      vy = zero_v ? (R)0 : ny;
-    }
-    // utils.rayleigh_to_normal / normal_to_rayleigh (utils.py:409-421), sigma = speed_mean
-    R speed_new = sm_kw;
-    SegRow<RIAB_H_DEG> hrow;
-    double nv64 = 0.0;
-    bool h_in_table = true;
-    if (sizeof(R) == 8) {
-      nv64 = seg_eval<RIAB_G_DEG>(grow, tG);
-      nv64 += m.speed_theta_kw * (0.0 - nv64) * m.dt + m.speed_sigma_kw * (m.dt * (double)z_spd);
-      h_in_table = fabs(nv64) < RIAB_H_NMAX;
-      const int sh = seg_H(nv64);
-      hrow = use_lds ? seg_fetch<RIAB_H_DEG>(lds_h + sh * RIAB_H_STRIDE) : seg_fetch<RIAB_H_DEG>(glb_h + sh * (RIAB_H_DEG + 3));
-    } else {
-      R u = (R)1 - r_exp(-v2 * inv_2s2);
-      u = (u < (R)1e-6) ? (R)1e-6 : u;
-      u = (u > (R)(1 - 1e-6)) ? (R)(1 - 1e-6) : u;
-      R nv = r_ndtri(u);
-      nv += (R)m.speed_theta_kw * ((R)0 - nv) * dt + (R)m.speed_sigma_kw * (dt * z_spd);
-      const R x = r_ndtr(nv);
-      speed_new = sm_kw * r_sqrt((R)-2 * r_log((R)1 - x));
-    }
-    // ---- _wall_velocity_update, pass 1 (Agent.py:357-415, utils.py:121-184) ---------------
-    // squared distances first: the sqrt / normalisation only for walls inside the repel
-    // distance, and ONE sqrt for distance_to_closest_wall (sqrt is monotone: same value)
-    R x2min = INFINITY;
-    uint64_t near_mask = 0;  // bit w: wall w is within the repel distance (pass 2 walks the set bits in order)
-    const R wd2 = wd * wd * (R)1.000001;
-    if (nw > 0) {
-      // pass 1 (cheap, every wall): squared distance to the nearest point of the wall; remember the
-      // walls inside the repel distance.  pass 2 (expensive: sqrt, 1/x, the spring / conveyor terms)
-      // runs only over those, in wall order, so the sums are the reference's sums (the skipped terms
-      // are exact zeros).  Instruction count matters here (one wave per SIMD issues an fp64
-      // instruction every 7.5 cycles): the clamps are v_min / v_max, the near set is a bit mask.
-      auto pass1 = [&](const Wall<R>& W, int w) {
-        const R dxw = px - W.ax, dyw = py - W.ay;
-        R l = (dxw * W.sx + dyw * W.sy) * W.inv_ss;
-        l = r_clamp01(l);
-        const R qx = px - (W.ax + l * W.sx), qy = py - (W.ay + l * W.sy);
-        const R x2 = qx * qx + qy * qy;
-        x2min = r_min(x2, x2min);
-        near_mask |= (uint64_t)(x2 <= wd2) << w;
-      };
-      // the first four walls (the box itself when boundaries are solid) live in registers for the
-      // whole launch: no LDS round trip per step for the common open-box case
-      if (nw >= 4) {  // one uniform test instead of four (each a spilled 64-bit mask read back per step)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) pass1(w4[w], w);
-        for (int w = 4; w < nw; ++w) pass1(s_w[w], w);
-      } else {
-        for (int w = 0; w < nw; ++w) pass1(s_w[w], w);
-      }
-    }
-    // ---- finish the speed update ---------------------------------------------------------------
-    if (sizeof(R) == 8) {
-      const double tnew = h_in_table ? seg_eval<RIAB_H_DEG>(hrow, nv64) : sqrt(-2.0 * log(1.0 - normcdf(nv64)));
-      speed_new = (R)(m.speed_mean_kw * tnew);
-    }
-    if (m.speed_std_is_zero) speed_new = sm_kw;
-    {
-      const R f = speed_new * ispeed;
-      vx *= f;
-      vy *= f;
-    }
-    // ---- _drift_velocity_update (Agent.py:331-341) ----------------------------------------
-    if (m.has_drift) {
-      vx += (R)m.drift_theta * (drx - vx) * dt;
-      vy += (R)m.drift_theta * (dry - vy) * dt;
-    }
-    // ---- _wall_velocity_update, pass 2 -----------------------------------------------------
-    if (nw > 0) {
-      if (repel) {
-        R ax_ = 0, ay_ = 0, sx_ = 0, sy_ = 0;
-        for (uint64_t rest = near_mask; rest; rest &= rest - 1) {
-          const int w = __ffsll((long long)rest) - 1;
-          const Wall<R> W = s_w[w];
-          const R dxw = px - W.ax, dyw = py - W.ay;
-          R l = (dxw * W.sx + dyw * W.sy) * W.inv_ss;
-          l = r_clamp01(l);
-          const R qx = px - (W.ax + l * W.sx), qy = py - (W.ay + l * W.sy);
-          const R xx = qx * qx + qy * qy;
-          const R ix = r_rsqrt(xx);  // 1/x and x from one reciprocal square root
-          const R x = xx * ix;
-          if (x <= wd) {
-            const R nx = qx * ix, ny = qy * ix;
-            const R acc = kspring * (wd - x);
-            const R spd = v0 * ((R)1 - r_sqrt((R)1 - ((wd - x) * (wd - x)) * inv_wd2));
-            ax_ += acc * nx;
-            ay_ += acc * ny;
-            sx_ += spd * nx;
-            sy_ += spd * ny;
-          }
-        }
-        dwall = r_sqrt(x2min);
-        vx += cvel * (ax_ * dt);
-        vy += cvel * (ay_ * dt);
-        px += cpos * (sx_ * dt);
-        py += cpos * (sy_ * dt);
-      }
-    }
-    // ---- propose (Agent.py:216) -----------------------------------------------------------
-    px += vx * dt;
-    py += vy * dt;
-    // ---- _check_and_handle_wall_collisions (Agent.py:426-441, utils.py:74-106, 304-328) ---
-    // A step shorter than the distance from prev_pos to the nearest wall cannot cross any wall:
-    // skip the per-wall segment tests (x2min was measured at prev_pos).
-    const R step2 = (px - ppx) * (px - ppx) + (py - ppy) * (py - ppy);
-    if (nw > 0 && !(step2 < (R)0.998 * x2min)) {
-      int it = 0;
-      for (; it < RIAB_MAX_BOUNCES; ++it) {
-        const R sbx = px - ppx, sby = py - ppy;  // the step (list b), walls are list a
-        int hit = -1;
-        for (int w = 0; w < nw; ++w) {
-          const Wall<R> W = s_w[w];
-          const R d0x = ppx - W.ax, d0y = ppy - W.ay;
-          const R den_a = W.sx * (-sby) + W.sy * sbx;
-          const R num_a = d0x * (-sby) + d0y * sbx;
-          const R den_b = sbx * (-W.sy) + sby * W.sx;
-          const R num_b = (-d0x) * (-W.sy) + (-d0y) * W.sx;
-          // 0 < num/den < 1 by sign logic (den == 0: +-inf / NaN in NumPy -> no hit)
-          const bool ia = (den_a > 0) ? (num_a > 0 && num_a < den_a) : (den_a < 0 ? (num_a < 0 && num_a > den_a) : false);
-          const bool ib = (den_b > 0) ? (num_b > 0 && num_b < den_b) : (den_b < 0 ? (num_b < 0 && num_b > den_b) : false);
-          if (ia && ib && hit < 0) hit = w;  // first colliding wall = lowest index
-        }
-        if (hit < 0) break;
-        const Wall<R> W = s_w[hit];
-        // utils.wall_bounce
-        R parx = W.sx * W.inv_len, pary = W.sy * W.inv_len;
-        R perx = -W.sy * W.inv_len, pery = W.sx * W.inv_len;
-        if ((-W.sy) * vx + W.sx * vy <= (R)0) {
-          perx = -perx;
-          pery = -pery;
-        }
-        if (W.sx * vx + W.sy * vy <= (R)0) {
-          parx = -parx;
-          pary = -pary;
-        }
-        const R vpar = vx * parx + vy * pary, vper = vx * perx + vy * pery;
-        R nvx = parx * vpar - perx * vper, nvy = pary * vpar - pery * vper;
-        const R f = ((R)0.5 * sm) / r_sqrt(nvx * nvx + nvy * nvy);
-        vx = f * nvx;
-        vy = f * nvy;
-        px = ppx + vx * dt;
-        py = ppy + vy * dt;
-        ++n_bounce;
-      }
-      if (it == RIAB_MAX_BOUNCES) ++n_sat;
-    }
-    // ---- boundary safety net (Agent.py:221-222, Environment.py:781-894) -------------------
-    if (!(px > e0 && px < e1 && py > e2 && py < e3)) {
-      ++n_bc;
-      if (a.periodic) {
-        px = px - e1 * floor(px / e1);  // np.mod(pos, extent)
-        py = py - e3 * floor(py / e3);
-      } else {
-        const R lo_x = e0 + (R)0.01, hi_x = e1 - (R)0.01, lo_y = e2 + (R)0.01, hi_y = e3 - (R)0.01;
-        px = (lo_x > px) ? lo_x : px;  // python max(pos, lo): NaN stays NaN
-        px = (hi_x < px) ? hi_x : px;
-        py = (lo_y > py) ? lo_y : py;
-        py = (hi_y < py) ? hi_y : py;
-      }
-    }
-    }  // random-motion branch
-    // ---- _measure_velocity_of_step_taken (Agent.py:456-471) -------------------------------
-    R dpx = px - ppx, dpy = py - ppy;
-    if (a.periodic) {
-      const R sc = (R)a.scale, hs = (R)(a.scale / 2);
-      if (fabs(dpx) > hs) dpx = -copysign(sc - fabs(dpx), dpx);
-      if (fabs(dpy) > hs) dpy = -copysign(sc - fabs(dpy), dpy);
-    }
-    if (PC) {
-      // the rest of the step only produces outputs: the helper wave computes it from the displacement
-      s_dp[(t >> 2) & 1][t & 3][0][lane] = (double)dpx;
-      s_dp[(t >> 2) & 1][t & 3][1][lane] = (double)dpy;
-      s_pp[(t >> 2) & 1][t & 3][0][lane] = (float)px;
-      s_pp[(t >> 2) & 1][t & 3][1][lane] = (float)py;
-      if ((t & 3) == 3 || t == a.T - 1) __syncthreads();  // hand the block over; the next noise batch is ready
-      continue;
-    }
-    {
-      StepTail<R> tl{mvx, mvy, mrot, hx, hy, dist, n_still};
-      tl = step_tail<R>(tl, dpx, dpy, tail_c, a.step0 + (uint64_t)t, aid, a.k0, a.k1);
-      mvx = tl.mvx; mvy = tl.mvy; mrot = tl.mrot; hx = tl.hx; hy = tl.hy; dist = tl.dist; n_still = tl.n_still;
-    }
-    if (IN == 2) {  // overwrite_velocity=True (Agent.py:461-462, 469-470)
-      vx = mvx;
-      vy = mvy;
-      rot = mrot;
-    }
-    // ---- save_to_history (Agent.py:514-520) ------------------------------------------------
-    if (hist_staged) {
-      // Eight dword stores per step are eight places to queue behind the rate kernels' store stream.
-      // The rows of four steps are parked in LDS and written out as float4 rows: eight store instructions
-      // per FOUR steps, each covering four (step, row) pairs.
-      float* sh = &s_hist[0][t & 3][0][lane];
-      sh[0 * 64] = (float)px;
-      sh[1 * 64] = (float)py;
-      sh[2 * 64] = (float)mvx;
-      sh[3 * 64] = (float)mvy;
-      sh[4 * 64] = (float)hx;
-      sh[5 * 64] = (float)hy;
-      sh[6 * 64] = (float)mrot;
-      sh[7 * 64] = (float)dist;
-      if ((t & 3) == 3 || t == a.T - 1) {
-        __builtin_amdgcn_wave_barrier();  // (LDS serves a wave's requests in order: the reads below see the writes)
-        flush_hist(0, t - (t & 3), (t & 3) + 1);
-        __builtin_amdgcn_wave_barrier();
-      }
-    } else if (a.hist) {
-      float* h = a.hist + (int64_t)t * RIAB_HIST_ROWS * B + b;
-      h[0 * B] = (float)px;
-      h[1 * B] = (float)py;
-      h[2 * B] = (float)mvx;
-      h[3 * B] = (float)mvy;
-      h[4 * B] = (float)hx;
-      h[5 * B] = (float)hy;
-      h[6 * B] = (float)mrot;
-      h[7 * B] = (float)dist;
-    }
-  }
-  st[0 * B] = (double)px;
-  st[1 * B] = (double)py;
-  st[2 * B] = (double)vx;
-  st[3 * B] = (double)vy;
-  st[4 * B] = (double)rot;
-  if (!PC) {  // (the helper wave owns these rows)
-    st[5 * B] = (double)mvx;
-    st[6 * B] = (double)mvy;
-    st[7 * B] = (double)mrot;
-    st[8 * B] = (double)hx;
-    st[9 * B] = (double)hy;
-    st[10 * B] = (double)dist;
-  }
-  st[11 * B] = (double)dwall;
-  if (a.diag) {
-    if (n_bounce) atomicAdd(a.diag + 0, n_bounce);
-    if (n_sat) atomicAdd(a.diag + 1, n_sat);
-    if (n_bc) atomicAdd(a.diag + 2, n_bc);
-    if (n_still) atomicAdd(a.diag + 3, n_still);
-  }
+  const dim3 grid((unsigned)((ma.B + 63) / 64)), block(64);  // the motion batch is the (padded) larger one
+  const bool gv = gv_x != nullptr;
+#define RIAB_MT_LAUNCH(MODE)                                                                                 \
+  hipLaunchKernelGGL(motion_task_kernel<MODE>, grid, block, 0, s, ma, a, r, pos_x, pos_y, t_env, reward_out, \
+                     terminal_out, gv_scale, gv_x, gv_y, diag)
+  if (auto_reset && gv) RIAB_MT_LAUNCH(7);
+  else if (auto_reset) RIAB_MT_LAUNCH(3);
+  else if (gv) RIAB_MT_LAUNCH(5);
+  else RIAB_MT_LAUNCH(1);
+#undef RIAB_MT_LAUNCH
+  return (int)hipGetLastError();
 }
 
 }  // namespace riab
@@ -822,39 +55,15 @@ extern "C" int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, dou
                                int64_t agent_id0, const double* drift, const double* z_in, double* z_out,
                                const double* forced_pos, uint64_t seed, uint64_t step0, int32_t T, float* hist, int32_t* diag,
                                int32_t precision, riab_stream_t stream) {
-  if (!env || !motion || !state || B <= 0 || T <= 0 || agent_id0 < 0) return RIAB_EINVAL;
-  if (env->n_walls < 0 || (env->n_walls > 0 && !env->walls)) return RIAB_EINVAL;
-  if (env->n_walls > RIAB_MAX_WALLS) return RIAB_ETOOBIG;
-  if (motion->has_drift && !drift) return RIAB_EINVAL;
-  if (precision != 64 && precision != 32) return RIAB_EINVAL;
   AgentArgs a;
-  a.m = *motion;
-  a.e0 = env->extent[0];
-  a.e1 = env->extent[1];
-  a.e2 = env->extent[2];
-  a.e3 = env->extent[3];
-  a.scale = env->scale;
-  a.periodic = env->periodic;
-  a.n_walls = env->n_walls;
-  a.walls = env->walls;
-  a.state = state;
-  a.B = B;
-  a.agent_id0 = agent_id0;
-  a.drift = drift;
-  a.z_in = z_in;
-  a.z_out = z_out;
-  a.forced = forced_pos;
-  a.k0 = (uint32_t)seed;
-  a.k1 = (uint32_t)(seed >> 32);
-  a.step0 = step0;
-  a.T = T;
-  a.hist = hist;
-  a.diag = diag;
+  const int rc = fill_agent_args(a, env, motion, state, B, agent_id0, drift, z_in, z_out, forced_pos, seed, step0, T, hist,
+                                 diag, precision);
+  if (rc) return rc;
   const dim3 grid((unsigned)((B + 63) / 64));
   hipStream_t s = (hipStream_t)stream;
   const int in = forced_pos ? 2 : (z_in ? 1 : 0);
-  // long Philox launches of whole waves get the noise-producer wave (no lane may leave before the
-  // workgroup barriers, and z_out is written by the stepping wave of the single-wave kernel only)
+  // long Philox launches of whole waves get the helper wave (no lane may leave before the workgroup
+  // barriers, and z_out is written by the stepping wave of the single-wave kernel only)
   const bool pc = in == 0 && precision == 64 && T >= 2 * RIAB_Z_BATCH && B % 64 == 0 && !z_out && !getenv("RIAB_NO_PC");
   if (precision == 64) {
     if (pc) hipLaunchKernelGGL((agent_step_kernel<double, 0, true>), grid, dim3(128), 0, s, a);

@@ -7,10 +7,11 @@
 // pointers in C++ and enqueues the motion kernel and every population's rate kernel for each
 // requested step.  No allocation, no synchronisation: histories are chunks handed in by the
 // caller, and the call reports RIAB_EFULL (before launching anything) when a chunk is exhausted.
+#include <cstdlib>
 #include <new>
 #include <vector>
 
-#include "riab_device.h"
+#include "riab_agent_kernel.h"
 
 namespace riab {
 int launch_task_fused(const RiabEnv* env, const RiabTask* task, double* task_state, double* pos_x, double* pos_y, int64_t B,
@@ -18,7 +19,13 @@ int launch_task_fused(const RiabEnv* env, const RiabTask* task, double* task_sta
                       int64_t agent_id0, int32_t n_select, int32_t ordered, uint64_t seed, uint64_t counter,
                       int32_t teleport, float* hist_x, float* hist_y, double* ep_log, int64_t ep_log_cap,
                       int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y, hipStream_t s);
-}
+
+int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* task, double* task_state, double* pos_x,
+                       double* pos_y, int64_t task_B, double t_env, double* reward_out, uint8_t* terminal_out,
+                       int32_t* diag, bool auto_reset, int64_t agent_id0, int32_t n_select, int32_t ordered, uint64_t seed,
+                       uint64_t counter, int32_t teleport, float* hist_x, float* hist_y, double* ep_log,
+                       int64_t ep_log_cap, int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y, hipStream_t s);
+}  // namespace riab
 
 struct RiabPlan {
   RiabEnv env;
@@ -273,6 +280,25 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
         if (rc) return rc;
       }
     }
+    const bool fused = p->has_task && p->precision == 64 && !getenv("RIAB_NO_FUSED_TASK");
+    if (fused) {  // motion + the rest of TaskEnvironment.step (+ the caller's `if terminal: reset()`) in one launch
+      riab::AgentArgs ma;
+      rc = riab::fill_agent_args(ma, &p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr,
+                                 p->seed, p->step, 1, row, p->diag, p->precision);
+      if (rc) return rc;
+      p->step += 1;
+      if (p->hist_base) p->hist_fill += 1;
+      p->t_env += p->dt_env;
+      if (p->auto_reset) p->reset_counter += 1;
+      rc = riab::launch_motion_task(ma, &p->env, &p->task, p->task_state, pos_x, pos_y, p->task_B, p->t_env, p->reward_out,
+                                    p->terminal_out, p->task_diag, p->auto_reset != 0, p->agent_id0, p->n_select,
+                                    p->ordered, p->task_seed, p->reset_counter, p->teleport,
+                                    row + (int64_t)RIAB_H_POS_X * p->B, row + (int64_t)RIAB_H_POS_Y * p->B, p->ep_log,
+                                    p->ep_log_cap, p->ep_count, p->scripted_speed, scripted ? act : nullptr,
+                                    scripted ? act + p->B : nullptr, s);
+      if (rc) return rc;
+      p->action_ready = scripted;
+    } else {
     rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr,
                              p->seed, p->step, 1, row, p->diag, p->precision, s);
     if (rc) return rc;
@@ -288,6 +314,7 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
                                    p->scripted_speed, scripted ? act : nullptr, scripted ? act + p->B : nullptr, s);
       if (rc) return rc;
       p->action_ready = scripted;
+    }
     }
     for (size_t i = 0; i < p->pops.size(); ++i) {
       rc = launch_population(p, i, row, s);

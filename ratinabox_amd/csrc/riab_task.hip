@@ -1,510 +1,7 @@
-// Batched TaskEnvironment bookkeeping for gfx950 (reference contribs/TaskEnvironment.py).
-//
-// One lane = one agent of the batch = one independent single-agent replica of the reference's
-// TaskEnvironment.  After the motion kernel has moved the agents, task_kernel does for every lane
-// what TaskEnvironment.step does between Agent.update and its return (:410-449): decay the lane's
-// active rewards, check and consume its goals, append the termination-delay goal, total the reward.
-// The reference's list semantics are kept, including its two iteration quirks (the goal after a
-// popped goal is skipped in that pass, :1130-1141; the reward after an expired reward is skipped in
-// that update, :919-922), because they change which step a reward starts or ends on.
-//
-// All arithmetic is float64 like the reference (goal tests are discontinuous predicates; there are a
-// handful of operations per lane and step).  The kernel is latency-bound, not bandwidth-bound: at
-// 4096 lanes it is 64 wavefronts.  So it is organised around round trips, not bytes:
-//   * everything a lane needs is fetched by ONE batch of independent loads at the top (counts, the 16
-//     list rows, position, stats), the goal list then lives in registers as 16 packed bytes
-//     (pops are 128-bit shifts — no dynamically indexed arrays, hence no scratch memory, whose
-//     per-dispatch set-up alone costs ~10 us), and every row is written back once at the end;
-//   * the reward total is accumulated while the cache is walked (no read-back of what was just stored);
-//   * the caller's `if terminal: reset()` and the scripted goal-seeking action of the NEXT step are
-//     fused into the same launch for the step plan (riab_plan.hip): 3 kernels per closed-loop step.
-#include "riab_device.h"
-
-// The reward recursions are compared bit for bit with the reference's float64 python arithmetic:
-// no fused multiply-adds in this file.
-#pragma clang fp contract(off)
-
-#define RIAB_TAG_TASK 0x5441534Bu  // "TASK"
+// Batched TaskEnvironment on gfx950: the C ABI entry points of the task kernel (riab_task_kernel.h).
+#include "riab_task_kernel.h"
 
 namespace riab {
-
-typedef unsigned __int128 u128;
-// the staged goal pool is read with LDS instructions proper (ds_read): a generic pointer would compile
-// to flat loads, whose completion is tracked by vmcnt as well — every goal-row read would then also
-// wait for the reward rows stored just before it
-typedef const __attribute__((address_space(3))) double* lds_f64_ptr;
-
-struct TaskArgs {
-  const double* walls;  // [n_walls][4]
-  int n_walls;
-  const double* goals;  // [n_pool][8]
-  int n_pool;
-  int goalorder;
-  double terminate_delay;
-  double pad_reward[5];
-  double default_level;
-  double* ts;  // [RIAB_TS_ROWS][B]
-  int64_t B;
-};
-
-struct ResetArgs {
-  int64_t agent_id0;
-  int n_select, ordered, teleport;
-  uint64_t seed, counter;
-  const double* new_x;
-  const double* new_y;
-  double* pos_x;
-  double* pos_y;
-  float* hist_x;
-  float* hist_y;
-  double cx, cy, half;
-  double* ep_log;
-  int64_t ep_log_cap;
-  int32_t* ep_count;
-};
-
-__device__ __forceinline__ double& ts_at(const TaskArgs& a, int row, int64_t b) { return a.ts[(int64_t)row * a.B + b]; }
-
-// ---- the lane's goal list: 16 bytes in registers (pool index, 0xFE = termination-delay goal) ----
-__device__ __forceinline__ int list_get(u128 l, int i) {
-  const int v = (int)((uint32_t)(l >> (8 * i)) & 0xFFu);
-  return v == 0xFE ? RIAB_GOAL_TIME_ELAPSED : v;
-}
-__device__ __forceinline__ u128 list_set(u128 l, int i, int src) {
-  const u128 m = (u128)0xFF << (8 * i);
-  return (l & ~m) | ((u128)(uint32_t)(src & 0xFF) << (8 * i));
-}
-__device__ __forceinline__ u128 list_pop(u128 l, int g) {  // GoalCache.pop (:1154-1172)
-  const u128 low = g ? (l & ((((u128)1) << (8 * g)) - 1)) : (u128)0;
-  const u128 high = g < 15 ? ((l >> (8 * (g + 1))) << (8 * g)) : (u128)0;
-  return low | high;
-}
-
-struct Lane {
-  u128 list;
-  int n_goals, n_rw;
-  bool delayed, list_dirty;
-  double pad_start;
-  double px, py;
-  double new_total;  // states of the rewards awarded this step, in award order
-};
-
-__device__ __forceinline__ void load_list(const TaskArgs& a, int64_t b, Lane& L) {
-  double rows[RIAB_TASK_MAX_GOALS];
-#pragma unroll
-  for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i) rows[i] = ts_at(a, RIAB_TS_GOAL_LIST + i, b);
-  u128 l = 0;
-#pragma unroll
-  for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i) l |= (u128)(uint32_t)((int)rows[i] & 0xFF) << (8 * i);
-  L.list = l;
-  L.list_dirty = false;
-}
-
-__device__ __forceinline__ void store_list(const TaskArgs& a, int64_t b, const Lane& L) {
-#pragma unroll
-  for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i)
-    if (i < L.n_goals) ts_at(a, RIAB_TS_GOAL_LIST + i, b) = (double)list_get(L.list, i);
-}
-
-// Reward.get_delta with no external drive (:823-832): -(decay(state)), presets of :732-737
-__device__ __forceinline__ double reward_delta(int preset, double knob, double state) {
-  switch (preset) {
-    case RIAB_DECAY_CONSTANT: return -knob;
-    case RIAB_DECAY_LINEAR: return -(knob * state);
-    case RIAB_DECAY_EXPONENTIAL: return -(knob * exp(state));
-    default: return -0.0;
-  }
-}
-
-// the Reward template (init_state, dt, expire_clock, preset, knob) a goal hands out
-struct RewardTpl {
-  double init, dt, expire, knob;
-  int preset;
-};
-__device__ __forceinline__ RewardTpl reward_of(const TaskArgs& a, lds_f64_ptr goals, int src) {
-  if (src == RIAB_GOAL_TIME_ELAPSED) return {a.pad_reward[0], a.pad_reward[1], a.pad_reward[2], a.pad_reward[4], (int)a.pad_reward[3]};
-  const lds_f64_ptr r = goals + src * RIAB_GOAL_COLS + 3;
-  return {r[0], r[1], r[2], r[4], (int)r[3]};
-}
-
-// SpatialGoal._in_goal_radius (:1319-1332): line_of_sight distance < radius, i.e. the euclidean
-// distance unless a wall of walls[4:] crosses the segment agent -> goal (Environment.py:715-722: the
-// distance becomes 1000, which no radius reaches in practice but is compared all the same).  The
-// reference asserts solid boundaries for this geometry (Environment.py:710-713); so does the host.
-__device__ bool in_goal_radius(const TaskArgs& a, double px, double py, lds_f64_ptr g) {
-  const double gx = g[0], gy = g[1], radius = g[2];
-  const double vx = px - gx, vy = py - gy;
-  double dist = sqrt(vx * vx + vy * vy);
-  if (!(dist < radius)) return false;  // (a blocked line of sight can only turn a hit into a miss)
-  for (int w = 4; w < a.n_walls; ++w) {
-    const double* ww = a.walls + 4 * w;
-    if (seg_hit(px, py, gx, gy, ww[0], ww[1], ww[2], ww[3])) {
-      dist = 1000.0;
-      break;
-    }
-  }
-  return dist < radius;
-}
-
-// RewardCache.append (:902-911): a copy of the goal's reward joins the end of the cache
-__device__ void award(const TaskArgs& a, lds_f64_ptr goals, int64_t b, Lane& L, int src, int32_t* diag) {
-  if (L.n_rw >= RIAB_TASK_MAX_REWARDS) {
-    atomicAdd(diag + RIAB_TD_REWARD_OVERFLOW, 1);
-    return;
-  }
-  const RewardTpl r = reward_of(a, goals, src);
-  ts_at(a, RIAB_TS_RW_STATE + L.n_rw, b) = r.init;
-  ts_at(a, RIAB_TS_RW_EXPIRE + L.n_rw, b) = r.expire;
-  ts_at(a, RIAB_TS_RW_SRC + L.n_rw, b) = (double)src;
-  L.n_rw += 1;
-  L.new_total = L.new_total + r.init;
-}
-
-__device__ bool goal_met(const TaskArgs& a, lds_f64_ptr goals, const Lane& L, int src, double t_env) {
-  if (src == RIAB_GOAL_TIME_ELAPSED)  // TimeElapsedGoal.check (:1271-1278)
-    return t_env - L.pad_start >= a.terminate_delay;
-  return in_goal_radius(a, L.px, L.py, goals + src * RIAB_GOAL_COLS);
-}
-
-// One GoalCache.check(remove_finished=True) for the lane (:1076-1152); returns goals consumed.
-__device__ int check_pass(const TaskArgs& a, lds_f64_ptr goals, int64_t b, Lane& L, double t_env, int32_t* diag) {
-  int done = 0;
-  if (L.n_goals == 0) return 0;
-  if (a.goalorder == RIAB_GOALORDER_SEQUENTIAL) {
-    // `this` = last achieved + 1 is always the head of the list: pop() rewinds the marker (:1161-1163)
-    const int src = list_get(L.list, 0);
-    if (goal_met(a, goals, L, src, t_env)) {
-      award(a, goals, b, L, src, diag);
-      L.list = list_pop(L.list, 0);
-      L.n_goals -= 1;
-      L.list_dirty = true;
-      done = 1;
-    }
-    return done;
-  }
-  int g = 0;
-  while (g < L.n_goals) {  // :1130-1141: g advances after a pop too, so the goal that slid into slot g waits a pass
-    const int src = list_get(L.list, g);
-    if (goal_met(a, goals, L, src, t_env)) {
-      award(a, goals, b, L, src, diag);
-      L.list = list_pop(L.list, g);
-      L.n_goals -= 1;
-      L.list_dirty = true;
-      done += 1;
-    }
-    g += 1;
-  }
-  return done;
-}
-
-// RewardCache.update (:913-927) as an out-of-place compaction; returns the python sum() of the
-// surviving states (left to right from 0).  `cache.remove` while iterating makes the iterator skip
-// the reward after an expired one: it is carried over untouched.  The first RW_PRE entries were
-// fetched with the lane's first batch of loads (`pre`): walking the cache costs no further global
-// round trips unless more than RW_PRE rewards are active.
-constexpr int RW_PRE = 4;
-struct RewardRows {
-  double state[RW_PRE], expire[RW_PRE], src[RW_PRE];
-};
-
-__device__ __forceinline__ void load_rewards(const TaskArgs& a, int64_t b, RewardRows& pre) {
-#pragma unroll
-  for (int i = 0; i < RW_PRE; ++i) {
-    pre.state[i] = ts_at(a, RIAB_TS_RW_STATE + i, b);
-    pre.expire[i] = ts_at(a, RIAB_TS_RW_EXPIRE + i, b);
-    pre.src[i] = ts_at(a, RIAB_TS_RW_SRC + i, b);
-  }
-}
-
-__device__ double rewards_update(const TaskArgs& a, lds_f64_ptr goals, int64_t b, Lane& L, const RewardRows& pre) {
-  double total = 0.0;
-  int w = 0;
-  bool skip = false;  // the previous reward expired: this one is carried over untouched
-  const int nr = L.n_rw;
-  auto visit = [&](int i, double state, double expire, double srcd) {
-    if (skip) {
-      ts_at(a, RIAB_TS_RW_STATE + w, b) = state;
-      ts_at(a, RIAB_TS_RW_EXPIRE + w, b) = expire;
-      ts_at(a, RIAB_TS_RW_SRC + w, b) = srcd;
-      total = total + state;
-      w += 1;
-      skip = false;
-      return;
-    }
-    const RewardTpl r = reward_of(a, goals, (int)srcd);
-    const double rdt = r.dt;
-    state = state + reward_delta(r.preset, r.knob, state) * rdt;  // Reward.update (:817-821)
-    expire -= rdt;
-    if (expire <= 0.0) {
-      skip = true;
-    } else {
-      ts_at(a, RIAB_TS_RW_STATE + w, b) = state;
-      ts_at(a, RIAB_TS_RW_EXPIRE + w, b) = expire;
-      if (w != i) ts_at(a, RIAB_TS_RW_SRC + w, b) = srcd;
-      total = total + state;
-      w += 1;
-    }
-  };
-#pragma unroll
-  for (int i = 0; i < RW_PRE; ++i)
-    if (i < nr) visit(i, pre.state[i], pre.expire[i], pre.src[i]);
-  for (int i = RW_PRE; i < nr; ++i)
-    visit(i, ts_at(a, RIAB_TS_RW_STATE + i, b), ts_at(a, RIAB_TS_RW_EXPIRE + i, b), ts_at(a, RIAB_TS_RW_SRC + i, b));
-  L.n_rw = w;
-  return total;
-}
-
-// TaskEnvironment.reset for one lane (:307-351, GoalCache.reset :1218-1252): episode bookkeeping in
-// memory, goal list / position in the lane's registers.
-__device__ void reset_lane(const TaskArgs& a, const ResetArgs& r, int64_t b, Lane& L, double t_env, int32_t* diag) {
-  atomicAdd(diag + RIAB_TD_RESETS, 1);
-  const uint64_t id = (uint64_t)(r.agent_id0 + b);
-  // ---- write_end_episode (:536-539) + the episode counter (:333-338)
-  bool zero_duration = false;
-  bool any_ended = ts_at(a, RIAB_TS_EP_ANY_ENDED, b) != 0.0;
-  if (ts_at(a, RIAB_TS_STARTED, b) != 0.0) {
-    const double start = ts_at(a, RIAB_TS_EP_START, b);
-    const double duration = t_env - start;
-    zero_duration = duration == 0.0;
-    if (!zero_duration) {  // a zero-duration episode is popped again right away (:333-335)
-      any_ended = true;
-      ts_at(a, RIAB_TS_EP_ANY_ENDED, b) = 1.0;
-      if (r.ep_log) {
-        const int slot = atomicAdd(r.ep_count, 1);
-        if (slot < r.ep_log_cap) {
-          double* e = r.ep_log + (int64_t)slot * 5;
-          e[0] = (double)id;
-          e[1] = ts_at(a, RIAB_TS_EPISODE, b);
-          e[2] = start;
-          e[3] = t_env;
-          e[4] = duration;
-        } else {
-          atomicAdd(diag + RIAB_TD_EPLOG_OVERFLOW, 1);
-        }
-      }
-    }
-  }
-  if (!zero_duration) ts_at(a, RIAB_TS_EPISODE, b) += 1.0;
-  ts_at(a, RIAB_TS_STARTED, b) = 1.0;
-  // _current_episode_start (:526-527): the end of the last kept episode, 0 before any
-  ts_at(a, RIAB_TS_EP_START, b) = any_ended ? t_env : 0.0;
-  // ---- teleport_on_reset (:323-330)
-  if (r.teleport) {
-    double x, y;
-    if (r.new_x) {
-      x = r.new_x[b];
-      y = r.new_y[b];
-    } else {  // sample_positions(1), "uniform_jitter": the centre of the box +- 0.45 * scale (Philox block 0)
-      const u32x4 rnd = philox4x32_10((uint32_t)r.counter, (uint32_t)(r.counter >> 32), (uint32_t)id, RIAB_TAG_TASK,
-                                      (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
-      const double ux = ((double)rnd.x + 0.5) * 0x1.0p-32, uy = ((double)rnd.y + 0.5) * 0x1.0p-32;
-      x = r.cx + (2.0 * ux - 1.0) * r.half;
-      y = r.cy + (2.0 * uy - 1.0) * r.half;
-    }
-    L.px = x;
-    L.py = y;
-    r.pos_x[b] = x;
-    r.pos_y[b] = y;
-    if (r.hist_x) {  // agent.history["pos"][-1] = agent.pos
-      r.hist_x[b] = (float)x;
-      r.hist_y[b] = (float)y;
-    }
-  }
-  // ---- GoalCache.reset (:1218-1252)
-  const int n = r.n_select < a.n_pool ? r.n_select : a.n_pool;
-  u128 list = 0;
-  if (r.ordered) {
-    for (int i = 0; i < n; ++i) list = list_set(list, i, i);
-  } else {
-    // uniform sample without replacement: draw i picks the j-th goal still in the pool (ascending
-    // order), j = floor(w_i * (n_pool - i) / 2^32), w_i = word i%4 of Philox block 1 + i/4
-    uint64_t remaining = a.n_pool >= 64 ? ~0ull : ((1ull << a.n_pool) - 1ull);
-    u32x4 words = {0, 0, 0, 0};
-    for (int i = 0; i < n; ++i) {
-      if ((i & 3) == 0)
-        words = philox4x32_10((uint32_t)r.counter, (uint32_t)(r.counter >> 32), (uint32_t)id,
-                              RIAB_TAG_TASK + 1u + (uint32_t)(i >> 2), (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
-      const int q = i & 3;
-      const uint32_t w = q == 0 ? words.x : (q == 1 ? words.y : (q == 2 ? words.z : words.w));
-      int j = (int)(((uint64_t)w * (uint64_t)(a.n_pool - i)) >> 32);
-      uint64_t m = remaining;
-      while (j > 0) {  // drop the j lowest remaining goals
-        m &= m - 1;
-        j -= 1;
-      }
-      const int pick = __ffsll((long long)m) - 1;
-      remaining &= ~(1ull << pick);
-      list = list_set(list, i, pick);
-    }
-  }
-  L.list = list;
-  L.n_goals = n;
-  L.list_dirty = true;
-  L.delayed = false;
-}
-
-// get_goal_vector (:1555-1584): goal - position for the head of the list (sequential) or the nearest
-// pending spatial goal; (0,0) when none is pending.  scale > 0: scale * unit vector instead (the
-// scripted policy of the reference's test loop, :1599-1605, with its NaN -> 0 of :403-404).
-__device__ void goal_vector(const TaskArgs& a, lds_f64_ptr goals, const Lane& L, double scale, double* vx_out, double* vy_out) {
-  double vx = 0.0, vy = 0.0, best = INFINITY;
-  for (int g = 0; g < L.n_goals; ++g) {
-    const int src = list_get(L.list, g);
-    if (src < 0) {
-      if (a.goalorder == RIAB_GOALORDER_SEQUENTIAL) break;
-      continue;
-    }
-    const lds_f64_ptr gl = goals + src * RIAB_GOAL_COLS;
-    const double dx = gl[0] - L.px, dy = gl[1] - L.py;
-    const double d = sqrt(dx * dx + dy * dy);
-    if (d < best) {  // strict: the first of equidistant goals, like argmin
-      best = d;
-      vx = dx;
-      vy = dy;
-    }
-    if (a.goalorder == RIAB_GOALORDER_SEQUENTIAL) break;
-  }
-  if (scale > 0.0) {
-    const double nrm = sqrt(vx * vx + vy * vy);
-    vx = nrm > 0.0 ? scale * (vx / nrm) : 0.0;
-    vy = nrm > 0.0 ? scale * (vy / nrm) : 0.0;
-  }
-  *vx_out = vx;
-  *vy_out = vy;
-}
-
-// MODE bit 0: TaskEnvironment.step; bit 1: reset the lanes selected by `mask` (terminal lanes when
-// fused with the step); bit 2: write the goal vector of the (possibly reset) lane.
-template <int MODE>
-__global__ __launch_bounds__(64) void task_kernel(TaskArgs a, ResetArgs r, const double* pos_x, const double* pos_y,
-                                                  double t_env, double* reward_out, uint8_t* terminal_out,
-                                                  const uint8_t* mask, double gv_scale, double* gv_x, double* gv_y,
-                                                  int32_t* diag) {
-  constexpr bool STEP = MODE & 1, RESET = MODE & 2, GOALVEC = MODE & 4;
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  // the goal pool (<= 4 KB) goes to LDS with the first batch of loads: goal rows and reward templates
-  // are then ~100 ns away instead of one more global round trip per check pass / cached reward
-  __shared__ double s_goals[RIAB_TASK_MAX_POOL * RIAB_GOAL_COLS];
-  for (int i = threadIdx.x; i < a.n_pool * RIAB_GOAL_COLS; i += 64) s_goals[i] = a.goals[i];
-  const bool live = b < a.B && !(RESET && !STEP && mask && !mask[b]);
-  // ---- one batch of independent loads
-  Lane L;
-  if (!live) {
-    __syncthreads();
-    return;
-  }
-  L.n_goals = (int)ts_at(a, RIAB_TS_N_GOALS, b);
-  L.n_rw = (int)ts_at(a, RIAB_TS_N_REWARDS, b);
-  L.delayed = ts_at(a, RIAB_TS_DELAYED, b) != 0.0;
-  L.pad_start = ts_at(a, RIAB_TS_PAD_START, b);
-  L.px = pos_x[b];
-  L.py = pos_y[b];
-  L.new_total = 0.0;
-  load_list(a, b, L);
-  RewardRows pre;
-  if (STEP) load_rewards(a, b, pre);
-  __syncthreads();
-  const lds_f64_ptr goals = (lds_f64_ptr)s_goals;
-  const int n_goals0 = L.n_goals, n_rw0 = L.n_rw;
-  const bool delayed0 = L.delayed;
-  bool terminal_last = false;
-  if (STEP) {
-    const double rmax = ts_at(a, RIAB_TS_R_MAX, b), rmin = ts_at(a, RIAB_TS_R_MIN, b);
-    const double steps_active = ts_at(a, RIAB_TS_STEPS_ACTIVE, b), steps_inactive = ts_at(a, RIAB_TS_STEPS_INACTIVE, b);
-    // ---- RewardCache.update (:913-927)
-    double total = 0.0;
-    if (n_rw0 > 0) total = rewards_update(a, goals, b, L, pre);
-    if (n_rw0 > 0) ts_at(a, RIAB_TS_STEPS_ACTIVE, b) = steps_active + 1.0;
-    else ts_at(a, RIAB_TS_STEPS_INACTIVE, b) = steps_inactive + 1.0;
-    // ---- goals: _is_terminal_state (:278-290) as step() calls it (:418-440)
-    check_pass(a, goals, b, L, t_env, diag);
-    bool terminal = L.n_goals == 0;
-    if (terminal && a.terminate_delay != 0.0 && !L.delayed) {
-      // :421-434: one unrewarded TimeElapsedGoal pads the episode
-      L.delayed = true;
-      L.pad_start = t_env;
-      L.list = list_set(L.list, 0, RIAB_GOAL_TIME_ELAPSED);
-      L.n_goals = 1;
-      L.list_dirty = true;
-      check_pass(a, goals, b, L, t_env, diag);
-      terminal = L.n_goals == 0;
-    }
-    const int late = check_pass(a, goals, b, L, t_env, diag);  // the pass of the `for agent, term in ...` loop (:438)
-    terminal_last = L.n_goals == 0;
-    if (late > 0 && terminal_last && !terminal) atomicAdd(diag + RIAB_TD_LATE_COMPLETIONS, 1);
-    // ---- RewardCache.get_total (:929-939): survivors, then this step's awards, then the default level
-    total = total + L.new_total;
-    total = total + a.default_level;
-    if (total > rmax) ts_at(a, RIAB_TS_R_MAX, b) = total;
-    if (total < rmin) ts_at(a, RIAB_TS_R_MIN, b) = total;
-    reward_out[b] = total;
-    terminal_out[b] = terminal_last ? 1 : 0;
-  }
-  if (RESET && (STEP ? terminal_last : true)) reset_lane(a, r, b, L, t_env, diag);
-  if (GOALVEC) goal_vector(a, goals, L, gv_scale, gv_x + b, gv_y + b);
-  // ---- write back what changed
-  if (STEP || RESET) {
-    if (L.n_goals != n_goals0) ts_at(a, RIAB_TS_N_GOALS, b) = (double)L.n_goals;
-    if (L.n_rw != n_rw0) ts_at(a, RIAB_TS_N_REWARDS, b) = (double)L.n_rw;
-    if (L.delayed != delayed0) {
-      ts_at(a, RIAB_TS_DELAYED, b) = L.delayed ? 1.0 : 0.0;
-      if (L.delayed) ts_at(a, RIAB_TS_PAD_START, b) = L.pad_start;
-    }
-    if (L.list_dirty) store_list(a, b, L);
-  }
-}
-
-static int fill_args(TaskArgs& a, const RiabEnv* env, const RiabTask* task, double* task_state, int64_t B) {
-  if (!env || !task || !task_state || B <= 0) return RIAB_EINVAL;
-  if (task->n_pool < 0 || task->n_pool > RIAB_TASK_MAX_POOL) return RIAB_ETOOBIG;
-  if (task->n_pool > 0 && !task->goals) return RIAB_EINVAL;
-  if (env->n_walls > 0 && !env->walls) return RIAB_EINVAL;
-  if (env->periodic && task->n_pool > 0) return RIAB_EUNSUPPORTED;  // line_of_sight needs solid boundaries
-  if (task->goalorder != RIAB_GOALORDER_NONSEQUENTIAL && task->goalorder != RIAB_GOALORDER_SEQUENTIAL)
-    return RIAB_EUNSUPPORTED;
-  a.walls = env->walls;
-  a.n_walls = env->n_walls;
-  a.goals = task->goals;
-  a.n_pool = task->n_pool;
-  a.goalorder = task->goalorder;
-  a.terminate_delay = task->terminate_delay;
-  for (int i = 0; i < 5; ++i) a.pad_reward[i] = task->pad_reward[i];
-  a.default_level = task->default_reward_level;
-  a.ts = task_state;
-  a.B = B;
-  return RIAB_OK;
-}
-
-static int fill_reset(ResetArgs& r, const RiabEnv* env, int64_t agent_id0, int32_t n_select, int32_t ordered, uint64_t seed,
-                      uint64_t counter, int32_t teleport, const double* new_x, const double* new_y, double* pos_x,
-                      double* pos_y, float* hist_x, float* hist_y, double* ep_log, int64_t ep_log_cap, int32_t* ep_count) {
-  if (n_select < 0) return RIAB_EINVAL;
-  if (n_select > RIAB_TASK_MAX_GOALS - 1) return RIAB_ETOOBIG;  // one slot stays free for the termination-delay goal
-  if (teleport && (!pos_x || !pos_y)) return RIAB_EINVAL;
-  if ((new_x == nullptr) != (new_y == nullptr) || (hist_x == nullptr) != (hist_y == nullptr)) return RIAB_EINVAL;
-  if (ep_log && (!ep_count || ep_log_cap <= 0)) return RIAB_EINVAL;
-  const double w = env->extent[1] - env->extent[0], h = env->extent[3] - env->extent[2];
-  if (teleport && !new_x && w != h) return RIAB_EUNSUPPORTED;  // sample_positions(1) only works for a square box
-  r.agent_id0 = agent_id0;
-  r.n_select = n_select;
-  r.ordered = ordered;
-  r.teleport = teleport;
-  r.seed = seed;
-  r.counter = counter;
-  r.new_x = new_x;
-  r.new_y = new_y;
-  r.pos_x = pos_x;
-  r.pos_y = pos_y;
-  r.hist_x = hist_x;
-  r.hist_y = hist_y;
-  r.cx = 0.5 * (env->extent[0] + env->extent[1]);
-  r.cy = 0.5 * (env->extent[2] + env->extent[3]);
-  r.half = 0.45 * sqrt(w * h);
-  r.ep_log = ep_log;
-  r.ep_log_cap = ep_log_cap;
-  r.ep_count = ep_count;
-  return RIAB_OK;
-}
 
 // The step plan's fused launch: TaskEnvironment.step, reset of the lanes that became terminal (when
 // auto_reset) and the scripted action of the next step (when gv_x is given) in one kernel.
