@@ -49,14 +49,19 @@ def build(force=False, verbose=False):
                 return LIB_PATH
             hipcc = _hipcc()
             work = tempfile.mkdtemp(prefix="build_", dir=LIB_DIR)
-            objs = []
-            for src in SOURCES:
+            from concurrent.futures import ThreadPoolExecutor
+
+            def compile_one(src):
                 obj = os.path.join(work, src.replace(".hip", ".o"))
                 cmd = [hipcc, *FLAGS, "-I", INCLUDE, "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
                 if verbose:
                     print(" ".join(cmd), flush=True)
                 subprocess.run(cmd, check=True)
-                objs.append(obj)
+                return obj
+
+            # the translation units are independent: compile them side by side
+            with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+                objs = list(pool.map(compile_one, SOURCES))
             tmp_lib = os.path.join(work, "libriab_hip.so")
             cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib, *objs]
             if verbose:
