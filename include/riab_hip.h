@@ -275,6 +275,19 @@ int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* io, const d
                                const float* inv_norm, int32_t n, int32_t egocentric,
                                float* ray_out, riab_stream_t stream);
 
+/* riab_boundary_vector_cells with direction windows for allocentric cells (K % 4 == 0): the caller hands
+ * the tables (table, vm_table, inv_norm) in an order of its choosing — cell_rows[i] = the cell (output
+ * row) table row i belongs to — and, per group g of four consecutive table rows, windows[2g] = first test
+ * direction and windows[2g+1] = number of directions (both multiples of 4; the window wraps modulo K) to
+ * accumulate; directions outside the window are skipped.  The caller chooses the windows so that every
+ * skipped von Mises weight is negligible (ratinabox_amd: below 2^-24 of the peak).  cell_rows / windows:
+ * device int32 [n] / [ceil(n/4)][2]; both NULL = riab_boundary_vector_cells. */
+int riab_boundary_vector_cells_windowed(const RiabEnv* env, const RiabRateIO* io, const double* test_dirs,
+                                        const double* ray_rden, int32_t K, const float* table,
+                                        const float* vm_table, const float* inv_norm, int32_t n,
+                                        int32_t egocentric, float* ray_out, const int32_t* cell_rows,
+                                        const int32_t* windows, riab_stream_t stream);
+
 /* ObjectVectorCells.get_state (Neurons.py:1991-2116; FieldOfViewOVCs Neurons.py:2119-2150 is
  * the same on a radial manifold) with Environment.get_distances_between___accounting_for_
  * environment(..., return_vectors=True) (Environment.py:677-730).
@@ -360,6 +373,8 @@ typedef struct RiabPopulation {
   int32_t egocentric;        /* bvc / ovc */
   const float* vm_table;     /* bvc */
   const float* inv_norm;     /* bvc */
+  const int32_t* cell_rows;  /* bvc direction windows (riab_boundary_vector_cells_windowed) or NULL */
+  const int32_t* windows;    /* bvc */
   const float* objects;      /* ovc */
   const int32_t* object_types; /* ovc */
   int32_t n_objects;         /* ovc */

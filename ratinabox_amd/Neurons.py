@@ -689,22 +689,57 @@ class BoundaryVectorCells(VectorCells):
             else:
                 vm = np.full((n, Kp), -np.inf)
                 vm[:, :K] = LOG2E * kappa[:, None] * (np.cos(diff) - 1)
+            # Direction windows (allocentric, K a multiple of 4): a cell's von Mises weight is below 2^-24 of its
+            # peak outside an arc that shrinks with its angular spread (60 degrees either side at sigma = 10
+            # degrees, the whole circle from 23 degrees up).  The kernel accumulates four table rows at a time,
+            # so rows are regrouped by (arc length, tuning angle) and every group of four gets the smallest
+            # arc, in whole quads of directions, that holds all its cells' arcs; the rest is skipped.
+            rows_t = win_t = None
+            inv = 1 / norm
+            if use_windows and not ego and K % 4 == 0:
+                keep = vm[:, :K] >= -24.0
+                if not keep.all():
+                    band = np.minimum(keep.sum(axis=1) // 24, 7)
+                    order = np.lexsort((np.mod(mu_t, 2 * np.pi), band))
+                    cells, vm, inv = cells[:, order], vm[order], inv[order]
+                    keep = keep[order]
+                    win = np.zeros(((n + 3) // 4, 2), dtype=np.int32)
+                    for g in range(len(win)):
+                        u = keep[np.minimum(np.arange(4 * g, 4 * g + 4), n - 1)].any(axis=0)
+                        gap_len, gap_start, run = 0, 0, 0
+                        for k in range(2 * K):  # longest circular run of skippable directions
+                            run = run + 1 if not u[k % K] else 0
+                            if min(run, K) > gap_len:
+                                gap_len, gap_start = min(run, K), (k - min(run, K) + 1) % K
+                        first = (gap_start + gap_len) % K
+                        k0 = first // 4 * 4
+                        length = min(K, (first - k0 + (K - gap_len) + 3) // 4 * 4)
+                        win[g] = (0, K) if length >= K else (k0, length)
+                    rows_t = torch.from_numpy(order.astype(np.int32)).to(self._device)
+                    win_t = torch.from_numpy(win).to(self._device)
             f32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self._device)  # noqa: E731
             # position-independent denominators of the ray/wall intercepts (utils.py:96): sa . sb_p
             s_w = walls[:, 1, :] - walls[:, 0, :]
             with np.errstate(divide="ignore"):
                 rden = 1.0 / (dirs[:, None, 0] * (-s_w[None, :, 1]) + dirs[:, None, 1] * s_w[None, :, 0])
             f64 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(self._device)  # noqa: E731
-            return (f64(dirs), f64(rden), f32(cells), f32(vm), f32(1 / norm))
+            return (f64(dirs), f64(rden), f32(cells), f32(vm), f32(inv), rows_t, win_t)
 
+        import os
+        use_windows = os.environ.get("RIAB_NO_BVC_WINDOWS") is None  # (A/B switch: every direction for every cell)
         walls = np.asarray(self.Agent.Environment.walls, dtype=np.float64).reshape(-1, 2, 2)
-        dirs_t, rden_t, cells_t, vm_t, inv_t = self._tables((mu_d, sg_d, mu_t, sg_t, ang, dirs, norm, ego, walls), build)
+        dirs_t, rden_t, cells_t, vm_t, inv_t, rows_t, win_t = self._tables(
+            (mu_d, sg_d, mu_t, sg_t, ang, dirs, norm, ego, walls, use_windows), build)
         if io is None:
-            return dict(kind=_L.POP_KINDS["bvc"], table=cells_t, test_dirs=dirs_t, ray_rden=rden_t, K=K, vm_table=vm_t,
-                        inv_norm=inv_t, egocentric=1 if ego else 0)
+            d = dict(kind=_L.POP_KINDS["bvc"], table=cells_t, test_dirs=dirs_t, ray_rden=rden_t, K=K, vm_table=vm_t,
+                     inv_norm=inv_t, egocentric=1 if ego else 0)
+            if rows_t is not None:
+                d.update(cell_rows=rows_t, windows=win_t)
+            return d
         env, _w = self.Agent.Environment.device_tables(self._device)
-        rc = _L.lib.riab_boundary_vector_cells(env, io, _L.ptr(dirs_t), _L.ptr(rden_t), K, _L.ptr(cells_t), _L.ptr(vm_t),
-                                               _L.ptr(inv_t), n, 1 if ego else 0, None, stream)
+        rc = _L.lib.riab_boundary_vector_cells_windowed(env, io, _L.ptr(dirs_t), _L.ptr(rden_t), K, _L.ptr(cells_t),
+                                                        _L.ptr(vm_t), _L.ptr(inv_t), n, 1 if ego else 0, None,
+                                                        _L.ptr(rows_t), _L.ptr(win_t), stream)
         _L.check(rc, "riab_boundary_vector_cells")
 
 

@@ -42,6 +42,12 @@ struct BvcArgs {
   const float* vm;          // [n][K] or [2][n][K]
   const float* inv_norm;    // [n]
   float* ray_out;           // [T][K][B] or null
+  // direction windows (allocentric, K % 4 == 0): the table rows are given in an order that groups cells with
+  // overlapping angular support; rows[i] = output row (cell index) of table row i, win[g] = (first direction,
+  // number of directions) — both multiples of 4, wrapping modulo K — outside which all four cells of group g
+  // have a von Mises weight below the caller's threshold.  NULL: identity order, every direction.
+  const int* rows;
+  const int* win;
 };
 
 typedef const __attribute__((address_space(4))) double* const_f64_ptr;
@@ -148,15 +154,25 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
     typedef const __attribute__((address_space(4))) v4f* const_v4f_ptr;
     float d[4];
     v4f vc[4], vs[4];
+    // the group's direction window [k, k + wlen) modulo Kw (the whole circle without a window table)
+    typedef const __attribute__((address_space(4))) int* const_i32_ptr;
+    int k = 0, wlen = Kp;
+    const int Kw = Kp;
+    if (!EGO && a.win) {
+      const const_i32_ptr win = (const_i32_ptr)(const void*)a.win;
+      k = win[2 * g];
+      wlen = win[2 * g + 1];
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) d[i] = s_d[i * 64 + lane];
+    for (int i = 0; i < 4; ++i) d[i] = s_d[(k + i) * 64 + lane];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      vc[j] = *(const_v4f_ptr)(tc[j]);
-      if (EGO) vs[j] = *(const_v4f_ptr)(ts[j]);
+      vc[j] = *(const_v4f_ptr)(tc[j] + k);
+      if (EGO) vs[j] = *(const_v4f_ptr)(ts[j] + k);
     }
-    for (int k = 0; k < Kp; k += 4) {
-      const int kn = (k + 4 < Kp) ? k + 4 : k;
+    for (int kk = 0; kk < wlen; kk += 4) {
+      // next four directions of the window, wrapping round the circle (or, on the last pass, these again)
+      const int kn = (kk + 4 < wlen) ? ((k + 4 < Kw) ? k + 4 : k + 4 - Kw) : k;
       float dn[4];
       v4f vcn[4], vsn[4];
 #pragma unroll
@@ -193,12 +209,14 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
         vc[j] = vcn[j];
         if (EGO) vs[j] = vsn[j];
       }
+      k = kn;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = 4 * g + j;
-      if (c < n && live) {
-        float r = (acc2[j].x + acc2[j].y) * a.inv_norm[c];
+      const int ci = 4 * g + j;  // table row
+      if (ci < n && live) {
+        const int c = a.rows ? a.rows[ci] : ci;  // the cell it belongs to
+        float r = (acc2[j].x + acc2[j].y) * a.inv_norm[ci];
         r = r * a.fr_scale + a.fr_min;
         const int64_t off = (t * n + c) * a.B + b;
         a.rates[off] = r;
@@ -227,6 +245,17 @@ using namespace riab;
 extern "C" int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* io, const double* test_dirs,
                                           const double* ray_rden, int32_t K, const float* cells, const float* vm_table, const float* inv_norm,
                                           int32_t n, int32_t egocentric, float* ray_out, riab_stream_t stream) {
+  return riab_boundary_vector_cells_windowed(env, io, test_dirs, ray_rden, K, cells, vm_table, inv_norm, n, egocentric,
+                                             ray_out, nullptr, nullptr, stream);
+}
+
+extern "C" int riab_boundary_vector_cells_windowed(const RiabEnv* env, const RiabRateIO* io, const double* test_dirs,
+                                                   const double* ray_rden, int32_t K, const float* cells,
+                                                   const float* vm_table, const float* inv_norm, int32_t n,
+                                                   int32_t egocentric, float* ray_out, const int32_t* cell_rows,
+                                                   const int32_t* windows, riab_stream_t stream) {
+  if ((cell_rows == nullptr) != (windows == nullptr)) return RIAB_EINVAL;
+  if (windows && (egocentric || K % 4 != 0)) return RIAB_EUNSUPPORTED;
   if (!env || !io || !test_dirs || !ray_rden || !cells || !vm_table || !inv_norm || n <= 0 || K <= 0) return RIAB_EINVAL;
   if (io->T <= 0 || io->B <= 0 || !io->rates || !io->pos_x || !io->pos_y) return RIAB_EINVAL;
   if (egocentric && (!io->hd_x || !io->hd_y)) return RIAB_EINVAL;
@@ -263,6 +292,8 @@ extern "C" int riab_boundary_vector_cells(const RiabEnv* env, const RiabRateIO* 
   a.vm = vm_table;
   a.inv_norm = inv_norm;
   a.ray_out = ray_out;
+  a.rows = cell_rows;
+  a.win = windows;
   const size_t lds = sizeof(float) * (size_t)((K + 3) / 4 * 4) * 64;
   if (lds > 160 * 1024) return RIAB_ETOOBIG;
   const dim3 grid((unsigned)((a.P + 63) / 64));

@@ -225,8 +225,8 @@ static int launch_population(RiabPlan* p, size_t i, const float* row, hipStream_
       rc = riab_random_spatial_neurons(&p->env, &io, q.table, q.n_anchors, q.targets, q.n, q.geometry, s);
       break;
     case RIAB_POP_BVC:
-      rc = riab_boundary_vector_cells(&p->env, &io, q.test_dirs, q.ray_rden, q.K, q.table, q.vm_table, q.inv_norm, q.n,
-                                      q.egocentric, nullptr, s);
+      rc = riab_boundary_vector_cells_windowed(&p->env, &io, q.test_dirs, q.ray_rden, q.K, q.table, q.vm_table,
+                                               q.inv_norm, q.n, q.egocentric, nullptr, q.cell_rows, q.windows, s);
       break;
     case RIAB_POP_OVC:
       rc = riab_object_vector_cells(&p->env, &io, q.objects, q.object_types, q.n_objects, q.table, q.n, q.walls_occlude,

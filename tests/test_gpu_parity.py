@@ -1202,3 +1202,38 @@ def test_noise_producer_wave_is_bit_identical(riab, B, monkeypatch):
         s0, h0, d0 = run(T, True)
         assert torch.equal(s1, s0) and torch.equal(h1, h0) and d1 == d0, T
     monkeypatch.delenv("RIAB_NO_PC", raising=False)
+
+
+def test_bvc_direction_windows(riab, monkeypatch):
+    """Allocentric BVCs skip, per group of four regrouped cells, the test directions where every cell's von
+    Mises weight is below 2^-24 of its peak: same rates as the full sum (RIAB_NO_BVC_WINDOWS=1) and as the
+    oracle, cells back in their own rows, and a real saving for the default spread of tunings."""
+    walls = [[[.2, 0], [.2, .4]], [[.4, 1], [.4, .6]], [[.6, 0], [.6, .4]], [[.3, .5], [.7, .5]]]
+    rs = np.random.RandomState(12)
+    pos = rs.uniform(0, 1, (500, 2)).astype(np.float32).astype(np.float64)
+
+    def rates(n, no_windows):
+        if no_windows:
+            monkeypatch.setenv("RIAB_NO_BVC_WINDOWS", "1")
+        else:
+            monkeypatch.delenv("RIAB_NO_BVC_WINDOWS", raising=False)
+        np.random.seed(8)
+        env = make_env(riab, walls)
+        BVs = riab.BoundaryVectorCells(riab.Agent(env), {"n": n})
+        out = BVs.get_state(evaluate_at=None, pos=pos)
+        tabs = BVs._table_cache["t"][1]
+        return env, BVs, out, tabs
+
+    for n in (256, 37, 3):
+        env, BVs, got, tabs = rates(n, False)
+        _, _, full, tabs0 = rates(n, True)
+        assert tabs0[5] is None and tabs0[6] is None
+        ref = orc.bvc(pos, env.walls, BVs.tuning_distances, BVs.tuning_angles, BVs.sigma_distances, BVs.sigma_angles)
+        assert_rates(got, ref, floor=1.0)
+        assert np.abs(got - full).max() < 2e-6
+        if n == 256:
+            rows, win = tabs[5].cpu().numpy(), tabs[6].cpu().numpy()
+            assert sorted(rows.tolist()) == list(range(n))
+            assert (win % 4 == 0).all() and (win[:, 1] <= 180).all() and (win[:, 1] > 0).all()
+            assert win[:, 1].mean() < 0.9 * 180  # at least a tenth of the terms is skipped
+    monkeypatch.delenv("RIAB_NO_BVC_WINDOWS", raising=False)
