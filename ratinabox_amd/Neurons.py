@@ -460,7 +460,9 @@ class PlaceCells(Neurons):
     def _call(self, io, stream):
         n = int(self.n)
         centres = np.asarray(self.place_cell_centres, dtype=np.float64).reshape(-1, 2)
-        widths = np.asarray(self.place_cell_widths, dtype=np.float64) * np.ones(n)
+        widths = np.asarray(self.place_cell_widths, dtype=np.float64)
+        if widths.shape != (n,):
+            widths = widths * np.ones(n)
 
         def build():
             tab = np.empty((n, 3), dtype=np.float64)
