@@ -12,12 +12,11 @@ attribute shapes are the reference's (`pos (2,)`, ...); otherwise they carry a
 leading agent axis (`pos (B,2)`, `history["pos"] (T,B,2)`).
 
 All per-step arithmetic runs in the HIP kernel `riab_agent_step`
-(csrc/riab_agent.hip); this class owns the state tensor `[12, B]` (float64, HBM),
+(csrc/riab_agent_kernel.h); this class owns the state tensor `[12, B]` (float64, HBM),
 the trajectory history chunks `[T, 8, B]` (float32, HBM) and resolves parameters.
 `simulate(T)` is the fused path: T steps per launch on one stream while the
 firing-rate kernels of the previous chunk run on another."""
 import copy
-import warnings
 
 import numpy as np
 import torch

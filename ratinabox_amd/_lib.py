@@ -57,7 +57,8 @@ class RiabPopulation(C.Structure):
                 ("spikes_base", C.c_void_p), ("capacity_rows", C.c_int64), ("table", C.c_void_p),
                 ("description", C.c_int32), ("geometry", C.c_int32), ("top_hat_width", C.c_float), ("f0", C.c_float),
                 ("test_dirs", C.c_void_p), ("ray_rden", C.c_void_p), ("K", C.c_int32), ("egocentric", C.c_int32),
-                ("vm_table", C.c_void_p), ("inv_norm", C.c_void_p), ("cell_rows", C.c_void_p), ("windows", C.c_void_p), ("objects", C.c_void_p),
+                ("vm_table", C.c_void_p), ("inv_norm", C.c_void_p), ("cell_rows", C.c_void_p), ("windows", C.c_void_p),
+                ("objects", C.c_void_p),
                 ("object_types", C.c_void_p), ("n_objects", C.c_int32), ("walls_occlude", C.c_int32),
                 ("one_sigma_speed", C.c_float), ("targets", C.c_void_p), ("n_anchors", C.c_int32),
                 ("noise_state", C.c_void_p), ("noise_theta_dt", C.c_float), ("noise_sigma_dt", C.c_float),
@@ -113,9 +114,9 @@ PROTOTYPES = {
     "riab_boundary_vector_cells": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                              C.c_void_p]),
-    "riab_boundary_vector_cells_windowed": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_void_p, C.c_int32,
-                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
-                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    "riab_boundary_vector_cells_windowed": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_void_p,
+                                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_object_vector_cells": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "riab_spikes": (C.c_int, [C.POINTER(RiabRateIO), C.c_int32, C.c_void_p]),
