@@ -1237,3 +1237,45 @@ def test_bvc_direction_windows(riab, monkeypatch):
             assert (win % 4 == 0).all() and (win[:, 1] <= 180).all() and (win[:, 1] > 0).all()
             assert win[:, 1].mean() < 0.9 * 180  # at least a tenth of the terms is skipped
     monkeypatch.delenv("RIAB_NO_BVC_WINDOWS", raising=False)
+
+
+def test_config3_and_config4_at_full_width(riab):
+    """BASELINE configs 3 and 4 at their full per-GPU sizes (4096 agents; 1024 GridCells + 256 BVCs in the
+    9-wall maze; 4096 PlaceCells): a spread sample of agents against the oracle, size-independent
+    properties on everything (finite, within the rate range, agents inside the box)."""
+    maze = [[[.2, 0], [.2, .4]], [[.4, 1], [.4, .6]], [[.6, 0], [.6, .4]], [[.8, 1], [.8, .6]], [[.3, .5], [.7, .5]]]
+    B, T = 4096, 5
+    sel = np.arange(0, B, 131)
+    # ---- config 3
+    np.random.seed(6)
+    env = make_env(riab, maze)
+    Ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "seed": 21})
+    GCs = riab.GridCells(Ag, {"n": 1024})
+    BVs = riab.BoundaryVectorCells(Ag, {"n": 256})
+    traj = Ag.simulate(T, chunk=4)
+    torch.cuda.synchronize()
+    pos_all = traj[:, 0:2].cpu().numpy()
+    assert (pos_all > 0).all() and (pos_all < 1).all()
+    pos = pos_all[T - 1][:, sel].T.astype(np.float64)
+    for N, ref in ((GCs, orc.grid_cells(pos, GCs.gridscales, GCs.phase_offsets, GCs.w)),
+                   (BVs, orc.bvc(pos, env.walls, BVs.tuning_distances, BVs.tuning_angles, BVs.sigma_distances,
+                                 BVs.sigma_angles))):
+        fr, _ = N.get_history_tensors()
+        assert fr.shape == (T, N.n, B) and torch.isfinite(fr).all()
+        # (a BVC facing a long nearby wall sums to slightly more than its nominal maximum, as in the reference)
+        assert float(fr.min()) >= 0 and float(fr.max()) <= (1 + 1e-6 if N is GCs else 1.2)
+        assert_rates(fr[T - 1][:, sel].cpu().numpy(), ref, floor=1.0)
+    del traj, GCs, BVs, Ag
+    # ---- config 4 (one shard)
+    np.random.seed(7)
+    env = make_env(riab)
+    Ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "seed": 22})
+    PCs = riab.PlaceCells(Ag, {"n": 4096})
+    traj = Ag.simulate(T, chunk=4)
+    torch.cuda.synchronize()
+    fr, sp = PCs.get_history_tensors()
+    assert fr.shape == (T, 4096, B) and torch.isfinite(fr).all() and float(fr.min()) >= 0 and float(fr.max()) <= 1
+    pos = traj[T - 1, 0:2].cpu().numpy()[:, sel].T.astype(np.float64)
+    assert_rates(fr[T - 1][:, sel].cpu().numpy(), orc.place_cells(orc.EnvSpec(), pos, PCs.place_cell_centres, 0.2))
+    expected = float((0.01 * fr.double()).sum())
+    assert abs(float(sp.sum()) - expected) < 5 * np.sqrt(expected) + 1
