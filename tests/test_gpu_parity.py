@@ -1279,3 +1279,32 @@ def test_config3_and_config4_at_full_width(riab):
     assert_rates(fr[T - 1][:, sel].cpu().numpy(), orc.place_cells(orc.EnvSpec(), pos, PCs.place_cell_centres, 0.2))
     expected = float((0.01 * fr.double()).sum())
     assert abs(float(sp.sum()) - expected) < 5 * np.sqrt(expected) + 1
+
+
+def test_two_wave_motion_kernel_without_history_rows(riab, monkeypatch):
+    """riab_agent_step with hist = NULL on the two-wave kernel (the host layer always passes a row buffer):
+    the state equals the single-wave kernel's and the run with history rows."""
+    L = riab._lib
+
+    def run(hist, no_pc):
+        if no_pc:
+            monkeypatch.setenv("RIAB_NO_PC", "1")
+        else:
+            monkeypatch.delenv("RIAB_NO_PC", raising=False)
+        np.random.seed(3)
+        env = make_env(riab, [[[.5, .2], [.5, .8]]])
+        Ag = riab.Agent(env, {"n_agents": 128, "dt": 0.05, "speed_mean": 0.3, "seed": 8})
+        e, _w = env.device_tables(Ag._device)
+        m = Ag._motion(Ag.dt, False, 1, {})
+        h = torch.zeros((70, 8, 128), dtype=torch.float32, device="cuda") if hist else None
+        rc = L.lib.riab_agent_step(e, m, L.ptr(Ag._state), 128, 0, None, None, None, None, 8, 0, 70, L.ptr(h),
+                                   L.ptr(Ag._diag), 64, L.current_stream())
+        L.check(rc, "riab_agent_step")
+        torch.cuda.synchronize()
+        return Ag._state.clone(), Ag._diag.clone()
+
+    s_ref, d_ref = run(True, True)
+    for hist, no_pc in ((False, False), (True, False), (False, True)):
+        s, d = run(hist, no_pc)
+        assert torch.equal(s, s_ref) and torch.equal(d, d_ref), (hist, no_pc)
+    monkeypatch.delenv("RIAB_NO_PC", raising=False)
