@@ -231,8 +231,8 @@ int riab_grid_cells(const RiabRateIO* io, const float* table, int32_t n, int32_t
                     float f0, riab_stream_t stream);
 
 /* HeadDirectionCells.get_state, 2D (Neurons.py:2421-2485): von Mises of
- * utils.get_angle(head_direction).  table device float32 [n][2] = (preferred
- * angle, log2(e)/sigma^2) per cell.  Needs io->hd_x / hd_y. */
+ * utils.get_angle(head_direction).  table device float32 [n][3] = (cosine and sine of the
+ * preferred angle, log2(e)/sigma^2) per cell.  Needs io->hd_x / hd_y. */
 int riab_head_direction_cells(const RiabRateIO* io, const float* table, int32_t n,
                               riab_stream_t stream);
 

@@ -1015,7 +1015,7 @@ class HeadDirectionCells(Neurons):
 
         def build():
             f32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self._device)  # noqa: E731
-            return f32(np.stack((pref, LOG2E / sig ** 2), axis=-1))
+            return f32(np.stack((np.cos(pref), np.sin(pref), LOG2E / sig ** 2), axis=-1))
 
         tab = self._tables((pref, sig), build)
         if io is None:

@@ -397,12 +397,12 @@ struct GridCell {
 template <int MODE>
 struct HDCell {
   struct Pos {
-    v4f ang;
-    v4f speed;  // |v| / one_sigma_speed (MODE >= 1)
+    v4f cs, sn;  // cosine / sine of utils.get_angle(direction) = atan2(y, x + 1e-6)
+    v4f speed;   // |v| / one_sigma_speed (MODE >= 1)
   };
   static constexpr int LDS_DOUBLES = 1;
   __device__ __forceinline__ void stage(double*) {}
-  const float* tab;  // [n][2] = (preferred angle, kappa * log2(e))
+  const float* tab;  // [n][3] = (cos, sin of the preferred angle, kappa * log2(e))
   float speed_inv;   // 1 / one_sigma_speed
   const double* vx64;  // MODE 1 at the agent: rows RIAB_S_VEL_X / _Y of the float64 state (T = 1), or NULL
   const double* vy64;
@@ -429,22 +429,25 @@ struct HDCell {
     } else {
       P.speed = v4f{1.0f, 1.0f, 1.0f, 1.0f};
     }
-    // utils.get_angle: atan2(y, x + 1e-6); the mod 2pi is irrelevant under the cosine
-    P.ang.x = atan2f(hy.x, hx.x + 1e-6f);
-    P.ang.y = atan2f(hy.y, hx.y + 1e-6f);
-    P.ang.z = atan2f(hy.z, hx.z + 1e-6f);
-    P.ang.w = atan2f(hy.w, hx.w + 1e-6f);
+    // No trigonometry: the tuning only needs cos(angle - preferred) = cos a cos p + sin a sin p, and
+    // (cos a, sin a) of a = atan2(y, x + 1e-6) is the vector (x + 1e-6, y) normalised.  (An fp32 atan2 +
+    // cos pair costs 2e-5 of relative accuracy in the tails of narrow tunings; this form stays at the
+    // rounding of the cosine itself.)
+    const v4f bx = hx + 1e-6f;
+    const v4f inv = {1.0f / sqrtf(fmaf(hy.x, hy.x, bx.x * bx.x)), 1.0f / sqrtf(fmaf(hy.y, hy.y, bx.y * bx.y)),
+                     1.0f / sqrtf(fmaf(hy.z, hy.z, bx.z * bx.z)), 1.0f / sqrtf(fmaf(hy.w, hy.w, bx.w * bx.w))};
+    P.cs = bx * inv;
+    P.sn = hy * inv;
     return P;
   }
-  __device__ __forceinline__ float one(float ang, float pr, float k2) const {
-    return __builtin_amdgcn_exp2f(k2 * (cosf(ang - pr) - 1.0f));
-  }
-  static constexpr int NP = 2;
-  static constexpr int CPB = 32;  // amortise the per-position atan2 over many cells
+  static constexpr int NP = 3;
+  static constexpr int CPB = 16;
   __device__ __forceinline__ v4f eval(const float* p, const Pos& P) const {
     if (MODE == 2) return P.speed;
-    const float pr = p[0], k2 = p[1];
-    return v4f{one(P.ang.x, pr, k2), one(P.ang.y, pr, k2), one(P.ang.z, pr, k2), one(P.ang.w, pr, k2)};
+    const float cp = p[0], sp = p[1], k2 = p[2];
+    const v4f e = (P.cs * cp + P.sn * sp - 1.0f) * k2;
+    return v4f{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y), __builtin_amdgcn_exp2f(e.z),
+               __builtin_amdgcn_exp2f(e.w)};
   }
 };
 
@@ -724,7 +727,7 @@ extern "C" int riab_speed_cell(const RiabRateIO* io, float one_sigma_speed, riab
   if (!(one_sigma_speed > 0.0f)) return RIAB_EINVAL;
   const int rc = check_io(io, 1, false, true);
   if (rc) return rc;
-  // the single cell has no parameters; the table pointer only has to be readable (two floats)
+  // the single cell has no parameters; the table pointer only has to be readable (three floats)
   HDCell<2> c{io->hd_x, 1.0f / one_sigma_speed, nullptr, nullptr};
   return launch_rate(io, 1, c, (hipStream_t)stream);
 }

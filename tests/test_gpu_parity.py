@@ -1308,3 +1308,70 @@ def test_two_wave_motion_kernel_without_history_rows(riab, monkeypatch):
         s, d = run(hist, no_pc)
         assert torch.equal(s, s_ref) and torch.equal(d, d_ref), (hist, no_pc)
     monkeypatch.delenv("RIAB_NO_PC", raising=False)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RIAB_TEST_WORLDS", "10"))))
+def test_randomised_worlds_vs_oracle(riab, seed):
+    """Random boxes (scale, aspect, 0-6 interior walls, objects) and random population parameters: every rate
+    kernel against the oracle on the same positions.  (The goldens and the fixed stress cases cover what the
+    reference's defaults reach; this sweeps combinations nobody wrote down.)"""
+    rs = np.random.RandomState(1000 + seed)
+    np.random.seed(2000 + seed)
+    scale, aspect = rs.uniform(0.6, 2.5), rs.uniform(0.6, 1.8)
+    W, H = aspect * scale, scale
+    n_walls = int(rs.randint(0, 7))
+    a = np.stack((rs.uniform(0.1 * W, 0.9 * W, n_walls), rs.uniform(0.1 * H, 0.9 * H, n_walls)), -1)
+    th = rs.uniform(0, np.pi, n_walls)
+    half = rs.uniform(0.05, 0.3, n_walls)[:, None] * scale * np.stack((np.cos(th), np.sin(th)), -1)
+    walls = np.clip(np.stack((a - half, a + half), 1), [0.02 * W, 0.02 * H], [0.98 * W, 0.98 * H]).tolist() if n_walls else []
+    env = make_env(riab, walls, scale=scale, aspect=aspect)
+    oenv = orc.EnvSpec(scale=scale, aspect=aspect, walls=walls)
+    P = int(rs.choice([5, 64, 257, 1100]))
+    pos = np.stack((rs.uniform(0, W, P), rs.uniform(0, H, P)), -1).astype(np.float32).astype(np.float64)
+    hd = rs.normal(size=(P, 2))
+    hd = (hd / np.linalg.norm(hd, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    Ag = riab.Agent(env)
+    # PlaceCells
+    desc = str(rs.choice(["gaussian", "gaussian_threshold", "diff_of_gaussians", "top_hat", "one_hot"]))
+    geom = str(rs.choice(["euclidean", "line_of_sight"] + (["geodesic"] if n_walls <= 1 else [])))
+    n = int(rs.choice([1, 6, 37, 130]))
+    centres = np.stack((rs.uniform(0, W, n), rs.uniform(0, H, n)), -1)
+    widths = float(rs.uniform(0.08, 0.4) * scale)
+    PCs = riab.PlaceCells(Ag, {"place_cell_centres": centres, "widths": widths, "description": desc,
+                               "wall_geometry": geom, "min_fr": 0.1, "max_fr": 2.5})
+    got = PCs.get_state(evaluate_at=None, pos=pos)
+    ref = orc.place_cells(oenv, pos, centres, widths, description=desc, wall_geometry=geom, min_fr=0.1, max_fr=2.5,
+                          widths_scalar=widths)
+    if desc in ("one_hot", "top_hat"):
+        assert (~np.isclose(got, ref, rtol=1e-6)).mean() < 2e-3, (desc, geom)
+    else:
+        assert_rates(got, ref, scale=2.4, floor=0.0 if desc == "gaussian" else 1.0)
+    # GridCells
+    gdesc = str(rs.choice(["rectified_cosines", "shifted_cosines"]))
+    GCs = riab.GridCells(Ag, {"n": int(rs.choice([1, 13, 70])), "description": gdesc, "max_fr": 3.0})
+    ref = orc.grid_cells(pos, GCs.gridscales, GCs.phase_offsets, GCs.w, description=gdesc, max_fr=3.0)
+    assert_rates(GCs.get_state(evaluate_at=None, pos=pos), ref, scale=3.0, floor=1.0)
+    # BoundaryVectorCells: both frames, several angular resolutions
+    dtheta = int(rs.choice([2, 3, 4, 5, 6, 7]))
+    ego = bool(rs.randint(0, 2))
+    BVs = riab.BoundaryVectorCells(Ag, {"n": int(rs.choice([3, 16, 45])), "dtheta": dtheta,
+                                        "reference_frame": "egocentric" if ego else "allocentric"})
+    kw = dict(head_direction=hd) if ego else {}
+    ref = orc.bvc(pos, env.walls, BVs.tuning_distances, BVs.tuning_angles, BVs.sigma_distances, BVs.sigma_angles,
+                  dtheta=dtheta, **kw)
+    assert_rates(BVs.get_state(evaluate_at=None, pos=pos, **kw), ref, floor=1.0)
+    # HeadDirectionCells
+    HDs = riab.HeadDirectionCells(Ag, {"n": int(rs.choice([1, 9, 40])), "angular_spread_degrees": float(rs.uniform(10, 90))})
+    ref = orc.head_direction_cells(hd, HDs.n, HDs.params["angular_spread_degrees"])
+    assert_rates(HDs.get_state(evaluate_at=None, pos=pos, head_direction=hd), ref)
+    # ObjectVectorCells
+    n_obj = int(rs.randint(1, 6))
+    for _ in range(n_obj):
+        env.add_object([rs.uniform(0.05 * W, 0.95 * W), rs.uniform(0.05 * H, 0.95 * H)],
+                       type=min(int(rs.randint(0, 3)), env.n_object_types))
+    OVs = riab.ObjectVectorCells(Ag, {"n": int(rs.choice([2, 11])), "walls_occlude": bool(rs.randint(0, 2)),
+                                      "reference_frame": "egocentric" if ego else "allocentric"})
+    ref = orc.object_vector_cells(oenv, pos, env.objects["objects"], env.objects["object_types"], OVs.tuning_distances,
+                                  OVs.tuning_angles, OVs.sigma_distances, OVs.sigma_angles, OVs.tuning_types,
+                                  walls_occlude=OVs.walls_occlude, **kw)
+    assert_rates(OVs.get_state(evaluate_at=None, pos=pos, **kw), ref, floor=1.0)
