@@ -1375,3 +1375,61 @@ def test_randomised_worlds_vs_oracle(riab, seed):
                                   OVs.tuning_angles, OVs.sigma_distances, OVs.sigma_angles, OVs.tuning_types,
                                   walls_occlude=OVs.walls_occlude, **kw)
     assert_rates(OVs.get_state(evaluate_at=None, pos=pos, **kw), ref, floor=1.0)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RIAB_TEST_WORLDS", "8"))))
+def test_randomised_motion_vs_oracle(riab, seed):
+    """Random boxes and random motion parameters (speeds, coherence times, thigmotaxis, wall repulsion, dt, a
+    constant drift with a random strength ratio), production noise captured and replayed through the oracle:
+    the trajectory of 64 agents over 80 steps to 1e-9, the long (T = 80) launch on the two-wave kernel."""
+    rs = np.random.RandomState(3000 + seed)
+    periodic = rs.rand() < 0.25
+    scale = rs.uniform(0.7, 2.0)
+    aspect = 1.0 if periodic else rs.uniform(0.7, 1.6)
+    W, H = aspect * scale, scale
+    n_walls = int(rs.randint(0, 6))
+    a = np.stack((rs.uniform(0.15 * W, 0.85 * W, n_walls), rs.uniform(0.15 * H, 0.85 * H, n_walls)), -1)
+    th = rs.uniform(0, np.pi, n_walls)
+    half = rs.uniform(0.05, 0.25, n_walls)[:, None] * scale * np.stack((np.cos(th), np.sin(th)), -1)
+    walls = np.clip(np.stack((a - half, a + half), 1), [0.03 * W, 0.03 * H], [0.97 * W, 0.97 * H]).tolist() if n_walls else []
+    env_kw = dict(scale=scale, aspect=aspect, boundary_conditions="periodic" if periodic else "solid")
+    # (dt = 0.1 with a stiff wall spring — strength 2-2.5 over 4 cm — is an unstable regime of the model itself:
+    # speeds run away to 10 x speed_mean and rounding differences of 1e-16 reach 1e-7 within 50 steps)
+    dt = float(rs.choice([0.005, 0.01, 0.02, 0.05]))
+    params = {"dt": dt, "speed_mean": float(rs.uniform(0.03, 0.4) * scale),
+              "speed_std": float(rs.choice([0.0, rs.uniform(0.01, 0.2)])),
+              "speed_coherence_time": float(rs.uniform(max(0.2, 2 * dt), 2.0)),
+              "rotational_velocity_coherence_time": float(rs.uniform(max(0.05, 2 * dt), 0.5)),
+              "rotational_velocity_std": float(rs.uniform(0.5, 4.0)),
+              "thigmotaxis": float(rs.choice([0.0, 0.5, 1.0, rs.uniform(0, 1)])),
+              "wall_repel_distance": float(rs.uniform(0.04, 0.2) * scale),
+              "wall_repel_strength": float(rs.choice([0.0, 1.0, rs.uniform(0.2, 2.0)])),
+              "head_direction_smoothing_timescale": float(rs.choice([0.0, 0.15, rs.uniform(0.01, 1.0)]))}
+    drift = None if rs.rand() < 0.5 else rs.uniform(-0.2, 0.2, 2) * scale
+    ratio = float(rs.uniform(0.2, 5.0))
+    B, T = 64, 80
+    env = make_env(riab, walls, **env_kw)
+    np.random.seed(seed)
+    Ag = riab.Agent(env, dict(params, n_agents=B, seed=100 + seed))
+    st0 = {k: np.array(getattr(Ag, k)) for k in gu.PRE_SLICES}
+    zout = torch.zeros((T, 2, B), dtype=torch.float64, device="cuda")
+    Ag._advance(T, None, drift, ratio, {}, z_out=zout)
+    torch.cuda.synchronize()
+    z = zout.cpu().numpy()
+    st = dict(st0, measured_rotational_velocity=np.zeros(B), distance_to_closest_wall=np.full(B, np.inf))
+    oenv = orc.EnvSpec(walls=walls, **env_kw)
+    prm = {k: v for k, v in params.items() if k != "dt"}
+    for t in range(T):
+        st = orc.agent_step(oenv, st, dt, z[t, 0], z[t, 1], params=prm,
+                            drift_velocity=None if drift is None else np.broadcast_to(drift, (B, 2)),
+                            drift_to_random_strength_ratio=ratio)
+    np.testing.assert_allclose(Ag.pos, st["pos"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(Ag.velocity, st["velocity"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(Ag.head_direction, st["head_direction"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(Ag.distance_travelled, st["distance_travelled"], rtol=1e-9)
+    # the same launch without recording the normals runs on the two-wave kernel: identical state
+    np.random.seed(seed)
+    Ag2 = riab.Agent(env, dict(params, n_agents=B, seed=100 + seed))
+    Ag2._advance(T, None, drift, ratio, {})
+    torch.cuda.synchronize()
+    assert torch.equal(Ag2.state_tensor, Ag.state_tensor)
