@@ -335,3 +335,66 @@ def test_task_plan_with_manual_resets(riab):
     assert np.array_equal(A1.pos, A2.pos) and torch.equal(e1.task_state, e2.task_state)
     assert np.array_equal(A1.history["pos"], A2.history["pos"]) and e1.episodes == e2.episodes
     assert np.array_equal(P1.history["firingrate"], P2.history["firingrate"])
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RIAB_TEST_WORLDS", "6"))))
+def test_randomised_tasks_vs_oracle(riab, seed):
+    """Random tasks (walls, goal pool size / positions / radii, goals per episode, goal order, termination delay,
+    reward presets and time constants) in a closed loop with auto-reset, probe lanes replayed through the
+    oracle's TaskLane from the observations: reward totals and terminal flags bit for bit."""
+    from ratinabox_amd.contribs.TaskEnvironment import (SpatialGoalEnvironment, SpatialGoal, Reward, get_goal_vector)
+    rs = np.random.RandomState(4000 + seed)
+    np.random.seed(5000 + seed)
+    n_walls = int(rs.randint(0, 3))
+    walls = [[[float(x), float(rs.uniform(0.05, 0.3))], [float(x), float(rs.uniform(0.6, 0.9))]]
+             for x in rs.uniform(0.3, 0.7, n_walls)]
+    n_pool = int(rs.randint(2, 9))
+    n_sel = int(rs.randint(1, min(4, n_pool) + 1))
+    order = str(rs.choice(["nonsequential", "sequential"]))
+    delay = float(rs.choice([0.0, 0.03, 0.1]))
+    dt = float(rs.choice([0.01, 0.02]))
+    B, T = 256, 250
+    env = SpatialGoalEnvironment(params={"walls": walls}, possible_goal_positions=[[0.5, 0.5]],
+                                 goalcachekws=dict(reset_n_goals=n_sel, goalorder=order),
+                                 episode_terminate_delay=delay, teleport_on_reset=bool(rs.randint(0, 2)), seed=int(seed),
+                                 dt=dt)
+    pool = []
+    for _ in range(n_pool):
+        preset = str(rs.choice(["linear", "constant", "exponential", "none"]))
+        rw = Reward(float(rs.uniform(0.5, 3.0)), dt, expire_clock=float(rs.uniform(0.05, 0.6)), decay=preset,
+                    decay_knobs=[float(rs.uniform(0.3, 2.0))])
+        pool.append(SpatialGoal(env, pos=rs.uniform(0.08, 0.92, 2), goal_radius=float(rs.uniform(0.04, 0.15)), reward=rw))
+    env.goal_cache.reset_goals = pool
+    Ag = riab.Agent(env, {"dt": dt, "n_agents": B, "seed": 50 + seed})
+    env.add_agents(Ag)
+    probe = [0, 7, 100, 255]
+    table = np.array([[g.pos[0], g.pos[1], g.radius] + g.reward.row() for g in env.goal_cache.get_goals()])
+    oenv = orc.EnvSpec(walls=walls)
+    lanes = {}
+    for b in probe:
+        lanes[b] = orc.TaskLane(oenv, table, order, delay)
+        lanes[b].reset(0.0, env.goal_cache.goal_lists()[b, :n_sel])
+    t, finished = 0.0, 0
+    for k in range(T):
+        v = get_goal_vector(Ag)
+        a = 9.0 * Ag.speed_mean * v / torch.linalg.norm(v, dim=1, keepdim=True)
+        obs, rew, term, trunc, info = env.step(a)
+        t = t + dt
+        o, r, tm = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+        if env.diagnostics["reward_overflow"]:
+            # more than RIAB_TASK_MAX_REWARDS (16) rewards alive in one lane: the device cache drops the surplus
+            # (counted; the reference's list is unbounded) — nothing left to compare in this world
+            return
+        for b in probe:
+            total, terminal = lanes[b].step(o[b], t)
+            # (the exponential preset goes through the device exp: last-ulp differences)
+            assert abs(total - r[b]) <= 4e-15 * max(1.0, abs(total)) and terminal == tm[b], \
+                (k, b, total, r[b], env.diagnostics)
+        if term.any():
+            finished += int(term.sum())
+            env.reset(mask=term)
+            sel = env.goal_cache.goal_lists()
+            for b in probe:
+                if tm[b]:
+                    lanes[b].reset(t, sel[b, :n_sel])
+    assert env.diagnostics["episode_log_overflow"] == 0
