@@ -1433,3 +1433,39 @@ def test_randomised_motion_vs_oracle(riab, seed):
     Ag2._advance(T, None, drift, ratio, {})
     torch.cuda.synchronize()
     assert torch.equal(Ag2.state_tensor, Ag.state_tensor)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RIAB_TEST_WORLDS", "8"))))
+def test_randomised_feedforward_shapes_vs_oracle(riab, seed):
+    """FeedForwardLayer on random shapes: 1-3 input populations of ragged widths, ragged output widths on
+    either side of the tile sizes (32 / 64 / 128), ragged position counts, linear and relu activations with
+    random gain / threshold, against the oracle's float64 product."""
+    rs = np.random.RandomState(6000 + seed)
+    np.random.seed(seed)
+    Ag = riab.Agent(make_env(riab))
+    n_inputs = int(rs.randint(1, 4))
+    layers = []
+    for i in range(n_inputs):
+        kind = rs.randint(0, 2)
+        n_in = int(rs.choice([1, 3, 15, 16, 17, 31, 64, 100, 257]))
+        layers.append(riab.PlaceCells(Ag, {"n": n_in, "name": f"in{i}"}) if kind == 0 else
+                      riab.GridCells(Ag, {"n": n_in, "name": f"in{i}"}))
+    n_out = int(rs.choice([1, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 300]))
+    act = str(rs.choice(["linear", "relu"]))
+    spec = {"activation": act, "gain": float(rs.uniform(0.5, 2.0)), "threshold": float(rs.uniform(-0.5, 0.5))}
+    bias = rs.normal(0, 0.3, n_out)
+    F = riab.FeedForwardLayer(Ag, {"n": n_out, "input_layers": layers, "activation_function": spec, "biases": bias.copy()})
+    ws = []
+    for L_ in layers:
+        w = rs.normal(0, 1 / np.sqrt(L_.n), (n_out, L_.n))
+        F.inputs[L_.name]["w"] = w.copy()
+        ws.append(w.astype(np.float32).astype(np.float64))
+    P = int(rs.choice([1, 7, 127, 128, 129, 500, 1025]))
+    pos = rs.uniform(0, 1, (P, 2)).astype(np.float32).astype(np.float64)
+    ins = [L_.get_state(evaluate_at=None, pos=pos) for L_ in layers]          # the kernels' own fp32 rates
+    got = F.get_state(evaluate_at=None, pos=pos)
+    ref, _ = orc.feedforward(ins, ws, bias.astype(np.float32).astype(np.float64), spec)
+    cond = sum(np.abs(w).sum(1) for w in ws) + np.abs(bias)
+    tol = 2e-6 * cond[:, None] * spec["gain"] + 1e-6 * np.abs(ref)
+    assert got.shape == ref.shape == (n_out, P)
+    assert (np.abs(got - ref) <= tol).all(), (n_inputs, [L_.n for L_ in layers], n_out, P, act, np.abs(got - ref).max())
