@@ -1469,3 +1469,46 @@ def test_randomised_feedforward_shapes_vs_oracle(riab, seed):
     tol = 2e-6 * cond[:, None] * spec["gain"] + 1e-6 * np.abs(ref)
     assert got.shape == ref.shape == (n_out, P)
     assert (np.abs(got - ref) <= tol).all(), (n_inputs, [L_.n for L_ in layers], n_out, P, act, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RIAB_TEST_WORLDS", "6"))))
+def test_randomised_spike_shapes_bit_exact(riab, seed):
+    """Poisson spikes of every population kind (each family of kernels has its own spike epilogue) on ragged
+    batch / cell counts, shard offsets and step counts, per-step and fused: bit-exact against the
+    exactly-specified rule on the kernel's own rates and host-regenerated Philox uniforms."""
+    rs = np.random.RandomState(7000 + seed)
+    np.random.seed(seed)
+    B = int(rs.choice([1, 4, 7, 68, 300, 1024, 1100]))
+    id0 = int(rs.choice([0, 4, 4096, 1 << 20]))
+    T = int(rs.randint(1, 5))
+    dt = float(rs.choice([0.01, 0.05]))
+    rng_seed = int(rs.randint(1, 1 << 30))
+    env = make_env(riab, [[[.5, .1], [.5, .6]]])
+    env.add_object([0.3, 0.3], type=0)
+    env.add_object([0.7, 0.6], type=0)
+    Ag = riab.Agent(env, {"n_agents": B, "dt": dt, "seed": rng_seed, "agent_id0": id0})
+    mk = lambda n: int(rs.choice([1, 3, 17, n]))  # noqa: E731
+    pops = [riab.PlaceCells(Ag, {"n": mk(70), "max_fr": 30.0}), riab.GridCells(Ag, {"n": mk(40), "max_fr": 30.0}),
+            riab.HeadDirectionCells(Ag, {"n": mk(33), "max_fr": 30.0}),
+            riab.BoundaryVectorCells(Ag, {"n": mk(21), "max_fr": 30.0}),
+            riab.ObjectVectorCells(Ag, {"n": mk(9), "max_fr": 30.0})]
+    fused = bool(rs.randint(0, 2))
+    if fused:
+        Ag.simulate(T, chunk=int(rs.choice([1, 2, 4])))
+    else:
+        for _ in range(T):
+            Ag.update()
+            for N in pops:
+                N.update()
+    torch.cuda.synchronize()
+    total = 0
+    for N in pops:
+        fr, sp = N.get_history_tensors()
+        assert fr.shape[0] == T
+        for t in range(T):
+            u = orc.spike_uniforms(rng_seed, t + 1, N.pop_id, int(N.n), (B + 3) // 4 * 4, agent_id0=id0)[:, :B]
+            want = orc.spikes_f32(fr[t][:, :B].cpu().numpy(), u, dt)
+            got = sp[t][:, :B].cpu().numpy().astype(bool)
+            assert np.array_equal(got, want), (type(N).__name__, B, id0, t, fused)
+            total += int(got.sum())
+    assert total > 0 or B * T < 20
