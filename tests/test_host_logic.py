@@ -206,3 +206,31 @@ def test_agent_registry_lookup():
     assert c.name == "agent_2"
     env.remove_agent("rat")
     assert env.Agents == [a, c] and "rat" not in env.agents_dict
+
+
+def test_bvc_direction_windows_cover_every_significant_term():
+    """Host side of the BVC direction windows (Neurons.BoundaryVectorCells._call): the regrouped table rows are
+    a permutation of the cells, every window is whole quads of directions, and no (row, direction) pair with a
+    von Mises weight of 2^-24 of the peak or more falls outside its group's window."""
+    np.random.seed(3)
+    env = riab.Environment()
+    Ag = riab.Agent(env, dict(CPU))
+    for n in (256, 37, 5):
+        BVs = riab.BoundaryVectorCells(Ag, {"n": n})
+        d = BVs._call(None, None)
+        K = d["K"]
+        rows, win, vm = d["cell_rows"].numpy(), d["windows"].numpy(), d["vm_table"].numpy()
+        assert sorted(rows.tolist()) == list(range(n)) and win.shape == ((n + 3) // 4, 2)
+        assert (win % 4 == 0).all() and (win[:, 0] >= 0).all() and (win[:, 0] < K).all()
+        assert (win[:, 1] > 0).all() and (win[:, 1] <= K).all()
+        # the table rows are in regrouped order: row i belongs to cell rows[i]
+        kappa = 1 / np.asarray(BVs.sigma_angles) ** 2
+        diff = np.asarray(BVs.test_angles)[None, :] - np.asarray(BVs.tuning_angles)[:, None]
+        full = (np.log2(np.e) * kappa[:, None] * (np.cos(diff) - 1))[rows]
+        np.testing.assert_allclose(vm[:, :K], full, rtol=1e-5, atol=1e-5)
+        for i in range(n):
+            k0, length = win[i // 4]
+            inside = ((np.arange(K) - k0) % K) < length
+            assert not ((full[i] >= -24.0) & ~inside).any(), (n, i)
+        if n == 256:
+            assert win[:, 1].mean() < 0.9 * K
