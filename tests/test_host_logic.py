@@ -234,3 +234,32 @@ def test_bvc_direction_windows_cover_every_significant_term():
             assert not ((full[i] >= -24.0) & ~inside).any(), (n, i)
         if n == 256:
             assert win[:, 1].mean() < 0.9 * K
+
+
+def test_velocity_speed_and_agent_vector_cell_construction():
+    """Host side of VelocityCells / SpeedCell / AgentVectorCells / FieldOfViewAVCs (reference Neurons.py:2151-2651):
+    defaults, the fixed single speed cell, the speed scale taken at construction, the manifold of the
+    field-of-view cells, and the lane-matching rule of the batched extension."""
+    np.random.seed(0)
+    env = riab.Environment()
+    Ag = riab.Agent(env, dict(CPU, speed_mean=0.1, speed_std=0.04))
+    VCs = riab.VelocityCells(Ag, {"n": 6})
+    assert VCs.n == 6 and np.isclose(VCs.one_sigma_speed, 0.14) and VCs.name == "VelocityCells"
+    np.testing.assert_allclose(VCs.preferred_angles, np.linspace(0, 2 * np.pi, 7)[:-1])
+    with pytest.warns(UserWarning):
+        SC = riab.SpeedCell(Ag, {"n": 4})
+    assert SC.n == 1 and SC.firingrate.shape == (1,) and np.isclose(SC.one_sigma_speed, 0.14)
+    Ag.speed_mean = 0.3  # the scale was fixed when the cells were made
+    assert np.isclose(VCs.one_sigma_speed, 0.14)
+    other = riab.Agent(env, dict(CPU))
+    AV = riab.AgentVectorCells(Ag, other, {"n": 7})
+    assert AV.n == 7 and AV.wall_geometry == "line_of_sight" and AV.tuning_type_agent is other
+    assert riab.AgentVectorCells(Ag, other, {"walls_occlude": False}).wall_geometry == "euclidean"
+    FA = riab.FieldOfViewAVCs(Ag, other, {"spatial_resolution": 0.1})
+    assert FA.reference_frame == "egocentric" and FA.n == len(FA.tuning_distances) > 3
+    many = riab.Agent(env, dict(CPU, n_agents=8))
+    with pytest.raises(ValueError):  # 8 lanes cannot be matched with 3
+        riab.AgentVectorCells(many, riab.Agent(env, dict(CPU, n_agents=3)))
+    assert riab.AgentVectorCells(many, other).n == 10  # a single-agent Other_Agent is seen by every lane
+    d = riab.VelocityCells.get_all_default_params()
+    assert d["name"] == "VelocityCells" and "angular_spread_degrees" in d and "noise_std" in d
