@@ -433,7 +433,7 @@ int riab_plan_step(RiabPlan* plan, int32_t n_steps, riab_stream_t stream);
  * Per-lane task state: device float64 [RIAB_TS_ROWS][B], lane axis fastest (small integers are
  * stored as doubles so that the whole state is one tensor). */
 #define RIAB_TASK_MAX_GOALS 16   /* goals in one episode's list, incl. the termination-delay goal */
-#define RIAB_TASK_MAX_REWARDS 16 /* simultaneously active rewards of one lane */
+#define RIAB_TASK_MAX_REWARDS 32 /* simultaneously active rewards of one lane */
 #define RIAB_TASK_MAX_POOL 64    /* goals in the pool the episodes draw from */
 enum {
   RIAB_TS_N_GOALS = 0,        /* length of the lane's goal list */
@@ -449,10 +449,10 @@ enum {
   RIAB_TS_R_MIN = 10,
   RIAB_TS_STARTED = 11,       /* len(episodes["start"]) > 0 */
   RIAB_TS_GOAL_LIST = 12,     /* [MAX_GOALS] pool index of list entry i; RIAB_GOAL_TIME_ELAPSED = delay goal */
-  RIAB_TS_RW_STATE = 28,      /* [MAX_REWARDS] Reward.state, in cache (append) order */
-  RIAB_TS_RW_EXPIRE = 44,     /* [MAX_REWARDS] Reward.expire_clock */
-  RIAB_TS_RW_SRC = 60,        /* [MAX_REWARDS] pool index of the goal that gave it (decay parameters) */
-  RIAB_TS_ROWS = 76
+  RIAB_TS_RW_STATE = RIAB_TS_GOAL_LIST + RIAB_TASK_MAX_GOALS,     /* [MAX_REWARDS] Reward.state, in cache (append) order */
+  RIAB_TS_RW_EXPIRE = RIAB_TS_RW_STATE + RIAB_TASK_MAX_REWARDS,  /* [MAX_REWARDS] Reward.expire_clock */
+  RIAB_TS_RW_SRC = RIAB_TS_RW_EXPIRE + RIAB_TASK_MAX_REWARDS,    /* [MAX_REWARDS] pool index of the goal that gave it */
+  RIAB_TS_ROWS = RIAB_TS_RW_SRC + RIAB_TASK_MAX_REWARDS          /* = 124 */
 };
 #define RIAB_GOAL_TIME_ELAPSED (-2)
 /* goal pool row (float64 x 8): x, y, radius, then the goal's Reward: init_state, dt, expire_clock,

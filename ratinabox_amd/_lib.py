@@ -75,8 +75,12 @@ class RiabTask(C.Structure):
 # rows of the per-lane task state tensor (include/riab_hip.h RIAB_TS_*)
 TS_N_GOALS, TS_DELAYED, TS_PAD_START, TS_N_REWARDS, TS_EPISODE, TS_EP_START, TS_EP_ANY_ENDED = range(7)
 TS_STEPS_ACTIVE, TS_STEPS_INACTIVE, TS_R_MAX, TS_R_MIN, TS_STARTED = 7, 8, 9, 10, 11
-TS_GOAL_LIST, TS_RW_STATE, TS_RW_EXPIRE, TS_RW_SRC, TS_ROWS = 12, 28, 44, 60, 76
-TASK_MAX_GOALS, TASK_MAX_REWARDS, TASK_MAX_POOL = 16, 16, 64
+TASK_MAX_GOALS, TASK_MAX_REWARDS, TASK_MAX_POOL = 16, 32, 64
+TS_GOAL_LIST = 12
+TS_RW_STATE = TS_GOAL_LIST + TASK_MAX_GOALS
+TS_RW_EXPIRE = TS_RW_STATE + TASK_MAX_REWARDS
+TS_RW_SRC = TS_RW_EXPIRE + TASK_MAX_REWARDS
+TS_ROWS = TS_RW_SRC + TASK_MAX_REWARDS
 GOAL_TIME_ELAPSED = -2
 DECAYS = {"constant": 0, "linear": 1, "exponential": 2, "none": 3}
 GOALORDERS = {"nonsequential": 0, "sequential": 1}

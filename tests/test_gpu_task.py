@@ -382,7 +382,7 @@ def test_randomised_tasks_vs_oracle(riab, seed):
         t = t + dt
         o, r, tm = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
         if env.diagnostics["reward_overflow"]:
-            # more than RIAB_TASK_MAX_REWARDS (16) rewards alive in one lane: the device cache drops the surplus
+            # more than RIAB_TASK_MAX_REWARDS (32) rewards alive in one lane: the device cache drops the surplus
             # (counted; the reference's list is unbounded) — nothing left to compare in this world
             return
         for b in probe:
