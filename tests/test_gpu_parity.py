@@ -1512,3 +1512,63 @@ def test_randomised_spike_shapes_bit_exact(riab, seed):
             assert np.array_equal(got, want), (type(N).__name__, B, id0, t, fused)
             total += int(got.sum())
     assert total > 0 or B * T < 20
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RIAB_TEST_WORLDS", "6"))))
+def test_randomised_plans_equal_eager_and_fused(riab, seed):
+    """Random sets of populations (every plannable kind, some with OU noise, a FeedForwardLayer on top, spikes on
+    or off) and random batch widths: a step plan, the eager per-step loop and — where every population allows
+    it — the fused simulate() leave bit-identical state, rates and spikes."""
+    rs = np.random.RandomState(8000 + seed)
+    B = int(rs.choice([1, 5, 64, 130, 1024]))
+    T = int(rs.randint(3, 9))
+    kinds = list(rs.choice(["place", "grid", "bvc", "hdc", "ovc", "velocity", "speed", "random_spatial"],
+                           size=int(rs.randint(2, 6)), replace=False))
+    noisy = set(int(i) for i in rs.choice(len(kinds), size=int(rs.randint(0, 2)), replace=False))
+    with_ff = bool(rs.randint(0, 2))
+    cap = int(rs.choice([2, 3, 64]))
+    ns = {k: int(rs.choice([1, 6, 19])) for k in kinds}
+
+    def world():
+        np.random.seed(seed)
+        env = make_env(riab, [[[0.5, 0.1], [0.5, 0.55]]])
+        env.add_object([0.25, 0.7])
+        Ag = riab.Agent(env, {"n_agents": B, "dt": 0.02, "seed": 40 + seed})
+        pops = []
+        for i, k in enumerate(kinds):
+            prm = {"n": ns[k], "max_fr": 20.0}
+            if i in noisy:
+                prm.update(noise_std=0.3, noise_coherence_time=0.1)
+            cls = {"place": riab.PlaceCells, "grid": riab.GridCells, "bvc": riab.BoundaryVectorCells,
+                   "hdc": riab.HeadDirectionCells, "ovc": riab.ObjectVectorCells, "velocity": riab.VelocityCells,
+                   "speed": riab.SpeedCell, "random_spatial": riab.RandomSpatialNeurons}[k]
+            if k == "speed":
+                prm.pop("n")
+            if k == "random_spatial":
+                prm.update(lengthscale=0.15, wall_geometry="euclidean")
+            pops.append(cls(Ag, prm))
+        if with_ff:
+            F = riab.FeedForwardLayer(Ag, {"n": 4, "input_layers": pops[:2], "activation_function": {"activation": "relu"}})
+            pops.append(F)
+        return Ag, pops
+
+    A1, P1 = world()
+    for _ in range(T):
+        A1.update()
+        for p in P1:
+            p.update()
+    A2, P2 = world()
+    plan = A2.make_step_plan(capacity=cap)
+    for _ in range(T):
+        plan.step()
+    assert torch.equal(A1.state_tensor, A2.state_tensor)
+    for a, b in zip(P1, P2):
+        assert np.array_equal(a.history["firingrate"], b.history["firingrate"]), (type(a).__name__, kinds, B)
+        assert np.array_equal(a.history["spikes"], b.history["spikes"]), (type(a).__name__, kinds, B)
+    if "velocity" not in kinds:
+        A3, P3 = world()
+        A3.simulate(T, chunk=int(rs.choice([1, 2, 4, 8])))
+        assert torch.equal(A1.state_tensor, A3.state_tensor)
+        for a, b in zip(P1, P3):
+            assert np.array_equal(a.history["firingrate"], b.history["firingrate"]), (type(a).__name__, kinds, B, "fused")
+            assert np.array_equal(a.history["spikes"], b.history["spikes"]), (type(a).__name__, kinds, B, "fused")
