@@ -398,3 +398,56 @@ def test_randomised_tasks_vs_oracle(riab, seed):
                 if tm[b]:
                     lanes[b].reset(t, sel[b, :n_sel])
     assert env.diagnostics["episode_log_overflow"] == 0
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RIAB_TEST_WORLDS", "5"))))
+def test_randomised_task_plans_equal_eager_loop(riab, seed):
+    """Random tasks (as in test_randomised_tasks_vs_oracle) and batch widths: the step plan — motion + task in one
+    launch, auto-reset, scripted action — against the eager `goal vector -> step -> reset(mask) -> update` loop:
+    rewards and terminal flags every step, then state, task state, histories and episode tables, bit for bit."""
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment, SpatialGoal, Reward
+    rs = np.random.RandomState(9000 + seed)
+    n_walls = int(rs.randint(0, 3))
+    walls = [[[float(x), float(rs.uniform(0.05, 0.3))], [float(x), float(rs.uniform(0.6, 0.9))]]
+             for x in rs.uniform(0.3, 0.7, n_walls)]
+    n_pool = int(rs.randint(2, 9))
+    n_sel = int(rs.randint(1, min(4, n_pool) + 1))
+    order = str(rs.choice(["nonsequential", "sequential"]))
+    delay = float(rs.choice([0.0, 0.03, 0.1]))
+    dt = float(rs.choice([0.01, 0.02]))
+    teleport = bool(rs.randint(0, 2))
+    B = int(rs.choice([1, 6, 64, 257, 1024]))
+    T = int(rs.randint(40, 160))
+    goal_prm = [(rs.uniform(0.08, 0.92, 2), float(rs.uniform(0.04, 0.15)), float(rs.uniform(0.5, 3.0)),
+                 float(rs.uniform(0.05, 0.6)), str(rs.choice(["linear", "constant", "exponential", "none"])),
+                 float(rs.uniform(0.3, 2.0))) for _ in range(n_pool)]
+    speed = float(rs.uniform(4, 12)) * 0.08
+    n_cells = int(rs.choice([1, 40]))
+
+    def build():
+        np.random.seed(seed)
+        env = SpatialGoalEnvironment(params={"walls": walls}, possible_goal_positions=[[0.5, 0.5]],
+                                     goalcachekws=dict(reset_n_goals=n_sel, goalorder=order),
+                                     episode_terminate_delay=delay, teleport_on_reset=teleport, seed=int(seed), dt=dt)
+        env.goal_cache.reset_goals = [
+            SpatialGoal(env, pos=p, goal_radius=r, reward=Reward(s0, dt, expire_clock=ex, decay=pre, decay_knobs=[kn]))
+            for p, r, s0, ex, pre, kn in goal_prm]
+        Ag = riab.Agent(env, {"dt": dt, "n_agents": B, "seed": 60 + seed})
+        PCs = riab.PlaceCells(Ag, {"n": n_cells})
+        env.add_agents(Ag)
+        return env, Ag, PCs
+
+    e1, A1, P1 = build()
+    e2, A2, P2 = build()
+    plan = e2.make_step_plan(auto_reset=True, scripted_speed=speed)
+    for k in range(T):
+        obs, rew, term, trunc, info = e1.step(e1._goal_vector(speed))
+        e1.reset(mask=term)
+        P1.update()
+        plan.step(1)
+        assert torch.equal(e2.get_reward(), rew) and torch.equal(e2.terminal, term), (k, B, order)
+    # (lanes B..B_padded-1 only pad the batch to a multiple of 4: no task, never read back)
+    assert torch.equal(A1.state_tensor[:, :B], A2.state_tensor[:, :B]) and torch.equal(e1.task_state, e2.task_state)
+    assert e1.episodes == e2.episodes and e1.t == e2.t and e1.diagnostics == e2.diagnostics
+    assert np.array_equal(A1.history["pos"], A2.history["pos"])
+    assert np.array_equal(P1.history["firingrate"], P2.history["firingrate"])
