@@ -1572,3 +1572,39 @@ def test_randomised_plans_equal_eager_and_fused(riab, seed):
         for a, b in zip(P1, P3):
             assert np.array_equal(a.history["firingrate"], b.history["firingrate"]), (type(a).__name__, kinds, B, "fused")
             assert np.array_equal(a.history["spikes"], b.history["spikes"]), (type(a).__name__, kinds, B, "fused")
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RIAB_TEST_WORLDS", "5"))))
+def test_randomised_environment_queries_vs_oracle(riab, seed):
+    """The Environment API's geometry queries on random boxes / walls / point sets against the oracle."""
+    rs = np.random.RandomState(11000 + seed)
+    periodic = rs.rand() < 0.3
+    scale = rs.uniform(0.6, 2.5)
+    aspect = 1.0 if periodic else rs.uniform(0.6, 1.8)
+    W, H = aspect * scale, scale
+    n_walls = int(rs.randint(0, 8))
+    a = np.stack((rs.uniform(0.1 * W, 0.9 * W, n_walls), rs.uniform(0.1 * H, 0.9 * H, n_walls)), -1)
+    th = rs.uniform(0, np.pi, n_walls)
+    half = rs.uniform(0.05, 0.3, n_walls)[:, None] * scale * np.stack((np.cos(th), np.sin(th)), -1)
+    walls = np.clip(np.stack((a - half, a + half), 1), [0.02 * W, 0.02 * H], [0.98 * W, 0.98 * H]).tolist() if n_walls else []
+    kw = dict(scale=scale, aspect=aspect, boundary_conditions="periodic" if periodic else "solid")
+    env = make_env(riab, walls, **kw)
+    oenv = orc.EnvSpec(walls=walls, **kw)
+    n1, n2 = int(rs.choice([1, 9, 300])), int(rs.choice([1, 17, 1000]))
+    p1 = np.stack((rs.uniform(0, W, n1), rs.uniform(0, H, n1)), -1)
+    p2 = np.stack((rs.uniform(0, W, n2), rs.uniform(0, H, n2)), -1)
+    np.testing.assert_allclose(env.get_vectors_between___accounting_for_environment(p1, p2),
+                               orc.env_vectors_between(oenv, p1, p2), rtol=0, atol=1e-15)
+    geoms = ["euclidean"] if periodic else ["euclidean", "line_of_sight"] + (["geodesic"] if n_walls <= 1 else [])
+    for geom in geoms:
+        np.testing.assert_allclose(env.get_distances_between___accounting_for_environment(p1, p2, wall_geometry=geom),
+                                   orc.env_distances(oenv, p1, p2, geom), rtol=1e-14)
+    pts = np.stack((rs.uniform(-0.3 * W, 1.3 * W, 200), rs.uniform(-0.3 * H, 1.3 * H, 200)), -1)
+    if len(env.walls):
+        np.testing.assert_allclose(env.vectors_from_walls(pts), orc.shortest_vectors_from_walls(pts, env.walls),
+                                   rtol=1e-12, atol=1e-14)
+        steps = np.stack((pts, pts + rs.normal(0, 0.2 * scale, pts.shape)), axis=1)
+        assert np.array_equal(env.check_wall_collisions(steps)[1], orc.segments_collide(steps, env.walls))
+    inside = orc.env_is_inside(oenv, pts)
+    want = np.where(inside[:, None], pts, orc.env_apply_boundary_conditions(oenv, pts))
+    np.testing.assert_allclose(env.apply_boundary_conditions(pts), want, rtol=0, atol=1e-15)
