@@ -2,8 +2,9 @@
 """bench.py — agent-steps/s of the batched hot path on MI355X.
 
     python bench.py --gpus 1 --steps 1000 --warmup 100
+    python bench.py --gpus N ...      # launches the N ranks itself (torch.distributed.run on 127.0.0.1), or is
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W          # launched as N ranks by the driver
 
 Workload (BASELINE.json configs[1], "cfg2"): per GPU 4096 batched agents x 1024 gaussian
 PlaceCells, open 1x1 m box, dt = 10 ms, default motion parameters, in-kernel Philox
@@ -13,19 +14,23 @@ trajectory history row written, 1024 firing rates per agent written to HBM).  Ag
 independent: ranks own disjoint agent ranges (weak scaling, no collective on the step
 path; the only communication is the barrier / max-reduce around the timed region).
 
+Timing: W untimed warm-up steps, then the K-step region — bracketed by barrier +
+torch.cuda.synchronize() on both sides, maximum over ranks — is run `repeats` times, every
+repeat doing the full work into freshly reserved history rows; `value` comes from the MEDIAN
+repeat, the spread is reported (`timed_region_ms`).  A 20-step region is ~80 us: one sample
+of it is mostly host jitter.
+
 Rank 0 prints ONE JSON line: the contract fields plus
-  roofline      the dominant kernel (PlaceCells rate kernel): algorithmic bytes per launch /
+  roofline      the dominant kernel (the PlaceCells rate kernel): algorithmic bytes per launch /
                 its average duration, measured with HIP events on the stream it runs on
-  cpu_baseline  the float64 NumPy oracle of the same path timed on the host (rank 0, N=1)
+  cpu_baseline  the float64 NumPy oracle of the same path timed on the host cores (rank 0, N=1)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -47,6 +52,13 @@ CONFIGS = {
 }
 
 
+def metric_name(cfg):
+    cells = " + ".join(f"{cfg[k]} {name}" for k, name in (("place", "PlaceCells"), ("grid", "GridCells"),
+                                                          ("bvc", "BoundaryVectorCells"), ("hdc", "HeadDirectionCells"))
+                       if cfg[k])
+    return f"agent-steps/sec (whole node) at {cfg['agents']} agents x {cells}"
+
+
 def bytes_per_agent_step(cfg):
     """4*n_cells (+1*n_cells if spiking) + 112 B of state/history."""
     n = cfg["place"] + cfg["grid"] + cfg["bvc"] + cfg["hdc"]
@@ -54,6 +66,7 @@ def bytes_per_agent_step(cfg):
 
 
 def build_world(riab, cfg, rank, precision, seed=1234, task=False):
+    import numpy as np
     np.random.seed(1000 + rank)
     if task:  # the same world inside a goal-directed task (closed loop: contribs/TaskEnvironment.py)
         from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
@@ -80,34 +93,71 @@ def build_world(riab, cfg, rank, precision, seed=1234, task=False):
     return env, ag, pops
 
 
-def cpu_baseline(cfg, budget_s=12.0):
-    """The float64 NumPy oracle (oracle/riab_oracle.py) of the same path, one host core,
-    on a bounded sample of the workload: 256 agents, as many steps as fit the budget."""
-    from oracle import riab_oracle as orc
-    rs = np.random.RandomState(0)
-    B = 256
-    env = orc.EnvSpec(walls=np.asarray(cfg["walls"], dtype=float).reshape(-1, 2, 2))
-    st = orc.init_state(env, B, 0.08, rs)
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, seconds=8.0):
+    """The float64 NumPy oracle (oracle/riab_oracle.py) of the same path on the host cores, SURVEY.md §8(d)(ii):
+    one worker process per core (`oracle/cpu_bench.py`, single-threaded NumPy), each stepping its share of the
+    GPU batch (agents / cores, at least 16) for `seconds` seconds; the rates add up.  The one-core figure on a
+    256-agent batch (round 1's number) is kept beside it."""
+    cores = os.cpu_count() or 1
+    B = cfg["agents"]
+    per = max(16, B // cores)
     n = cfg["place"]
-    side = int(np.sqrt(max(n, 1)))
-    gx = (np.arange(side) + 0.5) / side
-    centres = np.stack(np.meshgrid(gx, gx), -1).reshape(-1, 2)
-    steps = 0
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    base = [sys.executable, "-m", "oracle.cpu_bench", "--cells", str(n), "--walls-json", json.dumps(cfg["walls"])]
+    if cfg["spikes"]:
+        base.append("--spikes")
+
+    def launch(agents, secs, seed):
+        return subprocess.Popen(base + ["--agents", str(agents), "--seconds", str(secs), "--seed", str(seed)],
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT, env=env, text=True)
+
+    def collect(procs):
+        total, longest, ok = 0.0, 0.0, 0
+        for p in procs:
+            out, _ = p.communicate()
+            try:
+                steps, el = out.split()
+                total += float(steps) / float(el)
+                longest = max(longest, float(el))
+                ok += 1
+            except ValueError:
+                pass
+        return total, longest, ok
+
     t0 = time.perf_counter()
-    while True:
-        z = rs.standard_normal((2, B))
-        st = orc.agent_step(env, st, 0.01, z[0], z[1])
-        if n:
-            fr = orc.place_cells(env, st["pos"], centres, 0.2)
-            if cfg["spikes"]:
-                orc.spikes_ref(fr, rs.random_sample(fr.shape), 0.01)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s:
-            break
-    return {"value": B * steps / el, "unit": "agent-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{B} agents x {steps} steps of Agent.update + PlaceCells({n}).update, float64 NumPy oracle, "
-                      f"{el:.1f} s on 1 of {os.cpu_count()} host cores"}
+    one_rate, one_el, _ = collect([launch(256, min(seconds, 4.0), 0)])
+    all_rate, all_el, ok = collect([launch(per, seconds, 1 + i) for i in range(cores)])
+    wall = time.perf_counter() - t0
+    return {"value": all_rate, "unit": "agent-steps/s", "cores": ok, "kind": "port",
+            "cpu_model": cpu_model(),
+            "sample": f"{ok} single-threaded worker processes (one per host core) x {per} agents x ~{all_el:.1f} s of "
+                      f"Agent.update + PlaceCells({n}).update, float64 NumPy oracle; {wall:.1f} s wall in total",
+            "one_core": {"value": one_rate, "agents": 256, "seconds": round(one_el, 2)}}
+
+
+def relaunch_as_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -116,8 +166,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--chunk", type=int, default=128, help="steps per kernel launch in the fused path")
+    ap.add_argument("--chunk", type=int, default=128, help="steps per kernel launch in the chunked two-stream path")
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64), help="motion-kernel arithmetic")
+    ap.add_argument("--repeats", type=int, default=0, help="repeats of the timed K-step region (0 = by K)")
     ap.add_argument("--per-step", action="store_true", help="time the drop-in per-step API instead of simulate()")
     ap.add_argument("--plan", action="store_true", help="time the closed-loop path through a native step plan")
     ap.add_argument("--plan-batch", type=int, default=1, help="steps per riab_plan_step call (1 = closed loop)")
@@ -128,11 +179,18 @@ def main():
     ap.add_argument("--no-history", action="store_true", help="ring buffers instead of a full T-long history")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(relaunch_as_ranks(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run", file=sys.stderr)
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a line for the wrong rank count",
+              file=sys.stderr)
+        sys.exit(2)
+
+    import numpy as np
+    import torch
     share = os.environ.get("RIAB_BENCH_SHARE_GPU") == "1"  # test hook: all ranks on cuda:0, gloo control plane
     if share:
         local = 0
@@ -163,12 +221,15 @@ def main():
             p.save_history = False
     B = cfg["agents"]
     K, W = args.steps, args.warmup
-    # short runs: about four chunks in flight so that the two pipeline stages still overlap (below ~64 steps
-    # a single launch of each stage is faster than several short ones) [MI355X: K=200 853 -> 961 M/s]
+    R = args.repeats or max(3, min(20, 4096 // max(K, 1)))
+    # the chunked two-stream path (several populations): about four chunks in flight for short runs so that the
+    # two pipeline stages still overlap (below ~64 steps a single launch of each stage is faster)
     if K < 4 * args.chunk:
         args.chunk = K if K <= 64 else max(32, (K // 4 + 3) // 4 * 4)
 
     plan = {"p": None}
+    fused_mode = not (args.per_step or args.plan) and ag._fused_eligible(pops)
+    ag._time_rate_kernel = fused_mode
 
     def run(n_steps):
         if args.plan:
@@ -194,26 +255,32 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # ---- warmup (untimed); its history is dropped so the timed run owns fresh HBM
-    run(W)
+    def fresh_history(n):
+        ag.reset_history()
+        for p in pops:
+            p.reset_history()
+        ag.preallocate_history(n)  # output buffers are allocated outside the timed region
+
+    # ---- warmup (untimed); its history is dropped so the timed runs own fresh HBM
+    if W > 0:
+        run(W)
     torch.cuda.synchronize()
-    ag.reset_history()
-    for p in pops:
-        p.reset_history()
+    warm_ms = ag.last_rate_kernel_ms() if (fused_mode and W > 0) else None
 
-    # ---- HIP-event timing of the dominant kernel's launches, on the stream it runs on
+    # ---- HIP-event timing of the dominant kernel's launches, on the stream it runs on.
+    # flag-coupled path: the native call records the events around its rate kernel (Agent.last_rate_kernel_ms).
+    # chunked path: torch events around the first population's launches (every launch when there are few; every
+    # second one otherwise: each record is a packet on a stream that runs back to back, ~3 % of the value).
     spans = []
-
-    # Every event record is a packet on the rate stream, which runs back to back: bracketing all eight
-    # launches costs ~3 % of the whole-path value [MI355X], so every second launch is bracketed.
     seen = {"n": 0}
+    n_launches = (K + args.chunk - 1) // max(args.chunk, 1)
 
     def hook(pop, what, tc):
         if pop is not pops[0]:
             return
         if what == "begin":
             seen["n"] += 1
-        if seen["n"] % 2 == 1:
+        if n_launches > 4 and seen["n"] % 2 == 1:
             return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
@@ -222,36 +289,51 @@ def main():
         else:
             spans[-1][1] = ev
 
-    if not (args.per_step or args.plan):
+    if not (args.per_step or args.plan or fused_mode):
         ag._profile_hook = hook
-    ag.preallocate_history(K)  # output buffers are allocated outside the timed region
-    torch.cuda.synchronize()
 
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(K)
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed, kernel_ms = [], []
+    for _r in range(R):
+        fresh_history(K)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(K)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        elapsed.append(t1 - t0)
+        if fused_mode:
+            kernel_ms.append(ag.last_rate_kernel_ms())
+    el = torch.tensor(elapsed, dtype=torch.float64)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        el = el.to("cpu" if share else "cuda")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)  # per repeat: the slowest rank
+        el = el.cpu()
+    el_sorted = sorted(el.tolist())
+    med = el_sorted[len(el_sorted) // 2] if len(el_sorted) % 2 else 0.5 * (el_sorted[len(el_sorted) // 2 - 1] +
+                                                                           el_sorted[len(el_sorted) // 2])
 
     total_units = world * B * K
-    value = total_units / elapsed
+    value = total_units / med
     bpu = bytes_per_agent_step(cfg)
 
     roofline = None
-    if spans:
+    n0 = int(pops[0].n)
+    # the contract's `achieved` uses SURVEY §8(d)'s per-unit figure (rates written + spikes + the 112 B of state /
+    # history that the trajectory kernel moves while the rate kernel runs), restricted to the dominant population;
+    # the rate kernel ALONE moves 4*n0 (+n0) + 8 B per unit: `achieved_kernel_own_bytes`
+    unit_bytes = 4 * n0 + (n0 if cfg["spikes"] else 0) + 112
+    own_bytes = 4 * n0 + (n0 if cfg["spikes"] else 0) + 8
+    ms, units = [], []
+    if fused_mode:
+        ms = [m for m in kernel_ms if m is not None]
+        units = [B * K] * len(ms)
+    elif spans:
         ms = [a.elapsed_time(b) for a, b, _ in spans]
         units = [B * tc for _, _, tc in spans]
-        n0 = pops[0].n
-        # the dominant kernel moves, per agent-step, 4*n0 B of rates (+n0 B spikes) and reads 8 B of position;
-        # the contract's `achieved` uses SURVEY §8(d)'s per-unit figure restricted to this population
-        unit_bytes = 4 * n0 + (n0 if cfg["spikes"] else 0) + 112
+    if ms:
         avg_ms = float(np.mean(ms))
         avg_units = float(np.mean(units))
         achieved = unit_bytes * avg_units / (avg_ms * 1e-3) / 1e9
@@ -260,19 +342,25 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = round(json.load(f).get("hbm_bytes_per_unit") * avg_units)  # PMC bytes/unit x units/launch
+        kname = ("rate_stream_kernel" if fused_mode else "rate_kernel_wide") + f"<{type(pops[0]).__name__}>"
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": f"rate_kernel<{type(pops[0]).__name__}>", "launches": len(ms),
-                    "launches_in_timed_region": seen["n"],
-                    "avg_launch_ms": round(avg_ms, 4), "units_per_launch": int(avg_units),
-                    "bytes_per_unit": unit_bytes, "kernel_own_bytes_per_unit": 4 * n0 + 8,
-                    # the averages above are over ALL timed launches (what rocprofv3 --stats averages too)
-                    "full_chunk_launch_ms": round(float(np.mean([m for m, u in zip(ms, units) if u == max(units)])), 4),
+                    "kernel": kname, "launches": len(ms),
+                    "avg_launch_ms": round(avg_ms, 5), "min_launch_ms": round(float(np.min(ms)), 5),
+                    "max_launch_ms": round(float(np.max(ms)), 5), "units_per_launch": int(avg_units),
+                    "bytes_per_unit": unit_bytes, "bytes_per_unit_is": "SURVEY.md 8(d): 4*n (+n spikes) + 112",
+                    "achieved_kernel_own_bytes": round(own_bytes * avg_units / (avg_ms * 1e-3) / 1e9, 1),
+                    "kernel_own_bytes_per_unit": own_bytes,
                     "frac_of_measured_copy_bw_6290": round(achieved / 6290.0, 4)}
+        if fused_mode:
+            roofline["note"] = ("persistent rate kernel, concurrent with the trajectory kernel whose rows it consumes "
+                                "(flag-coupled, one launch each per timed region): its duration includes waiting for rows")
+            if warm_ms is not None:  # rocprofv3 --stats averages over ALL launches of the process, warm-up included
+                roofline["avg_launch_ms_incl_warmup_launch"] = round(float(np.mean(ms + [warm_ms])), 5)
+                roofline["warmup_launch_ms"] = round(warm_ms, 5)
 
     # the chip's measured store ceiling in this same process (riab_fill: one float4 per thread,
     # address-ordered), for context next to the spec peak
-    store_ceiling = None
     if rank == 0 and roofline is not None:
         L = riab._lib
         nbytes = 1 << 30
@@ -291,21 +379,28 @@ def main():
         del buf
 
     if rank == 0:
+        api = ("TaskEnvironment step plan: action, Agent.update, rewards/goals, auto-reset, rates; one native call per step"
+               if args.task else "step plan (one native call per step)" if args.plan else "per-step update()"
+               if args.per_step else "simulate(): trajectory kernel + persistent rate kernel coupled by flags, one native call"
+               if fused_mode else f"simulate(): chunked two-stream pipeline, {args.chunk} steps/launch")
         out = {
-            "metric": "agent-steps/sec (whole node) at 4096 agents x 1024 PlaceCells",
+            "metric": metric_name(cfg),
             "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(elapsed / K * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(med / K * 1e3, 6), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 rates / f%d motion" % args.precision, "data": "synthetic",
             "config": {"workload": args.config + ": " + cfg["desc"], "agents_per_gpu": B,
                        "cells": {k: cfg[k] for k in ("place", "grid", "bvc", "hdc")},
                        "parallelism": f"agent-sharded x{world}, no step-path collective",
-                       "api": ("TaskEnvironment step plan: action, Agent.update, rewards/goals, auto-reset, rates; one "
-                               "native call per step" if args.task else
-                               "step plan (one native call per step)" if args.plan else "per-step update()"
-                               if args.per_step else f"simulate(), {args.chunk} steps/launch"),
-                       "history": "ring" if args.no_history else "full", "spikes": cfg["spikes"],
+                       "api": api, "history": "ring" if args.no_history else "full", "spikes": cfg["spikes"],
                        "bytes_per_agent_step": bpu},
+            "repeats": R,
+            "timed_region_ms": {"median": round(med * 1e3, 5), "min": round(el_sorted[0] * 1e3, 5),
+                                "max": round(el_sorted[-1] * 1e3, 5), "first": round(float(el[0]) * 1e3, 5),
+                                "note": "every repeat runs the full K steps into fresh history rows; value = total "
+                                        "agent-steps of one repeat / the median repeat (max over ranks per repeat)"},
+            "value_best_repeat": round(total_units / el_sorted[0], 1),
             "hbm_GBps_whole_path": round(value / world * bpu / 1e9, 1),
+            "frac_whole_path": round(value / world * bpu / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RIAB_ABI_VERSION 1
+#define RIAB_ABI_VERSION 2
 #define RIAB_MAX_WALLS 64     /* walls staged in LDS by the motion / BVC / line-of-sight kernels */
 #define RIAB_MAX_TEST_ANGLES 360
 #define RIAB_STATE_ROWS 12    /* rows of the agent state matrix, see below */
@@ -520,6 +520,52 @@ int riab_plan_set_task(RiabPlan* plan, const RiabTask* task, double* task_state,
                        uint64_t reset_counter, int32_t teleport, double* ep_log, int64_t ep_log_cap,
                        int32_t* ep_count, double scripted_speed);
 double riab_plan_task_clock(const RiabPlan* plan);
+
+/* ---- the open-loop path as ONE native call: flag-coupled trajectory + firing-rate kernels -------
+ * `for t in range(T): Agent.update(); N.update()` (demos/simple_example.ipynb cell 4) for one
+ * population N, with no kernel boundary between the two stages: the trajectory kernel (the
+ * riab_agent_step kernel in Philox mode, float64) publishes its history rows write-through and a
+ * per-workgroup "steps done" word every four steps; a PERSISTENT firing-rate kernel running
+ * concurrently polls those words and evaluates time row t as soon as the 256 agents of its wave
+ * have been stepped past t.  Results are bit-identical to riab_agent_step followed by the
+ * population's own entry point on the finished trajectory.
+ *
+ * A RiabStreamer owns what the coupling needs besides the kernels: a second HIP stream, two
+ * events, and the running count of started trajectory workgroups.
+ *
+ *  ctrl   device uint32 [RIAB_CTRL_PROGRESS + B/64], zeroed ONCE by the caller when it is created
+ *         (not per call: progress words hold absolute step counts, the started word accumulates):
+ *         [RIAB_CTRL_STARTED] trajectory workgroups that have become resident (all calls),
+ *         [RIAB_CTRL_TIMEOUTS] waves that gave up waiting (must stay 0; results are invalid otherwise),
+ *         [RIAB_CTRL_ABORT] set with the first timeout: every later wait returns at once,
+ *         [RIAB_CTRL_PROGRESS + w] (uint32)(step0 + steps whose rows workgroup w has published).
+ *  pop    the population: kind RIAB_POP_PLACE (not one_hot) / RIAB_POP_GRID / RIAB_POP_HDC, its table and
+ *         parameters, io.min_fr / max_fr / pop_id, rates_base [capacity_rows][n][B] and spikes_base (or NULL);
+ *         capacity_rows < T makes the rate rows a ring (row t % capacity_rows).
+ *  hist   device float32 [T][8][B], required (the rate kernel reads it in place)
+ *  B      a multiple of 256 (four whole trajectory workgroups per rate wave)
+ *  wgs_per_cu  rate workgroups (256 threads) launched per compute unit, 0 = default
+ *  mode   0: the rate kernel on the streamer's second stream behind a gate kernel that waits until every
+ *            trajectory workgroup is resident (the rate kernel would otherwise be able to fill the chip
+ *            with waiting waves before the kernel they wait for has been placed);
+ *         1: both kernels on `stream`, the second launched with hipExtAnyOrderLaunch (experimental)
+ * Returns RIAB_EUNSUPPORTED (nothing launched) for populations / shapes it does not cover: callers fall
+ * back to riab_agent_step + the population's entry point. */
+enum { RIAB_CTRL_STARTED = 0, RIAB_CTRL_TIMEOUTS = 1, RIAB_CTRL_ABORT = 2, RIAB_CTRL_PROGRESS = 16 };
+typedef struct RiabStreamer RiabStreamer;
+RiabStreamer* riab_streamer_create(void);
+void riab_streamer_destroy(RiabStreamer* h);
+int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
+                        int64_t agent_id0, const double* drift, uint64_t seed, uint64_t step0, int32_t T,
+                        float* hist, int32_t* diag, const struct RiabPopulation* pop, uint32_t* ctrl,
+                        int32_t wgs_per_cu, int32_t mode, int32_t timing, riab_stream_t stream);
+/* with `timing` != 0 in the last riab_simulate_fused call: the duration of its rate kernel in ms (HIP events
+ * on the stream the kernel ran on), after the caller has synchronised; < 0 if unavailable */
+float riab_streamer_last_rate_ms(RiabStreamer* h);
+
+/* sizeof of the ABI's structs as compiled into the library (which: 0 RiabEnv, 1 RiabMotion, 2 RiabRateIO,
+ * 3 RiabPopulation, 4 RiabTask, 5 RiabFFInput; 6 returns RIAB_TS_ROWS): bindings verify their mirrors at load */
+int64_t riab_abi_sizeof(int32_t which);
 
 /* Streaming-store calibration kernel: writes `bytes` bytes (multiple of 16) of
  * a constant with the same 16-B/lane store pattern as the rate kernels.  Used

@@ -81,6 +81,9 @@ class Agent:
         self._scratch_row = None
         self._last_row = None   # newest fp32 history row; None when the state was edited from the host
         self._plan = None       # an active StepPlan (plan.py), if any
+        self._streamer = None   # native handle of the flag-coupled pipeline (created on first use)
+        self._ctrl = None       # its control words on the device
+        self._time_rate_kernel = False
 
         self._state = torch.zeros((_L.STATE_ROWS, self._Bp), dtype=torch.float64, device=self._device)
         self.initialise_position_and_velocity()
@@ -93,8 +96,9 @@ class Agent:
         st[_L.S_HD_Y] = st[_L.S_VEL_Y] / nrm
         st[_L.S_DIST] = 0.0
         st[_L.S_DWALL] = float("inf")
+        # (the version is read AFTER an active step plan has published its rows: a plan commits rows lazily)
         self.history = HistoryView(("t", "pos", "distance_travelled", "vel", "rot_vel", "head_direction"),
-                                   self._materialise_history, lambda: self._hist.version)
+                                   self._materialise_history, lambda: (self._sync_plan(), self._hist.version)[1])
 
     @classmethod
     def get_all_default_params(cls, verbose=False):
@@ -103,6 +107,19 @@ class Agent:
             import pprint
             pprint.pprint(all_params)
         return all_params
+
+    @property
+    def rng_seed(self):
+        """Philox key of this Agent OBJECT's streams (motion noise, neuron noise, spikes).  The reference's agents
+        all draw from the global np.random stream and are independent of each other; here every stream is a pure
+        function of (key, global agent id, population, step), so a second Agent object of the same Environment
+        with the same `seed` and id range would replay the first one's noise.  The object's index in
+        `Environment.Agents` is therefore folded into the key (agent 0 keeps `seed` itself; shards of ONE logical
+        agent population on several GPUs are each agent 0 of their own Environment and share the key, which is
+        what makes results independent of the sharding)."""
+        if self.agent_idx == 0:
+            return int(self.seed)
+        return (int(self.seed) + self.agent_idx * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
 
     # ---- initial state (Agent.py:523-535) ---------------------------------------------------
     def initialise_position_and_velocity(self):
@@ -158,8 +175,11 @@ class Agent:
         """Counters accumulated by the kernel: bounces, bounce-loop saturations,
         boundary conditions applied, zero-displacement steps."""
         d = self._diag.cpu().numpy()
-        return dict(bounces=int(d[0]), bounce_saturations=int(d[1]), boundary_conditions=int(d[2]),
-                    zero_displacement=int(d[3]))
+        out = dict(bounces=int(d[0]), bounce_saturations=int(d[1]), boundary_conditions=int(d[2]),
+                   zero_displacement=int(d[3]))
+        if self._ctrl is not None:  # waits of the flag-coupled pipeline that gave up: must be 0
+            out["pipeline_timeouts"] = int(self._ctrl[_L.CTRL_TIMEOUTS].item())
+        return out
 
     # ---- parameter resolution ---------------------------------------------------------------
     def _motion(self, dt, has_drift, ratio, kwargs):
@@ -270,7 +290,7 @@ class Agent:
             hist_view = self._scratch_row[:T]
         s = stream if stream is not None else _L.current_stream()
         rc = _L.lib.riab_agent_step(env, m, _L.ptr(self._state), self._Bp, int(self.agent_id0), _L.ptr(drift),
-                                    _L.ptr(z), _L.ptr(z_out), _L.ptr(forced), int(self.seed),
+                                    _L.ptr(z), _L.ptr(z_out), _L.ptr(forced), int(self.rng_seed),
                                     int(self._step_index), int(T),
                                     _L.ptr(hist_view), _L.ptr(self._diag), int(self.precision), s)
         _L.check(rc, "riab_agent_step")
@@ -297,6 +317,11 @@ class Agent:
         update() would have left them.  Returns the trajectory history tensor of this call
         `[n_steps, 8, B_padded]` (device)."""
         neurons = list(self.Neurons if neurons is None else neurons)
+        if noise is None and not kwargs and self._fused_eligible(neurons):
+            traj = self._simulate_fused(int(n_steps), dt or self.dt, drift_velocity, drift_to_random_strength_ratio,
+                                        neurons[0], chunk)
+            if traj is not None:
+                return traj
         if self._streams is None:
             self._streams = self._make_streams()
         s_traj, s_rate = self._streams
@@ -345,6 +370,87 @@ class Agent:
         for N, out in zip(neurons, outs):
             N._finish_rows(out, n_steps, self._times[-n_steps:] if self.save_history else None)
         return traj
+
+    # ---- fused path, one population: flag-coupled kernels, one native call (riab_simulate_fused) ----------------
+    def _fused_eligible(self, neurons):
+        """The trajectory kernel and ONE persistent rate kernel run concurrently, coupled by flags in device
+        memory (csrc/riab_simulate.hip): Philox noise, float64 motion, whole 256-agent groups, one
+        PlaceCells / GridCells / HeadDirectionCells population without additive noise.  Everything else goes
+        through the chunked two-stream pipeline below.  `RIAB_NO_FUSED=1` switches it off (A/B comparisons:
+        the results are bit-identical)."""
+        import os
+        if len(neurons) != 1 or self.use_imported_trajectory or self.precision != 64 or self._Bp % 256:
+            return False
+        if os.environ.get("RIAB_NO_FUSED") == "1":
+            return False
+        N = neurons[0]
+        return getattr(N, "_stream_kind", None) is not None and N.noise_std == 0 and N.Agent is self
+
+    def _simulate_fused(self, n_steps, dt, drift_velocity, ratio, N, chunk):
+        if self._plan is not None:
+            self._plan.close()
+        if self._streamer is None:
+            h = _L.lib.riab_streamer_create()
+            if not h:
+                raise _L.RiabError("riab_streamer_create failed")
+            self._streamer = _L.C.c_void_p(h)
+            self._ctrl = torch.zeros(_L.CTRL_PROGRESS + self._Bp // 64, dtype=torch.int32, device=self._device)
+        has_drift = drift_velocity is not None
+        m = self._motion(dt, has_drift, ratio, {})
+        env, _walls = self.Environment.device_tables(self._device)
+        drift = self._as_device_f64(drift_velocity, 2) if has_drift else None
+        pop = N._population()
+        if self.save_history:
+            traj = self._hist.reserve(n_steps)
+        else:
+            traj = torch.empty((n_steps, _L.HIST_ROWS, self._Bp), dtype=torch.float32, device=self._device)
+        out = N._reserve_rows(n_steps, ring=min(chunk, n_steps))
+        pop.rates_base = out["fr"].data_ptr()
+        pop.spikes_base = out["sp"].data_ptr() if out["sp"] is not None else None
+        pop.capacity_rows = out["fr"].shape[0]
+        import os
+        rc = _L.lib.riab_simulate_fused(self._streamer, env, m, _L.ptr(self._state), self._Bp, int(self.agent_id0),
+                                        _L.ptr(drift), int(self.rng_seed), int(self._step_index), n_steps, _L.ptr(traj),
+                                        _L.ptr(self._diag), pop, _L.ptr(self._ctrl),
+                                        int(os.environ.get("RIAB_STREAM_WGS_PER_CU", 0)),
+                                        int(os.environ.get("RIAB_STREAM_MODE", 0)), 1 if self._time_rate_kernel else 0,
+                                        _L.current_stream())
+        if rc == _L.EUNSUPPORTED:  # (nothing was launched; the reserved rows are reused by the chunked path)
+            if self.save_history:
+                self._hist.unreserve(n_steps)
+            N._unreserve_rows(out, n_steps)
+            return None
+        _L.check(rc, "riab_simulate_fused")
+        self.dt = dt
+        self._keep = (drift, _walls, traj, out, pop)
+        self._last_row = traj[n_steps - 1]
+        t = self.t
+        times = [t + dt * (i + 1) for i in range(n_steps)] if (self.save_history or N.save_history) else None
+        self.prev_t = self.t + dt * (n_steps - 1)
+        self.t = self.t + dt * n_steps
+        if self.save_history:
+            self._times.extend(times)
+        self._step_index += n_steps
+        if out["ring"] is not None:
+            out["last"] = out["fr"][(n_steps - 1) % out["ring"]]
+        N._finish_rows(out, n_steps, times)
+        return traj
+
+    def last_rate_kernel_ms(self):
+        """Duration of the rate kernel of the last fused simulate() (HIP events on the stream it ran on), after a
+        device synchronisation; None when not timed (`Agent._time_rate_kernel = True` enables it)."""
+        if self._streamer is None:
+            return None
+        ms = float(_L.lib.riab_streamer_last_rate_ms(self._streamer))
+        return ms if ms >= 0 else None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_streamer", None):
+                _L.lib.riab_streamer_destroy(self._streamer)
+                self._streamer = None
+        except Exception:  # noqa: BLE001 (interpreter shutdown)
+            pass
 
     @staticmethod
     def _chunk_schedule(n_steps, chunk):

@@ -50,6 +50,8 @@ class Neurons:
     # which per-agent direction rows feed io.hd_x / hd_y: (history-record rows, float64 state rows)
     _H_DIR = (_L.H_HD_X, _L.H_HD_Y)
     _S_DIR = (_L.S_HD_X, _L.S_HD_Y)
+    # populations the persistent rate kernel of the flag-coupled pipeline covers (Agent._simulate_fused) set this
+    _stream_kind = None
 
     def __init__(self, Agent, params={}):
         self.Agent = Agent
@@ -75,7 +77,7 @@ class Neurons:
         self._hist_sp = DeviceHistory((n, self._Bp), torch.uint8, self._device)
         self._times = []
         self.history = HistoryView(("t", "firingrate", "spikes"), self._materialise_history,
-                                   lambda: self._hist_fr.version)
+                                   lambda: (self.Agent._sync_plan(), self._hist_fr.version)[1])
 
     @classmethod
     def get_all_default_params(cls, verbose=False):
@@ -168,7 +170,8 @@ class Neurons:
         Poisson spikes `U(0,1) < dt*rate` to the history.  kwargs: `spike_uniforms=`
         `(n, B)` and `noise_normals=` `(n, B)` replace the in-kernel Philox draws."""
         Ag = self.Agent
-        Ag._sync_plan()
+        if Ag._plan is not None:
+            Ag._plan.close()  # eager stepping resumes: the plan's open rows and cursors would go stale
         u = kwargs.pop("spike_uniforms", None)
         zn = kwargs.pop("noise_normals", None)
         save = bool(self.save_history)
@@ -197,7 +200,7 @@ class Neurons:
             sigma = float(np.sqrt((2 * float(self.noise_std) ** 2) / (tau * Ag.dt)))
             z_t = None if zn is None else self._as_rows(zn, torch.float32)
             rc = _L.lib.riab_neuron_noise(_L.ptr(self._noise), _L.ptr(rates), _L.ptr(z_t), int(self.n), self._Bp, 1,
-                                          float(Ag.dt / tau), float(sigma * Ag.dt), int(Ag.seed),
+                                          float(Ag.dt / tau), float(sigma * Ag.dt), int(Ag.rng_seed),
                                           int(Ag._step_index), int(self.pop_id), int(Ag.agent_id0),
                                           _L.current_stream())
             _L.check(rc, "riab_neuron_noise")
@@ -295,7 +298,7 @@ class Neurons:
         io.u_in = u_in.data_ptr() if u_in is not None else None
         io.dt = dt
         io.min_fr, io.max_fr = self.min_fr, self.max_fr
-        io.seed = self.Agent.seed
+        io.seed = self.Agent.rng_seed
         io.step0 = step0
         io.agent_id0 = self.Agent.agent_id0
         io.pop_id = self.pop_id
@@ -335,6 +338,12 @@ class Neurons:
         return dict(fr=torch.empty((rows, n, self._Bp), dtype=torch.float32, device=self._device), sp=None,
                     ring=rows)
 
+    def _unreserve_rows(self, out, n_steps):
+        if out["ring"] is None:
+            self._hist_fr.unreserve(n_steps)
+            if out["sp"] is not None:
+                self._hist_sp.unreserve(n_steps)
+
     def _rates_from_trajectory(self, traj, out, t0, tc, step0, dt, stream):
         """Rates (+ spikes) for trajectory rows `traj [tc, 8, Bp]`, written to rows
         t0..t0+tc of the reserved output."""
@@ -356,7 +365,7 @@ class Neurons:
             sigma = float(np.sqrt((2 * float(self.noise_std) ** 2) / (tau * dt)))
             Ag = self.Agent
             rc = _L.lib.riab_neuron_noise(_L.ptr(self._noise), _L.ptr(fr), None, int(self.n), Bp, int(tc),
-                                          float(dt / tau), float(sigma * dt), int(Ag.seed), int(step0 + 1),
+                                          float(dt / tau), float(sigma * dt), int(Ag.rng_seed), int(step0 + 1),
                                           int(self.pop_id), int(Ag.agent_id0), stream)
             _L.check(rc, "riab_neuron_noise")
             if sp is not None:
@@ -402,6 +411,8 @@ class Neurons:
         return self._hist_fr.stack(), self._hist_sp.stack()
 
     def reset_history(self):
+        if self.Agent._plan is not None:
+            self.Agent._plan.close()  # (its open rows live in the chunks dropped here)
         self._hist_fr.reset()
         self._hist_sp.reset()
         self._times = []
@@ -417,6 +428,7 @@ class PlaceCells(Neurons):
     gaussian_threshold, diff_of_gaussians, top_hat, one_hot; wall geometries:
     euclidean, line_of_sight, geodesic."""
 
+    _stream_kind = "place"
     default_params = {
         "n": 10,
         "name": "PlaceCells",
@@ -493,6 +505,7 @@ class GridCells(Neurons):
     """Grid cells: rectified or shifted sum of three cosines 60 degrees apart
     (reference Neurons.py:1033-1256)."""
 
+    _stream_kind = "grid"
     default_params = {
         "n": 30,
         "gridscale_distribution": "modules",
@@ -972,6 +985,7 @@ class HeadDirectionCells(Neurons):
     """Head direction cells: von Mises tuning to the agent's head direction
     (reference Neurons.py:2357-2485)."""
 
+    _stream_kind = "hdc"
     default_params = {
         "min_fr": 0,
         "max_fr": 1,
@@ -1033,6 +1047,7 @@ class VelocityCells(HeadDirectionCells):
     state only: `update()`, `get_state()` and step plans read it there; `Agent.simulate()` cannot
     (its rate stage runs on the float32 history records) and raises."""
 
+    _stream_kind = None  # reads the float64 velocity state, not the history rows
     default_params = {
         "min_fr": 0,
         "max_fr": 1,
@@ -1216,7 +1231,8 @@ class FeedForwardLayer(Neurons):
 
     `inputs[name]` keeps the reference's dictionary (`"layer"`, `"w"` (n, n_in) NumPy — edit it
     freely, e.g. in a learning rule; the device copy is refreshed when it changes —, `"w_init"`,
-    `"I"`, `"n"`, `"recurrent"`).  The contraction runs on the fp32 matrix cores
+    `"n"`, `"recurrent"`; `"I"` is NOT refreshed per step as the reference does (Neurons.py:2825): the inputs
+    stay on the device, read `inputs[name]["layer"].firingrate` instead).  The contraction runs on the fp32 matrix cores
     (`riab_feedforward`, csrc/riab_ff.hip) directly on the input layers' device-resident rates;
     `firingrate_prime` holds the activation derivative like the reference.  Activation functions:
     the reference's named ones (linear, sigmoid, relu, tanh, retanh, softmax); a Python callable
@@ -1365,15 +1381,28 @@ class FeedForwardLayer(Neurons):
         return t[:, :self._last_P].cpu().numpy().astype(np.float64)
 
     def _rates_from_trajectory(self, traj, out, t0, tc, step0, dt, stream):
-        """Fused path: the input layers' rows of the same chunk feed the GEMM in place."""
+        """Fused path: the input layers' rows of the same chunk feed the GEMM in place; then, like every
+        population (Neurons._rates_from_trajectory), the OU noise pass and the spikes on the final rates."""
         outs = self.Agent._sim_outs
+        order = list(outs)
         xs = []
         for e in self.inputs.values():
             if e["recurrent"] or e["layer"] is self:
                 raise NotImplementedError("recurrent inputs need one step per launch: use update(), not simulate()")
+            if e["layer"] not in outs or order.index(e["layer"]) >= order.index(self):
+                raise ValueError(f"simulate(): input layer {e['layer'].name} must be in `neurons` BEFORE {self.name} "
+                                 "(its rows of the chunk are read in place)")
             xs.append(e["layer"]._chunk_view(outs[e["layer"]], t0, tc)[0])
         fr, sp = self._chunk_view(out, t0, tc)
         self._gemm(xs, tc, self._Bp, fr, None, stream)
+        if self.noise_std != 0:
+            tau = float(self.noise_coherence_time)
+            sigma = float(np.sqrt((2 * float(self.noise_std) ** 2) / (tau * dt)))
+            Ag = self.Agent
+            rc = _L.lib.riab_neuron_noise(_L.ptr(self._noise), _L.ptr(fr), None, int(self.n), self._Bp, int(tc),
+                                          float(dt / tau), float(sigma * dt), int(Ag.rng_seed), int(step0 + 1),
+                                          int(self.pop_id), int(Ag.agent_id0), stream)
+            _L.check(rc, "riab_neuron_noise")
         if sp is not None:
             io = self._io(None, None, None, None, self._Bp, tc, self._Bp, fr, sp, None, dt, step0 + 1)
             _L.check(_L.lib.riab_spikes(io, int(self.n), stream), "riab_spikes")

@@ -39,6 +39,12 @@ class DeviceHistory:
         self.filled.append(T)
         return self.chunks[-1][:T]
 
+    def unreserve(self, T):
+        """Give back the T rows of the latest reserve() (nothing was written to them)."""
+        self.filled[-1] -= int(T)
+        assert self.filled[-1] >= 0
+        self.version += 1
+
     def preallocate(self, T):
         """Make sure the next `reserve(T)` finds T free rows (allocation happens here, not
         in the stepping loop)."""
@@ -91,10 +97,10 @@ class HistoryView:
         self._cache_version = None
 
     def _get(self):
-        v = self._version()
+        v = self._version()  # (owners publish pending step-plan rows inside this call, before the version is read)
         if self._cache is None or self._cache_version != v:
             self._cache = self._materialise()
-            self._cache_version = v
+            self._cache_version = self._version()
         return self._cache
 
     def __getitem__(self, key):

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 
 from . import _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_WALLS = 64
 STATE_ROWS = 12
 HIST_ROWS = 8
@@ -88,6 +88,8 @@ TD_REWARD_OVERFLOW, TD_LATE_COMPLETIONS, TD_EPLOG_OVERFLOW, TD_RESETS = range(4)
 
 POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4, "ff": 5, "velocity": 6, "speed": 7, "random_spatial": 8}
 EFULL = -5
+EUNSUPPORTED = -4
+CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_PROGRESS = 0, 1, 2, 16  # riab_hip.h RIAB_CTRL_*
 
 ACTIVATIONS = {"linear": 0, "sigmoid": 1, "relu": 2, "tanh": 3, "retanh": 4, "softmax": 5}
 
@@ -151,6 +153,13 @@ PROTOTYPES = {
                                   C.c_double, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "riab_streamer_create": (C.c_void_p, []),
+    "riab_streamer_destroy": (None, [C.c_void_p]),
+    "riab_simulate_fused": (C.c_int, [C.c_void_p, C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
+                                      C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.POINTER(RiabPopulation), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "riab_streamer_last_rate_ms": (C.c_float, [C.c_void_p]),
+    "riab_abi_sizeof": (C.c_int64, [C.c_int32]),
     "riab_abi_version": (C.c_int, []),
     "riab_strerror": (C.c_char_p, [C.c_int]),
 }
@@ -173,6 +182,11 @@ def _load():
                 raise ImportError(
                     "ratinabox_amd: libriab_hip.so is missing and could not be built with hipcc "
                     f"({e}). There is no CPU fallback; build it with `python -m ratinabox_amd._build`.") from e
+            # an older library is there but the sources are newer and cannot be rebuilt here: say so (the struct
+            # checks below still refuse a library whose layouts differ from this binding's)
+            import warnings
+            warnings.warn(f"ratinabox_amd: libriab_hip.so is older than its sources and could not be rebuilt ({e}); "
+                          "loading the existing library", RuntimeWarning)
     lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
@@ -180,6 +194,15 @@ def _load():
         fn.argtypes = args
     if lib.riab_abi_version() != ABI_VERSION:
         raise ImportError(f"libriab_hip.so ABI {lib.riab_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    # the ctypes mirrors must have the layouts the library was compiled with (a stale library with the same
+    # version number would otherwise corrupt memory silently)
+    mirrors = ((0, RiabEnv), (1, RiabMotion), (2, RiabRateIO), (3, RiabPopulation), (4, RiabTask), (5, RiabFFInput))
+    for which, cls in mirrors:
+        if lib.riab_abi_sizeof(which) != C.sizeof(cls):
+            raise ImportError(f"libriab_hip.so: sizeof({cls.__name__}) is {lib.riab_abi_sizeof(which)} in the library, "
+                              f"{C.sizeof(cls)} in the binding: rebuild (python -m ratinabox_amd._build --force)")
+    if lib.riab_abi_sizeof(6) != TS_ROWS:
+        raise ImportError(f"libriab_hip.so: RIAB_TS_ROWS is {lib.riab_abi_sizeof(6)}, the binding has {TS_ROWS}: rebuild")
     return lib, path
 
 

@@ -47,6 +47,15 @@ int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* 
   return (int)hipGetLastError();
 }
 
+// The publishing variant of the trajectory kernel (riab_simulate_fused): Philox noise, float64, helper wave;
+// a.ctrl carries the control words.  Whole waves only (B % 64 == 0), any T.
+int launch_agent_pub(const AgentArgs& a, hipStream_t s) {
+  if (!a.ctrl || !a.hist || a.z_in || a.z_out || a.forced || a.B % 64 != 0) return RIAB_EINVAL;
+  const dim3 grid((unsigned)(a.B / 64));
+  hipLaunchKernelGGL((agent_step_kernel<double, 0, true, true>), grid, dim3(128), 0, s, a);
+  return (int)hipGetLastError();
+}
+
 }  // namespace riab
 
 using namespace riab;

@@ -104,6 +104,7 @@ struct AgentArgs {
   int T;
   float* hist;  // [T][8][B] or null
   int* diag;
+  uint32_t* ctrl;  // PUB kernels only: control words of the flag-coupled pipeline (riab_hip.h RIAB_CTRL_*)
 };
 
 // ---- math wrappers ---------------------------------------------------------------------------
@@ -225,7 +226,24 @@ struct Wall {  // staged in LDS
 //     loop and never queues behind the rate kernels' store stream.
 // The waves meet at one workgroup barrier per four steps.  Values are bit-identical to the single-wave
 // kernel (the same inlined functions on the same operands).
+//
+// PUB (with PC): the trajectory is consumed by a firing-rate kernel that runs CONCURRENTLY (riab_simulate_fused,
+// rate_stream_kernel in riab_rates.hip).  The helper wave then writes the history rows write-through (agent-scope
+// `sc1` stores: the consumer sits on other CUs / XCDs whose L2s are not coherent with this one), drains them
+// (`s_waitcnt vmcnt(0)`) and publishes "steps done" in ctrl[RIAB_CTRL_PROGRESS + workgroup] with one relaxed
+// agent-scope store per four-step block.  Values are bit-identical to the other variants.
 #define RIAB_Z_BATCH 16
+
+typedef __attribute__((address_space(1))) unsigned long long riab_gu64;
+typedef __attribute__((address_space(1))) uint32_t riab_gu32;
+// 16 bytes write-through (two 8-byte agent-scope relaxed stores = global_store_dwordx2 ... sc1)
+__device__ __forceinline__ void store_v4f_agent(void* p, v4f v) {
+  riab_gu64* g = (riab_gu64*)(uintptr_t)p;
+  const unsigned long long lo = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+  const unsigned long long hi = ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
+  __hip_atomic_store(g, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(g + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // the two standard normals of `step` for agent `aid` as floats; `pw` carries the Philox block that
 // serves an (even, odd) pair of steps
@@ -319,9 +337,10 @@ __device__ __forceinline__ MotionDraw motion_normals(uint64_t step, bool first, 
   return MotionDraw{pw, rr * __builtin_amdgcn_cosf(u2), rr * __builtin_amdgcn_sinf(u2)};
 }
 
-template <class R, int IN, bool PC>
+template <class R, int IN, bool PC, bool PUB = false>
 __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
   static_assert(!PC || IN == 0, "the producer wave only exists in Philox mode");
+  static_assert(!PUB || PC, "rows are published by the helper wave");
   const int lane = (int)(threadIdx.x & 63);
   const int wave = PC ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   __shared__ float s_z[PC ? 2 : 1][PC ? RIAB_Z_BATCH : 1][2][PC ? 64 : 1];
@@ -340,7 +359,8 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
       if (j < n2) {
         const v4f v = *reinterpret_cast<const v4f*>(&s_hist[buf][j >> 1][(j & 1) * 4][0] + hist_lds_lane);
         char* const gj = reinterpret_cast<char*>(g0 + (int64_t)((j >> 1) * RIAB_HIST_ROWS + (j & 1) * 4) * a.B);
-        *reinterpret_cast<v4f*>(gj + hist_glb_lane) = v;
+        if (PUB) store_v4f_agent(gj + hist_glb_lane, v);
+        else *reinterpret_cast<v4f*>(gj + hist_glb_lane) = v;
       }
     }
   };
@@ -394,7 +414,16 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
         flush_hist(0, t0, n_steps);
         __builtin_amdgcn_wave_barrier();
       }
+      if (PUB) {
+        // every row of steps < t0 + n_steps has left this wave write-through; once the stores are acknowledged
+        // the consumer may read them: publish the absolute step count (no per-launch reset of the word needed)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_store((riab_gu32*)(uintptr_t)(a.ctrl + RIAB_CTRL_PROGRESS + blockIdx.x),
+                             (uint32_t)a.step0 + (uint32_t)(t0 + n_steps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     };
+    if (PUB && lane == 0) atomicAdd(a.ctrl + RIAB_CTRL_STARTED, 1u);  // this workgroup is resident
     __syncthreads();  // (the table-staging barrier of the stepping wave)
     draw_batch(0);
     __syncthreads();  // noise batch 0 ready
@@ -820,9 +849,9 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
   }
 }
 
-template <class R, int IN, bool PC>
+template <class R, int IN, bool PC, bool PUB = false>
 __global__ __launch_bounds__(PC ? 128 : 64) void agent_step_kernel(const AgentArgs a) {
-  agent_step_body<R, IN, PC>(a);
+  agent_step_body<R, IN, PC, PUB>(a);
 }
 
 // argument checks + the kernel's argument block (shared by riab_agent_step and the step plan's fused
@@ -858,6 +887,7 @@ static inline int fill_agent_args(AgentArgs& a, const RiabEnv* env, const RiabMo
   a.T = T;
   a.hist = hist;
   a.diag = diag;
+  a.ctrl = nullptr;
   return RIAB_OK;
 }
 

@@ -17,6 +17,10 @@
 //     SGPRs: no LDS, no per-lane table traffic;
 // small batches (B < 1024, e.g. one agent over a long trajectory) use the generic kernel:
 // lanes are quads of agents flattened over all time rows, each walking a chunk of cells.
+#include <hip/hip_ext.h>
+
+#include <type_traits>
+
 #include "riab_device.h"
 
 namespace riab {
@@ -50,6 +54,17 @@ struct PosQuad {
 };
 
 __device__ __forceinline__ v4f ldv4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
+// 16 bytes another kernel has published write-through: two 8-byte relaxed agent-scope loads
+// (global_load_dwordx2 ... sc1: served by L2, never by this CU's L1)
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+__device__ __forceinline__ v4f ldv4_agent(const float* p) {
+  gu64* g = (gu64*)(uintptr_t)p;
+  const unsigned long long lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v4f{__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
+             __uint_as_float((uint32_t)(hi >> 32))};
+}
 
 // finish_rate: per-position epilogue on the rate already scaled to [min_fr, max_fr].
 // Neurons.update returns zeros while the agent's position is NaN (reference Neurons.py:163-164)
@@ -184,6 +199,9 @@ struct PlaceCell {
   }
   __device__ __forceinline__ Pos load(const RateArgs& a, int64_t off) const {
     return Pos{ldv4(a.pos_x + off), ldv4(a.pos_y + off)};
+  }
+  __device__ __forceinline__ Pos load_agent(const RateArgs& a, int64_t off) const {  // rows another kernel is publishing
+    return Pos{ldv4_agent(a.pos_x + off), ldv4_agent(a.pos_y + off)};
   }
   __device__ __forceinline__ float wrap(float v) const {
     const float av = fabsf(v);
@@ -361,6 +379,9 @@ struct GridCell {
   __device__ __forceinline__ Pos load(const RateArgs& a, int64_t off) const {
     return Pos{ldv4(a.pos_x + off), ldv4(a.pos_y + off)};
   }
+  __device__ __forceinline__ Pos load_agent(const RateArgs& a, int64_t off) const {
+    return Pos{ldv4_agent(a.pos_x + off), ldv4_agent(a.pos_y + off)};
+  }
   // two agents per instruction: the phase arithmetic and the final affine map are packed fp32
   // (v_pk_mul / v_pk_fma / v_pk_add); v_fract and v_cos stay one per term
   __device__ __forceinline__ v2f two(const float* p, v2f x, v2f y) const {
@@ -406,6 +427,9 @@ struct HDCell {
   float speed_inv;   // 1 / one_sigma_speed
   const double* vx64;  // MODE 1 at the agent: rows RIAB_S_VEL_X / _Y of the float64 state (T = 1), or NULL
   const double* vy64;
+  __device__ __forceinline__ Pos load_agent(const RateArgs& a, int64_t off) const {
+    return from_dirs(ldv4_agent(a.hd_x + off), ldv4_agent(a.hd_y + off));
+  }
   __device__ __forceinline__ Pos load(const RateArgs& a, int64_t off) const {
     v4f hx, hy;
     if (MODE == 1 && vx64) {
@@ -417,6 +441,9 @@ struct HDCell {
       hx = ldv4(a.hd_x + off);
       hy = ldv4(a.hd_y + off);
     }
+    return from_dirs(hx, hy);
+  }
+  __device__ __forceinline__ Pos from_dirs(v4f hx, v4f hy) const {
     Pos P;
     if (MODE >= 1) {
       const v4f sp{sqrtf(fmaf(hy.x, hy.x, hx.x * hx.x)), sqrtf(fmaf(hy.y, hy.y, hx.y * hx.y)),
@@ -508,6 +535,195 @@ __global__ __launch_bounds__(256) void noise_kernel(float* noise, float* rates, 
 __global__ __launch_bounds__(256) void fill_kernel(float* dst, int64_t n4, float value) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n4) reinterpret_cast<v4f*>(dst)[i] = v4f{value, value, value, value};
+}
+
+// ---- persistent consumer of a trajectory that is still being written (riab_simulate_fused) -------------------
+// The trajectory kernel (riab_agent_kernel.h, PUB variant) publishes, per workgroup of 64 agents, how many steps
+// of history rows it has written (write-through stores, then ctrl[RIAB_CTRL_PROGRESS + workgroup]).  This kernel
+// is launched ONCE for all T time rows with a grid that stays resident; a WAVE walks the items
+//   (time row t, group of GPI x CPB cells, 256-agent sub-segment q)          -- q fastest, then group, then t --
+// with stride = number of waves, so that at any moment the resident waves write one contiguous window of
+// out[t][c][b] in address order (what made the wide kernel's store stream fast, tools/store_bench.hip).
+//   * vmcnt retires in order on gfx9 — a wave that waits for a load also waits for every store issued before
+//     it.  The loop is therefore software-pipelined by hand: the positions and cell parameters of item k+1 are
+//     requested BEFORE the stores of item k are issued, so using them only needs vmcnt(stores of k).
+//   * readiness: lanes 0-3 read the four progress words of the wave's sub-segment (relaxed agent-scope loads),
+//     the minimum is cached ("rows below `known` are published"); with the stride a multiple of the number of
+//     sub-segments a wave keeps its q and polls only when it catches up with the trajectory.
+//   * positions are read with agent-scope (sc1) loads: the producer's stores are write-through, the lines are
+//     never in this CU's L1 before they are published, and sc1 loads do not allocate there.
+//   * every wait is bounded: a wave that gives up sets ctrl[RIAB_CTRL_ABORT] (all other waits then return
+//     at once) and counts itself in ctrl[RIAB_CTRL_TIMEOUTS]; the host treats a non-zero count as an error.
+struct StreamArgs {
+  uint32_t* ctrl;
+  uint32_t step_base;     // (uint32) step0 of the launch: progress words are absolute step counts
+  int32_t T;
+  int32_t ring;           // rows of the rates / spikes buffers; row = t % ring (ring >= T: row = t)
+  int32_t groups;         // items per (t, q): ceil(n / (GPI * CPB))
+  int32_t q256;           // 256-agent sub-segments per time row
+  int32_t d_t, d_g, d_q;  // the stride (number of waves) in the mixed radix (groups, q256)
+  uint32_t spin_limit;
+};
+
+// rows of sub-segment q published so far, relative to this launch (0 .. T); INT_MAX once the pipeline was aborted
+__device__ __forceinline__ int stream_progress(const StreamArgs& s, uint32_t q, int lane) {
+  int rel = 0x7fffffff;
+  if (lane < 4) {
+    const uint32_t v = __hip_atomic_load((gu32*)(uintptr_t)(s.ctrl + RIAB_CTRL_PROGRESS + 4 * q + lane), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+    rel = (int)(v - s.step_base);      // stale words of earlier launches are <= step_base
+    rel = rel < 0 ? 0 : rel;
+  }
+  uint32_t ab = 0;
+  if (lane == 4)
+    ab = __hip_atomic_load((gu32*)(uintptr_t)(s.ctrl + RIAB_CTRL_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int r0 = __builtin_amdgcn_readlane(rel, 0), r1 = __builtin_amdgcn_readlane(rel, 1);
+  const int r2 = __builtin_amdgcn_readlane(rel, 2), r3 = __builtin_amdgcn_readlane(rel, 3);
+  const int k = min(min(r0, r1), min(r2, r3));
+  return __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane((int)ab, 4) ? 0x7fffffff : k);
+}
+// wait until row t of sub-segment q is published; returns the cached bound (rows < bound are published)
+__device__ __forceinline__ int stream_wait(const StreamArgs& s, uint32_t q, int t, int lane) {
+  int known = stream_progress(s, q, lane);
+  for (uint32_t spins = 0; known <= t; ++spins) {
+    if (spins >= s.spin_limit) {
+      if (lane == 0) {
+        atomicAdd(s.ctrl + RIAB_CTRL_TIMEOUTS, 1u);
+        __hip_atomic_store((gu32*)(uintptr_t)(s.ctrl + RIAB_CTRL_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return 0x7fffffff;
+    }
+    __builtin_amdgcn_s_sleep(8);
+    known = stream_progress(s, q, lane);
+  }
+  return known;
+}
+
+template <class Cell, int SPK, int GPI>
+__global__ __launch_bounds__(256) void rate_stream_kernel(const RateArgs a, Cell cell, const StreamArgs s) {
+  __shared__ double s_lds[Cell::LDS_DOUBLES];
+  cell.stage(s_lds);
+  constexpr int NP = Cell::NP, CPB = Cell::CPB, CPI = GPI * CPB;
+  static_assert(NP * CPB <= 64, "a cell group's parameters must fit one wave");
+  const int lane = threadIdx.x & 63;
+  const uint32_t gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+  // first item of this wave (the stride brings the later ones: incremental mixed-radix addition, all scalar)
+  uint32_t q = gw % (uint32_t)s.q256;
+  const uint32_t rest = gw / (uint32_t)s.q256;
+  uint32_t g = rest % (uint32_t)s.groups;
+  int t = (int)(rest / (uint32_t)s.groups);
+  if (t >= s.T) return;
+  // (read once, declared uniform: a reload behind the timeout path's atomics would make the loops below divergent)
+  const int n_cells = __builtin_amdgcn_readfirstlane(a.n);
+  const int last_param = n_cells * NP - 1;
+  // every lane loads (index clamped): no exec-masked loads, so the number of memory operations in flight is
+  // the same on every path and the compiler's s_waitcnt counts are exact (see the header comment)
+  auto load_params = [&](uint32_t gg, float (&m)[GPI]) {
+#pragma unroll
+    for (int i = 0; i < GPI; ++i) m[i] = cell.tab[min(((int)gg * GPI + i) * CPB * NP + lane, last_param)];
+  };
+  auto pos_off = [&](int tt, uint32_t qq) { return (int64_t)tt * a.pos_ld + (int64_t)qq * 256 + 4 * lane; };
+  struct Next {
+    uint32_t q, g;
+    int t;
+  };
+  auto advance = [&](uint32_t q0, uint32_t g0, int t0) {
+    uint32_t nq = q0 + (uint32_t)s.d_q;
+    const uint32_t cq = nq >= (uint32_t)s.q256 ? 1u : 0u;
+    nq -= cq ? (uint32_t)s.q256 : 0u;
+    uint32_t ng = g0 + (uint32_t)s.d_g + cq;
+    const uint32_t cg = ng >= (uint32_t)s.groups ? 1u : 0u;
+    ng -= cg ? (uint32_t)s.groups : 0u;
+    // (wave-uniform by construction; saying so keeps the item state in scalar registers and the loops scalar)
+    return Next{(uint32_t)__builtin_amdgcn_readfirstlane((int)nq), (uint32_t)__builtin_amdgcn_readfirstlane((int)ng),
+                __builtin_amdgcn_readfirstlane(t0 + s.d_t + (int)cg)};
+  };
+  // rates (+ spikes) of one item; GUARD: the item's last cells may not exist (n not a multiple of CPI)
+  auto emit = [&](auto guard, uint32_t qq, uint32_t gg, int tt, const typename Cell::Pos& P, const float (&m)[GPI]) {
+    constexpr bool GUARD = decltype(guard)::value;
+    const int row = (s.ring >= s.T) ? tt : tt % s.ring;
+    const int c00 = (int)gg * CPI;
+    int64_t off = ((int64_t)row * n_cells + c00) * a.B + (int64_t)qq * 256 + 4 * lane;
+    const uint32_t step = a.step0 + (uint32_t)tt;
+    const uint32_t group = a.group0 + qq * 64u + (uint32_t)lane;
+#pragma unroll
+    for (int i = 0; i < GPI; ++i) {
+#pragma unroll
+      for (int j = 0; j < CPB; ++j) {
+        const int c = c00 + i * CPB + j;
+        if (!GUARD || c < n_cells) {  // wave-uniform
+          float p[NP];
+#pragma unroll
+          for (int k = 0; k < NP; ++k)
+            p[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m[i]), j * NP + k));
+          v4f r = cell.eval(p, P);
+          r = finish_rate(r * a.fr_scale + a.fr_min, P);
+          *reinterpret_cast<v4f*>(a.rates + off) = r;
+          if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)c, group);
+          off += a.B;
+        }
+      }
+    }
+  };
+
+  int known = __builtin_amdgcn_readfirstlane(stream_wait(s, q, t, lane));
+  uint32_t known_q = q;
+  typename Cell::Pos P = cell.load_agent(a, pos_off(t, q));
+  float mine[GPI];
+  load_params(g, mine);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the end of the outer loop
+  for (;;) {
+    // ---- steady state: the next item's rows are known to be published.  Straight-line body: request the next
+    // item's operands, then evaluate and store this item (its operands were requested one iteration ago, BEFORE
+    // that iteration's stores: using them never waits for a store).
+    for (;;) {
+      const Next nx = advance(q, g, t);
+      const bool ahead = nx.t < s.T && nx.q == known_q && nx.t < known;
+      const bool whole = (int)(g + 1) * CPI <= n_cells;
+      if (!(ahead && whole)) break;
+      const typename Cell::Pos Pn = cell.load_agent(a, pos_off(nx.t, nx.q));
+      float mine_n[GPI];
+      load_params(nx.g, mine_n);
+      emit(std::false_type{}, q, g, t, P, mine);
+      q = nx.q;
+      g = nx.g;
+      t = nx.t;
+      P = Pn;
+#pragma unroll
+      for (int i = 0; i < GPI; ++i) mine[i] = mine_n[i];
+    }
+    // ---- this item without look-ahead; then wait for the next one's rows
+    emit(std::true_type{}, q, g, t, P, mine);
+    const Next nx = advance(q, g, t);
+    if (nx.t >= s.T) return;
+    known = __builtin_amdgcn_readfirstlane(stream_wait(s, nx.q, nx.t, lane));
+    known_q = nx.q;
+    q = nx.q;
+    g = nx.g;
+    t = nx.t;
+    P = cell.load_agent(a, pos_off(t, q));
+    load_params(g, mine);
+    // nothing in flight when the steady-state loop is (re-)entered: its wait counts then only reflect its own body
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (gfx9 encoding: expcnt / lgkmcnt fields at their maxima)
+  }
+}
+
+// the gate in front of the rate kernel on its stream: returns once every trajectory workgroup of this launch
+// is resident (ctrl[RIAB_CTRL_STARTED] has reached `target`), so that the persistent rate waves can never
+// occupy the slots the kernel they wait for still needs
+__global__ __launch_bounds__(64) void stream_gate_kernel(uint32_t* ctrl, uint32_t target, uint32_t spin_limit) {
+  if (threadIdx.x != 0) return;
+  for (uint32_t spins = 0;; ++spins) {
+    const uint32_t v = __hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_STARTED), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int32_t)(v - target) >= 0) return;
+    if (__hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (spins >= spin_limit) {
+      atomicAdd(ctrl + RIAB_CTRL_TIMEOUTS, 1u);
+      __hip_atomic_store((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -611,6 +827,157 @@ static int place_dispatch(const RiabEnv* env, const RiabRateIO* io, const float*
   c.e0 = env->extent[0]; c.e1 = env->extent[1]; c.e2 = env->extent[2]; c.e3 = env->extent[3];
   c.lds = nullptr;
   return launch_place<GX>(io, n, desc, c, s);
+}
+
+// ---- launch of the persistent consumer (called by riab_simulate_fused, riab_simulate.hip) --------------------
+template <class Cell, int GPI>
+static int launch_stream_cell(const RateArgs& a, const Cell& cell, StreamArgs st, int max_wgs, bool spikes, bool any_order,
+                              hipStream_t s) {
+  constexpr int CPI = GPI * Cell::CPB;
+  st.groups = (a.n + CPI - 1) / CPI;
+  const int64_t items = (int64_t)st.T * st.groups * st.q256;
+  if (items >= ((int64_t)1 << 31)) return RIAB_ETOOBIG;
+  // a grid that stays resident; the stride (waves) a multiple of the sub-segment count when possible, so that a
+  // wave keeps its 256 agents (its cached readiness bound stays valid) — and never more waves than items
+  int64_t wgs = max_wgs;
+  const int64_t need = (items + 3) / 4;
+  if (wgs > need) wgs = need;
+  {
+    int64_t unit = st.q256;  // waves per row of sub-segments; workgroups must supply a multiple of it
+    while (unit % 4 != 0) unit *= 2;
+    unit /= 4;               // workgroups
+    if (wgs >= unit) wgs -= wgs % unit;
+  }
+  if (wgs < 1) wgs = 1;
+  const int64_t nw = wgs * 4;
+  st.d_q = (int32_t)(nw % st.q256);
+  const int64_t rest = nw / st.q256;
+  st.d_g = (int32_t)(rest % st.groups);
+  st.d_t = (int32_t)(rest / st.groups);
+  const dim3 grid((unsigned)wgs), block(256);
+  const unsigned flags = any_order ? hipExtAnyOrderLaunch : 0u;
+  if (spikes) hipExtLaunchKernelGGL((rate_stream_kernel<Cell, 1, GPI>), grid, block, 0, s, nullptr, nullptr, flags, a, cell, st);
+  else hipExtLaunchKernelGGL((rate_stream_kernel<Cell, 0, GPI>), grid, block, 0, s, nullptr, nullptr, flags, a, cell, st);
+  return (int)hipGetLastError();
+}
+
+template <int GX>
+static int launch_stream_place(const RiabEnv* env, const RiabPopulation* pop, const RateArgs& a, const StreamArgs& st,
+                               int max_wgs, int gpi, bool spikes, bool any_order, hipStream_t s) {
+  PlaceCell<RIAB_PC_GAUSSIAN, GX> c;
+  c.tab = pop->table;
+  c.scale = (float)env->scale;
+  c.half_scale = (float)(env->scale / 2);
+  c.top_hat_w2 = pop->top_hat_width * pop->top_hat_width;
+  c.walls = env->walls;
+  c.n_internal = env->n_walls > 4 ? env->n_walls - 4 : 0;
+  if (GX == 2 && c.n_internal > 1) c.n_internal = 1;
+  c.e0 = env->extent[0]; c.e1 = env->extent[1]; c.e2 = env->extent[2]; c.e3 = env->extent[3];
+  c.lds = nullptr;
+  switch (pop->description) {
+    case RIAB_PC_GAUSSIAN:
+      if (GX == 0 && gpi == 1) return launch_stream_cell<PlaceCell<RIAB_PC_GAUSSIAN, GX>, 1>(a, c, st, max_wgs, spikes, any_order, s);
+      if (GX == 0 && gpi == 4) return launch_stream_cell<PlaceCell<RIAB_PC_GAUSSIAN, GX>, 4>(a, c, st, max_wgs, spikes, any_order, s);
+      return launch_stream_cell<PlaceCell<RIAB_PC_GAUSSIAN, GX>, 2>(a, c, st, max_wgs, spikes, any_order, s);
+    case RIAB_PC_GAUSSIAN_THRESHOLD:
+      return launch_stream_cell<PlaceCell<RIAB_PC_GAUSSIAN_THRESHOLD, GX>, 2>(a, c.template as<RIAB_PC_GAUSSIAN_THRESHOLD>(), st,
+                                                                             max_wgs, spikes, any_order, s);
+    case RIAB_PC_DIFF_OF_GAUSSIANS:
+      return launch_stream_cell<PlaceCell<RIAB_PC_DIFF_OF_GAUSSIANS, GX>, 2>(a, c.template as<RIAB_PC_DIFF_OF_GAUSSIANS>(), st,
+                                                                            max_wgs, spikes, any_order, s);
+    case RIAB_PC_TOP_HAT:
+      return launch_stream_cell<PlaceCell<RIAB_PC_TOP_HAT, GX>, 2>(a, c.template as<RIAB_PC_TOP_HAT>(), st, max_wgs, spikes,
+                                                                  any_order, s);
+    default: return RIAB_EUNSUPPORTED;  // one_hot scans every cell per position: not a streaming shape
+  }
+}
+
+// 0 when the stream kernel covers this population, RIAB_EUNSUPPORTED otherwise (checked before anything is launched)
+int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B) {
+  if (!env || !pop || pop->n <= 0 || B <= 0 || B % 256 != 0) return RIAB_EUNSUPPORTED;
+  if (pop->noise_state) return RIAB_EUNSUPPORTED;  // the OU noise pass is sequential over the finished rows
+  switch (pop->kind) {
+    case RIAB_POP_PLACE:
+      if (pop->description == RIAB_PC_ONE_HOT) return RIAB_EUNSUPPORTED;
+      if (env->periodic && pop->geometry != RIAB_GEOM_EUCLIDEAN) return RIAB_EUNSUPPORTED;
+      if (pop->geometry != RIAB_GEOM_EUCLIDEAN && env->n_walls - 4 > RIAB_MAX_WALLS) return RIAB_EUNSUPPORTED;
+      if (pop->geometry == RIAB_GEOM_GEODESIC && env->n_walls > 5) return RIAB_EUNSUPPORTED;
+      return pop->table ? RIAB_OK : RIAB_EINVAL;
+    case RIAB_POP_GRID:
+    case RIAB_POP_HDC: return pop->table ? RIAB_OK : RIAB_EINVAL;
+    default: return RIAB_EUNSUPPORTED;
+  }
+}
+
+int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t T, float dt,
+                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, int max_wgs, int gpi,
+                       uint32_t spin_limit, bool any_order, hipStream_t s) {
+  int rc = stream_supported(env, pop, B);
+  if (rc) return rc;
+  if (!hist || !ctrl || !pop->rates_base || T <= 0 || pop->capacity_rows <= 0 || agent_id0 % 4) return RIAB_EINVAL;
+  if ((((uintptr_t)hist | (uintptr_t)pop->rates_base) & 15) || ((uintptr_t)pop->spikes_base & 3)) return RIAB_EALIGN;
+  RateArgs a;
+  a.pos_x = hist + (int64_t)RIAB_H_POS_X * B;
+  a.pos_y = hist + (int64_t)RIAB_H_POS_Y * B;
+  a.hd_x = hist + (int64_t)RIAB_H_HD_X * B;
+  a.hd_y = hist + (int64_t)RIAB_H_HD_Y * B;
+  a.pos_ld = (int64_t)RIAB_HIST_ROWS * B;
+  a.qrow = B / 4;
+  a.nquads = (int64_t)T * a.qrow;
+  a.B = B;
+  a.rates = pop->rates_base;
+  a.spikes = pop->spikes_base;
+  a.u_in = nullptr;
+  a.dt = dt;
+  a.fr_scale = pop->io.max_fr - pop->io.min_fr;
+  a.fr_min = pop->io.min_fr;
+  a.k0 = (uint32_t)seed;
+  a.k1 = (uint32_t)(seed >> 32);
+  a.step0 = (uint32_t)(step0 + 1);  // Neurons.update after the (step0 + t + 1)-th Agent.update
+  a.tag = RIAB_TAG_SPIKES | ((uint32_t)pop->io.pop_id & 0xFFu);
+  a.group0 = (uint32_t)(agent_id0 / 4);
+  a.n = pop->n;
+  a.cells_per_block = 0;
+  StreamArgs st;
+  st.ctrl = ctrl;
+  st.step_base = (uint32_t)step0;
+  st.T = T;
+  st.ring = (int32_t)(pop->capacity_rows < T ? pop->capacity_rows : T);
+  st.groups = 0;
+  st.q256 = (int32_t)(B / 256);
+  st.d_t = st.d_g = st.d_q = 0;
+  st.spin_limit = spin_limit;
+  const bool spikes = pop->spikes_base != nullptr;
+  switch (pop->kind) {
+    case RIAB_POP_PLACE:
+      if (env->periodic) return launch_stream_place<3>(env, pop, a, st, max_wgs, gpi, spikes, any_order, s);
+      switch (pop->geometry) {
+        case RIAB_GEOM_EUCLIDEAN: return launch_stream_place<0>(env, pop, a, st, max_wgs, gpi, spikes, any_order, s);
+        case RIAB_GEOM_LINE_OF_SIGHT: return launch_stream_place<1>(env, pop, a, st, max_wgs, gpi, spikes, any_order, s);
+        case RIAB_GEOM_GEODESIC: return launch_stream_place<2>(env, pop, a, st, max_wgs, gpi, spikes, any_order, s);
+        default: return RIAB_EINVAL;
+      }
+    case RIAB_POP_GRID:
+      if (pop->description == RIAB_GC_RECTIFIED) {
+        GridCell<RIAB_GC_RECTIFIED> c{pop->table, pop->f0, 1.0f / (1.0f - pop->f0)};
+        return launch_stream_cell<GridCell<RIAB_GC_RECTIFIED>, 2>(a, c, st, max_wgs, spikes, any_order, s);
+      }
+      if (pop->description == RIAB_GC_SHIFTED) {
+        GridCell<RIAB_GC_SHIFTED> c{pop->table, pop->f0, 1.0f};
+        return launch_stream_cell<GridCell<RIAB_GC_SHIFTED>, 2>(a, c, st, max_wgs, spikes, any_order, s);
+      }
+      return RIAB_EINVAL;
+    case RIAB_POP_HDC: {
+      HDCell<0> c{pop->table, 0.0f, nullptr, nullptr};
+      return launch_stream_cell<HDCell<0>, 1>(a, c, st, max_wgs, spikes, any_order, s);
+    }
+    default: return RIAB_EUNSUPPORTED;
+  }
+}
+
+int launch_stream_gate(uint32_t* ctrl, uint32_t target, uint32_t spin_limit, hipStream_t s) {
+  hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(64), 0, s, ctrl, target, spin_limit);
+  return (int)hipGetLastError();
 }
 
 }  // namespace riab

@@ -30,6 +30,9 @@ def sharded_agent_params(n_agents_total, rank=None, world_size=None, **params):
     if world_size is None:
         world_size = dist.get_world_size() if dist.is_initialized() else 1
     a0, n = shard_range(n_agents_total, rank, world_size)
+    if n == 0:
+        raise ValueError(f"rank {rank} of {world_size} gets no agents out of {n_agents_total} (shards are multiples "
+                         "of 4 agents): use fewer ranks or leave this rank out of the run")
     return dict(params, n_agents=n, agent_id0=a0)
 
 

@@ -38,7 +38,7 @@ class StepPlan:
         self._drift_t = None
         env, self._walls = agent.Environment.device_tables(agent._device)
         motion = agent._motion(agent.dt, False, 1, {})
-        self._h = _L.lib.riab_plan_create(env, motion, _L.ptr(agent._state), Bp, int(agent.agent_id0), int(agent.seed),
+        self._h = _L.lib.riab_plan_create(env, motion, _L.ptr(agent._state), Bp, int(agent.agent_id0), int(agent.rng_seed),
                                           int(agent._step_index), int(agent.precision), _L.ptr(self._row_scratch),
                                           _L.ptr(agent._diag))
         if not self._h:

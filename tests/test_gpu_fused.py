@@ -1,0 +1,252 @@
+"""GPU tests of the flag-coupled pipeline (`riab_simulate_fused`: the trajectory kernel publishing its rows to a
+persistent firing-rate kernel that runs concurrently, csrc/riab_simulate.hip).
+
+The pipeline runs the SAME arithmetic as the chunked two-stream path (`RIAB_NO_FUSED=1`), which the parity
+tests pin against the reference goldens and the oracle; so the requirement here is bit-identity with that path —
+every history row, every rate, every spike — plus a direct oracle check of the rates on the trajectory rows the
+pipeline produced, and that no wait of the pipeline ever gave up (`diagnostics["pipeline_timeouts"] == 0`).
+A stale read (a rate evaluated on a row that was not published yet) shows as a mismatch of whole 4-float groups."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import riab_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+MAZE = [[[.2, 0], [.2, .4]], [[.4, 1], [.4, .6]], [[.6, 0], [.6, .4]], [[.8, 1], [.8, .6]], [[.3, .5], [.7, .5]]]
+
+
+@pytest.fixture(scope="module")
+def riab():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    import ratinabox_amd
+    return ratinabox_amd
+
+
+def _world(riab, B, make_pop, env_params=None, seed=7, agent_params=None):
+    np.random.seed(seed)
+    env = riab.Environment(env_params or {})
+    ag = riab.Agent(env, dict({"n_agents": B, "dt": 0.01, "seed": 99}, **(agent_params or {})))
+    np.random.seed(seed + 1)
+    pop = make_pop(riab, ag)
+    return env, ag, pop
+
+
+def _run(riab, fused, B, make_pop, schedule, env_params=None, drift=None, agent_params=None):
+    """schedule: list of ("sim", T) / ("step", k) entries.  Returns (trajectory, rates, spikes, agent)."""
+    os.environ["RIAB_NO_FUSED"] = "0" if fused else "1"
+    try:
+        env, ag, pop = _world(riab, B, make_pop, env_params, agent_params=agent_params)
+        for what, n in schedule:
+            if what == "sim":
+                ag.simulate(n, drift_velocity=drift)
+            else:
+                for _ in range(n):
+                    ag.update(drift_velocity=drift)
+                    pop.update()
+        torch.cuda.synchronize()
+        traj = ag.get_history_tensor().cpu().numpy()
+        fr, sp = pop.get_history_tensors()
+        return traj, fr.cpu().numpy(), sp.cpu().numpy(), ag
+    finally:
+        os.environ.pop("RIAB_NO_FUSED", None)
+
+
+def _pc(n, **kw):
+    def make(riab, ag):
+        return riab.PlaceCells(ag, dict({"n": n, "wall_geometry": "euclidean"}, **kw))
+    return make
+
+
+def _gc(n, **kw):
+    def make(riab, ag):
+        return riab.GridCells(ag, dict({"n": n}, **kw))
+    return make
+
+
+def _hdc(n, **kw):
+    def make(riab, ag):
+        return riab.HeadDirectionCells(ag, dict({"n": n}, **kw))
+    return make
+
+
+CASES = [
+    # name, B, population, schedule, env, drift
+    ("pc_cfg2_20", 4096, _pc(1024, save_spikes=False), [("sim", 20)], None, None),
+    ("pc_cfg2_133", 4096, _pc(1024, save_spikes=False), [("sim", 133)], None, None),
+    ("pc_short_runs", 1024, _pc(256, save_spikes=False), [("sim", 1), ("sim", 3), ("sim", 4), ("sim", 9)], None, None),
+    ("pc_ragged_cells_spikes", 512, _pc(203), [("sim", 37)], None, None),
+    ("pc_tiny", 256, _pc(5), [("sim", 50)], None, None),
+    ("pc_mixed_with_eager", 1024, _pc(64), [("step", 3), ("sim", 21), ("step", 2), ("sim", 8)], None, None),
+    ("pc_threshold_los_maze", 1024, _pc(100, description="gaussian_threshold", wall_geometry="line_of_sight"),
+     [("sim", 60)], {"walls": MAZE}, None),
+    ("pc_dog_periodic", 512, _pc(77, description="diff_of_gaussians", widths=0.1), [("sim", 45)],
+     {"boundary_conditions": "periodic"}, None),
+    ("pc_top_hat_drift", 512, _pc(64, description="top_hat"), [("sim", 30)], None, np.array([0.3, -0.1])),
+    ("gc_rectified_spikes", 1024, _gc(300), [("sim", 40)], None, None),
+    ("gc_shifted", 512, _gc(64, description="shifted_cosines", save_spikes=False), [("sim", 25)], {"walls": MAZE}, None),
+    ("hdc_spikes", 1024, _hdc(50), [("sim", 64)], None, None),
+    ("hdc_wide", 2048, _hdc(200, save_spikes=False), [("sim", 17)], None, None),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_fused_equals_chunked_pipeline(riab, case):
+    _name, B, make_pop, schedule, env_params, drift = case
+    t_a, fr_a, sp_a, ag_a = _run(riab, True, B, make_pop, schedule, env_params, drift)
+    assert ag_a._streamer is not None, "the flag-coupled pipeline did not run"
+    assert ag_a.diagnostics["pipeline_timeouts"] == 0
+    t_b, fr_b, sp_b, ag_b = _run(riab, False, B, make_pop, schedule, env_params, drift)
+    assert ag_b._streamer is None
+    assert t_a.shape == t_b.shape and fr_a.shape == fr_b.shape and sp_a.shape == sp_b.shape
+    np.testing.assert_array_equal(t_a, t_b)
+    np.testing.assert_array_equal(fr_a, fr_b)
+    np.testing.assert_array_equal(sp_a, sp_b)
+    np.testing.assert_array_equal(ag_a.state_tensor.cpu().numpy(), ag_b.state_tensor.cpu().numpy())
+    assert ag_a.t == pytest.approx(ag_b.t) and ag_a._step_index == ag_b._step_index
+
+
+def test_fused_rates_match_oracle_on_its_own_rows(riab):
+    """Independent of the chunked path: the rates the pipeline wrote are the oracle's rates at the positions the
+    pipeline's own trajectory rows hold (1e-5 relative, north_star) — for every time row of a 20-step run at the
+    bench shape, so a row evaluated before it was published cannot hide."""
+    os.environ.pop("RIAB_NO_FUSED", None)
+    env, ag, pcs = _world(riab, 4096, _pc(1024, save_spikes=False))
+    ag.simulate(20)
+    torch.cuda.synchronize()
+    assert ag._streamer is not None and ag.diagnostics["pipeline_timeouts"] == 0
+    traj = ag.get_history_tensor().cpu().numpy()
+    fr = pcs.get_history_tensors()[0].cpu().numpy()
+    oenv = orc.EnvSpec(walls=np.zeros((0, 2, 2)))
+    for t in range(20):
+        pos = np.stack((traj[t, 0], traj[t, 1]), -1).astype(np.float64)
+        ref = orc.place_cells(oenv, pos, pcs.place_cell_centres, pcs.place_cell_widths)
+        np.testing.assert_allclose(fr[t], ref, rtol=1e-5, atol=1e-37)
+
+
+def test_fused_many_calls_and_long_run(riab):
+    """Progress words are absolute step counts and are never reset: many back-to-back calls (no synchronisation
+    in between), then one long call, all equal to the chunked path."""
+    sched = [("sim", 5)] * 12 + [("sim", 700)]
+    t_a, fr_a, _sp, ag_a = _run(riab, True, 1024, _pc(128, save_spikes=False), sched)
+    assert ag_a.diagnostics["pipeline_timeouts"] == 0
+    t_b, fr_b, _sp, _ag = _run(riab, False, 1024, _pc(128, save_spikes=False), sched)
+    np.testing.assert_array_equal(t_a, t_b)
+    np.testing.assert_array_equal(fr_a, fr_b)
+
+
+def test_fused_without_history_keeps_last_rows(riab):
+    """save_history=False: the rates stream through a ring; the newest row is what `firingrate` shows."""
+    res = []
+    for fused in (True, False):
+        os.environ["RIAB_NO_FUSED"] = "0" if fused else "1"
+        try:
+            env, ag, pcs = _world(riab, 512, _pc(96, save_history=False), agent_params={"save_history": False})
+            ag.simulate(300, chunk=32)
+            torch.cuda.synchronize()
+            res.append((np.asarray(ag.pos), pcs.firingrate))
+            if fused:
+                assert ag._streamer is not None and ag.diagnostics["pipeline_timeouts"] == 0
+        finally:
+            os.environ.pop("RIAB_NO_FUSED", None)
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_fused_launch_modes(riab, mode):
+    """Both ways of getting the two kernels to run concurrently (second stream behind a gate kernel / one stream
+    with an any-order launch) give the same, correct results; whether they overlap is a performance matter."""
+    os.environ["RIAB_STREAM_MODE"] = mode
+    try:
+        t_a, fr_a, _sp, ag_a = _run(riab, True, 1024, _pc(256, save_spikes=False), [("sim", 48), ("sim", 16)])
+        assert ag_a.diagnostics["pipeline_timeouts"] == 0
+    finally:
+        os.environ.pop("RIAB_STREAM_MODE", None)
+    t_b, fr_b, _sp, _ag = _run(riab, False, 1024, _pc(256, save_spikes=False), [("sim", 48), ("sim", 16)])
+    np.testing.assert_array_equal(t_a, t_b)
+    np.testing.assert_array_equal(fr_a, fr_b)
+
+
+def test_fused_falls_back_for_uncovered_populations(riab):
+    """one_hot PlaceCells (and anything else the stream kernel does not cover) take the chunked path and give
+    the same answer as before; nothing is left half-reserved in the histories."""
+    os.environ.pop("RIAB_NO_FUSED", None)
+    env, ag, pcs = _world(riab, 512, _pc(32, description="one_hot"))
+    ag.simulate(10)
+    ag.simulate(6)
+    torch.cuda.synchronize()
+    assert len(ag.history["t"]) == 16 and pcs.history["firingrate"].shape == (16, 32, 512)
+    assert np.all(pcs.history["firingrate"].sum(axis=1) == 1.0)
+
+
+def test_history_view_after_plan_steps(riab):
+    """read Ag.history, step a plan, read again — the second read must see the new rows."""
+    env, ag, pcs = _world(riab, 256, _pc(16))
+    plan = ag.make_step_plan(capacity=32)
+    plan.step(5)
+    assert ag.history["pos"].shape[0] == 5 and pcs.history["firingrate"].shape[0] == 5
+    plan.step(5)
+    assert ag.history["pos"].shape[0] == 10 and pcs.history["firingrate"].shape[0] == 10
+    assert len(ag.get_history_arrays()["t"]) == 10
+    # an eager Neurons.update() / reset_history() closes the plan instead of sharing its open rows
+    ag.update()
+    pcs.update()
+    assert ag._plan is None and pcs.history["firingrate"].shape[0] == 11
+    with pytest.raises(RuntimeError):
+        plan.step(1)
+
+
+def test_two_agent_objects_draw_different_noise(riab):
+    np.random.seed(3)
+    env = riab.Environment()
+    a0 = riab.Agent(env, {"n_agents": 64, "dt": 0.01})
+    a1 = riab.Agent(env, {"n_agents": 64, "dt": 0.01})
+    a1.pos, a1.velocity = a0.pos, a0.velocity
+    a1.head_direction, a1.measured_velocity = a0.head_direction, a0.measured_velocity
+    for _ in range(5):
+        a0.update()
+        a1.update()
+    assert not np.allclose(a0.pos, a1.pos), "two Agent objects replayed the same Philox streams"
+
+
+def _bench(args, extra_env=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **(extra_env or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_contract_line_on_the_drivers_command(riab):
+    """`bench.py --gpus 1 --steps 20 --warmup 5` must carry a non-null roofline whose numbers are
+    consistent with the line's own value."""
+    out = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5 and out["repeats"] >= 3
+    rf = out["roofline"]
+    assert rf is not None and rf["bound"] == "hbm" and rf["launches"] == out["repeats"]
+    assert 0.0 < rf["frac"] <= 1.0 and rf["units_per_launch"] == 4096 * 20
+    # the dominant kernel cannot take longer than the region it is timed in
+    assert rf["avg_launch_ms"] <= out["timed_region_ms"]["max"]
+    assert out["diagnostics"].get("pipeline_timeouts", 0) == 0
+    assert abs(out["value"] - 4096 * 20 / (out["timed_region_ms"]["median"] * 1e-3)) / out["value"] < 1e-3
+
+
+def test_bench_launches_its_own_ranks(riab):
+    """`python bench.py --gpus 2` (no launcher) must start two ranks and say so.  Both ranks share
+    this box's one GPU (RIAB_BENCH_SHARE_GPU: gloo control plane), which exercises everything but RCCL."""
+    out = _bench(["--gpus", "2", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"], {"RIAB_BENCH_SHARE_GPU": "1"})
+    assert out["n_gpus"] == 2 and out["steps"] == 64
+    assert out["config"]["parallelism"].startswith("agent-sharded x2")
+    assert out["value"] > 1e6 and out["diagnostics"].get("pipeline_timeouts", 0) == 0

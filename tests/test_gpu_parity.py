@@ -230,7 +230,8 @@ def test_production_rng_matches_host_philox(riab):
 # ----------------------------------------------------------------------------- Neurons.update / spikes
 def test_update_noise_and_spikes_vs_reference(riab):
     """G4: Neurons.update end to end for one agent with the reference's recorded noise
-    normals and spike uniforms: rates within 1e-5, spikes bit-exact."""
+    normals and spike uniforms: rates within 1e-5 relative (north_star) + 1e-5 x noise_std absolute for the
+    additive zero-mean OU term (firingrate = rate + noise passes through zero), spikes bit-exact."""
     g = gu.load("update_init.npz")
     dt = float(g["upd_dt"])
     Ag = riab.Agent(make_env(riab), {"dt": dt})
@@ -240,7 +241,7 @@ def test_update_noise_and_spikes_vs_reference(riab):
         Ag.pos = g["upd_pos"][t]
         Ag.t += dt
         PCs.update(spike_uniforms=g["upd_u"][t][:, None], noise_normals=g["upd_z"][t][:, None])
-        np.testing.assert_allclose(PCs.firingrate, g["upd_fr"][t], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(PCs.firingrate, g["upd_fr"][t], rtol=1e-5, atol=1e-5 * 0.5)
     assert np.array_equal(PCs.history["spikes"], g["upd_spikes"])
     np.testing.assert_allclose(PCs.noise, g["upd_noise"][-1], rtol=1e-4, atol=1e-5)
 
