@@ -342,7 +342,9 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = round(json.load(f).get("hbm_bytes_per_unit") * avg_units)  # PMC bytes/unit x units/launch
-        kname = ("rate_stream_kernel" if fused_mode else "rate_kernel_wide") + f"<{type(pops[0]).__name__}>"
+        poll_max = int(os.environ.get("RIAB_STREAM_POLL_MAX", 256))
+        kname = (("rate_kernel_gated" if K <= poll_max else "rate stage = rate_kernel_wide per chunk behind progress gates")
+                 if fused_mode else "rate_kernel_wide") + f"<{type(pops[0]).__name__}>"
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": kname, "launches": len(ms),
@@ -353,8 +355,10 @@ def main():
                     "kernel_own_bytes_per_unit": own_bytes,
                     "frac_of_measured_copy_bw_6290": round(achieved / 6290.0, 4)}
         if fused_mode:
-            roofline["note"] = ("persistent rate kernel, concurrent with the trajectory kernel whose rows it consumes "
-                                "(flag-coupled, one launch each per timed region): its duration includes waiting for rows")
+            roofline["note"] = ("the rate stage runs concurrently with the trajectory kernel whose rows it consumes (coupled "
+                                "by flags in device memory, one native call per timed region): its duration includes "
+                                "waiting for rows; up to 256 steps it is ONE kernel (every wave waits for its rows), beyond "
+                                "that one rate_kernel_wide launch per chunk of rows behind a one-wave progress gate")
             if warm_ms is not None:  # rocprofv3 --stats averages over ALL launches of the process, warm-up included
                 roofline["avg_launch_ms_incl_warmup_launch"] = round(float(np.mean(ms + [warm_ms])), 5)
                 roofline["warmup_launch_ms"] = round(warm_ms, 5)

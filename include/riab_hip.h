@@ -525,33 +525,41 @@ double riab_plan_task_clock(const RiabPlan* plan);
  * `for t in range(T): Agent.update(); N.update()` (demos/simple_example.ipynb cell 4) for one
  * population N, with no kernel boundary between the two stages: the trajectory kernel (the
  * riab_agent_step kernel in Philox mode, float64) publishes its history rows write-through and a
- * per-workgroup "steps done" word every four steps; a PERSISTENT firing-rate kernel running
- * concurrently polls those words and evaluates time row t as soon as the 256 agents of its wave
- * have been stepped past t.  Results are bit-identical to riab_agent_step followed by the
+ * per-workgroup "steps done" word every four steps; the firing-rate kernel, launched once for all T
+ * rows and running concurrently, lets every wave wait on those words and evaluates time row t as soon
+ * as the 256 agents of the wave have been stepped past t.  Results are bit-identical to riab_agent_step followed by the
  * population's own entry point on the finished trajectory.
  *
  * A RiabStreamer owns what the coupling needs besides the kernels: a second HIP stream, two
  * events, and the running count of started trajectory workgroups.
  *
- *  ctrl   device uint32 [RIAB_CTRL_PROGRESS + B/64], zeroed ONCE by the caller when it is created
+ *  ctrl   device uint32 [RIAB_CTRL_WORDS(B)], zeroed ONCE by the caller when it is created
  *         (not per call: progress words hold absolute step counts, the started word accumulates):
  *         [RIAB_CTRL_STARTED] trajectory workgroups that have become resident (all calls),
  *         [RIAB_CTRL_TIMEOUTS] waves that gave up waiting (must stay 0; results are invalid otherwise),
  *         [RIAB_CTRL_ABORT] set with the first timeout: every later wait returns at once,
- *         [RIAB_CTRL_PROGRESS + w] (uint32)(step0 + steps whose rows workgroup w has published).
+ *         [RIAB_CTRL_PROGRESS_WORD(w)] (uint32)(step0 + steps whose rows trajectory workgroup w (agents 64w ..
+ *         64w+63) has published).  The four words of a 256-agent sub-segment share one 128-byte line that no
+ *         other sub-segment touches: every wave of the rate kernel reads exactly one such line, and with all of
+ *         them in ONE line (first layout) that line — rewritten by 64 workgroups every few microseconds, so
+ *         never served from L2 — throttled the rate kernel to 2.3 TB/s while the trajectory kernel ran [MI355X].
  *  pop    the population: kind RIAB_POP_PLACE (not one_hot) / RIAB_POP_GRID / RIAB_POP_HDC, its table and
  *         parameters, io.min_fr / max_fr / pop_id, rates_base [capacity_rows][n][B] and spikes_base (or NULL);
- *         capacity_rows < T makes the rate rows a ring (row t % capacity_rows).
+ *         capacity_rows >= T (callers that stream through fewer rows issue one call per buffer length: inside
+ *         a call the rate waves are several time rows apart, so rows of one call must not alias).
  *  hist   device float32 [T][8][B], required (the rate kernel reads it in place)
  *  B      a multiple of 256 (four whole trajectory workgroups per rate wave)
- *  wgs_per_cu  rate workgroups (256 threads) launched per compute unit, 0 = default
+ *  T      at most 65535 per call (time rows are the z axis of the rate kernel's grid)
+ *  wgs_per_cu  unused (sized the resident grid of an earlier, persistent form of the rate kernel); pass 0
  *  mode   0: the rate kernel on the streamer's second stream behind a gate kernel that waits until every
  *            trajectory workgroup is resident (the rate kernel would otherwise be able to fill the chip
  *            with waiting waves before the kernel they wait for has been placed);
  *         1: both kernels on `stream`, the second launched with hipExtAnyOrderLaunch (experimental)
  * Returns RIAB_EUNSUPPORTED (nothing launched) for populations / shapes it does not cover: callers fall
  * back to riab_agent_step + the population's entry point. */
-enum { RIAB_CTRL_STARTED = 0, RIAB_CTRL_TIMEOUTS = 1, RIAB_CTRL_ABORT = 2, RIAB_CTRL_PROGRESS = 16 };
+enum { RIAB_CTRL_STARTED = 0, RIAB_CTRL_TIMEOUTS = 1, RIAB_CTRL_ABORT = 2, RIAB_CTRL_PROGRESS = 32 };
+#define RIAB_CTRL_PROGRESS_WORD(w) (RIAB_CTRL_PROGRESS + 32 * ((w) >> 2) + ((w) & 3))
+#define RIAB_CTRL_WORDS(B) (RIAB_CTRL_PROGRESS + 32 * (((B) + 255) / 256))
 typedef struct RiabStreamer RiabStreamer;
 RiabStreamer* riab_streamer_create(void);
 void riab_streamer_destroy(RiabStreamer* h);

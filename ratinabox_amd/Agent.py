@@ -61,8 +61,15 @@ class Agent:
             self.name = f"agent_{self.agent_idx}"
         self.Environment.add_agent(agent=self)
 
+        self._explicit_rng = "seed" in params or "agent_id0" in params
         self.n_agents = int(self.n_agents)
         assert self.n_agents >= 1
+        for other in self.Environment.Agents[:self.agent_idx]:
+            lo, hi = int(other.agent_id0), int(other.agent_id0) + int(other.n_agents)
+            if other.rng_seed == self.rng_seed and lo < int(self.agent_id0) + self.n_agents and int(self.agent_id0) < hi:
+                import warnings
+                warnings.warn(f"{self.name} and {other.name} share the RNG key {self.rng_seed} and overlapping agent ids: "
+                              "they will draw IDENTICAL noise (give them different `seed`s or disjoint `agent_id0` ranges)")
         assert self.agent_id0 % 4 == 0, "agent_id0 must be a multiple of 4"
         self._B = self.n_agents
         self._Bp = (self.n_agents + 3) // 4 * 4  # kernels need a multiple of 4 on the agent axis
@@ -113,11 +120,12 @@ class Agent:
         """Philox key of this Agent OBJECT's streams (motion noise, neuron noise, spikes).  The reference's agents
         all draw from the global np.random stream and are independent of each other; here every stream is a pure
         function of (key, global agent id, population, step), so a second Agent object of the same Environment
-        with the same `seed` and id range would replay the first one's noise.  The object's index in
-        `Environment.Agents` is therefore folded into the key (agent 0 keeps `seed` itself; shards of ONE logical
-        agent population on several GPUs are each agent 0 of their own Environment and share the key, which is
-        what makes results independent of the sharding)."""
-        if self.agent_idx == 0:
+        with the same key and id range replays the first one's noise.  An Agent constructed WITHOUT an explicit
+        `seed` / `agent_id0` therefore gets the object's index in `Environment.Agents` folded into its key
+        (agent 0 keeps `seed` itself).  Explicit `seed` / `agent_id0` are taken as given — that is how shards of
+        one logical population reproduce the same agents on any number of GPUs — and a warning is raised at
+        construction when two Agents of an Environment then share a key with overlapping id ranges."""
+        if self.agent_idx == 0 or self._explicit_rng:
             return int(self.seed)
         return (int(self.seed) + self.agent_idx * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
 
@@ -394,7 +402,7 @@ class Agent:
             if not h:
                 raise _L.RiabError("riab_streamer_create failed")
             self._streamer = _L.C.c_void_p(h)
-            self._ctrl = torch.zeros(_L.CTRL_PROGRESS + self._Bp // 64, dtype=torch.int32, device=self._device)
+            self._ctrl = torch.zeros(_L.ctrl_words(self._Bp), dtype=torch.int32, device=self._device)
         has_drift = drift_velocity is not None
         m = self._motion(dt, has_drift, ratio, {})
         env, _walls = self.Environment.device_tables(self._device)
@@ -405,40 +413,54 @@ class Agent:
         else:
             traj = torch.empty((n_steps, _L.HIST_ROWS, self._Bp), dtype=torch.float32, device=self._device)
         out = N._reserve_rows(n_steps, ring=min(chunk, n_steps))
-        pop.rates_base = out["fr"].data_ptr()
-        pop.spikes_base = out["sp"].data_ptr() if out["sp"] is not None else None
-        pop.capacity_rows = out["fr"].shape[0]
+        fr, sp = out["fr"], out["sp"]
+        # rates kept in full: one launch for all steps.  Rates streamed through a ring (save_history=False): one
+        # launch per ring length — inside a launch the persistent waves are many time rows apart, so rows of one
+        # launch must not alias; launches are ordered by the stream.
+        piece = min(n_steps if out["ring"] is None else int(out["ring"]), 32768)  # (time rows are the grid's z axis)
         import os
-        rc = _L.lib.riab_simulate_fused(self._streamer, env, m, _L.ptr(self._state), self._Bp, int(self.agent_id0),
-                                        _L.ptr(drift), int(self.rng_seed), int(self._step_index), n_steps, _L.ptr(traj),
-                                        _L.ptr(self._diag), pop, _L.ptr(self._ctrl),
-                                        int(os.environ.get("RIAB_STREAM_WGS_PER_CU", 0)),
-                                        int(os.environ.get("RIAB_STREAM_MODE", 0)), 1 if self._time_rate_kernel else 0,
-                                        _L.current_stream())
-        if rc == _L.EUNSUPPORTED:  # (nothing was launched; the reserved rows are reused by the chunked path)
-            if self.save_history:
-                self._hist.unreserve(n_steps)
-            N._unreserve_rows(out, n_steps)
-            return None
-        _L.check(rc, "riab_simulate_fused")
+        wgs = int(os.environ.get("RIAB_STREAM_WGS_PER_CU", 0))
+        mode = int(os.environ.get("RIAB_STREAM_MODE", 0))
+        t0 = 0
+        while t0 < n_steps:
+            tc = min(piece, n_steps - t0)
+            rows0 = t0 if out["ring"] is None else 0
+            pop.rates_base = fr[rows0].data_ptr()
+            pop.spikes_base = sp[rows0].data_ptr() if sp is not None else None
+            pop.capacity_rows = tc
+            rc = _L.lib.riab_simulate_fused(self._streamer, env, m, _L.ptr(self._state), self._Bp, int(self.agent_id0),
+                                            _L.ptr(drift), int(self.rng_seed), int(self._step_index) + t0, tc,
+                                            _L.ptr(traj[t0]), _L.ptr(self._diag), pop, _L.ptr(self._ctrl), wgs, mode,
+                                            1 if self._time_rate_kernel else 0, _L.current_stream())
+            if rc == _L.EUNSUPPORTED and t0 == 0:  # (nothing was launched; the chunked path reserves its own rows)
+                if self.save_history:
+                    self._hist.unreserve(n_steps)
+                N._unreserve_rows(out, n_steps)
+                return None
+            _L.check(rc, "riab_simulate_fused")
+            t0 += tc
         self.dt = dt
         self._keep = (drift, _walls, traj, out, pop)
         self._last_row = traj[n_steps - 1]
-        t = self.t
-        times = [t + dt * (i + 1) for i in range(n_steps)] if (self.save_history or N.save_history) else None
-        self.prev_t = self.t + dt * (n_steps - 1)
-        self.t = self.t + dt * n_steps
+        self._last_fused_units = self._Bp * tc  # agent-steps of the launch `last_rate_kernel_ms` refers to
+        t, times = self.t, []
+        for _ in range(n_steps):  # (the reference's clock: repeated `t += dt`, not t0 + i*dt)
+            self.prev_t = t
+            t += dt
+            times.append(t)
+        self.t = t
         if self.save_history:
             self._times.extend(times)
         self._step_index += n_steps
         if out["ring"] is not None:
-            out["last"] = out["fr"][(n_steps - 1) % out["ring"]]
+            out["last"] = fr[(n_steps - 1) % piece]
         N._finish_rows(out, n_steps, times)
         return traj
 
     def last_rate_kernel_ms(self):
-        """Duration of the rate kernel of the last fused simulate() (HIP events on the stream it ran on), after a
-        device synchronisation; None when not timed (`Agent._time_rate_kernel = True` enables it)."""
+        """Duration of the rate stage of the last fused simulate() — one kernel for runs of up to 256 steps, a
+        sequence of kernels behind progress gates for longer ones — from HIP events on the stream it ran on, after
+        a device synchronisation; None when not timed (`Agent._time_rate_kernel = True` enables it)."""
         if self._streamer is None:
             return None
         ms = float(_L.lib.riab_streamer_last_rate_ms(self._streamer))

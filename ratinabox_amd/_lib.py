@@ -89,7 +89,12 @@ TD_REWARD_OVERFLOW, TD_LATE_COMPLETIONS, TD_EPLOG_OVERFLOW, TD_RESETS = range(4)
 POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4, "ff": 5, "velocity": 6, "speed": 7, "random_spatial": 8}
 EFULL = -5
 EUNSUPPORTED = -4
-CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_PROGRESS = 0, 1, 2, 16  # riab_hip.h RIAB_CTRL_*
+CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_PROGRESS = 0, 1, 2, 32  # riab_hip.h RIAB_CTRL_*
+
+
+def ctrl_words(B):
+    """RIAB_CTRL_WORDS(B): control words of the flag-coupled pipeline for B agents."""
+    return CTRL_PROGRESS + 32 * ((int(B) + 255) // 256)
 
 ACTIVATIONS = {"linear": 0, "sigmoid": 1, "relu": 2, "tanh": 3, "retanh": 4, "softmax": 5}
 

@@ -393,6 +393,16 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
         s_z[batch & 1][i][1][lane] = d.z_spd;
       }
     };
+    // PUB: rows of steps < n have left this wave write-through and been acknowledged: the consumer may read them
+    auto publish = [&](int n) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        __hip_atomic_store((riab_gu32*)(uintptr_t)(a.ctrl + RIAB_CTRL_PROGRESS_WORD(blockIdx.x)), (uint32_t)a.step0 + (uint32_t)n,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // Short launches publish a block as soon as the stepping wave has been released for the next one (latency
+    // matters, and the rate kernel has not saturated HBM for long); long ones one block later (see finish_block).
+    const bool early_pub = a.T <= 64;
     auto finish_block = [&](int buf, int t0, int n_steps) {
       for (int i = 0; i < n_steps; ++i) {
         tl = step_tail<R>(tl, (R)s_dp[buf][i][0][lane], (R)s_dp[buf][i][1][lane], tail_c, a.step0 + (uint64_t)(t0 + i),
@@ -409,18 +419,15 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
           sh[7 * 64] = (float)tl.dist;
         }
       }
+      // The previous block's rows were stored one block ago (a whole block of the stepping wave's time plus this
+      // block's tails): by now they are acknowledged and the wait below is free.  Waiting right after the stores
+      // instead put the write-through latency under a saturated HBM on the stepping wave's barrier (the pair of
+      // kernels then ran at 3.9-4.3 us per step [MI355X]).
+      if (PUB && !early_pub && t0 > 0) publish(t0);
       if (a.hist) {
         __builtin_amdgcn_wave_barrier();  // (LDS serves a wave's requests in order: the reads below see the writes)
         flush_hist(0, t0, n_steps);
         __builtin_amdgcn_wave_barrier();
-      }
-      if (PUB) {
-        // every row of steps < t0 + n_steps has left this wave write-through; once the stores are acknowledged
-        // the consumer may read them: publish the absolute step count (no per-launch reset of the word needed)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
-          __hip_atomic_store((riab_gu32*)(uintptr_t)(a.ctrl + RIAB_CTRL_PROGRESS + blockIdx.x),
-                             (uint32_t)a.step0 + (uint32_t)(t0 + n_steps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     };
     if (PUB && lane == 0) atomicAdd(a.ctrl + RIAB_CTRL_STARTED, 1u);  // this workgroup is resident
@@ -429,11 +436,14 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
     __syncthreads();  // noise batch 0 ready
     const int n_blocks = (a.T + 3) >> 2;
     for (int k = 0; k < n_blocks; ++k) {
+      if (PUB && early_pub && k >= 2) publish(4 * (k - 1));  // the rows flushed before the last barrier
       if ((k & 3) == 0 && (k / 4 + 1) * RIAB_Z_BATCH < a.T) draw_batch(k / 4 + 1);
       if (k > 0) finish_block((k - 1) & 1, 4 * (k - 1), 4);
       __syncthreads();  // block k is handed over; noise for block k + 1 is ready
     }
+    if (PUB && early_pub && n_blocks >= 2) publish(4 * (n_blocks - 1));
     finish_block((n_blocks - 1) & 1, 4 * (n_blocks - 1), a.T - 4 * (n_blocks - 1));
+    if (PUB) publish(a.T);
     st[5 * B] = (double)tl.mvx;
     st[6 * B] = (double)tl.mvy;
     st[7 * B] = (double)tl.mrot;

@@ -537,192 +537,133 @@ __global__ __launch_bounds__(256) void fill_kernel(float* dst, int64_t n4, float
   if (i < n4) reinterpret_cast<v4f*>(dst)[i] = v4f{value, value, value, value};
 }
 
-// ---- persistent consumer of a trajectory that is still being written (riab_simulate_fused) -------------------
+// ---- consumer of a trajectory that is still being written (riab_simulate_fused) --------------------------------
 // The trajectory kernel (riab_agent_kernel.h, PUB variant) publishes, per workgroup of 64 agents, how many steps
 // of history rows it has written (write-through stores, then ctrl[RIAB_CTRL_PROGRESS + workgroup]).  This kernel
-// is launched ONCE for all T time rows with a grid that stays resident; a WAVE walks the items
-//   (time row t, group of GPI x CPB cells, 256-agent sub-segment q)          -- q fastest, then group, then t --
-// with stride = number of waves, so that at any moment the resident waves write one contiguous window of
-// out[t][c][b] in address order (what made the wide kernel's store stream fast, tools/store_bench.hip).
-//   * vmcnt retires in order on gfx9 — a wave that waits for a load also waits for every store issued before
-//     it.  The loop is therefore software-pipelined by hand: the positions and cell parameters of item k+1 are
-//     requested BEFORE the stores of item k are issued, so using them only needs vmcnt(stores of k).
-//   * readiness: lanes 0-3 read the four progress words of the wave's sub-segment (relaxed agent-scope loads),
-//     the minimum is cached ("rows below `known` are published"); with the stride a multiple of the number of
-//     sub-segments a wave keeps its q and polls only when it catches up with the trajectory.
-//   * positions are read with agent-scope (sc1) loads: the producer's stores are write-through, the lines are
-//     never in this CU's L1 before they are published, and sc1 loads do not allocate there.
-//   * every wait is bounded: a wave that gives up sets ctrl[RIAB_CTRL_ABORT] (all other waits then return
-//     at once) and counts itself in ctrl[RIAB_CTRL_TIMEOUTS]; the host treats a non-zero count as an error.
+// is rate_kernel_wide launched ONCE for all T time rows — same grid (1024-agent segments, CPB-cell groups, time
+// rows; x fastest), same address-ordered store stream — in which every WAVE first waits until the four
+// trajectory workgroups of its 256 agents have published row t:
+//   * workgroups are dispatched in grid order, so only the waves at the frontier ever wait, and what they wait for
+//     is produced by a kernel that is already resident (the gate kernel below guarantees that): no deadlock;
+//   * the wait is one relaxed agent-scope load of four words by four lanes + s_sleep with back-off; it is
+//     bounded: a wave that gives up sets ctrl[RIAB_CTRL_ABORT] (every later wait returns at once) and counts
+//     itself in ctrl[RIAB_CTRL_TIMEOUTS]; the host treats a non-zero count as an error;
+//   * positions are then read with agent-scope (sc1) loads: the producer's stores are write-through (sc1), the
+//     pairing MI355X_MICROARCH.md lists as valid without a cache-invalidating acquire.
+// Why not a persistent kernel (a resident grid whose waves stride over the items; built and measured first, see
+// tools/stream_bench.hip): a persistent wave holds its stores' credits — vmcnt retires in order, at most 63 in
+// flight — whereas a wave of this kernel ENDS after its stores and the slot is refilled at once.  With the
+// PlaceCells arithmetic in front of every store the persistent form reached 5.5-5.8 TB/s in every item shape
+// (5.3 in the real kernel), the non-persistent one with a poll per wave 6.2-6.3 [MI355X].
 struct StreamArgs {
   uint32_t* ctrl;
   uint32_t step_base;     // (uint32) step0 of the launch: progress words are absolute step counts
-  int32_t T;
-  int32_t ring;           // rows of the rates / spikes buffers; row = t % ring (ring >= T: row = t)
-  int32_t groups;         // items per (t, q): ceil(n / (GPI * CPB))
-  int32_t q256;           // 256-agent sub-segments per time row
-  int32_t d_t, d_g, d_q;  // the stride (number of waves) in the mixed radix (groups, q256)
   uint32_t spin_limit;
 };
 
-// rows of sub-segment q published so far, relative to this launch (0 .. T); INT_MAX once the pipeline was aborted
+// rows of sub-segment q published so far, relative to this launch: one 16-byte read of the sub-segment's own line
 __device__ __forceinline__ int stream_progress(const StreamArgs& s, uint32_t q, int lane) {
   int rel = 0x7fffffff;
   if (lane < 4) {
-    const uint32_t v = __hip_atomic_load((gu32*)(uintptr_t)(s.ctrl + RIAB_CTRL_PROGRESS + 4 * q + lane), __ATOMIC_RELAXED,
+    const uint32_t v = __hip_atomic_load((gu32*)(uintptr_t)(s.ctrl + RIAB_CTRL_PROGRESS + 32 * q + lane), __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
     rel = (int)(v - s.step_base);      // stale words of earlier launches are <= step_base
     rel = rel < 0 ? 0 : rel;
   }
-  uint32_t ab = 0;
-  if (lane == 4)
-    ab = __hip_atomic_load((gu32*)(uintptr_t)(s.ctrl + RIAB_CTRL_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int r0 = __builtin_amdgcn_readlane(rel, 0), r1 = __builtin_amdgcn_readlane(rel, 1);
   const int r2 = __builtin_amdgcn_readlane(rel, 2), r3 = __builtin_amdgcn_readlane(rel, 3);
-  const int k = min(min(r0, r1), min(r2, r3));
-  return __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane((int)ab, 4) ? 0x7fffffff : k);
+  return __builtin_amdgcn_readfirstlane(min(min(r0, r1), min(r2, r3)));
 }
-// wait until row t of sub-segment q is published; returns the cached bound (rows < bound are published)
-__device__ __forceinline__ int stream_wait(const StreamArgs& s, uint32_t q, int t, int lane) {
+// wait until row t of sub-segment q is published
+__device__ __forceinline__ void stream_wait(const StreamArgs& s, uint32_t q, int t, int lane) {
   int known = stream_progress(s, q, lane);
   for (uint32_t spins = 0; known <= t; ++spins) {
+    const uint32_t ab = __hip_atomic_load((gu32*)(uintptr_t)(s.ctrl + RIAB_CTRL_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__builtin_amdgcn_readfirstlane((int)ab)) return;  // the pipeline was aborted: results are invalid anyway
     if (spins >= s.spin_limit) {
       if (lane == 0) {
         atomicAdd(s.ctrl + RIAB_CTRL_TIMEOUTS, 1u);
         __hip_atomic_store((gu32*)(uintptr_t)(s.ctrl + RIAB_CTRL_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      return 0x7fffffff;
-    }
-    __builtin_amdgcn_s_sleep(8);
-    known = stream_progress(s, q, lane);
-  }
-  return known;
-}
-
-template <class Cell, int SPK, int GPI>
-__global__ __launch_bounds__(256) void rate_stream_kernel(const RateArgs a, Cell cell, const StreamArgs s) {
-  __shared__ double s_lds[Cell::LDS_DOUBLES];
-  cell.stage(s_lds);
-  constexpr int NP = Cell::NP, CPB = Cell::CPB, CPI = GPI * CPB;
-  static_assert(NP * CPB <= 64, "a cell group's parameters must fit one wave");
-  const int lane = threadIdx.x & 63;
-  const uint32_t gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
-  // first item of this wave (the stride brings the later ones: incremental mixed-radix addition, all scalar)
-  uint32_t q = gw % (uint32_t)s.q256;
-  const uint32_t rest = gw / (uint32_t)s.q256;
-  uint32_t g = rest % (uint32_t)s.groups;
-  int t = (int)(rest / (uint32_t)s.groups);
-  if (t >= s.T) return;
-  // (read once, declared uniform: a reload behind the timeout path's atomics would make the loops below divergent)
-  const int n_cells = __builtin_amdgcn_readfirstlane(a.n);
-  const int last_param = n_cells * NP - 1;
-  // every lane loads (index clamped): no exec-masked loads, so the number of memory operations in flight is
-  // the same on every path and the compiler's s_waitcnt counts are exact (see the header comment)
-  auto load_params = [&](uint32_t gg, float (&m)[GPI]) {
-#pragma unroll
-    for (int i = 0; i < GPI; ++i) m[i] = cell.tab[min(((int)gg * GPI + i) * CPB * NP + lane, last_param)];
-  };
-  auto pos_off = [&](int tt, uint32_t qq) { return (int64_t)tt * a.pos_ld + (int64_t)qq * 256 + 4 * lane; };
-  struct Next {
-    uint32_t q, g;
-    int t;
-  };
-  auto advance = [&](uint32_t q0, uint32_t g0, int t0) {
-    uint32_t nq = q0 + (uint32_t)s.d_q;
-    const uint32_t cq = nq >= (uint32_t)s.q256 ? 1u : 0u;
-    nq -= cq ? (uint32_t)s.q256 : 0u;
-    uint32_t ng = g0 + (uint32_t)s.d_g + cq;
-    const uint32_t cg = ng >= (uint32_t)s.groups ? 1u : 0u;
-    ng -= cg ? (uint32_t)s.groups : 0u;
-    // (wave-uniform by construction; saying so keeps the item state in scalar registers and the loops scalar)
-    return Next{(uint32_t)__builtin_amdgcn_readfirstlane((int)nq), (uint32_t)__builtin_amdgcn_readfirstlane((int)ng),
-                __builtin_amdgcn_readfirstlane(t0 + s.d_t + (int)cg)};
-  };
-  // rates (+ spikes) of one item; GUARD: the item's last cells may not exist (n not a multiple of CPI)
-  auto emit = [&](auto guard, uint32_t qq, uint32_t gg, int tt, const typename Cell::Pos& P, const float (&m)[GPI]) {
-    constexpr bool GUARD = decltype(guard)::value;
-    const int row = (s.ring >= s.T) ? tt : tt % s.ring;
-    const int c00 = (int)gg * CPI;
-    int64_t off = ((int64_t)row * n_cells + c00) * a.B + (int64_t)qq * 256 + 4 * lane;
-    const uint32_t step = a.step0 + (uint32_t)tt;
-    const uint32_t group = a.group0 + qq * 64u + (uint32_t)lane;
-#pragma unroll
-    for (int i = 0; i < GPI; ++i) {
-#pragma unroll
-      for (int j = 0; j < CPB; ++j) {
-        const int c = c00 + i * CPB + j;
-        if (!GUARD || c < n_cells) {  // wave-uniform
-          float p[NP];
-#pragma unroll
-          for (int k = 0; k < NP; ++k)
-            p[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m[i]), j * NP + k));
-          v4f r = cell.eval(p, P);
-          r = finish_rate(r * a.fr_scale + a.fr_min, P);
-          *reinterpret_cast<v4f*>(a.rates + off) = r;
-          if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)c, group);
-          off += a.B;
-        }
-      }
-    }
-  };
-
-  int known = __builtin_amdgcn_readfirstlane(stream_wait(s, q, t, lane));
-  uint32_t known_q = q;
-  typename Cell::Pos P = cell.load_agent(a, pos_off(t, q));
-  float mine[GPI];
-  load_params(g, mine);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the end of the outer loop
-  for (;;) {
-    // ---- steady state: the next item's rows are known to be published.  Straight-line body: request the next
-    // item's operands, then evaluate and store this item (its operands were requested one iteration ago, BEFORE
-    // that iteration's stores: using them never waits for a store).
-    for (;;) {
-      const Next nx = advance(q, g, t);
-      const bool ahead = nx.t < s.T && nx.q == known_q && nx.t < known;
-      const bool whole = (int)(g + 1) * CPI <= n_cells;
-      if (!(ahead && whole)) break;
-      const typename Cell::Pos Pn = cell.load_agent(a, pos_off(nx.t, nx.q));
-      float mine_n[GPI];
-      load_params(nx.g, mine_n);
-      emit(std::false_type{}, q, g, t, P, mine);
-      q = nx.q;
-      g = nx.g;
-      t = nx.t;
-      P = Pn;
-#pragma unroll
-      for (int i = 0; i < GPI; ++i) mine[i] = mine_n[i];
-    }
-    // ---- this item without look-ahead; then wait for the next one's rows
-    emit(std::true_type{}, q, g, t, P, mine);
-    const Next nx = advance(q, g, t);
-    if (nx.t >= s.T) return;
-    known = __builtin_amdgcn_readfirstlane(stream_wait(s, nx.q, nx.t, lane));
-    known_q = nx.q;
-    q = nx.q;
-    g = nx.g;
-    t = nx.t;
-    P = cell.load_agent(a, pos_off(t, q));
-    load_params(g, mine);
-    // nothing in flight when the steady-state loop is (re-)entered: its wait counts then only reflect its own body
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (gfx9 encoding: expcnt / lgkmcnt fields at their maxima)
-  }
-}
-
-// the gate in front of the rate kernel on its stream: returns once every trajectory workgroup of this launch
-// is resident (ctrl[RIAB_CTRL_STARTED] has reached `target`), so that the persistent rate waves can never
-// occupy the slots the kernel they wait for still needs
-__global__ __launch_bounds__(64) void stream_gate_kernel(uint32_t* ctrl, uint32_t target, uint32_t spin_limit) {
-  if (threadIdx.x != 0) return;
-  for (uint32_t spins = 0;; ++spins) {
-    const uint32_t v = __hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_STARTED), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((int32_t)(v - target) >= 0) return;
-    if (__hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    if (spins >= spin_limit) {
-      atomicAdd(ctrl + RIAB_CTRL_TIMEOUTS, 1u);
-      __hip_atomic_store((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
-    __builtin_amdgcn_s_sleep(8);
+    // back off: the waves at the frontier all poll the same few lines
+    if (spins < 4) __builtin_amdgcn_s_sleep(4);
+    else if (spins < 16) __builtin_amdgcn_s_sleep(16);
+    else __builtin_amdgcn_s_sleep(48);
+    known = stream_progress(s, q, lane);
+  }
+}
+
+template <class Cell, int SPK, int CPB, bool SC1>
+__global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell cell, const StreamArgs s) {
+  __shared__ double s_lds[Cell::LDS_DOUBLES];
+  cell.stage(s_lds);
+  constexpr int NP = Cell::NP;
+  static_assert(NP * CPB <= 64, "a cell group's parameters must fit one wave");
+  const int lane = threadIdx.x & 63;
+  const int c0 = blockIdx.y * CPB;
+  const uint32_t t = blockIdx.z;
+  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t wq = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+  if (wq * 64u >= (uint32_t)a.qrow) return;  // (B is a multiple of 256: whole waves)
+  // one coalesced load brings the whole group's parameters into the wave (independent of the trajectory)
+  const int pi = c0 * NP + lane;
+  const float mine = (lane < NP * CPB && pi < a.n * NP) ? cell.tab[pi] : 0.0f;
+  stream_wait(s, wq, (int)t, lane);
+  const int64_t po = (int64_t)t * a.pos_ld + 4 * (int64_t)q;
+  const typename Cell::Pos P = SC1 ? cell.load_agent(a, po) : cell.load(a, po);
+  int64_t off = ((int64_t)t * a.n + c0) * a.B + 4 * (int64_t)q;
+  const uint32_t step = a.step0 + t;
+  const uint32_t group = a.group0 + q;
+#pragma unroll
+  for (int j = 0; j < CPB; ++j) {
+    if (c0 + j < a.n) {  // wave-uniform
+      float p[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        p[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), j * NP + i));
+      v4f r = cell.eval(p, P);
+      r = finish_rate(r * a.fr_scale + a.fr_min, P);
+      *reinterpret_cast<v4f*>(a.rates + off) = r;
+      if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)(c0 + j), group);
+      off += a.B;
+    }
+  }
+}
+
+// The gates on the rate kernels' stream (one wave each):
+//   started gate   returns once every trajectory workgroup of this launch is resident (ctrl[RIAB_CTRL_STARTED] has
+//                  reached `started_target`): the rate waves that follow can then never occupy the slots the kernel
+//                  they wait for still needs;
+//   progress gate  (n_traj > 0) additionally returns only once all n_traj trajectory workgroups have published
+//                  `progress_target` steps: what follows on the stream is a plain rate kernel for rows below that.
+__global__ __launch_bounds__(64) void stream_gate_kernel(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj,
+                                                         uint32_t progress_target, uint32_t spin_limit, uint32_t sleep_long) {
+  const int lane = threadIdx.x;
+  for (uint32_t spins = 0;; ++spins) {
+    const uint32_t v = __hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_STARTED), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = (int32_t)(v - started_target) >= 0;
+    if (ok) {
+      for (uint32_t w = lane; w < n_traj; w += 64) {
+        const uint32_t p = __hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_PROGRESS_WORD(w)), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        ok = ok && (int32_t)(p - progress_target) >= 0;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0) return;
+    if (__hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (spins >= spin_limit) {
+      if (lane == 0) {
+        atomicAdd(ctrl + RIAB_CTRL_TIMEOUTS, 1u);
+        __hip_atomic_store((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    // the started gate may have to sit out whatever was queued in front of the trajectory kernel (long sleeps);
+    // a progress gate is on the critical path of its chunk
+    if (sleep_long) __builtin_amdgcn_s_sleep(127);
+    else __builtin_amdgcn_s_sleep(16);
   }
 }
 
@@ -830,40 +771,30 @@ static int place_dispatch(const RiabEnv* env, const RiabRateIO* io, const float*
 }
 
 // ---- launch of the persistent consumer (called by riab_simulate_fused, riab_simulate.hip) --------------------
-template <class Cell, int GPI>
-static int launch_stream_cell(const RateArgs& a, const Cell& cell, StreamArgs st, int max_wgs, bool spikes, bool any_order,
-                              hipStream_t s) {
-  constexpr int CPI = GPI * Cell::CPB;
-  st.groups = (a.n + CPI - 1) / CPI;
-  const int64_t items = (int64_t)st.T * st.groups * st.q256;
-  if (items >= ((int64_t)1 << 31)) return RIAB_ETOOBIG;
-  // a grid that stays resident; the stride (waves) a multiple of the sub-segment count when possible, so that a
-  // wave keeps its 256 agents (its cached readiness bound stays valid) — and never more waves than items
-  int64_t wgs = max_wgs;
-  const int64_t need = (items + 3) / 4;
-  if (wgs > need) wgs = need;
-  {
-    int64_t unit = st.q256;  // waves per row of sub-segments; workgroups must supply a multiple of it
-    while (unit % 4 != 0) unit *= 2;
-    unit /= 4;               // workgroups
-    if (wgs >= unit) wgs -= wgs % unit;
-  }
-  if (wgs < 1) wgs = 1;
-  const int64_t nw = wgs * 4;
-  st.d_q = (int32_t)(nw % st.q256);
-  const int64_t rest = nw / st.q256;
-  st.d_g = (int32_t)(rest % st.groups);
-  st.d_t = (int32_t)(rest / st.groups);
-  const dim3 grid((unsigned)wgs), block(256);
+template <class Cell>
+static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamArgs& st, int T, bool spikes, bool plain_loads,
+                              bool any_order, hipStream_t s) {
+  constexpr int CPB = Cell::CPB;
+  const int64_t groups = (a.n + CPB - 1) / CPB;
+  if (T > 65535 || groups > 65535) return RIAB_ETOOBIG;  // grid y / z limits: the caller splits longer runs
+  const dim3 grid((unsigned)((a.qrow + 255) / 256), (unsigned)groups, (unsigned)T), block(256);
   const unsigned flags = any_order ? hipExtAnyOrderLaunch : 0u;
-  if (spikes) hipExtLaunchKernelGGL((rate_stream_kernel<Cell, 1, GPI>), grid, block, 0, s, nullptr, nullptr, flags, a, cell, st);
-  else hipExtLaunchKernelGGL((rate_stream_kernel<Cell, 0, GPI>), grid, block, 0, s, nullptr, nullptr, flags, a, cell, st);
+#define RIAB_GATED(SPKV, SC1V) \
+  hipExtLaunchKernelGGL((rate_kernel_gated<Cell, SPKV, CPB, SC1V>), grid, block, 0, s, nullptr, nullptr, flags, a, cell, st)
+  if (spikes) {
+    if (plain_loads) RIAB_GATED(1, false);
+    else RIAB_GATED(1, true);
+  } else {
+    if (plain_loads) RIAB_GATED(0, false);
+    else RIAB_GATED(0, true);
+  }
+#undef RIAB_GATED
   return (int)hipGetLastError();
 }
 
 template <int GX>
-static int launch_stream_place(const RiabEnv* env, const RiabPopulation* pop, const RateArgs& a, const StreamArgs& st,
-                               int max_wgs, int gpi, bool spikes, bool any_order, hipStream_t s) {
+static int launch_stream_place(const RiabEnv* env, const RiabPopulation* pop, const RateArgs& a, const StreamArgs& st, int T,
+                               bool spikes, bool plain_loads, bool any_order, hipStream_t s) {
   PlaceCell<RIAB_PC_GAUSSIAN, GX> c;
   c.tab = pop->table;
   c.scale = (float)env->scale;
@@ -875,19 +806,12 @@ static int launch_stream_place(const RiabEnv* env, const RiabPopulation* pop, co
   c.e0 = env->extent[0]; c.e1 = env->extent[1]; c.e2 = env->extent[2]; c.e3 = env->extent[3];
   c.lds = nullptr;
   switch (pop->description) {
-    case RIAB_PC_GAUSSIAN:
-      if (GX == 0 && gpi == 1) return launch_stream_cell<PlaceCell<RIAB_PC_GAUSSIAN, GX>, 1>(a, c, st, max_wgs, spikes, any_order, s);
-      if (GX == 0 && gpi == 4) return launch_stream_cell<PlaceCell<RIAB_PC_GAUSSIAN, GX>, 4>(a, c, st, max_wgs, spikes, any_order, s);
-      return launch_stream_cell<PlaceCell<RIAB_PC_GAUSSIAN, GX>, 2>(a, c, st, max_wgs, spikes, any_order, s);
+    case RIAB_PC_GAUSSIAN: return launch_stream_cell(a, c, st, T, spikes, plain_loads, any_order, s);
     case RIAB_PC_GAUSSIAN_THRESHOLD:
-      return launch_stream_cell<PlaceCell<RIAB_PC_GAUSSIAN_THRESHOLD, GX>, 2>(a, c.template as<RIAB_PC_GAUSSIAN_THRESHOLD>(), st,
-                                                                             max_wgs, spikes, any_order, s);
+      return launch_stream_cell(a, c.template as<RIAB_PC_GAUSSIAN_THRESHOLD>(), st, T, spikes, plain_loads, any_order, s);
     case RIAB_PC_DIFF_OF_GAUSSIANS:
-      return launch_stream_cell<PlaceCell<RIAB_PC_DIFF_OF_GAUSSIANS, GX>, 2>(a, c.template as<RIAB_PC_DIFF_OF_GAUSSIANS>(), st,
-                                                                            max_wgs, spikes, any_order, s);
-    case RIAB_PC_TOP_HAT:
-      return launch_stream_cell<PlaceCell<RIAB_PC_TOP_HAT, GX>, 2>(a, c.template as<RIAB_PC_TOP_HAT>(), st, max_wgs, spikes,
-                                                                  any_order, s);
+      return launch_stream_cell(a, c.template as<RIAB_PC_DIFF_OF_GAUSSIANS>(), st, T, spikes, plain_loads, any_order, s);
+    case RIAB_PC_TOP_HAT: return launch_stream_cell(a, c.template as<RIAB_PC_TOP_HAT>(), st, T, spikes, plain_loads, any_order, s);
     default: return RIAB_EUNSUPPORTED;  // one_hot scans every cell per position: not a streaming shape
   }
 }
@@ -910,11 +834,11 @@ int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B) {
 }
 
 int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t T, float dt,
-                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, int max_wgs, int gpi,
+                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, bool plain_loads,
                        uint32_t spin_limit, bool any_order, hipStream_t s) {
   int rc = stream_supported(env, pop, B);
   if (rc) return rc;
-  if (!hist || !ctrl || !pop->rates_base || T <= 0 || pop->capacity_rows <= 0 || agent_id0 % 4) return RIAB_EINVAL;
+  if (!hist || !ctrl || !pop->rates_base || T <= 0 || pop->capacity_rows < T || agent_id0 % 4) return RIAB_EINVAL;
   if ((((uintptr_t)hist | (uintptr_t)pop->rates_base) & 15) || ((uintptr_t)pop->spikes_base & 3)) return RIAB_EALIGN;
   RateArgs a;
   a.pos_x = hist + (int64_t)RIAB_H_POS_X * B;
@@ -941,43 +865,69 @@ int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const floa
   StreamArgs st;
   st.ctrl = ctrl;
   st.step_base = (uint32_t)step0;
-  st.T = T;
-  st.ring = (int32_t)(pop->capacity_rows < T ? pop->capacity_rows : T);
-  st.groups = 0;
-  st.q256 = (int32_t)(B / 256);
-  st.d_t = st.d_g = st.d_q = 0;
   st.spin_limit = spin_limit;
   const bool spikes = pop->spikes_base != nullptr;
   switch (pop->kind) {
     case RIAB_POP_PLACE:
-      if (env->periodic) return launch_stream_place<3>(env, pop, a, st, max_wgs, gpi, spikes, any_order, s);
+      if (env->periodic) return launch_stream_place<3>(env, pop, a, st, T, spikes, plain_loads, any_order, s);
       switch (pop->geometry) {
-        case RIAB_GEOM_EUCLIDEAN: return launch_stream_place<0>(env, pop, a, st, max_wgs, gpi, spikes, any_order, s);
-        case RIAB_GEOM_LINE_OF_SIGHT: return launch_stream_place<1>(env, pop, a, st, max_wgs, gpi, spikes, any_order, s);
-        case RIAB_GEOM_GEODESIC: return launch_stream_place<2>(env, pop, a, st, max_wgs, gpi, spikes, any_order, s);
+        case RIAB_GEOM_EUCLIDEAN: return launch_stream_place<0>(env, pop, a, st, T, spikes, plain_loads, any_order, s);
+        case RIAB_GEOM_LINE_OF_SIGHT: return launch_stream_place<1>(env, pop, a, st, T, spikes, plain_loads, any_order, s);
+        case RIAB_GEOM_GEODESIC: return launch_stream_place<2>(env, pop, a, st, T, spikes, plain_loads, any_order, s);
         default: return RIAB_EINVAL;
       }
     case RIAB_POP_GRID:
       if (pop->description == RIAB_GC_RECTIFIED) {
         GridCell<RIAB_GC_RECTIFIED> c{pop->table, pop->f0, 1.0f / (1.0f - pop->f0)};
-        return launch_stream_cell<GridCell<RIAB_GC_RECTIFIED>, 2>(a, c, st, max_wgs, spikes, any_order, s);
+        return launch_stream_cell(a, c, st, T, spikes, plain_loads, any_order, s);
       }
       if (pop->description == RIAB_GC_SHIFTED) {
         GridCell<RIAB_GC_SHIFTED> c{pop->table, pop->f0, 1.0f};
-        return launch_stream_cell<GridCell<RIAB_GC_SHIFTED>, 2>(a, c, st, max_wgs, spikes, any_order, s);
+        return launch_stream_cell(a, c, st, T, spikes, plain_loads, any_order, s);
       }
       return RIAB_EINVAL;
     case RIAB_POP_HDC: {
       HDCell<0> c{pop->table, 0.0f, nullptr, nullptr};
-      return launch_stream_cell<HDCell<0>, 1>(a, c, st, max_wgs, spikes, any_order, s);
+      return launch_stream_cell(a, c, st, T, spikes, plain_loads, any_order, s);
     }
     default: return RIAB_EUNSUPPORTED;
   }
 }
 
-int launch_stream_gate(uint32_t* ctrl, uint32_t target, uint32_t spin_limit, hipStream_t s) {
-  hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(64), 0, s, ctrl, target, spin_limit);
+int launch_stream_gate(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj, uint32_t progress_target,
+                       uint32_t spin_limit, bool sleep_long, hipStream_t s) {
+  hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(64), 0, s, ctrl, started_target, n_traj, progress_target, spin_limit,
+                     sleep_long ? 1u : 0u);
   return (int)hipGetLastError();
+}
+
+// rows [t0, t0 + tc) of a finished part of the trajectory through the population's ordinary kernel (the chunks of
+// a long riab_simulate_fused run, each behind a progress gate)
+int launch_rate_rows(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t t0, int32_t tc,
+                     float dt, uint64_t seed, uint64_t step0, int64_t agent_id0, hipStream_t s) {
+  RiabRateIO io = pop->io;
+  const float* row = hist + (int64_t)t0 * RIAB_HIST_ROWS * B;
+  io.pos_x = row + (int64_t)RIAB_H_POS_X * B;
+  io.pos_y = row + (int64_t)RIAB_H_POS_Y * B;
+  io.hd_x = row + (int64_t)RIAB_H_HD_X * B;
+  io.hd_y = row + (int64_t)RIAB_H_HD_Y * B;
+  io.pos_ld = (int64_t)RIAB_HIST_ROWS * B;
+  io.T = tc;
+  io.B = B;
+  io.rates = pop->rates_base + (int64_t)t0 * pop->n * B;
+  io.spikes = pop->spikes_base ? pop->spikes_base + (int64_t)t0 * pop->n * B : nullptr;
+  io.u_in = nullptr;
+  io.dt = dt;
+  io.seed = seed;
+  io.step0 = step0 + 1 + (uint64_t)t0;  // Neurons.update after the (step0 + t + 1)-th Agent.update
+  io.agent_id0 = agent_id0;
+  switch (pop->kind) {
+    case RIAB_POP_PLACE:
+      return riab_place_cells(env, &io, pop->table, pop->n, pop->description, pop->geometry, pop->top_hat_width, s);
+    case RIAB_POP_GRID: return riab_grid_cells(&io, pop->table, pop->n, pop->description, pop->f0, s);
+    case RIAB_POP_HDC: return riab_head_direction_cells(&io, pop->table, pop->n, s);
+    default: return RIAB_EUNSUPPORTED;
+  }
 }
 
 }  // namespace riab

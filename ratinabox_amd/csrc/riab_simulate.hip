@@ -5,8 +5,8 @@
 // Why not one launch: a launch has ONE register and LDS allocation.  The trajectory kernel needs 256 VGPRs and
 // 58 KB of LDS per 64 agents; the rate kernel needs 40 VGPRs and no LDS and lives on occupancy.  Why not launches
 // per chunk (Agent.simulate's two-stream pipeline): every chunk pays the fill of the first stage and a dependent
-// launch boundary, and a 20-step run has nothing to overlap.  With flags the rate waves start 4 steps behind the
-// trajectory and stay there.
+// launch boundary, and a 20-step run has nothing to overlap.  With flags the rate kernel's waves start 4 steps
+// behind the trajectory and stay there.
 #include <hip/hip_ext.h>
 
 #include <new>
@@ -17,14 +17,17 @@ namespace riab {
 int launch_agent_pub(const AgentArgs& a, hipStream_t s);
 int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
 int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t T, float dt,
-                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, int max_wgs, int gpi,
+                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, bool plain_loads,
                        uint32_t spin_limit, bool any_order, hipStream_t s);
-int launch_stream_gate(uint32_t* ctrl, uint32_t target, uint32_t spin_limit, hipStream_t s);
+int launch_stream_gate(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj, uint32_t progress_target,
+                       uint32_t spin_limit, bool sleep_long, hipStream_t s);
+int launch_rate_rows(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t t0, int32_t tc,
+                     float dt, uint64_t seed, uint64_t step0, int64_t agent_id0, hipStream_t s);
 }  // namespace riab
 
 struct RiabStreamer {
   hipStream_t side;          // the rate kernel's stream (mode 0)
-  hipEvent_t fork, join;     // main -> side, side -> main
+  hipEvent_t join;           // side -> main
   hipEvent_t t0, t1;         // timing of the rate kernel (created on first use)
   bool timed;
   uint32_t started_total;    // trajectory workgroups launched so far through this object (wraps like the device word)
@@ -35,14 +38,13 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
   RiabStreamer* h = new (std::nothrow) RiabStreamer();
   if (!h) return nullptr;
   h->side = nullptr;
-  h->fork = h->join = h->t0 = h->t1 = nullptr;
+  h->join = h->t0 = h->t1 = nullptr;
   h->timed = false;
   h->started_total = 0;
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
       hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess) {
     delete h;
     return nullptr;
@@ -55,7 +57,6 @@ extern "C" void riab_streamer_destroy(RiabStreamer* h) {
   if (!h) return;
   if (h->t0) (void)hipEventDestroy(h->t0);
   if (h->t1) (void)hipEventDestroy(h->t1);
-  if (h->fork) (void)hipEventDestroy(h->fork);
   if (h->join) (void)hipEventDestroy(h->join);
   if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
@@ -85,32 +86,59 @@ extern "C" int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const Ri
   const bool any_order = mode == 1;
   hipStream_t rate_s = any_order ? main_s : h->side;
   // ~0.3 us per poll: a generous second or two before a wait gives up (a healthy wait is tens of microseconds)
-  const uint32_t spin_limit = 4u << 20;
-  if (wgs_per_cu <= 0) wgs_per_cu = 7;
-  if (wgs_per_cu > 8) wgs_per_cu = 8;
-  int gpi = 2;
-  if (const char* e = getenv("RIAB_STREAM_GPI")) gpi = atoi(e);
+  const uint32_t spin_limit = 1u << 20;
+  (void)wgs_per_cu;  // (sized a resident grid when the rate kernel was persistent; see riab_rates.hip)
+  const bool plain_loads = getenv("RIAB_GATED_PLAIN") != nullptr;  // experiment: positions through plain loads
   if (timing && !h->t0) {
     if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess) return RIAB_EINVAL;
   }
   h->timed = false;
-  if (!any_order) {
-    hipError_t e = hipEventRecord(h->fork, main_s);  // the side stream starts after everything queued on `stream`
-    if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->fork, 0);
-    if (e != hipSuccess) return (int)e;
-  }
+  // The trajectory kernel goes first, with no host work in front of it.  The side stream needs no event to order
+  // it behind what is queued on `stream`: its first kernel is the gate, which returns only once every trajectory
+  // workgroup of THIS launch is resident — and the trajectory kernel starts after everything queued before it.
   rc = riab::launch_agent_pub(a, main_s);
   if (rc) return rc;
   const uint32_t n_traj = (uint32_t)(B / 64);
   h->started_total += n_traj;
+  // Two forms of the rate stage (mode 0):
+  //  * up to RIAB_STREAM_POLL_MAX steps: ONE rate kernel for all rows whose waves wait for their rows themselves
+  //    (rate_kernel_gated): it follows the trajectory at a distance of one four-step block, which is what a short
+  //    run needs; its per-wave poll costs ~15 % of the store bandwidth;
+  //  * longer runs: the population's ordinary kernel per chunk of rows, each chunk behind a progress gate (one
+  //    wave) on the same stream — full store bandwidth, at the price of a chunk of distance to the trajectory
+  //    (the first chunks are short) and a gate + launch boundary (~5 us) per chunk.
+  int poll_max = 256;
+  if (const char* e = getenv("RIAB_STREAM_POLL_MAX")) poll_max = atoi(e);
+  const bool chunks = !any_order && T > poll_max;
   if (!any_order) {
-    rc = riab::launch_stream_gate(ctrl, h->started_total, spin_limit, rate_s);
+    // (the started gate is one sleeping wave; it may have to sit out whatever was queued on `stream`: ~1 min)
+    rc = riab::launch_stream_gate(ctrl, h->started_total, 0, 0, 1u << 24, true, rate_s);
     if (rc) return rc;
   }
   if (timing) (void)hipEventRecord(h->t0, rate_s);
-  rc = riab::launch_rate_stream(env, pop, hist, B, T, (float)motion->dt, seed, step0, agent_id0, ctrl, wgs_per_cu * h->cus,
-                                gpi, spin_limit, any_order, rate_s);
-  if (rc) return rc;
+  if (!chunks) {
+    rc = riab::launch_rate_stream(env, pop, hist, B, T, (float)motion->dt, seed, step0, agent_id0, ctrl, plain_loads,
+                                  spin_limit, any_order, rate_s);
+    if (rc) return rc;
+  } else {
+    int32_t t0 = 0, k = 0;
+    while (t0 < T) {
+      // The trajectory advances ~2.3 us per step and the rate kernels need ~2.8 us per row, so a chunk may be at
+      // most ~1.25x its predecessor for its rows to be finished when the stream gets to it (a 16, 16, 32, 64, 128
+      // ramp spent 230 us of a 1024-step run inside the gates [MI355X, rocprofv3 trace]).
+      static const int32_t ramp[10] = {16, 16, 20, 24, 32, 40, 48, 64, 80, 96};
+      int32_t tc = k < 10 ? ramp[k] : 128;
+      if (tc > T - t0) tc = T - t0;
+      // ~0.5 us per poll: seconds before a gate gives up (a healthy wait is one chunk of trajectory, < 1 ms)
+      rc = riab::launch_stream_gate(ctrl, h->started_total, n_traj, (uint32_t)step0 + (uint32_t)(t0 + tc), 1u << 22, false,
+                                    rate_s);
+      if (rc) return rc;
+      rc = riab::launch_rate_rows(env, pop, hist, B, t0, tc, (float)motion->dt, seed, step0, agent_id0, rate_s);
+      if (rc) return rc;
+      t0 += tc;
+      ++k;
+    }
+  }
   if (timing) {
     (void)hipEventRecord(h->t1, rate_s);
     h->timed = true;

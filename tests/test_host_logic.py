@@ -303,10 +303,12 @@ def test_second_agent_object_gets_its_own_rng_key():
     a1 = riab.Agent(env, CPU)
     a2 = riab.Agent(env, dict(CPU, seed=5))
     assert a0.rng_seed == a0.seed == 0
-    assert a1.rng_seed != a0.rng_seed and a2.rng_seed not in (a0.rng_seed, a1.rng_seed)
-    assert 0 <= a1.rng_seed < 2 ** 64
-    # shards of one logical population (each the first agent of its own Environment) share the key
-    assert riab.Agent(riab.Environment(), dict(CPU, agent_id0=4096)).rng_seed == 0
+    assert a1.rng_seed != a0.rng_seed and 0 <= a1.rng_seed < 2 ** 64
+    assert a2.rng_seed == 5, "an explicit seed is taken as given"
+    # shards of one logical population carry explicit ids: same key wherever they are constructed
+    assert riab.Agent(env, dict(CPU, agent_id0=4096)).rng_seed == 0
+    with pytest.warns(UserWarning, match="IDENTICAL noise"):
+        riab.Agent(env, dict(CPU, seed=5))
 
 
 def test_bench_refuses_a_mismatched_world_size():
