@@ -296,12 +296,22 @@ class Agent:
             if self._scratch_row is None or self._scratch_row.shape[0] < T:
                 self._scratch_row = torch.empty((T, _L.HIST_ROWS, self._Bp), dtype=torch.float32, device=self._device)
             hist_view = self._scratch_row[:T]
-        s = stream if stream is not None else _L.current_stream()
-        rc = _L.lib.riab_agent_step(env, m, _L.ptr(self._state), self._Bp, int(self.agent_id0), _L.ptr(drift),
-                                    _L.ptr(z), _L.ptr(z_out), _L.ptr(forced), int(self.rng_seed),
-                                    int(self._step_index), int(T),
-                                    _L.ptr(hist_view), _L.ptr(self._diag), int(self.precision), s)
-        _L.check(rc, "riab_agent_step")
+        if stream is None and self._device.type == "cuda":
+            # the eager per-step path goes through the registered operator (ops.py): torch.ops.riab.agent_step_
+            from . import ops
+            Env = self.Environment
+            torch.ops.riab.agent_step_(self._state, hist_view, self._diag, _walls if len(Env.walls) else None,
+                                       [float(x) for x in Env.extent] + [float(Env.scale)],
+                                       Env.boundary_conditions == "periodic", ops.motion_list(m), drift, z, z_out, forced,
+                                       int(self.rng_seed), int(self._step_index), int(self.agent_id0), int(T),
+                                       int(self.precision))
+        else:
+            s = stream if stream is not None else _L.current_stream()
+            rc = _L.lib.riab_agent_step(env, m, _L.ptr(self._state), self._Bp, int(self.agent_id0), _L.ptr(drift),
+                                        _L.ptr(z), _L.ptr(z_out), _L.ptr(forced), int(self.rng_seed),
+                                        int(self._step_index), int(T),
+                                        _L.ptr(hist_view), _L.ptr(self._diag), int(self.precision), s)
+            _L.check(rc, "riab_agent_step")
         self._keep = (drift, z, _walls, hist_view, forced)  # keep operands alive until the stream is done
         self._last_row = hist_view[T - 1]            # fp32 [8, Bp]: positions / head directions of the newest step
         for _ in range(T):

@@ -50,8 +50,18 @@ class Neurons:
     # which per-agent direction rows feed io.hd_x / hd_y: (history-record rows, float64 state rows)
     _H_DIR = (_L.H_HD_X, _L.H_HD_Y)
     _S_DIR = (_L.S_HD_X, _L.S_HD_Y)
-    # populations the persistent rate kernel of the flag-coupled pipeline covers (Agent._simulate_fused) set this
+    # populations the rate stage of the flag-coupled pipeline covers (Agent._simulate_fused) set this
     _stream_kind = None
+    # get_state() through the registered PyTorch operator (ops.py: torch.ops.riab.*): set by the classes that have one.
+    # Called with float32 rows `d [4, P]` = (pos x, pos y, direction x, direction y); returns rates `[n, P]`.
+    _state_op = None
+
+    def _env_op_args(self):
+        """(walls tensor or None, [l, r, b, t, scale], periodic) of the Environment for the operators."""
+        Env = self.Agent.Environment
+        _env, wt = Env.device_tables(self._device)
+        walls = wt if len(Env.walls) else None
+        return walls, [float(x) for x in Env.extent] + [float(Env.scale)], Env.boundary_conditions == "periodic"
 
     def __init__(self, Agent, params={}):
         self.Agent = Agent
@@ -260,6 +270,8 @@ class Neurons:
             P = self._Bp
             self._last_P = self._B
             px, py, hx, hy = (st[_L.S_POS_X], st[_L.S_POS_Y], st[self._S_DIR[0]], st[self._S_DIR[1]])
+            if self._state_op is not None and self._device.type == "cuda":
+                return self._state_op(torch.stack((px, py, hx, hy)).to(torch.float32))
             out = torch.empty((1, int(self.n), P), dtype=torch.float32, device=self._device)
             self._launch(px, py, hx, hy, pos_ld=P, T=1, B=P, rates=out, spikes=None, u_in=None, dt=float(Ag.dt),
                          step0=0, from_f64=True)
@@ -284,6 +296,8 @@ class Neurons:
             buf[2, :P], buf[3, :P] = hd[:, 0], hd[:, 1]
             buf[2, P:], buf[3, P:] = hd[0, 0], hd[0, 1]
         d = torch.from_numpy(buf).to(self._device)
+        if self._state_op is not None and self._device.type == "cuda":
+            return self._state_op(d)  # torch.ops.riab.* (ops.py)
         out = torch.empty((1, int(self.n), Pp), dtype=torch.float32, device=self._device)
         self._launch(d[0], d[1], d[2], d[3], pos_ld=Pp, T=1, B=Pp, rates=out, spikes=None, u_in=None,
                      dt=float(Ag.dt), step0=0, from_f64=False)
@@ -503,6 +517,13 @@ class PlaceCells(Neurons):
                                      _L.GEOMETRIES[geom], thw, stream)
         _L.check(rc, "riab_place_cells")
 
+    def _state_op(self, d):
+        from . import ops  # noqa: F401  (registers torch.ops.riab.*)
+        f = self._call(None, None)
+        walls, env, periodic = self._env_op_args()
+        return torch.ops.riab.place_cells(d[0:2], f["table"], walls, env, periodic, f["description"], f["geometry"],
+                                          f["top_hat_width"], float(self.min_fr), float(self.max_fr))
+
     def remap(self):
         self.place_cell_centres = self.Agent.Environment.sample_positions(n=self.n, method="uniform_jitter")
         np.random.shuffle(self.place_cell_centres)
@@ -602,6 +623,11 @@ class GridCells(Neurons):
                         f0=float(f0))
         rc = _L.lib.riab_grid_cells(io, _L.ptr(tab), n, _L.GC_DESCRIPTIONS[self.description], float(f0), stream)
         _L.check(rc, "riab_grid_cells")
+
+    def _state_op(self, d):
+        from . import ops  # noqa: F401  (registers torch.ops.riab.*)
+        f = self._call(None, None)
+        return torch.ops.riab.grid_cells(d[0:2], f["table"], f["description"], f["f0"], float(self.min_fr), float(self.max_fr))
 
 
 # ================================================================================================
@@ -764,6 +790,16 @@ class BoundaryVectorCells(VectorCells):
                                                         _L.ptr(vm_t), _L.ptr(inv_t), n, 1 if ego else 0, None,
                                                         _L.ptr(rows_t), _L.ptr(win_t), stream)
         _L.check(rc, "riab_boundary_vector_cells")
+
+    def _state_op(self, d):
+        from . import ops  # noqa: F401  (registers torch.ops.riab.*)
+        f = self._call(None, None)
+        walls, env, periodic = self._env_op_args()
+        ego = bool(f["egocentric"])
+        return torch.ops.riab.boundary_vector_cells(d[0:2], d[2:4] if ego else None, walls, env, periodic, f["test_dirs"],
+                                                    f["ray_rden"], f["table"], f["vm_table"], f["inv_norm"], ego,
+                                                    f.get("cell_rows"), f.get("windows"), float(self.min_fr),
+                                                    float(self.max_fr))
 
 
 class FieldOfViewBVCs(BoundaryVectorCells):
@@ -1045,6 +1081,11 @@ class HeadDirectionCells(Neurons):
         rc = _L.lib.riab_head_direction_cells(io, _L.ptr(tab), n, stream)
         _L.check(rc, "riab_head_direction_cells")
 
+    def _state_op(self, d):
+        from . import ops  # noqa: F401  (registers torch.ops.riab.*)
+        f = self._call(None, None)
+        return torch.ops.riab.head_direction_cells(d[2:4], f["table"], float(self.min_fr), float(self.max_fr))
+
 
 # ================================================================================================
 class VelocityCells(HeadDirectionCells):
@@ -1056,6 +1097,7 @@ class VelocityCells(HeadDirectionCells):
     (its rate stage runs on the float32 history records) and raises."""
 
     _stream_kind = None  # reads the float64 velocity state, not the history rows
+    _state_op = None     # (its own kernel entry: riab_velocity_cells)
     default_params = {
         "min_fr": 0,
         "max_fr": 1,

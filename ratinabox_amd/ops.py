@@ -1,0 +1,267 @@
+"""`torch.ops.riab.*` — the C ABI of libriab_hip.so (include/riab_hip.h) registered as PyTorch custom operators.
+
+The reference's only PyTorch touch-point is a user network consuming firing rates
+(ratinabox/contribs/NeuralNetworkNeurons.py:6-7); registering the kernels as operators is what lets such code —
+and `torch.compile` / CUDA-graph capture around it — call the accelerated path directly on device tensors:
+
+    rates = torch.ops.riab.place_cells(pos, table, None, [0, 1, 0, 1, 1.0], False, 0, 0, 0.2, 0.0, 1.0)   # (n, P)
+
+Every operator is a thin wrapper: it checks shapes, fills the ABI's structs with `data_ptr()`s and enqueues the
+kernel on the CURRENT stream; nothing is synchronised.  Each has a fake (meta) implementation, so the operators
+trace under `torch.compile(fullgraph=True)` and FakeTensorMode.  Layouts are the ABI's: the position / agent axis
+is the last (fastest) one and must be a multiple of 4 (pad; padding columns are computed like any other).
+
+Functional operators (return a new tensor)
+    place_cells, grid_cells, head_direction_cells, boundary_vector_cells   rates float32 (n, P)
+    spikes                                                              uint8 (T, n, B) from rates (T, n, B)
+    feedforward                                                         float32 (T, n_out, B)
+In-place operator
+    agent_step_      T fused Agent.update() steps on the float64 state (12, B); writes the history rows
+
+`Neurons.get_state()` and `Agent.update()` go through these operators (the fused / planned paths call the ABI
+directly: their launches are issued from C++)."""
+from typing import List, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib as _L
+
+C = _L.C
+
+_lib_ns = torch.library.Library("riab", "FRAGMENT")  # noqa: F841  (keeps the namespace alive for custom_op)
+
+
+def _env_struct(walls: Optional[Tensor], env: List[float], periodic: bool):
+    """RiabEnv from operator arguments: env = [left, right, bottom, top, scale]."""
+    if len(env) != 5:
+        raise ValueError("env must be [left, right, bottom, top, scale]")
+    e = _L.RiabEnv()
+    for i in range(4):
+        e.extent[i] = float(env[i])
+    e.scale = float(env[4])
+    e.periodic = 1 if periodic else 0
+    if walls is None:
+        e.n_walls, e.walls = 0, None
+    else:
+        if walls.dtype != torch.float64 or walls.dim() != 2 or walls.shape[1] != 4 or not walls.is_contiguous():
+            raise ValueError("walls must be a contiguous float64 tensor (n_walls, 4) = (ax, ay, bx, by)")
+        e.n_walls, e.walls = int(walls.shape[0]), walls.data_ptr()
+    return e
+
+
+def _rows(t: Tensor, rows: int, what: str):
+    if t.dtype != torch.float32 or t.dim() != 2 or t.shape[0] != rows or not t.is_contiguous() or t.shape[1] % 4:
+        raise ValueError(f"{what} must be a contiguous float32 tensor ({rows}, P) with P a multiple of 4, got "
+                         f"{tuple(t.shape)} {t.dtype}")
+    return int(t.shape[1])
+
+
+def _io(pos: Optional[Tensor], hd: Optional[Tensor], P: int, out: Tensor, min_fr: float, max_fr: float):
+    io = _L.RiabRateIO()
+    if pos is not None:
+        io.pos_x, io.pos_y = pos[0].data_ptr(), pos[1].data_ptr()
+    if hd is not None:
+        io.hd_x, io.hd_y = hd[0].data_ptr(), hd[1].data_ptr()
+    io.pos_ld, io.T, io.B = P, 1, P
+    io.rates = out.data_ptr()
+    io.dt = 0.0
+    io.min_fr, io.max_fr = float(min_fr), float(max_fr)
+    return io
+
+
+# ---- PlaceCells ------------------------------------------------------------------------------------------------
+@torch.library.custom_op("riab::place_cells", mutates_args=(), device_types="cuda")
+def place_cells(pos: Tensor, table: Tensor, walls: Optional[Tensor], env: List[float], periodic: bool, description: int,
+                geometry: int, top_hat_width: float, min_fr: float, max_fr: float) -> Tensor:
+    """PlaceCells.get_state (riab_place_cells).  pos float32 (2, P); table float32 (n, 3) = (centre x, centre y,
+    -log2(e)/(2 w^2)); walls float64 (n_walls, 4) in Environment.walls order or None; env = [l, r, b, t, scale];
+    description RIAB_PC_*; geometry RIAB_GEOM_*.  Returns rates float32 (n, P)."""
+    P = _rows(pos, 2, "pos")
+    n = int(table.shape[0])
+    out = torch.empty((n, P), dtype=torch.float32, device=pos.device)
+    e = _env_struct(walls, env, periodic)
+    io = _io(pos, None, P, out, min_fr, max_fr)
+    _L.check(_L.lib.riab_place_cells(e, io, _L.ptr(table), n, int(description), int(geometry), float(top_hat_width),
+                                     _L.current_stream()), "riab_place_cells")
+    return out
+
+
+@place_cells.register_fake
+def _(pos, table, walls, env, periodic, description, geometry, top_hat_width, min_fr, max_fr):
+    return pos.new_empty((table.shape[0], pos.shape[1]))
+
+
+# ---- GridCells -------------------------------------------------------------------------------------------------
+@torch.library.custom_op("riab::grid_cells", mutates_args=(), device_types="cuda")
+def grid_cells(pos: Tensor, table: Tensor, description: int, f0: float, min_fr: float, max_fr: float) -> Tensor:
+    """GridCells.get_state (riab_grid_cells).  table float32 (n, 9), see include/riab_hip.h."""
+    P = _rows(pos, 2, "pos")
+    n = int(table.shape[0])
+    out = torch.empty((n, P), dtype=torch.float32, device=pos.device)
+    io = _io(pos, None, P, out, min_fr, max_fr)
+    _L.check(_L.lib.riab_grid_cells(io, _L.ptr(table), n, int(description), float(f0), _L.current_stream()),
+             "riab_grid_cells")
+    return out
+
+
+@grid_cells.register_fake
+def _(pos, table, description, f0, min_fr, max_fr):
+    return pos.new_empty((table.shape[0], pos.shape[1]))
+
+
+# ---- HeadDirectionCells ----------------------------------------------------------------------------------------
+@torch.library.custom_op("riab::head_direction_cells", mutates_args=(), device_types="cuda")
+def head_direction_cells(head_direction: Tensor, table: Tensor, min_fr: float, max_fr: float) -> Tensor:
+    """HeadDirectionCells.get_state (riab_head_direction_cells).  head_direction float32 (2, P); table float32 (n, 3)
+    = (cos, sin of the preferred angle, log2(e)/sigma^2)."""
+    P = _rows(head_direction, 2, "head_direction")
+    n = int(table.shape[0])
+    out = torch.empty((n, P), dtype=torch.float32, device=head_direction.device)
+    io = _io(None, head_direction, P, out, min_fr, max_fr)
+    _L.check(_L.lib.riab_head_direction_cells(io, _L.ptr(table), n, _L.current_stream()), "riab_head_direction_cells")
+    return out
+
+
+@head_direction_cells.register_fake
+def _(head_direction, table, min_fr, max_fr):
+    return head_direction.new_empty((table.shape[0], head_direction.shape[1]))
+
+
+# ---- BoundaryVectorCells ---------------------------------------------------------------------------------------
+@torch.library.custom_op("riab::boundary_vector_cells", mutates_args=(), device_types="cuda")
+def boundary_vector_cells(pos: Tensor, head_direction: Optional[Tensor], walls: Tensor, env: List[float], periodic: bool,
+                          test_dirs: Tensor, ray_rden: Tensor, cells: Tensor, vm_table: Tensor, inv_norm: Tensor,
+                          egocentric: bool, cell_rows: Optional[Tensor], windows: Optional[Tensor], min_fr: float,
+                          max_fr: float) -> Tensor:
+    """BoundaryVectorCells.get_state (riab_boundary_vector_cells_windowed).  Tables as documented in
+    include/riab_hip.h (test_dirs float64 (K, 2), ray_rden float64 (K, n_walls), cells float32 (4, n), vm_table,
+    inv_norm float32 (n,), optional direction windows)."""
+    P = _rows(pos, 2, "pos")
+    if egocentric:
+        if head_direction is None or _rows(head_direction, 2, "head_direction") != P:
+            raise ValueError("egocentric cells need head_direction (2, P)")
+    n, K = int(cells.shape[1]), int(test_dirs.shape[0])
+    out = torch.empty((n, P), dtype=torch.float32, device=pos.device)
+    e = _env_struct(walls, env, periodic)
+    io = _io(pos, head_direction if egocentric else None, P, out, min_fr, max_fr)
+    _L.check(_L.lib.riab_boundary_vector_cells_windowed(e, io, _L.ptr(test_dirs), _L.ptr(ray_rden), K, _L.ptr(cells),
+                                                        _L.ptr(vm_table), _L.ptr(inv_norm), n, 1 if egocentric else 0, None,
+                                                        _L.ptr(cell_rows), _L.ptr(windows), _L.current_stream()),
+             "riab_boundary_vector_cells")
+    return out
+
+
+@boundary_vector_cells.register_fake
+def _(pos, head_direction, walls, env, periodic, test_dirs, ray_rden, cells, vm_table, inv_norm, egocentric, cell_rows,
+      windows, min_fr, max_fr):
+    return pos.new_empty((cells.shape[1], pos.shape[1]))
+
+
+# ---- Poisson spikes --------------------------------------------------------------------------------------------
+@torch.library.custom_op("riab::spikes", mutates_args=(), device_types="cuda")
+def spikes(rates: Tensor, uniforms: Optional[Tensor], dt: float, seed: int, step0: int, pop_id: int,
+           agent_id0: int) -> Tensor:
+    """Neurons.save_to_history's spike rule `u < dt * rate` (riab_spikes) on rates float32 (T, n, B): with explicit
+    `uniforms` (same shape) or, when None, the Philox uniforms keyed by (seed; step0 + t, cell, agent id, pop_id).
+    Returns uint8 (T, n, B)."""
+    if rates.dtype != torch.float32 or rates.dim() != 3 or not rates.is_contiguous() or rates.shape[2] % 4:
+        raise ValueError("rates must be a contiguous float32 tensor (T, n, B) with B a multiple of 4")
+    T, n, B = (int(x) for x in rates.shape)
+    if uniforms is not None and (uniforms.shape != rates.shape or uniforms.dtype != torch.float32 or
+                                 not uniforms.is_contiguous()):
+        raise ValueError("uniforms must match rates (contiguous float32)")
+    out = torch.empty((T, n, B), dtype=torch.uint8, device=rates.device)
+    io = _L.RiabRateIO()
+    io.pos_ld, io.T, io.B = B, T, B
+    io.rates, io.spikes = rates.data_ptr(), out.data_ptr()
+    io.u_in = uniforms.data_ptr() if uniforms is not None else None
+    io.dt = float(dt)
+    io.seed, io.step0, io.agent_id0, io.pop_id = int(seed), int(step0), int(agent_id0), int(pop_id)
+    _L.check(_L.lib.riab_spikes(io, n, _L.current_stream()), "riab_spikes")
+    return out
+
+
+@spikes.register_fake
+def _(rates, uniforms, dt, seed, step0, pop_id, agent_id0):
+    return rates.new_empty(rates.shape, dtype=torch.uint8)
+
+
+# ---- FeedForwardLayer ------------------------------------------------------------------------------------------
+@torch.library.custom_op("riab::feedforward", mutates_args=(), device_types="cuda")
+def feedforward(inputs: List[Tensor], weights_t: List[Tensor], bias: Tensor, activation: int,
+                act_params: List[float]) -> Tensor:
+    """FeedForwardLayer.get_state (riab_feedforward, fp32 matrix cores): out[t][m][b] = act(sum_l sum_k
+    w_l[m][k] * inputs_l[t][k][b] + bias[m]).  inputs_l float32 (T, n_in_l, B); weights_t_l float32 (n_in_l, Mp) =
+    the weight matrix TRANSPOSED, rows zero-padded to Mp = n_out rounded up to 32; bias float32 (n_out,);
+    activation RIAB_ACT_*; act_params as in include/riab_hip.h.  Returns float32 (T, n_out, B)."""
+    if not inputs or len(inputs) != len(weights_t) or len(inputs) > 8:
+        raise ValueError("1..8 input layers, one transposed weight matrix each")
+    T, _, B = (int(x) for x in inputs[0].shape)
+    n_out = int(bias.shape[0])
+    arr = (_L.RiabFFInput * len(inputs))()
+    for l, (x, w) in enumerate(zip(inputs, weights_t)):
+        if x.dtype != torch.float32 or x.dim() != 3 or not x.is_contiguous() or x.shape[0] != T or x.shape[2] != B:
+            raise ValueError("inputs must be contiguous float32 (T, n_in, B) with equal T and B")
+        if w.dtype != torch.float32 or not w.is_contiguous() or w.shape[0] != x.shape[1] or w.shape[1] % 32 or \
+                w.shape[1] < n_out:
+            raise ValueError("weights_t[l] must be contiguous float32 (n_in_l, Mp), Mp = n_out rounded up to 32")
+        arr[l].rates, arr[l].wt, arr[l].n_in = x.data_ptr(), w.data_ptr(), int(x.shape[1])
+    pars = (C.c_float * 4)(*[float(p) for p in (list(act_params) + [0.0] * 4)[:4]])
+    out = torch.empty((T, n_out, B), dtype=torch.float32, device=inputs[0].device)
+    _L.check(_L.lib.riab_feedforward(arr, len(inputs), _L.ptr(bias), n_out, T, B, int(activation), pars, _L.ptr(out), None,
+                                     _L.current_stream()), "riab_feedforward")
+    return out
+
+
+@feedforward.register_fake
+def _(inputs, weights_t, bias, activation, act_params):
+    return inputs[0].new_empty((inputs[0].shape[0], bias.shape[0], inputs[0].shape[2]))
+
+
+# ---- Agent.update ----------------------------------------------------------------------------------------------
+MOTION_FIELDS = ("dt", "rot_theta_kw", "rot_sigma_kw", "rot_drift_kw", "speed_theta_kw", "speed_sigma_kw", "speed_mean_kw",
+                 "speed_mean", "speed_std_is_zero", "has_drift", "drift_theta", "wall_repel_strength_kw",
+                 "wall_repel_distance_kw", "thigmotaxis_kw", "hd_tau")
+
+
+def motion_list(m) -> List[float]:
+    """RiabMotion struct -> the flat list `agent_step_` takes (MOTION_FIELDS order)."""
+    return [float(getattr(m, k)) for k in MOTION_FIELDS]
+
+
+@torch.library.custom_op("riab::agent_step_", mutates_args=("state", "hist", "diag", "noise_out"), device_types="cuda")
+def agent_step_(state: Tensor, hist: Optional[Tensor], diag: Optional[Tensor], walls: Optional[Tensor], env: List[float],
+                periodic: bool, motion: List[float], drift: Optional[Tensor], noise: Optional[Tensor],
+                noise_out: Optional[Tensor], forced_pos: Optional[Tensor], seed: int, step0: int, agent_id0: int, T: int,
+                precision: int) -> None:
+    """T fused Agent.update() steps (riab_agent_step), in place: state float64 (12, B) (rows RIAB_S_*), hist float32
+    (T, 8, B) or None, diag int32 (4,) or None.  motion = the RiabMotion fields in MOTION_FIELDS order; drift float64
+    (2, B); noise float64 (T, 2, B) explicit standard normals (None: Philox keyed by (seed; step0 + t, agent_id0 + b));
+    noise_out records the normals used; forced_pos float64 (T, 2, B) moves the agents instead of the motion model."""
+    if state.dtype != torch.float64 or state.dim() != 2 or state.shape[0] != _L.STATE_ROWS or not state.is_contiguous():
+        raise ValueError("state must be a contiguous float64 tensor (12, B)")
+    B = int(state.shape[1])
+    if len(motion) != len(MOTION_FIELDS):
+        raise ValueError(f"motion must hold the {len(MOTION_FIELDS)} RiabMotion fields")
+    m = _L.RiabMotion()
+    for k, v in zip(MOTION_FIELDS, motion):
+        setattr(m, k, int(v) if k in ("speed_std_is_zero", "has_drift") else float(v))
+    if hist is not None and (hist.dtype != torch.float32 or tuple(hist.shape) != (T, _L.HIST_ROWS, B) or
+                             not hist.is_contiguous()):
+        raise ValueError("hist must be a contiguous float32 tensor (T, 8, B)")
+    for name, t in (("noise", noise), ("noise_out", noise_out), ("forced_pos", forced_pos)):
+        if t is not None and (t.dtype != torch.float64 or tuple(t.shape) != (T, 2, B) or not t.is_contiguous()):
+            raise ValueError(f"{name} must be a contiguous float64 tensor (T, 2, B)")
+    if drift is not None and (drift.dtype != torch.float64 or tuple(drift.shape) != (2, B) or not drift.is_contiguous()):
+        raise ValueError("drift must be a contiguous float64 tensor (2, B)")
+    e = _env_struct(walls, env, periodic)
+    _L.check(_L.lib.riab_agent_step(e, m, _L.ptr(state), B, int(agent_id0), _L.ptr(drift), _L.ptr(noise), _L.ptr(noise_out),
+                                    _L.ptr(forced_pos), int(seed), int(step0), int(T), _L.ptr(hist), _L.ptr(diag),
+                                    int(precision), _L.current_stream()), "riab_agent_step")
+
+
+@agent_step_.register_fake
+def _(state, hist, diag, walls, env, periodic, motion, drift, noise, noise_out, forced_pos, seed, step0, agent_id0, T,
+      precision):
+    return None

@@ -1,0 +1,138 @@
+"""GPU tests of the registered PyTorch operators (ratinabox_amd/ops.py: torch.ops.riab.*): called DIRECTLY on device
+tensors against the reference goldens, checked with torch.library.opcheck (schema, fake implementation, mutation
+annotations) and traced under torch.compile(fullgraph=True)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+LOG2E = 1.4426950408889634
+
+
+@pytest.fixture(scope="module")
+def riab():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    import ratinabox_amd
+    import ratinabox_amd.ops  # noqa: F401
+    return ratinabox_amd
+
+
+def _pos_rows(pos):
+    P = len(pos)
+    Pp = (P + 3) // 4 * 4
+    buf = np.zeros((2, Pp), dtype=np.float32)
+    buf[:, :P] = np.asarray(pos, dtype=np.float64).T
+    buf[:, P:] = buf[:, :1]
+    return torch.from_numpy(buf).cuda(), P
+
+
+def _pc_table(centres, widths):
+    tab = np.empty((len(centres), 3))
+    tab[:, :2] = centres
+    tab[:, 2] = -LOG2E / (2 * np.asarray(widths, dtype=np.float64) ** 2)
+    return torch.from_numpy(tab.astype(np.float32)).cuda()
+
+
+def test_place_cells_op_vs_reference(riab):
+    """torch.ops.riab.place_cells on raw tensors == the reference's PlaceCells.get_state (rates.npz), 1e-5."""
+    g = gu.load("rates.npz")
+    pos, P = _pos_rows(g["pos"])
+    tab = _pc_table(g["pc_gaussian_centres"], g["pc_gaussian_widths"])
+    out = torch.ops.riab.place_cells(pos, tab, None, [0.0, 1.0, 0.0, 1.0, 1.0], False, 0, 0, 0.2, 0.1, 2.0)
+    np.testing.assert_allclose(out[:, :P].cpu().numpy(), g["pc_gaussian_rates"], rtol=1e-5, atol=1e-37)
+    # line of sight through the maze's walls (float64 wall table, Environment.walls order)
+    walls = torch.from_numpy(np.ascontiguousarray(g["maze_walls"].reshape(-1, 4))).cuda()
+    tab = _pc_table(g["pc_los_centres"], 0.25 * np.ones(len(g["pc_los_centres"])))
+    out = torch.ops.riab.place_cells(pos, tab, walls, [0.0, 1.0, 0.0, 1.0, 1.0], False, 0, 1, 0.25, 0.0, 1.0)
+    np.testing.assert_allclose(out[:, :P].cpu().numpy(), g["pc_los_rates"], rtol=1e-5, atol=1e-37)
+
+
+def test_ops_pass_opcheck(riab):
+    g = gu.load("rates.npz")
+    pos, P = _pos_rows(g["pos"][:64])
+    tab = _pc_table(g["pc_gaussian_centres"], g["pc_gaussian_widths"])
+    torch.library.opcheck(torch.ops.riab.place_cells.default,
+                          (pos, tab, None, [0.0, 1.0, 0.0, 1.0, 1.0], False, 0, 0, 0.2, 0.0, 1.0))
+    rates = torch.rand((3, 8, 64), device="cuda") * 50
+    torch.library.opcheck(torch.ops.riab.spikes.default, (rates, None, 0.01, 7, 0, 1, 0))
+    torch.library.opcheck(torch.ops.riab.spikes.default, (rates, torch.rand_like(rates), 0.01, 7, 0, 1, 0))
+    x = torch.rand((2, 48, 64), device="cuda")
+    wt = torch.zeros((48, 32), device="cuda")
+    wt[:, :5] = torch.randn((48, 5), device="cuda")
+    torch.library.opcheck(torch.ops.riab.feedforward.default, ([x], [wt], torch.zeros(5, device="cuda"), 3, [1.0, 0.0]))
+
+
+def test_spikes_and_feedforward_ops_match_their_definitions(riab):
+    rates = torch.rand((4, 16, 128), device="cuda") * 60
+    u = torch.rand_like(rates)
+    sp = torch.ops.riab.spikes(rates, u, 0.01, 0, 0, 0, 0)
+    assert torch.equal(sp.bool(), u < torch.tensor(0.01, dtype=torch.float32, device="cuda") * rates)
+    x = torch.rand((2, 40, 64), device="cuda")
+    w = torch.randn((7, 40), device="cuda")
+    wt = torch.zeros((40, 32), device="cuda")
+    wt[:, :7] = w.t()
+    b = torch.randn(7, device="cuda")
+    out = torch.ops.riab.feedforward([x], [wt], b, 2, [1.5, 0.1])  # relu(gain, threshold): gain * max(x - threshold, 0)
+    ref = 1.5 * torch.clamp(torch.einsum("mk,tkb->tmb", w.double(), x.double()) + b.double()[None, :, None] - 0.1, min=0)
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_ops_trace_under_torch_compile(riab):
+    """fullgraph=True: the operators' fake implementations and mutation annotations are enough for Dynamo /
+    AOTAutograd to trace a function that mixes them with ordinary torch code (backend aot_eager: the traced graph
+    runs as is; this image has no Triton for inductor's own kernels, and none is wanted)."""
+    g = gu.load("rates.npz")
+    pos, P = _pos_rows(g["pos"])
+    tab = _pc_table(g["pc_gaussian_centres"], g["pc_gaussian_widths"])
+
+    def population_vector(pos, tab):
+        r = torch.ops.riab.place_cells(pos, tab, None, [0.0, 1.0, 0.0, 1.0, 1.0], False, 0, 0, 0.2, 0.0, 1.0)
+        return (r / r.sum(0, keepdim=True).clamp_min(1e-12)).t() @ tab[:, :2]   # decoded positions (P, 2)
+
+    eager = population_vector(pos, tab)
+    compiled = torch.compile(population_vector, fullgraph=True, backend="aot_eager")(pos, tab)
+    torch.testing.assert_close(compiled, eager, rtol=0, atol=0)
+
+    # the in-place operator: state is mutated, the history rows are written
+    np.random.seed(0)
+    ag = riab.Agent(riab.Environment(), {"n_agents": 64, "dt": 0.01, "seed": 3})
+    from ratinabox_amd import ops
+    m = ops.motion_list(ag._motion(0.01, False, 1, {}))
+    walls = ag.Environment.device_tables(ag._device)[1]
+    env = [0.0, 1.0, 0.0, 1.0, 1.0]
+
+    def two_steps(state, hist):
+        torch.ops.riab.agent_step_(state, hist, None, walls, env, False, m, None, None, None, None, 3, 0, 0, 2, 64)
+        return hist[:, 0] + 0.0
+
+    s_a, s_b = ag.state_tensor.clone(), ag.state_tensor.clone()
+    h_a = torch.zeros((2, 8, 64), dtype=torch.float32, device="cuda")
+    h_b = torch.zeros_like(h_a)
+    x_a = two_steps(s_a, h_a)
+    x_b = torch.compile(two_steps, fullgraph=True, backend="aot_eager")(s_b, h_b)
+    assert torch.equal(s_a, s_b) and torch.equal(h_a, h_b) and torch.equal(x_a, x_b)
+    assert not torch.equal(s_a, ag.state_tensor), "the operator must have advanced the state"
+
+
+def test_get_state_and_update_go_through_the_operators(riab, monkeypatch):
+    """Neurons.get_state / Agent.update call torch.ops.riab.* (counted here), with unchanged results."""
+    from ratinabox_amd import _lib as L
+    calls = {"place": 0, "step": 0}
+    real_place, real_step = L.lib.riab_place_cells, L.lib.riab_agent_step
+    np.random.seed(1)
+    ag = riab.Agent(riab.Environment(), {"n_agents": 8, "dt": 0.01})
+    pcs = riab.PlaceCells(ag, {"n": 12})
+    seen = []
+    orig = torch.ops.riab.place_cells
+
+    class Spy:
+        def __call__(self, *a, **k):
+            seen.append("place_cells")
+            return orig(*a, **k)
+    monkeypatch.setattr(torch.ops.riab, "place_cells", Spy(), raising=False)
+    fr = pcs.get_state(evaluate_at=None, pos=np.array([[0.3, 0.4], [0.9, 0.1]]))
+    assert seen == ["place_cells"] and fr.shape == (12, 2)
+    d = np.linalg.norm(pcs.place_cell_centres[:, None, :] - np.array([[0.3, 0.4], [0.9, 0.1]])[None], axis=-1)
+    np.testing.assert_allclose(fr, np.exp(-d ** 2 / (2 * 0.2 ** 2)), rtol=1e-5)
