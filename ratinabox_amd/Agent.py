@@ -303,7 +303,7 @@ class Agent:
             torch.ops.riab.agent_step_(self._state, hist_view, self._diag, _walls if len(Env.walls) else None,
                                        [float(x) for x in Env.extent] + [float(Env.scale)],
                                        Env.boundary_conditions == "periodic", ops.motion_list(m), drift, z, z_out, forced,
-                                       int(self.rng_seed), int(self._step_index), int(self.agent_id0), int(T),
+                                       ops.seed_arg(self.rng_seed), int(self._step_index), int(self.agent_id0), int(T),
                                        int(self.precision))
         else:
             s = stream if stream is not None else _L.current_stream()

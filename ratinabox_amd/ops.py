@@ -29,7 +29,23 @@ from . import _lib as _L
 
 C = _L.C
 
-_lib_ns = torch.library.Library("riab", "FRAGMENT")  # noqa: F841  (keeps the namespace alive for custom_op)
+# Schemas are DEFINED once (Library "DEF") and the implementations registered for the CUDA (= HIP) key directly:
+# `torch.library.custom_op` wraps every call in ~15 us of Python (measured on the per-step path), this route costs
+# the dispatcher's boxed call into the Python function and nothing else.
+_ns = torch.library.Library("riab", "DEF")
+_TAGS = (torch.Tag.pt2_compliant_tag,)
+
+
+def _register(schema, fake):
+    """decorator: define `riab::<schema>`, register the function for CUDA and `fake` as its meta implementation"""
+    name = schema.split("(", 1)[0]
+
+    def deco(fn):
+        _ns.define(schema, tags=_TAGS)
+        _ns.impl(name, fn, "CUDA")
+        torch.library.register_fake("riab::" + name, fake, lib=_ns)
+        return fn
+    return deco
 
 
 def _env_struct(walls: Optional[Tensor], env: List[float], periodic: bool):
@@ -71,7 +87,10 @@ def _io(pos: Optional[Tensor], hd: Optional[Tensor], P: int, out: Tensor, min_fr
 
 
 # ---- PlaceCells ------------------------------------------------------------------------------------------------
-@torch.library.custom_op("riab::place_cells", mutates_args=(), device_types="cuda")
+@_register("place_cells(Tensor pos, Tensor table, Tensor? walls, float[] env, bool periodic, int description, "
+           "int geometry, float top_hat_width, float min_fr, float max_fr) -> Tensor",
+           lambda pos, table, walls, env, periodic, description, geometry, top_hat_width, min_fr, max_fr:
+           pos.new_empty((table.shape[0], pos.shape[1])))
 def place_cells(pos: Tensor, table: Tensor, walls: Optional[Tensor], env: List[float], periodic: bool, description: int,
                 geometry: int, top_hat_width: float, min_fr: float, max_fr: float) -> Tensor:
     """PlaceCells.get_state (riab_place_cells).  pos float32 (2, P); table float32 (n, 3) = (centre x, centre y,
@@ -87,13 +106,9 @@ def place_cells(pos: Tensor, table: Tensor, walls: Optional[Tensor], env: List[f
     return out
 
 
-@place_cells.register_fake
-def _(pos, table, walls, env, periodic, description, geometry, top_hat_width, min_fr, max_fr):
-    return pos.new_empty((table.shape[0], pos.shape[1]))
-
-
 # ---- GridCells -------------------------------------------------------------------------------------------------
-@torch.library.custom_op("riab::grid_cells", mutates_args=(), device_types="cuda")
+@_register("grid_cells(Tensor pos, Tensor table, int description, float f0, float min_fr, float max_fr) -> Tensor",
+           lambda pos, table, description, f0, min_fr, max_fr: pos.new_empty((table.shape[0], pos.shape[1])))
 def grid_cells(pos: Tensor, table: Tensor, description: int, f0: float, min_fr: float, max_fr: float) -> Tensor:
     """GridCells.get_state (riab_grid_cells).  table float32 (n, 9), see include/riab_hip.h."""
     P = _rows(pos, 2, "pos")
@@ -105,13 +120,9 @@ def grid_cells(pos: Tensor, table: Tensor, description: int, f0: float, min_fr: 
     return out
 
 
-@grid_cells.register_fake
-def _(pos, table, description, f0, min_fr, max_fr):
-    return pos.new_empty((table.shape[0], pos.shape[1]))
-
-
 # ---- HeadDirectionCells ----------------------------------------------------------------------------------------
-@torch.library.custom_op("riab::head_direction_cells", mutates_args=(), device_types="cuda")
+@_register("head_direction_cells(Tensor head_direction, Tensor table, float min_fr, float max_fr) -> Tensor",
+           lambda head_direction, table, min_fr, max_fr: head_direction.new_empty((table.shape[0], head_direction.shape[1])))
 def head_direction_cells(head_direction: Tensor, table: Tensor, min_fr: float, max_fr: float) -> Tensor:
     """HeadDirectionCells.get_state (riab_head_direction_cells).  head_direction float32 (2, P); table float32 (n, 3)
     = (cos, sin of the preferred angle, log2(e)/sigma^2)."""
@@ -123,13 +134,12 @@ def head_direction_cells(head_direction: Tensor, table: Tensor, min_fr: float, m
     return out
 
 
-@head_direction_cells.register_fake
-def _(head_direction, table, min_fr, max_fr):
-    return head_direction.new_empty((table.shape[0], head_direction.shape[1]))
-
-
 # ---- BoundaryVectorCells ---------------------------------------------------------------------------------------
-@torch.library.custom_op("riab::boundary_vector_cells", mutates_args=(), device_types="cuda")
+@_register("boundary_vector_cells(Tensor pos, Tensor? head_direction, Tensor walls, float[] env, bool periodic, "
+           "Tensor test_dirs, Tensor ray_rden, Tensor cells, Tensor vm_table, Tensor inv_norm, bool egocentric, "
+           "Tensor? cell_rows, Tensor? windows, float min_fr, float max_fr) -> Tensor",
+           lambda pos, head_direction, walls, env, periodic, test_dirs, ray_rden, cells, vm_table, inv_norm, egocentric,
+           cell_rows, windows, min_fr, max_fr: pos.new_empty((cells.shape[1], pos.shape[1])))
 def boundary_vector_cells(pos: Tensor, head_direction: Optional[Tensor], walls: Tensor, env: List[float], periodic: bool,
                           test_dirs: Tensor, ray_rden: Tensor, cells: Tensor, vm_table: Tensor, inv_norm: Tensor,
                           egocentric: bool, cell_rows: Optional[Tensor], windows: Optional[Tensor], min_fr: float,
@@ -152,14 +162,9 @@ def boundary_vector_cells(pos: Tensor, head_direction: Optional[Tensor], walls: 
     return out
 
 
-@boundary_vector_cells.register_fake
-def _(pos, head_direction, walls, env, periodic, test_dirs, ray_rden, cells, vm_table, inv_norm, egocentric, cell_rows,
-      windows, min_fr, max_fr):
-    return pos.new_empty((cells.shape[1], pos.shape[1]))
-
-
 # ---- Poisson spikes --------------------------------------------------------------------------------------------
-@torch.library.custom_op("riab::spikes", mutates_args=(), device_types="cuda")
+@_register("spikes(Tensor rates, Tensor? uniforms, float dt, int seed, int step0, int pop_id, int agent_id0) -> Tensor",
+           lambda rates, uniforms, dt, seed, step0, pop_id, agent_id0: rates.new_empty(rates.shape, dtype=torch.uint8))
 def spikes(rates: Tensor, uniforms: Optional[Tensor], dt: float, seed: int, step0: int, pop_id: int,
            agent_id0: int) -> Tensor:
     """Neurons.save_to_history's spike rule `u < dt * rate` (riab_spikes) on rates float32 (T, n, B): with explicit
@@ -177,18 +182,15 @@ def spikes(rates: Tensor, uniforms: Optional[Tensor], dt: float, seed: int, step
     io.rates, io.spikes = rates.data_ptr(), out.data_ptr()
     io.u_in = uniforms.data_ptr() if uniforms is not None else None
     io.dt = float(dt)
-    io.seed, io.step0, io.agent_id0, io.pop_id = int(seed), int(step0), int(agent_id0), int(pop_id)
+    io.seed, io.step0, io.agent_id0, io.pop_id = int(seed) & 0xFFFFFFFFFFFFFFFF, int(step0), int(agent_id0), int(pop_id)
     _L.check(_L.lib.riab_spikes(io, n, _L.current_stream()), "riab_spikes")
     return out
 
 
-@spikes.register_fake
-def _(rates, uniforms, dt, seed, step0, pop_id, agent_id0):
-    return rates.new_empty(rates.shape, dtype=torch.uint8)
-
-
 # ---- FeedForwardLayer ------------------------------------------------------------------------------------------
-@torch.library.custom_op("riab::feedforward", mutates_args=(), device_types="cuda")
+@_register("feedforward(Tensor[] inputs, Tensor[] weights_t, Tensor bias, int activation, float[] act_params) -> Tensor",
+           lambda inputs, weights_t, bias, activation, act_params:
+           inputs[0].new_empty((inputs[0].shape[0], bias.shape[0], inputs[0].shape[2])))
 def feedforward(inputs: List[Tensor], weights_t: List[Tensor], bias: Tensor, activation: int,
                 act_params: List[float]) -> Tensor:
     """FeedForwardLayer.get_state (riab_feedforward, fp32 matrix cores): out[t][m][b] = act(sum_l sum_k
@@ -214,15 +216,16 @@ def feedforward(inputs: List[Tensor], weights_t: List[Tensor], bias: Tensor, act
     return out
 
 
-@feedforward.register_fake
-def _(inputs, weights_t, bias, activation, act_params):
-    return inputs[0].new_empty((inputs[0].shape[0], bias.shape[0], inputs[0].shape[2]))
-
-
 # ---- Agent.update ----------------------------------------------------------------------------------------------
 MOTION_FIELDS = ("dt", "rot_theta_kw", "rot_sigma_kw", "rot_drift_kw", "speed_theta_kw", "speed_sigma_kw", "speed_mean_kw",
                  "speed_mean", "speed_std_is_zero", "has_drift", "drift_theta", "wall_repel_strength_kw",
                  "wall_repel_distance_kw", "thigmotaxis_kw", "hd_tau")
+
+
+def seed_arg(seed: int) -> int:
+    """A uint64 Philox key as the int64 the operator schemas carry (two's complement; the operators undo it)."""
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    return seed - (1 << 64) if seed >= (1 << 63) else seed
 
 
 def motion_list(m) -> List[float]:
@@ -230,7 +233,11 @@ def motion_list(m) -> List[float]:
     return [float(getattr(m, k)) for k in MOTION_FIELDS]
 
 
-@torch.library.custom_op("riab::agent_step_", mutates_args=("state", "hist", "diag", "noise_out"), device_types="cuda")
+@_register("agent_step_(Tensor(a!) state, Tensor(b!)? hist, Tensor(c!)? diag, Tensor? walls, float[] env, bool periodic, "
+           "float[] motion, Tensor? drift, Tensor? noise, Tensor(d!)? noise_out, Tensor? forced_pos, int seed, int step0, "
+           "int agent_id0, int T, int precision) -> ()",
+           lambda state, hist, diag, walls, env, periodic, motion, drift, noise, noise_out, forced_pos, seed, step0,
+           agent_id0, T, precision: None)
 def agent_step_(state: Tensor, hist: Optional[Tensor], diag: Optional[Tensor], walls: Optional[Tensor], env: List[float],
                 periodic: bool, motion: List[float], drift: Optional[Tensor], noise: Optional[Tensor],
                 noise_out: Optional[Tensor], forced_pos: Optional[Tensor], seed: int, step0: int, agent_id0: int, T: int,
@@ -257,11 +264,5 @@ def agent_step_(state: Tensor, hist: Optional[Tensor], diag: Optional[Tensor], w
         raise ValueError("drift must be a contiguous float64 tensor (2, B)")
     e = _env_struct(walls, env, periodic)
     _L.check(_L.lib.riab_agent_step(e, m, _L.ptr(state), B, int(agent_id0), _L.ptr(drift), _L.ptr(noise), _L.ptr(noise_out),
-                                    _L.ptr(forced_pos), int(seed), int(step0), int(T), _L.ptr(hist), _L.ptr(diag),
+                                    _L.ptr(forced_pos), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step0), int(T), _L.ptr(hist), _L.ptr(diag),
                                     int(precision), _L.current_stream()), "riab_agent_step")
-
-
-@agent_step_.register_fake
-def _(state, hist, diag, walls, env, periodic, motion, drift, noise, noise_out, forced_pos, seed, step0, agent_id0, T,
-      precision):
-    return None

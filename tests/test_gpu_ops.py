@@ -116,23 +116,34 @@ def test_ops_trace_under_torch_compile(riab):
     assert not torch.equal(s_a, ag.state_tensor), "the operator must have advanced the state"
 
 
-def test_get_state_and_update_go_through_the_operators(riab, monkeypatch):
-    """Neurons.get_state / Agent.update call torch.ops.riab.* (counted here), with unchanged results."""
-    from ratinabox_amd import _lib as L
-    calls = {"place": 0, "step": 0}
-    real_place, real_step = L.lib.riab_place_cells, L.lib.riab_agent_step
-    np.random.seed(1)
-    ag = riab.Agent(riab.Environment(), {"n_agents": 8, "dt": 0.01})
-    pcs = riab.PlaceCells(ag, {"n": 12})
-    seen = []
-    orig = torch.ops.riab.place_cells
+def test_get_state_and_update_go_through_the_operators(riab):
+    """Neurons.get_state / Agent.update dispatch torch.ops.riab.* (recorded with a TorchDispatchMode), with
+    unchanged results."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    names = []
 
-    class Spy:
-        def __call__(self, *a, **k):
-            seen.append("place_cells")
-            return orig(*a, **k)
-    monkeypatch.setattr(torch.ops.riab, "place_cells", Spy(), raising=False)
-    fr = pcs.get_state(evaluate_at=None, pos=np.array([[0.3, 0.4], [0.9, 0.1]]))
-    assert seen == ["place_cells"] and fr.shape == (12, 2)
-    d = np.linalg.norm(pcs.place_cell_centres[:, None, :] - np.array([[0.3, 0.4], [0.9, 0.1]])[None], axis=-1)
+    class Rec(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            names.append(str(func))
+            return func(*args, **(kwargs or {}))
+
+    np.random.seed(1)
+    ag = riab.Agent(riab.Environment({"walls": [[[0.5, 0.0], [0.5, 0.4]]]}), {"n_agents": 8, "dt": 0.01})
+    pcs = riab.PlaceCells(ag, {"n": 12, "wall_geometry": "euclidean"})
+    gcs = riab.GridCells(ag, {"n": 6})
+    hds = riab.HeadDirectionCells(ag, {"n": 5})
+    bvs = riab.BoundaryVectorCells(ag, {"n": 4})
+    q = np.array([[0.3, 0.4], [0.9, 0.1]])
+    with Rec():
+        fr = pcs.get_state(evaluate_at=None, pos=q)
+        gcs.get_state(evaluate_at=None, pos=q)
+        hds.get_state(evaluate_at=None, pos=q, head_direction=np.array([[1.0, 0.0], [0.0, 1.0]]))
+        bvs.get_state(evaluate_at=None, pos=q)
+        p0 = np.array(ag.pos)
+        ag.update()
+    for op in ("riab.place_cells", "riab.grid_cells", "riab.head_direction_cells", "riab.boundary_vector_cells",
+               "riab.agent_step_"):
+        assert any(op in n for n in names), f"{op} was not dispatched: {sorted(set(names))}"
+    d = np.linalg.norm(pcs.place_cell_centres[:, None, :] - q[None], axis=-1)
     np.testing.assert_allclose(fr, np.exp(-d ** 2 / (2 * 0.2 ** 2)), rtol=1e-5)
+    assert not np.allclose(np.array(ag.pos), p0)
