@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RIAB_ABI_VERSION 2
+#define RIAB_ABI_VERSION 3
 #define RIAB_MAX_WALLS 64     /* walls staged in LDS by the motion / BVC / line-of-sight kernels */
 #define RIAB_MAX_TEST_ANGLES 360
 #define RIAB_STATE_ROWS 12    /* rows of the agent state matrix, see below */
@@ -71,16 +71,25 @@ enum {
   RIAB_H_DIST = 7                              /* history["distance_travelled"] */
 };
 
-/* Environment geometry read by the hot path (Environment.py:65-191, 657-894):
- * rectangular 2D box, solid or periodic.  `walls` is Environment.walls
- * flattened to [n_walls][4] = (ax, ay, bx, by), reference order (boundary walls
- * first when solid). */
+/* Environment geometry read by the hot path (Environment.py:65-191, 657-894): a 2D box (solid or
+ * periodic) or a simple polygon (solid), optionally with polygonal holes.  `walls` is Environment.walls
+ * flattened to [n_walls][4] = (ax, ay, bx, by), reference order (Environment.py:128-163): the
+ * boundary's edges first (when solid), then the user's walls, then the holes' edges.
+ * "Inside the environment" (Environment.check_if_position_is_in_environment, :781-818) is the STRICT
+ * interior of the boundary polygon minus the strict interiors of the holes: even-odd crossings over
+ * walls[0 : n_boundary] and over the walls flagged in hole_mask (holes are disjoint, so one crossing count
+ * serves them all; hole edges may sit anywhere behind the boundary's: Environment.add_wall / add_hole
+ * append in call order, Environment.py:330-364); a point on a boundary edge is outside, a point on a hole's
+ * edge inside. */
 typedef struct RiabEnv {
-  double extent[4];      /* left, right, bottom, top */
+  double extent[4];      /* left, right, bottom, top (the bounding box of the boundary) */
   double scale;          /* Environment.scale (periodic wrap length, Environment.py:670-674) */
   int32_t periodic;      /* boundary_conditions == "periodic" */
   int32_t n_walls;
   const double* walls;   /* device, float64 [n_walls][4] */
+  int32_t polygon;       /* the boundary is not the rectangle `extent` (Environment.is_rectangular == False) */
+  int32_t n_boundary;    /* boundary edges at the head of `walls` (4 for a solid box; only read when polygon) */
+  uint64_t hole_mask;    /* bit k: walls[k] is an edge of a hole (RIAB_MAX_WALLS = 64 walls; 0: no holes) */
 } RiabEnv;
 
 /* Motion parameters of one Agent.update call, resolved on the host:
@@ -127,16 +136,21 @@ typedef struct RiabMotion {
  *             rotational velocity are overwritten by the measured ones
  *             (Agent._update_position_along_imported_trajectory / forced_next_position,
  *             Agent.py:229-238, 244-266)
+ *  resample_pos device float64 [T][2][B] or NULL: where an agent that ends a step outside a polygonal
+ *             boundary or inside a hole is put (Environment.apply_boundary_conditions' resample branch,
+ *             Environment.py:886-893: the reference draws `sample_positions(n=1, method="random")` from
+ *             np.random; parity runs hand the accepted positions in).  NULL => uniform draws over
+ *             `extent` from Philox(seed; step, agent id, attempt), rejected until inside (at most 64)
  *  hist       device float32 [T][RIAB_HIST_ROWS][B] or NULL
  *  diag       device int32 [4] or NULL, atomically accumulated:
- *             [0] bounces, [1] bounce-loop saturations, [2] boundary
+ *             [0] bounces, [1] saturations of the bounded loops (bounces, resample attempts), [2] boundary
  *             conditions applied, [3] zero-displacement steps
  *  precision  64 (float64 arithmetic, parity mode) or 32 (float32 arithmetic)
  */
 int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
                     int64_t agent_id0, const double* drift, const double* z_in, double* z_out,
-                    const double* forced_pos, uint64_t seed, uint64_t step0, int32_t T, float* hist, int32_t* diag,
-                    int32_t precision, riab_stream_t stream);
+                    const double* forced_pos, const double* resample_pos, uint64_t seed, uint64_t step0, int32_t T,
+                    float* hist, int32_t* diag, int32_t precision, riab_stream_t stream);
 
 /* ---- Environment geometry queries ---------------------------------------------------------
  * The stand-alone forms of the helpers riab_agent_step / riab_place_cells inline, for callers of
@@ -165,10 +179,13 @@ int riab_env_vectors_from_walls(const RiabEnv* env, const double* pos_x, const d
 int riab_env_check_wall_collisions(const RiabEnv* env, const double* x0, const double* y0, const double* x1,
                                    const double* y1, int64_t P, uint8_t* out, riab_stream_t stream);
 
-/* Environment.check_if_position_is_in_environment (Environment.py:781-818, rectangular box: strict
- * interior) -> inside_out uint8 [P] (or NULL), and, when `apply`, Environment.apply_boundary_conditions
- * (Environment.py:855-894) in place: positions outside are clamped to [min+0.01, max-0.01] (solid)
- * or wrapped modulo the extent (periodic). */
+/* Environment.check_if_position_is_in_environment (Environment.py:781-818: strict interior of the
+ * boundary, outside every hole) -> inside_out uint8 [P] (or NULL), and, when `apply`,
+ * Environment.apply_boundary_conditions (Environment.py:855-894) in place for a rectangular environment:
+ * positions outside the box are clamped to [min+0.01, max-0.01] (solid) or wrapped modulo the extent
+ * (periodic).  Positions that need the RESAMPLE branch (inside a hole, or outside a polygonal boundary) are
+ * left unchanged and flagged 2 in inside_out: the caller draws their replacements (the reference draws them
+ * from np.random). */
 int riab_env_boundary_conditions(const RiabEnv* env, double* pos_x, double* pos_y, int64_t P, uint8_t* inside_out,
                                  int32_t apply, riab_stream_t stream);
 

@@ -130,23 +130,34 @@ def shortest_vectors_from_walls(pos, walls):
 # Environment queries (Environment.py)
 # --------------------------------------------------------------------------- #
 class EnvSpec:
-    """The subset of `Environment` state the hot path reads (Environment.py:65-191):
-    rectangular 2D box `[0, aspect*scale] x [0, scale]`, solid or periodic,
-    `walls` in reference order (4 boundary walls first when solid)."""
+    """The subset of `Environment` state the hot path reads (Environment.py:65-191): a 2D box
+    `[0, aspect*scale] x [0, scale]` (solid or periodic) or a simple polygon `boundary` (solid), `walls` in
+    reference order (Environment.py:128-163): the boundary's edges first when solid — edge i runs from corner
+    i+1 to corner i —, then the user's walls, then the edges of the `holes`."""
 
-    def __init__(self, scale=1.0, aspect=1.0, boundary_conditions="solid", walls=()):
+    def __init__(self, scale=1.0, aspect=1.0, boundary_conditions="solid", walls=(), boundary=None, holes=()):
         self.scale = float(scale)
         self.aspect = float(aspect)
         self.boundary_conditions = boundary_conditions
-        b = [[0, 0], [aspect * scale, 0], [aspect * scale, scale], [0, scale]]
+        self.is_rectangular = boundary is None
+        b = [[0, 0], [aspect * scale, 0], [aspect * scale, scale], [0, scale]] if boundary is None else \
+            np.asarray(boundary, dtype=np.float64).reshape(-1, 2).tolist()
+        self.boundary = np.asarray(b, dtype=np.float64)
+        self.holes = [np.asarray(h, dtype=np.float64).reshape(-1, 2) for h in holes]
         user = np.asarray(walls, dtype=np.float64).reshape(-1, 2, 2)
         if boundary_conditions == "solid":
             # Environment.py:137-144: wall i runs from b[i+1] to b[i]
-            bw = np.array([[b[(i + 1) % 4], b[i]] for i in range(4)], dtype=np.float64)
+            nb = len(b)
+            bw = np.array([[b[(i + 1) % nb], b[i]] for i in range(nb)], dtype=np.float64)
             self.walls = np.vstack((bw, user))
         else:
+            assert boundary is None, "periodic boundary conditions need the rectangular box"
             self.walls = user
-        self.extent = np.array([0.0, aspect * scale, 0.0, scale])
+        for h in self.holes:  # Environment.py:154-161
+            k = len(h)
+            self.walls = np.vstack((self.walls, np.array([[h[(i + 1) % k], h[i]] for i in range(k)])))
+        self.extent = np.array([self.boundary[:, 0].min(), self.boundary[:, 0].max(), self.boundary[:, 1].min(),
+                                self.boundary[:, 1].max()])
 
     @property
     def periodic(self):
@@ -189,7 +200,7 @@ def env_distances(env, pos1, pos2, wall_geometry="euclidean"):
         wall = env.walls[4]
         via = []
         for e in wall:  # Environment.py:746-753: only endpoints strictly inside the env
-            if (e[0] > env.extent[0]) and (e[0] < env.extent[1]) and (e[1] > env.extent[2]) and (e[1] < env.extent[3]):
+            if env_is_inside(env, e[None])[0]:
                 d1 = np.sqrt(((pos1 - e) ** 2).sum(-1))[:, None]
                 d2 = np.sqrt(((e - pos2) ** 2).sum(-1))[None, :]
                 via.append(d1 + d2)
@@ -200,24 +211,86 @@ def env_distances(env, pos1, pos2, wall_geometry="euclidean"):
     raise ValueError(wall_geometry)
 
 
+def polygon_contains(corners, pos):
+    """`shapely.Polygon(corners).contains(Point(p))` for `(P, 2)` points: the STRICT interior (a point on an
+    edge is not contained) by the even-odd rule — what Environment.check_if_position_is_in_environment calls
+    for the boundary and for every hole (Environment.py:808-816)."""
+    c = np.asarray(corners, dtype=np.float64).reshape(-1, 2)
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 2)
+    px, py = pos[:, 0][:, None], pos[:, 1][:, None]
+    a, b = c, np.roll(c, -1, axis=0)
+    ax, ay, bx, by = a[None, :, 0], a[None, :, 1], b[None, :, 0], b[None, :, 1]
+    cross = (bx - ax) * (py - ay) - (by - ay) * (px - ax)
+    on_edge = ((cross == 0) & (np.minimum(ax, bx) <= px) & (px <= np.maximum(ax, bx)) &
+               (np.minimum(ay, by) <= py) & (py <= np.maximum(ay, by))).any(axis=1)
+    straddle = (ay > py) != (by > py)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        x_cross = ax + (py - ay) * (bx - ax) / (by - ay)
+    odd = (np.count_nonzero(straddle & (px < x_cross), axis=1) % 2) == 1
+    return odd & ~on_edge
+
+
 def env_is_inside(env, pos):
-    """Environment.check_if_position_is_in_environment (Environment.py:781-818)
-    for a rectangular box without holes: strict interior (shapely `contains`)."""
+    """Environment.check_if_position_is_in_environment (Environment.py:781-818): strictly inside the boundary
+    (the rectangle, or the polygon) and not strictly inside any hole."""
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 2)
+    if env.is_rectangular:
+        e = env.extent
+        inside = (pos[:, 0] > e[0]) & (pos[:, 0] < e[1]) & (pos[:, 1] > e[2]) & (pos[:, 1] < e[3])
+    else:
+        inside = polygon_contains(env.boundary, pos)
+    for h in env.holes:
+        inside = inside & ~polygon_contains(h, pos)
+    return inside
+
+
+def env_needs_resample(env, pos):
+    """Which positions take the RESAMPLE branch of apply_boundary_conditions (Environment.py:886-893): outside a
+    polygonal boundary, or inside the bounding box of a rectangular environment but not in it (i.e. in a hole)."""
     pos = np.asarray(pos, dtype=np.float64).reshape(-1, 2)
     e = env.extent
-    return (pos[:, 0] > e[0]) & (pos[:, 0] < e[1]) & (pos[:, 1] > e[2]) & (pos[:, 1] < e[3])
+    in_box = (pos[:, 0] > e[0]) & (pos[:, 0] < e[1]) & (pos[:, 1] > e[2]) & (pos[:, 1] < e[3])
+    return ~env_is_inside(env, pos) & (in_box | (not env.is_rectangular))
 
 
-def env_apply_boundary_conditions(env, pos):
-    """Environment.apply_boundary_conditions (Environment.py:855-894), rectangular:
-    solid -> clamp to [min+0.01, max-0.01]; periodic -> modulo the extent."""
+def env_apply_boundary_conditions(env, pos, resample_pos=None):
+    """Environment.apply_boundary_conditions (Environment.py:855-894) for positions that are NOT inside: outside
+    a rectangular box, solid -> clamp to [min+0.01, max-0.01], periodic -> modulo the extent; in a hole / outside
+    a polygon -> `resample_pos` (the reference draws `sample_positions(n=1, method="random")` from np.random: the
+    accepted draws are an input here)."""
     pos = np.array(pos, dtype=np.float64).reshape(-1, 2)
     e = env.extent
     if env.periodic:
-        return np.stack((pos[:, 0] % e[1], pos[:, 1] % e[3]), axis=-1)
-    x = np.minimum(np.maximum(pos[:, 0], e[0] + 0.01), e[1] - 0.01)
-    y = np.minimum(np.maximum(pos[:, 1], e[2] + 0.01), e[3] - 0.01)
-    return np.stack((x, y), axis=-1)
+        out = np.stack((pos[:, 0] % e[1], pos[:, 1] % e[3]), axis=-1)
+    else:
+        x = np.minimum(np.maximum(pos[:, 0], e[0] + 0.01), e[1] - 0.01)
+        y = np.minimum(np.maximum(pos[:, 1], e[2] + 0.01), e[3] - 0.01)
+        out = np.stack((x, y), axis=-1)
+    rs = env_needs_resample(env, pos)
+    if rs.any():
+        assert resample_pos is not None, "positions in a hole / outside the polygon need resample positions"
+        out = np.where(rs[:, None], np.asarray(resample_pos, dtype=np.float64).reshape(-1, 2), out)
+    return out
+
+
+def resample_draws(seed, step, agent_ids, env, max_attempts=64):
+    """The production-mode resample (riab_agent_kernel.h): per attempt one Philox call keyed by
+    (step lo, step hi ^ attempt << 24, agent id, TAG_MOTION ^ 2), two 24-bit uniforms over the extent, until the
+    position is inside.  -> `(B, 2)` accepted positions."""
+    agent_ids = np.asarray(agent_ids, dtype=np.uint64)
+    out = np.zeros((len(agent_ids), 2))
+    k0, k1 = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    e = env.extent
+    for i, aid in enumerate(agent_ids):
+        for attempt in range(max_attempts):
+            w = philox4x32_10(np.uint32(step & 0xFFFFFFFF), np.uint32(((step >> 32) & 0xFFFFFFFF) ^ (attempt << 24)),
+                              np.uint32(aid), np.uint32(TAG_MOTION ^ 2), k0, k1)
+            u0 = float(np.float32(int(w[0]) >> 8) * np.float32(2.0 ** -24))
+            u1 = float(np.float32(int(w[1]) >> 8) * np.float32(2.0 ** -24))
+            out[i] = (e[0] + u0 * (e[1] - e[0]), e[2] + u1 * (e[3] - e[2]))
+            if env_is_inside(env, out[i][None])[0]:
+                break
+    return out
 
 
 # --------------------------------------------------------------------------- #
@@ -260,7 +333,7 @@ def init_state(env, n_agents, speed_mean, rng):
 
 
 def agent_step(env, state, dt, z_rot, z_speed, params=None, drift_velocity=None,
-               drift_to_random_strength_ratio=1.0, z_zero=None, kwargs=None, forced_pos=None):
+               drift_to_random_strength_ratio=1.0, z_zero=None, kwargs=None, forced_pos=None, resample_pos=None):
     """One `Agent.update()` (Agent.py:160-242, random-motion branch, 2D) for B
     independent agents.  `state` is a dict of `(B,...)` float64 arrays (see
     `init_state`); `z_rot`, `z_speed` `(B,)` are the two standard-normal draws
@@ -272,7 +345,8 @@ def agent_step(env, state, dt, z_rot, z_speed, params=None, drift_velocity=None,
     new state dict plus `n_bounces (B,)` and `bc_applied (B,)` diagnostics.
     `forced_pos (B,2)`: the imported / forced-trajectory branches (Agent.py:229-238): the motion
     model is skipped, the agent is put at `forced_pos` and velocity / rotational velocity are
-    overwritten by the measured ones."""
+    overwritten by the measured ones.  `resample_pos (B,2)`: where an agent that ends the step in a hole / outside
+    a polygonal boundary is put (the reference's np.random draw, Environment.py:886-893)."""
     p = dict(DEFAULT_MOTION)
     if params:
         p.update(params)
@@ -370,11 +444,14 @@ def agent_step(env, state, dt, z_rot, z_speed, params=None, drift_velocity=None,
 
     # -- boundary safety net (Agent.py:221-222)
     outside = ~env_is_inside(env, pos)
+    pos_before_bc = pos.copy()
     if outside.any():
-        pos = np.where(outside[:, None], env_apply_boundary_conditions(env, pos), pos)
+        pos = np.where(outside[:, None], env_apply_boundary_conditions(env, pos, resample_pos), pos)
 
-    return _finish_step(env, p, dt, pos, prev_pos, vel, rot, prev_mv, hd, dist_trav, dclose, n_bounces, outside,
-                        z_zero, overwrite=False)
+    out = _finish_step(env, p, dt, pos, prev_pos, vel, rot, prev_mv, hd, dist_trav, dclose, n_bounces, outside,
+                       z_zero, overwrite=False)
+    out["pos_before_bc"] = pos_before_bc  # (diagnostic: which branch of apply_boundary_conditions a step took)
+    return out
 
 
 def _finish_step(env, p, dt, pos, prev_pos, vel, rot, prev_mv, hd, dist_trav, dclose, n_bounces, outside, z_zero,

@@ -272,6 +272,7 @@ class Agent:
         dt = dt or self.dt
         self.dt = dt
         noise = kwargs.pop("noise", None) if "noise" in kwargs else None
+        resample = kwargs.pop("resample_positions", None) if "resample_positions" in kwargs else None
         has_drift = drift_velocity is not None
         m = self._motion(dt, has_drift, ratio, kwargs)
         env, _walls = self.Environment.device_tables(self._device)
@@ -289,6 +290,16 @@ class Agent:
                 zt = torch.cat((zt, pad), dim=-1)
             z = zt.contiguous()
             assert z.shape == (T, 2, self._Bp), f"noise must be (T,2,B), got {tuple(z.shape)}"
+        rs = None
+        if resample is not None:
+            # where agents that end a step in a hole / outside a polygonal boundary are put (parity runs: the
+            # reference's np.random draws); (T, B, 2) / (B, 2) / (2,)
+            r = np.asarray(resample, dtype=np.float64)
+            r = np.broadcast_to(r.reshape((1,) * (3 - r.ndim) + r.shape) if r.ndim < 3 else r, (T, self._B, 2))
+            full = np.empty((T, 2, self._Bp))
+            full[:, :, :self._B] = np.transpose(r, (0, 2, 1))
+            full[:, :, self._B:] = full[:, :, :1]
+            rs = torch.from_numpy(full).to(self._device)
         if hist_view is None and self.save_history:
             hist_view = self._hist.reserve(T)
         if hist_view is None:
@@ -299,20 +310,18 @@ class Agent:
         if stream is None and self._device.type == "cuda":
             # the eager per-step path goes through the registered operator (ops.py): torch.ops.riab.agent_step_
             from . import ops
-            Env = self.Environment
-            torch.ops.riab.agent_step_(self._state, hist_view, self._diag, _walls if len(Env.walls) else None,
-                                       [float(x) for x in Env.extent] + [float(Env.scale)],
-                                       Env.boundary_conditions == "periodic", ops.motion_list(m), drift, z, z_out, forced,
-                                       ops.seed_arg(self.rng_seed), int(self._step_index), int(self.agent_id0), int(T),
-                                       int(self.precision))
+            w_op, e_op, periodic = self.Environment.op_env_args(self._device)
+            torch.ops.riab.agent_step_(self._state, hist_view, self._diag, w_op, e_op, periodic, ops.motion_list(m), drift, z,
+                                       z_out, forced, rs, ops.seed_arg(self.rng_seed), int(self._step_index),
+                                       int(self.agent_id0), int(T), int(self.precision))
         else:
             s = stream if stream is not None else _L.current_stream()
             rc = _L.lib.riab_agent_step(env, m, _L.ptr(self._state), self._Bp, int(self.agent_id0), _L.ptr(drift),
-                                        _L.ptr(z), _L.ptr(z_out), _L.ptr(forced), int(self.rng_seed),
+                                        _L.ptr(z), _L.ptr(z_out), _L.ptr(forced), _L.ptr(rs), int(self.rng_seed),
                                         int(self._step_index), int(T),
                                         _L.ptr(hist_view), _L.ptr(self._diag), int(self.precision), s)
             _L.check(rc, "riab_agent_step")
-        self._keep = (drift, z, _walls, hist_view, forced)  # keep operands alive until the stream is done
+        self._keep = (drift, z, _walls, hist_view, forced, rs)  # keep operands alive until the stream is done
         self._last_row = hist_view[T - 1]            # fp32 [8, Bp]: positions / head directions of the newest step
         for _ in range(T):
             self.prev_t = self.t

@@ -10,9 +10,10 @@ walls, inside test, boundary conditions: Environment.py:657-894) are not Python
 here: they are inlined into the HIP kernels, which read the device copy of the
 wall table kept by `device_tables()`.
 
-In scope: rectangular 2D boxes, solid or periodic, with interior walls.
-Polygonal boundaries, holes and 1D environments are outside the
-accelerated path and raise NotImplementedError."""
+In scope: 2D environments — rectangular boxes (solid or periodic) and simple-polygon
+boundaries (solid), with interior walls and polygonal holes (reference
+Environment.py:71-73, 128-163).  1D environments are outside the accelerated path and
+raise NotImplementedError."""
 import copy
 import warnings
 
@@ -28,9 +29,9 @@ class Environment:
         "scale": 1,        # metres
         "aspect": 1,       # width / height of the rectangular box
         "dx": 0.01,        # discretisation used by evaluate_at="all"
-        "boundary": None,  # polygon boundary: not supported on the accelerated path
+        "boundary": None,  # corners [[x0,y0],[x1,y1],...] of a simple polygon bounding the environment (None: the box)
         "walls": [],       # interior walls [[x0,y0],[x1,y1]]
-        "holes": [],       # not supported on the accelerated path
+        "holes": [],       # corners [[[x0,y0],...],...] of polygonal holes inside the environment
         "objects": [],     # object positions [[x0,y0],...] (all type 0); or use add_object
     }
 
@@ -44,24 +45,44 @@ class Environment:
         self.agents_dict = {}
         if self.dimensionality != "2D":
             raise NotImplementedError("ratinabox_amd accelerates 2D environments only")
-        if self.boundary is not None:
-            raise NotImplementedError("polygonal boundaries are outside the accelerated path (rectangular boxes only)")
-        if len(self.holes) > 0:
-            raise NotImplementedError("holes are outside the accelerated path")
+        self._device_cache = {}
         if self.boundary_conditions not in ("solid", "periodic"):
             raise ValueError("boundary_conditions must be 'solid' or 'periodic'")
         self.D = 2
-        self.is_rectangular = True
-        self.has_holes = False
-        b = [[0, 0], [self.aspect * self.scale, 0], [self.aspect * self.scale, self.scale], [0, self.scale]]
+        self.is_rectangular = self.boundary is None
+        if self.is_rectangular:
+            b = [[0, 0], [self.aspect * self.scale, 0], [self.aspect * self.scale, self.scale], [0, self.scale]]
+        else:
+            b = np.asarray(self.boundary, dtype=float).reshape(-1, 2).tolist()
+            assert len(b) >= 3, "a polygonal boundary needs at least 3 corners"
+            if self.boundary_conditions == "periodic":
+                # (the reference warns, rewrites only params["boundary_conditions"] and carries on with a periodic
+                # attribute and no boundary walls, Environment.py:130-136: an accident, not a behaviour to mirror)
+                raise NotImplementedError("periodic boundary conditions need a rectangular environment")
         self.boundary = b
         self.walls = np.array(self.walls, dtype=float).reshape(-1, 2, 2)
+        self._wall_is_hole = [False] * len(self.walls)
+        self._n_boundary = 0
         if self.boundary_conditions == "solid":
             # reference order (Environment.py:137-144): boundary wall i runs from corner i+1 to corner i
-            boundary_walls = np.array([[b[(i + 1) % 4], b[i]] for i in range(4)], dtype=float)
+            nb = len(b)
+            boundary_walls = np.array([[b[(i + 1) % nb], b[i]] for i in range(nb)], dtype=float)
             self.walls = np.vstack((boundary_walls, self.walls))
-        left, right = 0.0, float(self.aspect * self.scale)
-        bottom, top = 0.0, float(self.scale)
+            self._wall_is_hole = [False] * nb + self._wall_is_hole
+            self._n_boundary = nb
+        # holes: their edges follow the walls (Environment.py:146-162)
+        holes, self.holes = list(self.holes), []
+        self.holes_polygons = []   # (corner arrays; the reference keeps shapely polygons)
+        self.has_holes = False
+        if len(holes) > 0:
+            assert np.array(holes, dtype=object).ndim >= 1 and all(np.ndim(h) == 2 for h in holes), \
+                "Incorrect dimensionality for holes list. It must be a list of lists of coordinates"
+            for h in holes:
+                self.add_hole(h)
+        self.boundary_polygon = np.asarray(b, dtype=float)
+        left, right = min(c[0] for c in b), max(c[0] for c in b)
+        bottom, top = min(c[1] for c in b), max(c[1] for c in b)
+        left, right, bottom, top = float(left), float(right), float(bottom), float(top)
         self.centre = np.array([(left + right) / 2, (top + bottom) / 2])
         self.extent = np.array([left, right, bottom, top])
         # objects seen by ObjectVectorCells (Environment.py:166-176)
@@ -129,10 +150,23 @@ class Environment:
         """Append one wall [[x1,y1],[x2,y2]] (Environment.py:330-342)."""
         wall = np.asarray(wall, dtype=float).reshape(1, 2, 2)
         self.walls = wall if len(self.walls) == 0 else np.concatenate((self.walls, wall), axis=0)
+        self._wall_is_hole.append(False)
         self._device_cache.clear()
 
     def add_hole(self, hole):
-        raise NotImplementedError("holes are outside the accelerated path")
+        """Add a polygonal hole [[x1,y1],[x2,y2],...] (>= 3 corners): its edges are appended to `walls`
+        (edge i runs from corner i+1 to corner i) and its interior stops being part of the environment
+        (reference Environment.py:344-364)."""
+        hole = np.asarray(hole, dtype=float).reshape(-1, 2)
+        assert len(hole) >= 3, "holes must have at least 3 corners"
+        self.holes.append(hole.tolist())
+        self.has_holes = True
+        k = len(hole)
+        hole_walls = np.array([[hole[(i + 1) % k], hole[i]] for i in range(k)], dtype=float)
+        self.walls = hole_walls if len(self.walls) == 0 else np.vstack((self.walls, hole_walls))
+        self._wall_is_hole.extend([True] * k)
+        self.holes_polygons.append(hole)
+        self._device_cache.clear()
 
     def add_object(self, object, type="new"):
         """Add an object at `object` (x, y).  type: "new" (a new type id), "same" (the last
@@ -155,17 +189,29 @@ class Environment:
         """n positions in the box: "random", "uniform" (a grid, x fastest) or
         "uniform_jitter"; draws from the global np.random state in the reference's order."""
         ex = self.extent
+        constrained = (not self.is_rectangular) or self.has_holes
         if method == "random":
             positions = np.zeros((n, 2))
             positions[:, 0] = np.random.uniform(ex[0], ex[1], size=n)
             positions[:, 1] = np.random.uniform(ex[2], ex[3], size=n)
+            if constrained:
+                # positions outside the polygon / inside a hole are redrawn until they pass, in the reference's
+                # (recursive) draw order (Environment.py:593-600)
+                for i in range(n):
+                    if not self.check_if_position_is_in_environment(positions[i]):
+                        positions[i] = self.sample_positions(n=1, method="random").reshape(-1)
             return positions
         if method[:7] == "uniform":
             area = (ex[1] - ex[0]) * (ex[3] - ex[2])
+            if self.has_holes:
+                area -= sum(utils.polygon_area(h) for h in self.holes)
             delta = np.sqrt(area / n)
             x = np.linspace(ex[0] + delta / 2, ex[1] - delta / 2, int((ex[1] - ex[0]) / delta))
             y = np.linspace(ex[2] + delta / 2, ex[3] - delta / 2, int((ex[3] - ex[2]) / delta))
             positions = np.array(np.meshgrid(x, y)).reshape(2, -1).T
+            if constrained:  # grid points that are not legal positions are dropped (and made up for below)
+                keep = [i for i, p in enumerate(positions) if self.check_if_position_is_in_environment(p)]
+                positions = positions[keep]
             n_uniform = positions.shape[0]
             if method[7:] == "_jitter":
                 positions = positions + np.random.uniform(-0.45 * delta, 0.45 * delta, positions.shape)
@@ -189,10 +235,18 @@ class Environment:
         return np.stack((xm, ym), axis=-1)
 
     def check_if_position_is_in_environment(self, pos):
-        """Strict interior test (Environment.py:781-818), host-side convenience."""
+        """True if `pos` is strictly inside the boundary and not strictly inside a hole (reference
+        Environment.py:781-818; host-side, one position: what the init-time samplers call per point.  The
+        per-step test runs in the motion kernel, the batched one in `apply_boundary_conditions`)."""
         pos = np.asarray(pos, dtype=float).reshape(-1)
-        e = self.extent
-        return bool((pos[0] > e[0]) and (pos[0] < e[1]) and (pos[1] > e[2]) and (pos[1] < e[3]))
+        if self.is_rectangular:
+            e = self.extent
+            inside = bool((pos[0] > e[0]) and (pos[0] < e[1]) and (pos[1] > e[2]) and (pos[1] < e[3]))
+        else:
+            inside = utils.polygon_contains(self.boundary_polygon, pos)
+        if inside and self.has_holes:
+            inside = not any(utils.polygon_contains(h, pos) for h in self.holes_polygons)
+        return inside
 
     # -- geometry queries on device (the stand-alone forms of what the kernels inline) ----------
     def _query_rows(self, pos):
@@ -273,18 +327,35 @@ class Environment:
         return (self.walls, hit[0] if single else hit)
 
     def apply_boundary_conditions(self, pos):
-        """Positions outside the box are clamped 1 cm inside it (solid) or wrapped (periodic); positions
-        inside are returned unchanged (reference Environment.py:855-894).  `(2,)` or `(P, 2)`."""
+        """Positions inside the environment are returned unchanged.  Outside a rectangular box: clamped 1 cm
+        inside it (solid) or wrapped (periodic).  Inside a hole, or outside a polygonal boundary: replaced by
+        `sample_positions(n=1, method="random")` — drawn from np.random here on the host, in the reference's
+        order (reference Environment.py:855-894).  `(2,)` or `(P, 2)`."""
         import torch
         from . import _lib as L
         single = np.ndim(pos) == 1
         x, y = self._query_rows(pos)
         xy = torch.stack((x, y)).contiguous()
+        flags = torch.empty(x.numel(), dtype=torch.uint8, device=xy.device)
         env, _keep = self.device_tables(self.query_device)
-        L.check(L.lib.riab_env_boundary_conditions(env, L.ptr(xy[0]), L.ptr(xy[1]), x.numel(), None, 1,
+        L.check(L.lib.riab_env_boundary_conditions(env, L.ptr(xy[0]), L.ptr(xy[1]), x.numel(), L.ptr(flags), 1,
                                                    L.current_stream()), "riab_env_boundary_conditions")
         out = xy.t().cpu().numpy()
+        for i in np.flatnonzero(flags.cpu().numpy() == 2):  # (2: the kernel leaves the random draw to the caller)
+            out[i] = self.sample_positions(n=1, method="random").reshape(-1)
         return out[0] if single else out
+
+    def positions_in_environment(self, pos):
+        """check_if_position_is_in_environment for `(P, 2)` positions at once, on the device -> `(P,)` bools
+        (batched extension)."""
+        import torch
+        from . import _lib as L
+        x, y = self._query_rows(pos)
+        flags = torch.empty(x.numel(), dtype=torch.uint8, device=x.device)
+        env, _keep = self.device_tables(self.query_device)
+        L.check(L.lib.riab_env_boundary_conditions(env, L.ptr(x), L.ptr(y), x.numel(), L.ptr(flags), 0,
+                                                   L.current_stream()), "riab_env_boundary_conditions")
+        return flags.cpu().numpy() == 1
 
     # -- device tables --------------------------------------------------------------------
     def device_tables(self, device):
@@ -298,13 +369,20 @@ class Environment:
         # the wall table as bytes: catches in-place edits of Environment.walls at ~1 us per call
         w_bytes = w_now.tobytes() if type(w_now) is np.ndarray and w_now.dtype == np.float64 else \
             np.asarray(w_now, dtype=np.float64).tobytes()
+        if len(self._wall_is_hole) != len(np.asarray(w_now).reshape(-1, 4)):
+            if any(self._wall_is_hole):
+                raise ValueError("Environment.walls was replaced in an environment with holes: use add_wall / add_hole, "
+                                 "which keep track of which walls are hole edges")
+            self._wall_is_hole = [False] * len(np.asarray(w_now).reshape(-1, 4))
+        shape_key = (self.is_rectangular, self._n_boundary, tuple(self._wall_is_hole))
         if hit is not None:
-            (src, bc, sc, asp), env, wt = hit
+            (src, bc, sc, asp, shp), env, wt = hit
             # fast path (every step): same geometry, wall array unchanged
-            if src == w_bytes and bc == self.boundary_conditions and sc == self.scale and asp == self.aspect:
+            if src == w_bytes and bc == self.boundary_conditions and sc == self.scale and asp == self.aspect and \
+                    shp == shape_key:
                 return env, wt
         walls = np.ascontiguousarray(np.asarray(self.walls, dtype=np.float64).reshape(-1, 4))
-        key = (w_bytes, self.boundary_conditions, self.scale, self.aspect)
+        key = (w_bytes, self.boundary_conditions, self.scale, self.aspect, shape_key)
         if len(walls) > _lib.MAX_WALLS:
             raise ValueError(f"at most {_lib.MAX_WALLS} walls are supported on device, got {len(walls)}")
         wt = torch.from_numpy(walls if len(walls) else np.zeros((1, 4))).to(device)
@@ -315,8 +393,21 @@ class Environment:
         env.periodic = 1 if self.boundary_conditions == "periodic" else 0
         env.n_walls = int(len(walls))
         env.walls = wt.data_ptr()
+        env.polygon = 0 if self.is_rectangular else 1
+        env.n_boundary = int(self._n_boundary)
+        env.hole_mask = sum(1 << k for k, h in enumerate(self._wall_is_hole) if h)
         self._device_cache[slot] = (key, env, wt)
         return env, wt
+
+    def op_env_args(self, device):
+        """(walls tensor or None, env list, periodic) for the registered operators (ops.py: torch.ops.riab.*)."""
+        env, wt = self.device_tables(device)
+        e = [float(x) for x in self.extent] + [float(self.scale)]
+        if env.polygon or env.hole_mask:
+            if env.hole_mask >= 1 << 53:
+                raise ValueError("through the operators, hole edges must be among the first 53 walls")
+            e += [float(env.polygon), float(env.n_boundary), float(env.hole_mask)]
+        return (wt if env.n_walls else None), e, bool(env.periodic)
 
     def plot_environment(self, *a, **k):
         raise NotImplementedError("plotting is outside the accelerated path; use the reference package for figures")

@@ -57,11 +57,8 @@ class Neurons:
     _state_op = None
 
     def _env_op_args(self):
-        """(walls tensor or None, [l, r, b, t, scale], periodic) of the Environment for the operators."""
-        Env = self.Agent.Environment
-        _env, wt = Env.device_tables(self._device)
-        walls = wt if len(Env.walls) else None
-        return walls, [float(x) for x in Env.extent] + [float(Env.scale)], Env.boundary_conditions == "periodic"
+        """(walls tensor or None, env list, periodic) of the Environment for the operators."""
+        return self.Agent.Environment.op_env_args(self._device)
 
     def __init__(self, Agent, params={}):
         self.Agent = Agent

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 
 from . import _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_WALLS = 64
 STATE_ROWS = 12
 HIST_ROWS = 8
@@ -29,7 +29,8 @@ GC_DESCRIPTIONS = {"rectified_cosines": 0, "shifted_cosines": 1}
 
 class RiabEnv(C.Structure):
     _fields_ = [("extent", C.c_double * 4), ("scale", C.c_double), ("periodic", C.c_int32),
-                ("n_walls", C.c_int32), ("walls", C.c_void_p)]
+                ("n_walls", C.c_int32), ("walls", C.c_void_p), ("polygon", C.c_int32), ("n_boundary", C.c_int32),
+                ("hole_mask", C.c_uint64)]
 
 
 class RiabMotion(C.Structure):
@@ -101,8 +102,8 @@ ACTIVATIONS = {"linear": 0, "sigmoid": 1, "relu": 2, "tanh": 3, "retanh": 4, "so
 # name -> (restype, argtypes): every symbol include/riab_hip.h declares
 PROTOTYPES = {
     "riab_agent_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
-                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32,
-                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "riab_place_cells": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_float, C.c_void_p]),
     "riab_grid_cells": (C.c_int, [C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),

@@ -62,11 +62,11 @@ using namespace riab;
 
 extern "C" int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
                                int64_t agent_id0, const double* drift, const double* z_in, double* z_out,
-                               const double* forced_pos, uint64_t seed, uint64_t step0, int32_t T, float* hist, int32_t* diag,
-                               int32_t precision, riab_stream_t stream) {
+                               const double* forced_pos, const double* resample_pos, uint64_t seed, uint64_t step0,
+                               int32_t T, float* hist, int32_t* diag, int32_t precision, riab_stream_t stream) {
   AgentArgs a;
   const int rc = fill_agent_args(a, env, motion, state, B, agent_id0, drift, z_in, z_out, forced_pos, seed, step0, T, hist,
-                                 diag, precision);
+                                 diag, precision, resample_pos);
   if (rc) return rc;
   const dim3 grid((unsigned)((B + 63) / 64));
   hipStream_t s = (hipStream_t)stream;

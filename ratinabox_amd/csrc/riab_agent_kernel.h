@@ -99,6 +99,8 @@ struct AgentArgs {
   const double* z_in;   // [T][2][B] or null
   double* z_out;        // [T][2][B] or null
   const double* forced; // [T][2][B] or null: imported / forced positions (Agent.py:229-238)
+  const double* resample;  // [T][2][B] or null: explicit replacement positions of the resample boundary condition
+  EnvShape shape;          // boundary polygon / holes (Environment.py:781-818)
   uint32_t k0, k1;
   uint64_t step0;
   int T;
@@ -545,6 +547,7 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
   const R cpos = (R)6 * (g * g);
   const bool repel = (m.wall_repel_strength_kw != 0.0) && nw > 0;
   const R e0 = (R)a.e0, e1 = (R)a.e1, e2 = (R)a.e2, e3 = (R)a.e3;
+  const bool simple_box = !a.shape.boundary_mask && !a.shape.hole_mask;  // (the rectangle test alone decides)
   // divisions by loop constants become multiplications (<= 1 ulp from the reference's quotient)
   const R inv_dt = (R)(1.0 / m.dt);
   const TailConst<R> tail_c = {dt, inv_dt, (R)(1.0 - m.dt / m.hd_tau), (R)(m.dt / m.hd_tau), m.hd_tau <= m.dt};
@@ -766,17 +769,50 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
       if (it == RIAB_MAX_BOUNCES) ++n_sat;
     }
     // ---- boundary safety net (Agent.py:221-222, Environment.py:781-894) -------------------
-    if (!(px > e0 && px < e1 && py > e2 && py < e3)) {
+    const bool in_box = px > e0 && px < e1 && py > e2 && py < e3;
+    bool inside = in_box;
+    if (!simple_box) {  // polygonal boundary and / or holes: the strict interior of the one minus those of the others
+      auto edge = [&](int k, double& ax, double& ay, double& bx, double& by) {
+        const Wall<R> W = s_w[k];
+        ax = (double)W.ax; ay = (double)W.ay; bx = (double)(W.ax + W.sx); by = (double)(W.ay + W.sy);
+      };
+      inside = env_contains(a.shape, (double)px, (double)py, edge);
+    }
+    if (!inside) {
       ++n_bc;
-      if (a.periodic) {
-        px = px - e1 * floor(px / e1);  // np.mod(pos, extent)
-        py = py - e3 * floor(py / e3);
+      if (!a.shape.boundary_mask && !in_box) {  // outside the box itself (Environment.py:871-885)
+        if (a.periodic) {
+          px = px - e1 * floor(px / e1);  // np.mod(pos, extent)
+          py = py - e3 * floor(py / e3);
+        } else {
+          const R lo_x = e0 + (R)0.01, hi_x = e1 - (R)0.01, lo_y = e2 + (R)0.01, hi_y = e3 - (R)0.01;
+          px = (lo_x > px) ? lo_x : px;  // python max(pos, lo): NaN stays NaN
+          px = (hi_x < px) ? hi_x : px;
+          py = (lo_y > py) ? lo_y : py;
+          py = (hi_y < py) ? hi_y : py;
+        }
+      } else if (a.resample) {  // in a hole / outside the polygon: a new random position (Environment.py:886-893)
+        px = (R)a.resample[((int64_t)t * 2 + 0) * B + b];
+        py = (R)a.resample[((int64_t)t * 2 + 1) * B + b];
       } else {
-        const R lo_x = e0 + (R)0.01, hi_x = e1 - (R)0.01, lo_y = e2 + (R)0.01, hi_y = e3 - (R)0.01;
-        px = (lo_x > px) ? lo_x : px;  // python max(pos, lo): NaN stays NaN
-        px = (hi_x < px) ? hi_x : px;
-        py = (lo_y > py) ? lo_y : py;
-        py = (hi_y < py) ? hi_y : py;
+        // uniform over the extent, rejected until inside (the reference's recursive sample_positions(1, "random"),
+        // Environment.py:584-600); its own Philox stream, one call per attempt
+        auto edge = [&](int k, double& ax, double& ay, double& bx, double& by) {
+          const Wall<R> W = s_w[k];
+          ax = (double)W.ax; ay = (double)W.ay; bx = (double)(W.ax + W.sx); by = (double)(W.ay + W.sy);
+        };
+        const uint64_t stp = a.step0 + (uint64_t)t;
+        int attempt = 0;
+        for (; attempt < RIAB_MAX_RESAMPLES; ++attempt) {
+          const u32x4 w = philox4x32_10((uint32_t)stp, (uint32_t)(stp >> 32) ^ ((uint32_t)attempt << 24), aid,
+                                        RIAB_TAG_MOTION ^ 2u, a.k0, a.k1);
+          const double cx = uniform_between(a.shape.e0, a.shape.e1, u01_24(w.x));
+          const double cy = uniform_between(a.shape.e2, a.shape.e3, u01_24(w.y));
+          px = (R)cx;
+          py = (R)cy;
+          if (env_contains(a.shape, cx, cy, edge)) break;
+        }
+        if (attempt == RIAB_MAX_RESAMPLES) ++n_sat;
       }
     }
     }  // random-motion branch
@@ -869,10 +905,13 @@ __global__ __launch_bounds__(PC ? 128 : 64) void agent_step_kernel(const AgentAr
 static inline int fill_agent_args(AgentArgs& a, const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
                                   int64_t agent_id0, const double* drift, const double* z_in, double* z_out,
                                   const double* forced_pos, uint64_t seed, uint64_t step0, int32_t T, float* hist,
-                                  int32_t* diag, int32_t precision) {
+                                  int32_t* diag, int32_t precision, const double* resample_pos = nullptr) {
   if (!env || !motion || !state || B <= 0 || T <= 0 || agent_id0 < 0) return RIAB_EINVAL;
   if (env->n_walls < 0 || (env->n_walls > 0 && !env->walls)) return RIAB_EINVAL;
   if (env->n_walls > RIAB_MAX_WALLS) return RIAB_ETOOBIG;
+  if (check_env_shape(env)) return RIAB_EINVAL;
+  a.resample = resample_pos;
+  a.shape = make_env_shape(env);
   if (motion->has_drift && !drift) return RIAB_EINVAL;
   if (precision != 64 && precision != 32) return RIAB_EINVAL;
   a.m = *motion;

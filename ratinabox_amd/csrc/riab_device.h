@@ -10,6 +10,7 @@
 #define RIAB_TAG_MOTION 0x4D4F5449u
 #define RIAB_TAG_SPIKES 0x53504B00u
 #define RIAB_TAG_NOISE 0x4E4F4900u
+#define RIAB_MAX_RESAMPLES 64  // bound on the rejection loop of the resample boundary condition
 
 namespace riab {
 
@@ -63,5 +64,70 @@ __device__ __forceinline__ bool seg_hit(double p0x, double p0y, double p1x, doub
   const bool ia = (den_a > 0) ? (num_a > 0 && num_a < den_a) : (den_a < 0 ? (num_a < 0 && num_a > den_a) : false);
   const bool ib = (den_b > 0) ? (num_b > 0 && num_b < den_b) : (den_b < 0 ? (num_b < 0 && num_b > den_b) : false);
   return ia && ib;
+}
+// Strict point-in-polygon over the edges flagged in `mask`, read through `edge(k, ax, ay, bx, by)`: even-odd
+// crossings of the ray towards +x; a point ON an edge is not contained (shapely's `Polygon.contains`, which the
+// reference calls in Environment.check_if_position_is_in_environment, Environment.py:808-816).  The edges may
+// belong to several disjoint polygons (the holes): the parity then says "inside one of them".
+template <class EdgeFn>
+__device__ __forceinline__ bool polygon_contains_strict(double px, double py, uint64_t mask, EdgeFn edge) {
+  // (no fused multiply-adds: whether a point is ON an edge is `cross == 0` in the reference's plain float64 arithmetic)
+#pragma clang fp contract(off)
+  bool odd = false, on_edge = false;
+  for (uint64_t rest = mask; rest; rest &= rest - 1) {
+    const int k = __ffsll((long long)rest) - 1;
+    // a wall of the table runs from corner i+1 to corner i (Environment.py:139-142); the polygon's own edge, as the
+    // reference's geometry library walks it, from corner i to corner i+1: same segment, but `cross == 0` and the
+    // crossing abscissa round differently for the two orientations, so the edge is read back to front
+    double ax, ay, bx, by;
+    edge(k, bx, by, ax, ay);
+    const double cross = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+    if (cross == 0.0 && fmin(ax, bx) <= px && px <= fmax(ax, bx) && fmin(ay, by) <= py && py <= fmax(ay, by)) on_edge = true;
+    if ((ay > py) != (by > py)) {
+      const double x_cross = ax + (py - ay) * (bx - ax) / (by - ay);
+      if (px < x_cross) odd = !odd;
+    }
+  }
+  return odd && !on_edge;
+}
+
+// lo + u * (hi - lo) with every operation rounded on its own (the host restates these draws bit for bit; HIP's
+// __dmul_rn / __dadd_rn are plain operators and contract like any other)
+__device__ __forceinline__ double uniform_between(double lo, double hi, float u) {
+#pragma clang fp contract(off)
+  const double span = hi - lo;
+  const double prod = (double)u * span;
+  return lo + prod;
+}
+
+// Environment.check_if_position_is_in_environment (Environment.py:781-818) for the geometry of a RiabEnv
+struct EnvShape {
+  double e0, e1, e2, e3;
+  uint64_t boundary_mask;  // edges of a polygonal boundary (0: the boundary is the rectangle e0..e3)
+  uint64_t hole_mask;      // edges of the holes
+};
+__host__ __device__ __forceinline__ EnvShape make_env_shape(const RiabEnv* env) {
+  EnvShape s;
+  s.e0 = env->extent[0]; s.e1 = env->extent[1]; s.e2 = env->extent[2]; s.e3 = env->extent[3];
+  s.boundary_mask = env->polygon ? (env->n_boundary >= 64 ? ~0ull : ((1ull << env->n_boundary) - 1ull)) : 0ull;
+  s.hole_mask = env->hole_mask;
+  return s;
+}
+template <class EdgeFn>
+__device__ __forceinline__ bool env_contains(const EnvShape& s, double px, double py, EdgeFn edge) {
+  bool in = s.boundary_mask ? polygon_contains_strict(px, py, s.boundary_mask, edge)
+                            : (px > s.e0 && px < s.e1 && py > s.e2 && py < s.e3);
+  if (in && s.hole_mask) in = !polygon_contains_strict(px, py, s.hole_mask, edge);
+  return in;
+}
+// argument checks shared by the entry points
+static inline int check_env_shape(const RiabEnv* env) {
+  const uint64_t all = env->n_walls >= 64 ? ~0ull : ((1ull << (env->n_walls < 0 ? 0 : env->n_walls)) - 1ull);
+  if (env->hole_mask & ~all) return RIAB_EINVAL;
+  if (env->polygon) {
+    if (env->periodic || env->n_boundary < 3 || env->n_boundary > env->n_walls) return RIAB_EINVAL;
+    if (env->hole_mask & ((1ull << env->n_boundary) - 1ull)) return RIAB_EINVAL;
+  }
+  return RIAB_OK;
 }
 }  // namespace riab

@@ -16,6 +16,7 @@ struct EnvQuery {
   int periodic;
   int n_walls;
   const double* walls;  // [n_walls][4]
+  EnvShape shape;       // boundary polygon / holes
 };
 
 static EnvQuery make_query(const RiabEnv* env) {
@@ -25,6 +26,7 @@ static EnvQuery make_query(const RiabEnv* env) {
   q.periodic = env->periodic;
   q.n_walls = env->n_walls;
   q.walls = env->walls;
+  q.shape = make_env_shape(env);
   return q;
 }
 
@@ -78,7 +80,9 @@ __global__ __launch_bounds__(256) void pairwise_kernel(const EnvQuery q, const d
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const double ex = w[2 * e], ey = w[2 * e + 1];
-          if (ex > q.e0 && ex < q.e1 && ey > q.e2 && ey < q.e3) {
+          if (env_contains(q.shape, ex, ey, [&](int k, double& ax, double& ay, double& bx, double& by) {
+                ax = q.walls[4 * k]; ay = q.walls[4 * k + 1]; bx = q.walls[4 * k + 2]; by = q.walls[4 * k + 3];
+              })) {
             const double d1 = sqrt((ax - ex) * (ax - ex) + (ay - ey) * (ay - ey));
             const double d2 = sqrt((ex - bx) * (ex - bx) + (ey - by) * (ey - by));
             best = fmin(best, d1 + d2);
@@ -138,9 +142,17 @@ __global__ __launch_bounds__(256) void boundary_conditions_kernel(const EnvQuery
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
   double x = px[p], y = py[p];
-  const bool inside = x > q.e0 && x < q.e1 && y > q.e2 && y < q.e3;  // strict interior (shapely `contains`)
-  if (inside_out) inside_out[p] = inside ? 1 : 0;
-  if (inside || !apply) return;
+  const bool in_box = x > q.e0 && x < q.e1 && y > q.e2 && y < q.e3;  // strict interior (shapely `contains`)
+  bool inside = in_box;
+  if (q.shape.boundary_mask || q.shape.hole_mask)
+    inside = env_contains(q.shape, x, y, [&](int k, double& ax, double& ay, double& bx, double& by) {
+      ax = q.walls[4 * k]; ay = q.walls[4 * k + 1]; bx = q.walls[4 * k + 2]; by = q.walls[4 * k + 3];
+    });
+  // 2: outside, and what apply_boundary_conditions does about it is a random draw (in a hole / outside a polygon,
+  // Environment.py:886-893): left to the caller
+  const bool resample = !inside && (q.shape.boundary_mask || in_box);
+  if (inside_out) inside_out[p] = inside ? 1 : (resample ? 2 : 0);
+  if (inside || !apply || resample) return;
   if (q.periodic) {
     x = x - q.e1 * floor(x / q.e1);  // np.mod(pos, extent)
     y = y - q.e3 * floor(y / q.e3);
@@ -157,6 +169,8 @@ __global__ __launch_bounds__(256) void boundary_conditions_kernel(const EnvQuery
 
 static int check_env(const RiabEnv* env, bool need_walls) {
   if (!env || env->n_walls < 0) return RIAB_EINVAL;
+  if (check_env_shape(env)) return RIAB_EINVAL;
+  if ((env->polygon || env->hole_mask) && !env->walls) return RIAB_EINVAL;
   if (env->n_walls > RIAB_MAX_WALLS) return RIAB_ETOOBIG;
   if (need_walls && env->n_walls > 0 && !env->walls) return RIAB_EINVAL;
   return RIAB_OK;

@@ -299,8 +299,8 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
       if (rc) return rc;
       p->action_ready = scripted;
     } else {
-    rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr,
-                             p->seed, p->step, 1, row, p->diag, p->precision, s);
+    rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr, nullptr,
+                         p->seed, p->step, 1, row, p->diag, p->precision, s);
     if (rc) return rc;
     p->step += 1;
     if (p->hist_base) p->hist_fill += 1;

@@ -188,6 +188,7 @@ struct PlaceCell {
   const double* walls;  // device [n_walls][4]; internal walls = walls[4:] (Environment.py:715-717)
   int n_internal;
   double e0, e1, e2, e3;  // extent, for the geodesic "endpoint inside the env" test
+  EnvShape shape;         // (and the boundary polygon / holes for the same test)
   const double* lds;      // set by stage()
 
   __device__ __forceinline__ void stage(double* s) {
@@ -228,7 +229,9 @@ struct PlaceCell {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const double exd = lds[2 * e], eyd = lds[2 * e + 1];
-          if (exd > e0 && exd < e1 && eyd > e2 && eyd < e3) {
+          if (env_contains(shape, exd, eyd, [&](int k, double& ax, double& ay, double& bx, double& by) {
+                ax = walls[4 * k]; ay = walls[4 * k + 1]; bx = walls[4 * k + 2]; by = walls[4 * k + 3];
+              })) {
             const float ex = (float)exd, ey = (float)eyd;
             const float d1 = sqrtf(fmaf(cys - ey, cys - ey, (cxs - ex) * (cxs - ex)));
             const float d2e = sqrtf(fmaf(ey - py, ey - py, (ex - px) * (ex - px)));
@@ -270,7 +273,7 @@ struct PlaceCell {
   __host__ PlaceCell<D2, GX> as() const {
     PlaceCell<D2, GX> c;
     c.tab = tab; c.scale = scale; c.half_scale = half_scale; c.top_hat_w2 = top_hat_w2;
-    c.walls = walls; c.n_internal = n_internal; c.e0 = e0; c.e1 = e1; c.e2 = e2; c.e3 = e3; c.lds = nullptr;
+    c.walls = walls; c.n_internal = n_internal; c.e0 = e0; c.e1 = e1; c.e2 = e2; c.e3 = e3; c.shape = shape; c.lds = nullptr;
     return c;
   }
 };
@@ -766,6 +769,7 @@ static int place_dispatch(const RiabEnv* env, const RiabRateIO* io, const float*
   c.n_internal = env->n_walls > 4 ? env->n_walls - 4 : 0;
   if (GX == 2 && c.n_internal > 1) c.n_internal = 1;
   c.e0 = env->extent[0]; c.e1 = env->extent[1]; c.e2 = env->extent[2]; c.e3 = env->extent[3];
+  c.shape = make_env_shape(env);
   c.lds = nullptr;
   return launch_place<GX>(io, n, desc, c, s);
 }
@@ -804,6 +808,7 @@ static int launch_stream_place(const RiabEnv* env, const RiabPopulation* pop, co
   c.n_internal = env->n_walls > 4 ? env->n_walls - 4 : 0;
   if (GX == 2 && c.n_internal > 1) c.n_internal = 1;
   c.e0 = env->extent[0]; c.e1 = env->extent[1]; c.e2 = env->extent[2]; c.e3 = env->extent[3];
+  c.shape = make_env_shape(env);
   c.lds = nullptr;
   switch (pop->description) {
     case RIAB_PC_GAUSSIAN: return launch_stream_cell(a, c, st, T, spikes, plain_loads, any_order, s);
@@ -969,6 +974,7 @@ static int random_spatial_dispatch(const RiabEnv* env, const RiabRateIO* io, con
   c.n_internal = env->n_walls > 4 ? env->n_walls - 4 : 0;
   if (GX == 2 && c.n_internal > 1) c.n_internal = 1;
   c.e0 = env->extent[0]; c.e1 = env->extent[1]; c.e2 = env->extent[2]; c.e3 = env->extent[3];
+  c.shape = make_env_shape(env);
   c.lds = nullptr;
   dim3 grid;
   RateArgs a = make_args(io, n, &grid);

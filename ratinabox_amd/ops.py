@@ -49,14 +49,18 @@ def _register(schema, fake):
 
 
 def _env_struct(walls: Optional[Tensor], env: List[float], periodic: bool):
-    """RiabEnv from operator arguments: env = [left, right, bottom, top, scale]."""
-    if len(env) != 5:
-        raise ValueError("env must be [left, right, bottom, top, scale]")
+    """RiabEnv from operator arguments: env = [left, right, bottom, top, scale] for a box, or
+    [left, right, bottom, top, scale, polygon, n_boundary, hole_mask] (include/riab_hip.h: RiabEnv) when the
+    boundary is a general polygon and / or the environment has holes."""
+    if len(env) not in (5, 8):
+        raise ValueError("env must be [left, right, bottom, top, scale] (+ [polygon, n_boundary, hole_mask])")
     e = _L.RiabEnv()
     for i in range(4):
         e.extent[i] = float(env[i])
     e.scale = float(env[4])
     e.periodic = 1 if periodic else 0
+    if len(env) == 8:
+        e.polygon, e.n_boundary, e.hole_mask = int(env[5]), int(env[6]), int(env[7])  # (mask < 2^53: exact as a float)
     if walls is None:
         e.n_walls, e.walls = 0, None
     else:
@@ -234,18 +238,20 @@ def motion_list(m) -> List[float]:
 
 
 @_register("agent_step_(Tensor(a!) state, Tensor(b!)? hist, Tensor(c!)? diag, Tensor? walls, float[] env, bool periodic, "
-           "float[] motion, Tensor? drift, Tensor? noise, Tensor(d!)? noise_out, Tensor? forced_pos, int seed, int step0, "
-           "int agent_id0, int T, int precision) -> ()",
-           lambda state, hist, diag, walls, env, periodic, motion, drift, noise, noise_out, forced_pos, seed, step0,
-           agent_id0, T, precision: None)
+           "float[] motion, Tensor? drift, Tensor? noise, Tensor(d!)? noise_out, Tensor? forced_pos, Tensor? resample_pos, "
+           "int seed, int step0, int agent_id0, int T, int precision) -> ()",
+           lambda state, hist, diag, walls, env, periodic, motion, drift, noise, noise_out, forced_pos, resample_pos, seed,
+           step0, agent_id0, T, precision: None)
 def agent_step_(state: Tensor, hist: Optional[Tensor], diag: Optional[Tensor], walls: Optional[Tensor], env: List[float],
                 periodic: bool, motion: List[float], drift: Optional[Tensor], noise: Optional[Tensor],
-                noise_out: Optional[Tensor], forced_pos: Optional[Tensor], seed: int, step0: int, agent_id0: int, T: int,
-                precision: int) -> None:
+                noise_out: Optional[Tensor], forced_pos: Optional[Tensor], resample_pos: Optional[Tensor], seed: int,
+                step0: int, agent_id0: int, T: int, precision: int) -> None:
     """T fused Agent.update() steps (riab_agent_step), in place: state float64 (12, B) (rows RIAB_S_*), hist float32
     (T, 8, B) or None, diag int32 (4,) or None.  motion = the RiabMotion fields in MOTION_FIELDS order; drift float64
     (2, B); noise float64 (T, 2, B) explicit standard normals (None: Philox keyed by (seed; step0 + t, agent_id0 + b));
-    noise_out records the normals used; forced_pos float64 (T, 2, B) moves the agents instead of the motion model."""
+    noise_out records the normals used; forced_pos float64 (T, 2, B) moves the agents instead of the motion model;
+    resample_pos float64 (T, 2, B): explicit replacement positions for agents that end a step in a hole / outside a
+    polygonal boundary (None: Philox draws)."""
     if state.dtype != torch.float64 or state.dim() != 2 or state.shape[0] != _L.STATE_ROWS or not state.is_contiguous():
         raise ValueError("state must be a contiguous float64 tensor (12, B)")
     B = int(state.shape[1])
@@ -257,12 +263,13 @@ def agent_step_(state: Tensor, hist: Optional[Tensor], diag: Optional[Tensor], w
     if hist is not None and (hist.dtype != torch.float32 or tuple(hist.shape) != (T, _L.HIST_ROWS, B) or
                              not hist.is_contiguous()):
         raise ValueError("hist must be a contiguous float32 tensor (T, 8, B)")
-    for name, t in (("noise", noise), ("noise_out", noise_out), ("forced_pos", forced_pos)):
+    for name, t in (("noise", noise), ("noise_out", noise_out), ("forced_pos", forced_pos), ("resample_pos", resample_pos)):
         if t is not None and (t.dtype != torch.float64 or tuple(t.shape) != (T, 2, B) or not t.is_contiguous()):
             raise ValueError(f"{name} must be a contiguous float64 tensor (T, 2, B)")
     if drift is not None and (drift.dtype != torch.float64 or tuple(drift.shape) != (2, B) or not drift.is_contiguous()):
         raise ValueError("drift must be a contiguous float64 tensor (2, B)")
     e = _env_struct(walls, env, periodic)
     _L.check(_L.lib.riab_agent_step(e, m, _L.ptr(state), B, int(agent_id0), _L.ptr(drift), _L.ptr(noise), _L.ptr(noise_out),
-                                    _L.ptr(forced_pos), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step0), int(T), _L.ptr(hist), _L.ptr(diag),
-                                    int(precision), _L.current_stream()), "riab_agent_step")
+                                    _L.ptr(forced_pos), _L.ptr(resample_pos), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step0),
+                                    int(T), _L.ptr(hist), _L.ptr(diag), int(precision), _L.current_stream()),
+             "riab_agent_step")

@@ -211,3 +211,33 @@ def create_diverging_radial_assembly(distance_range=[0.01, 0.2], angle_range=[0,
             sigma_theta.append(size / radius)
         radius = (2 * radius + size + xi) / (2 - 1 / beta)
     return mu_d, mu_theta, sigma_d, sigma_theta
+
+
+def polygon_area(corners):
+    """Area of a simple polygon given by its corners (shoelace); what the reference asks shapely for when it
+    discounts the holes in `Environment.sample_positions` (reference Environment.py:605-606)."""
+    c = np.asarray(corners, dtype=float).reshape(-1, 2)
+    x, y = c[:, 0], c[:, 1]
+    return 0.5 * abs(float(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))))
+
+
+def polygon_contains(corners, point):
+    """True if `point` lies STRICTLY inside the simple polygon `corners` — a point on an edge or a corner is not
+    contained, the semantics of the `shapely.Polygon.contains` the reference calls
+    (reference Environment.py:808-816).  Even-odd rule on the ray towards +x; host-side, one point (the init-time
+    samplers); the kernels carry their own form (csrc/riab_device.h: polygon_contains_strict)."""
+    c = np.asarray(corners, dtype=float).reshape(-1, 2)
+    px, py = float(point[0]), float(point[1])
+    if not (np.isfinite(px) and np.isfinite(py)):
+        return False
+    a, b = c, np.roll(c, -1, axis=0)
+    ax, ay, bx, by = a[:, 0], a[:, 1], b[:, 0], b[:, 1]
+    cross = (bx - ax) * (py - ay) - (by - ay) * (px - ax)
+    on_edge = (cross == 0) & (np.minimum(ax, bx) <= px) & (px <= np.maximum(ax, bx)) & \
+        (np.minimum(ay, by) <= py) & (py <= np.maximum(ay, by))
+    if on_edge.any():
+        return False
+    straddle = (ay > py) != (by > py)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        x_cross = ax + (py - ay) * (bx - ax) / (by - ay)
+    return bool(np.count_nonzero(straddle & (px < x_cross)) % 2)

@@ -39,6 +39,16 @@ from ratinabox.Neurons import (  # noqa: E402
 from ratinabox import utils as rutils  # noqa: E402
 
 _real = np.random.RandomState(12345)
+
+
+def _section(name):
+    """Every section starts its private noise stream from its own seed, so any subset of sections — and the full
+    run in any order — reproduces the committed files (tools/check_golden.py regenerates and compares)."""
+    import zlib
+    _real.seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    print(name)
+
+
 _rec = {"normal": [], "uniform": []}
 _orig_normal = np.random.normal
 _orig_uniform = np.random.uniform
@@ -83,12 +93,34 @@ _bc = {"n": 0}
 _orig_abc = Environment.apply_boundary_conditions
 
 
+_resampled = {"depth": 0, "pos": None}
+_orig_sample = Environment.sample_positions
+
+
+def _recording_sample(self, n=10, method="uniform_jitter"):
+    """(inside apply_boundary_conditions: the position the outermost sample_positions(n=1, "random") call finally
+    returns is the one the agent is put at; the recursive retries of rejected draws are its own business)"""
+    if _resampled["depth"] == 0:
+        return _orig_sample(self, n=n, method=method)
+    _resampled["depth"] += 1
+    out = _orig_sample(self, n=n, method=method)
+    _resampled["depth"] -= 1
+    if _resampled["depth"] == 1:
+        _resampled["pos"] = np.array(out, dtype=np.float64).reshape(-1)
+    return out
+
+
 def _count_abc(self, pos):
     _bc["n"] += 1
-    return _orig_abc(self, pos)
+    _resampled["depth"] = 1
+    try:
+        return _orig_abc(self, pos)
+    finally:
+        _resampled["depth"] = 0
 
 
 Environment.apply_boundary_conditions = _count_abc
+Environment.sample_positions = _recording_sample
 
 STATE_KEYS = ["pos", "velocity", "rotational_velocity", "measured_velocity", "head_direction",
               "distance_travelled"]
@@ -108,12 +140,18 @@ def f32exact(x):
 
 # ------------------------------------------------------------------ G2 / G3 -- #
 def motion_records(name, env_params, agent_params, n_agents, n_steps, seed, drift=None, ratio=1.0,
-                   update_kwargs=None, keep=1500):
+                   update_kwargs=None, keep=1500, teleports=None):
+    """`teleports` {(t, i): (x, y)}: agent i is put at (x, y) before its update of step t, like a user writing
+    `Ag.pos = ...` — how agents get into holes / outside a polygonal boundary, where the step ends in the resample
+    branch of apply_boundary_conditions."""
+    teleports = teleports or {}
     np.random.seed(seed)
     Env = Environment(env_params)
     agents = [Agent(Env, dict(agent_params)) for _ in range(n_agents)]
     update_kwargs = update_kwargs or {}
-    pre, post, zs, nb, bc = [], [], [], [], []
+    pre, post, zs, nb, bc, rsp = [], [], [], [], [], []
+    zroll_rs = np.full((n_steps, n_agents, 2), np.nan)
+    tele_roll = np.full((n_steps, n_agents, 2), np.nan)
     traj = np.zeros((n_steps + 1, n_agents, 2))
     traj[0] = [a.pos for a in agents]
     zroll = np.zeros((n_steps, n_agents, 2))
@@ -121,10 +159,14 @@ def motion_records(name, env_params, agent_params, n_agents, n_steps, seed, drif
     _capture["on"] = True
     for t in range(n_steps):
         for i, ag in enumerate(agents):
+            if (t, i) in teleports:
+                ag.pos = np.array(teleports[(t, i)], dtype=float)
+                tele_roll[t, i] = ag.pos
             s0 = _get_state(ag)
             _rec["normal"].clear()
             _bounces["n"] = 0
             _bc["n"] = 0
+            _resampled["pos"] = None
             dv = None if drift is None else np.array(drift[(t + i) % len(drift)], float)
             ag.update(drift_velocity=dv, drift_to_random_strength_ratio=ratio, **update_kwargs)
             scal = [z for shp, z in _rec["normal"] if shp == ()]
@@ -137,10 +179,12 @@ def motion_records(name, env_params, agent_params, n_agents, n_steps, seed, drif
             zs.append([float(scal[0]), float(scal[1])])
             nb.append(_bounces["n"])
             bc.append(_bc["n"])
+            rsp.append(_resampled["pos"] if _resampled["pos"] is not None else np.full(2, np.nan))
+            zroll_rs[t, i] = rsp[-1]
             zroll[t, i] = zs[-1]
             traj[t + 1, i] = ag.pos
     _capture["on"] = False
-    pre, post, zs = np.array(pre), np.array(post), np.array(zs)
+    pre, post, zs, rsp = np.array(pre), np.array(post), np.array(zs), np.array(rsp)
     nb, bc = np.array(nb), np.array(bc)
     # keep every "interesting" record plus a random subsample of the rest
     interesting = np.nonzero((nb > 0) | (bc > 0))[0]
@@ -162,6 +206,12 @@ def motion_records(name, env_params, agent_params, n_agents, n_steps, seed, drif
         kw_keys=np.array(sorted(update_kwargs.keys())),
         kw_vals=np.array([float(update_kwargs[k]) for k in sorted(update_kwargs.keys())]),
         pre=pre[sel], post=post[sel], z=zs[sel], n_bounces=nb[sel], bc_applied=bc[sel],
+        # polygonal boundary / holes (empty: the rectangular box); resample positions (NaN: none drawn)
+        env_boundary=np.array(env_params.get("boundary") if env_params.get("boundary") is not None else np.zeros((0, 2)),
+                              dtype=float).reshape(-1, 2),
+        env_holes=np.array([c for h in env_params.get("holes", []) for c in h], dtype=float).reshape(-1, 2),
+        env_hole_sizes=np.array([len(h) for h in env_params.get("holes", [])], dtype=np.int64),
+        resample=rsp[sel], roll_resample=zroll_rs, roll_teleport=tele_roll,
         drift=drift_arr, drift_ratio=float(ratio),
         # rollout (G3): first 16 agents, all steps
         roll_state0=np.array([np.concatenate([np.ravel(x) for x in s]) for s in state0]),
@@ -169,12 +219,18 @@ def motion_records(name, env_params, agent_params, n_agents, n_steps, seed, drif
         roll_final=np.array([np.concatenate([np.ravel(x) for x in _get_state(a)]) for a in agents]),
     )
     print(f"  {name}: {len(sel)} step records ({int((nb[sel] > 0).sum())} with bounces, "
-          f"{int((nb[sel] > 1).sum())} multi-bounce, {int((bc[sel] > 0).sum())} boundary-clamped)")
+          f"{int((nb[sel] > 1).sum())} multi-bounce, {int((bc[sel] > 0).sum())} boundary conditions, "
+          f"{int(np.isfinite(rsp[sel][:, 0]).sum())} resampled)")
     np.savez_compressed(os.path.join(HERE, f"motion_{name}.npz"), **out)
 
 
+L_ROOM = [[0, 0], [1, 0], [1, 0.5], [0.5, 0.5], [0.5, 1], [0, 1]]
+HOLE_A = [[0.35, 0.35], [0.65, 0.35], [0.65, 0.65], [0.35, 0.65]]
+HOLE_B = [[0.1, 0.7], [0.25, 0.7], [0.22, 0.9], [0.12, 0.88]]  # (the reference needs equal corner counts: np.array(holes).ndim == 3)
+
+
 def make_motion():
-    print("motion (G2 single steps + G3 rollouts)")
+    _section("motion (G2 single steps + G3 rollouts)")
     motion_records("open_dt10ms", {}, {"dt": 0.01}, 16, 400, seed=1)
     motion_records("maze_dt10ms", {"walls": MAZE_WALLS}, {"dt": 0.01}, 16, 400, seed=2)
     motion_records("maze_dt50ms", {"walls": MAZE_WALLS}, {"dt": 0.05, "thigmotaxis": 0.2}, 16, 300, seed=3)
@@ -189,6 +245,25 @@ def make_motion():
                    update_kwargs={"thigmotaxis": 0.8, "wall_repel_distance": 0.2, "speed_mean": 0.12,
                                   "rotational_velocity_std": 1.0, "speed_coherence_time": 0.3,
                                   "rotational_velocity_coherence_time": 0.2, "wall_repel_strength": 1.5})
+    # row a6: polygonal boundary and holes (Environment.py:128-163, 781-818, 855-894).  Some agents are put into a
+    # hole / outside the polygon now and then: those steps end in the resample branch.
+    rs = np.random.RandomState(99)
+    tele = {}
+    for t in range(10, 300, 17):
+        tele[(t, int(rs.randint(16)))] = (0.5 + 0.4 * rs.rand(), 0.5 + 0.4 * rs.rand())      # the notch of the L
+    for t in range(5, 300, 23):
+        tele[(t, int(rs.randint(16)))] = (0.05 + 0.4 * rs.rand(), 0.05 + 0.9 * rs.rand())    # a legal jump
+    motion_records("lroom_dt20ms", {"boundary": L_ROOM, "walls": [[[0.25, 0.0], [0.25, 0.3]]]},
+                   {"dt": 0.02, "speed_mean": 0.15}, 16, 300, seed=9, teleports=tele)
+    tele = {}
+    for t in range(8, 300, 13):
+        hole = HOLE_A if (t // 13) % 2 == 0 else HOLE_B
+        c = np.mean(hole, axis=0)
+        tele[(t, int(rs.randint(16)))] = tuple(c + 0.02 * (rs.rand(2) - 0.5))                # inside a hole
+    for t in range(3, 300, 29):
+        tele[(t, int(rs.randint(16)))] = (1.0 + 0.01 * rs.rand(), 0.3 + 0.4 * rs.rand())      # outside the box: clamp
+    motion_records("box_holes_dt20ms", {"holes": [HOLE_A, HOLE_B]}, {"dt": 0.02, "speed_mean": 0.15, "thigmotaxis": 0.3},
+                   16, 300, seed=10, teleports=tele)
 
 
 # ----------------------------------------------------------------------- G1 -- #
@@ -203,7 +278,7 @@ def test_positions(P, scale=1.0, aspect=1.0, seed=0):
 
 
 def make_rates():
-    print("rates (G1)")
+    _section("rates (G1)")
     np.random.seed(11)
     out = {}
     pos = test_positions(192, seed=3)
@@ -305,7 +380,7 @@ def make_rates():
 def make_update_and_init():
     """Neurons.update() end-to-end (rates + noise OU + spikes) for a single agent,
     and seeded init tables (host-side parameter sampling)."""
-    print("update/spikes (G4) + init tables (G5)")
+    _section("update/spikes (G4) + init tables (G5)")
     out = {}
     np.random.seed(21)
     Env = Environment()
@@ -365,7 +440,7 @@ def make_update_and_init():
 
 def make_imported():
     """Imported (cubic-spline playback) and forced trajectories: Agent.py:229-266, 543-659."""
-    print("imported / forced trajectories")
+    _section("imported / forced trajectories")
     out = {}
     times = np.arange(0, 12.01, 0.4)
     positions = np.stack((0.5 + 0.35 * np.sin(0.9 * times), 0.5 + 0.3 * np.cos(1.3 * times + 0.4)), axis=-1)
@@ -409,7 +484,7 @@ def make_imported():
 def make_feedforward():
     """FeedForwardLayer (Neurons.py:2654-2860) over PlaceCells + GridCells, every named activation."""
     from ratinabox.Neurons import FeedForwardLayer
-    print("feedforward")
+    _section("feedforward")
     out = {}
     np.random.seed(41)
     Env = Environment()
@@ -459,7 +534,7 @@ def make_feedforward():
 def make_ovc():
     """ObjectVectorCells / FieldOfViewOVCs (Neurons.py:1892-2150) with occluding walls."""
     from ratinabox.Neurons import ObjectVectorCells, FieldOfViewOVCs
-    print("object vector cells")
+    _section("object vector cells")
     out = {}
     np.random.seed(51)
     Env = Environment({"walls": [[[0.5, 0.0], [0.5, 0.55]], [[0.2, 0.8], [0.6, 0.8]]]})
@@ -496,7 +571,7 @@ def make_avc():
     """AgentVectorCells / FieldOfViewAVCs (Neurons.py:2151-2355): two agents in a walled box updated in
     turn; per step both positions, the observer's head direction and the rates of its cells."""
     from ratinabox.Neurons import AgentVectorCells, FieldOfViewAVCs
-    print("agent vector cells")
+    _section("agent vector cells")
     out = {}
     np.random.seed(61)
     Env = Environment({"walls": [[[0.5, 0.0], [0.5, 0.55]], [[0.2, 0.8], [0.6, 0.8]]]})
@@ -534,7 +609,7 @@ def make_velocity():
     the velocity state (what VelocityCells read), the measured velocity (history["vel"][-1], what the
     SpeedCell reads) and both populations' rates after update(); plus get_state on given velocities."""
     from ratinabox.Neurons import VelocityCells, SpeedCell
-    print("velocity / speed cells")
+    _section("velocity / speed cells")
     np.random.seed(41)
     out = {}
     Env = Environment({"walls": MAZE_WALLS})
@@ -567,7 +642,7 @@ def make_velocity():
 def make_env_queries():
     """Environment geometry queries called directly (Environment.py:657-894): pairwise vectors / distances
     under each wall geometry, vectors_from_walls, check_wall_collisions, apply_boundary_conditions."""
-    print("environment queries")
+    _section("environment queries")
     rs = np.random.RandomState(17)
     out = {}
     p1, p2 = f32exact(rs.uniform(0, 1, (40, 2))), f32exact(rs.uniform(0, 1, (50, 2)))
@@ -605,7 +680,7 @@ def make_random_spatial():
     """RandomSpatialNeurons (Neurons.py:2865-2960): seeded targets (one multivariate-normal draw over the
     anchor grid) and get_state at given positions, for each wall geometry."""
     from ratinabox.Neurons import RandomSpatialNeurons
-    print("random spatial neurons")
+    _section("random spatial neurons")
     out = {}
     rs = np.random.RandomState(8)
     pos = f32exact(rs.uniform(0, 1, (150, 2)))
@@ -632,7 +707,7 @@ def make_task():
     SpatialGoalEnvironment, one per lane, driven towards their goals; per step the action, the two
     OU normals, the resulting position, reward total, terminal flag and goal / reward cache sizes."""
     from ratinabox.contribs.TaskEnvironment import (SpatialGoalEnvironment, SpatialGoal, Reward, get_goal_vector)
-    print("task environment")
+    _section("task environment")
     presets = {"constant": 0, "linear": 1, "exponential": 2, "none": 3}
     scenarios = {
         # name: (env params, goal positions, radius, rewards per goal (None = reward_default), goalcachekws,
@@ -737,10 +812,86 @@ def make_task():
         np.savez_compressed(os.path.join(HERE, f"task_{name}.npz"), **out)
 
 
+# ------------------------------------------------------------------ row a6 -- #
+def make_polygon():
+    """Polygonal boundary and holes away from the motion records: wall table order, the strict inside test on
+    random and on-the-edge points, the samplers (seeded), apply_boundary_conditions with its recorded random
+    replacements, PlaceCells under the three wall geometries in an L-shaped room."""
+    _section("polygon boundary + holes")
+    out = {}
+    envs = {"lroom": {"boundary": L_ROOM, "walls": [[[0.25, 0.0], [0.25, 0.3]]]},
+            "holes": {"holes": [HOLE_A, HOLE_B], "walls": [[[0.8, 0.1], [0.8, 0.4]]]},
+            "both": {"boundary": [[0, 0], [2, 0], [2.5, 1], [1, 1.5], [-0.2, 1]], "holes": [[[0.5, 0.4], [1.0, 0.4], [0.7, 0.8]]]}}
+    rs = np.random.RandomState(4321)
+    for tag, ep in envs.items():
+        Env = Environment(ep)
+        out[f"{tag}_boundary"] = np.array(ep.get("boundary") if ep.get("boundary") is not None else np.zeros((0, 2)), float)
+        out[f"{tag}_holes"] = np.array([c for h in ep.get("holes", []) for c in h], float).reshape(-1, 2)
+        out[f"{tag}_hole_sizes"] = np.array([len(h) for h in ep.get("holes", [])], np.int64)
+        out[f"{tag}_user_walls"] = np.array(ep.get("walls", []), float).reshape(-1, 2, 2)
+        out[f"{tag}_walls"] = np.array(Env.walls, float)
+        out[f"{tag}_extent"] = np.array(Env.extent, float)
+        ex = Env.extent
+        P = 400
+        pts = np.stack((rs.uniform(ex[0] - 0.1, ex[1] + 0.1, P), rs.uniform(ex[2] - 0.1, ex[3] + 0.1, P)), -1)
+        # points exactly on edges and corners of the boundary and of the holes
+        polys = [np.array(Env.boundary, float)] + [np.array(h, float) for h in ep.get("holes", [])]
+        edge_pts = []
+        for poly in polys:
+            for i in range(len(poly)):
+                a, b = poly[i], poly[(i + 1) % len(poly)]
+                edge_pts += [a, 0.5 * (a + b), a + 0.25 * (b - a)]
+        pts = np.vstack((pts, np.array(edge_pts)))
+        out[f"{tag}_points"] = pts
+        out[f"{tag}_inside"] = np.array([Env.check_if_position_is_in_environment(p) for p in pts])
+        # the samplers, global np.random seeded (the product draws in the same order)
+        for method in ("random", "uniform", "uniform_jitter"):
+            np.random.seed(77)
+            out[f"{tag}_sample_{method}"] = Env.sample_positions(n=53, method=method)
+        # apply_boundary_conditions on all the points, with the replacement each resample drew
+        _capture["on"] = False
+        np.random.seed(5)
+        new, rsp = [], []
+        for p in pts:
+            _resampled["pos"] = None
+            q = Env.apply_boundary_conditions(np.array(p, float))
+            new.append(np.array(q, float).reshape(-1))
+            rsp.append(_resampled["pos"] if _resampled["pos"] is not None else np.full(2, np.nan))
+        out[f"{tag}_bc_out"] = np.array(new)
+        out[f"{tag}_bc_resample"] = np.array(rsp)
+    # PlaceCells in the L room: euclidean, line_of_sight (internal walls = walls[4:], whatever the boundary has:
+    # Environment.py:715-717), and geodesic in a quadrilateral room with one wall
+    Env = Environment(envs["lroom"])
+    Ag = Agent(Env)
+    pos = np.stack((rs.uniform(0, 1, 300), rs.uniform(0, 1, 300)), -1)
+    pos = pos[[Env.check_if_position_is_in_environment(p) for p in pos]][:160]
+    out["pc_pos"] = f32exact(pos)
+    np.random.seed(3)
+    for geom in ("euclidean", "line_of_sight"):
+        PCs = PlaceCells(Ag, {"n": 40, "widths": 0.15, "wall_geometry": geom, "description": "gaussian_threshold"})
+        out[f"pc_{geom}_centres"] = f32exact(PCs.place_cell_centres)
+        PCs.place_cell_centres = out[f"pc_{geom}_centres"]
+        out[f"pc_{geom}_rates"] = PCs.get_state(evaluate_at=None, pos=out["pc_pos"])
+    quad = {"boundary": [[0, 0], [1.2, 0.1], [1.0, 1.0], [0.1, 0.8]], "walls": [[[0.6, 0.05], [0.55, 0.5]]]}
+    out["quad_boundary"] = np.array(quad["boundary"], float)
+    out["quad_user_walls"] = np.array(quad["walls"], float)
+    EnvQ = Environment(quad)
+    AgQ = Agent(EnvQ)
+    posq = np.stack((rs.uniform(0, 1.2, 400), rs.uniform(0, 1.0, 400)), -1)
+    posq = posq[[EnvQ.check_if_position_is_in_environment(p) for p in posq]][:160]
+    out["quad_pos"] = f32exact(posq)
+    PCs = PlaceCells(AgQ, {"n": 30, "widths": 0.2, "wall_geometry": "geodesic"})
+    out["quad_centres"] = f32exact(PCs.place_cell_centres)
+    PCs.place_cell_centres = out["quad_centres"]
+    out["quad_rates"] = PCs.get_state(evaluate_at=None, pos=out["quad_pos"])
+    np.savez_compressed(os.path.join(HERE, "polygon.npz"), **out)
+    print("  polygon.npz written:", len(out), "arrays")
+
+
 def make_stats():
     """G6: long-run statistics of the reference's own motion model (its own NumPy RNG), for validating the
     production (in-kernel Philox) mode, which cannot be compared draw by draw."""
-    print("long-run statistics (this takes a few minutes)")
+    _section("long-run statistics (this takes a few minutes)")
     out = {}
     for name, envp in (("open", {}), ("wall", {"walls": [[[0.5, 0.0], [0.5, 0.6]]]})):
         np.random.seed(77)
@@ -772,7 +923,15 @@ def make_stats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task", "stats"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task", "polygon", "stats"]
+    if "--out" in which:  # write somewhere else (tools/check_golden.py regenerates into a temporary directory)
+        HERE = which[which.index("--out") + 1]
+        which = [w for i, w in enumerate(which) if w != "--out" and (i == 0 or which[i - 1] != "--out")] or \
+            ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task",
+             "polygon", "stats"]
+        os.makedirs(HERE, exist_ok=True)
+    if "polygon" in which:
+        make_polygon()
     if "stats" in which:
         make_stats()
     if "task" in which:

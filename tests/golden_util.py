@@ -19,9 +19,31 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
+def shape_from(g, prefix="env_"):
+    """(boundary corners or None, list of hole corner arrays) stored by make_golden.py."""
+    b = g[prefix + "boundary"]
+    holes, k = [], 0
+    for n in g[prefix + "hole_sizes"]:
+        holes.append(g[prefix + "holes"][k:k + int(n)])
+        k += int(n)
+    return (b if len(b) else None), holes
+
+
 def env_from(g):
+    boundary, holes = shape_from(g)
     return orc.EnvSpec(scale=float(g["env_scale"]), aspect=float(g["env_aspect"]),
-                       boundary_conditions=str(g["env_bc"]), walls=g["user_walls"])
+                       boundary_conditions=str(g["env_bc"]), walls=g["user_walls"], boundary=boundary, holes=holes)
+
+
+def product_env_params(g, prefix="env_"):
+    """The polygon / holes entries of the product Environment's params for a golden file."""
+    boundary, holes = shape_from(g, prefix)
+    out = {}
+    if boundary is not None:
+        out["boundary"] = boundary.tolist()
+    if holes:
+        out["holes"] = [h.tolist() for h in holes]
+    return out
 
 
 def params_from(g):

@@ -38,7 +38,7 @@ def test_library_is_in_tree(L):
 
 def test_struct_layouts_match_header(L):
     # natural C layout of the three ABI structs on LP64
-    assert C.sizeof(L.RiabEnv) == 4 * 8 + 8 + 4 + 4 + 8
+    assert C.sizeof(L.RiabEnv) == 4 * 8 + 8 + 4 + 4 + 8 + 4 * 4 and L.RiabEnv.polygon.offset == 56
     assert C.sizeof(L.RiabMotion) == 8 * 8 + 4 + 4 + 5 * 8
     assert L.RiabRateIO.pos_ld.offset == 32 and L.RiabRateIO.rates.offset == 56
     assert L.RiabRateIO.dt.offset == 80 and L.RiabRateIO.seed.offset == 96
@@ -57,13 +57,13 @@ def test_argument_errors_before_launch(L):
     assert L.lib.riab_place_cells(env, io, C.c_void_p(16), 4, 0, 0, 0.2, None) == -1  # io has null pointers
     assert L.lib.riab_grid_cells(io, None, 4, 0, 0.0, None) == -1
     assert L.lib.riab_head_direction_cells(io, None, 4, None) == -1
-    assert L.lib.riab_agent_step(None, None, None, 4, 0, None, None, None, None, 0, 0, 1, None, None, 64, None) == -1
+    assert L.lib.riab_agent_step(None, None, None, 4, 0, None, None, None, None, None, 0, 0, 1, None, None, 64, None) == -1
     m = L.RiabMotion()
     env.n_walls = 1000
     env.walls = 16
-    assert L.lib.riab_agent_step(env, m, C.c_void_p(16), 4, 0, None, None, None, None, 0, 0, 1, None, None, 64, None) == -3
+    assert L.lib.riab_agent_step(env, m, C.c_void_p(16), 4, 0, None, None, None, None, None, 0, 0, 1, None, None, 64, None) == -3
     env.n_walls = 0
-    assert L.lib.riab_agent_step(env, m, C.c_void_p(16), 4, 0, None, None, None, None, 0, 0, 1, None, None, 16, None) == -1
+    assert L.lib.riab_agent_step(env, m, C.c_void_p(16), 4, 0, None, None, None, None, None, 0, 0, 1, None, None, 16, None) == -1
     io.pos_x = io.pos_y = io.rates = 16
     io.T, io.B, io.pos_ld = 1, 6, 8
     assert L.lib.riab_place_cells(env, io, C.c_void_p(16), 4, 0, 0, 0.2, None) == -2  # B % 4

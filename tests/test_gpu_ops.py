@@ -104,7 +104,7 @@ def test_ops_trace_under_torch_compile(riab):
     env = [0.0, 1.0, 0.0, 1.0, 1.0]
 
     def two_steps(state, hist):
-        torch.ops.riab.agent_step_(state, hist, None, walls, env, False, m, None, None, None, None, 3, 0, 0, 2, 64)
+        torch.ops.riab.agent_step_(state, hist, None, walls, env, False, m, None, None, None, None, None, 3, 0, 0, 2, 64)
         return hist[:, 0] + 0.0
 
     s_a, s_b = ag.state_tensor.clone(), ag.state_tensor.clone()

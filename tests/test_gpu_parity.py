@@ -141,7 +141,7 @@ def test_head_direction_cells_vs_reference(riab):
 def _agent_from_rows(riab, g, rows, precision=64):
     p, kw, dt = gu.params_from(g)
     env = make_env(riab, g["user_walls"], scale=float(g["env_scale"]), aspect=float(g["env_aspect"]),
-                   boundary_conditions=str(g["env_bc"]))
+                   boundary_conditions=str(g["env_bc"]), **gu.product_env_params(g))
     assert np.array_equal(env.walls, g["ref_walls"])
     Ag = riab.Agent(env, dict(p, dt=dt, n_agents=len(rows), precision=precision))
     for k, s in gu.PRE_SLICES.items():
@@ -155,10 +155,13 @@ def test_motion_single_steps_vs_reference(riab, fname):
     g = gu.load(fname)
     Ag, kw, dt = _agent_from_rows(riab, g, g["pre"])
     drift = g["drift"] if g["drift"].shape[0] else None
-    Ag.update(drift_velocity=drift, drift_to_random_strength_ratio=float(g["drift_ratio"]), noise=g["z"].T, **kw)
+    # (resample_positions: where the reference put the agents that ended the step in a hole / outside the polygon)
+    Ag.update(drift_velocity=drift, drift_to_random_strength_ratio=float(g["drift_ratio"]), noise=g["z"].T,
+              resample_positions=np.nan_to_num(g["resample"]), **kw)
     post = g["post"]
     for k, s in gu.PRE_SLICES.items():
         np.testing.assert_allclose(getattr(Ag, k), post[:, s], rtol=1e-9, atol=1e-12, err_msg=k)
+    assert Ag.diagnostics["boundary_conditions"] == int((g["bc_applied"] > 0).sum())
     # output-only quantity: the wrapped angle difference goes through an fp32 arctangent (rel. 1e-7)
     np.testing.assert_allclose(Ag.measured_rotational_velocity, post[:, 10], rtol=2e-6, atol=2e-6)
     fin = np.isfinite(post[:, 11])
@@ -174,11 +177,17 @@ def test_motion_rollout_vs_reference(riab, fname):
     T = g["roll_z"].shape[0]
     z = np.transpose(g["roll_z"], (0, 2, 1))  # (T, 2, B)
     Ag, kw, dt = _agent_from_rows(riab, g, g["roll_state0"])
+    tele, rsp = g["roll_teleport"], np.nan_to_num(g["roll_resample"])
+    jumps = np.isfinite(tele[:, :, 0]).any()
     for t in range(T):
-        Ag.update(noise=z[t], **kw)
+        if np.isfinite(tele[t, :, 0]).any():  # (the generator moved these agents first, like `Ag.pos = ...`)
+            Ag.pos = np.where(np.isfinite(tele[t]), tele[t], Ag.pos)
+        Ag.update(noise=z[t], resample_positions=rsp[t], **kw)
     np.testing.assert_allclose(Ag.history["pos"], g["roll_pos"][1:], rtol=2e-6, atol=2e-7)  # fp32 history rows
     np.testing.assert_allclose(Ag.pos, g["roll_pos"][-1], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(Ag.distance_travelled, g["roll_final"][:, 9], rtol=1e-7)
+    if jumps:
+        return  # (host-side position edits between steps: nothing for the fused path to replay)
     Ag2, kw, dt = _agent_from_rows(riab, g, g["roll_state0"])
     Ag2.simulate(T, noise=torch.as_tensor(z), chunk=64, **kw)
     assert np.array_equal(Ag2.pos, Ag.pos)  # same kernel, same inputs: bit-identical
@@ -1298,7 +1307,7 @@ def test_two_wave_motion_kernel_without_history_rows(riab, monkeypatch):
         e, _w = env.device_tables(Ag._device)
         m = Ag._motion(Ag.dt, False, 1, {})
         h = torch.zeros((70, 8, 128), dtype=torch.float32, device="cuda") if hist else None
-        rc = L.lib.riab_agent_step(e, m, L.ptr(Ag._state), 128, 0, None, None, None, None, 8, 0, 70, L.ptr(h),
+        rc = L.lib.riab_agent_step(e, m, L.ptr(Ag._state), 128, 0, None, None, None, None, None, 8, 0, 70, L.ptr(h),
                                    L.ptr(Ag._diag), 64, L.current_stream())
         L.check(rc, "riab_agent_step")
         torch.cuda.synchronize()

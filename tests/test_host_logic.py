@@ -41,7 +41,7 @@ def test_environment_walls_and_unsupported():
     assert per.walls.shape == (0, 2, 2)
     assert riab.Environment({"scale": 2, "aspect": 1.5}).extent.tolist() == [0, 3, 0, 2]
     assert env.flattened_discrete_coords.shape == (10000, 2)
-    for bad in ({"dimensionality": "1D"}, {"boundary": [[0, 0], [1, 0], [0, 1]]}, {"holes": [[[.1, .1], [.2, .1], [.1, .2]]]}):
+    for bad in ({"dimensionality": "1D"}, {"boundary": [[0, 0], [1, 0], [0, 1]], "boundary_conditions": "periodic"}):
         with pytest.raises(NotImplementedError):
             riab.Environment(bad)
 
@@ -321,3 +321,26 @@ def test_bench_refuses_a_mismatched_world_size():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode == 2 and p.stdout.strip() == "" and "WORLD_SIZE=2" in p.stderr
+
+
+@pytest.mark.parametrize("tag", ["lroom", "holes", "both"])
+def test_polygon_environment_host_side(tag):
+    """Row a6 on the host: walls in the reference's order (boundary edges, user walls, hole edges), the strict
+    inside test point by point, and the three samplers drawing from np.random in the reference's order
+    (tests/golden/polygon.npz, generated by the reference)."""
+    g = gu.load("polygon.npz")
+    params = dict(gu.product_env_params(g, tag + "_"), walls=g[f"{tag}_user_walls"].tolist())
+    env = riab.Environment(params)
+    assert np.array_equal(env.walls, g[f"{tag}_walls"])
+    np.testing.assert_array_equal(env.extent, g[f"{tag}_extent"])
+    assert env.is_rectangular == (tag == "holes") and env.has_holes == (tag != "lroom")
+    got = np.array([env.check_if_position_is_in_environment(p) for p in g[f"{tag}_points"]])
+    assert np.array_equal(got, g[f"{tag}_inside"])
+    for method in ("random", "uniform", "uniform_jitter"):
+        np.random.seed(77)
+        np.testing.assert_array_equal(env.sample_positions(n=53, method=method), g[f"{tag}_sample_{method}"])
+    # hole edges added later keep their flag wherever they land in the table
+    env.add_wall([[0.05, 0.05], [0.06, 0.3]])
+    env.add_hole([[0.3, 0.05], [0.34, 0.05], [0.32, 0.09]])
+    assert env._wall_is_hole[-4:] == [False, True, True, True] and len(env._wall_is_hole) == len(env.walls)
+    assert not env.check_if_position_is_in_environment([0.32, 0.06])

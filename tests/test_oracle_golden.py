@@ -18,9 +18,12 @@ def test_single_steps(fname):
     st = gu.state_from_rows(g["pre"])
     drift = g["drift"] if g["drift"].shape[0] else None
     out = orc.agent_step(env, st, dt, g["z"][:, 0], g["z"][:, 1], params=p, kwargs=kw, drift_velocity=drift,
-                         drift_to_random_strength_ratio=float(g["drift_ratio"]))
+                         drift_to_random_strength_ratio=float(g["drift_ratio"]), resample_pos=g["resample"])
     post = g["post"]
     assert np.array_equal(out["n_bounces"], g["n_bounces"])
+    assert np.array_equal(out["bc_applied"], g["bc_applied"] > 0)
+    # the steps that drew a random replacement are exactly the ones the oracle sends to the resample branch
+    assert np.array_equal(np.isfinite(g["resample"][:, 0]), out["bc_applied"] & orc.env_needs_resample(env, out["pos_before_bc"]))
     for k, s in gu.PRE_SLICES.items():
         np.testing.assert_allclose(out[k], post[:, s], rtol=RT, atol=1e-13, err_msg=k)
     # measured rotational velocity is an angle difference / dt: absolute tolerance
@@ -41,7 +44,10 @@ def test_rollout(fname):
     st = gu.state_from_rows(g["roll_state0"])
     T = g["roll_z"].shape[0]
     for t in range(T):
-        st = orc.agent_step(env, st, dt, g["roll_z"][t, :, 0], g["roll_z"][t, :, 1], params=p, kwargs=kw)
+        tele = np.isfinite(g["roll_teleport"][t, :, 0])  # (the generator put these agents somewhere else first)
+        st["pos"] = np.where(tele[:, None], g["roll_teleport"][t], st["pos"])
+        st = orc.agent_step(env, st, dt, g["roll_z"][t, :, 0], g["roll_z"][t, :, 1], params=p, kwargs=kw,
+                            resample_pos=g["roll_resample"][t])
         np.testing.assert_allclose(st["pos"], g["roll_pos"][t + 1], rtol=1e-8, atol=1e-10, err_msg=f"step {t}")
     np.testing.assert_allclose(st["head_direction"], g["roll_final"][:, 7:9], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(st["distance_travelled"], g["roll_final"][:, 9], rtol=1e-8)
@@ -334,3 +340,37 @@ def test_agent_vector_cells(tag):
     got = orc.agent_vector_cells(env, g["p1"], g["p2"], g[f"{tag}_tuning_distances"], g[f"{tag}_tuning_angles"],
                                  g[f"{tag}_sigma_distances"], g[f"{tag}_sigma_angles"], head_direction=hd, **kw)
     np.testing.assert_allclose(got, g[f"{tag}_rates"].T, rtol=1e-10, atol=1e-14)
+
+
+# ----------------------------------------------------------------------------- row a6: polygons and holes
+@pytest.mark.parametrize("tag", ["lroom", "holes", "both"])
+def test_polygon_environment(tag):
+    """Wall table order, strict inside test (random points + points exactly on edges / corners) and
+    apply_boundary_conditions with the replacements the reference drew (tests/golden/polygon.npz)."""
+    g = gu.load("polygon.npz")
+    boundary, holes = gu.shape_from(g, tag + "_")
+    env = orc.EnvSpec(walls=g[f"{tag}_user_walls"], boundary=boundary, holes=holes)
+    assert np.array_equal(env.walls, g[f"{tag}_walls"])
+    np.testing.assert_array_equal(env.extent, g[f"{tag}_extent"])
+    pts = g[f"{tag}_points"]
+    inside = orc.env_is_inside(env, pts)
+    assert np.array_equal(inside, g[f"{tag}_inside"])
+    assert 0.2 < inside.mean() < 0.9
+    rs = g[f"{tag}_bc_resample"]
+    assert np.array_equal(np.isfinite(rs[:, 0]), orc.env_needs_resample(env, pts))
+    out = np.where(inside[:, None], pts, orc.env_apply_boundary_conditions(env, pts, rs))
+    np.testing.assert_array_equal(out, g[f"{tag}_bc_out"])
+    assert orc.env_is_inside(env, out).all()
+
+
+def test_polygon_place_cells():
+    g = gu.load("polygon.npz")
+    boundary, holes = gu.shape_from(g, "lroom_")
+    env = orc.EnvSpec(walls=g["lroom_user_walls"], boundary=boundary, holes=holes)
+    for geom in ("euclidean", "line_of_sight"):
+        got = orc.place_cells(env, g["pc_pos"], g[f"pc_{geom}_centres"], 0.15, description="gaussian_threshold",
+                              wall_geometry=geom)
+        np.testing.assert_allclose(got, g[f"pc_{geom}_rates"], rtol=1e-12, atol=1e-15)
+    quad = orc.EnvSpec(walls=g["quad_user_walls"], boundary=g["quad_boundary"])
+    got = orc.place_cells(quad, g["quad_pos"], g["quad_centres"], 0.2, wall_geometry="geodesic")
+    np.testing.assert_allclose(got, g["quad_rates"], rtol=1e-12, atol=1e-15)
