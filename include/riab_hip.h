@@ -432,6 +432,12 @@ uint64_t riab_plan_step_index(const RiabPlan* plan);
 /* n_steps x (Agent.update(); every population's update()); RIAB_EFULL (nothing launched) when a
  * history chunk has fewer than n_steps free rows. */
 int riab_plan_step(RiabPlan* plan, int32_t n_steps, riab_stream_t stream);
+/* The two halves of one plan step as separate calls — Agent.update() / one population's Neurons.update() on the
+ * agent's newest history row — for callers that keep the reference's per-object call structure
+ * (demos/simple_example.ipynb cell 4: `Ag.update(); PCs.update()`): same kernels, arguments and RNG counters as
+ * riab_plan_step.  RIAB_EFULL when the object's history chunk is exhausted (attach a new one).  Not with a task. */
+int riab_plan_step_agent(RiabPlan* plan, riab_stream_t stream);
+int riab_plan_step_population(RiabPlan* plan, int32_t index, riab_stream_t stream);
 
 /* ---- batched TaskEnvironment (contribs/TaskEnvironment.py) ------------------------------------
  * The closed-loop caller of the path: `TaskEnvironment.step(actions)` = Agent.update(drift_velocity

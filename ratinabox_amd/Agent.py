@@ -23,6 +23,7 @@ import torch
 
 from . import _lib, utils
 from ._history import DeviceHistory, HistoryView
+from .plan import AutoStepper as _AutoStepper
 
 _L = _lib
 
@@ -48,6 +49,8 @@ class Agent:
         "precision": 64,      # arithmetic of the motion kernel: 64 (parity) or 32
         "agent_id0": 0,       # global id of agent 0 (multi-GPU shards; keys the RNG)
     }
+
+    AUTO_AFTER = 4   # plain update() calls in a row before the per-step loop is served from a native plan
 
     def __init__(self, Environment, params={}):
         self.params = copy.deepcopy(__class__.default_params)
@@ -88,6 +91,9 @@ class Agent:
         self._scratch_row = None
         self._last_row = None   # newest fp32 history row; None when the state was edited from the host
         self._plan = None       # an active StepPlan (plan.py), if any
+        self._auto_streak = 0   # consecutive plain update() calls (plan.AutoStepper engages after AUTO_AFTER)
+        import os
+        self._auto_enabled = os.environ.get("RIAB_NO_AUTO_PLAN") != "1"
         self._streamer = None   # native handle of the flag-coupled pipeline (created on first use)
         self._ctrl = None       # its control words on the device
         self._time_rate_kernel = False
@@ -155,6 +161,8 @@ class Agent:
 
     def _upload(self, row, value):
         """Host edit of a state attribute: one value (broadcast to every agent) or one row per agent."""
+        if self._plan is not None and self._plan.__class__ is _AutoStepper:
+            self._plan.close()  # (the populations must now read the edited float64 state, which the eager path does)
         self._last_row = None  # the fp32 row the rate kernels read no longer mirrors the state
         width = 2 if row in (_L.S_POS_X, _L.S_VEL_X, _L.S_MVEL_X, _L.S_HD_X) else 1
         v = np.asarray(value, dtype=np.float64).reshape(-1, width)
@@ -226,6 +234,12 @@ class Agent:
             self._motion_cache = (key, m)
         return m
 
+    def _motion_key_now(self, dt):
+        """The attribute values `_motion` resolves a plain update() from (its cache key)."""
+        return (dt, False, 1, self.rotational_velocity_std, self.rotational_velocity_coherence_time,
+                self.speed_coherence_time, self.speed_mean, self.speed_std, self.wall_repel_strength,
+                self.wall_repel_distance, self.thigmotaxis, self.head_direction_smoothing_timescale)
+
     def _as_device_f64(self, x, rows):
         """array-like `(B, rows)` / `(rows,)` / tensor `[rows, B]` -> device float64 `[rows, Bp]`."""
         if torch.is_tensor(x):  # stays on the device: closed-loop callers pass policy outputs directly
@@ -254,6 +268,26 @@ class Agent:
         kwargs: the reference's per-call overrides (speed_mean, thigmotaxis, ...), plus
         `noise=` — explicit standard normals `(2, B)` / `(B, 2)` [rotation OU, speed OU]
         instead of the in-kernel Philox draws (parity mode)."""
+        # ---- the unchanged reference loop, served natively (plan.AutoStepper) ----
+        if dt is None and drift_velocity is None and not kwargs and drift_to_random_strength_ratio == 1 and \
+                not self.use_imported_trajectory and self._auto_enabled:
+            st = self._plan
+            if st is not None and st.__class__ is _AutoStepper:
+                if st.step_agent():
+                    return
+                st.close()
+            elif st is None:
+                self._auto_streak += 1
+                if self._auto_streak > self.AUTO_AFTER and self._device.type == "cuda":
+                    try:
+                        if _AutoStepper(self).step_agent():
+                            return
+                    except NotImplementedError:      # a population a plan cannot hold: stay eager
+                        self._auto_enabled = False
+                        if self._plan is not None:
+                            self._plan.close()
+        else:
+            self._auto_streak = 0
         forced = kwargs.pop("forced_next_position", None)
         if forced is not None:
             # Agent._update_position_to_forced_next_position (Agent.py:244-253): overrides everything else
@@ -344,6 +378,9 @@ class Agent:
         update() would have left them.  Returns the trajectory history tensor of this call
         `[n_steps, 8, B_padded]` (device)."""
         neurons = list(self.Neurons if neurons is None else neurons)
+        if self._plan is not None:
+            self._plan.close()  # (before any history row is reserved: a plan's pending rows are not committed yet)
+        self._auto_streak = 0
         if noise is None and not kwargs and self._fused_eligible(neurons):
             traj = self._simulate_fused(int(n_steps), dt or self.dt, drift_velocity, drift_to_random_strength_ratio,
                                         neurons[0], chunk)

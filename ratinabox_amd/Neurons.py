@@ -56,6 +56,13 @@ class Neurons:
     # Called with float32 rows `d [4, P]` = (pos x, pos y, direction x, direction y); returns rates `[n, P]`.
     _state_op = None
 
+    def _auto_key(self):
+        """What `update()` depends on besides the agent's state, by VALUE (users edit tuning arrays in place,
+        reference tests/test_advanced.py:59): compared on every update() served by plan.AutoStepper."""
+        f = self._call(None, None)  # (content-keyed device tables: identical objects while nothing changed)
+        return (tuple(id(v) if torch.is_tensor(v) else v for v in f.values()), float(self.min_fr), float(self.max_fr),
+                self.noise_std, self.noise_coherence_time, bool(self.save_history), bool(self.save_spikes))
+
     def _env_op_args(self):
         """(walls tensor or None, env list, periodic) of the Environment for the operators."""
         return self.Agent.Environment.op_env_args(self._device)
@@ -185,8 +192,11 @@ class Neurons:
         Poisson spikes `U(0,1) < dt*rate` to the history.  kwargs: `spike_uniforms=`
         `(n, B)` and `noise_normals=` `(n, B)` replace the in-kernel Philox draws."""
         Ag = self.Agent
-        if Ag._plan is not None:
-            Ag._plan.close()  # eager stepping resumes: the plan's open rows and cursors would go stale
+        st = Ag._plan
+        if st is not None:
+            if not kwargs and st.__class__.__name__ == "AutoStepper" and st.step_population(self):
+                return  # served from the native plan of the unchanged per-step loop (plan.AutoStepper)
+            st.close()  # eager stepping resumes: the plan's open rows and cursors would go stale
         u = kwargs.pop("spike_uniforms", None)
         zn = kwargs.pop("noise_normals", None)
         save = bool(self.save_history)
@@ -1351,6 +1361,13 @@ class FeedForwardLayer(Neurons):
             d.update(spec)
             p = (d["gain"], d["threshold"], 0, 0)
         return _L.ACTIVATIONS[name], (_L.C.c_float * 4)(*[float(x) for x in p])
+
+    def _auto_key(self):
+        acts = self._activation()
+        return (tuple(id(self._device_weights(e)) for e in self.inputs.values()),
+                np.asarray(self.biases, dtype=np.float32).tobytes(), acts[0], tuple(float(x) for x in acts[1]),
+                float(self.min_fr), float(self.max_fr), self.noise_std, self.noise_coherence_time,
+                bool(self.save_history), bool(self.save_spikes))
 
     def _device_weights(self, entry):
         """W^T padded to a multiple of 32 outputs, float32 on device; refreshed when `w` changes."""

@@ -147,6 +147,8 @@ PROTOTYPES = {
     "riab_plan_rows_free": (C.c_int64, [C.c_void_p]),
     "riab_plan_step_index": (C.c_uint64, [C.c_void_p]),
     "riab_plan_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "riab_plan_step_agent": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "riab_plan_step_population": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "riab_task_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_task_goal_vector": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

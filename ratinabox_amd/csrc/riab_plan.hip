@@ -261,6 +261,34 @@ static int launch_population(RiabPlan* p, size_t i, const float* row, hipStream_
   return rc;
 }
 
+// The two halves of a plan step, for callers that keep the reference's call structure — `Ag.update()` here,
+// `N.update()` there (demos/simple_example.ipynb cell 4) — and only want each call to cost one native transition:
+// the same kernels, arguments and counters as riab_plan_step, so the same results bit for bit.  No task attached.
+extern "C" int riab_plan_step_agent(RiabPlan* p, riab_stream_t stream) {
+  if (!p || p->has_task) return RIAB_EINVAL;
+  if (p->hist_base && p->hist_fill >= p->hist_cap) return RIAB_EFULL;
+  float* row = p->hist_base ? p->hist_base + p->hist_fill * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
+  const int rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr, nullptr,
+                                 p->seed, p->step, 1, row, p->diag, p->precision, (hipStream_t)stream);
+  if (rc) return rc;
+  p->step += 1;
+  if (p->hist_base) p->hist_fill += 1;
+  return RIAB_OK;
+}
+
+// Neurons.update() of population `index` on the agent's newest history row
+extern "C" int riab_plan_step_population(RiabPlan* p, int32_t index, riab_stream_t stream) {
+  if (!p || p->has_task || index < 0 || index >= (int)p->pops.size()) return RIAB_EINVAL;
+  const size_t i = (size_t)index;
+  if (p->pops[i].capacity_rows > 0 && p->pop_fill[i] >= p->pops[i].capacity_rows) return RIAB_EFULL;
+  if (p->hist_base && p->hist_fill == 0) return RIAB_EINVAL;  // no agent row written into this chunk yet
+  const float* row = p->hist_base ? p->hist_base + (p->hist_fill - 1) * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
+  const int rc = launch_population(p, i, row, (hipStream_t)stream);
+  if (rc) return rc;
+  if (p->pops[i].capacity_rows > 0) p->pop_fill[i] += 1;
+  return RIAB_OK;
+}
+
 extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream) {
   if (!p || n_steps <= 0) return RIAB_EINVAL;
   if (riab_plan_rows_free(p) < n_steps) return RIAB_EFULL;

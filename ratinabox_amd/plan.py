@@ -207,3 +207,183 @@ class StepPlan:
                 self._h = None
         except Exception:  # noqa: BLE001 (interpreter shutdown)
             pass
+
+
+class AutoStepper:
+    """The reference's per-object loop served natively WITHOUT the caller changing a line:
+
+        for i in range(T):
+            Ag.update()          # -> one riab_plan_step_agent call
+            PCs.update()         # -> one riab_plan_step_population call
+
+    After `Agent.AUTO_AFTER` consecutive plain `Agent.update()` calls (no arguments) the Agent records itself and
+    its populations in a native plan and serves the following plain `update()` calls — its own and its
+    populations' — from it: the per-call host work drops from ~15 us (parameter resolution, struct filling, history
+    bookkeeping) to one ctypes transition and a staleness check.  The calls keep their meaning: every call launches
+    its own kernel at the time of the call, on the same rows, with the same arguments and RNG counters as the eager
+    path, so results are bit-identical; any call that is not plain (kwargs, drift, another dt), any host edit of the
+    agent state, `simulate()`, `reset_history()` or an explicit step plan closes the stepper and the eager path
+    takes over (and re-engages later).  Attribute edits are caught by value: the motion parameters, the wall table
+    and each population's tables are compared with what the plan was built from on every call.
+
+    Registered in `agent._plan`, so the history accessors publish its pending rows like a StepPlan's."""
+
+    CAPACITY = 4096
+
+    def __init__(self, agent):
+        self.agent = agent
+        self.neurons = list(agent.Neurons)
+        agent._sync_plan()
+        if agent._plan is not None:
+            agent._plan.close()
+        Bp = agent._Bp
+        self._row_scratch = torch.empty((_L.HIST_ROWS, Bp), dtype=torch.float32, device=agent._device)
+        self._dt = agent.dt
+        self._env_struct, self._walls = agent.Environment.device_tables(agent._device)
+        self._motion = agent._motion(agent.dt, False, 1, {})
+        self._motion_key = agent._motion_cache[0]
+        self._h = _L.lib.riab_plan_create(self._env_struct, self._motion, _L.ptr(agent._state), Bp, int(agent.agent_id0),
+                                          int(agent.rng_seed), int(agent._step_index), int(agent.precision),
+                                          _L.ptr(self._row_scratch), _L.ptr(agent._diag))
+        if not self._h:
+            raise _L.RiabError("riab_plan_create failed")
+        self._h = _L.C.c_void_p(self._h)
+        self._index, self._pops, self._keys = {}, [], []
+        for N in self.neurons:
+            pop = N._population(self._index)          # (raises NotImplementedError for populations a plan cannot hold)
+            idx = _L.lib.riab_plan_add(self._h, pop)
+            if idx < 0:
+                raise _L.RiabError(f"riab_plan_add failed: {_L.strerror(idx)}")
+            self._index[N] = idx
+            self._pops.append(pop)
+            self._keys.append(N._auto_key())
+        self._a_pending, self._a_times = 0, []
+        self._p_pending = [0] * len(self.neurons)
+        self._p_times = [[] for _ in self.neurons]
+        self._agent_rows, self._a_done = None, 0
+        self._pop_rows = [None] * len(self.neurons)
+        self._p_done = [0] * len(self.neurons)
+        self._scratch_rates = [None] * len(self.neurons)
+        agent._plan = self
+        self._attach()
+
+    # ---- history chunks -------------------------------------------------------------------------
+    def _attach(self):
+        self.sync()
+        ag, cap = self.agent, self.CAPACITY
+        if ag.save_history:
+            self._agent_rows = ag._hist.open_rows(cap)
+            rc = _L.lib.riab_plan_set_agent_history(self._h, _L.ptr(self._agent_rows), cap)
+        else:
+            self._agent_rows = None
+            rc = _L.lib.riab_plan_set_agent_history(self._h, None, 0)
+        _L.check(rc, "riab_plan_set_agent_history")
+        self._a_done = 0
+        for i in range(len(self.neurons)):
+            self._attach_pop(i)
+
+    def _attach_pop(self, i):
+        N, ag = self.neurons[i], self.agent
+        self._sync_pop(i)
+        if N.save_history:
+            fr = N._hist_fr.open_rows(self.CAPACITY)
+            sp = N._hist_sp.open_rows(self.CAPACITY) if N.save_spikes else None
+            self._pop_rows[i] = (fr, sp)
+            rc = _L.lib.riab_plan_set_population_history(self._h, i, _L.ptr(fr), _L.ptr(sp), self.CAPACITY)
+        else:
+            if self._scratch_rates[i] is None:
+                self._scratch_rates[i] = torch.empty((1, int(N.n), ag._Bp), dtype=torch.float32, device=ag._device)
+            self._pop_rows[i] = (self._scratch_rates[i], None)
+            rc = _L.lib.riab_plan_set_population_history(self._h, i, _L.ptr(self._scratch_rates[i]), None, 0)
+        _L.check(rc, "riab_plan_set_population_history")
+        self._p_done[i] = 0
+
+    # ---- the two fast paths ---------------------------------------------------------------------
+    def step_agent(self):
+        """Agent.update() with no arguments.  False: something changed — the caller closes the stepper and goes eager."""
+        ag = self.agent
+        if ag.dt != self._dt or ag._motion_key_now(ag.dt) != self._motion_key:
+            return False
+        env, _w = ag.Environment.device_tables(ag._device)
+        if env is not self._env_struct:   # (device_tables returns the cached struct while the geometry is unchanged)
+            return False
+        rc = _L.lib.riab_plan_step_agent(self._h, _L.current_stream())
+        if rc == _L.EFULL:
+            self._attach()
+            rc = _L.lib.riab_plan_step_agent(self._h, _L.current_stream())
+        _L.check(rc, "riab_plan_step_agent")
+        ag.prev_t = ag.t
+        ag.t += self._dt
+        ag._step_index += 1
+        self._a_pending += 1
+        self._a_times.append(ag.t)
+        return True
+
+    def step_population(self, N):
+        """N.update() with no arguments, N one of the recorded populations with unchanged tables."""
+        i = self._index.get(N)
+        if i is None or N._auto_key() != self._keys[i]:
+            return False
+        rc = _L.lib.riab_plan_step_population(self._h, i, _L.current_stream())
+        if rc == _L.EFULL:
+            self._attach_pop(i)
+            rc = _L.lib.riab_plan_step_population(self._h, i, _L.current_stream())
+        _L.check(rc, "riab_plan_step_population")
+        self._p_pending[i] += 1
+        self._p_times[i].append(self.agent.t)
+        return True
+
+    # ---- publishing -----------------------------------------------------------------------------
+    def _sync_pop(self, i):
+        n = self._p_pending[i]
+        if not n or self._pop_rows[i] is None:
+            return
+        self._p_pending[i] = 0
+        N = self.neurons[i]
+        fr, sp = self._pop_rows[i]
+        times, self._p_times[i] = self._p_times[i], []
+        if N.save_history:
+            done = self._p_done[i]
+            N._hist_fr.commit(n)
+            if sp is not None:
+                N._hist_sp.commit(n)
+            N._times.extend(times)
+            N._rates = fr[done + n - 1]
+            N._spikes_last = None if sp is None else sp[done + n - 1]
+            self._p_done[i] = done + n
+        else:
+            N._rates = fr[0]
+
+    def sync(self):
+        """Publish the rows written since the last sync to the Python-side mirrors."""
+        ag = self.agent
+        n = self._a_pending
+        if n:
+            self._a_pending = 0
+            times, self._a_times = self._a_times, []
+            if ag.save_history:
+                ag._hist.commit(n)
+                ag._times.extend(times)
+                ag._last_row = self._agent_rows[self._a_done + n - 1]
+                self._a_done += n
+            else:
+                ag._last_row = self._row_scratch
+        for i in range(len(self.neurons)):
+            self._sync_pop(i)
+
+    def close(self):
+        self.sync()
+        if self.agent._plan is self:
+            self.agent._plan = None
+        self.agent._auto_streak = 0
+        if self._h:
+            _L.lib.riab_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _L.lib.riab_plan_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001 (interpreter shutdown)
+            pass

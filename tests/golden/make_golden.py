@@ -812,6 +812,43 @@ def make_task():
         np.savez_compressed(os.path.join(HERE, f"task_{name}.npz"), **out)
 
 
+# ------------------------------------------------------------- BASELINE cfg 1 -- #
+def make_cfg1():
+    """BASELINE.json configs[0] / README.md:43: 1 agent, 1 m box, 100 gaussian PlaceCells, dt = 10 ms, 60 s =
+    6000 `Ag.update(); PCs.update()` steps of the reference with the OU normals recorded.  Kept: the normals, the
+    trajectory, the firing rates of every 50th step and of the last one."""
+    _section("cfg 1: 1 agent x 100 PlaceCells x 6000 steps")
+    np.random.seed(0)
+    Env = Environment()
+    Ag = Agent(Env, {"dt": 0.01})
+    PCs = PlaceCells(Ag, {"n": 100})
+    PCs.place_cell_centres = f32exact(PCs.place_cell_centres)
+    T = 6000
+    state0 = np.concatenate([np.ravel(x) for x in _get_state(Ag)])
+    z = np.zeros((T, 2))
+    pos = np.zeros((T + 1, 2))
+    pos[0] = Ag.pos
+    _capture["on"] = True
+    bounces = 0
+    for t in range(T):
+        _rec["normal"].clear()
+        _bounces["n"] = 0
+        Ag.update()
+        scal = [v for shp, v in _rec["normal"] if shp == ()]
+        assert len(scal) == 2
+        z[t] = scal
+        bounces += _bounces["n"]
+        PCs.update()
+        pos[t + 1] = Ag.pos
+    _capture["on"] = False
+    fr = np.array(PCs.history["firingrate"])
+    out = dict(state0=state0, z=z, pos=pos, centres=np.array(PCs.place_cell_centres), widths=np.array(PCs.place_cell_widths),
+               rates_every_50=fr[49::50], rates_last=fr[-1], head_direction=np.array(Ag.history["head_direction"])[49::50],
+               distance_travelled=float(Ag.distance_travelled), n_bounces=bounces, t_end=float(Ag.t))
+    np.savez_compressed(os.path.join(HERE, "cfg1.npz"), **out)
+    print(f"  cfg1.npz: {T} steps, {bounces} bounces, distance {out['distance_travelled']:.3f} m")
+
+
 # ------------------------------------------------------------------ row a6 -- #
 def make_polygon():
     """Polygonal boundary and holes away from the motion records: wall table order, the strict inside test on
@@ -923,15 +960,17 @@ def make_stats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task", "polygon", "stats"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task", "polygon", "cfg1", "stats"]
     if "--out" in which:  # write somewhere else (tools/check_golden.py regenerates into a temporary directory)
         HERE = which[which.index("--out") + 1]
         which = [w for i, w in enumerate(which) if w != "--out" and (i == 0 or which[i - 1] != "--out")] or \
             ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task",
-             "polygon", "stats"]
+             "polygon", "cfg1", "stats"]
         os.makedirs(HERE, exist_ok=True)
     if "polygon" in which:
         make_polygon()
+    if "cfg1" in which:
+        make_cfg1()
     if "stats" in which:
         make_stats()
     if "task" in which:

@@ -250,3 +250,75 @@ def test_bench_launches_its_own_ranks(riab):
     assert out["n_gpus"] == 2 and out["steps"] == 64
     assert out["config"]["parallelism"].startswith("agent-sharded x2")
     assert out["value"] > 1e6 and out["diagnostics"].get("pipeline_timeouts", 0) == 0
+
+
+# ----------------------------------------------------------------------------- the unchanged per-step loop
+def _loop(riab, auto, script, B=256, seed=11):
+    """Run `script(riab, env, ag, pops)` — reference-style per-object update() calls — with the AutoStepper on/off."""
+    os.environ["RIAB_NO_AUTO_PLAN"] = "0" if auto else "1"
+    try:
+        np.random.seed(seed)
+        env = riab.Environment({"walls": [[[0.5, 0.0], [0.5, 0.35]]]})
+        ag = riab.Agent(env, {"n_agents": B, "dt": 0.02, "seed": 4})
+        np.random.seed(seed + 1)
+        pops = [riab.PlaceCells(ag, {"n": 40, "wall_geometry": "line_of_sight"}), riab.BoundaryVectorCells(ag, {"n": 12}), riab.HeadDirectionCells(ag, {"n": 8}),
+                riab.GridCells(ag, {"n": 16, "noise_std": 0.1})]
+        ff = riab.FeedForwardLayer(ag, {"n": 6, "input_layers": [pops[0], pops[3]],
+                                        "activation_function": {"activation": "tanh", "gain": 1.0, "threshold": 0.0}})
+        pops.append(ff)
+        used = script(riab, env, ag, pops)
+        torch.cuda.synchronize()
+        out = {"traj": ag.get_history_tensor().cpu().numpy(), "state": ag.state_tensor.cpu().numpy(), "t": list(ag.history["t"])}
+        for i, p in enumerate(pops):
+            fr, sp = p.get_history_tensors()
+            out[f"fr{i}"], out[f"sp{i}"], out[f"t{i}"] = fr.cpu().numpy(), sp.cpu().numpy(), list(p.history["t"])
+            out[f"last{i}"] = p.firingrate
+        return out, used
+    finally:
+        os.environ.pop("RIAB_NO_AUTO_PLAN", None)
+
+
+def _plain(riab, env, ag, pops):
+    for _ in range(40):
+        ag.update()
+        for p in pops:
+            p.update()
+    return ag._plan is not None and type(ag._plan).__name__ == "AutoStepper"
+
+
+def _with_edits(riab, env, ag, pops):
+    engaged = []
+    for t in range(60):
+        if t == 15:
+            ag.speed_mean = 0.2                      # reference tests/test_advanced.py:47-48
+        if t == 22:
+            pops[0].place_cell_centres[-1] = [0.9, 0.9]   # in-place edit of a tuning array (:59)
+        if t == 30:
+            ag.pos = np.full((ag.n_agents, 2), 0.25)  # the populations must read the edited state
+        if t == 38:
+            env.add_wall([[0.2, 0.6], [0.8, 0.6]])
+        ag.update()
+        for i, p in enumerate(pops):
+            if not (i == 2 and t % 3 == 0):          # a population that is not updated every step
+                p.update()
+        if t == 45:
+            ag.update(drift_velocity=np.array([0.1, 0.0]))   # a call that is not plain
+            pops[0].update()
+        engaged.append(ag._plan is not None and type(ag._plan).__name__ == "AutoStepper")
+    return any(engaged[5:14]) and any(engaged[50:])
+
+
+@pytest.mark.parametrize("script", [_plain, _with_edits], ids=["plain", "with_edits"])
+def test_unchanged_reference_loop_is_served_natively_and_bit_identical(riab, script):
+    """`Ag.update(); N.update() ...` from Python, no plan made by the caller: after a few rounds the
+    calls are served by plan.AutoStepper; histories, states, spikes, times: identical to the eager calls, also
+    across attribute edits, skipped populations, added walls and calls with arguments."""
+    a, used = _loop(riab, True, script)
+    b, used_b = _loop(riab, False, script)
+    assert used and not used_b
+    assert a.keys() == b.keys()
+    for k in a:
+        if isinstance(a[k], list):
+            assert a[k] == b[k], k
+        else:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)

@@ -195,6 +195,32 @@ def test_motion_rollout_vs_reference(riab, fname):
     assert np.allclose(Ag2.history["t"], Ag.history["t"])
 
 
+def test_cfg1_vs_reference(riab):
+    """BASELINE.json configs[0] (reference README.md:43): 1 agent, 1 m box, 100 gaussian PlaceCells, dt = 10 ms,
+    6000 unchanged `Ag.update(); PCs.update()` steps — the reference's loop with only the import changed and its
+    recorded OU normals fed in.  Trajectory 1e-9 in the float64 state (the fp32 history rows 2e-6), firing rates 1e-5."""
+    g = gu.load("cfg1.npz")
+    Ag = riab.Agent(make_env(riab), {"dt": 0.01})
+    PCs = riab.PlaceCells(Ag, {"place_cell_centres": g["centres"], "widths": 0.2, "wall_geometry": "euclidean"})
+    for k, s in gu.PRE_SLICES.items():
+        setattr(Ag, k, g["state0"][None][:, s])
+    z = g["z"]
+    for t in range(6000):
+        Ag.update(noise=z[t].reshape(2, 1))
+        PCs.update()
+    np.testing.assert_allclose(Ag.pos, g["pos"][-1], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(Ag.distance_travelled, float(g["distance_travelled"]), rtol=1e-9)
+    assert Ag.t == pytest.approx(float(g["t_end"]), rel=1e-12)
+    # (the agent axis is padded to 4 lanes; the explicit normals are broadcast to the padding, which bounces along)
+    assert Ag.diagnostics["bounces"] == 4 * int(g["n_bounces"])
+    np.testing.assert_allclose(Ag.history["pos"], g["pos"][1:], rtol=2e-6, atol=2e-7)
+    fr = PCs.history["firingrate"]
+    assert fr.shape == (6000, 100)
+    np.testing.assert_allclose(fr[49::50], g["rates_every_50"], rtol=1e-5, atol=1e-30)
+    np.testing.assert_allclose(PCs.firingrate, g["rates_last"], rtol=1e-5, atol=1e-30)
+    np.testing.assert_allclose(Ag.history["head_direction"][49::50], g["head_direction"], rtol=2e-6, atol=2e-7)
+
+
 def test_motion_fp32_variant_tracks_oracle(riab):
     """precision=32: single steps agree with the float64 reference to fp32 accuracy."""
     g = gu.load("motion_maze_dt10ms.npz")

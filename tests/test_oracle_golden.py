@@ -374,3 +374,18 @@ def test_polygon_place_cells():
     quad = orc.EnvSpec(walls=g["quad_user_walls"], boundary=g["quad_boundary"])
     got = orc.place_cells(quad, g["quad_pos"], g["quad_centres"], 0.2, wall_geometry="geodesic")
     np.testing.assert_allclose(got, g["quad_rates"], rtol=1e-12, atol=1e-15)
+
+
+def test_cfg1_rollout():
+    """BASELINE cfg 1 (1 agent, 100 PlaceCells, dt 10 ms, 6000 steps of the reference with its OU normals recorded):
+    the oracle tracks the whole minute of trajectory and the firing rates along it."""
+    g = gu.load("cfg1.npz")
+    env = orc.EnvSpec()
+    st = gu.state_from_rows(g["state0"][None])
+    for t in range(6000):
+        st = orc.agent_step(env, st, 0.01, g["z"][t, 0:1], g["z"][t, 1:2])
+        if t % 50 == 49:
+            np.testing.assert_allclose(st["pos"][0], g["pos"][t + 1], rtol=1e-10, atol=1e-12)
+            fr = orc.place_cells(env, st["pos"], g["centres"], g["widths"])
+            np.testing.assert_allclose(fr[:, 0], g["rates_every_50"][t // 50], rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(st["distance_travelled"][0], float(g["distance_travelled"]), rtol=1e-12)
