@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured-achievable copy
+VALU_EXP_PEAK_TTERMS = 11.3  # (v_mul_f32 + v_exp_f32) pairs per second, chip-wide, measured: tools/exp_bench.hip
 
 CONFIGS = {
     # name: agents per GPU, cells, walls, spikes
@@ -275,8 +276,12 @@ def main():
     seen = {"n": 0}
     n_launches = (K + args.chunk - 1) // max(args.chunk, 1)
 
+    # the dominant kernel: BoundaryVectorCells where there are any (65-70 % of the kernel time of cfg 3 / cfg 5,
+    # profiles/r02_cfg3_kernel_stats.csv), else the first population
+    dominant = next((p for p in pops if type(p).__name__ == "BoundaryVectorCells"), pops[0])
+
     def hook(pop, what, tc):
-        if pop is not pops[0]:
+        if pop is not dominant:
             return
         if what == "begin":
             seen["n"] += 1
@@ -320,7 +325,7 @@ def main():
     bpu = bytes_per_agent_step(cfg)
 
     roofline = None
-    n0 = int(pops[0].n)
+    n0 = int(dominant.n)
     # the contract's `achieved` uses SURVEY §8(d)'s per-unit figure (rates written + spikes + the 112 B of state /
     # history that the trajectory kernel moves while the rate kernel runs), restricted to the dominant population;
     # the rate kernel ALONE moves 4*n0 (+n0) + 8 B per unit: `achieved_kernel_own_bytes`
@@ -344,7 +349,7 @@ def main():
                 traffic = round(json.load(f).get("hbm_bytes_per_unit") * avg_units)  # PMC bytes/unit x units/launch
         poll_max = int(os.environ.get("RIAB_STREAM_POLL_MAX", 256))
         kname = (("rate_kernel_gated" if K <= poll_max else "rate stage = rate_kernel_wide per chunk behind progress gates")
-                 if fused_mode else "rate_kernel_wide") + f"<{type(pops[0]).__name__}>"
+                 if fused_mode else "rate_kernel_wide") + f"<{type(dominant).__name__}>"
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": kname, "launches": len(ms),
@@ -354,6 +359,19 @@ def main():
                     "achieved_kernel_own_bytes": round(own_bytes * avg_units / (avg_ms * 1e-3) / 1e9, 1),
                     "kernel_own_bytes_per_unit": own_bytes,
                     "frac_of_measured_copy_bw_6290": round(achieved / 6290.0, 4)}
+        if type(dominant).__name__ == "BoundaryVectorCells":
+            # BVC is bound by transcendental issue, not by HBM: n*K exponentials per position.  Peak =
+            # the v_mul + v_exp issue ceiling MEASURED on this chip (tools/exp_bench.hip); achieved = the terms of the
+            # full sum per second (the direction windows skip ~17 % of them, so this is useful terms, not issued ones).
+            terms = float(n0) * float(dominant.n_test_angles)
+            t_ach = terms * avg_units / (avg_ms * 1e-3) / 1e12
+            roofline = {"bound": "valu", "achieved": round(t_ach, 3), "peak": VALU_EXP_PEAK_TTERMS, "unit": "Tterm/s",
+                        "frac": round(t_ach / VALU_EXP_PEAK_TTERMS, 4), "traffic": None,
+                        "kernel": "bvc_kernel", "launches": len(ms), "avg_launch_ms": round(avg_ms, 5),
+                        "units_per_launch": int(avg_units), "terms_per_unit": int(terms),
+                        "peak_is": "v_mul_f32 + v_exp_f32 issue ceiling measured with tools/exp_bench.hip on MI355X "
+                                   "(DESIGN.md 3.2); one term = one fused exponent exp2(-(a d - a mu)^2 + T[c][k])",
+                        "hbm_GBps_of_this_kernel": round(achieved, 1), "hbm_frac_of_this_kernel": round(achieved / HBM_PEAK_GBS, 4)}
         if fused_mode:
             roofline["note"] = ("the rate stage runs concurrently with the trajectory kernel whose rows it consumes (coupled "
                                 "by flags in device memory, one native call per timed region): its duration includes "
@@ -379,7 +397,8 @@ def main():
         torch.cuda.synchronize()
         store_ceiling = 5 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
         roofline["measured_store_ceiling_GBps"] = round(store_ceiling, 1)
-        roofline["frac_of_measured_store_ceiling"] = round(roofline["achieved"] / store_ceiling, 4)
+        if roofline["bound"] == "hbm":
+            roofline["frac_of_measured_store_ceiling"] = round(roofline["achieved"] / store_ceiling, 4)
         del buf
 
     if rank == 0:

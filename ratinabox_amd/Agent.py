@@ -17,6 +17,7 @@ the trajectory history chunks `[T, 8, B]` (float32, HBM) and resolves parameters
 `simulate(T)` is the fused path: T steps per launch on one stream while the
 firing-rate kernels of the previous chunk run on another."""
 import copy
+import os
 
 import numpy as np
 import torch
@@ -92,7 +93,6 @@ class Agent:
         self._last_row = None   # newest fp32 history row; None when the state was edited from the host
         self._plan = None       # an active StepPlan (plan.py), if any
         self._auto_streak = 0   # consecutive plain update() calls (plan.AutoStepper engages after AUTO_AFTER)
-        import os
         self._auto_enabled = os.environ.get("RIAB_NO_AUTO_PLAN") != "1"
         self._streamer = None   # native handle of the flag-coupled pipeline (created on first use)
         self._ctrl = None       # its control words on the device
@@ -442,17 +442,16 @@ class Agent:
         PlaceCells / GridCells / HeadDirectionCells population without additive noise.  Everything else goes
         through the chunked two-stream pipeline below.  `RIAB_NO_FUSED=1` switches it off (A/B comparisons:
         the results are bit-identical)."""
-        import os
         if len(neurons) != 1 or self.use_imported_trajectory or self.precision != 64 or self._Bp % 256:
             return False
-        if os.environ.get("RIAB_NO_FUSED") == "1":
-            return False
         N = neurons[0]
-        return getattr(N, "_stream_kind", None) is not None and N.noise_std == 0 and N.Agent is self
+        if N._stream_kind is None or N.noise_std != 0 or N.Agent is not self:
+            return False
+        return _L.env("RIAB_NO_FUSED") != "1"
 
     def _simulate_fused(self, n_steps, dt, drift_velocity, ratio, N, chunk):
-        if self._plan is not None:
-            self._plan.close()
+        """One native call (riab_simulate_fused).  A 20-step run is ~80 us of GPU time: everything that is not needed
+        to issue the call — views, clocks, mirrors — happens AFTER it, while the kernels run."""
         if self._streamer is None:
             h = _L.lib.riab_streamer_create()
             if not h:
@@ -464,41 +463,58 @@ class Agent:
         env, _walls = self.Environment.device_tables(self._device)
         drift = self._as_device_f64(drift_velocity, 2) if has_drift else None
         pop = N._population()
+        Bp, n = self._Bp, int(N.n)
+        traj_row, fr_row, sp_row = _L.HIST_ROWS * Bp * 4, n * Bp * 4, n * Bp
+        # rows: (tensor, first row) pairs now, views later
         if self.save_history:
-            traj = self._hist.reserve(n_steps)
+            traj_c, traj_s = self._hist.reserve_at(n_steps)
         else:
-            traj = torch.empty((n_steps, _L.HIST_ROWS, self._Bp), dtype=torch.float32, device=self._device)
-        out = N._reserve_rows(n_steps, ring=min(chunk, n_steps))
-        fr, sp = out["fr"], out["sp"]
-        # rates kept in full: one launch for all steps.  Rates streamed through a ring (save_history=False): one
-        # launch per ring length — inside a launch the persistent waves are many time rows apart, so rows of one
-        # launch must not alias; launches are ordered by the stream.
-        piece = min(n_steps if out["ring"] is None else int(out["ring"]), 32768)  # (time rows are the grid's z axis)
-        import os
-        wgs = int(os.environ.get("RIAB_STREAM_WGS_PER_CU", 0))
-        mode = int(os.environ.get("RIAB_STREAM_MODE", 0))
+            traj_c, traj_s = torch.empty((n_steps, _L.HIST_ROWS, Bp), dtype=torch.float32, device=self._device), 0
+        full = bool(N.save_history)
+        if full:
+            fr_c, fr_s = N._hist_fr.reserve_at(n_steps)
+            sp_c, sp_s = N._hist_sp.reserve_at(n_steps) if N.save_spikes else (None, 0)
+            piece = n_steps
+        else:
+            # rates streamed through a ring: one launch per ring length (inside a launch the rate waves are several
+            # time rows apart, so rows of one launch must not alias; launches are ordered by the stream)
+            piece = min(n_steps, 2 * min(chunk, n_steps))
+            fr_c, fr_s = torch.empty((piece, n, Bp), dtype=torch.float32, device=self._device), 0
+            sp_c, sp_s = None, 0
+        piece = min(piece, 32768)  # (time rows are the z axis of the rate kernel's grid)
+        wgs = int(_L.env("RIAB_STREAM_WGS_PER_CU", 0))
+        mode = int(_L.env("RIAB_STREAM_MODE", 0))
+        traj_p = traj_c.data_ptr() + traj_s * traj_row
+        fr_p = fr_c.data_ptr() + fr_s * fr_row
+        sp_p = sp_c.data_ptr() + sp_s * sp_row if sp_c is not None else None
+        state_p, diag_p, ctrl_p, drift_p = self._state.data_ptr(), self._diag.data_ptr(), self._ctrl.data_ptr(), _L.ptr(drift)
+        seed, a0, step, timing = int(self.rng_seed), int(self.agent_id0), int(self._step_index), 1 if self._time_rate_kernel else 0
+        call, stream = _L.lib.riab_simulate_fused, _L.current_stream()
         t0 = 0
         while t0 < n_steps:
             tc = min(piece, n_steps - t0)
-            rows0 = t0 if out["ring"] is None else 0
-            pop.rates_base = fr[rows0].data_ptr()
-            pop.spikes_base = sp[rows0].data_ptr() if sp is not None else None
+            rows0 = t0 if full else 0
+            pop.rates_base = fr_p + rows0 * fr_row
+            pop.spikes_base = sp_p + rows0 * sp_row if sp_p is not None else None
             pop.capacity_rows = tc
-            rc = _L.lib.riab_simulate_fused(self._streamer, env, m, _L.ptr(self._state), self._Bp, int(self.agent_id0),
-                                            _L.ptr(drift), int(self.rng_seed), int(self._step_index) + t0, tc,
-                                            _L.ptr(traj[t0]), _L.ptr(self._diag), pop, _L.ptr(self._ctrl), wgs, mode,
-                                            1 if self._time_rate_kernel else 0, _L.current_stream())
+            rc = call(self._streamer, env, m, state_p, Bp, a0, drift_p, seed, step + t0, tc, traj_p + t0 * traj_row, diag_p,
+                      pop, ctrl_p, wgs, mode, timing, stream)
             if rc == _L.EUNSUPPORTED and t0 == 0:  # (nothing was launched; the chunked path reserves its own rows)
                 if self.save_history:
                     self._hist.unreserve(n_steps)
-                N._unreserve_rows(out, n_steps)
+                if full:
+                    N._hist_fr.unreserve(n_steps)
+                    if sp_c is not None:
+                        N._hist_sp.unreserve(n_steps)
                 return None
             _L.check(rc, "riab_simulate_fused")
             t0 += tc
+        # ---- the kernels are running: now the views and the Python-side mirrors
+        traj = traj_c[traj_s:traj_s + n_steps]
         self.dt = dt
-        self._keep = (drift, _walls, traj, out, pop)
+        self._keep = (drift, _walls, traj_c, fr_c, sp_c, pop)
         self._last_row = traj[n_steps - 1]
-        self._last_fused_units = self._Bp * tc  # agent-steps of the launch `last_rate_kernel_ms` refers to
+        self._last_fused_units = Bp * tc  # agent-steps of the launch `last_rate_kernel_ms` refers to
         t, times = self.t, []
         for _ in range(n_steps):  # (the reference's clock: repeated `t += dt`, not t0 + i*dt)
             self.prev_t = t
@@ -508,9 +524,12 @@ class Agent:
         if self.save_history:
             self._times.extend(times)
         self._step_index += n_steps
-        if out["ring"] is not None:
-            out["last"] = fr[(n_steps - 1) % piece]
-        N._finish_rows(out, n_steps, times)
+        if full:
+            N._rates = fr_c[fr_s + n_steps - 1]
+            N._spikes_last = None if sp_c is None else sp_c[sp_s + n_steps - 1]
+            N._times.extend(times)
+        else:
+            N._rates = fr_c[(n_steps - 1) % piece]
         return traj
 
     def last_rate_kernel_ms(self):

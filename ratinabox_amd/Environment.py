@@ -369,20 +369,21 @@ class Environment:
         # the wall table as bytes: catches in-place edits of Environment.walls at ~1 us per call
         w_bytes = w_now.tobytes() if type(w_now) is np.ndarray and w_now.dtype == np.float64 else \
             np.asarray(w_now, dtype=np.float64).tobytes()
-        if len(self._wall_is_hole) != len(np.asarray(w_now).reshape(-1, 4)):
+        if len(self._wall_is_hole) != len(w_now):
             if any(self._wall_is_hole):
                 raise ValueError("Environment.walls was replaced in an environment with holes: use add_wall / add_hole, "
                                  "which keep track of which walls are hole edges")
             self._wall_is_hole = [False] * len(np.asarray(w_now).reshape(-1, 4))
-        shape_key = (self.is_rectangular, self._n_boundary, tuple(self._wall_is_hole))
+        shape_key = (self.is_rectangular, self._n_boundary, self._wall_is_hole)
         if hit is not None:
             (src, bc, sc, asp, shp), env, wt = hit
             # fast path (every step): same geometry, wall array unchanged
             if src == w_bytes and bc == self.boundary_conditions and sc == self.scale and asp == self.aspect and \
-                    shp == shape_key:
+                    shp[0] == shape_key[0] and shp[1] == shape_key[1] and shp[2] == shape_key[2]:
                 return env, wt
         walls = np.ascontiguousarray(np.asarray(self.walls, dtype=np.float64).reshape(-1, 4))
-        key = (w_bytes, self.boundary_conditions, self.scale, self.aspect, shape_key)
+        key = (w_bytes, self.boundary_conditions, self.scale, self.aspect,
+               (shape_key[0], shape_key[1], list(shape_key[2])))
         if len(walls) > _lib.MAX_WALLS:
             raise ValueError(f"at most {_lib.MAX_WALLS} walls are supported on device, got {len(walls)}")
         wt = torch.from_numpy(walls if len(walls) else np.zeros((1, 4))).to(device)

@@ -105,6 +105,15 @@ class Neurons:
         """This population as the ABI's RiabPopulation (for a step plan); keeps its tables alive.
         `plan_index`: {Neurons object: index in the plan} of the populations recorded before this one
         (what a FeedForwardLayer's inputs are looked up in)."""
+        if not isinstance(self, FeedForwardLayer):
+            # (the descriptor only changes when a table was rebuilt: simulate() of a short run asks for it every time,
+            # and building the ctypes struct costs ~50 us)
+            f = self._call(None, None)
+            vals = tuple(f.values())
+            hit = self.__dict__.get("_pop_cache")
+            if hit is not None and self.noise_std == 0 and hit[1] == (float(self.min_fr), float(self.max_fr)) and \
+                    len(hit[0]) == len(vals) and all(a is b if torch.is_tensor(a) else a == b for a, b in zip(hit[0], vals)):
+                return hit[2]
         pop = _L.RiabPopulation()
         pop.n = int(self.n)
         pop.io.min_fr, pop.io.max_fr, pop.io.pop_id = float(self.min_fr), float(self.max_fr), int(self.pop_id)
@@ -129,20 +138,13 @@ class Neurons:
                 pop.act_params[i] = pars[i]
             self._plan_tables = keep + [bias_t]
         else:
-            f = self._call(None, None)
-            # (the descriptor only changes when a table was rebuilt: simulate() of a short run calls this every time)
-            key = (tuple(f.values()), float(self.min_fr), float(self.max_fr), self.noise_std != 0)
-            hit = self.__dict__.get("_pop_cache")
-            if hit is not None and len(hit[0][0]) == len(key[0]) and hit[0][1:] == key[1:] and \
-                    all(a is b if torch.is_tensor(a) else a == b for a, b in zip(hit[0][0], key[0])):
-                return hit[1]
             pop.kind = f["kind"]
             self._plan_tables = [v for v in f.values() if torch.is_tensor(v)]
             for k, v in f.items():
                 if k != "kind":
                     setattr(pop, k, v.data_ptr() if torch.is_tensor(v) else v)
             if self.noise_std == 0:
-                self.__dict__["_pop_cache"] = (key, pop)
+                self.__dict__["_pop_cache"] = (vals, (float(self.min_fr), float(self.max_fr)), pop)
         if self.noise_std != 0:  # the OU parameters of update() (Neurons.py:153-168), fixed for the plan's dt
             tau, dt = float(self.noise_coherence_time), float(self.Agent.dt)
             pop.noise_state = self._noise.data_ptr()

@@ -28,16 +28,22 @@ class DeviceHistory:
         """A writable view `[T, *row_shape]` of fresh rows (contiguous).  A request
         that does not fit the current chunk's free tail opens a new chunk of
         exactly max(T, chunk_rows) rows."""
+        chunk, s = self.reserve_at(T)
+        return chunk[s:s + int(T)]
+
+    def reserve_at(self, T):
+        """reserve() without making the view: (chunk tensor, first row).  Callers on a latency-critical path take
+        the address as `chunk.data_ptr() + first_row * row_bytes` and build the view after their launch."""
         T = int(T)
         self.version += 1
         if self.chunks and self.chunks[-1].shape[0] - self.filled[-1] >= T:
             s = self.filled[-1]
             self.filled[-1] += T
-            return self.chunks[-1][s:s + T]
+            return self.chunks[-1], s
         rows = max(T, self.chunk_rows) if T == 1 else T
         self.chunks.append(torch.empty((rows, *self.row_shape), dtype=self.dtype, device=self.device))
         self.filled.append(T)
-        return self.chunks[-1][:T]
+        return self.chunks[-1], 0
 
     def unreserve(self, T):
         """Give back the T rows of the latest reserve() (nothing was written to them)."""

@@ -227,6 +227,18 @@ def check(code, what):
         raise RiabError(f"{what} failed with code {code}: {strerror(code)}")
 
 
+_ENV_DATA = getattr(os.environ, "_data", None)
+
+
+def env(name, default=None):
+    """os.environ.get for the A/B switches read on latency-critical paths: `os.environ.get` encodes the key and
+    goes through two wrappers (3-4 us per lookup); CPython keeps the raw mapping in `os.environ._data`."""
+    if _ENV_DATA is not None:
+        v = _ENV_DATA.get(name.encode() if os.name != "nt" else name.upper())
+        return default if v is None else (v.decode() if isinstance(v, bytes) else v)
+    return os.environ.get(name, default)
+
+
 def ptr(t):
     """Device pointer of a torch tensor (or None)."""
     return None if t is None else C.c_void_p(t.data_ptr())

@@ -775,16 +775,21 @@ static int place_dispatch(const RiabEnv* env, const RiabRateIO* io, const float*
 }
 
 // ---- launch of the persistent consumer (called by riab_simulate_fused, riab_simulate.hip) --------------------
+// start / stop events of the one rate_kernel_gated launch of a launch_rate_stream call (kernel-level timing through
+// hipExtLaunchKernel; per thread, set and cleared by launch_rate_stream)
+static thread_local hipEvent_t t_stream_ev0 = nullptr, t_stream_ev1 = nullptr;
+
 template <class Cell>
 static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamArgs& st, int T, bool spikes, bool plain_loads,
                               bool any_order, hipStream_t s) {
+  const hipEvent_t ev0 = t_stream_ev0, ev1 = t_stream_ev1;
   constexpr int CPB = Cell::CPB;
   const int64_t groups = (a.n + CPB - 1) / CPB;
   if (T > 65535 || groups > 65535) return RIAB_ETOOBIG;  // grid y / z limits: the caller splits longer runs
   const dim3 grid((unsigned)((a.qrow + 255) / 256), (unsigned)groups, (unsigned)T), block(256);
   const unsigned flags = any_order ? hipExtAnyOrderLaunch : 0u;
 #define RIAB_GATED(SPKV, SC1V) \
-  hipExtLaunchKernelGGL((rate_kernel_gated<Cell, SPKV, CPB, SC1V>), grid, block, 0, s, nullptr, nullptr, flags, a, cell, st)
+  hipExtLaunchKernelGGL((rate_kernel_gated<Cell, SPKV, CPB, SC1V>), grid, block, 0, s, ev0, ev1, flags, a, cell, st)
   if (spikes) {
     if (plain_loads) RIAB_GATED(1, false);
     else RIAB_GATED(1, true);
@@ -840,7 +845,11 @@ int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B) {
 
 int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t T, float dt,
                        uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, bool plain_loads,
-                       uint32_t spin_limit, bool any_order, hipStream_t s) {
+                       uint32_t spin_limit, bool any_order, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  struct EventScope {
+    EventScope(hipEvent_t a, hipEvent_t b) { t_stream_ev0 = a; t_stream_ev1 = b; }
+    ~EventScope() { t_stream_ev0 = t_stream_ev1 = nullptr; }
+  } scope(ev_start, ev_stop);
   int rc = stream_supported(env, pop, B);
   if (rc) return rc;
   if (!hist || !ctrl || !pop->rates_base || T <= 0 || pop->capacity_rows < T || agent_id0 % 4) return RIAB_EINVAL;

@@ -18,7 +18,7 @@ int launch_agent_pub(const AgentArgs& a, hipStream_t s);
 int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
 int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t T, float dt,
                        uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, bool plain_loads,
-                       uint32_t spin_limit, bool any_order, hipStream_t s);
+                       uint32_t spin_limit, bool any_order, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
 int launch_stream_gate(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj, uint32_t progress_target,
                        uint32_t spin_limit, bool sleep_long, hipStream_t s);
 int launch_rate_rows(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t t0, int32_t tc,
@@ -115,12 +115,15 @@ extern "C" int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const Ri
     rc = riab::launch_stream_gate(ctrl, h->started_total, 0, 0, 1u << 24, true, rate_s);
     if (rc) return rc;
   }
-  if (timing) (void)hipEventRecord(h->t0, rate_s);
   if (!chunks) {
+    // (timed through the launch's own start / stop events: the kernel's duration as rocprofv3 reports it, not the
+    // ~10 us between the gate's end and the kernel's start)
     rc = riab::launch_rate_stream(env, pop, hist, B, T, (float)motion->dt, seed, step0, agent_id0, ctrl, plain_loads,
-                                  spin_limit, any_order, rate_s);
+                                  spin_limit, any_order, rate_s, timing ? h->t0 : nullptr, timing ? h->t1 : nullptr);
     if (rc) return rc;
+    if (timing) h->timed = true;
   } else {
+    if (timing) (void)hipEventRecord(h->t0, rate_s);
     int32_t t0 = 0, k = 0;
     while (t0 < T) {
       // The trajectory advances ~2.3 us per step and the rate kernels need ~2.8 us per row, so a chunk may be at
@@ -138,10 +141,10 @@ extern "C" int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const Ri
       t0 += tc;
       ++k;
     }
-  }
-  if (timing) {
-    (void)hipEventRecord(h->t1, rate_s);
-    h->timed = true;
+    if (timing) {  // (the whole stage: gates and chunk kernels)
+      (void)hipEventRecord(h->t1, rate_s);
+      h->timed = true;
+    }
   }
   if (!any_order) {
     hipError_t e = hipEventRecord(h->join, h->side);
