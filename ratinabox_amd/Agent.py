@@ -437,10 +437,10 @@ class Agent:
 
     # ---- fused path, one population: flag-coupled kernels, one native call (riab_simulate_fused) ----------------
     def _fused_eligible(self, neurons):
-        """The trajectory kernel and ONE persistent rate kernel run concurrently, coupled by flags in device
-        memory (csrc/riab_simulate.hip): Philox noise, float64 motion, whole 256-agent groups, one
+        """The trajectory kernel and the rate stage run concurrently, coupled by flags in device memory
+        (csrc/riab_simulate.hip), behind ONE native call: Philox noise, float64 motion, whole 256-agent groups, one
         PlaceCells / GridCells / HeadDirectionCells population without additive noise.  Everything else goes
-        through the chunked two-stream pipeline below.  `RIAB_NO_FUSED=1` switches it off (A/B comparisons:
+        through the chunked two-stream pipeline above.  `RIAB_NO_FUSED=1` switches it off (A/B comparisons:
         the results are bit-identical)."""
         if len(neurons) != 1 or self.use_imported_trajectory or self.precision != 64 or self._Bp % 256:
             return False

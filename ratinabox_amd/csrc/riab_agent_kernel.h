@@ -230,7 +230,7 @@ struct Wall {  // staged in LDS
 // kernel (the same inlined functions on the same operands).
 //
 // PUB (with PC): the trajectory is consumed by a firing-rate kernel that runs CONCURRENTLY (riab_simulate_fused,
-// rate_stream_kernel in riab_rates.hip).  The helper wave then writes the history rows write-through (agent-scope
+// rate_kernel_gated / stream_gate_kernel in riab_rates.hip).  The helper wave then writes the history rows write-through (agent-scope
 // `sc1` stores: the consumer sits on other CUs / XCDs whose L2s are not coherent with this one), drains them
 // (`s_waitcnt vmcnt(0)`) and publishes "steps done" in ctrl[RIAB_CTRL_PROGRESS + workgroup] with one relaxed
 // agent-scope store per four-step block.  Values are bit-identical to the other variants.

@@ -774,7 +774,7 @@ static int place_dispatch(const RiabEnv* env, const RiabRateIO* io, const float*
   return launch_place<GX>(io, n, desc, c, s);
 }
 
-// ---- launch of the persistent consumer (called by riab_simulate_fused, riab_simulate.hip) --------------------
+// ---- launches of the flag-coupled rate stage (called by riab_simulate_fused, riab_simulate.hip) ----------------
 // start / stop events of the one rate_kernel_gated launch of a launch_rate_stream call (kernel-level timing through
 // hipExtLaunchKernel; per thread, set and cleared by launch_rate_stream)
 static thread_local hipEvent_t t_stream_ev0 = nullptr, t_stream_ev1 = nullptr;

@@ -1,12 +1,18 @@
-// The open-loop path as one native call: the trajectory kernel and a persistent firing-rate kernel coupled by
-// flags in device memory (include/riab_hip.h: riab_simulate_fused).  This file is host code only: the kernels live
-// in riab_agent_kernel.h (PUB variant) and riab_rates.hip (rate_stream_kernel, stream_gate_kernel).
+// The open-loop path as one native call: the trajectory kernel and the firing-rate stage run CONCURRENTLY on two
+// streams, coupled by flags in device memory (include/riab_hip.h: riab_simulate_fused).  This file is
+// host code only: the kernels live in riab_agent_kernel.h (PUB variant: rows written through + published) and
+// riab_rates.hip (rate_kernel_gated, stream_gate_kernel, rate_kernel_wide).
 //
 // Why not one launch: a launch has ONE register and LDS allocation.  The trajectory kernel needs 256 VGPRs and
 // 58 KB of LDS per 64 agents; the rate kernel needs 40 VGPRs and no LDS and lives on occupancy.  Why not launches
-// per chunk (Agent.simulate's two-stream pipeline): every chunk pays the fill of the first stage and a dependent
-// launch boundary, and a 20-step run has nothing to overlap.  With flags the rate kernel's waves start 4 steps
-// behind the trajectory and stay there.
+// per chunk behind HIP events (Agent.simulate's two-stream pipeline): every chunk pays the fill of the first stage
+// and a dependent launch boundary, and a 20-step run has nothing to overlap.  With flags the rate stage starts 4
+// steps behind the trajectory and stays there.  Up to RIAB_STREAM_POLL_MAX (256) steps the rate stage is ONE
+// ordinary (non-persistent) kernel over all rows whose waves each wait for the row they need; beyond that it is one
+// rate_kernel_wide launch per chunk of rows behind a one-wave gate kernel that waits for the chunk's last row (a
+// kernel with ten thousand waiting workgroups in front of the runnable ones starves them).  A PERSISTENT rate kernel
+// was built first (three versions) and removed: waves that stay resident hold store credits and lose 9-12 % of the
+// store bandwidth against freshly dispatched ones (tools/stream_bench.hip).
 #include <hip/hip_ext.h>
 
 #include <new>
