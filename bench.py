@@ -306,8 +306,8 @@ def main():
         t0 = time.perf_counter()
         run(K)
         torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
+        t1 = time.perf_counter()  # this rank's K steps are done; the MAX over ranks is taken per repeat below,
+        barrier()                 # so the closing barrier (an RCCL all-reduce, tens of us) stays outside the interval
         elapsed.append(t1 - t0)
         if fused_mode:
             kernel_ms.append(ag.last_rate_kernel_ms())

@@ -381,6 +381,15 @@ class Agent:
         if self._plan is not None:
             self._plan.close()  # (before any history row is reserved: a plan's pending rows are not committed yet)
         self._auto_streak = 0
+        if any(getattr(N, "_reads_agent_state", False) for N in neurons):
+            # VelocityCells / SpeedCell read the float64 velocity STATE, which no history row keeps: such a run is
+            # n_steps native plan steps (one motion launch + the rate launches per step, looped in C++)
+            if noise is not None or kwargs or self.use_imported_trajectory:
+                raise NotImplementedError("simulate() with populations that read the agent's state (VelocityCells, "
+                                          "SpeedCell) takes neither explicit noise, per-call motion kwargs nor an "
+                                          "imported trajectory: use update()")
+            return self._simulate_by_plan(int(n_steps), dt or self.dt, drift_velocity, drift_to_random_strength_ratio,
+                                          neurons)
         if noise is None and not kwargs and self._fused_eligible(neurons):
             traj = self._simulate_fused(int(n_steps), dt or self.dt, drift_velocity, drift_to_random_strength_ratio,
                                         neurons[0], chunk)
@@ -434,6 +443,19 @@ class Agent:
         for N, out in zip(neurons, outs):
             N._finish_rows(out, n_steps, self._times[-n_steps:] if self.save_history else None)
         return traj
+
+    def _simulate_by_plan(self, n_steps, dt, drift_velocity, ratio, neurons):
+        """simulate() as `n_steps` steps of a native step plan (plan.StepPlan): the same kernels, arguments and
+        counters as `n_steps` x (update(); N.update()), so bit-identical to that loop."""
+        from .plan import StepPlan
+        plan = StepPlan(self, neurons, capacity=max(1, min(n_steps, 1024)))
+        done = 0
+        while done < n_steps:
+            n = min(plan.capacity, n_steps - done)
+            plan.step(n, drift_velocity=drift_velocity, drift_to_random_strength_ratio=ratio, dt=dt)
+            done += n
+        plan.close()
+        return self._hist.stack()[len(self._hist) - n_steps:] if self.save_history else None
 
     # ---- fused path, one population: flag-coupled kernels, one native call (riab_simulate_fused) ----------------
     def _fused_eligible(self, neurons):

@@ -1102,8 +1102,8 @@ class VelocityCells(HeadDirectionCells):
     `|velocity| / one_sigma_speed`, one_sigma_speed = speed_mean + speed_std when the cells are made
     (reference Neurons.py:2534-2583).  At the agent the reference reads `Agent.velocity` (the state of
     the motion model, not the measured velocity the history keeps), which lives in the float64 agent
-    state only: `update()`, `get_state()` and step plans read it there; `Agent.simulate()` cannot
-    (its rate stage runs on the float32 history records) and raises."""
+    state only: `update()`, `get_state()` and step plans read it there; `Agent.simulate()` (whose rate
+    stage otherwise runs on the float32 history records) advances such populations through a native step plan."""
 
     _stream_kind = None  # reads the float64 velocity state, not the history rows
     _state_op = None     # (its own kernel entry: riab_velocity_cells)
@@ -1161,9 +1161,11 @@ class VelocityCells(HeadDirectionCells):
         t = self.get_state_tensor(evaluate_at, **kwargs)
         return t[:, :self._last_P].cpu().numpy().astype(np.float64)
 
+    _reads_agent_state = True  # Agent.simulate() runs such populations through a native step plan
+
     def _rates_from_trajectory(self, traj, out, t0, tc, step0, dt, stream):
-        raise NotImplementedError("VelocityCells read Agent.velocity, which the fused simulate() pipeline does not "
-                                  "keep per step; advance them with update() or a step plan")
+        raise NotImplementedError("VelocityCells read Agent.velocity, which the history rows do not keep "
+                                  "(Agent.simulate() advances them through a step plan instead)")
 
     def _call(self, io, stream):
         if getattr(self, "_as_hdc", False):

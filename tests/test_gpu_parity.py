@@ -997,7 +997,7 @@ def test_velocity_and_speed_cells_vs_reference(riab):
 def test_velocity_and_speed_cells_closed_loop(riab):
     """VelocityCells + SpeedCell feeding a FeedForwardLayer while the agents move through the maze: the
     eager loop against the oracle on each step's Agent.velocity / history["vel"][-1]; a step plan
-    reproduces the eager loop; float32 velocity rows through the C ABI; simulate() refuses VelocityCells."""
+    reproduces the eager loop; float32 velocity rows through the C ABI; simulate() runs them through a plan."""
     walls = [[[.2, 0], [.2, .4]], [[.6, 1], [.6, .5]]]
 
     def world():
@@ -1044,8 +1044,16 @@ def test_velocity_and_speed_cells_closed_loop(riab):
     for t in range(3):
         assert_rates(out[t].cpu().numpy(), orc.velocity_cells(vel[t].T.astype(np.float64), 6, VCs.one_sigma_speed,
                                                               max_fr=2.0))
+    # simulate() advances populations that read the agent's state through a native step plan: the same T steps
+    Ag, VCs, SC, FF = world()
+    traj = Ag.simulate(T)
+    assert traj.shape[0] == T and np.array_equal(np.asarray(Ag.pos), pos)
+    for i, N in enumerate((VCs, SC, FF)):
+        assert np.array_equal(np.array(N.history["firingrate"]), ref[N.name + str(i)])
+    assert np.array_equal(traj[-1, 0, :70].cpu().numpy(), pos[:, 0].astype(np.float32))
+    Ag.update()  # (and the eager path takes over again)
     with pytest.raises(NotImplementedError):
-        Ag.simulate(4)
+        Ag.simulate(4, noise=torch.zeros((4, 2, Ag._Bp), dtype=torch.float64, device="cuda"))
 
 
 def test_environment_queries_vs_reference(riab):
