@@ -137,6 +137,8 @@ __device__ __forceinline__ double r_clamp01(double l) { return fmin(fmax(l, 0.0)
 __device__ __forceinline__ float r_clamp01(float l) { return fminf(fmaxf(l, 0.0f), 1.0f); }
 __device__ __forceinline__ double r_min(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ float r_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double r_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float r_max(float a, float b) { return fmaxf(a, b); }
 
 // atan2 in fp32 for the measured rotational velocity (an output: it does not feed back into the
 // motion): Cephes-style argument reduction to [0, tan(pi/8)] and a degree-9 odd polynomial (~2 ulp),
@@ -556,6 +558,42 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
   Wall<R> w4[4];
 #pragma unroll
   for (int w = 0; w < 4; ++w) w4[w] = s_w[w < nw ? w : 0];
+  // Box fast path.  In a solid rectangular room the first four walls are the room's own edges (Environment.py:128-163)
+  // and every agent is inside them, so for those four the general point-to-segment arithmetic collapses: the nearest
+  // point of an axis-aligned edge that spans the room is the foot of the perpendicular, the distance is a coordinate
+  // difference, the unit normal is +-x or +-y, and of two opposite edges at most one is within the repel distance
+  // (room wider than twice that distance).  Same quantities as the general formulas below up to their own rounding
+  // (those carry ~1e-16 residues in the components that are exactly 0 / 1 here).  Checked once per launch, on the
+  // wall table itself; any other geometry takes the general path.
+  bool box_fast = false;
+  R bxl = 0, bxr = 0, byb = 0, byt = 0;
+  if (nw >= 4 && simple_box && !a.periodic) {
+    int nh = 0, nv = 0;
+    R xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+    bool ok = true;
+    const R tol = (R)1e-9 * ((e1 - e0) + (e3 - e2));
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const Wall<R> W = w4[w];
+      if (W.sy == (R)0 && W.sx != (R)0) {  // horizontal edge: spans [e0, e1]
+        ++nh;
+        ylo = r_min(ylo, W.ay);
+        yhi = r_max(yhi, W.ay);
+        ok = ok && r_min(W.ax, W.ax + W.sx) <= e0 + tol && r_max(W.ax, W.ax + W.sx) >= e1 - tol;
+      } else if (W.sx == (R)0 && W.sy != (R)0) {  // vertical edge: spans [e2, e3]
+        ++nv;
+        xlo = r_min(xlo, W.ax);
+        xhi = r_max(xhi, W.ax);
+        ok = ok && r_min(W.ay, W.ay + W.sy) <= e2 + tol && r_max(W.ay, W.ay + W.sy) >= e3 - tol;
+      } else {
+        ok = false;
+      }
+    }
+    ok = ok && nh == 2 && nv == 2 && xlo == e0 && xhi == e1 && ylo == e2 && yhi == e3;
+    ok = ok && (e1 - e0) > (R)2.01 * wd && (e3 - e2) > (R)2.01 * wd;
+    box_fast = __builtin_amdgcn_readfirstlane((int)ok) != 0;  // (the same value in every lane: a scalar branch)
+    bxl = xlo; bxr = xhi; byb = ylo; byt = yhi;
+  }
 
   for (int t = 0; t < a.T; ++t) {
     // ---- the step's standard normals -------------------------------------------------------
@@ -646,6 +684,7 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
     // squared distances first: the sqrt / normalisation only for walls inside the repel
     // distance, and ONE sqrt for distance_to_closest_wall (sqrt is monotone: same value)
     R x2min = INFINITY;
+    R box_tx = 0, box_ty = 0, box_nx = 0, box_ny = 0;  // box fast path: (repel distance - distance)+ and normal per axis
     uint64_t near_mask = 0;  // bit w: wall w is within the repel distance (pass 2 walks the set bits in order)
     const R wd2 = wd * wd * (R)1.000001;
     if (nw > 0) {
@@ -665,7 +704,20 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
       };
       // the first four walls (the box itself when boundaries are solid) live in registers for the
       // whole launch: no LDS round trip per step for the common open-box case
-      if (nw >= 4) {  // one uniform test instead of four (each a spilled 64-bit mask read back per step)
+      if (box_fast) {
+        // the room's own edges: distance = coordinate difference; only the nearer edge of each pair can repel
+        const R dl = px - bxl, dr = bxr - px, db = py - byb, dtp = byt - py;
+        const R dxm = r_min(dl, dr), dym = r_min(db, dtp);
+        box_tx = r_max(wd - fabs(dxm), (R)0);
+        box_ty = r_max(wd - fabs(dym), (R)0);
+        // normal = from the edge to the agent: into the room for an agent inside it (the other sign only for a
+        // position handed in from outside the room, where the general formula points outwards as well)
+        box_nx = ((dl < dr) == (dxm >= (R)0)) ? (R)1 : (R)-1;
+        box_ny = ((db < dtp) == (dym >= (R)0)) ? (R)1 : (R)-1;
+        const R dm = r_min(dxm, dym);
+        x2min = dm * dm;
+        for (int w = 4; w < nw; ++w) pass1(s_w[w], w);
+      } else if (nw >= 4) {  // one uniform test instead of four (each a spilled 64-bit mask read back per step)
 #pragma unroll
         for (int w = 0; w < 4; ++w) pass1(w4[w], w);
         for (int w = 4; w < nw; ++w) pass1(s_w[w], w);
@@ -693,6 +745,16 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
     if (nw > 0) {
       if (repel) {
         R ax_ = 0, ay_ = 0, sx_ = 0, sy_ = 0;
+        if (box_fast) {
+          // spring + conveyor of the nearer vertical and the nearer horizontal edge: exact zeros beyond the repel
+          // distance (t = 0), so the sums are the reference's sums over the four edges
+          const R spx = v0 * ((R)1 - r_sqrt((R)1 - (box_tx * box_tx) * inv_wd2));
+          const R spy = v0 * ((R)1 - r_sqrt((R)1 - (box_ty * box_ty) * inv_wd2));
+          ax_ = (kspring * box_tx) * box_nx;
+          ay_ = (kspring * box_ty) * box_ny;
+          sx_ = spx * box_nx;
+          sy_ = spy * box_ny;
+        }
         for (uint64_t rest = near_mask; rest; rest &= rest - 1) {
           const int w = __ffsll((long long)rest) - 1;
           const Wall<R> W = s_w[w];
