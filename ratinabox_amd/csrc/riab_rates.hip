@@ -783,7 +783,10 @@ template <class Cell>
 static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamArgs& st, int T, bool spikes, bool plain_loads,
                               bool any_order, hipStream_t s) {
   const hipEvent_t ev0 = t_stream_ev0, ev1 = t_stream_ev1;
-  constexpr int CPB = Cell::CPB;
+  // Twice the wide kernel's cells per wave where the group's parameters still fit one wave (PlaceCells: 8): a gated
+  // wave pays two dependent round trips to memory (progress words, then the write-through positions) before its
+  // first store, so it should bring more stores with it.  [MI355X] cfg 2: K = 20 +1.5 %, K = 128 +4 %; x4: the same.
+  constexpr int CPB = (Cell::NP * 2 * Cell::CPB <= 64) ? 2 * Cell::CPB : Cell::CPB;
   const int64_t groups = (a.n + CPB - 1) / CPB;
   if (T > 65535 || groups > 65535) return RIAB_ETOOBIG;  // grid y / z limits: the caller splits longer runs
   const dim3 grid((unsigned)((a.qrow + 255) / 256), (unsigned)groups, (unsigned)T), block(256);

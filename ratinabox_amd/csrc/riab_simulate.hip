@@ -130,14 +130,19 @@ extern "C" int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const Ri
     if (timing) h->timed = true;
   } else {
     if (timing) (void)hipEventRecord(h->t0, rate_s);
+    const bool box_room = !env->polygon && !env->hole_mask && !env->periodic && env->n_walls >= 4;
     int32_t t0 = 0, k = 0;
     while (t0 < T) {
-      // The trajectory advances ~2.3 us per step and the rate kernels need ~2.8 us per row, so a chunk may be at
-      // most ~1.25x its predecessor for its rows to be finished when the stream gets to it (a 16, 16, 32, 64, 128
-      // ramp spent 230 us of a 1024-step run inside the gates [MI355X, rocprofv3 trace]).
-      static const int32_t ramp[10] = {16, 16, 20, 24, 32, 40, 48, 64, 80, 96};
-      int32_t tc = k < 10 ? ramp[k] : 128;
-      if (tc > T - t0) tc = T - t0;
+      // A chunk should be finished by the trajectory when the stream gets to its gate.  In a solid rectangular room
+      // (the trajectory kernel's box fast path: ~1.8 us per step next to the rate kernels, which need ~2.7 us per
+      // row) the trajectory pulls away and a chunk may be ~1.5x its predecessor; in other rooms it advances ~2.8 us
+      // per step and ~1.25x is the most (a 16, 16, 32, 64, 128 ramp then spent 230 us of a 1024-step run inside the
+      // gates [MI355X, rocprofv3 trace]).  Larger chunks are cheaper per row (3.6 us at 16 rows, 2.7 at 128) and
+      // every chunk costs a gate (~5 us).
+      static const int32_t ramp_fast[5] = {16, 28, 44, 64, 96};
+      static const int32_t ramp_slow[10] = {16, 16, 20, 24, 32, 40, 48, 64, 80, 96};
+      int32_t tc = box_room ? (k < 5 ? ramp_fast[k] : 128) : (k < 10 ? ramp_slow[k] : 128);
+      if (tc > T - t0 || T - t0 - tc < 32) tc = T - t0;  // (no sliver at the end)
       // ~0.5 us per poll: seconds before a gate gives up (a healthy wait is one chunk of trajectory, < 1 ms)
       rc = riab::launch_stream_gate(ctrl, h->started_total, n_traj, (uint32_t)step0 + (uint32_t)(t0 + tc), 1u << 22, false,
                                     rate_s);
