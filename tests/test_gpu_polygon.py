@@ -84,3 +84,37 @@ def test_production_resample_is_the_oracles_philox_rejection_sampling(riab):
     assert env.positions_in_environment(ag.pos).all()
     traj = ag.get_history_tensor()[-3000:, :2].permute(0, 2, 1).reshape(-1, 2).cpu().numpy()
     assert env.positions_in_environment(traj[::37]).all()
+
+
+@pytest.mark.parametrize("case", ["open", "walls", "narrow", "thigmotaxis"])
+def test_box_fast_path_equals_general_wall_arithmetic(riab, case):
+    """The trajectory kernel's box fast path (a solid rectangular room: the four boundary edges as coordinate
+    differences, csrc/riab_agent_kernel.h) against the general point-to-segment arithmetic: the SAME room handed over
+    as a polygonal boundary has the same wall table but takes the general path.  Agents that never needed the
+    boundary safety net (clamp in the box, re-sampling in the polygon) must agree to rounding."""
+    scale, aspect = (0.19, 1.0) if case == "narrow" else (0.8, 1.5)
+    walls = [[[0.5, 0.0], [0.5, 0.45]], [[0.9, 0.8], [0.9, 0.4]]] if case == "walls" else []
+    corners = [[0, 0], [aspect * scale, 0], [aspect * scale, scale], [0, scale]]
+    box = riab.Environment({"scale": scale, "aspect": aspect, "walls": walls})
+    poly = riab.Environment({"boundary": corners, "walls": walls})
+    assert np.array_equal(box.walls, poly.walls) and box.is_rectangular and not poly.is_rectangular
+    params = {"n_agents": 512, "dt": 0.02, "seed": 7, "agent_id0": 0}
+    if case == "thigmotaxis":
+        params.update(thigmotaxis=0.95, wall_repel_distance=0.2, wall_repel_strength=2.0, speed_mean=0.2)
+    np.random.seed(3)
+    a = riab.Agent(box, dict(params))
+    b = riab.Agent(poly, dict(params))
+    b.state_tensor.copy_(a.state_tensor)
+    T = 600
+    ta = a.simulate(T, neurons=[])
+    tb = b.simulate(T, neurons=[])
+    torch.cuda.synchronize()
+    sa, sb = a.state_tensor.cpu().numpy()[:, :512], b.state_tensor.cpu().numpy()[:, :512]
+    # lanes whose two runs stayed on the common code path: no boundary-condition event in either
+    moved = (ta[:, :2, :512] - tb[:, :2, :512]).abs().amax(dim=(0, 1)).cpu().numpy()
+    same = moved < 1e-3
+    assert same.mean() > 0.97, same.mean()   # (an escape through a corner is rare; those lanes diverge by design)
+    np.testing.assert_allclose(sa[:, same], sb[:, same], rtol=0, atol=2e-9)
+    assert a.diagnostics["bounce_saturations"] == 0
+    if case == "narrow":   # narrower than twice the repel distance: the box itself takes the general path, bit for bit
+        assert np.array_equal(sa[:, same], sb[:, same])
