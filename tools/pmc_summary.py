@@ -3,8 +3,10 @@
 /opt/skills/guides/MI355X_MICROARCH.md prescribes) -> profiles/pmc_traffic_<cfg>.json, which bench.py reads for
 `roofline.traffic`.
 
-    python tools/pmc_summary.py gpurun_out/r02_driver_pmc_WRITE_SIZE.csv gpurun_out/r02_driver_pmc_FETCH_SIZE.csv \
+    python tools/pmc_summary.py profiles/r02_driver_pmc_WRITE_SIZE.csv profiles/r02_driver_pmc_FETCH_SIZE.csv \
         --kernel rate_kernel_gated --units-per-launch 81920 --out profiles/pmc_traffic_cfg2.json
+    python tools/pmc_summary.py profiles/r02_default_pmc_WRITE_SIZE.csv profiles/r02_default_pmc_FETCH_SIZE.csv \
+        --kernel rate_kernel_wide --units-per-thread 0.015625 --out profiles/r02_pmc_traffic_cfg2_default_run.json
 
 Corrections (the guide's HBM section): FETCH_SIZE on gfx950 tallies 128-B read requests at 64 B -> doubled;
 WRITE_SIZE is calibrated in the same pass on riab::fill_kernel dispatches of a known size (bench.py's store-ceiling
@@ -28,7 +30,10 @@ def main():
     ap.add_argument("write_csv")
     ap.add_argument("fetch_csv")
     ap.add_argument("--kernel", required=True)
-    ap.add_argument("--units-per-launch", type=int, required=True)
+    ap.add_argument("--units-per-launch", type=int, default=0)
+    ap.add_argument("--units-per-thread", type=float, default=0.0,
+                    help="agent-steps per thread of the grid (rate_kernel_wide at n cells: 16 / n; rate_kernel_gated with "
+                         "8 cells per wave: 32 / n): launches of different sizes are then summed, bytes / units")
     ap.add_argument("--alg-bytes-kernel", type=int, default=4104)
     ap.add_argument("--alg-bytes-survey", type=int, default=4208)
     ap.add_argument("--source", default="")
@@ -43,6 +48,14 @@ def main():
         return sum(vals) / len(vals), len(vals), gmax
     w_kib, n_w, grid = per_launch(w)
     f_kib, n_f, _ = per_launch(f)
+    if a.units_per_thread > 0:   # every launch of the kernel: totals
+        mw = [(g, v) for k, g, v in w if a.kernel in k]
+        mf = [(g, v) for k, g, v in f if a.kernel in k]
+        assert [g for g, _ in mw] == [g for g, _ in mf], "the two passes must have seen the same launches"
+        n_w = n_f = len(mw)
+        w_kib, f_kib = sum(v for _, v in mw) / n_w, sum(v for _, v in mf) / n_f
+        grid = sum(g for g, _ in mw) / n_w
+        a.units_per_launch = grid * a.units_per_thread
     fills = [v for k, g, v in w if "fill_kernel" in k]
     calib = (sum(fills) / len(fills)) / (1 << 20) if fills else None   # reported KiB / true KiB (1 GiB = 2^20 KiB)
     w_true = w_kib / calib if calib else w_kib
