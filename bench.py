@@ -404,7 +404,7 @@ def main():
     if rank == 0:
         api = ("TaskEnvironment step plan: action, Agent.update, rewards/goals, auto-reset, rates; one native call per step"
                if args.task else "step plan (one native call per step)" if args.plan else "per-step update()"
-               if args.per_step else "simulate(): trajectory kernel + persistent rate kernel coupled by flags, one native call"
+               if args.per_step else "simulate(): trajectory kernel + rate stage running concurrently, coupled by flags in device memory, one native call"
                if fused_mode else f"simulate(): chunked two-stream pipeline, {args.chunk} steps/launch")
         out = {
             "metric": metric_name(cfg),
