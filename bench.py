@@ -230,7 +230,11 @@ def main():
 
     plan = {"p": None}
     fused_mode = not (args.per_step or args.plan) and ag._fused_eligible(pops)
-    ag._time_rate_kernel = fused_mode
+    # several populations: the same pipeline through riab_simulate_pops (every chunk of rows behind a gate, one native
+    # call per timed region); the events then bracket every launch of the DOMINANT population's kernel
+    native_mode = (not (args.per_step or args.plan) and not fused_mode and not args.no_history
+                   and os.environ.get("RIAB_NO_NATIVE") != "1" and ag.precision == 64 and ag._Bp % 64 == 0)
+    ag._time_rate_kernel = fused_mode or native_mode
 
     def run(n_steps):
         if args.plan:
@@ -294,7 +298,8 @@ def main():
         else:
             spans[-1][1] = ev
 
-    if not (args.per_step or args.plan or fused_mode):
+    ag._timed_population = dominant
+    if not (args.per_step or args.plan or fused_mode or native_mode):
         ag._profile_hook = hook
 
     elapsed, kernel_ms = [], []
@@ -309,7 +314,7 @@ def main():
         t1 = time.perf_counter()  # this rank's K steps are done; the MAX over ranks is taken per repeat below,
         barrier()                 # so the closing barrier (an RCCL all-reduce, tens of us) stays outside the interval
         elapsed.append(t1 - t0)
-        if fused_mode:
+        if fused_mode or native_mode:
             kernel_ms.append(ag.last_rate_kernel_ms())
     el = torch.tensor(elapsed, dtype=torch.float64)
     if dist is not None:
@@ -332,7 +337,7 @@ def main():
     unit_bytes = 4 * n0 + (n0 if cfg["spikes"] else 0) + 112
     own_bytes = 4 * n0 + (n0 if cfg["spikes"] else 0) + 8
     ms, units = [], []
-    if fused_mode:
+    if fused_mode or native_mode:
         ms = [m for m in kernel_ms if m is not None]
         units = [B * K] * len(ms)
     elif spans:
@@ -350,6 +355,8 @@ def main():
         poll_max = int(os.environ.get("RIAB_STREAM_POLL_MAX", 256))
         kname = (("rate_kernel_gated" if K <= poll_max else "rate stage = rate_kernel_wide per chunk behind progress gates")
                  if fused_mode else "rate_kernel_wide") + f"<{type(dominant).__name__}>"
+        if native_mode:
+            kname = f"every launch of {type(dominant).__name__}'s kernel in one riab_simulate_pops call (chunks of rows behind gates)"
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": kname, "launches": len(ms),
@@ -372,6 +379,10 @@ def main():
                         "peak_is": "v_mul_f32 + v_exp_f32 issue ceiling measured with tools/exp_bench.hip on MI355X "
                                    "(DESIGN.md 3.2); one term = one fused exponent exp2(-(a d - a mu)^2 + T[c][k])",
                         "hbm_GBps_of_this_kernel": round(achieved, 1), "hbm_frac_of_this_kernel": round(achieved / HBM_PEAK_GBS, 4)}
+        if native_mode:
+            roofline["note"] = ("`avg_launch_ms` is the SUM of the kernel's launches of one timed region (HIP events around each "
+                                "launch on the stream it runs on, riab_streamer_last_rate_ms), `units_per_launch` the agent-"
+                                "steps of the region; rocprofv3's per-launch average x launches per region is the same sum")
         if fused_mode:
             roofline["note"] = ("the rate stage runs concurrently with the trajectory kernel whose rows it consumes (coupled "
                                 "by flags in device memory, one native call per timed region): its duration includes "
@@ -405,7 +416,9 @@ def main():
         api = ("TaskEnvironment step plan: action, Agent.update, rewards/goals, auto-reset, rates; one native call per step"
                if args.task else "step plan (one native call per step)" if args.plan else "per-step update()"
                if args.per_step else "simulate(): trajectory kernel + rate stage running concurrently, coupled by flags in device memory, one native call"
-               if fused_mode else f"simulate(): chunked two-stream pipeline, {args.chunk} steps/launch")
+               if fused_mode else "simulate(): trajectory kernel + every population's kernels per chunk of rows behind gates, "
+               "one native call (riab_simulate_pops)" if native_mode
+               else f"simulate(): chunked two-stream pipeline, {args.chunk} steps/launch")
         out = {
             "metric": metric_name(cfg),
             "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,

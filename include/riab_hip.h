@@ -590,6 +590,19 @@ int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const RiabMotion* m
                         int64_t agent_id0, const double* drift, uint64_t seed, uint64_t step0, int32_t T,
                         float* hist, int32_t* diag, const struct RiabPopulation* pop, uint32_t* ctrl,
                         int32_t wgs_per_cu, int32_t mode, int32_t timing, riab_stream_t stream);
+/* The same pipeline for ANY ordered set of populations (n_pops structs, contiguous; a FeedForwardLayer's
+ * input_index refers to EARLIER entries of this array): T x (Agent.update(); N.update() for N in pops) — the loop of
+ * demos/simple_example.ipynb cell 4 with several populations — as one call.  The trajectory kernel publishes its rows
+ * as in riab_simulate_fused; on the streamer's second stream every chunk of rows (16, 28, 44, ... 128) waits behind a
+ * one-wave gate and is then consumed by each population's ordinary kernel in array order (noise pass and spikes
+ * after it, as in riab_plan_step).  Every population needs rows for the whole run (capacity_rows >= T; rates_base /
+ * spikes_base = row 0 of this call).  Velocity cells (they read the float64 state) are not covered: RIAB_EUNSUPPORTED,
+ * nothing launched.  timed_pop >= 0: HIP events around every launch of that population; their sum is what
+ * riab_streamer_last_rate_ms returns afterwards.  B a multiple of 64. */
+int riab_simulate_pops(RiabStreamer* h, const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
+                       int64_t agent_id0, const double* drift, uint64_t seed, uint64_t step0, int32_t T, float* hist,
+                       int32_t* diag, const struct RiabPopulation* pops, int32_t n_pops, uint32_t* ctrl,
+                       int32_t timed_pop, riab_stream_t stream);
 /* with `timing` != 0 in the last riab_simulate_fused call: the duration of its rate kernel in ms (HIP events
  * on the stream the kernel ran on), after the caller has synchronised; < 0 if unavailable */
 float riab_streamer_last_rate_ms(RiabStreamer* h);

@@ -96,6 +96,7 @@ class Agent:
         self._auto_enabled = os.environ.get("RIAB_NO_AUTO_PLAN") != "1"
         self._streamer = None   # native handle of the flag-coupled pipeline (created on first use)
         self._ctrl = None       # its control words on the device
+        self._pipeline_unchecked = False
         self._time_rate_kernel = False
 
         self._state = torch.zeros((_L.STATE_ROWS, self._Bp), dtype=torch.float64, device=self._device)
@@ -155,7 +156,23 @@ class Agent:
     def _squeeze(self, a):
         return a[0] if self._B == 1 else a
 
+    def _check_pipeline(self):
+        """After a fused simulate(): a wait of the flag-coupled pipeline that gave up (bounded spins: a stuck or
+        starved producer) leaves rows unwritten.  Checked on the first host read that follows — which synchronises
+        anyway — and reported as an error; the control words are cleared so that the next run starts clean."""
+        if not self._pipeline_unchecked:
+            return
+        self._pipeline_unchecked = False
+        w = self._ctrl[:4].cpu()
+        if int(w[_L.CTRL_TIMEOUTS]) or int(w[_L.CTRL_ABORT]):
+            n = int(w[_L.CTRL_TIMEOUTS])
+            self._ctrl[_L.CTRL_TIMEOUTS] = 0
+            self._ctrl[_L.CTRL_ABORT] = 0
+            raise _L.RiabError(f"the flag-coupled simulate() pipeline was aborted ({n} waits timed out): the rows of "
+                               f"that run are incomplete (RIAB_NO_FUSED=1 selects the chunked pipeline)")
+
     def _download(self, row, width):
+        self._check_pipeline()
         a = self._state[row:row + width, :self._B].t().contiguous().cpu().numpy()
         return self._squeeze(a if width > 1 else a[:, 0])
 
@@ -395,6 +412,10 @@ class Agent:
                                         neurons[0], chunk)
             if traj is not None:
                 return traj
+        if noise is None and not kwargs:
+            traj = self._simulate_native(int(n_steps), dt or self.dt, drift_velocity, drift_to_random_strength_ratio, neurons)
+            if traj is not None:
+                return traj
         if self._streams is None:
             self._streams = self._make_streams()
         s_traj, s_rate = self._streams
@@ -532,6 +553,7 @@ class Agent:
             _L.check(rc, "riab_simulate_fused")
             t0 += tc
         # ---- the kernels are running: now the views and the Python-side mirrors
+        self._pipeline_unchecked = True
         traj = traj_c[traj_s:traj_s + n_steps]
         self.dt = dt
         self._keep = (drift, _walls, traj_c, fr_c, sp_c, pop)
@@ -552,6 +574,75 @@ class Agent:
             N._times.extend(times)
         else:
             N._rates = fr_c[(n_steps - 1) % piece]
+        return traj
+
+    # ---- any set of populations, one native call (riab_simulate_pops) ---------------------------------------------
+    def _simulate_native(self, n_steps, dt, drift_velocity, ratio, neurons):
+        """The flag-coupled pipeline for an ordered set of populations: the trajectory kernel publishes its rows,
+        every chunk of rows is consumed behind a gate by each population's ordinary kernel — the launch loop of the
+        chunked path below, moved into C++ (csrc/riab_simulate.hip).  Bit-identical to it.  None (nothing reserved,
+        nothing launched) when the set is not covered: rates not saved (rings), populations that cannot be recorded
+        (AgentVectorCells, recurrent FeedForwardLayers), float32 motion, imported trajectories; `RIAB_NO_NATIVE=1`
+        switches it off."""
+        if not neurons or len(neurons) > 16 or self.use_imported_trajectory or self.precision != 64 or self._Bp % 64 \
+                or not self.save_history or _L.env("RIAB_NO_NATIVE") == "1" or n_steps <= 0:
+            return None
+        if any((not N.save_history) or N.Agent is not self for N in neurons):
+            return None
+        self.dt = dt  # (the populations' OU-noise constants are those of this dt, as in update(dt=...))
+        index, structs = {}, []
+        try:
+            for N in neurons:
+                structs.append(N._population(index))
+                index[N] = len(index)
+        except NotImplementedError:
+            return None
+        if self._streamer is None:
+            h = _L.lib.riab_streamer_create()
+            if not h:
+                raise _L.RiabError("riab_streamer_create failed")
+            self._streamer = _L.C.c_void_p(h)
+            self._ctrl = torch.zeros(_L.ctrl_words(self._Bp), dtype=torch.int32, device=self._device)
+        has_drift = drift_velocity is not None
+        m = self._motion(dt, has_drift, ratio, {})
+        env, _walls = self.Environment.device_tables(self._device)
+        drift = self._as_device_f64(drift_velocity, 2) if has_drift else None
+        Bp = self._Bp
+        traj = self._hist.reserve(n_steps)
+        outs = [N._reserve_rows(n_steps, ring=n_steps) for N in neurons]
+        arr = (_L.RiabPopulation * len(neurons))()
+        for i, (pop, out) in enumerate(zip(structs, outs)):
+            _L.C.memmove(_L.C.byref(arr, i * _L.C.sizeof(_L.RiabPopulation)), _L.C.byref(pop), _L.C.sizeof(_L.RiabPopulation))
+            arr[i].rates_base = out["fr"].data_ptr()
+            arr[i].spikes_base = out["sp"].data_ptr() if out["sp"] is not None else None
+            arr[i].capacity_rows = n_steps
+        timed = -1
+        if self._time_rate_kernel:
+            tp = getattr(self, "_timed_population", None)
+            timed = neurons.index(tp) if tp in neurons else 0
+        rc = _L.lib.riab_simulate_pops(self._streamer, env, m, self._state.data_ptr(), Bp, int(self.agent_id0), _L.ptr(drift),
+                                       int(self.rng_seed), int(self._step_index), n_steps, traj.data_ptr(), self._diag.data_ptr(),
+                                       _L.C.addressof(arr), len(neurons), self._ctrl.data_ptr(), timed, _L.current_stream())
+        if rc == _L.EUNSUPPORTED:
+            self._hist.unreserve(n_steps)
+            for N, out in zip(neurons, outs):
+                N._unreserve_rows(out, n_steps)
+            return None
+        _L.check(rc, "riab_simulate_pops")
+        self._pipeline_unchecked = True
+        self._keep = (drift, _walls, arr, structs, outs)
+        self._last_row = traj[n_steps - 1]
+        self._last_fused_units = Bp * n_steps
+        t, times = self.t, []
+        for _ in range(n_steps):
+            self.prev_t = t
+            t += dt
+            times.append(t)
+        self.t = t
+        self._times.extend(times)
+        self._step_index += n_steps
+        for N, out in zip(neurons, outs):
+            N._finish_rows(out, n_steps, times)
         return traj
 
     def last_rate_kernel_ms(self):
@@ -617,6 +708,7 @@ class Agent:
 
     def _materialise_history(self):
         self._sync_plan()
+        self._check_pipeline()
         h = self._hist.stack()[:, :, :self._B].cpu().numpy()  # (T, 8, B)
         sq = (lambda a: a[:, 0]) if self._B == 1 else (lambda a: a)
         pair = lambda i: sq(np.stack((h[:, i], h[:, i + 1]), axis=-1))  # noqa: E731

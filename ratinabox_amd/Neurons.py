@@ -174,6 +174,7 @@ class Neurons:
     @property
     def firingrate(self):
         self.Agent._sync_plan()
+        self.Agent._check_pipeline()
         a = self._rates[:, :self._B].cpu().numpy().astype(np.float64)
         return a[:, 0] if self._B == 1 else a
 
@@ -425,6 +426,7 @@ class Neurons:
     # ---- history ---------------------------------------------------------------------------------
     def _materialise_history(self):
         self.Agent._sync_plan()
+        self.Agent._check_pipeline()
         fr = self._hist_fr.stack()[:, :, :self._B].cpu().numpy()
         sp = self._hist_sp.stack()[:, :, :self._B].cpu().numpy().astype(bool)
         if len(sp) == 0:

@@ -167,6 +167,9 @@ PROTOTYPES = {
                                       C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.POINTER(RiabPopulation), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "riab_streamer_last_rate_ms": (C.c_float, [C.c_void_p]),
+    "riab_simulate_pops": (C.c_int, [C.c_void_p, C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
+                                     C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "riab_abi_sizeof": (C.c_int64, [C.c_int32]),
     "riab_abi_version": (C.c_int, []),
     "riab_strerror": (C.c_char_p, [C.c_int]),

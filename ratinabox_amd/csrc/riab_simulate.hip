@@ -16,6 +16,7 @@
 #include <hip/hip_ext.h>
 
 #include <new>
+#include <vector>
 
 #include "riab_agent_kernel.h"
 
@@ -35,6 +36,8 @@ struct RiabStreamer {
   hipStream_t side;          // the rate kernel's stream (mode 0)
   hipEvent_t join;           // side -> main
   hipEvent_t t0, t1;         // timing of the rate kernel (created on first use)
+  std::vector<hipEvent_t> pairs;  // riab_simulate_pops: (start, stop) around every launch of the timed population
+  int n_pairs;               // pairs recorded by the last call (0: t0 / t1 hold the measurement)
   bool timed;
   uint32_t started_total;    // trajectory workgroups launched so far through this object (wraps like the device word)
   int cus;                   // compute units of the device the object was created on
@@ -46,6 +49,7 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
   h->side = nullptr;
   h->join = h->t0 = h->t1 = nullptr;
   h->timed = false;
+  h->n_pairs = 0;
   h->started_total = 0;
   int dev = 0;
   hipDeviceProp_t prop;
@@ -63,6 +67,7 @@ extern "C" void riab_streamer_destroy(RiabStreamer* h) {
   if (!h) return;
   if (h->t0) (void)hipEventDestroy(h->t0);
   if (h->t1) (void)hipEventDestroy(h->t1);
+  for (hipEvent_t e : h->pairs) (void)hipEventDestroy(e);
   if (h->join) (void)hipEventDestroy(h->join);
   if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
@@ -71,6 +76,14 @@ extern "C" void riab_streamer_destroy(RiabStreamer* h) {
 extern "C" float riab_streamer_last_rate_ms(RiabStreamer* h) {
   if (!h || !h->timed) return -1.0f;
   float ms = -1.0f;
+  if (h->n_pairs > 0) {  // the sum over the timed population's launches of the last riab_simulate_pops call
+    float total = 0.0f;
+    for (int i = 0; i < h->n_pairs; ++i) {
+      if (hipEventElapsedTime(&ms, h->pairs[2 * i], h->pairs[2 * i + 1]) != hipSuccess) return -1.0f;
+      total += ms;
+    }
+    return total;
+  }
   if (hipEventElapsedTime(&ms, h->t0, h->t1) != hipSuccess) return -1.0f;
   return ms;
 }
@@ -99,6 +112,7 @@ extern "C" int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const Ri
     if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess) return RIAB_EINVAL;
   }
   h->timed = false;
+  h->n_pairs = 0;
   // The trajectory kernel goes first, with no host work in front of it.  The side stream needs no event to order
   // it behind what is queued on `stream`: its first kernel is the gate, which returns only once every trajectory
   // workgroup of THIS launch is resident — and the trajectory kernel starts after everything queued before it.
@@ -162,6 +176,159 @@ extern "C" int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const Ri
     if (e == hipSuccess) e = hipStreamWaitEvent(main_s, h->join, 0);
     if (e != hipSuccess) return (int)e;
   }
+  return RIAB_OK;
+}
+
+
+// ---- any set of populations: the chunked form of the rate stage for all of them, one native call ----------------
+// rows [t0, t0 + tc) of population i from the trajectory rows of the same chunk (the T-row form of riab_plan.hip's
+// launch_population: same entry points, same arguments as `tc` calls of Neurons.update on successive rows)
+static int launch_pop_rows(const RiabEnv* env, const RiabPopulation* pops, int i, const float* hist, int64_t B, int32_t t0,
+                           int32_t tc, float dt, uint64_t seed, uint64_t step0, int64_t agent_id0, hipStream_t s) {
+  const RiabPopulation& q = pops[i];
+  RiabRateIO io = q.io;
+  const float* row = hist + (int64_t)t0 * RIAB_HIST_ROWS * B;
+  io.pos_x = row + (int64_t)RIAB_H_POS_X * B;
+  io.pos_y = row + (int64_t)RIAB_H_POS_Y * B;
+  io.hd_x = row + (int64_t)RIAB_H_HD_X * B;
+  io.hd_y = row + (int64_t)RIAB_H_HD_Y * B;
+  io.pos_ld = (int64_t)RIAB_HIST_ROWS * B;
+  io.T = tc;
+  io.B = B;
+  io.rates = q.rates_base + (int64_t)t0 * q.n * B;
+  io.spikes = q.spikes_base ? q.spikes_base + (int64_t)t0 * q.n * B : nullptr;
+  io.u_in = nullptr;
+  io.dt = dt;
+  io.seed = seed;
+  io.step0 = step0 + 1 + (uint64_t)t0;  // Neurons.update after the (step0 + t + 1)-th Agent.update
+  io.agent_id0 = agent_id0;
+  const bool noisy = q.noise_state != nullptr;
+  uint8_t* const spikes = io.spikes;
+  if (noisy) io.spikes = nullptr;  // spikes are drawn on the final rates, after the noise pass
+  int rc = RIAB_EUNSUPPORTED;
+  switch (q.kind) {
+    case RIAB_POP_PLACE:
+      rc = riab_place_cells(env, &io, q.table, q.n, q.description, q.geometry, q.top_hat_width, s);
+      break;
+    case RIAB_POP_GRID: rc = riab_grid_cells(&io, q.table, q.n, q.description, q.f0, s); break;
+    case RIAB_POP_HDC: rc = riab_head_direction_cells(&io, q.table, q.n, s); break;
+    case RIAB_POP_SPEED:  // history["vel"]: the measured velocity rows
+      io.hd_x = row + (int64_t)RIAB_H_VEL_X * B;
+      io.hd_y = row + (int64_t)RIAB_H_VEL_Y * B;
+      rc = riab_speed_cell(&io, q.one_sigma_speed, s);
+      break;
+    case RIAB_POP_RANDOM_SPATIAL:
+      rc = riab_random_spatial_neurons(env, &io, q.table, q.n_anchors, q.targets, q.n, q.geometry, s);
+      break;
+    case RIAB_POP_BVC:
+      rc = riab_boundary_vector_cells_windowed(env, &io, q.test_dirs, q.ray_rden, q.K, q.table, q.vm_table, q.inv_norm, q.n,
+                                               q.egocentric, nullptr, q.cell_rows, q.windows, s);
+      break;
+    case RIAB_POP_OVC:
+      rc = riab_object_vector_cells(env, &io, q.objects, q.object_types, q.n_objects, q.table, q.n, q.walls_occlude,
+                                    q.egocentric, s);
+      break;
+    case RIAB_POP_FF: {
+      RiabFFInput in[RIAB_FF_MAX_INPUTS];
+      for (int l = 0; l < q.n_inputs; ++l) {
+        const RiabPopulation& src = pops[q.input_index[l]];  // (an earlier population: its rows of this chunk exist)
+        in[l].rates = src.rates_base + (int64_t)t0 * src.n * B;
+        in[l].wt = q.input_wt[l];
+        in[l].n_in = src.n;
+      }
+      rc = riab_feedforward(in, q.n_inputs, q.bias, q.n, tc, B, q.activation, q.act_params, io.rates, nullptr, s);
+      if (rc == RIAB_OK && io.spikes) rc = riab_spikes(&io, q.n, s);
+      break;
+    }
+    default: break;  // (velocity cells read the float64 state: they advance through a step plan)
+  }
+  if (rc) return rc;
+  if (noisy) {
+    rc = riab_neuron_noise(q.noise_state, io.rates, nullptr, q.n, B, tc, q.noise_theta_dt, q.noise_sigma_dt, seed,
+                           step0 + 1 + (uint64_t)t0, q.io.pop_id, agent_id0, s);
+    if (rc) return rc;
+    if (spikes) {
+      io.spikes = spikes;
+      rc = riab_spikes(&io, q.n, s);
+    }
+  }
+  return rc;
+}
+
+extern "C" int riab_simulate_pops(RiabStreamer* h, const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
+                                  int64_t agent_id0, const double* drift, uint64_t seed, uint64_t step0, int32_t T,
+                                  float* hist, int32_t* diag, const RiabPopulation* pops, int32_t n_pops, uint32_t* ctrl,
+                                  int32_t timed_pop, riab_stream_t stream) {
+  if (!h || !env || !pops || !ctrl || !hist || n_pops <= 0 || T <= 0) return RIAB_EINVAL;
+  if (B <= 0 || B % 64 != 0) return RIAB_EUNSUPPORTED;  // (the publishing trajectory kernel runs whole waves)
+  for (int i = 0; i < n_pops; ++i) {
+    const RiabPopulation& q = pops[i];
+    if (q.n <= 0 || !q.rates_base || q.capacity_rows < T) return RIAB_EINVAL;
+    switch (q.kind) {
+      case RIAB_POP_PLACE: case RIAB_POP_GRID: case RIAB_POP_HDC: case RIAB_POP_SPEED: case RIAB_POP_RANDOM_SPATIAL:
+      case RIAB_POP_BVC: case RIAB_POP_OVC: break;
+      case RIAB_POP_FF:
+        if (q.n_inputs <= 0 || q.n_inputs > RIAB_FF_MAX_INPUTS) return RIAB_EINVAL;
+        for (int l = 0; l < q.n_inputs; ++l)
+          if (q.input_index[l] < 0 || q.input_index[l] >= i || pops[q.input_index[l]].capacity_rows < T) return RIAB_EINVAL;
+        break;
+      default: return RIAB_EUNSUPPORTED;
+    }
+  }
+  riab::AgentArgs a;
+  int rc = riab::fill_agent_args(a, env, motion, state, B, agent_id0, drift, nullptr, nullptr, nullptr, seed, step0, T, hist,
+                                 diag, 64);
+  if (rc) return rc;
+  a.ctrl = ctrl;
+  hipStream_t main_s = (hipStream_t)stream, rate_s = h->side;
+  // chunk schedule of riab_simulate_fused's long runs (the trajectory is the faster stage here too: every population
+  // kernel of a chunk runs before the next chunk's gate is looked at)
+  const bool box_room = !env->polygon && !env->hole_mask && !env->periodic && env->n_walls >= 4;
+  static const int32_t ramp_fast[5] = {16, 28, 44, 64, 96};
+  static const int32_t ramp_slow[10] = {16, 16, 20, 24, 32, 40, 48, 64, 80, 96};
+  std::vector<int32_t> sched;
+  for (int32_t t0 = 0, k = 0; t0 < T; ++k) {
+    int32_t tc = box_room ? (k < 5 ? ramp_fast[k] : 128) : (k < 10 ? ramp_slow[k] : 128);
+    if (tc > T - t0 || T - t0 - tc < 32) tc = T - t0;
+    sched.push_back(tc);
+    t0 += tc;
+  }
+  const bool timing = timed_pop >= 0 && timed_pop < n_pops;
+  if (timing) {
+    while (h->pairs.size() < 2 * sched.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return RIAB_EINVAL;
+      h->pairs.push_back(e);
+    }
+  }
+  h->timed = false;
+  h->n_pairs = 0;
+  rc = riab::launch_agent_pub(a, main_s);
+  if (rc) return rc;
+  const uint32_t n_traj = (uint32_t)(B / 64);
+  h->started_total += n_traj;
+  rc = riab::launch_stream_gate(ctrl, h->started_total, 0, 0, 1u << 24, true, rate_s);
+  if (rc) return rc;
+  int32_t t0 = 0;
+  for (size_t k = 0; k < sched.size(); ++k) {
+    const int32_t tc = sched[k];
+    rc = riab::launch_stream_gate(ctrl, h->started_total, n_traj, (uint32_t)step0 + (uint32_t)(t0 + tc), 1u << 22, false, rate_s);
+    if (rc) return rc;
+    for (int i = 0; i < n_pops; ++i) {
+      if (timing && i == timed_pop) (void)hipEventRecord(h->pairs[2 * k], rate_s);
+      rc = launch_pop_rows(env, pops, i, hist, B, t0, tc, (float)motion->dt, seed, step0, agent_id0, rate_s);
+      if (rc) return rc;
+      if (timing && i == timed_pop) (void)hipEventRecord(h->pairs[2 * k + 1], rate_s);
+    }
+    t0 += tc;
+  }
+  if (timing) {
+    h->n_pairs = (int)sched.size();
+    h->timed = true;
+  }
+  hipError_t e = hipEventRecord(h->join, h->side);
+  if (e == hipSuccess) e = hipStreamWaitEvent(main_s, h->join, 0);
+  if (e != hipSuccess) return (int)e;
   return RIAB_OK;
 }
 

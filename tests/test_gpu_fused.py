@@ -38,6 +38,7 @@ def _world(riab, B, make_pop, env_params=None, seed=7, agent_params=None):
 def _run(riab, fused, B, make_pop, schedule, env_params=None, drift=None, agent_params=None):
     """schedule: list of ("sim", T) / ("step", k) entries.  Returns (trajectory, rates, spikes, agent)."""
     os.environ["RIAB_NO_FUSED"] = "0" if fused else "1"
+    os.environ["RIAB_NO_NATIVE"] = "0" if fused else "1"   # (the reference is the Python-driven chunked pipeline)
     try:
         env, ag, pop = _world(riab, B, make_pop, env_params, agent_params=agent_params)
         for what, n in schedule:
@@ -53,6 +54,7 @@ def _run(riab, fused, B, make_pop, schedule, env_params=None, drift=None, agent_
         return traj, fr.cpu().numpy(), sp.cpu().numpy(), ag
     finally:
         os.environ.pop("RIAB_NO_FUSED", None)
+        os.environ.pop("RIAB_NO_NATIVE", None)
 
 
 def _pc(n, **kw):
@@ -169,6 +171,24 @@ def test_fused_launch_modes(riab, mode):
     t_b, fr_b, _sp, _ag = _run(riab, False, 1024, _pc(256, save_spikes=False), [("sim", 48), ("sim", 16)])
     np.testing.assert_array_equal(t_a, t_b)
     np.testing.assert_array_equal(fr_a, fr_b)
+
+
+def test_aborted_pipeline_is_reported_on_the_next_host_read(riab):
+    """A wait that gave up (here: the abort / timeout words set by hand) must not pass silently: the first host read
+    after the run raises, the control words are cleared and the next run is clean."""
+    env, ag, pop = _world(riab, 1024, _pc(64, save_spikes=False), None)
+    ag.simulate(8)
+    _ = ag.pos                                   # a clean run: reading is fine
+    ag.simulate(8)
+    L = riab._lib
+    ag._ctrl[L.CTRL_TIMEOUTS] = 3
+    ag._ctrl[L.CTRL_ABORT] = 1
+    with pytest.raises(L.RiabError, match="aborted"):
+        _ = ag.history["pos"]
+    assert ag.diagnostics["pipeline_timeouts"] == 0
+    ag.simulate(8)
+    assert np.isfinite(np.asarray(ag.pos)).all() and np.isfinite(pop.firingrate).all()
+    assert len(ag.history["t"]) == 24
 
 
 def test_fused_falls_back_for_uncovered_populations(riab):
@@ -322,3 +342,63 @@ def test_unchanged_reference_loop_is_served_natively_and_bit_identical(riab, scr
             assert a[k] == b[k], k
         else:
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+# ----------------------------------------------------------------------------- several populations, one native call
+def _multi_world(riab, B, seed=5):
+    np.random.seed(seed)
+    env = riab.Environment({"walls": [[[0.5, 0.0], [0.5, 0.35]], [[0.2, 0.7], [0.6, 0.7]]]})
+    env.add_object([0.3, 0.3], type=0)
+    env.add_object([0.8, 0.6], type=1)
+    ag = riab.Agent(env, {"n_agents": B, "dt": 0.02, "seed": 4})
+    np.random.seed(seed + 1)
+    pops = [riab.PlaceCells(ag, {"n": 40, "wall_geometry": "line_of_sight", "save_spikes": True}),
+            riab.BoundaryVectorCells(ag, {"n": 12}),
+            riab.HeadDirectionCells(ag, {"n": 8}),
+            riab.GridCells(ag, {"n": 16, "noise_std": 0.1, "save_spikes": True}),
+            riab.ObjectVectorCells(ag, {"n": 6}),
+            riab.BoundaryVectorCells(ag, {"n": 5, "reference_frame": "egocentric"})]
+    pops.append(riab.FeedForwardLayer(ag, {"n": 6, "input_layers": [pops[0], pops[3]], "noise_std": 0.05,
+                                           "activation_function": {"activation": "tanh", "gain": 1.0, "threshold": 0.0}}))
+    return env, ag, pops
+
+
+@pytest.mark.parametrize("B, schedule, drift", [(64, [20], None), (256, [150, 7], [0.05, -0.02]), (128, [300], None)])
+def test_native_multi_population_simulate_equals_chunked_pipeline(riab, B, schedule, drift):
+    """Agent.simulate() with several populations is ONE native call (riab_simulate_pops: every chunk of rows behind a
+    gate, each population's ordinary kernel, noise pass and spikes after it) and gives, bit for bit, what the
+    Python-driven chunked pipeline gives: place / grid (+ OU noise) / head direction / boundary (allo- and egocentric) /
+    object vector cells and a FeedForwardLayer reading two of them, spikes included."""
+    got = {}
+    for native in (True, False):
+        os.environ["RIAB_NO_NATIVE"] = "0" if native else "1"
+        try:
+            env, ag, pops = _multi_world(riab, B)
+            used = []
+            orig = riab._lib.lib.riab_simulate_pops
+            for n in schedule:
+                ag.simulate(n, drift_velocity=drift)
+            torch.cuda.synchronize()
+            got[native] = dict(traj=ag.get_history_tensor().cpu().numpy(), state=ag.state_tensor.cpu().numpy(),
+                               t=list(ag.history["t"]), diag=ag.diagnostics,
+                               pops=[tuple(x.cpu().numpy() for x in N.get_history_tensors()) for N in pops],
+                               last=[np.array(N.firingrate) for N in pops])
+        finally:
+            os.environ.pop("RIAB_NO_NATIVE", None)
+    a, b = got[True], got[False]
+    assert a["diag"]["pipeline_timeouts"] == 0 and "pipeline_timeouts" not in b["diag"]   # (only the native path has them)
+    np.testing.assert_array_equal(a["traj"], b["traj"])
+    np.testing.assert_array_equal(a["state"], b["state"])
+    assert a["t"] == b["t"] and len(a["t"]) == sum(schedule)
+    for (fa, sa), (fb, sb), la, lb in zip(a["pops"], b["pops"], a["last"], b["last"]):
+        np.testing.assert_array_equal(fa, fb)
+        np.testing.assert_array_equal(sa, sb)
+        np.testing.assert_array_equal(la, lb)
+        assert fa.shape[0] == sum(schedule) and np.isfinite(fa).all()
+    # and the eager per-step loop continues from there on both
+    env, ag, pops = _multi_world(riab, B)
+    ag.simulate(schedule[0], drift_velocity=drift)
+    ag.update()
+    for N in pops:
+        N.update()
+    assert len(ag.history["t"]) == schedule[0] + 1 and np.isfinite(pops[-1].firingrate).all()
