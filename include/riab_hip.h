@@ -423,6 +423,10 @@ RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* motion, double*
                            float* row_scratch, int32_t* diag);
 void riab_plan_destroy(RiabPlan* plan);
 int riab_plan_set_motion(RiabPlan* plan, const RiabMotion* motion, const double* drift);
+/* imported / forced trajectories (Agent.py:229-266): the coming `n_rows` agent steps of the plan move the agents to
+ * the rows of `forced` (device float64 [n_rows][2][B]) instead of running the motion model, exactly as
+ * riab_agent_step(forced_pos = row) would; RIAB_EFULL when they are used up.  NULL: back to the motion model. */
+int riab_plan_set_forced(RiabPlan* plan, const double* forced, int64_t n_rows);
 int riab_plan_set_agent_history(RiabPlan* plan, float* hist_base, int64_t capacity_rows);
 int riab_plan_add(RiabPlan* plan, const RiabPopulation* pop);  /* returns the population's index */
 int riab_plan_set_population_history(RiabPlan* plan, int32_t index, float* rates_base, uint8_t* spikes_base,

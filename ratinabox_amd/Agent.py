@@ -287,7 +287,7 @@ class Agent:
         instead of the in-kernel Philox draws (parity mode)."""
         # ---- the unchanged reference loop, served natively (plan.AutoStepper) ----
         if dt is None and drift_velocity is None and not kwargs and drift_to_random_strength_ratio == 1 and \
-                not self.use_imported_trajectory and self._auto_enabled:
+                (not self.use_imported_trajectory or self.interpolate) and self._auto_enabled:
             st = self._plan
             if st is not None and st.__class__ is _AutoStepper:
                 if st.step_agent():
@@ -761,6 +761,9 @@ class Agent:
         history are computed exactly as for simulated motion."""
         from scipy.interpolate import interp1d
         assert self.Environment.boundary_conditions == "solid", "Only solid boundary conditions are supported"
+        if self._plan is not None:
+            self._plan.close()  # (a recorded plan holds positions of the trajectory it was recorded with)
+        self._trajectory_id = getattr(self, "_trajectory_id", 0) + 1
         if dataset is not None:
             data = np.load(dataset if str(dataset).endswith(".npz") else str(dataset) + ".npz")
             times, positions = data["t"], data["pos"]

@@ -141,6 +141,7 @@ PROTOTYPES = {
                                       C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
     "riab_plan_destroy": (None, [C.c_void_p]),
     "riab_plan_set_motion": (C.c_int, [C.c_void_p, C.POINTER(RiabMotion), C.c_void_p]),
+    "riab_plan_set_forced": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "riab_plan_set_agent_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "riab_plan_add": (C.c_int, [C.c_void_p, C.POINTER(RiabPopulation)]),
     "riab_plan_set_population_history": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),

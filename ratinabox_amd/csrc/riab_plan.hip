@@ -37,6 +37,9 @@ struct RiabPlan {
   uint64_t step;  // number of Agent.update() steps taken so far (the RNG counter)
   int32_t precision;
   const double* drift;
+  // imported / forced trajectory (riab_plan_set_forced): positions of the coming steps, [rows][2][B]; null = motion model
+  const double* forced;
+  int64_t forced_rows, forced_fill;
   float* hist_base;     // [cap][8][B]
   int64_t hist_cap, hist_fill;
   float* row_scratch;   // [8][B] used when no history chunk is attached
@@ -76,6 +79,8 @@ extern "C" RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* moti
   p->step = step;
   p->precision = precision;
   p->drift = nullptr;
+  p->forced = nullptr;
+  p->forced_rows = p->forced_fill = 0;
   p->hist_base = nullptr;
   p->hist_cap = p->hist_fill = 0;
   p->row_scratch = row_scratch;
@@ -93,6 +98,17 @@ extern "C" int riab_plan_set_motion(RiabPlan* p, const RiabMotion* motion, const
   p->motion = *motion;
   p->drift = drift;
   p->action_ready = false;
+  return RIAB_OK;
+}
+
+// Agent._update_position_along_imported_trajectory / forced_next_position (Agent.py:229-266) for the coming
+// `n_rows` steps: every agent step of the plan then MOVES the agents to the next row of `forced` ([n_rows][2][B],
+// float64, device) instead of running the motion model; RIAB_EFULL once the rows are used up (set the next ones).
+extern "C" int riab_plan_set_forced(RiabPlan* p, const double* forced, int64_t n_rows) {
+  if (!p || n_rows < 0 || (forced && n_rows == 0) || p->has_task) return RIAB_EINVAL;
+  p->forced = forced;
+  p->forced_rows = forced ? n_rows : 0;
+  p->forced_fill = 0;
   return RIAB_OK;
 }
 
@@ -267,10 +283,16 @@ static int launch_population(RiabPlan* p, size_t i, const float* row, hipStream_
 extern "C" int riab_plan_step_agent(RiabPlan* p, riab_stream_t stream) {
   if (!p || p->has_task) return RIAB_EINVAL;
   if (p->hist_base && p->hist_fill >= p->hist_cap) return RIAB_EFULL;
+  const double* forced = nullptr;
+  if (p->forced) {
+    if (p->forced_fill >= p->forced_rows) return RIAB_EFULL;
+    forced = p->forced + p->forced_fill * 2 * p->B;
+  }
   float* row = p->hist_base ? p->hist_base + p->hist_fill * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
-  const int rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr, nullptr,
+  const int rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, forced, nullptr,
                                  p->seed, p->step, 1, row, p->diag, p->precision, (hipStream_t)stream);
   if (rc) return rc;
+  if (forced) p->forced_fill += 1;
   p->step += 1;
   if (p->hist_base) p->hist_fill += 1;
   return RIAB_OK;
@@ -292,6 +314,7 @@ extern "C" int riab_plan_step_population(RiabPlan* p, int32_t index, riab_stream
 extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream) {
   if (!p || n_steps <= 0) return RIAB_EINVAL;
   if (riab_plan_rows_free(p) < n_steps) return RIAB_EFULL;
+  if (p->forced && (p->has_task || p->forced_rows - p->forced_fill < n_steps)) return p->has_task ? RIAB_EINVAL : RIAB_EFULL;
   hipStream_t s = (hipStream_t)stream;
   for (int32_t k = 0; k < n_steps; ++k) {
     float* row = p->hist_base ? p->hist_base + p->hist_fill * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
@@ -327,9 +350,11 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
       if (rc) return rc;
       p->action_ready = scripted;
     } else {
-    rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr, nullptr,
+    const double* forced = p->forced ? p->forced + p->forced_fill * 2 * p->B : nullptr;
+    rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, forced, nullptr,
                          p->seed, p->step, 1, row, p->diag, p->precision, s);
     if (rc) return rc;
+    if (forced) p->forced_fill += 1;
     p->step += 1;
     if (p->hist_base) p->hist_fill += 1;
     if (p->has_task) {  // the rest of TaskEnvironment.step (+ the caller's `if terminal: reset()`)

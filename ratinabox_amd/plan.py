@@ -21,6 +21,44 @@ from . import _lib
 _L = _lib
 
 
+class _ForcedRows:
+    """Positions of the coming steps of an agent that follows an imported trajectory (Agent.import_trajectory with
+    interpolate=True; reference Agent.py:255-266), handed to a native plan in blocks (riab_plan_set_forced): the
+    interpolation runs on the host once per block instead of once per update()."""
+
+    def __init__(self, agent, handle, block=None):
+        if not agent.interpolate:
+            raise NotImplementedError("interpolate=False trajectories reset dt to the sample spacing every step: "
+                                      "they advance through update()")
+        self.agent, self._h = agent, handle
+        self.block = int(block or max(64, min(1024, (1 << 22) // max(agent._Bp, 1))))
+        self.left = 0
+        self._buf = None
+
+    def ensure(self, n, dt):
+        """Rows for at least the next n steps (n <= block) are with the plan."""
+        if self.left >= n:
+            return
+        ag = self.agent
+        rows = max(self.block, n)
+        t, ts = ag.t, np.empty(rows)
+        for k in range(rows):   # the clock the eager path would have had at each of these steps: repeated `t += dt`
+            t += dt
+            ts[k] = t
+        pos = np.broadcast_to(ag.pos_interp(ts % max(ag.t_interp)), (rows, ag._B, 2))
+        full = np.empty((rows, 2, ag._Bp))
+        full[:, :, :ag._B] = np.transpose(pos, (0, 2, 1))
+        full[:, :, ag._B:] = full[:, :, :1]
+        self._buf = torch.from_numpy(full).to(ag._device)   # (the previous block may still be read by queued kernels:
+        self._keep_prev = getattr(self, "_buf_prev", None)  #  keep it alive for one more block)
+        self._buf_prev = self._buf
+        _L.check(_L.lib.riab_plan_set_forced(self._h, _L.ptr(self._buf), rows), "riab_plan_set_forced")
+        self.left = rows
+
+    def used(self, n):
+        self.left -= n
+
+
 class StepPlan:
     def __init__(self, agent, neurons=None, capacity=1024):
         self.agent = agent
@@ -29,8 +67,6 @@ class StepPlan:
         agent._sync_plan()
         if agent._plan is not None:
             agent._plan.close()
-        if agent.use_imported_trajectory:
-            raise NotImplementedError("imported trajectories advance through update()/simulate()")
         Bp = agent._Bp
         self._row_scratch = torch.empty((_L.HIST_ROWS, Bp), dtype=torch.float32, device=agent._device)
         self._dt = agent.dt
@@ -43,6 +79,7 @@ class StepPlan:
                                           _L.ptr(agent._diag))
         if not self._h:
             raise _L.RiabError("riab_plan_create failed")
+        self._forced = _ForcedRows(agent, self._h, block=self.capacity) if agent.use_imported_trajectory else None
         self._pops = []
         index = {}
         for N in self.neurons:
@@ -148,8 +185,14 @@ class StepPlan:
             if n_steps > self.capacity:
                 raise ValueError(f"n_steps {n_steps} exceeds the plan's chunk capacity {self.capacity}")
             self._attach()
+        if self._forced is not None:   # the agent follows its imported trajectory: positions of the coming steps
+            if drift_velocity is not None or self._task_env is not None:
+                raise NotImplementedError("an agent on an imported trajectory takes neither a drift velocity nor a task")
+            self._forced.ensure(int(n_steps), dt)
         rc = _L.lib.riab_plan_step(self._h, int(n_steps), _L.current_stream())
         _L.check(rc, "riab_plan_step")
+        if self._forced is not None:
+            self._forced.used(int(n_steps))
         self._rows_open -= n_steps
         self._pending += n_steps
         for _ in range(n_steps):
@@ -248,6 +291,8 @@ class AutoStepper:
         if not self._h:
             raise _L.RiabError("riab_plan_create failed")
         self._h = _L.C.c_void_p(self._h)
+        self._forced = _ForcedRows(agent, self._h) if agent.use_imported_trajectory else None
+        self._traj_id = getattr(agent, "_trajectory_id", 0)
         self._index, self._pops, self._keys = {}, [], []
         for N in self.neurons:
             pop = N._population(self._index)          # (raises NotImplementedError for populations a plan cannot hold)
@@ -307,11 +352,17 @@ class AutoStepper:
         env, _w = ag.Environment.device_tables(ag._device)
         if env is not self._env_struct:   # (device_tables returns the cached struct while the geometry is unchanged)
             return False
+        if (self._forced is not None) != bool(ag.use_imported_trajectory) or self._traj_id != getattr(ag, "_trajectory_id", 0):
+            return False                  # (a trajectory was imported, or another one, since the plan was recorded)
+        if self._forced is not None:
+            self._forced.ensure(1, self._dt)
         rc = _L.lib.riab_plan_step_agent(self._h, _L.current_stream())
         if rc == _L.EFULL:
             self._attach()
             rc = _L.lib.riab_plan_step_agent(self._h, _L.current_stream())
         _L.check(rc, "riab_plan_step_agent")
+        if self._forced is not None:
+            self._forced.used(1)
         ag.prev_t = ag.t
         ag.t += self._dt
         ag._step_index += 1

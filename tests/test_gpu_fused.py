@@ -402,3 +402,71 @@ def test_native_multi_population_simulate_equals_chunked_pipeline(riab, B, sched
     for N in pops:
         N.update()
     assert len(ag.history["t"]) == schedule[0] + 1 and np.isfinite(pops[-1].firingrate).all()
+
+
+# ----------------------------------------------------------------------------- imported trajectories through plans
+def _replay_world(riab, B=8):
+    np.random.seed(2)
+    env = riab.Environment({"walls": [[[0.5, 0.0], [0.5, 0.4]]]})
+    ag = riab.Agent(env, {"n_agents": B, "dt": 0.02, "seed": 3})
+    np.random.seed(4)
+    pcs = riab.PlaceCells(ag, {"n": 24, "wall_geometry": "line_of_sight"})
+    hdc = riab.HeadDirectionCells(ag, {"n": 6})
+    tt = np.linspace(0, 3.0, 61)
+    base = np.stack((0.5 + 0.35 * np.cos(2.1 * tt), 0.5 + 0.3 * np.sin(1.3 * tt + 0.4)), axis=-1)       # (61, 2)
+    per_agent = base[:, None, :] + 0.05 * np.random.RandomState(9).uniform(-1, 1, (1, B, 2))              # (61, B, 2)
+    ag.import_trajectory(times=tt, positions=per_agent)
+    return env, ag, [pcs, hdc]
+
+
+def test_imported_trajectory_through_plans_equals_eager_loop(riab):
+    """An agent replaying an imported trajectory (reference Agent.py:255-266): the unchanged per-object loop served by
+    the automatic step plan, and an explicit StepPlan, against the eager loop (one interpolation + one upload per
+    update()) — bit for bit, across the wrap-around of the trajectory and a re-import in the middle."""
+    T = 230   # (3.0 s of trajectory at dt = 0.02: wraps after 150 steps)
+
+    def loop(auto):
+        os.environ["RIAB_NO_AUTO_PLAN"] = "0" if auto else "1"
+        try:
+            env, ag, pops = _replay_world(riab)
+            engaged = 0
+            for i in range(T):
+                ag.update()
+                for N in pops:
+                    N.update()
+                engaged += int(ag._plan is not None)
+                if i == 120:   # a new trajectory: the recorded positions are dropped, the loop goes on
+                    tt = np.linspace(0, 2.0, 41)
+                    ag.import_trajectory(times=tt, positions=np.stack((0.2 + 0.3 * tt, 0.8 - 0.25 * tt), axis=-1))
+            torch.cuda.synchronize()
+            return (np.array(ag.history["pos"]), np.array(ag.history["vel"]), np.array(ag.history["t"]),
+                    [np.array(N.history["firingrate"]) for N in pops], engaged)
+        finally:
+            os.environ.pop("RIAB_NO_AUTO_PLAN", None)
+
+    pa, va, ta, ra, engaged = loop(True)
+    pb, vb, tb, rb, none = loop(False)
+    assert engaged > T - 20 and none == 0
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(va, vb)
+    np.testing.assert_array_equal(ta, tb)
+    for x, y in zip(ra, rb):
+        np.testing.assert_array_equal(x, y)
+    # explicit plan, several steps per call
+    env, ag, pops = _replay_world(riab)
+    plan = ag.make_step_plan(capacity=64)
+    for n in (1, 7, 64, 40, 8):
+        plan.step(n)
+    env2, ag2, pops2 = _replay_world(riab)
+    os.environ["RIAB_NO_AUTO_PLAN"] = "1"
+    try:
+        for _ in range(120):
+            ag2.update()
+            for N in pops2:
+                N.update()
+    finally:
+        os.environ.pop("RIAB_NO_AUTO_PLAN", None)
+    np.testing.assert_array_equal(np.array(ag.history["pos"]), np.array(ag2.history["pos"]))
+    np.testing.assert_array_equal(np.array(pops[0].history["firingrate"]), np.array(pops2[0].history["firingrate"]))
+    with pytest.raises(NotImplementedError):
+        plan.step(1, drift_velocity=[0.1, 0.0])
