@@ -251,9 +251,9 @@ class Agent:
             self._motion_cache = (key, m)
         return m
 
-    def _motion_key_now(self, dt):
-        """The attribute values `_motion` resolves a plain update() from (its cache key)."""
-        return (dt, False, 1, self.rotational_velocity_std, self.rotational_velocity_coherence_time,
+    def _motion_key_now(self, dt, has_drift=False, ratio=1):
+        """The attribute values `_motion` resolves an update() without per-call overrides from (its cache key)."""
+        return (dt, has_drift, ratio, self.rotational_velocity_std, self.rotational_velocity_coherence_time,
                 self.speed_coherence_time, self.speed_mean, self.speed_std, self.wall_repel_strength,
                 self.wall_repel_distance, self.thigmotaxis, self.head_direction_smoothing_timescale)
 
@@ -286,18 +286,18 @@ class Agent:
         `noise=` — explicit standard normals `(2, B)` / `(B, 2)` [rotation OU, speed OU]
         instead of the in-kernel Philox draws (parity mode)."""
         # ---- the unchanged reference loop, served natively (plan.AutoStepper) ----
-        if dt is None and drift_velocity is None and not kwargs and drift_to_random_strength_ratio == 1 and \
-                (not self.use_imported_trajectory or self.interpolate) and self._auto_enabled:
+        if (dt is None or dt == self.dt) and not kwargs and self._auto_enabled and \
+                (not self.use_imported_trajectory or (self.interpolate and drift_velocity is None)):
             st = self._plan
             if st is not None and st.__class__ is _AutoStepper:
-                if st.step_agent():
+                if st.step_agent(drift_velocity, drift_to_random_strength_ratio):
                     return
                 st.close()
             elif st is None:
                 self._auto_streak += 1
                 if self._auto_streak > self.AUTO_AFTER and self._device.type == "cuda":
                     try:
-                        if _AutoStepper(self).step_agent():
+                        if _AutoStepper(self).step_agent(drift_velocity, drift_to_random_strength_ratio):
                             return
                     except NotImplementedError:      # a population a plan cannot hold: stay eager
                         self._auto_enabled = False

@@ -271,7 +271,8 @@ class AutoStepper:
 
     Registered in `agent._plan`, so the history accessors publish its pending rows like a StepPlan's."""
 
-    CAPACITY = 4096
+    CAPACITY = 4096          # rows per attached history chunk, at most
+    CHUNK_BYTES = 4 << 30    # ... and at most this much HBM per population and chunk (cfg 2: 16.8 MB per row -> 255 rows)
 
     def __init__(self, agent):
         self.agent = agent
@@ -285,6 +286,7 @@ class AutoStepper:
         self._env_struct, self._walls = agent.Environment.device_tables(agent._device)
         self._motion = agent._motion(agent.dt, False, 1, {})
         self._motion_key = agent._motion_cache[0]
+        self._drift_buf = None
         self._h = _L.lib.riab_plan_create(self._env_struct, self._motion, _L.ptr(agent._state), Bp, int(agent.agent_id0),
                                           int(agent.rng_seed), int(agent._step_index), int(agent.precision),
                                           _L.ptr(self._row_scratch), _L.ptr(agent._diag))
@@ -331,10 +333,11 @@ class AutoStepper:
         N, ag = self.neurons[i], self.agent
         self._sync_pop(i)
         if N.save_history:
-            fr = N._hist_fr.open_rows(self.CAPACITY)
-            sp = N._hist_sp.open_rows(self.CAPACITY) if N.save_spikes else None
+            cap = int(max(64, min(self.CAPACITY, self.CHUNK_BYTES // max(1, int(N.n) * ag._Bp * 4))))
+            fr = N._hist_fr.open_rows(cap)
+            sp = N._hist_sp.open_rows(cap) if N.save_spikes else None
             self._pop_rows[i] = (fr, sp)
-            rc = _L.lib.riab_plan_set_population_history(self._h, i, _L.ptr(fr), _L.ptr(sp), self.CAPACITY)
+            rc = _L.lib.riab_plan_set_population_history(self._h, i, _L.ptr(fr), _L.ptr(sp), cap)
         else:
             if self._scratch_rates[i] is None:
                 self._scratch_rates[i] = torch.empty((1, int(N.n), ag._Bp), dtype=torch.float32, device=ag._device)
@@ -344,11 +347,26 @@ class AutoStepper:
         self._p_done[i] = 0
 
     # ---- the two fast paths ---------------------------------------------------------------------
-    def step_agent(self):
-        """Agent.update() with no arguments.  False: something changed — the caller closes the stepper and goes eager."""
+    def step_agent(self, drift_velocity=None, ratio=1):
+        """Agent.update() with no arguments, or with a drift velocity (the closed loop: `update(drift_velocity=
+        policy(obs))`, TaskEnvironment.step).  False: something changed — the caller closes the stepper and goes eager."""
         ag = self.agent
-        if ag.dt != self._dt or ag._motion_key_now(ag.dt) != self._motion_key:
+        if ag.dt != self._dt:
             return False
+        has = drift_velocity is not None
+        key = ag._motion_key_now(ag.dt, has, ratio if has else 1)
+        if key != self._motion_key:
+            if key[3:] != self._motion_key[3:] or self._forced is not None:
+                return False              # a motion parameter changed (or a drift on a replayed trajectory): eager
+            # only (drift given?, its strength ratio) differ: the plan takes the other struct, same kernels
+            self._motion = ag._motion(ag.dt, has, ratio, {})
+            if has and self._drift_buf is None:
+                self._drift_buf = torch.zeros((2, ag._Bp), dtype=torch.float64, device=ag._device)
+            _L.check(_L.lib.riab_plan_set_motion(self._h, self._motion, _L.ptr(self._drift_buf) if has else None),
+                     "riab_plan_set_motion")
+            self._motion_key = key
+        if has:
+            self._write_drift(drift_velocity)
         env, _w = ag.Environment.device_tables(ag._device)
         if env is not self._env_struct:   # (device_tables returns the cached struct while the geometry is unchanged)
             return False
@@ -369,6 +387,24 @@ class AutoStepper:
         self._a_pending += 1
         self._a_times.append(ag.t)
         return True
+
+    def _write_drift(self, x):
+        """The step's drift velocity into the plan's persistent device buffer [2, Bp] (what Agent._as_device_f64 would
+        have allocated: padded lanes carry agent 0's value)."""
+        buf, ag = self._drift_buf, self.agent
+        B, Bp = ag._B, ag._Bp
+        if torch.is_tensor(x) and x.device == buf.device and x.dim() == 2:
+            if x.shape == (B, 2):
+                buf[:, :B].copy_(x.t())
+            elif x.shape == (2, B):
+                buf[:, :B].copy_(x)
+            else:
+                buf.copy_(ag._as_device_f64(x, 2))
+                return
+            if Bp != B:
+                buf[:, B:] = buf[:, :1]
+        else:
+            buf.copy_(ag._as_device_f64(x, 2))
 
     def step_population(self, N):
         """N.update() with no arguments, N one of the recorded populations with unchanged tables."""

@@ -328,7 +328,32 @@ def _with_edits(riab, env, ag, pops):
     return any(engaged[5:14]) and any(engaged[50:])
 
 
-@pytest.mark.parametrize("script", [_plain, _with_edits], ids=["plain", "with_edits"])
+def _closed_loop(riab, env, ag, pops):
+    """The closed loop of the reference (a policy producing drift_velocity every step, TaskEnvironment.py:399-408):
+    a device tensor per agent, a plain array for everyone, another strength ratio, plain steps in between."""
+    B = ag.n_agents
+    target = torch.tensor([0.8, 0.8], dtype=torch.float64, device="cuda")
+    engaged = []
+    for t in range(70):
+        pos = ag.state_tensor[:2, :B].t()                       # (B, 2) on the device
+        v = 0.3 * (target - pos) / (target - pos).norm(dim=1, keepdim=True).clamp_min(1e-9)
+        if t < 25:
+            ag.update(drift_velocity=v)
+        elif t < 35:
+            ag.update(drift_velocity=v.t().contiguous(), drift_to_random_strength_ratio=3.0)   # (2, B), another ratio
+        elif t < 45:
+            ag.update()
+        elif t < 55:
+            ag.update(drift_velocity=np.array([0.05, -0.1]))
+        else:
+            ag.update(dt=ag.dt, drift_velocity=v.float())        # the way TaskEnvironment.step calls it; float32 policy
+        for p in pops:
+            p.update()
+        engaged.append(ag._plan is not None and type(ag._plan).__name__ == "AutoStepper")
+    return all(engaged[8:])
+
+
+@pytest.mark.parametrize("script", [_plain, _with_edits, _closed_loop], ids=["plain", "with_edits", "closed_loop"])
 def test_unchanged_reference_loop_is_served_natively_and_bit_identical(riab, script):
     """`Ag.update(); N.update() ...` from Python, no plan made by the caller: after a few rounds the
     calls are served by plan.AutoStepper; histories, states, spikes, times: identical to the eager calls, also
