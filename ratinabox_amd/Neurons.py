@@ -783,7 +783,11 @@ class BoundaryVectorCells(VectorCells):
             with np.errstate(divide="ignore"):
                 rden = 1.0 / (dirs[:, None, 0] * (-s_w[None, :, 1]) + dirs[:, None, 1] * s_w[None, :, 0])
             f64 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(self._device)  # noqa: E731
-            return (f64(dirs), f64(rden), f32(cells), f32(vm), f32(inv), rows_t, win_t)
+            dirs_dev = dirs
+            if os.environ.get("RIAB_EXP_NO_RAY_PAIRS"):   # (A/B: a table without exact opposites -> one ray at a time)
+                dirs_dev = dirs.copy()
+                dirs_dev[2, 0] += 1e-9
+            return (f64(dirs_dev), f64(rden), f32(cells), f32(vm), f32(inv), rows_t, win_t)
 
         import os
         use_windows = os.environ.get("RIAB_NO_BVC_WINDOWS") is None  # (A/B switch: every direction for every cell)

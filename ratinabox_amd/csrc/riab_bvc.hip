@@ -8,7 +8,8 @@
 //
 // Workgroup = 512 threads = 8 waves sharing one tile of 64 positions (lane = position):
 //   stage A  all 8 waves cast the K rays of the tile against the walls in float64 (the
-//            nearest-wall decision is discrete; walls + 1/denominator table staged in LDS)
+//            nearest-wall decision is discrete; walls and the 1/denominator table are scalar loads),
+//            a ray and its opposite from one pair of wall intercepts where the table holds opposites,
 //            and leave d[k][lane] (fp32) in LDS;
 //   stage B  wave w owns the 4-cell groups g = w (mod 8); per group the K-loop reads d[k][lane]
 //            (conflict-free ds_read_b32) and the wave-uniform angular table entry (scalar
@@ -79,41 +80,112 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
   // Four test directions per pass over the walls: the wall-only quantities (d0, its cross product
   // with the wall) are computed once per wall and pass, leaving 1 + 3 multiply-adds per (ray, wall).
   constexpr int KB = 4;
-  for (int k0 = wave; k0 < K; k0 += 8 * KB) {
-    double ux[KB], uy[KB], best[KB], fallback[KB];
-    int kk[KB];
-#pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      kk[i] = min(k0 + 8 * i, K - 1);  // (wave-uniform; a clamped duplicate is computed but not stored)
-      ux[i] = dirs[2 * kk[i]];
-      uy[i] = dirs[2 * kk[i] + 1];
-      best[i] = INFINITY;  // smallest valid l_a == largest preference 1/l_a; first index wins ties
-      fallback[i] = 0.0;
-    }
-    for (int w = 0; w < nw; ++w) {
-      const double ax = walls[4 * w], ay = walls[4 * w + 1];
-      const double sx = walls[4 * w + 2] - ax, sy = walls[4 * w + 3] - ay;
-      const double d0x = ax - px, d0y = ay - py;
-      const double num_a = d0x * (-sy) + d0y * sx;
+  // rays without a partner (see below), `count` of them: table index 0 for t = 0, t + off otherwise
+  auto cast_single = [&](int count, int off) {
+    for (int t0 = wave; t0 < count; t0 += 8 * KB) {
+      double ux[KB], uy[KB], best[KB], fallback[KB];
+      int kk[KB];
 #pragma unroll
       for (int i = 0; i < KB; ++i) {
-        const double rd = rden[kk[i] * nw + w];
-        const double la = num_a * rd;
-        const double lb = ((-d0x) * (-uy[i]) + (-d0y) * ux[i]) * (-rd);
-        const bool valid = (la > 0.0) && !(lb < 0.0) && !(lb > 1.0);
-        if (valid && la < best[i]) best[i] = la;
-        if (w == 0) fallback[i] = la;  // argmax over all -1 preferences picks wall 0
+        const int t = min(t0 + 8 * i, count - 1);  // (wave-uniform; a clamped duplicate is computed but not stored)
+        kk[i] = t == 0 ? 0 : t + off;
+        ux[i] = dirs[2 * kk[i]];
+        uy[i] = dirs[2 * kk[i] + 1];
+        best[i] = INFINITY;  // smallest valid l_a == largest preference 1/l_a; first index wins ties
+        fallback[i] = 0.0;
       }
-    }
+      for (int w = 0; w < nw; ++w) {
+        const double ax = walls[4 * w], ay = walls[4 * w + 1];
+        const double sx = walls[4 * w + 2] - ax, sy = walls[4 * w + 3] - ay;
+        const double d0x = ax - px, d0y = ay - py;
+        const double num_a = d0x * (-sy) + d0y * sx;
 #pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      const int k = k0 + 8 * i;
-      if (k < K) {
-        const float d = (float)((best[i] < INFINITY) ? best[i] : fallback[i]);
-        s_d[k * 64 + lane] = d;
-        if (a.ray_out && live) a.ray_out[(t * K + k) * a.B + b] = d;
+        for (int i = 0; i < KB; ++i) {
+          const double rd = rden[kk[i] * nw + w];
+          const double la = num_a * rd;
+          const double lb = ((-d0x) * (-uy[i]) + (-d0y) * ux[i]) * (-rd);
+          const bool valid = (la > 0.0) && !(lb < 0.0) && !(lb > 1.0);
+          if (valid && la < best[i]) best[i] = la;
+          if (w == 0) fallback[i] = la;  // argmax over all -1 preferences picks wall 0
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        if (t0 + 8 * i < count) {
+          const int k = kk[i];
+          const float d = (float)((best[i] < INFINITY) ? best[i] : fallback[i]);
+          s_d[k * 64 + lane] = d;
+          if (a.ray_out && live) a.ray_out[(t * K + k) * a.B + b] = d;
+        }
       }
     }
+  };
+  // Opposite rays share their wall intercepts.  With u' = -u the line through the position is the same: l_b (the
+  // place on the wall) is unchanged and l_a changes sign, so ONE (l_a, l_b) pair per wall serves the ray (hits with
+  // l_a > 0) and its opposite (hits with l_a < 0, at distance -l_a): 14 instead of 24 float64 instructions per pair of
+  // rays and wall.  The reference's table of K test directions (0, 0, d, 2d, ... 360 - 2d degrees, Neurons.py:1584-1596)
+  // holds an opposite for the indices 1 .. K/2 - 1 when K is even; whether THIS table does is checked here, on the
+  // table itself (every wave for itself: a few loads per lane, once per tile), and any other table takes the
+  // one-ray-at-a-time path.  The opposite direction in the table is -u up to its own rounding (1e-16).
+  const int m = K >> 1, np = K - 1 - m;  // pairs (j, j + m) for j = 1 .. np
+  bool paired = false;
+  if ((K & 1) == 0 && np >= 8) {
+    bool ok = true;
+    for (int jq = 1 + lane; jq <= np; jq += 64) {
+      const double e0 = a.test_dirs[2 * jq] + a.test_dirs[2 * (jq + m)];
+      const double e1 = a.test_dirs[2 * jq + 1] + a.test_dirs[2 * (jq + m) + 1];
+      ok = ok && fabs(e0) <= 1e-12 && fabs(e1) <= 1e-12;
+    }
+    paired = __builtin_amdgcn_ballot_w64(!ok) == 0;  // (wave-uniform, and the same in every wave)
+  }
+  if (paired) {
+    for (int q0 = wave; q0 < np; q0 += 8 * KB) {
+      double ux[KB], uy[KB], bpos[KB], bneg[KB], fallback[KB];
+      int jj[KB];
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        jj[i] = 1 + min(q0 + 8 * i, np - 1);
+        ux[i] = dirs[2 * jj[i]];
+        uy[i] = dirs[2 * jj[i] + 1];
+        bpos[i] = INFINITY;  // nearest hit along +u ...
+        bneg[i] = INFINITY;  // ... and along -u
+        fallback[i] = 0.0;
+      }
+      for (int w = 0; w < nw; ++w) {
+        const double ax = walls[4 * w], ay = walls[4 * w + 1];
+        const double sx = walls[4 * w + 2] - ax, sy = walls[4 * w + 3] - ay;
+        const double d0x = ax - px, d0y = ay - py;
+        const double num_a = d0x * (-sy) + d0y * sx;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          const double rd = rden[jj[i] * nw + w];
+          const double la = num_a * rd;
+          const double lb = ((-d0x) * (-uy[i]) + (-d0y) * ux[i]) * (-rd);
+          const bool on_wall = !(lb < 0.0) && !(lb > 1.0);
+          const double nla = -la;
+          if (on_wall && la > 0.0 && la < bpos[i]) bpos[i] = la;
+          if (on_wall && nla > 0.0 && nla < bneg[i]) bneg[i] = nla;
+          if (w == 0) fallback[i] = la;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        if (q0 + 8 * i < np) {
+          const int k = jj[i];
+          const float dp = (float)((bpos[i] < INFINITY) ? bpos[i] : fallback[i]);
+          const float dn = (float)((bneg[i] < INFINITY) ? bneg[i] : -fallback[i]);
+          s_d[k * 64 + lane] = dp;
+          s_d[(k + m) * 64 + lane] = dn;
+          if (a.ray_out && live) {
+            a.ray_out[(t * K + k) * a.B + b] = dp;
+            a.ray_out[(t * K + k + m) * a.B + b] = dn;
+          }
+        }
+      }
+    }
+    cast_single(1 + (m - np), np);  // table index 0 (the duplicated first direction) and np + 1 .. m
+  } else {
+    cast_single(K, 0);
   }
   // pad rows: an infinite distance makes the term exp2(-inf) = 0 for any (finite or -inf) table entry
   for (int k = K + wave; k < a.Kp; k += 8) s_d[k * 64 + lane] = INFINITY;
