@@ -1,0 +1,44 @@
+"""Stress of the flag-coupled pipelines: thousands of back-to-back simulate() calls at the bench shape; every call's
+rates are reduced to a checksum on the device and compared, call by call, with the Python-driven chunked pipeline
+(a row consumed before it was published, or not at all, changes the checksum).  python tools/fused_stress.py [calls]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ratinabox_amd as riab
+
+def run(native, calls, K, B=4096, n=1024, two=False):
+    os.environ["RIAB_NO_FUSED"] = "0" if native else "1"
+    os.environ["RIAB_NO_NATIVE"] = "0" if native else "1"
+    np.random.seed(0)
+    env = riab.Environment()
+    ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "seed": 5})
+    pops = [riab.PlaceCells(ag, {"n": n, "save_spikes": False})]
+    if two:
+        pops.append(riab.GridCells(ag, {"n": 256, "save_spikes": False}))
+    sums = torch.zeros((calls, len(pops)), dtype=torch.float64, device="cuda")
+    t0 = time.perf_counter()
+    for i in range(calls):
+        per = max(1, 1200 // K)   # (about 20 GB of rate rows at a time)
+        if i % per == 0:
+            ag.reset_history()
+            for p in pops:
+                p.reset_history()
+            ag.preallocate_history(per * K)
+        ag.simulate(K)
+        for j, p in enumerate(pops):
+            fr, _ = p.get_history_tensors()
+            sums[i, j] = fr[-K:].sum(dtype=torch.float64)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    d = ag.diagnostics
+    return sums.cpu().numpy(), ag.state_tensor.cpu().numpy(), d, el
+
+calls = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+for K, two, c in ((20, False, calls), (64, False, calls // 4), (300, False, calls // 16), (20, True, calls // 4), (300, True, calls // 16)):
+    a, sa, da, ta = run(True, c, K, two=two)
+    b, sb, db, tb = run(False, c, K, two=two)
+    ok = np.array_equal(a, b) and np.array_equal(sa, sb)
+    print("K=%-4d populations=%d calls=%-5d identical=%s timeouts=%s  (%.1f s native, %.1f s chunked)" % (
+        K, 2 if two else 1, c, ok, da.get("pipeline_timeouts"), ta, tb), flush=True)
+    assert ok and da.get("pipeline_timeouts", 0) == 0
+print("OK")
