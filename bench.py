@@ -200,10 +200,27 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        ctrl_on_cpu = share
         if share:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            # The step path has no collective: the process group only carries the barriers and the max-reduce of the
+            # timings.  RCCL first; if it cannot be brought up on this node, the same control plane over gloo (every
+            # rank fails the same way, so every rank falls back) rather than no line at all.
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                probe = torch.zeros(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: RCCL control plane failed ({type(e).__name__}: {e}); using gloo", file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                dist.init_process_group("gloo")
+                ctrl_on_cpu = True
 
     import ratinabox_amd as riab
     cfg = CONFIGS[args.config]
@@ -318,7 +335,7 @@ def main():
             kernel_ms.append(ag.last_rate_kernel_ms())
     el = torch.tensor(elapsed, dtype=torch.float64)
     if dist is not None:
-        el = el.to("cpu" if share else "cuda")
+        el = el.to("cpu" if ctrl_on_cpu else "cuda")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)  # per repeat: the slowest rank
         el = el.cpu()
     el_sorted = sorted(el.tolist())
