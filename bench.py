@@ -177,6 +177,9 @@ def main():
                     help="closed loop through the batched TaskEnvironment: goal-seeking actions, rewards, goal checks "
                          "and per-lane auto-reset every step (implies --plan)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the config's agents are the TOTAL, split over the ranks (default: weak scaling, "
+                         "the config's agents per GPU)")
     ap.add_argument("--no-history", action="store_true", help="ring buffers instead of a full T-long history")
     args = ap.parse_args()
 
@@ -223,7 +226,14 @@ def main():
                 ctrl_on_cpu = True
 
     import ratinabox_amd as riab
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.strong and world > 1:   # (a fixed batch over more GPUs is launch-bound; labelled "strong")
+        per = cfg["agents"] // world // 256 * 256
+        if per <= 0:
+            print(f"[bench] --strong: {cfg['agents']} agents do not split into whole 256-agent groups over {world} ranks",
+                  file=sys.stderr)
+            sys.exit(2)
+        cfg["agents"] = per
     args.plan = args.plan or args.task
     env, ag, pops = build_world(riab, cfg, rank, args.precision, task=args.task)
     # the full rate history of K steps must fit in HBM next to the warmup's; otherwise stream
@@ -439,7 +449,8 @@ def main():
         out = {
             "metric": metric_name(cfg),
             "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(med / K * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(med / K * 1e3, 6), "higher_is_better": True,
+            "scaling": "strong" if (args.strong and world > 1) else "weak",
             "vs_baseline": None, "dtype": "f32 rates / f%d motion" % args.precision, "data": "synthetic",
             "config": {"workload": args.config + ": " + cfg["desc"], "agents_per_gpu": B,
                        "cells": {k: cfg[k] for k in ("place", "grid", "bvc", "hdc")},

@@ -270,6 +270,10 @@ def test_bench_launches_its_own_ranks(riab):
     assert out["n_gpus"] == 2 and out["steps"] == 64
     assert out["config"]["parallelism"].startswith("agent-sharded x2")
     assert out["value"] > 1e6 and out["diagnostics"].get("pipeline_timeouts", 0) == 0
+    assert out["scaling"] == "weak" and out["config"]["agents_per_gpu"] == 4096
+    strong = _bench(["--gpus", "2", "--strong", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"],
+                    {"RIAB_BENCH_SHARE_GPU": "1"})
+    assert strong["scaling"] == "strong" and strong["config"]["agents_per_gpu"] == 2048 and strong["n_gpus"] == 2
 
 
 # ----------------------------------------------------------------------------- the unchanged per-step loop
