@@ -88,6 +88,7 @@ GOALORDERS = {"nonsequential": 0, "sequential": 1}
 TD_REWARD_OVERFLOW, TD_LATE_COMPLETIONS, TD_EPLOG_OVERFLOW, TD_RESETS = range(4)
 
 POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4, "ff": 5, "velocity": 6, "speed": 7, "random_spatial": 8}
+EINVAL = -1
 EFULL = -5
 EUNSUPPORTED = -4
 CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_PROGRESS = 0, 1, 2, 32  # riab_hip.h RIAB_CTRL_*

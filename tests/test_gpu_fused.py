@@ -499,3 +499,48 @@ def test_imported_trajectory_through_plans_equals_eager_loop(riab):
     np.testing.assert_array_equal(np.array(pops[0].history["firingrate"]), np.array(pops2[0].history["firingrate"]))
     with pytest.raises(NotImplementedError):
         plan.step(1, drift_velocity=[0.1, 0.0])
+
+
+def test_simulate_pops_argument_errors_launch_nothing(riab):
+    """riab_simulate_pops validates before it launches: bad argument sets come back as negative codes and leave the
+    agent state and the control words untouched."""
+    L = riab._lib
+    env, ag, pops = _multi_world(riab, 64)
+    ag.simulate(4)                                    # (creates the streamer and the control block)
+    torch.cuda.synchronize()
+    before = ag.state_tensor.clone()
+    ctrl_before = ag._ctrl.clone()
+    envs, _w = env.device_tables(ag._device)
+    m = ag._motion(ag.dt, False, 1, {})
+    index, structs = {}, []
+    for N in pops:
+        structs.append(N._population(index))
+        index[N] = len(index)
+    T = 8
+    outs = [torch.empty((T, int(N.n), ag._Bp), dtype=torch.float32, device="cuda") for N in pops]
+    hist = torch.empty((T, L.HIST_ROWS, ag._Bp), dtype=torch.float32, device="cuda")
+
+    def call(n_pops=None, B=None, cap=T, ff_input=None, kind=None):
+        arr = (L.RiabPopulation * len(pops))()
+        for i, (p, o) in enumerate(zip(structs, outs)):
+            L.C.memmove(L.C.byref(arr, i * L.C.sizeof(L.RiabPopulation)), L.C.byref(p), L.C.sizeof(L.RiabPopulation))
+            arr[i].rates_base, arr[i].spikes_base, arr[i].capacity_rows = o.data_ptr(), None, cap
+        if ff_input is not None:
+            arr[len(pops) - 1].input_index[0] = ff_input
+        if kind is not None:
+            arr[1].kind = kind
+        return L.lib.riab_simulate_pops(ag._streamer, envs, m, ag._state.data_ptr(), ag._Bp if B is None else B, 0, None,
+                                        int(ag.rng_seed), int(ag._step_index), T, hist.data_ptr(), ag._diag.data_ptr(),
+                                        L.C.addressof(arr), len(pops) if n_pops is None else n_pops, ag._ctrl.data_ptr(),
+                                        -1, L.current_stream())
+
+    assert call(n_pops=0) == L.EINVAL
+    assert call(B=ag._Bp + 4) == L.EUNSUPPORTED            # not whole waves
+    assert call(cap=T - 1) == L.EINVAL                      # rows for the whole run are required
+    assert call(ff_input=len(pops) - 1) == L.EINVAL         # a layer reading itself / a later population
+    assert call(kind=L.POP_KINDS["velocity"]) == L.EUNSUPPORTED
+    torch.cuda.synchronize()
+    assert torch.equal(before, ag.state_tensor) and torch.equal(ctrl_before, ag._ctrl)
+    assert call() == 0                                      # and the well-formed call runs
+    torch.cuda.synchronize()
+    assert not torch.equal(before, ag.state_tensor) and all(torch.isfinite(o).all() for o in outs)
