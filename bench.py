@@ -259,7 +259,7 @@ def main():
     fused_mode = not (args.per_step or args.plan) and ag._fused_eligible(pops)
     # several populations: the same pipeline through riab_simulate_pops (every chunk of rows behind a gate, one native
     # call per timed region); the events then bracket every launch of the DOMINANT population's kernel
-    native_mode = (not (args.per_step or args.plan) and not fused_mode and not args.no_history
+    native_mode = (not (args.per_step or args.plan) and not fused_mode
                    and os.environ.get("RIAB_NO_NATIVE") != "1" and ag.precision == 64 and ag._Bp % 64 == 0)
     ag._time_rate_kernel = fused_mode or native_mode
 
@@ -329,7 +329,7 @@ def main():
     if not (args.per_step or args.plan or fused_mode or native_mode):
         ag._profile_hook = hook
 
-    elapsed, kernel_ms = [], []
+    elapsed, kernel_ms, kernel_units = [], [], []
     for _r in range(R):
         fresh_history(K)
         torch.cuda.synchronize()
@@ -343,6 +343,7 @@ def main():
         elapsed.append(t1 - t0)
         if fused_mode or native_mode:
             kernel_ms.append(ag.last_rate_kernel_ms())
+            kernel_units.append(getattr(ag, "_last_fused_units", B * K))  # (rings: the last ring-length piece of the run)
     el = torch.tensor(elapsed, dtype=torch.float64)
     if dist is not None:
         el = el.to("cpu" if ctrl_on_cpu else "cuda")
@@ -365,8 +366,8 @@ def main():
     own_bytes = 4 * n0 + (n0 if cfg["spikes"] else 0) + 8
     ms, units = [], []
     if fused_mode or native_mode:
+        units = [u for m, u in zip(kernel_ms, kernel_units) if m is not None]
         ms = [m for m in kernel_ms if m is not None]
-        units = [B * K] * len(ms)
     elif spans:
         ms = [a.elapsed_time(b) for a, b, _ in spans]
         units = [B * tc for _, _, tc in spans]

@@ -436,6 +436,7 @@ class Agent:
         if noise is not None:
             z_all = noise
         step0 = self._step_index
+        t_start = self.t
         t0 = 0
         for tc in self._chunk_schedule(n_steps, chunk):
             view = traj[t0:t0 + tc]
@@ -461,8 +462,15 @@ class Agent:
         done_b.record(s_rate)
         cur.wait_event(done_a)
         cur.wait_event(done_b)
+        if self.save_history:
+            times = self._times[-n_steps:]
+        else:  # (the agent keeps no history, its populations may: the clock values of these steps, `t += dt` repeated)
+            t, times = t_start, []
+            for _ in range(n_steps):
+                t += dt
+                times.append(t)
         for N, out in zip(neurons, outs):
-            N._finish_rows(out, n_steps, self._times[-n_steps:] if self.save_history else None)
+            N._finish_rows(out, n_steps, times)
         return traj
 
     def _simulate_by_plan(self, n_steps, dt, drift_velocity, ratio, neurons):
@@ -580,14 +588,16 @@ class Agent:
     def _simulate_native(self, n_steps, dt, drift_velocity, ratio, neurons):
         """The flag-coupled pipeline for an ordered set of populations: the trajectory kernel publishes its rows,
         every chunk of rows is consumed behind a gate by each population's ordinary kernel — the launch loop of the
-        chunked path below, moved into C++ (csrc/riab_simulate.hip).  Bit-identical to it.  None (nothing reserved,
-        nothing launched) when the set is not covered: rates not saved (rings), populations that cannot be recorded
-        (AgentVectorCells, recurrent FeedForwardLayers), float32 motion, imported trajectories; `RIAB_NO_NATIVE=1`
-        switches it off."""
+        chunked path below, moved into C++ (csrc/riab_simulate.hip).  Bit-identical to it.  Populations that do not
+        save their history stream through a ring of rows: one native call per ring length (inside a call the kernels
+        of a chunk may run while the next chunk's rows are produced, so the rows of one call must not alias; calls
+        are ordered by the stream).  None (nothing reserved, nothing launched) when the set is not covered:
+        populations that cannot be recorded (AgentVectorCells, recurrent FeedForwardLayers), float32 motion, imported
+        trajectories; `RIAB_NO_NATIVE=1` switches it off."""
         if not neurons or len(neurons) > 16 or self.use_imported_trajectory or self.precision != 64 or self._Bp % 64 \
-                or not self.save_history or _L.env("RIAB_NO_NATIVE") == "1" or n_steps <= 0:
+                or _L.env("RIAB_NO_NATIVE") == "1" or n_steps <= 0:
             return None
-        if any((not N.save_history) or N.Agent is not self for N in neurons):
+        if any(N.Agent is not self for N in neurons):
             return None
         self.dt = dt  # (the populations' OU-noise constants are those of this dt, as in update(dt=...))
         index, structs = {}, []
@@ -608,40 +618,59 @@ class Agent:
         env, _walls = self.Environment.device_tables(self._device)
         drift = self._as_device_f64(drift_velocity, 2) if has_drift else None
         Bp = self._Bp
-        traj = self._hist.reserve(n_steps)
-        outs = [N._reserve_rows(n_steps, ring=n_steps) for N in neurons]
+        if self.save_history:
+            traj = self._hist.reserve(n_steps)
+        else:
+            traj = torch.empty((n_steps, _L.HIST_ROWS, Bp), dtype=torch.float32, device=self._device)
+        outs = [N._reserve_rows(n_steps, ring=128) for N in neurons]   # (rings of 256 rows where rates are not saved)
+        piece = min([n_steps] + [o["ring"] for o in outs if o["ring"] is not None])
         arr = (_L.RiabPopulation * len(neurons))()
+        bases = []
         for i, (pop, out) in enumerate(zip(structs, outs)):
             _L.C.memmove(_L.C.byref(arr, i * _L.C.sizeof(_L.RiabPopulation)), _L.C.byref(pop), _L.C.sizeof(_L.RiabPopulation))
-            arr[i].rates_base = out["fr"].data_ptr()
-            arr[i].spikes_base = out["sp"].data_ptr() if out["sp"] is not None else None
-            arr[i].capacity_rows = n_steps
+            n = int(neurons[i].n)
+            bases.append((out["fr"].data_ptr(), out["sp"].data_ptr() if out["sp"] is not None else None,
+                          n * Bp * 4 if out["ring"] is None else 0, n * Bp if out["ring"] is None else 0))
         timed = -1
         if self._time_rate_kernel:
             tp = getattr(self, "_timed_population", None)
             timed = neurons.index(tp) if tp in neurons else 0
-        rc = _L.lib.riab_simulate_pops(self._streamer, env, m, self._state.data_ptr(), Bp, int(self.agent_id0), _L.ptr(drift),
-                                       int(self.rng_seed), int(self._step_index), n_steps, traj.data_ptr(), self._diag.data_ptr(),
-                                       _L.C.addressof(arr), len(neurons), self._ctrl.data_ptr(), timed, _L.current_stream())
-        if rc == _L.EUNSUPPORTED:
-            self._hist.unreserve(n_steps)
-            for N, out in zip(neurons, outs):
-                N._unreserve_rows(out, n_steps)
-            return None
-        _L.check(rc, "riab_simulate_pops")
+        traj_p, traj_row = traj.data_ptr(), _L.HIST_ROWS * Bp * 4
+        seed, a0, step = int(self.rng_seed), int(self.agent_id0), int(self._step_index)
+        t0 = tc = 0
+        while t0 < n_steps:
+            tc = min(piece, n_steps - t0)
+            for i, (fr_p, sp_p, fr_row, sp_row) in enumerate(bases):
+                arr[i].rates_base = fr_p + t0 * fr_row
+                arr[i].spikes_base = None if sp_p is None else sp_p + t0 * sp_row
+                arr[i].capacity_rows = tc
+            rc = _L.lib.riab_simulate_pops(self._streamer, env, m, self._state.data_ptr(), Bp, a0, _L.ptr(drift), seed,
+                                           step + t0, tc, traj_p + t0 * traj_row, self._diag.data_ptr(),
+                                           _L.C.addressof(arr), len(neurons), self._ctrl.data_ptr(), timed, _L.current_stream())
+            if rc == _L.EUNSUPPORTED and t0 == 0:
+                if self.save_history:
+                    self._hist.unreserve(n_steps)
+                for N, out in zip(neurons, outs):
+                    N._unreserve_rows(out, n_steps)
+                return None
+            _L.check(rc, "riab_simulate_pops")
+            t0 += tc
         self._pipeline_unchecked = True
-        self._keep = (drift, _walls, arr, structs, outs)
+        self._keep = (drift, _walls, arr, structs, outs, traj)
         self._last_row = traj[n_steps - 1]
-        self._last_fused_units = Bp * n_steps
+        self._last_fused_units = Bp * tc  # agent-steps of the call `last_rate_kernel_ms` refers to (the last piece)
         t, times = self.t, []
         for _ in range(n_steps):
             self.prev_t = t
             t += dt
             times.append(t)
         self.t = t
-        self._times.extend(times)
+        if self.save_history:
+            self._times.extend(times)
         self._step_index += n_steps
         for N, out in zip(neurons, outs):
+            if out["ring"] is not None:
+                out["last"] = out["fr"][tc - 1]   # (every piece starts at the ring's first row)
             N._finish_rows(out, n_steps, times)
         return traj
 

@@ -544,3 +544,32 @@ def test_simulate_pops_argument_errors_launch_nothing(riab):
     assert call() == 0                                      # and the well-formed call runs
     torch.cuda.synchronize()
     assert not torch.equal(before, ag.state_tensor) and all(torch.isfinite(o).all() for o in outs)
+
+
+def test_native_multi_population_rings_equal_chunked_pipeline(riab):
+    """save_history=False on some / all populations (and on the agent): their rates stream through a ring, one
+    native call per ring length; the newest rows, the saved histories of the others and the state are those of the
+    Python-driven pipeline."""
+    res = []
+    for native in (True, False):
+        os.environ["RIAB_NO_NATIVE"] = "0" if native else "1"
+        try:
+            env, ag, pops = _multi_world(riab, 128)
+            ag.save_history = False
+            for i, N in enumerate(pops):
+                N.save_history = i in (1, 3)          # BVCs and the noisy GridCells keep theirs; the FF layer reads a ring
+            ag.simulate(700)
+            ag.simulate(33)
+            torch.cuda.synchronize()
+            res.append(dict(state=ag.state_tensor.cpu().numpy(), last=[np.array(N.firingrate) for N in pops],
+                            hist=[np.array(N.history["firingrate"]) for i, N in enumerate(pops) if i in (1, 3)],
+                            nrows=[len(N.history["t"]) for N in pops], t=ag.t))
+            if native:
+                assert ag._streamer is not None and ag.diagnostics["pipeline_timeouts"] == 0
+        finally:
+            os.environ.pop("RIAB_NO_NATIVE", None)
+    a, b = res
+    np.testing.assert_array_equal(a["state"], b["state"])
+    assert a["t"] == b["t"] and a["nrows"] == b["nrows"] and a["nrows"][1] == 733 and a["nrows"][0] == 0
+    for x, y in zip(a["last"] + a["hist"], b["last"] + b["hist"]):
+        np.testing.assert_array_equal(x, y)
