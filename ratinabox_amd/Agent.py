@@ -398,6 +398,9 @@ class Agent:
         if self._plan is not None:
             self._plan.close()  # (before any history row is reserved: a plan's pending rows are not committed yet)
         self._auto_streak = 0
+        if int(n_steps) <= 0:   # nothing to do: an empty trajectory, no row reserved, no launch
+            assert int(n_steps) == 0, "n_steps must not be negative"
+            return torch.empty((0, _L.HIST_ROWS, self._Bp), dtype=torch.float32, device=self._device)
         if any(getattr(N, "_reads_agent_state", False) for N in neurons):
             # VelocityCells / SpeedCell read the float64 velocity STATE, which no history row keeps: such a run is
             # n_steps native plan steps (one motion launch + the rate launches per step, looped in C++)

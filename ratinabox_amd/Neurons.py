@@ -294,6 +294,8 @@ class Neurons:
         P = pos.shape[0]
         Pp = _pad4(P)
         self._last_P = P
+        if P == 0:  # no positions: an (n, 0) result, nothing to launch (the reference's broadcasting gives the same shape)
+            return torch.empty((int(self.n), 0), dtype=torch.float32, device=self._device)
         buf = np.zeros((4, Pp), dtype=np.float32)
         buf[0, :P], buf[1, :P] = pos[:, 0], pos[:, 1]
         buf[0, P:], buf[1, P:] = pos[0, 0], pos[0, 1]

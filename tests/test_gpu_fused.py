@@ -573,3 +573,35 @@ def test_native_multi_population_rings_equal_chunked_pipeline(riab):
     assert a["t"] == b["t"] and a["nrows"] == b["nrows"] and a["nrows"][1] == 733 and a["nrows"][0] == 0
     for x, y in zip(a["last"] + a["hist"], b["last"] + b["hist"]):
         np.testing.assert_array_equal(x, y)
+
+
+def test_empty_and_tiny_inputs(riab):
+    """Empty and ragged inputs: no positions -> (n, 0) rates; zero steps -> an empty trajectory and no history row;
+    one agent / an agent count that is not a multiple of four / 64 / one more than a wave, one cell, run lengths 1, 2, 7
+    through every path (fused, native multi-population, chunked, per-step)."""
+    env = riab.Environment({"walls": [[[0.5, 0.0], [0.5, 0.4]]]})
+    for B in (1, 3, 64, 65):
+        np.random.seed(1)
+        ag = riab.Agent(env, {"n_agents": B, "dt": 0.02})
+        pops = [riab.PlaceCells(ag, {"n": 1}), riab.GridCells(ag, {"n": 5}), riab.BoundaryVectorCells(ag, {"n": 3}),
+                riab.HeadDirectionCells(ag, {"n": 7})]
+        rows = 0
+        for n in (1, 0, 2, 7):
+            traj = ag.simulate(n)
+            assert traj.shape[0] == n
+            rows += n
+        for _ in range(6):
+            ag.update()
+            for p in pops:
+                p.update()
+        rows += 6
+        assert len(ag.history["t"]) == rows and np.asarray(ag.history["pos"]).shape[0] == rows
+        for p in pops:
+            fr = np.asarray(p.history["firingrate"])
+            assert fr.shape[:2] == (rows, int(p.n)) and np.isfinite(fr).all()
+            for P in (0, 1, 5):
+                out = p.get_state(evaluate_at=None, pos=np.full((P, 2), 0.3), head_direction=np.tile([0.0, 1.0], (P, 1)))
+                assert out.shape == (int(p.n), P) and np.isfinite(out).all()
+    solo = riab.Agent(env, {"n_agents": 256, "dt": 0.02})
+    pcs = riab.PlaceCells(solo, {"n": 4})
+    assert solo.simulate(0).shape[0] == 0 and len(solo.history["t"]) == 0 and solo._streamer is None
