@@ -388,12 +388,14 @@ class Agent:
         """`n_steps` x (Agent.update(); N.update() for N in neurons) without returning to
         Python between steps (new; the open-loop workload of SURVEY §7.3-1).
 
-        The trajectory kernel advances `chunk` steps per launch on one HIP stream; the
-        firing-rate kernels of every Neurons population consume each finished chunk
-        `[chunk, 8, B]` in place on a second stream, overlapping the next trajectory
-        chunk.  Histories land in HBM (`save_history=True`) exactly as `n_steps` calls of
-        update() would have left them.  Returns the trajectory history tensor of this call
-        `[n_steps, 8, B_padded]` (device)."""
+        One native call: the trajectory kernel publishes its history rows through flags in device
+        memory and the firing-rate kernels of the populations consume them on a second stream while it runs —
+        `riab_simulate_fused` for one store-bound population, `riab_simulate_pops` for any other covered set,
+        a native step plan for populations that read the agent's float64 state (VelocityCells).  What those do not
+        cover (AgentVectorCells, recurrent layers, explicit `noise=`, per-call motion kwargs, imported trajectories)
+        runs as trajectory chunks of `chunk` steps on one HIP stream with the rate kernels of each finished chunk on
+        a second one.  Histories land in HBM (`save_history=True`) exactly as `n_steps` calls of update() would have
+        left them.  Returns the trajectory history tensor of this call `[n_steps, 8, B_padded]` (device)."""
         neurons = list(self.Neurons if neurons is None else neurons)
         if self._plan is not None:
             self._plan.close()  # (before any history row is reserved: a plan's pending rows are not committed yet)
