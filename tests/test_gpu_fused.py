@@ -374,9 +374,16 @@ def test_unchanged_reference_loop_is_served_natively_and_bit_identical(riab, scr
 
 
 # ----------------------------------------------------------------------------- several populations, one native call
-def _multi_world(riab, B, seed=5):
+L_ROOM = [[0, 0], [1, 0], [1, 0.5], [0.5, 0.5], [0.5, 1], [0, 1]]
+
+
+def _multi_world(riab, B, seed=5, polygon=False):
     np.random.seed(seed)
-    env = riab.Environment({"walls": [[[0.5, 0.0], [0.5, 0.35]], [[0.2, 0.7], [0.6, 0.7]]]})
+    if polygon:   # an L-shaped room with a hole: the general wall arithmetic, re-sampling, the slow chunk ramp
+        env = riab.Environment({"boundary": L_ROOM, "holes": [[[0.15, 0.15], [0.3, 0.15], [0.3, 0.3], [0.15, 0.3]]],
+                                "walls": [[[0.7, 0.0], [0.7, 0.3]]]})
+    else:
+        env = riab.Environment({"walls": [[[0.5, 0.0], [0.5, 0.35]], [[0.2, 0.7], [0.6, 0.7]]]})
     env.add_object([0.3, 0.3], type=0)
     env.add_object([0.8, 0.6], type=1)
     ag = riab.Agent(env, {"n_agents": B, "dt": 0.02, "seed": 4})
@@ -392,8 +399,9 @@ def _multi_world(riab, B, seed=5):
     return env, ag, pops
 
 
-@pytest.mark.parametrize("B, schedule, drift", [(64, [20], None), (256, [150, 7], [0.05, -0.02]), (128, [300], None)])
-def test_native_multi_population_simulate_equals_chunked_pipeline(riab, B, schedule, drift):
+@pytest.mark.parametrize("B, schedule, drift, polygon", [(64, [20], None, False), (256, [150, 7], [0.05, -0.02], False),
+                                                        (128, [300], None, False), (128, [300, 40], None, True)])
+def test_native_multi_population_simulate_equals_chunked_pipeline(riab, B, schedule, drift, polygon):
     """Agent.simulate() with several populations is ONE native call (riab_simulate_pops: every chunk of rows behind a
     gate, each population's ordinary kernel, noise pass and spikes after it) and gives, bit for bit, what the
     Python-driven chunked pipeline gives: place / grid (+ OU noise) / head direction / boundary (allo- and egocentric) /
@@ -402,9 +410,7 @@ def test_native_multi_population_simulate_equals_chunked_pipeline(riab, B, sched
     for native in (True, False):
         os.environ["RIAB_NO_NATIVE"] = "0" if native else "1"
         try:
-            env, ag, pops = _multi_world(riab, B)
-            used = []
-            orig = riab._lib.lib.riab_simulate_pops
+            env, ag, pops = _multi_world(riab, B, polygon=polygon)
             for n in schedule:
                 ag.simulate(n, drift_velocity=drift)
             torch.cuda.synchronize()
@@ -425,7 +431,7 @@ def test_native_multi_population_simulate_equals_chunked_pipeline(riab, B, sched
         np.testing.assert_array_equal(la, lb)
         assert fa.shape[0] == sum(schedule) and np.isfinite(fa).all()
     # and the eager per-step loop continues from there on both
-    env, ag, pops = _multi_world(riab, B)
+    env, ag, pops = _multi_world(riab, B, polygon=polygon)
     ag.simulate(schedule[0], drift_velocity=drift)
     ag.update()
     for N in pops:
