@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RIAB_ABI_VERSION 3
+#define RIAB_ABI_VERSION 4
 #define RIAB_MAX_WALLS 64     /* walls staged in LDS by the motion / BVC / line-of-sight kernels */
 #define RIAB_MAX_TEST_ANGLES 360
 #define RIAB_STATE_ROWS 12    /* rows of the agent state matrix, see below */
@@ -43,7 +43,9 @@ enum {
   RIAB_EALIGN = -2,       /* B % 4 != 0 or misaligned row pointer */
   RIAB_ETOOBIG = -3,      /* more walls / test angles than the LDS staging allows */
   RIAB_EUNSUPPORTED = -4, /* combination not implemented on device */
-  RIAB_EFULL = -5         /* a step plan's history chunk has no free row left */
+  RIAB_EFULL = -5,        /* a step plan's history chunk has no free row left */
+  RIAB_EPARTIAL = -6      /* riab_simulate_*: a launch failed AFTER the trajectory kernel had been launched: the agent
+                             state and the trajectory rows have advanced T steps, the rates of this call are incomplete */
 };
 
 typedef void* riab_stream_t; /* hipStream_t */
@@ -577,11 +579,17 @@ double riab_plan_task_clock(const RiabPlan* plan);
  *  hist   device float32 [T][8][B], required (the rate kernel reads it in place)
  *  B      a multiple of 256 (four whole trajectory workgroups per rate wave)
  *  T      at most 65535 per call (time rows are the z axis of the rate kernel's grid)
- *  wgs_per_cu  unused (sized the resident grid of an earlier, persistent form of the rate kernel); pass 0
- *  mode   0: the rate kernel on the streamer's second stream behind a gate kernel that waits until every
- *            trajectory workgroup is resident (the rate kernel would otherwise be able to fill the chip
- *            with waiting waves before the kernel they wait for has been placed);
- *         1: both kernels on `stream`, the second launched with hipExtAnyOrderLaunch (experimental)
+ *  timing != 0: the rate kernel's launch carries start / stop events (riab_streamer_last_rate_ms)
+ *
+ * Residency.  Both kernels must be on the chip at once or the rate waves spin for nothing.  The trajectory kernel is
+ * launched first.  When `stream` is idle at the call (hipStreamQuery) it is dispatched at once and the rate kernel
+ * simply follows it; when work is queued in front of it, a one-wave gate kernel on the streamer's second stream holds
+ * the rate stage back until every trajectory workgroup of this launch is resident (the rate kernel could otherwise
+ * fill the chip with waiting waves before the kernel they wait for has been placed).  riab_streamer_configure(h,
+ * RIAB_STREAMER_OPT_ALWAYS_GATE, 1) forces the gate (callers that keep OTHER streams busy on the same device).
+ * Every wait is bounded; a wait that gives up sets ctrl[RIAB_CTRL_ABORT] and is counted in ctrl[RIAB_CTRL_TIMEOUTS].
+ * All argument checks run before the first launch: an argument error has launched nothing; a failure after the
+ * trajectory launch returns RIAB_EPARTIAL.
  * Returns RIAB_EUNSUPPORTED (nothing launched) for populations / shapes it does not cover: callers fall
  * back to riab_agent_step + the population's entry point. */
 enum { RIAB_CTRL_STARTED = 0, RIAB_CTRL_TIMEOUTS = 1, RIAB_CTRL_ABORT = 2, RIAB_CTRL_PROGRESS = 32 };
@@ -590,10 +598,14 @@ enum { RIAB_CTRL_STARTED = 0, RIAB_CTRL_TIMEOUTS = 1, RIAB_CTRL_ABORT = 2, RIAB_
 typedef struct RiabStreamer RiabStreamer;
 RiabStreamer* riab_streamer_create(void);
 void riab_streamer_destroy(RiabStreamer* h);
+/* options of a streamer: ALWAYS_GATE (0 / 1, default 0: see "Residency"); POLL_MAX (default 256): runs of more steps
+ * take the chunk form of the rate stage (the population's ordinary kernel per chunk of rows behind a progress gate) */
+enum { RIAB_STREAMER_OPT_ALWAYS_GATE = 0, RIAB_STREAMER_OPT_POLL_MAX = 1 };
+int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t value);
 int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
                         int64_t agent_id0, const double* drift, uint64_t seed, uint64_t step0, int32_t T,
                         float* hist, int32_t* diag, const struct RiabPopulation* pop, uint32_t* ctrl,
-                        int32_t wgs_per_cu, int32_t mode, int32_t timing, riab_stream_t stream);
+                        int32_t timing, riab_stream_t stream);
 /* The same pipeline for ANY ordered set of populations (n_pops structs, contiguous; a FeedForwardLayer's
  * input_index refers to EARLIER entries of this array): T x (Agent.update(); N.update() for N in pops) — the loop of
  * demos/simple_example.ipynb cell 4 with several populations — as one call.  The trajectory kernel publishes its rows
@@ -610,6 +622,12 @@ int riab_simulate_pops(RiabStreamer* h, const RiabEnv* env, const RiabMotion* mo
 /* with `timing` != 0 in the last riab_simulate_fused call: the duration of its rate kernel in ms (HIP events
  * on the stream the kernel ran on), after the caller has synchronised; < 0 if unavailable */
 float riab_streamer_last_rate_ms(RiabStreamer* h);
+
+/* Process-level host setting for latency-bound callers (one short simulate() per synchronisation, as in bench.py's
+ * 20-step region): on != 0 makes the calling thread SPIN on completion signals in hipDeviceSynchronize /
+ * hipStreamSynchronize (hipSetDeviceFlags(hipDeviceScheduleSpin)) instead of blocking in the driver after ~100 us of
+ * active waiting; 0 restores the runtime's default.  Affects the current device of the calling thread. */
+int riab_host_wait_spin(int32_t on);
 
 /* sizeof of the ABI's structs as compiled into the library (which: 0 RiabEnv, 1 RiabMotion, 2 RiabRateIO,
  * 3 RiabPopulation, 4 RiabTask, 5 RiabFFInput; 6 returns RIAB_TS_ROWS): bindings verify their mirrors at load */

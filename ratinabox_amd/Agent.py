@@ -491,6 +491,20 @@ class Agent:
         plan.close()
         return self._hist.stack()[len(self._hist) - n_steps:] if self.save_history else None
 
+    def _make_streamer(self):
+        """The native handle of the flag-coupled pipeline and its control words.  The words are zeroed ONCE, and the
+        zero-fill (an asynchronous kernel on the current stream) is waited for here: the gate and rate kernels run on
+        the streamer's own non-blocking stream, which nothing else orders behind that fill — without the wait they
+        could read a recycled block's old contents as started counts / progress / abort flags."""
+        h = _L.lib.riab_streamer_create()
+        if not h:
+            raise _L.RiabError("riab_streamer_create failed")
+        self._streamer = _L.C.c_void_p(h)
+        self._ctrl = torch.zeros(_L.ctrl_words(self._Bp), dtype=torch.int32, device=self._device)
+        torch.cuda.current_stream(self._device).synchronize()
+        if _L.env("RIAB_ALWAYS_GATE") == "1":  # A/B comparisons: the started gate in front of every rate kernel
+            _L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_ALWAYS_GATE, 1)
+
     # ---- fused path, one population: flag-coupled kernels, one native call (riab_simulate_fused) ----------------
     def _fused_eligible(self, neurons):
         """The trajectory kernel and the rate stage run concurrently, coupled by flags in device memory
@@ -509,11 +523,7 @@ class Agent:
         """One native call (riab_simulate_fused).  A 20-step run is ~80 us of GPU time: everything that is not needed
         to issue the call — views, clocks, mirrors — happens AFTER it, while the kernels run."""
         if self._streamer is None:
-            h = _L.lib.riab_streamer_create()
-            if not h:
-                raise _L.RiabError("riab_streamer_create failed")
-            self._streamer = _L.C.c_void_p(h)
-            self._ctrl = torch.zeros(_L.ctrl_words(self._Bp), dtype=torch.int32, device=self._device)
+            self._make_streamer()
         has_drift = drift_velocity is not None
         m = self._motion(dt, has_drift, ratio, {})
         env, _walls = self.Environment.device_tables(self._device)
@@ -538,8 +548,6 @@ class Agent:
             fr_c, fr_s = torch.empty((piece, n, Bp), dtype=torch.float32, device=self._device), 0
             sp_c, sp_s = None, 0
         piece = min(piece, 32768)  # (time rows are the z axis of the rate kernel's grid)
-        wgs = int(_L.env("RIAB_STREAM_WGS_PER_CU", 0))
-        mode = int(_L.env("RIAB_STREAM_MODE", 0))
         traj_p = traj_c.data_ptr() + traj_s * traj_row
         fr_p = fr_c.data_ptr() + fr_s * fr_row
         sp_p = sp_c.data_ptr() + sp_s * sp_row if sp_c is not None else None
@@ -554,7 +562,7 @@ class Agent:
             pop.spikes_base = sp_p + rows0 * sp_row if sp_p is not None else None
             pop.capacity_rows = tc
             rc = call(self._streamer, env, m, state_p, Bp, a0, drift_p, seed, step + t0, tc, traj_p + t0 * traj_row, diag_p,
-                      pop, ctrl_p, wgs, mode, timing, stream)
+                      pop, ctrl_p, timing, stream)
             if rc == _L.EUNSUPPORTED and t0 == 0:  # (nothing was launched; the chunked path reserves its own rows)
                 if self.save_history:
                     self._hist.unreserve(n_steps)
@@ -613,11 +621,7 @@ class Agent:
         except NotImplementedError:
             return None
         if self._streamer is None:
-            h = _L.lib.riab_streamer_create()
-            if not h:
-                raise _L.RiabError("riab_streamer_create failed")
-            self._streamer = _L.C.c_void_p(h)
-            self._ctrl = torch.zeros(_L.ctrl_words(self._Bp), dtype=torch.int32, device=self._device)
+            self._make_streamer()
         has_drift = drift_velocity is not None
         m = self._motion(dt, has_drift, ratio, {})
         env, _walls = self.Environment.device_tables(self._device)

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 
 from . import _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_WALLS = 64
 STATE_ROWS = 12
 HIST_ROWS = 8
@@ -91,6 +91,8 @@ POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4, "ff": 5, "velo
 EINVAL = -1
 EFULL = -5
 EUNSUPPORTED = -4
+EPARTIAL = -6
+STREAMER_OPT_ALWAYS_GATE, STREAMER_OPT_POLL_MAX = 0, 1
 CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_PROGRESS = 0, 1, 2, 32  # riab_hip.h RIAB_CTRL_*
 
 
@@ -167,11 +169,13 @@ PROTOTYPES = {
     "riab_streamer_destroy": (None, [C.c_void_p]),
     "riab_simulate_fused": (C.c_int, [C.c_void_p, C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
                                       C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p,
-                                      C.POINTER(RiabPopulation), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+                                      C.POINTER(RiabPopulation), C.c_void_p, C.c_int32, C.c_void_p]),
+    "riab_streamer_configure": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "riab_streamer_last_rate_ms": (C.c_float, [C.c_void_p]),
     "riab_simulate_pops": (C.c_int, [C.c_void_p, C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "riab_host_wait_spin": (C.c_int, [C.c_int32]),
     "riab_abi_sizeof": (C.c_int64, [C.c_int32]),
     "riab_abi_version": (C.c_int, []),
     "riab_strerror": (C.c_char_p, [C.c_int]),

@@ -780,8 +780,8 @@ static int place_dispatch(const RiabEnv* env, const RiabRateIO* io, const float*
 static thread_local hipEvent_t t_stream_ev0 = nullptr, t_stream_ev1 = nullptr;
 
 template <class Cell>
-static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamArgs& st, int T, bool spikes, bool plain_loads,
-                              bool any_order, hipStream_t s) {
+static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamArgs& st, int T, bool spikes, bool dry_run,
+                              hipStream_t s) {
   const hipEvent_t ev0 = t_stream_ev0, ev1 = t_stream_ev1;
   // Twice the wide kernel's cells per wave where the group's parameters still fit one wave (PlaceCells: 8): a gated
   // wave pays two dependent round trips to memory (progress words, then the write-through positions) before its
@@ -789,24 +789,22 @@ static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamA
   constexpr int CPB = (Cell::NP * 2 * Cell::CPB <= 64) ? 2 * Cell::CPB : Cell::CPB;
   const int64_t groups = (a.n + CPB - 1) / CPB;
   if (T > 65535 || groups > 65535) return RIAB_ETOOBIG;  // grid y / z limits: the caller splits longer runs
+  if (dry_run) return RIAB_OK;  // (every argument check is above: nothing is launched)
   const dim3 grid((unsigned)((a.qrow + 255) / 256), (unsigned)groups, (unsigned)T), block(256);
-  const unsigned flags = any_order ? hipExtAnyOrderLaunch : 0u;
-#define RIAB_GATED(SPKV, SC1V) \
-  hipExtLaunchKernelGGL((rate_kernel_gated<Cell, SPKV, CPB, SC1V>), grid, block, 0, s, ev0, ev1, flags, a, cell, st)
-  if (spikes) {
-    if (plain_loads) RIAB_GATED(1, false);
-    else RIAB_GATED(1, true);
+  // positions through agent-scope (sc1) loads: the producer's rows are written through
+  if (ev0 || ev1) {
+    if (spikes) hipExtLaunchKernelGGL((rate_kernel_gated<Cell, 1, CPB, true>), grid, block, 0, s, ev0, ev1, 0u, a, cell, st);
+    else hipExtLaunchKernelGGL((rate_kernel_gated<Cell, 0, CPB, true>), grid, block, 0, s, ev0, ev1, 0u, a, cell, st);
   } else {
-    if (plain_loads) RIAB_GATED(0, false);
-    else RIAB_GATED(0, true);
+    if (spikes) hipLaunchKernelGGL((rate_kernel_gated<Cell, 1, CPB, true>), grid, block, 0, s, a, cell, st);
+    else hipLaunchKernelGGL((rate_kernel_gated<Cell, 0, CPB, true>), grid, block, 0, s, a, cell, st);
   }
-#undef RIAB_GATED
   return (int)hipGetLastError();
 }
 
 template <int GX>
 static int launch_stream_place(const RiabEnv* env, const RiabPopulation* pop, const RateArgs& a, const StreamArgs& st, int T,
-                               bool spikes, bool plain_loads, bool any_order, hipStream_t s) {
+                               bool spikes, bool dry_run, hipStream_t s) {
   PlaceCell<RIAB_PC_GAUSSIAN, GX> c;
   c.tab = pop->table;
   c.scale = (float)env->scale;
@@ -819,12 +817,12 @@ static int launch_stream_place(const RiabEnv* env, const RiabPopulation* pop, co
   c.shape = make_env_shape(env);
   c.lds = nullptr;
   switch (pop->description) {
-    case RIAB_PC_GAUSSIAN: return launch_stream_cell(a, c, st, T, spikes, plain_loads, any_order, s);
+    case RIAB_PC_GAUSSIAN: return launch_stream_cell(a, c, st, T, spikes, dry_run, s);
     case RIAB_PC_GAUSSIAN_THRESHOLD:
-      return launch_stream_cell(a, c.template as<RIAB_PC_GAUSSIAN_THRESHOLD>(), st, T, spikes, plain_loads, any_order, s);
+      return launch_stream_cell(a, c.template as<RIAB_PC_GAUSSIAN_THRESHOLD>(), st, T, spikes, dry_run, s);
     case RIAB_PC_DIFF_OF_GAUSSIANS:
-      return launch_stream_cell(a, c.template as<RIAB_PC_DIFF_OF_GAUSSIANS>(), st, T, spikes, plain_loads, any_order, s);
-    case RIAB_PC_TOP_HAT: return launch_stream_cell(a, c.template as<RIAB_PC_TOP_HAT>(), st, T, spikes, plain_loads, any_order, s);
+      return launch_stream_cell(a, c.template as<RIAB_PC_DIFF_OF_GAUSSIANS>(), st, T, spikes, dry_run, s);
+    case RIAB_PC_TOP_HAT: return launch_stream_cell(a, c.template as<RIAB_PC_TOP_HAT>(), st, T, spikes, dry_run, s);
     default: return RIAB_EUNSUPPORTED;  // one_hot scans every cell per position: not a streaming shape
   }
 }
@@ -847,8 +845,8 @@ int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B) {
 }
 
 int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t T, float dt,
-                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, bool plain_loads,
-                       uint32_t spin_limit, bool any_order, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, uint32_t spin_limit, hipStream_t s,
+                       hipEvent_t ev_start, hipEvent_t ev_stop, bool dry_run) {
   struct EventScope {
     EventScope(hipEvent_t a, hipEvent_t b) { t_stream_ev0 = a; t_stream_ev1 = b; }
     ~EventScope() { t_stream_ev0 = t_stream_ev1 = nullptr; }
@@ -886,26 +884,26 @@ int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const floa
   const bool spikes = pop->spikes_base != nullptr;
   switch (pop->kind) {
     case RIAB_POP_PLACE:
-      if (env->periodic) return launch_stream_place<3>(env, pop, a, st, T, spikes, plain_loads, any_order, s);
+      if (env->periodic) return launch_stream_place<3>(env, pop, a, st, T, spikes, dry_run, s);
       switch (pop->geometry) {
-        case RIAB_GEOM_EUCLIDEAN: return launch_stream_place<0>(env, pop, a, st, T, spikes, plain_loads, any_order, s);
-        case RIAB_GEOM_LINE_OF_SIGHT: return launch_stream_place<1>(env, pop, a, st, T, spikes, plain_loads, any_order, s);
-        case RIAB_GEOM_GEODESIC: return launch_stream_place<2>(env, pop, a, st, T, spikes, plain_loads, any_order, s);
+        case RIAB_GEOM_EUCLIDEAN: return launch_stream_place<0>(env, pop, a, st, T, spikes, dry_run, s);
+        case RIAB_GEOM_LINE_OF_SIGHT: return launch_stream_place<1>(env, pop, a, st, T, spikes, dry_run, s);
+        case RIAB_GEOM_GEODESIC: return launch_stream_place<2>(env, pop, a, st, T, spikes, dry_run, s);
         default: return RIAB_EINVAL;
       }
     case RIAB_POP_GRID:
       if (pop->description == RIAB_GC_RECTIFIED) {
         GridCell<RIAB_GC_RECTIFIED> c{pop->table, pop->f0, 1.0f / (1.0f - pop->f0)};
-        return launch_stream_cell(a, c, st, T, spikes, plain_loads, any_order, s);
+        return launch_stream_cell(a, c, st, T, spikes, dry_run, s);
       }
       if (pop->description == RIAB_GC_SHIFTED) {
         GridCell<RIAB_GC_SHIFTED> c{pop->table, pop->f0, 1.0f};
-        return launch_stream_cell(a, c, st, T, spikes, plain_loads, any_order, s);
+        return launch_stream_cell(a, c, st, T, spikes, dry_run, s);
       }
       return RIAB_EINVAL;
     case RIAB_POP_HDC: {
       HDCell<0> c{pop->table, 0.0f, nullptr, nullptr};
-      return launch_stream_cell(a, c, st, T, spikes, plain_loads, any_order, s);
+      return launch_stream_cell(a, c, st, T, spikes, dry_run, s);
     }
     default: return RIAB_EUNSUPPORTED;
   }
@@ -1111,6 +1109,7 @@ extern "C" const char* riab_strerror(int code) {
     case RIAB_ETOOBIG: return "too many walls / test angles for the LDS staging";
     case RIAB_EUNSUPPORTED: return "combination not supported on device";
     case RIAB_EFULL: return "a step plan's history chunk is full: attach a new chunk";
+    case RIAB_EPARTIAL: return "a launch failed after the trajectory kernel had been launched: the state has advanced, the rates of this call are incomplete";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown riab error";
   }
 }

@@ -24,8 +24,8 @@ namespace riab {
 int launch_agent_pub(const AgentArgs& a, hipStream_t s);
 int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
 int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t T, float dt,
-                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, bool plain_loads,
-                       uint32_t spin_limit, bool any_order, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
+                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, uint32_t spin_limit, hipStream_t s,
+                       hipEvent_t ev_start, hipEvent_t ev_stop, bool dry_run);
 int launch_stream_gate(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj, uint32_t progress_target,
                        uint32_t spin_limit, bool sleep_long, hipStream_t s);
 int launch_rate_rows(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t t0, int32_t tc,
@@ -41,6 +41,8 @@ struct RiabStreamer {
   bool timed;
   uint32_t started_total;    // trajectory workgroups launched so far through this object (wraps like the device word)
   int cus;                   // compute units of the device the object was created on
+  int always_gate;           // RIAB_STREAMER_OPT_ALWAYS_GATE
+  int poll_max;              // RIAB_STREAMER_OPT_POLL_MAX
 };
 
 extern "C" RiabStreamer* riab_streamer_create(void) {
@@ -51,6 +53,8 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
   h->timed = false;
   h->n_pairs = 0;
   h->started_total = 0;
+  h->always_gate = 0;
+  h->poll_max = 256;
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
@@ -61,6 +65,18 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
   }
   h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   return h;
+}
+
+extern "C" int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t value) {
+  if (!h) return RIAB_EINVAL;
+  switch (option) {
+    case RIAB_STREAMER_OPT_ALWAYS_GATE: h->always_gate = value != 0; return RIAB_OK;
+    case RIAB_STREAMER_OPT_POLL_MAX:
+      if (value < 0 || value > 65535) return RIAB_EINVAL;
+      h->poll_max = value;
+      return RIAB_OK;
+    default: return RIAB_EINVAL;
+  }
 }
 
 extern "C" void riab_streamer_destroy(RiabStreamer* h) {
@@ -91,9 +107,8 @@ extern "C" float riab_streamer_last_rate_ms(RiabStreamer* h) {
 extern "C" int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
                                    int64_t agent_id0, const double* drift, uint64_t seed, uint64_t step0, int32_t T,
                                    float* hist, int32_t* diag, const RiabPopulation* pop, uint32_t* ctrl,
-                                   int32_t wgs_per_cu, int32_t mode, int32_t timing, riab_stream_t stream) {
+                                   int32_t timing, riab_stream_t stream) {
   if (!h || !pop || !ctrl || !hist) return RIAB_EINVAL;
-  if (mode != 0 && mode != 1) return RIAB_EINVAL;
   int rc = riab::stream_supported(env, pop, B);
   if (rc) return rc;
   riab::AgentArgs a;
@@ -102,80 +117,86 @@ extern "C" int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const Ri
   if (rc) return rc;
   a.ctrl = ctrl;
   hipStream_t main_s = (hipStream_t)stream;
-  const bool any_order = mode == 1;
-  hipStream_t rate_s = any_order ? main_s : h->side;
+  hipStream_t rate_s = h->side;
   // ~0.3 us per poll: a generous second or two before a wait gives up (a healthy wait is tens of microseconds)
   const uint32_t spin_limit = 1u << 20;
-  (void)wgs_per_cu;  // (sized a resident grid when the rate kernel was persistent; see riab_rates.hip)
-  const bool plain_loads = getenv("RIAB_GATED_PLAIN") != nullptr;  // experiment: positions through plain loads
+  const bool chunks = T > h->poll_max;
+  // Every argument check of the rate stage runs BEFORE the trajectory kernel is launched (a dry run of the launch
+  // path): a call that returns an argument error has launched nothing and advanced no state.
+  if (!chunks) {
+    rc = riab::launch_rate_stream(env, pop, hist, B, T, (float)motion->dt, seed, step0, agent_id0, ctrl, spin_limit, rate_s,
+                                  nullptr, nullptr, /*dry_run=*/true);
+    if (rc) return rc;
+  } else if (T > 65535) {
+    return RIAB_ETOOBIG;
+  }
   if (timing && !h->t0) {
     if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess) return RIAB_EINVAL;
   }
   h->timed = false;
   h->n_pairs = 0;
-  // The trajectory kernel goes first, with no host work in front of it.  The side stream needs no event to order
-  // it behind what is queued on `stream`: its first kernel is the gate, which returns only once every trajectory
-  // workgroup of THIS launch is resident — and the trajectory kernel starts after everything queued before it.
+  // Both kernels must be resident at once or the rate waves spin for nothing.  When the caller's stream is idle the
+  // trajectory kernel — launched first — is dispatched at once, ahead of the rate kernel that follows it by one
+  // launch call (~5 us of host time), and no gate is needed.  When work is queued in front of it, a one-wave gate on
+  // the side stream holds the rate stage back until every trajectory workgroup of THIS launch has announced itself:
+  // the rate waves can then never occupy the slots the kernel they wait for still needs.  (The side stream needs no
+  // event to order it behind what is queued on `stream`: the progress words it waits for are only written by this
+  // launch's trajectory kernel.)
+  const bool gate = h->always_gate || hipStreamQuery(main_s) != hipSuccess;
   rc = riab::launch_agent_pub(a, main_s);
   if (rc) return rc;
   const uint32_t n_traj = (uint32_t)(B / 64);
   h->started_total += n_traj;
-  // Two forms of the rate stage (mode 0):
-  //  * up to RIAB_STREAM_POLL_MAX steps: ONE rate kernel for all rows whose waves wait for their rows themselves
-  //    (rate_kernel_gated): it follows the trajectory at a distance of one four-step block, which is what a short
+  // From here on the state has advanced: a later failure still joins the side stream and is reported as
+  // RIAB_EPARTIAL (the trajectory rows are complete, the rates of this call are not).
+  // Two forms of the rate stage:
+  //  * up to `poll_max` (256) steps: ONE rate kernel for all rows whose waves wait for their rows themselves
+  //    (rate_kernel_gated): it follows the trajectory at a distance of one block of steps, which is what a short
   //    run needs; its per-wave poll costs ~15 % of the store bandwidth;
   //  * longer runs: the population's ordinary kernel per chunk of rows, each chunk behind a progress gate (one
   //    wave) on the same stream — full store bandwidth, at the price of a chunk of distance to the trajectory
-  //    (the first chunks are short) and a gate + launch boundary (~5 us) per chunk.
-  int poll_max = 256;
-  if (const char* e = getenv("RIAB_STREAM_POLL_MAX")) poll_max = atoi(e);
-  const bool chunks = !any_order && T > poll_max;
-  if (!any_order) {
-    // (the started gate is one sleeping wave; it may have to sit out whatever was queued on `stream`: ~1 min)
-    rc = riab::launch_stream_gate(ctrl, h->started_total, 0, 0, 1u << 24, true, rate_s);
-    if (rc) return rc;
-  }
+  //    (the first chunks are short) and a gate + launch boundary (~5 us) per chunk.  (A progress gate also waits
+  //    for the started count: no separate started gate.)
+  int fail = RIAB_OK;
   if (!chunks) {
-    // (timed through the launch's own start / stop events: the kernel's duration as rocprofv3 reports it, not the
-    // ~10 us between the gate's end and the kernel's start)
-    rc = riab::launch_rate_stream(env, pop, hist, B, T, (float)motion->dt, seed, step0, agent_id0, ctrl, plain_loads,
-                                  spin_limit, any_order, rate_s, timing ? h->t0 : nullptr, timing ? h->t1 : nullptr);
-    if (rc) return rc;
-    if (timing) h->timed = true;
+    // (the started gate is one sleeping wave; it may have to sit out whatever was queued on `stream`: ~1 min)
+    if (gate) fail = riab::launch_stream_gate(ctrl, h->started_total, 0, 0, 1u << 24, true, rate_s);
+    // (timed through the launch's own start / stop events: the kernel's duration as rocprofv3 reports it)
+    if (!fail)
+      fail = riab::launch_rate_stream(env, pop, hist, B, T, (float)motion->dt, seed, step0, agent_id0, ctrl, spin_limit,
+                                      rate_s, timing ? h->t0 : nullptr, timing ? h->t1 : nullptr, false);
+    if (!fail && timing) h->timed = true;
   } else {
     if (timing) (void)hipEventRecord(h->t0, rate_s);
     const bool box_room = !env->polygon && !env->hole_mask && !env->periodic && env->n_walls >= 4;
     int32_t t0 = 0, k = 0;
-    while (t0 < T) {
+    while (t0 < T && !fail) {
       // A chunk should be finished by the trajectory when the stream gets to its gate.  In a solid rectangular room
-      // (the trajectory kernel's box fast path: ~1.8 us per step next to the rate kernels, which need ~2.7 us per
-      // row) the trajectory pulls away and a chunk may be ~1.5x its predecessor; in other rooms it advances ~2.8 us
-      // per step and ~1.25x is the most (a 16, 16, 32, 64, 128 ramp then spent 230 us of a 1024-step run inside the
-      // gates [MI355X, rocprofv3 trace]).  Larger chunks are cheaper per row (3.6 us at 16 rows, 2.7 at 128) and
-      // every chunk costs a gate (~5 us).
+      // the trajectory pulls away from the rate kernels (which need ~2.7 us per row) and a chunk may be ~1.5x its
+      // predecessor; in other rooms ~1.25x is the most (a 16, 16, 32, 64, 128 ramp then spent 230 us of a 1024-step
+      // run inside the gates [MI355X, rocprofv3 trace]).  Larger chunks are cheaper per row (3.6 us at 16 rows, 2.7 at
+      // 128) and every chunk costs a gate (~5 us).
       static const int32_t ramp_fast[5] = {16, 28, 44, 64, 96};
       static const int32_t ramp_slow[10] = {16, 16, 20, 24, 32, 40, 48, 64, 80, 96};
       int32_t tc = box_room ? (k < 5 ? ramp_fast[k] : 128) : (k < 10 ? ramp_slow[k] : 128);
       if (tc > T - t0 || T - t0 - tc < 32) tc = T - t0;  // (no sliver at the end)
-      // ~0.5 us per poll: seconds before a gate gives up (a healthy wait is one chunk of trajectory, < 1 ms)
-      rc = riab::launch_stream_gate(ctrl, h->started_total, n_traj, (uint32_t)step0 + (uint32_t)(t0 + tc), 1u << 22, false,
-                                    rate_s);
-      if (rc) return rc;
-      rc = riab::launch_rate_rows(env, pop, hist, B, t0, tc, (float)motion->dt, seed, step0, agent_id0, rate_s);
-      if (rc) return rc;
+      // ~0.5 us per poll: seconds before a gate gives up (a healthy wait is one chunk of trajectory, < 1 ms); the
+      // first gate may also have to sit out what is queued in front of the trajectory kernel
+      fail = riab::launch_stream_gate(ctrl, h->started_total, n_traj, (uint32_t)step0 + (uint32_t)(t0 + tc),
+                                      k == 0 ? 1u << 24 : 1u << 22, false, rate_s);
+      if (!fail) fail = riab::launch_rate_rows(env, pop, hist, B, t0, tc, (float)motion->dt, seed, step0, agent_id0, rate_s);
       t0 += tc;
       ++k;
     }
-    if (timing) {  // (the whole stage: gates and chunk kernels)
+    if (!fail && timing) {  // (the whole stage: gates and chunk kernels)
       (void)hipEventRecord(h->t1, rate_s);
       h->timed = true;
     }
   }
-  if (!any_order) {
-    hipError_t e = hipEventRecord(h->join, h->side);
-    if (e == hipSuccess) e = hipStreamWaitEvent(main_s, h->join, 0);
-    if (e != hipSuccess) return (int)e;
-  }
+  hipError_t e = hipEventRecord(h->join, h->side);
+  if (e == hipSuccess) e = hipStreamWaitEvent(main_s, h->join, 0);
+  if (fail) return RIAB_EPARTIAL;
+  if (e != hipSuccess) return (int)e;
   return RIAB_OK;
 }
 
@@ -307,29 +328,39 @@ extern "C" int riab_simulate_pops(RiabStreamer* h, const RiabEnv* env, const Ria
   if (rc) return rc;
   const uint32_t n_traj = (uint32_t)(B / 64);
   h->started_total += n_traj;
-  rc = riab::launch_stream_gate(ctrl, h->started_total, 0, 0, 1u << 24, true, rate_s);
-  if (rc) return rc;
+  // (from here on the state has advanced: a later failure still joins the side stream and returns RIAB_EPARTIAL.
+  // The first progress gate also waits until every trajectory workgroup of this launch is resident — it may have to
+  // sit out what is queued in front of the trajectory kernel — so there is no separate started gate.)
+  int fail = RIAB_OK;
   int32_t t0 = 0;
-  for (size_t k = 0; k < sched.size(); ++k) {
+  for (size_t k = 0; k < sched.size() && !fail; ++k) {
     const int32_t tc = sched[k];
-    rc = riab::launch_stream_gate(ctrl, h->started_total, n_traj, (uint32_t)step0 + (uint32_t)(t0 + tc), 1u << 22, false, rate_s);
-    if (rc) return rc;
-    for (int i = 0; i < n_pops; ++i) {
+    fail = riab::launch_stream_gate(ctrl, h->started_total, n_traj, (uint32_t)step0 + (uint32_t)(t0 + tc),
+                                    k == 0 ? 1u << 24 : 1u << 22, false, rate_s);
+    for (int i = 0; i < n_pops && !fail; ++i) {
       if (timing && i == timed_pop) (void)hipEventRecord(h->pairs[2 * k], rate_s);
-      rc = launch_pop_rows(env, pops, i, hist, B, t0, tc, (float)motion->dt, seed, step0, agent_id0, rate_s);
-      if (rc) return rc;
+      fail = launch_pop_rows(env, pops, i, hist, B, t0, tc, (float)motion->dt, seed, step0, agent_id0, rate_s);
       if (timing && i == timed_pop) (void)hipEventRecord(h->pairs[2 * k + 1], rate_s);
     }
     t0 += tc;
   }
-  if (timing) {
+  if (!fail && timing) {
     h->n_pairs = (int)sched.size();
     h->timed = true;
   }
   hipError_t e = hipEventRecord(h->join, h->side);
   if (e == hipSuccess) e = hipStreamWaitEvent(main_s, h->join, 0);
+  if (fail) return RIAB_EPARTIAL;
   if (e != hipSuccess) return (int)e;
   return RIAB_OK;
+}
+
+extern "C" int riab_host_wait_spin(int32_t on) {
+  // hipDeviceScheduleSpin: the host thread spins on the completion signal in hipDeviceSynchronize / hipStreamSynchronize
+  // instead of blocking in the kernel driver after ~100 us of active waiting (the default): a region of a few kernels
+  // ends 10-20 us sooner from the host's point of view, at the price of a busy core while it waits.
+  const hipError_t e = hipSetDeviceFlags(on ? hipDeviceScheduleSpin : hipDeviceScheduleAuto);
+  return e == hipSuccess ? RIAB_OK : (int)e;
 }
 
 extern "C" int64_t riab_abi_sizeof(int32_t which) {

@@ -158,16 +158,17 @@ def test_fused_without_history_keeps_last_rows(riab):
     np.testing.assert_array_equal(res[0][1], res[1][1])
 
 
-@pytest.mark.parametrize("mode", ["0", "1"])
-def test_fused_launch_modes(riab, mode):
-    """Both ways of getting the two kernels to run concurrently (second stream behind a gate kernel / one stream
-    with an any-order launch) give the same, correct results; whether they overlap is a performance matter."""
-    os.environ["RIAB_STREAM_MODE"] = mode
+@pytest.mark.parametrize("gate", ["0", "1"])
+def test_fused_launch_modes(riab, gate):
+    """The rate kernel straight behind the trajectory kernel (the caller's stream is idle at the call) and behind the
+    started gate (forced here; taken automatically when work is queued in front of the trajectory kernel) give the
+    same, correct results."""
+    os.environ["RIAB_ALWAYS_GATE"] = gate
     try:
         t_a, fr_a, _sp, ag_a = _run(riab, True, 1024, _pc(256, save_spikes=False), [("sim", 48), ("sim", 16)])
         assert ag_a.diagnostics["pipeline_timeouts"] == 0
     finally:
-        os.environ.pop("RIAB_STREAM_MODE", None)
+        os.environ.pop("RIAB_ALWAYS_GATE", None)
     t_b, fr_b, _sp, _ag = _run(riab, False, 1024, _pc(256, save_spikes=False), [("sim", 48), ("sim", 16)])
     np.testing.assert_array_equal(t_a, t_b)
     np.testing.assert_array_equal(fr_a, fr_b)
