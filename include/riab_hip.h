@@ -582,11 +582,11 @@ double riab_plan_task_clock(const RiabPlan* plan);
  *  timing != 0: the rate kernel's launch carries start / stop events (riab_streamer_last_rate_ms)
  *
  * Residency.  Both kernels must be on the chip at once or the rate waves spin for nothing.  The trajectory kernel is
- * launched first.  When `stream` is idle at the call (hipStreamQuery) it is dispatched at once and the rate kernel
- * simply follows it; when work is queued in front of it, a one-wave gate kernel on the streamer's second stream holds
- * the rate stage back until every trajectory workgroup of this launch is resident (the rate kernel could otherwise
- * fill the chip with waiting waves before the kernel they wait for has been placed).  riab_streamer_configure(h,
- * RIAB_STREAMER_OPT_ALWAYS_GATE, 1) forces the gate (callers that keep OTHER streams busy on the same device).
+ * launched first, and a one-wave gate kernel on the streamer's second stream holds the rate stage back until every
+ * trajectory workgroup of this launch is resident (the rate kernel could otherwise fill the chip with waiting waves
+ * before the kernel they wait for has been placed — it did, with two processes sharing one GPU).
+ * riab_streamer_configure(h, RIAB_STREAMER_OPT_GATE, RIAB_GATE_WHEN_BUSY) drops the gate when `stream` is idle at the
+ * call (hipStreamQuery): for callers that own the device.
  * Every wait is bounded; a wait that gives up sets ctrl[RIAB_CTRL_ABORT] and is counted in ctrl[RIAB_CTRL_TIMEOUTS].
  * All argument checks run before the first launch: an argument error has launched nothing; a failure after the
  * trajectory launch returns RIAB_EPARTIAL.
@@ -598,9 +598,11 @@ enum { RIAB_CTRL_STARTED = 0, RIAB_CTRL_TIMEOUTS = 1, RIAB_CTRL_ABORT = 2, RIAB_
 typedef struct RiabStreamer RiabStreamer;
 RiabStreamer* riab_streamer_create(void);
 void riab_streamer_destroy(RiabStreamer* h);
-/* options of a streamer: ALWAYS_GATE (0 / 1, default 0: see "Residency"); POLL_MAX (default 256): runs of more steps
- * take the chunk form of the rate stage (the population's ordinary kernel per chunk of rows behind a progress gate) */
-enum { RIAB_STREAMER_OPT_ALWAYS_GATE = 0, RIAB_STREAMER_OPT_POLL_MAX = 1 };
+/* options of a streamer: GATE (RIAB_GATE_ALWAYS, the default, or RIAB_GATE_WHEN_BUSY: see "Residency"); POLL_MAX
+ * (default 256): runs of more steps take the chunk form of the rate stage (the population's ordinary kernel per chunk
+ * of rows behind a progress gate) */
+enum { RIAB_STREAMER_OPT_GATE = 0, RIAB_STREAMER_OPT_POLL_MAX = 1 };
+enum { RIAB_GATE_ALWAYS = 0, RIAB_GATE_WHEN_BUSY = 1 };
 int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t value);
 int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
                         int64_t agent_id0, const double* drift, uint64_t seed, uint64_t step0, int32_t T,

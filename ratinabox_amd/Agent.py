@@ -52,6 +52,9 @@ class Agent:
     }
 
     AUTO_AFTER = 4   # plain update() calls in a row before the per-step loop is served from a native plan
+    AUTO_AFTER_MAX = 1024  # ... after back-off: a stepper that served fewer than AUTO_KEEP steps before something
+    AUTO_KEEP = 4          #     closed it doubles the wait for the next one (a loop that edits a weight every step
+                           #     would otherwise rebuild a plan every five steps for nothing)
 
     def __init__(self, Environment, params={}):
         self.params = copy.deepcopy(__class__.default_params)
@@ -92,7 +95,8 @@ class Agent:
         self._scratch_row = None
         self._last_row = None   # newest fp32 history row; None when the state was edited from the host
         self._plan = None       # an active StepPlan (plan.py), if any
-        self._auto_streak = 0   # consecutive plain update() calls (plan.AutoStepper engages after AUTO_AFTER)
+        self._auto_streak = 0   # consecutive plain update() calls (plan.AutoStepper engages after _auto_after)
+        self._auto_after = self.AUTO_AFTER
         self._auto_enabled = os.environ.get("RIAB_NO_AUTO_PLAN") != "1"
         self._streamer = None   # native handle of the flag-coupled pipeline (created on first use)
         self._ctrl = None       # its control words on the device
@@ -295,7 +299,7 @@ class Agent:
                 st.close()
             elif st is None:
                 self._auto_streak += 1
-                if self._auto_streak > self.AUTO_AFTER and self._device.type == "cuda":
+                if self._auto_streak > self._auto_after and self._device.type == "cuda":
                     try:
                         if _AutoStepper(self).step_agent(drift_velocity, drift_to_random_strength_ratio):
                             return
@@ -502,8 +506,8 @@ class Agent:
         self._streamer = _L.C.c_void_p(h)
         self._ctrl = torch.zeros(_L.ctrl_words(self._Bp), dtype=torch.int32, device=self._device)
         torch.cuda.current_stream(self._device).synchronize()
-        if _L.env("RIAB_ALWAYS_GATE") == "1":  # A/B comparisons: the started gate in front of every rate kernel
-            _L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_ALWAYS_GATE, 1)
+        if _L.env("RIAB_GATE_WHEN_BUSY") == "1":  # this process owns the device: no started gate while the stream is idle
+            _L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_GATE, _L.GATE_WHEN_BUSY)
 
     # ---- fused path, one population: flag-coupled kernels, one native call (riab_simulate_fused) ----------------
     def _fused_eligible(self, neurons):

@@ -60,12 +60,25 @@ class DeviceHistory:
         self.chunks.append(torch.empty((T, *self.row_shape), dtype=self.dtype, device=self.device))
         self.filled.append(0)
 
+    def free_rows(self):
+        """Rows left in the current chunk (0: the next reservation opens a new chunk)."""
+        return self.chunks[-1].shape[0] - self.filled[-1] if self.chunks else 0
+
     def open_rows(self, T):
-        """A writable view of T free rows that are NOT yet counted as history (a step plan writes
-        them one by one); `commit(n)` then publishes the first n of them."""
-        self.preallocate(T)
+        """A writable view of UP TO T free rows that are NOT yet counted as history (a step plan writes them one by
+        one); `commit(n)` then publishes the first n of them.  A non-empty free tail of the current chunk is handed
+        out as it is, however short (the caller re-opens when it is used up): a plan that is closed and rebuilt —
+        the automatic stepper does that whenever a non-plain call interrupts the loop — continues in the rows its
+        predecessor left instead of abandoning them behind a new chunk.  Only a full chunk is followed by a new one
+        of T rows."""
+        T = int(T)
+        free = self.free_rows()
+        if free <= 0:
+            self.chunks.append(torch.empty((T, *self.row_shape), dtype=self.dtype, device=self.device))
+            self.filled.append(0)
+            free = T
         s = self.filled[-1]
-        return self.chunks[-1][s:s + int(T)]
+        return self.chunks[-1][s:s + min(T, free)]
 
     def commit(self, n):
         if n:

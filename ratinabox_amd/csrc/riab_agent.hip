@@ -1,6 +1,7 @@
 // Agent.update on gfx950: the C ABI entry point of the motion kernel (riab_agent_kernel.h) and the step
 // plan's fused motion + task launch.
 #include "riab_agent_kernel.h"
+#include "riab_traj4_kernel.h"
 #include "riab_task_kernel.h"  // (after the motion kernel: this header turns fp contraction off for its own code)
 
 namespace riab {
@@ -47,12 +48,16 @@ int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* 
   return (int)hipGetLastError();
 }
 
-// The publishing variant of the trajectory kernel (riab_simulate_fused): Philox noise, float64, helper wave;
-// a.ctrl carries the control words.  Whole waves only (B % 64 == 0), any T.
+// The publishing variant of the trajectory kernel (riab_simulate_*): float64, four waves per 64 agents
+// (riab_traj4_kernel.h), Philox noise or explicit normals (a.z_in); a.ctrl carries the control words.  Whole waves
+// only (B % 64 == 0), any T.  RIAB_TRAJ2=1 (A/B comparisons): the two-wave kernel of round 1 (Philox only).
 int launch_agent_pub(const AgentArgs& a, hipStream_t s) {
-  if (!a.ctrl || !a.hist || a.z_in || a.z_out || a.forced || a.B % 64 != 0) return RIAB_EINVAL;
+  if (!a.ctrl || !a.hist || a.forced || a.B % 64 != 0) return RIAB_EINVAL;
   const dim3 grid((unsigned)(a.B / 64));
-  hipLaunchKernelGGL((agent_step_kernel<double, 0, true, true>), grid, dim3(128), 0, s, a);
+  static const bool two_wave = getenv("RIAB_TRAJ2") != nullptr;
+  if (two_wave && !a.z_in && !a.z_out) hipLaunchKernelGGL((agent_step_kernel<double, 0, true, true>), grid, dim3(128), 0, s, a);
+  else if (a.z_in) hipLaunchKernelGGL((traj4_kernel<1, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((traj4_kernel<0, true>), grid, dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -73,9 +78,14 @@ extern "C" int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, dou
   const int in = forced_pos ? 2 : (z_in ? 1 : 0);
   // long Philox launches of whole waves get the helper wave (no lane may leave before the workgroup
   // barriers, and z_out is written by the stepping wave of the single-wave kernel only)
-  const bool pc = in == 0 && precision == 64 && T >= 2 * RIAB_Z_BATCH && B % 64 == 0 && !z_out && !getenv("RIAB_NO_PC");
+  static const bool no_pc = getenv("RIAB_NO_PC") != nullptr, two_wave = getenv("RIAB_TRAJ2") != nullptr;
+  const bool pc = in == 0 && precision == 64 && T >= 2 * RIAB_Z_BATCH && B % 64 == 0 && !z_out && !no_pc && two_wave;
+  // multi-step float64 launches of whole waves: one agent's step over four specialised waves (riab_traj4_kernel.h)
+  const bool t4 = in != 2 && precision == 64 && T >= 8 && B % 64 == 0 && !no_pc && !two_wave;
   if (precision == 64) {
-    if (pc) hipLaunchKernelGGL((agent_step_kernel<double, 0, true>), grid, dim3(128), 0, s, a);
+    if (t4 && in == 0) hipLaunchKernelGGL((traj4_kernel<0, false>), grid, dim3(256), 0, s, a);
+    else if (t4) hipLaunchKernelGGL((traj4_kernel<1, false>), grid, dim3(256), 0, s, a);
+    else if (pc) hipLaunchKernelGGL((agent_step_kernel<double, 0, true>), grid, dim3(128), 0, s, a);
     else if (in == 0) hipLaunchKernelGGL((agent_step_kernel<double, 0, false>), grid, dim3(64), 0, s, a);
     else if (in == 1) hipLaunchKernelGGL((agent_step_kernel<double, 1, false>), grid, dim3(64), 0, s, a);
     else hipLaunchKernelGGL((agent_step_kernel<double, 2, false>), grid, dim3(64), 0, s, a);

@@ -41,7 +41,7 @@ struct RiabStreamer {
   bool timed;
   uint32_t started_total;    // trajectory workgroups launched so far through this object (wraps like the device word)
   int cus;                   // compute units of the device the object was created on
-  int always_gate;           // RIAB_STREAMER_OPT_ALWAYS_GATE
+  int gate_mode;             // RIAB_STREAMER_OPT_GATE
   int poll_max;              // RIAB_STREAMER_OPT_POLL_MAX
 };
 
@@ -53,7 +53,7 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
   h->timed = false;
   h->n_pairs = 0;
   h->started_total = 0;
-  h->always_gate = 0;
+  h->gate_mode = RIAB_GATE_ALWAYS;
   h->poll_max = 256;
   int dev = 0;
   hipDeviceProp_t prop;
@@ -70,7 +70,10 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
 extern "C" int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t value) {
   if (!h) return RIAB_EINVAL;
   switch (option) {
-    case RIAB_STREAMER_OPT_ALWAYS_GATE: h->always_gate = value != 0; return RIAB_OK;
+    case RIAB_STREAMER_OPT_GATE:
+      if (value != RIAB_GATE_ALWAYS && value != RIAB_GATE_WHEN_BUSY) return RIAB_EINVAL;
+      h->gate_mode = value;
+      return RIAB_OK;
     case RIAB_STREAMER_OPT_POLL_MAX:
       if (value < 0 || value > 65535) return RIAB_EINVAL;
       h->poll_max = value;
@@ -135,14 +138,15 @@ extern "C" int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const Ri
   }
   h->timed = false;
   h->n_pairs = 0;
-  // Both kernels must be resident at once or the rate waves spin for nothing.  When the caller's stream is idle the
-  // trajectory kernel — launched first — is dispatched at once, ahead of the rate kernel that follows it by one
-  // launch call (~5 us of host time), and no gate is needed.  When work is queued in front of it, a one-wave gate on
-  // the side stream holds the rate stage back until every trajectory workgroup of THIS launch has announced itself:
-  // the rate waves can then never occupy the slots the kernel they wait for still needs.  (The side stream needs no
-  // event to order it behind what is queued on `stream`: the progress words it waits for are only written by this
-  // launch's trajectory kernel.)
-  const bool gate = h->always_gate || hipStreamQuery(main_s) != hipSuccess;
+  // Both kernels must be resident at once or the rate waves spin for nothing: the trajectory kernel is launched first,
+  // and a one-wave gate on the side stream holds the rate stage back until every trajectory workgroup of THIS launch
+  // has announced itself — the rate waves can then never occupy the slots the kernel they wait for still needs,
+  // whatever else is queued on this stream or running on the device (another stream, another process: two ranks
+  // sharing one GPU without the gate ran into the waits' time limit).  The gate costs < 1 us of a 20-step region
+  // [MI355X: 119.0 vs 118.2 us]; RIAB_GATE_WHEN_BUSY drops it when the caller's stream is idle at the call (for
+  // callers that own the device).  (The side stream needs no event to order it behind what is queued on `stream`:
+  // the words it waits for are only written by this launch's trajectory kernel.)
+  const bool gate = h->gate_mode == RIAB_GATE_ALWAYS || hipStreamQuery(main_s) != hipSuccess;
   rc = riab::launch_agent_pub(a, main_s);
   if (rc) return rc;
   const uint32_t n_traj = (uint32_t)(B / 64);

@@ -104,11 +104,20 @@ class StepPlan:
         self._attach()
 
     # ---- history chunks --------------------------------------------------------------------------
-    def _attach(self):
-        """Open `capacity` fresh rows in every history and hand their base pointers to the plan."""
+    def _attach(self, need=1):
+        """Open up to `capacity` free rows in every history — the same number in each: what the shortest non-empty
+        free tail holds, at least `need` (the rows of one step() call are contiguous: a tail shorter than that is left
+        behind) — and hand their base pointers to the plan."""
         self.sync()
         ag = self.agent
+        hists = ([ag._hist] if ag.save_history else []) + [h for N in self.neurons if N.save_history
+                                                            for h in ((N._hist_fr, N._hist_sp) if N.save_spikes else (N._hist_fr,))]
         cap = self.capacity
+        for h in hists:
+            if 0 < h.free_rows() < need:
+                h.preallocate(cap)
+            if h.free_rows() > 0:
+                cap = min(cap, h.free_rows())
         if ag.save_history:
             self._agent_rows = ag._hist.open_rows(cap)
             _L.check(_L.lib.riab_plan_set_agent_history(self._h, _L.ptr(self._agent_rows), cap), "riab_plan_set_agent_history")
@@ -184,7 +193,7 @@ class StepPlan:
         if n_steps > self._rows_open:
             if n_steps > self.capacity:
                 raise ValueError(f"n_steps {n_steps} exceeds the plan's chunk capacity {self.capacity}")
-            self._attach()
+            self._attach(need=n_steps)
         if self._forced is not None:   # the agent follows its imported trajectory: positions of the coming steps
             if drift_velocity is not None or self._task_env is not None:
                 raise NotImplementedError("an agent on an imported trajectory takes neither a drift velocity nor a task")
@@ -316,25 +325,34 @@ class AutoStepper:
 
     # ---- history chunks -------------------------------------------------------------------------
     def _attach(self):
+        self._attach_agent()
+        for i in range(len(self.neurons)):
+            self._attach_pop(i)
+
+    def _attach_agent(self):
+        """Open history rows for the agent (what is left of the current chunk, else a new chunk) — the agent's only:
+        a full agent chunk does not touch the populations' part-filled ones."""
         self.sync()
-        ag, cap = self.agent, self.CAPACITY
+        ag = self.agent
         if ag.save_history:
-            self._agent_rows = ag._hist.open_rows(cap)
-            rc = _L.lib.riab_plan_set_agent_history(self._h, _L.ptr(self._agent_rows), cap)
+            self._agent_rows = ag._hist.open_rows(self.CAPACITY)
+            rc = _L.lib.riab_plan_set_agent_history(self._h, _L.ptr(self._agent_rows), int(self._agent_rows.shape[0]))
         else:
             self._agent_rows = None
             rc = _L.lib.riab_plan_set_agent_history(self._h, None, 0)
         _L.check(rc, "riab_plan_set_agent_history")
         self._a_done = 0
-        for i in range(len(self.neurons)):
-            self._attach_pop(i)
 
     def _attach_pop(self, i):
         N, ag = self.neurons[i], self.agent
         self._sync_pop(i)
         if N.save_history:
             cap = int(max(64, min(self.CAPACITY, self.CHUNK_BYTES // max(1, int(N.n) * ag._Bp * 4))))
+            if N.save_spikes:  # (rates and spikes advance together; should their free tails differ, the shorter one counts)
+                tails = [h.free_rows() for h in (N._hist_fr, N._hist_sp) if h.free_rows() > 0]
+                cap = min([cap] + tails)
             fr = N._hist_fr.open_rows(cap)
+            cap = int(fr.shape[0])
             sp = N._hist_sp.open_rows(cap) if N.save_spikes else None
             self._pop_rows[i] = (fr, sp)
             rc = _L.lib.riab_plan_set_population_history(self._h, i, _L.ptr(fr), _L.ptr(sp), cap)
@@ -376,7 +394,7 @@ class AutoStepper:
             self._forced.ensure(1, self._dt)
         rc = _L.lib.riab_plan_step_agent(self._h, _L.current_stream())
         if rc == _L.EFULL:
-            self._attach()
+            self._attach_agent()
             rc = _L.lib.riab_plan_step_agent(self._h, _L.current_stream())
         _L.check(rc, "riab_plan_step_agent")
         if self._forced is not None:
@@ -386,6 +404,7 @@ class AutoStepper:
         ag._step_index += 1
         self._a_pending += 1
         self._a_times.append(ag.t)
+        self._served = getattr(self, "_served", 0) + 1
         return True
 
     def _write_drift(self, x):
@@ -460,9 +479,16 @@ class AutoStepper:
 
     def close(self):
         self.sync()
-        if self.agent._plan is self:
-            self.agent._plan = None
-        self.agent._auto_streak = 0
+        ag = self.agent
+        if ag._plan is self:
+            ag._plan = None
+        ag._auto_streak = 0
+        # back-off: a stepper that was closed after a handful of steps was not worth recording
+        served = getattr(self, "_served", 0)
+        if served < ag.AUTO_KEEP:
+            ag._auto_after = min(2 * max(ag._auto_after, 1), ag.AUTO_AFTER_MAX)
+        else:
+            ag._auto_after = ag.AUTO_AFTER
         if self._h:
             _L.lib.riab_plan_destroy(self._h)
             self._h = None

@@ -158,17 +158,17 @@ def test_fused_without_history_keeps_last_rows(riab):
     np.testing.assert_array_equal(res[0][1], res[1][1])
 
 
-@pytest.mark.parametrize("gate", ["0", "1"])
-def test_fused_launch_modes(riab, gate):
-    """The rate kernel straight behind the trajectory kernel (the caller's stream is idle at the call) and behind the
-    started gate (forced here; taken automatically when work is queued in front of the trajectory kernel) give the
+@pytest.mark.parametrize("when_busy", ["0", "1"])
+def test_fused_launch_modes(riab, when_busy):
+    """The rate kernel behind the started gate (the default) and straight behind the trajectory kernel (an option
+    for callers that own the device: the gate only when work is queued in front of the trajectory kernel) give the
     same, correct results."""
-    os.environ["RIAB_ALWAYS_GATE"] = gate
+    os.environ["RIAB_GATE_WHEN_BUSY"] = when_busy
     try:
         t_a, fr_a, _sp, ag_a = _run(riab, True, 1024, _pc(256, save_spikes=False), [("sim", 48), ("sim", 16)])
         assert ag_a.diagnostics["pipeline_timeouts"] == 0
     finally:
-        os.environ.pop("RIAB_ALWAYS_GATE", None)
+        os.environ.pop("RIAB_GATE_WHEN_BUSY", None)
     t_b, fr_b, _sp, _ag = _run(riab, False, 1024, _pc(256, save_spikes=False), [("sim", 48), ("sim", 16)])
     np.testing.assert_array_equal(t_a, t_b)
     np.testing.assert_array_equal(fr_a, fr_b)

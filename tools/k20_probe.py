@@ -68,7 +68,7 @@ def main():
                 ag._time_rate_kernel = timing
                 fresh(ag, pops)
                 ag.simulate(K)
-                L.lib.riab_streamer_configure(ag._streamer, L.STREAMER_OPT_ALWAYS_GATE, gate)
+                L.lib.riab_streamer_configure(ag._streamer, L.STREAMER_OPT_GATE, 0 if gate else 1)
                 measure(ag, pops, "spin=%d timing=%d gate=%s" % (spin, timing, "always" if gate else "auto"))
                 del ag, pops
                 torch.cuda.empty_cache()
