@@ -181,6 +181,9 @@ def main():
                     help="strong scaling: the config's agents are the TOTAL, split over the ranks (default: weak scaling, "
                          "the config's agents per GPU)")
     ap.add_argument("--no-history", action="store_true", help="ring buffers instead of a full T-long history")
+    ap.add_argument("--event-timing", action="store_true",
+                    help="time the one-kernel rate stage with HIP start / stop events on its launch instead of the "
+                         "device clock stamps")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -256,12 +259,16 @@ def main():
         args.chunk = K if K <= 64 else max(32, (K // 4 + 3) // 4 * 4)
 
     plan = {"p": None}
-    fused_mode = not (args.per_step or args.plan) and ag._fused_eligible(pops)
-    # several populations: the same pipeline through riab_simulate_pops (every chunk of rows behind a gate, one native
+    native = not (args.per_step or args.plan) and os.environ.get("RIAB_NO_NATIVE") != "1" and ag.precision == 64
+    # one store-bound population: the one-kernel form of riab_simulate's rate stage (its waves wait for their rows)
+    fused_mode = (native and len(pops) == 1 and pops[0]._stream_kind is not None and pops[0].noise_std == 0
+                  and ag._Bp % 256 == 0 and os.environ.get("RIAB_NO_FUSED") != "1")
+    # anything else: the chunk form (every chunk of rows behind a gate, each population's ordinary kernel; one native
     # call per timed region); the events then bracket every launch of the DOMINANT population's kernel
-    native_mode = (not (args.per_step or args.plan) and not fused_mode
-                   and os.environ.get("RIAB_NO_NATIVE") != "1" and ag.precision == 64 and ag._Bp % 64 == 0)
-    ag._time_rate_kernel = fused_mode or native_mode
+    native_mode = native and not fused_mode
+    # the one-kernel form is timed by the device's own clock (first wave's start / last wave's end, no host cost);
+    # --event-timing attaches HIP start / stop events to the launch instead (~7 us of host time per region)
+    ag._time_rate_kernel = ("events" if args.event_timing else True) if (fused_mode or native_mode) else False
 
     def run(n_steps):
         if args.plan:
@@ -344,6 +351,20 @@ def main():
         if fused_mode or native_mode:
             kernel_ms.append(ag.last_rate_kernel_ms())
             kernel_units.append(getattr(ag, "_last_fused_units", B * K))  # (rings: the last ring-length piece of the run)
+    # cross-check of the device-clock timing of the one-kernel rate stage: a few more regions — not part of `value` —
+    # with HIP start / stop events attached to the kernel's launch (what rocprofv3 would report for it)
+    event_ms = []
+    if fused_mode and K <= 256 and ag._time_rate_kernel is True:
+        ag._time_rate_kernel = "events"
+        for _r in range(3):
+            fresh_history(K)
+            torch.cuda.synchronize()
+            run(K)
+            torch.cuda.synchronize()
+            m = ag.last_rate_kernel_ms()
+            if m is not None:
+                event_ms.append(m)
+        ag._time_rate_kernel = True
     el = torch.tensor(elapsed, dtype=torch.float64)
     if dist is not None:
         el = el.to("cpu" if ctrl_on_cpu else "cuda")
@@ -380,11 +401,11 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = round(json.load(f).get("hbm_bytes_per_unit") * avg_units)  # PMC bytes/unit x units/launch
-        poll_max = int(os.environ.get("RIAB_STREAM_POLL_MAX", 256))
+        poll_max = 256
         kname = (("rate_kernel_gated" if K <= poll_max else "rate stage = rate_kernel_wide per chunk behind progress gates")
                  if fused_mode else "rate_kernel_wide") + f"<{type(dominant).__name__}>"
         if native_mode:
-            kname = f"every launch of {type(dominant).__name__}'s kernel in one riab_simulate_pops call (chunks of rows behind gates)"
+            kname = f"every launch of {type(dominant).__name__}'s kernel in one riab_simulate call (chunks of rows behind gates)"
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": kname, "launches": len(ms),
@@ -411,6 +432,15 @@ def main():
             roofline["note"] = ("`avg_launch_ms` is the SUM of the kernel's launches of one timed region (HIP events around each "
                                 "launch on the stream it runs on, riab_streamer_last_rate_ms), `units_per_launch` the agent-"
                                 "steps of the region; rocprofv3's per-launch average x launches per region is the same sum")
+        if fused_mode and K <= 256:
+            roofline["timed_by"] = ("HIP start / stop events attached to the kernel's launch (hipExtLaunchKernel)"
+                                    if ag._time_rate_kernel == "events" else
+                                    "the device's constant clock (s_memrealtime) read by the kernel's first-row waves at "
+                                    "their start and its last-row waves after their stores: no host-side cost in the "
+                                    "timed region; `avg_launch_ms_hip_events`: the same kernel in extra regions with HIP "
+                                    "start / stop events on its launch")
+            if event_ms:
+                roofline["avg_launch_ms_hip_events"] = round(float(np.mean(event_ms)), 5)
         if fused_mode:
             roofline["note"] = ("the rate stage runs concurrently with the trajectory kernel whose rows it consumes (coupled "
                                 "by flags in device memory, one native call per timed region): its duration includes "
@@ -445,7 +475,7 @@ def main():
                if args.task else "step plan (one native call per step)" if args.plan else "per-step update()"
                if args.per_step else "simulate(): trajectory kernel + rate stage running concurrently, coupled by flags in device memory, one native call"
                if fused_mode else "simulate(): trajectory kernel + every population's kernels per chunk of rows behind gates, "
-               "one native call (riab_simulate_pops)" if native_mode
+               "one native call (riab_simulate)" if native_mode
                else f"simulate(): chunked two-stream pipeline, {args.chunk} steps/launch")
         out = {
             "metric": metric_name(cfg),

@@ -551,78 +551,100 @@ int riab_plan_set_task(RiabPlan* plan, const RiabTask* task, double* task_state,
 double riab_plan_task_clock(const RiabPlan* plan);
 
 /* ---- the open-loop path as ONE native call: flag-coupled trajectory + firing-rate kernels -------
- * `for t in range(T): Agent.update(); N.update()` (demos/simple_example.ipynb cell 4) for one
- * population N, with no kernel boundary between the two stages: the trajectory kernel (the
- * riab_agent_step kernel in Philox mode, float64) publishes its history rows write-through and a
- * per-workgroup "steps done" word every four steps; the firing-rate kernel, launched once for all T
- * rows and running concurrently, lets every wave wait on those words and evaluates time row t as soon
- * as the 256 agents of the wave have been stepped past t.  Results are bit-identical to riab_agent_step followed by the
- * population's own entry point on the finished trajectory.
+ * `for t in range(T): Agent.update(); [N.update() for N in Neurons]` (demos/simple_example.ipynb cell 4;
+ * Agent.update: ratinabox/Agent.py:160-242, Neurons.update: ratinabox/Neurons.py:145-171) with no kernel boundary
+ * between the two stages: the trajectory kernel (float64, one agent's step spread over four specialised waves,
+ * csrc/riab_traj4_kernel.h) writes its history rows through to memory and publishes a per-workgroup "steps done"
+ * word; the firing-rate stage runs concurrently and consumes the rows as they appear.  Results are bit-identical to
+ * T calls of riab_agent_step(T = 1) each followed by the populations' own entry points.
  *
- * A RiabStreamer owns what the coupling needs besides the kernels: a second HIP stream, two
- * events, and the running count of started trajectory workgroups.
+ * Two forms of the rate stage, chosen by the call:
+ *  - ONE population of kind RIAB_POP_PLACE (not one_hot) / RIAB_POP_GRID / RIAB_POP_HDC without OU noise, B a
+ *    multiple of 256 and T <= POLL_MAX (256): one rate kernel for all T rows whose waves each wait until the 256
+ *    agents of the wave have been stepped past their row;
+ *  - anything else (several populations, boundary / object vector cells, random spatial neurons, speed cell,
+ *    FeedForwardLayers — input_index refers to EARLIER entries of `pops` —, OU noise, spikes; longer runs): per chunk
+ *    of rows (16, 28, 44, ... 128) a one-wave gate that waits for the chunk's last row, then each population's
+ *    ordinary kernel in array order (noise pass and spikes after it, as in riab_plan_step).
+ * forced_pos != NULL (Agent.import_trajectory / forced_next_position, Agent.py:229-266): there is no recurrence to
+ * overlap: the forced-position kernel and the populations' kernels follow each other on `stream`.
+ * Velocity cells (they read the float64 state, which no history row keeps) are not covered: RIAB_EUNSUPPORTED,
+ * nothing launched; callers advance them through a step plan.
  *
- *  ctrl   device uint32 [RIAB_CTRL_WORDS(B)], zeroed ONCE by the caller when it is created
- *         (not per call: progress words hold absolute step counts, the started word accumulates):
- *         [RIAB_CTRL_STARTED] trajectory workgroups that have become resident (all calls),
+ * A RiabStreamer owns what the coupling needs besides the kernels: a second HIP stream (the trajectory kernel runs
+ * there; the rate stage — which ends last — on `stream`, so that a host synchronisation returns as soon after the
+ * last kernel as after any single kernel), two events, and the running count of started trajectory workgroups.
+ *
+ *  ctrl   device uint32 [RIAB_CTRL_WORDS(B)], zeroed ONCE by the caller when it is created (and that zero-fill
+ *         complete before the first call: the kernels that read the words run on the streamer's stream too):
+ *         [RIAB_CTRL_STARTED] trajectory workgroups that have become resident (all calls; progress words hold
+ *         absolute step counts, the started word accumulates),
  *         [RIAB_CTRL_TIMEOUTS] waves that gave up waiting (must stay 0; results are invalid otherwise),
  *         [RIAB_CTRL_ABORT] set with the first timeout: every later wait returns at once,
+ *         [RIAB_CTRL_STAMPS .. +3] two uint64: device clock at the first wave's start / the last wave's end of the
+ *         rate kernel of the last call timed with RIAB_TIMING_STAMPS,
  *         [RIAB_CTRL_PROGRESS_WORD(w)] (uint32)(step0 + steps whose rows trajectory workgroup w (agents 64w ..
  *         64w+63) has published).  The four words of a 256-agent sub-segment share one 128-byte line that no
  *         other sub-segment touches: every wave of the rate kernel reads exactly one such line, and with all of
  *         them in ONE line (first layout) that line — rewritten by 64 workgroups every few microseconds, so
  *         never served from L2 — throttled the rate kernel to 2.3 TB/s while the trajectory kernel ran [MI355X].
- *  pop    the population: kind RIAB_POP_PLACE (not one_hot) / RIAB_POP_GRID / RIAB_POP_HDC, its table and
- *         parameters, io.min_fr / max_fr / pop_id, rates_base [capacity_rows][n][B] and spikes_base (or NULL);
- *         capacity_rows >= T (callers that stream through fewer rows issue one call per buffer length: inside
- *         a call the rate waves are several time rows apart, so rows of one call must not alias).
- *  hist   device float32 [T][8][B], required (the rate kernel reads it in place)
- *  B      a multiple of 256 (four whole trajectory workgroups per rate wave)
- *  T      at most 65535 per call (time rows are the z axis of the rate kernel's grid)
- *  timing != 0: the rate kernel's launch carries start / stop events (riab_streamer_last_rate_ms)
+ *  pops   n_pops structs, contiguous: kind, table and parameters, io.min_fr / max_fr / pop_id, rates_base
+ *         [capacity_rows][n][B] and spikes_base (or NULL) = row 0 of this call; capacity_rows >= T (callers that
+ *         stream through fewer rows issue one call per buffer length: inside a call the rate waves are several
+ *         time rows apart, so rows of one call must not alias)
+ *  hist   device float32 [T][8][B], required (the rate kernels read it in place)
+ *  B      a multiple of 4 (256 for the one-kernel form)
+ *  noise  explicit standard normals [T][2][B] (rotation OU, speed OU) instead of the in-kernel Philox draws, or NULL
+ *  timed_pop >= 0: that population's kernels are timed (riab_streamer_last_rate_ms afterwards): chunk form: HIP
+ *         events around every launch, summed; one-kernel form: timing_mode RIAB_TIMING_STAMPS = the device's
+ *         constant clock read by the kernel's first and last waves (no host cost), RIAB_TIMING_EVENTS = start / stop
+ *         events attached to the launch (hipExtLaunchKernel; ~7 us of host time in front of the kernel)
  *
  * Residency.  Both kernels must be on the chip at once or the rate waves spin for nothing.  The trajectory kernel is
- * launched first, and a one-wave gate kernel on the streamer's second stream holds the rate stage back until every
- * trajectory workgroup of this launch is resident (the rate kernel could otherwise fill the chip with waiting waves
- * before the kernel they wait for has been placed — it did, with two processes sharing one GPU).
- * riab_streamer_configure(h, RIAB_STREAMER_OPT_GATE, RIAB_GATE_WHEN_BUSY) drops the gate when `stream` is idle at the
- * call (hipStreamQuery): for callers that own the device.
+ * launched first, and a one-wave gate kernel in front of the rate stage holds it back until every trajectory
+ * workgroup of this launch is resident (the rate kernel could otherwise fill the chip with waiting waves before
+ * the kernel they wait for has been placed — it did, with two processes sharing one GPU).
+ * riab_streamer_configure(h, RIAB_STREAMER_OPT_GATE, RIAB_GATE_WHEN_BUSY) drops the gate of the one-kernel form when
+ * `stream` is idle at the call (hipStreamQuery): for callers that own the device.
  * Every wait is bounded; a wait that gives up sets ctrl[RIAB_CTRL_ABORT] and is counted in ctrl[RIAB_CTRL_TIMEOUTS].
  * All argument checks run before the first launch: an argument error has launched nothing; a failure after the
- * trajectory launch returns RIAB_EPARTIAL.
- * Returns RIAB_EUNSUPPORTED (nothing launched) for populations / shapes it does not cover: callers fall
- * back to riab_agent_step + the population's entry point. */
-enum { RIAB_CTRL_STARTED = 0, RIAB_CTRL_TIMEOUTS = 1, RIAB_CTRL_ABORT = 2, RIAB_CTRL_PROGRESS = 32 };
+ * trajectory launch returns RIAB_EPARTIAL. */
+enum { RIAB_CTRL_STARTED = 0, RIAB_CTRL_TIMEOUTS = 1, RIAB_CTRL_ABORT = 2, RIAB_CTRL_STAMPS = 8, RIAB_CTRL_PROGRESS = 32 };
 #define RIAB_CTRL_PROGRESS_WORD(w) (RIAB_CTRL_PROGRESS + 32 * ((w) >> 2) + ((w) & 3))
 #define RIAB_CTRL_WORDS(B) (RIAB_CTRL_PROGRESS + 32 * (((B) + 255) / 256))
+enum { RIAB_TIMING_STAMPS = 0, RIAB_TIMING_EVENTS = 1 };
+typedef struct RiabSimulate {
+  const RiabEnv* env;
+  const RiabMotion* motion;
+  double* state;              /* [RIAB_STATE_ROWS][B] */
+  int64_t B;
+  int64_t agent_id0;
+  const double* drift;        /* [2][B] or NULL */
+  const double* noise;        /* [T][2][B] or NULL */
+  const double* forced_pos;   /* [T][2][B] or NULL */
+  const double* resample_pos; /* [T][2][B] or NULL: replacement positions of the resample boundary condition */
+  uint64_t seed;
+  uint64_t step0;
+  int32_t T;
+  int32_t n_pops;
+  const struct RiabPopulation* pops;
+  float* hist;
+  int32_t* diag;
+  uint32_t* ctrl;
+  int32_t timed_pop;
+  int32_t timing_mode;
+} RiabSimulate;
 typedef struct RiabStreamer RiabStreamer;
 RiabStreamer* riab_streamer_create(void);
 void riab_streamer_destroy(RiabStreamer* h);
 /* options of a streamer: GATE (RIAB_GATE_ALWAYS, the default, or RIAB_GATE_WHEN_BUSY: see "Residency"); POLL_MAX
- * (default 256): runs of more steps take the chunk form of the rate stage (the population's ordinary kernel per chunk
- * of rows behind a progress gate) */
+ * (default 256): longer runs take the chunk form of the rate stage */
 enum { RIAB_STREAMER_OPT_GATE = 0, RIAB_STREAMER_OPT_POLL_MAX = 1 };
 enum { RIAB_GATE_ALWAYS = 0, RIAB_GATE_WHEN_BUSY = 1 };
 int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t value);
-int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
-                        int64_t agent_id0, const double* drift, uint64_t seed, uint64_t step0, int32_t T,
-                        float* hist, int32_t* diag, const struct RiabPopulation* pop, uint32_t* ctrl,
-                        int32_t timing, riab_stream_t stream);
-/* The same pipeline for ANY ordered set of populations (n_pops structs, contiguous; a FeedForwardLayer's
- * input_index refers to EARLIER entries of this array): T x (Agent.update(); N.update() for N in pops) — the loop of
- * demos/simple_example.ipynb cell 4 with several populations — as one call.  The trajectory kernel publishes its rows
- * as in riab_simulate_fused; on the streamer's second stream every chunk of rows (16, 28, 44, ... 128) waits behind a
- * one-wave gate and is then consumed by each population's ordinary kernel in array order (noise pass and spikes
- * after it, as in riab_plan_step).  Every population needs rows for the whole run (capacity_rows >= T; rates_base /
- * spikes_base = row 0 of this call).  Velocity cells (they read the float64 state) are not covered: RIAB_EUNSUPPORTED,
- * nothing launched.  timed_pop >= 0: HIP events around every launch of that population; their sum is what
- * riab_streamer_last_rate_ms returns afterwards.  B a multiple of 64. */
-int riab_simulate_pops(RiabStreamer* h, const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
-                       int64_t agent_id0, const double* drift, uint64_t seed, uint64_t step0, int32_t T, float* hist,
-                       int32_t* diag, const struct RiabPopulation* pops, int32_t n_pops, uint32_t* ctrl,
-                       int32_t timed_pop, riab_stream_t stream);
-/* with `timing` != 0 in the last riab_simulate_fused call: the duration of its rate kernel in ms (HIP events
- * on the stream the kernel ran on), after the caller has synchronised; < 0 if unavailable */
+int riab_simulate(RiabStreamer* h, const RiabSimulate* run, riab_stream_t stream);
+/* after a riab_simulate call with timed_pop >= 0 and after the caller has synchronised: the duration of the timed
+ * population's kernel(s) in ms; < 0 if unavailable */
 float riab_streamer_last_rate_ms(RiabStreamer* h);
 
 /* Process-level host setting for latency-bound callers (one short simulate() per synchronisation, as in bench.py's
@@ -632,7 +654,8 @@ float riab_streamer_last_rate_ms(RiabStreamer* h);
 int riab_host_wait_spin(int32_t on);
 
 /* sizeof of the ABI's structs as compiled into the library (which: 0 RiabEnv, 1 RiabMotion, 2 RiabRateIO,
- * 3 RiabPopulation, 4 RiabTask, 5 RiabFFInput; 6 returns RIAB_TS_ROWS): bindings verify their mirrors at load */
+ * 3 RiabPopulation, 4 RiabTask, 5 RiabFFInput, 7 RiabSimulate; 6 returns RIAB_TS_ROWS): bindings verify their mirrors at
+ * load */
 int64_t riab_abi_sizeof(int32_t which);
 
 /* Streaming-store calibration kernel: writes `bytes` bytes (multiple of 16) of

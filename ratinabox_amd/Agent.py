@@ -99,6 +99,7 @@ class Agent:
         self._auto_after = self.AUTO_AFTER
         self._auto_enabled = os.environ.get("RIAB_NO_AUTO_PLAN") != "1"
         self._streamer = None   # native handle of the flag-coupled pipeline (created on first use)
+        self._run_struct = None  # its argument block (RiabSimulate), reused from call to call
         self._ctrl = None       # its control words on the device
         self._pipeline_unchecked = False
         self._time_rate_kernel = False
@@ -173,7 +174,7 @@ class Agent:
             self._ctrl[_L.CTRL_TIMEOUTS] = 0
             self._ctrl[_L.CTRL_ABORT] = 0
             raise _L.RiabError(f"the flag-coupled simulate() pipeline was aborted ({n} waits timed out): the rows of "
-                               f"that run are incomplete (RIAB_NO_FUSED=1 selects the chunked pipeline)")
+                               f"that run are incomplete (RIAB_NO_NATIVE=1 selects the Python-driven chunk pipeline)")
 
     def _download(self, row, width):
         self._check_pipeline()
@@ -332,29 +333,8 @@ class Agent:
         m = self._motion(dt, has_drift, ratio, kwargs)
         env, _walls = self.Environment.device_tables(self._device)
         drift = self._as_device_f64(drift_velocity, 2) if has_drift else None
-        z = None
-        if noise is not None:
-            zt = noise if torch.is_tensor(noise) else torch.as_tensor(np.asarray(noise, dtype=np.float64))
-            zt = zt.to(self._device, torch.float64)
-            if T == 1 and zt.dim() == 2:
-                zt = zt.unsqueeze(0)
-            if zt.shape[-1] == 2 and zt.shape[-2] != 2:
-                zt = zt.transpose(-1, -2)
-            if zt.shape[-1] != self._Bp:  # pad agents
-                pad = zt[..., :1].expand(*zt.shape[:-1], self._Bp - zt.shape[-1])
-                zt = torch.cat((zt, pad), dim=-1)
-            z = zt.contiguous()
-            assert z.shape == (T, 2, self._Bp), f"noise must be (T,2,B), got {tuple(z.shape)}"
-        rs = None
-        if resample is not None:
-            # where agents that end a step in a hole / outside a polygonal boundary are put (parity runs: the
-            # reference's np.random draws); (T, B, 2) / (B, 2) / (2,)
-            r = np.asarray(resample, dtype=np.float64)
-            r = np.broadcast_to(r.reshape((1,) * (3 - r.ndim) + r.shape) if r.ndim < 3 else r, (T, self._B, 2))
-            full = np.empty((T, 2, self._Bp))
-            full[:, :, :self._B] = np.transpose(r, (0, 2, 1))
-            full[:, :, self._B:] = full[:, :, :1]
-            rs = torch.from_numpy(full).to(self._device)
+        z = self._noise_tensor(noise, T) if noise is not None else None
+        rs = self._resample_tensor(resample, T) if resample is not None else None
         if hist_view is None and self.save_history:
             hist_view = self._hist.reserve(T)
         if hist_view is None:
@@ -392,14 +372,15 @@ class Agent:
         """`n_steps` x (Agent.update(); N.update() for N in neurons) without returning to
         Python between steps (new; the open-loop workload of SURVEY §7.3-1).
 
-        One native call: the trajectory kernel publishes its history rows through flags in device
-        memory and the firing-rate kernels of the populations consume them on a second stream while it runs —
-        `riab_simulate_fused` for one store-bound population, `riab_simulate_pops` for any other covered set,
-        a native step plan for populations that read the agent's float64 state (VelocityCells).  What those do not
-        cover (AgentVectorCells, recurrent layers, explicit `noise=`, per-call motion kwargs, imported trajectories)
-        runs as trajectory chunks of `chunk` steps on one HIP stream with the rate kernels of each finished chunk on
-        a second one.  Histories land in HBM (`save_history=True`) exactly as `n_steps` calls of update() would have
-        left them.  Returns the trajectory history tensor of this call `[n_steps, 8, B_padded]` (device)."""
+        One native call (`riab_simulate`): the trajectory kernel publishes its history rows through
+        flags in device memory and the firing-rate kernels of the populations consume them while it runs — one gated
+        rate kernel for a single store-bound population, every population's kernels per chunk of rows behind a gate
+        for any other set; any batch size, explicit `noise=` normals, per-call motion kwargs and imported trajectories
+        included.  Populations that read the agent's float64 state (VelocityCells) advance through a native step plan.
+        What neither covers (AgentVectorCells, recurrent layers, float32 motion) runs as trajectory chunks of `chunk`
+        steps on one HIP stream with the rate kernels of each finished chunk on a second one.  Histories land in HBM
+        (`save_history=True`) exactly as `n_steps` calls of update() would have left them.  Returns the trajectory
+        history tensor of this call `[n_steps, 8, B_padded]` (device)."""
         neurons = list(self.Neurons if neurons is None else neurons)
         if self._plan is not None:
             self._plan.close()  # (before any history row is reserved: a plan's pending rows are not committed yet)
@@ -416,15 +397,10 @@ class Agent:
                                           "imported trajectory: use update()")
             return self._simulate_by_plan(int(n_steps), dt or self.dt, drift_velocity, drift_to_random_strength_ratio,
                                           neurons)
-        if noise is None and not kwargs and self._fused_eligible(neurons):
-            traj = self._simulate_fused(int(n_steps), dt or self.dt, drift_velocity, drift_to_random_strength_ratio,
-                                        neurons[0], chunk)
-            if traj is not None:
-                return traj
-        if noise is None and not kwargs:
-            traj = self._simulate_native(int(n_steps), dt or self.dt, drift_velocity, drift_to_random_strength_ratio, neurons)
-            if traj is not None:
-                return traj
+        traj = self._simulate_native(int(n_steps), dt or self.dt, drift_velocity, drift_to_random_strength_ratio, neurons,
+                                     noise, kwargs)
+        if traj is not None:
+            return traj
         if self._streams is None:
             self._streams = self._make_streams()
         s_traj, s_rate = self._streams
@@ -508,148 +484,104 @@ class Agent:
         torch.cuda.current_stream(self._device).synchronize()
         if _L.env("RIAB_GATE_WHEN_BUSY") == "1":  # this process owns the device: no started gate while the stream is idle
             _L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_GATE, _L.GATE_WHEN_BUSY)
+        if _L.env("RIAB_NO_FUSED") == "1":  # A/B comparisons: always the chunk form of the rate stage
+            _L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_POLL_MAX, 0)
 
-    # ---- fused path, one population: flag-coupled kernels, one native call (riab_simulate_fused) ----------------
-    def _fused_eligible(self, neurons):
-        """The trajectory kernel and the rate stage run concurrently, coupled by flags in device memory
-        (csrc/riab_simulate.hip), behind ONE native call: Philox noise, float64 motion, whole 256-agent groups, one
-        PlaceCells / GridCells / HeadDirectionCells population without additive noise.  Everything else goes
-        through the chunked two-stream pipeline above.  `RIAB_NO_FUSED=1` switches it off (A/B comparisons:
-        the results are bit-identical)."""
-        if len(neurons) != 1 or self.use_imported_trajectory or self.precision != 64 or self._Bp % 256:
-            return False
-        N = neurons[0]
-        if N._stream_kind is None or N.noise_std != 0 or N.Agent is not self:
-            return False
-        return _L.env("RIAB_NO_FUSED") != "1"
-
-    def _simulate_fused(self, n_steps, dt, drift_velocity, ratio, N, chunk):
-        """One native call (riab_simulate_fused).  A 20-step run is ~80 us of GPU time: everything that is not needed
-        to issue the call — views, clocks, mirrors — happens AFTER it, while the kernels run."""
+    # ---- the open-loop run as ONE native call (riab_simulate) -----------------------------------------------------------
+    def _simulate_native(self, n_steps, dt, drift_velocity, ratio, neurons, noise=None, kwargs=None):
+        """`riab_simulate` (csrc/riab_simulate.hip): the trajectory kernel publishes its rows through
+        flags in device memory and the firing-rate stage consumes them on the caller's stream while it runs — one
+        gated rate kernel for a single store-bound population (PlaceCells / GridCells / HeadDirectionCells without OU
+        noise, whole 256-agent groups, up to 256 steps), every population's ordinary kernel per chunk of rows behind a
+        progress gate for any other set.  Any batch size, explicit `noise=` normals, per-call motion kwargs,
+        `resample_positions=` and imported trajectories (the forced-position kernel followed by the populations'
+        kernels) are covered: a 20-step run is ~70 us of GPU time, so everything that is not needed to issue the call
+        — views, clocks, mirrors — happens AFTER it, while the kernels run.  Populations that do not save their
+        history stream through a ring of rows: one native call per ring length (inside a call the kernels of a chunk
+        run while the next chunk's rows are produced, so the rows of one call must not alias; calls are ordered by
+        the stream).  Returns None — nothing reserved, nothing launched — for what it does not cover: populations
+        that cannot be recorded (AgentVectorCells, recurrent FeedForwardLayers), float32 motion; `RIAB_NO_NATIVE=1`
+        switches it off (A/B comparisons: the Python-driven chunk pipeline gives identical results)."""
+        if not neurons or len(neurons) > 16 or self.precision != 64 or n_steps <= 0 or _L.env("RIAB_NO_NATIVE") == "1":
+            return None
+        for N in neurons:
+            if N.Agent is not self:
+                return None
+        self.dt = dt  # (the populations' OU-noise constants are those of this dt, as in update(dt=...))
+        if len(neurons) == 1:
+            try:
+                structs = [neurons[0]._population()]
+            except NotImplementedError:
+                return None
+        else:
+            index, structs = {}, []
+            try:
+                for N in neurons:
+                    structs.append(N._population(index))
+                    index[N] = len(index)
+            except NotImplementedError:
+                return None
         if self._streamer is None:
             self._make_streamer()
+        kwargs = dict(kwargs) if kwargs else {}
+        resample = kwargs.pop("resample_positions", None)
         has_drift = drift_velocity is not None
-        m = self._motion(dt, has_drift, ratio, {})
+        m = self._motion(dt, has_drift, ratio, kwargs)
         env, _walls = self.Environment.device_tables(self._device)
         drift = self._as_device_f64(drift_velocity, 2) if has_drift else None
-        pop = N._population()
-        Bp, n = self._Bp, int(N.n)
-        traj_row, fr_row, sp_row = _L.HIST_ROWS * Bp * 4, n * Bp * 4, n * Bp
+        Bp, B = self._Bp, self._B
+        z = rs = forced = None
+        if self.use_imported_trajectory:
+            if noise is not None or has_drift or not self.interpolate:
+                return None
+            # the positions of the coming steps on the clock the loop would have had (repeated `t += dt`)
+            ts = np.cumsum(np.concatenate(([self.t + dt], np.full(n_steps - 1, dt))))
+            pos = np.broadcast_to(self.pos_interp(ts % max(self.t_interp)), (n_steps, B, 2))
+            full = np.empty((n_steps, 2, Bp))
+            full[:, :, :B] = np.transpose(pos, (0, 2, 1))
+            full[:, :, B:] = full[:, :, :1]
+            forced = torch.from_numpy(full).to(self._device)
+        if noise is not None:
+            z = self._noise_tensor(noise, n_steps)
+        if resample is not None:
+            rs = self._resample_tensor(resample, n_steps)
         # rows: (tensor, first row) pairs now, views later
         if self.save_history:
             traj_c, traj_s = self._hist.reserve_at(n_steps)
         else:
             traj_c, traj_s = torch.empty((n_steps, _L.HIST_ROWS, Bp), dtype=torch.float32, device=self._device), 0
-        full = bool(N.save_history)
-        if full:
-            fr_c, fr_s = N._hist_fr.reserve_at(n_steps)
-            sp_c, sp_s = N._hist_sp.reserve_at(n_steps) if N.save_spikes else (None, 0)
-            piece = n_steps
-        else:
-            # rates streamed through a ring: one launch per ring length (inside a launch the rate waves are several
-            # time rows apart, so rows of one launch must not alias; launches are ordered by the stream)
-            piece = min(n_steps, 2 * min(chunk, n_steps))
-            fr_c, fr_s = torch.empty((piece, n, Bp), dtype=torch.float32, device=self._device), 0
-            sp_c, sp_s = None, 0
-        piece = min(piece, 32768)  # (time rows are the z axis of the rate kernel's grid)
-        traj_p = traj_c.data_ptr() + traj_s * traj_row
-        fr_p = fr_c.data_ptr() + fr_s * fr_row
-        sp_p = sp_c.data_ptr() + sp_s * sp_row if sp_c is not None else None
-        state_p, diag_p, ctrl_p, drift_p = self._state.data_ptr(), self._diag.data_ptr(), self._ctrl.data_ptr(), _L.ptr(drift)
-        seed, a0, step, timing = int(self.rng_seed), int(self.agent_id0), int(self._step_index), 1 if self._time_rate_kernel else 0
-        call, stream = _L.lib.riab_simulate_fused, _L.current_stream()
-        t0 = 0
-        while t0 < n_steps:
-            tc = min(piece, n_steps - t0)
-            rows0 = t0 if full else 0
-            pop.rates_base = fr_p + rows0 * fr_row
-            pop.spikes_base = sp_p + rows0 * sp_row if sp_p is not None else None
-            pop.capacity_rows = tc
-            rc = call(self._streamer, env, m, state_p, Bp, a0, drift_p, seed, step + t0, tc, traj_p + t0 * traj_row, diag_p,
-                      pop, ctrl_p, timing, stream)
-            if rc == _L.EUNSUPPORTED and t0 == 0:  # (nothing was launched; the chunked path reserves its own rows)
-                if self.save_history:
-                    self._hist.unreserve(n_steps)
-                if full:
-                    N._hist_fr.unreserve(n_steps)
-                    if sp_c is not None:
-                        N._hist_sp.unreserve(n_steps)
-                return None
-            _L.check(rc, "riab_simulate_fused")
-            t0 += tc
-        # ---- the kernels are running: now the views and the Python-side mirrors
-        self._pipeline_unchecked = True
-        traj = traj_c[traj_s:traj_s + n_steps]
-        self.dt = dt
-        self._keep = (drift, _walls, traj_c, fr_c, sp_c, pop)
-        self._last_row = traj[n_steps - 1]
-        self._last_fused_units = Bp * tc  # agent-steps of the launch `last_rate_kernel_ms` refers to
-        t, times = self.t, []
-        for _ in range(n_steps):  # (the reference's clock: repeated `t += dt`, not t0 + i*dt)
-            self.prev_t = t
-            t += dt
-            times.append(t)
-        self.t = t
-        if self.save_history:
-            self._times.extend(times)
-        self._step_index += n_steps
-        if full:
-            N._rates = fr_c[fr_s + n_steps - 1]
-            N._spikes_last = None if sp_c is None else sp_c[sp_s + n_steps - 1]
-            N._times.extend(times)
-        else:
-            N._rates = fr_c[(n_steps - 1) % piece]
-        return traj
-
-    # ---- any set of populations, one native call (riab_simulate_pops) ---------------------------------------------
-    def _simulate_native(self, n_steps, dt, drift_velocity, ratio, neurons):
-        """The flag-coupled pipeline for an ordered set of populations: the trajectory kernel publishes its rows,
-        every chunk of rows is consumed behind a gate by each population's ordinary kernel — the launch loop of the
-        chunked path below, moved into C++ (csrc/riab_simulate.hip).  Bit-identical to it.  Populations that do not
-        save their history stream through a ring of rows: one native call per ring length (inside a call the kernels
-        of a chunk may run while the next chunk's rows are produced, so the rows of one call must not alias; calls
-        are ordered by the stream).  None (nothing reserved, nothing launched) when the set is not covered:
-        populations that cannot be recorded (AgentVectorCells, recurrent FeedForwardLayers), float32 motion, imported
-        trajectories; `RIAB_NO_NATIVE=1` switches it off."""
-        if not neurons or len(neurons) > 16 or self.use_imported_trajectory or self.precision != 64 or self._Bp % 64 \
-                or _L.env("RIAB_NO_NATIVE") == "1" or n_steps <= 0:
-            return None
-        if any(N.Agent is not self for N in neurons):
-            return None
-        self.dt = dt  # (the populations' OU-noise constants are those of this dt, as in update(dt=...))
-        index, structs = {}, []
-        try:
-            for N in neurons:
-                structs.append(N._population(index))
-                index[N] = len(index)
-        except NotImplementedError:
-            return None
-        if self._streamer is None:
-            self._make_streamer()
-        has_drift = drift_velocity is not None
-        m = self._motion(dt, has_drift, ratio, {})
-        env, _walls = self.Environment.device_tables(self._device)
-        drift = self._as_device_f64(drift_velocity, 2) if has_drift else None
-        Bp = self._Bp
-        if self.save_history:
-            traj = self._hist.reserve(n_steps)
-        else:
-            traj = torch.empty((n_steps, _L.HIST_ROWS, Bp), dtype=torch.float32, device=self._device)
         outs = [N._reserve_rows(n_steps, ring=128) for N in neurons]   # (rings of 256 rows where rates are not saved)
-        piece = min([n_steps] + [o["ring"] for o in outs if o["ring"] is not None])
-        arr = (_L.RiabPopulation * len(neurons))()
+        piece = n_steps
+        for o in outs:
+            if o["ring"] is not None and o["ring"] < piece:
+                piece = o["ring"]
+        npop = len(neurons)
+        arr = (_L.RiabPopulation * npop)()
         bases = []
         for i, (pop, out) in enumerate(zip(structs, outs)):
-            _L.C.memmove(_L.C.byref(arr, i * _L.C.sizeof(_L.RiabPopulation)), _L.C.byref(pop), _L.C.sizeof(_L.RiabPopulation))
+            _L.C.memmove(_L.C.byref(arr, i * _L.POP_SIZE), _L.C.byref(pop), _L.POP_SIZE)
             n = int(neurons[i].n)
+            full_rows = out["ring"] is None
             bases.append((out["fr"].data_ptr(), out["sp"].data_ptr() if out["sp"] is not None else None,
-                          n * Bp * 4 if out["ring"] is None else 0, n * Bp if out["ring"] is None else 0))
+                          n * Bp * 4 if full_rows else 0, n * Bp if full_rows else 0))
         timed = -1
         if self._time_rate_kernel:
             tp = getattr(self, "_timed_population", None)
             timed = neurons.index(tp) if tp in neurons else 0
-        traj_p, traj_row = traj.data_ptr(), _L.HIST_ROWS * Bp * 4
-        seed, a0, step = int(self.rng_seed), int(self.agent_id0), int(self._step_index)
+        traj_row = _L.HIST_ROWS * Bp * 4
+        traj_p = traj_c.data_ptr() + traj_s * traj_row
+        run = self._run_struct
+        if run is None:
+            run = self._run_struct = _L.RiabSimulate()
+        run.env, run.motion = _L.C.pointer(env), _L.C.pointer(m)
+        run.state, run.B, run.agent_id0 = self._state.data_ptr(), Bp, int(self.agent_id0)
+        run.drift = drift.data_ptr() if drift is not None else None
+        run.seed, run.n_pops, run.pops = int(self.rng_seed), npop, _L.C.cast(arr, _L.C.POINTER(_L.RiabPopulation))
+        run.diag, run.ctrl, run.timed_pop = self._diag.data_ptr(), self._ctrl.data_ptr(), timed
+        run.timing_mode = 1 if self._time_rate_kernel == "events" else 0
+        step = int(self._step_index)
+        call, handle, stream, byref = _L.lib.riab_simulate, self._streamer, _L.current_stream(), _L.C.byref(run)
+        noise_row = 2 * Bp * 8
         t0 = tc = 0
         while t0 < n_steps:
             tc = min(piece, n_steps - t0)
@@ -657,23 +589,28 @@ class Agent:
                 arr[i].rates_base = fr_p + t0 * fr_row
                 arr[i].spikes_base = None if sp_p is None else sp_p + t0 * sp_row
                 arr[i].capacity_rows = tc
-            rc = _L.lib.riab_simulate_pops(self._streamer, env, m, self._state.data_ptr(), Bp, a0, _L.ptr(drift), seed,
-                                           step + t0, tc, traj_p + t0 * traj_row, self._diag.data_ptr(),
-                                           _L.C.addressof(arr), len(neurons), self._ctrl.data_ptr(), timed, _L.current_stream())
-            if rc == _L.EUNSUPPORTED and t0 == 0:
+            run.step0, run.T, run.hist = step + t0, tc, traj_p + t0 * traj_row
+            run.noise = z.data_ptr() + t0 * noise_row if z is not None else None
+            run.forced_pos = forced.data_ptr() + t0 * noise_row if forced is not None else None
+            run.resample_pos = rs.data_ptr() + t0 * noise_row if rs is not None else None
+            rc = call(handle, byref, stream)
+            if rc == _L.EUNSUPPORTED and t0 == 0:  # (nothing was launched; the chunk pipeline reserves its own rows)
                 if self.save_history:
                     self._hist.unreserve(n_steps)
                 for N, out in zip(neurons, outs):
                     N._unreserve_rows(out, n_steps)
                 return None
-            _L.check(rc, "riab_simulate_pops")
+            if rc:
+                self._native_failed(rc, t0, tc, dt)
             t0 += tc
+        # ---- the kernels are running: now the views and the Python-side mirrors
         self._pipeline_unchecked = True
-        self._keep = (drift, _walls, arr, structs, outs, traj)
+        traj = traj_c[traj_s:traj_s + n_steps]
+        self._keep = (drift, _walls, arr, structs, outs, traj_c, z, rs, forced, env, m)
         self._last_row = traj[n_steps - 1]
         self._last_fused_units = Bp * tc  # agent-steps of the call `last_rate_kernel_ms` refers to (the last piece)
         t, times = self.t, []
-        for _ in range(n_steps):
+        for _ in range(n_steps):  # (the reference's clock: repeated `t += dt`, not t0 + i*dt)
             self.prev_t = t
             t += dt
             times.append(t)
@@ -686,6 +623,44 @@ class Agent:
                 out["last"] = out["fr"][tc - 1]   # (every piece starts at the ring's first row)
             N._finish_rows(out, n_steps, times)
         return traj
+
+    def _native_failed(self, rc, t0, tc, dt):
+        """A native call failed after earlier pieces (or, RIAB_EPARTIAL, its own trajectory kernel) had been launched:
+        the device state has advanced — advance the host mirrors by what ran, then raise."""
+        done = t0 + (tc if rc == _L.EPARTIAL else 0)
+        for _ in range(done):
+            self.prev_t = self.t
+            self.t += dt
+            if self.save_history:
+                self._times.append(self.t)
+        self._step_index += done
+        self._last_row = None
+        _L.check(rc, "riab_simulate")
+
+    def _noise_tensor(self, noise, T):
+        """explicit standard normals `(T, 2, B)` / `(T, B, 2)` / tensor -> device float64 `[T, 2, Bp]`"""
+        zt = noise if torch.is_tensor(noise) else torch.as_tensor(np.asarray(noise, dtype=np.float64))
+        zt = zt.to(self._device, torch.float64)
+        if T == 1 and zt.dim() == 2:
+            zt = zt.unsqueeze(0)
+        if zt.shape[-1] == 2 and zt.shape[-2] != 2:
+            zt = zt.transpose(-1, -2)
+        if zt.shape[-1] != self._Bp:  # pad agents
+            pad = zt[..., :1].expand(*zt.shape[:-1], self._Bp - zt.shape[-1])
+            zt = torch.cat((zt, pad), dim=-1)
+        z = zt.contiguous()
+        assert z.shape == (T, 2, self._Bp), f"noise must be (T,2,B), got {tuple(z.shape)}"
+        return z
+
+    def _resample_tensor(self, resample, T):
+        """where agents that end a step in a hole / outside a polygonal boundary are put (parity runs: the reference's
+        np.random draws); (T, B, 2) / (B, 2) / (2,) -> device float64 `[T, 2, Bp]`"""
+        r = np.asarray(resample, dtype=np.float64)
+        r = np.broadcast_to(r.reshape((1,) * (3 - r.ndim) + r.shape) if r.ndim < 3 else r, (T, self._B, 2))
+        full = np.empty((T, 2, self._Bp))
+        full[:, :, :self._B] = np.transpose(r, (0, 2, 1))
+        full[:, :, self._B:] = full[:, :, :1]
+        return torch.from_numpy(full).to(self._device)
 
     def last_rate_kernel_ms(self):
         """Duration of the rate stage of the last fused simulate() — one kernel for runs of up to 256 steps, a

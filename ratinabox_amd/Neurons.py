@@ -50,7 +50,7 @@ class Neurons:
     # which per-agent direction rows feed io.hd_x / hd_y: (history-record rows, float64 state rows)
     _H_DIR = (_L.H_HD_X, _L.H_HD_Y)
     _S_DIR = (_L.S_HD_X, _L.S_HD_Y)
-    # populations the rate stage of the flag-coupled pipeline covers (Agent._simulate_fused) set this
+    # populations the rate stage of the flag-coupled pipeline covers (the one-kernel form of riab_simulate) set this
     _stream_kind = None
     # get_state() through the registered PyTorch operator (ops.py: torch.ops.riab.*): set by the classes that have one.
     # Called with float32 rows `d [4, P]` = (pos x, pos y, direction x, direction y); returns rates `[n, P]`.

@@ -68,6 +68,17 @@ class RiabPopulation(C.Structure):
                 ("rates_prime", C.c_void_p)]
 
 
+class RiabSimulate(C.Structure):
+    _fields_ = [("env", C.POINTER(RiabEnv)), ("motion", C.POINTER(RiabMotion)), ("state", C.c_void_p), ("B", C.c_int64),
+                ("agent_id0", C.c_int64), ("drift", C.c_void_p), ("noise", C.c_void_p), ("forced_pos", C.c_void_p),
+                ("resample_pos", C.c_void_p), ("seed", C.c_uint64), ("step0", C.c_uint64), ("T", C.c_int32),
+                ("n_pops", C.c_int32), ("pops", C.POINTER(RiabPopulation)), ("hist", C.c_void_p), ("diag", C.c_void_p),
+                ("ctrl", C.c_void_p), ("timed_pop", C.c_int32), ("timing_mode", C.c_int32)]
+
+
+POP_SIZE = C.sizeof(RiabPopulation)
+
+
 class RiabTask(C.Structure):
     _fields_ = [("goals", C.c_void_p), ("n_pool", C.c_int32), ("goalorder", C.c_int32), ("terminate_delay", C.c_double),
                 ("pad_reward", C.c_double * 5), ("default_reward_level", C.c_double)]
@@ -89,12 +100,13 @@ TD_REWARD_OVERFLOW, TD_LATE_COMPLETIONS, TD_EPLOG_OVERFLOW, TD_RESETS = range(4)
 
 POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4, "ff": 5, "velocity": 6, "speed": 7, "random_spatial": 8}
 EINVAL = -1
+EALIGN = -2
 EFULL = -5
 EUNSUPPORTED = -4
 EPARTIAL = -6
 STREAMER_OPT_GATE, STREAMER_OPT_POLL_MAX = 0, 1
 GATE_ALWAYS, GATE_WHEN_BUSY = 0, 1
-CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_PROGRESS = 0, 1, 2, 32  # riab_hip.h RIAB_CTRL_*
+CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_STAMPS, CTRL_PROGRESS = 0, 1, 2, 8, 32  # riab_hip.h RIAB_CTRL_*
 
 
 def ctrl_words(B):
@@ -168,14 +180,9 @@ PROTOTYPES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_streamer_create": (C.c_void_p, []),
     "riab_streamer_destroy": (None, [C.c_void_p]),
-    "riab_simulate_fused": (C.c_int, [C.c_void_p, C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
-                                      C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p,
-                                      C.POINTER(RiabPopulation), C.c_void_p, C.c_int32, C.c_void_p]),
+    "riab_simulate": (C.c_int, [C.c_void_p, C.POINTER(RiabSimulate), C.c_void_p]),
     "riab_streamer_configure": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "riab_streamer_last_rate_ms": (C.c_float, [C.c_void_p]),
-    "riab_simulate_pops": (C.c_int, [C.c_void_p, C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
-                                     C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "riab_host_wait_spin": (C.c_int, [C.c_int32]),
     "riab_abi_sizeof": (C.c_int64, [C.c_int32]),
     "riab_abi_version": (C.c_int, []),
@@ -214,7 +221,8 @@ def _load():
         raise ImportError(f"libriab_hip.so ABI {lib.riab_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     # the ctypes mirrors must have the layouts the library was compiled with (a stale library with the same
     # version number would otherwise corrupt memory silently)
-    mirrors = ((0, RiabEnv), (1, RiabMotion), (2, RiabRateIO), (3, RiabPopulation), (4, RiabTask), (5, RiabFFInput))
+    mirrors = ((0, RiabEnv), (1, RiabMotion), (2, RiabRateIO), (3, RiabPopulation), (4, RiabTask), (5, RiabFFInput),
+               (7, RiabSimulate))
     for which, cls in mirrors:
         if lib.riab_abi_sizeof(which) != C.sizeof(cls):
             raise ImportError(f"libriab_hip.so: sizeof({cls.__name__}) is {lib.riab_abi_sizeof(which)} in the library, "

@@ -52,12 +52,21 @@ int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* 
 // (riab_traj4_kernel.h), Philox noise or explicit normals (a.z_in); a.ctrl carries the control words.  Whole waves
 // only (B % 64 == 0), any T.  RIAB_TRAJ2=1 (A/B comparisons): the two-wave kernel of round 1 (Philox only).
 int launch_agent_pub(const AgentArgs& a, hipStream_t s) {
-  if (!a.ctrl || !a.hist || a.forced || a.B % 64 != 0) return RIAB_EINVAL;
-  const dim3 grid((unsigned)(a.B / 64));
+  if (!a.ctrl || !a.hist || a.forced || a.B % 4 != 0) return RIAB_EINVAL;
+  const dim3 grid((unsigned)((a.B + 63) / 64));
   static const bool two_wave = getenv("RIAB_TRAJ2") != nullptr;
-  if (two_wave && !a.z_in && !a.z_out) hipLaunchKernelGGL((agent_step_kernel<double, 0, true, true>), grid, dim3(128), 0, s, a);
+  if (two_wave && !a.z_in && !a.z_out && a.B % 64 == 0) hipLaunchKernelGGL((agent_step_kernel<double, 0, true, true>), grid, dim3(128), 0, s, a);
   else if (a.z_in) hipLaunchKernelGGL((traj4_kernel<1, true>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((traj4_kernel<0, true>), grid, dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+// the forced-position trajectory (Agent.import_trajectory / forced_next_position) of riab_simulate: the single-wave
+// kernel in forced mode, plain stores (what follows it on the stream is ordered by the stream)
+int launch_agent_forced(const AgentArgs& a, hipStream_t s) {
+  if (!a.forced || !a.hist) return RIAB_EINVAL;
+  const dim3 grid((unsigned)((a.B + 63) / 64));
+  hipLaunchKernelGGL((agent_step_kernel<double, 2, false>), grid, dim3(64), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -81,7 +90,7 @@ extern "C" int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, dou
   static const bool no_pc = getenv("RIAB_NO_PC") != nullptr, two_wave = getenv("RIAB_TRAJ2") != nullptr;
   const bool pc = in == 0 && precision == 64 && T >= 2 * RIAB_Z_BATCH && B % 64 == 0 && !z_out && !no_pc && two_wave;
   // multi-step float64 launches of whole waves: one agent's step over four specialised waves (riab_traj4_kernel.h)
-  const bool t4 = in != 2 && precision == 64 && T >= 8 && B % 64 == 0 && !no_pc && !two_wave;
+  const bool t4 = in != 2 && precision == 64 && T >= 8 && B % 4 == 0 && !no_pc && !two_wave;
   if (precision == 64) {
     if (t4 && in == 0) hipLaunchKernelGGL((traj4_kernel<0, false>), grid, dim3(256), 0, s, a);
     else if (t4) hipLaunchKernelGGL((traj4_kernel<1, false>), grid, dim3(256), 0, s, a);

@@ -562,7 +562,9 @@ struct StreamArgs {
   uint32_t* ctrl;
   uint32_t step_base;     // (uint32) step0 of the launch: progress words are absolute step counts
   uint32_t spin_limit;
+  uint32_t stamps;        // != 0: the waves of the first / last time row record the device clock in ctrl[RIAB_CTRL_STAMPS]
 };
+typedef __attribute__((address_space(1))) unsigned long long gu64;
 
 // rows of sub-segment q published so far, relative to this launch: one 16-byte read of the sub-segment's own line
 __device__ __forceinline__ int stream_progress(const StreamArgs& s, uint32_t q, int lane) {
@@ -613,6 +615,13 @@ __global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell 
   // one coalesced load brings the whole group's parameters into the wave (independent of the trajectory)
   const int pi = c0 * NP + lane;
   const float mine = (lane < NP * CPB && pi < a.n * NP) ? cell.tab[pi] : 0.0f;
+  // kernel duration without a host-side event, on the device's constant clock: the first workgroup of the grid (the
+  // first one dispatched) leaves its start, the workgroups of the last cell group of the last time row (the last ones
+  // dispatched) the latest end, after their stores have been acknowledged.  (A first version let every wave of the
+  // first / last ROW take part: 4096 device-scope atomics on two words, 86 instead of 60 us per launch.)
+  if (s.stamps && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    __hip_atomic_store((gu64*)(uintptr_t)(s.ctrl + RIAB_CTRL_STAMPS), (unsigned long long)__builtin_amdgcn_s_memrealtime(),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   stream_wait(s, wq, (int)t, lane);
   const int64_t po = (int64_t)t * a.pos_ld + 4 * (int64_t)q;
   const typename Cell::Pos P = SC1 ? cell.load_agent(a, po) : cell.load(a, po);
@@ -633,6 +642,12 @@ __global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell 
       off += a.B;
     }
   }
+  if (s.stamps && t + 1 == gridDim.z && blockIdx.y + 1 == gridDim.y) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+      __hip_atomic_fetch_max((gu64*)(uintptr_t)(s.ctrl + RIAB_CTRL_STAMPS + 2), (unsigned long long)__builtin_amdgcn_s_memrealtime(),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // The gates on the rate kernels' stream (one wave each):
@@ -642,8 +657,13 @@ __global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell 
 //   progress gate  (n_traj > 0) additionally returns only once all n_traj trajectory workgroups have published
 //                  `progress_target` steps: what follows on the stream is a plain rate kernel for rows below that.
 __global__ __launch_bounds__(64) void stream_gate_kernel(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj,
-                                                         uint32_t progress_target, uint32_t spin_limit, uint32_t sleep_long) {
+                                                         uint32_t progress_target, uint32_t spin_limit, uint32_t sleep_long,
+                                                         uint32_t reset_stamps) {
   const int lane = threadIdx.x;
+  if (reset_stamps && lane == 0) {  // (the rate kernel that follows on this stream records min(start) / max(end))
+    __hip_atomic_store((gu64*)(uintptr_t)(ctrl + RIAB_CTRL_STAMPS), ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((gu64*)(uintptr_t)(ctrl + RIAB_CTRL_STAMPS + 2), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   for (uint32_t spins = 0;; ++spins) {
     const uint32_t v = __hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_STARTED), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool ok = (int32_t)(v - started_target) >= 0;
@@ -845,8 +865,8 @@ int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B) {
 }
 
 int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t T, float dt,
-                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, uint32_t spin_limit, hipStream_t s,
-                       hipEvent_t ev_start, hipEvent_t ev_stop, bool dry_run) {
+                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, uint32_t spin_limit, bool stamps,
+                       hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, bool dry_run) {
   struct EventScope {
     EventScope(hipEvent_t a, hipEvent_t b) { t_stream_ev0 = a; t_stream_ev1 = b; }
     ~EventScope() { t_stream_ev0 = t_stream_ev1 = nullptr; }
@@ -881,6 +901,7 @@ int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const floa
   st.ctrl = ctrl;
   st.step_base = (uint32_t)step0;
   st.spin_limit = spin_limit;
+  st.stamps = stamps ? 1u : 0u;
   const bool spikes = pop->spikes_base != nullptr;
   switch (pop->kind) {
     case RIAB_POP_PLACE:
@@ -910,39 +931,10 @@ int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const floa
 }
 
 int launch_stream_gate(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj, uint32_t progress_target,
-                       uint32_t spin_limit, bool sleep_long, hipStream_t s) {
+                       uint32_t spin_limit, bool sleep_long, bool reset_stamps, hipStream_t s) {
   hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(64), 0, s, ctrl, started_target, n_traj, progress_target, spin_limit,
-                     sleep_long ? 1u : 0u);
+                     sleep_long ? 1u : 0u, reset_stamps ? 1u : 0u);
   return (int)hipGetLastError();
-}
-
-// rows [t0, t0 + tc) of a finished part of the trajectory through the population's ordinary kernel (the chunks of
-// a long riab_simulate_fused run, each behind a progress gate)
-int launch_rate_rows(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t t0, int32_t tc,
-                     float dt, uint64_t seed, uint64_t step0, int64_t agent_id0, hipStream_t s) {
-  RiabRateIO io = pop->io;
-  const float* row = hist + (int64_t)t0 * RIAB_HIST_ROWS * B;
-  io.pos_x = row + (int64_t)RIAB_H_POS_X * B;
-  io.pos_y = row + (int64_t)RIAB_H_POS_Y * B;
-  io.hd_x = row + (int64_t)RIAB_H_HD_X * B;
-  io.hd_y = row + (int64_t)RIAB_H_HD_Y * B;
-  io.pos_ld = (int64_t)RIAB_HIST_ROWS * B;
-  io.T = tc;
-  io.B = B;
-  io.rates = pop->rates_base + (int64_t)t0 * pop->n * B;
-  io.spikes = pop->spikes_base ? pop->spikes_base + (int64_t)t0 * pop->n * B : nullptr;
-  io.u_in = nullptr;
-  io.dt = dt;
-  io.seed = seed;
-  io.step0 = step0 + 1 + (uint64_t)t0;  // Neurons.update after the (step0 + t + 1)-th Agent.update
-  io.agent_id0 = agent_id0;
-  switch (pop->kind) {
-    case RIAB_POP_PLACE:
-      return riab_place_cells(env, &io, pop->table, pop->n, pop->description, pop->geometry, pop->top_hat_width, s);
-    case RIAB_POP_GRID: return riab_grid_cells(&io, pop->table, pop->n, pop->description, pop->f0, s);
-    case RIAB_POP_HDC: return riab_head_direction_cells(&io, pop->table, pop->n, s);
-    default: return RIAB_EUNSUPPORTED;
-  }
 }
 
 }  // namespace riab

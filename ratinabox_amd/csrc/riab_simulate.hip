@@ -1,18 +1,33 @@
-// The open-loop path as one native call: the trajectory kernel and the firing-rate stage run CONCURRENTLY on two
-// streams, coupled by flags in device memory (include/riab_hip.h: riab_simulate_fused).  This file is
-// host code only: the kernels live in riab_agent_kernel.h (PUB variant: rows written through + published) and
-// riab_rates.hip (rate_kernel_gated, stream_gate_kernel, rate_kernel_wide).
+// The open-loop path as ONE native call (include/riab_hip.h: riab_simulate): the trajectory kernel and the
+// firing-rate stage run CONCURRENTLY on two streams, coupled by flags in device memory.  This file is host code only:
+// the kernels live in riab_traj4_kernel.h (the publishing trajectory kernel: rows written through + progress words)
+// and riab_rates.hip (rate_kernel_gated, stream_gate_kernel, and every population's ordinary kernel).
 //
-// Why not one launch: a launch has ONE register and LDS allocation.  The trajectory kernel needs 256 VGPRs and
-// 58 KB of LDS per 64 agents; the rate kernel needs 40 VGPRs and no LDS and lives on occupancy.  Why not launches
-// per chunk behind HIP events (Agent.simulate's two-stream pipeline): every chunk pays the fill of the first stage
-// and a dependent launch boundary, and a 20-step run has nothing to overlap.  With flags the rate stage starts 4
-// steps behind the trajectory and stays there.  Up to RIAB_STREAM_POLL_MAX (256) steps the rate stage is ONE
-// ordinary (non-persistent) kernel over all rows whose waves each wait for the row they need; beyond that it is one
-// rate_kernel_wide launch per chunk of rows behind a one-wave gate kernel that waits for the chunk's last row (a
-// kernel with ten thousand waiting workgroups in front of the runnable ones starves them).  A PERSISTENT rate kernel
-// was built first (three versions) and removed: waves that stay resident hold store credits and lose 9-12 % of the
-// store bandwidth against freshly dispatched ones (tools/stream_bench.hip).
+// Why not one launch: a launch has ONE register and LDS allocation.  The trajectory kernel needs 220 VGPRs and 80 KB
+// of LDS per 64 agents; the rate kernels need ~40 VGPRs and no LDS and live on occupancy.  Why not launches per chunk
+// behind HIP events: every chunk pays the fill of the first stage and a dependent launch boundary, and a 20-step run
+// has nothing to overlap.  With flags the rate stage starts a step or two behind the trajectory and stays there.
+//
+// Which stream carries what.  The rate stage ends last, so IT runs on the caller's stream and the trajectory kernel on
+// the streamer's own: the join (caller's stream waits for the trajectory kernel) is then a barrier whose dependency was
+// met tens of microseconds before the rate stage finishes, and a host synchronisation returns as soon after the last
+// kernel as after any single kernel (~10 us).  The other way round — rate stage on the second stream, round 2 — the
+// join sat behind the LAST kernel: its signal had to travel second queue -> event -> barrier packet on the first
+// queue -> host, 25 us from the end of the rate kernel to the return of hipDeviceSynchronize [MI355X, rocprofv3
+// --hip-trace --kernel-trace of the driver's bench command].
+//
+// Two forms of the rate stage:
+//  * one store-bound population (place / grid / head-direction cells without OU noise), up to `poll_max` (256) steps:
+//    ONE rate kernel for all rows whose waves wait for their rows themselves (rate_kernel_gated); it follows the
+//    trajectory at a distance of one block of steps; its per-wave poll costs ~10 % of the store bandwidth;
+//  * anything else: per chunk of rows (16, 28, 44, ... 128) a one-wave progress gate, then every population's ordinary
+//    kernel over the chunk in list order — full store bandwidth, at the price of a chunk of distance to the trajectory
+//    and a gate + launch boundary (~5 us) per chunk.  (A kernel with ten thousand waiting workgroups in front of the
+//    runnable ones starves them: long runs cannot use the first form.)  A PERSISTENT rate kernel was built first
+//    (three versions) and removed: waves that stay resident hold store credits and lose 9-12 % of the store bandwidth
+//    against freshly dispatched ones (tools/stream_bench.hip).
+// Forced (imported) trajectories have no recurrence to hide: their kernel and the populations' kernels simply follow
+// each other on the caller's stream.
 #include <hip/hip_ext.h>
 
 #include <new>
@@ -22,25 +37,25 @@
 
 namespace riab {
 int launch_agent_pub(const AgentArgs& a, hipStream_t s);
+int launch_agent_forced(const AgentArgs& a, hipStream_t s);
 int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
 int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t T, float dt,
-                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, uint32_t spin_limit, hipStream_t s,
-                       hipEvent_t ev_start, hipEvent_t ev_stop, bool dry_run);
+                       uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, uint32_t spin_limit, bool stamps,
+                       hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, bool dry_run);
 int launch_stream_gate(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj, uint32_t progress_target,
-                       uint32_t spin_limit, bool sleep_long, hipStream_t s);
-int launch_rate_rows(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t t0, int32_t tc,
-                     float dt, uint64_t seed, uint64_t step0, int64_t agent_id0, hipStream_t s);
+                       uint32_t spin_limit, bool sleep_long, bool reset_stamps, hipStream_t s);
 }  // namespace riab
 
 struct RiabStreamer {
-  hipStream_t side;          // the rate kernel's stream (mode 0)
-  hipEvent_t join;           // side -> main
-  hipEvent_t t0, t1;         // timing of the rate kernel (created on first use)
-  std::vector<hipEvent_t> pairs;  // riab_simulate_pops: (start, stop) around every launch of the timed population
-  int n_pairs;               // pairs recorded by the last call (0: t0 / t1 hold the measurement)
-  bool timed;
+  hipStream_t side;          // the trajectory kernel's stream
+  hipEvent_t fork, join;     // caller's stream -> side (only when the caller's stream is busy), side -> caller's stream
+  hipEvent_t t0, t1;         // HIP-event timing of the rate kernel (created on first use)
+  std::vector<hipEvent_t> pairs;  // chunk form: (start, stop) around every launch of the timed population
+  int n_pairs;               // pairs recorded by the last call (0: t0 / t1 or the device stamps hold the measurement)
+  int timed;                 // 0 nothing, 1 events, 2 device time stamps (ctrl[RIAB_CTRL_STAMPS])
+  uint32_t* stamp_ctrl;      // control block of the last stamped call
   uint32_t started_total;    // trajectory workgroups launched so far through this object (wraps like the device word)
-  int cus;                   // compute units of the device the object was created on
+  int wall_khz;              // rate of the device's constant clock (s_memrealtime)
   int gate_mode;             // RIAB_STREAMER_OPT_GATE
   int poll_max;              // RIAB_STREAMER_OPT_POLL_MAX
 };
@@ -49,21 +64,22 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
   RiabStreamer* h = new (std::nothrow) RiabStreamer();
   if (!h) return nullptr;
   h->side = nullptr;
-  h->join = h->t0 = h->t1 = nullptr;
-  h->timed = false;
+  h->fork = h->join = h->t0 = h->t1 = nullptr;
+  h->timed = 0;
   h->n_pairs = 0;
+  h->stamp_ctrl = nullptr;
   h->started_total = 0;
   h->gate_mode = RIAB_GATE_ALWAYS;
   h->poll_max = 256;
-  int dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess) {
-    delete h;
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) != hipSuccess) {
+    riab_streamer_destroy(h);
     return nullptr;
   }
-  h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+  h->wall_khz = khz;
   return h;
 }
 
@@ -88,6 +104,7 @@ extern "C" void riab_streamer_destroy(RiabStreamer* h) {
   if (h->t1) (void)hipEventDestroy(h->t1);
   for (hipEvent_t e : h->pairs) (void)hipEventDestroy(e);
   if (h->join) (void)hipEventDestroy(h->join);
+  if (h->fork) (void)hipEventDestroy(h->fork);
   if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
 }
@@ -95,7 +112,13 @@ extern "C" void riab_streamer_destroy(RiabStreamer* h) {
 extern "C" float riab_streamer_last_rate_ms(RiabStreamer* h) {
   if (!h || !h->timed) return -1.0f;
   float ms = -1.0f;
-  if (h->n_pairs > 0) {  // the sum over the timed population's launches of the last riab_simulate_pops call
+  if (h->timed == 2) {  // first wave's start / last wave's end of the gated rate kernel, on the device's constant clock
+    unsigned long long st[2] = {0, 0};
+    if (hipMemcpy(st, h->stamp_ctrl + RIAB_CTRL_STAMPS, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return -1.0f;
+    if (st[1] <= st[0]) return -1.0f;
+    return (float)((double)(st[1] - st[0]) / (double)h->wall_khz);
+  }
+  if (h->n_pairs > 0) {  // the sum over the timed population's launches of the last chunk-form call
     float total = 0.0f;
     for (int i = 0; i < h->n_pairs; ++i) {
       if (hipEventElapsedTime(&ms, h->pairs[2 * i], h->pairs[2 * i + 1]) != hipSuccess) return -1.0f;
@@ -106,104 +129,6 @@ extern "C" float riab_streamer_last_rate_ms(RiabStreamer* h) {
   if (hipEventElapsedTime(&ms, h->t0, h->t1) != hipSuccess) return -1.0f;
   return ms;
 }
-
-extern "C" int riab_simulate_fused(RiabStreamer* h, const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
-                                   int64_t agent_id0, const double* drift, uint64_t seed, uint64_t step0, int32_t T,
-                                   float* hist, int32_t* diag, const RiabPopulation* pop, uint32_t* ctrl,
-                                   int32_t timing, riab_stream_t stream) {
-  if (!h || !pop || !ctrl || !hist) return RIAB_EINVAL;
-  int rc = riab::stream_supported(env, pop, B);
-  if (rc) return rc;
-  riab::AgentArgs a;
-  rc = riab::fill_agent_args(a, env, motion, state, B, agent_id0, drift, nullptr, nullptr, nullptr, seed, step0, T, hist,
-                             diag, 64);
-  if (rc) return rc;
-  a.ctrl = ctrl;
-  hipStream_t main_s = (hipStream_t)stream;
-  hipStream_t rate_s = h->side;
-  // ~0.3 us per poll: a generous second or two before a wait gives up (a healthy wait is tens of microseconds)
-  const uint32_t spin_limit = 1u << 20;
-  const bool chunks = T > h->poll_max;
-  // Every argument check of the rate stage runs BEFORE the trajectory kernel is launched (a dry run of the launch
-  // path): a call that returns an argument error has launched nothing and advanced no state.
-  if (!chunks) {
-    rc = riab::launch_rate_stream(env, pop, hist, B, T, (float)motion->dt, seed, step0, agent_id0, ctrl, spin_limit, rate_s,
-                                  nullptr, nullptr, /*dry_run=*/true);
-    if (rc) return rc;
-  } else if (T > 65535) {
-    return RIAB_ETOOBIG;
-  }
-  if (timing && !h->t0) {
-    if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess) return RIAB_EINVAL;
-  }
-  h->timed = false;
-  h->n_pairs = 0;
-  // Both kernels must be resident at once or the rate waves spin for nothing: the trajectory kernel is launched first,
-  // and a one-wave gate on the side stream holds the rate stage back until every trajectory workgroup of THIS launch
-  // has announced itself — the rate waves can then never occupy the slots the kernel they wait for still needs,
-  // whatever else is queued on this stream or running on the device (another stream, another process: two ranks
-  // sharing one GPU without the gate ran into the waits' time limit).  The gate costs < 1 us of a 20-step region
-  // [MI355X: 119.0 vs 118.2 us]; RIAB_GATE_WHEN_BUSY drops it when the caller's stream is idle at the call (for
-  // callers that own the device).  (The side stream needs no event to order it behind what is queued on `stream`:
-  // the words it waits for are only written by this launch's trajectory kernel.)
-  const bool gate = h->gate_mode == RIAB_GATE_ALWAYS || hipStreamQuery(main_s) != hipSuccess;
-  rc = riab::launch_agent_pub(a, main_s);
-  if (rc) return rc;
-  const uint32_t n_traj = (uint32_t)(B / 64);
-  h->started_total += n_traj;
-  // From here on the state has advanced: a later failure still joins the side stream and is reported as
-  // RIAB_EPARTIAL (the trajectory rows are complete, the rates of this call are not).
-  // Two forms of the rate stage:
-  //  * up to `poll_max` (256) steps: ONE rate kernel for all rows whose waves wait for their rows themselves
-  //    (rate_kernel_gated): it follows the trajectory at a distance of one block of steps, which is what a short
-  //    run needs; its per-wave poll costs ~15 % of the store bandwidth;
-  //  * longer runs: the population's ordinary kernel per chunk of rows, each chunk behind a progress gate (one
-  //    wave) on the same stream — full store bandwidth, at the price of a chunk of distance to the trajectory
-  //    (the first chunks are short) and a gate + launch boundary (~5 us) per chunk.  (A progress gate also waits
-  //    for the started count: no separate started gate.)
-  int fail = RIAB_OK;
-  if (!chunks) {
-    // (the started gate is one sleeping wave; it may have to sit out whatever was queued on `stream`: ~1 min)
-    if (gate) fail = riab::launch_stream_gate(ctrl, h->started_total, 0, 0, 1u << 24, true, rate_s);
-    // (timed through the launch's own start / stop events: the kernel's duration as rocprofv3 reports it)
-    if (!fail)
-      fail = riab::launch_rate_stream(env, pop, hist, B, T, (float)motion->dt, seed, step0, agent_id0, ctrl, spin_limit,
-                                      rate_s, timing ? h->t0 : nullptr, timing ? h->t1 : nullptr, false);
-    if (!fail && timing) h->timed = true;
-  } else {
-    if (timing) (void)hipEventRecord(h->t0, rate_s);
-    const bool box_room = !env->polygon && !env->hole_mask && !env->periodic && env->n_walls >= 4;
-    int32_t t0 = 0, k = 0;
-    while (t0 < T && !fail) {
-      // A chunk should be finished by the trajectory when the stream gets to its gate.  In a solid rectangular room
-      // the trajectory pulls away from the rate kernels (which need ~2.7 us per row) and a chunk may be ~1.5x its
-      // predecessor; in other rooms ~1.25x is the most (a 16, 16, 32, 64, 128 ramp then spent 230 us of a 1024-step
-      // run inside the gates [MI355X, rocprofv3 trace]).  Larger chunks are cheaper per row (3.6 us at 16 rows, 2.7 at
-      // 128) and every chunk costs a gate (~5 us).
-      static const int32_t ramp_fast[5] = {16, 28, 44, 64, 96};
-      static const int32_t ramp_slow[10] = {16, 16, 20, 24, 32, 40, 48, 64, 80, 96};
-      int32_t tc = box_room ? (k < 5 ? ramp_fast[k] : 128) : (k < 10 ? ramp_slow[k] : 128);
-      if (tc > T - t0 || T - t0 - tc < 32) tc = T - t0;  // (no sliver at the end)
-      // ~0.5 us per poll: seconds before a gate gives up (a healthy wait is one chunk of trajectory, < 1 ms); the
-      // first gate may also have to sit out what is queued in front of the trajectory kernel
-      fail = riab::launch_stream_gate(ctrl, h->started_total, n_traj, (uint32_t)step0 + (uint32_t)(t0 + tc),
-                                      k == 0 ? 1u << 24 : 1u << 22, false, rate_s);
-      if (!fail) fail = riab::launch_rate_rows(env, pop, hist, B, t0, tc, (float)motion->dt, seed, step0, agent_id0, rate_s);
-      t0 += tc;
-      ++k;
-    }
-    if (!fail && timing) {  // (the whole stage: gates and chunk kernels)
-      (void)hipEventRecord(h->t1, rate_s);
-      h->timed = true;
-    }
-  }
-  hipError_t e = hipEventRecord(h->join, h->side);
-  if (e == hipSuccess) e = hipStreamWaitEvent(main_s, h->join, 0);
-  if (fail) return RIAB_EPARTIAL;
-  if (e != hipSuccess) return (int)e;
-  return RIAB_OK;
-}
-
 
 // ---- any set of populations: the chunked form of the rate stage for all of them, one native call ----------------
 // rows [t0, t0 + tc) of population i from the trajectory rows of the same chunk (the T-row form of riab_plan.hip's
@@ -280,12 +205,7 @@ static int launch_pop_rows(const RiabEnv* env, const RiabPopulation* pops, int i
   return rc;
 }
 
-extern "C" int riab_simulate_pops(RiabStreamer* h, const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
-                                  int64_t agent_id0, const double* drift, uint64_t seed, uint64_t step0, int32_t T,
-                                  float* hist, int32_t* diag, const RiabPopulation* pops, int32_t n_pops, uint32_t* ctrl,
-                                  int32_t timed_pop, riab_stream_t stream) {
-  if (!h || !env || !pops || !ctrl || !hist || n_pops <= 0 || T <= 0) return RIAB_EINVAL;
-  if (B <= 0 || B % 64 != 0) return RIAB_EUNSUPPORTED;  // (the publishing trajectory kernel runs whole waves)
+static int check_populations(const RiabPopulation* pops, int32_t n_pops, int32_t T) {
   for (int i = 0; i < n_pops; ++i) {
     const RiabPopulation& q = pops[i];
     if (q.n <= 0 || !q.rates_base || q.capacity_rows < T) return RIAB_EINVAL;
@@ -297,61 +217,145 @@ extern "C" int riab_simulate_pops(RiabStreamer* h, const RiabEnv* env, const Ria
         for (int l = 0; l < q.n_inputs; ++l)
           if (q.input_index[l] < 0 || q.input_index[l] >= i || pops[q.input_index[l]].capacity_rows < T) return RIAB_EINVAL;
         break;
-      default: return RIAB_EUNSUPPORTED;
+      default: return RIAB_EUNSUPPORTED;  // (velocity cells read the float64 state: they advance through a step plan)
     }
   }
-  riab::AgentArgs a;
-  int rc = riab::fill_agent_args(a, env, motion, state, B, agent_id0, drift, nullptr, nullptr, nullptr, seed, step0, T, hist,
-                                 diag, 64);
-  if (rc) return rc;
-  a.ctrl = ctrl;
-  hipStream_t main_s = (hipStream_t)stream, rate_s = h->side;
-  // chunk schedule of riab_simulate_fused's long runs (the trajectory is the faster stage here too: every population
-  // kernel of a chunk runs before the next chunk's gate is looked at)
+  return RIAB_OK;
+}
+
+// chunks of rows of the chunk form: a chunk should be finished by the trajectory when the stream gets to its gate.  In a
+// solid rectangular room the trajectory pulls away from the rate kernels (which need ~2.7 us per row at cfg 2) and a
+// chunk may be ~1.5x its predecessor; in other rooms ~1.25x is the most (a 16, 16, 32, 64, 128 ramp then spent 230 us
+// of a 1024-step run inside the gates [MI355X, rocprofv3 trace]).  Larger chunks are cheaper per row (3.6 us at 16
+// rows, 2.7 at 128) and every chunk costs a gate (~5 us).
+static std::vector<int32_t> chunk_schedule(const RiabEnv* env, int32_t T) {
   const bool box_room = !env->polygon && !env->hole_mask && !env->periodic && env->n_walls >= 4;
   static const int32_t ramp_fast[5] = {16, 28, 44, 64, 96};
   static const int32_t ramp_slow[10] = {16, 16, 20, 24, 32, 40, 48, 64, 80, 96};
   std::vector<int32_t> sched;
   for (int32_t t0 = 0, k = 0; t0 < T; ++k) {
     int32_t tc = box_room ? (k < 5 ? ramp_fast[k] : 128) : (k < 10 ? ramp_slow[k] : 128);
-    if (tc > T - t0 || T - t0 - tc < 32) tc = T - t0;
+    if (tc > T - t0 || T - t0 - tc < 32) tc = T - t0;  // (no sliver at the end)
     sched.push_back(tc);
     t0 += tc;
   }
-  const bool timing = timed_pop >= 0 && timed_pop < n_pops;
-  if (timing) {
-    while (h->pairs.size() < 2 * sched.size()) {
-      hipEvent_t e;
-      if (hipEventCreate(&e) != hipSuccess) return RIAB_EINVAL;
-      h->pairs.push_back(e);
-    }
-  }
-  h->timed = false;
-  h->n_pairs = 0;
-  rc = riab::launch_agent_pub(a, main_s);
+  return sched;
+}
+
+extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream_t stream) {
+  if (!h || !q || !q->env || !q->motion || !q->pops || !q->ctrl || !q->hist || q->n_pops <= 0 || q->T <= 0) return RIAB_EINVAL;
+  const RiabEnv* env = q->env;
+  const RiabPopulation* pops = q->pops;
+  const int32_t T = q->T, n_pops = q->n_pops;
+  const int64_t B = q->B;
+  if (B <= 0 || B % 4 != 0) return RIAB_EALIGN;
+  if (q->forced_pos && (q->noise || q->drift)) return RIAB_EINVAL;
+  int rc = check_populations(pops, n_pops, T);
   if (rc) return rc;
-  const uint32_t n_traj = (uint32_t)(B / 64);
-  h->started_total += n_traj;
-  // (from here on the state has advanced: a later failure still joins the side stream and returns RIAB_EPARTIAL.
-  // The first progress gate also waits until every trajectory workgroup of this launch is resident — it may have to
-  // sit out what is queued in front of the trajectory kernel — so there is no separate started gate.)
-  int fail = RIAB_OK;
-  int32_t t0 = 0;
-  for (size_t k = 0; k < sched.size() && !fail; ++k) {
-    const int32_t tc = sched[k];
-    fail = riab::launch_stream_gate(ctrl, h->started_total, n_traj, (uint32_t)step0 + (uint32_t)(t0 + tc),
-                                    k == 0 ? 1u << 24 : 1u << 22, false, rate_s);
-    for (int i = 0; i < n_pops && !fail; ++i) {
-      if (timing && i == timed_pop) (void)hipEventRecord(h->pairs[2 * k], rate_s);
-      fail = launch_pop_rows(env, pops, i, hist, B, t0, tc, (float)motion->dt, seed, step0, agent_id0, rate_s);
-      if (timing && i == timed_pop) (void)hipEventRecord(h->pairs[2 * k + 1], rate_s);
+  riab::AgentArgs a;
+  rc = riab::fill_agent_args(a, env, q->motion, q->state, B, q->agent_id0, q->drift, q->noise, nullptr, q->forced_pos, q->seed,
+                             q->step0, T, q->hist, q->diag, 64, q->resample_pos);
+  if (rc) return rc;
+  a.ctrl = q->ctrl;
+  hipStream_t main_s = (hipStream_t)stream;
+  const float dt = (float)q->motion->dt;
+  const bool timing = q->timed_pop >= 0 && q->timed_pop < n_pops;
+  h->timed = 0;
+  h->n_pairs = 0;
+
+  // ---- forced positions: no recurrence, nothing to overlap: one stream, kernel after kernel --------------------------
+  if (q->forced_pos) {
+    rc = riab::launch_agent_forced(a, main_s);
+    if (rc) return rc;
+    int fail = RIAB_OK;
+    for (int32_t t0 = 0; t0 < T && !fail; t0 += 4096) {  // (time rows are a grid axis of the rate kernels)
+      const int32_t tc = T - t0 < 4096 ? T - t0 : 4096;
+      for (int i = 0; i < n_pops && !fail; ++i)
+        fail = launch_pop_rows(env, pops, i, q->hist, B, t0, tc, dt, q->seed, q->step0, q->agent_id0, main_s);
     }
-    t0 += tc;
+    return fail ? RIAB_EPARTIAL : RIAB_OK;
   }
-  if (!fail && timing) {
-    h->n_pairs = (int)sched.size();
-    h->timed = true;
+
+  // ---- which form of the rate stage; every argument check before the first launch ------------------------------------
+  const bool gated = n_pops == 1 && T <= h->poll_max && riab::stream_supported(env, &pops[0], B) == RIAB_OK;
+  // ~0.3 us per poll: a generous second or two before a wait gives up (a healthy wait is tens of microseconds)
+  const uint32_t spin_limit = 1u << 20;
+  std::vector<int32_t> sched;
+  if (gated) {
+    rc = riab::launch_rate_stream(env, &pops[0], q->hist, B, T, dt, q->seed, q->step0, q->agent_id0, q->ctrl, spin_limit, false,
+                                  main_s, nullptr, nullptr, /*dry_run=*/true);
+    if (rc) return rc;
+    if (q->timing_mode == RIAB_TIMING_EVENTS && timing && !h->t0) {
+      if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess) return RIAB_EINVAL;
+    }
+  } else {
+    sched = chunk_schedule(env, T);
+    if (timing) {
+      while (h->pairs.size() < 2 * sched.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return RIAB_EINVAL;
+        h->pairs.push_back(e);
+      }
+    }
   }
+
+  // ---- the trajectory kernel, on the streamer's own stream -----------------------------------------------------------
+  // It has to start after what the caller's stream holds (earlier calls' kernels wrote the state it reads).  When that
+  // stream is idle — the case that matters for latency: one short call per synchronisation — there is nothing to wait
+  // for and the launch goes out with no API call in front of it but the query; otherwise an event carries the order.
+  const bool idle = hipStreamQuery(main_s) == hipSuccess;
+  if (!idle) {
+    hipError_t e = hipEventRecord(h->fork, main_s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->fork, 0);
+    if (e != hipSuccess) return (int)e;
+  }
+  rc = riab::launch_agent_pub(a, h->side);
+  if (rc) return rc;
+  const uint32_t n_traj = (uint32_t)((B + 63) / 64);
+  h->started_total += n_traj;
+  // From here on the state has advanced: a later failure still joins the two streams and is reported as RIAB_EPARTIAL
+  // (the trajectory rows are complete, the rates of this call are not).
+  int fail = RIAB_OK;
+  if (gated) {
+    // Both kernels must be resident at once or the rate waves spin for nothing: a one-wave gate in front of the rate
+    // kernel returns only once every trajectory workgroup of THIS launch has announced itself — the rate waves can then
+    // never occupy the slots the kernel they wait for still needs, whatever else runs on the device (another stream,
+    // another process: two ranks sharing one GPU ran into the waits' time limit without it).  RIAB_GATE_WHEN_BUSY drops
+    // it when the caller's stream was idle (callers that own the device).  The gate also resets the device time stamps.
+    const bool stamps = timing && q->timing_mode != RIAB_TIMING_EVENTS;
+    const bool gate = stamps || h->gate_mode == RIAB_GATE_ALWAYS || !idle;
+    // (the started gate is one sleeping wave; it may have to sit out whatever runs in front of the trajectory kernel)
+    if (gate) fail = riab::launch_stream_gate(q->ctrl, h->started_total, 0, 0, 1u << 24, true, stamps, main_s);
+    const bool events = timing && !stamps;
+    if (!fail)
+      fail = riab::launch_rate_stream(env, &pops[0], q->hist, B, T, dt, q->seed, q->step0, q->agent_id0, q->ctrl, spin_limit,
+                                      stamps, main_s, events ? h->t0 : nullptr, events ? h->t1 : nullptr, false);
+    if (!fail && timing) {
+      h->timed = stamps ? 2 : 1;
+      h->stamp_ctrl = q->ctrl;
+    }
+  } else {
+    // (the first progress gate also waits until every trajectory workgroup of this launch is resident — it may have to
+    // sit out what is queued in front of the trajectory kernel — so there is no separate started gate)
+    int32_t t0 = 0;
+    for (size_t k = 0; k < sched.size() && !fail; ++k) {
+      const int32_t tc = sched[k];
+      // ~0.5 us per poll: seconds before a gate gives up (a healthy wait is one chunk of trajectory, < 1 ms)
+      fail = riab::launch_stream_gate(q->ctrl, h->started_total, n_traj, (uint32_t)q->step0 + (uint32_t)(t0 + tc),
+                                      k == 0 ? 1u << 24 : 1u << 22, false, false, main_s);
+      for (int i = 0; i < n_pops && !fail; ++i) {
+        if (timing && i == q->timed_pop) (void)hipEventRecord(h->pairs[2 * k], main_s);
+        fail = launch_pop_rows(env, pops, i, q->hist, B, t0, tc, dt, q->seed, q->step0, q->agent_id0, main_s);
+        if (timing && i == q->timed_pop) (void)hipEventRecord(h->pairs[2 * k + 1], main_s);
+      }
+      t0 += tc;
+    }
+    if (!fail && timing) {
+      h->n_pairs = (int)sched.size();
+      h->timed = 1;
+    }
+  }
+  // the caller's stream continues after the trajectory kernel as well (its state rows, its last history rows)
   hipError_t e = hipEventRecord(h->join, h->side);
   if (e == hipSuccess) e = hipStreamWaitEvent(main_s, h->join, 0);
   if (fail) return RIAB_EPARTIAL;
@@ -376,6 +380,7 @@ extern "C" int64_t riab_abi_sizeof(int32_t which) {
     case 4: return (int64_t)sizeof(RiabTask);
     case 5: return (int64_t)sizeof(RiabFFInput);
     case 6: return (int64_t)RIAB_TS_ROWS;
+    case 7: return (int64_t)sizeof(RiabSimulate);
     default: return -1;
   }
 }

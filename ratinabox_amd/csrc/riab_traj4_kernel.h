@@ -45,6 +45,11 @@ namespace riab {
 #ifndef RIAB_T4_ABLATE
 #define RIAB_T4_ABLATE 0  // timing experiments only (tools/traj_probe.py): bits switch parts of the step off
 #endif
+#ifdef RIAB_T4_PROFILE  // timing experiments only: shader-clock stamps of workgroup 0's G and S waves into a.z_out
+#define T4_STAMP(k) do { if (blockIdx.x == 0 && t < 256) { const long long c_ = clock64(); if (lane == 0) ((long long*)a.z_out)[t * 8 + (k)] = c_; } } while (0)
+#else
+#define T4_STAMP(k) do { } while (0)
+#endif
 #define RIAB_T4_RING 16  // steps of noise ahead of the stepping waves / of hand-over slack in front of the tail wave
 #define RIAB_T4_SENT 0x7FF8DEADBEEF0001ull  // a NaN payload no arithmetic produces: "slot empty"
 #define RIAB_T4_SPIN_LIMIT (1u << 24)       // ~70 ns per poll: about a second
@@ -90,6 +95,7 @@ __device__ __forceinline__ void t4_flush_hist(const AgentArgs& a, const float* s
   const uint32_t hist_glb_lane = (uint32_t)(((int64_t)(lane >> 4) * a.B + (lane & 15) * 4) * 4);  // bytes
   const int n2 = 2 * n_steps;
   float* const g0 = a.hist + (int64_t)t0 * RIAB_HIST_ROWS * a.B + (int64_t)blockIdx.x * 64;
+  if ((int64_t)blockIdx.x * 64 + (lane & 15) * 4 >= a.B) return;  // (a quad of agents beyond the batch: last workgroup only)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if (j < n2) {
@@ -101,7 +107,9 @@ __device__ __forceinline__ void t4_flush_hist(const AgentArgs& a, const float* s
   }
 }
 
-// IN: 0 = in-kernel Philox noise, 1 = explicit normals a.z_in.  Whole waves (B % 64 == 0), float64.
+// IN: 0 = in-kernel Philox noise, 1 = explicit normals a.z_in.  float64.  Any B that is a multiple of 4: the lanes of
+// the last workgroup beyond B shadow the workgroup's first agent (same loads, same arithmetic, same values) and store
+// nothing.
 template <int IN, bool PUB>
 __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
   RIAB_EXACT_FP
@@ -131,7 +139,8 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
   const t4_slot_ptr slot_v2 = (t4_slot_ptr)&s_v2[lane], slot_f = (t4_slot_ptr)&s_f[lane];
   const RiabMotion& m = a.m;
   const int64_t B = a.B;
-  const int64_t b = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = (int64_t)blockIdx.x * 64 + lane < B;
+  const int64_t b = live ? (int64_t)blockIdx.x * 64 + lane : (int64_t)blockIdx.x * 64;
   const uint32_t aid = (uint32_t)(a.agent_id0 + b);
   double* st = a.state + b;
   const int T = a.T;
@@ -161,6 +170,7 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
         noise_ready = t4_wait_counter(cnt, T4_C_NOISE, (uint32_t)t, false);
         if (!noise_ready) { gave_up = true; break; }
       }
+      T4_STAMP(0);
       const R cs = s_cs[t % RIAB_T4_RING][lane], sn = s_sn[t % RIAB_T4_RING][lane];
       const R ppx = px, ppy = py;  // prev_pos (Agent.py:199)
       // ---- _stochastic_velocity_update: the rotation (Agent.py:287-300) ----
@@ -178,8 +188,10 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
         dwall = r_sqrt_fast(near.x2min);
       }
       // ---- the speed factor of this step from wave S ----
+      T4_STAMP(1);
       R f;
       if (!t4_take(slot_f, &f)) { gave_up = true; break; }
+      T4_STAMP(2);
       vx *= f;
       vy *= f;
       // ---- _drift_velocity_update (Agent.py:331-341) ----
@@ -191,6 +203,7 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
       // the velocity of this step is final: wave S can start on the next one
       v2 = norm2(vx, vy);
       if (t + 1 < T) *slot_v2 = (unsigned long long)__double_as_longlong(v2);
+      T4_STAMP(3);
       if (!(RIAB_T4_ABLATE & 2)) boundary_net<R>(K, a, s_w, t, b, aid, px, py, n_bc, n_sat);
       // ---- hand the step over to wave T (Agent.py:456-458: the displacement, periodic-aware) ----
       R dpx, dpy;
@@ -206,13 +219,16 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
       *reinterpret_cast<v2f32*>(&s_pp[t % RIAB_T4_RING][lane][0]) = v2f32{(float)px, (float)py};
       asm volatile("" ::: "memory");  // (LDS executes a wave's instructions in order: data, then the counter)
       cnt[T4_C_GDONE] = (uint32_t)(t + 1);
+      T4_STAMP(4);
     }
-    st[0 * B] = px;
-    st[1 * B] = py;
-    st[2 * B] = vx;
-    st[3 * B] = vy;
-    st[11 * B] = dwall;
-    if (a.diag) {
+    if (live) {
+      st[0 * B] = px;
+      st[1 * B] = py;
+      st[2 * B] = vx;
+      st[3 * B] = vy;
+      st[11 * B] = dwall;
+    }
+    if (a.diag && live) {
       if (n_bounce) atomicAdd(a.diag + 0, n_bounce);
       if (n_sat) atomicAdd(a.diag + 1, n_sat);
       if (n_bc) atomicAdd(a.diag + 2, n_bc);
@@ -226,6 +242,7 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
     for (int t = 0; t < T; ++t) {
       R v2;
       if (!t4_take(slot_v2, &v2)) { gave_up = true; break; }
+      T4_STAMP(5);
       if ((uint32_t)t >= noise_ready) {
         noise_ready = t4_wait_counter(cnt, T4_C_NOISE, (uint32_t)t, false);
         if (!noise_ready) { gave_up = true; break; }
@@ -253,6 +270,7 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
       if (m.speed_std_is_zero) speed_new = sm_kw;
       const R f = speed_new * ispeed;
       *slot_f = (unsigned long long)__double_as_longlong(f);
+      T4_STAMP(6);
     }
   } else if (wave == 2) {
     // ================================ wave N: noise and the rotational-velocity OU =================================
@@ -290,10 +308,12 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
         z_rot = (R)d.z_rot;
         z_spd = (R)d.z_spd;
       }
-      if (a.z_out) {
+#ifndef RIAB_T4_PROFILE
+      if (a.z_out && live) {
         a.z_out[((int64_t)t * 2 + 0) * B + b] = (double)z_rot;
         a.z_out[((int64_t)t * 2 + 1) * B + b] = (double)z_spd;
       }
+#endif
       // utils.ornstein_uhlenbeck on the rotational velocity (Agent.py:287-294), then sin / cos of the heading increment
       rot = ou_step<R>(rot, (R)m.rot_theta_kw, (R)m.rot_drift_kw, (R)m.rot_sigma_kw, dt, z_rot);
       R sn, cs;
@@ -309,7 +329,7 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
       asm volatile("" ::: "memory");
       cnt[T4_C_NOISE] = (uint32_t)(t + 1);
     }
-    st[4 * B] = rot;
+    if (live) st[4 * B] = rot;
   } else {
     // ================================ wave T: output-only tail, history rows, publication ==========================
     const TailConst<R> tail_c = {(R)m.dt, (R)(1.0 / m.dt), (R)(1.0 - m.dt / m.hd_tau), (R)(m.dt / m.hd_tau),
@@ -385,13 +405,15 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       publish(T);
     }
-    st[5 * B] = (double)tl.mvx;
-    st[6 * B] = (double)tl.mvy;
-    st[7 * B] = (double)tl.mrot;
-    st[8 * B] = (double)tl.hx;
-    st[9 * B] = (double)tl.hy;
-    st[10 * B] = (double)tl.dist;
-    if (a.diag && tl.n_still) atomicAdd(a.diag + 3, tl.n_still);
+    if (live) {
+      st[5 * B] = (double)tl.mvx;
+      st[6 * B] = (double)tl.mvy;
+      st[7 * B] = (double)tl.mrot;
+      st[8 * B] = (double)tl.hx;
+      st[9 * B] = (double)tl.hy;
+      st[10 * B] = (double)tl.dist;
+      if (a.diag && tl.n_still) atomicAdd(a.diag + 3, tl.n_still);
+    }
   }
   if (gave_up && lane == 0) {
     // report it like the consumers' timeouts (Agent.diagnostics["pipeline_timeouts"]; diag[1]: saturations)

@@ -1,4 +1,4 @@
-"""GPU tests of the flag-coupled pipeline (`riab_simulate_fused`: the trajectory kernel publishing its rows to a
+"""GPU tests of the flag-coupled pipeline (`riab_simulate`: the trajectory kernel publishing its rows to a
 persistent firing-rate kernel that runs concurrently, csrc/riab_simulate.hip).
 
 The pipeline runs the SAME arithmetic as the chunked two-stream path (`RIAB_NO_FUSED=1`), which the parity
@@ -403,7 +403,7 @@ def _multi_world(riab, B, seed=5, polygon=False):
 @pytest.mark.parametrize("B, schedule, drift, polygon", [(64, [20], None, False), (256, [150, 7], [0.05, -0.02], False),
                                                         (128, [300], None, False), (128, [300, 40], None, True)])
 def test_native_multi_population_simulate_equals_chunked_pipeline(riab, B, schedule, drift, polygon):
-    """Agent.simulate() with several populations is ONE native call (riab_simulate_pops: every chunk of rows behind a
+    """Agent.simulate() with several populations is ONE native call (riab_simulate: every chunk of rows behind a
     gate, each population's ordinary kernel, noise pass and spikes after it) and gives, bit for bit, what the
     Python-driven chunked pipeline gives: place / grid (+ OU noise) / head direction / boundary (allo- and egocentric) /
     object vector cells and a FeedForwardLayer reading two of them, spikes included."""
@@ -509,7 +509,7 @@ def test_imported_trajectory_through_plans_equals_eager_loop(riab):
 
 
 def test_simulate_pops_argument_errors_launch_nothing(riab):
-    """riab_simulate_pops validates before it launches: bad argument sets come back as negative codes and leave the
+    """riab_simulate validates before it launches: bad argument sets come back as negative codes and leave the
     agent state and the control words untouched."""
     L = riab._lib
     env, ag, pops = _multi_world(riab, 64)
@@ -536,13 +536,17 @@ def test_simulate_pops_argument_errors_launch_nothing(riab):
             arr[len(pops) - 1].input_index[0] = ff_input
         if kind is not None:
             arr[1].kind = kind
-        return L.lib.riab_simulate_pops(ag._streamer, envs, m, ag._state.data_ptr(), ag._Bp if B is None else B, 0, None,
-                                        int(ag.rng_seed), int(ag._step_index), T, hist.data_ptr(), ag._diag.data_ptr(),
-                                        L.C.addressof(arr), len(pops) if n_pops is None else n_pops, ag._ctrl.data_ptr(),
-                                        -1, L.current_stream())
+        run = L.RiabSimulate()
+        run.env, run.motion = L.C.pointer(envs), L.C.pointer(m)
+        run.state, run.B, run.agent_id0 = ag._state.data_ptr(), ag._Bp if B is None else B, 0
+        run.seed, run.step0, run.T = int(ag.rng_seed), int(ag._step_index), T
+        run.hist, run.diag, run.ctrl = hist.data_ptr(), ag._diag.data_ptr(), ag._ctrl.data_ptr()
+        run.pops, run.n_pops = L.C.cast(arr, L.C.POINTER(L.RiabPopulation)), len(pops) if n_pops is None else n_pops
+        run.timed_pop = -1
+        return L.lib.riab_simulate(ag._streamer, L.C.byref(run), L.current_stream())
 
     assert call(n_pops=0) == L.EINVAL
-    assert call(B=ag._Bp + 4) == L.EUNSUPPORTED            # not whole waves
+    assert call(B=ag._Bp + 2) == L.EALIGN                  # not whole quads of agents
     assert call(cap=T - 1) == L.EINVAL                      # rows for the whole run are required
     assert call(ff_input=len(pops) - 1) == L.EINVAL         # a layer reading itself / a later population
     assert call(kind=L.POP_KINDS["velocity"]) == L.EUNSUPPORTED

@@ -19,7 +19,7 @@ for _ in range(300):
 print("K=%d  simulate() returns after %.1f us (min %.1f); synchronize() waits another %.1f us (min %.1f); total median %.1f us" % (
     K, 1e6 * np.median(a), 1e6 * min(a), 1e6 * np.median(b), 1e6 * min(b), 1e6 * np.median(np.add(a, b))))
 # the native call itself inside simulate(): time before it, inside it, after it
-real = riab._lib.lib.riab_simulate_fused
+real = riab._lib.lib.riab_simulate
 marks = []
 class _Lib:
     def __getattr__(self, k):
@@ -27,7 +27,7 @@ class _Lib:
 def wrapped(*a):
     t = time.perf_counter(); rc = real(*a); marks.append((t, time.perf_counter())); return rc
 _orig = riab._lib.lib
-proxy = _Lib(); proxy.__dict__["riab_simulate_fused"] = wrapped
+proxy = _Lib(); proxy.__dict__["riab_simulate"] = wrapped
 riab._lib.lib = proxy
 import ratinabox_amd.Agent as A
 pre, nat, post = [], [], []

@@ -62,14 +62,14 @@ def main():
         if spin:
             rc = L.lib.riab_host_wait_spin(1)  # hipSetDeviceFlags(hipDeviceScheduleSpin)
             print("riab_host_wait_spin(1) ->", rc, flush=True)
-        for timing in (True, False):
+        for timing in (True, "events", False):
             for gate in (1, 0):
                 ag, pops = world()
                 ag._time_rate_kernel = timing
                 fresh(ag, pops)
                 ag.simulate(K)
                 L.lib.riab_streamer_configure(ag._streamer, L.STREAMER_OPT_GATE, 0 if gate else 1)
-                measure(ag, pops, "spin=%d timing=%d gate=%s" % (spin, timing, "always" if gate else "auto"))
+                measure(ag, pops, "spin=%d timing=%s gate=%s" % (spin, timing, "always" if gate else "when-busy"))
                 del ag, pops
                 torch.cuda.empty_cache()
 
