@@ -161,75 +161,13 @@ def relaunch_as_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1024)
-    ap.add_argument("--warmup", type=int, default=128)
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--chunk", type=int, default=128, help="steps per kernel launch in the chunked two-stream path")
-    ap.add_argument("--precision", type=int, default=64, choices=(32, 64), help="motion-kernel arithmetic")
-    ap.add_argument("--repeats", type=int, default=0, help="repeats of the timed K-step region (0 = by K)")
-    ap.add_argument("--per-step", action="store_true", help="time the drop-in per-step API instead of simulate()")
-    ap.add_argument("--plan", action="store_true", help="time the closed-loop path through a native step plan")
-    ap.add_argument("--plan-batch", type=int, default=1, help="steps per riab_plan_step call (1 = closed loop)")
-    ap.add_argument("--task", action="store_true",
-                    help="closed loop through the batched TaskEnvironment: goal-seeking actions, rewards, goal checks "
-                         "and per-lane auto-reset every step (implies --plan)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling: the config's agents are the TOTAL, split over the ranks (default: weak scaling, "
-                         "the config's agents per GPU)")
-    ap.add_argument("--no-history", action="store_true", help="ring buffers instead of a full T-long history")
-    ap.add_argument("--event-timing", action="store_true",
-                    help="time the one-kernel rate stage with HIP start / stop events on its launch instead of the "
-                         "device clock stamps")
-    args = ap.parse_args()
-
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(relaunch_as_ranks(args))
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus:
-        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a line for the wrong rank count",
-              file=sys.stderr)
-        sys.exit(2)
-
+def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, control_plane, store_ceiling=True):
+    """One configuration: build the world, W warm-up steps, `repeats` timed K-step regions; the contract's fields
+    (rank 0; None elsewhere) and the configuration."""
     import numpy as np
     import torch
-    share = os.environ.get("RIAB_BENCH_SHARE_GPU") == "1"  # test hook: all ranks on cuda:0, gloo control plane
-    if share:
-        local = 0
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        ctrl_on_cpu = share
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            # The step path has no collective: the process group only carries the barriers and the max-reduce of the
-            # timings.  RCCL first; if it cannot be brought up on this node, the same control plane over gloo (every
-            # rank fails the same way, so every rank falls back) rather than no line at all.
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-                probe = torch.zeros(1, device="cuda")
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-            except Exception as e:  # noqa: BLE001
-                print(f"[bench] rank {rank}: RCCL control plane failed ({type(e).__name__}: {e}); using gloo", file=sys.stderr)
-                try:
-                    dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-                dist.init_process_group("gloo")
-                ctrl_on_cpu = True
-
     import ratinabox_amd as riab
-    cfg = dict(CONFIGS[args.config])
+    cfg = dict(CONFIGS[config])
     if args.strong and world > 1:   # (SURVEY 8e: a fixed batch over more GPUs is launch-bound; labelled "strong")
         per = cfg["agents"] // world // 256 * 256
         if per <= 0:
@@ -242,7 +180,7 @@ def main():
     # the full rate history of K steps must fit in HBM next to the warmup's; otherwise stream
     # through ring buffers (every byte is still written, the oldest rows are overwritten)
     n_cells = sum(int(p.n) for p in pops)
-    need = (args.steps + args.warmup) * cfg["agents"] * (n_cells * (5 if cfg["spikes"] else 4) + 32)
+    need = (K + W) * cfg["agents"] * (n_cells * (5 if cfg["spikes"] else 4) + 32)
     free_b, _total_b = torch.cuda.mem_get_info()
     if need > 0.6 * free_b:
         args.no_history = True
@@ -251,12 +189,12 @@ def main():
         for p in pops:
             p.save_history = False
     B = cfg["agents"]
-    K, W = args.steps, args.warmup
-    R = args.repeats or max(3, min(20, 4096 // max(K, 1)))
+    R = repeats or max(3, min(20, 4096 // max(K, 1)))
     # the chunked two-stream path (several populations): about four chunks in flight for short runs so that the
     # two pipeline stages still overlap (below ~64 steps a single launch of each stage is faster)
-    if K < 4 * args.chunk:
-        args.chunk = K if K <= 64 else max(32, (K // 4 + 3) // 4 * 4)
+    chunk = args.chunk
+    if K < 4 * chunk:
+        chunk = K if K <= 64 else max(32, (K // 4 + 3) // 4 * 4)
 
     plan = {"p": None}
     native = not (args.per_step or args.plan) and os.environ.get("RIAB_NO_NATIVE") != "1" and ag.precision == 64
@@ -288,7 +226,7 @@ def main():
                 for p in pops:
                     p.update()
         else:
-            ag.simulate(n_steps, chunk=args.chunk)
+            ag.simulate(n_steps, chunk=chunk)
 
     def barrier():
         if dist is not None:
@@ -312,7 +250,7 @@ def main():
     # second one otherwise: each record is a packet on a stream that runs back to back, ~3 % of the value).
     spans = []
     seen = {"n": 0}
-    n_launches = (K + args.chunk - 1) // max(args.chunk, 1)
+    n_launches = (K + chunk - 1) // max(chunk, 1)
 
     # the dominant kernel: BoundaryVectorCells where there are any (65-70 % of the kernel time of cfg 3 / cfg 5,
     # profiles/r02_cfg3_kernel_stats.csv), else the first population
@@ -397,7 +335,7 @@ def main():
         avg_units = float(np.mean(units))
         achieved = unit_bytes * avg_units / (avg_ms * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}.json")
+        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{config}.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = round(json.load(f).get("hbm_bytes_per_unit") * avg_units)  # PMC bytes/unit x units/launch
@@ -452,7 +390,7 @@ def main():
 
     # the chip's measured store ceiling in this same process (riab_fill: one float4 per thread,
     # address-ordered), for context next to the spec peak
-    if rank == 0 and roofline is not None:
+    if rank == 0 and roofline is not None and store_ceiling:
         L = riab._lib
         nbytes = 1 << 30
         buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
@@ -464,28 +402,29 @@ def main():
             L.lib.riab_fill(L.ptr(buf), nbytes, 1.0, L.current_stream())
         e1.record()
         torch.cuda.synchronize()
-        store_ceiling = 5 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        roofline["measured_store_ceiling_GBps"] = round(store_ceiling, 1)
+        ceiling = 5 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        roofline["measured_store_ceiling_GBps"] = round(ceiling, 1)
         if roofline["bound"] == "hbm":
-            roofline["frac_of_measured_store_ceiling"] = round(roofline["achieved"] / store_ceiling, 4)
+            roofline["frac_of_measured_store_ceiling"] = round(roofline["achieved"] / ceiling, 4)
         del buf
 
+    out = None
     if rank == 0:
         api = ("TaskEnvironment step plan: action, Agent.update, rewards/goals, auto-reset, rates; one native call per step"
                if args.task else "step plan (one native call per step)" if args.plan else "per-step update()"
                if args.per_step else "simulate(): trajectory kernel + rate stage running concurrently, coupled by flags in device memory, one native call"
                if fused_mode else "simulate(): trajectory kernel + every population's kernels per chunk of rows behind gates, "
                "one native call (riab_simulate)" if native_mode
-               else f"simulate(): chunked two-stream pipeline, {args.chunk} steps/launch")
+               else f"simulate(): chunked two-stream pipeline, {chunk} steps/launch")
         out = {
             "metric": metric_name(cfg),
             "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(med / K * 1e3, 6), "higher_is_better": True,
             "scaling": "strong" if (args.strong and world > 1) else "weak",
             "vs_baseline": None, "dtype": "f32 rates / f%d motion" % args.precision, "data": "synthetic",
-            "config": {"workload": args.config + ": " + cfg["desc"], "agents_per_gpu": B,
+            "config": {"workload": config + ": " + cfg["desc"], "agents_per_gpu": B,
                        "cells": {k: cfg[k] for k in ("place", "grid", "bvc", "hdc")},
-                       "parallelism": f"agent-sharded x{world}, no step-path collective",
+                       "parallelism": f"agent-sharded x{world}, no step-path collective", "control_plane": control_plane,
                        "api": api, "history": "ring" if args.no_history else "full", "spikes": cfg["spikes"],
                        "bytes_per_agent_step": bpu},
             "repeats": R,
@@ -498,12 +437,120 @@ def main():
             "frac_whole_path": round(value / world * bpu / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
         diag = ag.diagnostics
         if args.task:
             diag = dict(diag, **env.diagnostics, episodes_finished=len(env.episodes["episode"]))
         out["diagnostics"] = diag
+    del ag, pops, env
+    torch.cuda.empty_cache()
+    return out, cfg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--chunk", type=int, default=128, help="steps per kernel launch in the chunked two-stream path")
+    ap.add_argument("--precision", type=int, default=64, choices=(32, 64), help="motion-kernel arithmetic")
+    ap.add_argument("--repeats", type=int, default=0, help="repeats of the timed K-step region (0 = by K)")
+    ap.add_argument("--per-step", action="store_true", help="time the drop-in per-step API instead of simulate()")
+    ap.add_argument("--plan", action="store_true", help="time the closed-loop path through a native step plan")
+    ap.add_argument("--plan-batch", type=int, default=1, help="steps per riab_plan_step call (1 = closed loop)")
+    ap.add_argument("--task", action="store_true",
+                    help="closed loop through the batched TaskEnvironment: goal-seeking actions, rewards, goal checks "
+                         "and per-lane auto-reset every step (implies --plan)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the config's agents are the TOTAL, split over the ranks (default: weak scaling, "
+                         "the config's agents per GPU)")
+    ap.add_argument("--no-history", action="store_true", help="ring buffers instead of a full T-long history")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="bring the process group (RCCL control plane: barriers + the max-reduce of the timings) up even "
+                         "for one rank, when launched by torch.distributed.run (a one-GPU test of the multi-GPU launch form)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short cfg3 / cfg4 / cfg5 runs reported in the `secondary` block of the cfg2 line")
+    ap.add_argument("--event-timing", action="store_true",
+                    help="time the one-kernel rate stage with HIP start / stop events on its launch instead of the "
+                         "device clock stamps")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(relaunch_as_ranks(args))
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a line for the wrong rank count",
+              file=sys.stderr)
+        sys.exit(2)
+
+    import numpy as np
+    import torch
+    share = os.environ.get("RIAB_BENCH_SHARE_GPU") == "1"  # test hook: all ranks on cuda:0, gloo control plane
+    if share:
+        local = 0
+    torch.cuda.set_device(local)
+    dist = None
+    control_plane = "none"
+    if world > 1 or (args.force_process_group and "RANK" in os.environ):
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        ctrl_on_cpu = share
+        if share:
+            dist.init_process_group("gloo")
+            control_plane = "gloo"
+        else:
+            # The step path has no collective: the process group only carries the barriers and the max-reduce of the
+            # timings.  RCCL first; if it cannot be brought up on this node, the same control plane over gloo (every
+            # rank fails the same way, so every rank falls back) rather than no line at all.
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                probe = torch.zeros(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                control_plane = "nccl"
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: RCCL control plane failed ({type(e).__name__}: {e}); using gloo", file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                dist.init_process_group("gloo")
+                ctrl_on_cpu = True
+                control_plane = "gloo"
+
+    out, cfg = measure(args, args.config, args.steps, args.warmup, args.repeats, rank, world, local, dist, ctrl_on_cpu if dist
+                       is not None else False, control_plane)
+    # ---- the other BASELINE configurations under the same clock: short runs, one block in the same line ----------------
+    secondary = {}
+    if world == 1 and args.config == "cfg2" and not (args.no_secondary or args.per_step or args.plan or args.task):
+        saved = args.no_history
+        for name in ("cfg3", "cfg4", "cfg5"):
+            args.no_history = False
+            t0 = time.perf_counter()
+            try:
+                o, c = measure(args, name, 256, 32, 3, rank, world, local, dist, False, control_plane, store_ceiling=False)
+            except Exception as e:  # noqa: BLE001  (the headline line must not be lost to a secondary run)
+                secondary[name] = {"error": f"{type(e).__name__}: {e}"}
+                continue
+            r = o["roofline"] or {}
+            secondary[name] = {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "steps": 256,
+                               "warmup": 32, "repeats": o["repeats"], "ms_per_step": o["ms_per_step"],
+                               "timed_region_ms": o["timed_region_ms"]["median"],
+                               "bytes_per_agent_step": o["config"]["bytes_per_agent_step"],
+                               "frac_whole_path": o["frac_whole_path"],
+                               "roofline": {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel",
+                                                                  "launches", "avg_launch_ms", "units_per_launch")},
+                               "wall_s": round(time.perf_counter() - t0, 2)}
+        args.no_history = saved
+    if rank == 0:
+        if secondary:
+            out["secondary"] = secondary
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -99,7 +99,7 @@ class Agent:
         self._auto_after = self.AUTO_AFTER
         self._auto_enabled = os.environ.get("RIAB_NO_AUTO_PLAN") != "1"
         self._streamer = None   # native handle of the flag-coupled pipeline (created on first use)
-        self._run_struct = None  # its argument block (RiabSimulate), reused from call to call
+        self._run_cache = None  # (population structs, their array, the RiabSimulate argument block, key) of the last call
         self._ctrl = None       # its control words on the device
         self._pipeline_unchecked = False
         self._time_rate_kernel = False
@@ -550,45 +550,54 @@ class Agent:
             traj_c, traj_s = self._hist.reserve_at(n_steps)
         else:
             traj_c, traj_s = torch.empty((n_steps, _L.HIST_ROWS, Bp), dtype=torch.float32, device=self._device), 0
-        outs = [N._reserve_rows(n_steps, ring=128) for N in neurons]   # (rings of 256 rows where rates are not saved)
+        ats = [N._reserve_rows_at(n_steps, 128) for N in neurons]   # (rings of 256 rows where rates are not saved)
         piece = n_steps
-        for o in outs:
-            if o["ring"] is not None and o["ring"] < piece:
-                piece = o["ring"]
+        for at in ats:
+            if at[4] is not None and at[4] < piece:
+                piece = at[4]
         npop = len(neurons)
-        arr = (_L.RiabPopulation * npop)()
-        bases = []
-        for i, (pop, out) in enumerate(zip(structs, outs)):
-            _L.C.memmove(_L.C.byref(arr, i * _L.POP_SIZE), _L.C.byref(pop), _L.POP_SIZE)
-            n = int(neurons[i].n)
-            full_rows = out["ring"] is None
-            bases.append((out["fr"].data_ptr(), out["sp"].data_ptr() if out["sp"] is not None else None,
-                          n * Bp * 4 if full_rows else 0, n * Bp if full_rows else 0))
         timed = -1
         if self._time_rate_kernel:
             tp = getattr(self, "_timed_population", None)
             timed = neurons.index(tp) if tp in neurons else 0
+        # The array of population structs and the argument block are kept from call to call, with everything that does
+        # not change between two calls of a loop already in them (the structs themselves are cached by the populations
+        # while their tables do not change; `env` / `m` are cached objects while geometry / parameters do not change).
+        key = (env, m, self.agent_id0, self.seed, self.agent_idx, timed, self._time_rate_kernel, drift is None)
+        cache = self._run_cache
+        if cache is None or cache[3] != key or len(cache[0]) != npop or any(x is not y for x, y in zip(cache[0], structs)):
+            arr = (_L.RiabPopulation * npop)()
+            for i, pop in enumerate(structs):
+                _L.C.memmove(_L.C.byref(arr, i * _L.POP_SIZE), _L.C.byref(pop), _L.POP_SIZE)
+            run = _L.RiabSimulate()
+            run.pops, run.n_pops = _L.C.cast(arr, _L.C.POINTER(_L.RiabPopulation)), npop
+            run.env, run.motion = _L.C.pointer(env), _L.C.pointer(m)
+            run.state, run.B, run.agent_id0 = self._state.data_ptr(), Bp, int(self.agent_id0)
+            run.seed = int(self.rng_seed)
+            run.diag, run.ctrl, run.timed_pop = self._diag.data_ptr(), self._ctrl.data_ptr(), timed
+            run.timing_mode = 1 if self._time_rate_kernel == "events" else 0
+            cache = self._run_cache = (list(structs), arr, run, key, _L.C.byref(run))
+        arr, run, byref = cache[1], cache[2], cache[4]
+        run.drift = drift.data_ptr() if drift is not None else None
+        bases = []
+        for N, at in zip(neurons, ats):
+            n = int(N.n)
+            fr_row, sp_row = (n * Bp * 4, n * Bp) if at[4] is None else (0, 0)
+            bases.append((at[0].data_ptr() + at[1] * n * Bp * 4, None if at[2] is None else at[2].data_ptr() + at[3] * n * Bp,
+                          fr_row, sp_row))
         traj_row = _L.HIST_ROWS * Bp * 4
         traj_p = traj_c.data_ptr() + traj_s * traj_row
-        run = self._run_struct
-        if run is None:
-            run = self._run_struct = _L.RiabSimulate()
-        run.env, run.motion = _L.C.pointer(env), _L.C.pointer(m)
-        run.state, run.B, run.agent_id0 = self._state.data_ptr(), Bp, int(self.agent_id0)
-        run.drift = drift.data_ptr() if drift is not None else None
-        run.seed, run.n_pops, run.pops = int(self.rng_seed), npop, _L.C.cast(arr, _L.C.POINTER(_L.RiabPopulation))
-        run.diag, run.ctrl, run.timed_pop = self._diag.data_ptr(), self._ctrl.data_ptr(), timed
-        run.timing_mode = 1 if self._time_rate_kernel == "events" else 0
         step = int(self._step_index)
-        call, handle, stream, byref = _L.lib.riab_simulate, self._streamer, _L.current_stream(), _L.C.byref(run)
+        call, handle, stream = _L.lib.riab_simulate, self._streamer, _L.current_stream()
         noise_row = 2 * Bp * 8
         t0 = tc = 0
         while t0 < n_steps:
             tc = min(piece, n_steps - t0)
             for i, (fr_p, sp_p, fr_row, sp_row) in enumerate(bases):
-                arr[i].rates_base = fr_p + t0 * fr_row
-                arr[i].spikes_base = None if sp_p is None else sp_p + t0 * sp_row
-                arr[i].capacity_rows = tc
+                q = arr[i]
+                q.rates_base = fr_p + t0 * fr_row
+                q.spikes_base = None if sp_p is None else sp_p + t0 * sp_row
+                q.capacity_rows = tc
             run.step0, run.T, run.hist = step + t0, tc, traj_p + t0 * traj_row
             run.noise = z.data_ptr() + t0 * noise_row if z is not None else None
             run.forced_pos = forced.data_ptr() + t0 * noise_row if forced is not None else None
@@ -597,12 +606,16 @@ class Agent:
             if rc == _L.EUNSUPPORTED and t0 == 0:  # (nothing was launched; the chunk pipeline reserves its own rows)
                 if self.save_history:
                     self._hist.unreserve(n_steps)
-                for N, out in zip(neurons, outs):
-                    N._unreserve_rows(out, n_steps)
+                for N, at in zip(neurons, ats):
+                    if at[4] is None:
+                        N._hist_fr.unreserve(n_steps)
+                        if at[2] is not None:
+                            N._hist_sp.unreserve(n_steps)
                 return None
             if rc:
                 self._native_failed(rc, t0, tc, dt)
             t0 += tc
+        outs = [N._rows_views(at, n_steps) for N, at in zip(neurons, ats)]
         # ---- the kernels are running: now the views and the Python-side mirrors
         self._pipeline_unchecked = True
         traj = traj_c[traj_s:traj_s + n_steps]

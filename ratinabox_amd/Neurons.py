@@ -372,6 +372,24 @@ class Neurons:
         return dict(fr=torch.empty((rows, n, self._Bp), dtype=torch.float32, device=self._device), sp=None,
                     ring=rows)
 
+    def _reserve_rows_at(self, n_steps, ring):
+        """_reserve_rows without making the views (each a torch slicing call of a few microseconds, and simulate() of
+        a short run is in a hurry to launch): (rates chunk, first row, spikes chunk or None, first row, ring rows or
+        None); `_rows_views` turns it into the dict the other hooks take."""
+        if self.save_history:
+            fr_c, fr_s = self._hist_fr.reserve_at(n_steps)
+            sp_c, sp_s = self._hist_sp.reserve_at(n_steps) if self.save_spikes else (None, 0)
+            return fr_c, fr_s, sp_c, sp_s, None
+        rows = min(n_steps, 2 * ring)
+        return torch.empty((rows, int(self.n), self._Bp), dtype=torch.float32, device=self._device), 0, None, 0, rows
+
+    @staticmethod
+    def _rows_views(at, n_steps):
+        fr_c, fr_s, sp_c, sp_s, ring = at
+        if ring is not None:
+            return dict(fr=fr_c, sp=None, ring=ring)
+        return dict(fr=fr_c[fr_s:fr_s + n_steps], sp=None if sp_c is None else sp_c[sp_s:sp_s + n_steps], ring=None)
+
     def _unreserve_rows(self, out, n_steps):
         if out["ring"] is None:
             self._hist_fr.unreserve(n_steps)

@@ -510,14 +510,60 @@ template <class R>
 struct NearWalls {
   R x2min;
   R box_tx, box_ty, box_nx, box_ny;  // box fast path: (repel distance - distance)+ and normal per axis
+  R box_dmin;                        // box fast path: signed distance to the nearest of the four edges
   uint64_t near_mask;                // bit w: wall w is within the repel distance (pass 2 walks the set bits in order)
 };
+// the four edges of a solid rectangular room (box fast path, see make_motion_const): distance = coordinate difference;
+// of two opposite edges only the nearer one can repel
+template <class R>
+__device__ __forceinline__ void box_pass1(const MotionConst<R>& k, R px, R py, NearWalls<R>& n) {
+  RIAB_EXACT_FP
+  const R dl = px - k.bxl, dr = k.bxr - px, db = py - k.byb, dtp = k.byt - py;
+  const R dxm = r_min(dl, dr), dym = r_min(db, dtp);
+  n.box_tx = r_max(k.wd - fabs(dxm), (R)0);
+  n.box_ty = r_max(k.wd - fabs(dym), (R)0);
+  // normal = from the edge to the agent: into the room for an agent inside it (the other sign only for a
+  // position handed in from outside the room, where the general formula points outwards as well)
+  n.box_nx = ((dl < dr) == (dxm >= (R)0)) ? (R)1 : (R)-1;
+  n.box_ny = ((db < dtp) == (dym >= (R)0)) ? (R)1 : (R)-1;
+  const R dm = r_min(dxm, dym);
+  n.box_dmin = dm;
+  n.x2min = dm * dm;
+}
+// spring + conveyor of the nearer vertical and the nearer horizontal edge: exact zeros beyond the repel distance
+// (t = 0), so the sums are the reference's sums over the four edges
+template <class R>
+struct WallPush {
+  R ax, ay, sx, sy;
+};
+template <class R>
+__device__ __forceinline__ WallPush<R> box_pass2_terms(const MotionConst<R>& k, const NearWalls<R>& n) {
+  RIAB_EXACT_FP
+  const R spx = k.v0 * ((R)1 - r_sqrt_fast(r_fma(-(n.box_tx * n.box_tx), k.inv_wd2, (R)1)));
+  const R spy = k.v0 * ((R)1 - r_sqrt_fast(r_fma(-(n.box_ty * n.box_ty), k.inv_wd2, (R)1)));
+  return WallPush<R>{(k.kspring * n.box_tx) * n.box_nx, (k.kspring * n.box_ty) * n.box_ny, spx * n.box_nx, spy * n.box_ny};
+}
+// Agent.distance_to_closest_wall (Agent.py:415): the open solid box knows it exactly (|nearest coordinate difference|)
+template <class R>
+__device__ __forceinline__ R closest_wall_distance(const MotionConst<R>& k, const NearWalls<R>& n) {
+  return (k.box_fast && k.nw == 4) ? (R)fabs(n.box_dmin) : r_sqrt_fast(n.x2min);
+}
+// the rectangle's own safety net (Environment.py:871-885, solid boundaries): clamp to [min + 0.01, max - 0.01]
+template <class R>
+__device__ __forceinline__ void box_clamp(const MotionConst<R>& k, R& px, R& py) {
+  RIAB_EXACT_FP
+  const R lo_x = k.e0 + (R)0.01, hi_x = k.e1 - (R)0.01, lo_y = k.e2 + (R)0.01, hi_y = k.e3 - (R)0.01;
+  px = (lo_x > px) ? lo_x : px;  // python max(pos, lo): NaN stays NaN
+  px = (hi_x < px) ? hi_x : px;
+  py = (lo_y > py) ? lo_y : py;
+  py = (hi_y < py) ? hi_y : py;
+}
 template <class R>
 __device__ __forceinline__ NearWalls<R> walls_pass1(const MotionConst<R>& k, const Wall<R>* s_w, R px, R py) {
   RIAB_EXACT_FP
   NearWalls<R> n;
   n.x2min = INFINITY;
-  n.box_tx = 0; n.box_ty = 0; n.box_nx = 0; n.box_ny = 0;
+  n.box_tx = 0; n.box_ty = 0; n.box_nx = 0; n.box_ny = 0; n.box_dmin = 0;
   n.near_mask = 0;
   const int nw = k.nw;
   if (nw > 0) {
@@ -539,17 +585,7 @@ __device__ __forceinline__ NearWalls<R> walls_pass1(const MotionConst<R>& k, con
     // the first four walls (the box itself when boundaries are solid) live in registers for the
     // whole launch: no LDS round trip per step for the common open-box case
     if (k.box_fast) {
-      // the room's own edges: distance = coordinate difference; only the nearer edge of each pair can repel
-      const R dl = px - k.bxl, dr = k.bxr - px, db = py - k.byb, dtp = k.byt - py;
-      const R dxm = r_min(dl, dr), dym = r_min(db, dtp);
-      n.box_tx = r_max(k.wd - fabs(dxm), (R)0);
-      n.box_ty = r_max(k.wd - fabs(dym), (R)0);
-      // normal = from the edge to the agent: into the room for an agent inside it (the other sign only for a
-      // position handed in from outside the room, where the general formula points outwards as well)
-      n.box_nx = ((dl < dr) == (dxm >= (R)0)) ? (R)1 : (R)-1;
-      n.box_ny = ((db < dtp) == (dym >= (R)0)) ? (R)1 : (R)-1;
-      const R dm = r_min(dxm, dym);
-      n.x2min = dm * dm;
+      box_pass1<R>(k, px, py, n);
       for (int w = 4; w < nw; ++w) pass1(s_w[w], w);
     } else if (nw >= 4) {  // one uniform test instead of four (each a spilled 64-bit mask read back per step)
 #pragma unroll
@@ -565,24 +601,17 @@ __device__ __forceinline__ NearWalls<R> walls_pass1(const MotionConst<R>& k, con
 // ---- _wall_velocity_update, pass 2: the spring acceleration and the conveyor speed summed over the near walls
 // (they depend on the position only), and their application to velocity and position
 template <class R>
-struct WallPush {
-  R ax, ay, sx, sy;
-};
-template <class R>
 __device__ __forceinline__ WallPush<R> walls_pass2_terms(const MotionConst<R>& k, const Wall<R>* s_w, const NearWalls<R>& n,
                                                          R px, R py) {
   RIAB_EXACT_FP
   R ax_ = 0, ay_ = 0, sx_ = 0, sy_ = 0;
   const R wd = k.wd, v0 = k.v0, kspring = k.kspring, inv_wd2 = k.inv_wd2;
   if (k.box_fast) {
-    // spring + conveyor of the nearer vertical and the nearer horizontal edge: exact zeros beyond the repel
-    // distance (t = 0), so the sums are the reference's sums over the four edges
-    const R spx = v0 * ((R)1 - r_sqrt_fast(r_fma(-(n.box_tx * n.box_tx), inv_wd2, (R)1)));
-    const R spy = v0 * ((R)1 - r_sqrt_fast(r_fma(-(n.box_ty * n.box_ty), inv_wd2, (R)1)));
-    ax_ = (kspring * n.box_tx) * n.box_nx;
-    ay_ = (kspring * n.box_ty) * n.box_ny;
-    sx_ = spx * n.box_nx;
-    sy_ = spy * n.box_ny;
+    const WallPush<R> bx = box_pass2_terms<R>(k, n);
+    ax_ = bx.ax;
+    ay_ = bx.ay;
+    sx_ = bx.sx;
+    sy_ = bx.sy;
   }
   for (uint64_t rest = n.near_mask; rest; rest &= rest - 1) {
     const int w = __ffsll((long long)rest) - 1;
@@ -692,11 +721,7 @@ __device__ __forceinline__ void boundary_net(const MotionConst<R>& k, const Agen
         px = r_fma(-e1, floor(px / e1), px);  // np.mod(pos, extent)
         py = r_fma(-e3, floor(py / e3), py);
       } else {
-        const R lo_x = e0 + (R)0.01, hi_x = e1 - (R)0.01, lo_y = e2 + (R)0.01, hi_y = e3 - (R)0.01;
-        px = (lo_x > px) ? lo_x : px;  // python max(pos, lo): NaN stays NaN
-        px = (hi_x < px) ? hi_x : px;
-        py = (lo_y > py) ? lo_y : py;
-        py = (hi_y < py) ? hi_y : py;
+        box_clamp<R>(k, px, py);
       }
     } else if (a.resample) {  // in a hole / outside the polygon: a new random position (Environment.py:886-893)
       px = (R)a.resample[((int64_t)t * 2 + 0) * B + b];
@@ -1038,7 +1063,7 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
     // ---- _wall_velocity_update, pass 2 -----------------------------------------------------
     if (nw > 0 && K.repel) {
       const WallPush<R> push = walls_pass2_terms<R>(K, s_w, near, px, py);
-      dwall = r_sqrt_fast(near.x2min);
+      dwall = closest_wall_distance<R>(K, near);
       walls_pass2_apply<R>(K, push, px, py, vx, vy);
     }
     // ---- propose (Agent.py:216) -----------------------------------------------------------

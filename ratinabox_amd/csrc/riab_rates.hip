@@ -816,7 +816,11 @@ static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamA
     if (spikes) hipExtLaunchKernelGGL((rate_kernel_gated<Cell, 1, CPB, true>), grid, block, 0, s, ev0, ev1, 0u, a, cell, st);
     else hipExtLaunchKernelGGL((rate_kernel_gated<Cell, 0, CPB, true>), grid, block, 0, s, ev0, ev1, 0u, a, cell, st);
   } else {
-    if (spikes) hipLaunchKernelGGL((rate_kernel_gated<Cell, 1, CPB, true>), grid, block, 0, s, a, cell, st);
+    static const bool plain = getenv("RIAB_GATED_PLAIN") != nullptr;  // (experiment: positions through L2-cached loads)
+    if (plain) {
+      if (spikes) hipLaunchKernelGGL((rate_kernel_gated<Cell, 1, CPB, false>), grid, block, 0, s, a, cell, st);
+      else hipLaunchKernelGGL((rate_kernel_gated<Cell, 0, CPB, false>), grid, block, 0, s, a, cell, st);
+    } else if (spikes) hipLaunchKernelGGL((rate_kernel_gated<Cell, 1, CPB, true>), grid, block, 0, s, a, cell, st);
     else hipLaunchKernelGGL((rate_kernel_gated<Cell, 0, CPB, true>), grid, block, 0, s, a, cell, st);
   }
   return (int)hipGetLastError();

@@ -56,6 +56,10 @@ namespace riab {
 
 enum { T4_C_NOISE = 0, T4_C_GDONE = 1, T4_C_TDONE = 2, T4_C_WORDS = 3 };
 
+template <bool V>
+struct T4Tag {
+  static constexpr bool value = V;
+};
 typedef volatile __attribute__((address_space(3))) unsigned long long* t4_slot_ptr;
 typedef volatile __attribute__((address_space(3))) uint32_t* t4_cnt_ptr;
 
@@ -162,65 +166,88 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
       dry = a.drift[B + b];
     }
     int n_bounce = 0, n_sat = 0, n_bc = 0;
-    uint32_t noise_ready = 0, tail_done = 0;
     R v2 = norm2(vx, vy);
     *slot_v2 = (unsigned long long)__double_as_longlong(v2);
-    for (int t = 0; t < T; ++t) {
-      if ((uint32_t)t >= noise_ready) {
-        noise_ready = t4_wait_counter(cnt, T4_C_NOISE, (uint32_t)t, false);
-        if (!noise_ready) { gave_up = true; break; }
-      }
-      T4_STAMP(0);
-      const R cs = s_cs[t % RIAB_T4_RING][lane], sn = s_sn[t % RIAB_T4_RING][lane];
-      const R ppx = px, ppy = py;  // prev_pos (Agent.py:199)
-      // ---- _stochastic_velocity_update: the rotation (Agent.py:287-300) ----
-      const bool zero_v = (v2 == (R)0);  // the reference replaces a zero velocity by (1e-8, 0) (Agent.py:299-300)
-      rotate_by<R>(cs, sn, vx, vy);
-      vx = zero_v ? (R)1e-8 : vx;
-      vy = zero_v ? (R)0 : vy;
-      // ---- wall repulsion: everything that depends on the position only ----
-      NearWalls<R> near = {INFINITY, 0, 0, 0, 0, 0};
-      if (!(RIAB_T4_ABLATE & 2)) near = walls_pass1<R>(K, s_w, px, py);
-      WallPush<R> push = {0, 0, 0, 0};
+    // The loop is compiled twice.  OPEN: a solid rectangular room with no wall inside it and no drift (BASELINE
+    // configs 2, 4, 5) — the four edges by coordinate differences, nothing else: no wall loops, no near-wall mask, no
+    // polygon tests.  A lone wave pays ~7.5 cycles for every instruction it issues, scalar branches around unused
+    // paths included: the general loop is ~370 issue slots per step in this room, the specialised one ~130.
+    auto steps = [&](auto open_tag) {
+      RIAB_EXACT_FP
+      constexpr bool OPEN = decltype(open_tag)::value;
+      uint32_t noise_ready = 0, tail_done = 0;
       const bool repel = K.nw > 0 && K.repel && !(RIAB_T4_ABLATE & 2);
-      if (repel) {
-        push = walls_pass2_terms<R>(K, s_w, near, px, py);
-        dwall = r_sqrt_fast(near.x2min);
+      for (int t = 0; t < T; ++t) {
+        if ((uint32_t)t >= noise_ready) {
+          noise_ready = t4_wait_counter(cnt, T4_C_NOISE, (uint32_t)t, false);
+          if (!noise_ready) { gave_up = true; break; }
+        }
+        T4_STAMP(0);
+        const R cs = s_cs[t % RIAB_T4_RING][lane], sn = s_sn[t % RIAB_T4_RING][lane];
+        const R ppx = px, ppy = py;  // prev_pos (Agent.py:199)
+        // ---- _stochastic_velocity_update: the rotation (Agent.py:287-300) ----
+        const bool zero_v = (v2 == (R)0);  // the reference replaces a zero velocity by (1e-8, 0) (Agent.py:299-300)
+        rotate_by<R>(cs, sn, vx, vy);
+        vx = zero_v ? (R)1e-8 : vx;
+        vy = zero_v ? (R)0 : vy;
+        // ---- wall repulsion: everything that depends on the position only ----
+        NearWalls<R> near = {INFINITY, 0, 0, 0, 0, 0, 0};
+        WallPush<R> push = {0, 0, 0, 0};
+        if (!(RIAB_T4_ABLATE & 2)) {
+          if (OPEN) box_pass1<R>(K, px, py, near);
+          else near = walls_pass1<R>(K, s_w, px, py);
+        }
+        if (repel) {
+          push = OPEN ? box_pass2_terms<R>(K, near) : walls_pass2_terms<R>(K, s_w, near, px, py);
+          dwall = closest_wall_distance<R>(K, near);
+        }
+        // ---- the speed factor of this step from wave S ----
+        T4_STAMP(1);
+        R f;
+        if (!t4_take(slot_f, &f)) { gave_up = true; break; }
+        T4_STAMP(2);
+        vx *= f;
+        vy *= f;
+        // ---- _drift_velocity_update (Agent.py:331-341) ----
+        if (!OPEN && m.has_drift) drift_update<R>((R)m.drift_theta, drx, dry, dt, vx, vy);
+        if (repel) walls_pass2_apply<R>(K, push, px, py, vx, vy);
+        // ---- propose (Agent.py:216), collisions ----
+        propose_step<R>(vx, vy, dt, px, py);
+        if (!(RIAB_T4_ABLATE & 2)) handle_collisions<R>(K, s_w, near.x2min, ppx, ppy, px, py, vx, vy, n_bounce, n_sat);
+        // the velocity of this step is final: wave S can start on the next one
+        v2 = norm2(vx, vy);
+        if (t + 1 < T) *slot_v2 = (unsigned long long)__double_as_longlong(v2);
+        T4_STAMP(3);
+        // ---- boundary safety net; the displacement as wave T needs it (Agent.py:456-458) ----
+        R dpx, dpy;
+        if (OPEN) {
+          if (!(px > K.e0 && px < K.e1 && py > K.e2 && py < K.e3)) {
+            ++n_bc;
+            box_clamp<R>(K, px, py);
+          }
+          dpx = px - ppx;
+          dpy = py - ppy;
+        } else {
+          if (!(RIAB_T4_ABLATE & 2)) boundary_net<R>(K, a, s_w, t, b, aid, px, py, n_bc, n_sat);
+          step_displacement<R>(a, px, py, ppx, ppy, dpx, dpy);
+        }
+        if ((uint32_t)t >= tail_done + RIAB_T4_RING) {  // the ring slot still holds a step wave T has not taken
+          const uint32_t v = t4_wait_counter(cnt, T4_C_TDONE, (uint32_t)t - RIAB_T4_RING, true);
+          if (!v) { gave_up = true; break; }
+          tail_done = v;
+        }
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        typedef float v2f32 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<v2d*>(&s_dp[t % RIAB_T4_RING][lane][0]) = v2d{dpx, dpy};
+        *reinterpret_cast<v2f32*>(&s_pp[t % RIAB_T4_RING][lane][0]) = v2f32{(float)px, (float)py};
+        asm volatile("" ::: "memory");  // (LDS executes a wave's instructions in order: data, then the counter)
+        cnt[T4_C_GDONE] = (uint32_t)(t + 1);
+        T4_STAMP(4);
       }
-      // ---- the speed factor of this step from wave S ----
-      T4_STAMP(1);
-      R f;
-      if (!t4_take(slot_f, &f)) { gave_up = true; break; }
-      T4_STAMP(2);
-      vx *= f;
-      vy *= f;
-      // ---- _drift_velocity_update (Agent.py:331-341) ----
-      if (m.has_drift) drift_update<R>((R)m.drift_theta, drx, dry, dt, vx, vy);
-      if (repel) walls_pass2_apply<R>(K, push, px, py, vx, vy);
-      // ---- propose (Agent.py:216), collisions ----
-      propose_step<R>(vx, vy, dt, px, py);
-      if (!(RIAB_T4_ABLATE & 2)) handle_collisions<R>(K, s_w, near.x2min, ppx, ppy, px, py, vx, vy, n_bounce, n_sat);
-      // the velocity of this step is final: wave S can start on the next one
-      v2 = norm2(vx, vy);
-      if (t + 1 < T) *slot_v2 = (unsigned long long)__double_as_longlong(v2);
-      T4_STAMP(3);
-      if (!(RIAB_T4_ABLATE & 2)) boundary_net<R>(K, a, s_w, t, b, aid, px, py, n_bc, n_sat);
-      // ---- hand the step over to wave T (Agent.py:456-458: the displacement, periodic-aware) ----
-      R dpx, dpy;
-      step_displacement<R>(a, px, py, ppx, ppy, dpx, dpy);
-      if ((uint32_t)t >= tail_done + RIAB_T4_RING) {  // the ring slot still holds a step wave T has not taken
-        const uint32_t v = t4_wait_counter(cnt, T4_C_TDONE, (uint32_t)t - RIAB_T4_RING, true);
-        if (!v) { gave_up = true; break; }
-        tail_done = v;
-      }
-      typedef double v2d __attribute__((ext_vector_type(2)));
-      typedef float v2f32 __attribute__((ext_vector_type(2)));
-      *reinterpret_cast<v2d*>(&s_dp[t % RIAB_T4_RING][lane][0]) = v2d{dpx, dpy};
-      *reinterpret_cast<v2f32*>(&s_pp[t % RIAB_T4_RING][lane][0]) = v2f32{(float)px, (float)py};
-      asm volatile("" ::: "memory");  // (LDS executes a wave's instructions in order: data, then the counter)
-      cnt[T4_C_GDONE] = (uint32_t)(t + 1);
-      T4_STAMP(4);
-    }
+    };
+    const bool open_room = K.box_fast && K.nw == 4 && !m.has_drift && !a.resample;
+    if (open_room) steps(T4Tag<true>{});
+    else steps(T4Tag<false>{});
     if (live) {
       st[0 * B] = px;
       st[1 * B] = py;

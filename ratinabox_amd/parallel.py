@@ -36,13 +36,14 @@ def sharded_agent_params(n_agents_total, rank=None, world_size=None, **params):
     return dict(params, n_agents=n, agent_id0=a0)
 
 
-def all_gather_trajectory(hist, n_local, group=None):
+def all_gather_trajectory(hist, n_local, group=None, single_rank_shortcut=True):
     """Concatenate per-rank trajectory histories `[T, 8, B_local_padded]` along the agent
     axis -> `[T, 8, sum(n_local)]` on every rank.  Off the step path: call it once per
     run / chunk.  Shards may differ in size (last rank), so rows are gathered at the
-    largest padded width and trimmed."""
+    largest padded width and trimmed.  A group of one rank needs no collective and returns its own rows
+    (`single_rank_shortcut=False` runs the collectives anyway: the one-GPU test of the RCCL code path)."""
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (single_rank_shortcut and dist.get_world_size(group) == 1):
         return hist[..., :n_local].contiguous()
     world = dist.get_world_size(group)
     sizes = [torch.zeros(1, dtype=torch.int64, device=hist.device) for _ in range(world)]
