@@ -36,7 +36,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured-achievable copy
-VALU_EXP_PEAK_TTERMS = 11.3  # (v_mul_f32 + v_exp_f32) pairs per second, chip-wide, measured: tools/exp_bench.hip
+# BoundaryVectorCells: one v_exp_f32 per (cell, direction, position) term is irreducible.  Issue rates of single
+# instructions measured on MI355X at 8 waves per SIMD (tools/exp_bench.hip, profiles/r03_exp_bench.txt), in cycles per
+# wave-instruction per SIMD at 2.4 GHz: v_exp_f32 9.44 (CDNA4's transcendental rate: not the 16 of a quarter-rate
+# unit), v_pk_fma_f32 5.17, v_pk_add_f32 4.98.
+VALU_CYCLES = {"v_exp_f32": 9.44, "v_pk_fma_f32": 5.17, "v_pk_add_f32": 4.98}
+VALU_SIMDS, VALU_CLOCK_GHZ = 1024, 2.4
+# peak = the v_exp_f32 issue ceiling alone: 1024 SIMDs x 64 lanes x 2.4 GHz / 9.44 cycles = 16.7 T exponentials/s
+VALU_EXP_PEAK_TTERMS = VALU_SIMDS * 64 * VALU_CLOCK_GHZ / VALU_CYCLES["v_exp_f32"] / 1e3
+# the kernel's own instruction mix per term (1 v_exp + 1 v_pk_fma + 1/2 v_pk_add: two terms per packed instruction):
+# 17.1 cycles if nothing overlapped = 9.2 T terms/s; measured with that mix in a register-only loop: 15.7 cycles = 10.0
+VALU_MIX_SERIAL_TTERMS = VALU_SIMDS * 64 * VALU_CLOCK_GHZ / (9.44 + 5.17 + 0.5 * 4.98) / 1e3
+VALU_MIX_MEASURED_TTERMS = 10.0
 
 CONFIGS = {
     # name: agents per GPU, cells, walls, spikes
@@ -66,7 +77,7 @@ def bytes_per_agent_step(cfg):
     return 4 * n + (n if cfg["spikes"] else 0) + 112
 
 
-def build_world(riab, cfg, rank, precision, seed=1234, task=False):
+def build_world(riab, cfg, rank, seed=1234, task=False):
     import numpy as np
     np.random.seed(1000 + rank)
     if task:  # the same world inside a goal-directed task (closed loop: contribs/TaskEnvironment.py)
@@ -77,7 +88,7 @@ def build_world(riab, cfg, rank, precision, seed=1234, task=False):
     else:
         env = riab.Environment({"walls": cfg["walls"]})
     B = cfg["agents"]
-    ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "seed": seed, "agent_id0": rank * B, "precision": precision})
+    ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "seed": seed, "agent_id0": rank * B})
     pops = []
     np.random.seed(0)  # identical cell tables on every rank
     common = {"save_spikes": cfg["spikes"]}
@@ -176,7 +187,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
             sys.exit(2)
         cfg["agents"] = per
     args.plan = args.plan or args.task
-    env, ag, pops = build_world(riab, cfg, rank, args.precision, task=args.task)
+    env, ag, pops = build_world(riab, cfg, rank, task=args.task)
     # the full rate history of K steps must fit in HBM next to the warmup's; otherwise stream
     # through ring buffers (every byte is still written, the oldest rows are overwritten)
     n_cells = sum(int(p.n) for p in pops)
@@ -197,7 +208,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         chunk = K if K <= 64 else max(32, (K // 4 + 3) // 4 * 4)
 
     plan = {"p": None}
-    native = not (args.per_step or args.plan) and os.environ.get("RIAB_NO_NATIVE") != "1" and ag.precision == 64
+    native = not (args.per_step or args.plan) and os.environ.get("RIAB_NO_NATIVE") != "1"
     # one store-bound population: the one-kernel form of riab_simulate's rate stage (its waves wait for their rows)
     fused_mode = (native and len(pops) == 1 and pops[0]._stream_kind is not None and pops[0].noise_std == 0
                   and ag._Bp % 256 == 0 and os.environ.get("RIAB_NO_FUSED") != "1")
@@ -334,18 +345,28 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         avg_ms = float(np.mean(ms))
         avg_units = float(np.mean(units))
         achieved = unit_bytes * avg_units / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{config}.json")
-        if os.path.exists(tpath):
+        # HBM bytes from the PMC counters: NOT collected in this run — the per-unit figure of the kernel that was timed,
+        # from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, keyed by kernel), times the units
+        traffic = traffic_from = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        pmc_kernel = None
+        if type(dominant).__name__ == "PlaceCells" and not cfg["spikes"]:
+            pmc_kernel = "rate_kernel_gated" if (fused_mode and K <= 256) else "rate_kernel_wide"
+        if pmc_kernel and os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = round(json.load(f).get("hbm_bytes_per_unit") * avg_units)  # PMC bytes/unit x units/launch
+                entry = json.load(f).get("kernels", {}).get(pmc_kernel)
+            if entry:
+                traffic = round(entry["hbm_bytes_per_unit"] * avg_units)
+                traffic_from = (f"profiles/pmc_traffic.json[{pmc_kernel}]: {entry['hbm_bytes_per_unit']:.1f} B per agent-step "
+                                f"(rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, {entry['source'].split(': ')[-1]}) x units "
+                                "of this run's launches; counters are not collected inside bench.py")
         poll_max = 256
         kname = (("rate_kernel_gated" if K <= poll_max else "rate stage = rate_kernel_wide per chunk behind progress gates")
                  if fused_mode else "rate_kernel_wide") + f"<{type(dominant).__name__}>"
         if native_mode:
             kname = f"every launch of {type(dominant).__name__}'s kernel in one riab_simulate call (chunks of rows behind gates)"
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from": traffic_from,
                     "kernel": kname, "launches": len(ms),
                     "avg_launch_ms": round(avg_ms, 5), "min_launch_ms": round(float(np.min(ms)), 5),
                     "max_launch_ms": round(float(np.max(ms)), 5), "units_per_launch": int(avg_units),
@@ -354,17 +375,25 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
                     "kernel_own_bytes_per_unit": own_bytes,
                     "frac_of_measured_copy_bw_6290": round(achieved / 6290.0, 4)}
         if type(dominant).__name__ == "BoundaryVectorCells":
-            # BVC is bound by transcendental issue, not by HBM: n*K exponentials per position.  Peak =
-            # the v_mul + v_exp issue ceiling MEASURED on this chip (tools/exp_bench.hip); achieved = the terms of the
-            # full sum per second (the direction windows skip ~17 % of them, so this is useful terms, not issued ones).
+            # BVC is bound by transcendental issue, not by HBM: n*K exponentials per position, minus
+            # the directions the cells' windows leave out.  achieved = terms ISSUED per second; peak = the v_exp_f32
+            # issue ceiling derived from the instruction's measured issue rate (independent of this kernel).
             terms = float(n0) * float(dominant.n_test_angles)
-            t_ach = terms * avg_units / (avg_ms * 1e-3) / 1e12
-            roofline = {"bound": "valu", "achieved": round(t_ach, 3), "peak": VALU_EXP_PEAK_TTERMS, "unit": "Tterm/s",
+            issued = float(getattr(dominant, "_window_stats", {}).get("issued", 1.0)) if hasattr(dominant, "_window_stats") else 1.0
+            t_full = terms * avg_units / (avg_ms * 1e-3) / 1e12
+            t_ach = t_full * issued
+            roofline = {"bound": "valu", "achieved": round(t_ach, 3), "peak": round(VALU_EXP_PEAK_TTERMS, 2), "unit": "Tterm/s",
                         "frac": round(t_ach / VALU_EXP_PEAK_TTERMS, 4), "traffic": None,
                         "kernel": "bvc_kernel", "launches": len(ms), "avg_launch_ms": round(avg_ms, 5),
                         "units_per_launch": int(avg_units), "terms_per_unit": int(terms),
-                        "peak_is": "v_mul_f32 + v_exp_f32 issue ceiling measured with tools/exp_bench.hip on MI355X "
-                                   "(DESIGN.md 3.2); one term = one fused exponent exp2(-(a d - a mu)^2 + T[c][k])",
+                        "issued_fraction_of_terms": round(issued, 4), "full_sum_terms_per_s_T": round(t_full, 3),
+                        "peak_is": "v_exp_f32 issue ceiling: 1024 SIMDs x 64 lanes x 2.4 GHz / 9.44 cycles per "
+                                   "wave-instruction (measured for the single instruction, tools/exp_bench.hip); one term = "
+                                   "one fused exponent exp2(-(a d - a mu)^2 + T[c][k])",
+                        "instruction_mix_ceiling_Tterm_s": {"serial_sum_of_measured_issue_cycles": round(VALU_MIX_SERIAL_TTERMS, 2),
+                                                            "measured_register_only_loop": VALU_MIX_MEASURED_TTERMS,
+                                                            "mix": "per term 1 v_exp_f32 + 1 v_pk_fma_f32 + 1/2 v_pk_add_f32"},
+                        "frac_of_measured_mix_ceiling": round(t_ach / VALU_MIX_MEASURED_TTERMS, 4),
                         "hbm_GBps_of_this_kernel": round(achieved, 1), "hbm_frac_of_this_kernel": round(achieved / HBM_PEAK_GBS, 4)}
         if native_mode:
             roofline["note"] = ("`avg_launch_ms` is the SUM of the kernel's launches of one timed region (HIP events around each "
@@ -421,7 +450,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
             "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(med / K * 1e3, 6), "higher_is_better": True,
             "scaling": "strong" if (args.strong and world > 1) else "weak",
-            "vs_baseline": None, "dtype": "f32 rates / f%d motion" % args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 rates / f64 motion", "data": "synthetic",
             "config": {"workload": config + ": " + cfg["desc"], "agents_per_gpu": B,
                        "cells": {k: cfg[k] for k in ("place", "grid", "bvc", "hdc")},
                        "parallelism": f"agent-sharded x{world}, no step-path collective", "control_plane": control_plane,
@@ -453,7 +482,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--chunk", type=int, default=128, help="steps per kernel launch in the chunked two-stream path")
-    ap.add_argument("--precision", type=int, default=64, choices=(32, 64), help="motion-kernel arithmetic")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the timed K-step region (0 = by K)")
     ap.add_argument("--per-step", action="store_true", help="time the drop-in per-step API instead of simulate()")
     ap.add_argument("--plan", action="store_true", help="time the closed-loop path through a native step plan")
@@ -532,7 +560,7 @@ def main():
             args.no_history = False
             t0 = time.perf_counter()
             try:
-                o, c = measure(args, name, 256, 32, 3, rank, world, local, dist, False, control_plane, store_ceiling=False)
+                o, c = measure(args, name, 256, 32, 5, rank, world, local, dist, False, control_plane, store_ceiling=False)
             except Exception as e:  # noqa: BLE001  (the headline line must not be lost to a secondary run)
                 secondary[name] = {"error": f"{type(e).__name__}: {e}"}
                 continue

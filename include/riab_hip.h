@@ -147,12 +147,14 @@ typedef struct RiabMotion {
  *  diag       device int32 [4] or NULL, atomically accumulated:
  *             [0] bounces, [1] saturations of the bounded loops (bounces, resample attempts), [2] boundary
  *             conditions applied, [3] zero-displacement steps
- *  precision  64 (float64 arithmetic, parity mode) or 32 (float32 arithmetic)
+ * Arithmetic is float64, like the reference's: on gfx950 a float64 FMA issues at the float32 rate, and the float32
+ * variant this entry point had in rounds 1-2 (library exp / log / erf in float32) was SLOWER than the table-driven
+ * float64 path (2.9 vs 1.8 us per step) and 1e-5 instead of 1e-12 accurate: removed in ABI v4.
  */
 int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
                     int64_t agent_id0, const double* drift, const double* z_in, double* z_out,
                     const double* forced_pos, const double* resample_pos, uint64_t seed, uint64_t step0, int32_t T,
-                    float* hist, int32_t* diag, int32_t precision, riab_stream_t stream);
+                    float* hist, int32_t* diag, riab_stream_t stream);
 
 /* ---- Environment geometry queries ---------------------------------------------------------
  * The stand-alone forms of the helpers riab_agent_step / riab_place_cells inline, for callers of
@@ -421,8 +423,7 @@ typedef struct RiabPlan RiabPlan;
 /* state / diag / row_scratch as in riab_agent_step (row_scratch: device float32 [8][B], receives the
  * newest history row when no agent history chunk is attached); step = Agent updates taken so far. */
 RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
-                           int64_t agent_id0, uint64_t seed, uint64_t step, int32_t precision,
-                           float* row_scratch, int32_t* diag);
+                           int64_t agent_id0, uint64_t seed, uint64_t step, float* row_scratch, int32_t* diag);
 void riab_plan_destroy(RiabPlan* plan);
 int riab_plan_set_motion(RiabPlan* plan, const RiabMotion* motion, const double* drift);
 /* imported / forced trajectories (Agent.py:229-266): the coming `n_rows` agent steps of the plan move the agents to
@@ -646,6 +647,18 @@ int riab_simulate(RiabStreamer* h, const RiabSimulate* run, riab_stream_t stream
 /* after a riab_simulate call with timed_pop >= 0 and after the caller has synchronised: the duration of the timed
  * population's kernel(s) in ms; < 0 if unavailable */
 float riab_streamer_last_rate_ms(RiabStreamer* h);
+
+/* A/B switches of the library (comparisons and tests; the defaults are what production runs): process-wide, read on
+ * every call they affect (plain loads of an int: the library never calls getenv).  Returns the previous value, or
+ * RIAB_EINVAL for an unknown option / value.
+ *   RIAB_OPT_TRAJ_KERNEL   which kernel multi-step riab_agent_step launches and riab_simulate's trajectory stage use:
+ *                          0 (default) four specialised waves per 64 agents (csrc/riab_traj4_kernel.h); 1 the single-wave
+ *                          kernel for every launch; 2 round 1's two-wave kernel (Philox launches of >= 32 steps)
+ *   RIAB_OPT_FUSED_TASK    1 (default) a task plan's motion + task step is one launch; 0 two launches
+ *   RIAB_OPT_BVC_BOX       1 (default) box fast path of the boundary-vector ray stage; 0 the general stage everywhere
+ *   RIAB_OPT_GATED_PLAIN   0 (default) the gated rate kernel reads positions with agent-scope loads; 1 ordinary loads */
+enum { RIAB_OPT_TRAJ_KERNEL = 0, RIAB_OPT_FUSED_TASK = 1, RIAB_OPT_BVC_BOX = 2, RIAB_OPT_GATED_PLAIN = 3, RIAB_OPT_COUNT = 4 };
+int riab_set_option(int32_t option, int32_t value);
 
 /* Process-level host setting for latency-bound callers (one short simulate() per synchronisation, as in bench.py's
  * 20-step region): on != 0 makes the calling thread SPIN on completion signals in hipDeviceSynchronize /

@@ -47,10 +47,14 @@ class Agent:
         "n_agents": 1,        # independent agents held by this object
         "device": "cuda",     # torch device of the state / history tensors
         "seed": 0,            # Philox key of the in-kernel noise (production mode)
-        "precision": 64,      # arithmetic of the motion kernel: 64 (parity) or 32
         "agent_id0": 0,       # global id of agent 0 (multi-GPU shards; keys the RNG)
     }
 
+    # simulate(): True = call riab_simulate through ctypes (the default: ~3 us less host time per call, which is 3 % of a
+    # 20-step run); False = through torch.ops.riab.simulate_, which a dispatch mode / tracer sees — taken automatically
+    # while a TorchDispatchMode is active.  User code that wants the run inside a compiled function calls the operator
+    # itself (Agent.simulate_args).
+    DIRECT_NATIVE_CALL = True
     AUTO_AFTER = 4   # plain update() calls in a row before the per-step loop is served from a native plan
     AUTO_AFTER_MAX = 1024  # ... after back-off: a stepper that served fewer than AUTO_KEEP steps before something
     AUTO_KEEP = 4          #     closed it doubles the wait for the next one (a loop that edits a weight every step
@@ -348,13 +352,13 @@ class Agent:
             w_op, e_op, periodic = self.Environment.op_env_args(self._device)
             torch.ops.riab.agent_step_(self._state, hist_view, self._diag, w_op, e_op, periodic, ops.motion_list(m), drift, z,
                                        z_out, forced, rs, ops.seed_arg(self.rng_seed), int(self._step_index),
-                                       int(self.agent_id0), int(T), int(self.precision))
+                                       int(self.agent_id0), int(T))
         else:
             s = stream if stream is not None else _L.current_stream()
             rc = _L.lib.riab_agent_step(env, m, _L.ptr(self._state), self._Bp, int(self.agent_id0), _L.ptr(drift),
                                         _L.ptr(z), _L.ptr(z_out), _L.ptr(forced), _L.ptr(rs), int(self.rng_seed),
                                         int(self._step_index), int(T),
-                                        _L.ptr(hist_view), _L.ptr(self._diag), int(self.precision), s)
+                                        _L.ptr(hist_view), _L.ptr(self._diag), s)
             _L.check(rc, "riab_agent_step")
         self._keep = (drift, z, _walls, hist_view, forced, rs)  # keep operands alive until the stream is done
         self._last_row = hist_view[T - 1]            # fp32 [8, Bp]: positions / head directions of the newest step
@@ -380,7 +384,11 @@ class Agent:
         What neither covers (AgentVectorCells, recurrent layers, float32 motion) runs as trajectory chunks of `chunk`
         steps on one HIP stream with the rate kernels of each finished chunk on a second one.  Histories land in HBM
         (`save_history=True`) exactly as `n_steps` calls of update() would have left them.  Returns the trajectory
-        history tensor of this call `[n_steps, 8, B_padded]` (device)."""
+        history tensor of this call `[n_steps, 8, B_padded]` (device; None when populations that read the agent's state
+        are advanced through a step plan and the agent keeps no history).  The tensor is returned while the kernels
+        still run and is not validated: a wait of the flag-coupled pipeline that gave up (bounded spins: a producer
+        starved for about a second) is reported by the next host read, by get_history_tensor() / get_history_tensors()
+        / firingrate_tensor, and counted in diagnostics["pipeline_timeouts"]."""
         neurons = list(self.Neurons if neurons is None else neurons)
         if self._plan is not None:
             self._plan.close()  # (before any history row is reserved: a plan's pending rows are not committed yet)
@@ -469,6 +477,7 @@ class Agent:
             plan.step(n, drift_velocity=drift_velocity, drift_to_random_strength_ratio=ratio, dt=dt)
             done += n
         plan.close()
+        # (an agent that keeps no history has only its newest row in this mode: nothing to return)
         return self._hist.stack()[len(self._hist) - n_steps:] if self.save_history else None
 
     def _make_streamer(self):
@@ -502,7 +511,7 @@ class Agent:
         the stream).  Returns None — nothing reserved, nothing launched — for what it does not cover: populations
         that cannot be recorded (AgentVectorCells, recurrent FeedForwardLayers), float32 motion; `RIAB_NO_NATIVE=1`
         switches it off (A/B comparisons: the Python-driven chunk pipeline gives identical results)."""
-        if not neurons or len(neurons) > 16 or self.precision != 64 or n_steps <= 0 or _L.env("RIAB_NO_NATIVE") == "1":
+        if not neurons or len(neurons) > 16 or n_steps <= 0 or _L.env("RIAB_NO_NATIVE") == "1":
             return None
         for N in neurons:
             if N.Agent is not self:
@@ -588,6 +597,16 @@ class Agent:
         traj_row = _L.HIST_ROWS * Bp * 4
         traj_p = traj_c.data_ptr() + traj_s * traj_row
         step = int(self._step_index)
+        # the call goes through the registered operator (torch.ops.riab.simulate_: traceable, composes with torch code
+        # on the same stream); `Agent.DIRECT_NATIVE_CALL = True` calls the ABI entry point directly (~3 us less host
+        # time per call, nothing a tracer can see)
+        via_op = not self.DIRECT_NATIVE_CALL or torch._C._len_torch_dispatch_stack() > 0
+        if via_op:
+            from . import ops  # noqa: F401  (registers torch.ops.riab.*)
+            op = torch.ops.riab.simulate_
+            handle_i, run_i = self._streamer.value, _L.C.addressof(run)
+            op_rates = [at[0] for at in ats]
+            op_spikes = [at[2] for at in ats if at[2] is not None]
         call, handle, stream = _L.lib.riab_simulate, self._streamer, _L.current_stream()
         noise_row = 2 * Bp * 8
         t0 = tc = 0
@@ -602,7 +621,16 @@ class Agent:
             run.noise = z.data_ptr() + t0 * noise_row if z is not None else None
             run.forced_pos = forced.data_ptr() + t0 * noise_row if forced is not None else None
             run.resample_pos = rs.data_ptr() + t0 * noise_row if rs is not None else None
-            rc = call(handle, byref, stream)
+            if via_op:
+                try:
+                    op(self._state, traj_c, op_rates, op_spikes, self._ctrl, self._diag, handle_i, run_i, traj_s + t0,
+                       [at[1] + (t0 if at[4] is None else 0) for at in ats],
+                       [at[3] + t0 for at in ats if at[2] is not None])
+                    rc = 0
+                except _L.RiabError as e:
+                    rc = getattr(e, "code", _L.EINVAL)
+            else:
+                rc = call(handle, byref, stream)
             if rc == _L.EUNSUPPORTED and t0 == 0:  # (nothing was launched; the chunk pipeline reserves its own rows)
                 if self.save_history:
                     self._hist.unreserve(n_steps)
@@ -636,6 +664,55 @@ class Agent:
                 out["last"] = out["fr"][tc - 1]   # (every piece starts at the ring's first row)
             N._finish_rows(out, n_steps, times)
         return traj
+
+    def simulate_args(self, n_steps, neurons=None):
+        """The arguments of `torch.ops.riab.simulate_` for `n_steps` steps of this agent and `neurons` (default: all of
+        its populations) into buffers of their own — for user code that wants the open-loop run as an operator inside
+        a traced / compiled function:
+
+            a = Ag.simulate_args(64)
+            def run_and_reduce(state, hist, rates):
+                torch.ops.riab.simulate_(state, hist, rates, a.spikes, a.ctrl, a.diag, a.streamer, a.run, 0, a.rate_rows,
+                                         a.spike_rows)
+                return rates[0].mean(dim=(0, 2))
+            torch.compile(run_and_reduce, fullgraph=True)(a.state, a.hist, a.rates)
+
+        The block describes ONE run (steps `step_index .. step_index + n_steps` of the agent's Philox streams from the
+        state tensor's current contents); the host-side clocks and histories of the Agent object are not advanced by
+        calls of the operator.  Keep the returned object alive while the operator may run."""
+        import types
+        neurons = list(self.Neurons if neurons is None else neurons)
+        if self._streamer is None:
+            self._make_streamer()
+        index, structs = {}, []
+        for N in neurons:
+            structs.append(N._population(index))
+            index[N] = len(index)
+        env, walls = self.Environment.device_tables(self._device)
+        m = self._motion(self.dt, False, 1, {})
+        Bp, T = self._Bp, int(n_steps)
+        arr = (_L.RiabPopulation * len(neurons))()
+        rates, spikes = [], []
+        for i, (N, pop) in enumerate(zip(neurons, structs)):
+            _L.C.memmove(_L.C.byref(arr, i * _L.POP_SIZE), _L.C.byref(pop), _L.POP_SIZE)
+            fr = torch.empty((T, int(N.n), Bp), dtype=torch.float32, device=self._device)
+            rates.append(fr)
+            arr[i].rates_base, arr[i].capacity_rows, arr[i].spikes_base = fr.data_ptr(), T, None
+            if N.save_spikes:
+                sp = torch.empty((T, int(N.n), Bp), dtype=torch.uint8, device=self._device)
+                spikes.append(sp)
+                arr[i].spikes_base = sp.data_ptr()
+        hist = torch.empty((T, _L.HIST_ROWS, Bp), dtype=torch.float32, device=self._device)
+        run = _L.RiabSimulate()
+        run.env, run.motion = _L.C.pointer(env), _L.C.pointer(m)
+        run.state, run.B, run.agent_id0 = self._state.data_ptr(), Bp, int(self.agent_id0)
+        run.seed, run.step0, run.T = int(self.rng_seed), int(self._step_index), T
+        run.pops, run.n_pops = _L.C.cast(arr, _L.C.POINTER(_L.RiabPopulation)), len(neurons)
+        run.hist, run.diag, run.ctrl, run.timed_pop = hist.data_ptr(), self._diag.data_ptr(), self._ctrl.data_ptr(), -1
+        return types.SimpleNamespace(state=self._state, hist=hist, rates=rates, spikes=spikes, ctrl=self._ctrl, diag=self._diag,
+                                     streamer=self._streamer.value, run=_L.C.addressof(run), hist_row=0,
+                                     rate_rows=[0] * len(rates), spike_rows=[0] * len(spikes),
+                                     _keep=(run, arr, structs, env, walls, m, neurons))
 
     def _native_failed(self, rc, t0, tc, dt):
         """A native call failed after earlier pieces (or, RIAB_EPARTIAL, its own trajectory kernel) had been launched:
@@ -767,8 +844,12 @@ class Agent:
         return dict(self.history.items())
 
     def get_history_tensor(self):
-        """Trajectory history on device: float32 `[T, 8, B_padded]` (rows RIAB_H_*)."""
+        """Trajectory history on device: float32 `[T, 8, B_padded]` (rows RIAB_H_*).  After a native simulate() this
+        accessor (like every host read) first looks at the pipeline's control words — which waits for the run to
+        finish — and raises if a wait of the flag-coupled pipeline gave up and left rows unwritten; the tensor that
+        simulate() itself returns is handed out while the kernels run and carries no such check."""
         self._sync_plan()
+        self._check_pipeline()
         return self._hist.stack()
 
     def reset_history(self):

@@ -405,9 +405,8 @@ class Environment:
         env, wt = self.device_tables(device)
         e = [float(x) for x in self.extent] + [float(self.scale)]
         if env.polygon or env.hole_mask:
-            if env.hole_mask >= 1 << 53:
-                raise ValueError("through the operators, hole edges must be among the first 53 walls")
-            e += [float(env.polygon), float(env.n_boundary), float(env.hole_mask)]
+            mask = int(env.hole_mask)
+            e += [float(env.polygon), float(env.n_boundary), float(mask & 0xFFFFFFFF), float(mask >> 32)]
         return (wt if env.n_walls else None), e, bool(env.periodic)
 
     def plot_environment(self, *a, **k):

@@ -185,8 +185,9 @@ class Neurons:
 
     @property
     def firingrate_tensor(self):
-        """Device firing rates of the last update: float32 `[n, B_padded]`."""
+        """Device firing rates of the last update: float32 `[n, B_padded]` (checked like Agent.get_history_tensor)."""
         self.Agent._sync_plan()
+        self.Agent._check_pipeline()
         return self._rates
 
     # ---- the reference's per-step entry point (Neurons.py:145-171) ---------------------------
@@ -459,8 +460,9 @@ class Neurons:
         return dict(self.history.items())
 
     def get_history_tensors(self):
-        """(firingrate float32 [T, n, Bp], spikes uint8 [T, n, Bp]) on device."""
+        """(firingrate float32 [T, n, Bp], spikes uint8 [T, n, Bp]) on device (checked like Agent.get_history_tensor)."""
         self.Agent._sync_plan()
+        self.Agent._check_pipeline()
         return self._hist_fr.stack(), self._hist_sp.stack()
 
     def reset_history(self):
@@ -715,6 +717,10 @@ class BoundaryVectorCells(VectorCells):
     directions the distance to the first wall, weighted by a gaussian in distance and
     a von Mises in angle, summed over directions and normalised analytically."""
 
+    # share of a cell's angular weight that its direction window may leave out (see _call): bounds the change of a
+    # normalised rate, a tenth of the parity tolerance's floor
+    BVC_WINDOW_SHARE = 1e-6
+
     default_params = {
         "n": 10,
         "name": "BoundaryVectorCells",
@@ -769,15 +775,24 @@ class BoundaryVectorCells(VectorCells):
             else:
                 vm = np.full((n, Kp), -np.inf)
                 vm[:, :K] = LOG2E * kappa[:, None] * (np.cos(diff) - 1)
-            # Direction windows (allocentric, K a multiple of 4): a cell's von Mises weight is below 2^-24 of its
-            # peak outside an arc that shrinks with its angular spread (60 degrees either side at sigma = 10
-            # degrees, the whole circle from 23 degrees up).  The kernel accumulates four table rows at a time,
+            # Direction windows (allocentric, K a multiple of 4).  A rate is sum_k g_k w_k / sum_k w_k with radial
+            # factors g_k <= 1 and von Mises weights w_k (peak 1; the denominator is the reference's cell_fr_norm,
+            # Neurons.py:1598-1604): leaving directions out changes it by at most the share of their weights in the
+            # sum.  Each cell keeps its heaviest directions and drops the rest as long as the dropped share stays
+            # below BVC_WINDOW_SHARE = 1e-6 — a tenth of the floor of the parity tolerance (1e-5 relative + 1e-5 of
+            # the range), and for narrow tunings an arc of 4.9 sigma either side instead of the 5.8 sigma of the
+            # first criterion (weight below 2^-24 of the peak).  The kernel accumulates four table rows at a time,
             # so rows are regrouped by (arc length, tuning angle) and every group of four gets the smallest
             # arc, in whole quads of directions, that holds all its cells' arcs; the rest is skipped.
             rows_t = win_t = None
             inv = 1 / norm
             if use_windows and not ego and K % 4 == 0:
-                keep = vm[:, :K] >= -24.0
+                w_lin = np.exp2(vm[:, :K])
+                idx = np.argsort(w_lin, axis=1)
+                dropped = np.cumsum(np.take_along_axis(w_lin, idx, axis=1), axis=1) <= self.BVC_WINDOW_SHARE * w_lin.sum(axis=1)[:, None]
+                keep = np.ones((n, K), dtype=bool)
+                np.put_along_axis(keep, idx, ~dropped, axis=1)
+                self._window_stats = dict(share=self.BVC_WINDOW_SHARE, cells_need=float(keep.mean()))
                 if not keep.all():
                     band = np.minimum(keep.sum(axis=1) // 24, 7)
                     order = np.lexsort((np.mod(mu_t, 2 * np.pi), band))
@@ -797,6 +812,7 @@ class BoundaryVectorCells(VectorCells):
                         win[g] = (0, K) if length >= K else (k0, length)
                     rows_t = torch.from_numpy(order.astype(np.int32)).to(self._device)
                     win_t = torch.from_numpy(win).to(self._device)
+                    self._window_stats["issued"] = float(win[:, 1].sum() * 4 / (len(win) * 4 * K))
             f32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self._device)  # noqa: E731
             # position-independent denominators of the ray/wall intercepts (utils.py:96): sa . sb_p
             s_w = walls[:, 1, :] - walls[:, 0, :]

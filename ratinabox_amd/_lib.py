@@ -119,7 +119,7 @@ ACTIVATIONS = {"linear": 0, "sigmoid": 1, "relu": 2, "tanh": 3, "retanh": 4, "so
 PROTOTYPES = {
     "riab_agent_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
-                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_place_cells": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_float, C.c_void_p]),
     "riab_grid_cells": (C.c_int, [C.POINTER(RiabRateIO), C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
@@ -154,7 +154,7 @@ PROTOTYPES = {
                                    C.c_int32, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_fill": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "riab_plan_create": (C.c_void_p, [C.POINTER(RiabEnv), C.POINTER(RiabMotion), C.c_void_p, C.c_int64, C.c_int64,
-                                      C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
+                                      C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "riab_plan_destroy": (None, [C.c_void_p]),
     "riab_plan_set_motion": (C.c_int, [C.c_void_p, C.POINTER(RiabMotion), C.c_void_p]),
     "riab_plan_set_forced": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -184,6 +184,7 @@ PROTOTYPES = {
     "riab_streamer_configure": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "riab_streamer_last_rate_ms": (C.c_float, [C.c_void_p]),
     "riab_host_wait_spin": (C.c_int, [C.c_int32]),
+    "riab_set_option": (C.c_int, [C.c_int32, C.c_int32]),
     "riab_abi_sizeof": (C.c_int64, [C.c_int32]),
     "riab_abi_version": (C.c_int, []),
     "riab_strerror": (C.c_char_p, [C.c_int]),
@@ -233,6 +234,24 @@ def _load():
 
 
 lib, LIB_PATH = _load()
+
+
+OPTIONS = {"traj_kernel": 0, "fused_task": 1, "bvc_box": 2, "gated_plain": 3}   # riab_hip.h RIAB_OPT_*
+
+
+def set_option(name, value):
+    """riab_set_option: an A/B switch of the library (tests, comparisons); returns the previous value."""
+    old = lib.riab_set_option(OPTIONS[name], int(value))
+    if old < 0:
+        raise RiabError(f"riab_set_option({name}, {value}) refused")
+    return old
+
+
+# environment variables set BEFORE the import select the same switches for a whole process (tools, A/B runs)
+for _name, _opt, _val in (("RIAB_NO_PC", "traj_kernel", 1), ("RIAB_TRAJ2", "traj_kernel", 2), ("RIAB_NO_FUSED_TASK", "fused_task", 0),
+                          ("RIAB_NO_BVC_BOX", "bvc_box", 0), ("RIAB_GATED_PLAIN", "gated_plain", 1)):
+    if os.environ.get(_name):
+        set_option(_opt, _val)
 
 
 def strerror(code):

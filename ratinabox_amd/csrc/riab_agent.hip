@@ -50,11 +50,11 @@ int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* 
 
 // The publishing variant of the trajectory kernel (riab_simulate_*): float64, four waves per 64 agents
 // (riab_traj4_kernel.h), Philox noise or explicit normals (a.z_in); a.ctrl carries the control words.  Whole waves
-// only (B % 64 == 0), any T.  RIAB_TRAJ2=1 (A/B comparisons): the two-wave kernel of round 1 (Philox only).
+// only (B % 64 == 0), any T.  RIAB_OPT_TRAJ_KERNEL = 2 (A/B comparisons): the two-wave kernel of round 1 (Philox only).
 int launch_agent_pub(const AgentArgs& a, hipStream_t s) {
   if (!a.ctrl || !a.hist || a.forced || a.B % 4 != 0) return RIAB_EINVAL;
   const dim3 grid((unsigned)((a.B + 63) / 64));
-  static const bool two_wave = getenv("RIAB_TRAJ2") != nullptr;
+  const bool two_wave = g_options[RIAB_OPT_TRAJ_KERNEL] == 2;
   if (two_wave && !a.z_in && !a.z_out && a.B % 64 == 0) hipLaunchKernelGGL((agent_step_kernel<double, 0, true, true>), grid, dim3(128), 0, s, a);
   else if (a.z_in) hipLaunchKernelGGL((traj4_kernel<1, true>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((traj4_kernel<0, true>), grid, dim3(256), 0, s, a);
@@ -77,31 +77,25 @@ using namespace riab;
 extern "C" int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
                                int64_t agent_id0, const double* drift, const double* z_in, double* z_out,
                                const double* forced_pos, const double* resample_pos, uint64_t seed, uint64_t step0,
-                               int32_t T, float* hist, int32_t* diag, int32_t precision, riab_stream_t stream) {
+                               int32_t T, float* hist, int32_t* diag, riab_stream_t stream) {
   AgentArgs a;
   const int rc = fill_agent_args(a, env, motion, state, B, agent_id0, drift, z_in, z_out, forced_pos, seed, step0, T, hist,
-                                 diag, precision, resample_pos);
+                                 diag, resample_pos);
   if (rc) return rc;
   const dim3 grid((unsigned)((B + 63) / 64));
   hipStream_t s = (hipStream_t)stream;
   const int in = forced_pos ? 2 : (z_in ? 1 : 0);
-  // long Philox launches of whole waves get the helper wave (no lane may leave before the workgroup
-  // barriers, and z_out is written by the stepping wave of the single-wave kernel only)
-  static const bool no_pc = getenv("RIAB_NO_PC") != nullptr, two_wave = getenv("RIAB_TRAJ2") != nullptr;
-  const bool pc = in == 0 && precision == 64 && T >= 2 * RIAB_Z_BATCH && B % 64 == 0 && !z_out && !no_pc && two_wave;
-  // multi-step float64 launches of whole waves: one agent's step over four specialised waves (riab_traj4_kernel.h)
-  const bool t4 = in != 2 && precision == 64 && T >= 8 && B % 4 == 0 && !no_pc && !two_wave;
-  if (precision == 64) {
-    if (t4 && in == 0) hipLaunchKernelGGL((traj4_kernel<0, false>), grid, dim3(256), 0, s, a);
-    else if (t4) hipLaunchKernelGGL((traj4_kernel<1, false>), grid, dim3(256), 0, s, a);
-    else if (pc) hipLaunchKernelGGL((agent_step_kernel<double, 0, true>), grid, dim3(128), 0, s, a);
-    else if (in == 0) hipLaunchKernelGGL((agent_step_kernel<double, 0, false>), grid, dim3(64), 0, s, a);
-    else if (in == 1) hipLaunchKernelGGL((agent_step_kernel<double, 1, false>), grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((agent_step_kernel<double, 2, false>), grid, dim3(64), 0, s, a);
-  } else {
-    if (in == 0) hipLaunchKernelGGL((agent_step_kernel<float, 0, false>), grid, dim3(64), 0, s, a);
-    else if (in == 1) hipLaunchKernelGGL((agent_step_kernel<float, 1, false>), grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((agent_step_kernel<float, 2, false>), grid, dim3(64), 0, s, a);
-  }
+  // (A/B comparisons, riab_set_option(RIAB_OPT_TRAJ_KERNEL): 1 the single-wave kernel for every launch, 2 round 1's
+  // two-wave kernel)
+  const bool no_pc = g_options[RIAB_OPT_TRAJ_KERNEL] == 1, two_wave = g_options[RIAB_OPT_TRAJ_KERNEL] == 2;
+  const bool pc = in == 0 && T >= 2 * RIAB_Z_BATCH && B % 64 == 0 && !z_out && !no_pc && two_wave;
+  // multi-step launches: one agent's step over four specialised waves (riab_traj4_kernel.h)
+  const bool t4 = in != 2 && T >= 8 && B % 4 == 0 && !no_pc && !two_wave;
+  if (t4 && in == 0) hipLaunchKernelGGL((traj4_kernel<0, false>), grid, dim3(256), 0, s, a);
+  else if (t4) hipLaunchKernelGGL((traj4_kernel<1, false>), grid, dim3(256), 0, s, a);
+  else if (pc) hipLaunchKernelGGL((agent_step_kernel<double, 0, true>), grid, dim3(128), 0, s, a);
+  else if (in == 0) hipLaunchKernelGGL((agent_step_kernel<double, 0, false>), grid, dim3(64), 0, s, a);
+  else if (in == 1) hipLaunchKernelGGL((agent_step_kernel<double, 1, false>), grid, dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((agent_step_kernel<double, 2, false>), grid, dim3(64), 0, s, a);
   return (int)hipGetLastError();
 }

@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(PC ? 128 : 64) void agent_step_kernel(const AgentAr
 static inline int fill_agent_args(AgentArgs& a, const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
                                   int64_t agent_id0, const double* drift, const double* z_in, double* z_out,
                                   const double* forced_pos, uint64_t seed, uint64_t step0, int32_t T, float* hist,
-                                  int32_t* diag, int32_t precision, const double* resample_pos = nullptr) {
+                                  int32_t* diag, const double* resample_pos = nullptr) {
   if (!env || !motion || !state || B <= 0 || T <= 0 || agent_id0 < 0) return RIAB_EINVAL;
   if (env->n_walls < 0 || (env->n_walls > 0 && !env->walls)) return RIAB_EINVAL;
   if (env->n_walls > RIAB_MAX_WALLS) return RIAB_ETOOBIG;
@@ -1165,7 +1165,6 @@ static inline int fill_agent_args(AgentArgs& a, const RiabEnv* env, const RiabMo
   a.resample = resample_pos;
   a.shape = make_env_shape(env);
   if (motion->has_drift && !drift) return RIAB_EINVAL;
-  if (precision != 64 && precision != 32) return RIAB_EINVAL;
   a.m = *motion;
   a.e0 = env->extent[0];
   a.e1 = env->extent[1];

@@ -49,6 +49,8 @@ struct BvcArgs {
   // have a von Mises weight below the caller's threshold.  NULL: identity order, every direction.
   const int* rows;
   const int* win;
+  double e0, e1, e2, e3;  // extent
+  int rect_room;          // solid rectangular boundary, no holes: the first four walls may be the room's own edges
 };
 
 typedef const __attribute__((address_space(4))) double* const_f64_ptr;
@@ -80,6 +82,33 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
   // Four test directions per pass over the walls: the wall-only quantities (d0, its cross product
   // with the wall) are computed once per wall and pass, leaving 1 + 3 multiply-adds per (ray, wall).
   constexpr int KB = 4;
+  // Box fast path.  When the first four walls are the edges of the rectangular room (checked here on the wall table
+  // itself: axis-aligned, on the extent, spanning it) and every position of the tile is strictly inside it, a ray
+  // leaves the room through the edge whose LINE it crosses first: the nearest positive l_a over the four edges is
+  // the hit, and l_b — whether the crossing lies on the segment, half of the per-(ray, wall) arithmetic — need not
+  // be computed for them.  Same l_a expression, same value; interior walls keep the full test after the edges.
+  bool box4 = false;
+  if (a.rect_room && nw >= 4) {
+    bool ok = true;
+    int nh = 0, nv = 0;
+    const double tol = 1e-9 * ((a.e1 - a.e0) + (a.e3 - a.e2));
+    for (int w = 0; w < 4; ++w) {
+      const double ax = walls[4 * w], ay = walls[4 * w + 1], bx = walls[4 * w + 2], by = walls[4 * w + 3];
+      if (ay == by && ax != bx) {
+        ++nh;
+        ok = ok && (ay == a.e2 || ay == a.e3) && fmin(ax, bx) <= a.e0 + tol && fmax(ax, bx) >= a.e1 - tol;
+      } else if (ax == bx && ay != by) {
+        ++nv;
+        ok = ok && (ax == a.e0 || ax == a.e1) && fmin(ay, by) <= a.e2 + tol && fmax(ay, by) >= a.e3 - tol;
+      } else {
+        ok = false;
+      }
+    }
+    ok = ok && nh == 2 && nv == 2;
+    const bool inside = px > a.e0 && px < a.e1 && py > a.e2 && py < a.e3;
+    box4 = ok && __builtin_amdgcn_ballot_w64(live && !inside) == 0;  // (wave-uniform; the same in every wave of the tile)
+  }
+  const int w_full = box4 ? 4 : 0;  // walls from here on take the full (l_a, l_b) test
   // rays without a partner (see below), `count` of them: table index 0 for t = 0, t + off otherwise
   auto cast_single = [&](int count, int off) {
     for (int t0 = wave; t0 < count; t0 += 8 * KB) {
@@ -94,7 +123,19 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
         best[i] = INFINITY;  // smallest valid l_a == largest preference 1/l_a; first index wins ties
         fallback[i] = 0.0;
       }
-      for (int w = 0; w < nw; ++w) {
+      for (int w = 0; w < w_full; ++w) {  // the room's own edges (box fast path): the first line crossed is the hit
+        const double ax = walls[4 * w], ay = walls[4 * w + 1];
+        const double sx = walls[4 * w + 2] - ax, sy = walls[4 * w + 3] - ay;
+        const double d0x = ax - px, d0y = ay - py;
+        const double num_a = d0x * (-sy) + d0y * sx;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          const double la = num_a * rden[kk[i] * nw + w];
+          if (la > 0.0 && la < best[i]) best[i] = la;
+          if (w == 0) fallback[i] = la;
+        }
+      }
+      for (int w = w_full; w < nw; ++w) {
         const double ax = walls[4 * w], ay = walls[4 * w + 1];
         const double sx = walls[4 * w + 2] - ax, sy = walls[4 * w + 3] - ay;
         const double d0x = ax - px, d0y = ay - py;
@@ -151,7 +192,21 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
         bneg[i] = INFINITY;  // ... and along -u
         fallback[i] = 0.0;
       }
-      for (int w = 0; w < nw; ++w) {
+      for (int w = 0; w < w_full; ++w) {  // the room's own edges (box fast path)
+        const double ax = walls[4 * w], ay = walls[4 * w + 1];
+        const double sx = walls[4 * w + 2] - ax, sy = walls[4 * w + 3] - ay;
+        const double d0x = ax - px, d0y = ay - py;
+        const double num_a = d0x * (-sy) + d0y * sx;
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          const double la = num_a * rden[jj[i] * nw + w];
+          const double nla = -la;
+          if (la > 0.0 && la < bpos[i]) bpos[i] = la;
+          if (nla > 0.0 && nla < bneg[i]) bneg[i] = nla;
+          if (w == 0) fallback[i] = la;
+        }
+      }
+      for (int w = w_full; w < nw; ++w) {
         const double ax = walls[4 * w], ay = walls[4 * w + 1];
         const double sx = walls[4 * w + 2] - ax, sy = walls[4 * w + 3] - ay;
         const double d0x = ax - px, d0y = ay - py;
@@ -366,6 +421,8 @@ extern "C" int riab_boundary_vector_cells_windowed(const RiabEnv* env, const Ria
   a.ray_out = ray_out;
   a.rows = cell_rows;
   a.win = windows;
+  a.e0 = env->extent[0]; a.e1 = env->extent[1]; a.e2 = env->extent[2]; a.e3 = env->extent[3];
+  a.rect_room = (!env->polygon && !env->hole_mask && !env->periodic && g_options[RIAB_OPT_BVC_BOX]) ? 1 : 0;
   const size_t lds = sizeof(float) * (size_t)((K + 3) / 4 * 4) * 64;
   if (lds > 160 * 1024) return RIAB_ETOOBIG;
   const dim3 grid((unsigned)((a.P + 63) / 64));

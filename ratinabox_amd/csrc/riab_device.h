@@ -14,6 +14,9 @@
 
 namespace riab {
 
+// riab_set_option's storage (defined in riab_rates.hip): plain ints, read per call
+extern int g_options[RIAB_OPT_COUNT];
+
 struct u32x4 {
   uint32_t x, y, z, w;
 };

@@ -35,7 +35,6 @@ struct RiabPlan {
   int64_t agent_id0;
   uint64_t seed;
   uint64_t step;  // number of Agent.update() steps taken so far (the RNG counter)
-  int32_t precision;
   const double* drift;
   // imported / forced trajectory (riab_plan_set_forced): positions of the coming steps, [rows][2][B]; null = motion model
   const double* forced;
@@ -65,8 +64,8 @@ struct RiabPlan {
 };
 
 extern "C" RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
-                                      int64_t agent_id0, uint64_t seed, uint64_t step, int32_t precision,
-                                      float* row_scratch, int32_t* diag) {
+                                      int64_t agent_id0, uint64_t seed, uint64_t step, float* row_scratch,
+                                      int32_t* diag) {
   if (!env || !motion || !state || B <= 0 || !row_scratch) return nullptr;
   RiabPlan* p = new (std::nothrow) RiabPlan();
   if (!p) return nullptr;
@@ -77,7 +76,6 @@ extern "C" RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* moti
   p->agent_id0 = agent_id0;
   p->seed = seed;
   p->step = step;
-  p->precision = precision;
   p->drift = nullptr;
   p->forced = nullptr;
   p->forced_rows = p->forced_fill = 0;
@@ -290,7 +288,7 @@ extern "C" int riab_plan_step_agent(RiabPlan* p, riab_stream_t stream) {
   }
   float* row = p->hist_base ? p->hist_base + p->hist_fill * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
   const int rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, forced, nullptr,
-                                 p->seed, p->step, 1, row, p->diag, p->precision, (hipStream_t)stream);
+                                 p->seed, p->step, 1, row, p->diag, (hipStream_t)stream);
   if (rc) return rc;
   if (forced) p->forced_fill += 1;
   p->step += 1;
@@ -331,11 +329,11 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
         if (rc) return rc;
       }
     }
-    const bool fused = p->has_task && p->precision == 64 && !getenv("RIAB_NO_FUSED_TASK");
+    const bool fused = p->has_task && riab::g_options[RIAB_OPT_FUSED_TASK] != 0;  // (A/B: 0 = motion and task launched separately)
     if (fused) {  // motion + the rest of TaskEnvironment.step (+ the caller's `if terminal: reset()`) in one launch
       riab::AgentArgs ma;
       rc = riab::fill_agent_args(ma, &p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr,
-                                 p->seed, p->step, 1, row, p->diag, p->precision);
+                                 p->seed, p->step, 1, row, p->diag);
       if (rc) return rc;
       p->step += 1;
       if (p->hist_base) p->hist_fill += 1;
@@ -352,7 +350,7 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
     } else {
     const double* forced = p->forced ? p->forced + p->forced_fill * 2 * p->B : nullptr;
     rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, forced, nullptr,
-                         p->seed, p->step, 1, row, p->diag, p->precision, s);
+                         p->seed, p->step, 1, row, p->diag, s);
     if (rc) return rc;
     if (forced) p->forced_fill += 1;
     p->step += 1;

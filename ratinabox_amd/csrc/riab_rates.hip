@@ -816,8 +816,7 @@ static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamA
     if (spikes) hipExtLaunchKernelGGL((rate_kernel_gated<Cell, 1, CPB, true>), grid, block, 0, s, ev0, ev1, 0u, a, cell, st);
     else hipExtLaunchKernelGGL((rate_kernel_gated<Cell, 0, CPB, true>), grid, block, 0, s, ev0, ev1, 0u, a, cell, st);
   } else {
-    static const bool plain = getenv("RIAB_GATED_PLAIN") != nullptr;  // (experiment: positions through L2-cached loads)
-    if (plain) {
+    if (g_options[RIAB_OPT_GATED_PLAIN]) {  // (A/B: positions through L2-cached loads; no difference measured)
       if (spikes) hipLaunchKernelGGL((rate_kernel_gated<Cell, 1, CPB, false>), grid, block, 0, s, a, cell, st);
       else hipLaunchKernelGGL((rate_kernel_gated<Cell, 0, CPB, false>), grid, block, 0, s, a, cell, st);
     } else if (spikes) hipLaunchKernelGGL((rate_kernel_gated<Cell, 1, CPB, true>), grid, block, 0, s, a, cell, st);
@@ -1093,6 +1092,17 @@ extern "C" int riab_fill(void* dst, int64_t bytes, float value, riab_stream_t st
   if (blocks > 0x7fffffffLL) return RIAB_ETOOBIG;
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float*)dst, n4, value);
   return (int)hipGetLastError();
+}
+
+namespace riab {
+int g_options[RIAB_OPT_COUNT] = {0, 1, 1, 0};
+}
+extern "C" int riab_set_option(int32_t option, int32_t value) {
+  static const int hi[RIAB_OPT_COUNT] = {2, 1, 1, 1};
+  if (option < 0 || option >= RIAB_OPT_COUNT || value < 0 || value > hi[option]) return RIAB_EINVAL;
+  const int old = riab::g_options[option];
+  riab::g_options[option] = value;
+  return old;
 }
 
 extern "C" int riab_abi_version(void) { return RIAB_ABI_VERSION; }

@@ -254,7 +254,7 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   if (rc) return rc;
   riab::AgentArgs a;
   rc = riab::fill_agent_args(a, env, q->motion, q->state, B, q->agent_id0, q->drift, q->noise, nullptr, q->forced_pos, q->seed,
-                             q->step0, T, q->hist, q->diag, 64, q->resample_pos);
+                             q->step0, T, q->hist, q->diag, q->resample_pos);
   if (rc) return rc;
   a.ctrl = q->ctrl;
   hipStream_t main_s = (hipStream_t)stream;

@@ -15,10 +15,12 @@ Functional operators (return a new tensor)
     place_cells, grid_cells, head_direction_cells, boundary_vector_cells   rates float32 (n, P)
     spikes                                                              uint8 (T, n, B) from rates (T, n, B)
     feedforward                                                         float32 (T, n_out, B)
-In-place operator
+In-place operators
     agent_step_      T fused Agent.update() steps on the float64 state (12, B); writes the history rows
+    simulate_        T x (Agent.update(); N.update() for N in populations) as ONE native call (riab_simulate): the state,
+                     the trajectory rows and every population's rate / spike rows are written
 
-`Neurons.get_state()` and `Agent.update()` go through these operators (the fused / planned paths call the ABI
+`Neurons.get_state()`, `Agent.update()` and `Agent.simulate()` go through these operators (step plans call the ABI
 directly: their launches are issued from C++)."""
 from typing import List, Optional
 
@@ -50,17 +52,18 @@ def _register(schema, fake):
 
 def _env_struct(walls: Optional[Tensor], env: List[float], periodic: bool):
     """RiabEnv from operator arguments: env = [left, right, bottom, top, scale] for a box, or
-    [left, right, bottom, top, scale, polygon, n_boundary, hole_mask] (include/riab_hip.h: RiabEnv) when the
-    boundary is a general polygon and / or the environment has holes."""
-    if len(env) not in (5, 8):
-        raise ValueError("env must be [left, right, bottom, top, scale] (+ [polygon, n_boundary, hole_mask])")
+    [left, right, bottom, top, scale, polygon, n_boundary, hole_mask_low32, hole_mask_high32] (include/riab_hip.h:
+    RiabEnv) when the boundary is a general polygon and / or the environment has holes.  (The 64-bit edge mask travels
+    as two 32-bit halves: a float list holds each of them exactly, all 64 walls of the C ABI included.)"""
+    if len(env) not in (5, 9):
+        raise ValueError("env must be [left, right, bottom, top, scale] (+ [polygon, n_boundary, hole_mask_lo, hole_mask_hi])")
     e = _L.RiabEnv()
     for i in range(4):
         e.extent[i] = float(env[i])
     e.scale = float(env[4])
     e.periodic = 1 if periodic else 0
-    if len(env) == 8:
-        e.polygon, e.n_boundary, e.hole_mask = int(env[5]), int(env[6]), int(env[7])  # (mask < 2^53: exact as a float)
+    if len(env) == 9:
+        e.polygon, e.n_boundary, e.hole_mask = int(env[5]), int(env[6]), int(env[7]) | (int(env[8]) << 32)
     if walls is None:
         e.n_walls, e.walls = 0, None
     else:
@@ -239,13 +242,13 @@ def motion_list(m) -> List[float]:
 
 @_register("agent_step_(Tensor(a!) state, Tensor(b!)? hist, Tensor(c!)? diag, Tensor? walls, float[] env, bool periodic, "
            "float[] motion, Tensor? drift, Tensor? noise, Tensor(d!)? noise_out, Tensor? forced_pos, Tensor? resample_pos, "
-           "int seed, int step0, int agent_id0, int T, int precision) -> ()",
+           "int seed, int step0, int agent_id0, int T) -> ()",
            lambda state, hist, diag, walls, env, periodic, motion, drift, noise, noise_out, forced_pos, resample_pos, seed,
-           step0, agent_id0, T, precision: None)
+           step0, agent_id0, T: None)
 def agent_step_(state: Tensor, hist: Optional[Tensor], diag: Optional[Tensor], walls: Optional[Tensor], env: List[float],
                 periodic: bool, motion: List[float], drift: Optional[Tensor], noise: Optional[Tensor],
                 noise_out: Optional[Tensor], forced_pos: Optional[Tensor], resample_pos: Optional[Tensor], seed: int,
-                step0: int, agent_id0: int, T: int, precision: int) -> None:
+                step0: int, agent_id0: int, T: int) -> None:
     """T fused Agent.update() steps (riab_agent_step), in place: state float64 (12, B) (rows RIAB_S_*), hist float32
     (T, 8, B) or None, diag int32 (4,) or None.  motion = the RiabMotion fields in MOTION_FIELDS order; drift float64
     (2, B); noise float64 (T, 2, B) explicit standard normals (None: Philox keyed by (seed; step0 + t, agent_id0 + b));
@@ -271,5 +274,53 @@ def agent_step_(state: Tensor, hist: Optional[Tensor], diag: Optional[Tensor], w
     e = _env_struct(walls, env, periodic)
     _L.check(_L.lib.riab_agent_step(e, m, _L.ptr(state), B, int(agent_id0), _L.ptr(drift), _L.ptr(noise), _L.ptr(noise_out),
                                     _L.ptr(forced_pos), _L.ptr(resample_pos), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step0),
-                                    int(T), _L.ptr(hist), _L.ptr(diag), int(precision), _L.current_stream()),
+                                    int(T), _L.ptr(hist), _L.ptr(diag), _L.current_stream()),
              "riab_agent_step")
+
+
+# ---- the open-loop run: riab_simulate ----------------------------------------------------------------------------
+@_register("simulate_(Tensor(a!) state, Tensor(b!) hist, Tensor(c!)[] rates, Tensor(d!)[] spikes, Tensor(e!) ctrl, "
+           "Tensor(f!)? diag, int streamer, int run, int hist_row, int[] rate_rows, int[] spike_rows) -> ()",
+           lambda state, hist, rates, spikes, ctrl, diag, streamer, run, hist_row, rate_rows, spike_rows: None)
+def simulate_(state: Tensor, hist: Tensor, rates: List[Tensor], spikes: List[Tensor], ctrl: Tensor, diag: Optional[Tensor],
+              streamer: int, run: int, hist_row: int, rate_rows: List[int], spike_rows: List[int]) -> None:
+    """One riab_simulate call (include/riab_hip.h).  `run` is the address of a RiabSimulate argument block — built by
+    `Agent.simulate_args()` or by hand through `ratinabox_amd._lib.RiabSimulate`; the caller keeps it, its population
+    array and the tables they point to alive — and `streamer` the RiabStreamer handle.  What the call WRITES is taken
+    from the tensors given here, not from the block (a tracer may hand the operator other tensors than the ones the
+    block was built from: functionalisation runs it on copies): state float64 (12, B); hist float32 (rows, 8, B), the
+    T rows from `hist_row` on; rates[i] float32 (rows, n_i, B) from `rate_rows[i]` on, one tensor per population of the
+    block; spikes uint8 likewise for the populations whose block entry has a spike buffer, in order; ctrl int32
+    control words; diag int32 (4,) or None.  Enqueues on the current stream, synchronises nothing.  Raises `RiabError`
+    on a non-zero return code of the ABI (its `.code` holds it: RIAB_EUNSUPPORTED = nothing was launched)."""
+    r = C.cast(C.c_void_p(run), C.POINTER(_L.RiabSimulate)).contents
+    B, T, npop = int(r.B), int(r.T), int(r.n_pops)
+    if state.dtype != torch.float64 or tuple(state.shape) != (_L.STATE_ROWS, B) or not state.is_contiguous():
+        raise ValueError("state must be a contiguous float64 tensor (12, B) with the block's B")
+    if hist.dtype != torch.float32 or hist.dim() != 3 or tuple(hist.shape[1:]) != (_L.HIST_ROWS, B) or \
+            hist_row < 0 or hist_row + T > hist.shape[0] or not hist.is_contiguous():
+        raise ValueError("hist must be a contiguous float32 tensor (rows, 8, B) holding rows hist_row .. hist_row + T")
+    if len(rates) != npop or len(rate_rows) != npop:
+        raise ValueError("one rates tensor and one first row per population of the block")
+    r.state, r.hist, r.ctrl = state.data_ptr(), hist.data_ptr() + hist_row * _L.HIST_ROWS * B * 4, ctrl.data_ptr()
+    r.diag = diag.data_ptr() if diag is not None else None
+    j = 0
+    for i in range(npop):
+        q = r.pops[i]
+        n, fr = int(q.n), rates[i]
+        if fr.dtype != torch.float32 or fr.dim() != 3 or tuple(fr.shape[1:]) != (n, B) or not fr.is_contiguous() or \
+                rate_rows[i] < 0 or rate_rows[i] + int(q.capacity_rows) > fr.shape[0]:
+            raise ValueError(f"rates[{i}] must be a contiguous float32 tensor (rows, {n}, {B}) holding the block's rows")
+        q.rates_base = fr.data_ptr() + rate_rows[i] * n * B * 4
+        if q.spikes_base:
+            sp = spikes[j]
+            if sp.dtype != torch.uint8 or tuple(sp.shape[1:]) != (n, B) or not sp.is_contiguous() or \
+                    spike_rows[j] < 0 or spike_rows[j] + int(q.capacity_rows) > sp.shape[0]:
+                raise ValueError(f"spikes[{j}] must be a contiguous uint8 tensor (rows, {n}, {B}) holding the block's rows")
+            q.spikes_base = sp.data_ptr() + spike_rows[j] * n * B
+            j += 1
+    rc = int(_L.lib.riab_simulate(C.c_void_p(streamer), C.byref(r), _L.current_stream()))
+    if rc:
+        e = _L.RiabError(f"riab_simulate failed with code {rc}: {_L.strerror(rc)}")
+        e.code = rc
+        raise e

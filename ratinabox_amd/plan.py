@@ -75,7 +75,7 @@ class StepPlan:
         env, self._walls = agent.Environment.device_tables(agent._device)
         motion = agent._motion(agent.dt, False, 1, {})
         self._h = _L.lib.riab_plan_create(env, motion, _L.ptr(agent._state), Bp, int(agent.agent_id0), int(agent.rng_seed),
-                                          int(agent._step_index), int(agent.precision), _L.ptr(self._row_scratch),
+                                          int(agent._step_index), _L.ptr(self._row_scratch),
                                           _L.ptr(agent._diag))
         if not self._h:
             raise _L.RiabError("riab_plan_create failed")
@@ -297,7 +297,7 @@ class AutoStepper:
         self._motion_key = agent._motion_cache[0]
         self._drift_buf = None
         self._h = _L.lib.riab_plan_create(self._env_struct, self._motion, _L.ptr(agent._state), Bp, int(agent.agent_id0),
-                                          int(agent.rng_seed), int(agent._step_index), int(agent.precision),
+                                          int(agent.rng_seed), int(agent._step_index),
                                           _L.ptr(self._row_scratch), _L.ptr(agent._diag))
         if not self._h:
             raise _L.RiabError("riab_plan_create failed")

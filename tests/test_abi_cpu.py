@@ -57,13 +57,12 @@ def test_argument_errors_before_launch(L):
     assert L.lib.riab_place_cells(env, io, C.c_void_p(16), 4, 0, 0, 0.2, None) == -1  # io has null pointers
     assert L.lib.riab_grid_cells(io, None, 4, 0, 0.0, None) == -1
     assert L.lib.riab_head_direction_cells(io, None, 4, None) == -1
-    assert L.lib.riab_agent_step(None, None, None, 4, 0, None, None, None, None, None, 0, 0, 1, None, None, 64, None) == -1
+    assert L.lib.riab_agent_step(None, None, None, 4, 0, None, None, None, None, None, 0, 0, 1, None, None, None) == -1
     m = L.RiabMotion()
     env.n_walls = 1000
     env.walls = 16
-    assert L.lib.riab_agent_step(env, m, C.c_void_p(16), 4, 0, None, None, None, None, None, 0, 0, 1, None, None, 64, None) == -3
+    assert L.lib.riab_agent_step(env, m, C.c_void_p(16), 4, 0, None, None, None, None, None, 0, 0, 1, None, None, None) == -3
     env.n_walls = 0
-    assert L.lib.riab_agent_step(env, m, C.c_void_p(16), 4, 0, None, None, None, None, None, 0, 0, 1, None, None, 16, None) == -1
     io.pos_x = io.pos_y = io.rates = 16
     io.T, io.B, io.pos_ld = 1, 6, 8
     assert L.lib.riab_place_cells(env, io, C.c_void_p(16), 4, 0, 0, 0.2, None) == -2  # B % 4
@@ -97,9 +96,9 @@ def test_no_cpu_fallback_in_product():
 def test_step_plan_validation_without_gpu(L):
     """riab_plan_*: argument validation and the 'history chunk full' report happen before any launch."""
     env, m = L.RiabEnv(), L.RiabMotion()
-    assert not L.lib.riab_plan_create(None, m, C.c_void_p(16), 4, 0, 0, 0, 64, C.c_void_p(16), None)
-    assert not L.lib.riab_plan_create(env, m, None, 4, 0, 0, 0, 64, C.c_void_p(16), None)
-    h = L.lib.riab_plan_create(env, m, C.c_void_p(16), 4, 0, 7, 5, 64, C.c_void_p(16), None)
+    assert not L.lib.riab_plan_create(None, m, C.c_void_p(16), 4, 0, 0, 0, C.c_void_p(16), None)
+    assert not L.lib.riab_plan_create(env, m, None, 4, 0, 0, 0, C.c_void_p(16), None)
+    h = L.lib.riab_plan_create(env, m, C.c_void_p(16), 4, 0, 7, 5, C.c_void_p(16), None)
     assert h and L.lib.riab_plan_step_index(h) == 5
     assert L.lib.riab_plan_step(h, 0, None) == -1
     pop = L.RiabPopulation()

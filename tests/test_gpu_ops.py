@@ -104,7 +104,7 @@ def test_ops_trace_under_torch_compile(riab):
     env = [0.0, 1.0, 0.0, 1.0, 1.0]
 
     def two_steps(state, hist):
-        torch.ops.riab.agent_step_(state, hist, None, walls, env, False, m, None, None, None, None, None, 3, 0, 0, 2, 64)
+        torch.ops.riab.agent_step_(state, hist, None, walls, env, False, m, None, None, None, None, None, 3, 0, 0, 2)
         return hist[:, 0] + 0.0
 
     s_a, s_b = ag.state_tensor.clone(), ag.state_tensor.clone()
@@ -114,6 +114,68 @@ def test_ops_trace_under_torch_compile(riab):
     x_b = torch.compile(two_steps, fullgraph=True, backend="aot_eager")(s_b, h_b)
     assert torch.equal(s_a, s_b) and torch.equal(h_a, h_b) and torch.equal(x_a, x_b)
     assert not torch.equal(s_a, ag.state_tensor), "the operator must have advanced the state"
+
+
+def test_simulate_operator_traces_and_matches_the_method(riab):
+    """torch.ops.riab.simulate_ (riab_simulate as a mutating operator): opcheck on its schema / fake implementation /
+    mutation annotations; a function that simulates K steps and reduces the rates compiles with fullgraph=True and
+    gives what eager gives; and Agent.simulate() itself dispatches the operator (same rows as the direct ABI call)."""
+    def world(seed=4, B=256):
+        np.random.seed(seed)
+        ag = riab.Agent(riab.Environment(), {"n_agents": B, "dt": 0.01, "seed": 21})
+        np.random.seed(seed + 1)
+        return ag, riab.PlaceCells(ag, {"n": 64, "save_spikes": False}), riab.GridCells(ag, {"n": 16, "save_spikes": True})
+
+    K = 24
+    ag, pcs, gcs = world()
+    a = ag.simulate_args(K)
+    torch.library.opcheck(torch.ops.riab.simulate_, (a.state.clone(), a.hist, a.rates, a.spikes, a.ctrl, a.diag, a.streamer, a.run,
+                                                     0, a.rate_rows, a.spike_rows), test_utils=("test_schema", "test_faketensor"))
+
+    def run_and_reduce(state, hist, rates, spikes, ctrl, diag, streamer, run):
+        torch.ops.riab.simulate_(state, hist, rates, spikes, ctrl, diag, streamer, run, 0, [0, 0], [0])
+        return rates[0].mean(dim=(0, 2)) + rates[1].sum() * 0.0, hist[-1, 0:2].clone()
+
+    res = []
+    for compiled in (False, True):
+        ag, pcs, gcs = world()
+        a = ag.simulate_args(K)
+        fn = torch.compile(run_and_reduce, fullgraph=True, backend="aot_eager") if compiled else run_and_reduce
+        m, last = fn(a.state, a.hist, a.rates, a.spikes, a.ctrl, a.diag, a.streamer, a.run)
+        torch.cuda.synchronize()
+        res.append((m.cpu(), last.cpu(), a.state.clone().cpu(), a.rates[0].cpu(), a.spikes[0].cpu()))
+        assert ag.diagnostics["pipeline_timeouts"] == 0
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
+    # the method: same rows, through the operator (recorded) and through the direct call
+    from torch.utils._python_dispatch import TorchDispatchMode
+    names = []
+
+    class Rec(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            names.append(str(func))
+            return func(*args, **(kwargs or {}))
+
+    got = []
+    for direct in (False, True):
+        ag, pcs, gcs = world()
+        ag.DIRECT_NATIVE_CALL = direct
+        with Rec():
+            ag.simulate(K)
+        torch.cuda.synchronize()
+        got.append((ag.get_history_tensor().cpu(), pcs.get_history_tensors()[0].cpu(), gcs.get_history_tensors()[1].cpu()))
+        assert any("riab.simulate_" in n for n in names), sorted(set(names))   # (a dispatch mode is active: the operator)
+        names.clear()
+    # without a dispatch mode the two routes are the attribute's choice; the rows are the same
+    for direct in (False, True):
+        ag, pcs, gcs = world()
+        ag.DIRECT_NATIVE_CALL = direct
+        ag.simulate(K)
+        torch.cuda.synchronize()
+        assert torch.equal(ag.get_history_tensor().cpu(), got[0][0]) and torch.equal(pcs.get_history_tensors()[0].cpu(), got[0][1])
+    for x, y in zip(got[0], got[1]):
+        assert torch.equal(x, y)
+    assert torch.equal(got[0][1], res[0][3][:, :, :]) and torch.equal(got[0][0][-1, 0:2], res[0][1])
 
 
 def test_get_state_and_update_go_through_the_operators(riab):

@@ -210,8 +210,9 @@ def test_agent_registry_lookup():
 
 def test_bvc_direction_windows_cover_every_significant_term():
     """Host side of the BVC direction windows (Neurons.BoundaryVectorCells._call): the regrouped table rows are
-    a permutation of the cells, every window is whole quads of directions, and no (row, direction) pair with a
-    von Mises weight of 2^-24 of the peak or more falls outside its group's window."""
+    a permutation of the cells, every window is whole quads of directions, and the directions outside a row's
+    window carry at most BVC_WINDOW_SHARE = 1e-6 of the row's summed von Mises weight — the bound on the change of
+    the normalised rate (rate = sum_k g_k w_k / sum_k w_k with g_k <= 1)."""
     np.random.seed(3)
     env = riab.Environment()
     Ag = riab.Agent(env, dict(CPU))
@@ -231,9 +232,10 @@ def test_bvc_direction_windows_cover_every_significant_term():
         for i in range(n):
             k0, length = win[i // 4]
             inside = ((np.arange(K) - k0) % K) < length
-            assert not ((full[i] >= -24.0) & ~inside).any(), (n, i)
+            w = np.exp2(full[i])
+            assert w[~inside].sum() <= BVs.BVC_WINDOW_SHARE * w.sum() * (1 + 1e-9), (n, i)
         if n == 256:
-            assert win[:, 1].mean() < 0.9 * K
+            assert win[:, 1].mean() < 0.82 * K and BVs._window_stats["cells_need"] < 0.75
 
 
 def test_velocity_speed_and_agent_vector_cell_construction():

@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 import bench, ratinabox_amd as riab
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 cfg = bench.CONFIGS["cfg2"]
-env, ag, pops = bench.build_world(riab, cfg, 0, 64)
+env, ag, pops = bench.build_world(riab, cfg, 0)
 ag.preallocate_history(K * 400)
 for _ in range(5):
     ag.simulate(K)

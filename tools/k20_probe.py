@@ -22,7 +22,7 @@ L = riab._lib
 
 def world():
     cfg = bench.CONFIGS["cfg2"]
-    env, ag, pops = bench.build_world(riab, cfg, 0, 64)
+    env, ag, pops = bench.build_world(riab, cfg, 0)
     return ag, pops
 
 

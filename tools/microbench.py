@@ -36,11 +36,11 @@ def agent():
     T = 256
     for B in (4096, 32768):
         for walls, wname in (([], "open"), (MAZE, "maze")):
-            for prec in (64, 32):
+            for prec in (64,):
                 for mode in ("philox", "z_in"):
                     np.random.seed(0)
                     env = riab.Environment({"walls": walls})
-                    ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "precision": prec, "save_history": True})
+                    ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "save_history": True})
                     z = torch.randn((T, 2, B), dtype=torch.float64, device="cuda") if mode == "z_in" else None
                     hist = torch.empty((T, 8, B), dtype=torch.float32, device="cuda")
 

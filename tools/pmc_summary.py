@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """HBM traffic of the dominant kernel from rocprofv3 PMC passes (tools/prof_r02.sh: one counter per pass, as
-/opt/skills/guides/MI355X_MICROARCH.md prescribes) -> profiles/pmc_traffic_<cfg>.json, which bench.py reads for
+/opt/skills/guides/MI355X_MICROARCH.md prescribes) -> a per-kernel summary (merged by hand into profiles/pmc_traffic.json), which bench.py reads for
 `roofline.traffic`.
 
     python tools/pmc_summary.py profiles/r02_driver_pmc_WRITE_SIZE.csv profiles/r02_driver_pmc_FETCH_SIZE.csv \

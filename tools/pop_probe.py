@@ -3,7 +3,7 @@ import numpy as np, torch
 sys.path.insert(0, ".")
 import bench, ratinabox_amd as riab
 L = riab._lib
-env, ag, pops = bench.build_world(riab, bench.CONFIGS["cfg2"], 0, 64)
+env, ag, pops = bench.build_world(riab, bench.CONFIGS["cfg2"], 0)
 N = pops[0]
 p1 = N._population(); p2 = N._population()
 print("same object:", p1 is p2, "cache:", "_pop_cache" in N.__dict__)

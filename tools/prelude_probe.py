@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 import bench, ratinabox_amd as riab
 L = riab._lib
 cfg = bench.CONFIGS["cfg2"]
-env, ag, pops = bench.build_world(riab, cfg, 0, 64)
+env, ag, pops = bench.build_world(riab, cfg, 0)
 N = pops[0]
 ag.preallocate_history(64)
 ag.simulate(20); torch.cuda.synchronize()

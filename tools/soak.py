@@ -19,7 +19,6 @@ cases = {
     "periodic + wall": ({"boundary_conditions": "periodic", "walls": [[[0.5, 0.2], [0.5, 0.8]]]}, {"dt": 0.02}, None),
     "2x1 box, drift": ({"aspect": 2, "walls": [[[1.0, 0.0], [1.0, 0.7]]]}, {"dt": 0.02}, [0.1, -0.05]),
     "no repulsion, thigmotaxis 1": ({"walls": MAZE}, {"dt": 0.02, "wall_repel_strength": 0.0, "thigmotaxis": 1.0}, None),
-    "fp32 arithmetic": ({"walls": MAZE}, {"dt": 0.01, "precision": 32}, None),
 }
 for name, (envp, agp, drift) in cases.items():
     np.random.seed(1)
