@@ -49,6 +49,11 @@ VALU_EXP_PEAK_TTERMS = VALU_SIMDS * 64 * VALU_CLOCK_GHZ / VALU_CYCLES["v_exp_f32
 VALU_MIX_SERIAL_TTERMS = VALU_SIMDS * 64 * VALU_CLOCK_GHZ / (9.44 + 5.17 + 0.5 * 4.98) / 1e3
 VALU_MIX_MEASURED_TTERMS = 10.0
 
+# steps of the short cfg3 / cfg4 / cfg5 runs in the `secondary` block of the cfg2 line.  More than 256: every run then takes
+# the chunk form of the rate stage, so that `rate_kernel_gated` in a rocprofv3 summary of the driver's command is the
+# headline configuration's kernel alone (cfg4's PlaceCells would otherwise share its name at 150 times its size).
+SECONDARY_STEPS = 320
+
 CONFIGS = {
     # name: agents per GPU, cells, walls, spikes
     "cfg2": dict(agents=4096, place=1024, grid=0, bvc=0, hdc=0, walls=[], spikes=False,
@@ -560,12 +565,12 @@ def main():
             args.no_history = False
             t0 = time.perf_counter()
             try:
-                o, c = measure(args, name, 256, 32, 5, rank, world, local, dist, False, control_plane, store_ceiling=False)
+                o, c = measure(args, name, SECONDARY_STEPS, 32, 5, rank, world, local, dist, False, control_plane, store_ceiling=False)
             except Exception as e:  # noqa: BLE001  (the headline line must not be lost to a secondary run)
                 secondary[name] = {"error": f"{type(e).__name__}: {e}"}
                 continue
             r = o["roofline"] or {}
-            secondary[name] = {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "steps": 256,
+            secondary[name] = {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "steps": SECONDARY_STEPS,
                                "warmup": 32, "repeats": o["repeats"], "ms_per_step": o["ms_per_step"],
                                "timed_region_ms": o["timed_region_ms"]["median"],
                                "bytes_per_agent_step": o["config"]["bytes_per_agent_step"],

@@ -158,6 +158,66 @@ def test_fused_without_history_keeps_last_rows(riab):
     np.testing.assert_array_equal(res[0][1], res[1][1])
 
 
+def test_repeated_simulate_calls_see_every_edit(riab, monkeypatch):
+    """simulate() after a plain native simulate() takes a short road that reuses what the first call prepared
+    (Agent._simulate_repeat) — after re-examining all of it.  A script that edits motion parameters, a tuning array in
+    place, the firing-rate range, the geometry, the state, a seed, the history switches, steps with update() and
+    changes dt between calls gives the same rows with the short road and without it."""
+    def script(ag, pcs, gcs, env):
+        ag.simulate(20)
+        ag.simulate(20)                                   # (the short road, when it exists)
+        ag.speed_mean = 0.2                               # reference tests/test_advanced.py:47-48
+        ag.simulate(12)
+        pcs.place_cell_centres[-1] = [0.9, 0.9]           # in-place edit of a tuning array (:59)
+        ag.simulate(12)
+        gcs.max_fr = 3.0
+        ag.simulate(9)
+        env.add_wall([[0.2, 0.6], [0.8, 0.6]])
+        ag.simulate(16)
+        ag.pos = np.full((ag.n_agents, 2), 0.25)
+        ag.simulate(8)
+        ag.update(); pcs.update(); gcs.update()
+        ag.simulate(8)
+        ag.simulate(8, dt=0.02)
+        ag.simulate(8)
+        gcs.save_history = False
+        ag.simulate(8)
+        gcs.save_history = True
+        ag.simulate(8, drift_velocity=[0.05, 0.0])
+        ag.simulate(8)
+        ag.simulate(300)
+        ag.simulate(8)
+        torch.cuda.synchronize()
+        return (ag.get_history_tensor().cpu(), pcs.get_history_tensors()[0].cpu(), gcs.get_history_tensors()[0].cpu(),
+                gcs.get_history_tensors()[1].cpu(), ag.state_tensor.cpu(), list(ag.history["t"]), ag.diagnostics)
+
+    res, used = [], []
+    for short in (True, False):
+        np.random.seed(3)
+        env = riab.Environment({})
+        ag = riab.Agent(env, {"n_agents": 512, "dt": 0.01, "seed": 17})
+        np.random.seed(4)
+        pcs = riab.PlaceCells(ag, {"n": 32, "save_spikes": False})
+        gcs = riab.GridCells(ag, {"n": 16})
+        count = {"n": 0}
+        real = type(ag)._simulate_repeat
+
+        def repeat(self, n, _real=real, _short=short, _count=count):
+            if not _short:
+                return None
+            out = _real(self, n)
+            _count["n"] += out is not None
+            return out
+        monkeypatch.setattr(type(ag), "_simulate_repeat", repeat)
+        res.append(script(ag, pcs, gcs, env))
+        used.append(count["n"])
+        monkeypatch.undo()
+    assert used[0] >= 4 and used[1] == 0, used
+    for x, y in zip(res[0][:5], res[1][:5]):
+        assert torch.equal(x, y)
+    assert res[0][5] == res[1][5] and res[0][6] == res[1][6] and res[0][6]["pipeline_timeouts"] == 0
+
+
 @pytest.mark.parametrize("when_busy", ["0", "1"])
 def test_fused_launch_modes(riab, when_busy):
     """The rate kernel behind the started gate (the default) and straight behind the trajectory kernel (an option
