@@ -254,6 +254,10 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
             p.reset_history()
         ag.preallocate_history(n)  # output buffers are allocated outside the timed region
 
+    # the dominant kernel: BoundaryVectorCells where there are any (65-70 % of the kernel time of cfg 3 / cfg 5,
+    # profiles/r03_cfg3_kernel_stats.csv), else the first population
+    dominant = next((p for p in pops if type(p).__name__ == "BoundaryVectorCells"), pops[0])
+    ag._timed_population = dominant
     # ---- warmup (untimed); its history is dropped so the timed runs own fresh HBM
     if W > 0:
         run(W)
@@ -268,9 +272,6 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
     seen = {"n": 0}
     n_launches = (K + chunk - 1) // max(chunk, 1)
 
-    # the dominant kernel: BoundaryVectorCells where there are any (65-70 % of the kernel time of cfg 3 / cfg 5,
-    # profiles/r02_cfg3_kernel_stats.csv), else the first population
-    dominant = next((p for p in pops if type(p).__name__ == "BoundaryVectorCells"), pops[0])
 
     def hook(pop, what, tc):
         if pop is not dominant:
@@ -286,7 +287,6 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         else:
             spans[-1][1] = ev
 
-    ag._timed_population = dominant
     if not (args.per_step or args.plan or fused_mode or native_mode):
         ag._profile_hook = hook
 

@@ -663,6 +663,7 @@ class Agent:
         if plain:
             self._snap = dict(neurons=list(neurons), structs=structs, arr=arr, run=run, byref=byref, env=env, m=m, dt=dt,
                               seed=self.seed, a0=self.agent_id0, timing=self._time_rate_kernel,
+                              timed=getattr(self, "_timed_population", None),
                               pops=[(N, int(N.n), at[2] is not None) for N, at in zip(neurons, ats)])
         return traj
 
@@ -701,6 +702,7 @@ class Agent:
         pops = sn["pops"]
         if len(Ns) != len(pops) or self.use_imported_trajectory or not self.save_history or self.seed != sn["seed"] or \
                 self.agent_id0 != sn["a0"] or self._time_rate_kernel != sn["timing"] or not self.DIRECT_NATIVE_CALL or \
+                getattr(self, "_timed_population", None) is not sn["timed"] or \
                 torch._C._len_torch_dispatch_stack() > 0 or _L.env("RIAB_NO_NATIVE") == "1":
             return None
         structs = sn["structs"]
