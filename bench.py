@@ -310,7 +310,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
     event_ms = []
     if fused_mode and K <= 256 and ag._time_rate_kernel is True:
         ag._time_rate_kernel = "events"
-        for _r in range(3):
+        for _r in range(10):
             fresh_history(K)
             torch.cuda.synchronize()
             run(K)
@@ -413,6 +413,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
                                     "start / stop events on its launch")
             if event_ms:
                 roofline["avg_launch_ms_hip_events"] = round(float(np.mean(event_ms)), 5)
+                roofline["frac_hip_events"] = round(unit_bytes * float(np.mean(units)) / (float(np.mean(event_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if fused_mode:
             roofline["note"] = ("the rate stage runs concurrently with the trajectory kernel whose rows it consumes (coupled "
                                 "by flags in device memory, one native call per timed region): its duration includes "

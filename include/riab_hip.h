@@ -567,6 +567,7 @@ double riab_plan_task_clock(const RiabPlan* plan);
  *    FeedForwardLayers — input_index refers to EARLIER entries of `pops` —, OU noise, spikes; longer runs): per chunk
  *    of rows (16, 28, 44, ... 128) a one-wave gate that waits for the chunk's last row, then each population's
  *    ordinary kernel in array order (noise pass and spikes after it, as in riab_plan_step).
+ * n_pops == 0 (an agent without populations): the trajectory kernel alone, on `stream`.
  * forced_pos != NULL (Agent.import_trajectory / forced_next_position, Agent.py:229-266): there is no recurrence to
  * overlap: the forced-position kernel and the populations' kernels follow each other on `stream`.
  * Velocity cells (they read the float64 state, which no history row keeps) are not covered: RIAB_EUNSUPPORTED,

@@ -107,6 +107,9 @@ class Agent:
         self._auto_enabled = os.environ.get("RIAB_NO_AUTO_PLAN") != "1"
         self._streamer = None   # native handle of the flag-coupled pipeline (created on first use)
         self._snap = None       # what the last plain native simulate() prepared (see _simulate_repeat)
+        # simulate() calls served by each engine: "native" = riab_simulate, "plan" = a native step plan (populations that
+        # read the float64 state), "chunks" = the Python-driven chunk pipeline (RIAB_NO_NATIVE=1, > 16 populations)
+        self.engine_runs = {"native": 0, "plan": 0, "chunks": 0}
         self._run_cache = None  # (population structs, their array, the RiabSimulate argument block, key) of the last call
         self._ctrl = None       # its control words on the device
         self._pipeline_unchecked = False
@@ -385,8 +388,10 @@ class Agent:
         rate kernel for a single store-bound population, every population's kernels per chunk of rows behind a gate
         for any other set; any batch size, explicit `noise=` normals, per-call motion kwargs and imported trajectories
         included.  Populations that read the agent's float64 state (VelocityCells) advance through a native step plan.
-        What neither covers (AgentVectorCells, recurrent layers, float32 motion) runs as trajectory chunks of `chunk`
-        steps on one HIP stream with the rate kernels of each finished chunk on a second one.  Histories land in HBM
+        AgentVectorCells and recurrent layers have no open-loop run (NotImplementedError: they advance through
+        update()).  The older Python-driven pipeline — trajectory chunks of `chunk` steps on one HIP stream, the rate
+        kernels of each finished chunk on a second one — is kept as the comparator of the tests (`RIAB_NO_NATIVE=1`)
+        and for more than 16 populations; `Agent.engine_runs` counts which engine served each call.  Histories land in HBM
         (`save_history=True`) exactly as `n_steps` calls of update() would have left them.  Returns the trajectory
         history tensor of this call `[n_steps, 8, B_padded]` (device; None when populations that read the agent's state
         are advanced through a step plan and the agent keeps no history).  The tensor is returned while the kernels
@@ -419,6 +424,7 @@ class Agent:
                                      noise, kwargs)
         if traj is not None:
             return traj
+        self.engine_runs["chunks"] += 1
         if self._streams is None:
             self._streams = self._make_streams()
         s_traj, s_rate = self._streams
@@ -481,6 +487,7 @@ class Agent:
         counters as `n_steps` x (update(); N.update()), so bit-identical to that loop."""
         from .plan import StepPlan
         plan = StepPlan(self, neurons, capacity=max(1, min(n_steps, 1024)))
+        self.engine_runs["plan"] += 1
         done = 0
         while done < n_steps:
             n = min(plan.capacity, n_steps - done)
@@ -521,7 +528,7 @@ class Agent:
         the stream).  Returns None — nothing reserved, nothing launched — for what it does not cover: populations
         that cannot be recorded (AgentVectorCells, recurrent FeedForwardLayers), float32 motion; `RIAB_NO_NATIVE=1`
         switches it off (A/B comparisons: the Python-driven chunk pipeline gives identical results)."""
-        if not neurons or len(neurons) > 16 or n_steps <= 0 or _L.env("RIAB_NO_NATIVE") == "1":
+        if len(neurons) > 16 or n_steps <= 0 or _L.env("RIAB_NO_NATIVE") == "1":
             return None
         for N in neurons:
             if N.Agent is not self:
@@ -589,7 +596,7 @@ class Agent:
             for i, pop in enumerate(structs):
                 _L.C.memmove(_L.C.byref(arr, i * _L.POP_SIZE), _L.C.byref(pop), _L.POP_SIZE)
             run = _L.RiabSimulate()
-            run.pops, run.n_pops = _L.C.cast(arr, _L.C.POINTER(_L.RiabPopulation)), npop
+            run.pops, run.n_pops = (_L.C.cast(arr, _L.C.POINTER(_L.RiabPopulation)) if npop else None), npop
             run.env, run.motion = _L.C.pointer(env), _L.C.pointer(m)
             run.state, run.B, run.agent_id0 = self._state.data_ptr(), Bp, int(self.agent_id0)
             run.seed = int(self.rng_seed)
@@ -671,6 +678,7 @@ class Agent:
         """The kernels of a native run are in flight: now the views and the Python-side mirrors (clocks, step index,
         the populations' newest rows)."""
         outs = [N._rows_views(at, n_steps) for N, at in zip(neurons, ats)]
+        self.engine_runs["native"] += 1
         self._pipeline_unchecked = True
         traj = traj_c[traj_s:traj_s + n_steps]
         self._keep = (keep, outs)
@@ -980,7 +988,7 @@ class Agent:
         """T steps along the imported trajectory (Agent._update_position_along_imported_trajectory)."""
         dt = dt or self.dt
         if self.interpolate:
-            ts = self.t + dt * np.arange(1, T + 1)
+            ts = np.cumsum(np.concatenate(([self.t + dt], np.full(T - 1, dt))))  # the loop's clock: `t += dt` repeated
             pos = self.pos_interp(ts % max(self.t_interp))            # (T, 1|B, 2)
             pos = np.broadcast_to(pos, (T, self._B, 2))
             full = np.empty((T, 2, self._Bp))

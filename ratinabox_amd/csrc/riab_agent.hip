@@ -63,6 +63,8 @@ int launch_agent_pub(const AgentArgs& a, hipStream_t s) {
 
 // the forced-position trajectory (Agent.import_trajectory / forced_next_position) of riab_simulate: the single-wave
 // kernel in forced mode, plain stores (what follows it on the stream is ordered by the stream)
+int launch_agent_plain(const AgentArgs& a, hipStream_t s);
+
 int launch_agent_forced(const AgentArgs& a, hipStream_t s) {
   if (!a.forced || !a.hist) return RIAB_EINVAL;
   const dim3 grid((unsigned)((a.B + 63) / 64));
@@ -82,9 +84,18 @@ extern "C" int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, dou
   const int rc = fill_agent_args(a, env, motion, state, B, agent_id0, drift, z_in, z_out, forced_pos, seed, step0, T, hist,
                                  diag, resample_pos);
   if (rc) return rc;
+  return riab::launch_agent_plain(a, (hipStream_t)stream);
+}
+
+// the trajectory kernel that fits the launch (no publication: what follows on the stream is ordered by the stream):
+// riab_agent_step, and riab_simulate for an agent without populations
+int riab::launch_agent_plain(const AgentArgs& a, hipStream_t s) {
+  {
+  const int64_t B = a.B;
+  const int32_t T = a.T;
+  const double* const z_out = a.z_out;
   const dim3 grid((unsigned)((B + 63) / 64));
-  hipStream_t s = (hipStream_t)stream;
-  const int in = forced_pos ? 2 : (z_in ? 1 : 0);
+  const int in = a.forced ? 2 : (a.z_in ? 1 : 0);
   // (A/B comparisons, riab_set_option(RIAB_OPT_TRAJ_KERNEL): 1 the single-wave kernel for every launch, 2 round 1's
   // two-wave kernel)
   const bool no_pc = g_options[RIAB_OPT_TRAJ_KERNEL] == 1, two_wave = g_options[RIAB_OPT_TRAJ_KERNEL] == 2;
@@ -97,5 +108,6 @@ extern "C" int riab_agent_step(const RiabEnv* env, const RiabMotion* motion, dou
   else if (in == 0) hipLaunchKernelGGL((agent_step_kernel<double, 0, false>), grid, dim3(64), 0, s, a);
   else if (in == 1) hipLaunchKernelGGL((agent_step_kernel<double, 1, false>), grid, dim3(64), 0, s, a);
   else hipLaunchKernelGGL((agent_step_kernel<double, 2, false>), grid, dim3(64), 0, s, a);
+  }
   return (int)hipGetLastError();
 }

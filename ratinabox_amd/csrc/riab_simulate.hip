@@ -38,6 +38,7 @@
 namespace riab {
 int launch_agent_pub(const AgentArgs& a, hipStream_t s);
 int launch_agent_forced(const AgentArgs& a, hipStream_t s);
+int launch_agent_plain(const AgentArgs& a, hipStream_t s);
 int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
 int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t T, float dt,
                        uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, uint32_t spin_limit, bool stamps,
@@ -243,7 +244,8 @@ static std::vector<int32_t> chunk_schedule(const RiabEnv* env, int32_t T) {
 }
 
 extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream_t stream) {
-  if (!h || !q || !q->env || !q->motion || !q->pops || !q->ctrl || !q->hist || q->n_pops <= 0 || q->T <= 0) return RIAB_EINVAL;
+  if (!h || !q || !q->env || !q->motion || !q->ctrl || !q->hist || q->n_pops < 0 || (q->n_pops > 0 && !q->pops) || q->T <= 0)
+    return RIAB_EINVAL;
   const RiabEnv* env = q->env;
   const RiabPopulation* pops = q->pops;
   const int32_t T = q->T, n_pops = q->n_pops;
@@ -262,6 +264,9 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   const bool timing = q->timed_pop >= 0 && q->timed_pop < n_pops;
   h->timed = 0;
   h->n_pairs = 0;
+
+  // ---- an agent without populations: the trajectory alone, on the caller's stream -----------------------------------
+  if (n_pops == 0) return riab::launch_agent_plain(a, main_s);
 
   // ---- forced positions: no recurrence, nothing to overlap: one stream, kernel after kernel --------------------------
   if (q->forced_pos) {

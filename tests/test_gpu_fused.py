@@ -158,6 +158,81 @@ def test_fused_without_history_keeps_last_rows(riab):
     np.testing.assert_array_equal(res[0][1], res[1][1])
 
 
+def test_one_engine_for_simulate(riab, monkeypatch):
+    """Agent.simulate() is the native call for every run it accepts (AgentVectorCells and recurrent layers advance
+    through update() only; the Python-driven chunk pipeline is left as the RIAB_NO_NATIVE=1 comparator): explicit `noise=`
+    normals, per-call motion kwargs, `resample_positions=`, an imported trajectory, a batch that is neither whole waves
+    nor whole 256-agent groups, an agent without populations — each makes riab_simulate calls (counted) and gives,
+    bit for bit, the rows of the Python-driven chunk pipeline (RIAB_NO_NATIVE=1)."""
+    L = riab._lib
+    calls = {"n": 0}
+    real = L.lib
+
+    class Counting:
+        def __getattr__(self, k):
+            return getattr(real, k)
+
+        def riab_simulate(self, *a):
+            calls["n"] += 1
+            return real.riab_simulate(*a)
+
+    def world(B, pops=True, env_params=None):
+        np.random.seed(11)
+        env = riab.Environment(env_params or {"walls": [[[0.5, 0.0], [0.5, 0.4]]]})
+        ag = riab.Agent(env, {"n_agents": B, "dt": 0.02, "seed": 5})
+        np.random.seed(12)
+        ps = [riab.PlaceCells(ag, {"n": 24}), riab.BoundaryVectorCells(ag, {"n": 6})] if pops else []
+        return env, ag, ps
+
+    rs = np.random.RandomState(0)
+    z100 = rs.normal(size=(40, 2, 100))
+    traj_t = np.linspace(0, 3, 60)
+    traj_p = np.stack((0.5 + 0.3 * np.cos(traj_t), 0.5 + 0.3 * np.sin(traj_t)), -1)
+    hole_env = {"holes": [[[0.4, 0.4], [0.6, 0.4], [0.6, 0.6], [0.4, 0.6]]]}
+    rs_pos = np.stack((np.full((40, 100), 0.2), np.full((40, 100), 0.8)), -1)
+
+    def cases():
+        yield "noise", 100, True, None, lambda ag: ag.simulate(40, noise=z100)
+        yield "kwargs", 100, True, None, lambda ag: ag.simulate(40, speed_mean=0.3, thigmotaxis=0.9)
+        yield "ragged", 300, True, None, lambda ag: ag.simulate(70)
+        yield "no populations", 128, False, None, lambda ag: ag.simulate(40, noise=np.zeros((40, 2, 128)))
+        yield "resample", 100, True, hole_env, lambda ag: ag.simulate(40, resample_positions=rs_pos)
+
+        def imported(ag):
+            ag.import_trajectory(times=traj_t, positions=traj_p)
+            ag.simulate(50)
+        yield "imported", 4, True, None, imported
+
+    for name, B, pops, envp, run in cases():
+        got = []
+        for native in (True, False):
+            monkeypatch.setenv("RIAB_NO_NATIVE", "0" if native else "1")
+            monkeypatch.setattr(L, "lib", Counting())
+            calls["n"] = 0
+            env, ag, ps = world(B, pops, envp)
+            run(ag)
+            torch.cuda.synchronize()
+            monkeypatch.setattr(L, "lib", real)
+            assert (calls["n"] >= 1) == native, (name, native, calls["n"])
+            assert ag.engine_runs == {"native": int(native), "plan": 0, "chunks": int(not native)}, (name, ag.engine_runs)
+            got.append([ag.get_history_tensor().cpu(), ag.state_tensor.cpu()] + [t.cpu() for N in ps for t in N.get_history_tensors()])
+            assert ag.diagnostics.get("pipeline_timeouts", 0) == 0
+        for x, y in zip(*got):
+            assert torch.equal(x, y), name
+    monkeypatch.delenv("RIAB_NO_NATIVE", raising=False)
+    # populations that read the float64 state -> a native step plan; populations that follow ANOTHER Agent object
+    # have no open-loop run at all (both agents advance through update())
+    env, ag, ps = world(8)
+    riab.VelocityCells(ag)
+    ag.simulate(12)
+    assert ag.engine_runs == {"native": 0, "plan": 1, "chunks": 0}
+    env, ag, ps = world(8)
+    other = riab.Agent(env, {"n_agents": 8, "dt": 0.02, "seed": 6})
+    riab.AgentVectorCells(ag, other, {"n": 4})
+    with pytest.raises(NotImplementedError):
+        ag.simulate(12)
+
+
 def test_repeated_simulate_calls_see_every_edit(riab, monkeypatch):
     """simulate() after a plain native simulate() takes a short road that reuses what the first call prepared
     (Agent._simulate_repeat) — after re-examining all of it.  A script that edits motion parameters, a tuning array in
@@ -605,7 +680,7 @@ def test_simulate_pops_argument_errors_launch_nothing(riab):
         run.timed_pop = -1
         return L.lib.riab_simulate(ag._streamer, L.C.byref(run), L.current_stream())
 
-    assert call(n_pops=0) == L.EINVAL
+    assert call(n_pops=-1) == L.EINVAL                      # (0 populations: the trajectory kernel alone)
     assert call(B=ag._Bp + 2) == L.EALIGN                  # not whole quads of agents
     assert call(cap=T - 1) == L.EINVAL                      # rows for the whole run are required
     assert call(ff_input=len(pops) - 1) == L.EINVAL         # a layer reading itself / a later population

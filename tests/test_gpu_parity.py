@@ -214,6 +214,7 @@ def test_motion_rollout_vs_reference(riab, fname):
         return  # (host-side position edits between steps: nothing for the fused path to replay)
     Ag2, kw, dt = _agent_from_rows(riab, g, g["roll_state0"])
     Ag2.simulate(T, noise=torch.as_tensor(z), chunk=64, **kw)
+    assert Ag2.engine_runs == {"native": 1, "plan": 0, "chunks": 0}  # the native call, not the Python chunk loop
     assert np.array_equal(Ag2.pos, Ag.pos)  # same kernel, same inputs: bit-identical
     assert np.array_equal(Ag2.history["pos"], Ag.history["pos"])
     assert np.allclose(Ag2.history["t"], Ag.history["t"])
