@@ -622,7 +622,15 @@ __global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell 
   if (s.stamps && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
     __hip_atomic_store((gu64*)(uintptr_t)(s.ctrl + RIAB_CTRL_STAMPS), (unsigned long long)__builtin_amdgcn_s_memrealtime(),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef RIAB_PIPE_PROFILE  // (tools/pipe_profile.py: per time row, on the device's constant clock, u64 words behind the ctrl block)
+  gu64* const dbg = (gu64*)(uintptr_t)(s.ctrl + 2048);
+  const bool first_wg = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  if (first_wg) dbg[1 * 64 + t] = (unsigned long long)__builtin_amdgcn_s_memrealtime();   // the row's first workgroup runs
+#endif
   stream_wait(s, wq, (int)t, lane);
+#ifdef RIAB_PIPE_PROFILE
+  if (first_wg) dbg[2 * 64 + t] = (unsigned long long)__builtin_amdgcn_s_memrealtime();   // ... and has its row
+#endif
   const int64_t po = (int64_t)t * a.pos_ld + 4 * (int64_t)q;
   const typename Cell::Pos P = SC1 ? cell.load_agent(a, po) : cell.load(a, po);
   int64_t off = ((int64_t)t * a.n + c0) * a.B + 4 * (int64_t)q;
@@ -642,6 +650,12 @@ __global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell 
       off += a.B;
     }
   }
+#ifdef RIAB_PIPE_PROFILE
+  if (blockIdx.y + 1 == gridDim.y && blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {  // the row's last workgroup is done
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dbg[3 * 64 + t] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+  }
+#endif
   if (s.stamps && t + 1 == gridDim.z && blockIdx.y + 1 == gridDim.y) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0)

@@ -362,9 +362,16 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
     const TailConst<R> tail_c = {(R)m.dt, (R)(1.0 / m.dt), (R)(1.0 - m.dt / m.hd_tau), (R)(m.dt / m.hd_tau),
                                  m.hd_tau <= m.dt};
     StepTail<R> tl{st[5 * B], st[6 * B], st[7 * B], st[8 * B], st[9 * B], st[10 * B], 0};
+#ifdef RIAB_PIPE_PROFILE
+    if (PUB && lane == 0 && blockIdx.x == 0) ((unsigned long long*)(a.ctrl + 2048))[0] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+#endif
     if (PUB && lane == 0) atomicAdd(a.ctrl + RIAB_CTRL_STARTED, 1u);  // this workgroup is resident
     // PUB: rows of steps < n have left this wave write-through and been acknowledged: the consumer may read them
     auto publish = [&](int n) {
+#ifdef RIAB_PIPE_PROFILE  // (tools/pipe_profile.py)
+      if (lane == 0 && (blockIdx.x == 0 || blockIdx.x + 1 == gridDim.x) && n <= 64)
+        ((unsigned long long*)(a.ctrl + 2048))[(blockIdx.x == 0 ? 0 : 4) * 64 + n] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+#endif
       if (lane == 0)
         __hip_atomic_store((riab_gu32*)(uintptr_t)(a.ctrl + RIAB_CTRL_PROGRESS_WORD(blockIdx.x)), (uint32_t)a.step0 + (uint32_t)n,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
