@@ -49,10 +49,10 @@ VALU_EXP_PEAK_TTERMS = VALU_SIMDS * 64 * VALU_CLOCK_GHZ / VALU_CYCLES["v_exp_f32
 VALU_MIX_SERIAL_TTERMS = VALU_SIMDS * 64 * VALU_CLOCK_GHZ / (9.44 + 5.17 + 0.5 * 4.98) / 1e3
 VALU_MIX_MEASURED_TTERMS = 10.0
 
-# steps of the short cfg3 / cfg4 / cfg5 runs in the `secondary` block of the cfg2 line.  More than 256: every run then takes
-# the chunk form of the rate stage, so that `rate_kernel_gated` in a rocprofv3 summary of the driver's command is the
-# headline configuration's kernel alone (cfg4's PlaceCells would otherwise share its name at 150 times its size).
-SECONDARY_STEPS = 320
+# steps of the cfg3 / cfg4 / cfg5 runs in the `secondary` block of the cfg2 line: what `--config cfgN` runs by default.
+# (More than 256: every run then takes the chunk form of the rate stage, so that `rate_kernel_gated` in a rocprofv3 summary of the driver's command is the
+# headline configuration's kernel alone — cfg4's PlaceCells would otherwise share its name at 150 times its size.)
+SECONDARY_STEPS = 1024
 
 CONFIGS = {
     # name: agents per GPU, cells, walls, spikes
@@ -571,6 +571,7 @@ def main():
                 secondary[name] = {"error": f"{type(e).__name__}: {e}"}
                 continue
             r = o["roofline"] or {}
+            torch.cuda.empty_cache()   # (tens of GB of history per configuration: give them back before the next one)
             secondary[name] = {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "steps": SECONDARY_STEPS,
                                "warmup": 32, "repeats": o["repeats"], "ms_per_step": o["ms_per_step"],
                                "timed_region_ms": o["timed_region_ms"]["median"],

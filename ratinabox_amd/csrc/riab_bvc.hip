@@ -55,6 +55,17 @@ struct BvcArgs {
 
 typedef const __attribute__((address_space(4))) double* const_f64_ptr;
 
+// word `qi` of the Philox block held by lane J of this lane's aligned quad (DPP quad_perm broadcast; every lane of the
+// wave must execute it)
+template <int J>
+__device__ __forceinline__ uint32_t quad_word(const u32x4& blk, int qi) {
+  const uint32_t wx = (uint32_t)__builtin_amdgcn_mov_dpp((int)blk.x, J * 0x55, 0xF, 0xF, true);
+  const uint32_t wy = (uint32_t)__builtin_amdgcn_mov_dpp((int)blk.y, J * 0x55, 0xF, 0xF, true);
+  const uint32_t wz = (uint32_t)__builtin_amdgcn_mov_dpp((int)blk.z, J * 0x55, 0xF, 0xF, true);
+  const uint32_t ww = (uint32_t)__builtin_amdgcn_mov_dpp((int)blk.w, J * 0x55, 0xF, 0xF, true);
+  return qi == 0 ? wx : (qi == 1 ? wy : (qi == 2 ? wz : ww));
+}
+
 // LDS (dynamic): float d[Kp][64] — the tile's first-wall distances.  Walls, test directions and the
 // 1/denominator table are wave-uniform: they are read from global memory with scalar loads.
 template <bool EGO>
@@ -338,9 +349,24 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
       }
       k = kn;
     }
+    // Spikes: one Philox block serves four consecutive agents of one cell (words x, y, z, w: riab_rates.hip
+    // spike_store).  Here a lane is ONE agent and holds the group's four cells: lane i of each aligned quad computes the
+    // block of cell 4g + i once and the quad exchanges words (DPP quad_perm) — agent i of the quad takes word i of every
+    // cell's block — instead of every lane computing all four blocks for one word each.  (Quads are whole: B, agent_id0
+    // and the tile base are multiples of four, so the four lanes share the time row and gid >> 2.)
+    u32x4 blk = {0u, 0u, 0u, 0u};
+    const int qi = lane & 3;
+    if (a.spikes && !a.u_in) {
+      const int ci = min(4 * g + qi, n - 1);
+      const int c = a.rows ? a.rows[ci] : ci;
+      const uint64_t gid = (uint64_t)(a.agent_id0 + b);
+      blk = philox4x32_10(a.step0 + (uint32_t)t, (uint32_t)c, (uint32_t)(gid >> 2), a.tag, a.k0, a.k1);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ci = 4 * g + j;  // table row
+      // word `qi` of the block that lane j of the quad holds (all lanes take part in the exchange)
+      const uint32_t word = j == 0 ? quad_word<0>(blk, qi) : (j == 1 ? quad_word<1>(blk, qi) : (j == 2 ? quad_word<2>(blk, qi) : quad_word<3>(blk, qi)));
       if (ci < n && live) {
         const int c = a.rows ? a.rows[ci] : ci;  // the cell it belongs to
         float r = (acc2[j].x + acc2[j].y) * a.inv_norm[ci];
@@ -348,16 +374,7 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
         const int64_t off = (t * n + c) * a.B + b;
         a.rates[off] = r;
         if (a.spikes) {
-          float u;
-          if (a.u_in) {
-            u = a.u_in[off];
-          } else {
-            const uint64_t gid = (uint64_t)(a.agent_id0 + b);
-            const u32x4 w4 = philox4x32_10(a.step0 + (uint32_t)t, (uint32_t)c, (uint32_t)(gid >> 2), a.tag, a.k0, a.k1);
-            const uint32_t jj = (uint32_t)gid & 3u;
-            const uint32_t word = jj == 0 ? w4.x : (jj == 1 ? w4.y : (jj == 2 ? w4.z : w4.w));
-            u = u01_24(word);
-          }
+          const float u = a.u_in ? a.u_in[off] : u01_24(word);
           a.spikes[off] = (u < a.dt * r) ? 1 : 0;
         }
       }
@@ -389,6 +406,8 @@ extern "C" int riab_boundary_vector_cells_windowed(const RiabEnv* env, const Ria
   if (env->n_walls <= 0 || !env->walls) return RIAB_EINVAL;  // BVCs need solid boundaries (Neurons.py:1580-1582)
   if (env->n_walls > RIAB_MAX_WALLS || K > RIAB_MAX_TEST_ANGLES) return RIAB_ETOOBIG;
   if (io->u_in && !io->spikes) return RIAB_EINVAL;
+  // (in-kernel spike draws share one Philox block between the four agents of an aligned quad, like the rate kernels)
+  if (io->spikes && !io->u_in && (io->B % 4 != 0 || io->agent_id0 % 4 != 0)) return RIAB_EALIGN;
   BvcArgs a;
   a.pos_x = io->pos_x;
   a.pos_y = io->pos_y;

@@ -304,11 +304,16 @@ def test_philox_spikes_bit_exact(riab):
     Ag = riab.Agent(make_env(riab), {"n_agents": B, "dt": 0.01, "seed": seed, "agent_id0": 1024})
     PCs = riab.PlaceCells(Ag, {"n": n, "max_fr": 30.0})
     HDs = riab.HeadDirectionCells(Ag, {"n": 12, "max_fr": 50.0})
+    # (boundary vector cells: a lane is one agent and the four lanes of a quad share their Philox blocks; 10 cells = two
+    # whole groups of four and a partial one)
+    np.random.seed(9)
+    BVs = riab.BoundaryVectorCells(Ag, {"n": 10, "max_fr": 40.0})
     for t in range(T):
         Ag.update()
         PCs.update()
         HDs.update()
-    for pop in (PCs, HDs):
+        BVs.update()
+    for pop in (PCs, HDs, BVs):
         fr, sp = pop.get_history_tensors()
         fr, sp = fr.cpu().numpy(), sp.cpu().numpy().astype(bool)
         for t in range(T):
@@ -320,14 +325,16 @@ def test_philox_spikes_bit_exact(riab):
     Ag2 = riab.Agent(make_env(riab), {"n_agents": B, "dt": 0.01, "seed": seed, "agent_id0": 1024})
     P2 = riab.PlaceCells(Ag2, {"place_cell_centres": PCs.place_cell_centres, "max_fr": 30.0})
     H2 = riab.HeadDirectionCells(Ag2, {"n": 12, "max_fr": 50.0})
-    for k in gu.PRE_SLICES:
-        pass
+    np.random.seed(9)
+    B2 = riab.BoundaryVectorCells(Ag2, {"n": 10, "max_fr": 40.0})
     Ag2.simulate(T, chunk=4)
     torch.cuda.synchronize()
     assert np.array_equal(Ag2.history["pos"], Ag.history["pos"])
     assert np.array_equal(P2.history["firingrate"], PCs.history["firingrate"])
     assert np.array_equal(P2.history["spikes"], PCs.history["spikes"])
     assert np.array_equal(H2.history["spikes"], HDs.history["spikes"])
+    assert np.array_equal(B2.history["firingrate"], BVs.history["firingrate"])
+    assert np.array_equal(B2.history["spikes"], BVs.history["spikes"]) and BVs.history["spikes"].sum() > 0
 
 
 # ----------------------------------------------------------------------------- oracle on seeded inputs, config shapes
