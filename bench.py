@@ -308,7 +308,8 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
     # cross-check of the device-clock timing of the one-kernel rate stage: a few more regions — not part of `value` —
     # with HIP start / stop events attached to the kernel's launch (what rocprofv3 would report for it)
     event_ms = []
-    if fused_mode and K <= 256 and ag._time_rate_kernel is True:
+    one_kernel = fused_mode and ag.last_rate_stage_form() == "one-kernel"   # (what the library chose: riab_streamer_last_form)
+    if one_kernel and ag._time_rate_kernel is True:
         ag._time_rate_kernel = "events"
         for _r in range(10):
             fresh_history(K)
@@ -356,7 +357,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         pmc_kernel = None
         if type(dominant).__name__ == "PlaceCells" and not cfg["spikes"]:
-            pmc_kernel = "rate_kernel_gated" if (fused_mode and K <= 256) else "rate_kernel_wide"
+            pmc_kernel = "rate_kernel_gated" if one_kernel else "rate_kernel_wide"
         if pmc_kernel and os.path.exists(tpath):
             with open(tpath) as f:
                 entry = json.load(f).get("kernels", {}).get(pmc_kernel)
@@ -365,8 +366,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
                 traffic_from = (f"profiles/pmc_traffic.json[{pmc_kernel}]: {entry['hbm_bytes_per_unit']:.1f} B per agent-step "
                                 f"(rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, {entry['source'].split(': ')[-1]}) x units "
                                 "of this run's launches; counters are not collected inside bench.py")
-        poll_max = 256
-        kname = (("rate_kernel_gated" if K <= poll_max else "rate stage = rate_kernel_wide per chunk behind progress gates")
+        kname = (("rate_kernel_gated" if one_kernel else "rate stage = rate_kernel_wide per chunk behind progress gates")
                  if fused_mode else "rate_kernel_wide") + f"<{type(dominant).__name__}>"
         if native_mode:
             kname = f"every launch of {type(dominant).__name__}'s kernel in one riab_simulate call (chunks of rows behind gates)"
@@ -404,7 +404,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
             roofline["note"] = ("`avg_launch_ms` is the SUM of the kernel's launches of one timed region (HIP events around each "
                                 "launch on the stream it runs on, riab_streamer_last_rate_ms), `units_per_launch` the agent-"
                                 "steps of the region; rocprofv3's per-launch average x launches per region is the same sum")
-        if fused_mode and K <= 256:
+        if one_kernel:
             roofline["timed_by"] = ("HIP start / stop events attached to the kernel's launch (hipExtLaunchKernel)"
                                     if ag._time_rate_kernel == "events" else
                                     "the device's constant clock (s_memrealtime) read by the kernel's first-row waves at "
@@ -417,8 +417,9 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         if fused_mode:
             roofline["note"] = ("the rate stage runs concurrently with the trajectory kernel whose rows it consumes (coupled "
                                 "by flags in device memory, one native call per timed region): its duration includes "
-                                "waiting for rows; up to 256 steps it is ONE kernel (every wave waits for its rows), beyond "
-                                "that one rate_kernel_wide launch per chunk of rows behind a one-wave progress gate")
+                                "waiting for rows; for one store-bound population it is ONE kernel (every wave waits for "
+                                "its rows), otherwise every population's kernel per chunk of rows behind a one-wave gate")
+            roofline["rate_stage_form"] = ag.last_rate_stage_form()
             if warm_ms is not None:  # rocprofv3 --stats averages over ALL launches of the process, warm-up included
                 roofline["avg_launch_ms_incl_warmup_launch"] = round(float(np.mean(ms + [warm_ms])), 5)
                 roofline["warmup_launch_ms"] = round(warm_ms, 5)

@@ -561,7 +561,7 @@ double riab_plan_task_clock(const RiabPlan* plan);
  *
  * Two forms of the rate stage, chosen by the call:
  *  - ONE population of kind RIAB_POP_PLACE (not one_hot) / RIAB_POP_GRID / RIAB_POP_HDC without OU noise, B a
- *    multiple of 256 and T <= POLL_MAX (256): one rate kernel for all T rows whose waves each wait until the 256
+ *    multiple of 256 and T <= POLL_MAX (65535): one rate kernel for all T rows whose waves each wait until the 256
  *    agents of the wave have been stepped past their row;
  *  - anything else (several populations, boundary / object vector cells, random spatial neurons, speed cell,
  *    FeedForwardLayers — input_index refers to EARLIER entries of `pops` —, OU noise, spikes; longer runs): per chunk
@@ -640,7 +640,8 @@ typedef struct RiabStreamer RiabStreamer;
 RiabStreamer* riab_streamer_create(void);
 void riab_streamer_destroy(RiabStreamer* h);
 /* options of a streamer: GATE (RIAB_GATE_ALWAYS, the default, or RIAB_GATE_WHEN_BUSY: see "Residency"); POLL_MAX
- * (default 256): longer runs take the chunk form of the rate stage */
+ * (default 65535, the most the one-kernel form's grid holds; 0: never): longer runs take the chunk form of the rate
+ * stage */
 enum { RIAB_STREAMER_OPT_GATE = 0, RIAB_STREAMER_OPT_POLL_MAX = 1 };
 enum { RIAB_GATE_ALWAYS = 0, RIAB_GATE_WHEN_BUSY = 1 };
 int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t value);
@@ -648,6 +649,9 @@ int riab_simulate(RiabStreamer* h, const RiabSimulate* run, riab_stream_t stream
 /* after a riab_simulate call with timed_pop >= 0 and after the caller has synchronised: the duration of the timed
  * population's kernel(s) in ms; < 0 if unavailable */
 float riab_streamer_last_rate_ms(RiabStreamer* h);
+/* which form the rate stage of the last riab_simulate call through `h` took */
+enum { RIAB_FORM_NONE = 0, RIAB_FORM_ONE_KERNEL = 1, RIAB_FORM_CHUNKS = 2, RIAB_FORM_SERIAL = 3 };
+int riab_streamer_last_form(RiabStreamer* h);
 
 /* A/B switches of the library (comparisons and tests; the defaults are what production runs): process-wide, read on
  * every call they affect (plain loads of an int: the library never calls getenv).  Returns the previous value, or
@@ -657,8 +661,9 @@ float riab_streamer_last_rate_ms(RiabStreamer* h);
  *                          kernel for every launch; 2 round 1's two-wave kernel (Philox launches of >= 32 steps)
  *   RIAB_OPT_FUSED_TASK    1 (default) a task plan's motion + task step is one launch; 0 two launches
  *   RIAB_OPT_BVC_BOX       1 (default) box fast path of the boundary-vector ray stage; 0 the general stage everywhere
- *   RIAB_OPT_GATED_PLAIN   0 (default) the gated rate kernel reads positions with agent-scope loads; 1 ordinary loads */
-enum { RIAB_OPT_TRAJ_KERNEL = 0, RIAB_OPT_FUSED_TASK = 1, RIAB_OPT_BVC_BOX = 2, RIAB_OPT_GATED_PLAIN = 3, RIAB_OPT_COUNT = 4 };
+ *   RIAB_OPT_NT_STORES     0 (default) only the one-kernel rate stage of riab_simulate writes its rows with nontemporal
+ *                          stores; 1 the ungated PlaceCells / GridCells / HDC kernel too (A/B: measured slower) */
+enum { RIAB_OPT_TRAJ_KERNEL = 0, RIAB_OPT_FUSED_TASK = 1, RIAB_OPT_BVC_BOX = 2, RIAB_OPT_NT_STORES = 3, RIAB_OPT_COUNT = 4 };
 int riab_set_option(int32_t option, int32_t value);
 
 /* Process-level host setting for latency-bound callers (one short simulate() per synchronisation, as in bench.py's

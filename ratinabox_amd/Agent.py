@@ -512,6 +512,9 @@ class Agent:
             _L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_GATE, _L.GATE_WHEN_BUSY)
         if _L.env("RIAB_NO_FUSED") == "1":  # A/B comparisons: always the chunk form of the rate stage
             _L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_POLL_MAX, 0)
+        elif _L.env("RIAB_POLL_MAX"):       # (... or the one-kernel form up to this many steps)
+            _L.check(_L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_POLL_MAX, int(_L.env("RIAB_POLL_MAX"))),
+                     "riab_streamer_configure")
 
     # ---- the open-loop run as ONE native call (riab_simulate) -----------------------------------------------------------
     def _simulate_native(self, n_steps, dt, drift_velocity, ratio, neurons, noise=None, kwargs=None):
@@ -839,13 +842,21 @@ class Agent:
         return torch.from_numpy(full).to(self._device)
 
     def last_rate_kernel_ms(self):
-        """Duration of the rate stage of the last fused simulate() — one kernel for runs of up to 256 steps, a
-        sequence of kernels behind progress gates for longer ones — from HIP events on the stream it ran on, after
-        a device synchronisation; None when not timed (`Agent._time_rate_kernel = True` enables it)."""
+        """Duration of the rate stage of the last native simulate() — one kernel for a single store-bound population,
+        a sequence of kernels behind progress gates otherwise (`last_rate_stage_form()`) — from the device clock /
+        HIP events on the stream it ran on, after a device synchronisation; None when not timed
+        (`Agent._time_rate_kernel = True` enables it)."""
         if self._streamer is None:
             return None
         ms = float(_L.lib.riab_streamer_last_rate_ms(self._streamer))
         return ms if ms >= 0 else None
+
+    def last_rate_stage_form(self):
+        """Which form the rate stage of the last native simulate() took: "one-kernel", "chunks", "serial" (forced
+        positions) or None (riab_streamer_last_form)."""
+        if self._streamer is None:
+            return None
+        return {1: "one-kernel", 2: "chunks", 3: "serial"}.get(int(_L.lib.riab_streamer_last_form(self._streamer)))
 
     def __del__(self):
         try:

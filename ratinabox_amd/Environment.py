@@ -56,9 +56,13 @@ class Environment:
             b = np.asarray(self.boundary, dtype=float).reshape(-1, 2).tolist()
             assert len(b) >= 3, "a polygonal boundary needs at least 3 corners"
             if self.boundary_conditions == "periodic":
-                # (the reference warns, rewrites only params["boundary_conditions"] and carries on with a periodic
-                # attribute and no boundary walls, Environment.py:130-136: an accident, not a behaviour to mirror)
-                raise NotImplementedError("periodic boundary conditions need a rectangular environment")
+                # The reference's warning and what it announces (Environment.py:130-136).  The reference itself then
+                # rewrites only params["boundary_conditions"]: its attribute stays "periodic" and the polygon gets no
+                # boundary walls — an accident; here the announced change is carried out.
+                warnings.warn("Periodic boundary conditions are only allowed in rectangual environments. Changing "
+                              "boundary conditions to 'solid'.")
+                self.params["boundary_conditions"] = "solid"
+                self.boundary_conditions = "solid"
         self.boundary = b
         self.walls = np.array(self.walls, dtype=float).reshape(-1, 2, 2)
         self._wall_is_hole = [False] * len(self.walls)

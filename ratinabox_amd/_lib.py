@@ -183,6 +183,7 @@ PROTOTYPES = {
     "riab_simulate": (C.c_int, [C.c_void_p, C.POINTER(RiabSimulate), C.c_void_p]),
     "riab_streamer_configure": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "riab_streamer_last_rate_ms": (C.c_float, [C.c_void_p]),
+    "riab_streamer_last_form": (C.c_int, [C.c_void_p]),
     "riab_host_wait_spin": (C.c_int, [C.c_int32]),
     "riab_set_option": (C.c_int, [C.c_int32, C.c_int32]),
     "riab_abi_sizeof": (C.c_int64, [C.c_int32]),
@@ -236,7 +237,7 @@ def _load():
 lib, LIB_PATH = _load()
 
 
-OPTIONS = {"traj_kernel": 0, "fused_task": 1, "bvc_box": 2, "gated_plain": 3}   # riab_hip.h RIAB_OPT_*
+OPTIONS = {"traj_kernel": 0, "fused_task": 1, "bvc_box": 2, "nt_stores": 3}   # riab_hip.h RIAB_OPT_*
 
 
 def set_option(name, value):
@@ -249,7 +250,7 @@ def set_option(name, value):
 
 # environment variables set BEFORE the import select the same switches for a whole process (tools, A/B runs)
 for _name, _opt, _val in (("RIAB_NO_PC", "traj_kernel", 1), ("RIAB_TRAJ2", "traj_kernel", 2), ("RIAB_NO_FUSED_TASK", "fused_task", 0),
-                          ("RIAB_NO_BVC_BOX", "bvc_box", 0), ("RIAB_GATED_PLAIN", "gated_plain", 1)):
+                          ("RIAB_NO_BVC_BOX", "bvc_box", 0), ("RIAB_NT_STORES_WIDE", "nt_stores", 1)):
     if os.environ.get(_name):
         set_option(_opt, _val)
 

@@ -18,7 +18,8 @@ Same names and constructor arguments as the reference: `TaskEnvironment`, `Spati
 `Reward`, `Goal`, `SpatialGoal`, `TimeElapsedGoal`, `GoalCache`, `RewardCache`, `get_goal_vector`,
 `reward_default`, `no_reward_default`.  Outside the accelerated path (raise NotImplementedError):
 rendering, custom python decay / external-drive functions on rewards, user `TimeElapsedGoal`s in
-the pool, several Agent objects (put the agents in one batched Agent).  `agentmode` is accepted for
+the pool, several Agent objects (put the agents in one batched Agent).  `goalorder="custom"` behaves as in the
+reference: accepted by the constructor, `ValueError("Unknown mode: custom")` from the first step's goal check.  `agentmode` is accepted for
 compatibility: with one agent per replica "interact" and "noninteract" coincide."""
 import copy
 import random
@@ -153,9 +154,9 @@ class GoalCache:
     def __init__(self, env, goalorder="nonsequential", agentmode="interact", reset_goals=[], reset_n_goals=1,
                  reset_orders_goal=False, verbose=False, **kws):
         self.env = env
-        if goalorder == "custom":
-            raise NotImplementedError("goalorder='custom' is outside the accelerated path")
-        if goalorder not in ("sequential", "nonsequential"):
+        # ("custom" is accepted here and refused by the first goal check, as in the reference: its GoalCache.check has
+        # no branch for it and raises ValueError("Unknown mode: custom"), TaskEnvironment.py:1094-1138)
+        if goalorder not in ("sequential", "nonsequential", "custom"):
             raise ValueError("goalorder must be 'sequential', 'nonsequential', or 'custom'")
         if agentmode not in ("interact", "noninteract"):
             raise ValueError("agentmode must be 'interact' or 'noninteract'")
@@ -337,7 +338,7 @@ class TaskEnvironment(Environment):
         t = _L.RiabTask()
         t.goals = self._pool_dev.data_ptr()
         t.n_pool = len(rows)
-        t.goalorder = _L.GOALORDERS[self.goal_cache.goalorder]
+        t.goalorder = _L.GOALORDERS.get(self.goal_cache.goalorder, 0)   # ("custom": step() raises before any check)
         t.terminate_delay = float(self.episode_terminate_delay or 0.0)
         for i, v in enumerate(no_reward_default.row()):
             t.pad_reward[i] = v
@@ -447,6 +448,8 @@ class TaskEnvironment(Environment):
         ag.update(dt=dt, drift_velocity=actions, drift_to_random_strength_ratio=drift_to_random_strength_ratio,
                   **agent_kwargs)
         self.update(*pos, **kws)
+        if self.goal_cache.goalorder == "custom":   # (after the agents have moved: where the reference's check raises)
+            raise ValueError("Unknown mode: {}".format(self.goal_cache.goalorder))
         dev = ag.state_tensor.device
         env_s, walls = self.device_tables(dev)
         task = self._task_struct()

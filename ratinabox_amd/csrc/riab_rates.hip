@@ -97,7 +97,7 @@ __device__ __forceinline__ void spike_store(const RateArgs& a, v4f r, int64_t of
 
 // ---- drivers --------------------------------------------------------------------------------
 // SPK: 0 none, 1 Philox uniforms, 2 explicit uniforms.
-template <class Cell, int SPK, int CPB>
+template <class Cell, int SPK, int CPB, bool NT>
 __global__ __launch_bounds__(256) void rate_kernel_wide(const RateArgs a, Cell cell) {
   __shared__ double s_lds[Cell::LDS_DOUBLES];
   cell.stage(s_lds);
@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void rate_kernel_wide(const RateArgs a, Cell c
       v4f r = cell.eval(p, P);
       r = finish_rate(r * a.fr_scale + a.fr_min, P);  // [0,1] -> [min_fr, max_fr]
       if (live) {
-        *reinterpret_cast<v4f*>(a.rates + off) = r;
+        if (NT) __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(a.rates + off));
+        else *reinterpret_cast<v4f*>(a.rates + off) = r;
         if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)(c0 + j), group);
         if (SPK == 2) spike_store<true>(a, r, off, step, (uint32_t)(c0 + j), group);
       }
@@ -600,7 +601,9 @@ __device__ __forceinline__ void stream_wait(const StreamArgs& s, uint32_t q, int
   }
 }
 
-template <class Cell, int SPK, int CPB, bool SC1>
+// LONG changes nothing but the kernel's NAME: launches of more than 256 time rows are a different workload (a run, not
+// a step of a closed loop) and get their own line in a profiler's per-kernel statistics.
+template <class Cell, int SPK, int CPB, bool LONG>
 __global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell cell, const StreamArgs s) {
   __shared__ double s_lds[Cell::LDS_DOUBLES];
   cell.stage(s_lds);
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell 
   if (first_wg) dbg[2 * 64 + t] = (unsigned long long)__builtin_amdgcn_s_memrealtime();   // ... and has its row
 #endif
   const int64_t po = (int64_t)t * a.pos_ld + 4 * (int64_t)q;
-  const typename Cell::Pos P = SC1 ? cell.load_agent(a, po) : cell.load(a, po);
+  const typename Cell::Pos P = cell.load_agent(a, po);  // agent-scope (sc1) loads: the producer's rows are written through
   int64_t off = ((int64_t)t * a.n + c0) * a.B + 4 * (int64_t)q;
   const uint32_t step = a.step0 + t;
   const uint32_t group = a.group0 + q;
@@ -645,7 +648,11 @@ __global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell 
         p[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), j * NP + i));
       v4f r = cell.eval(p, P);
       r = finish_rate(r * a.fr_scale + a.fr_min, P);
-      *reinterpret_cast<v4f*>(a.rates + off) = r;
+      // Nontemporal: the rows stream past the L2 (nothing of them is read again by this call) and leave no dirty lines to
+      // write back when the kernel ends.  [MI355X] cfg 2 against ordinary stores: 20 steps: the kernel 57.9 -> 54.4 us,
+      // the region 102-104 -> 98-100 us; 64 / 256 steps + 5 / + 6 %.  (The ungated rate_kernel_wide is the other way
+      // round: - 4 % at 1024 steps, - 6 % at cfg 4 with nontemporal stores — RIAB_OPT_NT_STORES.)
+      __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(a.rates + off));
       if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)(c0 + j), group);
       off += a.B;
     }
@@ -761,9 +768,13 @@ static int launch_rate(const RiabRateIO* io, int n, const Cell& cell, hipStream_
   if (a.qrow >= 256 && io->T <= 65535 && (n + kCellsPerGroup - 1) / kCellsPerGroup <= 65535) {
     // address-ordered wide kernel
     const dim3 g((unsigned)((a.qrow + 255) / 256), (unsigned)((n + kCellsPerGroup - 1) / kCellsPerGroup), (unsigned)io->T);
-    if (!io->spikes) hipLaunchKernelGGL((rate_kernel_wide<Cell, 0, kCellsPerGroup>), g, dim3(256), 0, s, a, cell);
-    else if (!io->u_in) hipLaunchKernelGGL((rate_kernel_wide<Cell, 1, kCellsPerGroup>), g, dim3(256), 0, s, a, cell);
-    else hipLaunchKernelGGL((rate_kernel_wide<Cell, 2, kCellsPerGroup>), g, dim3(256), 0, s, a, cell);
+    if (g_options[RIAB_OPT_NT_STORES]) {  // (A/B: nontemporal stores in the ungated kernel too: slower, see rate_kernel_gated)
+      if (!io->spikes) hipLaunchKernelGGL((rate_kernel_wide<Cell, 0, kCellsPerGroup, true>), g, dim3(256), 0, s, a, cell);
+      else if (!io->u_in) hipLaunchKernelGGL((rate_kernel_wide<Cell, 1, kCellsPerGroup, true>), g, dim3(256), 0, s, a, cell);
+      else hipLaunchKernelGGL((rate_kernel_wide<Cell, 2, kCellsPerGroup, true>), g, dim3(256), 0, s, a, cell);
+    } else if (!io->spikes) hipLaunchKernelGGL((rate_kernel_wide<Cell, 0, kCellsPerGroup, false>), g, dim3(256), 0, s, a, cell);
+    else if (!io->u_in) hipLaunchKernelGGL((rate_kernel_wide<Cell, 1, kCellsPerGroup, false>), g, dim3(256), 0, s, a, cell);
+    else hipLaunchKernelGGL((rate_kernel_wide<Cell, 2, kCellsPerGroup, false>), g, dim3(256), 0, s, a, cell);
     return (int)hipGetLastError();
   }
   if (!io->spikes) hipLaunchKernelGGL((rate_kernel_generic<Cell, 0>), grid, dim3(256), 0, s, a, cell);
@@ -825,16 +836,17 @@ static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamA
   if (T > 65535 || groups > 65535) return RIAB_ETOOBIG;  // grid y / z limits: the caller splits longer runs
   if (dry_run) return RIAB_OK;  // (every argument check is above: nothing is launched)
   const dim3 grid((unsigned)((a.qrow + 255) / 256), (unsigned)groups, (unsigned)T), block(256);
-  // positions through agent-scope (sc1) loads: the producer's rows are written through
-  if (ev0 || ev1) {
-    if (spikes) hipExtLaunchKernelGGL((rate_kernel_gated<Cell, 1, CPB, true>), grid, block, 0, s, ev0, ev1, 0u, a, cell, st);
-    else hipExtLaunchKernelGGL((rate_kernel_gated<Cell, 0, CPB, true>), grid, block, 0, s, ev0, ev1, 0u, a, cell, st);
+  auto go = [&](auto kernel) {
+    if (ev0 || ev1) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, ev0, ev1, 0u, a, cell, st);
+    else hipLaunchKernelGGL(kernel, grid, block, 0, s, a, cell, st);
+  };
+  const bool lng = T > 256;
+  if (spikes) {
+    if (lng) go(rate_kernel_gated<Cell, 1, CPB, true>);
+    else go(rate_kernel_gated<Cell, 1, CPB, false>);
   } else {
-    if (g_options[RIAB_OPT_GATED_PLAIN]) {  // (A/B: positions through L2-cached loads; no difference measured)
-      if (spikes) hipLaunchKernelGGL((rate_kernel_gated<Cell, 1, CPB, false>), grid, block, 0, s, a, cell, st);
-      else hipLaunchKernelGGL((rate_kernel_gated<Cell, 0, CPB, false>), grid, block, 0, s, a, cell, st);
-    } else if (spikes) hipLaunchKernelGGL((rate_kernel_gated<Cell, 1, CPB, true>), grid, block, 0, s, a, cell, st);
-    else hipLaunchKernelGGL((rate_kernel_gated<Cell, 0, CPB, true>), grid, block, 0, s, a, cell, st);
+    if (lng) go(rate_kernel_gated<Cell, 0, CPB, true>);
+    else go(rate_kernel_gated<Cell, 0, CPB, false>);
   }
   return (int)hipGetLastError();
 }

@@ -17,15 +17,20 @@
 // --hip-trace --kernel-trace of the driver's bench command].
 //
 // Two forms of the rate stage:
-//  * one store-bound population (place / grid / head-direction cells without OU noise), up to `poll_max` (256) steps:
-//    ONE rate kernel for all rows whose waves wait for their rows themselves (rate_kernel_gated); it follows the
-//    trajectory at a distance of one block of steps; its per-wave poll costs ~10 % of the store bandwidth;
+//  * one store-bound population (place / grid / head-direction cells without OU noise), up to `poll_max` steps
+//    (default 65535, the grid's limit): ONE rate kernel for all rows whose waves wait for their rows themselves
+//    (rate_kernel_gated, nontemporal stores).  Workgroups are dispatched in row order, so the resident ones are always
+//    the oldest unfinished rows — the ones at or behind the trajectory's frontier.
 //  * anything else: per chunk of rows (16, 28, 44, ... 128) a one-wave progress gate, then every population's ordinary
-//    kernel over the chunk in list order — full store bandwidth, at the price of a chunk of distance to the trajectory
-//    and a gate + launch boundary (~5 us) per chunk.  (A kernel with ten thousand waiting workgroups in front of the
-//    runnable ones starves them: long runs cannot use the first form.)  A PERSISTENT rate kernel was built first
-//    (three versions) and removed: waves that stay resident hold store credits and lose 9-12 % of the store bandwidth
-//    against freshly dispatched ones (tools/stream_bench.hip).
+//    kernel over the chunk in list order, at the price of a chunk of distance to the trajectory and a gate + launch
+//    boundary (~5 us) per chunk.
+//    Until round 3 the first form was limited to 256 steps: with the single-wave trajectory kernel (2.6 us per step,
+//    slower than most rate kernels) and ordinary stores the chunk form was ahead beyond that.  With the four-wave
+//    trajectory kernel and nontemporal stores the one-kernel form is level or ahead at every length and population
+//    size measured [MI355X, tools/form_probe.py, 4096 agents, 1024 / 4096 steps: n = 64: 5.0 / 5.5 G agent-steps/s in
+//    both forms; n = 384: 3.47 vs 2.57 G; n = 1024: 1.36 vs 1.15 G at 1024 steps, level at 4096].
+//    A PERSISTENT rate kernel was built first (three versions) and removed: waves that stay resident hold store credits
+//    and lose 9-12 % of the store bandwidth against freshly dispatched ones (tools/stream_bench.hip).
 // Forced (imported) trajectories have no recurrence to hide: their kernel and the populations' kernels simply follow
 // each other on the caller's stream.
 #include <hip/hip_ext.h>
@@ -59,6 +64,7 @@ struct RiabStreamer {
   int wall_khz;              // rate of the device's constant clock (s_memrealtime)
   int gate_mode;             // RIAB_STREAMER_OPT_GATE
   int poll_max;              // RIAB_STREAMER_OPT_POLL_MAX
+  int last_form;             // riab_streamer_last_form
 };
 
 extern "C" RiabStreamer* riab_streamer_create(void) {
@@ -71,7 +77,8 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
   h->stamp_ctrl = nullptr;
   h->started_total = 0;
   h->gate_mode = RIAB_GATE_ALWAYS;
-  h->poll_max = 256;
+  h->poll_max = 65535;
+  h->last_form = RIAB_FORM_NONE;
   int dev = 0, khz = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess ||
@@ -109,6 +116,8 @@ extern "C" void riab_streamer_destroy(RiabStreamer* h) {
   if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
 }
+
+extern "C" int riab_streamer_last_form(RiabStreamer* h) { return h ? h->last_form : RIAB_FORM_NONE; }
 
 extern "C" float riab_streamer_last_rate_ms(RiabStreamer* h) {
   if (!h || !h->timed) return -1.0f;
@@ -265,6 +274,7 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   h->timed = 0;
   h->n_pairs = 0;
 
+  h->last_form = RIAB_FORM_NONE;
   // ---- an agent without populations: the trajectory alone, on the caller's stream -----------------------------------
   if (n_pops == 0) return riab::launch_agent_plain(a, main_s);
 
@@ -272,6 +282,7 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   if (q->forced_pos) {
     rc = riab::launch_agent_forced(a, main_s);
     if (rc) return rc;
+    h->last_form = RIAB_FORM_SERIAL;
     int fail = RIAB_OK;
     for (int32_t t0 = 0; t0 < T && !fail; t0 += 4096) {  // (time rows are a grid axis of the rate kernels)
       const int32_t tc = T - t0 < 4096 ? T - t0 : 4096;
@@ -283,6 +294,7 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
 
   // ---- which form of the rate stage; every argument check before the first launch ------------------------------------
   const bool gated = n_pops == 1 && T <= h->poll_max && riab::stream_supported(env, &pops[0], B) == RIAB_OK;
+  h->last_form = gated ? RIAB_FORM_ONE_KERNEL : RIAB_FORM_CHUNKS;
   // ~0.3 us per poll: a generous second or two before a wait gives up (a healthy wait is tens of microseconds)
   const uint32_t spin_limit = 1u << 20;
   std::vector<int32_t> sched;

@@ -191,6 +191,16 @@ def test_task_edge_cases(riab):
     Ag = riab.Agent(env, {"dt": 0.01})
     with pytest.raises(AssertionError):
         env.add_agents(Ag)
+    # goalorder="custom": accepted, reset works, the first goal check refuses it — after the agents have moved, as in the
+    # reference (GoalCache.check has no branch for it: ValueError("Unknown mode: custom"), TaskEnvironment.py:1137-1138)
+    env = SpatialGoalEnvironment(possible_goal_positions=[[0.5, 0.5]], goalcachekws=dict(goalorder="custom"))
+    Ag = riab.Agent(env, {"dt": 0.01, "n_agents": 4})
+    env.add_agents(Ag)
+    env.reset()
+    p0 = Ag.pos.copy()
+    with pytest.raises(ValueError, match="Unknown mode: custom"):
+        env.step(np.array([0.1, 0.0]))
+    assert not np.array_equal(Ag.pos, p0)
     env = SpatialGoalEnvironment(possible_goal_positions=[[0.5, 0.5]])
     with pytest.raises(NotImplementedError):
         env.add_agents(riab.Agent(env, {"dt": 0.05}))       # agent dt != environment dt

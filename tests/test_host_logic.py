@@ -41,9 +41,12 @@ def test_environment_walls_and_unsupported():
     assert per.walls.shape == (0, 2, 2)
     assert riab.Environment({"scale": 2, "aspect": 1.5}).extent.tolist() == [0, 3, 0, 2]
     assert env.flattened_discrete_coords.shape == (10000, 2)
-    for bad in ({"dimensionality": "1D"}, {"boundary": [[0, 0], [1, 0], [0, 1]], "boundary_conditions": "periodic"}):
-        with pytest.raises(NotImplementedError):
-            riab.Environment(bad)
+    with pytest.raises(NotImplementedError):
+        riab.Environment({"dimensionality": "1D"})
+    # a polygonal boundary cannot be periodic: the reference's warning (Environment.py:130-136), and what it announces
+    with pytest.warns(UserWarning, match="Changing boundary conditions to 'solid'"):
+        tri = riab.Environment({"boundary": [[0, 0], [1, 0], [0, 1]], "boundary_conditions": "periodic"})
+    assert tri.boundary_conditions == "solid" and tri.params["boundary_conditions"] == "solid" and tri.walls.shape == (3, 2, 2)
 
 
 @pytest.mark.parametrize("seed", [0, 7])

@@ -70,8 +70,7 @@ def test_goal_cache_validation_and_pool():
         GoalCache(None, agentmode="compete")
     with pytest.raises(ValueError):
         GoalCache(None, reset_n_goals=0)
-    with pytest.raises(NotImplementedError):
-        GoalCache(None, goalorder="custom")
+    assert GoalCache(None, goalorder="custom").goalorder == "custom"   # (refused by the first goal check, like the reference)
     np.random.seed(3)
     env = SpatialGoalEnvironment(possible_goal_positions="random_4", goalkws={"goal_radius": 0.07})
     pool = env.goal_cache.get_goals()
