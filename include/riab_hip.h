@@ -563,10 +563,14 @@ double riab_plan_task_clock(const RiabPlan* plan);
  *  - ONE population of kind RIAB_POP_PLACE (not one_hot) / RIAB_POP_GRID / RIAB_POP_HDC without OU noise, B a
  *    multiple of 256 and T <= POLL_MAX (65535): one rate kernel for all T rows whose waves each wait until the 256
  *    agents of the wave have been stepped past their row;
- *  - anything else (several populations, boundary / object vector cells, random spatial neurons, speed cell,
- *    FeedForwardLayers — input_index refers to EARLIER entries of `pops` —, OU noise, spikes; longer runs): per chunk
- *    of rows (16, 28, 44, ... 128) a one-wave gate that waits for the chunk's last row, then each population's
- *    ordinary kernel in array order (noise pass and spikes after it, as in riab_plan_step).
+ *  - several populations of which those of the first kind write enough per time row between them to keep pace with
+ *    the trajectory kernel (their bytes at 6.5 TB/s against 1.35 us per step + 0.375 us per wall beyond four): those
+ *    first, each as one such kernel over all T rows; then the others (boundary / object vector cells, random spatial neurons,
+ *    speed cell, FeedForwardLayers — input_index refers to EARLIER entries of `pops` —, populations with OU noise) as
+ *    their ordinary kernels over the whole run, in array order;
+ *  - anything else (a single population of the second kind, runs of more than POLL_MAX rows, ...): per chunk of rows
+ *    (16, 28, 44, ... 128) a one-wave gate that waits for the chunk's last row, then each population's ordinary
+ *    kernel in array order (noise pass and spikes after it, as in riab_plan_step).
  * n_pops == 0 (an agent without populations): the trajectory kernel alone, on `stream`.
  * forced_pos != NULL (Agent.import_trajectory / forced_next_position, Agent.py:229-266): there is no recurrence to
  * overlap: the forced-position kernel and the populations' kernels follow each other on `stream`.
@@ -650,7 +654,7 @@ int riab_simulate(RiabStreamer* h, const RiabSimulate* run, riab_stream_t stream
  * population's kernel(s) in ms; < 0 if unavailable */
 float riab_streamer_last_rate_ms(RiabStreamer* h);
 /* which form the rate stage of the last riab_simulate call through `h` took */
-enum { RIAB_FORM_NONE = 0, RIAB_FORM_ONE_KERNEL = 1, RIAB_FORM_CHUNKS = 2, RIAB_FORM_SERIAL = 3 };
+enum { RIAB_FORM_NONE = 0, RIAB_FORM_ONE_KERNEL = 1, RIAB_FORM_CHUNKS = 2, RIAB_FORM_SERIAL = 3, RIAB_FORM_POPULATIONS = 4 };
 int riab_streamer_last_form(RiabStreamer* h);
 
 /* A/B switches of the library (comparisons and tests; the defaults are what production runs): process-wide, read on

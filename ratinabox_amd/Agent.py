@@ -852,11 +852,12 @@ class Agent:
         return ms if ms >= 0 else None
 
     def last_rate_stage_form(self):
-        """Which form the rate stage of the last native simulate() took: "one-kernel", "chunks", "serial" (forced
-        positions) or None (riab_streamer_last_form)."""
+        """Which form the rate stage of the last native simulate() took: "one-kernel", "populations" (one kernel per
+        store-bound population, then the others over the whole run), "chunks", "serial" (forced positions) or None
+        (riab_streamer_last_form)."""
         if self._streamer is None:
             return None
-        return {1: "one-kernel", 2: "chunks", 3: "serial"}.get(int(_L.lib.riab_streamer_last_form(self._streamer)))
+        return {1: "one-kernel", 2: "chunks", 3: "serial", 4: "populations"}.get(int(_L.lib.riab_streamer_last_form(self._streamer)))
 
     def __del__(self):
         try:

@@ -294,16 +294,59 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
 
   // ---- which form of the rate stage; every argument check before the first launch ------------------------------------
   const bool gated = n_pops == 1 && T <= h->poll_max && riab::stream_supported(env, &pops[0], B) == RIAB_OK;
-  h->last_form = gated ? RIAB_FORM_ONE_KERNEL : RIAB_FORM_CHUNKS;
+
   // ~0.3 us per poll: a generous second or two before a wait gives up (a healthy wait is tens of microseconds)
   const uint32_t spin_limit = 1u << 20;
   std::vector<int32_t> sched;
+  // Several populations: those the one-kernel form can serve ("lead": store-bound, no OU noise) run FIRST, each as one
+  // kernel over all T rows that follows the trajectory by itself; once they are done every row has been published, and
+  // the others ("rest": boundary / object vector cells, layers, noisy populations, ...) follow as ordinary kernels over
+  // the whole run, in list order (a layer's inputs are earlier entries, or lead).  Against chunks of rows behind gates:
+  // no gate and launch boundary per chunk, no short first chunks (bvc_kernel: 22 us per row in a 16-row chunk, 16.7 in a
+  // 104-row one [MI355X, cfg 3]), and the lead kernels' nontemporal stores.  Taken when the lead populations' stores
+  // per row (at 6.5 TB/s) take at least as long as a step of the trajectory kernel next to them (0.9 us in an open room,
+  // + 0.25 us per further wall, x 1.5 next to a kernel that saturates HBM [MI355X: cfg 2 / cfg 5 0.85-1.1 us per step,
+  // cfg 3's nine walls 2.05]); otherwise the lead kernels would sit waiting for rows while nothing else runs, and the
+  // chunk form keeps the trajectory hidden behind ALL the populations' work.  [MI355X, 1024 steps: cfg 5 158-161 ->
+  // 167-168 M agent-steps/s, bvc_kernel 38.4 -> 33.8 ms; cfg 3 (16.8 MB of GridCells per row against nine walls) would
+  // lose 3 % and keeps the chunks.]
+  std::vector<int> lead, rest;
+  bool pop_major = false;
+  if (!gated && n_pops > 1 && T <= h->poll_max) {
+    int64_t lead_bytes = 0;
+    for (int i = 0; i < n_pops; ++i) {
+      if (pops[i].kind != RIAB_POP_FF && riab::stream_supported(env, &pops[i], B) == RIAB_OK) {
+        lead.push_back(i);
+        lead_bytes += (int64_t)pops[i].n * B * (pops[i].spikes_base ? 5 : 4);
+      } else {
+        rest.push_back(i);
+      }
+    }
+    const double step_us = (0.9 + 0.25 * (env->n_walls > 4 ? env->n_walls - 4 : 0)) * 1.5;
+    pop_major = !lead.empty() && (double)lead_bytes / 6.5e6 >= step_us;
+  }
+  h->last_form = gated ? RIAB_FORM_ONE_KERNEL : (pop_major ? RIAB_FORM_POPULATIONS : RIAB_FORM_CHUNKS);
+  const int32_t rest_piece = 1024;  // rows per launch of a rest population (their kernels' grids, the noise pass's loop)
   if (gated) {
     rc = riab::launch_rate_stream(env, &pops[0], q->hist, B, T, dt, q->seed, q->step0, q->agent_id0, q->ctrl, spin_limit, false,
                                   main_s, nullptr, nullptr, /*dry_run=*/true);
     if (rc) return rc;
     if (q->timing_mode == RIAB_TIMING_EVENTS && timing && !h->t0) {
       if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess) return RIAB_EINVAL;
+    }
+  } else if (pop_major) {
+    for (int i : lead) {
+      rc = riab::launch_rate_stream(env, &pops[i], q->hist, B, T, dt, q->seed, q->step0, q->agent_id0, q->ctrl, spin_limit, false,
+                                    main_s, nullptr, nullptr, /*dry_run=*/true);
+      if (rc) return rc;
+    }
+    if (timing) {
+      const size_t need = 2 * (size_t)((T + rest_piece - 1) / rest_piece);
+      while (h->pairs.size() < need) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return RIAB_EINVAL;
+        h->pairs.push_back(e);
+      }
     }
   } else {
     sched = chunk_schedule(env, T);
@@ -350,6 +393,39 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
     if (!fail && timing) {
       h->timed = stamps ? 2 : 1;
       h->stamp_ctrl = q->ctrl;
+    }
+  } else if (pop_major) {
+    fail = riab::launch_stream_gate(q->ctrl, h->started_total, 0, 0, 1u << 24, true, false, main_s);
+    int n_timed = 0;
+    for (size_t k = 0; k < lead.size() && !fail; ++k) {
+      const int i = lead[k];
+      const bool timed = timing && i == q->timed_pop;
+      if (timed) (void)hipEventRecord(h->pairs[0], main_s);
+      fail = riab::launch_rate_stream(env, &pops[i], q->hist, B, T, dt, q->seed, q->step0, q->agent_id0, q->ctrl, spin_limit,
+                                      false, main_s, nullptr, nullptr, false);
+      if (timed) {
+        (void)hipEventRecord(h->pairs[1], main_s);
+        n_timed = 1;
+      }
+    }
+    // (every lead workgroup has waited for its row: when the last lead kernel ends, all T rows are in memory, and the
+    // kernel boundary makes them visible to ordinary loads — what a progress gate does in the chunk form)
+    for (size_t k = 0; k < rest.size() && !fail; ++k) {
+      const int i = rest[k];
+      for (int32_t t0 = 0; t0 < T && !fail; t0 += rest_piece) {
+        const int32_t tc = T - t0 < rest_piece ? T - t0 : rest_piece;
+        const bool timed = timing && i == q->timed_pop;
+        if (timed) (void)hipEventRecord(h->pairs[2 * n_timed], main_s);
+        fail = launch_pop_rows(env, pops, i, q->hist, B, t0, tc, dt, q->seed, q->step0, q->agent_id0, main_s);
+        if (timed) {
+          (void)hipEventRecord(h->pairs[2 * n_timed + 1], main_s);
+          ++n_timed;
+        }
+      }
+    }
+    if (!fail && timing) {
+      h->n_pairs = n_timed;
+      h->timed = n_timed > 0 ? 1 : 0;
     }
   } else {
     // (the first progress gate also waits until every trajectory workgroup of this launch is resident — it may have to

@@ -575,6 +575,52 @@ def test_native_multi_population_simulate_equals_chunked_pipeline(riab, B, sched
     assert len(ag.history["t"]) == schedule[0] + 1 and np.isfinite(pops[-1].firingrate).all()
 
 
+def test_population_major_form_equals_chunked_pipeline(riab):
+    """Several populations whose store-bound members write enough per row to keep pace with the trajectory kernel:
+    those run first, one kernel each over the whole run (following the trajectory through its progress words), the
+    others afterwards over all rows (riab_simulate, RIAB_FORM_POPULATIONS).  Same rows, bit for bit, as the chunk form
+    (RIAB_NO_FUSED=1) and as the Python-driven pipeline; a room with many walls (a slower trajectory kernel) keeps the
+    chunks."""
+    def world(walls=()):
+        np.random.seed(21)
+        env = riab.Environment({"walls": list(walls)})
+        ag = riab.Agent(env, {"n_agents": 1024, "dt": 0.02, "seed": 8})
+        np.random.seed(22)
+        pcs = riab.PlaceCells(ag, {"n": 2400, "save_spikes": False})                       # lead: 9.8 MB per row
+        bvc = riab.BoundaryVectorCells(ag, {"n": 8, "save_spikes": True})                  # rest
+        hdc = riab.HeadDirectionCells(ag, {"n": 16, "save_spikes": True})                  # lead, listed after a rest one
+        gcn = riab.GridCells(ag, {"n": 12, "noise_std": 0.1, "save_spikes": True})         # rest (OU noise)
+        ffl = riab.FeedForwardLayer(ag, {"n": 5, "input_layers": [hdc, bvc, gcn], "save_spikes": False,
+                                         "activation_function": {"activation": "tanh", "gain": 1.0, "threshold": 0.0}})
+        return ag, [pcs, bvc, hdc, gcn, ffl]
+
+    got = {}
+    for mode, envs in (("populations", {}), ("chunks", {"RIAB_NO_FUSED": "1"}), ("python", {"RIAB_NO_NATIVE": "1"})):
+        os.environ.update(envs)
+        try:
+            ag, pops = world()
+            for n in (70, 1100):     # (the second run is longer than a rest population's 1024-row launches)
+                ag.simulate(n)
+            torch.cuda.synchronize()
+            if mode != "python":
+                assert ag.last_rate_stage_form() == mode and ag.diagnostics["pipeline_timeouts"] == 0
+            got[mode] = [ag.get_history_tensor().cpu(), ag.state_tensor.cpu()] + \
+                        [t.cpu() for N in pops for t in N.get_history_tensors() if t is not None]
+        finally:
+            for k in envs:
+                os.environ.pop(k, None)
+    for other in ("chunks", "python"):
+        assert len(got[other]) == len(got["populations"])
+        for x, y in zip(got["populations"], got[other]):
+            assert torch.equal(x, y), other
+    # nine walls: the trajectory kernel's step outlasts the lead populations' stores of a row
+    maze = [[[.2, 0], [.2, .4]], [[.4, 1], [.4, .6]], [[.6, 0], [.6, .4]], [[.8, 1], [.8, .6]], [[.3, .5], [.7, .5]]]
+    ag, pops = world(maze)
+    ag.simulate(40)
+    torch.cuda.synchronize()
+    assert ag.last_rate_stage_form() == "chunks" and ag.diagnostics["pipeline_timeouts"] == 0
+
+
 # ----------------------------------------------------------------------------- imported trajectories through plans
 def _replay_world(riab, B=8):
     np.random.seed(2)
