@@ -373,7 +373,10 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
                 traffic_from = (f"profiles/pmc_traffic.json[{pmc_kernel}]: {entry['hbm_bytes_per_unit']:.1f} B per agent-step "
                                 f"(rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, {entry['source'].split(': ')[-1]}) x units "
                                 "of this run's launches; counters are not collected inside bench.py")
-        kname = (("rate_kernel_gated" if one_kernel else "rate stage = rate_kernel_wide per chunk behind progress gates")
+        kname = (("rate_kernel_gated" if one_kernel else
+                  ("rate stage = rate_kernel_gated (256 rows) + rate_kernel_wide (512 rows per launch behind progress gates)"
+                   if ag.last_rate_stage_form() == "head+pieces" else
+                   "rate stage = rate_kernel_wide per chunk behind progress gates"))
                  if fused_mode else "rate_kernel_wide") + f"<{type(dominant).__name__}>"
         if native_mode:
             kname = f"every launch of {type(dominant).__name__}'s kernel in one riab_simulate call (chunks of rows behind gates)"

@@ -559,18 +559,20 @@ double riab_plan_task_clock(const RiabPlan* plan);
  * word; the firing-rate stage runs concurrently and consumes the rows as they appear.  Results are bit-identical to
  * T calls of riab_agent_step(T = 1) each followed by the populations' own entry points.
  *
- * Two forms of the rate stage, chosen by the call:
- *  - ONE population of kind RIAB_POP_PLACE (not one_hot) / RIAB_POP_GRID / RIAB_POP_HDC without OU noise, B a
- *    multiple of 256 and T <= POLL_MAX (65535): one rate kernel for all T rows whose waves each wait until the 256
- *    agents of the wave have been stepped past their row;
- *  - several populations of which those of the first kind write enough per time row between them to keep pace with
- *    the trajectory kernel (their bytes at 6.5 TB/s against 1.35 us per step + 0.375 us per wall beyond four): those
- *    first, each as one such kernel over all T rows; then the others (boundary / object vector cells, random spatial neurons,
- *    speed cell, FeedForwardLayers — input_index refers to EARLIER entries of `pops` —, populations with OU noise) as
- *    their ordinary kernels over the whole run, in array order;
- *  - anything else (a single population of the second kind, runs of more than POLL_MAX rows, ...): per chunk of rows
- *    (16, 28, 44, ... 128) a one-wave gate that waits for the chunk's last row, then each population's ordinary
- *    kernel in array order (noise pass and spikes after it, as in riab_plan_step).
+ * Forms of the rate stage, chosen by the call (riab_streamer_last_form):
+ *  - a "lead" population — kind RIAB_POP_PLACE (not one_hot) / RIAB_POP_GRID / RIAB_POP_HDC without OU noise, B a
+ *    multiple of 256, T <= POLL_MAX — is served by ONE kernel for all its rows whose waves each wait until the 256 agents
+ *    of the wave have been stepped past their row (runs of more than 2048 rows: the first HEAD_ROWS rows; the others by
+ *    the population's ordinary kernel, 512 rows per launch behind a progress gate);
+ *      - a single population: that is the whole stage (RIAB_FORM_ONE_KERNEL / RIAB_FORM_HEAD_AND_PIECES);
+ *      - several populations: the largest such population leads if its stores of a row keep pace with the trajectory
+ *        kernel (its bytes at 6.5 TB/s against 1.35 us per step + 0.375 us per wall beyond four); the others
+ *        (boundary / object vector cells, random spatial neurons, speed cell, FeedForwardLayers — input_index refers
+ *        to EARLIER entries of `pops` —, populations with OU noise, further store-bound ones) follow as their ordinary
+ *        kernels over the whole run, in array order (RIAB_FORM_POPULATIONS);
+ *  - anything else (no lead, runs of more than POLL_MAX rows): per chunk of rows (16, 28, 44, ... 128) a one-wave gate
+ *    that waits for the chunk's last row, then each population's ordinary kernel in array order (noise pass and spikes
+ *    after it, as in riab_plan_step) (RIAB_FORM_CHUNKS).
  * n_pops == 0 (an agent without populations): the trajectory kernel alone, on `stream`.
  * forced_pos != NULL (Agent.import_trajectory / forced_next_position, Agent.py:229-266): there is no recurrence to
  * overlap: the forced-position kernel and the populations' kernels follow each other on `stream`.
@@ -644,9 +646,10 @@ typedef struct RiabStreamer RiabStreamer;
 RiabStreamer* riab_streamer_create(void);
 void riab_streamer_destroy(RiabStreamer* h);
 /* options of a streamer: GATE (RIAB_GATE_ALWAYS, the default, or RIAB_GATE_WHEN_BUSY: see "Residency"); POLL_MAX
- * (default 65535, the most the one-kernel form's grid holds; 0: never): longer runs take the chunk form of the rate
- * stage */
-enum { RIAB_STREAMER_OPT_GATE = 0, RIAB_STREAMER_OPT_POLL_MAX = 1 };
+ * (default 65535, the most the row-following kernel's grid holds; 0: never): longer runs take the chunk form of the
+ * rate stage; HEAD_ROWS (default 256): runs of more than 2048 rows give only their first HEAD_ROWS rows to the
+ * row-following kernel and the rest to the population's ordinary kernel behind progress gates (65535: never) */
+enum { RIAB_STREAMER_OPT_GATE = 0, RIAB_STREAMER_OPT_POLL_MAX = 1, RIAB_STREAMER_OPT_HEAD_ROWS = 2 };
 enum { RIAB_GATE_ALWAYS = 0, RIAB_GATE_WHEN_BUSY = 1 };
 int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t value);
 int riab_simulate(RiabStreamer* h, const RiabSimulate* run, riab_stream_t stream);
@@ -654,7 +657,8 @@ int riab_simulate(RiabStreamer* h, const RiabSimulate* run, riab_stream_t stream
  * population's kernel(s) in ms; < 0 if unavailable */
 float riab_streamer_last_rate_ms(RiabStreamer* h);
 /* which form the rate stage of the last riab_simulate call through `h` took */
-enum { RIAB_FORM_NONE = 0, RIAB_FORM_ONE_KERNEL = 1, RIAB_FORM_CHUNKS = 2, RIAB_FORM_SERIAL = 3, RIAB_FORM_POPULATIONS = 4 };
+enum { RIAB_FORM_NONE = 0, RIAB_FORM_ONE_KERNEL = 1, RIAB_FORM_CHUNKS = 2, RIAB_FORM_SERIAL = 3, RIAB_FORM_POPULATIONS = 4,
+       RIAB_FORM_HEAD_AND_PIECES = 5 };
 int riab_streamer_last_form(RiabStreamer* h);
 
 /* A/B switches of the library (comparisons and tests; the defaults are what production runs): process-wide, read on

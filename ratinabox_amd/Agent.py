@@ -515,6 +515,9 @@ class Agent:
         elif _L.env("RIAB_POLL_MAX"):       # (... or the one-kernel form up to this many steps)
             _L.check(_L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_POLL_MAX, int(_L.env("RIAB_POLL_MAX"))),
                      "riab_streamer_configure")
+        if _L.env("RIAB_HEAD_ROWS"):        # (rows of a long run that the row-following kernel serves: 65535 = all)
+            _L.check(_L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_HEAD_ROWS, int(_L.env("RIAB_HEAD_ROWS"))),
+                     "riab_streamer_configure")
 
     # ---- the open-loop run as ONE native call (riab_simulate) -----------------------------------------------------------
     def _simulate_native(self, n_steps, dt, drift_velocity, ratio, neurons, noise=None, kwargs=None):
@@ -852,12 +855,13 @@ class Agent:
         return ms if ms >= 0 else None
 
     def last_rate_stage_form(self):
-        """Which form the rate stage of the last native simulate() took: "one-kernel", "populations" (one kernel per
-        store-bound population, then the others over the whole run), "chunks", "serial" (forced positions) or None
-        (riab_streamer_last_form)."""
+        """Which form the rate stage of the last native simulate() took: "one-kernel", "head+pieces" (a long run of one
+        population: the row-following kernel for the first rows, ordinary launches behind progress gates after them),
+        "populations" (a leading store-bound population like that, then the others over the whole run), "chunks",
+        "serial" (forced positions) or None (riab_streamer_last_form)."""
         if self._streamer is None:
             return None
-        return {1: "one-kernel", 2: "chunks", 3: "serial", 4: "populations"}.get(int(_L.lib.riab_streamer_last_form(self._streamer)))
+        return {1: "one-kernel", 2: "chunks", 3: "serial", 4: "populations", 5: "head+pieces"}.get(int(_L.lib.riab_streamer_last_form(self._streamer)))
 
     def __del__(self):
         try:

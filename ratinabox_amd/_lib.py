@@ -104,7 +104,7 @@ EALIGN = -2
 EFULL = -5
 EUNSUPPORTED = -4
 EPARTIAL = -6
-STREAMER_OPT_GATE, STREAMER_OPT_POLL_MAX = 0, 1
+STREAMER_OPT_GATE, STREAMER_OPT_POLL_MAX, STREAMER_OPT_HEAD_ROWS = 0, 1, 2
 GATE_ALWAYS, GATE_WHEN_BUSY = 0, 1
 CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_STAMPS, CTRL_PROGRESS = 0, 1, 2, 8, 32  # riab_hip.h RIAB_CTRL_*
 

@@ -64,6 +64,7 @@ struct RiabStreamer {
   int wall_khz;              // rate of the device's constant clock (s_memrealtime)
   int gate_mode;             // RIAB_STREAMER_OPT_GATE
   int poll_max;              // RIAB_STREAMER_OPT_POLL_MAX
+  int head_rows;             // RIAB_STREAMER_OPT_HEAD_ROWS
   int last_form;             // riab_streamer_last_form
 };
 
@@ -78,6 +79,7 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
   h->started_total = 0;
   h->gate_mode = RIAB_GATE_ALWAYS;
   h->poll_max = 65535;
+  h->head_rows = 256;
   h->last_form = RIAB_FORM_NONE;
   int dev = 0, khz = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
@@ -101,6 +103,10 @@ extern "C" int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t 
     case RIAB_STREAMER_OPT_POLL_MAX:
       if (value < 0 || value > 65535) return RIAB_EINVAL;
       h->poll_max = value;
+      return RIAB_OK;
+    case RIAB_STREAMER_OPT_HEAD_ROWS:
+      if (value < 1 || value > 65535) return RIAB_EINVAL;
+      h->head_rows = value;
       return RIAB_OK;
     default: return RIAB_EINVAL;
   }
@@ -293,55 +299,58 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   }
 
   // ---- which form of the rate stage; every argument check before the first launch ------------------------------------
-  const bool gated = n_pops == 1 && T <= h->poll_max && riab::stream_supported(env, &pops[0], B) == RIAB_OK;
-
   // ~0.3 us per poll: a generous second or two before a wait gives up (a healthy wait is tens of microseconds)
   const uint32_t spin_limit = 1u << 20;
   std::vector<int32_t> sched;
-  // Several populations: those the one-kernel form can serve ("lead": store-bound, no OU noise) run FIRST, each as one
-  // kernel over all T rows that follows the trajectory by itself; once they are done every row has been published, and
-  // the others ("rest": boundary / object vector cells, layers, noisy populations, ...) follow as ordinary kernels over
-  // the whole run, in list order (a layer's inputs are earlier entries, or lead).  Against chunks of rows behind gates:
-  // no gate and launch boundary per chunk, no short first chunks (bvc_kernel: 22 us per row in a 16-row chunk, 16.7 in a
-  // 104-row one [MI355X, cfg 3]), and the lead kernels' nontemporal stores.  Taken when the lead populations' stores
-  // per row (at 6.5 TB/s) take at least as long as a step of the trajectory kernel next to them (0.9 us in an open room,
-  // + 0.25 us per further wall, x 1.5 next to a kernel that saturates HBM [MI355X: cfg 2 / cfg 5 0.85-1.1 us per step,
-  // cfg 3's nine walls 2.05]); otherwise the lead kernels would sit waiting for rows while nothing else runs, and the
-  // chunk form keeps the trajectory hidden behind ALL the populations' work.  [MI355X, 1024 steps: cfg 5 158-161 ->
-  // 167-168 M agent-steps/s, bvc_kernel 38.4 -> 33.8 ms; cfg 3 (16.8 MB of GridCells per row against nine walls) would
-  // lose 3 % and keeps the chunks.]
-  std::vector<int> lead, rest;
-  bool pop_major = false;
-  if (!gated && n_pops > 1 && T <= h->poll_max) {
-    int64_t lead_bytes = 0;
-    for (int i = 0; i < n_pops; ++i) {
-      if (pops[i].kind != RIAB_POP_FF && riab::stream_supported(env, &pops[i], B) == RIAB_OK) {
-        lead.push_back(i);
-        lead_bytes += (int64_t)pops[i].n * B * (pops[i].spikes_base ? 5 : 4);
-      } else {
-        rest.push_back(i);
+  // `lead`: the population whose kernel follows the trajectory row by row (rate_kernel_gated: store-bound cells without
+  // OU noise, whole 256-agent groups).  Alone it is the one-kernel form.  With other populations beside it, it runs
+  // first — when it ends every row has been published — and the others follow as their ordinary kernels over the whole
+  // run, in list order (a layer's inputs are earlier entries, or the lead): no gate and launch boundary per chunk, no
+  // short first chunks (bvc_kernel: 22 us per row in a 16-row chunk, 16.7 in a 104-row one [MI355X, cfg 3]).  That
+  // needs the lead's stores of a row (at 6.5 TB/s) to take at least as long as a step of the trajectory kernel next to
+  // it (0.9 us in an open room, + 0.25 us per further wall, x 1.5 next to a kernel that saturates HBM [MI355X: cfg 2 /
+  // cfg 5 0.85-1.1 us per step, cfg 3's nine walls 2.05]); otherwise its waves would sit waiting for rows while nothing
+  // else runs, and the chunk form keeps the trajectory hidden behind ALL the populations' work.  [MI355X, 1024 steps:
+  // cfg 5 158-161 -> 167-168 M agent-steps/s, bvc_kernel 38.4 -> 33.8 ms; cfg 3 (16.8 MB of GridCells per row against
+  // nine walls) would lose 3 % and keeps the chunks.]
+  int lead = -1;
+  if (T <= h->poll_max) {
+    if (n_pops == 1) {
+      if (riab::stream_supported(env, &pops[0], B) == RIAB_OK) lead = 0;
+    } else {
+      int64_t best = 0;
+      for (int i = 0; i < n_pops; ++i) {
+        const int64_t bytes = (int64_t)pops[i].n * B * (pops[i].spikes_base ? 5 : 4);
+        if (pops[i].kind != RIAB_POP_FF && bytes > best && riab::stream_supported(env, &pops[i], B) == RIAB_OK) {
+          best = bytes;
+          lead = i;
+        }
       }
+      const double step_us = (0.9 + 0.25 * (env->n_walls > 4 ? env->n_walls - 4 : 0)) * 1.5;
+      if ((double)best / 6.5e6 < step_us) lead = -1;
     }
-    const double step_us = (0.9 + 0.25 * (env->n_walls > 4 ? env->n_walls - 4 : 0)) * 1.5;
-    pop_major = !lead.empty() && (double)lead_bytes / 6.5e6 >= step_us;
   }
-  h->last_form = gated ? RIAB_FORM_ONE_KERNEL : (pop_major ? RIAB_FORM_POPULATIONS : RIAB_FORM_CHUNKS);
-  const int32_t rest_piece = 1024;  // rows per launch of a rest population (their kernels' grids, the noise pass's loop)
-  if (gated) {
-    rc = riab::launch_rate_stream(env, &pops[0], q->hist, B, T, dt, q->seed, q->step0, q->agent_id0, q->ctrl, spin_limit, false,
-                                  main_s, nullptr, nullptr, /*dry_run=*/true);
+  // Very long runs (more than 2048 rows): the row-following kernel serves the first `head_rows` rows — by then the
+  // trajectory kernel (0.8-1.1 us per step) is far ahead of the rate stage (2.5 us per row at cfg 2) — and the rest of
+  // the lead's rows go through its ordinary kernel, `tail_piece` rows per launch behind a progress gate that the
+  // trajectory has long passed: no poll and no agent-scope position loads per workgroup.  [MI355X, cfg 2, all rows by
+  // the row-following kernel vs head + pieces: 1024 steps 1.38-1.40 vs 1.37 G agent-steps/s, 2048 level, 3072 1.39-1.41
+  // vs 1.45, 4096 1.34-1.38 vs 1.43-1.46, 8192 1.38-1.44 vs 1.49; cfg 4 at 1024 steps 0.37-0.39 vs 0.36 G.]
+  const int32_t tail_piece = 512;
+  const int32_t head = lead < 0 ? 0 : ((T <= 2048 || T <= h->head_rows) ? T : h->head_rows);
+  const bool pure = lead >= 0 && n_pops == 1 && head == T;  // exactly one kernel: device stamps / launch events time it
+  h->last_form = lead < 0 ? RIAB_FORM_CHUNKS
+                          : (n_pops > 1 ? RIAB_FORM_POPULATIONS : (pure ? RIAB_FORM_ONE_KERNEL : RIAB_FORM_HEAD_AND_PIECES));
+  const int32_t rest_piece = 1024;  // rows per launch of another population (their kernels' grids, the noise pass's loop)
+  if (lead >= 0) {
+    rc = riab::launch_rate_stream(env, &pops[lead], q->hist, B, head, dt, q->seed, q->step0, q->agent_id0, q->ctrl, spin_limit,
+                                  false, main_s, nullptr, nullptr, /*dry_run=*/true);
     if (rc) return rc;
-    if (q->timing_mode == RIAB_TIMING_EVENTS && timing && !h->t0) {
+    if (pure && q->timing_mode == RIAB_TIMING_EVENTS && timing && !h->t0) {
       if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess) return RIAB_EINVAL;
     }
-  } else if (pop_major) {
-    for (int i : lead) {
-      rc = riab::launch_rate_stream(env, &pops[i], q->hist, B, T, dt, q->seed, q->step0, q->agent_id0, q->ctrl, spin_limit, false,
-                                    main_s, nullptr, nullptr, /*dry_run=*/true);
-      if (rc) return rc;
-    }
-    if (timing) {
-      const size_t need = 2 * (size_t)((T + rest_piece - 1) / rest_piece);
+    if (timing && !pure) {
+      const size_t need = 2 * (size_t)(1 + (T + rest_piece - 1) / rest_piece);
       while (h->pairs.size() < need) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return RIAB_EINVAL;
@@ -376,42 +385,37 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   // From here on the state has advanced: a later failure still joins the two streams and is reported as RIAB_EPARTIAL
   // (the trajectory rows are complete, the rates of this call are not).
   int fail = RIAB_OK;
-  if (gated) {
+  if (lead >= 0) {
     // Both kernels must be resident at once or the rate waves spin for nothing: a one-wave gate in front of the rate
     // kernel returns only once every trajectory workgroup of THIS launch has announced itself — the rate waves can then
     // never occupy the slots the kernel they wait for still needs, whatever else runs on the device (another stream,
     // another process: two ranks sharing one GPU ran into the waits' time limit without it).  RIAB_GATE_WHEN_BUSY drops
     // it when the caller's stream was idle (callers that own the device).  The gate also resets the device time stamps.
-    const bool stamps = timing && q->timing_mode != RIAB_TIMING_EVENTS;
-    const bool gate = stamps || h->gate_mode == RIAB_GATE_ALWAYS || !idle;
+    const bool timed_lead = timing && q->timed_pop == lead;
+    const bool stamps = pure && timed_lead && q->timing_mode != RIAB_TIMING_EVENTS;
+    const bool events = pure && timed_lead && !stamps;
+    const bool gate = stamps || h->gate_mode == RIAB_GATE_ALWAYS || !idle || !pure;
     // (the started gate is one sleeping wave; it may have to sit out whatever runs in front of the trajectory kernel)
     if (gate) fail = riab::launch_stream_gate(q->ctrl, h->started_total, 0, 0, 1u << 24, true, stamps, main_s);
-    const bool events = timing && !stamps;
-    if (!fail)
-      fail = riab::launch_rate_stream(env, &pops[0], q->hist, B, T, dt, q->seed, q->step0, q->agent_id0, q->ctrl, spin_limit,
-                                      stamps, main_s, events ? h->t0 : nullptr, events ? h->t1 : nullptr, false);
-    if (!fail && timing) {
-      h->timed = stamps ? 2 : 1;
-      h->stamp_ctrl = q->ctrl;
-    }
-  } else if (pop_major) {
-    fail = riab::launch_stream_gate(q->ctrl, h->started_total, 0, 0, 1u << 24, true, false, main_s);
     int n_timed = 0;
-    for (size_t k = 0; k < lead.size() && !fail; ++k) {
-      const int i = lead[k];
-      const bool timed = timing && i == q->timed_pop;
-      if (timed) (void)hipEventRecord(h->pairs[0], main_s);
-      fail = riab::launch_rate_stream(env, &pops[i], q->hist, B, T, dt, q->seed, q->step0, q->agent_id0, q->ctrl, spin_limit,
-                                      false, main_s, nullptr, nullptr, false);
-      if (timed) {
-        (void)hipEventRecord(h->pairs[1], main_s);
-        n_timed = 1;
-      }
+    if (timed_lead && !pure) (void)hipEventRecord(h->pairs[0], main_s);
+    if (!fail)
+      fail = riab::launch_rate_stream(env, &pops[lead], q->hist, B, head, dt, q->seed, q->step0, q->agent_id0, q->ctrl,
+                                      spin_limit, stamps, main_s, events ? h->t0 : nullptr, events ? h->t1 : nullptr, false);
+    for (int32_t t0 = head; t0 < T && !fail; t0 += tail_piece) {
+      const int32_t tc = T - t0 < tail_piece ? T - t0 : tail_piece;
+      fail = riab::launch_stream_gate(q->ctrl, h->started_total, n_traj, (uint32_t)q->step0 + (uint32_t)(t0 + tc), 1u << 22,
+                                      false, false, main_s);
+      if (!fail) fail = launch_pop_rows(env, pops, lead, q->hist, B, t0, tc, dt, q->seed, q->step0, q->agent_id0, main_s);
     }
-    // (every lead workgroup has waited for its row: when the last lead kernel ends, all T rows are in memory, and the
-    // kernel boundary makes them visible to ordinary loads — what a progress gate does in the chunk form)
-    for (size_t k = 0; k < rest.size() && !fail; ++k) {
-      const int i = rest[k];
+    if (timed_lead && !pure) {
+      (void)hipEventRecord(h->pairs[1], main_s);
+      n_timed = 1;
+    }
+    // (every workgroup of the row-following kernel has waited for its row, the last gate of a tail for row T: when the
+    // lead's last kernel ends, all T rows are in memory, and the kernel boundary makes them visible to ordinary loads)
+    for (int i = 0; i < n_pops && !fail; ++i) {
+      if (i == lead) continue;
       for (int32_t t0 = 0; t0 < T && !fail; t0 += rest_piece) {
         const int32_t tc = T - t0 < rest_piece ? T - t0 : rest_piece;
         const bool timed = timing && i == q->timed_pop;
@@ -424,8 +428,13 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
       }
     }
     if (!fail && timing) {
-      h->n_pairs = n_timed;
-      h->timed = n_timed > 0 ? 1 : 0;
+      if (pure) {
+        h->timed = stamps ? 2 : 1;
+        h->stamp_ctrl = q->ctrl;
+      } else {
+        h->n_pairs = n_timed;
+        h->timed = n_timed > 0 ? 1 : 0;
+      }
     }
   } else {
     // (the first progress gate also waits until every trajectory workgroup of this launch is resident — it may have to

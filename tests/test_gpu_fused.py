@@ -391,7 +391,9 @@ def test_bench_contract_line_on_the_drivers_command(riab):
     out = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
     assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5 and out["repeats"] >= 3
     rf = out["roofline"]
-    assert rf is not None and rf["bound"] == "hbm" and rf["launches"] == out["repeats"]
+    # (the kernel's duration: HIP events in ten extra regions; the device-clock figure of the timed regions beside it)
+    assert rf is not None and rf["bound"] == "hbm" and rf["launches"] == 10 and rf["rate_stage_form"] == "one-kernel"
+    assert 0.0 < rf["avg_launch_ms_device_clock"] <= rf["avg_launch_ms"] * 1.05
     assert 0.0 < rf["frac"] <= 1.0 and rf["units_per_launch"] == 4096 * 20
     # the dominant kernel cannot take longer than the region it is timed in
     assert rf["avg_launch_ms"] <= out["timed_region_ms"]["max"]
@@ -619,6 +621,42 @@ def test_population_major_form_equals_chunked_pipeline(riab):
     ag.simulate(40)
     torch.cuda.synchronize()
     assert ag.last_rate_stage_form() == "chunks" and ag.diagnostics["pipeline_timeouts"] == 0
+
+
+def test_very_long_runs_head_and_pieces(riab):
+    """More than 2048 rows of one store-bound population: the row-following kernel serves the first 256 rows, the
+    population's ordinary kernel the rest (512 rows per launch behind progress gates).  Bit-equal to the row-following
+    kernel over all rows (RIAB_HEAD_ROWS=65535) and to the Python-driven pipeline; so is the same run with a second
+    population (at this batch size: the chunk form)."""
+    def world(two):
+        np.random.seed(31)
+        ag = riab.Agent(riab.Environment({}), {"n_agents": 256, "dt": 0.02, "seed": 9})
+        np.random.seed(32)
+        pops = [riab.PlaceCells(ag, {"n": 96, "save_spikes": True})]
+        if two:
+            pops.append(riab.BoundaryVectorCells(ag, {"n": 6, "save_spikes": False}))
+        return ag, pops
+
+    for two, form in ((False, "head+pieces"), (True, "chunks")):
+        got = {}
+        for mode, envs in (("default", {}), ("all rows", {"RIAB_HEAD_ROWS": "65535"}), ("python", {"RIAB_NO_NATIVE": "1"})):
+            os.environ.update(envs)
+            try:
+                ag, pops = world(two)
+                ag.simulate(2300)
+                torch.cuda.synchronize()
+                if mode == "default":
+                    assert ag.last_rate_stage_form() == form
+                if mode == "all rows" and not two:
+                    assert ag.last_rate_stage_form() == "one-kernel"
+                assert ag.diagnostics.get("pipeline_timeouts", 0) == 0
+                got[mode] = [ag.get_history_tensor().cpu()] + [t.cpu() for N in pops for t in N.get_history_tensors() if t is not None]
+            finally:
+                for k in envs:
+                    os.environ.pop(k, None)
+        for other in ("all rows", "python"):
+            for x, y in zip(got["default"], got[other]):
+                assert torch.equal(x, y), (two, other)
 
 
 # ----------------------------------------------------------------------------- imported trajectories through plans

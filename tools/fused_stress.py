@@ -13,7 +13,9 @@ def run(native, calls, K, B=4096, n=1024, two=False):
     env = riab.Environment()
     ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "seed": 5})
     pops = [riab.PlaceCells(ag, {"n": n, "save_spikes": False})]
-    if two:
+    if two == "bvc":     # a store-bound and an issue-bound population: the populations form of the rate stage
+        pops.append(riab.BoundaryVectorCells(ag, {"n": 16, "save_spikes": True}))
+    elif two:
         pops.append(riab.GridCells(ag, {"n": 256, "save_spikes": False}))
     sums = torch.zeros((calls, len(pops)), dtype=torch.float64, device="cuda")
     t0 = time.perf_counter()
@@ -31,14 +33,16 @@ def run(native, calls, K, B=4096, n=1024, two=False):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     d = ag.diagnostics
-    return sums.cpu().numpy(), ag.state_tensor.cpu().numpy(), d, el
+    return sums.cpu().numpy(), ag.state_tensor.cpu().numpy(), d, el, ag.last_rate_stage_form()
 
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-for K, two, c in ((20, False, calls), (64, False, calls // 4), (300, False, calls // 16), (20, True, calls // 4), (300, True, calls // 16)):
-    a, sa, da, ta = run(True, c, K, two=two)
-    b, sb, db, tb = run(False, c, K, two=two)
+for K, two, c in ((20, False, calls), (64, False, calls // 4), (300, False, calls // 16), (1100, False, calls // 64),
+                  (20, True, calls // 4), (300, True, calls // 16), (1100, True, calls // 64),
+                  (20, "bvc", calls // 8), (300, "bvc", calls // 32), (1100, "bvc", calls // 128)):
+    a, sa, da, ta, form = run(True, c, K, two=two)
+    b, sb, db, tb, _ = run(False, c, K, two=two)
     ok = np.array_equal(a, b) and np.array_equal(sa, sb)
-    print("K=%-4d populations=%d calls=%-5d identical=%s timeouts=%s  (%.1f s native, %.1f s chunked)" % (
-        K, 2 if two else 1, c, ok, da.get("pipeline_timeouts"), ta, tb), flush=True)
+    print("K=%-4d populations=%s calls=%-5d form=%-11s identical=%s timeouts=%s  (%.1f s native, %.1f s chunked)" % (
+        K, {False: "place", True: "place+grid", "bvc": "place+bvc"}[two], c, form, ok, da.get("pipeline_timeouts"), ta, tb), flush=True)
     assert ok and da.get("pipeline_timeouts", 0) == 0
 print("OK")
