@@ -129,6 +129,42 @@ def test_fused_rates_match_oracle_on_its_own_rows(riab):
         np.testing.assert_allclose(fr[t], ref, rtol=1e-5, atol=1e-37)
 
 
+def test_cfg2_full_length_run_in_every_form(riab):
+    """BASELINE configs[1] at its full size and length — 4096 agents x 1024 PlaceCells, 1000 steps after 100 — through
+    the row-following kernel, the chunk form (RIAB_NO_FUSED=1) and the Python-driven pipeline (RIAB_NO_NATIVE=1): the
+    trajectories are identical and so is every time row's checksum of rates (float64 sum and sum of squares per row,
+    reduced on the device: 18 GB of rates per run are not downloaded); the last row against the oracle."""
+    sums = {}
+    for mode, envs in (("one-kernel", {}), ("chunks", {"RIAB_NO_FUSED": "1"}), ("python", {"RIAB_NO_NATIVE": "1"})):
+        os.environ.update(envs)
+        try:
+            env, ag, pcs = _world(riab, 4096, _pc(1024, save_spikes=False))
+            ag.simulate(100)
+            ag.simulate(1000)
+            torch.cuda.synchronize()
+            if mode != "python":
+                assert ag.last_rate_stage_form() == mode and ag.diagnostics["pipeline_timeouts"] == 0
+            fr = pcs.get_history_tensors()[0]
+            assert fr.shape == (1100, 1024, 4096)
+            f64 = [fr[i:i + 50].to(torch.float64) for i in range(0, 1100, 50)]
+            sums[mode] = (ag.get_history_tensor().cpu(), torch.cat([x.sum((1, 2)) for x in f64]).cpu(),
+                          torch.cat([(x * x).sum((1, 2)) for x in f64]).cpu())
+            if mode == "one-kernel":
+                row = ag.get_history_tensor()[-1].cpu().numpy()
+                sel = np.arange(0, 4096, 129)
+                pos = np.stack((row[0, sel], row[1, sel]), -1).astype(np.float64)
+                ref = orc.place_cells(orc.EnvSpec(walls=np.zeros((0, 2, 2))), pos, pcs.place_cell_centres, pcs.place_cell_widths)
+                np.testing.assert_allclose(fr[-1][:, sel].cpu().numpy(), ref, rtol=1e-5, atol=1e-37)
+            del fr, f64, ag, pcs
+            torch.cuda.empty_cache()
+        finally:
+            for k in envs:
+                os.environ.pop(k, None)
+    for other in ("chunks", "python"):
+        for x, y in zip(sums["one-kernel"], sums[other]):
+            assert torch.equal(x, y), other
+
+
 def test_fused_many_calls_and_long_run(riab):
     """Progress words are absolute step counts and are never reset: many back-to-back calls (no synchronisation
     in between), then one long call, all equal to the chunked path."""
