@@ -690,26 +690,35 @@ class VectorCells(Neurons):
         self.params.update(params)
         super().__init__(Agent, self.params)
         arr = self.cell_arrangement
-        if callable(arr):
-            mu_d, mu_t, sg_d, sg_t = arr(**self.params)
-        elif arr is None or arr[:6] == "random":
-            mu_d, mu_t, sg_d, sg_t = utils.create_random_assembly(**self.params)
-        elif arr == "uniform_manifold":
-            mu_d, mu_t, sg_d, sg_t = utils.create_uniform_radial_assembly(**self.params)
-        elif arr == "diverging_manifold":
-            mu_d, mu_t, sg_d, sg_t = utils.create_diverging_radial_assembly(**self.params)
-        else:
-            raise ValueError("cell_arrangement must be 'random', 'uniform_manifold', 'diverging_manifold' or a function")
-        self.tuning_distances, self.tuning_angles = np.array(mu_d), np.array(mu_t)
-        self.sigma_distances, self.sigma_angles = np.array(sg_d), np.array(sg_t)
-        assert len(self.tuning_distances) == len(self.tuning_angles) == len(self.sigma_distances) == len(
-            self.sigma_angles), "All manifold tuning parameters must be of the same length"
+        (self.tuning_distances, self.tuning_angles, self.sigma_distances,
+         self.sigma_angles) = self.set_tuning_parameters(**self.params)
         manifold = isinstance(arr, str) and arr.endswith("manifold")
         if getattr(self, "_warn_if_n_changes", False) and (manifold or self.n != len(self.tuning_distances)):
             warnings.warn(f"Ignoring 'n' parameter value ({params['n']}) that was passed, and setting number of "
                           f"{self.name} neurons to {len(self.tuning_distances)}, inferred from the cell arrangement.")
         self.n = len(self.tuning_distances)
         self._alloc_state()
+
+
+    def set_tuning_parameters(self, **kwargs):
+        """The cells' tuning (reference VectorCells.set_tuning_parameters, Neurons.py:1388-1437): four arrays of equal
+        length — tuning distances, tuning angles (rad), distance sigmas, angle sigmas — from `cell_arrangement`:
+        "random…" / None (`utils.create_random_assembly`), "uniform_manifold", "diverging_manifold", or a function of
+        the keyword arguments returning the four lists.  Returns them; the constructor stores them."""
+        arr = self.cell_arrangement
+        if callable(arr):
+            tuning = arr(**kwargs)
+        elif arr is None or arr[:6] == "random":
+            tuning = utils.create_random_assembly(**kwargs)
+        elif arr == "uniform_manifold":
+            tuning = utils.create_uniform_radial_assembly(**kwargs)
+        elif arr == "diverging_manifold":
+            tuning = utils.create_diverging_radial_assembly(**kwargs)
+        else:
+            raise ValueError("cell_arrangement must be 'random', 'uniform_manifold', 'diverging_manifold' or a function")
+        mu_d, mu_t, sg_d, sg_t = (np.array(v) for v in tuning)
+        assert len(mu_d) == len(mu_t) == len(sg_d) == len(sg_t), "All manifold tuning parameters must be of the same length"
+        return mu_d, mu_t, sg_d, sg_t
 
 
 class BoundaryVectorCells(VectorCells):
@@ -747,6 +756,19 @@ class BoundaryVectorCells(VectorCells):
         self.test_directions[0] = np.array([1.0, 0.0])
         kappa = 1 / np.asarray(self.sigma_angles, dtype=float).reshape(-1, 1) ** 2
         self.cell_fr_norm = np.exp(kappa * (np.cos(self.test_angles.reshape(1, -1)) - 1)).sum(axis=1)
+
+    def boundary_vector_preference_function(self, x):
+        """Preference of a ray for each wall from the pair of line parameters `x[..., :] = (l_a, l_b)` that
+        `utils.vector_intercepts(rays, walls)` gives: `1 / l_a` (nearer is better) when the crossing lies ahead of the
+        ray's origin and on the wall, -1 when it lies behind (`l_a < 0`) or off the wall (`l_b < 0` or `l_b > 1`)
+        (reference BoundaryVectorCells.boundary_vector_preference_function, Neurons.py:1746-1778; the device form of
+        this selection is stage A of csrc/riab_bvc.hip).  Host side, for user code; not on the accelerated path."""
+        x = np.asarray(x, dtype=float)
+        assert x.shape[-1] == 2
+        la, lb = x[..., 0], x[..., 1]
+        with np.errstate(divide="ignore"):
+            pref = np.where(la > 0, 1 / la, np.where(la < 0, -1.0, 0.0))
+        return np.where((lb < 0) | (lb > 1), -1.0, pref)
 
     def _call(self, io, stream):
         n, K = int(self.n), int(self.n_test_angles)

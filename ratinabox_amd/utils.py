@@ -72,10 +72,16 @@ def rotate(vector, theta):
     return np.matmul(np.array([[c, -s], [s, c]]), vector)
 
 
-def get_angle(vec):
+def get_angle(vec, is_array=False):
     """Angle of direction vectors `(..., 2)`, anticlockwise from the x-axis, in
-    [0, 2pi): `mod(arctan2(y, x + 1e-6), 2pi)` (the 1e-6 is the reference's)."""
+    [0, 2pi): `mod(arctan2(y, x + 1e-6), 2pi)` (the 1e-6 is the reference's).
+    A segment `(2, 2)` = [start, end] counts as its direction; `is_array=True` says the
+    first axis is a list (of vectors `(N, 2)` or segments `(N, 2, 2)`), which only matters
+    for telling two vectors from one segment (reference utils.get_angle, utils.py:231-273)."""
     vec = np.asarray(vec, dtype=float)
+    one = vec[0] if is_array else vec
+    if one.shape == (2, 2):
+        vec = vec[..., 1, :] - vec[..., 0, :]
     return np.mod(np.arctan2(vec[..., 1], vec[..., 0] + 1e-6), 2 * np.pi)
 
 
@@ -241,3 +247,177 @@ def polygon_contains(corners, point):
     with np.errstate(divide="ignore", invalid="ignore"):
         x_cross = ax + (py - ay) * (bx - ax) / (by - ay)
     return bool(np.count_nonzero(straddle & (px < x_cross)) % 2)
+
+
+# --------------------------------------------------------------------------- #
+# the reference's public geometry / statistics helpers, for user code that calls them
+# --------------------------------------------------------------------------- #
+# NumPy, host side, for scripts written against `ratinabox.utils`.  None of them is on the accelerated path: the kernels
+# (csrc/) carry their own arithmetic and nothing in Agent / Neurons / Environment calls these.  Deterministic: the
+# reference perturbs the inputs of `vector_intercepts` / `shortest_vectors_from_points_to_lines` by N(0, 1e-9 / 1e-6)
+# to dodge exact degeneracies (utils.py:62-67, 150-151); these do not.
+def get_perpendicular(a=None):
+    """`[x, y] -> [-y, x]` (reference utils.get_perpendicular, utils.py:17-27)."""
+    a = np.asarray(a, dtype=float)
+    return np.stack((-a[..., 1], a[..., 0]), axis=-1)
+
+
+def _cross2(u, v):
+    return u[..., 0] * v[..., 1] - u[..., 1] * v[..., 0]
+
+
+def vector_intercepts(vector_list_a, vector_list_b, return_collisions=False):
+    """Where the LINES through two lists of segments `(N_a, 2, 2)`, `(N_b, 2, 2)` meet, as the pair of line parameters
+    `(l_a, l_b)` of every (a, b): shape `(N_a, N_b, 2)`; the segments themselves cross iff both lie strictly in (0, 1).
+    `return_collisions=True`: that boolean `(N_a, N_b)` instead; `"as_well"`: both (reference utils.vector_intercepts,
+    utils.py:30-118).  With a = p0 + l_a sa, b = q0 + l_b sb and d0 = q0 - p0: l_a = (d0 x sb) / (sa x sb),
+    l_b = (d0 x sa) / (sa x sb); parallel segments give inf / nan as in the reference."""
+    a = np.asarray(vector_list_a, dtype=float)
+    b = np.asarray(vector_list_b, dtype=float)
+    assert a.shape[-2:] == (2, 2) and b.shape[-2:] == (2, 2), "vector_list_a and vector_list_b must be shape (_,2,2), _ is optional"
+    a, b = a.reshape(-1, 2, 2), b.reshape(-1, 2, 2)
+    sa = (a[:, 1] - a[:, 0])[:, None, :]
+    sb = (b[:, 1] - b[:, 0])[None, :, :]
+    d0 = b[None, :, 0, :] - a[:, None, 0, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        den = _cross2(sa, sb)
+        intercepts = np.stack((_cross2(d0, sb) / den, _cross2(d0, sa) / den), axis=-1)
+    hit = ((intercepts > 0) & (intercepts < 1)).all(-1)
+    if return_collisions is True:
+        return hit
+    if return_collisions == "as_well":
+        return intercepts, hit
+    return intercepts
+
+
+def shortest_vectors_from_points_to_lines(positions, vectors):
+    """For positions `(N_p, 2)` and segments `(N_v, 2, 2)`: the shortest vector FROM each segment TO each position,
+    `(N_p, N_v, 2)` — the foot of the perpendicular clamped to the segment's ends (reference utils.py:121-184)."""
+    p = np.asarray(positions, dtype=float).reshape(-1, 2)
+    v = np.asarray(vectors, dtype=float).reshape(-1, 2, 2)
+    s = v[:, 1] - v[:, 0]
+    d = p[:, None, :] - v[None, :, 0, :]
+    lam = np.clip((d * s).sum(-1) / (s * s).sum(-1), 0.0, 1.0)
+    return d - lam[..., None] * s
+
+
+def get_line_segments_between(pos1, pos2):
+    """Pairwise segments `[pos1[i], pos2[j]]`: `(N, M, 2, D)` (reference utils.py:187-200)."""
+    pos1, pos2 = np.asarray(pos1, dtype=float), np.asarray(pos2, dtype=float)
+    a = pos1.reshape(-1, 1, pos1.shape[-1])
+    b = pos2.reshape(1, -1, pos2.shape[-1])
+    a, b = np.broadcast_arrays(a, b)
+    return np.stack((a, b), axis=-2)
+
+
+def get_vectors_between(pos1=None, pos2=None, line_segments=None):
+    """Pairwise `pos1[i] - pos2[j]`, `(N, M, D)` (reference utils.py:203-214: FROM pos2 TO pos1)."""
+    if line_segments is None:
+        line_segments = get_line_segments_between(pos1, pos2)
+    line_segments = np.asarray(line_segments, dtype=float)
+    return line_segments[..., 0, :] - line_segments[..., 1, :]
+
+
+def get_distances_between(pos1=None, pos2=None, vectors=None):
+    """Pairwise Euclidean distances `(N, M)` (reference utils.py:217-228)."""
+    if vectors is None:
+        vectors = get_vectors_between(pos1, pos2)
+    return np.linalg.norm(np.asarray(vectors, dtype=float), axis=-1)
+
+
+def get_bearing(segment, is_array=False):
+    """Bearing of a direction vector / segment: clockwise from North (+y), in [0, 2pi) = `mod(pi/2 - get_angle, 2pi)`
+    (reference utils.py:276-289)."""
+    return np.mod(np.pi / 2 - get_angle(segment, is_array=is_array), 2 * np.pi)
+
+
+def wall_bounce(current_velocity, wall):
+    """Velocity after reflecting off `wall` = [start, end]: the component along the wall is kept, the one across it
+    changes sign (reference utils.wall_bounce, utils.py:304-328)."""
+    v = np.asarray(current_velocity, dtype=float)
+    wall = np.asarray(wall, dtype=float)
+    along = wall[1] - wall[0]
+    along = along / np.linalg.norm(along)
+    across = get_perpendicular(along)
+    return along * np.dot(v, along) - across * np.dot(v, across)
+
+
+def pi_domain(x):
+    """Angles recast onto (-pi, pi] (reference utils.pi_domain, utils.py:331-341)."""
+    x = np.mod(np.asarray(x, dtype=float), 2 * np.pi)
+    return np.where(x > np.pi, x - 2 * np.pi, x)
+
+
+def ornstein_uhlenbeck(dt, x, drift=0.0, noise_scale=0.2, coherence_time=5.0):
+    """Increment `dx` of an Ornstein-Uhlenbeck process in `x` over `dt`: `(drift - x) dt / tau + sigma N(0, dt)` with
+    `sigma = sqrt(2 noise_scale^2 / (tau dt))`, one normal per element from the global NumPy stream (reference
+    utils.ornstein_uhlenbeck, utils.py:347-368; the motion kernel's form of it: csrc/riab_agent_kernel.h `ou_step`)."""
+    x = np.asarray(x, dtype=float)
+    tau = coherence_time * np.ones_like(x)
+    sigma = np.sqrt(2 * (noise_scale * np.ones_like(x)) ** 2 / (tau * dt))
+    return (drift * np.ones_like(x) - x) * dt / tau + sigma * np.random.normal(size=x.shape, scale=dt)
+
+
+def normal_to_rayleigh(x, sigma=1):
+    """N(0, 1) variate -> Rayleigh(sigma) variate through the two CDFs (reference utils.py:409-413)."""
+    from scipy import stats
+    return sigma * np.sqrt(-2 * np.log(1 - stats.norm.cdf(x)))
+
+
+def rayleigh_to_normal(x, sigma=1):
+    """Rayleigh(sigma) variate -> N(0, 1) variate; the uniform in between is clipped to [1e-6, 1 - 1e-6] (reference
+    utils.py:416-421, which takes scalars; arrays work here)."""
+    from scipy import stats
+    u = np.clip(1 - np.exp(-np.asarray(x, dtype=float) ** 2 / (2 * sigma ** 2)), 1e-6, 1 - 1e-6)
+    return stats.norm.ppf(u)
+
+
+def gaussian(x, mu, sigma, norm=None):
+    """`norm * exp(-(x - mu)^2 / 2 sigma^2)`; `norm` = the peak value, default the density's 1 / sqrt(2 pi sigma^2)
+    (reference utils.gaussian, utils.py:424-438: a `norm` of 0 or None selects the default)."""
+    peak = norm or 1 / np.sqrt(2 * np.pi * np.asarray(sigma, dtype=float) ** 2)
+    return peak * np.exp(-((x - mu) ** 2) / (2 * sigma ** 2))
+
+
+def von_mises(theta, mu, sigma, norm=None):
+    """`norm * exp(kappa (cos(theta - mu) - 1))`, `kappa = 1 / sigma^2`; `norm` = the value at the centre, default the
+    density's `exp(kappa) / (2 pi I0(kappa))` (reference utils.von_mises, utils.py:441-457)."""
+    kappa = 1 / np.asarray(sigma, dtype=float) ** 2
+    if not norm:
+        from scipy import special
+        norm = np.exp(kappa) / (2 * np.pi * special.i0(kappa))
+    return np.exp(kappa * np.cos(theta - mu)) * (norm / np.exp(kappa))
+
+
+_ACTIVATION_DEFAULTS = {"sigmoid": {"max_fr": 1, "min_fr": 0, "mid_x": 1, "width_x": 2}}
+
+
+def activate(x, activation="sigmoid", deriv=False, other_args={}):
+    """The reference's activation functions and their derivatives (utils.activate, utils.py:919-1026), NumPy:
+    "linear", "sigmoid" (max_fr, min_fr, mid_x, width_x = distance between the 5 % and 95 % points), "relu", "tanh",
+    "retanh", "softmax" (a softplus; gain, threshold each), or `other_args["function"](x, deriv=...)`;
+    `other_args["activation"]` overrides `activation`.  (FeedForwardLayer evaluates the same presets on the device:
+    csrc/riab_ff.hip.)  The derivatives of "tanh" / "retanh" ignore the threshold inside the tanh, as the
+    reference's do."""
+    if "function" in other_args:
+        return other_args["function"](x, deriv=deriv)
+    name = other_args.get("activation", activation)
+    assert name in ("linear", "sigmoid", "relu", "tanh", "retanh", "softmax")
+    x = np.asarray(x, dtype=float)
+    args = dict(_ACTIVATION_DEFAULTS.get(name, {"gain": 1, "threshold": 0}))
+    args.update(other_args)
+    if name == "linear":
+        return np.ones(x.shape) if deriv else x
+    if name == "sigmoid":
+        lo, hi = args["min_fr"], args["max_fr"]
+        beta = np.log(0.95 / 0.05) / (0.5 * args["width_x"])
+        f = (hi - lo) / (1 + np.exp(-beta * (x - args["mid_x"]))) + lo
+        return beta * (f - lo) * (1 - (f - lo) / (hi - lo)) if deriv else f
+    g, z = args["gain"], x - args["threshold"]
+    if name == "relu":
+        return g * (z > 0) if deriv else g * np.maximum(0, z)
+    if name == "tanh":
+        return g * (1 - np.tanh(x) ** 2) if deriv else g * np.tanh(z)
+    if name == "retanh":
+        return g * (1 - np.tanh(x) ** 2) * (z > 0) if deriv else g * np.maximum(0, np.tanh(z))
+    return g / (1 + np.exp(-z)) if deriv else g * np.log(1 + np.exp(z))

@@ -959,14 +959,72 @@ def make_stats():
     np.savez_compressed(os.path.join(HERE, "stats.npz"), **out)
 
 
+def make_helpers():
+    """The reference's public geometry / statistics helpers (ratinabox/utils.py) on seeded inputs: what
+    ratinabox_amd/utils.py offers under the same names (tests/test_host_logic.py::test_public_helpers_vs_reference).
+    The anti-degeneracy jitter of vector_intercepts / shortest_vectors_from_points_to_lines is patched to zero like
+    everywhere else in this file; ornstein_uhlenbeck's normals are recorded."""
+    _section("helpers")
+    rs = np.random.RandomState(77)
+    out = {}
+    a, b, p, q = rs.rand(7, 2, 2), rs.rand(5, 2, 2), rs.rand(9, 2), rs.rand(4, 2)
+    x, th = rs.randn(4, 5) * 6, rs.rand(3, 4) * 6
+    vs, segs = rs.randn(6, 2), rs.rand(6, 2, 2)
+    out.update(a=a, b=b, p=p, q=q, x=x, th=th, vs=vs, segs=segs)
+    out["vi"] = rutils.vector_intercepts(a, b)          # (np.random.normal is patched: jitter of scale 1e-9 / 1e-6 -> 0)
+    out["vi_hit"] = rutils.vector_intercepts(a, b, return_collisions=True)
+    out["sv"] = rutils.shortest_vectors_from_points_to_lines(p, b)
+    out["segs_pq"] = rutils.get_line_segments_between(p, q)
+    out["vec_pq"] = rutils.get_vectors_between(p, q)
+    out["dist_pq"] = rutils.get_distances_between(p, q)
+    out["angle_vs"] = rutils.get_angle(vs, is_array=True)
+    out["angle_segs"] = rutils.get_angle(segs, is_array=True)
+    out["bearing_vs"] = rutils.get_bearing(vs, is_array=True)
+    out["bearing_segs"] = rutils.get_bearing(segs, is_array=True)
+    out["perp_vs"] = np.stack([rutils.get_perpendicular(v) for v in vs])
+    out["bounce"] = np.stack([rutils.wall_bounce(v, w) for v, w in zip(vs, segs)])
+    out["pi_domain"] = rutils.pi_domain(x)
+    z = rs.normal(size=x.shape)
+    np.random.normal = lambda loc=0.0, scale=1.0, size=None: z * scale
+    try:
+        out["ou"] = rutils.ornstein_uhlenbeck(0.01, x, drift=0.5, noise_scale=0.3, coherence_time=0.7)
+    finally:
+        np.random.normal = _patched_normal
+    out["ou_z"] = z
+    out["n2r"] = rutils.normal_to_rayleigh(x / 3, 0.08)
+    speeds = np.array([0.0, 0.01, 0.05, 0.08, 0.3, 2.0])
+    out["speeds"] = speeds
+    out["r2n"] = np.array([rutils.rayleigh_to_normal(float(v), 0.08) for v in speeds])
+    for k, norm in (("d", None), ("1", 1), ("2p5", 2.5)):
+        out["gauss_" + k] = rutils.gaussian(th, 0.4, 0.3, norm)
+        out["vm_" + k] = rutils.von_mises(th, 0.4, 0.3, norm)
+    for name in ("linear", "sigmoid", "relu", "tanh", "retanh", "softmax"):
+        oa = {"max_fr": 3, "min_fr": 0.5, "mid_x": 0.2, "width_x": 1.5} if name == "sigmoid" else {"gain": 2.0, "threshold": 0.3}
+        for tag, args in (("dflt", {}), ("args", oa)):
+            for deriv in (False, True):
+                out[f"act_{name}_{tag}_{int(deriv)}"] = np.asarray(rutils.activate(x / 3, name, deriv, dict(args)), dtype=float)
+    # BoundaryVectorCells.boundary_vector_preference_function on (l_a, l_b) pairs, the exact zeros and ones included
+    lam = rs.randn(40, 7, 2) * 1.5
+    lam[0, 0], lam[0, 1], lam[0, 2], lam[0, 3] = [0.0, 0.5], [0.0, 2.0], [0.5, 0.0], [0.5, 1.0]
+    np.random.seed(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bv = BoundaryVectorCells(Agent(Environment()), params={"n": 3})
+        out["pref"] = bv.boundary_vector_preference_function(lam)
+    out["pref_lam"] = lam
+    np.savez_compressed(os.path.join(HERE, "helpers.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task", "polygon", "cfg1", "stats"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task", "polygon", "cfg1", "stats", "helpers"]
     if "--out" in which:  # write somewhere else (tools/check_golden.py regenerates into a temporary directory)
         HERE = which[which.index("--out") + 1]
         which = [w for i, w in enumerate(which) if w != "--out" and (i == 0 or which[i - 1] != "--out")] or \
             ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task",
-             "polygon", "cfg1", "stats"]
+             "polygon", "cfg1", "stats", "helpers"]
         os.makedirs(HERE, exist_ok=True)
+    if "helpers" in which:
+        make_helpers()
     if "polygon" in which:
         make_polygon()
     if "cfg1" in which:

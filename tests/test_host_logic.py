@@ -349,3 +349,56 @@ def test_polygon_environment_host_side(tag):
     env.add_hole([[0.3, 0.05], [0.34, 0.05], [0.32, 0.09]])
     assert env._wall_is_hole[-4:] == [False, True, True, True] and len(env._wall_is_hole) == len(env.walls)
     assert not env.check_if_position_is_in_environment([0.32, 0.06])
+
+
+def test_public_helpers_vs_reference():
+    """ratinabox_amd.utils carries the reference's public geometry / statistics helpers (utils.py: vector_intercepts,
+    shortest_vectors_from_points_to_lines, get_*_between, get_angle / get_bearing on vectors and segments, wall_bounce,
+    pi_domain, ornstein_uhlenbeck, the Rayleigh <-> normal maps, gaussian, von_mises, activate and its derivatives)
+    for user code written against `ratinabox.utils`: their outputs on the fixture's inputs (tests/golden/helpers.npz,
+    made by importing the reference: make_golden.py `helpers`)."""
+    from ratinabox_amd import utils as U
+    g = gu.load("helpers.npz")
+    a, b, p, q, x, th, vs, segs = (g[k] for k in ("a", "b", "p", "q", "x", "th", "vs", "segs"))
+    close = lambda got, key, **kw: np.testing.assert_allclose(got, g[key], **dict(dict(rtol=1e-12, atol=1e-14), **kw))  # noqa: E731
+    close(U.vector_intercepts(a, b), "vi")
+    assert np.array_equal(U.vector_intercepts(a, b, return_collisions=True), g["vi_hit"])
+    both = U.vector_intercepts(a, b, return_collisions="as_well")
+    close(both[0], "vi"), np.array_equal(both[1], g["vi_hit"])
+    close(U.shortest_vectors_from_points_to_lines(p, b), "sv")
+    assert np.array_equal(U.get_line_segments_between(p, q), g["segs_pq"])
+    assert np.array_equal(U.get_vectors_between(p, q), g["vec_pq"]) and np.array_equal(U.get_distances_between(p, q), g["dist_pq"])
+    close(U.get_angle(vs, is_array=True), "angle_vs"), close(U.get_angle(segs, is_array=True), "angle_segs")
+    close(U.get_bearing(vs, is_array=True), "bearing_vs"), close(U.get_bearing(segs, is_array=True), "bearing_segs")
+    assert np.isclose(U.get_angle(segs[0]), g["angle_segs"][0]) and np.isclose(U.get_bearing(vs[2]), g["bearing_vs"][2])
+    close(U.get_perpendicular(vs), "perp_vs")
+    close(np.stack([U.wall_bounce(v, w) for v, w in zip(vs, segs)]), "bounce")
+    close(U.pi_domain(x), "pi_domain")
+    z = g["ou_z"]
+    saved, np.random.normal = np.random.normal, (lambda loc=0.0, scale=1.0, size=None: z * scale)
+    try:
+        close(U.ornstein_uhlenbeck(0.01, x, drift=0.5, noise_scale=0.3, coherence_time=0.7), "ou")
+    finally:
+        np.random.normal = saved
+    close(U.normal_to_rayleigh(x / 3, 0.08), "n2r")
+    close(U.rayleigh_to_normal(g["speeds"], 0.08), "r2n")
+    for k, norm in (("d", None), ("1", 1), ("2p5", 2.5)):
+        close(U.gaussian(th, 0.4, 0.3, norm), "gauss_" + k), close(U.von_mises(th, 0.4, 0.3, norm), "vm_" + k)
+    for name in ("linear", "sigmoid", "relu", "tanh", "retanh", "softmax"):
+        oa = {"max_fr": 3, "min_fr": 0.5, "mid_x": 0.2, "width_x": 1.5} if name == "sigmoid" else {"gain": 2.0, "threshold": 0.3}
+        for tag, args in (("dflt", {}), ("args", oa)):
+            for deriv in (False, True):
+                close(U.activate(x / 3, name, deriv, dict(args)), f"act_{name}_{tag}_{int(deriv)}")
+    assert U.activate(x, other_args={"function": lambda x, deriv: 7}) == 7
+    close(U.activate(x / 3, "relu", False, {"activation": "tanh"}), "act_tanh_dflt_0")
+    # two public methods of the vector cells (host side): the ray -> wall preference and the tuning tables
+    assert np.array_equal(riab.BoundaryVectorCells.boundary_vector_preference_function(None, g["pref_lam"]), g["pref"])
+    np.random.seed(1)
+    bv = riab.BoundaryVectorCells(riab.Agent(riab.Environment(), CPU), {"n": 5})
+    four = bv.set_tuning_parameters(**bv.params)
+    assert len(four) == 4 and all(isinstance(v, np.ndarray) and len(v) == 5 for v in four)
+    bv.cell_arrangement = lambda **kw: ([0.1, 0.2], [0.0, 1.0], [0.05, 0.06], [0.2, 0.3])
+    assert [list(v) for v in bv.set_tuning_parameters()] == [[0.1, 0.2], [0.0, 1.0], [0.05, 0.06], [0.2, 0.3]]
+    bv.cell_arrangement = "hexagonal"
+    with pytest.raises(ValueError):
+        bv.set_tuning_parameters()
