@@ -51,11 +51,15 @@ int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* 
 // The publishing variant of the trajectory kernel (riab_simulate_*): float64, four waves per 64 agents
 // (riab_traj4_kernel.h), Philox noise or explicit normals (a.z_in); a.ctrl carries the control words.  Whole waves
 // only (B % 64 == 0), any T.  RIAB_OPT_TRAJ_KERNEL = 2 (A/B comparisons): the two-wave kernel of round 1 (Philox only).
-int launch_agent_pub(const AgentArgs& a, hipStream_t s) {
+// `*state_published` (optional): true when the kernel launched makes its LAST publication after its state stores have
+// been written through and acknowledged (the four-wave kernel): a consumer that has waited for that publication needs
+// no other ordering against this launch.
+int launch_agent_pub(const AgentArgs& a, hipStream_t s, bool* state_published) {
   if (!a.ctrl || !a.hist || a.forced || a.B % 4 != 0) return RIAB_EINVAL;
   const dim3 grid((unsigned)((a.B + 63) / 64));
-  const bool two_wave = g_options[RIAB_OPT_TRAJ_KERNEL] == 2;
-  if (two_wave && !a.z_in && !a.z_out && a.B % 64 == 0) hipLaunchKernelGGL((agent_step_kernel<double, 0, true, true>), grid, dim3(128), 0, s, a);
+  const bool two_wave = g_options[RIAB_OPT_TRAJ_KERNEL] == 2 && !a.z_in && !a.z_out && a.B % 64 == 0;
+  if (state_published) *state_published = !two_wave;
+  if (two_wave) hipLaunchKernelGGL((agent_step_kernel<double, 0, true, true>), grid, dim3(128), 0, s, a);
   else if (a.z_in) hipLaunchKernelGGL((traj4_kernel<1, true>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((traj4_kernel<0, true>), grid, dim3(256), 0, s, a);
   return (int)hipGetLastError();

@@ -41,7 +41,7 @@
 #include "riab_agent_kernel.h"
 
 namespace riab {
-int launch_agent_pub(const AgentArgs& a, hipStream_t s);
+int launch_agent_pub(const AgentArgs& a, hipStream_t s, bool* state_published);
 int launch_agent_forced(const AgentArgs& a, hipStream_t s);
 int launch_agent_plain(const AgentArgs& a, hipStream_t s);
 int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
@@ -378,7 +378,8 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
     if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->fork, 0);
     if (e != hipSuccess) return (int)e;
   }
-  rc = riab::launch_agent_pub(a, h->side);
+  bool state_published = false;
+  rc = riab::launch_agent_pub(a, h->side, &state_published);
   if (rc) return rc;
   const uint32_t n_traj = (uint32_t)((B + 63) / 64);
   h->started_total += n_traj;
@@ -457,9 +458,18 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
       h->timed = 1;
     }
   }
-  // the caller's stream continues after the trajectory kernel as well (its state rows, its last history rows)
-  hipError_t e = hipEventRecord(h->join, h->side);
-  if (e == hipSuccess) e = hipStreamWaitEvent(main_s, h->join, 0);
+  // The caller's stream continues after the trajectory kernel as well (its state rows, its last history rows).  Every
+  // form above ends with a kernel on the caller's stream that has waited for the trajectory kernel's LAST publication,
+  // and the four-wave kernel makes that publication after its state stores have been written through (t4_store_state):
+  // the stream order of the caller's stream already carries the dependency.  An event between the streams is only
+  // needed for the two-wave kernel (RIAB_OPT_TRAJ_KERNEL = 2) — and after a failure, when nothing may have waited.
+  // [MI355X, cfg 2, 20 steps: the event's record + wait were 4.7 us of host time and its barrier packet sat between the
+  // rate kernel's end and the host's wake-up: 97 -> 89 us per call without them.]
+  hipError_t e = hipSuccess;
+  if (!state_published || fail) {
+    e = hipEventRecord(h->join, h->side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main_s, h->join, 0);
+  }
   if (fail) return RIAB_EPARTIAL;
   if (e != hipSuccess) return (int)e;
   return RIAB_OK;

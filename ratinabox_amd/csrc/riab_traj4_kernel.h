@@ -54,7 +54,7 @@ namespace riab {
 #define RIAB_T4_SENT 0x7FF8DEADBEEF0001ull  // a NaN payload no arithmetic produces: "slot empty"
 #define RIAB_T4_SPIN_LIMIT (1u << 24)       // ~70 ns per poll: about a second
 
-enum { T4_C_NOISE = 0, T4_C_GDONE = 1, T4_C_TDONE = 2, T4_C_WORDS = 3 };
+enum { T4_C_NOISE = 0, T4_C_GDONE = 1, T4_C_TDONE = 2, T4_C_STATE = 3, T4_C_WORDS = 4 };
 
 template <bool V>
 struct T4Tag {
@@ -108,6 +108,25 @@ __device__ __forceinline__ void t4_flush_hist(const AgentArgs& a, const float* s
       if (PUB) store_v4f_agent(gj + hist_glb_lane, v);
       else *reinterpret_cast<v4f*>(gj + hist_glb_lane) = v;
     }
+  }
+}
+
+// One element of the float64 state.  PUB: written through (agent scope), like the history rows: the launch's LAST
+// publication comes after these stores have been acknowledged, so whoever has waited for it — every form of the rate
+// stage does, on the caller's stream — finds the state in memory too, and riab_simulate needs no event between the two
+// streams (the event's record + wait cost 4.7 us of host time per call and its barrier packet, processed after the
+// rate kernel, 3-4 us of the 11 us between that kernel's end and the return of a host synchronisation [MI355X]).
+template <bool PUB>
+__device__ __forceinline__ void t4_store_state(double* p, double v) {
+  if (PUB) __hip_atomic_store((riab_gu64*)(uintptr_t)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+// (PUB) this wave's state stores and counters have been acknowledged: tell the tail wave
+template <bool PUB>
+__device__ __forceinline__ void t4_state_stored(uint32_t* s_cnt, int lane) {
+  if (PUB) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&s_cnt[T4_C_STATE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
 
@@ -249,17 +268,18 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
     if (open_room) steps(T4Tag<true>{});
     else steps(T4Tag<false>{});
     if (live) {
-      st[0 * B] = px;
-      st[1 * B] = py;
-      st[2 * B] = vx;
-      st[3 * B] = vy;
-      st[11 * B] = dwall;
+      t4_store_state<PUB>(st + 0 * B, px);
+      t4_store_state<PUB>(st + 1 * B, py);
+      t4_store_state<PUB>(st + 2 * B, vx);
+      t4_store_state<PUB>(st + 3 * B, vy);
+      t4_store_state<PUB>(st + 11 * B, dwall);
     }
     if (a.diag && live) {
       if (n_bounce) atomicAdd(a.diag + 0, n_bounce);
       if (n_sat) atomicAdd(a.diag + 1, n_sat);
       if (n_bc) atomicAdd(a.diag + 2, n_bc);
     }
+    t4_state_stored<PUB>(s_cnt, lane);
   } else if (wave == 1) {
     // ================================ wave S: the speed chain ======================================================
     const lds_cf64_ptr lds_g = (lds_cf64_ptr)s_g, lds_h = (lds_cf64_ptr)s_h;
@@ -356,7 +376,8 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
       asm volatile("" ::: "memory");
       cnt[T4_C_NOISE] = (uint32_t)(t + 1);
     }
-    if (live) st[4 * B] = rot;
+    if (live) t4_store_state<PUB>(st + 4 * B, rot);
+    t4_state_stored<PUB>(s_cnt, lane);
   } else {
     // ================================ wave T: output-only tail, history rows, publication ==========================
     const TailConst<R> tail_c = {(R)m.dt, (R)(1.0 / m.dt), (R)(1.0 - m.dt / m.hd_tau), (R)(m.dt / m.hd_tau),
@@ -426,7 +447,7 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
         __builtin_amdgcn_wave_barrier();
       }
       t0 += n;
-      if (PUB) {
+      if (PUB && t0 < T) {   // (the launch's last publication follows the state, below)
         if (early_pub) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           publish(t0);
@@ -435,18 +456,21 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
         }
       }
     }
-    if (PUB && ok) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      publish(T);
-    }
     if (live) {
-      st[5 * B] = (double)tl.mvx;
-      st[6 * B] = (double)tl.mvy;
-      st[7 * B] = (double)tl.mrot;
-      st[8 * B] = (double)tl.hx;
-      st[9 * B] = (double)tl.hy;
-      st[10 * B] = (double)tl.dist;
+      t4_store_state<PUB>(st + 5 * B, (double)tl.mvx);
+      t4_store_state<PUB>(st + 6 * B, (double)tl.mvy);
+      t4_store_state<PUB>(st + 7 * B, (double)tl.mrot);
+      t4_store_state<PUB>(st + 8 * B, (double)tl.hx);
+      t4_store_state<PUB>(st + 9 * B, (double)tl.hy);
+      t4_store_state<PUB>(st + 10 * B, (double)tl.dist);
       if (a.diag && tl.n_still) atomicAdd(a.diag + 3, tl.n_still);
+    }
+    if (PUB && ok) {
+      // every row, this wave's part of the state, and — once the position / velocity wave and the noise wave have
+      // reported theirs — the whole state of these 64 agents is in memory: the publication that ends the launch
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (t4_wait_counter(cnt, T4_C_STATE, 1u, true)) publish(T);
+      else gave_up = true;
     }
   }
   if (gave_up && lane == 0) {
