@@ -28,6 +28,10 @@ Rank 0 prints ONE JSON line: the contract fields plus
 import argparse
 import json
 import os
+
+# (before anything initialises the HIP runtime: see ratinabox_amd/__init__.py — under torch.distributed.run the process
+# also holds an RCCL communicator, and with the default 4 hardware queues the two streams of simulate() shared one)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import subprocess
 import sys
 import time

@@ -82,7 +82,15 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
   h->head_rows = 256;
   h->last_form = RIAB_FORM_NONE;
   int dev = 0, khz = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+  // The trajectory kernel's stream has the device's HIGHEST priority.  Not for the arbitration — for the hardware queue:
+  // the runtime maps streams of one priority onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and in a
+  // process that also holds an RCCL communicator the second stream ended up on the SAME queue as the caller's stream —
+  // the two kernels that are meant to run side by side then ran one after the other (cfg 2 under torch.distributed.run
+  // with the nccl backend: 256 steps 1.04 instead of 0.78 ms, 20 steps 132 instead of 92 us [MI355X]).  Streams of
+  // another priority have queues of their own.
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (hipGetDevice(&dev) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, greatest) != hipSuccess ||
       hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) != hipSuccess) {
     riab_streamer_destroy(h);
