@@ -81,16 +81,19 @@ def test_bench_as_a_rank_of_torch_distributed_run_with_the_rccl_control_plane():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RIAB_BENCH_SHARE_GPU"):
         env.pop(k, None)
-    args = ["--gpus", "1", "--steps", "256", "--warmup", "32", "--no-cpu-baseline", "--no-secondary"]
-    plain, _ = _line([sys.executable, os.path.join(ROOT, "bench.py")] + args, env)
-    ranked, err = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-                         "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-                         "--force-process-group"] + args, env)
-    assert "using gloo" not in err, err[-2000:]
-    assert ranked["n_gpus"] == 1 and ranked["config"]["control_plane"] == "nccl"
-    assert plain["config"].get("control_plane") in (None, "none")
-    # (compared on the FASTEST region of each run: the boxes' hosts are shared and a median of a handful of 0.8 ms regions
-    # has been seen 40 % off for a whole run while its fastest region was within 3 %)
-    best = lambda o: o["timed_region_ms"]["min"]  # noqa: E731
-    assert abs(best(ranked) - best(plain)) / best(plain) < 0.25, (ranked["timed_region_ms"], plain["timed_region_ms"])
-    assert ranked["diagnostics"].get("pipeline_timeouts", 0) == 0
+    # 256 steps, and the driver's own 20 (where two kernels that run back to back instead of side by side cost 45 %: with
+    # an RCCL communicator in the process and the runtime's default of 4 hardware queues they did)
+    for steps, warmup in ((256, 32), (20, 5)):
+        args = ["--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-secondary"]
+        plain, _ = _line([sys.executable, os.path.join(ROOT, "bench.py")] + args, env)
+        ranked, err = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                             "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                             "--force-process-group"] + args, env)
+        assert "using gloo" not in err, err[-2000:]
+        assert ranked["n_gpus"] == 1 and ranked["config"]["control_plane"] == "nccl"
+        assert plain["config"].get("control_plane") in (None, "none")
+        # (compared on the FASTEST region of each run: the boxes' hosts are shared and a median of a handful of 0.8 ms
+        # regions has been seen 40 % off for a whole run while its fastest region was within 3 %)
+        best = lambda o: o["timed_region_ms"]["min"]  # noqa: E731
+        assert abs(best(ranked) - best(plain)) / best(plain) < 0.25, (steps, ranked["timed_region_ms"], plain["timed_region_ms"])
+        assert ranked["diagnostics"].get("pipeline_timeouts", 0) == 0
