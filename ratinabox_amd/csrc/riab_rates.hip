@@ -704,9 +704,11 @@ __global__ __launch_bounds__(64) void stream_gate_kernel(uint32_t* ctrl, uint32_
       }
       return;
     }
-    // the started gate may have to sit out whatever was queued in front of the trajectory kernel (long sleeps);
+    // the started gate may have to sit out whatever was queued in front of the trajectory kernel (long sleeps: 3.4 us),
+    // but normally that kernel is a microsecond away from announcing itself: the first polls are 0.2 us apart;
     // a progress gate is on the critical path of its chunk
-    if (sleep_long) __builtin_amdgcn_s_sleep(127);
+    if (sleep_long && spins >= 64) __builtin_amdgcn_s_sleep(127);
+    else if (sleep_long) __builtin_amdgcn_s_sleep(8);
     else __builtin_amdgcn_s_sleep(16);
   }
 }
