@@ -523,9 +523,10 @@ class Agent:
     def _simulate_native(self, n_steps, dt, drift_velocity, ratio, neurons, noise=None, kwargs=None):
         """`riab_simulate` (csrc/riab_simulate.hip): the trajectory kernel publishes its rows through
         flags in device memory and the firing-rate stage consumes them on the caller's stream while it runs — one
-        gated rate kernel for a single store-bound population (PlaceCells / GridCells / HeadDirectionCells without OU
-        noise, whole 256-agent groups, up to 256 steps), every population's ordinary kernel per chunk of rows behind a
-        progress gate for any other set.  Any batch size, explicit `noise=` normals, per-call motion kwargs,
+        row-following rate kernel for a single store-bound population (PlaceCells / GridCells / HeadDirectionCells
+        without OU noise, whole 256-agent groups), the same kernel for the largest such population followed by the
+        others' ordinary kernels when its stores keep pace with the trajectory, every population's ordinary kernel per
+        chunk of rows behind a progress gate otherwise (`last_rate_stage_form()`).  Any batch size, explicit `noise=` normals, per-call motion kwargs,
         `resample_positions=` and imported trajectories (the forced-position kernel followed by the populations'
         kernels) are covered: a 20-step run is ~70 us of GPU time, so everything that is not needed to issue the call
         — views, clocks, mirrors — happens AFTER it, while the kernels run.  Populations that do not save their
