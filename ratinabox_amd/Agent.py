@@ -108,7 +108,7 @@ class Agent:
         self._streamer = None   # native handle of the flag-coupled pipeline (created on first use)
         self._snap = None       # what the last plain native simulate() prepared (see _simulate_repeat)
         # simulate() calls served by each engine: "native" = riab_simulate, "plan" = a native step plan (populations that
-        # read the float64 state), "chunks" = the Python-driven chunk pipeline (RIAB_NO_NATIVE=1, > 16 populations)
+        # read the float64 state), "chunks" = the Python-driven chunk pipeline (RIAB_NO_NATIVE=1: the tests' comparator)
         self.engine_runs = {"native": 0, "plan": 0, "chunks": 0}
         self._run_cache = None  # (population structs, their array, the RiabSimulate argument block, key) of the last call
         self._ctrl = None       # its control words on the device
@@ -391,7 +391,7 @@ class Agent:
         AgentVectorCells and recurrent layers have no open-loop run (NotImplementedError: they advance through
         update()).  The older Python-driven pipeline — trajectory chunks of `chunk` steps on one HIP stream, the rate
         kernels of each finished chunk on a second one — is kept as the comparator of the tests (`RIAB_NO_NATIVE=1`)
-        and for more than 16 populations; `Agent.engine_runs` counts which engine served each call.  Histories land in HBM
+        only; `Agent.engine_runs` counts which engine served each call.  Histories land in HBM
         (`save_history=True`) exactly as `n_steps` calls of update() would have left them.  Returns the trajectory
         history tensor of this call `[n_steps, 8, B_padded]` (device; None when populations that read the agent's state
         are advanced through a step plan and the agent keeps no history).  The tensor is returned while the kernels
@@ -535,7 +535,7 @@ class Agent:
         the stream).  Returns None — nothing reserved, nothing launched — for what it does not cover: populations
         that cannot be recorded (AgentVectorCells, recurrent FeedForwardLayers), float32 motion; `RIAB_NO_NATIVE=1`
         switches it off (A/B comparisons: the Python-driven chunk pipeline gives identical results)."""
-        if len(neurons) > 16 or n_steps <= 0 or _L.env("RIAB_NO_NATIVE") == "1":
+        if n_steps <= 0 or _L.env("RIAB_NO_NATIVE") == "1":
             return None
         for N in neurons:
             if N.Agent is not self:

@@ -256,6 +256,20 @@ def test_one_engine_for_simulate(riab, monkeypatch):
         for x, y in zip(*got):
             assert torch.equal(x, y), name
     monkeypatch.delenv("RIAB_NO_NATIVE", raising=False)
+    # any number of populations (there is no table of fixed size behind the call)
+    got = []
+    for native in (True, False):
+        monkeypatch.setenv("RIAB_NO_NATIVE", "0" if native else "1")
+        env, ag, ps = world(64, pops=False)
+        np.random.seed(13)
+        many = [riab.PlaceCells(ag, {"n": 3 + k % 4, "save_spikes": bool(k % 2)}) if k % 3 else riab.HeadDirectionCells(ag, {"n": 4})
+                for k in range(40)]
+        ag.simulate(30)
+        torch.cuda.synchronize()
+        assert ag.engine_runs["native"] == int(native)
+        got.append([t.cpu() for N in many for t in N.get_history_tensors() if t is not None])
+    assert len(got[0]) == len(got[1]) and all(torch.equal(x, y) for x, y in zip(*got))
+    monkeypatch.delenv("RIAB_NO_NATIVE", raising=False)
     # populations that read the float64 state -> a native step plan; populations that follow ANOTHER Agent object
     # have no open-loop run at all (both agents advance through update())
     env, ag, ps = world(8)
