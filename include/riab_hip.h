@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RIAB_ABI_VERSION 4
+#define RIAB_ABI_VERSION 5
 #define RIAB_MAX_WALLS 64     /* walls staged in LDS by the motion / BVC / line-of-sight kernels */
 #define RIAB_MAX_TEST_ANGLES 360
 #define RIAB_STATE_ROWS 12    /* rows of the agent state matrix, see below */
@@ -44,8 +44,10 @@ enum {
   RIAB_ETOOBIG = -3,      /* more walls / test angles than the LDS staging allows */
   RIAB_EUNSUPPORTED = -4, /* combination not implemented on device */
   RIAB_EFULL = -5,        /* a step plan's history chunk has no free row left */
-  RIAB_EPARTIAL = -6      /* riab_simulate_*: a launch failed AFTER the trajectory kernel had been launched: the agent
+  RIAB_EPARTIAL = -6,     /* riab_simulate_*: a launch failed AFTER the trajectory kernel had been launched: the agent
                              state and the trajectory rows have advanced T steps, the rates of this call are incomplete */
+  RIAB_ECHANGED = -7      /* riab_simulate: a watched host array (RiabSimulate.watch) no longer equals its snapshot: the
+                             caller's cached device tables are stale; nothing was launched */
 };
 
 typedef void* riab_stream_t; /* hipStream_t */
@@ -589,8 +591,12 @@ double riab_plan_task_clock(const RiabPlan* plan);
  *         absolute step counts, the started word accumulates),
  *         [RIAB_CTRL_TIMEOUTS] waves that gave up waiting (must stay 0; results are invalid otherwise),
  *         [RIAB_CTRL_ABORT] set with the first timeout: every later wait returns at once,
- *         [RIAB_CTRL_STAMPS .. +3] two uint64: device clock at the first wave's start / the last wave's end of the
- *         rate kernel of the last call timed with RIAB_TIMING_STAMPS,
+ *         [RIAB_CTRL_SERIALISED] calls whose two kernels ran one after the other (see "Residency"),
+ *         [RIAB_CTRL_STAMPS .. +3] two uint64: device clock (s_memrealtime) at the first wave's start / the last
+ *         wave's end of the row-following rate kernel of the last call that ran one (the clock only moves forward, so
+ *         the words need no reset between calls: the newest start is stored, the end is a maximum),
+ *         [RIAB_CTRL_TRAJ_STAMPS .. +3] the same clock at the start of trajectory workgroup 0 and at its last
+ *         publication (every call; what RIAB_STREAMER_OPT_CALIBRATE reads),
  *         [RIAB_CTRL_PROGRESS_WORD(w)] (uint32)(step0 + steps whose rows trajectory workgroup w (agents 64w ..
  *         64w+63) has published).  The four words of a 256-agent sub-segment share one 128-byte line that no
  *         other sub-segment touches: every wave of the rate kernel reads exactly one such line, and with all of
@@ -609,15 +615,33 @@ double riab_plan_task_clock(const RiabPlan* plan);
  *         events attached to the launch (hipExtLaunchKernel; ~7 us of host time in front of the kernel)
  *
  * Residency.  Both kernels must be on the chip at once or the rate waves spin for nothing.  The trajectory kernel is
- * launched first, and a one-wave gate kernel in front of the rate stage holds it back until every trajectory
- * workgroup of this launch is resident (the rate kernel could otherwise fill the chip with waiting waves before
- * the kernel they wait for has been placed — it did, with two processes sharing one GPU).
- * riab_streamer_configure(h, RIAB_STREAMER_OPT_GATE, RIAB_GATE_WHEN_BUSY) drops the gate of the one-kernel form when
- * `stream` is idle at the call (hipStreamQuery): for callers that own the device.
+ * launched first.  Two ways of making sure that the rate kernel cannot fill the chip with waiting waves before the
+ * kernel they wait for has been placed (it did, with two processes sharing one GPU):
+ *  - RIAB_GATE_RESERVED (the default): when `stream` is idle at the call (hipStreamQuery) and the stage is the
+ *    row-following kernel of one population, that kernel is launched as workgroups of TWELVE waves, three per SIMD.
+ *    Two of them fit a compute unit, a third does not (8 wave slots per SIMD): on EVERY compute unit one wave slot per
+ *    SIMD stays free whatever the rate kernel does, and wave slots are the only resource the two kernels compete for
+ *    (the rate kernel holds 24 registers per lane and no LDS; a trajectory workgroup needs one slot per SIMD, 232
+ *    registers, 80 KB of LDS).  The trajectory workgroups can therefore always be placed: residency by construction,
+ *    two launches per call.  (Otherwise, RIAB_GATE_RESERVED behaves as RIAB_GATE_ALWAYS.)
+ *  - RIAB_GATE_ALWAYS: a one-wave gate kernel in front of the rate stage (four-wave workgroups, 8 waves per SIMD)
+ *    holds it back until every trajectory workgroup of this launch has announced itself in ctrl[RIAB_CTRL_STARTED]:
+ *    three launches per call.
+ *  - RIAB_GATE_WHEN_BUSY drops that gate when `stream` is idle, with nothing in its place: only for callers that own
+ *    the device (kept for A/B runs).
  * Every wait is bounded; a wait that gives up sets ctrl[RIAB_CTRL_ABORT] and is counted in ctrl[RIAB_CTRL_TIMEOUTS].
+ * A trajectory workgroup sets its progress word to step0 BEFORE it announces itself, so a call whose step0 is not
+ * beyond the last call's rows (the same block replayed: torch.ops.riab.simulate_ in a compiled function) never lets a
+ * consumer see the earlier run's words: such calls always take the started gate.
+ * ctrl[RIAB_CTRL_SERIALISED] counts calls of >= 8 rows whose rate stage found EVERY row already published when its
+ * first wave arrived: the two kernels ran one after the other, not side by side (both streams on one hardware queue —
+ * GPU_MAX_HW_QUEUES, many other streams in the process): results are right, the call is up to 45 % slower.
  * All argument checks run before the first launch: an argument error has launched nothing; a failure after the
  * trajectory launch returns RIAB_EPARTIAL. */
-enum { RIAB_CTRL_STARTED = 0, RIAB_CTRL_TIMEOUTS = 1, RIAB_CTRL_ABORT = 2, RIAB_CTRL_STAMPS = 8, RIAB_CTRL_PROGRESS = 32 };
+enum { RIAB_CTRL_STARTED = 0, RIAB_CTRL_TIMEOUTS = 1, RIAB_CTRL_ABORT = 2, RIAB_CTRL_SERIALISED = 3,
+       RIAB_CTRL_STAMPS = 8,        /* two uint64: the timed rate kernel's first-wave start / last-wave end */
+       RIAB_CTRL_TRAJ_STAMPS = 12,  /* two uint64: trajectory workgroup 0's start / last publication (every call) */
+       RIAB_CTRL_PROGRESS = 32 };
 #define RIAB_CTRL_PROGRESS_WORD(w) (RIAB_CTRL_PROGRESS + 32 * ((w) >> 2) + ((w) & 3))
 #define RIAB_CTRL_WORDS(B) (RIAB_CTRL_PROGRESS + 32 * (((B) + 255) / 256))
 enum { RIAB_TIMING_STAMPS = 0, RIAB_TIMING_EVENTS = 1 };
@@ -641,7 +665,18 @@ typedef struct RiabSimulate {
   uint32_t* ctrl;
   int32_t timed_pop;
   int32_t timing_mode;
+  /* Host arrays the caller's cached device tables were built from (cell centres, widths, wall arrays ...), each with
+   * the snapshot taken when the tables were built: compared (memcmp) before anything is launched; a difference returns
+   * RIAB_ECHANGED.  Lets a caller that re-issues the same run skip its own content checks (users of the Python layer
+   * edit tuning arrays in place, reference tests/test_advanced.py:59).  NULL / 0: nothing to compare. */
+  const struct RiabWatch* watch;
+  int32_t n_watch;
 } RiabSimulate;
+typedef struct RiabWatch {
+  const void* live;
+  const void* snapshot;
+  int64_t bytes;
+} RiabWatch;
 typedef struct RiabStreamer RiabStreamer;
 RiabStreamer* riab_streamer_create(void);
 void riab_streamer_destroy(RiabStreamer* h);
@@ -649,10 +684,23 @@ void riab_streamer_destroy(RiabStreamer* h);
  * (default 65535, the most the row-following kernel's grid holds; 0: never): longer runs take the chunk form of the
  * rate stage; HEAD_ROWS (default 256): runs of more than 2048 rows give only their first HEAD_ROWS rows to the
  * row-following kernel and the rest to the population's ordinary kernel behind progress gates (65535: never) */
-enum { RIAB_STREAMER_OPT_GATE = 0, RIAB_STREAMER_OPT_POLL_MAX = 1, RIAB_STREAMER_OPT_HEAD_ROWS = 2 };
-enum { RIAB_GATE_ALWAYS = 0, RIAB_GATE_WHEN_BUSY = 1 };
+/* ... SIDE_STREAM: where the trajectory kernel runs — 0 (default) a stream of the streamer's own at the device's
+ * highest priority, 1 a stream of its own at the default priority, 2 the caller's stream (the two kernels then run one
+ * after the other: for tests of the RIAB_CTRL_SERIALISED diagnostic); takes effect at the next call.
+ * STEP_NS / LEAD_MBPS: what the choice between the populations form and the chunk form compares — a trajectory step
+ * next to the rate stage, in nanoseconds, and the lead population's store rate in MB/s.  0 (default): measured — the
+ * first call with several populations that finds `stream` idle reads the device-clock stamps the previous call left
+ * in ctrl (one blocking 32-byte copy, once per streamer) and keeps the ratio; until then, and when the stamps are
+ * unusable, the constants measured on MI355X (900 ns + 250 ns per wall beyond four, x 1.5; 6.5 TB/s).  A non-zero
+ * value replaces the measurement (tests; chips whose clocks are known to differ). */
+enum { RIAB_STREAMER_OPT_GATE = 0, RIAB_STREAMER_OPT_POLL_MAX = 1, RIAB_STREAMER_OPT_HEAD_ROWS = 2,
+       RIAB_STREAMER_OPT_SIDE_STREAM = 3, RIAB_STREAMER_OPT_STEP_NS = 4, RIAB_STREAMER_OPT_LEAD_MBPS = 5 };
+enum { RIAB_GATE_ALWAYS = 0, RIAB_GATE_WHEN_BUSY = 1, RIAB_GATE_RESERVED = 2 };
 int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t value);
 int riab_simulate(RiabStreamer* h, const RiabSimulate* run, riab_stream_t stream);
+/* what riab_simulate does with RiabSimulate.watch before anything else (host memory only, no device): RIAB_OK when every
+ * live array equals its snapshot, RIAB_ECHANGED otherwise, RIAB_EINVAL for a malformed list */
+int riab_watch_compare(const RiabWatch* watch, int32_t n);
 /* after a riab_simulate call with timed_pop >= 0 and after the caller has synchronised: the duration of the timed
  * population's kernel(s) in ms; < 0 if unavailable */
 float riab_streamer_last_rate_ms(RiabStreamer* h);
@@ -660,6 +708,9 @@ float riab_streamer_last_rate_ms(RiabStreamer* h);
 enum { RIAB_FORM_NONE = 0, RIAB_FORM_ONE_KERNEL = 1, RIAB_FORM_CHUNKS = 2, RIAB_FORM_SERIAL = 3, RIAB_FORM_POPULATIONS = 4,
        RIAB_FORM_HEAD_AND_PIECES = 5 };
 int riab_streamer_last_form(RiabStreamer* h);
+/* what the form selection currently compares (which: 0 the trajectory step in ns, 1 the lead's store rate in MB/s, 2
+ * whether they were measured (1) or are the built-in constants / configured values (0), 3 launches of the last call) */
+int64_t riab_streamer_info(RiabStreamer* h, int32_t which);
 
 /* A/B switches of the library (comparisons and tests; the defaults are what production runs): process-wide, read on
  * every call they affect (plain loads of an int: the library never calls getenv).  Returns the previous value, or
@@ -670,8 +721,13 @@ int riab_streamer_last_form(RiabStreamer* h);
  *   RIAB_OPT_FUSED_TASK    1 (default) a task plan's motion + task step is one launch; 0 two launches
  *   RIAB_OPT_BVC_BOX       1 (default) box fast path of the boundary-vector ray stage; 0 the general stage everywhere
  *   RIAB_OPT_NT_STORES     0 (default) only the one-kernel rate stage of riab_simulate writes its rows with nontemporal
- *                          stores; 1 the ungated PlaceCells / GridCells / HDC kernel too (A/B: measured slower) */
-enum { RIAB_OPT_TRAJ_KERNEL = 0, RIAB_OPT_FUSED_TASK = 1, RIAB_OPT_BVC_BOX = 2, RIAB_OPT_NT_STORES = 3, RIAB_OPT_COUNT = 4 };
+ *                          stores; 1 the ungated PlaceCells / GridCells / HDC kernel too (A/B: measured slower)
+ *   RIAB_OPT_PUB_SINGLE_ROWS  how many of a publishing trajectory launch's first rows leave one by one before blocks
+ *                          of four (default 4; 0 .. 64)
+ *   RIAB_OPT_POLL_SLEEP    the longest s_sleep between two polls of a waiting rate wave, in units of 64 cycles (default
+ *                          48; 1 .. 127) */
+enum { RIAB_OPT_TRAJ_KERNEL = 0, RIAB_OPT_FUSED_TASK = 1, RIAB_OPT_BVC_BOX = 2, RIAB_OPT_NT_STORES = 3,
+       RIAB_OPT_PUB_SINGLE_ROWS = 4, RIAB_OPT_POLL_SLEEP = 5, RIAB_OPT_COUNT = 6 };
 int riab_set_option(int32_t option, int32_t value);
 
 /* Process-level host setting for latency-bound callers (one short simulate() per synchronisation, as in bench.py's

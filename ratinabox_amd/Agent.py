@@ -17,6 +17,7 @@ the trajectory history chunks `[T, 8, B]` (float32, HBM) and resolves parameters
 `simulate(T)` is the fused path: T steps per launch on one stream while the
 firing-rate kernels of the previous chunk run on another."""
 import copy
+import operator
 import os
 
 import numpy as np
@@ -30,6 +31,15 @@ _L = _lib
 
 
 _NO_KWARGS = {}
+_PLAIN = (int, float, str, bool, type(None), np.float64, np.float32, np.int64, np.int32, np.bool_)
+# what a repeated plain simulate() depends on besides the populations and the geometry, read with ONE attrgetter call
+_AGENT_FAST_ATTRS = ("save_history", "seed", "agent_id0", "dt", "_time_rate_kernel", "_timed_population",
+                     "use_imported_trajectory", "DIRECT_NATIVE_CALL", "rotational_velocity_std",
+                     "rotational_velocity_coherence_time", "speed_coherence_time", "speed_mean", "speed_std",
+                     "wall_repel_strength", "wall_repel_distance", "thigmotaxis", "head_direction_smoothing_timescale")
+_ENV_FAST_ATTRS = ("boundary_conditions", "scale", "aspect", "is_rectangular", "_n_boundary")
+_agent_fast = operator.attrgetter(*_AGENT_FAST_ATTRS)
+_env_fast = operator.attrgetter(*_ENV_FAST_ATTRS)
 
 
 class Agent:
@@ -114,6 +124,8 @@ class Agent:
         self._ctrl = None       # its control words on the device
         self._pipeline_unchecked = False
         self._time_rate_kernel = False
+        self._timed_population = None
+        self._serial_warned = False
 
         self._state = torch.zeros((_L.STATE_ROWS, self._Bp), dtype=torch.float64, device=self._device)
         self.initialise_position_and_velocity()
@@ -226,8 +238,19 @@ class Agent:
         d = self._diag.cpu().numpy()
         out = dict(bounces=int(d[0]), bounce_saturations=int(d[1]), boundary_conditions=int(d[2]),
                    zero_displacement=int(d[3]))
-        if self._ctrl is not None:  # waits of the flag-coupled pipeline that gave up: must be 0
-            out["pipeline_timeouts"] = int(self._ctrl[_L.CTRL_TIMEOUTS].item())
+        if self._ctrl is not None:
+            w = self._ctrl[:4].cpu()
+            out["pipeline_timeouts"] = int(w[_L.CTRL_TIMEOUTS])  # waits of the flag-coupled pipeline that gave up: must be 0
+            # simulate() calls (>= 8 steps) whose trajectory kernel had FINISHED before the firing-rate stage began: the
+            # two kernels are meant to run side by side on two hardware queues; results are right, the call is slower
+            out["pipeline_serialised"] = int(w[_L.CTRL_SERIALISED])
+            if out["pipeline_serialised"] and not self._serial_warned:
+                self._serial_warned = True
+                import warnings
+                warnings.warn(f"{out['pipeline_serialised']} simulate() call(s) ran their trajectory and firing-rate "
+                              "kernels one after the other instead of side by side: the process's HIP streams share a "
+                              "hardware queue (GPU_MAX_HW_QUEUES, many streams in flight, an RCCL communicator: "
+                              "DESIGN.md 7).  Results are unaffected; short runs are up to 45 % slower.", RuntimeWarning)
         return out
 
     # ---- parameter resolution ---------------------------------------------------------------
@@ -508,8 +531,18 @@ class Agent:
         self._streamer = _L.C.c_void_p(h)
         self._ctrl = torch.zeros(_L.ctrl_words(self._Bp), dtype=torch.int32, device=self._device)
         torch.cuda.current_stream(self._device).synchronize()
-        if _L.env("RIAB_GATE_WHEN_BUSY") == "1":  # this process owns the device: no started gate while the stream is idle
-            _L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_GATE, _L.GATE_WHEN_BUSY)
+        # residency of the two kernels (riab_hip.h "Residency"): the default is RIAB_GATE_RESERVED — a short call of one
+        # store-bound population from an idle stream is two launches, the rate kernel in its reserving shape; A/B:
+        # RIAB_GATE=always (the one-wave started gate in front of every rate stage: three launches), RIAB_GATE=when_busy
+        # or RIAB_GATE_WHEN_BUSY=1 (no gate and no reservation while the stream is idle: this process owns the device)
+        gate = (_L.env("RIAB_GATE") or ("when_busy" if _L.env("RIAB_GATE_WHEN_BUSY") == "1" else "")).lower()
+        if gate:
+            _L.check(_L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_GATE,
+                                                    {"always": _L.GATE_ALWAYS, "when_busy": _L.GATE_WHEN_BUSY,
+                                                     "reserved": _L.GATE_RESERVED}[gate]), "riab_streamer_configure")
+        if _L.env("RIAB_SIDE_STREAM"):      # (1: default-priority second stream; 2: the caller's stream — serial, diagnostics)
+            _L.check(_L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_SIDE_STREAM, int(_L.env("RIAB_SIDE_STREAM"))),
+                     "riab_streamer_configure")
         if _L.env("RIAB_NO_FUSED") == "1":  # A/B comparisons: always the chunk form of the rate stage
             _L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_POLL_MAX, 0)
         elif _L.env("RIAB_POLL_MAX"):       # (... or the one-kernel form up to this many steps)
@@ -674,12 +707,57 @@ class Agent:
         plain = z is None and rs is None and forced is None and drift is None and not kwargs and not via_op and \
             self.save_history and all(at[4] is None for at in ats)
         self._snap = None
-        if plain:
+        run.watch, run.n_watch = None, 0
+        # (a population that reads another's rows — a FeedForwardLayer — describes itself through the index of the
+        # recorded populations, which the short road does not rebuild: such sets take the general road every time)
+        if plain and not any(getattr(N, "inputs", None) for N in neurons):
             self._snap = dict(neurons=list(neurons), structs=structs, arr=arr, run=run, byref=byref, env=env, m=m, dt=dt,
                               seed=self.seed, a0=self.agent_id0, timing=self._time_rate_kernel,
                               timed=getattr(self, "_timed_population", None),
-                              pops=[(N, int(N.n), at[2] is not None) for N, at in zip(neurons, ats)])
+                              pops=[(N, int(N.n), at[2] is not None) for N, at in zip(neurons, ats)],
+                              fast=self._fast_record(neurons))
         return traj
+
+    def _fast_record(self, neurons):
+        """What lets the NEXT plain simulate() skip re-deriving every table key by content (`_simulate_repeat`): for
+        populations whose tables come straight from float64 arrays held in attributes (PlaceCells, GridCells,
+        HeadDirectionCells), those array OBJECTS (a replaced attribute is seen by identity), a snapshot of their bytes
+        (an edit in place — `PCs.place_cell_centres[-1] = ...`, reference tests/test_advanced.py:59 — is seen by the
+        library's memcmp against the snapshot, RiabSimulate.watch, before it launches anything), the scalar
+        parameters by value; the same for the Environment's wall table.  None when anything does not fit (the repeat
+        then re-examines every key the slower way)."""
+        if _L.env("RIAB_NO_FAST_REPEAT") == "1":
+            return None
+        from .Neurons import FAST_REPEAT_TYPES
+        keep, pops = [], []
+
+        def watchable(a):
+            return type(a) is np.ndarray and a.dtype == np.float64 and a.flags.c_contiguous
+
+        for N in neurons:
+            if type(N) not in FAST_REPEAT_TYPES:
+                return None
+            arrs = [(name, getattr(N, name, None)) for name in N._watch_arrays]
+            getter = N._fast_getter()
+            sc = getter(N)
+            if not all(watchable(a) for _, a in arrs) or not all(type(v) in _PLAIN for v in sc):
+                return None
+            pops.append((N, arrs, getter, sc))
+            keep.extend(a for _, a in arrs)
+        Env = self.Environment
+        walls = Env.walls
+        if not watchable(walls):
+            return None
+        keep.append(walls)
+        snaps = [a.copy() for a in keep]
+        watch = (_L.RiabWatch * len(keep))()
+        for w, a, c in zip(watch, keep, snaps):
+            w.live, w.snapshot, w.bytes = a.ctypes.data, c.ctypes.data, a.nbytes
+        ag = _agent_fast(self)
+        if not all(type(v) in _PLAIN for v in ag if v is not self._timed_population):
+            return None
+        return dict(pops=pops, walls=walls, env=_env_fast(Env), holes=list(Env._wall_is_hole), ag=ag, watch=watch,
+                    n_watch=len(keep), _keep=(keep, snaps))
 
     def _after_native(self, n_steps, dt, traj_c, traj_s, neurons, ats, tc, keep):
         """The kernels of a native run are in flight: now the views and the Python-side mirrors (clocks, step index,
@@ -708,31 +786,53 @@ class Agent:
 
     def _simulate_repeat(self, n_steps):
         """simulate(n_steps) again with what the previous plain native call prepared (`self._snap`): every input of
-        that preparation is re-examined — the list of populations, each population's tables (by content, through its
-        cached descriptor), the motion parameters, the geometry, seeds, history and timing switches — and anything
-        that has changed sends the call down the general road (None).  What is left is reserving the rows, eight
-        fields of the argument block and the call: ~9 us of host time instead of ~17 [MI355X host]."""
+        that preparation is re-examined, and anything that has changed sends the call down the general road (None).
+        Two ways of examining: with a `fast` record (`_fast_record`: PlaceCells / GridCells / HeadDirectionCells) the
+        attributes by identity and value here and the CONTENT of their arrays by the library, against snapshots, in the
+        same native call that launches (RIAB_ECHANGED: nothing launched, the general road rebuilds the tables);
+        otherwise each population's tables by content through its cached descriptor.  What is left is reserving the
+        rows, a few fields of the argument block and the call: ~5 / ~9 us of host time instead of ~17 [MI355X host]."""
         sn = self._snap
         Ns = self.Neurons
         pops = sn["pops"]
-        if len(Ns) != len(pops) or self.use_imported_trajectory or not self.save_history or self.seed != sn["seed"] or \
-                self.agent_id0 != sn["a0"] or self._time_rate_kernel != sn["timing"] or not self.DIRECT_NATIVE_CALL or \
-                getattr(self, "_timed_population", None) is not sn["timed"] or \
-                torch._C._len_torch_dispatch_stack() > 0 or _L.env("RIAB_NO_NATIVE") == "1":
+        fast = sn["fast"]
+        if len(Ns) != len(pops) or torch._C._len_torch_dispatch_stack() > 0 or _L.env("RIAB_NO_NATIVE") == "1":
             return None
-        structs = sn["structs"]
-        for i, (N, _n, has_sp) in enumerate(pops):
-            if Ns[i] is not N or not N.save_history or bool(N.save_spikes) != has_sp or N._population() is not structs[i]:
-                return None
-        dt = sn["dt"]
-        if self._motion(dt, False, 1, _NO_KWARGS) is not sn["m"] or \
-                self.Environment.device_tables(self._device)[0] is not sn["env"]:
-            return None
-        Bp = self._Bp
         arr, run = sn["arr"], sn["run"]
+        if fast is not None:
+            if _agent_fast(self) != fast["ag"]:
+                return None
+            i = 0
+            for N, arrs, getter, sc in fast["pops"]:
+                if Ns[i] is not N or getter(N) != sc:
+                    return None
+                for name, a in arrs:
+                    if getattr(N, name) is not a:
+                        return None
+                i += 1
+            Env = self.Environment
+            if Env.walls is not fast["walls"] or _env_fast(Env) != fast["env"] or Env._wall_is_hole != fast["holes"]:
+                return None
+            run.watch, run.n_watch = _L.C.addressof(fast["watch"]), fast["n_watch"]
+        else:
+            if self.use_imported_trajectory or not self.save_history or self.seed != sn["seed"] or \
+                    self.agent_id0 != sn["a0"] or self._time_rate_kernel != sn["timing"] or not self.DIRECT_NATIVE_CALL or \
+                    getattr(self, "_timed_population", None) is not sn["timed"]:
+                return None
+            structs = sn["structs"]
+            for i, (N, _n, has_sp) in enumerate(pops):
+                if Ns[i] is not N or not N.save_history or bool(N.save_spikes) != has_sp or N._population() is not structs[i]:
+                    return None
+            if self._motion(sn["dt"], False, 1, _NO_KWARGS) is not sn["m"] or \
+                    self.Environment.device_tables(self._device)[0] is not sn["env"]:
+                return None
+            run.watch, run.n_watch = None, 0
+        dt = sn["dt"]
+        Bp = self._Bp
         traj_c, traj_s = self._hist.reserve_at(n_steps)
         ats = []
-        for i, (N, n, has_sp) in enumerate(pops):
+        i = 0
+        for N, n, has_sp in pops:
             fr_c, fr_s = N._hist_fr.reserve_at(n_steps)
             q = arr[i]
             q.rates_base = fr_c.data_ptr() + fr_s * n * Bp * 4
@@ -743,12 +843,13 @@ class Agent:
                 sp_c, sp_s = None, 0
             q.capacity_rows = n_steps
             ats.append((fr_c, fr_s, sp_c, sp_s, None))
-        run.step0, run.T = int(self._step_index), n_steps
+            i += 1
+        run.step0, run.T = self._step_index, n_steps
         run.hist = traj_c.data_ptr() + traj_s * (_L.HIST_ROWS * Bp * 4)
         rc = _L.lib.riab_simulate(self._streamer, sn["byref"], _L.current_stream())
         if rc:
             self._snap = None
-            if rc == _L.EUNSUPPORTED:   # (nothing was launched: give the rows back, the general road decides)
+            if rc == _L.EUNSUPPORTED or rc == _L.ECHANGED:   # (nothing was launched: give the rows back, the general road decides)
                 self._hist.unreserve(n_steps)
                 for (N, _n, has_sp) in pops:
                     N._hist_fr.unreserve(n_steps)

@@ -56,6 +56,22 @@ class Neurons:
     # Called with float32 rows `d [4, P]` = (pos x, pos y, direction x, direction y); returns rates `[n, P]`.
     _state_op = None
 
+    # Agent._fast_record: the float64 array attributes `_call` builds this population's device tables from, and the scalar
+    # parameters it reads besides them — ONLY on the classes listed in FAST_REPEAT_TYPES (exact types: a subclass may
+    # read more), whose `_call` reads nothing else
+    _watch_arrays = None
+    _watch_scalars = ()
+    _COMMON_SCALARS = ("n", "min_fr", "max_fr", "noise_std", "noise_coherence_time", "save_history", "save_spikes")
+
+    @classmethod
+    def _fast_getter(cls):
+        g = cls.__dict__.get("_fast_getter_cached")
+        if g is None:
+            import operator
+            g = operator.attrgetter(*(cls._COMMON_SCALARS + tuple(cls._watch_scalars)))
+            cls._fast_getter_cached = g
+        return g
+
     def _auto_key(self):
         """What `update()` depends on besides the agent's state, by VALUE (users edit tuning arrays in place,
         reference tests/test_advanced.py:59): compared on every update() served by plan.AutoStepper."""
@@ -484,6 +500,8 @@ class PlaceCells(Neurons):
     euclidean, line_of_sight, geodesic."""
 
     _stream_kind = "place"
+    _watch_arrays = ("place_cell_centres", "place_cell_widths")
+    _watch_scalars = ("description", "wall_geometry", "widths")
     default_params = {
         "n": 10,
         "name": "PlaceCells",
@@ -568,6 +586,8 @@ class GridCells(Neurons):
     (reference Neurons.py:1033-1256)."""
 
     _stream_kind = "grid"
+    _watch_arrays = ("gridscales", "phase_offsets", "w")
+    _watch_scalars = ("description", "width_ratio")
     default_params = {
         "n": 30,
         "gridscale_distribution": "modules",
@@ -1103,6 +1123,8 @@ class HeadDirectionCells(Neurons):
     (reference Neurons.py:2357-2485)."""
 
     _stream_kind = "hdc"
+    _watch_arrays = ("preferred_angles", "angular_tunings")
+    _watch_scalars = ()
     default_params = {
         "min_fr": 0,
         "max_fr": 1,
@@ -1538,3 +1560,7 @@ class FeedForwardLayer(Neurons):
         if sp is not None:
             io = self._io(None, None, None, None, self._Bp, tc, self._Bp, fr, sp, None, dt, step0 + 1)
             _L.check(_L.lib.riab_spikes(io, int(self.n), stream), "riab_spikes")
+
+
+# Populations whose device tables derive from float64 array attributes alone (Agent._fast_record): exact types
+FAST_REPEAT_TYPES = (PlaceCells, GridCells, HeadDirectionCells)

@@ -48,6 +48,11 @@ def build(force=False, verbose=False):
             if not force and not is_stale():  # another rank built it while we waited
                 return LIB_PATH
             hipcc = _hipcc()
+            # (leftovers of builds that were interrupted: they would travel to the GPU box with every push; this process
+            # holds the build lock, so nobody is using them)
+            for old in os.listdir(LIB_DIR):
+                if old.startswith("build_"):
+                    shutil.rmtree(os.path.join(LIB_DIR, old), ignore_errors=True)
             work = tempfile.mkdtemp(prefix="build_", dir=LIB_DIR)
             from concurrent.futures import ThreadPoolExecutor
 
@@ -59,16 +64,18 @@ def build(force=False, verbose=False):
                 subprocess.run(cmd, check=True)
                 return obj
 
-            # the translation units are independent: compile them side by side
-            with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
-                objs = list(pool.map(compile_one, SOURCES))
-            tmp_lib = os.path.join(work, "libriab_hip.so")
-            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib, *objs]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
-            os.replace(tmp_lib, LIB_PATH)
-            shutil.rmtree(work, ignore_errors=True)
+            try:
+                # the translation units are independent: compile them side by side
+                with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+                    objs = list(pool.map(compile_one, SOURCES))
+                tmp_lib = os.path.join(work, "libriab_hip.so")
+                cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib, *objs]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                subprocess.run(cmd, check=True)
+                os.replace(tmp_lib, LIB_PATH)
+            finally:  # (a failed compile leaves no work directory behind either)
+                shutil.rmtree(work, ignore_errors=True)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH

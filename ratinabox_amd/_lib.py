@@ -13,7 +13,7 @@ import torch  # noqa: F401
 
 from . import _build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_WALLS = 64
 STATE_ROWS = 12
 HIST_ROWS = 8
@@ -73,7 +73,13 @@ class RiabSimulate(C.Structure):
                 ("agent_id0", C.c_int64), ("drift", C.c_void_p), ("noise", C.c_void_p), ("forced_pos", C.c_void_p),
                 ("resample_pos", C.c_void_p), ("seed", C.c_uint64), ("step0", C.c_uint64), ("T", C.c_int32),
                 ("n_pops", C.c_int32), ("pops", C.POINTER(RiabPopulation)), ("hist", C.c_void_p), ("diag", C.c_void_p),
-                ("ctrl", C.c_void_p), ("timed_pop", C.c_int32), ("timing_mode", C.c_int32)]
+                ("ctrl", C.c_void_p), ("timed_pop", C.c_int32), ("timing_mode", C.c_int32),
+                ("watch", C.c_void_p), ("n_watch", C.c_int32)]
+
+
+class RiabWatch(C.Structure):
+    """A host array a cached device table was built from + the snapshot taken then (riab_simulate compares them)."""
+    _fields_ = [("live", C.c_void_p), ("snapshot", C.c_void_p), ("bytes", C.c_int64)]
 
 
 POP_SIZE = C.sizeof(RiabPopulation)
@@ -104,9 +110,11 @@ EALIGN = -2
 EFULL = -5
 EUNSUPPORTED = -4
 EPARTIAL = -6
+ECHANGED = -7
 STREAMER_OPT_GATE, STREAMER_OPT_POLL_MAX, STREAMER_OPT_HEAD_ROWS = 0, 1, 2
-GATE_ALWAYS, GATE_WHEN_BUSY = 0, 1
-CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_STAMPS, CTRL_PROGRESS = 0, 1, 2, 8, 32  # riab_hip.h RIAB_CTRL_*
+STREAMER_OPT_SIDE_STREAM, STREAMER_OPT_STEP_NS, STREAMER_OPT_LEAD_MBPS = 3, 4, 5
+GATE_ALWAYS, GATE_WHEN_BUSY, GATE_RESERVED = 0, 1, 2
+CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_SERIALISED, CTRL_STAMPS, CTRL_TRAJ_STAMPS, CTRL_PROGRESS = 0, 1, 2, 3, 8, 12, 32  # riab_hip.h RIAB_CTRL_*
 
 
 def ctrl_words(B):
@@ -181,9 +189,11 @@ PROTOTYPES = {
     "riab_streamer_create": (C.c_void_p, []),
     "riab_streamer_destroy": (None, [C.c_void_p]),
     "riab_simulate": (C.c_int, [C.c_void_p, C.POINTER(RiabSimulate), C.c_void_p]),
+    "riab_watch_compare": (C.c_int, [C.c_void_p, C.c_int32]),
     "riab_streamer_configure": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "riab_streamer_last_rate_ms": (C.c_float, [C.c_void_p]),
     "riab_streamer_last_form": (C.c_int, [C.c_void_p]),
+    "riab_streamer_info": (C.c_int64, [C.c_void_p, C.c_int32]),
     "riab_host_wait_spin": (C.c_int, [C.c_int32]),
     "riab_set_option": (C.c_int, [C.c_int32, C.c_int32]),
     "riab_abi_sizeof": (C.c_int64, [C.c_int32]),
@@ -237,7 +247,7 @@ def _load():
 lib, LIB_PATH = _load()
 
 
-OPTIONS = {"traj_kernel": 0, "fused_task": 1, "bvc_box": 2, "nt_stores": 3}   # riab_hip.h RIAB_OPT_*
+OPTIONS = {"traj_kernel": 0, "fused_task": 1, "bvc_box": 2, "nt_stores": 3, "pub_single_rows": 4, "poll_sleep": 5}   # riab_hip.h RIAB_OPT_*
 
 
 def set_option(name, value):
@@ -253,6 +263,9 @@ for _name, _opt, _val in (("RIAB_NO_PC", "traj_kernel", 1), ("RIAB_TRAJ2", "traj
                           ("RIAB_NO_BVC_BOX", "bvc_box", 0), ("RIAB_NT_STORES_WIDE", "nt_stores", 1)):
     if os.environ.get(_name):
         set_option(_opt, _val)
+for _name, _opt in (("RIAB_PUB_SINGLE_ROWS", "pub_single_rows"), ("RIAB_POLL_SLEEP", "poll_sleep")):
+    if os.environ.get(_name):
+        set_option(_opt, int(os.environ[_name]))
 
 
 def strerror(code):

@@ -54,8 +54,10 @@ int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* 
 // `*state_published` (optional): true when the kernel launched makes its LAST publication after its state stores have
 // been written through and acknowledged (the four-wave kernel): a consumer that has waited for that publication needs
 // no other ordering against this launch.
-int launch_agent_pub(const AgentArgs& a, hipStream_t s, bool* state_published) {
-  if (!a.ctrl || !a.hist || a.forced || a.B % 4 != 0) return RIAB_EINVAL;
+int launch_agent_pub(const AgentArgs& a_in, hipStream_t s, bool* state_published) {
+  if (!a_in.ctrl || !a_in.hist || a_in.forced || a_in.B % 4 != 0) return RIAB_EINVAL;
+  AgentArgs a = a_in;
+  a.pub_single = g_options[RIAB_OPT_PUB_SINGLE_ROWS];
   const dim3 grid((unsigned)((a.B + 63) / 64));
   const bool two_wave = g_options[RIAB_OPT_TRAJ_KERNEL] == 2 && !a.z_in && !a.z_out && a.B % 64 == 0;
   if (state_published) *state_published = !two_wave;

@@ -108,6 +108,7 @@ struct AgentArgs {
   float* hist;  // [T][8][B] or null
   int* diag;
   uint32_t* ctrl;  // PUB kernels only: control words of the flag-coupled pipeline (riab_hip.h RIAB_CTRL_*)
+  int pub_single;  // PUB kernels only: the launch's first `pub_single` rows are published one by one, then blocks of four
 };
 
 // ---- math wrappers ---------------------------------------------------------------------------
@@ -889,7 +890,12 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
         __builtin_amdgcn_wave_barrier();
       }
     };
-    if (PUB && lane == 0) atomicAdd(a.ctrl + RIAB_CTRL_STARTED, 1u);  // this workgroup is resident
+    if (PUB && lane == 0) {  // this workgroup is resident; its progress word first goes back to "no row of this launch yet"
+      __hip_atomic_store((riab_gu32*)(uintptr_t)(a.ctrl + RIAB_CTRL_PROGRESS_WORD(blockIdx.x)), (uint32_t)a.step0, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      atomicAdd(a.ctrl + RIAB_CTRL_STARTED, 1u);
+    }
     __syncthreads();  // (the table-staging barrier of the stepping wave)
     draw_batch(0);
     __syncthreads();  // noise batch 0 ready
@@ -1188,6 +1194,7 @@ static inline int fill_agent_args(AgentArgs& a, const RiabEnv* env, const RiabMo
   a.hist = hist;
   a.diag = diag;
   a.ctrl = nullptr;
+  a.pub_single = 4;
   return RIAB_OK;
 }
 

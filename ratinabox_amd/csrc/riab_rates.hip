@@ -564,6 +564,9 @@ struct StreamArgs {
   uint32_t step_base;     // (uint32) step0 of the launch: progress words are absolute step counts
   uint32_t spin_limit;
   uint32_t stamps;        // != 0: the waves of the first / last time row record the device clock in ctrl[RIAB_CTRL_STAMPS]
+  uint32_t sleep_max;     // longest s_sleep between two polls (riab_set_option(RIAB_OPT_POLL_SLEEP))
+  uint32_t serial_rows;   // >= 8: rows of the whole call — the grid's first wave counts the call in
+                          // ctrl[RIAB_CTRL_SERIALISED] when it finds all of them published already; 0: no check
 };
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
@@ -595,26 +598,33 @@ __device__ __forceinline__ void stream_wait(const StreamArgs& s, uint32_t q, int
     }
     // back off: the waves at the frontier all poll the same few lines
     if (spins < 4) __builtin_amdgcn_s_sleep(4);
-    else if (spins < 16) __builtin_amdgcn_s_sleep(16);
-    else __builtin_amdgcn_s_sleep(48);
+    else if (spins < 16 || s.sleep_max <= 16) __builtin_amdgcn_s_sleep(16);
+    else if (s.sleep_max >= 48) __builtin_amdgcn_s_sleep(48);
+    else __builtin_amdgcn_s_sleep(32);
     known = stream_progress(s, q, lane);
   }
 }
 
 // LONG changes nothing but the kernel's NAME: launches of more than 256 time rows are a different workload (a run, not
 // a step of a closed loop) and get their own line in a profiler's per-kernel statistics.
-template <class Cell, int SPK, int CPB, bool LONG>
-__global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell cell, const StreamArgs s) {
+// WAVES: 4, or 12 = the RESERVING shape (riab_hip.h "Residency"): a workgroup of twelve waves is three per SIMD, two
+// such workgroups fill 6 of a SIMD's 8 wave slots and a third does not fit, so one slot per SIMD stays free on every
+// compute unit for a trajectory workgroup whatever this kernel does.  Waves 4g .. 4g+3 of a workgroup take cell group
+// 3 * blockIdx.y + g: the same (1024 agents) x (CPB cells) tile per four waves as in the four-wave shape.
+template <class Cell, int SPK, int CPB, bool LONG, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rate_kernel_gated(const RateArgs a, Cell cell, const StreamArgs s) {
   __shared__ double s_lds[Cell::LDS_DOUBLES];
   cell.stage(s_lds);
   constexpr int NP = Cell::NP;
   static_assert(NP * CPB <= 64, "a cell group's parameters must fit one wave");
+  static_assert(WAVES % 4 == 0, "four waves share a (1024 agents) x (CPB cells) tile");
   const int lane = threadIdx.x & 63;
-  const int c0 = blockIdx.y * CPB;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int c0 = (int)(blockIdx.y * (WAVES / 4) + (wv >> 2)) * CPB;
   const uint32_t t = blockIdx.z;
-  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
-  const uint32_t wq = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
-  if (wq * 64u >= (uint32_t)a.qrow) return;  // (B is a multiple of 256: whole waves)
+  const uint32_t q = blockIdx.x * 256u + (threadIdx.x & 255u);
+  const uint32_t wq = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (uint32_t)(wv & 3)));
+  if (wq * 64u >= (uint32_t)a.qrow || c0 >= a.n) return;  // (B is a multiple of 256: whole waves)
   // one coalesced load brings the whole group's parameters into the wave (independent of the trajectory)
   const int pi = c0 * NP + lane;
   const float mine = (lane < NP * CPB && pi < a.n * NP) ? cell.tab[pi] : 0.0f;
@@ -622,9 +632,16 @@ __global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell 
   // first one dispatched) leaves its start, the workgroups of the last cell group of the last time row (the last ones
   // dispatched) the latest end, after their stores have been acknowledged.  (A first version let every wave of the
   // first / last ROW take part: 4096 device-scope atomics on two words, 86 instead of 60 us per launch.)
-  if (s.stamps && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+  const bool grid_first = t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && wv == 0;
+  if (s.stamps && grid_first && lane == 0)
     __hip_atomic_store((gu64*)(uintptr_t)(s.ctrl + RIAB_CTRL_STAMPS), (unsigned long long)__builtin_amdgcn_s_memrealtime(),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // The two kernels are meant to run side by side.  When the grid's first wave finds EVERY row of the call published
+  // already, the trajectory kernel had finished before the rate stage began — both streams on one hardware queue
+  // (DESIGN.md 7): counted, the host warns (Agent.diagnostics["pipeline_serialised"]).
+  if (s.serial_rows >= 8u && grid_first) {
+    if (stream_progress(s, wq, lane) >= (int)s.serial_rows && lane == 0) atomicAdd(s.ctrl + RIAB_CTRL_SERIALISED, 1u);
+  }
 #ifdef RIAB_PIPE_PROFILE  // (tools/pipe_profile.py: per time row, on the device's constant clock, u64 words behind the ctrl block)
   gu64* const dbg = (gu64*)(uintptr_t)(s.ctrl + 2048);
   const bool first_wg = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
@@ -658,12 +675,12 @@ __global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell 
     }
   }
 #ifdef RIAB_PIPE_PROFILE
-  if (blockIdx.y + 1 == gridDim.y && blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {  // the row's last workgroup is done
+  if (c0 + CPB >= a.n && blockIdx.x + 1 == gridDim.x && (threadIdx.x & 255u) == 0) {  // the row's last workgroup is done
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dbg[3 * 64 + t] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
   }
 #endif
-  if (s.stamps && t + 1 == gridDim.z && blockIdx.y + 1 == gridDim.y) {
+  if (s.stamps && t + 1 == gridDim.z && c0 + CPB >= a.n) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0)
       __hip_atomic_fetch_max((gu64*)(uintptr_t)(s.ctrl + RIAB_CTRL_STAMPS + 2), (unsigned long long)__builtin_amdgcn_s_memrealtime(),
@@ -677,24 +694,27 @@ __global__ __launch_bounds__(256) void rate_kernel_gated(const RateArgs a, Cell 
 //                  they wait for still needs;
 //   progress gate  (n_traj > 0) additionally returns only once all n_traj trajectory workgroups have published
 //                  `progress_target` steps: what follows on the stream is a plain rate kernel for rows below that.
+//   `final_target` != 0 (the FIRST gate of a chunk-form call of >= 8 rows): the progress every workgroup has reached
+//                  when its last row is out; a gate that finds ALL of them there at its very first look counts the call
+//                  in ctrl[RIAB_CTRL_SERIALISED] (the trajectory kernel had finished before the rate stage began).
 __global__ __launch_bounds__(64) void stream_gate_kernel(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj,
                                                          uint32_t progress_target, uint32_t spin_limit, uint32_t sleep_long,
-                                                         uint32_t reset_stamps) {
+                                                         uint32_t final_target) {
   const int lane = threadIdx.x;
-  if (reset_stamps && lane == 0) {  // (the rate kernel that follows on this stream records min(start) / max(end))
-    __hip_atomic_store((gu64*)(uintptr_t)(ctrl + RIAB_CTRL_STAMPS), ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store((gu64*)(uintptr_t)(ctrl + RIAB_CTRL_STAMPS + 2), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   for (uint32_t spins = 0;; ++spins) {
     const uint32_t v = __hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_STARTED), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool ok = (int32_t)(v - started_target) >= 0;
+    bool all_done = ok && final_target != 0u && spins == 0u;
     if (ok) {
       for (uint32_t w = lane; w < n_traj; w += 64) {
         const uint32_t p = __hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_PROGRESS_WORD(w)), __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT);
         ok = ok && (int32_t)(p - progress_target) >= 0;
+        all_done = all_done && (int32_t)(p - final_target) >= 0;
       }
     }
+    if (spins == 0u && final_target != 0u && n_traj > 0u && __builtin_amdgcn_ballot_w64(!all_done) == 0 && lane == 0)
+      atomicAdd(ctrl + RIAB_CTRL_SERIALISED, 1u);
     if (__builtin_amdgcn_ballot_w64(!ok) == 0) return;
     if (__hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     if (spins >= spin_limit) {
@@ -826,6 +846,8 @@ static int place_dispatch(const RiabEnv* env, const RiabRateIO* io, const float*
 // hipExtLaunchKernel; per thread, set and cleared by launch_rate_stream)
 static thread_local hipEvent_t t_stream_ev0 = nullptr, t_stream_ev1 = nullptr;
 
+static thread_local bool t_stream_reserve = false;  // launch the reserving (twelve-wave) shape: set by launch_rate_stream
+
 template <class Cell>
 static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamArgs& st, int T, bool spikes, bool dry_run,
                               hipStream_t s) {
@@ -836,19 +858,46 @@ static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamA
   constexpr int CPB = (Cell::NP * 2 * Cell::CPB <= 64) ? 2 * Cell::CPB : Cell::CPB;
   const int64_t groups = (a.n + CPB - 1) / CPB;
   if (T > 65535 || groups > 65535) return RIAB_ETOOBIG;  // grid y / z limits: the caller splits longer runs
+  const bool reserve = t_stream_reserve;
+  const bool lng = T > 256;
+  if (reserve) {
+    // The reserving shape keeps its promise (riab_hip.h "Residency") only while wave slots are the ONLY resource it can
+    // exhaust: two twelve-wave workgroups per compute unit are six waves per SIMD, and next to them a trajectory
+    // workgroup's 224 registers per lane must still fit the SIMD's 512: at most 48 per lane here (the euclidean /
+    // periodic place, grid and head-direction kernels hold 32-40; the line-of-sight and geodesic ones 88-96, where one
+    // more register class would fit two workgroups and leave too little).  Asked of the code object once per kernel.
+    static int regs[4] = {0, 0, 0, 0};
+    int& r = regs[(spikes ? 2 : 0) + (lng ? 1 : 0)];
+    if (r == 0) {
+      hipFuncAttributes attr;
+      const void* f = spikes ? (lng ? (const void*)rate_kernel_gated<Cell, 1, CPB, true, 12> : (const void*)rate_kernel_gated<Cell, 1, CPB, false, 12>)
+                             : (lng ? (const void*)rate_kernel_gated<Cell, 0, CPB, true, 12> : (const void*)rate_kernel_gated<Cell, 0, CPB, false, 12>);
+      r = (hipFuncGetAttributes(&attr, f) == hipSuccess && attr.numRegs > 0) ? attr.numRegs : 1 << 20;
+      (void)hipGetLastError();
+    }
+    if (r > 48) return RIAB_EUNSUPPORTED;  // (the caller falls back to the started gate and the four-wave shape)
+  }
   if (dry_run) return RIAB_OK;  // (every argument check is above: nothing is launched)
-  const dim3 grid((unsigned)((a.qrow + 255) / 256), (unsigned)groups, (unsigned)T), block(256);
+  const dim3 grid((unsigned)((a.qrow + 255) / 256), (unsigned)(reserve ? (groups + 2) / 3 : groups), (unsigned)T);
+  const dim3 block(reserve ? 768 : 256);
   auto go = [&](auto kernel) {
     if (ev0 || ev1) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, ev0, ev1, 0u, a, cell, st);
     else hipLaunchKernelGGL(kernel, grid, block, 0, s, a, cell, st);
   };
-  const bool lng = T > 256;
-  if (spikes) {
-    if (lng) go(rate_kernel_gated<Cell, 1, CPB, true>);
-    else go(rate_kernel_gated<Cell, 1, CPB, false>);
+  if (reserve) {  // (short calls of one population from an idle stream: no spikes-with-LONG zoo needed, but keep all four)
+    if (spikes) {
+      if (lng) go(rate_kernel_gated<Cell, 1, CPB, true, 12>);
+      else go(rate_kernel_gated<Cell, 1, CPB, false, 12>);
+    } else {
+      if (lng) go(rate_kernel_gated<Cell, 0, CPB, true, 12>);
+      else go(rate_kernel_gated<Cell, 0, CPB, false, 12>);
+    }
+  } else if (spikes) {
+    if (lng) go(rate_kernel_gated<Cell, 1, CPB, true, 4>);
+    else go(rate_kernel_gated<Cell, 1, CPB, false, 4>);
   } else {
-    if (lng) go(rate_kernel_gated<Cell, 0, CPB, true>);
-    else go(rate_kernel_gated<Cell, 0, CPB, false>);
+    if (lng) go(rate_kernel_gated<Cell, 0, CPB, true, 4>);
+    else go(rate_kernel_gated<Cell, 0, CPB, false, 4>);
   }
   return (int)hipGetLastError();
 }
@@ -897,11 +946,12 @@ int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B) {
 
 int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t T, float dt,
                        uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, uint32_t spin_limit, bool stamps,
-                       hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, bool dry_run) {
+                       hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, bool dry_run, bool reserve,
+                       uint32_t serial_rows) {
   struct EventScope {
-    EventScope(hipEvent_t a, hipEvent_t b) { t_stream_ev0 = a; t_stream_ev1 = b; }
-    ~EventScope() { t_stream_ev0 = t_stream_ev1 = nullptr; }
-  } scope(ev_start, ev_stop);
+    EventScope(hipEvent_t a, hipEvent_t b, bool r) { t_stream_ev0 = a; t_stream_ev1 = b; t_stream_reserve = r; }
+    ~EventScope() { t_stream_ev0 = t_stream_ev1 = nullptr; t_stream_reserve = false; }
+  } scope(ev_start, ev_stop, reserve);
   int rc = stream_supported(env, pop, B);
   if (rc) return rc;
   if (!hist || !ctrl || !pop->rates_base || T <= 0 || pop->capacity_rows < T || agent_id0 % 4) return RIAB_EINVAL;
@@ -933,6 +983,8 @@ int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const floa
   st.step_base = (uint32_t)step0;
   st.spin_limit = spin_limit;
   st.stamps = stamps ? 1u : 0u;
+  st.sleep_max = (uint32_t)g_options[RIAB_OPT_POLL_SLEEP];
+  st.serial_rows = serial_rows;
   const bool spikes = pop->spikes_base != nullptr;
   switch (pop->kind) {
     case RIAB_POP_PLACE:
@@ -962,9 +1014,9 @@ int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const floa
 }
 
 int launch_stream_gate(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj, uint32_t progress_target,
-                       uint32_t spin_limit, bool sleep_long, bool reset_stamps, hipStream_t s) {
+                       uint32_t spin_limit, bool sleep_long, uint32_t final_target, hipStream_t s) {
   hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(64), 0, s, ctrl, started_target, n_traj, progress_target, spin_limit,
-                     sleep_long ? 1u : 0u, reset_stamps ? 1u : 0u);
+                     sleep_long ? 1u : 0u, final_target);
   return (int)hipGetLastError();
 }
 
@@ -1123,11 +1175,12 @@ extern "C" int riab_fill(void* dst, int64_t bytes, float value, riab_stream_t st
 }
 
 namespace riab {
-int g_options[RIAB_OPT_COUNT] = {0, 1, 1, 0};
+int g_options[RIAB_OPT_COUNT] = {0, 1, 1, 0, 4, 48};
 }
 extern "C" int riab_set_option(int32_t option, int32_t value) {
-  static const int hi[RIAB_OPT_COUNT] = {2, 1, 1, 1};
-  if (option < 0 || option >= RIAB_OPT_COUNT || value < 0 || value > hi[option]) return RIAB_EINVAL;
+  static const int lo[RIAB_OPT_COUNT] = {0, 0, 0, 0, 0, 1};
+  static const int hi[RIAB_OPT_COUNT] = {2, 1, 1, 1, 64, 127};
+  if (option < 0 || option >= RIAB_OPT_COUNT || value < lo[option] || value > hi[option]) return RIAB_EINVAL;
   const int old = riab::g_options[option];
   riab::g_options[option] = value;
   return old;
@@ -1144,6 +1197,7 @@ extern "C" const char* riab_strerror(int code) {
     case RIAB_EUNSUPPORTED: return "combination not supported on device";
     case RIAB_EFULL: return "a step plan's history chunk is full: attach a new chunk";
     case RIAB_EPARTIAL: return "a launch failed after the trajectory kernel had been launched: the state has advanced, the rates of this call are incomplete";
+    case RIAB_ECHANGED: return "a watched host array differs from its snapshot: the cached device tables are stale (nothing was launched)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown riab error";
   }
 }

@@ -35,6 +35,7 @@
 // each other on the caller's stream.
 #include <hip/hip_ext.h>
 
+#include <cstring>
 #include <new>
 #include <vector>
 
@@ -47,13 +48,27 @@ int launch_agent_plain(const AgentArgs& a, hipStream_t s);
 int stream_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
 int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const float* hist, int64_t B, int32_t T, float dt,
                        uint64_t seed, uint64_t step0, int64_t agent_id0, uint32_t* ctrl, uint32_t spin_limit, bool stamps,
-                       hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, bool dry_run);
+                       hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, bool dry_run, bool reserve,
+                       uint32_t serial_rows);
 int launch_stream_gate(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj, uint32_t progress_target,
-                       uint32_t spin_limit, bool sleep_long, bool reset_stamps, hipStream_t s);
+                       uint32_t spin_limit, bool sleep_long, uint32_t final_target, hipStream_t s);
 }  // namespace riab
 
 struct RiabStreamer {
-  hipStream_t side;          // the trajectory kernel's stream
+  hipStream_t side;          // the trajectory kernel's stream (SIDE_STREAM 0: highest priority; 1: side_normal below)
+  hipStream_t side_normal;   // ... at the default priority (created when RIAB_STREAMER_OPT_SIDE_STREAM = 1 is first used)
+  int side_mode;             // RIAB_STREAMER_OPT_SIDE_STREAM
+  // form selection (populations form against chunk form): a trajectory step next to the rate stage / the lead's store rate
+  int64_t step_ns_cfg, lead_mbps_cfg;    // configured (0: measure)
+  int64_t step_ns_meas, lead_mbps_meas;  // measured from the stamps of an earlier call (0: not yet)
+  bool calibrated;                       // the one blocking read of the stamps has been made (or given up)
+  // what the last call left for that measurement: its ctrl block, rows, walls, the lead's bytes per row (0: no lead)
+  uint32_t* prev_ctrl;
+  int32_t prev_T, prev_walls;
+  int64_t prev_lead_row_bytes;
+  uint32_t progress_end;     // (uint32) step0 + T of the last call on prev_ctrl: a later call must start at or beyond it
+  bool progress_valid;
+  int last_launches;         // kernel launches of the last call
   hipEvent_t fork, join;     // caller's stream -> side (only when the caller's stream is busy), side -> caller's stream
   hipEvent_t t0, t1;         // HIP-event timing of the rate kernel (created on first use)
   std::vector<hipEvent_t> pairs;  // chunk form: (start, stop) around every launch of the timed population
@@ -71,13 +86,22 @@ struct RiabStreamer {
 extern "C" RiabStreamer* riab_streamer_create(void) {
   RiabStreamer* h = new (std::nothrow) RiabStreamer();
   if (!h) return nullptr;
-  h->side = nullptr;
+  h->side = h->side_normal = nullptr;
+  h->side_mode = 0;
+  h->step_ns_cfg = h->lead_mbps_cfg = h->step_ns_meas = h->lead_mbps_meas = 0;
+  h->calibrated = false;
+  h->prev_ctrl = nullptr;
+  h->prev_T = h->prev_walls = 0;
+  h->prev_lead_row_bytes = 0;
+  h->progress_end = 0;
+  h->progress_valid = false;
+  h->last_launches = 0;
   h->fork = h->join = h->t0 = h->t1 = nullptr;
   h->timed = 0;
   h->n_pairs = 0;
   h->stamp_ctrl = nullptr;
   h->started_total = 0;
-  h->gate_mode = RIAB_GATE_ALWAYS;
+  h->gate_mode = RIAB_GATE_RESERVED;
   h->poll_max = 65535;
   h->head_rows = 256;
   h->last_form = RIAB_FORM_NONE;
@@ -105,8 +129,22 @@ extern "C" int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t 
   if (!h) return RIAB_EINVAL;
   switch (option) {
     case RIAB_STREAMER_OPT_GATE:
-      if (value != RIAB_GATE_ALWAYS && value != RIAB_GATE_WHEN_BUSY) return RIAB_EINVAL;
+      if (value != RIAB_GATE_ALWAYS && value != RIAB_GATE_WHEN_BUSY && value != RIAB_GATE_RESERVED) return RIAB_EINVAL;
       h->gate_mode = value;
+      return RIAB_OK;
+    case RIAB_STREAMER_OPT_SIDE_STREAM:
+      if (value < 0 || value > 2) return RIAB_EINVAL;
+      if (value == 1 && !h->side_normal && hipStreamCreateWithFlags(&h->side_normal, hipStreamNonBlocking) != hipSuccess)
+        return RIAB_EINVAL;
+      h->side_mode = value;
+      return RIAB_OK;
+    case RIAB_STREAMER_OPT_STEP_NS:
+      if (value < 0) return RIAB_EINVAL;
+      h->step_ns_cfg = value;
+      return RIAB_OK;
+    case RIAB_STREAMER_OPT_LEAD_MBPS:
+      if (value < 0) return RIAB_EINVAL;
+      h->lead_mbps_cfg = value;
       return RIAB_OK;
     case RIAB_STREAMER_OPT_POLL_MAX:
       if (value < 0 || value > 65535) return RIAB_EINVAL;
@@ -128,10 +166,60 @@ extern "C" void riab_streamer_destroy(RiabStreamer* h) {
   if (h->join) (void)hipEventDestroy(h->join);
   if (h->fork) (void)hipEventDestroy(h->fork);
   if (h->side) (void)hipStreamDestroy(h->side);
+  if (h->side_normal) (void)hipStreamDestroy(h->side_normal);
   delete h;
 }
 
 extern "C" int riab_streamer_last_form(RiabStreamer* h) { return h ? h->last_form : RIAB_FORM_NONE; }
+
+// ---- what the choice "populations form or chunk form" compares ----------------------------------------------------------
+// The lead's stores of a row must take at least 1.5 x as long as a trajectory step next to it, or the row-following
+// kernel sits waiting for rows while nothing else runs.  Built-in figures [MI355X]: a trajectory step takes 0.9 us in
+// an open room + 0.25 us per further wall (cfg 2 / cfg 5 next to their rate stage: 0.85-1.1 us, cfg 3's nine walls
+// 2.05); a store-bound population writes 6.5 TB/s.  They are the fallback: the streamer MEASURES both on the chip it
+// runs on from the device-clock stamps every call leaves in its control block (trajectory workgroup 0's start / last
+// publication; the row-following kernel's first-wave start / last-wave end) — read once, by the first call with
+// several populations that finds the caller's stream idle (the earlier call is then known to have finished), and kept
+// as a factor on the built-in step time (rooms differ in walls, chips in clocks).
+static double builtin_step_ns(int n_walls) { return 900.0 + 250.0 * (n_walls > 4 ? n_walls - 4 : 0); }
+
+static void calibrate_from_stamps(RiabStreamer* h) {
+  if (!h->prev_ctrl || h->prev_T < 8) return;  // (nothing to read yet: try again at the next call)
+  h->calibrated = true;                         // one blocking copy per streamer, not one per call
+  unsigned long long st[4] = {0, 0, 0, 0};      // STAMPS (2 x u64) and TRAJ_STAMPS (2 x u64): words 8 .. 15
+  static_assert(RIAB_CTRL_TRAJ_STAMPS == RIAB_CTRL_STAMPS + 4, "the two stamp pairs are read with one copy");
+  if (hipMemcpy(st, h->prev_ctrl + RIAB_CTRL_STAMPS, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return;
+  const double tick_ns = 1e6 / (double)h->wall_khz;
+  if (st[3] > st[2]) {
+    const double step = (double)(st[3] - st[2]) * tick_ns / (double)h->prev_T;
+    if (step > 50.0 && step < 1e6) h->step_ns_meas = (int64_t)(step * 1000.0 / builtin_step_ns(h->prev_walls));  // per mille
+  }
+  if (h->prev_lead_row_bytes > 0 && st[1] > st[0]) {
+    const double ns = (double)(st[1] - st[0]) * tick_ns;
+    const double mbps = (double)h->prev_lead_row_bytes * (double)h->prev_T / ns * 1e3;  // bytes / ns = GB/s; x 1e3 = MB/s
+    if (mbps > 1e4 && mbps < 2e7) h->lead_mbps_meas = (int64_t)mbps;
+  }
+}
+
+static double step_ns_now(const RiabStreamer* h, int n_walls) {
+  if (h->step_ns_cfg) return (double)h->step_ns_cfg;
+  const double b = builtin_step_ns(n_walls);
+  return h->step_ns_meas ? b * (double)h->step_ns_meas / 1000.0 : b;
+}
+static double lead_mbps_now(const RiabStreamer* h) {
+  return h->lead_mbps_cfg ? (double)h->lead_mbps_cfg : (h->lead_mbps_meas ? (double)h->lead_mbps_meas : 6.5e6);
+}
+
+extern "C" int64_t riab_streamer_info(RiabStreamer* h, int32_t which) {
+  if (!h) return -1;
+  switch (which) {
+    case 0: return (int64_t)step_ns_now(h, 4);
+    case 1: return (int64_t)lead_mbps_now(h);
+    case 2: return (h->step_ns_cfg == 0 && h->step_ns_meas != 0) ? 1 : 0;
+    case 3: return h->last_launches;
+    default: return -1;
+  }
+}
 
 extern "C" float riab_streamer_last_rate_ms(RiabStreamer* h) {
   if (!h || !h->timed) return -1.0f;
@@ -153,6 +241,7 @@ extern "C" float riab_streamer_last_rate_ms(RiabStreamer* h) {
   if (hipEventElapsedTime(&ms, h->t0, h->t1) != hipSuccess) return -1.0f;
   return ms;
 }
+
 
 // ---- any set of populations: the chunked form of the rate stage for all of them, one native call ----------------
 // rows [t0, t0 + tc) of population i from the trajectory rows of the same chunk (the T-row form of riab_plan.hip's
@@ -266,6 +355,16 @@ static std::vector<int32_t> chunk_schedule(const RiabEnv* env, int32_t T) {
   return sched;
 }
 
+extern "C" int riab_watch_compare(const RiabWatch* watch, int32_t n) {
+  if (n < 0 || (n > 0 && !watch)) return RIAB_EINVAL;
+  for (int32_t i = 0; i < n; ++i) {
+    const RiabWatch& w = watch[i];
+    if (w.bytes < 0 || (w.bytes > 0 && (!w.live || !w.snapshot))) return RIAB_EINVAL;
+    if (w.bytes > 0 && memcmp(w.live, w.snapshot, (size_t)w.bytes) != 0) return RIAB_ECHANGED;
+  }
+  return RIAB_OK;
+}
+
 extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream_t stream) {
   if (!h || !q || !q->env || !q->motion || !q->ctrl || !q->hist || q->n_pops < 0 || (q->n_pops > 0 && !q->pops) || q->T <= 0)
     return RIAB_EINVAL;
@@ -275,7 +374,10 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   const int64_t B = q->B;
   if (B <= 0 || B % 4 != 0) return RIAB_EALIGN;
   if (q->forced_pos && (q->noise || q->drift)) return RIAB_EINVAL;
-  int rc = check_populations(pops, n_pops, T);
+  // the caller's cached tables against the host arrays they were built from (RiabSimulate.watch): before anything else
+  int rc = riab_watch_compare(q->watch, q->n_watch);
+  if (rc) return rc;
+  rc = check_populations(pops, n_pops, T);
   if (rc) return rc;
   riab::AgentArgs a;
   rc = riab::fill_agent_args(a, env, q->motion, q->state, B, q->agent_id0, q->drift, q->noise, nullptr, q->forced_pos, q->seed,
@@ -289,8 +391,12 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   h->n_pairs = 0;
 
   h->last_form = RIAB_FORM_NONE;
+  h->last_launches = 0;
   // ---- an agent without populations: the trajectory alone, on the caller's stream -----------------------------------
-  if (n_pops == 0) return riab::launch_agent_plain(a, main_s);
+  if (n_pops == 0) {
+    h->last_launches = 1;
+    return riab::launch_agent_plain(a, main_s);
+  }
 
   // ---- forced positions: no recurrence, nothing to overlap: one stream, kernel after kernel --------------------------
   if (q->forced_pos) {
@@ -334,8 +440,13 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
           lead = i;
         }
       }
-      const double step_us = (0.9 + 0.25 * (env->n_walls > 4 ? env->n_walls - 4 : 0)) * 1.5;
-      if ((double)best / 6.5e6 < step_us) lead = -1;
+      // (the lead's stores of a row against 1.5 trajectory steps: measured on this chip once an earlier call's stamps can
+      // be read without waiting — the caller's stream is idle —, the MI355X constants until then: builtin_step_ns)
+      if (lead >= 0) {
+        if (!h->calibrated && h->step_ns_cfg == 0 && hipStreamQuery((hipStream_t)stream) == hipSuccess) calibrate_from_stamps(h);
+        const double row_ns = (double)best / lead_mbps_now(h) * 1e3;  // bytes / (MB/s) = us; x 1e3 = ns
+        if (row_ns < 1.5 * step_ns_now(h, env->n_walls)) lead = -1;
+      }
     }
   }
   // Very long runs (more than 2048 rows): the row-following kernel serves the first `head_rows` rows — by then the
@@ -350,10 +461,14 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   h->last_form = lead < 0 ? RIAB_FORM_CHUNKS
                           : (n_pops > 1 ? RIAB_FORM_POPULATIONS : (pure ? RIAB_FORM_ONE_KERNEL : RIAB_FORM_HEAD_AND_PIECES));
   const int32_t rest_piece = 1024;  // rows per launch of another population (their kernels' grids, the noise pass's loop)
+  bool reservable = false;
   if (lead >= 0) {
     rc = riab::launch_rate_stream(env, &pops[lead], q->hist, B, head, dt, q->seed, q->step0, q->agent_id0, q->ctrl, spin_limit,
-                                  false, main_s, nullptr, nullptr, /*dry_run=*/true);
+                                  false, main_s, nullptr, nullptr, /*dry_run=*/true, false, 0u);
     if (rc) return rc;
+    if (pure && h->gate_mode == RIAB_GATE_RESERVED)
+      reservable = riab::launch_rate_stream(env, &pops[lead], q->hist, B, head, dt, q->seed, q->step0, q->agent_id0, q->ctrl,
+                                            spin_limit, false, main_s, nullptr, nullptr, /*dry_run=*/true, true, 0u) == RIAB_OK;
     if (pure && q->timing_mode == RIAB_TIMING_EVENTS && timing && !h->t0) {
       if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess) return RIAB_EINVAL;
     }
@@ -381,16 +496,32 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   // stream is idle — the case that matters for latency: one short call per synchronisation — there is nothing to wait
   // for and the launch goes out with no API call in front of it but the query; otherwise an event carries the order.
   const bool idle = hipStreamQuery(main_s) == hipSuccess;
-  if (!idle) {
+  // (RIAB_STREAMER_OPT_SIDE_STREAM: 1 a stream at the default priority, 2 the caller's own stream — the two kernels then
+  // run one after the other, which is what the RIAB_CTRL_SERIALISED diagnostic is tested with)
+  const hipStream_t side_s = h->side_mode == 2 ? main_s : (h->side_mode == 1 && h->side_normal ? h->side_normal : h->side);
+  if (!idle && side_s != main_s) {
     hipError_t e = hipEventRecord(h->fork, main_s);
-    if (e == hipSuccess) e = hipStreamWaitEvent(h->side, h->fork, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side_s, h->fork, 0);
     if (e != hipSuccess) return (int)e;
   }
+  // Progress words hold absolute step counts and every trajectory workgroup resets its own to step0 before it
+  // announces itself.  A call that starts at or beyond the end of the last call on this block can never meet a word
+  // above its own rows; any other call (the same block replayed, another ctrl block) must not let a consumer look at
+  // the words before every workgroup has announced itself: it takes the started gate.
+  const bool monotonic = h->progress_valid && h->prev_ctrl == q->ctrl && (int32_t)((uint32_t)q->step0 - h->progress_end) >= 0;
   bool state_published = false;
-  rc = riab::launch_agent_pub(a, h->side, &state_published);
+  rc = riab::launch_agent_pub(a, side_s, &state_published);
   if (rc) return rc;
+  h->last_launches = 1;
   const uint32_t n_traj = (uint32_t)((B + 63) / 64);
   h->started_total += n_traj;
+  h->prev_ctrl = q->ctrl;
+  h->prev_T = T;
+  h->prev_walls = env->n_walls;
+  h->prev_lead_row_bytes = 0;
+  h->progress_end = (uint32_t)q->step0 + (uint32_t)T;
+  h->progress_valid = true;
+  const uint32_t serial_rows = T >= 8 ? (uint32_t)T : 0u;
   // From here on the state has advanced: a later failure still joins the two streams and is reported as RIAB_EPARTIAL
   // (the trajectory rows are complete, the rates of this call are not).
   int fail = RIAB_OK;
@@ -401,21 +532,37 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
     // another process: two ranks sharing one GPU ran into the waits' time limit without it).  RIAB_GATE_WHEN_BUSY drops
     // it when the caller's stream was idle (callers that own the device).  The gate also resets the device time stamps.
     const bool timed_lead = timing && q->timed_pop == lead;
-    const bool stamps = pure && timed_lead && q->timing_mode != RIAB_TIMING_EVENTS;
-    const bool events = pure && timed_lead && !stamps;
-    const bool gate = stamps || h->gate_mode == RIAB_GATE_ALWAYS || !idle || !pure;
+    const bool events = pure && timed_lead && q->timing_mode == RIAB_TIMING_EVENTS;
+    // (device-clock stamps of the row-following kernel: one store by the grid's first wave, one maximum by the sixteen
+    // waves of the last row's last cell group — always on unless HIP events time the launch; they need no reset: the
+    // clock only moves forward)
+    const bool stamps = !events;
+    // residency (riab_hip.h): the reserving shape of the row-following kernel needs no gate; everything else takes one —
+    // unless the caller has said that it owns the device (RIAB_GATE_WHEN_BUSY) and its stream is idle
+    const bool quiet = idle && pure && monotonic && side_s != main_s;
+    // (the reserving shape is only offered by kernels whose registers leave a trajectory workgroup room: launch_stream_cell)
+    const bool reserve = quiet && h->gate_mode == RIAB_GATE_RESERVED && reservable;
+    const bool gate = !(reserve || (quiet && h->gate_mode == RIAB_GATE_WHEN_BUSY)) && side_s != main_s;
     // (the started gate is one sleeping wave; it may have to sit out whatever runs in front of the trajectory kernel)
-    if (gate) fail = riab::launch_stream_gate(q->ctrl, h->started_total, 0, 0, 1u << 24, true, stamps, main_s);
+    if (gate) {
+      fail = riab::launch_stream_gate(q->ctrl, h->started_total, 0, 0, 1u << 24, true, 0u, main_s);
+      ++h->last_launches;
+    }
     int n_timed = 0;
     if (timed_lead && !pure) (void)hipEventRecord(h->pairs[0], main_s);
-    if (!fail)
+    if (!fail) {
       fail = riab::launch_rate_stream(env, &pops[lead], q->hist, B, head, dt, q->seed, q->step0, q->agent_id0, q->ctrl,
-                                      spin_limit, stamps, main_s, events ? h->t0 : nullptr, events ? h->t1 : nullptr, false);
+                                      spin_limit, stamps, main_s, events ? h->t0 : nullptr, events ? h->t1 : nullptr, false,
+                                      reserve, serial_rows);
+      ++h->last_launches;
+      if (head == T) h->prev_lead_row_bytes = (int64_t)pops[lead].n * B * (pops[lead].spikes_base ? 5 : 4);
+    }
     for (int32_t t0 = head; t0 < T && !fail; t0 += tail_piece) {
       const int32_t tc = T - t0 < tail_piece ? T - t0 : tail_piece;
       fail = riab::launch_stream_gate(q->ctrl, h->started_total, n_traj, (uint32_t)q->step0 + (uint32_t)(t0 + tc), 1u << 22,
-                                      false, false, main_s);
+                                      false, 0u, main_s);
       if (!fail) fail = launch_pop_rows(env, pops, lead, q->hist, B, t0, tc, dt, q->seed, q->step0, q->agent_id0, main_s);
+      h->last_launches += 2;
     }
     if (timed_lead && !pure) {
       (void)hipEventRecord(h->pairs[1], main_s);
@@ -438,7 +585,7 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
     }
     if (!fail && timing) {
       if (pure) {
-        h->timed = stamps ? 2 : 1;
+        h->timed = events ? 1 : 2;
         h->stamp_ctrl = q->ctrl;
       } else {
         h->n_pairs = n_timed;
@@ -453,7 +600,9 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
       const int32_t tc = sched[k];
       // ~0.5 us per poll: seconds before a gate gives up (a healthy wait is one chunk of trajectory, < 1 ms)
       fail = riab::launch_stream_gate(q->ctrl, h->started_total, n_traj, (uint32_t)q->step0 + (uint32_t)(t0 + tc),
-                                      k == 0 ? 1u << 24 : 1u << 22, false, false, main_s);
+                                      k == 0 ? 1u << 24 : 1u << 22, false,
+                                      (k == 0 && serial_rows) ? (uint32_t)q->step0 + (uint32_t)T : 0u, main_s);
+      h->last_launches += 1 + n_pops;
       for (int i = 0; i < n_pops && !fail; ++i) {
         if (timing && i == q->timed_pop) (void)hipEventRecord(h->pairs[2 * k], main_s);
         fail = launch_pop_rows(env, pops, i, q->hist, B, t0, tc, dt, q->seed, q->step0, q->agent_id0, main_s);
@@ -474,8 +623,8 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   // [MI355X, cfg 2, 20 steps: the event's record + wait were 4.7 us of host time and its barrier packet sat between the
   // rate kernel's end and the host's wake-up: 97 -> 89 us per call without them.]
   hipError_t e = hipSuccess;
-  if (!state_published || fail) {
-    e = hipEventRecord(h->join, h->side);
+  if ((!state_published || fail) && side_s != main_s) {
+    e = hipEventRecord(h->join, side_s);
     if (e == hipSuccess) e = hipStreamWaitEvent(main_s, h->join, 0);
   }
   if (fail) return RIAB_EPARTIAL;

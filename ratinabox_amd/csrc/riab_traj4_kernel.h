@@ -149,6 +149,24 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
   __shared__ __align__(16) float s_hist[4 * RIAB_HIST_ROWS * 64];                             // T: rows of one block
   __shared__ unsigned long long s_v2[64], s_f[64];                                            // G -> S: |v|^2;  S -> G: f
   __shared__ uint32_t s_cnt[T4_C_WORDS];
+  const RiabMotion& m = a.m;
+  const int64_t B = a.B;
+  const bool live = (int64_t)blockIdx.x * 64 + lane < B;
+  const int64_t b = live ? (int64_t)blockIdx.x * 64 + lane : (int64_t)blockIdx.x * 64;
+  const uint32_t aid = (uint32_t)(a.agent_id0 + b);
+  double* st = a.state + b;
+  const int T = a.T;
+  // ---- every wave asks for ITS part of the state first: the loads travel while the tables are staged (the state was
+  // written through by the previous launch and comes from memory: one round trip that used to sit between the barrier
+  // and the first step — and the first row's publication is what the rate stage of a short call waits for) ----
+  R pre0 = 0, pre1 = 0, pre2 = 0, pre3 = 0, pre4 = 0, pre5 = 0;
+  if (wave == 0) {
+    pre0 = st[0 * B]; pre1 = st[1 * B]; pre2 = st[2 * B]; pre3 = st[3 * B]; pre4 = st[11 * B];
+  } else if (wave == 2) {
+    pre0 = st[4 * B];
+  } else if (wave == 3) {
+    pre0 = st[5 * B]; pre1 = st[6 * B]; pre2 = st[7 * B]; pre3 = st[8 * B]; pre4 = st[9 * B]; pre5 = st[10 * B];
+  }
   // ---- staging by all four waves, one barrier ----
   stage_rayleigh_tables<256>(s_g, s_h, tid);
   stage_walls<R>(a, s_w, tid, 256);
@@ -160,13 +178,6 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
   __syncthreads();
   const t4_cnt_ptr cnt = (t4_cnt_ptr)s_cnt;
   const t4_slot_ptr slot_v2 = (t4_slot_ptr)&s_v2[lane], slot_f = (t4_slot_ptr)&s_f[lane];
-  const RiabMotion& m = a.m;
-  const int64_t B = a.B;
-  const bool live = (int64_t)blockIdx.x * 64 + lane < B;
-  const int64_t b = live ? (int64_t)blockIdx.x * 64 + lane : (int64_t)blockIdx.x * 64;
-  const uint32_t aid = (uint32_t)(a.agent_id0 + b);
-  double* st = a.state + b;
-  const int T = a.T;
   bool gave_up = false;  // a wait of this wave timed out (a partner is stuck): the launch ends, the error is reported
   // Latency-bound waves sharing their SIMDs with the bandwidth-bound rate kernels' waves: win the issue arbitration
   // whenever ready — all four (a noise or tail wave that falls behind stalls the other two through the rings).
@@ -176,9 +187,9 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
     // ================================ wave G: position and velocity ================================================
     const MotionConst<R> K = make_motion_const<R>(a, s_w);
     const R dt = K.dt;
-    R px = st[0 * B], py = st[1 * B];
-    R vx = st[2 * B], vy = st[3 * B];
-    R dwall = st[11 * B];
+    R px = pre0, py = pre1;
+    R vx = pre2, vy = pre3;
+    R dwall = pre4;
     R drx = 0, dry = 0;
     if (m.has_drift) {
       drx = a.drift[b];
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
   } else if (wave == 2) {
     // ================================ wave N: noise and the rotational-velocity OU =================================
     const R dt = (R)m.dt;
-    R rot = st[4 * B];
+    R rot = pre0;
     u32x4 pw = {0u, 0u, 0u, 0u};
     uint32_t g_done = 0;
     // explicit normals: the loads of four steps are issued together (one memory round trip per four steps)
@@ -382,11 +393,24 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
     // ================================ wave T: output-only tail, history rows, publication ==========================
     const TailConst<R> tail_c = {(R)m.dt, (R)(1.0 / m.dt), (R)(1.0 - m.dt / m.hd_tau), (R)(m.dt / m.hd_tau),
                                  m.hd_tau <= m.dt};
-    StepTail<R> tl{st[5 * B], st[6 * B], st[7 * B], st[8 * B], st[9 * B], st[10 * B], 0};
+    StepTail<R> tl{pre0, pre1, pre2, pre3, pre4, pre5, 0};
 #ifdef RIAB_PIPE_PROFILE
     if (PUB && lane == 0 && blockIdx.x == 0) ((unsigned long long*)(a.ctrl + 2048))[0] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    if (PUB && lane == 0) atomicAdd(a.ctrl + RIAB_CTRL_STARTED, 1u);  // this workgroup is resident
+    if (PUB && lane == 0) {
+      // This workgroup is resident.  Before it says so its progress word goes back to "no row of THIS launch yet":
+      // the words hold absolute step counts, and a launch that replays earlier steps (the same argument block run
+      // again) would otherwise let a consumer take the earlier run's count for its own.  Whoever has waited for the
+      // announcement (the started gate) finds the word reset; launches that continue where the last one ended never
+      // see a word above their own rows anyway.
+      __hip_atomic_store((riab_gu32*)(uintptr_t)(a.ctrl + RIAB_CTRL_PROGRESS_WORD(blockIdx.x)), (uint32_t)a.step0, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      if (blockIdx.x == 0)   // (device clock at the start of the trajectory: RIAB_STREAMER_OPT_STEP_NS measures with it)
+        __hip_atomic_store((riab_gu64*)(uintptr_t)(a.ctrl + RIAB_CTRL_TRAJ_STAMPS), (unsigned long long)__builtin_amdgcn_s_memrealtime(),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      atomicAdd(a.ctrl + RIAB_CTRL_STARTED, 1u);
+    }
     // PUB: rows of steps < n have left this wave write-through and been acknowledged: the consumer may read them
     auto publish = [&](int n) {
 #ifdef RIAB_PIPE_PROFILE  // (tools/pipe_profile.py)
@@ -406,7 +430,7 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
     int t0 = 0, pending = -1;  // pending: steps covered by flushed but unpublished blocks (-1: none)
     bool ok = true;
     while (t0 < T && ok) {
-      const int n = (t0 < 4) ? 1 : min(4, T - t0);
+      const int n = (t0 < a.pub_single) ? 1 : min(4, T - t0);
       for (int i = 0; i < n; ++i) {
         const int t = t0 + i;
         if ((uint32_t)t >= g_done) {
@@ -469,8 +493,14 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
       // every row, this wave's part of the state, and — once the position / velocity wave and the noise wave have
       // reported theirs — the whole state of these 64 agents is in memory: the publication that ends the launch
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (t4_wait_counter(cnt, T4_C_STATE, 1u, true)) publish(T);
-      else gave_up = true;
+      if (t4_wait_counter(cnt, T4_C_STATE, 1u, true)) {
+        if (lane == 0 && blockIdx.x == 0)
+          __hip_atomic_store((riab_gu64*)(uintptr_t)(a.ctrl + RIAB_CTRL_TRAJ_STAMPS + 2), (unsigned long long)__builtin_amdgcn_s_memrealtime(),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        publish(T);
+      } else {
+        gave_up = true;
+      }
     }
   }
   if (gave_up && lane == 0) {

@@ -115,3 +115,42 @@ def test_step_plan_validation_without_gpu(L):
     m.has_drift = 1
     assert L.lib.riab_plan_set_motion(h, m, None) == -1
     L.lib.riab_plan_destroy(h)
+
+
+def test_watch_list_and_fast_repeat_record(L):
+    """The short road of a repeated simulate() (Agent._fast_record / RiabSimulate.watch): the arrays a population's
+    tables derive from are watched by identity in Python and by CONTENT in the library (memcmp against a snapshot,
+    before anything is launched: RIAB_ECHANGED) — host memory only, no device needed."""
+    import numpy as np
+    import ratinabox_amd as riab
+    np.random.seed(0)
+    env = riab.Environment({})
+    ag = riab.Agent(env, {"n_agents": 8, "device": "cpu"})
+    pcs = riab.PlaceCells(ag, {"n": 16})
+    gcs = riab.GridCells(ag, {"n": 8})
+    hdc = riab.HeadDirectionCells(ag, {"n": 4})
+    rec = ag._fast_record([pcs, gcs, hdc])
+    assert rec is not None and rec["n_watch"] == 2 + 3 + 2 + 1          # centres, widths | scales, phases, w | angles, tunings | walls
+    w = C.addressof(rec["watch"])
+    assert L.lib.riab_watch_compare(w, rec["n_watch"]) == 0
+    pcs.place_cell_centres[-1] = [0.123, 0.456]                          # the in-place edit of reference tests/test_advanced.py:59
+    assert L.lib.riab_watch_compare(w, rec["n_watch"]) == L.ECHANGED
+    assert "snapshot" in L.strerror(L.ECHANGED)
+    rec = ag._fast_record([pcs, gcs, hdc])                               # (a new record holds the new content)
+    assert L.lib.riab_watch_compare(C.addressof(rec["watch"]), rec["n_watch"]) == 0
+    env.walls[0, 0, 0] += 1e-9
+    assert L.lib.riab_watch_compare(C.addressof(rec["watch"]), rec["n_watch"]) == L.ECHANGED
+    env.walls[0, 0, 0] -= 1e-9
+    # scalar parameters and replaced attributes are compared in Python: the getters return what the record holds
+    N, arrs, getter, sc = rec["pops"][0]
+    assert N is pcs and getter(pcs) == sc and all(getattr(pcs, name) is a for name, a in arrs)
+    pcs.max_fr = 2.0
+    assert getter(pcs) != sc
+    pcs.max_fr = 1.0
+    pcs.place_cell_widths = pcs.place_cell_widths.copy()                 # same content, another object: caught by identity
+    assert not all(getattr(pcs, name) is a for name, a in arrs)
+    # populations whose tables do not come straight from float64 array attributes have no record
+    assert ag._fast_record([riab.BoundaryVectorCells(ag, {"n": 4})]) is None
+    pcs.place_cell_centres = pcs.place_cell_centres.astype(np.float32)
+    assert ag._fast_record([pcs]) is None
+    assert L.lib.riab_watch_compare(None, 1) == -1 and L.lib.riab_watch_compare(None, 0) == 0
