@@ -39,6 +39,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_ALL_CPUS = None       # the process's affinity mask before bind_rank_to_gpu_numa narrowed it
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured-achievable copy
 # BoundaryVectorCells: one v_exp_f32 per (cell, direction, position) term is irreducible.  Issue rates of single
 # instructions measured on MI355X at 8 waves per SIMD (tools/exp_bench.hip, profiles/r03_exp_bench.txt), in cycles per
@@ -130,7 +131,7 @@ def cpu_baseline(cfg, seconds=8.0):
     one worker process per core (`oracle/cpu_bench.py`, single-threaded NumPy), each stepping its share of the
     GPU batch (agents / cores, at least 16) for `seconds` seconds; the rates add up.  The one-core figure on a
     256-agent batch (round 1's number) is kept beside it."""
-    cores = os.cpu_count() or 1
+    cores = len(_ALL_CPUS) if _ALL_CPUS else (os.cpu_count() or 1)
     B = cfg["agents"]
     per = max(16, B // cores)
     n = cfg["place"]
@@ -139,9 +140,12 @@ def cpu_baseline(cfg, seconds=8.0):
     if cfg["spikes"]:
         base.append("--spikes")
 
+    all_cpus = _ALL_CPUS or os.sched_getaffinity(0)   # (the workers run on every core, not on the rank's NUMA share)
+
     def launch(agents, secs, seed):
         return subprocess.Popen(base + ["--agents", str(agents), "--seconds", str(secs), "--seed", str(seed)],
-                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT, env=env, text=True)
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT, env=env, text=True,
+                                preexec_fn=lambda: os.sched_setaffinity(0, all_cpus))
 
     def collect(procs):
         total, longest, ok = 0.0, 0.0, 0
@@ -165,6 +169,95 @@ def cpu_baseline(cfg, seconds=8.0):
             "sample": f"{ok} single-threaded worker processes (one per host core) x {per} agents x ~{all_el:.1f} s of "
                       f"Agent.update + PlaceCells({n}).update, float64 NumPy oracle; {wall:.1f} s wall in total",
             "one_core": {"value": one_rate, "agents": 256, "seconds": round(one_el, 2)}}
+
+
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _format_cpulist(cpus):
+    cpus, out, i = sorted(cpus), [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def gpu_numa_nodes():
+    """[(numa node, [cpus of that node], pci address)] of the GPUs in the order the HIP runtime numbers them, from sysfs
+    only (no HIP call): the KFD topology lists the GPU nodes in the runtime's order and names each one's DRM render
+    node, whose PCI device carries `numa_node` / `local_cpulist`; ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES (integer lists)
+    are applied the way the runtime applies them."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    gpus = []
+    for node in sorted((d for d in os.listdir(base) if d.isdigit()), key=int):
+        props = {}
+        with open(os.path.join(base, node, "properties")) as f:
+            for line in f:
+                k, _, v = line.strip().partition(" ")
+                props[k] = v
+        if int(props.get("simd_count", "0")) <= 0:
+            continue  # a CPU node
+        dev = f"/sys/class/drm/renderD{int(props['drm_render_minor'])}/device"
+        with open(os.path.join(dev, "numa_node")) as f:
+            numa = int(f.read().strip())
+        with open(os.path.join(dev, "local_cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        gpus.append((numa, cpus, os.path.basename(os.path.realpath(dev))))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        sel = os.environ.get(var)
+        if sel is None or (var == "CUDA_VISIBLE_DEVICES" and "HIP_VISIBLE_DEVICES" in os.environ):
+            continue
+        idx = [int(x) for x in sel.split(",") if x.strip() != ""]   # (UUID lists raise: the caller reports "unbound")
+        gpus = [gpus[i] for i in idx]
+    return gpus
+
+
+def bind_rank_to_gpu_numa(local, n_local):
+    """Pin this process — before its first HIP call, so that the runtime's own threads inherit the mask — to cores of
+    the NUMA node its GPU hangs off.  Every rank spins on the host for a fifth of a 90 us region and `value` takes the
+    slowest rank of every repeat: a rank scheduled on the far socket, or two ranks sharing a core, would set the
+    8-GPU number.  Ranks whose GPUs share a node get disjoint, equal sets of whole cores (all hardware threads of a
+    core go to the same rank).  Returns what was done, for the bench line's `config`."""
+    try:
+        gpus = gpu_numa_nodes()
+        if local >= len(gpus):
+            return {"binding": "none", "why": f"{len(gpus)} GPUs found in sysfs, local rank {local}"}
+        numa, cpus, pci = gpus[local]
+        allowed = os.sched_getaffinity(0)
+        cpus = [c for c in cpus if c in allowed]
+        if numa < 0 or not cpus:
+            return {"binding": "none", "why": f"GPU {pci}: numa_node {numa}, {len(cpus)} usable cpus", "gpu_pci": pci}
+        mates = [r for r in range(min(n_local, len(gpus))) if gpus[r][0] == numa]
+        cores = {}
+        for c in cpus:  # hardware threads grouped into cores
+            try:
+                with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                    key = tuple(x for x in _parse_cpulist(f.read()) if x in allowed)
+            except OSError:
+                key = (c,)
+            cores.setdefault(key or (c,), None)
+        cores = sorted(cores)
+        per = len(cores) // len(mates)
+        if per >= 1:
+            k = mates.index(local)
+            mine = sorted(c for core in cores[k * per:(k + 1) * per] for c in core)
+        else:
+            mine = cpus
+        os.sched_setaffinity(0, mine)
+        return {"binding": "numa", "numa_node": numa, "gpu_pci": pci, "cpus": _format_cpulist(mine), "n_cpus": len(mine),
+                "ranks_on_this_node": len(mates)}
+    except Exception as e:  # noqa: BLE001  (sysfs layout, permissions, UUID device lists: run unbound rather than not at all)
+        return {"binding": "none", "why": f"{type(e).__name__}: {e}"}
 
 
 def relaunch_as_ranks(args):
@@ -325,8 +418,18 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
                 event_ms.append(m)
         ag._time_rate_kernel = True
     el = torch.tensor(elapsed, dtype=torch.float64)
+    per_rank = None
     if dist is not None:
         el = el.to("cpu" if ctrl_on_cpu else "cuda")
+        # every rank's own regions (min / median / max): `value` is set by the slowest rank of every repeat, so a slow
+        # HOST among the ranks must be visible in the line
+        parts = [torch.zeros_like(el) for _ in range(world)]
+        dist.all_gather(parts, el)
+        per_rank = []
+        for r, x in enumerate(parts):
+            xs = sorted(x.cpu().tolist())
+            per_rank.append({"rank": r, "min": round(xs[0] * 1e3, 5), "median": round(xs[len(xs) // 2] * 1e3, 5),
+                             "max": round(xs[-1] * 1e3, 5)})
         dist.all_reduce(el, op=dist.ReduceOp.MAX)  # per repeat: the slowest rank
         el = el.cpu()
     el_sorted = sorted(el.tolist())
@@ -482,6 +585,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
             "config": {"workload": config + ": " + cfg["desc"], "agents_per_gpu": B,
                        "cells": {k: cfg[k] for k in ("place", "grid", "bvc", "hdc")},
                        "parallelism": f"agent-sharded x{world}, no step-path collective", "control_plane": control_plane,
+                       "host_binding": getattr(args, "host_binding", None),
                        "api": api, "history": "ring" if args.no_history else "full", "spikes": cfg["spikes"],
                        "bytes_per_agent_step": bpu},
             "repeats": R,
@@ -489,6 +593,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
                                 "max": round(el_sorted[-1] * 1e3, 5), "first": round(float(el[0]) * 1e3, 5),
                                 "note": "every repeat runs the full K steps into fresh history rows; value = total "
                                         "agent-steps of one repeat / the median repeat (max over ranks per repeat)"},
+            "timed_region_ms_per_rank": per_rank,
             "value_best_repeat": round(total_units / el_sorted[0], 1),
             "hbm_GBps_whole_path": round(value / world * bpu / 1e9, 1),
             "frac_whole_path": round(value / world * bpu / 1e9 / HBM_PEAK_GBS, 4),
@@ -527,6 +632,8 @@ def main():
                          "for one rank, when launched by torch.distributed.run (a one-GPU test of the multi-GPU launch form)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short cfg3 / cfg4 / cfg5 runs reported in the `secondary` block of the cfg2 line")
+    ap.add_argument("--no-bind", action="store_true",
+                    help="do not pin the rank to cores of its GPU's NUMA node (default: pinned before the first HIP call)")
     ap.add_argument("--event-timing", action="store_true",
                     help="time the one-kernel rate stage with HIP start / stop events on its launch instead of the "
                          "device clock stamps")
@@ -545,6 +652,22 @@ def main():
     import numpy as np
     import torch
     share = os.environ.get("RIAB_BENCH_SHARE_GPU") == "1"  # test hook: all ranks on cuda:0, gloo control plane
+    # ---- host placement, before the first HIP call: cores of the GPU's NUMA node, disjoint between ranks -----------------
+    global _ALL_CPUS
+    _ALL_CPUS = os.sched_getaffinity(0)
+    n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if args.no_bind:
+        args.host_binding = {"binding": "none", "why": "--no-bind"}
+    elif share:   # (every rank on GPU 0: its node's cores, split between the ranks as if each had a GPU of that node)
+        args.host_binding = bind_rank_to_gpu_numa(0, 1)
+        if args.host_binding.get("binding") == "numa" and n_local > 1:
+            cpus = _parse_cpulist(args.host_binding["cpus"])
+            per = max(1, len(cpus) // n_local)
+            mine = cpus[local * per:(local + 1) * per] or cpus
+            os.sched_setaffinity(0, mine)
+            args.host_binding.update(cpus=_format_cpulist(mine), n_cpus=len(mine), ranks_on_this_node=n_local)
+    else:
+        args.host_binding = bind_rank_to_gpu_numa(local, n_local)
     if share:
         local = 0
     torch.cuda.set_device(local)
@@ -580,28 +703,47 @@ def main():
 
     out, cfg = measure(args, args.config, args.steps, args.warmup, args.repeats, rank, world, local, dist, ctrl_on_cpu if dist
                        is not None else False, control_plane)
-    # ---- the other BASELINE configurations under the same clock: short runs, one block in the same line ----------------
+    if dist is not None:   # every rank's placement in rank 0's line
+        allb = [None] * world
+        dist.all_gather_object(allb, args.host_binding)
+        if out is not None:
+            out["config"]["host_binding_per_rank"] = allb
+    # ---- the other BASELINE configurations under the same clock: one block in the same line -----------------------------
+    # cfg2 again at the length SURVEY 8(d) quotes it on (1000 steps after 100 warm-up: here 1024 / 128), cfg3 (a one-GPU
+    # configuration: only at N = 1), and the per-GPU shards of the two 8-GPU configurations cfg4 / cfg5 — at every N,
+    # so that a multi-rank line carries BASELINE configs[3] and [4] as they are defined
     secondary = {}
-    if world == 1 and args.config == "cfg2" and not (args.no_secondary or args.per_step or args.plan or args.task):
+    if args.config == "cfg2" and not (args.no_secondary or args.per_step or args.plan or args.task or args.strong):
         saved = args.no_history
-        for name in ("cfg3", "cfg4", "cfg5"):
+        runs = [("cfg2_T1024", "cfg2", 128)] + ([("cfg3", "cfg3", 32)] if world == 1 else []) + \
+            [("cfg4", "cfg4", 32), ("cfg5", "cfg5", 32)]
+        for key, name, warm in runs:
+            if key == "cfg2_T1024" and args.steps == SECONDARY_STEPS:
+                continue   # (the headline run IS that run)
             args.no_history = False
             t0 = time.perf_counter()
             try:
-                o, c = measure(args, name, SECONDARY_STEPS, 32, 5, rank, world, local, dist, False, control_plane, store_ceiling=False)
+                o, c = measure(args, name, SECONDARY_STEPS, warm, 5, rank, world, local, dist,
+                               ctrl_on_cpu if dist is not None else False, control_plane, store_ceiling=False)
             except Exception as e:  # noqa: BLE001  (the headline line must not be lost to a secondary run)
-                secondary[name] = {"error": f"{type(e).__name__}: {e}"}
+                secondary[key] = {"error": f"{type(e).__name__}: {e}"}
+                continue
+            torch.cuda.empty_cache()   # (tens of GB of history per configuration: give them back before the next one)
+            if o is None:
                 continue
             r = o["roofline"] or {}
-            torch.cuda.empty_cache()   # (tens of GB of history per configuration: give them back before the next one)
-            secondary[name] = {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "steps": SECONDARY_STEPS,
-                               "warmup": 32, "repeats": o["repeats"], "ms_per_step": o["ms_per_step"],
-                               "timed_region_ms": o["timed_region_ms"]["median"],
-                               "bytes_per_agent_step": o["config"]["bytes_per_agent_step"],
-                               "frac_whole_path": o["frac_whole_path"],
-                               "roofline": {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel",
-                                                                  "launches", "avg_launch_ms", "units_per_launch")},
-                               "wall_s": round(time.perf_counter() - t0, 2)}
+            secondary[key] = {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "n_gpus": world,
+                              "steps": SECONDARY_STEPS, "warmup": warm, "repeats": o["repeats"], "ms_per_step": o["ms_per_step"],
+                              "timed_region_ms": o["timed_region_ms"]["median"],
+                              "timed_region_ms_per_rank": o["timed_region_ms_per_rank"],
+                              "bytes_per_agent_step": o["config"]["bytes_per_agent_step"],
+                              "hbm_GBps_whole_path": o["hbm_GBps_whole_path"], "frac_whole_path": o["frac_whole_path"],
+                              "roofline": {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel",
+                                                                 "launches", "avg_launch_ms", "units_per_launch",
+                                                                 "avg_launch_ms_device_clock", "frac_device_clock",
+                                                                 "rate_stage_form")},
+                              "diagnostics": o.get("diagnostics"),
+                              "wall_s": round(time.perf_counter() - t0, 2)}
         args.no_history = saved
     if rank == 0:
         if secondary:

@@ -77,7 +77,8 @@ def _line(cmd, env):
 def test_bench_as_a_rank_of_torch_distributed_run_with_the_rccl_control_plane():
     """the driver's multi-GPU launch form at N = 1 — `python -m torch.distributed.run --nnodes=1
     --nproc-per-node 1 ... bench.py --gpus 1` — brings up the `nccl` process group (no gloo fallback) and reports the
-    same throughput as the plain one-process line (fastest timed region within 25 %)."""
+    two kernels of simulate() still run side by side (`diagnostics["pipeline_serialised"] == 0`; the ratio of the fastest
+    timed regions with and without the process group is printed, not asserted: the hosts are shared)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RIAB_BENCH_SHARE_GPU"):
         env.pop(k, None)
@@ -92,8 +93,13 @@ def test_bench_as_a_rank_of_torch_distributed_run_with_the_rccl_control_plane():
         assert "using gloo" not in err, err[-2000:]
         assert ranked["n_gpus"] == 1 and ranked["config"]["control_plane"] == "nccl"
         assert plain["config"].get("control_plane") in (None, "none")
-        # (compared on the FASTEST region of each run: the boxes' hosts are shared and a median of a handful of 0.8 ms
-        # regions has been seen 40 % off for a whole run while its fastest region was within 3 %)
+        # What an RCCL communicator in the process once did to this line: the two kernels of simulate() on ONE hardware
+        # queue, one after the other (0.62 instead of 0.90 G agent-steps/s).  That defect is now detected where it
+        # happens — the rate stage's first wave counts the calls that find every row published already — so the
+        # assertion is on the counter, not on a ratio of two timings taken on a shared host (reported, not asserted).
+        assert ranked["diagnostics"].get("pipeline_timeouts", 0) == 0 and plain["diagnostics"].get("pipeline_timeouts", 0) == 0
+        assert ranked["diagnostics"]["pipeline_serialised"] == 0, ranked["diagnostics"]
+        assert plain["diagnostics"]["pipeline_serialised"] == 0, plain["diagnostics"]
         best = lambda o: o["timed_region_ms"]["min"]  # noqa: E731
-        assert abs(best(ranked) - best(plain)) / best(plain) < 0.25, (steps, ranked["timed_region_ms"], plain["timed_region_ms"])
-        assert ranked["diagnostics"].get("pipeline_timeouts", 0) == 0
+        print(f"[bench as a rank, {steps} steps] fastest region with the nccl group up / without: "
+              f"{best(ranked):.4f} / {best(plain):.4f} ms = {best(ranked) / best(plain):.3f}")

@@ -343,20 +343,183 @@ def test_repeated_simulate_calls_see_every_edit(riab, monkeypatch):
     assert res[0][5] == res[1][5] and res[0][6] == res[1][6] and res[0][6]["pipeline_timeouts"] == 0
 
 
-@pytest.mark.parametrize("when_busy", ["0", "1"])
-def test_fused_launch_modes(riab, when_busy):
-    """The rate kernel behind the started gate (the default) and straight behind the trajectory kernel (an option
-    for callers that own the device: the gate only when work is queued in front of the trajectory kernel) give the
-    same, correct results."""
-    os.environ["RIAB_GATE_WHEN_BUSY"] = when_busy
+@pytest.mark.parametrize("gate,launches", [("reserved", 2), ("always", 3), ("when_busy", 2)])
+def test_fused_launch_modes(riab, gate, launches):
+    """Residency of the two kernels (include/riab_hip.h "Residency"): the row-following rate kernel in its RESERVING shape
+    (twelve-wave workgroups: two per compute unit, one wave slot per SIMD always free for a trajectory workgroup — the
+    default: two launches per call), behind the one-wave started gate (three launches), and straight behind the
+    trajectory kernel with neither (an option for callers that own the device) give the same, correct rows; a call
+    whose stream is busy takes the gate in every mode."""
+    os.environ["RIAB_GATE"] = gate
     try:
         t_a, fr_a, _sp, ag_a = _run(riab, True, 1024, _pc(256, save_spikes=False), [("sim", 48), ("sim", 16)])
+        assert ag_a.diagnostics["pipeline_timeouts"] == 0 and ag_a.diagnostics["pipeline_serialised"] == 0
+        L = riab._lib
+        torch.cuda.synchronize()
+        ag_a.simulate(16)                       # the stream is idle: the mode's own number of launches
+        assert L.lib.riab_streamer_info(ag_a._streamer, 3) == launches, (gate, L.lib.riab_streamer_info(ag_a._streamer, 3))
+        x = torch.zeros(1 << 26, device="cuda")
+        for _ in range(8):
+            x.add_(1.0)                         # the stream is busy: event + started gate, whatever the mode
+        ag_a.simulate(16)
+        assert L.lib.riab_streamer_info(ag_a._streamer, 3) == 3
+        torch.cuda.synchronize()
         assert ag_a.diagnostics["pipeline_timeouts"] == 0
+        tail = ag_a.get_history_tensor()[-32:].cpu().numpy()
     finally:
-        os.environ.pop("RIAB_GATE_WHEN_BUSY", None)
-    t_b, fr_b, _sp, _ag = _run(riab, False, 1024, _pc(256, save_spikes=False), [("sim", 48), ("sim", 16)])
-    np.testing.assert_array_equal(t_a, t_b)
+        os.environ.pop("RIAB_GATE", None)
+    sched = [("sim", 48), ("sim", 16), ("sim", 16), ("sim", 16)]
+    t_b, fr_b, _sp, _ag = _run(riab, False, 1024, _pc(256, save_spikes=False), sched)
+    np.testing.assert_array_equal(t_a, t_b[:64])
+    np.testing.assert_array_equal(fr_a, fr_b[:64])
+    np.testing.assert_array_equal(tail, t_b[64:])
+
+
+def test_reserving_shape_at_the_bench_size_and_with_ragged_cell_groups(riab):
+    """The twelve-wave shape of the row-following kernel covers three cell groups per workgroup: cell counts that are
+    not a multiple of 24 (place cells: 8 per group), a population with spikes, grid and head-direction cells, and the
+    bench shape itself — all bit-identical to the gated four-wave shape and to the Python-driven pipeline."""
+    for B, make, T in ((4096, _pc(1024, save_spikes=False), 20), (512, _pc(203), 37), (256, _pc(5), 50), (1024, _gc(300), 40),
+                       (1024, _hdc(50), 33), (2048, _pc(1000, save_spikes=False), 300)):
+        res = {}
+        for gate in ("reserved", "always"):
+            os.environ["RIAB_GATE"] = gate
+            try:
+                res[gate] = _run(riab, True, B, make, [("sim", T), ("sim", 9)])
+                ag = res[gate][3]
+                assert ag.diagnostics["pipeline_timeouts"] == 0
+                torch.cuda.synchronize()
+                ag.simulate(8)
+                assert riab._lib.lib.riab_streamer_info(ag._streamer, 3) == (2 if gate == "reserved" else 3)
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("RIAB_GATE", None)
+        ref = _run(riab, False, B, make, [("sim", T), ("sim", 9)])
+        for k in range(3):
+            np.testing.assert_array_equal(res["reserved"][k], res["always"][k])
+            np.testing.assert_array_equal(res["reserved"][k], ref[k])
+
+
+def test_reserving_shape_is_refused_by_kernels_that_hold_too_many_registers(riab):
+    """Line-of-sight / geodesic place cells hold ~90 registers per lane: two twelve-wave workgroups of them would not
+    leave a trajectory workgroup its 224 — the reserving shape is not offered for them, the call takes the gate."""
+    os.environ["RIAB_GATE"] = "reserved"
+    try:
+        t_a, fr_a, _sp, ag = _run(riab, True, 1024, _pc(100, wall_geometry="line_of_sight", save_spikes=False),
+                                  [("sim", 30)], {"walls": MAZE})
+        torch.cuda.synchronize()
+        ag.simulate(12)
+        assert ag.last_rate_stage_form() == "one-kernel" and riab._lib.lib.riab_streamer_info(ag._streamer, 3) == 3
+        torch.cuda.synchronize()
+        assert ag.diagnostics["pipeline_timeouts"] == 0
+    finally:
+        os.environ.pop("RIAB_GATE", None)
+    t_b, fr_b, _sp, _ag = _run(riab, False, 1024, _pc(100, wall_geometry="line_of_sight", save_spikes=False), [("sim", 30)],
+                               {"walls": MAZE})
     np.testing.assert_array_equal(fr_a, fr_b)
+
+
+def test_replayed_argument_block_never_sees_the_earlier_runs_progress(riab):
+    """torch.ops.riab.simulate_ on the SAME argument block twice (what a compiled function that
+    is called twice does) starts the second run at the step count of the first.  The progress words hold absolute
+    step counts, so the second run's consumers must not take the first run's words for their own: every trajectory
+    workgroup resets its word before it announces itself, and a call that does not continue beyond the last one's
+    rows takes the started gate.  Checked: the second run's rates are the oracle's rates on the second run's own rows
+    (a consumer that ran ahead of the producer reads unwritten / stale positions), twice, with 4096 agents."""
+    from ratinabox_amd import ops  # noqa: F401
+    np.random.seed(5)
+    ag = riab.Agent(riab.Environment(), {"n_agents": 4096, "dt": 0.01, "seed": 3})
+    pcs = riab.PlaceCells(ag, {"n": 256, "save_spikes": False, "wall_geometry": "euclidean"})
+    K = 40
+    a = ag.simulate_args(K)
+    oenv = orc.EnvSpec()
+    prev = None
+    for rep in range(3):
+        a.hist.fill_(float("nan"))
+        a.rates[0].fill_(float("nan"))
+        torch.ops.riab.simulate_(a.state, a.hist, a.rates, a.spikes, a.ctrl, a.diag, a.streamer, a.run, 0, a.rate_rows, a.spike_rows)
+        torch.cuda.synchronize()
+        # (a streamer's first call and every call that does not continue beyond the last one's rows take the started gate)
+        assert riab._lib.lib.riab_streamer_info(ag._streamer, 3) == 3
+        hist, fr = a.hist.cpu().numpy(), a.rates[0].cpu().numpy()
+        assert np.isfinite(hist).all() and np.isfinite(fr).all()
+        sel = np.arange(0, 4096, 131)
+        for t in (0, 1, 2, 3, 7, K // 2, K - 1):
+            pos = np.stack((hist[t, 0, sel], hist[t, 1, sel]), -1).astype(np.float64)
+            ref = orc.place_cells(oenv, pos, pcs.place_cell_centres, pcs.place_cell_widths)
+            np.testing.assert_allclose(fr[t][:, sel], ref, rtol=1e-5, atol=1e-37)
+        if prev is not None:
+            assert not np.array_equal(prev, hist), "the state did not advance"
+        prev = hist
+    assert ag.diagnostics["pipeline_timeouts"] == 0
+
+
+def test_repeated_simulate_with_a_feedforward_layer(riab):
+    """the second plain simulate() of an agent whose populations include a FeedForwardLayer (no
+    noisy population in the list) must not take the short road with a descriptor that needs the plan index."""
+    res = []
+    for native in (True, False):
+        os.environ["RIAB_NO_NATIVE"] = "0" if native else "1"
+        try:
+            np.random.seed(8)
+            ag = riab.Agent(riab.Environment(), {"n_agents": 256, "dt": 0.01, "seed": 2})
+            np.random.seed(9)
+            pcs = riab.PlaceCells(ag, {"n": 32, "save_spikes": False})
+            ff = riab.FeedForwardLayer(ag, {"n": 6, "input_layers": [pcs], "save_spikes": False,
+                                            "activation_function": {"activation": "relu", "gain": 1.0, "threshold": 0.0}})
+            for _ in range(3):
+                ag.simulate(24)
+            torch.cuda.synchronize()
+            if native:
+                assert ag.engine_runs["native"] == 3
+            res.append((ag.get_history_tensor().cpu(), pcs.get_history_tensors()[0].cpu(), ff.get_history_tensors()[0].cpu()))
+        finally:
+            os.environ.pop("RIAB_NO_NATIVE", None)
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    assert res[0][2].shape == (72, 6, 256) and float(res[0][2].abs().sum()) > 0
+
+
+def test_form_selection_follows_the_measured_step_and_store_rates(riab):
+    """populations form or chunk form is decided by comparing the lead population's stores of a row with
+    1.5 trajectory steps next to it — measured on this chip from the device-clock stamps an earlier call left (one
+    read per streamer), the MI355X constants until then.  Faking the figures flips the form; the rows are the same."""
+    L = riab._lib
+
+    def world():
+        np.random.seed(12)
+        ag = riab.Agent(riab.Environment(), {"n_agents": 2048, "dt": 0.01, "seed": 6})
+        np.random.seed(13)
+        return ag, riab.PlaceCells(ag, {"n": 512, "save_spikes": False}), riab.BoundaryVectorCells(ag, {"n": 8, "save_spikes": False})
+
+    rows = {}
+    for label, step_ns in (("constants", None), ("slow trajectory", 50_000), ("fast trajectory", 100)):
+        ag, pcs, bvs = world()
+        ag.simulate(16)                                # (creates the streamer; nothing measured yet)
+        torch.cuda.synchronize()
+        if step_ns is not None:
+            L.check(L.lib.riab_streamer_configure(ag._streamer, L.STREAMER_OPT_STEP_NS, step_ns), "configure")
+            assert L.lib.riab_streamer_info(ag._streamer, 0) == step_ns and L.lib.riab_streamer_info(ag._streamer, 2) == 0
+        ag.simulate(64)
+        torch.cuda.synchronize()
+        form = ag.last_rate_stage_form()
+        if label == "slow trajectory":                 # 4.2 MB per row at ~6.5 TB/s = 0.65 us < 1.5 x 50 us
+            assert form == "chunks"
+        elif label == "fast trajectory":
+            assert form == "populations"
+        else:                                          # the open-room constants: 0.65 us < 1.5 x 0.9 us -> chunks ...
+            assert form == "chunks"
+            # ... and this second multi-population call found the stream idle: it has read the first call's stamps
+            assert L.lib.riab_streamer_info(ag._streamer, 2) == 1
+            step, mbps = L.lib.riab_streamer_info(ag._streamer, 0), L.lib.riab_streamer_info(ag._streamer, 1)
+            assert 200 < step < 20_000, step           # a trajectory step of a 16-step call: a few microseconds at most
+            assert mbps == 6_500_000                   # (no row-following kernel ran: the store rate stays the constant)
+        rows[label] = (ag.get_history_tensor().cpu(), pcs.get_history_tensors()[0].cpu(), bvs.get_history_tensors()[0].cpu())
+        assert ag.diagnostics["pipeline_timeouts"] == 0
+    for label in ("slow trajectory", "fast trajectory"):
+        for x, y in zip(rows["constants"], rows[label]):
+            assert torch.equal(x, y), label
+
 
 
 def test_aborted_pipeline_is_reported_on_the_next_host_read(riab):
@@ -451,6 +614,15 @@ def test_bench_contract_line_on_the_drivers_command(riab):
     assert abs(out["value"] - 4096 * 20 / (out["timed_region_ms"]["median"] * 1e-3)) / out["value"] < 1e-3
 
 
+def bench_cpus(text):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    return bench._parse_cpulist(text)
+
+
 def test_bench_launches_its_own_ranks(riab):
     """`python bench.py --gpus 2` (no launcher) must start two ranks and say so.  Both ranks share
     this box's one GPU (RIAB_BENCH_SHARE_GPU: gloo control plane), which exercises everything but RCCL."""
@@ -459,6 +631,23 @@ def test_bench_launches_its_own_ranks(riab):
     assert out["config"]["parallelism"].startswith("agent-sharded x2")
     assert out["value"] > 1e6 and out["diagnostics"].get("pipeline_timeouts", 0) == 0
     assert out["scaling"] == "weak" and out["config"]["agents_per_gpu"] == 4096
+    # what a multi-rank line carries — where each rank's host thread runs (cores of its GPU's NUMA node,
+    # disjoint between the ranks), every rank's own timed regions, and BASELINE's 8-GPU configurations
+    hb = out["config"]["host_binding"]
+    assert hb["binding"] in ("numa", "none") and len(out["config"]["host_binding_per_rank"]) == 2
+    if hb["binding"] == "numa":
+        a, b = (set(bench_cpus(x["cpus"])) for x in out["config"]["host_binding_per_rank"])
+        assert a and b and not (a & b), "the two ranks share cores"
+    per = out["timed_region_ms_per_rank"]
+    assert [x["rank"] for x in per] == [0, 1] and all(0 < x["min"] <= x["median"] <= x["max"] for x in per)
+    assert out["timed_region_ms"]["median"] >= max(x["min"] for x in per)
+    sec = out["secondary"]
+    assert set(sec) == {"cfg2_T1024", "cfg4", "cfg5"}, sec.keys()
+    for name, blk in sec.items():
+        assert "error" not in blk, blk
+        assert blk["n_gpus"] == 2 and blk["value"] > 1e6 and len(blk["timed_region_ms_per_rank"]) == 2
+        assert blk["diagnostics"]["pipeline_timeouts"] == 0
+        assert 0 < blk["frac_whole_path"] < 1 and blk["roofline"]["frac"] > 0
     strong = _bench(["--gpus", "2", "--strong", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"],
                     {"RIAB_BENCH_SHARE_GPU": "1"})
     assert strong["scaling"] == "strong" and strong["config"]["agents_per_gpu"] == 2048 and strong["n_gpus"] == 2
@@ -885,3 +1074,74 @@ def test_empty_and_tiny_inputs(riab):
     solo = riab.Agent(env, {"n_agents": 256, "dt": 0.02})
     pcs = riab.PlaceCells(solo, {"n": 4})
     assert solo.simulate(0).shape[0] == 0 and len(solo.history["t"]) == 0 and solo._streamer is None
+
+
+_SERIAL_WORKER = r"""
+import os, sys, time, json
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import ratinabox_amd as riab
+np.random.seed(0)
+ag = riab.Agent(riab.Environment(), {"n_agents": 4096, "dt": 0.01, "seed": 1})
+pcs = riab.PlaceCells(ag, {"n": 256, "save_spikes": False, "wall_geometry": "euclidean"})
+ag.simulate(64); torch.cuda.synchronize()
+ts = []
+for _ in range(20):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); ag.simulate(64); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+import warnings
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    d = ag.diagnostics
+print(json.dumps({"serialised": d["pipeline_serialised"], "timeouts": d["pipeline_timeouts"], "ms": 1e3 * float(np.median(ts)),
+                  "checksum": float(pcs.get_history_tensors()[0].double().sum())}))
+"""
+
+
+def test_serialised_pipeline_is_detected(riab, tmp_path):
+    """the trajectory kernel and the rate stage are meant to run side by side on two hardware queues.  When
+    they run one after the other (the process's streams share a queue) nothing is wrong with the results, only with the
+    time — so the rate stage's first wave counts the calls (>= 8 rows) that find every row published already, and
+    `Agent.diagnostics` reports them (and warns once).  (i) deterministic: the trajectory kernel on the caller's own
+    stream (RIAB_SIDE_STREAM=2) — every call is counted, in both forms of the rate stage, and the rows are unchanged;
+    (ii) ONE hardware queue for the process (GPU_MAX_HW_QUEUES=1, second stream at the default priority): if the
+    runtime really serialised the two kernels — visible in the time — the counter has seen it."""
+    import json
+    import subprocess
+    import sys
+    import warnings
+    ref = _run(riab, True, 1024, _pc(128, save_spikes=False), [("sim", 40), ("sim", 7), ("sim", 24)])
+    assert ref[3].diagnostics["pipeline_serialised"] == 0
+    os.environ["RIAB_SIDE_STREAM"] = "2"
+    try:
+        got = _run(riab, True, 1024, _pc(128, save_spikes=False), [("sim", 40), ("sim", 7), ("sim", 24)])
+        with pytest.warns(RuntimeWarning, match="one after the other"):
+            d = got[3].diagnostics
+        assert d["pipeline_serialised"] == 2 and d["pipeline_timeouts"] == 0      # (the 7-step call is too short to tell)
+        for k in range(3):
+            np.testing.assert_array_equal(got[k], ref[k])
+        # the chunk form (two populations): its first gate does the counting
+        np.random.seed(1)
+        ag = riab.Agent(riab.Environment({"walls": MAZE}), {"n_agents": 512, "dt": 0.01, "seed": 5})
+        riab.GridCells(ag, {"n": 32, "save_spikes": False})
+        riab.BoundaryVectorCells(ag, {"n": 8, "save_spikes": False})
+        ag.simulate(48)
+        torch.cuda.synchronize()
+        assert ag.last_rate_stage_form() == "chunks"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert ag.diagnostics["pipeline_serialised"] == 1
+    finally:
+        os.environ.pop("RIAB_SIDE_STREAM", None)
+    script = tmp_path / "serial_worker.py"
+    script.write_text(_SERIAL_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for name, extra in (("default", {}), ("one_queue", {"GPU_MAX_HW_QUEUES": "1", "RIAB_SIDE_STREAM": "1"})):
+        env = dict(os.environ, **extra)
+        p = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[name] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    print("serialised-pipeline probe:", out)
+    assert out["default"]["serialised"] == 0 and out["default"]["timeouts"] == 0 and out["one_queue"]["timeouts"] == 0
+    assert out["default"]["checksum"] == out["one_queue"]["checksum"]
+    assert out["one_queue"]["serialised"] > 0 or out["one_queue"]["ms"] < 1.25 * out["default"]["ms"], out
