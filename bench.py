@@ -600,6 +600,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
             "roofline": roofline,
         }
         diag = ag.diagnostics
+        out["pipeline"] = ag.pipeline_info()
         if args.task:
             diag = dict(diag, **env.diagnostics, episodes_finished=len(env.episodes["episode"]))
         out["diagnostics"] = diag
@@ -632,6 +633,8 @@ def main():
                          "for one rank, when launched by torch.distributed.run (a one-GPU test of the multi-GPU launch form)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short cfg3 / cfg4 / cfg5 runs reported in the `secondary` block of the cfg2 line")
+    ap.add_argument("--secondary-timeout", type=float, default=240.0,
+                    help="seconds after which the secondary block is abandoned and the headline line printed without it")
     ap.add_argument("--no-bind", action="store_true",
                     help="do not pin the rank to cores of its GPU's NUMA node (default: pinned before the first HIP call)")
     ap.add_argument("--event-timing", action="store_true",
@@ -713,7 +716,27 @@ def main():
     # configuration: only at N = 1), and the per-GPU shards of the two 8-GPU configurations cfg4 / cfg5 — at every N,
     # so that a multi-rank line carries BASELINE configs[3] and [4] as they are defined
     secondary = {}
+    # A secondary run must never cost the headline line: every rank arms a watchdog that — should the block not finish
+    # (one rank failing alone leaves the others in a barrier) — lets rank 0 print the line with what it has and ends the
+    # process with the launcher's success code.
+    state = {"running": None, "done": False}
+
+    def bail():
+        if state["done"]:
+            return
+        if rank == 0 and out is not None:
+            if secondary:
+                out["secondary"] = secondary
+            out["secondary_error"] = f"watchdog: the secondary run '{state['running']}' did not finish in {args.secondary_timeout} s"
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    import threading
+    dog = threading.Timer(args.secondary_timeout, bail)
+    dog.daemon = True
+    sec_steps = 256 if share else SECONDARY_STEPS   # (the test hook: N ranks' histories on ONE GPU)
     if args.config == "cfg2" and not (args.no_secondary or args.per_step or args.plan or args.task or args.strong):
+        dog.start()
         saved = args.no_history
         runs = [("cfg2_T1024", "cfg2", 128)] + ([("cfg3", "cfg3", 32)] if world == 1 else []) + \
             [("cfg4", "cfg4", 32), ("cfg5", "cfg5", 32)]
@@ -721,9 +744,10 @@ def main():
             if key == "cfg2_T1024" and args.steps == SECONDARY_STEPS:
                 continue   # (the headline run IS that run)
             args.no_history = False
+            state["running"] = key
             t0 = time.perf_counter()
             try:
-                o, c = measure(args, name, SECONDARY_STEPS, warm, 5, rank, world, local, dist,
+                o, c = measure(args, name, sec_steps, warm, 5, rank, world, local, dist,
                                ctrl_on_cpu if dist is not None else False, control_plane, store_ceiling=False)
             except Exception as e:  # noqa: BLE001  (the headline line must not be lost to a secondary run)
                 secondary[key] = {"error": f"{type(e).__name__}: {e}"}
@@ -733,7 +757,7 @@ def main():
                 continue
             r = o["roofline"] or {}
             secondary[key] = {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "n_gpus": world,
-                              "steps": SECONDARY_STEPS, "warmup": warm, "repeats": o["repeats"], "ms_per_step": o["ms_per_step"],
+                              "steps": sec_steps, "warmup": warm, "repeats": o["repeats"], "ms_per_step": o["ms_per_step"],
                               "timed_region_ms": o["timed_region_ms"]["median"],
                               "timed_region_ms_per_rank": o["timed_region_ms_per_rank"],
                               "bytes_per_agent_step": o["config"]["bytes_per_agent_step"],
@@ -745,6 +769,8 @@ def main():
                               "diagnostics": o.get("diagnostics"),
                               "wall_s": round(time.perf_counter() - t0, 2)}
         args.no_history = saved
+    state["done"] = True
+    dog.cancel()
     if rank == 0:
         if secondary:
             out["secondary"] = secondary

@@ -581,9 +581,13 @@ double riab_plan_task_clock(const RiabPlan* plan);
  * Velocity cells (they read the float64 state, which no history row keeps) are not covered: RIAB_EUNSUPPORTED,
  * nothing launched; callers advance them through a step plan.
  *
- * A RiabStreamer owns what the coupling needs besides the kernels: a second HIP stream (the trajectory kernel runs
+ * A RiabStreamer holds what the coupling needs besides the kernels: a second HIP stream (the trajectory kernel runs
  * there; the rate stage — which ends last — on `stream`, so that a host synchronisation returns as soon after the
- * last kernel as after any single kernel), two events, and the running count of started trajectory workgroups.
+ * last kernel as after any single kernel), two events, and the running count of started trajectory workgroups.  The
+ * second stream is borrowed from a process-wide pool: one stream per (device, caller's stream), of the device's highest
+ * priority, chosen among up to six candidates by TIMING a pair of launches against the caller's stream at the first
+ * call that finds that stream idle — streams that share the caller's hardware queue are 30-50 us slower per pair and
+ * are set aside (csrc/riab_simulate.hip: side_stream_for; riab_streamer_info 4-6).
  *
  *  ctrl   device uint32 [RIAB_CTRL_WORDS(B)], zeroed ONCE by the caller when it is created (and that zero-fill
  *         complete before the first call: the kernels that read the words run on the streamer's stream too):
@@ -709,7 +713,13 @@ enum { RIAB_FORM_NONE = 0, RIAB_FORM_ONE_KERNEL = 1, RIAB_FORM_CHUNKS = 2, RIAB_
        RIAB_FORM_HEAD_AND_PIECES = 5 };
 int riab_streamer_last_form(RiabStreamer* h);
 /* what the form selection currently compares (which: 0 the trajectory step in ns, 1 the lead's store rate in MB/s, 2
- * whether they were measured (1) or are the built-in constants / configured values (0), 3 launches of the last call) */
+ * whether they were measured (1) or are the built-in constants / configured values (0), 3 launches of the last call),
+ * and how the trajectory kernel's stream was chosen: 4 the host time in ns of [one tiny launch on the caller's stream,
+ * one on that stream, synchronise both] (best of six; -1: not screened yet), 5 how many candidate streams were rejected
+ * before it (a stream that shares the caller's hardware queue makes that pair 30-50 us slower), 6 the same time with
+ * both launches on the caller's stream; 7 calls whose rate stage the HOST launched more than 12 us after the trajectory
+ * kernel's launch had returned (a descheduled thread, a kernel's first launch in the process): such a call can be counted
+ * in ctrl[RIAB_CTRL_SERIALISED] without any queue being shared — readers subtract */
 int64_t riab_streamer_info(RiabStreamer* h, int32_t which);
 
 /* A/B switches of the library (comparisons and tests; the defaults are what production runs): process-wide, read on

@@ -243,7 +243,10 @@ class Agent:
             out["pipeline_timeouts"] = int(w[_L.CTRL_TIMEOUTS])  # waits of the flag-coupled pipeline that gave up: must be 0
             # simulate() calls (>= 8 steps) whose trajectory kernel had FINISHED before the firing-rate stage began: the
             # two kernels are meant to run side by side on two hardware queues; results are right, the call is slower
-            out["pipeline_serialised"] = int(w[_L.CTRL_SERIALISED])
+            # (minus the calls whose second launch the HOST issued late — a descheduled thread: such a call finds every row
+            # published too, without any queue being shared; riab_streamer_info 7)
+            late = int(_L.lib.riab_streamer_info(self._streamer, 7)) if self._streamer is not None else 0
+            out["pipeline_serialised"] = max(0, int(w[_L.CTRL_SERIALISED]) - max(0, late))
             if out["pipeline_serialised"] and not self._serial_warned:
                 self._serial_warned = True
                 import warnings
@@ -955,6 +958,21 @@ class Agent:
             return None
         ms = float(_L.lib.riab_streamer_last_rate_ms(self._streamer))
         return ms if ms >= 0 else None
+
+    def pipeline_info(self):
+        """How the flag-coupled pipeline of this agent is set up (riab_streamer_info): launches of the last call; the
+        trajectory kernel's stream — host microseconds of [a tiny launch on the caller's stream, one on that stream,
+        synchronise both] against both launches on the caller's stream, and how many candidate streams were set aside
+        before it (streams that share the caller's hardware queue are 30-50 us slower per pair: csrc/riab_simulate.hip
+        side_stream_for); what the choice between the populations form and the chunk form compares."""
+        if self._streamer is None:
+            return None
+        f = lambda k: int(_L.lib.riab_streamer_info(self._streamer, k))  # noqa: E731
+        pair = f(4)
+        return {"launches_last_call": f(3),
+                "second_stream": {"screened": pair >= 0, "pair_us": round(pair / 1e3, 1) if pair >= 0 else None,
+                                  "same_stream_pair_us": round(f(6) / 1e3, 1), "candidates_set_aside": f(5)},
+                "form_selection": {"trajectory_step_ns": f(0), "lead_store_MBps": f(1), "measured": bool(f(2))}}
 
     def last_rate_stage_form(self):
         """Which form the rate stage of the last native simulate() took: "one-kernel", "head+pieces" (a long run of one

@@ -559,17 +559,26 @@ __global__ __launch_bounds__(256) void fill_kernel(float* dst, int64_t n4, float
 // flight — whereas a wave of this kernel ENDS after its stores and the slot is refilled at once.  With the
 // PlaceCells arithmetic in front of every store the persistent form reached 5.5-5.8 TB/s in every item shape
 // (5.3 in the real kernel), the non-persistent one with a poll per wave 6.2-6.3 [MI355X].
+typedef __attribute__((address_space(1))) unsigned long long gu64;
 struct StreamArgs {
   uint32_t* ctrl;
   uint32_t step_base;     // (uint32) step0 of the launch: progress words are absolute step counts
   uint32_t spin_limit;
   uint32_t stamps;        // != 0: the waves of the first / last time row record the device clock in ctrl[RIAB_CTRL_STAMPS]
   uint32_t sleep_max;     // longest s_sleep between two polls (riab_set_option(RIAB_OPT_POLL_SLEEP))
-  uint32_t serial_rows;   // >= 8: rows of the whole call — the grid's first wave counts the call in
-                          // ctrl[RIAB_CTRL_SERIALISED] when it finds all of them published already; 0: no check
+  uint32_t serial_rows;   // >= 8: rows of the whole call — the grid's first wave counts the call in ctrl[RIAB_CTRL_SERIALISED]
+                          // when it finds all of them published already AND the trajectory kernel ended less than
+  uint32_t serial_gap;    // `serial_gap` ticks of the device's constant clock ago; serial_rows == 0: no check
 };
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-
+// "The rate stage found every row published" has two causes: the two kernels shared a hardware queue — the rate stage then
+// starts within a few microseconds of the trajectory kernel's end (barrier, [gate,] dispatch) — or the HOST was late
+// with the second launch (a kernel's first launch in a process resolves its code object: tens of microseconds; a
+// descheduled thread), in which case the start is anywhere after that end.  Only the first is what the counter is for.
+__device__ __forceinline__ bool ended_just_now(const uint32_t* ctrl, uint32_t gap_ticks) {
+  const unsigned long long end = __hip_atomic_load((gu64*)(uintptr_t)(ctrl + RIAB_CTRL_TRAJ_STAMPS + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+  return now >= end && now - end < (unsigned long long)gap_ticks;
+}
 // rows of sub-segment q published so far, relative to this launch: one 16-byte read of the sub-segment's own line
 __device__ __forceinline__ int stream_progress(const StreamArgs& s, uint32_t q, int lane) {
   int rel = 0x7fffffff;
@@ -640,7 +649,8 @@ __global__ __launch_bounds__(64 * WAVES) void rate_kernel_gated(const RateArgs a
   // already, the trajectory kernel had finished before the rate stage began — both streams on one hardware queue
   // (DESIGN.md 7): counted, the host warns (Agent.diagnostics["pipeline_serialised"]).
   if (s.serial_rows >= 8u && grid_first) {
-    if (stream_progress(s, wq, lane) >= (int)s.serial_rows && lane == 0) atomicAdd(s.ctrl + RIAB_CTRL_SERIALISED, 1u);
+    if (stream_progress(s, wq, lane) >= (int)s.serial_rows && ended_just_now(s.ctrl, s.serial_gap) && lane == 0)
+      atomicAdd(s.ctrl + RIAB_CTRL_SERIALISED, 1u);
   }
 #ifdef RIAB_PIPE_PROFILE  // (tools/pipe_profile.py: per time row, on the device's constant clock, u64 words behind the ctrl block)
   gu64* const dbg = (gu64*)(uintptr_t)(s.ctrl + 2048);
@@ -699,7 +709,7 @@ __global__ __launch_bounds__(64 * WAVES) void rate_kernel_gated(const RateArgs a
 //                  in ctrl[RIAB_CTRL_SERIALISED] (the trajectory kernel had finished before the rate stage began).
 __global__ __launch_bounds__(64) void stream_gate_kernel(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj,
                                                          uint32_t progress_target, uint32_t spin_limit, uint32_t sleep_long,
-                                                         uint32_t final_target) {
+                                                         uint32_t final_target, uint32_t serial_gap) {
   const int lane = threadIdx.x;
   for (uint32_t spins = 0;; ++spins) {
     const uint32_t v = __hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_STARTED), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -713,7 +723,8 @@ __global__ __launch_bounds__(64) void stream_gate_kernel(uint32_t* ctrl, uint32_
         all_done = all_done && (int32_t)(p - final_target) >= 0;
       }
     }
-    if (spins == 0u && final_target != 0u && n_traj > 0u && __builtin_amdgcn_ballot_w64(!all_done) == 0 && lane == 0)
+    if (spins == 0u && final_target != 0u && n_traj > 0u && __builtin_amdgcn_ballot_w64(!all_done) == 0 &&
+        ended_just_now(ctrl, serial_gap) && lane == 0)
       atomicAdd(ctrl + RIAB_CTRL_SERIALISED, 1u);
     if (__builtin_amdgcn_ballot_w64(!ok) == 0) return;
     if (__hip_atomic_load((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
@@ -846,10 +857,23 @@ static int place_dispatch(const RiabEnv* env, const RiabRateIO* io, const float*
 // hipExtLaunchKernel; per thread, set and cleared by launch_rate_stream)
 static thread_local hipEvent_t t_stream_ev0 = nullptr, t_stream_ev1 = nullptr;
 
+// 25 us in ticks of the device's constant clock (s_memrealtime): how soon after the trajectory kernel's end a rate
+// stage that shared its hardware queue begins (barrier + [one-wave gate + barrier] + dispatch: 4-12 us [MI355X])
+static uint32_t serial_gap_ticks() {
+  static uint32_t ticks = 0;
+  if (!ticks) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+      khz = 100000;
+    ticks = (uint32_t)((long long)khz * 25 / 1000);
+  }
+  return ticks;
+}
+
 static thread_local bool t_stream_reserve = false;  // launch the reserving (twelve-wave) shape: set by launch_rate_stream
 
 template <class Cell>
-static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamArgs& st, int T, bool spikes, bool dry_run,
+static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamArgs& st_in, int T, bool spikes, bool dry_run,
                               hipStream_t s) {
   const hipEvent_t ev0 = t_stream_ev0, ev1 = t_stream_ev1;
   // Twice the wide kernel's cells per wave where the group's parameters still fit one wave (PlaceCells: 8): a gated
@@ -878,6 +902,13 @@ static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamA
     if (r > 48) return RIAB_EUNSUPPORTED;  // (the caller falls back to the started gate and the four-wave shape)
   }
   if (dry_run) return RIAB_OK;  // (every argument check is above: nothing is launched)
+  // (a kernel's FIRST launch in a process resolves its code object on the host — tens of microseconds in which a short
+  // trajectory kernel finishes: that call says nothing about hardware queues, it is not examined)
+  static bool launched[8] = {false, false, false, false, false, false, false, false};
+  bool& seen = launched[(reserve ? 4 : 0) + (spikes ? 2 : 0) + (lng ? 1 : 0)];
+  StreamArgs st = st_in;
+  if (!seen) st.serial_rows = 0u;
+  seen = true;
   const dim3 grid((unsigned)((a.qrow + 255) / 256), (unsigned)(reserve ? (groups + 2) / 3 : groups), (unsigned)T);
   const dim3 block(reserve ? 768 : 256);
   auto go = [&](auto kernel) {
@@ -985,6 +1016,7 @@ int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const floa
   st.stamps = stamps ? 1u : 0u;
   st.sleep_max = (uint32_t)g_options[RIAB_OPT_POLL_SLEEP];
   st.serial_rows = serial_rows;
+  st.serial_gap = serial_gap_ticks();
   const bool spikes = pop->spikes_base != nullptr;
   switch (pop->kind) {
     case RIAB_POP_PLACE:
@@ -1015,8 +1047,11 @@ int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const floa
 
 int launch_stream_gate(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj, uint32_t progress_target,
                        uint32_t spin_limit, bool sleep_long, uint32_t final_target, hipStream_t s) {
+  static bool launched = false;   // (the gate's first launch in the process: see launch_stream_cell)
+  if (!launched) final_target = 0u;
+  launched = true;
   hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(64), 0, s, ctrl, started_target, n_traj, progress_target, spin_limit,
-                     sleep_long ? 1u : 0u, final_target);
+                     sleep_long ? 1u : 0u, final_target, serial_gap_ticks());
   return (int)hipGetLastError();
 }
 

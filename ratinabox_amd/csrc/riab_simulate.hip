@@ -35,7 +35,9 @@
 // each other on the caller's stream.
 #include <hip/hip_ext.h>
 
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -55,7 +57,12 @@ int launch_stream_gate(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj,
 }  // namespace riab
 
 struct RiabStreamer {
-  hipStream_t side;          // the trajectory kernel's stream (SIDE_STREAM 0: highest priority; 1: side_normal below)
+  hipStream_t side;          // the trajectory kernel's stream (SIDE_STREAM 0): BORROWED from the process-wide pool of screened
+                             // streams (side_stream_for), for the caller's stream `side_main`; `side_screened`: it has been timed
+  hipStream_t side_main;
+  bool side_screened;
+  int dev;
+  int side_pair_ns, side_ref_ns, side_rejected;   // what the screening measured (riab_streamer_info 4 / 5 / 6)
   hipStream_t side_normal;   // ... at the default priority (created when RIAB_STREAMER_OPT_SIDE_STREAM = 1 is first used)
   int side_mode;             // RIAB_STREAMER_OPT_SIDE_STREAM
   // form selection (populations form against chunk form): a trajectory step next to the rate stage / the lead's store rate
@@ -69,6 +76,10 @@ struct RiabStreamer {
   uint32_t progress_end;     // (uint32) step0 + T of the last call on prev_ctrl: a later call must start at or beyond it
   bool progress_valid;
   int last_launches;         // kernel launches of the last call
+  int64_t late_calls;        // calls whose rate stage the HOST launched late (> 12 us after the trajectory kernel's launch had
+                             // returned: a descheduled thread, a kernel's first launch): such a call can find every row
+                             // published without any hardware queue being shared — the RIAB_CTRL_SERIALISED count is read
+                             // against this one (riab_streamer_info 7)
   hipEvent_t fork, join;     // caller's stream -> side (only when the caller's stream is busy), side -> caller's stream
   hipEvent_t t0, t1;         // HIP-event timing of the rate kernel (created on first use)
   std::vector<hipEvent_t> pairs;  // chunk form: (start, stop) around every launch of the timed population
@@ -83,10 +94,124 @@ struct RiabStreamer {
   int last_form;             // riab_streamer_last_form
 };
 
+// ---- the trajectory kernel's stream: screened, process-wide -----------------------------------------------------------
+// Not every HIP stream is as good as the next.  The runtime multiplexes a process's streams onto a few hardware queues
+// (GPU_MAX_HW_QUEUES), and a stream that lands on the CALLER's queue costs every pair of launches on the two streams
+// ~50 us: tools/queue_probe.hip — a tiny kernel on the null stream + one on the new stream + synchronise: 21 us on most
+// streams, 52-75 us on every third or fourth one created; simulate(20) at the bench shape then takes 124 us instead
+// of 80 although its kernels overlap on the device as usual (tools/slow_mode_probe.py) [MI355X, ROCm 7.2].  Which streams
+// are slow depends on how many the process has created and kept, at either priority.  So the second stream is not
+// simply created: candidates (highest priority: queues apart from the default-priority streams' in most processes,
+// DESIGN.md 7) are TIMED against the caller's stream — the same pair of launches, best of six — and the first one
+// within 20 us of two launches on the caller's stream alone is kept; rejected candidates stay allocated (destroying
+// one hands its queue to the next candidate).  One screened stream per (device, caller's stream) for the whole process:
+// every streamer of that caller borrows it (calls on one caller's stream are ordered anyway).  Screening needs the
+// caller's stream idle (it synchronises it); a first call that finds it busy borrows an unscreened stream and the
+// screening happens at the first idle call.
+namespace {
+struct SideEntry {
+  int dev;
+  hipStream_t main, side;
+  bool screened;
+  int pair_ns, ref_ns, rejected;
+};
+std::mutex g_side_mu;
+std::vector<SideEntry> g_side;
+std::vector<hipStream_t> g_parked;  // rejected candidates: kept for the life of the process
+uint32_t* g_scratch[64] = {nullptr};
+
+double host_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// a one-wave kernel that returns at once (started_target 0 against zeroed words)
+void tiny_launch(uint32_t* scratch, hipStream_t s) { (void)riab::launch_stream_gate(scratch, 0u, 0u, 0u, 1u, false, 0u, s); }
+
+// best of `n`: [one launch on `a`, one on `b`, synchronise both], microseconds
+double pair_us(uint32_t* scratch, hipStream_t a, hipStream_t b, int n) {
+  double best = 1e30;
+  for (int k = 0; k < n + 2; ++k) {
+    const double t0 = host_us();
+    tiny_launch(scratch, a);
+    tiny_launch(scratch, b);
+    (void)hipStreamSynchronize(b);
+    (void)hipStreamSynchronize(a);
+    const double t = host_us() - t0;
+    if (k >= 2 && t < best) best = t;  // (two warm-up rounds: a stream's first launches set its queue up)
+  }
+  return best;
+}
+
+hipStream_t new_candidate() {
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
+  return s;
+}
+
+// the screened stream for (dev, main_s); `idle`: the caller's stream is idle, screening may synchronise it
+bool side_stream_for(RiabStreamer* h, hipStream_t main_s, bool idle) {
+  std::lock_guard<std::mutex> lock(g_side_mu);
+  SideEntry* e = nullptr;
+  for (SideEntry& x : g_side)
+    if (x.dev == h->dev && x.main == main_s) e = &x;
+  if (!e) {
+    g_side.push_back(SideEntry{h->dev, main_s, nullptr, false, 0, 0, 0});
+    e = &g_side.back();
+  }
+  if (!e->screened && idle && h->dev >= 0 && h->dev < 64) {
+    uint32_t*& scratch = g_scratch[h->dev];
+    if (!scratch) {
+      if (hipMalloc((void**)&scratch, 256) != hipSuccess || hipMemset(scratch, 0, 256) != hipSuccess) scratch = nullptr;
+    }
+    if (scratch) {
+      const double ref = pair_us(scratch, main_s, main_s, 6);
+      hipStream_t best_s = e->side;  // (an unscreened stream borrowed by an earlier, busy call is the first candidate)
+      double best = 1e30;
+      int rejected = 0;
+      for (int c = 0; c < 6; ++c) {
+        hipStream_t cand = (c == 0 && e->side) ? e->side : new_candidate();
+        if (!cand) break;
+        const double t = pair_us(scratch, main_s, cand, 6);
+        if (t < best) {
+          if (best_s && best_s != cand) g_parked.push_back(best_s);
+          best = t;
+          best_s = cand;
+        } else {
+          g_parked.push_back(cand);
+        }
+        if (t <= ref + 20.0) break;
+        ++rejected;
+      }
+      if (best_s) {
+        e->side = best_s;
+        e->screened = true;
+        e->pair_ns = (int)(best * 1e3);
+        e->ref_ns = (int)(ref * 1e3);
+        e->rejected = rejected;
+      }
+    }
+  }
+  if (!e->side) e->side = new_candidate();
+  if (!e->side) return false;
+  h->side = e->side;
+  h->side_main = main_s;
+  h->side_screened = e->screened;
+  h->side_pair_ns = e->pair_ns;
+  h->side_ref_ns = e->ref_ns;
+  h->side_rejected = e->rejected;
+  return true;
+}
+}  // namespace
+
 extern "C" RiabStreamer* riab_streamer_create(void) {
   RiabStreamer* h = new (std::nothrow) RiabStreamer();
   if (!h) return nullptr;
   h->side = h->side_normal = nullptr;
+  h->side_main = nullptr;
+  h->side_screened = false;
+  h->dev = 0;
+  h->side_pair_ns = h->side_ref_ns = h->side_rejected = 0;
   h->side_mode = 0;
   h->step_ns_cfg = h->lead_mbps_cfg = h->step_ns_meas = h->lead_mbps_meas = 0;
   h->calibrated = false;
@@ -96,6 +221,7 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
   h->progress_end = 0;
   h->progress_valid = false;
   h->last_launches = 0;
+  h->late_calls = 0;
   h->fork = h->join = h->t0 = h->t1 = nullptr;
   h->timed = 0;
   h->n_pairs = 0;
@@ -106,20 +232,12 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
   h->head_rows = 256;
   h->last_form = RIAB_FORM_NONE;
   int dev = 0, khz = 0;
-  // The trajectory kernel's stream has the device's HIGHEST priority.  Not for the arbitration — for the hardware queue:
-  // the runtime maps streams of one priority onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and in a
-  // process that also holds an RCCL communicator the second stream ended up on the SAME queue as the caller's stream —
-  // the two kernels that are meant to run side by side then ran one after the other (cfg 2 under torch.distributed.run
-  // with the nccl backend: 256 steps 1.04 instead of 0.78 ms, 20 steps 132 instead of 92 us [MI355X]).  Streams of
-  // another priority have queues of their own.
-  int least = 0, greatest = 0;
-  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  if (hipGetDevice(&dev) != hipSuccess || hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, greatest) != hipSuccess ||
-      hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess ||
+  if (hipGetDevice(&dev) != hipSuccess || hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) != hipSuccess) {
     riab_streamer_destroy(h);
     return nullptr;
   }
+  h->dev = dev;
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
   h->wall_khz = khz;
   return h;
@@ -165,7 +283,7 @@ extern "C" void riab_streamer_destroy(RiabStreamer* h) {
   for (hipEvent_t e : h->pairs) (void)hipEventDestroy(e);
   if (h->join) (void)hipEventDestroy(h->join);
   if (h->fork) (void)hipEventDestroy(h->fork);
-  if (h->side) (void)hipStreamDestroy(h->side);
+  // (h->side belongs to the process-wide pool: side_stream_for)
   if (h->side_normal) (void)hipStreamDestroy(h->side_normal);
   delete h;
 }
@@ -217,6 +335,10 @@ extern "C" int64_t riab_streamer_info(RiabStreamer* h, int32_t which) {
     case 1: return (int64_t)lead_mbps_now(h);
     case 2: return (h->step_ns_cfg == 0 && h->step_ns_meas != 0) ? 1 : 0;
     case 3: return h->last_launches;
+    case 4: return h->side_screened ? h->side_pair_ns : -1;
+    case 5: return h->side_rejected;
+    case 6: return h->side_ref_ns;
+    case 7: return h->late_calls;
     default: return -1;
   }
 }
@@ -498,6 +620,9 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   const bool idle = hipStreamQuery(main_s) == hipSuccess;
   // (RIAB_STREAMER_OPT_SIDE_STREAM: 1 a stream at the default priority, 2 the caller's own stream — the two kernels then
   // run one after the other, which is what the RIAB_CTRL_SERIALISED diagnostic is tested with)
+  if (h->side_mode == 0 && (h->side_main != main_s || !h->side || (!h->side_screened && idle))) {
+    if (!side_stream_for(h, main_s, idle)) return RIAB_EINVAL;
+  }
   const hipStream_t side_s = h->side_mode == 2 ? main_s : (h->side_mode == 1 && h->side_normal ? h->side_normal : h->side);
   if (!idle && side_s != main_s) {
     hipError_t e = hipEventRecord(h->fork, main_s);
@@ -512,6 +637,12 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   bool state_published = false;
   rc = riab::launch_agent_pub(a, side_s, &state_published);
   if (rc) return rc;
+  const double t_traj_launched = host_us();
+  bool late_noted = false;
+  auto note_first_rate_launch = [&]() {   // (after the first launch of the rate stage has returned)
+    if (!late_noted && host_us() - t_traj_launched > 12.0) ++h->late_calls;
+    late_noted = true;
+  };
   h->last_launches = 1;
   const uint32_t n_traj = (uint32_t)((B + 63) / 64);
   h->started_total += n_traj;
@@ -555,6 +686,7 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
                                       spin_limit, stamps, main_s, events ? h->t0 : nullptr, events ? h->t1 : nullptr, false,
                                       reserve, serial_rows);
       ++h->last_launches;
+      note_first_rate_launch();
       if (head == T) h->prev_lead_row_bytes = (int64_t)pops[lead].n * B * (pops[lead].spikes_base ? 5 : 4);
     }
     for (int32_t t0 = head; t0 < T && !fail; t0 += tail_piece) {
@@ -602,6 +734,7 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
       fail = riab::launch_stream_gate(q->ctrl, h->started_total, n_traj, (uint32_t)q->step0 + (uint32_t)(t0 + tc),
                                       k == 0 ? 1u << 24 : 1u << 22, false,
                                       (k == 0 && serial_rows) ? (uint32_t)q->step0 + (uint32_t)T : 0u, main_s);
+      note_first_rate_launch();
       h->last_launches += 1 + n_pops;
       for (int i = 0; i < n_pops && !fail; ++i) {
         if (timing && i == q->timed_pop) (void)hipEventRecord(h->pairs[2 * k], main_s);

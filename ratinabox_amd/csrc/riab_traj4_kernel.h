@@ -492,15 +492,14 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
     if (PUB && ok) {
       // every row, this wave's part of the state, and — once the position / velocity wave and the noise wave have
       // reported theirs — the whole state of these 64 agents is in memory: the publication that ends the launch
+      // (device clock at the end of workgroup 0's work, stored BEFORE the wait below so that whoever sees the last
+      // publication finds this launch's stamp, not the previous one's)
+      if (lane == 0 && blockIdx.x == 0)
+        __hip_atomic_store((riab_gu64*)(uintptr_t)(a.ctrl + RIAB_CTRL_TRAJ_STAMPS + 2), (unsigned long long)__builtin_amdgcn_s_memrealtime(),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (t4_wait_counter(cnt, T4_C_STATE, 1u, true)) {
-        if (lane == 0 && blockIdx.x == 0)
-          __hip_atomic_store((riab_gu64*)(uintptr_t)(a.ctrl + RIAB_CTRL_TRAJ_STAMPS + 2), (unsigned long long)__builtin_amdgcn_s_memrealtime(),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        publish(T);
-      } else {
-        gave_up = true;
-      }
+      if (t4_wait_counter(cnt, T4_C_STATE, 1u, true)) publish(T);
+      else gave_up = true;
     }
   }
   if (gave_up && lane == 0) {

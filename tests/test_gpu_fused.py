@@ -626,7 +626,9 @@ def bench_cpus(text):
 def test_bench_launches_its_own_ranks(riab):
     """`python bench.py --gpus 2` (no launcher) must start two ranks and say so.  Both ranks share
     this box's one GPU (RIAB_BENCH_SHARE_GPU: gloo control plane), which exercises everything but RCCL."""
-    out = _bench(["--gpus", "2", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"], {"RIAB_BENCH_SHARE_GPU": "1"})
+    out = _bench(["--gpus", "2", "--steps", "64", "--warmup", "8", "--no-cpu-baseline", "--secondary-timeout", "150"],
+                 {"RIAB_BENCH_SHARE_GPU": "1"}, timeout=400)
+    assert "secondary_error" not in out, out["secondary_error"]
     assert out["n_gpus"] == 2 and out["steps"] == 64
     assert out["config"]["parallelism"].startswith("agent-sharded x2")
     assert out["value"] > 1e6 and out["diagnostics"].get("pipeline_timeouts", 0) == 0
@@ -649,7 +651,7 @@ def test_bench_launches_its_own_ranks(riab):
         assert blk["diagnostics"]["pipeline_timeouts"] == 0
         assert 0 < blk["frac_whole_path"] < 1 and blk["roofline"]["frac"] > 0
     strong = _bench(["--gpus", "2", "--strong", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"],
-                    {"RIAB_BENCH_SHARE_GPU": "1"})
+                    {"RIAB_BENCH_SHARE_GPU": "1"}, timeout=400)
     assert strong["scaling"] == "strong" and strong["config"]["agents_per_gpu"] == 2048 and strong["n_gpus"] == 2
 
 
@@ -1116,7 +1118,8 @@ def test_serialised_pipeline_is_detected(riab, tmp_path):
         got = _run(riab, True, 1024, _pc(128, save_spikes=False), [("sim", 40), ("sim", 7), ("sim", 24)])
         with pytest.warns(RuntimeWarning, match="one after the other"):
             d = got[3].diagnostics
-        assert d["pipeline_serialised"] == 2 and d["pipeline_timeouts"] == 0      # (the 7-step call is too short to tell)
+        # (the 7-step call is too short to tell; a call whose second launch the host issued late is not counted)
+        assert 1 <= d["pipeline_serialised"] <= 2 and d["pipeline_timeouts"] == 0
         for k in range(3):
             np.testing.assert_array_equal(got[k], ref[k])
         # the chunk form (two populations): its first gate does the counting

@@ -90,7 +90,9 @@ def measure(label, env=None, opts=None, timing=True):
             L.lib = orig
         torch.cuda.synchronize()
         d = ag.diagnostics
-        assert d["pipeline_timeouts"] == 0 and d["pipeline_serialised"] == 0, d
+        assert d["pipeline_timeouts"] == 0, d
+        if d["pipeline_serialised"]:
+            label += " [serialised %d]" % d["pipeline_serialised"]
         print("%-58s launches %d | call %5.1f sync %5.1f | total med %6.1f min %6.1f p90 %6.1f us -> %.3f G/s | kernel %s us | "
               "py-pre %4.1f native %4.1f py-post %4.1f" % (
                   label, n_launch, 1e6 * np.median(a), 1e6 * np.median(b), 1e6 * np.median(tot), 1e6 * tot.min(),
