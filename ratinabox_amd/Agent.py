@@ -194,6 +194,10 @@ class Agent:
         w = self._ctrl[:4].cpu()
         if int(w[_L.CTRL_TIMEOUTS]) or int(w[_L.CTRL_ABORT]):
             n = int(w[_L.CTRL_TIMEOUTS])
+            # (a rate stage that gave up did not wait for the trajectory kernel's last publication, which is what orders
+            # the caller's stream behind that kernel: wait for the whole device before the flags are cleared and the
+            # caller goes on — state uploads, the next update(), recycled buffers)
+            torch.cuda.synchronize(self._device)
             self._ctrl[_L.CTRL_TIMEOUTS] = 0
             self._ctrl[_L.CTRL_ABORT] = 0
             raise _L.RiabError(f"the flag-coupled simulate() pipeline was aborted ({n} waits timed out): the rows of "

@@ -14,9 +14,14 @@ import os as _os
 # backend "nccl") that was too few: the trajectory kernel's stream shared a queue with the caller's and the two kernels
 # ran one after the other (cfg 2, 20 steps: 131 instead of 90 us per call; 90 again with 8 queues [MI355X]).  The runtime
 # reads the variable when it initialises (the first HIP call of the process), so it is set here — unless the user has
-# set it — with a warning if the runtime was already up.
-_hwq_preset = "GPU_MAX_HW_QUEUES" in _os.environ
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# set it, or has asked for the process environment to be left alone (RIAB_KEEP_HW_QUEUES=1: child processes inherit
+# os.environ) — with a warning if the runtime was already up.  Round 4 added a second line of defence that needs no
+# environment variable: the library TIMES candidate streams against the caller's stream and sets aside those that
+# share its hardware queue (csrc/riab_simulate.hip side_stream_for, Agent.pipeline_info()); with more queues there
+# are more good candidates.
+_hwq_preset = "GPU_MAX_HW_QUEUES" in _os.environ or _os.environ.get("RIAB_KEEP_HW_QUEUES") == "1"
+if not _hwq_preset:
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 from . import _lib  # noqa: E402,F401  (fails loudly when the HIP library is unavailable)
 

@@ -64,19 +64,23 @@ class DeviceHistory:
         """Rows left in the current chunk (0: the next reservation opens a new chunk)."""
         return self.chunks[-1].shape[0] - self.filled[-1] if self.chunks else 0
 
-    def open_rows(self, T):
+    def open_rows(self, T, chunk_rows=None):
         """A writable view of UP TO T free rows that are NOT yet counted as history (a step plan writes them one by
         one); `commit(n)` then publishes the first n of them.  A non-empty free tail of the current chunk is handed
         out as it is, however short (the caller re-opens when it is used up): a plan that is closed and rebuilt —
         the automatic stepper does that whenever a non-plain call interrupts the loop — continues in the rows its
         predecessor left instead of abandoning them behind a new chunk.  Only a full chunk is followed by a new one
-        of T rows."""
+        of max(T, chunk_rows) rows."""
         T = int(T)
         free = self.free_rows()
         if free <= 0:
-            self.chunks.append(torch.empty((T, *self.row_shape), dtype=self.dtype, device=self.device))
+            # `chunk_rows`: the size of a NEW chunk when T was cut down to another history's short tail (a plan opens
+            # the same number of rows in every history): the new chunk is full-sized, only the view is T rows — a
+            # 3-row tail elsewhere must not leave a 3-row chunk here (stack() concatenates every chunk on every read)
+            rows = max(T, int(chunk_rows or T))
+            self.chunks.append(torch.empty((rows, *self.row_shape), dtype=self.dtype, device=self.device))
             self.filled.append(0)
-            free = T
+            free = rows
         s = self.filled[-1]
         return self.chunks[-1][s:s + min(T, free)]
 

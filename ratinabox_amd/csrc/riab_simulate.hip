@@ -617,6 +617,10 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   // It has to start after what the caller's stream holds (earlier calls' kernels wrote the state it reads).  When that
   // stream is idle — the case that matters for latency: one short call per synchronisation — there is nothing to wait
   // for and the launch goes out with no API call in front of it but the query; otherwise an event carries the order.
+  // (a stream that is being captured must not be queried — the query would invalidate the capture — and a run that
+  // hands work between two streams through words in memory is not something a graph can replay: refused, nothing launched)
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(main_s, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) return RIAB_EUNSUPPORTED;
   const bool idle = hipStreamQuery(main_s) == hipSuccess;
   // (RIAB_STREAMER_OPT_SIDE_STREAM: 1 a stream at the default priority, 2 the caller's own stream — the two kernels then
   // run one after the other, which is what the RIAB_CTRL_SERIALISED diagnostic is tested with)
@@ -755,8 +759,12 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   // needed for the two-wave kernel (RIAB_OPT_TRAJ_KERNEL = 2) — and after a failure, when nothing may have waited.
   // [MI355X, cfg 2, 20 steps: the event's record + wait were 4.7 us of host time and its barrier packet sat between the
   // rate kernel's end and the host's wake-up: 97 -> 89 us per call without them.]
+  // When the caller's stream was BUSY at the call, host time is not what the call is short of: the event is recorded as
+  // well — should a wait of the rate stage give up (abort flag), whatever follows on the caller's stream is then still
+  // ordered behind the trajectory kernel.  (After an abort on an idle stream the host layer synchronises the device
+  // before it clears the flags: Agent._check_pipeline.)
   hipError_t e = hipSuccess;
-  if ((!state_published || fail) && side_s != main_s) {
+  if ((!state_published || fail || !idle) && side_s != main_s) {
     e = hipEventRecord(h->join, side_s);
     if (e == hipSuccess) e = hipStreamWaitEvent(main_s, h->join, 0);
   }

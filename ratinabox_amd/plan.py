@@ -119,15 +119,15 @@ class StepPlan:
             if h.free_rows() > 0:
                 cap = min(cap, h.free_rows())
         if ag.save_history:
-            self._agent_rows = ag._hist.open_rows(cap)
+            self._agent_rows = ag._hist.open_rows(cap, self.capacity)
             _L.check(_L.lib.riab_plan_set_agent_history(self._h, _L.ptr(self._agent_rows), cap), "riab_plan_set_agent_history")
         else:
             self._agent_rows = None
             _L.check(_L.lib.riab_plan_set_agent_history(self._h, None, 0), "riab_plan_set_agent_history")
         for i, N in enumerate(self.neurons):
             if N.save_history:
-                fr = N._hist_fr.open_rows(cap)
-                sp = N._hist_sp.open_rows(cap) if N.save_spikes else None
+                fr = N._hist_fr.open_rows(cap, self.capacity)
+                sp = N._hist_sp.open_rows(cap, self.capacity) if N.save_spikes else None
                 self._pop_rows[i] = (fr, sp)
                 rc = _L.lib.riab_plan_set_population_history(self._h, i, _L.ptr(fr), _L.ptr(sp), cap)
             else:
@@ -347,13 +347,13 @@ class AutoStepper:
         N, ag = self.neurons[i], self.agent
         self._sync_pop(i)
         if N.save_history:
-            cap = int(max(64, min(self.CAPACITY, self.CHUNK_BYTES // max(1, int(N.n) * ag._Bp * 4))))
+            full = cap = int(max(64, min(self.CAPACITY, self.CHUNK_BYTES // max(1, int(N.n) * ag._Bp * 4))))
             if N.save_spikes:  # (rates and spikes advance together; should their free tails differ, the shorter one counts)
                 tails = [h.free_rows() for h in (N._hist_fr, N._hist_sp) if h.free_rows() > 0]
                 cap = min([cap] + tails)
-            fr = N._hist_fr.open_rows(cap)
+            fr = N._hist_fr.open_rows(cap, full)   # (a history without free rows opens a full-sized chunk, not a `cap`-row one)
             cap = int(fr.shape[0])
-            sp = N._hist_sp.open_rows(cap) if N.save_spikes else None
+            sp = N._hist_sp.open_rows(cap, full) if N.save_spikes else None
             self._pop_rows[i] = (fr, sp)
             rc = _L.lib.riab_plan_set_population_history(self._h, i, _L.ptr(fr), _L.ptr(sp), cap)
         else:

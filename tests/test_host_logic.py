@@ -131,6 +131,15 @@ def test_device_history_buffers():
     assert len(h.chunks) == n_chunks  # used the preallocated rows
     h.reset()
     assert len(h) == 0 and h.stack().shape == (0, 3, 4)
+    # a plan that opens the same number of rows in every history caps it by the shortest free tail — a
+    # history whose chunk is FULL then opens a full-sized chunk and hands out a short view, not a short chunk
+    h.preallocate(6)
+    h.reserve(6)
+    assert h.free_rows() == 0
+    v = h.open_rows(3, 50)
+    assert v.shape[0] == 3 and h.chunks[-1].shape[0] == 50 and h.free_rows() == 50
+    h.commit(3)
+    assert h.open_rows(100, 50).shape[0] == 47 and len(h) == 9      # (the rest of that chunk, however large the request)
 
 
 def test_samplers():
