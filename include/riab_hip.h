@@ -579,7 +579,9 @@ double riab_plan_task_clock(const RiabPlan* plan);
  * forced_pos != NULL (Agent.import_trajectory / forced_next_position, Agent.py:229-266): there is no recurrence to
  * overlap: the forced-position kernel and the populations' kernels follow each other on `stream`.
  * Velocity cells (they read the float64 state, which no history row keeps) are not covered: RIAB_EUNSUPPORTED,
- * nothing launched; callers advance them through a step plan.
+ * nothing launched; callers advance them through a step plan.  A `stream` that is being captured into a graph:
+ * RIAB_EUNSUPPORTED too (the call queries the stream, and two kernels coupled through words in memory on two streams
+ * are not something a graph replay can reproduce).
  *
  * A RiabStreamer holds what the coupling needs besides the kernels: a second HIP stream (the trajectory kernel runs
  * there; the rate stage — which ends last — on `stream`, so that a host synchronisation returns as soon after the
@@ -691,12 +693,14 @@ void riab_streamer_destroy(RiabStreamer* h);
 /* ... SIDE_STREAM: where the trajectory kernel runs — 0 (default) a stream of the streamer's own at the device's
  * highest priority, 1 a stream of its own at the default priority, 2 the caller's stream (the two kernels then run one
  * after the other: for tests of the RIAB_CTRL_SERIALISED diagnostic); takes effect at the next call.
- * STEP_NS / LEAD_MBPS: what the choice between the populations form and the chunk form compares — a trajectory step
- * next to the rate stage, in nanoseconds, and the lead population's store rate in MB/s.  0 (default): measured — the
- * first call with several populations that finds `stream` idle reads the device-clock stamps the previous call left
- * in ctrl (one blocking 32-byte copy, once per streamer) and keeps the ratio; until then, and when the stamps are
- * unusable, the constants measured on MI355X (900 ns + 250 ns per wall beyond four, x 1.5; 6.5 TB/s).  A non-zero
- * value replaces the measurement (tests; chips whose clocks are known to differ). */
+ * STEP_NS / LEAD_MBPS: what the choice between the populations form and the chunk form compares — a trajectory step,
+ * in nanoseconds, and the lead population's store rate in MB/s: the lead leads when its stores of a row take at least
+ * 1.5 steps (2 steps when the step time is a measurement: it was not taken next to a store stream).  0 (default):
+ * measured — the first call with several populations that finds `stream` idle reads the device-clock stamps the
+ * previous call left in ctrl (one blocking 32-byte copy, once per streamer) and keeps the step time as a factor on the
+ * built-in figure; until then, and when the stamps are unusable, the constants measured on MI355X (900 ns + 250 ns per
+ * wall beyond four; 6.5 TB/s).  A non-zero value replaces the measurement (tests; chips whose clocks are known to
+ * differ). */
 enum { RIAB_STREAMER_OPT_GATE = 0, RIAB_STREAMER_OPT_POLL_MAX = 1, RIAB_STREAMER_OPT_HEAD_ROWS = 2,
        RIAB_STREAMER_OPT_SIDE_STREAM = 3, RIAB_STREAMER_OPT_STEP_NS = 4, RIAB_STREAMER_OPT_LEAD_MBPS = 5 };
 enum { RIAB_GATE_ALWAYS = 0, RIAB_GATE_WHEN_BUSY = 1, RIAB_GATE_RESERVED = 2 };

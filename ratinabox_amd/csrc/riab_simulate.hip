@@ -567,7 +567,13 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
       if (lead >= 0) {
         if (!h->calibrated && h->step_ns_cfg == 0 && hipStreamQuery((hipStream_t)stream) == hipSuccess) calibrate_from_stamps(h);
         const double row_ns = (double)best / lead_mbps_now(h) * 1e3;  // bytes / (MB/s) = us; x 1e3 = ns
-        if (row_ns < 1.5 * step_ns_now(h, env->n_walls)) lead = -1;
+        // x 1.5: next to a kernel that saturates HBM the trajectory kernel's clock and its write-throughs slow down by that
+        // much (cfg 2 / cfg 5: 0.85-1.1 us per step measured next to the stores against the formula's 1.35; cfg 3: 2.05
+        // against 3.2).  x 2 for a MEASURED step: it was taken next to whatever the earlier call ran — in the chunk form
+        // the arithmetic-bound boundary-vector kernel, which slows the trajectory less than a store stream does — and
+        // includes a short call's start-up [MI355X: cfg 3's 32-step warm-up gives 1.6 us per step, not 2.05].
+        const double margin = (h->step_ns_cfg == 0 && h->step_ns_meas != 0) ? 2.0 : 1.5;
+        if (row_ns < margin * step_ns_now(h, env->n_walls)) lead = -1;
       }
     }
   }

@@ -107,13 +107,15 @@ def test_bench_length_run_native_against_comparator_and_oracle(riab, name, form)
         try:
             env, ag, pops = bench.build_world(riab, cfg, 0)
             ag.simulate(WARM)
-            ag.simulate(STEPS)
+            torch.cuda.synchronize()   # (as in bench.py: the timed call finds the stream idle — and, with several populations,
+            ag.simulate(STEPS)         # reads the warm-up call's device-clock stamps before it chooses its form)
             torch.cuda.synchronize()
             d = ag.diagnostics
             assert d["bounce_saturations"] == 0
             if engine == "native":
                 assert ag.engine_runs["native"] == 2 and ag.last_rate_stage_form() == form, (ag.engine_runs, ag.last_rate_stage_form())
                 assert d["pipeline_timeouts"] == 0 and d["pipeline_serialised"] == 0, d
+                assert ag.pipeline_info()["form_selection"]["measured"], "the form was chosen without the measured step time"
                 B = cfg["agents"]
                 sel = np.arange(0, B, B // 32) + 5
                 # rows of the whole history (warm-up call first): the first row, the long call's first row, both sides of a
