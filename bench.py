@@ -192,12 +192,12 @@ def _format_cpulist(cpus):
     return ",".join(out)
 
 
-def gpu_numa_nodes():
+def gpu_numa_nodes(sysfs="/sys"):
     """[(numa node, [cpus of that node], pci address)] of the GPUs in the order the HIP runtime numbers them, from sysfs
     only (no HIP call): the KFD topology lists the GPU nodes in the runtime's order and names each one's DRM render
     node, whose PCI device carries `numa_node` / `local_cpulist`; ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES (integer lists)
     are applied the way the runtime applies them."""
-    base = "/sys/class/kfd/kfd/topology/nodes"
+    base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
     gpus = []
     for node in sorted((d for d in os.listdir(base) if d.isdigit()), key=int):
         props = {}
@@ -207,7 +207,7 @@ def gpu_numa_nodes():
                 props[k] = v
         if int(props.get("simd_count", "0")) <= 0:
             continue  # a CPU node
-        dev = f"/sys/class/drm/renderD{int(props['drm_render_minor'])}/device"
+        dev = os.path.join(sysfs, f"class/drm/renderD{int(props['drm_render_minor'])}/device")
         with open(os.path.join(dev, "numa_node")) as f:
             numa = int(f.read().strip())
         with open(os.path.join(dev, "local_cpulist")) as f:
@@ -222,14 +222,14 @@ def gpu_numa_nodes():
     return gpus
 
 
-def bind_rank_to_gpu_numa(local, n_local):
+def bind_rank_to_gpu_numa(local, n_local, sysfs="/sys", apply=True):
     """Pin this process — before its first HIP call, so that the runtime's own threads inherit the mask — to cores of
     the NUMA node its GPU hangs off.  Every rank spins on the host for a fifth of a 90 us region and `value` takes the
     slowest rank of every repeat: a rank scheduled on the far socket, or two ranks sharing a core, would set the
     8-GPU number.  Ranks whose GPUs share a node get disjoint, equal sets of whole cores (all hardware threads of a
     core go to the same rank).  Returns what was done, for the bench line's `config`."""
     try:
-        gpus = gpu_numa_nodes()
+        gpus = gpu_numa_nodes(sysfs)
         if local >= len(gpus):
             return {"binding": "none", "why": f"{len(gpus)} GPUs found in sysfs, local rank {local}"}
         numa, cpus, pci = gpus[local]
@@ -241,7 +241,7 @@ def bind_rank_to_gpu_numa(local, n_local):
         cores = {}
         for c in cpus:  # hardware threads grouped into cores
             try:
-                with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                with open(os.path.join(sysfs, f"devices/system/cpu/cpu{c}/topology/thread_siblings_list")) as f:
                     key = tuple(x for x in _parse_cpulist(f.read()) if x in allowed)
             except OSError:
                 key = (c,)
@@ -253,7 +253,8 @@ def bind_rank_to_gpu_numa(local, n_local):
             mine = sorted(c for core in cores[k * per:(k + 1) * per] for c in core)
         else:
             mine = cpus
-        os.sched_setaffinity(0, mine)
+        if apply:
+            os.sched_setaffinity(0, mine)
         return {"binding": "numa", "numa_node": numa, "gpu_pci": pci, "cpus": _format_cpulist(mine), "n_cpus": len(mine),
                 "ranks_on_this_node": len(mates)}
     except Exception as e:  # noqa: BLE001  (sysfs layout, permissions, UUID device lists: run unbound rather than not at all)

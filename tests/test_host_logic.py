@@ -1,6 +1,7 @@
 """Host-side logic on CPU tensors (no kernels launched): the parameter protocol, the
 Environment's wall table, seeded init-time sampling against the reference's own values
 (tests/golden/update_init.npz, G5), history buffers."""
+import os
 import warnings
 
 import numpy as np
@@ -411,3 +412,54 @@ def test_public_helpers_vs_reference():
     bv.cell_arrangement = "hexagonal"
     with pytest.raises(ValueError):
         bv.set_tuning_parameters()
+
+
+def test_bench_pins_ranks_to_their_gpus_numa_node(tmp_path, monkeypatch):
+    """every rank of a multi-GPU bench line runs on cores of its GPU's NUMA node, and ranks whose GPUs share
+    a node get disjoint sets of WHOLE cores — worked out from sysfs alone (no HIP call).  A fake sysfs tree: 8 GPUs on 2
+    nodes (KFD nodes 2-9 after two CPU nodes), 16 cores x 2 hardware threads per node."""
+    import bench
+    sysfs = tmp_path / "sys"
+    kfd = sysfs / "class/kfd/kfd/topology/nodes"
+    for node in (0, 1):   # CPU nodes
+        (kfd / str(node)).mkdir(parents=True)
+        (kfd / str(node) / "properties").write_text("cpu_cores_count 32\nsimd_count 0\n")
+    cpus_of = {0: list(range(0, 16)) + list(range(32, 48)), 1: list(range(16, 32)) + list(range(48, 64))}
+    for g in range(8):
+        numa = 0 if g < 4 else 1
+        (kfd / str(2 + g)).mkdir(parents=True)
+        (kfd / str(2 + g) / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {128 + g}\n")
+        pci = sysfs / f"devices/pci0000:00/0000:{g:02x}:00.0"
+        pci.mkdir(parents=True)
+        (pci / "numa_node").write_text(f"{numa}\n")
+        (pci / "local_cpulist").write_text(bench._format_cpulist(cpus_of[numa]) + "\n")
+        drm = sysfs / f"class/drm/renderD{128 + g}"
+        drm.mkdir(parents=True)
+        os.symlink(pci, drm / "device")
+    for c in range(64):
+        d = sysfs / f"devices/system/cpu/cpu{c}/topology"
+        d.mkdir(parents=True)
+        (d / "thread_siblings_list").write_text(f"{c % 32},{c % 32 + 32}\n")
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    gpus = bench.gpu_numa_nodes(str(sysfs))
+    assert [g[0] for g in gpus] == [0, 0, 0, 0, 1, 1, 1, 1] and gpus[5][2] == "0000:05:00.0"
+    got = [bench.bind_rank_to_gpu_numa(r, 8, str(sysfs), apply=False) for r in range(8)]
+    sets = [set(bench._parse_cpulist(b["cpus"])) for b in got]
+    for r, b in enumerate(got):
+        assert b["binding"] == "numa" and b["numa_node"] == (0 if r < 4 else 1) and b["ranks_on_this_node"] == 4
+        assert b["n_cpus"] == 8 and sets[r] <= set(cpus_of[b["numa_node"]])
+        assert all((c % 32) in sets[r] and (c % 32 + 32) in sets[r] for c in sets[r]), "a core was split between ranks"
+        for q in range(r):
+            assert not (sets[r] & sets[q]), "two ranks share a core"
+    # the runtime's device selection is applied before the lookup
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "6,1")
+    assert [g[2] for g in bench.gpu_numa_nodes(str(sysfs))] == ["0000:06:00.0", "0000:01:00.0"]
+    two = [bench.bind_rank_to_gpu_numa(r, 2, str(sysfs), apply=False) for r in range(2)]
+    assert [b["numa_node"] for b in two] == [1, 0] and all(b["n_cpus"] == 32 and b["ranks_on_this_node"] == 1 for b in two)
+    # anything unexpected: unbound, with the reason, never an exception
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-deadbeef")
+    assert bench.bind_rank_to_gpu_numa(0, 1, str(sysfs), apply=False)["binding"] == "none"
+    assert bench.bind_rank_to_gpu_numa(0, 1, str(tmp_path / "nothing"), apply=False)["binding"] == "none"
+    assert bench._parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11] and bench._format_cpulist([3, 1, 2, 7]) == "1-3,7"

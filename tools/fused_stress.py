@@ -6,7 +6,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ratinabox_amd as riab
 
-def run(native, calls, K, B=4096, n=1024, two=False):
+def run(native, calls, K, B=4096, n=1024, two=False, idle=False):
     os.environ["RIAB_NO_FUSED"] = "0" if native else "1"
     os.environ["RIAB_NO_NATIVE"] = "0" if native else "1"
     np.random.seed(0)
@@ -26,6 +26,8 @@ def run(native, calls, K, B=4096, n=1024, two=False):
             for p in pops:
                 p.reset_history()
             ag.preallocate_history(per * K)
+        if idle:   # the caller's stream idle at every call: the short-call road (two launches, the reserving shape)
+            torch.cuda.synchronize()
         ag.simulate(K)
         for j, p in enumerate(pops):
             fr, _ = p.get_history_tensors()
@@ -33,15 +35,21 @@ def run(native, calls, K, B=4096, n=1024, two=False):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     d = ag.diagnostics
-    return sums.cpu().numpy(), ag.state_tensor.cpu().numpy(), d, el, ag.last_rate_stage_form()
+    return sums.cpu().numpy(), ag.state_tensor.cpu().numpy(), d, el, ag.last_rate_stage_form(), ag.pipeline_info()
 
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 for K, two, c in ((20, False, calls), (64, False, calls // 4), (300, False, calls // 16), (1100, False, calls // 64),
                   (20, True, calls // 4), (300, True, calls // 16), (1100, True, calls // 64),
                   (20, "bvc", calls // 8), (300, "bvc", calls // 32), (1100, "bvc", calls // 128)):
-    a, sa, da, ta, form = run(True, c, K, two=two)
-    b, sb, db, tb, _ = run(False, c, K, two=two)
+    a, sa, da, ta, form, _info = run(True, c, K, two=two)
+    b, sb, db, tb, _, _ = run(False, c, K, two=two)
     ok = np.array_equal(a, b) and np.array_equal(sa, sb)
+    if not two and K <= 64:   # the same calls from an idle stream: the reserving (twelve-wave) shape, no started gate
+        a2, sa2, da2, ta2, form2, info2 = run(True, c, K, two=two, idle=True)
+        ok2 = np.array_equal(a2, b) and np.array_equal(sa2, sb)
+        print("K=%-4d populations=place calls=%-5d idle stream: form=%s launches per call=%d identical=%s timeouts=%s serialised=%s (%.1f s)" % (
+            K, c, form2, info2["launches_last_call"], ok2, da2.get("pipeline_timeouts"), da2.get("pipeline_serialised"), ta2), flush=True)
+        assert ok2 and da2.get("pipeline_timeouts", 0) == 0 and info2["launches_last_call"] == 2
     print("K=%-4d populations=%s calls=%-5d form=%-11s identical=%s timeouts=%s  (%.1f s native, %.1f s chunked)" % (
         K, {False: "place", True: "place+grid", "bvc": "place+bvc"}[two], c, form, ok, da.get("pipeline_timeouts"), ta, tb), flush=True)
     assert ok and da.get("pipeline_timeouts", 0) == 0
