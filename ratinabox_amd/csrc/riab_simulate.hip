@@ -159,7 +159,9 @@ bool side_stream_for(RiabStreamer* h, hipStream_t main_s, bool idle) {
     g_side.push_back(SideEntry{h->dev, main_s, nullptr, false, 0, 0, 0});
     e = &g_side.back();
   }
-  if (!e->screened && idle && h->dev >= 0 && h->dev < 64) {
+  int cur_dev = -1;
+  (void)hipGetDevice(&cur_dev);   // (screening allocates and launches on the CURRENT device: only when that is the streamer's)
+  if (!e->screened && idle && cur_dev == h->dev && h->dev >= 0 && h->dev < 64) {
     uint32_t*& scratch = g_scratch[h->dev];
     if (!scratch) {
       if (hipMalloc((void**)&scratch, 256) != hipSuccess || hipMemset(scratch, 0, 256) != hipSuccess) scratch = nullptr;
