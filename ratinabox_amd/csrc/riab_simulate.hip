@@ -669,11 +669,12 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   // (the trajectory rows are complete, the rates of this call are not).
   int fail = RIAB_OK;
   if (lead >= 0) {
-    // Both kernels must be resident at once or the rate waves spin for nothing: a one-wave gate in front of the rate
-    // kernel returns only once every trajectory workgroup of THIS launch has announced itself — the rate waves can then
-    // never occupy the slots the kernel they wait for still needs, whatever else runs on the device (another stream,
-    // another process: two ranks sharing one GPU ran into the waits' time limit without it).  RIAB_GATE_WHEN_BUSY drops
-    // it when the caller's stream was idle (callers that own the device).  The gate also resets the device time stamps.
+    // Both kernels must be resident at once or the rate waves spin for nothing (riab_hip.h "Residency"): either the
+    // row-following kernel is launched in its reserving shape — twelve-wave workgroups, one wave slot per SIMD always
+    // free for a trajectory workgroup: no gate — or a one-wave gate in front of it returns only once every trajectory
+    // workgroup of THIS launch has announced itself: the rate waves can then never occupy the slots the kernel they wait
+    // for still needs, whatever else runs on the device (another stream, another process: two ranks sharing one GPU ran
+    // into the waits' time limit with neither).  RIAB_GATE_WHEN_BUSY drops both when the caller's stream was idle.
     const bool timed_lead = timing && q->timed_pop == lead;
     const bool events = pure && timed_lead && q->timing_mode == RIAB_TIMING_EVENTS;
     // (device-clock stamps of the row-following kernel: one store by the grid's first wave, one maximum by the sixteen
