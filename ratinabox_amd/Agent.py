@@ -547,6 +547,9 @@ class Agent:
             _L.check(_L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_GATE,
                                                     {"always": _L.GATE_ALWAYS, "when_busy": _L.GATE_WHEN_BUSY,
                                                      "reserved": _L.GATE_RESERVED}[gate]), "riab_streamer_configure")
+        if _L.env("RIAB_FORM_STEP_NS"):   # (A/B of the populations / chunk form: the trajectory step the choice compares, in ns)
+            _L.check(_L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_STEP_NS, int(_L.env("RIAB_FORM_STEP_NS"))),
+                     "riab_streamer_configure")
         if _L.env("RIAB_SIDE_STREAM"):      # (1: default-priority second stream; 2: the caller's stream — serial, diagnostics)
             _L.check(_L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_SIDE_STREAM, int(_L.env("RIAB_SIDE_STREAM"))),
                      "riab_streamer_configure")
