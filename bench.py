@@ -143,9 +143,13 @@ def cpu_baseline(cfg, seconds=8.0):
     all_cpus = _ALL_CPUS or os.sched_getaffinity(0)   # (the workers run on every core, not on the rank's NUMA share)
 
     def launch(agents, secs, seed):
-        return subprocess.Popen(base + ["--agents", str(agents), "--seconds", str(secs), "--seed", str(seed)],
-                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT, env=env, text=True,
-                                preexec_fn=lambda: os.sched_setaffinity(0, all_cpus))
+        p = subprocess.Popen(base + ["--agents", str(agents), "--seconds", str(secs), "--seed", str(seed)],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT, env=env, text=True)
+        try:   # (the child inherited this rank's NUMA share: give it every core back — from here, not in a preexec_fn)
+            os.sched_setaffinity(p.pid, all_cpus)
+        except OSError:
+            pass
+        return p
 
     def collect(procs):
         total, longest, ok = 0.0, 0.0, 0
