@@ -751,7 +751,7 @@ int riab_set_option(int32_t option, int32_t value);
 int riab_host_wait_spin(int32_t on);
 
 /* sizeof of the ABI's structs as compiled into the library (which: 0 RiabEnv, 1 RiabMotion, 2 RiabRateIO,
- * 3 RiabPopulation, 4 RiabTask, 5 RiabFFInput, 7 RiabSimulate; 6 returns RIAB_TS_ROWS): bindings verify their mirrors at
+ * 3 RiabPopulation, 4 RiabTask, 5 RiabFFInput, 7 RiabSimulate, 8 RiabWatch; 6 returns RIAB_TS_ROWS): bindings verify their mirrors at
  * load */
 int64_t riab_abi_sizeof(int32_t which);
 

@@ -234,7 +234,7 @@ def _load():
     # the ctypes mirrors must have the layouts the library was compiled with (a stale library with the same
     # version number would otherwise corrupt memory silently)
     mirrors = ((0, RiabEnv), (1, RiabMotion), (2, RiabRateIO), (3, RiabPopulation), (4, RiabTask), (5, RiabFFInput),
-               (7, RiabSimulate))
+               (7, RiabSimulate), (8, RiabWatch))
     for which, cls in mirrors:
         if lib.riab_abi_sizeof(which) != C.sizeof(cls):
             raise ImportError(f"libriab_hip.so: sizeof({cls.__name__}) is {lib.riab_abi_sizeof(which)} in the library, "

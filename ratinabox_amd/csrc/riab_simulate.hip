@@ -800,6 +800,7 @@ extern "C" int64_t riab_abi_sizeof(int32_t which) {
     case 5: return (int64_t)sizeof(RiabFFInput);
     case 6: return (int64_t)RIAB_TS_ROWS;
     case 7: return (int64_t)sizeof(RiabSimulate);
+    case 8: return (int64_t)sizeof(RiabWatch);
     default: return -1;
   }
 }
