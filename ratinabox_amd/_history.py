@@ -19,6 +19,7 @@ class DeviceHistory:
         self.chunk_rows = int(max(1, min(4096, chunk_bytes // self.row_bytes)))
         self.chunks = []   # tensors [rows, *row_shape]
         self.filled = []   # rows used per chunk
+        self.caps = []     # rows of each chunk (chunk.shape[0] builds a torch.Size: 0.3 us on a path that counts them)
         self.version = 0
 
     def __len__(self):
@@ -36,14 +37,21 @@ class DeviceHistory:
         the address as `chunk.data_ptr() + first_row * row_bytes` and build the view after their launch."""
         T = int(T)
         self.version += 1
-        if self.chunks and self.chunks[-1].shape[0] - self.filled[-1] >= T:
-            s = self.filled[-1]
-            self.filled[-1] += T
-            return self.chunks[-1], s
+        filled = self.filled
+        if filled:
+            s = filled[-1]
+            if self.caps[-1] - s >= T:
+                filled[-1] = s + T
+                return self.chunks[-1], s
         rows = max(T, self.chunk_rows) if T == 1 else T
-        self.chunks.append(torch.empty((rows, *self.row_shape), dtype=self.dtype, device=self.device))
-        self.filled.append(T)
+        self._new_chunk(rows)
+        filled[-1] = T
         return self.chunks[-1], 0
+
+    def _new_chunk(self, rows):
+        self.chunks.append(torch.empty((rows, *self.row_shape), dtype=self.dtype, device=self.device))
+        self.filled.append(0)
+        self.caps.append(int(rows))
 
     def unreserve(self, T):
         """Give back the T rows of the latest reserve() (nothing was written to them)."""
@@ -55,14 +63,13 @@ class DeviceHistory:
         """Make sure the next `reserve(T)` finds T free rows (allocation happens here, not
         in the stepping loop)."""
         T = int(T)
-        if self.chunks and self.chunks[-1].shape[0] - self.filled[-1] >= T:
+        if self.chunks and self.caps[-1] - self.filled[-1] >= T:
             return
-        self.chunks.append(torch.empty((T, *self.row_shape), dtype=self.dtype, device=self.device))
-        self.filled.append(0)
+        self._new_chunk(T)
 
     def free_rows(self):
         """Rows left in the current chunk (0: the next reservation opens a new chunk)."""
-        return self.chunks[-1].shape[0] - self.filled[-1] if self.chunks else 0
+        return self.caps[-1] - self.filled[-1] if self.chunks else 0
 
     def open_rows(self, T, chunk_rows=None):
         """A writable view of UP TO T free rows that are NOT yet counted as history (a step plan writes them one by
@@ -78,8 +85,7 @@ class DeviceHistory:
             # the same number of rows in every history): the new chunk is full-sized, only the view is T rows — a
             # 3-row tail elsewhere must not leave a 3-row chunk here (stack() concatenates every chunk on every read)
             rows = max(T, int(chunk_rows or T))
-            self.chunks.append(torch.empty((rows, *self.row_shape), dtype=self.dtype, device=self.device))
-            self.filled.append(0)
+            self._new_chunk(rows)
             free = rows
         s = self.filled[-1]
         return self.chunks[-1][s:s + min(T, free)]
@@ -87,7 +93,7 @@ class DeviceHistory:
     def commit(self, n):
         if n:
             self.filled[-1] += int(n)
-            assert self.filled[-1] <= self.chunks[-1].shape[0]
+            assert self.filled[-1] <= self.caps[-1]
             self.version += 1
 
     def stack(self):
@@ -104,7 +110,7 @@ class DeviceHistory:
         return None
 
     def reset(self):
-        self.chunks, self.filled = [], []
+        self.chunks, self.filled, self.caps = [], [], []
         self.version += 1
 
 

@@ -353,7 +353,7 @@ def test_fused_launch_modes(riab, gate, launches):
     os.environ["RIAB_GATE"] = gate
     try:
         t_a, fr_a, _sp, ag_a = _run(riab, True, 1024, _pc(256, save_spikes=False), [("sim", 48), ("sim", 16)])
-        assert ag_a.diagnostics["pipeline_timeouts"] == 0 and ag_a.diagnostics["pipeline_serialised"] == 0
+        assert ag_a.diagnostics["pipeline_timeouts"] == 0 and ag_a.diagnostics["pipeline_serialised"] <= 1   # (a lone count: a device hiccup)
         L = riab._lib
         torch.cuda.synchronize()
         ag_a.simulate(16)                       # the stream is idle: the mode's own number of launches
@@ -1111,15 +1111,16 @@ def test_serialised_pipeline_is_detected(riab, tmp_path):
     import subprocess
     import sys
     import warnings
-    ref = _run(riab, True, 1024, _pc(128, save_spikes=False), [("sim", 40), ("sim", 7), ("sim", 24)])
-    assert ref[3].diagnostics["pipeline_serialised"] == 0
+    sched = [("sim", 40), ("sim", 7), ("sim", 24), ("sim", 16), ("sim", 16)]
+    ref = _run(riab, True, 1024, _pc(128, save_spikes=False), sched)
+    assert ref[3].diagnostics["pipeline_serialised"] <= 1
     os.environ["RIAB_SIDE_STREAM"] = "2"
     try:
-        got = _run(riab, True, 1024, _pc(128, save_spikes=False), [("sim", 40), ("sim", 7), ("sim", 24)])
-        with pytest.warns(RuntimeWarning, match="one after the other"):
+        got = _run(riab, True, 1024, _pc(128, save_spikes=False), sched)
+        with pytest.warns(RuntimeWarning, match="one after the other"):   # (systematic: at least 3 calls and 5 % of them)
             d = got[3].diagnostics
         # (the 7-step call is too short to tell; a call whose second launch the host issued late is not counted)
-        assert 1 <= d["pipeline_serialised"] <= 2 and d["pipeline_timeouts"] == 0
+        assert 3 <= d["pipeline_serialised"] <= 4 and d["pipeline_timeouts"] == 0
         for k in range(3):
             np.testing.assert_array_equal(got[k], ref[k])
         # the chunk form (two populations): its first gate does the counting
@@ -1145,6 +1146,6 @@ def test_serialised_pipeline_is_detected(riab, tmp_path):
         assert p.returncode == 0, p.stderr[-2000:]
         out[name] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     print("serialised-pipeline probe:", out)
-    assert out["default"]["serialised"] == 0 and out["default"]["timeouts"] == 0 and out["one_queue"]["timeouts"] == 0
+    assert out["default"]["serialised"] <= 1 and out["default"]["timeouts"] == 0 and out["one_queue"]["timeouts"] == 0
     assert out["default"]["checksum"] == out["one_queue"]["checksum"]
     assert out["one_queue"]["serialised"] > 0 or out["one_queue"]["ms"] < 1.25 * out["default"]["ms"], out
