@@ -610,6 +610,8 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
             diag = dict(diag, **env.diagnostics, episodes_finished=len(env.episodes["episode"]))
         out["diagnostics"] = diag
     del ag, pops, env
+    import gc
+    gc.collect()                # (Agent <-> Neurons <-> history views are reference cycles: tens of GB of rows per configuration)
     torch.cuda.empty_cache()
     return out, cfg
 
