@@ -67,6 +67,22 @@ int launch_agent_pub(const AgentArgs& a_in, hipStream_t s, bool* state_published
   return (int)hipGetLastError();
 }
 
+// registers per lane the publishing trajectory kernel holds (the larger of its two instantiations, as allocated: in
+// units of 8), asked of the code object once: what the reserving shape of the rate kernel has to leave free on a SIMD
+// next to its own six waves (riab_rates.hip launch_stream_cell)
+int traj_kernel_regs() {
+  static int regs = 0;
+  if (!regs) {
+    int worst = 0;
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, (const void*)traj4_kernel<0, true>) == hipSuccess && attr.numRegs > worst) worst = attr.numRegs;
+    if (hipFuncGetAttributes(&attr, (const void*)traj4_kernel<1, true>) == hipSuccess && attr.numRegs > worst) worst = attr.numRegs;
+    (void)hipGetLastError();
+    regs = worst > 0 ? (worst + 7) / 8 * 8 : 512;   // (unknown: nothing can be promised)
+  }
+  return regs;
+}
+
 // the forced-position trajectory (Agent.import_trajectory / forced_next_position) of riab_simulate: the single-wave
 // kernel in forced mode, plain stores (what follows it on the stream is ordered by the stream)
 int launch_agent_plain(const AgentArgs& a, hipStream_t s);

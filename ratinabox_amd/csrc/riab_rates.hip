@@ -870,6 +870,7 @@ static uint32_t serial_gap_ticks() {
   return ticks;
 }
 
+int traj_kernel_regs();   // riab_agent.hip
 static thread_local bool t_stream_reserve = false;  // launch the reserving (twelve-wave) shape: set by launch_rate_stream
 
 template <class Cell>
@@ -899,7 +900,9 @@ static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamA
       r = (hipFuncGetAttributes(&attr, f) == hipSuccess && attr.numRegs > 0) ? attr.numRegs : 1 << 20;
       (void)hipGetLastError();
     }
-    if (r > 48) return RIAB_EUNSUPPORTED;  // (the caller falls back to the started gate and the four-wave shape)
+    // (six waves of this kernel and one of the trajectory kernel on a SIMD: 6 x r + its registers <= 512; with the
+    // trajectory kernel's 224 that is r <= 48)
+    if (6 * ((r + 7) / 8 * 8) + traj_kernel_regs() > 512) return RIAB_EUNSUPPORTED;  // (the caller falls back to the started gate)
   }
   if (dry_run) return RIAB_OK;  // (every argument check is above: nothing is launched)
   // (a kernel's FIRST launch in a process resolves its code object on the host — tens of microseconds in which a short
