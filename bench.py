@@ -674,8 +674,11 @@ def main():
             cpus = _parse_cpulist(args.host_binding["cpus"])
             per = max(1, len(cpus) // n_local)
             mine = cpus[local * per:(local + 1) * per] or cpus
-            os.sched_setaffinity(0, mine)
-            args.host_binding.update(cpus=_format_cpulist(mine), n_cpus=len(mine), ranks_on_this_node=n_local)
+            try:
+                os.sched_setaffinity(0, mine)
+                args.host_binding.update(cpus=_format_cpulist(mine), n_cpus=len(mine), ranks_on_this_node=n_local)
+            except OSError as e:
+                args.host_binding = {"binding": "none", "why": f"{type(e).__name__}: {e}"}
     else:
         args.host_binding = bind_rank_to_gpu_numa(local, n_local)
     if share:
