@@ -326,13 +326,18 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
     # --event-timing attaches HIP start / stop events to the launch instead (~7 us of host time per region)
     ag._time_rate_kernel = ("events" if args.event_timing else True) if (fused_mode or native_mode) else False
 
+    def prepare():
+        # (recording the plan is set-up, like building the world: outside the timed region — the history reset before every
+        # repeat closes the previous plan)
+        if args.plan and (plan["p"] is None or ag._plan is not plan["p"]):
+            if args.task:
+                plan["p"] = env.make_step_plan(capacity=max(K, W), auto_reset=True, scripted_speed=11 * ag.speed_mean)
+            else:
+                plan["p"] = ag.make_step_plan(capacity=max(K, W))
+
     def run(n_steps):
         if args.plan:
-            if plan["p"] is None or ag._plan is not plan["p"]:
-                if args.task:
-                    plan["p"] = env.make_step_plan(capacity=max(K, W), auto_reset=True, scripted_speed=11 * ag.speed_mean)
-                else:
-                    plan["p"] = ag.make_step_plan(capacity=max(K, W))
+            prepare()
             nb = args.plan_batch
             for _ in range(n_steps // nb):
                 plan["p"].step(nb)
@@ -395,6 +400,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
     elapsed, kernel_ms, kernel_units = [], [], []
     for _r in range(R):
         fresh_history(K)
+        prepare()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -553,6 +559,26 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
             if warm_ms is not None:  # (rocprofv3 --stats averages over ALL launches of the process, warm-up included)
                 roofline["warmup_launch_ms"] = round(warm_ms, 5)
 
+    plan_info = None
+    if args.plan and plan["p"] is not None:
+        plan_info = plan["p"].info()
+    elif args.per_step and ag._plan is not None and hasattr(ag._plan, "info"):
+        plan_info = ag._plan.info()
+    if roofline is None and (args.plan or args.per_step):
+        # the closed-loop paths: kernels follow each other on one stream, so a step's time on the host clock IS the
+        # time of its kernel(s) + the gap between them; no per-kernel events (they would sit between the launches)
+        step_s = med / K
+        ach = unit_bytes * B / step_s / 1e9
+        one = bool(plan_info and plan_info["fused_steps"] > 0)
+        roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": ("step1_kernel<%s> (Agent.update + Neurons.update in one launch)" % type(dominant).__name__) if one
+                    else "agent_step_kernel + rate_kernel_wide<%s> per step" % type(dominant).__name__,
+                    "launches": None, "avg_launch_ms": round(step_s * 1e3, 6), "units_per_launch": B,
+                    "bytes_per_unit": unit_bytes, "bytes_per_unit_is": "SURVEY.md 8(d): 4*n (+n spikes) + 112",
+                    "timed_by": "timed region / steps (host clock around K back-to-back steps): the step's kernel(s) plus the "
+                                "inter-kernel gap; rocprofv3's per-kernel average is in profiles/"}
+
     # the chip's measured store ceiling in this same process (riab_fill: one float4 per thread,
     # address-ordered), for context next to the spec peak
     if rank == 0 and roofline is not None and store_ceiling:
@@ -606,6 +632,9 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         }
         diag = ag.diagnostics
         out["pipeline"] = ag.pipeline_info()
+        if plan_info is not None:
+            out["plan"] = dict(plan_info, launches_per_step=round(plan_info["launches"] / max(1, (K * (R + 1) + W)), 3)
+                               if args.plan else None)
         if args.task:
             diag = dict(diag, **env.diagnostics, episodes_finished=len(env.episodes["episode"]))
         out["diagnostics"] = diag
@@ -748,26 +777,35 @@ def main():
     if args.config == "cfg2" and not (args.no_secondary or args.per_step or args.plan or args.task or args.strong):
         dog.start()
         saved = args.no_history
-        runs = [("cfg2_T1024", "cfg2", 128)] + ([("cfg3", "cfg3", 32)] if world == 1 else []) + \
-            [("cfg4", "cfg4", 32), ("cfg5", "cfg5", 32)]
-        for key, name, warm in runs:
+        # ... and the CLOSED-LOOP forms of cfg2 (the reference's per-step API, Agent.py:160-242 + Neurons.py:145-171, and
+        # its TaskEnvironment.step, contribs/TaskEnvironment.py:361-453): an explicit step plan (one native call per
+        # step), the unchanged `Ag.update(); PCs.update()` loop, a task plan — 256 steps after 32, five repeats each
+        runs = [("cfg2_T1024", "cfg2", 128, None)] + ([("cfg3", "cfg3", 32, None)] if world == 1 else []) + \
+            [("cfg4", "cfg4", 32, None), ("cfg5", "cfg5", 32, None),
+             ("cfg2_closed_loop_plan", "cfg2", 32, "plan"), ("cfg2_closed_loop_per_step", "cfg2", 32, "per_step"),
+             ("cfg2_closed_loop_task", "cfg2", 32, "task")]
+        for key, name, warm, mode in runs:
             if key == "cfg2_T1024" and args.steps == SECONDARY_STEPS:
                 continue   # (the headline run IS that run)
             args.no_history = False
+            args.plan, args.per_step, args.task = mode in ("plan", "task"), mode == "per_step", mode == "task"
             state["running"] = key
             t0 = time.perf_counter()
             try:
-                o, c = measure(args, name, sec_steps, warm, 5, rank, world, local, dist,
+                o, c = measure(args, name, 256 if mode else sec_steps, warm, 5, rank, world, local, dist,
                                ctrl_on_cpu if dist is not None else False, control_plane, store_ceiling=False)
             except Exception as e:  # noqa: BLE001  (the headline line must not be lost to a secondary run)
                 secondary[key] = {"error": f"{type(e).__name__}: {e}"}
                 continue
+            finally:
+                args.plan = args.per_step = args.task = False
             torch.cuda.empty_cache()   # (tens of GB of history per configuration: give them back before the next one)
             if o is None:
                 continue
             r = o["roofline"] or {}
-            secondary[key] = {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "n_gpus": world,
-                              "steps": sec_steps, "warmup": warm, "repeats": o["repeats"], "ms_per_step": o["ms_per_step"],
+            secondary[key] = {"workload": o["config"]["workload"], "api": o["config"]["api"], "plan": o.get("plan"),
+                              "value": o["value"], "unit": o["unit"], "n_gpus": world,
+                              "steps": o["steps"], "warmup": warm, "repeats": o["repeats"], "ms_per_step": o["ms_per_step"],
                               "timed_region_ms": o["timed_region_ms"]["median"],
                               "timed_region_ms_per_rank": o["timed_region_ms_per_rank"],
                               "bytes_per_agent_step": o["config"]["bytes_per_agent_step"],

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RIAB_ABI_VERSION 5
+#define RIAB_ABI_VERSION 6
 #define RIAB_MAX_WALLS 64     /* walls staged in LDS by the motion / BVC / line-of-sight kernels */
 #define RIAB_MAX_TEST_ANGLES 360
 #define RIAB_STATE_ROWS 12    /* rows of the agent state matrix, see below */
@@ -448,6 +448,34 @@ int riab_plan_step(RiabPlan* plan, int32_t n_steps, riab_stream_t stream);
 int riab_plan_step_agent(RiabPlan* plan, riab_stream_t stream);
 int riab_plan_step_population(RiabPlan* plan, int32_t index, riab_stream_t stream);
 
+/* The closed-loop step in ONE launch (csrc/riab_step1.hip).  Replaces, per step, the reference's
+ * `Agent.update()` (Agent.py:160-242) + `Neurons.update()` (Neurons.py:145-171) of ONE population — the pair
+ * contribs/TaskEnvironment.py:399-408 and every user loop call per step — which riab_plan_step otherwise issues as two
+ * dependent launches (riab_agent_step(T = 1), then the population's kernel).  Every workgroup of the launch advances the
+ * 256 agents whose rates it then writes; the workgroups of a 256-agent segment read the same float64 state and ONE of
+ * them writes it back, after the others have reported in `sync_words` that their loads have returned.  Bit-identical
+ * to the two-launch step.  No allocation, no synchronisation, nothing process-wide: capturable like every other entry
+ * point.
+ *   sync_words  device uint32 [RIAB_STEP1_SYNC_WORDS(B)], zeroed by the caller once, the plan's for its lifetime (NULL:
+ *               switch the one-launch step off).  Layout: RIAB_STEP1_SYNC_STRIDE arrival words per 256-agent segment
+ *               (word y = workgroup y of the segment; they hold the epoch of the plan's last one-launch step), then
+ *               RIAB_STEP1_SYNC_TAIL counters: [RIAB_STEP1_SYNC_TIMEOUTS] writers that gave up waiting (~1 s; must
+ *               stay 0: the state was then written while a workgroup of the grid had not run yet).
+ * What is fused: plain motion steps (Philox noise, drift or not; no forced trajectory, no task) of whole 256-agent
+ * segments, with the plan's LARGEST population among PlaceCells (euclidean geometry, not one_hot), GridCells and
+ * HeadDirectionCells without additive noise; the other populations follow as their own kernels in list order, as
+ * before.  With the split entry points riab_plan_step_agent launches the fused kernel (the population's row is written
+ * ahead of its update() call) and the population's riab_plan_step_population of the same step only advances the row
+ * cursor; a plan whose populations are not updated after each agent step stops fusing.
+ * riab_plan_info: 0 steps served by the one-launch kernel, 1 index of the fused population (-1: none), 2 kernels
+ * launched by the plan so far, 3 non-zero when arrival words are attached. */
+#define RIAB_STEP1_SYNC_STRIDE 64
+#define RIAB_STEP1_SYNC_TAIL 16
+#define RIAB_STEP1_SYNC_TIMEOUTS 0
+#define RIAB_STEP1_SYNC_WORDS(B) ((((B) + 255) / 256) * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TAIL)
+int riab_plan_set_fused(RiabPlan* plan, uint32_t* sync_words, int64_t n_words);
+int64_t riab_plan_info(const RiabPlan* plan, int32_t which);
+
 /* ---- batched TaskEnvironment (contribs/TaskEnvironment.py) ------------------------------------
  * The closed-loop caller of the path: `TaskEnvironment.step(actions)` = Agent.update(drift_velocity
  * = action) [riab_agent_step / riab_plan_step], then the task bookkeeping of
@@ -739,9 +767,12 @@ int64_t riab_streamer_info(RiabStreamer* h, int32_t which);
  *   RIAB_OPT_PUB_SINGLE_ROWS  how many of a publishing trajectory launch's first rows leave one by one before blocks
  *                          of four (default 4; 0 .. 64)
  *   RIAB_OPT_POLL_SLEEP    the longest s_sleep between two polls of a waiting rate wave, in units of 64 cycles (default
- *                          48; 1 .. 127) */
+ *                          48; 1 .. 127)
+ *   RIAB_OPT_FUSED_STEP    1 (default) a plan that was given arrival words (riab_plan_set_fused) advances the agent and
+ *                          its largest store-bound population in ONE launch per step; 2 the same with ordinary instead
+ *                          of nontemporal stores; 0 the motion kernel and every population's kernel one after the other */
 enum { RIAB_OPT_TRAJ_KERNEL = 0, RIAB_OPT_FUSED_TASK = 1, RIAB_OPT_BVC_BOX = 2, RIAB_OPT_NT_STORES = 3,
-       RIAB_OPT_PUB_SINGLE_ROWS = 4, RIAB_OPT_POLL_SLEEP = 5, RIAB_OPT_COUNT = 6 };
+       RIAB_OPT_PUB_SINGLE_ROWS = 4, RIAB_OPT_POLL_SLEEP = 5, RIAB_OPT_FUSED_STEP = 6, RIAB_OPT_COUNT = 7 };
 int riab_set_option(int32_t option, int32_t value);
 
 /* Process-level host setting for latency-bound callers (one short simulate() per synchronisation, as in bench.py's

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 
 from . import _build
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_WALLS = 64
 STATE_ROWS = 12
 HIST_ROWS = 8
@@ -117,6 +117,14 @@ GATE_ALWAYS, GATE_WHEN_BUSY, GATE_RESERVED = 0, 1, 2
 CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_SERIALISED, CTRL_STAMPS, CTRL_TRAJ_STAMPS, CTRL_PROGRESS = 0, 1, 2, 3, 8, 12, 32  # riab_hip.h RIAB_CTRL_*
 
 
+STEP1_SYNC_STRIDE, STEP1_SYNC_TAIL, STEP1_SYNC_TIMEOUTS = 64, 16, 0   # riab_hip.h RIAB_STEP1_SYNC_*
+
+
+def step1_sync_words(B):
+    """RIAB_STEP1_SYNC_WORDS(B): arrival words of the one-launch step for B agents."""
+    return ((int(B) + 255) // 256) * STEP1_SYNC_STRIDE + STEP1_SYNC_TAIL
+
+
 def ctrl_words(B):
     """RIAB_CTRL_WORDS(B): control words of the flag-coupled pipeline for B agents."""
     return CTRL_PROGRESS + 32 * ((int(B) + 255) // 256)
@@ -174,6 +182,8 @@ PROTOTYPES = {
     "riab_plan_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "riab_plan_step_agent": (C.c_int, [C.c_void_p, C.c_void_p]),
     "riab_plan_step_population": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "riab_plan_set_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "riab_plan_info": (C.c_int64, [C.c_void_p, C.c_int32]),
     "riab_task_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_task_goal_vector": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
@@ -247,7 +257,8 @@ def _load():
 lib, LIB_PATH = _load()
 
 
-OPTIONS = {"traj_kernel": 0, "fused_task": 1, "bvc_box": 2, "nt_stores": 3, "pub_single_rows": 4, "poll_sleep": 5}   # riab_hip.h RIAB_OPT_*
+OPTIONS = {"traj_kernel": 0, "fused_task": 1, "bvc_box": 2, "nt_stores": 3, "pub_single_rows": 4, "poll_sleep": 5,
+           "fused_step": 6}   # riab_hip.h RIAB_OPT_*
 
 
 def set_option(name, value):
@@ -260,7 +271,8 @@ def set_option(name, value):
 
 # environment variables set BEFORE the import select the same switches for a whole process (tools, A/B runs)
 for _name, _opt, _val in (("RIAB_NO_PC", "traj_kernel", 1), ("RIAB_TRAJ2", "traj_kernel", 2), ("RIAB_NO_FUSED_TASK", "fused_task", 0),
-                          ("RIAB_NO_BVC_BOX", "bvc_box", 0), ("RIAB_NT_STORES_WIDE", "nt_stores", 1)):
+                          ("RIAB_NO_BVC_BOX", "bvc_box", 0), ("RIAB_NT_STORES_WIDE", "nt_stores", 1),
+                          ("RIAB_NO_FUSED_STEP", "fused_step", 0), ("RIAB_FUSED_STEP_PLAIN_STORES", "fused_step", 2)):
     if os.environ.get(_name):
         set_option(_opt, _val)
 for _name, _opt in (("RIAB_PUB_SINGLE_ROWS", "pub_single_rows"), ("RIAB_POLL_SLEEP", "poll_sleep")):

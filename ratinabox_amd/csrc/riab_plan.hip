@@ -25,6 +25,11 @@ int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* 
                        int32_t* diag, bool auto_reset, int64_t agent_id0, int32_t n_select, int32_t ordered, uint64_t seed,
                        uint64_t counter, int32_t teleport, float* hist_x, float* hist_y, double* ep_log,
                        int64_t ep_log_cap, int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y, hipStream_t s);
+
+// the one-launch step (riab_step1.hip)
+int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
+int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
+                 uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, hipStream_t s);
 }  // namespace riab
 
 struct RiabPlan {
@@ -61,7 +66,55 @@ struct RiabPlan {
   int32_t* ep_count;
   double scripted_speed;
   bool action_ready;  // the drift buffer holds the scripted action of the coming step
+  // the one-launch step (riab_plan_set_fused)
+  uint32_t* sync_words;
+  uint32_t epoch;        // tag of the last one-launch step on sync_words
+  int lead;              // population fused with the agent step; -2: not worked out yet
+  int64_t fused_steps, launches;
+  bool pre_pending;      // split entry points: the lead's row of step `pre_step` was written by riab_plan_step_agent
+  uint64_t pre_step;
+  int pre_misses;        // ... and was not claimed by riab_plan_step_population that many times in a row
 };
+
+// the population the agent step is fused with: the store-bound one that writes most bytes per row (-1: none)
+static int plan_lead(RiabPlan* p) {
+  if (!p->sync_words || riab::g_options[RIAB_OPT_FUSED_STEP] == 0 || p->has_task || p->forced) return -1;
+  if (p->lead == -2) {
+    int best = -1;
+    int64_t best_bytes = 0;
+    for (size_t i = 0; i < p->pops.size(); ++i) {
+      const RiabPopulation& q = p->pops[i];
+      if (riab::step1_supported(&p->env, &q, p->B) != RIAB_OK) continue;
+      const int64_t bytes = (int64_t)q.n * (q.spikes_base ? 5 : 4);
+      if (bytes > best_bytes) {
+        best = (int)i;
+        best_bytes = bytes;
+      }
+    }
+    p->lead = best;
+  }
+  return p->lead;
+}
+
+// Agent.update() + the lead population's update() of the same step as one kernel; cursors are the caller's business
+static int fused_agent_step(RiabPlan* p, int lead, float* row, hipStream_t s) {
+  riab::AgentArgs ma;
+  int rc = riab::fill_agent_args(ma, &p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr,
+                                 p->seed, p->step, 1, row, p->diag);
+  if (rc) return rc;
+  const RiabPopulation& q = p->pops[lead];
+  const int64_t r = q.capacity_rows > 0 ? p->pop_fill[lead] : 0;
+  const int64_t row_elems = (int64_t)q.n * p->B;
+  p->epoch += 1u;
+  if (p->epoch == 0u) p->epoch = 1u;
+  rc = riab::launch_step1(ma, &p->env, &q, q.rates_base + r * row_elems, q.spikes_base ? q.spikes_base + r * row_elems : nullptr,
+                          p->seed, p->step + 1, p->sync_words, p->epoch, s);
+  if (rc == RIAB_OK) {
+    p->fused_steps += 1;
+    p->launches += 1;
+  }
+  return rc;
+}
 
 extern "C" RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* motion, double* state, int64_t B,
                                       int64_t agent_id0, uint64_t seed, uint64_t step, float* row_scratch,
@@ -85,7 +138,37 @@ extern "C" RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* moti
   p->diag = diag;
   p->has_task = false;
   p->action_ready = false;
+  p->sync_words = nullptr;
+  p->epoch = 0u;
+  p->lead = -2;
+  p->fused_steps = p->launches = 0;
+  p->pre_pending = false;
+  p->pre_step = 0;
+  p->pre_misses = 0;
   return p;
+}
+
+extern "C" int riab_plan_set_fused(RiabPlan* p, uint32_t* sync_words, int64_t n_words) {
+  if (!p || n_words < 0) return RIAB_EINVAL;
+  if (sync_words && n_words < (int64_t)RIAB_STEP1_SYNC_WORDS(p->B)) return RIAB_EINVAL;
+  if (((uintptr_t)sync_words) & 3) return RIAB_EALIGN;
+  p->sync_words = sync_words;
+  p->epoch = 0u;
+  p->lead = -2;
+  p->pre_pending = false;
+  p->pre_misses = 0;
+  return RIAB_OK;
+}
+
+extern "C" int64_t riab_plan_info(const RiabPlan* p, int32_t which) {
+  if (!p) return 0;
+  switch (which) {
+    case 0: return p->fused_steps;
+    case 1: return p->lead < 0 ? -1 : p->lead;
+    case 2: return p->launches;
+    case 3: return p->sync_words ? 1 : 0;
+    default: return 0;
+  }
 }
 
 extern "C" void riab_plan_destroy(RiabPlan* p) { delete p; }
@@ -127,6 +210,7 @@ extern "C" int riab_plan_add(RiabPlan* p, const RiabPopulation* pop) {
   }
   p->pops.push_back(*pop);
   p->pop_fill.push_back(0);
+  p->lead = -2;
   return (int)p->pops.size() - 1;
 }
 
@@ -139,6 +223,8 @@ extern "C" int riab_plan_set_population_history(RiabPlan* p, int32_t index, floa
   q.spikes_base = spikes_base;
   q.capacity_rows = capacity_rows;
   p->pop_fill[index] = 0;
+  if (p->pre_pending && index == p->lead) p->pre_pending = false;  // (the row written ahead was in the old chunk)
+  p->lead = -2;  // (spikes or not changes the bytes a row takes)
   return RIAB_OK;
 }
 
@@ -263,7 +349,9 @@ static int launch_population(RiabPlan* p, size_t i, const float* row, hipStream_
     }
   }
   if (rc) return rc;
+  p->launches += (q.kind == RIAB_POP_FF && io.spikes) ? 2 : 1;
   if (noisy) {
+    p->launches += spikes ? 2 : 1;
     rc = riab_neuron_noise(q.noise_state, io.rates, nullptr, q.n, B, 1, q.noise_theta_dt, q.noise_sigma_dt, p->seed, p->step,
                            q.io.pop_id, p->agent_id0, s);
     if (rc) return rc;
@@ -287,9 +375,27 @@ extern "C" int riab_plan_step_agent(RiabPlan* p, riab_stream_t stream) {
     forced = p->forced + p->forced_fill * 2 * p->B;
   }
   float* row = p->hist_base ? p->hist_base + p->hist_fill * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
+  // The one-launch step: the lead population's row of THIS step is written by the agent's launch, ahead of the
+  // population's own call, which then only moves its cursor (same inputs, same row, same bits).  A row written ahead
+  // that nobody claims (a loop that does not update the population after every agent step) switches this off.
+  if (p->pre_pending) {
+    p->pre_pending = false;
+    p->pre_misses += 1;
+  }
+  const int lead = p->pre_misses < 2 ? plan_lead(p) : -1;
+  if (lead >= 0 && (p->pops[lead].capacity_rows == 0 || p->pop_fill[lead] < p->pops[lead].capacity_rows)) {
+    const int rc = fused_agent_step(p, lead, row, (hipStream_t)stream);
+    if (rc) return rc;
+    p->step += 1;
+    if (p->hist_base) p->hist_fill += 1;
+    p->pre_pending = true;
+    p->pre_step = p->step;
+    return RIAB_OK;
+  }
   const int rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, forced, nullptr,
                                  p->seed, p->step, 1, row, p->diag, (hipStream_t)stream);
   if (rc) return rc;
+  p->launches += 1;
   if (forced) p->forced_fill += 1;
   p->step += 1;
   if (p->hist_base) p->hist_fill += 1;
@@ -302,6 +408,12 @@ extern "C" int riab_plan_step_population(RiabPlan* p, int32_t index, riab_stream
   const size_t i = (size_t)index;
   if (p->pops[i].capacity_rows > 0 && p->pop_fill[i] >= p->pops[i].capacity_rows) return RIAB_EFULL;
   if (p->hist_base && p->hist_fill == 0) return RIAB_EINVAL;  // no agent row written into this chunk yet
+  if (p->pre_pending && index == p->lead && p->pre_step == p->step) {  // written by this step's riab_plan_step_agent
+    p->pre_pending = false;
+    p->pre_misses = 0;
+    if (p->pops[i].capacity_rows > 0) p->pop_fill[i] += 1;
+    return RIAB_OK;
+  }
   const float* row = p->hist_base ? p->hist_base + (p->hist_fill - 1) * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
   const int rc = launch_population(p, i, row, (hipStream_t)stream);
   if (rc) return rc;
@@ -314,8 +426,24 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
   if (riab_plan_rows_free(p) < n_steps) return RIAB_EFULL;
   if (p->forced && (p->has_task || p->forced_rows - p->forced_fill < n_steps)) return p->has_task ? RIAB_EINVAL : RIAB_EFULL;
   hipStream_t s = (hipStream_t)stream;
+  p->pre_pending = false;
+  const int lead = plan_lead(p);
   for (int32_t k = 0; k < n_steps; ++k) {
     float* row = p->hist_base ? p->hist_base + p->hist_fill * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
+    if (lead >= 0) {  // Agent.update() and the lead population's update() in one launch, the other populations after it
+      int rc = fused_agent_step(p, lead, row, s);
+      if (rc) return rc;
+      p->step += 1;
+      if (p->hist_base) p->hist_fill += 1;
+      if (p->pops[lead].capacity_rows > 0) p->pop_fill[lead] += 1;
+      for (size_t i = 0; i < p->pops.size(); ++i) {
+        if ((int)i == lead) continue;
+        rc = launch_population(p, i, row, s);
+        if (rc) return rc;
+        if (p->pops[i].capacity_rows > 0) p->pop_fill[i] += 1;
+      }
+      continue;
+    }
     double* pos_x = p->state + (int64_t)RIAB_S_POS_X * p->B;
     double* pos_y = p->state + (int64_t)RIAB_S_POS_Y * p->B;
     int rc;
@@ -352,6 +480,7 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
     rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, forced, nullptr,
                          p->seed, p->step, 1, row, p->diag, s);
     if (rc) return rc;
+    p->launches += 1;
     if (forced) p->forced_fill += 1;
     p->step += 1;
     if (p->hist_base) p->hist_fill += 1;

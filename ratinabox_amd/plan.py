@@ -21,6 +21,25 @@ from . import _lib
 _L = _lib
 
 
+def _attach_fused(plan, agent):
+    """Arrival words for the one-launch step (riab_plan_set_fused, csrc/riab_step1.hip): whole 256-agent segments
+    only; the library decides per step whether the step qualifies."""
+    plan._sync_words = None
+    if agent._Bp % 256 == 0 and not _L.env("RIAB_NO_FUSED_STEP"):
+        n = _L.step1_sync_words(agent._Bp)
+        plan._sync_words = torch.zeros(n, dtype=torch.int32, device=agent._device)
+        _L.check(_L.lib.riab_plan_set_fused(plan._h, _L.ptr(plan._sync_words), n), "riab_plan_set_fused")
+
+
+def _check_fused(plan):
+    """A writer of the one-launch step that gave up waiting for its segment's workgroups (must never happen)."""
+    w = getattr(plan, "_sync_words", None)
+    if w is not None and plan._h and _L.lib.riab_plan_info(plan._h, 0) > 0:
+        if int(w[-_L.STEP1_SYNC_TAIL + _L.STEP1_SYNC_TIMEOUTS].item()):
+            raise _L.RiabError("one-launch step: a state write-back gave up waiting for its segment's workgroups; "
+                               "the agent state of that step is not trustworthy")
+
+
 class _ForcedRows:
     """Positions of the coming steps of an agent that follows an imported trajectory (Agent.import_trajectory with
     interpolate=True; reference Agent.py:255-266), handed to a native plan in blocks (riab_plan_set_forced): the
@@ -89,6 +108,7 @@ class StepPlan:
             if idx < 0:
                 raise _L.RiabError(f"riab_plan_add failed: {_L.strerror(idx)}")
             self._pops.append(pop)
+        _attach_fused(self, agent)
         self._pending = 0        # steps taken since the last sync()
         self._times_pending = []
         self._rows_open = 0      # rows still free in the attached chunks
@@ -249,8 +269,17 @@ class StepPlan:
         if self.agent._plan is self:
             self.agent._plan = None
         if self._h:
-            _L.lib.riab_plan_destroy(self._h)
-            self._h = None
+            try:
+                _check_fused(self)
+            finally:
+                _L.lib.riab_plan_destroy(self._h)
+                self._h = None
+
+    def info(self):
+        """Launch accounting of the native plan (riab_plan_info)."""
+        f = _L.lib.riab_plan_info
+        return {"fused_steps": int(f(self._h, 0)), "fused_population": int(f(self._h, 1)), "launches": int(f(self._h, 2)),
+                "fused_enabled": bool(f(self._h, 3))}
 
     def __del__(self):
         try:
@@ -313,6 +342,7 @@ class AutoStepper:
             self._index[N] = idx
             self._pops.append(pop)
             self._keys.append(N._auto_key())
+        _attach_fused(self, agent)
         self._a_pending, self._a_times = 0, []
         self._p_pending = [0] * len(self.neurons)
         self._p_times = [[] for _ in self.neurons]
@@ -490,8 +520,16 @@ class AutoStepper:
         else:
             ag._auto_after = ag.AUTO_AFTER
         if self._h:
-            _L.lib.riab_plan_destroy(self._h)
-            self._h = None
+            try:
+                _check_fused(self)
+            finally:
+                _L.lib.riab_plan_destroy(self._h)
+                self._h = None
+
+    def info(self):
+        f = _L.lib.riab_plan_info
+        return {"fused_steps": int(f(self._h, 0)), "fused_population": int(f(self._h, 1)), "launches": int(f(self._h, 2)),
+                "fused_enabled": bool(f(self._h, 3))}
 
     def __del__(self):
         try:
