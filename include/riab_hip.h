@@ -457,10 +457,14 @@ int riab_plan_step_population(RiabPlan* plan, int32_t index, riab_stream_t strea
  * to the two-launch step.  No allocation, no synchronisation, nothing process-wide: capturable like every other entry
  * point.
  *   sync_words  device uint32 [RIAB_STEP1_SYNC_WORDS(B)], zeroed by the caller once, the plan's for its lifetime (NULL:
- *               switch the one-launch step off).  Layout: RIAB_STEP1_SYNC_STRIDE arrival words per 256-agent segment
- *               (word y = workgroup y of the segment; they hold the epoch of the plan's last one-launch step), then
- *               RIAB_STEP1_SYNC_TAIL counters: [RIAB_STEP1_SYNC_TIMEOUTS] writers that gave up waiting (~1 s; must
- *               stay 0: the state was then written while a workgroup of the grid had not run yet).
+ *               switch the one-launch step off).  Layout: RIAB_STEP1_SYNC_STRIDE words per 256-agent segment — word y
+ *               (1 <= y < RIAB_STEP1_SYNC_MAX_Y) = arrival word of the segment's workgroup y, holding the epoch of the
+ *               plan's last one-launch step —, then RIAB_STEP1_SYNC_TAIL counters: [RIAB_STEP1_SYNC_TIMEOUTS] writers
+ *               that gave up waiting (~1 s; must stay 0: the state was then written while a workgroup of the grid had
+ *               not run yet), then float64 [RIAB_MAX_WALLS][6]: the wall table as the kernels keep it (start, direction,
+ *               1 / |direction|^2, 1 / |direction|) and one word (+ padding) saying whether the first four walls are the
+ *               edges of a solid rectangular room (the motion step's box fast path), both prepared by the plan's first
+ *               one-launch step (a one-wave kernel in front of it) and again when the repel distance changes.
  * What is fused: plain motion steps (Philox noise, drift or not; no forced trajectory, no task) of whole 256-agent
  * segments, with the plan's LARGEST population among PlaceCells (euclidean geometry, not one_hot), GridCells and
  * HeadDirectionCells without additive noise; the other populations follow as their own kernels in list order, as
@@ -470,9 +474,11 @@ int riab_plan_step_population(RiabPlan* plan, int32_t index, riab_stream_t strea
  * riab_plan_info: 0 steps served by the one-launch kernel, 1 index of the fused population (-1: none), 2 kernels
  * launched by the plan so far, 3 non-zero when arrival words are attached. */
 #define RIAB_STEP1_SYNC_STRIDE 64
+#define RIAB_STEP1_SYNC_MAX_Y 64     /* workgroups per segment (arrival words 1 .. 63) */
 #define RIAB_STEP1_SYNC_TAIL 16
 #define RIAB_STEP1_SYNC_TIMEOUTS 0
-#define RIAB_STEP1_SYNC_WORDS(B) ((((B) + 255) / 256) * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TAIL)
+#define RIAB_STEP1_SYNC_WALLS_AT(B) ((((B) + 255) / 256) * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TAIL)
+#define RIAB_STEP1_SYNC_WORDS(B) (RIAB_STEP1_SYNC_WALLS_AT(B) + 12 * RIAB_MAX_WALLS + 4)
 int riab_plan_set_fused(RiabPlan* plan, uint32_t* sync_words, int64_t n_words);
 int64_t riab_plan_info(const RiabPlan* plan, int32_t which);
 

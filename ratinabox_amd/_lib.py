@@ -120,9 +120,15 @@ CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_SERIALISED, CTRL_STAMPS, CTRL_TRAJ
 STEP1_SYNC_STRIDE, STEP1_SYNC_TAIL, STEP1_SYNC_TIMEOUTS = 64, 16, 0   # riab_hip.h RIAB_STEP1_SYNC_*
 
 
+def step1_sync_tail(B):
+    """Index of the counters behind the arrival words."""
+    return ((int(B) + 255) // 256) * STEP1_SYNC_STRIDE
+
+
 def step1_sync_words(B):
-    """RIAB_STEP1_SYNC_WORDS(B): arrival words of the one-launch step for B agents."""
-    return ((int(B) + 255) // 256) * STEP1_SYNC_STRIDE + STEP1_SYNC_TAIL
+    """RIAB_STEP1_SYNC_WORDS(B): arrival words, counters and the prepared wall table, for B agents."""
+    segs = (int(B) + 255) // 256
+    return segs * STEP1_SYNC_STRIDE + STEP1_SYNC_TAIL + 12 * MAX_WALLS + 4
 
 
 def ctrl_words(B):

@@ -440,10 +440,13 @@ struct MotionConst {
   Wall<R> w4[4];         // the first four walls (the box itself when boundaries are solid), in registers
 };
 
+// The constants of a launch in two parts: the scalars, functions of the motion parameters and the extent alone — also
+// evaluated on the HOST for the one-launch step (riab_step1.hip), where a per-thread evaluation would be paid on every
+// step: plain IEEE double arithmetic without a multiply-add in it, the same bits on either side —, and what is read off
+// the staged wall table.
 template <class R>
-__device__ __forceinline__ MotionConst<R> make_motion_const(const AgentArgs& a, const Wall<R>* s_w) {
+__host__ __device__ __forceinline__ void motion_const_scalars(MotionConst<R>& k, const AgentArgs& a) {
   const RiabMotion& m = a.m;
-  MotionConst<R> k;
   k.nw = a.n_walls;
   k.dt = (R)m.dt;
   k.sm_kw = (R)m.speed_mean_kw;
@@ -463,6 +466,10 @@ __device__ __forceinline__ MotionConst<R> make_motion_const(const AgentArgs& a, 
   // divisions by loop constants become multiplications (<= 1 ulp from the reference's quotient)
   k.inv_dt = (R)(1.0 / m.dt);
   k.wd2 = k.wd * k.wd * (R)1.000001;
+}
+
+template <class R>
+__device__ __forceinline__ void motion_const_walls(MotionConst<R>& k, const AgentArgs& a, const Wall<R>* s_w) {
 #pragma unroll
   for (int w = 0; w < 4; ++w) k.w4[w] = s_w[w < k.nw ? w : 0];
   // Box fast path.  In a solid rectangular room the first four walls are the room's own edges (Environment.py:128-163)
@@ -501,6 +508,13 @@ __device__ __forceinline__ MotionConst<R> make_motion_const(const AgentArgs& a, 
     k.box_fast = __builtin_amdgcn_readfirstlane((int)ok) != 0;  // (the same value in every lane: a scalar branch)
     k.bxl = xlo; k.bxr = xhi; k.byb = ylo; k.byt = yhi;
   }
+}
+
+template <class R>
+__device__ __forceinline__ MotionConst<R> make_motion_const(const AgentArgs& a, const Wall<R>* s_w) {
+  MotionConst<R> k;
+  motion_const_scalars<R>(k, a);
+  motion_const_walls<R>(k, a, s_w);
   return k;
 }
 
@@ -750,20 +764,28 @@ __device__ __forceinline__ void boundary_net(const MotionConst<R>& k, const Agen
   }
 }
 
+// one wall of the table as the kernels keep it: every operation rounded on its own and the one multiply-add spelled
+// out, so that whichever kernel prepares a wall (a trajectory kernel while staging; walls_prepare_kernel of
+// riab_step1.hip once per plan) produces the same bits
+template <class R>
+__device__ __forceinline__ Wall<R> make_wall(double ax, double ay, double bx, double by) {
+  RIAB_EXACT_FP
+  const double sx = bx - ax, sy = by - ay;
+  const double ss = fma(sx, sx, sy * sy);
+  Wall<R> w;
+  w.ax = (R)ax;
+  w.ay = (R)ay;
+  w.sx = (R)sx;
+  w.sy = (R)sy;
+  w.inv_ss = (R)(1.0 / ss);
+  w.inv_len = (R)(1.0 / sqrt(ss));
+  return w;
+}
 // walls of the launch into LDS (any number of threads of the workgroup)
 template <class R>
 __device__ __forceinline__ void stage_walls(const AgentArgs& a, Wall<R>* s_w, int tid, int nthreads) {
-  for (int w = tid; w < a.n_walls; w += nthreads) {
-    const double ax = a.walls[4 * w], ay = a.walls[4 * w + 1], bx = a.walls[4 * w + 2], by = a.walls[4 * w + 3];
-    const double sx = bx - ax, sy = by - ay;
-    const double ss = sx * sx + sy * sy;
-    s_w[w].ax = (R)ax;
-    s_w[w].ay = (R)ay;
-    s_w[w].sx = (R)sx;
-    s_w[w].sy = (R)sy;
-    s_w[w].inv_ss = (R)(1.0 / ss);
-    s_w[w].inv_len = (R)(1.0 / sqrt(ss));
-  }
+  for (int w = tid; w < a.n_walls; w += nthreads)
+    s_w[w] = make_wall<R>(a.walls[4 * w], a.walls[4 * w + 1], a.walls[4 * w + 2], a.walls[4 * w + 3]);
 }
 
 // the Rayleigh <-> normal tables into LDS (rows padded to RIAB_G_STRIDE / RIAB_H_STRIDE doubles): all of a thread's

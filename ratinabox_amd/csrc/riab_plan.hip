@@ -29,7 +29,7 @@ int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* 
 // the one-launch step (riab_step1.hip)
 int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
 int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
-                 uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, hipStream_t s);
+                 uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, hipStream_t s);
 }  // namespace riab
 
 struct RiabPlan {
@@ -69,6 +69,7 @@ struct RiabPlan {
   // the one-launch step (riab_plan_set_fused)
   uint32_t* sync_words;
   uint32_t epoch;        // tag of the last one-launch step on sync_words
+  bool walls_ready;      // the wall table behind sync_words has been prepared (the plan's first one-launch step does it)
   int lead;              // population fused with the agent step; -2: not worked out yet
   int64_t fused_steps, launches;
   bool pre_pending;      // split entry points: the lead's row of step `pre_step` was written by riab_plan_step_agent
@@ -108,7 +109,7 @@ static int fused_agent_step(RiabPlan* p, int lead, float* row, hipStream_t s) {
   p->epoch += 1u;
   if (p->epoch == 0u) p->epoch = 1u;
   rc = riab::launch_step1(ma, &p->env, &q, q.rates_base + r * row_elems, q.spikes_base ? q.spikes_base + r * row_elems : nullptr,
-                          p->seed, p->step + 1, p->sync_words, p->epoch, s);
+                          p->seed, p->step + 1, p->sync_words, p->epoch, &p->walls_ready, s);
   if (rc == RIAB_OK) {
     p->fused_steps += 1;
     p->launches += 1;
@@ -140,6 +141,7 @@ extern "C" RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* moti
   p->action_ready = false;
   p->sync_words = nullptr;
   p->epoch = 0u;
+  p->walls_ready = false;
   p->lead = -2;
   p->fused_steps = p->launches = 0;
   p->pre_pending = false;
@@ -154,6 +156,7 @@ extern "C" int riab_plan_set_fused(RiabPlan* p, uint32_t* sync_words, int64_t n_
   if (((uintptr_t)sync_words) & 3) return RIAB_EALIGN;
   p->sync_words = sync_words;
   p->epoch = 0u;
+  p->walls_ready = false;
   p->lead = -2;
   p->pre_pending = false;
   p->pre_misses = 0;
@@ -176,6 +179,7 @@ extern "C" void riab_plan_destroy(RiabPlan* p) { delete p; }
 extern "C" int riab_plan_set_motion(RiabPlan* p, const RiabMotion* motion, const double* drift) {
   if (!p || !motion) return RIAB_EINVAL;
   if (motion->has_drift && !drift) return RIAB_EINVAL;
+  if (motion->wall_repel_distance_kw != p->motion.wall_repel_distance_kw) p->walls_ready = false;  // (the box fast path's verdict depends on it)
   p->motion = *motion;
   p->drift = drift;
   p->action_ready = false;

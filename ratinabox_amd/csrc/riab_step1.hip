@@ -2,18 +2,18 @@
 //
 // The reference's API is the per-step loop `Ag.update(); PCs.update()` (reference Agent.py:160-242, Neurons.py:145-171;
 // contribs/TaskEnvironment.py:399-408).  As two kernels a step costs two dependent, latency-bound launches: 6.4 us for
-// a motion kernel of 64 waves + 6.8 us for a one-row rate kernel that is all ramp and drain.  One grid
-// cannot hand rows from "motion workgroups" to "rate workgroups" without a round trip through memory and a poll, so
-// this kernel does not hand anything over: EVERY workgroup advances the 256 agents whose rates it is about to write —
-// the same instruction stream on the same inputs in every workgroup of an agent segment, hence the same bits — keeps
-// their new positions in LDS, and then writes its own (256 agents) x (cell chunk) tile of the population's row with the
-// rate kernels' store pattern (a lane owns four agents, 1 KiB per wave store).  The motion arithmetic costs the same
-// wall time whether one workgroup or thirty-two run it (a step is a dependent chain, not throughput), and the chip is
-// otherwise idle while it runs.
+// a motion kernel of 64 waves + 6.8 us for a one-row rate kernel that is all ramp and drain (13.7 us per step at cfg 2).
+// One grid cannot hand rows from "motion workgroups" to "rate workgroups" without a round trip through memory and a
+// poll, so this kernel does not hand anything over: EVERY workgroup advances the 256 agents whose rates it is about to
+// write — the same instruction stream on the same inputs in every workgroup of an agent segment, hence the same bits —
+// keeps their new positions in LDS, and then writes its own (256 agents) x (cell chunk) tile of the population's row
+// with the rate kernels' store pattern (a lane owns four agents, 1 KiB per wave store).  A step is a dependent chain,
+// not throughput: it costs the same wall time whether one workgroup or sixteen run it, and the chip is otherwise idle.
 //
-//   grid  = (B / 256 agent segments, cell chunks), x fastest; block = 256 threads = 4 waves
-//   wave w of workgroup (x, y) evaluates the cell groups (4 y + w) * reps .. + reps - 1 (CPB cells each) for the
-//   segment's 256 agents; thread i advances agent 256 x + i.
+//   grid  = (B / 256 agent segments, cell chunks), x fastest; block = 512 threads = 8 waves, one workgroup per
+//   compute unit (cfg 2: 16 x 16 = 256 workgroups).  Waves 0-3 ("movers") advance the segment's 256 agents, one mover
+//   wave per SIMD — with all eight waves moving, two float64 chains shared every SIMD and the step took 0.7 us longer —;
+//   wave w of workgroup (x, y) then evaluates the cell groups (8 y + w) * reps .. + reps - 1 (CPB cells each).
 //
 // Only the workgroups with blockIdx.y == 0 (the "writers") store what a step leaves behind: the history row, the
 // float64 state, the diagnostics.  The state is read by all of a segment's workgroups and written in place by one, so
@@ -22,9 +22,14 @@
 // writer waits for workgroups that wait for nobody: no forward-progress assumption beyond "every workgroup of a grid
 // is eventually dispatched", no co-residency requirement, capturable, re-entrant per plan.
 //
+// What a step must not pay per thread is prepared outside it: the launch's scalar constants by the host (six float64
+// divisions), the wall table in the kernels' form and the box fast path's verdict once per plan (walls_prepare_kernel).
+//
 // Values: the motion step is assembled from the functions of riab_agent_kernel.h in the order of agent_step_body (the
 // kernel `riab_agent_step(T = 1)` launches), contraction off; the rates come from the functors of riab_rate_cells.h as
 // rate_kernel_wide evaluates them.  Bit-identical to the two-launch step (tests/test_gpu_step1.py).
+// [MI355X] cfg 2 (4096 agents x 1024 PlaceCells): 9.0-9.2 us per step against 13.7; where it goes and what was tried:
+// DESIGN.md 3.9, docs/EXPERIMENTS.md r05.
 #include "riab_agent_kernel.h"
 #include "riab_rate_cells.h"
 
@@ -35,15 +40,53 @@ struct Step1Sync {
   uint32_t epoch;      // this launch's tag (never 0, never repeated on the same words)
   uint32_t spin_limit;
   uint32_t n_segments;
+  const Wall<double>* walls;  // [n_walls] the wall table as the kernels keep it, prepared once per plan (walls_prepare_kernel)
 };
+
+// Once per plan (its first one-launch step): Wall<double>[n_walls] from the plan's wall table — a wall costs two float64
+// divisions and a square root, which a staging wave would otherwise pay in front of every step's first barrier — and,
+// behind the walls, the verdict of the box fast path (make_motion_const's check of the first four walls, ~600
+// instructions and thirty branches that every thread of every step would otherwise repeat): one word, 1 = box.
+__global__ __launch_bounds__(64) void walls_prepare_kernel(const AgentArgs a, Wall<double>* out) {
+  __shared__ Wall<double> s_w[RIAB_MAX_WALLS];
+  stage_walls<double>(a, s_w, (int)threadIdx.x, 64);
+  __syncthreads();
+  for (int w = (int)threadIdx.x; w < a.n_walls; w += 64) out[w] = s_w[w];
+  const MotionConst<double> k = make_motion_const<double>(a, s_w);
+  if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(out + RIAB_MAX_WALLS) = k.box_fast ? 1u : 0u;
+}
 
 typedef __attribute__((address_space(1))) uint32_t s1_gu32;
 
+// tools/step1_profile.py (a -DRIAB_STEP1_PROFILE build): three workgroups — the first writer, its segment's second
+// workgroup, the grid's last — leave the device's constant clock at the phase boundaries of the LAST step, behind the
+// arrival words' tail (the Python layer allocates 256 words of slack there)
+#ifdef RIAB_STEP1_PROFILE
+#define RIAB_S1_STAMP(k)                                                                                                  \
+  if (prof_slot >= 0 && tid == 0)                                                                                         \
+    ((unsigned long long*)(sy.words + RIAB_STEP1_SYNC_WORDS((int64_t)sy.n_segments * 256)))[prof_slot * 8 + (k)] = \
+        (unsigned long long)__builtin_amdgcn_s_memrealtime();
+#else
+#define RIAB_S1_STAMP(k)
+#endif
+// timing experiments (tools/build_step1_variants.sh): bit 0 no motion step, bit 1 no rate stores, bit 2 no write-back
+#ifndef RIAB_S1_ABLATE
+#define RIAB_S1_ABLATE 0
+#endif
+#ifndef RIAB_S1_WAVES_PER_EU
+#define RIAB_S1_WAVES_PER_EU 2
+#endif
+#ifndef RIAB_S1_WAVES   // waves per workgroup: the first four advance the 256 agents, all of them write rates
+#define RIAB_S1_WAVES 8
+#endif
 template <class Cell, int SPK, int CPB, bool NT>
-__global__ __launch_bounds__(256, 2) void step1_kernel(const AgentArgs a, const RateArgs ra, Cell cell, const Step1Sync sy,
-                                                       const int reps) {
+__global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_kernel(const AgentArgs a, const RateArgs ra, Cell cell,
+                                                                                           const Step1Sync sy, const int reps,
+                                                                                           const MotionConst<double> hk,
+                                                                                           const TailConst<double> tail_c) {
   RIAB_EXACT_FP
   constexpr int NP = Cell::NP;
+  constexpr int NT_ = 64 * RIAB_S1_WAVES;
   static_assert(NP * CPB <= 64, "a cell group's parameters must fit one wave");
   __shared__ Wall<double> s_w[RIAB_MAX_WALLS];
   __shared__ double s_g[RIAB_G_SEGS * RIAB_G_STRIDE];
@@ -53,44 +96,67 @@ __global__ __launch_bounds__(256, 2) void step1_kernel(const AgentArgs a, const 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool writer = blockIdx.y == 0;
+  const bool mover = RIAB_S1_WAVES == 4 || wave < 4;  // (wave-uniform) the waves that advance the segment's 256 agents
+#ifdef RIAB_STEP1_PROFILE
+  const int prof_slot = (blockIdx.x == 0 && blockIdx.y == 0) ? 0 : (blockIdx.x == 0 && blockIdx.y == 1) ? 1
+                        : (blockIdx.x + 1 == gridDim.x && blockIdx.y + 1 == gridDim.y) ? 2 : -1;
+#endif
+  RIAB_S1_STAMP(0)
   const int64_t B = a.B;
-  const int64_t b = (int64_t)blockIdx.x * 256 + tid;  // (B is a multiple of 256: whole workgroups)
+  const int64_t b = (int64_t)blockIdx.x * 256 + (tid & 255);  // (B is a multiple of 256: whole segments)
   const RiabMotion& m = a.m;
 
   // ---- everything that does not depend on anything: the tables into LDS, the state into registers — one round trip
   double* const st = a.state + b;
-  double px = st[0 * B], py = st[1 * B];
-  double vx = st[2 * B], vy = st[3 * B];
-  double rot = st[4 * B];
-  double mvx = st[5 * B], mvy = st[6 * B];
-  double mrot = st[7 * B];
-  double hx = st[8 * B], hy = st[9 * B];
-  double dist = st[10 * B];
-  double dwall = st[11 * B];
-  double drx = 0, dry = 0;
-  if (m.has_drift) {
-    drx = a.drift[b];
-    dry = a.drift[B + b];
+  double px = 0, py = 0, vx = 0, vy = 0, rot = 0, mvx = 0, mvy = 0, mrot = 0, hx = 0, hy = 0, dist = 0, dwall = 0, drx = 0, dry = 0;
+  if (mover) {
+    px = st[0 * B]; py = st[1 * B];
+    vx = st[2 * B]; vy = st[3 * B];
+    rot = st[4 * B];
+    mvx = st[5 * B]; mvy = st[6 * B];
+    mrot = st[7 * B];
+    hx = st[8 * B]; hy = st[9 * B];
+    dist = st[10 * B];
+    dwall = st[11 * B];
+    if (m.has_drift) {
+      drx = a.drift[b];
+      dry = a.drift[B + b];
+    }
   }
-  const int g0 = (int)(blockIdx.y * 4u + (uint32_t)wave) * reps;  // this wave's first cell group
+  // (the box fast path's verdict, worked out once per plan by walls_prepare_kernel)
+  const uint32_t box_word = *reinterpret_cast<const uint32_t*>(sy.walls + RIAB_MAX_WALLS);
+  const int g0 = (int)(blockIdx.y * (uint32_t)RIAB_S1_WAVES + (uint32_t)wave) * reps;  // this wave's first cell group
   auto group_params = [&](int g) -> float {
     const int pi = g * CPB * NP + lane;
     return (lane < NP * CPB && pi < ra.n * NP) ? cell.tab[pi] : 0.0f;
   };
   float mine = group_params(g0);
-  stage_rayleigh_tables<256>(s_g, s_h, tid);
-  stage_walls<double>(a, s_w, tid, 256);
+  stage_rayleigh_tables<NT_>(s_g, s_h, tid);
+  for (int i = tid; i < a.n_walls * (int)(sizeof(Wall<double>) / sizeof(double)); i += NT_)
+    reinterpret_cast<double*>(s_w)[i] = reinterpret_cast<const double*>(sy.walls)[i];
   __syncthreads();
+#ifdef RIAB_STEP1_PROFILE
+  if (prof_slot >= 0) {  // (the state must have arrived: its first use would otherwise be timed with the motion step)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RIAB_S1_STAMP(1)
+  }
+#endif
 
   // ---- Agent.update for agent b (agent_step_body's step, T = 1, Philox noise, tables in LDS) -----------------------
-  const lds_cf64_ptr lds_g = (lds_cf64_ptr)s_g, lds_h = (lds_cf64_ptr)s_h;
-  const double dt = m.dt;
-  const int nw = a.n_walls;
   int n_bounce = 0, n_sat = 0, n_bc = 0, n_still = 0;
-  const uint32_t aid = (uint32_t)(a.agent_id0 + b);
-  const MotionConst<double> K = make_motion_const<double>(a, s_w);
-  const TailConst<double> tail_c = {dt, K.inv_dt, 1.0 - m.dt / m.hd_tau, m.dt / m.hd_tau, m.hd_tau <= m.dt};
-  {
+  if (mover && !(RIAB_S1_ABLATE & 1)) {
+    const lds_cf64_ptr lds_g = (lds_cf64_ptr)s_g, lds_h = (lds_cf64_ptr)s_h;
+    const double dt = m.dt;
+    const int nw = a.n_walls;
+    const uint32_t aid = (uint32_t)(a.agent_id0 + b);
+    MotionConst<double> K = hk;  // (the scalars were worked out by the host: six float64 divisions less per thread and step)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) K.w4[w] = s_w[w < K.nw ? w : 0];
+    K.box_fast = __builtin_amdgcn_readfirstlane((int)box_word) != 0;  // motion_const_walls' verdict ...
+    K.bxl = K.box_fast ? K.e0 : 0.0;                                   // ... and its edges: the extent itself when it holds
+    K.bxr = K.box_fast ? K.e1 : 0.0;
+    K.byb = K.box_fast ? K.e2 : 0.0;
+    K.byt = K.box_fast ? K.e3 : 0.0;
     u32x4 pw = {0u, 0u, 0u, 0u};
     const MotionDraw d = motion_normals(a.step0, true, aid, a.k0, a.k1, pw);
     const double z_rot = (double)d.z_rot, z_spd = (double)d.z_spd;
@@ -149,27 +215,79 @@ __global__ __launch_bounds__(256, 2) void step1_kernel(const AgentArgs a, const 
     tl = step_tail<double>(tl, dpx, dpy, tail_c, a.step0, aid, a.k0, a.k1);
     mvx = tl.mvx; mvy = tl.mvy; mrot = tl.mrot; hx = tl.hx; hy = tl.hy; dist = tl.dist; n_still = tl.n_still;
   }
-  s_row[0][tid] = (float)px;
-  s_row[1][tid] = (float)py;
-  if (Cell::NEEDS_HD) {
-    s_row[2][tid] = (float)hx;
-    s_row[3][tid] = (float)hy;
-  }
-  if (writer && a.hist) {  // save_to_history (Agent.py:514-520)
-    float* h = a.hist + b;
-    h[0 * B] = (float)px;
-    h[1 * B] = (float)py;
-    h[2 * B] = (float)mvx;
-    h[3 * B] = (float)mvy;
-    h[4 * B] = (float)hx;
-    h[5 * B] = (float)hy;
-    h[6 * B] = (float)mrot;
-    h[7 * B] = (float)dist;
+  RIAB_S1_STAMP(2)
+  if (mover) {
+    s_row[0][tid] = (float)px;
+    s_row[1][tid] = (float)py;
+    if (Cell::NEEDS_HD) {
+      s_row[2][tid] = (float)hx;
+      s_row[3][tid] = (float)hy;
+    }
+    if (writer && a.hist) {  // save_to_history (Agent.py:514-520)
+      float* h = a.hist + b;
+      h[0 * B] = (float)px;
+      h[1 * B] = (float)py;
+      h[2 * B] = (float)mvx;
+      h[3 * B] = (float)mvy;
+      h[4 * B] = (float)hx;
+      h[5 * B] = (float)hy;
+      h[6 * B] = (float)mrot;
+      h[7 * B] = (float)dist;
+    }
   }
   __syncthreads();  // the row is in LDS; every state value of this workgroup has been consumed, i.e. loaded
   if (!writer && tid == 0)
     __hip_atomic_store((s1_gu32*)(uintptr_t)(sy.words + (int64_t)blockIdx.x * RIAB_STEP1_SYNC_STRIDE + blockIdx.y), sy.epoch,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  // ---- the writer's part: the state in place, once nobody can read the old one any more.  Each of its mover waves asks
+  // for its segment's arrival words BEFORE its share of the rates (the request travels while it stores) and looks at the
+  // answer after it; only a word that was not there yet costs a poll.  Bounded; counted when it gives up.
+  auto arrivals = [&]() -> uint32_t {
+    const uint32_t others = gridDim.y - 1u;  // (<= RIAB_STEP1_SYNC_MAX_Y - 1: one lane per word)
+    uint32_t v = sy.epoch;
+    if ((uint32_t)lane < others)
+      v = __hip_atomic_load((s1_gu32*)(uintptr_t)(sy.words + (int64_t)blockIdx.x * RIAB_STEP1_SYNC_STRIDE + 1 + lane), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+  };
+  const bool wb = writer && mover && !(RIAB_S1_ABLATE & 4);  // (wave-uniform)
+  uint32_t seen = sy.epoch;
+  if (wb) seen = arrivals();
+  auto write_back = [&]() {
+    bool timed_out = false;
+    for (uint32_t spins = 0; __builtin_amdgcn_ballot_w64(seen != sy.epoch) != 0; ++spins) {
+      if (spins >= sy.spin_limit) {  // (a workgroup of this grid that never ran: nothing sane to do but to say so)
+        timed_out = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+      seen = arrivals();
+    }
+    if (timed_out && lane == 0)
+      atomicAdd(sy.words + (int64_t)sy.n_segments * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TIMEOUTS, 1u);
+    RIAB_S1_STAMP(5)
+    {
+      st[0 * B] = px;
+      st[1 * B] = py;
+      st[2 * B] = vx;
+      st[3 * B] = vy;
+      st[4 * B] = rot;
+      st[5 * B] = mvx;
+      st[6 * B] = mvy;
+      st[7 * B] = mrot;
+      st[8 * B] = hx;
+      st[9 * B] = hy;
+      st[10 * B] = dist;
+      st[11 * B] = dwall;
+      if (a.diag) {
+        if (n_bounce) atomicAdd(a.diag + 0, n_bounce);
+        if (n_sat) atomicAdd(a.diag + 1, n_sat);
+        if (n_bc) atomicAdd(a.diag + 2, n_bc);
+        if (n_still) atomicAdd(a.diag + 3, n_still);
+      }
+    }
+  };
 
   // ---- Neurons.update of the population: this wave's cell groups for the segment's 256 agents ----------------------
   {
@@ -197,7 +315,9 @@ __global__ __launch_bounds__(256, 2) void step1_kernel(const AgentArgs a, const 
             p[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), j * NP + i));
           v4f rr = cell.eval(p, P);
           rr = finish_rate(rr * ra.fr_scale + ra.fr_min, P);  // [0,1] -> [min_fr, max_fr]
-          if (NT) __builtin_nontemporal_store(rr, reinterpret_cast<v4f*>(ra.rates + off));
+          if (RIAB_S1_ABLATE & 2) {
+            if (rr.x == 123.0f) *reinterpret_cast<v4f*>(ra.rates + off) = rr;
+          } else if (NT) __builtin_nontemporal_store(rr, reinterpret_cast<v4f*>(ra.rates + off));
           else *reinterpret_cast<v4f*>(ra.rates + off) = rr;
           if (SPK == 1) spike_store<false>(ra, rr, off, ra.step0, (uint32_t)(c0 + j), group);
           off += B;
@@ -205,46 +325,20 @@ __global__ __launch_bounds__(256, 2) void step1_kernel(const AgentArgs a, const 
       }
     }
   }
-  if (!writer) return;
-
-  // ---- the writer: the state in place, once nobody can read the old one any more -------------------------------------
-  if (wave == 0) {
-    const uint32_t others = gridDim.y - 1u;  // (<= RIAB_STEP1_SYNC_STRIDE - 1: one lane per word)
-    bool timed_out = false;
-    for (uint32_t spins = 0;; ++spins) {
-      uint32_t v = sy.epoch;
-      if ((uint32_t)lane < others)
-        v = __hip_atomic_load((s1_gu32*)(uintptr_t)(sy.words + (int64_t)blockIdx.x * RIAB_STEP1_SYNC_STRIDE + 1 + lane), __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_AGENT);
-      if (__builtin_amdgcn_ballot_w64(v != sy.epoch) == 0) break;
-      if (spins >= sy.spin_limit) {  // (a workgroup of this grid that never ran: nothing sane to do but to say so)
-        timed_out = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    if (timed_out && lane == 0)
-      atomicAdd(sy.words + (int64_t)sy.n_segments * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TIMEOUTS, 1u);
+  RIAB_S1_STAMP(3)
+#ifdef RIAB_STEP1_PROFILE
+  if (prof_slot >= 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RIAB_S1_STAMP(4)
   }
-  __syncthreads();
-  st[0 * B] = px;
-  st[1 * B] = py;
-  st[2 * B] = vx;
-  st[3 * B] = vy;
-  st[4 * B] = rot;
-  st[5 * B] = mvx;
-  st[6 * B] = mvy;
-  st[7 * B] = mrot;
-  st[8 * B] = hx;
-  st[9 * B] = hy;
-  st[10 * B] = dist;
-  st[11 * B] = dwall;
-  if (a.diag) {
-    if (n_bounce) atomicAdd(a.diag + 0, n_bounce);
-    if (n_sat) atomicAdd(a.diag + 1, n_sat);
-    if (n_bc) atomicAdd(a.diag + 2, n_bc);
-    if (n_still) atomicAdd(a.diag + 3, n_still);
+#endif
+  if (wb) write_back();
+#ifdef RIAB_STEP1_PROFILE
+  if (prof_slot >= 0 && writer) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RIAB_S1_STAMP(6)
   }
+#endif
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
@@ -254,12 +348,12 @@ __global__ __launch_bounds__(256, 2) void step1_kernel(const AgentArgs a, const 
 static void step1_shape(int64_t B, int n, int cpb, dim3* grid, int* reps) {
   const int64_t segs = B / 256;
   const int64_t groups = (n + cpb - 1) / cpb;
-  int64_t want_y = 512 / segs;  // workgroups per segment in one resident round
+  int64_t want_y = (2048 / RIAB_S1_WAVES) / segs;  // workgroups per segment in one resident round (eight waves per compute unit)
   if (want_y < 1) want_y = 1;
-  if (want_y > RIAB_STEP1_SYNC_STRIDE) want_y = RIAB_STEP1_SYNC_STRIDE;
-  int64_t r = (groups + 4 * want_y - 1) / (4 * want_y);
+  if (want_y > RIAB_STEP1_SYNC_MAX_Y) want_y = RIAB_STEP1_SYNC_MAX_Y;
+  int64_t r = (groups + RIAB_S1_WAVES * want_y - 1) / (RIAB_S1_WAVES * want_y);
   if (r < 1) r = 1;
-  int64_t gy = (groups + 4 * r - 1) / (4 * r);
+  int64_t gy = (groups + RIAB_S1_WAVES * r - 1) / (RIAB_S1_WAVES * r);
   *reps = (int)r;
   *grid = dim3((unsigned)segs, (unsigned)gy, 1);
 }
@@ -271,12 +365,17 @@ static int launch_step1_cell(const AgentArgs& a, const RateArgs& ra, const Cell&
   dim3 grid;
   int reps;
   step1_shape(a.B, ra.n, CPB, &grid, &reps);
+  // the launch's scalar constants, once, here (float64 divisions the kernel would otherwise repeat per thread and step)
+  MotionConst<double> hk = {};
+  motion_const_scalars<double>(hk, a);
+  const TailConst<double> tc = {a.m.dt, hk.inv_dt, 1.0 - a.m.dt / a.m.hd_tau, a.m.dt / a.m.hd_tau, a.m.hd_tau <= a.m.dt};
+  const dim3 block(64 * RIAB_S1_WAVES);
   if (spikes) {
-    if (nt) hipLaunchKernelGGL((step1_kernel<Cell, 1, CPB, true>), grid, dim3(256), 0, s, a, ra, cell, sy, reps);
-    else hipLaunchKernelGGL((step1_kernel<Cell, 1, CPB, false>), grid, dim3(256), 0, s, a, ra, cell, sy, reps);
+    if (nt) hipLaunchKernelGGL((step1_kernel<Cell, 1, CPB, true>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc);
+    else hipLaunchKernelGGL((step1_kernel<Cell, 1, CPB, false>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc);
   } else {
-    if (nt) hipLaunchKernelGGL((step1_kernel<Cell, 0, CPB, true>), grid, dim3(256), 0, s, a, ra, cell, sy, reps);
-    else hipLaunchKernelGGL((step1_kernel<Cell, 0, CPB, false>), grid, dim3(256), 0, s, a, ra, cell, sy, reps);
+    if (nt) hipLaunchKernelGGL((step1_kernel<Cell, 0, CPB, true>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc);
+    else hipLaunchKernelGGL((step1_kernel<Cell, 0, CPB, false>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc);
   }
   return (int)hipGetLastError();
 }
@@ -301,7 +400,7 @@ int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B) {
 // writes: `rates_row` / `spikes_row` are the population's rows of this step, `step_after` the number of agent steps
 // taken once this one is done (Neurons.update's spike counter, as riab_plan_step passes it)
 int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
-                 uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, hipStream_t s) {
+                 uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, hipStream_t s) {
   const int rc = step1_supported(env, pop, a.B);
   if (rc) return rc;
   if (a.z_in || a.z_out || a.forced || a.T != 1 || !sync_words || !rates_row || epoch == 0u) return RIAB_EINVAL;
@@ -330,6 +429,12 @@ int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* p
   sy.epoch = epoch;
   sy.spin_limit = 1u << 22;  // x ~0.3 us: about a second
   sy.n_segments = (uint32_t)(a.B / 256);
+  Wall<double>* const gw = reinterpret_cast<Wall<double>*>(sync_words + RIAB_STEP1_SYNC_WALLS_AT(a.B));
+  sy.walls = gw;
+  if (walls_ready && !*walls_ready) {  // (the plan's first one-launch step, and the first after its motion parameters changed)
+    hipLaunchKernelGGL(walls_prepare_kernel, dim3(1), dim3(64), 0, s, a, gw);
+    *walls_ready = true;
+  }
   const bool spikes = spikes_row != nullptr;
   const bool nt = g_options[RIAB_OPT_FUSED_STEP] != 2;
   switch (pop->kind) {

@@ -27,7 +27,7 @@ def _attach_fused(plan, agent):
     plan._sync_words = None
     if agent._Bp % 256 == 0 and not _L.env("RIAB_NO_FUSED_STEP"):
         n = _L.step1_sync_words(agent._Bp)
-        plan._sync_words = torch.zeros(n, dtype=torch.int32, device=agent._device)
+        plan._sync_words = torch.zeros(n + 256, dtype=torch.int32, device=agent._device)   # (+ slack: tools/step1_profile.py)
         _L.check(_L.lib.riab_plan_set_fused(plan._h, _L.ptr(plan._sync_words), n), "riab_plan_set_fused")
 
 
@@ -35,7 +35,7 @@ def _check_fused(plan):
     """A writer of the one-launch step that gave up waiting for its segment's workgroups (must never happen)."""
     w = getattr(plan, "_sync_words", None)
     if w is not None and plan._h and _L.lib.riab_plan_info(plan._h, 0) > 0:
-        if int(w[-_L.STEP1_SYNC_TAIL + _L.STEP1_SYNC_TIMEOUTS].item()):
+        if int(w[_L.step1_sync_tail(plan.agent._Bp) + _L.STEP1_SYNC_TIMEOUTS].item()):
             raise _L.RiabError("one-launch step: a state write-back gave up waiting for its segment's workgroups; "
                                "the agent state of that step is not trustworthy")
 

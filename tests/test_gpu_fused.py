@@ -644,11 +644,14 @@ def test_bench_launches_its_own_ranks(riab):
     assert [x["rank"] for x in per] == [0, 1] and all(0 < x["min"] <= x["median"] <= x["max"] for x in per)
     assert out["timed_region_ms"]["median"] >= max(x["min"] for x in per)
     sec = out["secondary"]
-    assert set(sec) == {"cfg2_T1024", "cfg4", "cfg5"}, sec.keys()
+    closed = {"cfg2_closed_loop_plan", "cfg2_closed_loop_per_step", "cfg2_closed_loop_task"}
+    assert set(sec) == {"cfg2_T1024", "cfg4", "cfg5"} | closed, sec.keys()
     for name, blk in sec.items():
         assert "error" not in blk, blk
         assert blk["n_gpus"] == 2 and blk["value"] > 1e6 and len(blk["timed_region_ms_per_rank"]) == 2
-        assert blk["diagnostics"]["pipeline_timeouts"] == 0
+        assert blk["diagnostics"].get("pipeline_timeouts", 0) == 0
+        if name in closed and name != "cfg2_closed_loop_task":   # the one-launch step served the loop
+            assert blk["plan"]["fused_steps"] > 0, blk["plan"]
         assert 0 < blk["frac_whole_path"] < 1 and blk["roofline"]["frac"] > 0
     strong = _bench(["--gpus", "2", "--strong", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"],
                     {"RIAB_BENCH_SHARE_GPU": "1"}, timeout=400)
