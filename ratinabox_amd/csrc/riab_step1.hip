@@ -76,9 +76,7 @@ typedef __attribute__((address_space(1))) uint32_t s1_gu32;
 #ifndef RIAB_S1_WAVES_PER_EU
 #define RIAB_S1_WAVES_PER_EU 2
 #endif
-#ifndef RIAB_S1_WAVES   // waves per workgroup: the first four advance the 256 agents, all of them write rates
-#define RIAB_S1_WAVES 8
-#endif
+#define RIAB_S1_WAVES 8  // waves per workgroup: 0-3 advance the 256 agents, 4-7 draw their normals, all of them write rates
 template <class Cell, int SPK, int CPB, bool NT>
 __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_kernel(const AgentArgs a, const RateArgs ra, Cell cell,
                                                                                            const Step1Sync sy, const int reps,
@@ -92,11 +90,12 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
   __shared__ double s_g[RIAB_G_SEGS * RIAB_G_STRIDE];
   __shared__ double s_h[RIAB_H_SEGS * RIAB_H_STRIDE];
   __shared__ __align__(16) float s_row[4][256];  // x, y, head direction x, y of the segment's agents as the history keeps them
+  __shared__ float s_z[2][256];                  // the step's two standard normals per agent (drawn by waves 4-7)
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool writer = blockIdx.y == 0;
-  const bool mover = RIAB_S1_WAVES == 4 || wave < 4;  // (wave-uniform) the waves that advance the segment's 256 agents
+  const bool mover = wave < 4;  // (wave-uniform) the waves that advance the segment's 256 agents
 #ifdef RIAB_STEP1_PROFILE
   const int prof_slot = (blockIdx.x == 0 && blockIdx.y == 0) ? 0 : (blockIdx.x == 0 && blockIdx.y == 1) ? 1
                         : (blockIdx.x + 1 == gridDim.x && blockIdx.y + 1 == gridDim.y) ? 2 : -1;
@@ -143,13 +142,27 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
 #endif
 
   // ---- Agent.update for agent b (agent_step_body's step, T = 1, Philox noise, tables in LDS) -----------------------
+  // In two halves around one more barrier.  The step's two standard normals are a function of (seed, step, agent)
+  // alone — Philox + Box-Muller, a fifth of a step's instructions — so the workgroup's OTHER four waves draw them (one
+  // lane per agent, into LDS) while the movers run everything that does not need them: the speed, its G-table
+  // polynomial, both wall passes (they read the position only).  The same functions on the same operands as
+  // agent_step_body, in another order where the order does not matter.
   int n_bounce = 0, n_sat = 0, n_bc = 0, n_still = 0;
-  if (mover && !(RIAB_S1_ABLATE & 1)) {
-    const lds_cf64_ptr lds_g = (lds_cf64_ptr)s_g, lds_h = (lds_cf64_ptr)s_h;
-    const double dt = m.dt;
-    const int nw = a.n_walls;
-    const uint32_t aid = (uint32_t)(a.agent_id0 + b);
-    MotionConst<double> K = hk;  // (the scalars were worked out by the host: six float64 divisions less per thread and step)
+  const uint32_t aid = (uint32_t)(a.agent_id0 + b);
+  const double dt = m.dt;
+  const int nw = a.n_walls;
+  MotionConst<double> K = hk;  // (the scalars were worked out by the host: six float64 divisions less per thread and step)
+  NearWalls<double> near = {};
+  WallPush<double> push = {};
+  double ispeed = 0, nv64 = 0, ppx = 0, ppy = 0;
+  bool zero_v = false;
+  if (!mover) {
+    u32x4 pw = {0u, 0u, 0u, 0u};
+    const MotionDraw d = motion_normals(a.step0, true, aid, a.k0, a.k1, pw);
+    s_z[0][tid & 255] = d.z_rot;
+    s_z[1][tid & 255] = d.z_spd;
+  } else if (!(RIAB_S1_ABLATE & 1)) {
+    const lds_cf64_ptr lds_g = (lds_cf64_ptr)s_g;
 #pragma unroll
     for (int w = 0; w < 4; ++w) K.w4[w] = s_w[w < K.nw ? w : 0];
     K.box_fast = __builtin_amdgcn_readfirstlane((int)box_word) != 0;  // motion_const_walls' verdict ...
@@ -157,18 +170,29 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
     K.bxr = K.box_fast ? K.e1 : 0.0;
     K.byb = K.box_fast ? K.e2 : 0.0;
     K.byt = K.box_fast ? K.e3 : 0.0;
-    u32x4 pw = {0u, 0u, 0u, 0u};
-    const MotionDraw d = motion_normals(a.step0, true, aid, a.k0, a.k1, pw);
-    const double z_rot = (double)d.z_rot, z_spd = (double)d.z_spd;
-    const double ppx = px, ppy = py;  // prev_pos (Agent.py:199)
-    // ---- _stochastic_velocity_update (Agent.py:287-312)
+    ppx = px;  // prev_pos (Agent.py:199)
+    ppy = py;
+    // ---- _stochastic_velocity_update (Agent.py:287-312), the part in front of the noise
     double v2 = norm2(vx, vy);
-    const bool zero_v = (v2 == 0.0);
+    zero_v = (v2 == 0.0);
     if (zero_v) v2 = 1e-16;  // the reference replaces a zero velocity by (1e-8, 0) (Agent.py:299-300)
-    const double ispeed = r_rsqrt(v2);
+    ispeed = r_rsqrt(v2);
     const double speed = v2 * ispeed;
     const double tG = clamp_G_arg(speed * K.inv_sm);
     const SegRow<RIAB_G_DEG> grow = seg_fetch<RIAB_G_DEG>(lds_g + seg_G(tG) * RIAB_G_STRIDE);
+    // ---- _wall_velocity_update: pass 1 and the spring / conveyor terms of pass 2 (functions of the position)
+    near = walls_pass1<double>(K, s_w, px, py);
+    if (nw > 0 && K.repel) {
+      push = walls_pass2_terms<double>(K, s_w, near, px, py);
+      dwall = closest_wall_distance<double>(K, near);
+    }
+    // utils.rayleigh_to_normal (utils.py:416-421), sigma = speed_mean
+    nv64 = seg_eval<RIAB_G_DEG>(grow, tG);
+  }
+  __syncthreads();  // the normals are in LDS
+  if (mover && !(RIAB_S1_ABLATE & 1)) {
+    const lds_cf64_ptr lds_h = (lds_cf64_ptr)s_h;
+    const double z_rot = (double)s_z[0][tid], z_spd = (double)s_z[1][tid];
     rot = ou_step<double>(rot, m.rot_theta_kw, m.rot_drift_kw, m.rot_sigma_kw, dt, z_rot);
     {
       double sn, cs;
@@ -177,14 +201,10 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
       vx = zero_v ? 1e-8 : vx;
       vy = zero_v ? 0.0 : vy;
     }
-    // utils.rayleigh_to_normal / normal_to_rayleigh (utils.py:409-421), sigma = speed_mean
-    double nv64 = seg_eval<RIAB_G_DEG>(grow, tG);
+    // the speed's OU step in normal space and normal_to_rayleigh (utils.py:409-413)
     nv64 = ou_step<double>(nv64, m.speed_theta_kw, 0.0, m.speed_sigma_kw, m.dt, z_spd);
     const bool h_in_table = fabs(nv64) < RIAB_H_NMAX;
     const SegRow<RIAB_H_DEG> hrow = seg_fetch<RIAB_H_DEG>(lds_h + seg_H(nv64) * RIAB_H_STRIDE);
-    // ---- _wall_velocity_update, pass 1
-    const NearWalls<double> near = walls_pass1<double>(K, s_w, px, py);
-    // ---- finish the speed update
     double speed_new;
     {
       const double tnew = h_in_table ? seg_eval<RIAB_H_DEG>(hrow, nv64) : sqrt(-2.0 * log(1.0 - normcdf(nv64)));
@@ -198,12 +218,8 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
     }
     // ---- _drift_velocity_update (Agent.py:331-341)
     if (m.has_drift) drift_update<double>(m.drift_theta, drx, dry, dt, vx, vy);
-    // ---- _wall_velocity_update, pass 2
-    if (nw > 0 && K.repel) {
-      const WallPush<double> push = walls_pass2_terms<double>(K, s_w, near, px, py);
-      dwall = closest_wall_distance<double>(K, near);
-      walls_pass2_apply<double>(K, push, px, py, vx, vy);
-    }
+    // ---- _wall_velocity_update, pass 2 applied
+    if (nw > 0 && K.repel) walls_pass2_apply<double>(K, push, px, py, vx, vy);
     // ---- propose (Agent.py:216), collisions, boundary safety net
     propose_step<double>(vx, vy, dt, px, py);
     handle_collisions<double>(K, s_w, near.x2min, ppx, ppy, px, py, vx, vy, n_bounce, n_sat);
