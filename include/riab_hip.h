@@ -636,7 +636,7 @@ double riab_plan_task_clock(const RiabPlan* plan);
  *         wave's end of the row-following rate kernel of the last call that ran one (the clock only moves forward, so
  *         the words need no reset between calls: the newest start is stored, the end is a maximum),
  *         [RIAB_CTRL_TRAJ_STAMPS .. +3] the same clock at the start of trajectory workgroup 0 and at its last
- *         publication (every call; what RIAB_STREAMER_OPT_CALIBRATE reads),
+ *         publication (every call; what the form selection's one-off measurement reads, see STEP_NS / LEAD_MBPS),
  *         [RIAB_CTRL_PROGRESS_WORD(w)] (uint32)(step0 + steps whose rows trajectory workgroup w (agents 64w ..
  *         64w+63) has published).  The four words of a 256-agent sub-segment share one 128-byte line that no
  *         other sub-segment touches: every wave of the rate kernel reads exactly one such line, and with all of
@@ -735,10 +735,35 @@ void riab_streamer_destroy(RiabStreamer* h);
  * built-in figure; until then, and when the stamps are unusable, the constants measured on MI355X (900 ns + 250 ns per
  * wall beyond four; 6.5 TB/s).  A non-zero value replaces the measurement (tests; chips whose clocks are known to
  * differ). */
+/* STRICT (0 / 1): see "Two modes" below.  SPIN_LIMIT: polls before a waiting rate wave / gate gives up (0, the default:
+ * 2^20 for waves, 2^22 - 2^24 for gates, about a second; tests set it to 1 to force the abort path). */
 enum { RIAB_STREAMER_OPT_GATE = 0, RIAB_STREAMER_OPT_POLL_MAX = 1, RIAB_STREAMER_OPT_HEAD_ROWS = 2,
-       RIAB_STREAMER_OPT_SIDE_STREAM = 3, RIAB_STREAMER_OPT_STEP_NS = 4, RIAB_STREAMER_OPT_LEAD_MBPS = 5 };
+       RIAB_STREAMER_OPT_SIDE_STREAM = 3, RIAB_STREAMER_OPT_STEP_NS = 4, RIAB_STREAMER_OPT_LEAD_MBPS = 5,
+       RIAB_STREAMER_OPT_STRICT = 6, RIAB_STREAMER_OPT_SPIN_LIMIT = 7 };
 enum { RIAB_GATE_ALWAYS = 0, RIAB_GATE_WHEN_BUSY = 1, RIAB_GATE_RESERVED = 2 };
 int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t value);
+/* Two modes of riab_simulate, against the contract SURVEY.md 8(b2) sets for the boundary ("no allocation, no sync, no
+ * host<->device copies inside; enqueue on the passed stream and return; hipGraph-capturable; re-entrant, no globals"):
+ *
+ *  DEFAULT (what Agent.simulate() and bench.py run: tuned for one short call per synchronisation).  Deviates from that
+ *    contract in documented ways, each measured into existence (docs/EXPERIMENTS.md r03 / r04): the trajectory kernel's
+ *    stream is taken from a process-wide pool and SCREENED by timing candidate streams the first time the caller's
+ *    stream is found idle (synchronises it; ~1 ms, once per (device, stream)); the caller's stream is queried
+ *    (hipStreamQuery) at every call; a call with several populations reads the previous call's device-clock stamps
+ *    once per streamer (a 32-byte blocking copy); timing events are created on first use.  Not capturable.
+ *  STRICT (riab_streamer_configure(RIAB_STREAMER_OPT_STRICT, 1); imposed on any call whose `stream` is being captured):
+ *    conforms.  Nothing is allocated, synchronised, queried or copied, nothing outside the streamer is touched: the
+ *    trajectory kernel runs on a stream of the streamer's own, the call opens with a one-wave kernel that re-bases the
+ *    announcement counter and the call's progress words ON THE DEVICE (so a replay of the captured call finds what the
+ *    first run found), the two streams are forked and joined with the streamer's two events at both ends, the started
+ *    gate is always taken (graph branches may be serialised by the runtime: the gate makes that safe,
+ *    ctrl[RIAB_CTRL_SERIALISED] makes it visible), calls are timed only with events that already exist.  Costs two
+ *    more launches and the fork's dependency per call (cfg 2, 20 steps: see DESIGN.md 3.8).  Needs
+ *    riab_streamer_warmup(h, stream) once beforehand — outside any capture —, which creates that stream and the events
+ *    and also performs the default mode's screening for `stream`; without it a strict call returns RIAB_EUNSUPPORTED
+ *    (nothing launched).  Same rows, bit for bit, in either mode.
+ * The per-kernel entry points above and the step-plan entry points conform unconditionally. */
+int riab_streamer_warmup(RiabStreamer* h, riab_stream_t stream);
 int riab_simulate(RiabStreamer* h, const RiabSimulate* run, riab_stream_t stream);
 /* what riab_simulate does with RiabSimulate.watch before anything else (host memory only, no device): RIAB_OK when every
  * live array equals its snapshot, RIAB_ECHANGED otherwise, RIAB_EINVAL for a malformed list */

@@ -129,6 +129,11 @@ class Agent:
         self._run_cache = None  # (population structs, their array, the RiabSimulate argument block, key) of the last call
         self._ctrl = None       # its control words on the device
         self._pipeline_unchecked = False
+        self._unchecked_runs = []     # native simulate() calls since the last pipeline check: what a recovery recomputes
+        self._unchecked_lost = False  # ... more of them than are kept
+        self._recovered_runs = 0      # diagnostics["pipeline_recovered"]
+        self._timeouts_recovered = 0
+        self._recover_warned = False
         self._time_rate_kernel = False
         self._timed_population = None
         self._serial_warned = False
@@ -190,24 +195,68 @@ class Agent:
     def _squeeze(self, a):
         return a[0] if self._B == 1 else a
 
+    MAX_UNCHECKED_RUNS = 1024   # native runs remembered between two pipeline checks
+
     def _check_pipeline(self):
-        """After a fused simulate(): a wait of the flag-coupled pipeline that gave up (bounded spins: a stuck or
-        starved producer) leaves rows unwritten.  Checked on the first host read that follows — which synchronises
-        anyway — and reported as an error; the control words are cleared so that the next run starts clean."""
+        """After a native simulate(): a wait of the flag-coupled pipeline that gave up (bounded spins: a producer starved
+        for about a second — forward progress between two kernels is not something the device promises) leaves rate
+        rows unwritten, in that call and in every later one until the flags are cleared.  Checked on the first host
+        read that follows, which synchronises anyway.  The trajectory kernel does not wait for anybody outside its own
+        workgroup, so its rows and the agent state are complete (verified on the progress words): the rates of every
+        run since the last check are then RECOMPUTED from those rows with the populations' ordinary, stream-ordered
+        kernels — the same functors on the same fp32 rows: the bits the pipeline would have written — counted in
+        diagnostics["pipeline_recovered"], and the caller gets a warning instead of an exception.  What cannot be
+        redone raises as before: a trajectory kernel that itself gave up, populations with additive OU noise (their
+        noise state has advanced), more unchecked runs than are remembered."""
         if not self._pipeline_unchecked:
             return
         self._pipeline_unchecked = False
         w = self._ctrl[:4].cpu()
-        if int(w[_L.CTRL_TIMEOUTS]) or int(w[_L.CTRL_ABORT]):
-            n = int(w[_L.CTRL_TIMEOUTS])
-            # (a rate stage that gave up did not wait for the trajectory kernel's last publication, which is what orders
-            # the caller's stream behind that kernel: wait for the whole device before the flags are cleared and the
-            # caller goes on — state uploads, the next update(), recycled buffers)
-            torch.cuda.synchronize(self._device)
-            self._ctrl[_L.CTRL_TIMEOUTS] = 0
-            self._ctrl[_L.CTRL_ABORT] = 0
-            raise _L.RiabError(f"the flag-coupled simulate() pipeline was aborted ({n} waits timed out): the rows of "
-                               f"that run are incomplete (RIAB_NO_NATIVE=1 selects the Python-driven chunk pipeline)")
+        runs, self._unchecked_runs = self._unchecked_runs, []
+        lost, self._unchecked_lost = self._unchecked_lost, False
+        if not (int(w[_L.CTRL_TIMEOUTS]) or int(w[_L.CTRL_ABORT])):
+            return
+        n = int(w[_L.CTRL_TIMEOUTS])
+        # (a rate stage that gave up did not wait for the trajectory kernel's last publication, which is what orders
+        # the caller's stream behind that kernel: wait for the whole device before the flags are cleared and the
+        # caller goes on — state uploads, the next update(), recycled buffers)
+        torch.cuda.synchronize(self._device)
+        n_traj = (self._Bp + 63) // 64
+        idx = torch.arange(n_traj, device=self._device)
+        words = self._ctrl[_L.CTRL_PROGRESS + 32 * (idx // 4) + (idx % 4)].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        complete = bool(runs) and bool((words == (int(self._step_index) & 0xFFFFFFFF)).all())
+        self._ctrl[_L.CTRL_TIMEOUTS] = 0
+        self._ctrl[_L.CTRL_ABORT] = 0
+        why = None
+        if not complete:
+            why = "the trajectory kernel itself did not finish"
+        elif lost:
+            why = f"more than {self.MAX_UNCHECKED_RUNS} runs since the last host read"
+        elif any(N.noise_std != 0 for r in runs for N in r[5]):
+            why = "a population with additive OU noise took part (its noise state has advanced)"
+        if why is not None:
+            raise _L.RiabError(f"the flag-coupled simulate() pipeline was aborted ({n} waits timed out) and its rows cannot "
+                               f"be recomputed: {why}; the rows of that run are incomplete (RIAB_NO_NATIVE=1 selects the "
+                               "Python-driven chunk pipeline)")
+        stream = _L.current_stream()
+        for traj_c, traj_s, n_steps, step0, dt, neurons, ats in runs:
+            traj = traj_c[traj_s:traj_s + n_steps]
+            outs = [N._rows_views(at, n_steps) for N, at in zip(neurons, ats)]
+            self._sim_outs = dict(zip(neurons, outs))   # (FeedForwardLayers read their inputs' rows of the same piece)
+            for t0 in range(0, n_steps, 1024):
+                tc = min(1024, n_steps - t0)
+                for N, out in zip(neurons, outs):
+                    N._rates_from_trajectory(traj[t0:t0 + tc], out, t0, tc, step0 + t0, float(dt), stream=stream)
+        torch.cuda.synchronize(self._device)
+        self._recovered_runs += len(runs)
+        self._timeouts_recovered += n
+        if not self._recover_warned:
+            self._recover_warned = True
+            import warnings
+            warnings.warn(f"the flag-coupled simulate() pipeline was aborted ({n} waits of its rate stage timed out: something "
+                          f"kept the trajectory kernel off the device for about a second); the firing rates of the last "
+                          f"{len(runs)} run(s) were recomputed from the complete trajectory with the stream-ordered kernels "
+                          "(diagnostics['pipeline_recovered'])", RuntimeWarning)
 
     def _download(self, row, width):
         self._check_pipeline()
@@ -251,6 +300,8 @@ class Agent:
         if self._ctrl is not None:
             w = self._ctrl[:4].cpu()
             out["pipeline_timeouts"] = int(w[_L.CTRL_TIMEOUTS])  # waits of the flag-coupled pipeline that gave up: must be 0
+            out["pipeline_recovered"] = self._recovered_runs     # runs whose rates were recomputed after such a wait
+            out["pipeline_timeouts_recovered"] = self._timeouts_recovered
             # simulate() calls (>= 8 steps) whose trajectory kernel had FINISHED before the firing-rate stage began: the
             # two kernels are meant to run side by side on two hardware queues; results are right, the call is slower
             # (minus the calls whose second launch the HOST issued late — a descheduled thread: such a call finds every row
@@ -570,6 +621,23 @@ class Agent:
         if _L.env("RIAB_HEAD_ROWS"):        # (rows of a long run that the row-following kernel serves: 65535 = all)
             _L.check(_L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_HEAD_ROWS, int(_L.env("RIAB_HEAD_ROWS"))),
                      "riab_streamer_configure")
+        # Everything a later call might have to set up, now (riab_hip.h "Two modes"): the strict mode's own stream, the
+        # screening of the default mode's second stream, the timing events.  A call on a stream that is being captured
+        # (torch.cuda.graph around Agent.simulate() / torch.ops.riab.simulate_) then runs in the strict mode by itself.
+        if not torch.cuda.is_current_stream_capturing():
+            _L.check(_L.lib.riab_streamer_warmup(self._streamer, _L.current_stream()), "riab_streamer_warmup")
+        if _L.env("RIAB_STRICT") == "1":
+            self.pipeline_mode(strict=True)
+
+    def pipeline_mode(self, strict):
+        """`strict=True`: native simulate() calls of this agent take the mode of riab_simulate that conforms to the C ABI's
+        contract (include/riab_hip.h "Two modes": nothing allocated, synchronised, queried or shared; capturable; two
+        more launches per call); `False` (the default): the mode tuned for one short call per synchronisation.  Calls on
+        a stream that is being captured are strict whatever this says.  Same rows either way."""
+        if self._streamer is None:
+            self._make_streamer()
+        _L.check(_L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_STRICT, 1 if strict else 0),
+                 "riab_streamer_configure")
 
     # ---- the open-loop run as ONE native call (riab_simulate) -----------------------------------------------------------
     def _simulate_native(self, n_steps, dt, drift_velocity, ratio, neurons, noise=None, kwargs=None):
@@ -776,8 +844,11 @@ class Agent:
         ag = _agent_fast(self)
         if not all(type(v) in _PLAIN for v in ag if v is not self._timed_population):
             return None
+        # (the argument block holds raw pointers into the populations' device tables and the wall table: snapshot-equal
+        # content must imply that those tensors still exist, whatever rebuilt the populations' caches in between)
+        tables = [list(getattr(N, "_plan_tables", None) or ()) for N in neurons]
         return dict(pops=pops, walls=walls, env=_env_fast(Env), holes=list(Env._wall_is_hole), ag=ag, watch=watch,
-                    n_watch=len(keep), _keep=(keep, snaps))
+                    n_watch=len(keep), _keep=(keep, snaps, tables, Env.device_tables(self._device)))
 
     def _after_native(self, n_steps, dt, traj_c, traj_s, neurons, ats, tc, keep):
         """The kernels of a native run are in flight: now the views and the Python-side mirrors (clocks, step index,
@@ -785,6 +856,12 @@ class Agent:
         outs = [N._rows_views(at, n_steps) for N, at in zip(neurons, ats)]
         self.engine_runs["native"] += 1
         self._pipeline_unchecked = True
+        # (what _check_pipeline needs to recompute this run's rates should a wait of its rate stage have given up)
+        runs = self._unchecked_runs
+        if len(runs) >= self.MAX_UNCHECKED_RUNS:
+            del runs[0]
+            self._unchecked_lost = True
+        runs.append((traj_c, traj_s, n_steps, self._step_index, dt, neurons, ats))
         traj = traj_c[traj_s:traj_s + n_steps]
         self._keep = (keep, outs)
         self._last_row = traj[n_steps - 1]
@@ -992,7 +1069,7 @@ class Agent:
             return None
         f = lambda k: int(_L.lib.riab_streamer_info(self._streamer, k))  # noqa: E731
         pair = f(4)
-        return {"launches_last_call": f(3),
+        return {"launches_last_call": f(3), "strict_last_call": bool(f(8)),
                 "second_stream": {"screened": pair >= 0, "pair_us": round(pair / 1e3, 1) if pair >= 0 else None,
                                   "same_stream_pair_us": round(f(6) / 1e3, 1), "candidates_set_aside": f(5)},
                 "form_selection": {"trajectory_step_ns": f(0), "lead_store_MBps": f(1), "measured": bool(f(2))}}
@@ -1100,6 +1177,7 @@ class Agent:
     def reset_history(self):
         if self._plan is not None:
             self._plan.close()
+        self._check_pipeline()   # (rows about to be dropped may still be owed a recovery: settle that first)
         self._hist.reset()
         self._times = []
 

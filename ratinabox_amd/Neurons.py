@@ -484,6 +484,7 @@ class Neurons:
     def reset_history(self):
         if self.Agent._plan is not None:
             self.Agent._plan.close()  # (its open rows live in the chunks dropped here)
+        self.Agent._check_pipeline()   # (rows about to be dropped may still be owed a recovery)
         self._hist_fr.reset()
         self._hist_sp.reset()
         self._times = []

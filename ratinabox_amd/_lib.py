@@ -113,6 +113,7 @@ EPARTIAL = -6
 ECHANGED = -7
 STREAMER_OPT_GATE, STREAMER_OPT_POLL_MAX, STREAMER_OPT_HEAD_ROWS = 0, 1, 2
 STREAMER_OPT_SIDE_STREAM, STREAMER_OPT_STEP_NS, STREAMER_OPT_LEAD_MBPS = 3, 4, 5
+STREAMER_OPT_STRICT, STREAMER_OPT_SPIN_LIMIT = 6, 7
 GATE_ALWAYS, GATE_WHEN_BUSY, GATE_RESERVED = 0, 1, 2
 CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_SERIALISED, CTRL_STAMPS, CTRL_TRAJ_STAMPS, CTRL_PROGRESS = 0, 1, 2, 3, 8, 12, 32  # riab_hip.h RIAB_CTRL_*
 
@@ -205,6 +206,7 @@ PROTOTYPES = {
     "riab_streamer_create": (C.c_void_p, []),
     "riab_streamer_destroy": (None, [C.c_void_p]),
     "riab_simulate": (C.c_int, [C.c_void_p, C.POINTER(RiabSimulate), C.c_void_p]),
+    "riab_streamer_warmup": (C.c_int, [C.c_void_p, C.c_void_p]),
     "riab_watch_compare": (C.c_int, [C.c_void_p, C.c_int32]),
     "riab_streamer_configure": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "riab_streamer_last_rate_ms": (C.c_float, [C.c_void_p]),

@@ -461,6 +461,17 @@ __global__ __launch_bounds__(64) void stream_gate_kernel(uint32_t* ctrl, uint32_
   }
 }
 
+// The opening kernel of a STRICT riab_simulate call (riab_hip.h "Two modes"): one wave on the caller's stream, in front
+// of everything else the call enqueues.  It zeroes the announcement counter and sets every progress word of the call to
+// `step_base`, so that nothing the call's gates and waiting waves compare depends on what an earlier call — or an
+// earlier replay of the same captured call — left in the control block.
+__global__ __launch_bounds__(64) void stream_open_kernel(uint32_t* ctrl, uint32_t n_traj, uint32_t step_base) {
+  for (uint32_t w = threadIdx.x; w < n_traj; w += 64)
+    __hip_atomic_store((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_PROGRESS_WORD(w)), step_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0)
+    __hip_atomic_store((gu32*)(uintptr_t)(ctrl + RIAB_CTRL_STARTED), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- host side ------------------------------------------------------------------------------
 static int check_io(const RiabRateIO* io, int n, bool need_pos, bool need_hd) {
   if (!io || n <= 0 || io->T <= 0 || io->B <= 0 || !io->rates) return RIAB_EINVAL;
@@ -763,6 +774,11 @@ int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const floa
     }
     default: return RIAB_EUNSUPPORTED;
   }
+}
+
+int launch_stream_open(uint32_t* ctrl, uint32_t n_traj, uint32_t step_base, hipStream_t s) {
+  hipLaunchKernelGGL(stream_open_kernel, dim3(1), dim3(64), 0, s, ctrl, n_traj, step_base);
+  return (int)hipGetLastError();
 }
 
 int launch_stream_gate(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj, uint32_t progress_target,

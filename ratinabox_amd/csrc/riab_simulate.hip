@@ -54,6 +54,7 @@ int launch_rate_stream(const RiabEnv* env, const RiabPopulation* pop, const floa
                        uint32_t serial_rows);
 int launch_stream_gate(uint32_t* ctrl, uint32_t started_target, uint32_t n_traj, uint32_t progress_target,
                        uint32_t spin_limit, bool sleep_long, uint32_t final_target, hipStream_t s);
+int launch_stream_open(uint32_t* ctrl, uint32_t n_traj, uint32_t step_base, hipStream_t s);
 }  // namespace riab
 
 struct RiabStreamer {
@@ -92,6 +93,14 @@ struct RiabStreamer {
   int poll_max;              // RIAB_STREAMER_OPT_POLL_MAX
   int head_rows;             // RIAB_STREAMER_OPT_HEAD_ROWS
   int last_form;             // riab_streamer_last_form
+  // the strict mode (riab_hip.h "Two modes")
+  int strict;                // RIAB_STREAMER_OPT_STRICT
+  hipStream_t side_own;      // the trajectory kernel's stream in strict calls: the streamer's own, made by riab_streamer_warmup
+  bool resync;               // a strict call has re-based the announcement counter: the next call of either mode opens with
+                             // stream_open_kernel as well
+  bool captured_once;        // ... and every later call does, once a strict call has been CAPTURED (it may be replayed any time)
+  uint32_t spin_limit;       // RIAB_STREAMER_OPT_SPIN_LIMIT: polls before a waiting wave / gate gives up (0: the defaults)
+  int last_strict;           // the last call ran in strict mode (riab_streamer_info 8)
 };
 
 // ---- the trajectory kernel's stream: screened, process-wide -----------------------------------------------------------
@@ -233,6 +242,12 @@ extern "C" RiabStreamer* riab_streamer_create(void) {
   h->poll_max = 65535;
   h->head_rows = 256;
   h->last_form = RIAB_FORM_NONE;
+  h->strict = 0;
+  h->side_own = nullptr;
+  h->resync = false;
+  h->captured_once = false;
+  h->spin_limit = 0u;
+  h->last_strict = 0;
   int dev = 0, khz = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) != hipSuccess) {
@@ -274,6 +289,14 @@ extern "C" int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t 
       if (value < 1 || value > 65535) return RIAB_EINVAL;
       h->head_rows = value;
       return RIAB_OK;
+    case RIAB_STREAMER_OPT_STRICT:
+      if (value != 0 && value != 1) return RIAB_EINVAL;
+      h->strict = value;
+      return RIAB_OK;
+    case RIAB_STREAMER_OPT_SPIN_LIMIT:
+      if (value < 0) return RIAB_EINVAL;
+      h->spin_limit = (uint32_t)value;
+      return RIAB_OK;
     default: return RIAB_EINVAL;
   }
 }
@@ -287,6 +310,7 @@ extern "C" void riab_streamer_destroy(RiabStreamer* h) {
   if (h->fork) (void)hipEventDestroy(h->fork);
   // (h->side belongs to the process-wide pool: side_stream_for)
   if (h->side_normal) (void)hipStreamDestroy(h->side_normal);
+  if (h->side_own) (void)hipStreamDestroy(h->side_own);
   delete h;
 }
 
@@ -341,6 +365,8 @@ extern "C" int64_t riab_streamer_info(RiabStreamer* h, int32_t which) {
     case 5: return h->side_rejected;
     case 6: return h->side_ref_ns;
     case 7: return h->late_calls;
+    case 8: return h->last_strict;
+    case 9: return h->side_own ? 1 : 0;
     default: return -1;
   }
 }
@@ -489,6 +515,33 @@ extern "C" int riab_watch_compare(const RiabWatch* watch, int32_t n) {
   return RIAB_OK;
 }
 
+// Everything riab_simulate may have to set up, done ahead of it (riab_hip.h "Two modes"): the strict mode's own second
+// stream, the screening of the default mode's second stream for `stream` (which synchronises it), the events a timed
+// call records.  Allocates and synchronises — that is its purpose; calls after it do neither.
+extern "C" int riab_streamer_warmup(RiabStreamer* h, riab_stream_t stream) {
+  if (!h) return RIAB_EINVAL;
+  hipStream_t main_s = (hipStream_t)stream;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(main_s, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) return RIAB_EUNSUPPORTED;
+  if (!h->side_own) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&h->side_own, hipStreamNonBlocking, greatest) != hipSuccess) {
+      h->side_own = nullptr;
+      return RIAB_EINVAL;
+    }
+  }
+  if (!h->t0 && (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess)) return RIAB_EINVAL;
+  while (h->pairs.size() < 64) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return RIAB_EINVAL;
+    h->pairs.push_back(e);
+  }
+  if (hipStreamSynchronize(main_s) != hipSuccess) return RIAB_EINVAL;
+  if (h->side_mode == 0 && !side_stream_for(h, main_s, true)) return RIAB_EINVAL;
+  return RIAB_OK;
+}
+
 extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream_t stream) {
   if (!h || !q || !q->env || !q->motion || !q->ctrl || !q->hist || q->n_pops < 0 || (q->n_pops > 0 && !q->pops) || q->T <= 0)
     return RIAB_EINVAL;
@@ -510,9 +563,19 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   a.ctrl = q->ctrl;
   hipStream_t main_s = (hipStream_t)stream;
   const float dt = (float)q->motion->dt;
-  const bool timing = q->timed_pop >= 0 && q->timed_pop < n_pops;
+  // Two modes (riab_hip.h).  STRICT — asked for (RIAB_STREAMER_OPT_STRICT) or imposed by a stream that is being captured —
+  // allocates nothing, synchronises nothing, queries nothing and touches nothing outside this streamer: its own second
+  // stream (riab_streamer_warmup), an opening kernel that re-bases the control words, the two streams joined by the
+  // streamer's events at both ends, the started gate always.  (The check comes first: a capturing stream must not be
+  // queried by anything below.)
+  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(main_s, &cap_status) == hipSuccess && cap_status != hipStreamCaptureStatusNone;
+  const bool strict = h->strict != 0 || capturing;
+  if (strict && !h->side_own) return RIAB_EUNSUPPORTED;  // (riab_streamer_warmup makes it; nothing was launched)
+  bool timing = q->timed_pop >= 0 && q->timed_pop < n_pops && !capturing;  // (no timing events inside a capture)
   h->timed = 0;
   h->n_pairs = 0;
+  h->last_strict = strict ? 1 : 0;
 
   h->last_form = RIAB_FORM_NONE;
   h->last_launches = 0;
@@ -538,7 +601,8 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
 
   // ---- which form of the rate stage; every argument check before the first launch ------------------------------------
   // ~0.3 us per poll: a generous second or two before a wait gives up (a healthy wait is tens of microseconds)
-  const uint32_t spin_limit = 1u << 20;
+  const uint32_t spin_limit = h->spin_limit ? h->spin_limit : 1u << 20;
+  auto gate_limit = [&](uint32_t dflt) { return h->spin_limit ? h->spin_limit : dflt; };
   std::vector<int32_t> sched;
   // `lead`: the population whose kernel follows the trajectory row by row (rate_kernel_gated: store-bound cells without
   // OU noise, whole 256-agent groups).  Alone it is the one-kernel form.  With other populations beside it, it runs
@@ -567,7 +631,9 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
       // (the lead's stores of a row against 1.5 trajectory steps: measured on this chip once an earlier call's stamps can
       // be read without waiting — the caller's stream is idle —, the MI355X constants until then: builtin_step_ns)
       if (lead >= 0) {
-        if (!h->calibrated && h->step_ns_cfg == 0 && hipStreamQuery((hipStream_t)stream) == hipSuccess) calibrate_from_stamps(h);
+        // (never in strict mode; and only when the earlier call ran on THIS stream: its idleness then says that call is over)
+        if (!strict && !h->calibrated && h->step_ns_cfg == 0 && h->side_main == main_s && hipStreamQuery(main_s) == hipSuccess)
+          calibrate_from_stamps(h);
         const double row_ns = (double)best / lead_mbps_now(h) * 1e3;  // bytes / (MB/s) = us; x 1e3 = ns
         // x 1.5: next to a kernel that saturates HBM the trajectory kernel's clock and its write-throughs slow down by that
         // much (cfg 2 / cfg 5: 0.85-1.1 us per step measured next to the stores against the formula's 1.35; cfg 3: 2.05
@@ -599,12 +665,15 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
     if (pure && h->gate_mode == RIAB_GATE_RESERVED)
       reservable = riab::launch_rate_stream(env, &pops[lead], q->hist, B, head, dt, q->seed, q->step0, q->agent_id0, q->ctrl,
                                             spin_limit, false, main_s, nullptr, nullptr, /*dry_run=*/true, true, 0u) == RIAB_OK;
+    // (a strict call creates nothing: it is timed with the events riab_streamer_warmup made, or not at all)
     if (pure && q->timing_mode == RIAB_TIMING_EVENTS && timing && !h->t0) {
-      if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess) return RIAB_EINVAL;
+      if (strict) timing = false;
+      else if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess) return RIAB_EINVAL;
     }
     if (timing && !pure) {
       const size_t need = 2 * (size_t)(1 + (T + rest_piece - 1) / rest_piece);
-      while (h->pairs.size() < need) {
+      if (strict && h->pairs.size() < need) timing = false;
+      while (timing && h->pairs.size() < need) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return RIAB_EINVAL;
         h->pairs.push_back(e);
@@ -613,7 +682,8 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   } else {
     sched = chunk_schedule(env, T);
     if (timing) {
-      while (h->pairs.size() < 2 * sched.size()) {
+      if (strict && h->pairs.size() < 2 * sched.size()) timing = false;
+      while (timing && h->pairs.size() < 2 * sched.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return RIAB_EINVAL;
         h->pairs.push_back(e);
@@ -625,18 +695,27 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   // It has to start after what the caller's stream holds (earlier calls' kernels wrote the state it reads).  When that
   // stream is idle — the case that matters for latency: one short call per synchronisation — there is nothing to wait
   // for and the launch goes out with no API call in front of it but the query; otherwise an event carries the order.
-  // (a stream that is being captured must not be queried — the query would invalidate the capture — and a run that
-  // hands work between two streams through words in memory is not something a graph can replay: refused, nothing launched)
-  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(main_s, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) return RIAB_EUNSUPPORTED;
-  const bool idle = hipStreamQuery(main_s) == hipSuccess;
+  const bool idle = strict ? false : hipStreamQuery(main_s) == hipSuccess;
   // (RIAB_STREAMER_OPT_SIDE_STREAM: 1 a stream at the default priority, 2 the caller's own stream — the two kernels then
   // run one after the other, which is what the RIAB_CTRL_SERIALISED diagnostic is tested with)
-  if (h->side_mode == 0 && (h->side_main != main_s || !h->side || (!h->side_screened && idle))) {
+  if (!strict && h->side_mode == 0 && (h->side_main != main_s || !h->side || (!h->side_screened && idle))) {
     if (!side_stream_for(h, main_s, idle)) return RIAB_EINVAL;
   }
-  const hipStream_t side_s = h->side_mode == 2 ? main_s : (h->side_mode == 1 && h->side_normal ? h->side_normal : h->side);
-  if (!idle && side_s != main_s) {
+  const hipStream_t side_s = strict ? h->side_own
+                                    : (h->side_mode == 2 ? main_s : (h->side_mode == 1 && h->side_normal ? h->side_normal : h->side));
+  const uint32_t n_traj = (uint32_t)((B + 63) / 64);
+  // The opening kernel: a strict call re-bases the announcement counter and this call's progress words on the device, so
+  // that a replay of the captured call finds what the first run found; once that has happened, the host's mirror of the
+  // counter means nothing any more and the next call of either mode re-bases as well.
+  const bool open = strict || h->resync;
+  if (open) {
+    rc = riab::launch_stream_open(q->ctrl, n_traj, (uint32_t)q->step0, main_s);
+    if (rc) return rc;
+    h->started_total = 0;
+    if (capturing) h->captured_once = true;
+    h->resync = strict || h->captured_once;   // (a default-mode call has re-based: its successors count on from here)
+  }
+  if ((!idle || open) && side_s != main_s) {
     hipError_t e = hipEventRecord(h->fork, main_s);
     if (e == hipSuccess) e = hipStreamWaitEvent(side_s, h->fork, 0);
     if (e != hipSuccess) return (int)e;
@@ -655,8 +734,7 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
     if (!late_noted && host_us() - t_traj_launched > 12.0) ++h->late_calls;
     late_noted = true;
   };
-  h->last_launches = 1;
-  const uint32_t n_traj = (uint32_t)((B + 63) / 64);
+  h->last_launches = open ? 2 : 1;
   h->started_total += n_traj;
   h->prev_ctrl = q->ctrl;
   h->prev_T = T;
@@ -683,13 +761,13 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
     const bool stamps = !events;
     // residency (riab_hip.h): the reserving shape of the row-following kernel needs no gate; everything else takes one —
     // unless the caller has said that it owns the device (RIAB_GATE_WHEN_BUSY) and its stream is idle
-    const bool quiet = idle && pure && monotonic && side_s != main_s;
+    const bool quiet = idle && !open && pure && monotonic && side_s != main_s;
     // (the reserving shape is only offered by kernels whose registers leave a trajectory workgroup room: launch_stream_cell)
     const bool reserve = quiet && h->gate_mode == RIAB_GATE_RESERVED && reservable;
     const bool gate = !(reserve || (quiet && h->gate_mode == RIAB_GATE_WHEN_BUSY)) && side_s != main_s;
     // (the started gate is one sleeping wave; it may have to sit out whatever runs in front of the trajectory kernel)
     if (gate) {
-      fail = riab::launch_stream_gate(q->ctrl, h->started_total, 0, 0, 1u << 24, true, 0u, main_s);
+      fail = riab::launch_stream_gate(q->ctrl, h->started_total, 0, 0, gate_limit(1u << 24), true, 0u, main_s);
       ++h->last_launches;
     }
     int n_timed = 0;
@@ -704,8 +782,8 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
     }
     for (int32_t t0 = head; t0 < T && !fail; t0 += tail_piece) {
       const int32_t tc = T - t0 < tail_piece ? T - t0 : tail_piece;
-      fail = riab::launch_stream_gate(q->ctrl, h->started_total, n_traj, (uint32_t)q->step0 + (uint32_t)(t0 + tc), 1u << 22,
-                                      false, 0u, main_s);
+      fail = riab::launch_stream_gate(q->ctrl, h->started_total, n_traj, (uint32_t)q->step0 + (uint32_t)(t0 + tc),
+                                      gate_limit(1u << 22), false, 0u, main_s);
       if (!fail) fail = launch_pop_rows(env, pops, lead, q->hist, B, t0, tc, dt, q->seed, q->step0, q->agent_id0, main_s);
       h->last_launches += 2;
     }
@@ -745,7 +823,7 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
       const int32_t tc = sched[k];
       // ~0.5 us per poll: seconds before a gate gives up (a healthy wait is one chunk of trajectory, < 1 ms)
       fail = riab::launch_stream_gate(q->ctrl, h->started_total, n_traj, (uint32_t)q->step0 + (uint32_t)(t0 + tc),
-                                      k == 0 ? 1u << 24 : 1u << 22, false,
+                                      gate_limit(k == 0 ? 1u << 24 : 1u << 22), false,
                                       (k == 0 && serial_rows) ? (uint32_t)q->step0 + (uint32_t)T : 0u, main_s);
       note_first_rate_launch();
       h->last_launches += 1 + n_pops;
@@ -773,7 +851,7 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   // ordered behind the trajectory kernel.  (After an abort on an idle stream the host layer synchronises the device
   // before it clears the flags: Agent._check_pipeline.)
   hipError_t e = hipSuccess;
-  if ((!state_published || fail || !idle) && side_s != main_s) {
+  if ((!state_published || fail || !idle || open) && side_s != main_s) {
     e = hipEventRecord(h->join, side_s);
     if (e == hipSuccess) e = hipStreamWaitEvent(main_s, h->join, 0);
   }

@@ -522,22 +522,169 @@ def test_form_selection_follows_the_measured_step_and_store_rates(riab):
 
 
 
-def test_aborted_pipeline_is_reported_on_the_next_host_read(riab):
-    """A wait that gave up (here: the abort / timeout words set by hand) must not pass silently: the first host read
-    after the run raises, the control words are cleared and the next run is clean."""
+def test_aborted_pipeline_flags_are_settled_on_the_next_host_read(riab):
+    """A wait that gave up (here: the abort / timeout words set by hand after complete runs) must not pass silently:
+    the first host read settles it — the rates of the runs since the last check are recomputed from the complete
+    trajectory (a warning, diagnostics["pipeline_recovered"]) — clears the control words, and the next run is clean.
+    What cannot be recomputed still raises: populations with additive noise."""
     env, ag, pop = _world(riab, 1024, _pc(64, save_spikes=False), None)
     ag.simulate(8)
     _ = ag.pos                                   # a clean run: reading is fine
     ag.simulate(8)
+    torch.cuda.synchronize()
+    before = pop.get_history_tensors()[0].clone()
     L = riab._lib
+    ag.simulate(8)
     ag._ctrl[L.CTRL_TIMEOUTS] = 3
+    ag._ctrl[L.CTRL_ABORT] = 1
+    with pytest.warns(RuntimeWarning, match="recomputed"):
+        _ = ag.history["pos"]
+    d = ag.diagnostics
+    assert d["pipeline_timeouts"] == 0 and d["pipeline_recovered"] == 1 and d["pipeline_timeouts_recovered"] == 3
+    after = pop.get_history_tensors()[0]
+    assert torch.equal(after[:16], before)       # (the recomputation wrote the same rows: nothing else was touched)
+    ag.simulate(8)
+    assert np.isfinite(np.asarray(ag.pos)).all() and np.isfinite(pop.firingrate).all()
+    assert len(ag.history["t"]) == 32
+    # additive noise: the noise state has advanced with the aborted run — not recomputable
+    env, ag, pop = _world(riab, 256, _pc(16, noise_std=0.1), None)
+    ag.simulate(8)
+    ag._ctrl[L.CTRL_TIMEOUTS] = 1
     ag._ctrl[L.CTRL_ABORT] = 1
     with pytest.raises(L.RiabError, match="aborted"):
         _ = ag.history["pos"]
-    assert ag.diagnostics["pipeline_timeouts"] == 0
     ag.simulate(8)
-    assert np.isfinite(np.asarray(ag.pos)).all() and np.isfinite(pop.firingrate).all()
-    assert len(ag.history["t"]) == 24
+    assert ag.diagnostics["pipeline_timeouts"] == 0
+
+
+@pytest.mark.parametrize("pops", ["one_kernel", "chunks"])
+def test_a_rate_stage_that_gives_up_is_recovered_bit_for_bit(riab, pops):
+    """a REAL abort — the waits of the rate stage are given one poll (RIAB_STREAMER_OPT_SPIN_LIMIT), so its
+    first waves give up before the trajectory kernel has published anything, set the abort flag, and every later wait
+    of that call and of the next call returns at once: rate rows unwritten or computed from stale positions.  The
+    trajectory kernel waits for nobody outside its workgroup and finishes.  The next host read recomputes both runs'
+    rates with the stream-ordered kernels: every row of every population equal, bit for bit, to the undisturbed
+    pipeline's."""
+    L = riab._lib
+
+    def world():
+        np.random.seed(17)
+        env = riab.Environment({"walls": [[[0.5, 0.0], [0.5, 0.4]]]} if pops == "chunks" else {})
+        ag = riab.Agent(env, {"n_agents": 1024, "dt": 0.01, "seed": 5})
+        np.random.seed(18)
+        if pops == "one_kernel":
+            ps = [riab.PlaceCells(ag, {"n": 96, "wall_geometry": "euclidean", "max_fr": 30})]
+        else:
+            ps = [riab.PlaceCells(ag, {"n": 40, "wall_geometry": "line_of_sight"}), riab.BoundaryVectorCells(ag, {"n": 12}),
+                  riab.GridCells(ag, {"n": 24, "save_spikes": True, "max_fr": 20})]
+            ps.append(riab.FeedForwardLayer(ag, {"n": 6, "input_layers": [ps[0], ps[2]],
+                                                 "activation_function": {"activation": "tanh", "gain": 1.0, "threshold": 0.0}}))
+        return ag, ps
+
+    def rows(ag, ps):
+        torch.cuda.synchronize()
+        out = [ag.get_history_tensor().cpu()]
+        for p in ps:
+            fr, sp = p.get_history_tensors()
+            out += [fr.cpu(), sp.cpu()]
+        return out + [ag.state_tensor.cpu()]
+
+    ag, ps = world()
+    for n in (16, 40, 24, 8):
+        ag.simulate(n)
+    ref = rows(ag, ps)
+    assert ag.diagnostics["pipeline_timeouts"] == 0 and ag.diagnostics["pipeline_recovered"] == 0
+
+    ag, ps = world()
+    ag.simulate(16)
+    _ = ag.pos
+    L.check(L.lib.riab_streamer_configure(ag._streamer, L.STREAMER_OPT_SPIN_LIMIT, 1), "configure")
+    ag.simulate(40)
+    ag.simulate(24)
+    L.check(L.lib.riab_streamer_configure(ag._streamer, L.STREAMER_OPT_SPIN_LIMIT, 0), "configure")
+    torch.cuda.synchronize()
+    assert int(ag._ctrl[L.CTRL_ABORT].item()) == 1 and int(ag._ctrl[L.CTRL_TIMEOUTS].item()) >= 1
+    with pytest.warns(RuntimeWarning, match="recomputed"):
+        _ = ps[0].history["firingrate"]
+    d = ag.diagnostics
+    assert d["pipeline_recovered"] == 2 and d["pipeline_timeouts"] == 0 and d["pipeline_timeouts_recovered"] >= 1
+    ag.simulate(8)                                # the pipeline itself again, clean
+    got = rows(ag, ps)
+    assert ag.diagnostics["pipeline_timeouts"] == 0
+    for x, y in zip(ref, got):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("pops", ["one_kernel", "populations"])
+def test_strict_mode_equals_default_mode_and_is_capturable(riab, pops):
+    """the b2-conforming mode of riab_simulate (include/riab_hip.h "Two modes").  Same rows as the
+    default mode bit for bit; four launches for the one-kernel form (opening kernel, trajectory, started gate, rates);
+    and a call on a stream that is being captured is strict by itself: Agent.simulate() inside torch.cuda.graph, the
+    graph replayed a hundred times, leaves — every time — the rows of the uncaptured call."""
+    def world():
+        np.random.seed(23)
+        ag = riab.Agent(riab.Environment(), {"n_agents": 1024, "dt": 0.01, "seed": 9})
+        np.random.seed(24)
+        ps = [riab.PlaceCells(ag, {"n": 128, "wall_geometry": "euclidean", "save_spikes": pops != "one_kernel", "max_fr": 20})]
+        if pops != "one_kernel":
+            ps += [riab.HeadDirectionCells(ag, {"n": 12}), riab.BoundaryVectorCells(ag, {"n": 8})]
+        return ag, ps
+
+    def rows(ag, ps):
+        torch.cuda.synchronize()
+        out = [ag.get_history_tensor().cpu(), ag.state_tensor.cpu()]
+        for p in ps:
+            fr, sp = p.get_history_tensors()
+            out += [fr.cpu(), sp.cpu()]
+        return out
+
+    ag, ps = world()
+    for n in (12, 30, 12):
+        ag.simulate(n)
+    ref = rows(ag, ps)
+    assert not ag.pipeline_info()["strict_last_call"]
+
+    ag, ps = world()
+    ag.pipeline_mode(strict=True)
+    ag.simulate(12)
+    info = ag.pipeline_info()
+    assert info["strict_last_call"] and (pops != "one_kernel" or info["launches_last_call"] == 4), info
+    ag.pipeline_mode(strict=False)
+    ag.simulate(30)                               # default mode after a strict call: re-bases once, then counts on
+    ag.pipeline_mode(strict=True)
+    ag.simulate(12)
+    got = rows(ag, ps)
+    assert ag.diagnostics["pipeline_timeouts"] == 0
+    for x, y in zip(ref, got):
+        assert torch.equal(x, y)
+
+    # captured: the same 12-step call, replayed
+    ag, ps = world()
+    ag.simulate(12)
+    ag.simulate(30)
+    torch.cuda.synchronize()
+    state0 = ag.state_tensor.clone()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            ag.simulate(12)
+    torch.cuda.synchronize()
+    assert ag.pipeline_info()["strict_last_call"]
+    g.replay()                                    # (a capture records, it does not run: this is the call's first run)
+    first = rows(ag, ps)
+    for x, y in zip(ref, first):                  # ... the third call of `ref`
+        assert torch.equal(x, y)
+    for k in range(100):
+        ag.state_tensor.copy_(state0)             # (a replay runs the same steps again: from the same state)
+        g.replay()
+    again = rows(ag, ps)
+    assert ag.diagnostics["pipeline_timeouts"] == 0
+    for x, y in zip(ref, again):
+        assert torch.equal(x, y)
+    ag.simulate(6)                                # default mode after a captured call: re-bases every time from now on
+    torch.cuda.synchronize()
+    assert ag.diagnostics["pipeline_timeouts"] == 0 and len(ag.history["t"]) == 60
 
 
 def test_fused_falls_back_for_uncovered_populations(riab):
