@@ -126,12 +126,54 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cores():
+    """(cores this process may actually use, what limits them): the affinity mask and the cgroup's CPU quota — a
+    container with `cpu.max = 1000000 100000` runs ten cores' worth however many the host shows."""
+    info = {"os_cpu_count": os.cpu_count()}
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    info["affinity"] = aff
+    quota = None
+    for path, v1 in (("/sys/fs/cgroup/cpu.max", False), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", True)):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if v1:
+                q = int(txt[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    per = int(f.read().split()[0])
+                quota = q / per if q > 0 else None
+                info["cgroup_cpu"] = f"cfs_quota_us {q} / cfs_period_us {per}"
+            else:
+                info["cgroup_cpu_max"] = " ".join(txt)
+                quota = int(txt[0]) / int(txt[1]) if txt[0] != "max" else None
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    try:
+        info["loadavg_1min"] = os.getloadavg()[0]
+    except OSError:
+        pass
+    n = aff if quota is None else max(1, min(aff, int(quota)))
+    info["cgroup_quota_cores"] = quota
+    info["usable"] = n
+    return n, info
+
+
 def cpu_baseline(cfg, seconds=8.0):
     """The float64 NumPy oracle (oracle/riab_oracle.py) of the same path on the host cores, SURVEY.md §8(d)(ii):
-    one worker process per core (`oracle/cpu_bench.py`, single-threaded NumPy), each stepping its share of the
-    GPU batch (agents / cores, at least 16) for `seconds` seconds; the rates add up.  The one-core figure on a
-    256-agent batch (round 1's number) is kept beside it."""
-    cores = len(_ALL_CPUS) if _ALL_CPUS else (os.cpu_count() or 1)
+    one single-threaded worker process (`oracle/cpu_bench.py`) per USABLE core — the affinity mask capped by the
+    cgroup's CPU quota —, each stepping its share of the GPU batch (agents / workers, at least 16) for `seconds`
+    seconds; the rates add up.  Every worker reports its CPU seconds next to its wall seconds: on a shared host the sum
+    is what the box gave this job, and `workers` says how evenly.  The one-core figure on a 256-agent batch (round 1's
+    number) is kept beside it."""
+    all_cpus = _ALL_CPUS or os.sched_getaffinity(0)   # (the workers run on every core, not on the rank's NUMA share)
+    usable, host = usable_cores()
+    quota = host["cgroup_quota_cores"]
+    cores = max(1, min(len(all_cpus), int(quota))) if quota else len(all_cpus)
+    host["workers_started"] = cores
     B = cfg["agents"]
     per = max(16, B // cores)
     n = cfg["place"]
@@ -139,8 +181,6 @@ def cpu_baseline(cfg, seconds=8.0):
     base = [sys.executable, "-m", "oracle.cpu_bench", "--cells", str(n), "--walls-json", json.dumps(cfg["walls"])]
     if cfg["spikes"]:
         base.append("--spikes")
-
-    all_cpus = _ALL_CPUS or os.sched_getaffinity(0)   # (the workers run on every core, not on the rank's NUMA share)
 
     def launch(agents, secs, seed):
         p = subprocess.Popen(base + ["--agents", str(agents), "--seconds", str(secs), "--seed", str(seed)],
@@ -152,27 +192,44 @@ def cpu_baseline(cfg, seconds=8.0):
         return p
 
     def collect(procs):
-        total, longest, ok = 0.0, 0.0, 0
+        rates, longest, cpu_frac = [], 0.0, []
         for p in procs:
             out, _ = p.communicate()
             try:
-                steps, el = out.split()
-                total += float(steps) / float(el)
-                longest = max(longest, float(el))
-                ok += 1
-            except ValueError:
+                parts = out.split()
+                steps, el = float(parts[0]), float(parts[1])
+                rates.append(steps / el)
+                if len(parts) > 2:
+                    cpu_frac.append(float(parts[2]) / el)
+                longest = max(longest, el)
+            except (ValueError, IndexError):
                 pass
-        return total, longest, ok
+        return rates, longest, cpu_frac
 
     t0 = time.perf_counter()
-    one_rate, one_el, _ = collect([launch(256, min(seconds, 4.0), 0)])
-    all_rate, all_el, ok = collect([launch(per, seconds, 1 + i) for i in range(cores)])
+    one_rates, one_el, _ = collect([launch(256, min(seconds, 4.0), 0)])
+    one_per, _e, _ = collect([launch(per, min(seconds, 3.0), 0)])     # one worker of the fleet's size, alone on the box
+    rates, all_el, cpu_frac = collect([launch(per, seconds, 1 + i) for i in range(cores)])
     wall = time.perf_counter() - t0
-    return {"value": all_rate, "unit": "agent-steps/s", "cores": ok, "kind": "port",
+    ok = len(rates)
+    rs, cf = sorted(rates), sorted(cpu_frac)
+    med = lambda v: v[len(v) // 2] if v else None   # noqa: E731
+    alone = one_per[0] if one_per else None
+    total = sum(rates)
+    return {"value": total, "unit": "agent-steps/s", "cores": ok, "kind": "port",
             "cpu_model": cpu_model(),
-            "sample": f"{ok} single-threaded worker processes (one per host core) x {per} agents x ~{all_el:.1f} s of "
+            "sample": f"{ok} single-threaded worker processes (one per usable host core) x {per} agents x ~{all_el:.1f} s of "
                       f"Agent.update + PlaceCells({n}).update, float64 NumPy oracle; {wall:.1f} s wall in total",
-            "one_core": {"value": one_rate, "agents": 256, "seconds": round(one_el, 2)}}
+            "host": host,
+            "workers": {"rate_min": rs[0] if rs else None, "rate_median": med(rs), "rate_max": rs[-1] if rs else None,
+                        "one_such_worker_alone": alone,
+                        "cores_worth": round(total / alone, 1) if alone else None,
+                        "cpu_seconds_per_wall_second_median": round(med(cf), 3) if cf else None,
+                        "cpu_seconds_per_wall_second_sum": round(sum(cf), 1) if cf else None,
+                        "note": "cores_worth = the fleet's rate / one such worker alone on the box: how many cores the host "
+                                "actually delivered (shared hosts, memory bandwidth, SMT siblings); "
+                                "cpu_seconds_per_wall_second = what the scheduler gave a worker"},
+            "one_core": {"value": one_rates[0] if one_rates else None, "agents": 256, "seconds": round(one_el, 2)}}
 
 
 def _parse_cpulist(text):
@@ -398,18 +455,23 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         ag._profile_hook = hook
 
     elapsed, kernel_ms, kernel_units = [], [], []
+    host_split = []   # per repeat (us): Python in front of the native call, inside it, from its return to the synchronised end
     for _r in range(R):
         fresh_history(K)
         prepare()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
+        ag._host_clock = [] if fused_mode else None
         t0 = time.perf_counter()
         run(K)
         torch.cuda.synchronize()
         t1 = time.perf_counter()  # this rank's K steps are done; the MAX over ranks is taken per repeat below,
         barrier()                 # so the closing barrier (an RCCL all-reduce, tens of us) stays outside the interval
         elapsed.append(t1 - t0)
+        hc, ag._host_clock = ag._host_clock, None
+        if hc and len(hc) == 1:   # (the short road of simulate(): one native call per region)
+            host_split.append(((hc[0][0] - t0) * 1e6, (hc[0][1] - hc[0][0]) * 1e6, (t1 - hc[0][1]) * 1e6))
         if fused_mode or native_mode:
             kernel_ms.append(ag.last_rate_kernel_ms())
             kernel_units.append(getattr(ag, "_last_fused_units", B * K))  # (rings: the last ring-length piece of the run)
@@ -430,6 +492,11 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         ag._time_rate_kernel = True
     el = torch.tensor(elapsed, dtype=torch.float64)
     per_rank = None
+    med3 = None
+    if host_split:
+        cols = list(zip(*host_split))
+        med3 = [round(sorted(c)[len(c) // 2], 2) for c in cols]
+    my_diag = dict(ag.diagnostics)
     if dist is not None:
         el = el.to("cpu" if ctrl_on_cpu else "cuda")
         # every rank's own regions (min / median / max): `value` is set by the slowest rank of every repeat, so a slow
@@ -441,6 +508,16 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
             xs = sorted(x.cpu().tolist())
             per_rank.append({"rank": r, "min": round(xs[0] * 1e3, 5), "median": round(xs[len(xs) // 2] * 1e3, 5),
                              "max": round(xs[-1] * 1e3, 5)})
+        # ... and where each rank's HOST spent its region (a slow rank is then attributable: a late Python, a slow
+        # launch path, or a late wake-up after the kernels) + its own pipeline diagnostics
+        extra = [None] * world
+        dist.all_gather_object(extra, {"host_us": med3, "diagnostics": my_diag})
+        for r, x in enumerate(extra):
+            if x["host_us"]:
+                per_rank[r]["host_us"] = dict(zip(("python_before_native_call", "in_native_call", "call_return_to_synchronised"),
+                                                  x["host_us"]))
+            per_rank[r]["pipeline_serialised"] = x["diagnostics"].get("pipeline_serialised")
+            per_rank[r]["pipeline_timeouts"] = x["diagnostics"].get("pipeline_timeouts")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)  # per repeat: the slowest rank
         el = el.cpu()
     el_sorted = sorted(el.tolist())
@@ -625,6 +702,8 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
                                 "note": "every repeat runs the full K steps into fresh history rows; value = total "
                                         "agent-steps of one repeat / the median repeat (max over ranks per repeat)"},
             "timed_region_ms_per_rank": per_rank,
+            "timed_region_host_us": (dict(zip(("python_before_native_call", "in_native_call", "call_return_to_synchronised"), med3))
+                                     if med3 else None),
             "value_best_repeat": round(total_units / el_sorted[0], 1),
             "hbm_GBps_whole_path": round(value / world * bpu / 1e9, 1),
             "frac_whole_path": round(value / world * bpu / 1e9 / HBM_PEAK_GBS, 4),
@@ -758,19 +837,24 @@ def main():
     # A secondary run must never cost the headline line: every rank arms a watchdog that — should the block not finish
     # (one rank failing alone leaves the others in a barrier) — lets rank 0 print the line with what it has and ends the
     # process with the launcher's success code.
+    import threading
     state = {"running": None, "done": False}
+    line_lock = threading.Lock()   # (the line is printed exactly once: by the watchdog or by the main thread)
 
     def bail():
-        if state["done"]:
-            return
-        if rank == 0 and out is not None:
-            if secondary:
-                out["secondary"] = secondary
-            out["secondary_error"] = f"watchdog: the secondary run '{state['running']}' did not finish in {args.secondary_timeout} s"
-            print(json.dumps(out), flush=True)
+        with line_lock:
+            if state["done"]:
+                return
+            state["done"] = True
+            if rank == 0 and out is not None:
+                if secondary:
+                    out["secondary"] = dict(secondary)
+                out["secondary_error"] = f"watchdog: the secondary run '{state['running']}' did not finish in {args.secondary_timeout} s"
+                print(json.dumps(out), flush=True)
+        # (the headline line is out; a rank stuck in a collective cannot be torn down cleanly.  Exit code 0 keeps the
+        # launcher from discarding that line; the line itself carries `secondary_error`)
         os._exit(0)
 
-    import threading
     dog = threading.Timer(args.secondary_timeout, bail)
     dog.daemon = True
     sec_steps = 256 if share else SECONDARY_STEPS   # (the test hook: N ranks' histories on ONE GPU)
@@ -817,11 +901,20 @@ def main():
                               "diagnostics": o.get("diagnostics"),
                               "wall_s": round(time.perf_counter() - t0, 2)}
         args.no_history = saved
-    state["done"] = True
+    with line_lock:
+        if state["done"]:      # (the watchdog has printed the line and is ending the process)
+            return
+        state["done"] = True
     dog.cancel()
     if rank == 0:
         if secondary:
             out["secondary"] = secondary
+            t1024 = secondary.get("cfg2_T1024")
+            if t1024 and "value" in t1024:
+                # the same configuration at SURVEY 8(d)'s length, where 36 us of host time per region are 1 % instead of
+                # 45 %: the figure the >= 7x-at-8-GPUs clause is ALSO read from
+                out["value_T1024"] = t1024["value"]
+                out["frac_whole_path_T1024"] = t1024.get("frac_whole_path")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)

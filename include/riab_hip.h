@@ -661,8 +661,9 @@ double riab_plan_task_clock(const RiabPlan* plan);
  *    row-following kernel of one population, that kernel is launched as workgroups of TWELVE waves, three per SIMD.
  *    Two of them fit a compute unit, a third does not (8 wave slots per SIMD): on EVERY compute unit one wave slot per
  *    SIMD stays free whatever the rate kernel does, and wave slots are the only resource the two kernels compete for
- *    (the rate kernel holds 24 registers per lane and no LDS; a trajectory workgroup needs one slot per SIMD, 232
- *    registers, 80 KB of LDS).  The trajectory workgroups can therefore always be placed: residency by construction,
+ *    (the euclidean / periodic place, grid and head-direction kernels hold 32-40 registers per lane and no LDS — asked
+ *    of the code object, hipFuncGetAttributes: a kernel with more than 48 registers or with LDS of its own is refused
+ *    the shape and takes the gate; a trajectory workgroup needs one slot per SIMD, 224 registers, 80 KB of LDS).  The trajectory workgroups can therefore always be placed: residency by construction,
  *    two launches per call.  (Otherwise, RIAB_GATE_RESERVED behaves as RIAB_GATE_ALWAYS.)
  *  - RIAB_GATE_ALWAYS: a one-wave gate kernel in front of the rate stage (four-wave workgroups, 8 waves per SIMD)
  *    holds it back until every trajectory workgroup of this launch has announced itself in ctrl[RIAB_CTRL_STARTED]:

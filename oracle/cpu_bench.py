@@ -4,7 +4,7 @@ float64 NumPy restatement of the path, never imported by the product).
     python -m oracle.cpu_bench --agents 16 --cells 1024 --seconds 8 [--walls-json ...] [--spikes]
 
 steps `agents` agents (Agent.update + PlaceCells.update, the cfg-2 shape of SURVEY.md §8(d)) for about `seconds`
-seconds on ONE core and prints `agent_steps seconds`.  bench.py starts one such process per host core and sums the
+seconds on ONE core and prints `agent_steps wall_seconds cpu_seconds`.  bench.py starts one such process per host core and sums the
 rates; each process pins BLAS/OpenMP to a single thread."""
 import os
 
@@ -50,5 +50,7 @@ if __name__ == "__main__":
     ap.add_argument("--spikes", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
+    c0 = time.process_time()
     n, el = run(a.agents, a.cells, a.seconds, json.loads(a.walls_json), a.spikes, a.seed)
-    print(n, el, flush=True)
+    # (agent-steps, wall seconds, CPU seconds of this process: CPU / wall well below 1 = the worker did not have a core)
+    print(n, el, time.process_time() - c0, flush=True)

@@ -43,6 +43,7 @@ _env_fast = operator.attrgetter(*_ENV_FAST_ATTRS)
 _ENV_RAW = getattr(os.environ, "_data", None)   # (os.environ's own mapping: bytes keys on POSIX; None elsewhere)
 _dispatch_depth = torch._C._len_torch_dispatch_stack
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+from time import perf_counter as _perf_counter  # noqa: E402
 
 
 class Agent:
@@ -129,6 +130,7 @@ class Agent:
         self._run_cache = None  # (population structs, their array, the RiabSimulate argument block, key) of the last call
         self._ctrl = None       # its control words on the device
         self._pipeline_unchecked = False
+        self._host_clock = None       # a list: _simulate_repeat appends (time before, time after) its native call
         self._unchecked_runs = []     # native simulate() calls since the last pipeline check: what a recovery recomputes
         self._unchecked_lost = False  # ... more of them than are kept
         self._recovered_runs = 0      # diagnostics["pipeline_recovered"]
@@ -949,7 +951,12 @@ class Agent:
         run.step0, run.T = self._step_index, n_steps
         run.hist = traj_c.data_ptr() + traj_s * (_L.HIST_ROWS * Bp * 4)
         stream = _L.C.c_void_p(_raw_stream(self._device_index)) if _raw_stream is not None else _L.current_stream()
+        hc = self._host_clock   # (bench.py: where a short region's host time goes — None unless asked for)
+        if hc is not None:
+            t_b = _perf_counter()
         rc = _L.lib.riab_simulate(self._streamer, sn["byref"], stream)
+        if hc is not None:
+            hc.append((t_b, _perf_counter()))
         if rc:
             self._snap = None
             if rc == _L.EUNSUPPORTED or rc == _L.ECHANGED:   # (nothing was launched: give the rows back, the general road decides)

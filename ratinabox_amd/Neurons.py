@@ -908,7 +908,7 @@ class FieldOfViewBVCs(BoundaryVectorCells):
         "spatial_resolution": 0.02,
         "cell_arrangement": "diverging_manifold",
         "beta": 5,
-        "color": "darkgrey",
+        "color": [0.3, 0.3, 0.3, 1],   # (reference Neurons.py:1869)
     }
 
     def __init__(self, Agent, params={}):

@@ -626,6 +626,9 @@ static int launch_stream_cell(const RateArgs& a, const Cell& cell, const StreamA
       const void* f = spikes ? (lng ? (const void*)rate_kernel_gated<Cell, 1, CPB, true, 12> : (const void*)rate_kernel_gated<Cell, 1, CPB, false, 12>)
                              : (lng ? (const void*)rate_kernel_gated<Cell, 0, CPB, true, 12> : (const void*)rate_kernel_gated<Cell, 0, CPB, false, 12>);
       r = (hipFuncGetAttributes(&attr, f) == hipSuccess && attr.numRegs > 0) ? attr.numRegs : 1 << 20;
+      // (... and LDS: two of these workgroups next to a trajectory workgroup's 80 KB must fit the compute unit's 160 KB; the
+      // kernels that are offered the shape declare 8 bytes — anything beyond a few KB is refused like too many registers)
+      if (r < (1 << 20) && 2 * (int64_t)attr.sharedSizeBytes + 81920 > 160 * 1024) r = 1 << 20;
       (void)hipGetLastError();
     }
     // (six waves of this kernel and one of the trajectory kernel on a SIMD: 6 x r + its registers <= 512; with the

@@ -731,7 +731,9 @@ extern "C" int riab_simulate(RiabStreamer* h, const RiabSimulate* q, riab_stream
   const double t_traj_launched = host_us();
   bool late_noted = false;
   auto note_first_rate_launch = [&]() {   // (after the first launch of the rate stage has returned)
-    if (!late_noted && host_us() - t_traj_launched > 12.0) ++h->late_calls;
+    // (only calls that CAN be counted as serialised — eight rows or more — are counted as late: the two counts are
+    // subtracted from each other)
+    if (!late_noted && T >= 8 && host_us() - t_traj_launched > 12.0) ++h->late_calls;
     late_noted = true;
   };
   h->last_launches = open ? 2 : 1;

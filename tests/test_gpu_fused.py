@@ -800,6 +800,14 @@ def test_bench_launches_its_own_ranks(riab):
         if name in closed and name != "cfg2_closed_loop_task":   # the one-launch step served the loop
             assert blk["plan"]["fused_steps"] > 0, blk["plan"]
         assert 0 < blk["frac_whole_path"] < 1 and blk["roofline"]["frac"] > 0
+    # the driver's region length with two ranks on the chip: neither rank's pipeline serialised or timed out, and every
+    # rank says where its host spent the region
+    short = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-secondary"],
+                   {"RIAB_BENCH_SHARE_GPU": "1"}, timeout=400)
+    for x in short["timed_region_ms_per_rank"]:
+        assert x["pipeline_timeouts"] == 0 and x["pipeline_serialised"] <= 1, x   # (a lone count is a hiccup)
+        assert set(x["host_us"]) == {"python_before_native_call", "in_native_call", "call_return_to_synchronised"}
+        assert 0 < x["host_us"]["in_native_call"] < 1000
     strong = _bench(["--gpus", "2", "--strong", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"],
                     {"RIAB_BENCH_SHARE_GPU": "1"}, timeout=400)
     assert strong["scaling"] == "strong" and strong["config"]["agents_per_gpu"] == 2048 and strong["n_gpus"] == 2
