@@ -3,7 +3,13 @@
 parity mode (the reference's replacement positions handed in) and in production mode (Philox rejection sampling,
 bit-exact against the oracle's restatement), PlaceCells under the wall geometries of a polygonal room.  Single steps
 and rollouts in an L-shaped room and in a box with two holes run with every other motion golden in
-tests/test_gpu_parity.py (motion_lroom_dt20ms.npz, motion_box_holes_dt20ms.npz)."""
+tests/test_gpu_parity.py (motion_lroom_dt20ms.npz, motion_box_holes_dt20ms.npz).
+
+STAND-IN: the reference decides "inside the environment" with shapely, which this image does not have; the goldens used
+here (polygon.npz, motion_lroom_*, motion_box_holes_*) were generated with the build's own strict point-in-polygon
+(oracle/ref_shims/shapely: even-odd crossings + an exact on-edge test).  For rectangles — all SURVEY 8 asks — strict
+interior is unambiguous; for points exactly ON a polygon's or hole's edge these fixtures pin the shim's semantics, not
+shapely's own."""
 import numpy as np
 import pytest
 import torch

@@ -6,7 +6,12 @@ and against the oracle's TaskLane restatement.
 Tolerances: positions 1e-9 relative (float64 motion); reward totals bit-exact (float64 recursions
 with the reference's operation order) except the "exponential" decay preset, which goes through the
 device exp (<= 1 ulp: 1e-14 relative); terminal flags, goal counts, reward-cache sizes, episode
-tables: exact."""
+tables: exact.
+
+STAND-INS: the reference's TaskEnvironment imports gymnasium and pettingzoo, which this image does not have; the
+task_*.npz goldens were generated with interface stubs for both (oracle/ref_shims/: `spaces.Box` as a shape holder,
+`ParallelEnv` as an empty base class).  The reference uses them to describe spaces and as a marker class only: no
+arithmetic of the recorded runs goes through them."""
 import numpy as np
 import pytest
 import torch
