@@ -647,8 +647,17 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         step_s = med / K
         ach = unit_bytes * B / step_s / 1e9
         one = bool(plan_info and plan_info["fused_steps"] > 0)
+        traffic = traffic_from = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if one and type(dominant).__name__ == "PlaceCells" and not cfg["spikes"] and os.path.exists(tpath):
+            with open(tpath) as f:
+                entry = json.load(f).get("kernels", {}).get("step1_kernel")
+            if entry:   # (counters are not collected in this run: the committed PMC passes' per-unit figure x this run's units)
+                traffic = round(entry["hbm_bytes_per_unit"] * B)
+                traffic_from = (f"profiles/pmc_traffic.json[step1_kernel]: {entry['hbm_bytes_per_unit']:.1f} B per agent-step "
+                                "(rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of `bench.py --plan`) x the units of one launch")
         roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from": traffic_from,
                     "kernel": ("step1_kernel<%s> (Agent.update + Neurons.update in one launch)" % type(dominant).__name__) if one
                     else "agent_step_kernel + rate_kernel_wide<%s> per step" % type(dominant).__name__,
                     "launches": None, "avg_launch_ms": round(step_s * 1e3, 6), "units_per_launch": B,
