@@ -464,7 +464,10 @@ int riab_plan_step_population(RiabPlan* plan, int32_t index, riab_stream_t strea
  *               not run yet), then float64 [RIAB_MAX_WALLS][6]: the wall table as the kernels keep it (start, direction,
  *               1 / |direction|^2, 1 / |direction|) and one word (+ padding) saying whether the first four walls are the
  *               edges of a solid rectangular room (the motion step's box fast path), both prepared by the plan's first
- *               one-launch step (a one-wave kernel in front of it) and again when the repel distance changes.
+ *               one-launch step (a one-wave kernel in front of it) and again when the repel distance changes; then
+ *               RIAB_STEP1_MAIL_STRIDE words per segment for a plan with a task attached: what the segment's writer
+ *               tells its other workgroups about this step's resets (which of its agents a reset moved, and where to, as
+ *               the history row keeps positions).
  * What is fused: plain motion steps (Philox noise, drift or not; no forced trajectory, no task) of whole 256-agent
  * segments, with the plan's LARGEST population among PlaceCells (euclidean geometry, not one_hot), GridCells and
  * HeadDirectionCells without additive noise; the other populations follow as their own kernels in list order, as
@@ -478,7 +481,9 @@ int riab_plan_step_population(RiabPlan* plan, int32_t index, riab_stream_t strea
 #define RIAB_STEP1_SYNC_TAIL 16
 #define RIAB_STEP1_SYNC_TIMEOUTS 0
 #define RIAB_STEP1_SYNC_WALLS_AT(B) ((((B) + 255) / 256) * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TAIL)
-#define RIAB_STEP1_SYNC_WORDS(B) (RIAB_STEP1_SYNC_WALLS_AT(B) + 12 * RIAB_MAX_WALLS + 4)
+#define RIAB_STEP1_SYNC_MAIL_AT(B) (RIAB_STEP1_SYNC_WALLS_AT(B) + 12 * RIAB_MAX_WALLS + 4)
+#define RIAB_STEP1_MAIL_STRIDE 1056  /* per segment, 8-byte entries (epoch << 32 | value): (at 0) 8 verdicts = halves of 4 lane masks, (at 32) x[256], y[256] */
+#define RIAB_STEP1_SYNC_WORDS(B) (RIAB_STEP1_SYNC_MAIL_AT(B) + (((B) + 255) / 256) * RIAB_STEP1_MAIL_STRIDE)
 int riab_plan_set_fused(RiabPlan* plan, uint32_t* sync_words, int64_t n_words);
 int64_t riab_plan_info(const RiabPlan* plan, int32_t which);
 

@@ -119,6 +119,7 @@ CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_SERIALISED, CTRL_STAMPS, CTRL_TRAJ
 
 
 STEP1_SYNC_STRIDE, STEP1_SYNC_TAIL, STEP1_SYNC_TIMEOUTS = 64, 16, 0   # riab_hip.h RIAB_STEP1_SYNC_*
+STEP1_MAIL_STRIDE = 1056                                                # riab_hip.h RIAB_STEP1_MAIL_STRIDE
 
 
 def step1_sync_tail(B):
@@ -129,7 +130,7 @@ def step1_sync_tail(B):
 def step1_sync_words(B):
     """RIAB_STEP1_SYNC_WORDS(B): arrival words, counters and the prepared wall table, for B agents."""
     segs = (int(B) + 255) // 256
-    return segs * STEP1_SYNC_STRIDE + STEP1_SYNC_TAIL + 12 * MAX_WALLS + 4
+    return segs * STEP1_SYNC_STRIDE + STEP1_SYNC_TAIL + 12 * MAX_WALLS + 4 + segs * STEP1_MAIL_STRIDE
 
 
 def ctrl_words(B):

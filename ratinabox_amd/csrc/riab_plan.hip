@@ -30,6 +30,12 @@ int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* 
 int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
 int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
                  uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, hipStream_t s);
+int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint64_t seed,
+                      uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, const RiabTask* task,
+                      double* task_state, int64_t task_B, double t_env, double* reward_out, uint8_t* terminal_out, int32_t* diag,
+                      bool auto_reset, int32_t n_select, int32_t ordered, uint64_t task_seed, uint64_t counter, int32_t teleport,
+                      double* ep_log, int64_t ep_log_cap, int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y,
+                      hipStream_t s);
 }  // namespace riab
 
 struct RiabPlan {
@@ -78,14 +84,17 @@ struct RiabPlan {
 };
 
 // the population the agent step is fused with: the store-bound one that writes most bytes per row (-1: none)
-static int plan_lead(RiabPlan* p) {
-  if (!p->sync_words || riab::g_options[RIAB_OPT_FUSED_STEP] == 0 || p->has_task || p->forced) return -1;
+// (a plan with a task: whole-plan steps only, motion + task fused (RIAB_OPT_FUSED_TASK), a lead without spikes)
+static int plan_lead(RiabPlan* p, bool whole_step = false) {
+  if (!p->sync_words || riab::g_options[RIAB_OPT_FUSED_STEP] == 0 || p->forced) return -1;
+  if (p->has_task && (!whole_step || riab::g_options[RIAB_OPT_FUSED_TASK] == 0)) return -1;
   if (p->lead == -2) {
     int best = -1;
     int64_t best_bytes = 0;
     for (size_t i = 0; i < p->pops.size(); ++i) {
       const RiabPopulation& q = p->pops[i];
       if (riab::step1_supported(&p->env, &q, p->B) != RIAB_OK) continue;
+      if (p->has_task && q.spikes_base) continue;
       const int64_t bytes = (int64_t)q.n * (q.spikes_base ? 5 : 4);
       if (bytes > best_bytes) {
         best = (int)i;
@@ -238,6 +247,7 @@ extern "C" int riab_plan_set_task(RiabPlan* p, const RiabTask* task, double* tas
                                   uint64_t reset_counter, int32_t teleport, double* ep_log, int64_t ep_log_cap,
                                   int32_t* ep_count, double scripted_speed) {
   if (!p) return RIAB_EINVAL;
+  p->lead = -2;  // (a task's lead carries no spikes)
   if (!task) {
     p->has_task = false;
     return RIAB_OK;
@@ -431,10 +441,10 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
   if (p->forced && (p->has_task || p->forced_rows - p->forced_fill < n_steps)) return p->has_task ? RIAB_EINVAL : RIAB_EFULL;
   hipStream_t s = (hipStream_t)stream;
   p->pre_pending = false;
-  const int lead = plan_lead(p);
+  const int lead = plan_lead(p, true);
   for (int32_t k = 0; k < n_steps; ++k) {
     float* row = p->hist_base ? p->hist_base + p->hist_fill * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
-    if (lead >= 0) {  // Agent.update() and the lead population's update() in one launch, the other populations after it
+    if (lead >= 0 && !p->has_task) {  // Agent.update() and the lead population's update() in one launch, the other populations after it
       int rc = fused_agent_step(p, lead, row, s);
       if (rc) return rc;
       p->step += 1;
@@ -471,6 +481,29 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
       if (p->hist_base) p->hist_fill += 1;
       p->t_env += p->dt_env;
       if (p->auto_reset) p->reset_counter += 1;
+      if (lead >= 0) {  // ... and the lead population's update() as well: the whole closed-loop step is one kernel
+        const RiabPopulation& q = p->pops[lead];
+        const int64_t r = q.capacity_rows > 0 ? p->pop_fill[lead] : 0;
+        p->epoch += 1u;
+        if (p->epoch == 0u) p->epoch = 1u;
+        rc = riab::launch_step1_task(ma, &p->env, &q, q.rates_base + r * (int64_t)q.n * p->B, p->seed, p->step, p->sync_words,
+                                     p->epoch, &p->walls_ready, &p->task, p->task_state, p->task_B, p->t_env, p->reward_out,
+                                     p->terminal_out, p->task_diag, p->auto_reset != 0, p->n_select, p->ordered, p->task_seed,
+                                     p->reset_counter, p->teleport, p->ep_log, p->ep_log_cap, p->ep_count, p->scripted_speed,
+                                     scripted ? act : nullptr, scripted ? act + p->B : nullptr, s);
+        if (rc) return rc;
+        p->fused_steps += 1;
+        p->launches += 1;
+        p->action_ready = scripted;
+        if (q.capacity_rows > 0) p->pop_fill[lead] += 1;
+        for (size_t i = 0; i < p->pops.size(); ++i) {
+          if ((int)i == lead) continue;
+          rc = launch_population(p, i, row, s);
+          if (rc) return rc;
+          if (p->pops[i].capacity_rows > 0) p->pop_fill[i] += 1;
+        }
+        continue;
+      }
       rc = riab::launch_motion_task(ma, &p->env, &p->task, p->task_state, pos_x, pos_y, p->task_B, p->t_env, p->reward_out,
                                     p->terminal_out, p->task_diag, p->auto_reset != 0, p->agent_id0, p->n_select,
                                     p->ordered, p->task_seed, p->reset_counter, p->teleport,

@@ -108,6 +108,7 @@ struct PlaceCell {
   // (riab_step1.hip: the same workgroup has just computed these positions and hands them over in LDS)
   __device__ __forceinline__ Pos from_rows(v4f x, v4f y, v4f, v4f) const { return Pos{x, y}; }
   static constexpr bool NEEDS_HD = false;
+  static constexpr bool NEEDS_POS = true;
   __device__ __forceinline__ float wrap(float v) const {
     const float av = fabsf(v);
     return (av > half_scale) ? -copysignf(scale - av, v) : v;
@@ -199,6 +200,7 @@ struct GridCell {
   }
   __device__ __forceinline__ Pos from_rows(v4f x, v4f y, v4f, v4f) const { return Pos{x, y}; }
   static constexpr bool NEEDS_HD = false;
+  static constexpr bool NEEDS_POS = true;
   // two agents per instruction: the phase arithmetic and the final affine map are packed fp32
   // (v_pk_mul / v_pk_fma / v_pk_add); v_fract and v_cos stay one per term
   __device__ __forceinline__ v2f two(const float* p, v2f x, v2f y) const {
@@ -249,6 +251,7 @@ struct HDCell {
   }
   __device__ __forceinline__ Pos from_rows(v4f, v4f, v4f hx, v4f hy) const { return from_dirs(hx, hy); }
   static constexpr bool NEEDS_HD = true;
+  static constexpr bool NEEDS_POS = false;
   __device__ __forceinline__ Pos load(const RateArgs& a, int64_t off) const {
     v4f hx, hy;
     if (MODE == 1 && vx64) {

@@ -32,6 +32,7 @@
 // DESIGN.md 3.9, docs/EXPERIMENTS.md r05.
 #include "riab_agent_kernel.h"
 #include "riab_rate_cells.h"
+#include "riab_task_kernel.h"  // (last: it turns fp contraction off for its own code)
 
 namespace riab {
 
@@ -57,6 +58,39 @@ __global__ __launch_bounds__(64) void walls_prepare_kernel(const AgentArgs a, Wa
 }
 
 typedef __attribute__((address_space(1))) uint32_t s1_gu32;
+typedef __attribute__((address_space(1))) unsigned long long s1_gu64;
+
+// The rest of TaskEnvironment.step in the same launch (TASK = task_kernel's MODE: 1 step, | 2 the caller's `if terminal:
+// reset()`, | 4 the scripted action of the next step) — what the step plan's motion + task launch did behind the motion
+// step, for a plan whose lead population can be fused as well (one kernel per closed-loop step instead of two).
+//   * The segment's writer workgroup (blockIdx.y == 0) does the bookkeeping of its 256 lanes (task_lane_*: the same code
+//     on the same operands as task_kernel) with the position its motion step has just produced, its task rows fetched
+//     with the state at the top, a whole motion step ahead of their use.  It writes no rates: the cell groups are
+//     dealt to the workgroups y >= 1.
+//   * A reset that teleports changes the position the rates are a function of.  The other workgroups cannot know — the
+//     goal lists are the writer's — so each mover wave of the writer posts two verdict entries per step ("epoch, these
+//     of my 64 lanes moved", write-through) as soon as its lanes' positions are final, and the workgroups y >= 1 read
+//     the eight entries after their last rate store: the lanes whose quad of agents has a mover fetch the new positions
+//     from the segment's mail and the wave runs its rate pass again, stored by those lanes only (own stores
+//     acknowledged first).  The rows end up as the population's kernel would have written them from the
+//     history row the reset patched.
+//   * What a lane's bookkeeping writes where other workgroups read (the position, the next action in the drift
+//     buffer) is handed back in registers and stored with the state, behind the arrival words.
+// Workgroups y >= 1 now wait for the writer's verdict, which the writer posts without waiting for anybody: still no
+// cycle; it needs the writers dispatched no later than the rest (they have the lowest workgroup ids) and is bounded by
+// the same spin limit and counter as the state write-back.
+struct Step1Task {
+  TaskArgs a;
+  ResetArgs r;  // (pos_x / hist_x null: the writer stores what it is handed back)
+  double t_env;
+  double* reward_out;
+  uint8_t* terminal_out;
+  double gv_scale;
+  double* gv_x;
+  double* gv_y;
+  int32_t* diag;
+  uint32_t* mail;  // [segments][RIAB_STEP1_MAIL_STRIDE]
+};
 
 // tools/step1_profile.py (a -DRIAB_STEP1_PROFILE build): three workgroups — the first writer, its segment's second
 // workgroup, the grid's last — leave the device's constant clock at the phase boundaries of the LAST step, behind the
@@ -64,7 +98,7 @@ typedef __attribute__((address_space(1))) uint32_t s1_gu32;
 #ifdef RIAB_STEP1_PROFILE
 #define RIAB_S1_STAMP(k)                                                                                                  \
   if (prof_slot >= 0 && tid == 0)                                                                                         \
-    ((unsigned long long*)(sy.words + RIAB_STEP1_SYNC_WORDS((int64_t)sy.n_segments * 256)))[prof_slot * 8 + (k)] = \
+    ((unsigned long long*)(sy.words + RIAB_STEP1_SYNC_WORDS((int64_t)sy.n_segments * 256)))[prof_slot * 16 + (k)] = \
         (unsigned long long)__builtin_amdgcn_s_memrealtime();
 #else
 #define RIAB_S1_STAMP(k)
@@ -73,15 +107,19 @@ typedef __attribute__((address_space(1))) uint32_t s1_gu32;
 #ifndef RIAB_S1_ABLATE
 #define RIAB_S1_ABLATE 0
 #endif
+// ... of the task modes: task_kernel MODE bits left out (1 the step's bookkeeping, 2 resets, 4 the next action), 8: the
+// workgroups y >= 1 do not wait for the writer's verdict
+#ifndef RIAB_S1_TASK_DROP
+#define RIAB_S1_TASK_DROP 0
+#endif
 #ifndef RIAB_S1_WAVES_PER_EU
 #define RIAB_S1_WAVES_PER_EU 2
 #endif
 #define RIAB_S1_WAVES 8  // waves per workgroup: 0-3 advance the 256 agents, 4-7 draw their normals, all of them write rates
-template <class Cell, int SPK, int CPB, bool NT>
-__global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_kernel(const AgentArgs a, const RateArgs ra, Cell cell,
-                                                                                           const Step1Sync sy, const int reps,
-                                                                                           const MotionConst<double> hk,
-                                                                                           const TailConst<double> tail_c) {
+template <class Cell, int SPK, int CPB, bool NT, int TASK>
+__device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& ra, const Cell& cell, const Step1Sync& sy,
+                                           const int reps, const MotionConst<double>& hk, const TailConst<double>& tail_c,
+                                           const Step1Task& tk) {
   RIAB_EXACT_FP
   constexpr int NP = Cell::NP;
   constexpr int NT_ = 64 * RIAB_S1_WAVES;
@@ -91,6 +129,13 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
   __shared__ double s_h[RIAB_H_SEGS * RIAB_H_STRIDE];
   __shared__ __align__(16) float s_row[4][256];  // x, y, head direction x, y of the segment's agents as the history keeps them
   __shared__ float s_z[2][256];                  // the step's two standard normals per agent (drawn by waves 4-7)
+  __shared__ double s_goals[TASK ? RIAB_TASK_MAX_POOL * RIAB_GOAL_COLS : 1];  // the task's goal pool (writer)
+  // (writer) what its noise-drawing waves work out for the lanes' books while the movers move: the reward cache's update
+  // (rewards alive, their total) and what a reset of the lane would draw (position, next episode's goals)
+  __shared__ double s_rw_total[TASK ? 256 : 1];
+  __shared__ int s_rw_n[TASK ? 256 : 1];
+  __shared__ double s_draw_xy[2][(TASK & 2) ? 256 : 1];
+  __shared__ unsigned long long s_draw_list[2][(TASK & 2) ? 256 : 1];
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,14 +167,31 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
       dry = a.drift[B + b];
     }
   }
+  // (task: the writer's lanes ask for their bookkeeping rows in the same batch; the pool goes to LDS with the tables)
+  // The bookkeeping is one long, branchy instruction stream per lane (~7 us behind a 4 us motion step when one wave does
+  // it all), and most of it does not depend on where the agent went: the reward cache's update and the draws of a reset
+  // are the helper waves' (4-7, idle once the normals are drawn), lane for lane beside the movers' second half; the
+  // movers keep what needs the new position — the goal checks, the reset itself, the next action.
+  // (dealing the lanes to all eight waves, 32 each, was tried: no faster — docs/EXPERIMENTS.md r05-5)
+  const bool tlive = TASK && writer && mover && b < tk.a.B;
+  const bool hlive = TASK && writer && !mover && b < tk.a.B;
+  LaneIn tin;
+  RewardsIn trin;
+  if (TASK) {
+    if (tlive) tin = task_lane_load<TASK & ~RIAB_S1_TASK_DROP>(tk.a, b);  // (TM, declared below)
+    if (hlive && (TASK & 1)) trin = load_rewards_in(tk.a, b);
+    if (writer) task_stage_goals(tk.a, s_goals, tid, NT_);
+  }
   // (the box fast path's verdict, worked out once per plan by walls_prepare_kernel)
   const uint32_t box_word = *reinterpret_cast<const uint32_t*>(sy.walls + RIAB_MAX_WALLS);
-  const int g0 = (int)(blockIdx.y * (uint32_t)RIAB_S1_WAVES + (uint32_t)wave) * reps;  // this wave's first cell group
+  // this wave's first cell group (task: the writer has none, the cell groups are dealt to the workgroups y >= 1)
+  const bool rates_here = !(TASK && writer);
+  const int g0 = (int)((blockIdx.y - (TASK ? 1u : 0u)) * (uint32_t)RIAB_S1_WAVES + (uint32_t)wave) * reps;
   auto group_params = [&](int g) -> float {
     const int pi = g * CPB * NP + lane;
     return (lane < NP * CPB && pi < ra.n * NP) ? cell.tab[pi] : 0.0f;
   };
-  float mine = group_params(g0);
+  float mine = rates_here ? group_params(g0) : 0.0f;
   stage_rayleigh_tables<NT_>(s_g, s_h, tid);
   for (int i = tid; i < a.n_walls * (int)(sizeof(Wall<double>) / sizeof(double)); i += NT_)
     reinterpret_cast<double*>(s_w)[i] = reinterpret_cast<const double*>(sy.walls)[i];
@@ -190,6 +252,27 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
     nv64 = seg_eval<RIAB_G_DEG>(grow, tG);
   }
   __syncthreads();  // the normals are in LDS
+  ResetArgs tr = tk.r;  // (what this kernel never does, said so that the compiler can drop it: no positions handed in,
+  tr.new_x = tr.new_y = nullptr;  // none stored by the lane's reset itself)
+  tr.pos_x = tr.pos_y = nullptr;
+  tr.hist_x = tr.hist_y = nullptr;
+  constexpr int TM = TASK & ~RIAB_S1_TASK_DROP;
+  if (TASK && writer && !mover) {  // (wave-uniform) the helper waves' share of the lanes' books, see above
+    if (hlive && (TM & 1)) {
+      const RewardsOut ro = rewards_step(tk.a, (lds_f64_ptr)s_goals, b, trin);
+      s_rw_n[tid & 255] = ro.n_rw;
+      s_rw_total[tid & 255] = ro.total;
+    }
+    __syncthreads();  // (writer) the reward caches are up to date
+    if (hlive && (TM & 2)) {
+      const ResetDraw d = reset_draw(tk.a, tr, b);
+      s_draw_xy[0][tid & 255] = d.x;
+      s_draw_xy[1][tid & 255] = d.y;
+      s_draw_list[0][tid & 255] = (unsigned long long)d.list;
+      s_draw_list[1][tid & 255] = (unsigned long long)(d.list >> 64);
+    }
+    __syncthreads();  // (writer) the resets' draws are in LDS
+  }
   if (mover && !(RIAB_S1_ABLATE & 1)) {
     const lds_cf64_ptr lds_h = (lds_cf64_ptr)s_h;
     const double z_rot = (double)s_z[0][tid], z_spd = (double)s_z[1][tid];
@@ -232,14 +315,87 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
     mvx = tl.mvx; mvy = tl.mvy; mrot = tl.mrot; hx = tl.hx; hy = tl.hy; dist = tl.dist; n_still = tl.n_still;
   }
   RIAB_S1_STAMP(2)
-  if (mover) {
+  // ---- the writer's part: the state in place, once nobody can read the old one any more.  Each of its mover waves asks
+  // for its segment's arrival words BEFORE its share of the rates (task: before its lanes' bookkeeping) — the request
+  // travels meanwhile — and looks at the answer after it; only a word that was not there yet costs a poll.  Bounded;
+  // counted when it gives up.
+  auto arrivals = [&]() -> uint32_t {
+    const uint32_t others = gridDim.y - 1u;  // (<= RIAB_STEP1_SYNC_MAX_Y - 1: one lane per word)
+    uint32_t v = sy.epoch;
+    if ((uint32_t)lane < others)
+      v = __hip_atomic_load((s1_gu32*)(uintptr_t)(sy.words + (int64_t)blockIdx.x * RIAB_STEP1_SYNC_STRIDE + 1 + lane), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+  };
+  const bool wb = writer && mover && !(RIAB_S1_ABLATE & 4);  // (wave-uniform)
+  uint32_t seen = sy.epoch;
+  double gvx = 0.0, gvy = 0.0;
+  LaneMid tmid = {0, 0, false, false, {false, 0, 0.0, 0.0, 0.0}, 0};
+  if (TASK && writer && mover) {
+    // ---- the rest of TaskEnvironment.step for the writer's lanes (contribs/TaskEnvironment.py:410-449), the caller's
+    // reset of the lanes that ended an episode, the next scripted action: task_kernel's lane, on the position just made
+    if (wb) seen = arrivals();
+    double qx = px, qy = py;
+    const double mx = qx, my = qy;
+#ifdef RIAB_STEP1_PROFILE
+    auto probe = [&](int k) { RIAB_S1_STAMP(k) };
+#else
+    const NoProbe probe;
+#endif
+    __syncthreads();  // (writer) the reward caches are up to date: the helper waves' rewards_step
+    if (tlive) {
+      const RewardsOut ro = {s_rw_n[tid], s_rw_total[tid]};
+      tmid = task_lane_goals<TM>(tk.a, b, (lds_f64_ptr)s_goals, tin, ro, qx, qy, tk.t_env, tk.reward_out, tk.terminal_out, tk.diag, probe);
+    }
+    __syncthreads();  // (writer) the resets' draws are in LDS
+    if (tlive)
+      task_lane_reset<TM>(tk.a, tr, b, tin, tmid, qx, qy, tk.t_env, tk.diag, [&]() {
+        return ResetDraw{s_draw_xy[0][tid], s_draw_xy[1][tid], ((u128)s_draw_list[1][tid] << 64) | (u128)s_draw_list[0][tid]};
+      });
+    const bool moved = tlive && !(qx == mx && qy == my);  // (a reset that teleported the lane)
+    uint32_t* const mail = tk.mail + (int64_t)blockIdx.x * RIAB_STEP1_MAIL_STRIDE;
+    // who moved and where to: 8-byte entries that carry the epoch themselves (epoch << 32 | value), so that none of them
+    // has to be ordered against another — or against the bookkeeping's stores and the episode table's atomic, which are
+    // still in flight.  This wave's two verdict entries (the halves of its lane mask) are posted every step.
+    const unsigned long long lanes = __builtin_amdgcn_ballot_w64(moved);
+    const unsigned long long tag = (unsigned long long)sy.epoch << 32;
+    s1_gu64* const mail64 = (s1_gu64*)(uintptr_t)(tk.mail + (int64_t)blockIdx.x * RIAB_STEP1_MAIL_STRIDE);
+    if (moved) {
+      __hip_atomic_store(mail64 + 16 + tid, tag | __float_as_uint((float)qx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mail64 + 272 + tid, tag | __float_as_uint((float)qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane < 2)
+      __hip_atomic_store(mail64 + 2 * wave + lane, tag | (uint32_t)(lanes >> (32 * lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    RIAB_S1_STAMP(7)
+    // (the others know; now what only this lane's books need: the new episode's goals, the next action, the rows back)
+    if (tlive) {
+      task_lane_finish<TM>(tk.a, tr, b, (lds_f64_ptr)s_goals, tin, tmid, tk.gv_scale, gvx, gvy, probe);
+      px = qx;
+      py = qy;
+    }
+    RIAB_S1_STAMP(15)
+  } else if (mover) {
     s_row[0][tid] = (float)px;
     s_row[1][tid] = (float)py;
     if (Cell::NEEDS_HD) {
       s_row[2][tid] = (float)hx;
       s_row[3][tid] = (float)hy;
     }
-    if (writer && a.hist) {  // save_to_history (Agent.py:514-520)
+  }
+  if (mover && writer && !TASK && a.hist) {  // save_to_history (Agent.py:514-520)
+    float* h = a.hist + b;
+    h[0 * B] = (float)px;
+    h[1 * B] = (float)py;
+    h[2 * B] = (float)mvx;
+    h[3 * B] = (float)mvy;
+    h[4 * B] = (float)hx;
+    h[5 * B] = (float)hy;
+    h[6 * B] = (float)mrot;
+    h[7 * B] = (float)dist;
+  }
+  __syncthreads();  // the row is in LDS; every state value of this workgroup has been consumed, i.e. loaded
+  if (TASK && writer && mover) {  // (the lanes' books are kept: a reset may have moved them)
+    if (a.hist) {  // save_to_history (Agent.py:514-520), agent.history["pos"][-1] = agent.pos of a teleporting reset included
       float* h = a.hist + b;
       h[0 * B] = (float)px;
       h[1 * B] = (float)py;
@@ -251,25 +407,11 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
       h[7 * B] = (float)dist;
     }
   }
-  __syncthreads();  // the row is in LDS; every state value of this workgroup has been consumed, i.e. loaded
   if (!writer && tid == 0)
     __hip_atomic_store((s1_gu32*)(uintptr_t)(sy.words + (int64_t)blockIdx.x * RIAB_STEP1_SYNC_STRIDE + blockIdx.y), sy.epoch,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-  // ---- the writer's part: the state in place, once nobody can read the old one any more.  Each of its mover waves asks
-  // for its segment's arrival words BEFORE its share of the rates (the request travels while it stores) and looks at the
-  // answer after it; only a word that was not there yet costs a poll.  Bounded; counted when it gives up.
-  auto arrivals = [&]() -> uint32_t {
-    const uint32_t others = gridDim.y - 1u;  // (<= RIAB_STEP1_SYNC_MAX_Y - 1: one lane per word)
-    uint32_t v = sy.epoch;
-    if ((uint32_t)lane < others)
-      v = __hip_atomic_load((s1_gu32*)(uintptr_t)(sy.words + (int64_t)blockIdx.x * RIAB_STEP1_SYNC_STRIDE + 1 + lane), __ATOMIC_RELAXED,
-                            __HIP_MEMORY_SCOPE_AGENT);
-    return v;
-  };
-  const bool wb = writer && mover && !(RIAB_S1_ABLATE & 4);  // (wave-uniform)
-  uint32_t seen = sy.epoch;
-  if (wb) seen = arrivals();
+  if (wb && !TASK) seen = arrivals();
   auto write_back = [&]() {
     bool timed_out = false;
     for (uint32_t spins = 0; __builtin_amdgcn_ballot_w64(seen != sy.epoch) != 0; ++spins) {
@@ -296,6 +438,10 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
       st[9 * B] = hy;
       st[10 * B] = dist;
       st[11 * B] = dwall;
+      if ((TASK & 4) && b < tk.a.B) {  // the coming step's action (the drift buffer every workgroup read at the top)
+        tk.gv_x[b] = gvx;
+        tk.gv_y[b] = gvy;
+      }
       if (a.diag) {
         if (n_bounce) atomicAdd(a.diag + 0, n_bounce);
         if (n_sat) atomicAdd(a.diag + 1, n_sat);
@@ -306,8 +452,8 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
   };
 
   // ---- Neurons.update of the population: this wave's cell groups for the segment's 256 agents ----------------------
-  {
-    const v4f rx = *reinterpret_cast<const v4f*>(&s_row[0][4 * lane]), ry = *reinterpret_cast<const v4f*>(&s_row[1][4 * lane]);
+  // (`store`: the lanes that write their quad's values — all of them, but for the pass that follows a reset, below)
+  auto rates_pass = [&](const v4f rx, const v4f ry, float params, const bool store) {
     v4f rhx = {0.0f, 0.0f, 0.0f, 0.0f}, rhy = rhx;
     if (Cell::NEEDS_HD) {
       rhx = *reinterpret_cast<const v4f*>(&s_row[2][4 * lane]);
@@ -319,8 +465,8 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
     for (int r = 0; r < reps; ++r) {
       const int c0 = (g0 + r) * CPB;
       if (c0 >= ra.n) break;  // wave-uniform
-      const float cur = mine;
-      if (r + 1 < reps) mine = group_params(g0 + r + 1);  // (requested before this group's stores are issued)
+      const float cur = params;
+      if (r + 1 < reps) params = group_params(g0 + r + 1);  // (requested before this group's stores are issued)
       int64_t off = (int64_t)c0 * B + 4 * (int64_t)q;
 #pragma unroll
       for (int j = 0; j < CPB; ++j) {
@@ -331,16 +477,20 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
             p[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), j * NP + i));
           v4f rr = cell.eval(p, P);
           rr = finish_rate(rr * ra.fr_scale + ra.fr_min, P);  // [0,1] -> [min_fr, max_fr]
-          if (RIAB_S1_ABLATE & 2) {
-            if (rr.x == 123.0f) *reinterpret_cast<v4f*>(ra.rates + off) = rr;
-          } else if (NT) __builtin_nontemporal_store(rr, reinterpret_cast<v4f*>(ra.rates + off));
-          else *reinterpret_cast<v4f*>(ra.rates + off) = rr;
-          if (SPK == 1) spike_store<false>(ra, rr, off, ra.step0, (uint32_t)(c0 + j), group);
+          if (store) {
+            if (RIAB_S1_ABLATE & 2) {
+              if (rr.x == 123.0f) *reinterpret_cast<v4f*>(ra.rates + off) = rr;
+            } else if (NT) __builtin_nontemporal_store(rr, reinterpret_cast<v4f*>(ra.rates + off));
+            else *reinterpret_cast<v4f*>(ra.rates + off) = rr;
+            if (SPK == 1) spike_store<false>(ra, rr, off, ra.step0, (uint32_t)(c0 + j), group);
+          }
           off += B;
         }
       }
     }
-  }
+  };
+  if (rates_here)
+    rates_pass(*reinterpret_cast<const v4f*>(&s_row[0][4 * lane]), *reinterpret_cast<const v4f*>(&s_row[1][4 * lane]), mine, true);
   RIAB_S1_STAMP(3)
 #ifdef RIAB_STEP1_PROFILE
   if (prof_slot >= 0) {
@@ -348,7 +498,83 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
     RIAB_S1_STAMP(4)
   }
 #endif
+  if (TASK && !writer && Cell::NEEDS_POS && !(RIAB_S1_TASK_DROP & 8)) {
+    // ---- did a reset move one of the segment's agents?  The writer's eight verdict entries of this launch: one round
+    // trip (they are usually there by now) says that they are posted and which agents moved.
+    const s1_gu64* const mail64 = (const s1_gu64*)(uintptr_t)(tk.mail + (int64_t)blockIdx.x * RIAB_STEP1_MAIL_STRIDE);
+    auto peek = [&](int at) -> unsigned long long {
+      return __hip_atomic_load((s1_gu64*)(mail64 + at), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // entry `at`, last seen as `e`, once it carries this launch's epoch (bounded); lanes that do not `want` it pass
+    auto fresh = [&](int at, bool want, unsigned long long e) -> unsigned long long {
+      if (!want) e = (unsigned long long)sy.epoch << 32;
+      for (uint32_t spins = 0; __builtin_amdgcn_ballot_w64((uint32_t)(e >> 32) != sy.epoch) != 0; ++spins) {
+        if (spins >= sy.spin_limit) break;
+        __builtin_amdgcn_s_sleep(4);
+        if (want) e = peek(at);
+      }
+      return e;
+    };
+    // (with the verdict, unasked: where this lane's four agents went if they were moved — the same round trip; an entry
+    // that turns out to be needed and is not there yet is asked for again below)
+    unsigned long long ex[4], ey[4];
+    const unsigned long long v0 = peek(lane & 7);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ex[k] = peek(16 + 4 * lane + k);
+      ey[k] = peek(272 + 4 * lane + k);
+    }
+    const unsigned long long verdict = fresh(lane & 7, lane < 8, v0);
+    bool stale = __builtin_amdgcn_ballot_w64((uint32_t)(verdict >> 32) != sy.epoch) != 0;
+    // this lane's quad of agents: bits 4 * lane .. + 3 of the 256, i.e. of half-mask (lane >> 3)
+    const uint32_t half = (uint32_t)__shfl((int)(uint32_t)verdict, lane >> 3);
+    const uint32_t mine4 = stale ? 0u : ((half >> ((4 * lane) & 31)) & 15u);
+    RIAB_S1_STAMP(7)
+    if (__builtin_amdgcn_ballot_w64(mine4 != 0u) != 0) {
+      // (wave-uniform) this wave's cell groups again for the quads an agent of which was moved: the same pass — the
+      // same instructions, hence the same bits as the population's own kernel gives on the patched history row — on
+      // the row with the new positions in, stored by the lanes whose quad changed
+      v4f rx = *reinterpret_cast<const v4f*>(&s_row[0][4 * lane]), ry = *reinterpret_cast<const v4f*>(&s_row[1][4 * lane]);
+      // the positions this lane needs: all of them asked for again in ONE batch while any is not this launch's yet
+      for (uint32_t spins = 0;; ++spins) {
+        bool waiting = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          waiting = waiting || (((mine4 >> k) & 1u) && ((uint32_t)(ex[k] >> 32) != sy.epoch || (uint32_t)(ey[k] >> 32) != sy.epoch));
+        if (__builtin_amdgcn_ballot_w64(waiting) == 0) break;
+        if (spins >= sy.spin_limit) {
+          stale = true;
+          break;
+        }
+        if (spins) __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if ((mine4 >> k) & 1u) {
+            ex[k] = peek(16 + 4 * lane + k);
+            ey[k] = peek(272 + 4 * lane + k);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool m = (mine4 >> k) & 1u;
+        const float fx = __uint_as_float((uint32_t)ex[k]), fy = __uint_as_float((uint32_t)ey[k]);
+        if (k == 0) { rx.x = m ? fx : rx.x; ry.x = m ? fy : ry.x; }
+        if (k == 1) { rx.y = m ? fx : rx.y; ry.y = m ? fy : ry.y; }
+        if (k == 2) { rx.z = m ? fx : rx.z; ry.z = m ? fy : ry.z; }
+        if (k == 3) { rx.w = m ? fx : rx.w; ry.w = m ? fy : ry.w; }
+      }
+      if (!stale) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the values this wave stored for those quads a moment ago are in place)
+        rates_pass(rx, ry, reps == 1 ? mine : group_params(g0), mine4 != 0u);  // (one group per wave: its parameters are still here)
+      }
+    }
+    RIAB_S1_STAMP(12)
+    if (stale && lane == 0) atomicAdd(sy.words + (int64_t)sy.n_segments * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TIMEOUTS, 1u);
+  }
   if (wb) write_back();
+  // (the ended episodes' rows, last: their slots in the table were asked for a write-back ago)
+  if ((TM & 2) && tlive) episode_log_store(tr, b, tmid.rec, tk.t_env, tk.diag);
 #ifdef RIAB_STEP1_PROFILE
   if (prof_slot >= 0 && writer) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -357,35 +583,73 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
 #endif
 }
 
+template <class Cell, int SPK, int CPB, bool NT>
+__global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_kernel(const AgentArgs a, const RateArgs ra, Cell cell,
+                                                                                           const Step1Sync sy, const int reps,
+                                                                                           const MotionConst<double> hk,
+                                                                                           const TailConst<double> tail_c) {
+  const Step1Task none = {};
+  step1_body<Cell, SPK, CPB, NT, 0>(a, ra, cell, sy, reps, hk, tail_c, none);
+}
+
+template <class Cell, int CPB, bool NT, int TASK>
+__global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_task_kernel(const AgentArgs a, const RateArgs ra,
+                                                                                                Cell cell, const Step1Sync sy,
+                                                                                                const int reps,
+                                                                                                const MotionConst<double> hk,
+                                                                                                const TailConst<double> tail_c,
+                                                                                                const Step1Task tk) {
+  step1_body<Cell, 0, CPB, NT, TASK>(a, ra, cell, sy, reps, hk, tail_c, tk);
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------
 // how a (B, n) problem is cut: `reps` cell groups per wave so that the grid is about one wave of workgroups (two per
 // compute unit: 512 on MI355X) — a second round of workgroups would run the motion step a second time — and a
 // segment's workgroups fit its line of arrival words
-static void step1_shape(int64_t B, int n, int cpb, dim3* grid, int* reps) {
+// (task: one of a segment's workgroups — its writer — keeps the task's books instead of writing rates)
+static void step1_shape(int64_t B, int n, int cpb, bool task, dim3* grid, int* reps) {
   const int64_t segs = B / 256;
   const int64_t groups = (n + cpb - 1) / cpb;
   int64_t want_y = (2048 / RIAB_S1_WAVES) / segs;  // workgroups per segment in one resident round (eight waves per compute unit)
-  if (want_y < 1) want_y = 1;
   if (want_y > RIAB_STEP1_SYNC_MAX_Y) want_y = RIAB_STEP1_SYNC_MAX_Y;
+  if (task) want_y -= 1;
+  if (want_y < 1) want_y = 1;
   int64_t r = (groups + RIAB_S1_WAVES * want_y - 1) / (RIAB_S1_WAVES * want_y);
   if (r < 1) r = 1;
   int64_t gy = (groups + RIAB_S1_WAVES * r - 1) / (RIAB_S1_WAVES * r);
   *reps = (int)r;
-  *grid = dim3((unsigned)segs, (unsigned)gy, 1);
+  *grid = dim3((unsigned)segs, (unsigned)(gy + (task ? 1 : 0)), 1);
 }
 
 template <class Cell>
 static int launch_step1_cell(const AgentArgs& a, const RateArgs& ra, const Cell& cell, const Step1Sync& sy, bool spikes,
-                             bool nt, hipStream_t s) {
+                             bool nt, hipStream_t s, const Step1Task* tk, int task_mode) {
   constexpr int CPB = (Cell::NP * 2 * Cell::CPB <= 64) ? 2 * Cell::CPB : Cell::CPB;  // (as the row-following kernel)
+  // (task: 15 of a segment's 16 workgroups write rates — a cell group a sixteenth larger keeps a population that filled
+  // one round of workgroups in one round: cfg 2, 1024 cells: 114 groups of 9 on 15 x 8 waves instead of 128 of 8 on 16 x 8)
+  constexpr int CPB_T = (Cell::NP * ((CPB * 16 + 14) / 15) <= 64) ? (CPB * 16 + 14) / 15 : CPB;
   dim3 grid;
   int reps;
-  step1_shape(a.B, ra.n, CPB, &grid, &reps);
+  step1_shape(a.B, ra.n, tk ? CPB_T : CPB, tk != nullptr, &grid, &reps);
   // the launch's scalar constants, once, here (float64 divisions the kernel would otherwise repeat per thread and step)
   MotionConst<double> hk = {};
   motion_const_scalars<double>(hk, a);
   const TailConst<double> tc = {a.m.dt, hk.inv_dt, 1.0 - a.m.dt / a.m.hd_tau, a.m.dt / a.m.hd_tau, a.m.hd_tau <= a.m.dt};
   const dim3 block(64 * RIAB_S1_WAVES);
+  if (tk) {  // (no spikes, non-temporal stores; TASK = task_kernel's MODE)
+    if (spikes) return RIAB_EUNSUPPORTED;
+#define RIAB_S1_TASK(MODE) \
+  hipLaunchKernelGGL((step1_task_kernel<Cell, CPB_T, true, MODE>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc, *tk)
+    switch (task_mode) {
+      case 1: RIAB_S1_TASK(1); break;
+      case 3: RIAB_S1_TASK(3); break;
+      case 5: RIAB_S1_TASK(5); break;
+      case 7: RIAB_S1_TASK(7); break;
+      default: return RIAB_EINVAL;
+    }
+#undef RIAB_S1_TASK
+    return (int)hipGetLastError();
+  }
   if (spikes) {
     if (nt) hipLaunchKernelGGL((step1_kernel<Cell, 1, CPB, true>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc);
     else hipLaunchKernelGGL((step1_kernel<Cell, 1, CPB, false>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc);
@@ -415,8 +679,9 @@ int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B) {
 // one Agent.update() (the arguments of riab_agent_step(T = 1), Philox noise) + the population's update() on the row it
 // writes: `rates_row` / `spikes_row` are the population's rows of this step, `step_after` the number of agent steps
 // taken once this one is done (Neurons.update's spike counter, as riab_plan_step passes it)
-int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
-                 uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, hipStream_t s) {
+static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row,
+                             uint8_t* spikes_row, uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch,
+                             bool* walls_ready, hipStream_t s, const Step1Task* tk, int task_mode) {
   const int rc = step1_supported(env, pop, a.B);
   if (rc) return rc;
   if (a.z_in || a.z_out || a.forced || a.T != 1 || !sync_words || !rates_row || epoch == 0u) return RIAB_EINVAL;
@@ -470,35 +735,71 @@ int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* p
         w.tab = c.tab; w.scale = c.scale; w.half_scale = c.half_scale; w.top_hat_w2 = c.top_hat_w2; w.walls = c.walls;
         w.n_internal = 0; w.e0 = c.e0; w.e1 = c.e1; w.e2 = c.e2; w.e3 = c.e3; w.shape = c.shape; w.lds = nullptr;
         switch (pop->description) {
-          case RIAB_PC_GAUSSIAN: return launch_step1_cell(a, ra, w, sy, spikes, nt, s);
-          case RIAB_PC_GAUSSIAN_THRESHOLD: return launch_step1_cell(a, ra, w.as<RIAB_PC_GAUSSIAN_THRESHOLD>(), sy, spikes, nt, s);
-          case RIAB_PC_DIFF_OF_GAUSSIANS: return launch_step1_cell(a, ra, w.as<RIAB_PC_DIFF_OF_GAUSSIANS>(), sy, spikes, nt, s);
-          case RIAB_PC_TOP_HAT: return launch_step1_cell(a, ra, w.as<RIAB_PC_TOP_HAT>(), sy, spikes, nt, s);
+          case RIAB_PC_GAUSSIAN: return launch_step1_cell(a, ra, w, sy, spikes, nt, s, tk, task_mode);
+          case RIAB_PC_GAUSSIAN_THRESHOLD: return launch_step1_cell(a, ra, w.as<RIAB_PC_GAUSSIAN_THRESHOLD>(), sy, spikes, nt, s, tk, task_mode);
+          case RIAB_PC_DIFF_OF_GAUSSIANS: return launch_step1_cell(a, ra, w.as<RIAB_PC_DIFF_OF_GAUSSIANS>(), sy, spikes, nt, s, tk, task_mode);
+          case RIAB_PC_TOP_HAT: return launch_step1_cell(a, ra, w.as<RIAB_PC_TOP_HAT>(), sy, spikes, nt, s, tk, task_mode);
           default: return RIAB_EUNSUPPORTED;
         }
       }
       switch (pop->description) {
-        case RIAB_PC_GAUSSIAN: return launch_step1_cell(a, ra, c, sy, spikes, nt, s);
-        case RIAB_PC_GAUSSIAN_THRESHOLD: return launch_step1_cell(a, ra, c.as<RIAB_PC_GAUSSIAN_THRESHOLD>(), sy, spikes, nt, s);
-        case RIAB_PC_DIFF_OF_GAUSSIANS: return launch_step1_cell(a, ra, c.as<RIAB_PC_DIFF_OF_GAUSSIANS>(), sy, spikes, nt, s);
-        case RIAB_PC_TOP_HAT: return launch_step1_cell(a, ra, c.as<RIAB_PC_TOP_HAT>(), sy, spikes, nt, s);
+        case RIAB_PC_GAUSSIAN: return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode);
+        case RIAB_PC_GAUSSIAN_THRESHOLD: return launch_step1_cell(a, ra, c.as<RIAB_PC_GAUSSIAN_THRESHOLD>(), sy, spikes, nt, s, tk, task_mode);
+        case RIAB_PC_DIFF_OF_GAUSSIANS: return launch_step1_cell(a, ra, c.as<RIAB_PC_DIFF_OF_GAUSSIANS>(), sy, spikes, nt, s, tk, task_mode);
+        case RIAB_PC_TOP_HAT: return launch_step1_cell(a, ra, c.as<RIAB_PC_TOP_HAT>(), sy, spikes, nt, s, tk, task_mode);
         default: return RIAB_EUNSUPPORTED;
       }
     }
     case RIAB_POP_GRID:
       if (pop->description == RIAB_GC_RECTIFIED) {
         GridCell<RIAB_GC_RECTIFIED> c{pop->table, pop->f0, 1.0f / (1.0f - pop->f0)};
-        return launch_step1_cell(a, ra, c, sy, spikes, nt, s);
+        return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode);
       } else {
         GridCell<RIAB_GC_SHIFTED> c{pop->table, pop->f0, 1.0f};
-        return launch_step1_cell(a, ra, c, sy, spikes, nt, s);
+        return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode);
       }
     case RIAB_POP_HDC: {
       HDCell<0> c{pop->table, 0.0f, nullptr, nullptr};
-      return launch_step1_cell(a, ra, c, sy, spikes, nt, s);
+      return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode);
     }
     default: return RIAB_EUNSUPPORTED;
   }
+}
+
+int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
+                 uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, hipStream_t s) {
+  return launch_step1_impl(a, env, pop, rates_row, spikes_row, seed, step_after, sync_words, epoch, walls_ready, s, nullptr, 0);
+}
+
+// ... + the rest of TaskEnvironment.step for the first `task_B` lanes: the arguments of launch_motion_task (riab_agent.hip),
+// whose two stages this replaces together with the lead population's launch
+int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint64_t seed,
+                      uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, const RiabTask* task,
+                      double* task_state, int64_t task_B, double t_env, double* reward_out, uint8_t* terminal_out, int32_t* diag,
+                      bool auto_reset, int32_t n_select, int32_t ordered, uint64_t task_seed, uint64_t counter, int32_t teleport,
+                      double* ep_log, int64_t ep_log_cap, int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y,
+                      hipStream_t s) {
+  Step1Task tk = {};
+  int rc = fill_args(tk.a, env, task, task_state, task_B);
+  if (rc) return rc;
+  if (task_B > a.B || !reward_out || !terminal_out || !diag || !sync_words) return RIAB_EINVAL;
+  if (auto_reset) {
+    double* const pos_x = a.state + (int64_t)RIAB_S_POS_X * a.B;
+    rc = fill_reset(tk.r, env, a.agent_id0, n_select, ordered, task_seed, counter, teleport, nullptr, nullptr, pos_x, pos_x + a.B,
+                    nullptr, nullptr, ep_log, ep_log_cap, ep_count);
+    if (rc) return rc;
+    tk.r.pos_x = tk.r.pos_y = nullptr;  // (the writer stores the position the lane hands back, with the state)
+  }
+  tk.t_env = t_env;
+  tk.reward_out = reward_out;
+  tk.terminal_out = terminal_out;
+  tk.gv_scale = gv_scale;
+  tk.gv_x = gv_x;
+  tk.gv_y = gv_y;
+  tk.diag = diag;
+  tk.mail = sync_words + RIAB_STEP1_SYNC_MAIL_AT(a.B);
+  const int mode = 1 | (auto_reset ? 2 : 0) | (gv_x ? 4 : 0);
+  return launch_step1_impl(a, env, pop, rates_row, nullptr, seed, step_after, sync_words, epoch, walls_ready, s, &tk, mode);
 }
 
 }  // namespace riab

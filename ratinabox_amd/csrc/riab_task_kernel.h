@@ -89,23 +89,31 @@ struct Lane {
   double pad_start;
   double px, py;
   double new_total;  // states of the rewards awarded this step, in award order
+  uint64_t met;      // bit `pool index`: the lane stands inside that goal's radius (goals_met, once per step)
 };
 
+// (16 rows are asked for — the count arrives with them — but only as many as the longest list of the wave are packed /
+// written back: a step is one dependent instruction stream, every instruction it does not issue is time)
 __device__ __forceinline__ void load_list(const TaskArgs& a, int64_t b, Lane& L) {
   double rows[RIAB_TASK_MAX_GOALS];
 #pragma unroll
   for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i) rows[i] = ts_at(a, RIAB_TS_GOAL_LIST + i, b);
   u128 l = 0;
 #pragma unroll
-  for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i) l |= (u128)(uint32_t)((int)rows[i] & 0xFF) << (8 * i);
+  for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i) {
+    if (__builtin_amdgcn_ballot_w64(i < L.n_goals) == 0) break;  // (wave-uniform; entries past a lane's count are never read)
+    l |= (u128)(uint32_t)((int)rows[i] & 0xFF) << (8 * i);
+  }
   L.list = l;
   L.list_dirty = false;
 }
 
 __device__ __forceinline__ void store_list(const TaskArgs& a, int64_t b, const Lane& L) {
 #pragma unroll
-  for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i)
+  for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i) {
+    if (__builtin_amdgcn_ballot_w64(i < L.n_goals) == 0) break;
     if (i < L.n_goals) ts_at(a, RIAB_TS_GOAL_LIST + i, b) = (double)list_get(L.list, i);
+  }
 }
 
 // Reward.get_delta with no external drive (:823-832): -(decay(state)), presets of :732-737
@@ -162,10 +170,26 @@ __device__ void award(const TaskArgs& a, lds_f64_ptr goals, int64_t b, Lane& L, 
   L.new_total = L.new_total + r.init;
 }
 
-__device__ bool goal_met(const TaskArgs& a, lds_f64_ptr goals, const Lane& L, int src, double t_env) {
+// The spatial tests of a step, once: the passes below ask about the same goals at the same position up to three times
+// (each answer a square root and a division-free comparison on float64, a line-of-sight loop behind it), and which of
+// them a pass asks about is list logic that does not change the answers.  Sequential order only ever looks at the head,
+// and at most two heads per step (the step's pass and the late pass).
+__device__ __forceinline__ uint64_t goals_met(const TaskArgs& a, lds_f64_ptr goals, const Lane& L) {
+  uint64_t met = 0;
+  const int n = (a.goalorder == RIAB_GOALORDER_SEQUENTIAL && L.n_goals > 2) ? 2 : L.n_goals;
+  u128 l = L.list;
+  for (int g = 0; g < n; ++g) {
+    const int v = (int)((uint32_t)l & 0xFFu);
+    l >>= 8;
+    if (v != 0xFE && in_goal_radius(a, L.px, L.py, goals + v * RIAB_GOAL_COLS)) met |= 1ull << v;
+  }
+  return met;
+}
+
+__device__ __forceinline__ bool goal_met(const TaskArgs& a, lds_f64_ptr goals, const Lane& L, int src, double t_env) {
   if (src == RIAB_GOAL_TIME_ELAPSED)  // TimeElapsedGoal.check (:1271-1278)
     return t_env - L.pad_start >= a.terminate_delay;
-  return in_goal_radius(a, L.px, L.py, goals + src * RIAB_GOAL_COLS);
+  return (L.met >> src) & 1ull;  // SpatialGoal.check: goals_met's answer
 }
 
 // One GoalCache.check(remove_finished=True) for the lane (:1076-1152); returns goals consumed.
@@ -184,16 +208,23 @@ __device__ int check_pass(const TaskArgs& a, lds_f64_ptr goals, int64_t b, Lane&
     }
     return done;
   }
+  // (shifts of a 128-bit value by a variable count are a dozen instructions each; this walk only shifts by constants:
+  // `rest` = the list from slot g on, `below` = one bit at slot g's byte)
   int g = 0;
+  u128 rest = L.list, below = 1;
   while (g < L.n_goals) {  // :1130-1141: g advances after a pop too, so the goal that slid into slot g waits a pass
-    const int src = list_get(L.list, g);
+    const int v = (int)((uint32_t)rest & 0xFFu);
+    const int src = v == 0xFE ? RIAB_GOAL_TIME_ELAPSED : v;
     if (goal_met(a, goals, L, src, t_env)) {
       award(a, goals, b, L, src, diag);
-      L.list = list_pop(L.list, g);
+      L.list = (L.list & (below - 1)) | ((L.list >> 8) & ~(below - 1));  // GoalCache.pop (:1154-1172) of slot g
       L.n_goals -= 1;
       L.list_dirty = true;
       done += 1;
+      rest >>= 8;  // (the goal that slid into slot g)
     }
+    rest >>= 8;
+    below <<= 8;
     g += 1;
   }
   return done;
@@ -218,11 +249,11 @@ __device__ __forceinline__ void load_rewards(const TaskArgs& a, int64_t b, Rewar
   }
 }
 
-__device__ double rewards_update(const TaskArgs& a, lds_f64_ptr goals, int64_t b, Lane& L, const RewardRows& pre) {
+__device__ double rewards_update(const TaskArgs& a, lds_f64_ptr goals, int64_t b, int& n_rw, const RewardRows& pre) {
   double total = 0.0;
   int w = 0;
   bool skip = false;  // the previous reward expired: this one is carried over untouched
-  const int nr = L.n_rw;
+  const int nr = n_rw;
   auto visit = [&](int i, double state, double expire, double srcd) {
     if (skip) {
       ts_at(a, RIAB_TS_RW_STATE + w, b) = state;
@@ -252,67 +283,72 @@ __device__ double rewards_update(const TaskArgs& a, lds_f64_ptr goals, int64_t b
     if (i < nr) visit(i, pre.state[i], pre.expire[i], pre.src[i]);
   for (int i = RW_PRE; i < nr; ++i)
     visit(i, ts_at(a, RIAB_TS_RW_STATE + i, b), ts_at(a, RIAB_TS_RW_EXPIRE + i, b), ts_at(a, RIAB_TS_RW_SRC + i, b));
-  L.n_rw = w;
+  n_rw = w;
   return total;
 }
 
+// The reward cache's share of TaskEnvironment.step — RewardCache.update and the step counters — as a unit of its own:
+// it needs nothing of the step's motion (not the position, not the goals' state), so a caller with idle lanes runs it
+// BESIDE the motion step (the one-launch step, riab_step1.hip: the workgroup's noise-drawing waves) and hands the lane
+// that keeps the goals two numbers: how many rewards are still alive, and their total.
+struct RewardsIn {
+  int n_rw;
+  RewardRows pre;
+  double steps_active, steps_inactive;
+};
+__device__ __forceinline__ RewardsIn load_rewards_in(const TaskArgs& a, int64_t b) {
+  RewardsIn in;
+  in.n_rw = (int)ts_at(a, RIAB_TS_N_REWARDS, b);
+  load_rewards(a, b, in.pre);
+  in.steps_active = ts_at(a, RIAB_TS_STEPS_ACTIVE, b);
+  in.steps_inactive = ts_at(a, RIAB_TS_STEPS_INACTIVE, b);
+  return in;
+}
+struct RewardsOut {
+  int n_rw;
+  double total;
+};
+__device__ __forceinline__ RewardsOut rewards_step(const TaskArgs& a, lds_f64_ptr goals, int64_t b, const RewardsIn& in) {
+  RewardsOut o = {in.n_rw, 0.0};
+  if (in.n_rw > 0) {
+    o.total = rewards_update(a, goals, b, o.n_rw, in.pre);
+    ts_at(a, RIAB_TS_STEPS_ACTIVE, b) = in.steps_active + 1.0;
+  } else {
+    ts_at(a, RIAB_TS_STEPS_INACTIVE, b) = in.steps_inactive + 1.0;
+  }
+  return o;
+}
+
 // TaskEnvironment.reset for one lane (:307-351, GoalCache.reset :1218-1252): episode bookkeeping in
-// memory, goal list / position in the lane's registers.
-__device__ void reset_lane(const TaskArgs& a, const ResetArgs& r, int64_t b, Lane& L, double t_env, int32_t* diag) {
-  atomicAdd(diag + RIAB_TD_RESETS, 1);
+// memory, goal list / position in the lane's registers.  In three parts, so that nothing a reset needs from memory sits
+// on a step's critical path (a closed-loop step is one dependent chain, and at 4096 lanes some lane ends an episode in
+// nearly every step): what it reads was fetched with the lane's first batch of loads (ResetIn), the slot of the episode
+// table — an atomic with a return value, a round trip of its own — is asked for in part 1 and used in part 3, which the
+// caller runs last.  The parts' stores do not overlap: any order gives the same memory.
+struct ResetIn {  // the lane's episode bookkeeping rows
+  double any_ended, started, ep_start, episode;
+};
+__device__ __forceinline__ ResetIn load_reset(const TaskArgs& a, int64_t b) {
+  return {ts_at(a, RIAB_TS_EP_ANY_ENDED, b), ts_at(a, RIAB_TS_STARTED, b), ts_at(a, RIAB_TS_EP_START, b), ts_at(a, RIAB_TS_EPISODE, b)};
+}
+// What a reset draws — where the lane is teleported to, which goals its next episode has — is a function of (seed, reset
+// counter, agent id) alone: a caller with idle lanes draws it for every lane ahead of time (two Philox blocks and a
+// sampling loop off the critical path of the lanes that do end an episode).
+struct ResetDraw {
+  double x, y;
+  u128 list;
+};
+__device__ __forceinline__ ResetDraw reset_draw(const TaskArgs& a, const ResetArgs& r, int64_t b) {
+  ResetDraw d = {0.0, 0.0, 0};
   const uint64_t id = (uint64_t)(r.agent_id0 + b);
-  // ---- write_end_episode (:536-539) + the episode counter (:333-338)
-  bool zero_duration = false;
-  bool any_ended = ts_at(a, RIAB_TS_EP_ANY_ENDED, b) != 0.0;
-  if (ts_at(a, RIAB_TS_STARTED, b) != 0.0) {
-    const double start = ts_at(a, RIAB_TS_EP_START, b);
-    const double duration = t_env - start;
-    zero_duration = duration == 0.0;
-    if (!zero_duration) {  // a zero-duration episode is popped again right away (:333-335)
-      any_ended = true;
-      ts_at(a, RIAB_TS_EP_ANY_ENDED, b) = 1.0;
-      if (r.ep_log) {
-        const int slot = atomicAdd(r.ep_count, 1);
-        if (slot < r.ep_log_cap) {
-          double* e = r.ep_log + (int64_t)slot * 5;
-          e[0] = (double)id;
-          e[1] = ts_at(a, RIAB_TS_EPISODE, b);
-          e[2] = start;
-          e[3] = t_env;
-          e[4] = duration;
-        } else {
-          atomicAdd(diag + RIAB_TD_EPLOG_OVERFLOW, 1);
-        }
-      }
-    }
+  if (r.teleport && !r.new_x) {  // sample_positions(1), "uniform_jitter": the centre of the box +- 0.45 * scale (Philox block 0)
+    const u32x4 rnd = philox4x32_10((uint32_t)r.counter, (uint32_t)(r.counter >> 32), (uint32_t)id, RIAB_TAG_TASK,
+                                    (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+    const double ux = ((double)rnd.x + 0.5) * 0x1.0p-32, uy = ((double)rnd.y + 0.5) * 0x1.0p-32;
+    d.x = r.cx + (2.0 * ux - 1.0) * r.half;
+    d.y = r.cy + (2.0 * uy - 1.0) * r.half;
   }
-  if (!zero_duration) ts_at(a, RIAB_TS_EPISODE, b) += 1.0;
-  ts_at(a, RIAB_TS_STARTED, b) = 1.0;
-  // _current_episode_start (:526-527): the end of the last kept episode, 0 before any
-  ts_at(a, RIAB_TS_EP_START, b) = any_ended ? t_env : 0.0;
-  // ---- teleport_on_reset (:323-330)
-  if (r.teleport) {
-    double x, y;
-    if (r.new_x) {
-      x = r.new_x[b];
-      y = r.new_y[b];
-    } else {  // sample_positions(1), "uniform_jitter": the centre of the box +- 0.45 * scale (Philox block 0)
-      const u32x4 rnd = philox4x32_10((uint32_t)r.counter, (uint32_t)(r.counter >> 32), (uint32_t)id, RIAB_TAG_TASK,
-                                      (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
-      const double ux = ((double)rnd.x + 0.5) * 0x1.0p-32, uy = ((double)rnd.y + 0.5) * 0x1.0p-32;
-      x = r.cx + (2.0 * ux - 1.0) * r.half;
-      y = r.cy + (2.0 * uy - 1.0) * r.half;
-    }
-    L.px = x;
-    L.py = y;
-    r.pos_x[b] = x;
-    r.pos_y[b] = y;
-    if (r.hist_x) {  // agent.history["pos"][-1] = agent.pos
-      r.hist_x[b] = (float)x;
-      r.hist_y[b] = (float)y;
-    }
-  }
-  // ---- GoalCache.reset (:1218-1252)
+  // GoalCache.reset (:1218-1252)
   const int n = r.n_select < a.n_pool ? r.n_select : a.n_pool;
   u128 list = 0;
   if (r.ordered) {
@@ -339,19 +375,101 @@ __device__ void reset_lane(const TaskArgs& a, const ResetArgs& r, int64_t b, Lan
       list = list_set(list, i, pick);
     }
   }
-  L.list = list;
-  L.n_goals = n;
+  d.list = list;
+  return d;
+}
+struct EpisodeRecord {  // write_end_episode's row, on its way into the table
+  bool pending;
+  int slot;
+  double episode, start, duration;
+};
+
+// part 1: write_end_episode (:536-539), the episode counter (:333-338), teleport_on_reset (:323-330)
+__device__ __forceinline__ EpisodeRecord reset_lane_position(const TaskArgs& a, const ResetArgs& r, int64_t b, Lane& L, const ResetIn& in,
+                                                             const ResetDraw& d, double t_env, int32_t* diag) {
+  atomicAdd(diag + RIAB_TD_RESETS, 1);
+  const uint64_t id = (uint64_t)(r.agent_id0 + b);
+  EpisodeRecord rec = {false, 0, in.episode, in.ep_start, 0.0};
+  bool zero_duration = false;
+  bool any_ended = in.any_ended != 0.0;
+  if (in.started != 0.0) {
+    const double duration = t_env - in.ep_start;
+    zero_duration = duration == 0.0;
+    if (!zero_duration) {  // a zero-duration episode is popped again right away (:333-335)
+      any_ended = true;
+      ts_at(a, RIAB_TS_EP_ANY_ENDED, b) = 1.0;
+      if (r.ep_log) {
+        rec.pending = true;
+        rec.duration = duration;
+        // (the counter's address goes through an opaque register: for an address it can prove uniform the compiler
+        // folds the lanes' requests into one and waits for the answer on the spot — the round trip this split is for)
+        uintptr_t counter = (uintptr_t)r.ep_count;
+        asm volatile("" : "+v"(counter));
+        rec.slot = __hip_atomic_fetch_add((__attribute__((address_space(1))) int*)counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  if (!zero_duration) ts_at(a, RIAB_TS_EPISODE, b) = in.episode + 1.0;
+  ts_at(a, RIAB_TS_STARTED, b) = 1.0;
+  // _current_episode_start (:526-527): the end of the last kept episode, 0 before any
+  ts_at(a, RIAB_TS_EP_START, b) = any_ended ? t_env : 0.0;
+  if (r.teleport) {
+    double x, y;
+    if (r.new_x) {
+      x = r.new_x[b];
+      y = r.new_y[b];
+    } else {
+      x = d.x;
+      y = d.y;
+    }
+    L.px = x;
+    L.py = y;
+    if (r.pos_x) {  // (null: the caller stores the position it is handed back — the one-launch step, riab_step1.hip)
+      r.pos_x[b] = x;
+      r.pos_y[b] = y;
+    }
+    if (r.hist_x) {  // agent.history["pos"][-1] = agent.pos
+      r.hist_x[b] = (float)x;
+      r.hist_y[b] = (float)y;
+    }
+  }
+  return rec;
+}
+
+// part 2: GoalCache.reset (:1218-1252)
+__device__ __forceinline__ void reset_lane_goals(const TaskArgs& a, const ResetArgs& r, Lane& L, const ResetDraw& d) {
+  L.list = d.list;
+  L.n_goals = r.n_select < a.n_pool ? r.n_select : a.n_pool;
   L.list_dirty = true;
   L.delayed = false;
+}
+
+// part 3: the episode's row into the table (the slot has had the rest of the lane's work to arrive)
+__device__ __forceinline__ void episode_log_store(const ResetArgs& r, int64_t b, const EpisodeRecord& rec, double t_env, int32_t* diag) {
+  if (!rec.pending) return;
+  if (rec.slot < r.ep_log_cap) {
+    double* e = r.ep_log + (int64_t)rec.slot * 5;
+    e[0] = (double)(uint64_t)(r.agent_id0 + b);
+    e[1] = rec.episode;
+    e[2] = rec.start;
+    e[3] = t_env;
+    e[4] = rec.duration;
+  } else {
+    atomicAdd(diag + RIAB_TD_EPLOG_OVERFLOW, 1);
+  }
 }
 
 // get_goal_vector (:1555-1584): goal - position for the head of the list (sequential) or the nearest
 // pending spatial goal; (0,0) when none is pending.  scale > 0: scale * unit vector instead (the
 // scripted policy of the reference's test loop, :1599-1605, with its NaN -> 0 of :403-404).
-__device__ void goal_vector(const TaskArgs& a, lds_f64_ptr goals, const Lane& L, double scale, double* vx_out, double* vy_out) {
+__device__ __forceinline__ void goal_vector(const TaskArgs& a, lds_f64_ptr goals, const Lane& L, double scale, double& vx_out,
+                                            double& vy_out) {
   double vx = 0.0, vy = 0.0, best = INFINITY;
+  u128 rest = L.list;
   for (int g = 0; g < L.n_goals; ++g) {
-    const int src = list_get(L.list, g);
+    const int v = (int)((uint32_t)rest & 0xFFu);
+    const int src = v == 0xFE ? RIAB_GOAL_TIME_ELAPSED : v;
+    rest >>= 8;
     if (src < 0) {
       if (a.goalorder == RIAB_GOALORDER_SEQUENTIAL) break;
       continue;
@@ -371,54 +489,82 @@ __device__ void goal_vector(const TaskArgs& a, lds_f64_ptr goals, const Lane& L,
     vx = nrm > 0.0 ? scale * (vx / nrm) : 0.0;
     vy = nrm > 0.0 ? scale * (vy / nrm) : 0.0;
   }
-  *vx_out = vx;
-  *vy_out = vy;
+  vx_out = vx;
+  vy_out = vy;
 }
 
 // MODE bit 0: TaskEnvironment.step; bit 1: reset the lanes selected by `mask` (terminal lanes when
 // fused with the step); bit 2: write the goal vector of the (possibly reset) lane.
-template <int MODE>
-__device__ __forceinline__ void task_body(const TaskArgs& a, const ResetArgs& r, const double* pos_x, const double* pos_y,
-                                          double t_env, double* reward_out, uint8_t* terminal_out, const uint8_t* mask,
-                                          double gv_scale, double* gv_x, double* gv_y, int32_t* diag) {
-  constexpr bool STEP = MODE & 1, RESET = MODE & 2, GOALVEC = MODE & 4;
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  // the goal pool (<= 4 KB) goes to LDS with the first batch of loads: goal rows and reward templates
-  // are then ~100 ns away instead of one more global round trip per check pass / cached reward
-  __shared__ double s_goals[RIAB_TASK_MAX_POOL * RIAB_GOAL_COLS];
-  for (int i = threadIdx.x; i < a.n_pool * RIAB_GOAL_COLS; i += 64) s_goals[i] = a.goals[i];
-  const bool live = b < a.B && !(RESET && !STEP && mask && !mask[b]);
-  // ---- one batch of independent loads
+//
+// task_lane_load / load_rewards_in, rewards_step, task_lane_goals, task_lane_reset, task_lane_finish, episode_log_store:
+// the bookkeeping of ONE lane `b` whose
+// position is handed in (and handed back: a reset with teleport_on_reset moves it), with the goal pool already staged in
+// LDS — no barrier, no dependence on how the caller's workgroup is shaped.  task_body (the stand-alone kernel and the
+// motion + task launch) stages the pool and calls them back to back with the position the state holds; the one-launch
+// closed-loop step (riab_step1.hip) calls them from the workgroup that writes a segment's state, with the position its
+// motion step has just computed, and does its own work in between.  Same code, same operands: same bits.
+// What a lane's bookkeeping reads before it can start is ONE batch of independent loads (counts, the 16 list rows, the
+// first reward rows, the reward statistics, the episode rows a reset needs) — issued by the caller as early as it likes
+// (the one-launch step: with its state loads, a whole motion step ahead of the use).
+struct LaneIn {
   Lane L;
-  if (!live) {
-    __syncthreads();
-    return;
+  double rmax, rmin;
+  ResetIn ep;
+};
+template <int MODE>
+__device__ __forceinline__ LaneIn task_lane_load(const TaskArgs& a, int64_t b) {
+  constexpr bool STEP = MODE & 1, RESET = MODE & 2;
+  LaneIn in;
+  in.L.n_goals = (int)ts_at(a, RIAB_TS_N_GOALS, b);
+  in.L.n_rw = (int)ts_at(a, RIAB_TS_N_REWARDS, b);
+  in.L.delayed = ts_at(a, RIAB_TS_DELAYED, b) != 0.0;
+  in.L.pad_start = ts_at(a, RIAB_TS_PAD_START, b);
+  in.L.px = in.L.py = 0.0;
+  in.L.new_total = 0.0;
+  in.L.met = 0;
+  load_list(a, b, in.L);
+  in.rmax = in.rmin = 0.0;
+  if (STEP) {
+    in.rmax = ts_at(a, RIAB_TS_R_MAX, b);
+    in.rmin = ts_at(a, RIAB_TS_R_MIN, b);
   }
-  L.n_goals = (int)ts_at(a, RIAB_TS_N_GOALS, b);
-  L.n_rw = (int)ts_at(a, RIAB_TS_N_REWARDS, b);
-  L.delayed = ts_at(a, RIAB_TS_DELAYED, b) != 0.0;
-  L.pad_start = ts_at(a, RIAB_TS_PAD_START, b);
-  L.px = pos_x[b];
-  L.py = pos_y[b];
-  L.new_total = 0.0;
-  load_list(a, b, L);
-  RewardRows pre;
-  if (STEP) load_rewards(a, b, pre);
-  __syncthreads();
-  const lds_f64_ptr goals = (lds_f64_ptr)s_goals;
-  const int n_goals0 = L.n_goals, n_rw0 = L.n_rw;
-  const bool delayed0 = L.delayed;
+  in.ep = ResetIn{0.0, 0.0, 0.0, 0.0};
+  if (RESET) in.ep = load_reset(a, b);
+  return in;
+}
+// ... in three calls: task_lane_goals (the step's goal checks and reward total; `ro`: rewards_step's result for the lane),
+// task_lane_reset (leaves the lane's position final — what a caller that shares it with others wants to know first;
+// `draw()`: the lane's ResetDraw, asked for only by a lane that resets), task_lane_finish (what is left); LaneMid
+// carries the state between them.
+struct NoProbe {  // (tools/step1_profile.py hands in one that reads the clock)
+  __device__ __forceinline__ void operator()(int) const {}
+};
+struct LaneMid {
+  int n_goals0, n_rw0;
+  bool delayed0, reset;
+  EpisodeRecord rec;
+  u128 new_list;
+};
+template <int MODE, class Probe = NoProbe>
+__device__ __forceinline__ LaneMid task_lane_goals(const TaskArgs& a, int64_t b, lds_f64_ptr goals, LaneIn& in, const RewardsOut& ro,
+                                                   double px, double py, double t_env, double* reward_out, uint8_t* terminal_out,
+                                                   int32_t* diag, const Probe& probe = Probe()) {
+  constexpr bool STEP = MODE & 1, RESET = MODE & 2;
+  Lane& L = in.L;
+  L.px = px;
+  L.py = py;
+  LaneMid mid = {L.n_goals, L.n_rw, L.delayed, false, {false, 0, 0.0, 0.0, 0.0}, 0};
   bool terminal_last = false;
   if (STEP) {
-    const double rmax = ts_at(a, RIAB_TS_R_MAX, b), rmin = ts_at(a, RIAB_TS_R_MIN, b);
-    const double steps_active = ts_at(a, RIAB_TS_STEPS_ACTIVE, b), steps_inactive = ts_at(a, RIAB_TS_STEPS_INACTIVE, b);
-    // ---- RewardCache.update (:913-927)
-    double total = 0.0;
-    if (n_rw0 > 0) total = rewards_update(a, goals, b, L, pre);
-    if (n_rw0 > 0) ts_at(a, RIAB_TS_STEPS_ACTIVE, b) = steps_active + 1.0;
-    else ts_at(a, RIAB_TS_STEPS_INACTIVE, b) = steps_inactive + 1.0;
+    const double rmax = in.rmax, rmin = in.rmin;
+    // ---- RewardCache.update (:913-927): done (rewards_step)
+    double total = ro.total;
+    L.n_rw = ro.n_rw;
+    probe(8);
     // ---- goals: _is_terminal_state (:278-290) as step() calls it (:418-440)
+    L.met = goals_met(a, goals, L);
     check_pass(a, goals, b, L, t_env, diag);
+    probe(9);
     bool terminal = L.n_goals == 0;
     if (terminal && a.terminate_delay != 0.0 && !L.delayed) {
       // :421-434: one unrewarded TimeElapsedGoal pads the episode
@@ -430,6 +576,7 @@ __device__ __forceinline__ void task_body(const TaskArgs& a, const ResetArgs& r,
       check_pass(a, goals, b, L, t_env, diag);
       terminal = L.n_goals == 0;
     }
+    probe(10);
     const int late = check_pass(a, goals, b, L, t_env, diag);  // the pass of the `for agent, term in ...` loop (:438)
     terminal_last = L.n_goals == 0;
     if (late > 0 && terminal_last && !terminal) atomicAdd(diag + RIAB_TD_LATE_COMPLETIONS, 1);
@@ -441,18 +588,82 @@ __device__ __forceinline__ void task_body(const TaskArgs& a, const ResetArgs& r,
     reward_out[b] = total;
     terminal_out[b] = terminal_last ? 1 : 0;
   }
-  if (RESET && (STEP ? terminal_last : true)) reset_lane(a, r, b, L, t_env, diag);
-  if (GOALVEC) goal_vector(a, goals, L, gv_scale, gv_x + b, gv_y + b);
+  probe(11);
+  mid.reset = RESET && (STEP ? terminal_last : true);
+  return mid;
+}
+template <int MODE, class Draw>
+__device__ __forceinline__ void task_lane_reset(const TaskArgs& a, const ResetArgs& r, int64_t b, LaneIn& in, LaneMid& mid, double& px,
+                                                double& py, double t_env, int32_t* diag, const Draw& draw) {
+  constexpr bool RESET = MODE & 2;
+  if (RESET && mid.reset) {
+    const ResetDraw d = draw();
+    mid.new_list = d.list;
+    mid.rec = reset_lane_position(a, r, b, in.L, in.ep, d, t_env, diag);
+    px = in.L.px;  // (moved by a reset that teleports)
+    py = in.L.py;
+  }
+}
+template <int MODE, class Probe = NoProbe>
+__device__ __forceinline__ void task_lane_finish(const TaskArgs& a, const ResetArgs& r, int64_t b, lds_f64_ptr goals, LaneIn& in,
+                                                 const LaneMid& mid, double gv_scale, double& gvx, double& gvy,
+                                                 const Probe& probe = Probe()) {
+  constexpr bool STEP = MODE & 1, RESET = MODE & 2, GOALVEC = MODE & 4;
+  Lane& L = in.L;
+  if (RESET && mid.reset) reset_lane_goals(a, r, L, ResetDraw{0.0, 0.0, mid.new_list});
+  probe(13);
+  if (GOALVEC) goal_vector(a, goals, L, gv_scale, gvx, gvy);  // (handed back: the caller stores it)
+  probe(14);
   // ---- write back what changed
   if (STEP || RESET) {
-    if (L.n_goals != n_goals0) ts_at(a, RIAB_TS_N_GOALS, b) = (double)L.n_goals;
-    if (L.n_rw != n_rw0) ts_at(a, RIAB_TS_N_REWARDS, b) = (double)L.n_rw;
-    if (L.delayed != delayed0) {
+    if (L.n_goals != mid.n_goals0) ts_at(a, RIAB_TS_N_GOALS, b) = (double)L.n_goals;
+    if (L.n_rw != mid.n_rw0) ts_at(a, RIAB_TS_N_REWARDS, b) = (double)L.n_rw;
+    if (L.delayed != mid.delayed0) {
       ts_at(a, RIAB_TS_DELAYED, b) = L.delayed ? 1.0 : 0.0;
       if (L.delayed) ts_at(a, RIAB_TS_PAD_START, b) = L.pad_start;
     }
     if (L.list_dirty) store_list(a, b, L);
   }
+}
+
+// the goal pool (<= 4 KB) into LDS, by any number of threads of the workgroup; the caller synchronises
+__device__ __forceinline__ void task_stage_goals(const TaskArgs& a, double* s_goals, int tid, int nthreads) {
+  for (int i = tid; i < a.n_pool * RIAB_GOAL_COLS; i += nthreads) s_goals[i] = a.goals[i];
+}
+
+template <int MODE>
+__device__ __forceinline__ void task_body(const TaskArgs& a, const ResetArgs& r, const double* pos_x, const double* pos_y,
+                                          double t_env, double* reward_out, uint8_t* terminal_out, const uint8_t* mask,
+                                          double gv_scale, double* gv_x, double* gv_y, int32_t* diag) {
+  constexpr bool STEP = MODE & 1, RESET = MODE & 2;
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  // the goal pool goes to LDS with the first batch of loads: goal rows and reward templates
+  // are then ~100 ns away instead of one more global round trip per check pass / cached reward
+  __shared__ double s_goals[RIAB_TASK_MAX_POOL * RIAB_GOAL_COLS];
+  task_stage_goals(a, s_goals, (int)threadIdx.x, 64);
+  const bool live = b < a.B && !(RESET && !STEP && mask && !mask[b]);
+  double px = 0.0, py = 0.0;
+  LaneIn in;
+  RewardsIn rin;
+  if (live) {  // (one batch of independent loads, in flight together with the pool's)
+    in = task_lane_load<MODE>(a, b);
+    if (STEP) rin = load_rewards_in(a, b);
+    px = pos_x[b];
+    py = pos_y[b];
+  }
+  __syncthreads();
+  if (!live) return;
+  double gvx = 0.0, gvy = 0.0;
+  RewardsOut ro = {0, 0.0};
+  if (STEP) ro = rewards_step(a, (lds_f64_ptr)s_goals, b, rin);
+  LaneMid mid = task_lane_goals<MODE>(a, b, (lds_f64_ptr)s_goals, in, ro, px, py, t_env, reward_out, terminal_out, diag);
+  task_lane_reset<MODE>(a, r, b, in, mid, px, py, t_env, diag, [&]() { return reset_draw(a, r, b); });
+  task_lane_finish<MODE>(a, r, b, (lds_f64_ptr)s_goals, in, mid, gv_scale, gvx, gvy);
+  if (MODE & 4) {
+    gv_x[b] = gvx;
+    gv_y[b] = gvy;
+  }
+  if (RESET) episode_log_store(r, b, mid.rec, t_env, diag);
 }
 
 template <int MODE>

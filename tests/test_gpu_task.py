@@ -466,3 +466,84 @@ def test_randomised_task_plans_equal_eager_loop(riab, seed):
     assert e1.episodes == e2.episodes and e1.t == e2.t and e1.diagnostics == e2.diagnostics
     assert np.array_equal(A1.history["pos"], A2.history["pos"])
     assert np.array_equal(P1.history["firingrate"], P2.history["firingrate"])
+
+
+def _task_world(riab, seed, B, n, teleport, order, delay, pop="place"):
+    n_cells = n
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
+    np.random.seed(seed)
+    env = SpatialGoalEnvironment(params={"walls": [[[0.5, 0.3], [0.5, 0.7]]]},
+                                 possible_goal_positions=[[0.2, 0.25], [0.8, 0.7], [0.5, 0.1], [0.3, 0.8]],
+                                 goalcachekws=dict(reset_n_goals=2, goalorder=order),
+                                 episode_terminate_delay=delay, teleport_on_reset=teleport, seed=seed)
+    Ag = riab.Agent(env, {"dt": 0.01, "n_agents": B, "seed": 4 + seed})
+    if pop == "place":
+        P = riab.PlaceCells(Ag, {"n": n_cells, "wall_geometry": "euclidean", "save_spikes": False})
+    elif pop == "grid":
+        P = riab.GridCells(Ag, {"n": n_cells, "save_spikes": False})
+    else:
+        P = riab.HeadDirectionCells(Ag, {"n": n_cells, "save_spikes": False})
+    env.add_agents(Ag)
+    return env, Ag, P
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=512, n=200, teleport=True, order="sequential", delay=0.03),
+    dict(B=256, n=37, teleport=True, order="nonsequential", delay=0.0),
+    dict(B=1024, n=64, teleport=False, order="sequential", delay=0.1),
+    dict(B=768, n=130, teleport=True, order="nonsequential", delay=0.03, pop="grid"),
+    dict(B=256, n=10, teleport=True, order="sequential", delay=0.0, pop="hdc"),
+    dict(B=512, n=200, teleport=True, order="sequential", delay=0.03, scripted=False),
+    dict(B=512, n=90, teleport=True, order="nonsequential", delay=0.0, auto_reset=False),
+])
+def test_one_launch_task_step_equals_the_two_launch_plan(riab, case):
+    """A task plan whose lead population fuses (csrc/riab_step1.hip, TASK modes): Agent.update, the rest of
+    TaskEnvironment.step, the reset of the lanes that ended an episode (teleports included: the rates of a teleported
+    lane are a function of where it landed), the next scripted action and the population's update() in ONE kernel per
+    step — against the same plan with RIAB_OPT_FUSED_STEP = 0 (motion + task kernel, then the rate kernel), which the
+    tests above pin against the eager loop, the oracle and the reference goldens.  Everything bit for bit."""
+    case = dict(case)
+    scripted, auto_reset = case.pop("scripted", True), case.pop("auto_reset", True)
+    T, speed = 220, 11.0 * 0.08
+
+    def run(fused):
+        old = riab._lib.set_option("fused_step", 1 if fused else 0)
+        try:
+            env, Ag, P = _task_world(riab, 11, **case)
+            plan = env.make_step_plan(auto_reset=auto_reset, scripted_speed=speed if scripted else None)
+            rews, terms = [], []
+            g = torch.Generator(device="cpu").manual_seed(5)
+            for k in range(T):
+                if scripted:
+                    plan.step(1)
+                else:
+                    # (the caller's policy: towards the goal, with noise)
+                    act = env._goal_vector(speed) + (torch.randn(Ag.n_agents, 2, dtype=torch.float64, generator=g) * 0.1).cuda()
+                    plan.step(1, drift_velocity=act)
+                rews.append(env.get_reward().clone())
+                terms.append(env.terminal.clone())
+                if not auto_reset and bool(terms[-1].any()):
+                    env.reset(mask=terms[-1])
+            torch.cuda.synchronize()
+            info = plan.info()
+            fr, _ = P.get_history_tensors()
+            out = dict(rew=torch.stack(rews).cpu().numpy(), term=torch.stack(terms).cpu().numpy(),
+                       state=Ag.state_tensor[:, :Ag.n_agents].cpu().numpy(), ts=env.task_state.cpu().numpy(),
+                       traj=Ag.get_history_tensor().cpu().numpy(), fr=fr.cpu().numpy(), last=np.array(P.firingrate),
+                       action=plan._actions[:, :Ag.n_agents].cpu().numpy())   # (the coming step's scripted action)
+            return out, dict(env.episodes), dict(env.diagnostics), dict(Ag.diagnostics), env.t, info
+        finally:
+            riab._lib.set_option("fused_step", old)
+
+    a, ep_a, d_a, ad_a, t_a, info_a = run(True)
+    b, ep_b, d_b, ad_b, t_b, info_b = run(False)
+    assert info_a["fused_steps"] == T and info_a["launches"] == T, info_a      # one kernel per closed-loop step
+    assert info_b["fused_steps"] == 0
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert ep_a == ep_b and d_a == d_b and ad_a == ad_b and t_a == t_b
+    if auto_reset:
+        assert a["term"].any() and len(ep_a["episode"]) > 3          # episodes ended, lanes were reset ...
+    if case["teleport"] and auto_reset:
+        jumps = np.abs(np.diff(a["traj"][:, 0, :], axis=0)).max()     # ... and teleported (visible in the stored trajectory)
+        assert jumps > 0.05

@@ -11,15 +11,33 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import ratinabox_amd as riab
 
+TASK = "--task" in sys.argv
+if TASK:
+    sys.argv.remove("--task")
 B, n, steps = (int(x) for x in (sys.argv[1:4] + ["4096", "1024", "256"][len(sys.argv) - 1:]))
 np.random.seed(0)
-env = riab.Environment()
+if TASK:  # (bench.py --task's world)
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
+    env = SpatialGoalEnvironment(params={}, possible_goal_positions="random_8", goalcachekws=dict(reset_n_goals=2),
+                                 teleport_on_reset=True, episode_terminate_delay=0.05, seed=1234)
+else:
+    env = riab.Environment()
 ag = riab.Agent(env, {"n_agents": B, "dt": 0.01, "seed": 1234})
 pcs = riab.PlaceCells(ag, {"n": n, "wall_geometry": "euclidean", "save_spikes": False})
+if TASK:
+    env.add_agents(ag)
+
+
+def make_plan():
+    if TASK:
+        return env.make_step_plan(capacity=steps, auto_reset=True, scripted_speed=11 * ag.speed_mean)
+    return ag.make_step_plan(capacity=steps)
+
+
 out = []
 for rep in range(6):
     ag.reset_history(); pcs.reset_history()
-    plan = ag.make_step_plan(capacity=steps)
+    plan = make_plan()
     plan.step(8)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
