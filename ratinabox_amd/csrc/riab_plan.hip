@@ -30,12 +30,12 @@ int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* 
 int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
 int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
                  uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, hipStream_t s);
-int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint64_t seed,
-                      uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, const RiabTask* task,
-                      double* task_state, int64_t task_B, double t_env, double* reward_out, uint8_t* terminal_out, int32_t* diag,
-                      bool auto_reset, int32_t n_select, int32_t ordered, uint64_t task_seed, uint64_t counter, int32_t teleport,
-                      double* ep_log, int64_t ep_log_cap, int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y,
-                      hipStream_t s);
+int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
+                      uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready,
+                      const RiabTask* task, double* task_state, int64_t task_B, double t_env, double* reward_out,
+                      uint8_t* terminal_out, int32_t* diag, bool auto_reset, int32_t n_select, int32_t ordered, uint64_t task_seed,
+                      uint64_t counter, int32_t teleport, double* ep_log, int64_t ep_log_cap, int32_t* ep_count, double gv_scale,
+                      double* gv_x, double* gv_y, hipStream_t s, bool query);
 }  // namespace riab
 
 struct RiabPlan {
@@ -84,7 +84,40 @@ struct RiabPlan {
 };
 
 // the population the agent step is fused with: the store-bound one that writes most bytes per row (-1: none)
-// (a plan with a task: whole-plan steps only, motion + task fused (RIAB_OPT_FUSED_TASK), a lead without spikes)
+// One closed-loop step of a plan with a task as ONE kernel: Agent.update(), the rest of TaskEnvironment.step (+ the caller's
+// `if terminal: reset()`, + the next scripted action) and population `lead`'s update().  The caller has advanced the
+// plan's step counter and clock.  `query`: nothing is launched; RIAB_OK when there is a kernel for this plan's step.
+static int fused_task_step(RiabPlan* p, int lead, float* row, hipStream_t s, bool query) {
+  riab::AgentArgs ma;
+  const uint64_t step_before = query ? p->step : p->step - 1;
+  int rc = riab::fill_agent_args(ma, &p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr, p->seed,
+                                 step_before, 1, row, p->diag);
+  if (rc) return rc;
+  const bool scripted = p->scripted_speed > 0.0;
+  double* act = const_cast<double*>(p->drift);
+  if (scripted && (!act || !p->motion.has_drift)) return RIAB_EINVAL;
+  const RiabPopulation& q = p->pops[lead];
+  const int64_t r = q.capacity_rows > 0 ? p->pop_fill[lead] : 0;
+  const int64_t row_elems = (int64_t)q.n * p->B;
+  uint32_t epoch = 1u;
+  if (!query) {
+    p->epoch += 1u;
+    if (p->epoch == 0u) p->epoch = 1u;
+    epoch = p->epoch;
+  }
+  rc = riab::launch_step1_task(ma, &p->env, &q, q.rates_base + r * row_elems, q.spikes_base ? q.spikes_base + r * row_elems : nullptr,
+                               p->seed, step_before + 1, p->sync_words, epoch, &p->walls_ready, &p->task, p->task_state, p->task_B,
+                               p->t_env, p->reward_out, p->terminal_out, p->task_diag, p->auto_reset != 0, p->n_select, p->ordered,
+                               p->task_seed, p->reset_counter, p->teleport, p->ep_log, p->ep_log_cap, p->ep_count,
+                               p->scripted_speed, scripted ? act : nullptr, scripted ? act + p->B : nullptr, s, query);
+  if (rc == RIAB_OK && !query) {
+    p->fused_steps += 1;
+    p->launches += 1;
+  }
+  return rc;
+}
+
+// (a plan with a task: whole-plan steps only, motion + task fused (RIAB_OPT_FUSED_TASK))
 static int plan_lead(RiabPlan* p, bool whole_step = false) {
   if (!p->sync_words || riab::g_options[RIAB_OPT_FUSED_STEP] == 0 || p->forced) return -1;
   if (p->has_task && (!whole_step || riab::g_options[RIAB_OPT_FUSED_TASK] == 0)) return -1;
@@ -94,7 +127,7 @@ static int plan_lead(RiabPlan* p, bool whole_step = false) {
     for (size_t i = 0; i < p->pops.size(); ++i) {
       const RiabPopulation& q = p->pops[i];
       if (riab::step1_supported(&p->env, &q, p->B) != RIAB_OK) continue;
-      if (p->has_task && q.spikes_base) continue;
+      if (p->has_task && fused_task_step(p, (int)i, p->row_scratch, nullptr, true) != RIAB_OK) continue;
       const int64_t bytes = (int64_t)q.n * (q.spikes_base ? 5 : 4);
       if (bytes > best_bytes) {
         best = (int)i;
@@ -483,17 +516,8 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
       if (p->auto_reset) p->reset_counter += 1;
       if (lead >= 0) {  // ... and the lead population's update() as well: the whole closed-loop step is one kernel
         const RiabPopulation& q = p->pops[lead];
-        const int64_t r = q.capacity_rows > 0 ? p->pop_fill[lead] : 0;
-        p->epoch += 1u;
-        if (p->epoch == 0u) p->epoch = 1u;
-        rc = riab::launch_step1_task(ma, &p->env, &q, q.rates_base + r * (int64_t)q.n * p->B, p->seed, p->step, p->sync_words,
-                                     p->epoch, &p->walls_ready, &p->task, p->task_state, p->task_B, p->t_env, p->reward_out,
-                                     p->terminal_out, p->task_diag, p->auto_reset != 0, p->n_select, p->ordered, p->task_seed,
-                                     p->reset_counter, p->teleport, p->ep_log, p->ep_log_cap, p->ep_count, p->scripted_speed,
-                                     scripted ? act : nullptr, scripted ? act + p->B : nullptr, s);
+        rc = fused_task_step(p, lead, row, s, false);
         if (rc) return rc;
-        p->fused_steps += 1;
-        p->launches += 1;
         p->action_ready = scripted;
         if (q.capacity_rows > 0) p->pop_fill[lead] += 1;
         for (size_t i = 0; i < p->pops.size(); ++i) {

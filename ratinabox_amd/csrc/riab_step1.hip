@@ -592,14 +592,14 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
   step1_body<Cell, SPK, CPB, NT, 0>(a, ra, cell, sy, reps, hk, tail_c, none);
 }
 
-template <class Cell, int CPB, bool NT, int TASK>
+template <class Cell, int SPK, int CPB, bool NT, int TASK>
 __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_task_kernel(const AgentArgs a, const RateArgs ra,
                                                                                                 Cell cell, const Step1Sync sy,
                                                                                                 const int reps,
                                                                                                 const MotionConst<double> hk,
                                                                                                 const TailConst<double> tail_c,
                                                                                                 const Step1Task tk) {
-  step1_body<Cell, 0, CPB, NT, TASK>(a, ra, cell, sy, reps, hk, tail_c, tk);
+  step1_body<Cell, SPK, CPB, NT, TASK>(a, ra, cell, sy, reps, hk, tail_c, tk);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
@@ -623,7 +623,7 @@ static void step1_shape(int64_t B, int n, int cpb, bool task, dim3* grid, int* r
 
 template <class Cell>
 static int launch_step1_cell(const AgentArgs& a, const RateArgs& ra, const Cell& cell, const Step1Sync& sy, bool spikes,
-                             bool nt, hipStream_t s, const Step1Task* tk, int task_mode) {
+                             bool nt, hipStream_t s, const Step1Task* tk, int task_mode, bool query) {
   constexpr int CPB = (Cell::NP * 2 * Cell::CPB <= 64) ? 2 * Cell::CPB : Cell::CPB;  // (as the row-following kernel)
   // (task: 15 of a segment's 16 workgroups write rates — a cell group a sixteenth larger keeps a population that filled
   // one round of workgroups in one round: cfg 2, 1024 cells: 114 groups of 9 on 15 x 8 waves instead of 128 of 8 on 16 x 8)
@@ -636,20 +636,33 @@ static int launch_step1_cell(const AgentArgs& a, const RateArgs& ra, const Cell&
   motion_const_scalars<double>(hk, a);
   const TailConst<double> tc = {a.m.dt, hk.inv_dt, 1.0 - a.m.dt / a.m.hd_tau, a.m.dt / a.m.hd_tau, a.m.hd_tau <= a.m.dt};
   const dim3 block(64 * RIAB_S1_WAVES);
-  if (tk) {  // (no spikes, non-temporal stores; TASK = task_kernel's MODE)
-    if (spikes) return RIAB_EUNSUPPORTED;
-#define RIAB_S1_TASK(MODE) \
-  hipLaunchKernelGGL((step1_task_kernel<Cell, CPB_T, true, MODE>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc, *tk)
+  if (tk) {  // (non-temporal stores; TASK = task_kernel's MODE)
+    // a kernel the register allocator gave a stack frame (a few bytes of spilled scalars, never touched) would have the
+    // dispatcher set scratch memory up for every launch — more than the fusion saves: such an instantiation is not used
+    auto launch = [&](auto kernel) -> int {
+      static int frame = -1;  // (per instantiation)
+      if (frame < 0) {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) != hipSuccess) return RIAB_EUNSUPPORTED;
+        frame = (int)fa.localSizeBytes;
+      }
+      if (frame > 0) return RIAB_EUNSUPPORTED;
+      if (query) return RIAB_OK;
+      hipLaunchKernelGGL(kernel, grid, block, 0, s, a, ra, cell, sy, reps, hk, tc, *tk);
+      return (int)hipGetLastError();
+    };
+#define RIAB_S1_TASK(MODE)                                                                     \
+  return spikes ? launch(step1_task_kernel<Cell, 1, CPB_T, true, MODE>) : launch(step1_task_kernel<Cell, 0, CPB_T, true, MODE>)
     switch (task_mode) {
-      case 1: RIAB_S1_TASK(1); break;
-      case 3: RIAB_S1_TASK(3); break;
-      case 5: RIAB_S1_TASK(5); break;
-      case 7: RIAB_S1_TASK(7); break;
+      case 1: RIAB_S1_TASK(1);
+      case 3: RIAB_S1_TASK(3);
+      case 5: RIAB_S1_TASK(5);
+      case 7: RIAB_S1_TASK(7);
       default: return RIAB_EINVAL;
     }
 #undef RIAB_S1_TASK
-    return (int)hipGetLastError();
   }
+  if (query) return RIAB_OK;
   if (spikes) {
     if (nt) hipLaunchKernelGGL((step1_kernel<Cell, 1, CPB, true>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc);
     else hipLaunchKernelGGL((step1_kernel<Cell, 1, CPB, false>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc);
@@ -681,7 +694,7 @@ int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B) {
 // taken once this one is done (Neurons.update's spike counter, as riab_plan_step passes it)
 static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row,
                              uint8_t* spikes_row, uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch,
-                             bool* walls_ready, hipStream_t s, const Step1Task* tk, int task_mode) {
+                             bool* walls_ready, hipStream_t s, const Step1Task* tk, int task_mode, bool query = false) {
   const int rc = step1_supported(env, pop, a.B);
   if (rc) return rc;
   if (a.z_in || a.z_out || a.forced || a.T != 1 || !sync_words || !rates_row || epoch == 0u) return RIAB_EINVAL;
@@ -712,7 +725,7 @@ static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const RiabP
   sy.n_segments = (uint32_t)(a.B / 256);
   Wall<double>* const gw = reinterpret_cast<Wall<double>*>(sync_words + RIAB_STEP1_SYNC_WALLS_AT(a.B));
   sy.walls = gw;
-  if (walls_ready && !*walls_ready) {  // (the plan's first one-launch step, and the first after its motion parameters changed)
+  if (!query && walls_ready && !*walls_ready) {  // (the plan's first one-launch step, and the first after its motion parameters changed)
     hipLaunchKernelGGL(walls_prepare_kernel, dim3(1), dim3(64), 0, s, a, gw);
     *walls_ready = true;
   }
@@ -735,32 +748,32 @@ static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const RiabP
         w.tab = c.tab; w.scale = c.scale; w.half_scale = c.half_scale; w.top_hat_w2 = c.top_hat_w2; w.walls = c.walls;
         w.n_internal = 0; w.e0 = c.e0; w.e1 = c.e1; w.e2 = c.e2; w.e3 = c.e3; w.shape = c.shape; w.lds = nullptr;
         switch (pop->description) {
-          case RIAB_PC_GAUSSIAN: return launch_step1_cell(a, ra, w, sy, spikes, nt, s, tk, task_mode);
-          case RIAB_PC_GAUSSIAN_THRESHOLD: return launch_step1_cell(a, ra, w.as<RIAB_PC_GAUSSIAN_THRESHOLD>(), sy, spikes, nt, s, tk, task_mode);
-          case RIAB_PC_DIFF_OF_GAUSSIANS: return launch_step1_cell(a, ra, w.as<RIAB_PC_DIFF_OF_GAUSSIANS>(), sy, spikes, nt, s, tk, task_mode);
-          case RIAB_PC_TOP_HAT: return launch_step1_cell(a, ra, w.as<RIAB_PC_TOP_HAT>(), sy, spikes, nt, s, tk, task_mode);
+          case RIAB_PC_GAUSSIAN: return launch_step1_cell(a, ra, w, sy, spikes, nt, s, tk, task_mode, query);
+          case RIAB_PC_GAUSSIAN_THRESHOLD: return launch_step1_cell(a, ra, w.as<RIAB_PC_GAUSSIAN_THRESHOLD>(), sy, spikes, nt, s, tk, task_mode, query);
+          case RIAB_PC_DIFF_OF_GAUSSIANS: return launch_step1_cell(a, ra, w.as<RIAB_PC_DIFF_OF_GAUSSIANS>(), sy, spikes, nt, s, tk, task_mode, query);
+          case RIAB_PC_TOP_HAT: return launch_step1_cell(a, ra, w.as<RIAB_PC_TOP_HAT>(), sy, spikes, nt, s, tk, task_mode, query);
           default: return RIAB_EUNSUPPORTED;
         }
       }
       switch (pop->description) {
-        case RIAB_PC_GAUSSIAN: return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode);
-        case RIAB_PC_GAUSSIAN_THRESHOLD: return launch_step1_cell(a, ra, c.as<RIAB_PC_GAUSSIAN_THRESHOLD>(), sy, spikes, nt, s, tk, task_mode);
-        case RIAB_PC_DIFF_OF_GAUSSIANS: return launch_step1_cell(a, ra, c.as<RIAB_PC_DIFF_OF_GAUSSIANS>(), sy, spikes, nt, s, tk, task_mode);
-        case RIAB_PC_TOP_HAT: return launch_step1_cell(a, ra, c.as<RIAB_PC_TOP_HAT>(), sy, spikes, nt, s, tk, task_mode);
+        case RIAB_PC_GAUSSIAN: return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode, query);
+        case RIAB_PC_GAUSSIAN_THRESHOLD: return launch_step1_cell(a, ra, c.as<RIAB_PC_GAUSSIAN_THRESHOLD>(), sy, spikes, nt, s, tk, task_mode, query);
+        case RIAB_PC_DIFF_OF_GAUSSIANS: return launch_step1_cell(a, ra, c.as<RIAB_PC_DIFF_OF_GAUSSIANS>(), sy, spikes, nt, s, tk, task_mode, query);
+        case RIAB_PC_TOP_HAT: return launch_step1_cell(a, ra, c.as<RIAB_PC_TOP_HAT>(), sy, spikes, nt, s, tk, task_mode, query);
         default: return RIAB_EUNSUPPORTED;
       }
     }
     case RIAB_POP_GRID:
       if (pop->description == RIAB_GC_RECTIFIED) {
         GridCell<RIAB_GC_RECTIFIED> c{pop->table, pop->f0, 1.0f / (1.0f - pop->f0)};
-        return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode);
+        return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode, query);
       } else {
         GridCell<RIAB_GC_SHIFTED> c{pop->table, pop->f0, 1.0f};
-        return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode);
+        return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode, query);
       }
     case RIAB_POP_HDC: {
       HDCell<0> c{pop->table, 0.0f, nullptr, nullptr};
-      return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode);
+      return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode, query);
     }
     default: return RIAB_EUNSUPPORTED;
   }
@@ -773,12 +786,13 @@ int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* p
 
 // ... + the rest of TaskEnvironment.step for the first `task_B` lanes: the arguments of launch_motion_task (riab_agent.hip),
 // whose two stages this replaces together with the lead population's launch
-int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint64_t seed,
-                      uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, const RiabTask* task,
+// (`query`: nothing is launched; RIAB_OK when this plan's step has a kernel to be launched with)
+int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
+                      uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, const RiabTask* task,
                       double* task_state, int64_t task_B, double t_env, double* reward_out, uint8_t* terminal_out, int32_t* diag,
                       bool auto_reset, int32_t n_select, int32_t ordered, uint64_t task_seed, uint64_t counter, int32_t teleport,
                       double* ep_log, int64_t ep_log_cap, int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y,
-                      hipStream_t s) {
+                      hipStream_t s, bool query) {
   Step1Task tk = {};
   int rc = fill_args(tk.a, env, task, task_state, task_B);
   if (rc) return rc;
@@ -799,7 +813,7 @@ int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const RiabPopulati
   tk.diag = diag;
   tk.mail = sync_words + RIAB_STEP1_SYNC_MAIL_AT(a.B);
   const int mode = 1 | (auto_reset ? 2 : 0) | (gv_x ? 4 : 0);
-  return launch_step1_impl(a, env, pop, rates_row, nullptr, seed, step_after, sync_words, epoch, walls_ready, s, &tk, mode);
+  return launch_step1_impl(a, env, pop, rates_row, spikes_row, seed, step_after, sync_words, epoch, walls_ready, s, &tk, mode, query);
 }
 
 }  // namespace riab

@@ -468,7 +468,7 @@ def test_randomised_task_plans_equal_eager_loop(riab, seed):
     assert np.array_equal(P1.history["firingrate"], P2.history["firingrate"])
 
 
-def _task_world(riab, seed, B, n, teleport, order, delay, pop="place"):
+def _task_world(riab, seed, B, n, teleport, order, delay, pop="place", spikes=False):
     n_cells = n
     from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
     np.random.seed(seed)
@@ -478,9 +478,9 @@ def _task_world(riab, seed, B, n, teleport, order, delay, pop="place"):
                                  episode_terminate_delay=delay, teleport_on_reset=teleport, seed=seed)
     Ag = riab.Agent(env, {"dt": 0.01, "n_agents": B, "seed": 4 + seed})
     if pop == "place":
-        P = riab.PlaceCells(Ag, {"n": n_cells, "wall_geometry": "euclidean", "save_spikes": False})
+        P = riab.PlaceCells(Ag, {"n": n_cells, "wall_geometry": "euclidean", "save_spikes": spikes, "max_fr": 30 if spikes else 1})
     elif pop == "grid":
-        P = riab.GridCells(Ag, {"n": n_cells, "save_spikes": False})
+        P = riab.GridCells(Ag, {"n": n_cells, "save_spikes": spikes, "max_fr": 30 if spikes else 1})
     else:
         P = riab.HeadDirectionCells(Ag, {"n": n_cells, "save_spikes": False})
     env.add_agents(Ag)
@@ -495,6 +495,9 @@ def _task_world(riab, seed, B, n, teleport, order, delay, pop="place"):
     dict(B=256, n=10, teleport=True, order="sequential", delay=0.0, pop="hdc"),
     dict(B=512, n=200, teleport=True, order="sequential", delay=0.03, scripted=False),
     dict(B=512, n=90, teleport=True, order="nonsequential", delay=0.0, auto_reset=False),
+    dict(B=256, n=50, teleport=True, order="sequential", delay=0.03, auto_reset=False, scripted=False),
+    dict(B=512, n=120, teleport=True, order="nonsequential", delay=0.03, spikes=True),     # (the default: save_spikes)
+    dict(B=256, n=33, teleport=True, order="sequential", delay=0.0, pop="grid", spikes=True, scripted=False),
 ])
 def test_one_launch_task_step_equals_the_two_launch_plan(riab, case):
     """A task plan whose lead population fuses (csrc/riab_step1.hip, TASK modes): Agent.update, the rest of
@@ -526,8 +529,8 @@ def test_one_launch_task_step_equals_the_two_launch_plan(riab, case):
                     env.reset(mask=terms[-1])
             torch.cuda.synchronize()
             info = plan.info()
-            fr, _ = P.get_history_tensors()
-            out = dict(rew=torch.stack(rews).cpu().numpy(), term=torch.stack(terms).cpu().numpy(),
+            fr, sp = P.get_history_tensors()
+            out = dict(spikes=np.zeros(1) if sp is None else sp.cpu().numpy(), rew=torch.stack(rews).cpu().numpy(), term=torch.stack(terms).cpu().numpy(),
                        state=Ag.state_tensor[:, :Ag.n_agents].cpu().numpy(), ts=env.task_state.cpu().numpy(),
                        traj=Ag.get_history_tensor().cpu().numpy(), fr=fr.cpu().numpy(), last=np.array(P.firingrate),
                        action=plan._actions[:, :Ag.n_agents].cpu().numpy())   # (the coming step's scripted action)
@@ -544,6 +547,8 @@ def test_one_launch_task_step_equals_the_two_launch_plan(riab, case):
     assert ep_a == ep_b and d_a == d_b and ad_a == ad_b and t_a == t_b
     if auto_reset:
         assert a["term"].any() and len(ep_a["episode"]) > 3          # episodes ended, lanes were reset ...
+    if case.get("spikes"):
+        assert a["spikes"].any()
     if case["teleport"] and auto_reset:
         jumps = np.abs(np.diff(a["traj"][:, 0, :], axis=0)).max()     # ... and teleported (visible in the stored trajectory)
         assert jumps > 0.05
