@@ -475,6 +475,21 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         if fused_mode or native_mode:
             kernel_ms.append(ag.last_rate_kernel_ms())
             kernel_units.append(getattr(ag, "_last_fused_units", B * K))  # (rings: the last ring-length piece of the run)
+    # the closed-loop plans once more with ALL K steps in one native call per region (`plan.step(K)`: no per-step action
+    # from the host, the step kernels back to back at the device's pace) — not part of `value`: how far the one-call-per-
+    # step figure above is from the kernels themselves
+    one_call_us = None
+    if args.plan and not args.per_step and rank == 0 and K > 1:
+        oc = []
+        for _r in range(5):
+            fresh_history(K)
+            prepare()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            plan["p"].step(K)
+            torch.cuda.synchronize()
+            oc.append((time.perf_counter() - t0) / K * 1e6)
+        one_call_us = round(sorted(oc)[len(oc) // 2], 3)
     # cross-check of the device-clock timing of the one-kernel rate stage: a few more regions — not part of `value` —
     # with HIP start / stop events attached to the kernel's launch (what rocprofv3 would report for it)
     event_ms = []
@@ -649,7 +664,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         one = bool(plan_info and plan_info["fused_steps"] > 0)
         traffic = traffic_from = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if one and type(dominant).__name__ == "PlaceCells" and not cfg["spikes"] and os.path.exists(tpath):
+        if one and not args.task and type(dominant).__name__ == "PlaceCells" and not cfg["spikes"] and os.path.exists(tpath):
             with open(tpath) as f:
                 entry = json.load(f).get("kernels", {}).get("step1_kernel")
             if entry:   # (counters are not collected in this run: the committed PMC passes' per-unit figure x this run's units)
@@ -658,7 +673,10 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
                                 "(rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of `bench.py --plan`) x the units of one launch")
         roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from": traffic_from,
-                    "kernel": ("step1_kernel<%s> (Agent.update + Neurons.update in one launch)" % type(dominant).__name__) if one
+                    "kernel": ("step1_task_kernel<%s> (Agent.update + the rest of TaskEnvironment.step + auto-reset + next action + "
+                               "Neurons.update in one launch)" % type(dominant).__name__) if one and args.task
+                    else ("step1_kernel<%s> (Agent.update + Neurons.update in one launch)" % type(dominant).__name__) if one
+                    else ("motion_task_kernel + rate_kernel_wide<%s> per step" % type(dominant).__name__) if args.task
                     else "agent_step_kernel + rate_kernel_wide<%s> per step" % type(dominant).__name__,
                     "launches": None, "avg_launch_ms": round(step_s * 1e3, 6), "units_per_launch": B,
                     "bytes_per_unit": unit_bytes, "bytes_per_unit_is": "SURVEY.md 8(d): 4*n (+n spikes) + 112",
@@ -721,8 +739,10 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         diag = ag.diagnostics
         out["pipeline"] = ag.pipeline_info()
         if plan_info is not None:
-            out["plan"] = dict(plan_info, launches_per_step=round(plan_info["launches"] / max(1, (K * (R + 1) + W)), 3)
-                               if args.plan else None)
+            # (a plan lives for one region: the history reset in front of every repeat closes it — these are the counters of
+            # the LAST region's plan, which served K steps)
+            out["plan"] = dict(plan_info, launches_per_step=round(plan_info["launches"] / max(1, K), 3) if args.plan else None,
+                               us_per_step_all_steps_in_one_native_call=one_call_us)
         if args.task:
             diag = dict(diag, **env.diagnostics, episodes_finished=len(env.episodes["episode"]))
         out["diagnostics"] = diag

@@ -468,10 +468,12 @@ int riab_plan_step_population(RiabPlan* plan, int32_t index, riab_stream_t strea
  *               RIAB_STEP1_MAIL_STRIDE words per segment for a plan with a task attached: what the segment's writer
  *               tells its other workgroups about this step's resets (which of its agents a reset moved, and where to, as
  *               the history row keeps positions).
- * What is fused: plain motion steps (Philox noise, drift or not; no forced trajectory, no task) of whole 256-agent
- * segments, with the plan's LARGEST population among PlaceCells (euclidean geometry, not one_hot), GridCells and
- * HeadDirectionCells without additive noise; the other populations follow as their own kernels in list order, as
- * before.  With the split entry points riab_plan_step_agent launches the fused kernel (the population's row is written
+ * What is fused: motion steps (Philox noise, drift or not; no forced trajectory) of whole 256-agent segments, with the
+ * plan's LARGEST population among PlaceCells (euclidean geometry, not one_hot), GridCells and HeadDirectionCells
+ * without additive noise; the other populations follow as their own kernels in list order, as before.  A plan with a
+ * task attached (riab_plan_set_task; RIAB_OPT_FUSED_TASK on) gets the rest of TaskEnvironment.step, the auto-reset and
+ * the next scripted action in the same launch as well (riab_plan_step only): the segment's writer workgroup keeps the
+ * task's books, the others learn from the mail which agents a reset moved and write those agents' rates again.  With the split entry points riab_plan_step_agent launches the fused kernel (the population's row is written
  * ahead of its update() call) and the population's riab_plan_step_population of the same step only advances the row
  * cursor; a plan whose populations are not updated after each agent step stops fusing.
  * riab_plan_info: 0 steps served by the one-launch kernel, 1 index of the fused population (-1: none), 2 kernels

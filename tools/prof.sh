@@ -32,9 +32,12 @@ run_trace plan --plan --steps 256 --warmup 32 --no-cpu-baseline --no-secondary
 run_pmc plan WRITE_SIZE --plan --steps 256 --warmup 32 --no-cpu-baseline --no-secondary --repeats 3
 run_pmc plan FETCH_SIZE --plan --steps 256 --warmup 32 --no-cpu-baseline --no-secondary --repeats 3
 run_trace task --task --steps 256 --warmup 32 --no-cpu-baseline --no-secondary
+run_pmc task WRITE_SIZE --task --steps 256 --warmup 32 --no-cpu-baseline --no-secondary --repeats 3
+run_pmc task FETCH_SIZE --task --steps 256 --warmup 32 --no-cpu-baseline --no-secondary --repeats 3
 run_trace cfg3 --config cfg3 --no-cpu-baseline --steps 256 --warmup 32
 run_trace cfg5 --config cfg5 --no-cpu-baseline --steps 256 --warmup 32
 cd $GRAFT_REPO_ROOT
 python tools/pmc_summary.py $O/${R}_driver_pmc_WRITE_SIZE.csv $O/${R}_driver_pmc_FETCH_SIZE.csv --kernel rate_kernel_gated --units-per-launch 81920 --out $O/${R}_pmc_traffic_driver.json > /dev/null 2>&1 && grep -E '"(hbm_bytes_per_unit|traffic_over_algorithmic_kernel|grid_threads)"' $O/${R}_pmc_traffic_driver.json
 python tools/pmc_summary.py $O/${R}_plan_pmc_WRITE_SIZE.csv $O/${R}_plan_pmc_FETCH_SIZE.csv --kernel step1_kernel --units-per-launch 4096 --out $O/${R}_pmc_traffic_plan.json > /dev/null 2>&1 && grep -E '"(hbm_bytes_per_unit|traffic_over_algorithmic_kernel|grid_threads)"' $O/${R}_pmc_traffic_plan.json
+python tools/pmc_summary.py $O/${R}_task_pmc_WRITE_SIZE.csv $O/${R}_task_pmc_FETCH_SIZE.csv --kernel step1_task_kernel --units-per-launch 4096 --out $O/${R}_pmc_traffic_task.json > /dev/null 2>&1 && grep -E '"(hbm_bytes_per_unit|traffic_over_algorithmic_kernel|grid_threads)"' $O/${R}_pmc_traffic_task.json
 echo "== done"
