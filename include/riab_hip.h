@@ -484,7 +484,7 @@ int riab_plan_step_population(RiabPlan* plan, int32_t index, riab_stream_t strea
 #define RIAB_STEP1_SYNC_TIMEOUTS 0
 #define RIAB_STEP1_SYNC_WALLS_AT(B) ((((B) + 255) / 256) * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TAIL)
 #define RIAB_STEP1_SYNC_MAIL_AT(B) (RIAB_STEP1_SYNC_WALLS_AT(B) + 12 * RIAB_MAX_WALLS + 4)
-#define RIAB_STEP1_MAIL_STRIDE 1056  /* per segment, 8-byte entries (epoch << 32 | value): (at 0) 8 verdicts = halves of 4 lane masks, (at 32) x[256], y[256] */
+#define RIAB_STEP1_MAIL_STRIDE 1088  /* per segment, 8-byte entries (epoch << 32 | value): (at 0) 4 x 8 verdict entries = per mover wave its lane mask in halves and its first two movers' x, y; (at 64) x[256], y[256] */
 #define RIAB_STEP1_SYNC_WORDS(B) (RIAB_STEP1_SYNC_MAIL_AT(B) + (((B) + 255) / 256) * RIAB_STEP1_MAIL_STRIDE)
 int riab_plan_set_fused(RiabPlan* plan, uint32_t* sync_words, int64_t n_words);
 int64_t riab_plan_info(const RiabPlan* plan, int32_t which);

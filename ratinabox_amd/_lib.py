@@ -119,7 +119,7 @@ CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_SERIALISED, CTRL_STAMPS, CTRL_TRAJ
 
 
 STEP1_SYNC_STRIDE, STEP1_SYNC_TAIL, STEP1_SYNC_TIMEOUTS = 64, 16, 0   # riab_hip.h RIAB_STEP1_SYNC_*
-STEP1_MAIL_STRIDE = 1056                                                # riab_hip.h RIAB_STEP1_MAIL_STRIDE
+STEP1_MAIL_STRIDE = 1088                                                # riab_hip.h RIAB_STEP1_MAIL_STRIDE
 
 
 def step1_sync_tail(B):

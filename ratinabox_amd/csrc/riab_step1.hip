@@ -58,6 +58,11 @@ __global__ __launch_bounds__(64) void walls_prepare_kernel(const AgentArgs a, Wa
 }
 
 typedef __attribute__((address_space(1))) uint32_t s1_gu32;
+// A workgroup barrier for hand-overs through LDS: __syncthreads() also waits for every global store and atomic the wave
+// has in flight (its fence covers global memory) — a round trip in the middle of the writer's dependent chain, where the
+// bookkeeping's stores and the episode table's atomic are meant to stay in flight.  Nothing in global memory is handed
+// over at these barriers.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 typedef __attribute__((address_space(1))) unsigned long long s1_gu64;
 
 // The rest of TaskEnvironment.step in the same launch (TASK = task_kernel's MODE: 1 step, | 2 the caller's `if terminal:
@@ -100,8 +105,13 @@ struct Step1Task {
   if (prof_slot >= 0 && tid == 0)                                                                                         \
     ((unsigned long long*)(sy.words + RIAB_STEP1_SYNC_WORDS((int64_t)sy.n_segments * 256)))[prof_slot * 16 + (k)] = \
         (unsigned long long)__builtin_amdgcn_s_memrealtime();
+#define RIAB_S1_STAMP_H(k) /* (the same, by the first helper wave) */                                                     \
+  if (prof_slot >= 0 && tid == 256)                                                                                       \
+    ((unsigned long long*)(sy.words + RIAB_STEP1_SYNC_WORDS((int64_t)sy.n_segments * 256)))[prof_slot * 16 + (k)] = \
+        (unsigned long long)__builtin_amdgcn_s_memrealtime();
 #else
 #define RIAB_S1_STAMP(k)
+#define RIAB_S1_STAMP_H(k)
 #endif
 // timing experiments (tools/build_step1_variants.sh): bit 0 no motion step, bit 1 no rate stores, bit 2 no write-back
 #ifndef RIAB_S1_ABLATE
@@ -134,8 +144,10 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
   // (rewards alive, their total) and what a reset of the lane would draw (position, next episode's goals)
   __shared__ double s_rw_total[TASK ? 256 : 1];
   __shared__ int s_rw_n[TASK ? 256 : 1];
-  __shared__ double s_draw_xy[2][(TASK & 2) ? 256 : 1];
-  __shared__ unsigned long long s_draw_list[2][(TASK & 2) ? 256 : 1];
+  __shared__ double s_draw_xy[2][(TASK & 6) ? 256 : 1];
+  __shared__ unsigned long long s_draw_list[2][(TASK & 6) ? 256 : 1];
+  // ... and, the same arrays later, what the movers hand BACK for the next action (TASK & 4): the lane's list and position
+  __shared__ int s_fin_n[(TASK & 4) ? 256 : 1];
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -263,7 +275,7 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
       s_rw_n[tid & 255] = ro.n_rw;
       s_rw_total[tid & 255] = ro.total;
     }
-    __syncthreads();  // (writer) the reward caches are up to date
+    lds_barrier();  // (writer) the reward caches are up to date
     if (hlive && (TM & 2)) {
       const ResetDraw d = reset_draw(tk.a, tr, b);
       s_draw_xy[0][tid & 255] = d.x;
@@ -271,7 +283,8 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
       s_draw_list[0][tid & 255] = (unsigned long long)d.list;
       s_draw_list[1][tid & 255] = (unsigned long long)(d.list >> 64);
     }
-    __syncthreads();  // (writer) the resets' draws are in LDS
+    lds_barrier();  // (writer) the resets' draws are in LDS
+    RIAB_S1_STAMP_H(14)
   }
   if (mover && !(RIAB_S1_ABLATE & 1)) {
     const lds_cf64_ptr lds_h = (lds_cf64_ptr)s_h;
@@ -329,7 +342,6 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
   };
   const bool wb = writer && mover && !(RIAB_S1_ABLATE & 4);  // (wave-uniform)
   uint32_t seen = sy.epoch;
-  double gvx = 0.0, gvy = 0.0;
   LaneMid tmid = {0, 0, false, false, {false, 0, 0.0, 0.0, 0.0}, 0};
   if (TASK && writer && mover) {
     // ---- the rest of TaskEnvironment.step for the writer's lanes (contribs/TaskEnvironment.py:410-449), the caller's
@@ -342,12 +354,17 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
 #else
     const NoProbe probe;
 #endif
-    __syncthreads();  // (writer) the reward caches are up to date: the helper waves' rewards_step
+    lds_barrier();  // (writer) the reward caches are up to date: the helper waves' rewards_step
+    // (the arrival words are taken delivery of HERE, before the bookkeeping's first store: the wait counter is one for
+    // loads and stores, and the compiler — which must assume the worst at every join of this branchy code — otherwise
+    // drains the bookkeeping's stores, the write-through mail included, in the middle of the chain to keep that one
+    // register safe; write_back() asks again in the rare case a word was not there yet)
+    asm volatile("" : "+v"(seen));
     if (tlive) {
       const RewardsOut ro = {s_rw_n[tid], s_rw_total[tid]};
       tmid = task_lane_goals<TM>(tk.a, b, (lds_f64_ptr)s_goals, tin, ro, qx, qy, tk.t_env, tk.reward_out, tk.terminal_out, tk.diag, probe);
     }
-    __syncthreads();  // (writer) the resets' draws are in LDS
+    lds_barrier();  // (writer) the resets' draws are in LDS
     if (tlive)
       task_lane_reset<TM>(tk.a, tr, b, tin, tmid, qx, qy, tk.t_env, tk.diag, [&]() {
         return ResetDraw{s_draw_xy[0][tid], s_draw_xy[1][tid], ((u128)s_draw_list[1][tid] << 64) | (u128)s_draw_list[0][tid]};
@@ -360,20 +377,73 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
     const unsigned long long lanes = __builtin_amdgcn_ballot_w64(moved);
     const unsigned long long tag = (unsigned long long)sy.epoch << 32;
     s1_gu64* const mail64 = (s1_gu64*)(uintptr_t)(tk.mail + (int64_t)blockIdx.x * RIAB_STEP1_MAIL_STRIDE);
-    if (moved) {
-      __hip_atomic_store(mail64 + 16 + tid, tag | __float_as_uint((float)qx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(mail64 + 272 + tid, tag | __float_as_uint((float)qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // this wave's six verdict entries, posted every step: the halves of its mask of moved lanes and — what the others
+    // would otherwise come back for, one more round trip — the new positions of its first two movers (a wave has more
+    // than two once in thousands of steps: the others' positions go to their per-agent entries)
+    const unsigned long long lanes2 = lanes & (lanes - 1), lanes3 = lanes2 & (lanes2 - 1);
+    const int i0 = lanes ? __ffsll((long long)lanes) - 1 : 0, i1 = lanes2 ? __ffsll((long long)lanes2) - 1 : 0;
+    const int xb = (int)__float_as_uint((float)qx), yb = (int)__float_as_uint((float)qy);
+    const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane(xb, i0), y0 = (uint32_t)__builtin_amdgcn_readlane(yb, i0);
+    const uint32_t x1 = (uint32_t)__builtin_amdgcn_readlane(xb, i1), y1 = (uint32_t)__builtin_amdgcn_readlane(yb, i1);
+    if (lane < 6) {
+      const uint32_t v = lane == 0 ? (uint32_t)lanes : lane == 1 ? (uint32_t)(lanes >> 32) : lane == 2 ? x0 : lane == 3 ? y0 : lane == 4 ? x1 : y1;
+      __hip_atomic_store(mail64 + 8 * wave + lane, tag | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane < 2)
-      __hip_atomic_store(mail64 + 2 * wave + lane, tag | (uint32_t)(lanes >> (32 * lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lanes3 && moved && lane != i0 && lane != i1) {
+      __hip_atomic_store(mail64 + 32 + tid, tag | (uint32_t)xb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mail64 + 288 + tid, tag | (uint32_t)yb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     RIAB_S1_STAMP(7)
-    // (the others know; now what only this lane's books need: the new episode's goals, the next action, the rows back)
+    // (the others know; now what only this lane's books need: the ended episode's row, the new episode's goals, the next
+    // action — the helper waves work it out from the list and the position while this wave stores —, the rows back)
     if (tlive) {
-      task_lane_finish<TM>(tk.a, tr, b, (lds_f64_ptr)s_goals, tin, tmid, tk.gv_scale, gvx, gvy, probe);
+      task_lane_episode<TM>(tk.a, tr, b, tin, tmid, tk.t_env, tk.diag);
+      task_lane_newgoals<TM>(tk.a, tr, tin, tmid);
+      if (TM & 4) {
+        s_draw_list[0][tid] = (unsigned long long)tin.L.list;
+        s_draw_list[1][tid] = (unsigned long long)(tin.L.list >> 64);
+        s_fin_n[tid] = tin.L.n_goals;
+        s_draw_xy[0][tid] = qx;
+        s_draw_xy[1][tid] = qy;
+      }
+    }
+    RIAB_S1_STAMP(13)
+    if (TM & 4) lds_barrier();  // (writer) the lanes' lists and positions are in LDS
+    if (tlive) {
+      task_lane_store<TM>(tk.a, b, tin, tmid);
       px = qx;
       py = qy;
     }
     RIAB_S1_STAMP(15)
+  } else if (TASK && (TM & 4) && writer) {
+    // ---- the helper waves' last share: the coming step's action of every lane (get_goal_vector, :1555-1584), into the
+    // drift buffer — which every workgroup of the segment read at the top: behind the arrival words, like the state
+    uint32_t hseen = arrivals();
+    lds_barrier();  // (writer) the lanes' lists and positions are in LDS
+    double hx_ = 0.0, hy_ = 0.0;
+    if (hlive) {
+      Lane hl = {};
+      hl.list = ((u128)s_draw_list[1][tid & 255] << 64) | (u128)s_draw_list[0][tid & 255];
+      hl.n_goals = s_fin_n[tid & 255];
+      hl.px = s_draw_xy[0][tid & 255];
+      hl.py = s_draw_xy[1][tid & 255];
+      goal_vector(tk.a, (lds_f64_ptr)s_goals, hl, tk.gv_scale, hx_, hy_);
+    }
+    bool late = false;
+    for (uint32_t spins = 0; __builtin_amdgcn_ballot_w64(hseen != sy.epoch) != 0; ++spins) {
+      if (spins >= sy.spin_limit) {
+        late = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+      hseen = arrivals();
+    }
+    if (late && lane == 0) atomicAdd(sy.words + (int64_t)sy.n_segments * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TIMEOUTS, 1u);
+    if (hlive) {
+      tk.gv_x[b] = hx_;
+      tk.gv_y[b] = hy_;
+    }
+    RIAB_S1_STAMP_H(12)
   } else if (mover) {
     s_row[0][tid] = (float)px;
     s_row[1][tid] = (float)py;
@@ -393,7 +463,9 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
     h[6 * B] = (float)mrot;
     h[7 * B] = (float)dist;
   }
-  __syncthreads();  // the row is in LDS; every state value of this workgroup has been consumed, i.e. loaded
+  // the row is in LDS; every state value of this workgroup has been consumed, i.e. loaded.  (A task's writer writes no
+  // rates: its movers go on to the write-back while its helper waves are still busy with the next action.)
+  if (!(TASK && writer)) __syncthreads();
   if (TASK && writer && mover) {  // (the lanes' books are kept: a reset may have moved them)
     if (a.hist) {  // save_to_history (Agent.py:514-520), agent.history["pos"][-1] = agent.pos of a teleporting reset included
       float* h = a.hist + b;
@@ -438,10 +510,6 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
       st[9 * B] = hy;
       st[10 * B] = dist;
       st[11 * B] = dwall;
-      if ((TASK & 4) && b < tk.a.B) {  // the coming step's action (the drift buffer every workgroup read at the top)
-        tk.gv_x[b] = gvx;
-        tk.gv_y[b] = gvy;
-      }
       if (a.diag) {
         if (n_bounce) atomicAdd(a.diag + 0, n_bounce);
         if (n_sat) atomicAdd(a.diag + 1, n_sat);
@@ -499,8 +567,8 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
   }
 #endif
   if (TASK && !writer && Cell::NEEDS_POS && !(RIAB_S1_TASK_DROP & 8)) {
-    // ---- did a reset move one of the segment's agents?  The writer's eight verdict entries of this launch: one round
-    // trip (they are usually there by now) says that they are posted and which agents moved.
+    // ---- did a reset move one of the segment's agents?  The writer's 4 x 6 verdict entries of this launch: one round
+    // trip (they are usually there by now) says that they are posted, which agents moved and where (almost all of) them went.
     const s1_gu64* const mail64 = (const s1_gu64*)(uintptr_t)(tk.mail + (int64_t)blockIdx.x * RIAB_STEP1_MAIL_STRIDE);
     auto peek = [&](int at) -> unsigned long long {
       return __hip_atomic_load((s1_gu64*)(mail64 + at), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -515,32 +583,48 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
       }
       return e;
     };
-    // (with the verdict, unasked: where this lane's four agents went if they were moved — the same round trip; an entry
-    // that turns out to be needed and is not there yet is asked for again below)
-    unsigned long long ex[4], ey[4];
-    const unsigned long long v0 = peek(lane & 7);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      ex[k] = peek(16 + 4 * lane + k);
-      ey[k] = peek(272 + 4 * lane + k);
-    }
-    const unsigned long long verdict = fresh(lane & 7, lane < 8, v0);
+    const bool polls = lane < 32 && (lane & 7) < 6;  // lane 8 w + l: entry l of the writer's mover wave w
+    const unsigned long long verdict = fresh(lane & 31, polls, polls ? peek(lane & 31) : 0ull);
     bool stale = __builtin_amdgcn_ballot_w64((uint32_t)(verdict >> 32) != sy.epoch) != 0;
-    // this lane's quad of agents: bits 4 * lane .. + 3 of the 256, i.e. of half-mask (lane >> 3)
-    const uint32_t half = (uint32_t)__shfl((int)(uint32_t)verdict, lane >> 3);
-    const uint32_t mine4 = stale ? 0u : ((half >> ((4 * lane) & 31)) & 15u);
     RIAB_S1_STAMP(7)
-    if (__builtin_amdgcn_ballot_w64(mine4 != 0u) != 0) {
-      // (wave-uniform) this wave's cell groups again for the quads an agent of which was moved: the same pass — the
-      // same instructions, hence the same bits as the population's own kernel gives on the patched history row — on
-      // the row with the new positions in, stored by the lanes whose quad changed
-      v4f rx = *reinterpret_cast<const v4f*>(&s_row[0][4 * lane]), ry = *reinterpret_cast<const v4f*>(&s_row[1][4 * lane]);
-      // the positions this lane needs: all of them asked for again in ONE batch while any is not this launch's yet
+    // this lane's quad of agents 4 lane .. 4 lane + 3 of the segment: patched where the mail says an agent was moved
+    v4f rx = *reinterpret_cast<const v4f*>(&s_row[0][4 * lane]), ry = *reinterpret_cast<const v4f*>(&s_row[1][4 * lane]);
+    bool mine_moved = false;
+    uint32_t extra4 = 0;  // this quad's agents whose positions did not ride in the verdict (third and later movers of a wave)
+    auto patch = [&](int agent, uint32_t xbits, uint32_t ybits) {  // (uniform arguments)
+      const bool here = lane == (agent >> 2);
+      const int k = agent & 3;
+      const float fx = __uint_as_float(xbits), fy = __uint_as_float(ybits);
+      mine_moved = mine_moved || here;
+      rx.x = (here && k == 0) ? fx : rx.x; ry.x = (here && k == 0) ? fy : ry.x;
+      rx.y = (here && k == 1) ? fx : rx.y; ry.y = (here && k == 1) ? fy : ry.y;
+      rx.z = (here && k == 2) ? fx : rx.z; ry.z = (here && k == 2) ? fy : ry.z;
+      rx.w = (here && k == 3) ? fx : rx.w; ry.w = (here && k == 3) ? fy : ry.w;
+    };
+    if (!stale) {
+      const int vlo = (int)(uint32_t)verdict;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(vlo, 8 * w) |
+                                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(vlo, 8 * w + 1) << 32);
+        if (m == 0) continue;  // (uniform)
+        patch(w * 64 + __ffsll((long long)m) - 1, (uint32_t)__builtin_amdgcn_readlane(vlo, 8 * w + 2),
+              (uint32_t)__builtin_amdgcn_readlane(vlo, 8 * w + 3));
+        const unsigned long long m2 = m & (m - 1);
+        if (m2 == 0) continue;
+        patch(w * 64 + __ffsll((long long)m2) - 1, (uint32_t)__builtin_amdgcn_readlane(vlo, 8 * w + 4),
+              (uint32_t)__builtin_amdgcn_readlane(vlo, 8 * w + 5));
+        const unsigned long long m3 = m2 & (m2 - 1);
+        if ((lane >> 4) == w) extra4 |= (uint32_t)(m3 >> (4 * (lane & 15))) & 15u;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(extra4 != 0u) != 0) {  // (rare) those positions: one batch per attempt, bounded
+      unsigned long long ex[4] = {0, 0, 0, 0}, ey[4] = {0, 0, 0, 0};
       for (uint32_t spins = 0;; ++spins) {
         bool waiting = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          waiting = waiting || (((mine4 >> k) & 1u) && ((uint32_t)(ex[k] >> 32) != sy.epoch || (uint32_t)(ey[k] >> 32) != sy.epoch));
+          waiting = waiting || (((extra4 >> k) & 1u) && ((uint32_t)(ex[k] >> 32) != sy.epoch || (uint32_t)(ey[k] >> 32) != sy.epoch));
         if (__builtin_amdgcn_ballot_w64(waiting) == 0) break;
         if (spins >= sy.spin_limit) {
           stale = true;
@@ -549,25 +633,29 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
         if (spins) __builtin_amdgcn_s_sleep(4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          if ((mine4 >> k) & 1u) {
-            ex[k] = peek(16 + 4 * lane + k);
-            ey[k] = peek(272 + 4 * lane + k);
+          if ((extra4 >> k) & 1u) {
+            ex[k] = peek(32 + 4 * lane + k);
+            ey[k] = peek(288 + 4 * lane + k);
           }
         }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const bool m = (mine4 >> k) & 1u;
+        const bool m = (extra4 >> k) & 1u;
         const float fx = __uint_as_float((uint32_t)ex[k]), fy = __uint_as_float((uint32_t)ey[k]);
         if (k == 0) { rx.x = m ? fx : rx.x; ry.x = m ? fy : ry.x; }
         if (k == 1) { rx.y = m ? fx : rx.y; ry.y = m ? fy : ry.y; }
         if (k == 2) { rx.z = m ? fx : rx.z; ry.z = m ? fy : ry.z; }
         if (k == 3) { rx.w = m ? fx : rx.w; ry.w = m ? fy : ry.w; }
       }
-      if (!stale) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the values this wave stored for those quads a moment ago are in place)
-        rates_pass(rx, ry, reps == 1 ? mine : group_params(g0), mine4 != 0u);  // (one group per wave: its parameters are still here)
-      }
+      mine_moved = mine_moved || extra4 != 0u;
+    }
+    if (!stale && __builtin_amdgcn_ballot_w64(mine_moved) != 0) {
+      // (wave-uniform) this wave's cell groups again for the quads an agent of which was moved: the same pass — the
+      // same instructions, hence the same bits as the population's own kernel gives on the patched history row — on
+      // the row with the new positions in, stored by the lanes whose quad changed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the values this wave stored for those quads a moment ago are in place)
+      rates_pass(rx, ry, reps == 1 ? mine : group_params(g0), mine_moved);  // (one group per wave: its parameters are still here)
     }
     RIAB_S1_STAMP(12)
     if (stale && lane == 0) atomicAdd(sy.words + (int64_t)sy.n_segments * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TIMEOUTS, 1u);

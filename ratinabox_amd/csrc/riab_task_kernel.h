@@ -384,11 +384,34 @@ struct EpisodeRecord {  // write_end_episode's row, on its way into the table
   double episode, start, duration;
 };
 
-// part 1: write_end_episode (:536-539), the episode counter (:333-338), teleport_on_reset (:323-330)
-__device__ __forceinline__ EpisodeRecord reset_lane_position(const TaskArgs& a, const ResetArgs& r, int64_t b, Lane& L, const ResetIn& in,
-                                                             const ResetDraw& d, double t_env, int32_t* diag) {
+// part 1a: teleport_on_reset (:323-330) — what others may be waiting to hear
+__device__ __forceinline__ void reset_lane_teleport(const ResetArgs& r, int64_t b, Lane& L, const ResetDraw& d) {
+  if (r.teleport) {
+    double x, y;
+    if (r.new_x) {
+      x = r.new_x[b];
+      y = r.new_y[b];
+    } else {
+      x = d.x;
+      y = d.y;
+    }
+    L.px = x;
+    L.py = y;
+    if (r.pos_x) {  // (null: the caller stores the position it is handed back — the one-launch step, riab_step1.hip)
+      r.pos_x[b] = x;
+      r.pos_y[b] = y;
+    }
+    if (r.hist_x) {  // agent.history["pos"][-1] = agent.pos
+      r.hist_x[b] = (float)x;
+      r.hist_y[b] = (float)y;
+    }
+  }
+}
+
+// part 1b: write_end_episode (:536-539), the episode counter (:333-338)
+__device__ __forceinline__ EpisodeRecord reset_lane_episode(const TaskArgs& a, const ResetArgs& r, int64_t b, const ResetIn& in,
+                                                            double t_env, int32_t* diag) {
   atomicAdd(diag + RIAB_TD_RESETS, 1);
-  const uint64_t id = (uint64_t)(r.agent_id0 + b);
   EpisodeRecord rec = {false, 0, in.episode, in.ep_start, 0.0};
   bool zero_duration = false;
   bool any_ended = in.any_ended != 0.0;
@@ -413,26 +436,6 @@ __device__ __forceinline__ EpisodeRecord reset_lane_position(const TaskArgs& a, 
   ts_at(a, RIAB_TS_STARTED, b) = 1.0;
   // _current_episode_start (:526-527): the end of the last kept episode, 0 before any
   ts_at(a, RIAB_TS_EP_START, b) = any_ended ? t_env : 0.0;
-  if (r.teleport) {
-    double x, y;
-    if (r.new_x) {
-      x = r.new_x[b];
-      y = r.new_y[b];
-    } else {
-      x = d.x;
-      y = d.y;
-    }
-    L.px = x;
-    L.py = y;
-    if (r.pos_x) {  // (null: the caller stores the position it is handed back — the one-launch step, riab_step1.hip)
-      r.pos_x[b] = x;
-      r.pos_y[b] = y;
-    }
-    if (r.hist_x) {  // agent.history["pos"][-1] = agent.pos
-      r.hist_x[b] = (float)x;
-      r.hist_y[b] = (float)y;
-    }
-  }
   return rec;
 }
 
@@ -599,23 +602,27 @@ __device__ __forceinline__ void task_lane_reset(const TaskArgs& a, const ResetAr
   if (RESET && mid.reset) {
     const ResetDraw d = draw();
     mid.new_list = d.list;
-    mid.rec = reset_lane_position(a, r, b, in.L, in.ep, d, t_env, diag);
+    reset_lane_teleport(r, b, in.L, d);
     px = in.L.px;  // (moved by a reset that teleports)
     py = in.L.py;
   }
 }
-template <int MODE, class Probe = NoProbe>
-__device__ __forceinline__ void task_lane_finish(const TaskArgs& a, const ResetArgs& r, int64_t b, lds_f64_ptr goals, LaneIn& in,
-                                                 const LaneMid& mid, double gv_scale, double& gvx, double& gvy,
-                                                 const Probe& probe = Probe()) {
-  constexpr bool STEP = MODE & 1, RESET = MODE & 2, GOALVEC = MODE & 4;
-  Lane& L = in.L;
-  if (RESET && mid.reset) reset_lane_goals(a, r, L, ResetDraw{0.0, 0.0, mid.new_list});
-  probe(13);
-  if (GOALVEC) goal_vector(a, goals, L, gv_scale, gvx, gvy);  // (handed back: the caller stores it)
-  probe(14);
-  // ---- write back what changed
-  if (STEP || RESET) {
+// ... between task_lane_reset and task_lane_finish, in either order with the latter: the ended episode's bookkeeping
+template <int MODE>
+__device__ __forceinline__ void task_lane_episode(const TaskArgs& a, const ResetArgs& r, int64_t b, const LaneIn& in, LaneMid& mid,
+                                                  double t_env, int32_t* diag) {
+  if ((MODE & 2) && mid.reset) mid.rec = reset_lane_episode(a, r, b, in.ep, t_env, diag);
+}
+// task_lane_finish = task_lane_newgoals, goal_vector, task_lane_store — in pieces for a caller that has other lanes work
+// out the next action (it needs the lane's list, count and position after task_lane_newgoals: nothing else)
+template <int MODE>
+__device__ __forceinline__ void task_lane_newgoals(const TaskArgs& a, const ResetArgs& r, LaneIn& in, const LaneMid& mid) {
+  if ((MODE & 2) && mid.reset) reset_lane_goals(a, r, in.L, ResetDraw{0.0, 0.0, mid.new_list});
+}
+template <int MODE>
+__device__ __forceinline__ void task_lane_store(const TaskArgs& a, int64_t b, const LaneIn& in, const LaneMid& mid) {
+  const Lane& L = in.L;
+  if (MODE & 3) {  // ---- write back what changed
     if (L.n_goals != mid.n_goals0) ts_at(a, RIAB_TS_N_GOALS, b) = (double)L.n_goals;
     if (L.n_rw != mid.n_rw0) ts_at(a, RIAB_TS_N_REWARDS, b) = (double)L.n_rw;
     if (L.delayed != mid.delayed0) {
@@ -624,6 +631,16 @@ __device__ __forceinline__ void task_lane_finish(const TaskArgs& a, const ResetA
     }
     if (L.list_dirty) store_list(a, b, L);
   }
+}
+template <int MODE, class Probe = NoProbe>
+__device__ __forceinline__ void task_lane_finish(const TaskArgs& a, const ResetArgs& r, int64_t b, lds_f64_ptr goals, LaneIn& in,
+                                                 const LaneMid& mid, double gv_scale, double& gvx, double& gvy,
+                                                 const Probe& probe = Probe()) {
+  task_lane_newgoals<MODE>(a, r, in, mid);
+  probe(13);
+  if (MODE & 4) goal_vector(a, goals, in.L, gv_scale, gvx, gvy);  // (handed back: the caller stores it)
+  probe(14);
+  task_lane_store<MODE>(a, b, in, mid);
 }
 
 // the goal pool (<= 4 KB) into LDS, by any number of threads of the workgroup; the caller synchronises
@@ -658,6 +675,7 @@ __device__ __forceinline__ void task_body(const TaskArgs& a, const ResetArgs& r,
   if (STEP) ro = rewards_step(a, (lds_f64_ptr)s_goals, b, rin);
   LaneMid mid = task_lane_goals<MODE>(a, b, (lds_f64_ptr)s_goals, in, ro, px, py, t_env, reward_out, terminal_out, diag);
   task_lane_reset<MODE>(a, r, b, in, mid, px, py, t_env, diag, [&]() { return reset_draw(a, r, b); });
+  task_lane_episode<MODE>(a, r, b, in, mid, t_env, diag);
   task_lane_finish<MODE>(a, r, b, (lds_f64_ptr)s_goals, in, mid, gv_scale, gvx, gvy);
   if (MODE & 4) {
     gv_x[b] = gvx;

@@ -468,13 +468,14 @@ def test_randomised_task_plans_equal_eager_loop(riab, seed):
     assert np.array_equal(P1.history["firingrate"], P2.history["firingrate"])
 
 
-def _task_world(riab, seed, B, n, teleport, order, delay, pop="place", spikes=False):
+def _task_world(riab, seed, B, n, teleport, order, delay, pop="place", spikes=False, radius=None):
     n_cells = n
     from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
     np.random.seed(seed)
     env = SpatialGoalEnvironment(params={"walls": [[[0.5, 0.3], [0.5, 0.7]]]},
                                  possible_goal_positions=[[0.2, 0.25], [0.8, 0.7], [0.5, 0.1], [0.3, 0.8]],
                                  goalcachekws=dict(reset_n_goals=2, goalorder=order),
+                                 goalkws=dict() if radius is None else dict(goal_radius=radius),
                                  episode_terminate_delay=delay, teleport_on_reset=teleport, seed=seed)
     Ag = riab.Agent(env, {"dt": 0.01, "n_agents": B, "seed": 4 + seed})
     if pop == "place":
@@ -497,6 +498,10 @@ def _task_world(riab, seed, B, n, teleport, order, delay, pop="place", spikes=Fa
     dict(B=512, n=90, teleport=True, order="nonsequential", delay=0.0, auto_reset=False),
     dict(B=256, n=50, teleport=True, order="sequential", delay=0.03, auto_reset=False, scripted=False),
     dict(B=512, n=120, teleport=True, order="nonsequential", delay=0.03, spikes=True),     # (the default: save_spikes)
+    # (goals a third of the room wide: many lanes of a wave end an episode in the same step — the positions of a wave's
+    # third and later movers travel in their per-agent mail entries, the first two in the verdict)
+    dict(B=512, n=64, teleport=True, order="nonsequential", delay=0.0, radius=0.3),
+    dict(B=256, n=40, teleport=True, order="sequential", delay=0.03, radius=0.35, pop="grid"),
     dict(B=256, n=33, teleport=True, order="sequential", delay=0.0, pop="grid", spikes=True, scripted=False),
 ])
 def test_one_launch_task_step_equals_the_two_launch_plan(riab, case):

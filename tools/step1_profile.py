@@ -40,8 +40,8 @@ def make_plan():
 
 plan = make_plan()
 names = ["entry", "state+tables in", "motion done", "rates issued", "rates acked", "writer: all arrived", "writer: state acked",
-         "task: verdict posted / read", "rewards updated", "goal pass 1", "pad + pass 2", "pass 3 + totals", "rates corrected", "new goals",
-         "next action", "lane done"]
+         "task: verdict posted / read", "rewards updated", "goal pass 1", "pad + pass 2", "pass 3 + totals", "rates corrected / helper: next action stored", "new goals",
+         "helper: draws done", "lane done"]
 rows = []
 for rep in range(5):
     plan.step(steps)
