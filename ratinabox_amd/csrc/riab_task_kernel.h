@@ -351,8 +351,9 @@ __device__ __forceinline__ ResetDraw reset_draw(const TaskArgs& a, const ResetAr
   // GoalCache.reset (:1218-1252)
   const int n = r.n_select < a.n_pool ? r.n_select : a.n_pool;
   u128 list = 0;
-  if (r.ordered) {
-    for (int i = 0; i < n; ++i) list = list_set(list, i, i);
+  if (r.ordered) {  // slots 0 .. n-1 hold goals 0 .. n-1
+    const u128 iota = ((u128)0x0F0E0D0C0B0A0908ull << 64) | (u128)0x0706050403020100ull;
+    list = n >= 16 ? iota : (iota & ((((u128)1) << (8 * n)) - 1));
   } else {
     // uniform sample without replacement: draw i picks the j-th goal still in the pool (ascending
     // order), j = floor(w_i * (n_pool - i) / 2^32), w_i = word i%4 of Philox block 1 + i/4
@@ -372,8 +373,9 @@ __device__ __forceinline__ ResetDraw reset_draw(const TaskArgs& a, const ResetAr
       }
       const int pick = __ffsll((long long)m) - 1;
       remaining &= ~(1ull << pick);
-      list = list_set(list, i, pick);
+      list = (list >> 8) | ((u128)(uint32_t)pick << 120);  // (enters at the top: constant shifts; brought down once, below)
     }
+    if (n > 0) list >>= 8 * (16 - n);
   }
   d.list = list;
   return d;
