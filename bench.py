@@ -664,13 +664,15 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         one = bool(plan_info and plan_info["fused_steps"] > 0)
         traffic = traffic_from = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if one and not args.task and type(dominant).__name__ == "PlaceCells" and not cfg["spikes"] and os.path.exists(tpath):
+        if one and type(dominant).__name__ == "PlaceCells" and not cfg["spikes"] and os.path.exists(tpath):
+            tkey = "step1_task_kernel" if args.task else "step1_kernel"
             with open(tpath) as f:
-                entry = json.load(f).get("kernels", {}).get("step1_kernel")
+                entry = json.load(f).get("kernels", {}).get(tkey)
             if entry:   # (counters are not collected in this run: the committed PMC passes' per-unit figure x this run's units)
                 traffic = round(entry["hbm_bytes_per_unit"] * B)
-                traffic_from = (f"profiles/pmc_traffic.json[step1_kernel]: {entry['hbm_bytes_per_unit']:.1f} B per agent-step "
-                                "(rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of `bench.py --plan`) x the units of one launch")
+                traffic_from = (f"profiles/pmc_traffic.json[{tkey}]: {entry['hbm_bytes_per_unit']:.1f} B per agent-step "
+                                f"(rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of `bench.py --{'task' if args.task else 'plan'}`) x "
+                                "the units of one launch")
         roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from": traffic_from,
                     "kernel": ("step1_task_kernel<%s> (Agent.update + the rest of TaskEnvironment.step + auto-reset + next action + "
