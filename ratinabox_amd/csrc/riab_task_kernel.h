@@ -19,7 +19,9 @@
 //   * the reward total is accumulated while the cache is walked (no read-back of what was just stored);
 //   * the caller's `if terminal: reset()` and the scripted goal-seeking action of the NEXT step are
 //     fused into the same launch for the step plan, which also puts the one-step motion launch in front of it
-//     (motion_task_kernel, riab_agent.hip): 2 kernels per closed-loop step.
+//     (motion_task_kernel, riab_agent.hip: 2 kernels per closed-loop step) or, where the plan's lead population
+//     can be fused as well, runs the whole step as ONE kernel that deals the pieces below to different waves
+//     (step1_task_kernel, riab_step1.hip).
 #include "riab_device.h"
 
 // The reward recursions are compared bit for bit with the reference's float64 python arithmetic:

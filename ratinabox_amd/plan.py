@@ -32,12 +32,13 @@ def _attach_fused(plan, agent):
 
 
 def _check_fused(plan):
-    """A writer of the one-launch step that gave up waiting for its segment's workgroups (must never happen)."""
+    """A workgroup of the one-launch step that gave up waiting — a writer for its segment's arrival words, or (task
+    plans) another workgroup for the writer's verdict on this step's resets; must never happen."""
     w = getattr(plan, "_sync_words", None)
     if w is not None and plan._h and _L.lib.riab_plan_info(plan._h, 0) > 0:
         if int(w[_L.step1_sync_tail(plan.agent._Bp) + _L.STEP1_SYNC_TIMEOUTS].item()):
-            raise _L.RiabError("one-launch step: a state write-back gave up waiting for its segment's workgroups; "
-                               "the agent state of that step is not trustworthy")
+            raise _L.RiabError("one-launch step: a workgroup gave up waiting for its segment's other workgroups; "
+                               "the agent state / the rates of that step are not trustworthy")
 
 
 class _ForcedRows:

@@ -502,6 +502,7 @@ def _task_world(riab, seed, B, n, teleport, order, delay, pop="place", spikes=Fa
     # third and later movers travel in their per-agent mail entries, the first two in the verdict)
     dict(B=512, n=64, teleport=True, order="nonsequential", delay=0.0, radius=0.3),
     dict(B=256, n=40, teleport=True, order="sequential", delay=0.03, radius=0.35, pop="grid"),
+    dict(B=254, n=48, teleport=True, order="nonsequential", delay=0.03, radius=0.2),   # (padded to 256: two lanes without a task)
     dict(B=256, n=33, teleport=True, order="sequential", delay=0.0, pop="grid", spikes=True, scripted=False),
 ])
 def test_one_launch_task_step_equals_the_two_launch_plan(riab, case):
