@@ -558,3 +558,90 @@ def test_one_launch_task_step_equals_the_two_launch_plan(riab, case):
     if case["teleport"] and auto_reset:
         jumps = np.abs(np.diff(a["traj"][:, 0, :], axis=0)).max()     # ... and teleported (visible in the stored trajectory)
         assert jumps > 0.05
+
+
+@pytest.mark.parametrize("batch", [1, 7])
+def test_one_launch_task_step_with_other_populations_and_batches(riab, batch):
+    """The lead population rides in the task step's kernel, the others (a smaller store-bound one, boundary vector
+    cells) follow as their own kernels on the row the reset patched; `plan.step(batch)` issues `batch` such steps from
+    one native call.  Against the two-launch plan, every population, bit for bit."""
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
+    T, speed = 210, 11.0 * 0.08
+
+    def run(fused):
+        old = riab._lib.set_option("fused_step", 1 if fused else 0)
+        try:
+            np.random.seed(21)
+            env = SpatialGoalEnvironment(params={"walls": [[[0.4, 0.0], [0.4, 0.5]]]}, possible_goal_positions="random_6",
+                                         goalcachekws=dict(reset_n_goals=3, goalorder="nonsequential"),
+                                         episode_terminate_delay=0.02, teleport_on_reset=True, seed=3)
+            Ag = riab.Agent(env, {"dt": 0.01, "n_agents": 512, "seed": 9})
+            pops = [riab.HeadDirectionCells(Ag, {"n": 12, "save_spikes": False}),
+                    riab.PlaceCells(Ag, {"n": 150, "wall_geometry": "euclidean", "save_spikes": True, "max_fr": 25}),
+                    riab.BoundaryVectorCells(Ag, {"n": 20, "save_spikes": False}),
+                    riab.GridCells(Ag, {"n": 30, "save_spikes": False})]
+            env.add_agents(Ag)
+            plan = env.make_step_plan(neurons=pops, capacity=256, auto_reset=True, scripted_speed=speed)
+            for _ in range(T // batch):
+                plan.step(batch)
+            torch.cuda.synchronize()
+            info = plan.info()
+            out = dict(state=Ag.state_tensor[:, :512].cpu().numpy(), ts=env.task_state.cpu().numpy(),
+                       traj=Ag.get_history_tensor().cpu().numpy(), rew=env.get_reward().cpu().numpy(),
+                       term=env.terminal.cpu().numpy())
+            for i, P in enumerate(pops):
+                fr, sp = P.get_history_tensors()
+                out[f"fr{i}"] = fr.cpu().numpy()
+                if sp is not None:
+                    out[f"sp{i}"] = sp.cpu().numpy()
+            return out, dict(env.episodes), dict(env.diagnostics), info
+        finally:
+            riab._lib.set_option("fused_step", old)
+
+    a, ep_a, d_a, info_a = run(True)
+    b, ep_b, d_b, info_b = run(False)
+    steps = T // batch * batch
+    assert info_a["fused_steps"] == steps and info_a["fused_population"] == 1, info_a    # (the PlaceCells: most bytes per row)
+    assert info_b["fused_steps"] == 0
+    assert a.keys() == b.keys()
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert ep_a == ep_b and d_a == d_b and len(ep_a["episode"]) > 3
+
+
+def test_one_launch_task_step_in_a_captured_graph(riab):
+    """The task step's kernels take no decision on the host beyond their scalar arguments and allocate / synchronise
+    nothing: four steps captured into a HIP graph and replayed once write what four plain steps write (rows, state, task
+    state, episode table, next action), bit for bit."""
+    def world():
+        env, Ag, P = _task_world(riab, 5, B=256, n=64, teleport=True, order="nonsequential", delay=0.0, radius=0.25)
+        plan = env.make_step_plan(capacity=64, auto_reset=True, scripted_speed=0.9)
+        plan.step(3)                               # (walls prepared, first action in place, the kernel's attributes asked for)
+        torch.cuda.synchronize()
+        return env, Ag, P, plan
+
+    def snapshot(env, Ag, P, plan):
+        torch.cuda.synchronize()
+        return dict(state=Ag.state_tensor.cpu().numpy(), ts=env.task_state.cpu().numpy(), act=plan._actions.cpu().numpy(),
+                    rew=env._reward.cpu().numpy(), term=env._terminal.cpu().numpy(), n_ep=env._ep_count.cpu().numpy(),
+                    ep=np.sort(env._ep_log.cpu().numpy(), axis=0), diag=env._diag.cpu().numpy(),
+                    traj=plan._agent_rows[:7].cpu().numpy(), fr=plan._pop_rows[0][0][:7].cpu().numpy())
+
+    env, Ag, P, plan = world()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            rc = riab._lib.lib.riab_plan_step(plan._h, 4, riab._lib.current_stream())
+        assert rc == 0
+        g.replay()
+    torch.cuda.synchronize()
+    assert riab._lib.lib.riab_plan_info(plan._h, 0) == 7                 # all seven steps were one-launch steps
+    a = snapshot(env, Ag, P, plan)
+    env2, Ag2, P2, plan2 = world()
+    plan2.step(4)
+    b = snapshot(env2, Ag2, P2, plan2)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert a["n_ep"][0] > 0
