@@ -725,6 +725,11 @@ static int launch_step1_cell(const AgentArgs& a, const RateArgs& ra, const Cell&
   const TailConst<double> tc = {a.m.dt, hk.inv_dt, 1.0 - a.m.dt / a.m.hd_tau, a.m.dt / a.m.hd_tau, a.m.hd_tau <= a.m.dt};
   const dim3 block(64 * RIAB_S1_WAVES);
   if (tk) {  // (non-temporal stores; TASK = task_kernel's MODE)
+    // The task step's workgroups wait for each other in both directions (the writer for the others' arrival, the others
+    // for the writer's verdict), and its 160+ registers per lane allow one workgroup per compute unit: the whole grid must
+    // be resident at once.  step1_shape keeps it to one round wherever a segment has room for a second workgroup; where
+    // it has not (more than 128 segments: 32768 agents) the plan keeps its two launches.
+    if ((int64_t)grid.x * grid.y > 2048 / RIAB_S1_WAVES) return RIAB_EUNSUPPORTED;
     // a kernel the register allocator gave a stack frame (a few bytes of spilled scalars, never touched) would have the
     // dispatcher set scratch memory up for every launch — more than the fusion saves: such an instantiation is not used
     auto launch = [&](auto kernel) -> int {

@@ -645,3 +645,17 @@ def test_one_launch_task_step_in_a_captured_graph(riab):
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     assert a["n_ep"][0] > 0
+
+
+@pytest.mark.parametrize("B,fits", [(32768, True), (65536, False)])
+def test_one_launch_task_step_only_where_its_grid_is_resident_at_once(riab, B, fits):
+    """The task step's workgroups wait for each other: it is used only where all of them fit the chip at once (one per
+    compute unit); 65536 agents = 256 writers + 256 others do not, and that plan keeps its two launches."""
+    env, Ag, P = _task_world(riab, 2, B=B, n=16, teleport=True, order="nonsequential", delay=0.0)
+    plan = env.make_step_plan(capacity=8, auto_reset=True, scripted_speed=0.9)
+    plan.step(6)
+    torch.cuda.synchronize()
+    info = plan.info()
+    assert (info["fused_steps"] == 6) == fits, info
+    plan.close()                      # (raises if a workgroup of a one-launch step gave up waiting)
+    assert np.isfinite(np.asarray(P.firingrate)).all()
