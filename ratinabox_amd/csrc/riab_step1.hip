@@ -68,22 +68,26 @@ typedef __attribute__((address_space(1))) unsigned long long s1_gu64;
 // The rest of TaskEnvironment.step in the same launch (TASK = task_kernel's MODE: 1 step, | 2 the caller's `if terminal:
 // reset()`, | 4 the scripted action of the next step) — what the step plan's motion + task launch did behind the motion
 // step, for a plan whose lead population can be fused as well (one kernel per closed-loop step instead of two).
-//   * The segment's writer workgroup (blockIdx.y == 0) does the bookkeeping of its 256 lanes (task_lane_*: the same code
-//     on the same operands as task_kernel) with the position its motion step has just produced, its task rows fetched
-//     with the state at the top, a whole motion step ahead of their use.  It writes no rates: the cell groups are
-//     dealt to the workgroups y >= 1.
+//   * The segment's writer workgroup (blockIdx.y == 0) keeps the books of its 256 lanes (the pieces of
+//     riab_task_kernel.h: the same code on the same operands as task_kernel), its task rows fetched with the state at
+//     the top, a whole motion step ahead of their use.  It writes no rates: the cell groups are dealt to the
+//     workgroups y >= 1.  The bookkeeping is a long, branchy per-lane instruction stream (7 us behind the motion step
+//     when one wave does all of it), so it is cut by function: what does not depend on where the agent went — the
+//     reward cache's update, everything a reset would draw — is the helper waves' (4-7), beside the movers' second
+//     half; the movers keep the goal checks and the reset; the next action is the helper waves' again, while the movers
+//     store rows, history and state.  Hand-overs go through LDS (lds_barrier).
 //   * A reset that teleports changes the position the rates are a function of.  The other workgroups cannot know — the
-//     goal lists are the writer's — so each mover wave of the writer posts two verdict entries per step ("epoch, these
-//     of my 64 lanes moved", write-through) as soon as its lanes' positions are final, and the workgroups y >= 1 read
-//     the eight entries after their last rate store: the lanes whose quad of agents has a mover fetch the new positions
-//     from the segment's mail and the wave runs its rate pass again, stored by those lanes only (own stores
-//     acknowledged first).  The rows end up as the population's kernel would have written them from the
-//     history row the reset patched.
+//     goal lists are the writer's — so each mover wave of the writer posts six verdict entries per step as soon as its
+//     lanes' positions are final (its mask of moved lanes in halves, the new positions of its first two movers; every
+//     entry carries the launch's epoch, none has to be ordered against another), and the workgroups y >= 1 read the 24
+//     entries after their last rate store: the wave runs its rate pass again on the patched row, stored by the lanes
+//     whose quad of agents has a mover (own stores acknowledged first).  The rows end up as the population's kernel
+//     would have written them from the history row the reset patched.
 //   * What a lane's bookkeeping writes where other workgroups read (the position, the next action in the drift
-//     buffer) is handed back in registers and stored with the state, behind the arrival words.
-// Workgroups y >= 1 now wait for the writer's verdict, which the writer posts without waiting for anybody: still no
-// cycle; it needs the writers dispatched no later than the rest (they have the lowest workgroup ids) and is bounded by
-// the same spin limit and counter as the state write-back.
+//     buffer) is stored behind the arrival words.
+// Workgroups y >= 1 now wait for the writer's verdict, which the writer posts without waiting for anybody: no cycle, but
+// the grid has to be resident at once (launch_step1_cell refuses shapes that are not); bounded by the same spin limit
+// and counter as the state write-back.
 struct Step1Task {
   TaskArgs a;
   ResetArgs r;  // (pos_x / hist_x null: the writer stores what it is handed back)
