@@ -25,6 +25,8 @@ import torch
 from . import _lib, utils
 from ._history import DeviceHistory, HistoryView
 
+_Tensor = torch.Tensor
+
 _L = _lib
 LOG2E = 1.4426950408889634
 
@@ -76,7 +78,7 @@ class Neurons:
         """What `update()` depends on besides the agent's state, by VALUE (users edit tuning arrays in place,
         reference tests/test_advanced.py:59): compared on every update() served by plan.AutoStepper."""
         f = self._call(None, None)  # (content-keyed device tables: identical objects while nothing changed)
-        return (tuple(id(v) if torch.is_tensor(v) else v for v in f.values()), float(self.min_fr), float(self.max_fr),
+        return (tuple([id(v) if type(v) is _Tensor else v for v in f.values()]), float(self.min_fr), float(self.max_fr),
                 self.noise_std, self.noise_coherence_time, bool(self.save_history), bool(self.save_spikes))
 
     def _env_op_args(self):

@@ -356,6 +356,12 @@ class AutoStepper:
             self._pops.append(pop)
             self._keys.append(N._auto_key())
         _attach_fused(self, agent)
+        # (two native calls per step of the user's loop: the stream handle straight from the C API by device index, the
+        # entry points bound once)
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        self._raw_stream = raw if raw is not None else (lambda _i: torch.cuda.current_stream().cuda_stream)
+        self._dev_index = agent._device_index
+        self._step_agent_fn, self._step_pop_fn = _L.lib.riab_plan_step_agent, _L.lib.riab_plan_step_population
         self._a_pending, self._a_times = 0, []
         self._p_pending = [0] * len(self.neurons)
         self._p_times = [[] for _ in self.neurons]
@@ -435,11 +441,12 @@ class AutoStepper:
             return False                  # (a trajectory was imported, or another one, since the plan was recorded)
         if self._forced is not None:
             self._forced.ensure(1, self._dt)
-        rc = _L.lib.riab_plan_step_agent(self._h, _L.current_stream())
-        if rc == _L.EFULL:
-            self._attach_agent()
-            rc = _L.lib.riab_plan_step_agent(self._h, _L.current_stream())
-        _L.check(rc, "riab_plan_step_agent")
+        rc = self._step_agent_fn(self._h, self._raw_stream(self._dev_index))
+        if rc:
+            if rc == _L.EFULL:
+                self._attach_agent()
+                rc = self._step_agent_fn(self._h, self._raw_stream(self._dev_index))
+            _L.check(rc, "riab_plan_step_agent")
         if self._forced is not None:
             self._forced.used(1)
         ag.prev_t = ag.t
@@ -473,11 +480,12 @@ class AutoStepper:
         i = self._index.get(N)
         if i is None or N._auto_key() != self._keys[i]:
             return False
-        rc = _L.lib.riab_plan_step_population(self._h, i, _L.current_stream())
-        if rc == _L.EFULL:
-            self._attach_pop(i)
-            rc = _L.lib.riab_plan_step_population(self._h, i, _L.current_stream())
-        _L.check(rc, "riab_plan_step_population")
+        rc = self._step_pop_fn(self._h, i, self._raw_stream(self._dev_index))
+        if rc:
+            if rc == _L.EFULL:
+                self._attach_pop(i)
+                rc = self._step_pop_fn(self._h, i, self._raw_stream(self._dev_index))
+            _L.check(rc, "riab_plan_step_population")
         self._p_pending[i] += 1
         self._p_times[i].append(self.agent.t)
         return True
