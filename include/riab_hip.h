@@ -790,7 +790,9 @@ int riab_streamer_last_form(RiabStreamer* h);
  * before it (a stream that shares the caller's hardware queue makes that pair 30-50 us slower), 6 the same time with
  * both launches on the caller's stream; 7 calls whose rate stage the HOST launched more than 12 us after the trajectory
  * kernel's launch had returned (a descheduled thread, a kernel's first launch in the process): such a call can be counted
- * in ctrl[RIAB_CTRL_SERIALISED] without any queue being shared — readers subtract */
+ * in ctrl[RIAB_CTRL_SERIALISED] without any queue being shared — readers subtract; 8 the last call ran in strict mode, 9
+ * the streamer has its own second stream (riab_streamer_warmup), 10 the HIP streams the process-wide pool holds (bounded:
+ * eight callers' streams per device have an entry, a ninth takes over the least recently used one) */
 int64_t riab_streamer_info(RiabStreamer* h, int32_t which);
 
 /* A/B switches of the library (comparisons and tests; the defaults are what production runs): process-wide, read on

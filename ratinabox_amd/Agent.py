@@ -1078,7 +1078,8 @@ class Agent:
         pair = f(4)
         return {"launches_last_call": f(3), "strict_last_call": bool(f(8)),
                 "second_stream": {"screened": pair >= 0, "pair_us": round(pair / 1e3, 1) if pair >= 0 else None,
-                                  "same_stream_pair_us": round(f(6) / 1e3, 1), "candidates_set_aside": f(5)},
+                                  "same_stream_pair_us": round(f(6) / 1e3, 1), "candidates_set_aside": f(5),
+                                  "streams_held_by_the_pool": f(10)},
                 "form_selection": {"trajectory_step_ns": f(0), "lead_store_MBps": f(1), "measured": bool(f(2))}}
 
     def last_rate_stage_form(self):

@@ -117,13 +117,22 @@ struct RiabStreamer {
 // every streamer of that caller borrows it (calls on one caller's stream are ordered anyway).  Screening needs the
 // caller's stream idle (it synchronises it); a first call that finds it busy borrows an unscreened stream and the
 // screening happens at the first idle call.
+// The pool is BOUNDED: at most SIDE_POOL_CAP caller streams per device have an entry.  One more caller's stream takes over
+// the least recently used entry with its stream (unscreened for the new pair; a streamer still holding that stream for
+// its old caller keeps working: a HIP stream shared by two callers is still an ordered queue, the two only queue behind
+// each other there), and once PARKED_CAP rejected candidates are parked they are tried again for other callers instead of
+// creating more.  A process that makes a new torch stream per task therefore holds a few dozen HIP streams, not six per
+// stream it ever used.
 namespace {
+constexpr size_t SIDE_POOL_CAP = 8, PARKED_CAP = 24;
 struct SideEntry {
   int dev;
   hipStream_t main, side;
   bool screened;
   int pair_ns, ref_ns, rejected;
+  uint64_t last_use;
 };
+uint64_t g_side_tick = 0;
 std::mutex g_side_mu;
 std::vector<SideEntry> g_side;
 std::vector<hipStream_t> g_parked;  // rejected candidates: kept for the life of the process
@@ -151,6 +160,11 @@ double pair_us(uint32_t* scratch, hipStream_t a, hipStream_t b, int n) {
 }
 
 hipStream_t new_candidate() {
+  if (g_parked.size() >= PARKED_CAP) {  // (set aside for another caller's stream: may do for this one)
+    hipStream_t s = g_parked.front();
+    g_parked.erase(g_parked.begin());
+    return s;
+  }
   int least = 0, greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
   hipStream_t s = nullptr;
@@ -165,9 +179,24 @@ bool side_stream_for(RiabStreamer* h, hipStream_t main_s, bool idle) {
   for (SideEntry& x : g_side)
     if (x.dev == h->dev && x.main == main_s) e = &x;
   if (!e) {
-    g_side.push_back(SideEntry{h->dev, main_s, nullptr, false, 0, 0, 0});
-    e = &g_side.back();
+    size_t on_dev = 0;
+    SideEntry* lru = nullptr;
+    for (SideEntry& x : g_side) {
+      if (x.dev != h->dev) continue;
+      on_dev += 1;
+      if (!lru || x.last_use < lru->last_use) lru = &x;
+    }
+    if (on_dev >= SIDE_POOL_CAP && lru) {  // bounded pool: the least recently used caller's entry, stream included
+      lru->main = main_s;
+      lru->screened = false;
+      lru->pair_ns = lru->ref_ns = lru->rejected = 0;
+      e = lru;
+    } else {
+      g_side.push_back(SideEntry{h->dev, main_s, nullptr, false, 0, 0, 0, 0});
+      e = &g_side.back();
+    }
   }
+  e->last_use = ++g_side_tick;
   int cur_dev = -1;
   (void)hipGetDevice(&cur_dev);   // (screening allocates and launches on the CURRENT device: only when that is the streamer's)
   if (!e->screened && idle && cur_dev == h->dev && h->dev >= 0 && h->dev < 64) {
@@ -367,6 +396,12 @@ extern "C" int64_t riab_streamer_info(RiabStreamer* h, int32_t which) {
     case 7: return h->late_calls;
     case 8: return h->last_strict;
     case 9: return h->side_own ? 1 : 0;
+    case 10: {  // HIP streams the process-wide pool holds on this streamer's device (entries' + parked)
+      std::lock_guard<std::mutex> lock(g_side_mu);
+      int64_t n = (int64_t)g_parked.size();
+      for (const SideEntry& x : g_side) n += (x.dev == h->dev && x.side) ? 1 : 0;
+      return n;
+    }
     default: return -1;
   }
 }

@@ -1309,3 +1309,31 @@ def test_serialised_pipeline_is_detected(riab, tmp_path):
     assert out["default"]["serialised"] <= 1 and out["default"]["timeouts"] == 0 and out["one_queue"]["timeouts"] == 0
     assert out["default"]["checksum"] == out["one_queue"]["checksum"]
     assert out["one_queue"]["serialised"] > 0 or out["one_queue"]["ms"] < 1.25 * out["default"]["ms"], out
+
+
+def test_the_second_stream_pool_is_bounded(riab):
+    """simulate() from twenty different caller streams: the same rows as from one stream, and the process-wide pool of
+    second streams (csrc/riab_simulate.hip side_stream_for) holds a bounded number of HIP streams — eight callers'
+    entries, a ninth takes over the least recently used one; rejected candidates are tried again beyond two dozen."""
+    def world():
+        np.random.seed(1)
+        env = riab.Environment()
+        ag = riab.Agent(env, {"n_agents": 256, "dt": 0.01, "seed": 5})
+        pcs = riab.PlaceCells(ag, {"n": 32, "wall_geometry": "euclidean", "save_spikes": False})
+        return ag, pcs
+
+    ag, pcs = world()
+    streams = [torch.cuda.Stream() for _ in range(20)]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            ag.simulate(8)
+        torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    held = ag.pipeline_info()["second_stream"]["streams_held_by_the_pool"]
+    assert 1 <= held <= 8 + 24 + 6, held
+    ref_ag, ref_pcs = world()
+    ref_ag.simulate(8 * len(streams))
+    torch.cuda.synchronize()
+    assert np.array_equal(np.asarray(ag.history["pos"]), np.asarray(ref_ag.history["pos"]))
+    assert np.array_equal(np.asarray(pcs.history["firingrate"]), np.asarray(ref_pcs.history["firingrate"]))
