@@ -3,8 +3,9 @@
 set -e
 R=$(cd $(dirname $0)/.. && pwd); W=/tmp/s1objs; mkdir -p $W $R/ratinabox_amd/lib/variants
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I $R/include -I $R/ratinabox_amd/csrc"
+NEWEST=$(ls -t $R/ratinabox_amd/csrc/*.h $R/include/riab_hip.h | head -1)   # (any header newer than an object: rebuild it)
 for u in riab_rates riab_agent riab_bvc riab_ff riab_ovc riab_plan riab_task riab_env riab_simulate; do
-  [ -f $W/$u.o ] && [ $W/$u.o -nt $R/ratinabox_amd/csrc/$u.hip ] && [ $W/$u.o -nt $R/include/riab_hip.h ] || hipcc $F -c $R/ratinabox_amd/csrc/$u.hip -o $W/$u.o &
+  [ -f $W/$u.o ] && [ $W/$u.o -nt $R/ratinabox_amd/csrc/$u.hip ] && [ $W/$u.o -nt $NEWEST ] || hipcc $F -c $R/ratinabox_amd/csrc/$u.hip -o $W/$u.o &
 done; wait
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
