@@ -916,9 +916,8 @@ class TaskLane:
             g += 1                    # also after a pop (:1141): the goal that slid into slot g waits
         return done
 
-    def step(self, pos, t_env):
-        """-> (reward total, terminal).  `t_env` is the clock after `self.t += self.dt`."""
-        # RewardCache.update (:913-927) with the remove-while-iterating skip
+    def _rewards_update(self):
+        """RewardCache.update (:913-927) with the remove-while-iterating skip."""
         i = 0
         while i < len(self.rewards):
             state, expire, src = self.rewards[i]
@@ -931,6 +930,10 @@ class TaskLane:
             else:
                 self.rewards[i] = [state, expire, src]
             i += 1
+
+    def step(self, pos, t_env):
+        """-> (reward total, terminal).  `t_env` is the clock after `self.t += self.dt`."""
+        self._rewards_update()
         self._check_pass(pos, t_env)
         terminal = len(self.goal_list) == 0
         if terminal and self.terminate_delay and not self.delayed:  # :421-434
@@ -951,6 +954,112 @@ class TaskLane:
 
     def reset(self, t_env, selected):
         """TaskEnvironment.reset (:307-351) with the goal selection given (`selected` pool indices)."""
+        zero = False
+        if self.started:
+            duration = t_env - self.ep_start
+            zero = duration == 0
+            if not zero:
+                self.any_ended = True
+                self.finished.append((self.episode, self.ep_start, t_env, duration))
+        if not zero:
+            self.episode += 1
+        self.started = True
+        self.ep_start = t_env if self.any_ended else 0.0
+        self.goal_list = [int(s) for s in selected]
+        self.delayed = False
+
+
+def world_check_pass(goal_list, met, sequential):
+    """One GoalCache.check(remove_finished=True) (:1076-1152) over SEVERAL agents with agentmode="interact"
+    (GoalCache.pop :1165-1172: a goal is popped from every agent's list, so all lists stay equal — one shared list).
+    `goal_list`: the shared list (modified in place); `met(agent, entry) -> bool`: Goal.check for that agent.
+    Agents take their turns in `agent_names` order against the list AS THE EARLIER AGENTS OF THE PASS LEFT IT.
+    Returns [(agent, entry), ...] in award order."""
+    awards = []
+    n_agents = met.n_agents
+    for a in range(n_agents):
+        if len(goal_list) == 0:           # :1102 / :1126
+            continue
+        if sequential:                    # `this` is the head for everybody: pop() rewinds every agent's marker (:1167-1172)
+            if met(a, goal_list[0]):
+                awards.append((a, goal_list[0]))
+                del goal_list[0]
+            continue
+        g = 0
+        while g < len(goal_list):
+            if met(a, goal_list[g]):
+                awards.append((a, goal_list[g]))
+                del goal_list[g]
+            g += 1                        # also after a pop (:1141): the goal that slid into slot g is left to the later agents
+    return awards
+
+
+class _Met:
+    def __init__(self, n_agents, fn):
+        self.n_agents = n_agents
+        self.fn = fn
+
+    def __call__(self, a, entry):
+        return self.fn(a, entry)
+
+
+class TaskWorld:
+    """A TaskEnvironment with `n_agents` agents in ONE world, agentmode="interact" (the reference's default, :1030):
+    one clock, one episode, one shared goal list; every agent keeps its own reward cache.  Stepped exactly as
+    TaskEnvironment.step does after the agents' updates (:410-449).  `goals`: rows as for TaskLane."""
+
+    def __init__(self, env, goals, n_agents, goalorder="nonsequential", terminate_delay=0.0, default_reward_level=0.0):
+        self.lanes = [TaskLane(env, goals, goalorder, terminate_delay, default_reward_level) for _ in range(n_agents)]
+        self.n_agents = n_agents
+        self.sequential = goalorder == "sequential"
+        self.terminate_delay = float(terminate_delay)
+        self.goal_list = []
+        self.pad_start = 0.0
+        self.delayed = False
+        self.episode = 0
+        self.ep_start = 0.0
+        self.started = False
+        self.any_ended = False
+        self.finished = []
+        self.late_completions = 0
+
+    def _pass(self, pos, t_env):
+        def met(a, entry):
+            L = self.lanes[a]
+            L.pad_start = self.pad_start
+            return L._met(entry, pos[a], t_env)
+        awards = world_check_pass(self.goal_list, _Met(self.n_agents, met), self.sequential)
+        for a, entry in awards:           # _is_terminal_state (:283-285): appended in award order
+            self.lanes[a]._award(entry)
+        return len(awards)
+
+    def step(self, pos, t_env):
+        """-> (reward totals [n_agents], terminal).  `pos` [n_agents, 2] after the agents' updates."""
+        pos = np.asarray(pos, float).reshape(self.n_agents, 2)
+        for L in self.lanes:              # RewardCache.update of every agent (:406-408)
+            L._rewards_update()
+        self._pass(pos, t_env)
+        terminal = len(self.goal_list) == 0
+        if terminal and self.terminate_delay and not self.delayed:   # :421-434: the pad goal joins every agent's list
+            self.delayed = True
+            self.pad_start = t_env
+            self.goal_list.append(GOAL_TIME_ELAPSED)
+            self._pass(pos, t_env)
+            terminal = len(self.goal_list) == 0
+        late = self._pass(pos, t_env)     # :438
+        terminal_last = len(self.goal_list) == 0
+        if late and terminal_last and not terminal:
+            self.late_completions += 1
+        totals = []
+        for L in self.lanes:
+            total = 0.0
+            for r in L.rewards:
+                total = total + r[0]
+            totals.append(total + L.default_level)
+        return np.array(totals), terminal_last
+
+    def reset(self, t_env, selected):
+        """TaskEnvironment.reset (:307-351): one episode table, one goal selection for everybody."""
         zero = False
         if self.started:
             duration = t_env - self.ep_start

@@ -812,6 +812,183 @@ def make_task():
         np.savez_compressed(os.path.join(HERE, f"task_{name}.npz"), **out)
 
 
+
+def make_task_world():
+    """TaskEnvironment.step / reset with SEVERAL agents in ONE environment, agentmode="interact" (the reference's
+    default, contribs/TaskEnvironment.py:1030, 1154-1172): one shared episode, a goal is consumed for everybody by the
+    first agent — in `agent_names` order — found inside it.  Per step: every agent's action and two OU normals, its
+    position and reward total afterwards, its reward-cache size; the returned terminal flag, the length of the shared
+    goal list and its pool indices."""
+    from ratinabox.contribs.TaskEnvironment import SpatialGoalEnvironment, SpatialGoal, Reward
+    _section("task world")
+    presets = {"constant": 0, "linear": 1, "exponential": 2, "none": 3}
+    scenarios = {
+        # name: (env params, goal positions, radius, rewards, goalcachekws, delay, teleport, n agents, n steps, speed,
+        #        start positions (None = the reference's own random ones))
+        "nonseq": ({}, [[0.2, 0.25], [0.8, 0.7], [0.5, 0.1], [0.3, 0.8], [0.7, 0.2]], None, None,
+                   dict(reset_n_goals=4, reset_orders_goal=True, goalorder="nonsequential", agentmode="interact"),
+                   0.0, False, 6, 500, 9.0, None),
+        # a wall between the goals; sequential order: the head of the shared list moves on within one pass
+        "seq_delay": ({"walls": [[[0.5, 0.0], [0.5, 0.6]]]}, [[0.45, 0.3], [0.25, 0.8], [0.75, 0.8], [0.55, 0.3]], 0.12,
+                      [dict(init_state=2.0, expire_clock=0.3, decay="constant", decay_knobs=[0.5]),
+                       dict(init_state=1.0, expire_clock=0.5, decay="linear", decay_knobs=[3]),
+                       dict(init_state=-1.0, expire_clock=0.5, decay="linear", decay_knobs=[6], dt=0.02),
+                       dict(init_state=0.5, expire_clock=0.2, decay="none", decay_knobs=[0])],
+                      dict(reset_n_goals=4, reset_orders_goal=True, goalorder="sequential", agentmode="interact"),
+                      0.05, False, 5, 800, 14.0, None),
+        # overlapping goals and agents that travel together: several agents stand in several goals on the same step
+        # (list-index skip after a pop, goals that pass to a later agent of the same pass, late completions)
+        "overlap_teleport": ({}, [[0.5, 0.5], [0.52, 0.5], [0.5, 0.53], [0.2, 0.8], [0.21, 0.79]], 0.12, None,
+                             dict(reset_n_goals=5, reset_orders_goal=True, goalorder="nonsequential", agentmode="interact"),
+                             0.03, True, 8, 600, 14.0, "cluster"),
+        # sequential, overlapping heads, a cluster of agents: more than one head consumed in one pass
+        "seq_overlap": ({}, [[0.5, 0.5], [0.52, 0.5], [0.5, 0.53], [0.8, 0.2]], 0.12, None,
+                        dict(reset_n_goals=4, reset_orders_goal=True, goalorder="sequential", agentmode="interact"),
+                        0.0, True, 6, 500, 14.0, "cluster"),
+    }
+    for name, (envp, gpos, radius, rewards, gckws, delay, teleport, n_agents, n_steps, speed, start) in scenarios.items():
+        np.random.seed(4000 + len(name))
+        env = SpatialGoalEnvironment(params=dict(envp), possible_goal_positions=np.array(gpos), render_mode="none",
+                                     goalcachekws=dict(gckws), episode_terminate_delay=delay, teleport_on_reset=teleport,
+                                     goalkws=({} if radius is None else {"goal_radius": radius}))
+        pool = env.goal_cache.reset_goals
+        if rewards is not None:
+            for g, rw in zip(pool, rewards):
+                g.reward = Reward(**dict({"dt": 0.01}, **rw))
+                g.reward.goal = g
+        goal_table = np.array([[g.pos[0], g.pos[1], g.radius, g.reward.state, g.reward.dt, g.reward.expire_clock,
+                                presets[g.reward.preset], g.reward.decay_knobs[0]] for g in pool], float)
+        index_of = {id(g): i for i, g in enumerate(pool)}
+        Ags = [Agent(env, {"dt": 0.01}) for _ in range(n_agents)]
+        env.add_agents(Ags)
+        names = list(env.agent_names)
+
+        def cluster():
+            c = np.array([0.78, 0.3])   # (the agents with the higher indices are nearer to the goals: they arrive first)
+            for i, A in enumerate(Ags):
+                A.pos = c + 0.03 * np.array([-(i % 3), i // 3], float)
+
+        if start == "cluster":
+            cluster()
+        state0 = np.array([np.concatenate([np.ravel(x) for x in _get_state(A)]) for A in Ags])
+        rec = {k: [] for k in ("action", "z", "pos", "reward", "terminal", "goals_left", "goal_list", "n_rewards", "reset",
+                               "teleport_pos", "late")}
+        _capture["on"] = True
+        for t in range(n_steps):
+            shared = env.goal_cache.goals[names[0]]
+            pend = [g.pos for g in shared if isinstance(g, SpatialGoal)]
+            acts = {}
+            for nm, A in zip(names, Ags):   # policy (input data only): the head (sequential) / the nearest pending goal
+                if not pend:
+                    v = np.zeros(2)
+                elif gckws["goalorder"] == "sequential":
+                    v = pend[0] - A.pos
+                else:
+                    v = min((p_ - A.pos for p_ in pend), key=np.linalg.norm)
+                nv = np.linalg.norm(v)
+                acts[nm] = speed * A.speed_mean * (v / nv) if nv > 0 else np.array([np.nan, np.nan])
+            _rec["normal"].clear()
+            if len(env.agents) != n_agents:
+                raise RuntimeError("inactive agents stepped")
+            obs, rew, term, trunc, info = env.step({k: np.array(v) for k, v in acts.items()})
+            scal = [z for shp, z in _rec["normal"] if shp == ()]
+            assert len(scal) == 2 * n_agents, len(scal)
+            lists = [env.goal_cache.goals[nm] for nm in names]
+            assert all([id(g) for g in l] == [id(g) for g in lists[0]] for l in lists)   # one shared list
+            left = len(lists[0])
+            assert len(set(term.values())) == 1
+            term = bool(term[names[0]])
+            rec["action"].append(np.array([acts[nm] for nm in names]))
+            rec["z"].append(np.array(scal, float).reshape(n_agents, 2))
+            rec["pos"].append(np.array([A.pos for A in Ags], float))
+            rec["reward"].append(np.array([float(rew[nm]) for nm in names]))
+            rec["terminal"].append(term)
+            rec["goals_left"].append(left)
+            gl = np.full(16, -1)
+            gl[:left] = [index_of.get(id(g), -2) for g in lists[0]]
+            rec["goal_list"].append(gl)
+            rec["n_rewards"].append(np.array([len(A.reward.cache) for A in Ags]))
+            rec["late"].append((left == 0) and not term)
+            if left == 0:   # (reset also after a late completion: the reference's next step would raise)
+                _capture["on"] = False
+                env.reset()
+                if start == "cluster" and teleport:   # (keeps the agents travelling together: input data)
+                    cluster()
+                _capture["on"] = True
+                rec["reset"].append(True)
+                rec["teleport_pos"].append(np.array([A.pos for A in Ags], float))
+            else:
+                rec["reset"].append(False)
+                rec["teleport_pos"].append(np.full((n_agents, 2), np.nan))
+        _capture["on"] = False
+        out = {k: np.array(v) for k, v in rec.items()}
+        ep = env.episodes
+        out.update(episodes=np.array([[e, s, en, d] for e, s, en, d in zip(ep["episode"], ep["start"], ep["end"], ep["duration"])],
+                                     float).reshape(-1, 4),
+                   state0=state0, goal_table=goal_table, user_walls=np.array(envp.get("walls", []), float).reshape(-1, 2, 2),
+                   goalorder=str(gckws["goalorder"]), reset_n_goals=int(gckws["reset_n_goals"]), terminate_delay=float(delay),
+                   teleport=bool(teleport), dt=0.01)
+        awards = np.diff(np.concatenate([[np.zeros(n_agents)], out["n_rewards"]]), axis=0)
+        print(f"  {name}: {n_agents} agents x {n_steps} steps, resets {int(out['reset'].sum())}, late completions "
+              f"{int(out['late'].sum())}, steps with awards to > 1 agent {int(((awards > 0).sum(axis=1) > 1).sum())}, "
+              f"awards per agent {(np.maximum(awards, 0)).sum(axis=0).astype(int).tolist()}, "
+              f"max rewards in a cache {int(out['n_rewards'].max())}")
+        np.savez_compressed(os.path.join(HERE, f"taskworld_{name}.npz"), **out)
+
+    # ---- the list logic alone: the reference's GoalCache.check over random "who stands in which goal" tables ----
+    from ratinabox.contribs.TaskEnvironment import GoalCache, Goal
+
+    class _TableGoal(Goal):   # (a goal whose check() reads a table: input data; the cache's walk is the reference's)
+        def __init__(self, env, index):
+            super().__init__(env, reward=Reward(1, 0.01, expire_clock=1, decay="linear"))   # (its own: reward.goal names it)
+            self.index = index
+
+        def check(self, agents=None):
+            return {a: self.reward for a in self.env._agentnames(agents) if self.env.met[self.env.agent_names.index(a), self.index]}
+
+    class _FakeEnv:
+        def __init__(self, n_agents):
+            self.agent_names = [f"agent_{i}" for i in range(n_agents)]
+            self.Ags = {nm: None for nm in self.agent_names}
+
+        def _agentnames(self, agents=None):
+            if agents is None:
+                return self.agent_names
+            return [agents] if isinstance(agents, str) else list(agents)
+
+    rs = np.random.RandomState(99)
+    n_cases, A_MAX, G_MAX, P_MAX = 400, 12, 8, 3
+    met_all = np.zeros((n_cases, A_MAX, G_MAX), bool)
+    dims = np.zeros((n_cases, 3), int)          # agents, goals, sequential
+    award_agent = np.full((n_cases, P_MAX, G_MAX), -1)
+    award_goal = np.full((n_cases, P_MAX, G_MAX), -1)
+    left_after = np.full((n_cases, P_MAX, G_MAX), -1)
+    for c in range(n_cases):
+        na, ng, seq = rs.randint(1, A_MAX + 1), rs.randint(1, G_MAX + 1), c % 2
+        fe = _FakeEnv(na)
+        fe.met = rs.random_sample((na, ng)) < rs.choice([0.05, 0.2, 0.5, 0.9])
+        goals = [_TableGoal(fe, i) for i in range(ng)]
+        gc = GoalCache(fe, goalorder="sequential" if seq else "nonsequential", agentmode="interact", reset_goals=goals,
+                       reset_n_goals=ng, reset_orders_goal=True)
+        gc.reset()
+        met_all[c, :na, :ng] = fe.met
+        dims[c] = na, ng, seq
+        for p_ in range(P_MAX):
+            before = [g.index for g in gc.goals[fe.agent_names[0]]]
+            rewards, agents = gc.check(remove_finished=True)
+            after = [g.index for g in gc.goals[fe.agent_names[0]]]
+            assert all([g.index for g in gc.goals[nm]] == after for nm in fe.agent_names)
+            gone = [g for g in before if g not in after]
+            assert sorted(gone) == sorted(r.goal.index for r in rewards) and len(gone) == len(agents)
+            award_agent[c, p_, :len(agents)] = [fe.agent_names.index(a) for a in agents]
+            award_goal[c, p_, :len(agents)] = [r.goal.index for r in rewards]
+            left_after[c, p_, :len(after)] = after
+    np.savez_compressed(os.path.join(HERE, "taskworld_list_logic.npz"), met=met_all, dims=dims, award_agent=award_agent,
+                        award_goal=award_goal, left_after=left_after)
+    print(f"  list logic: {n_cases} tables, {int((award_agent >= 0).sum())} awards, "
+          f"{int(((award_agent >= 0).sum(axis=2) > 1).sum())} passes with more than one")
+
+
 # ------------------------------------------------------------- BASELINE cfg 1 -- #
 def make_cfg1():
     """BASELINE.json configs[0] / README.md:43: 1 agent, 1 m box, 100 gaussian PlaceCells, dt = 10 ms, 60 s =
@@ -1016,12 +1193,12 @@ def make_helpers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task", "polygon", "cfg1", "stats", "helpers"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task", "task_world", "polygon", "cfg1", "stats", "helpers"]
     if "--out" in which:  # write somewhere else (tools/check_golden.py regenerates into a temporary directory)
         HERE = which[which.index("--out") + 1]
         which = [w for i, w in enumerate(which) if w != "--out" and (i == 0 or which[i - 1] != "--out")] or \
             ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task",
-             "polygon", "cfg1", "stats", "helpers"]
+             "task_world", "polygon", "cfg1", "stats", "helpers"]
         os.makedirs(HERE, exist_ok=True)
     if "helpers" in which:
         make_helpers()
@@ -1033,6 +1210,8 @@ if __name__ == "__main__":
         make_stats()
     if "task" in which:
         make_task()
+    if "task_world" in which:
+        make_task_world()
     if "random_spatial" in which:
         make_random_spatial()
     if "env" in which:

@@ -69,3 +69,4 @@ FF_ACTS = {"linear": {"activation": "linear"},
            "softmax": {"activation": "softmax", "gain": 0.7, "threshold": 0.3}}
 
 TASK_FILES = sorted(f for f in os.listdir(GOLDEN) if f.startswith("task_") and f.endswith(".npz"))
+TASKWORLD_FILES = sorted(f for f in os.listdir(GOLDEN) if f.startswith("taskworld_") and f.endswith(".npz") and "list_logic" not in f)

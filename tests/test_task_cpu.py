@@ -41,6 +41,53 @@ def test_task_lane_oracle_vs_reference(fname):
     assert late == int(g["late"].sum())
 
 
+def test_world_list_logic_oracle_vs_reference():
+    """The oracle's walk of the SHARED goal list (several agents, agentmode="interact") against the reference's own
+    GoalCache.check driven by random who-stands-in-which-goal tables: awards (agent, goal) in order and the list left
+    behind, for three consecutive passes (what one step runs)."""
+    g = gu.load("taskworld_list_logic.npz")
+    for c in range(g["met"].shape[0]):
+        na, ng, seq = (int(x) for x in g["dims"][c])
+        met = g["met"][c]
+        lst = list(range(ng))
+        for p in range(g["award_agent"].shape[1]):
+            awards = orc.world_check_pass(lst, orc._Met(na, lambda a, e: bool(met[a, e])), bool(seq))
+            n = int((g["award_agent"][c, p] >= 0).sum())
+            assert [a for a, _ in awards] == g["award_agent"][c, p, :n].tolist(), (c, p)
+            assert [e for _, e in awards] == g["award_goal"][c, p, :n].tolist(), (c, p)
+            assert lst == g["left_after"][c, p, :len(lst)].tolist() and (g["left_after"][c, p, len(lst):] == -1).all(), (c, p)
+
+
+@pytest.mark.parametrize("fname", gu.TASKWORLD_FILES)
+def test_task_world_oracle_vs_reference(fname):
+    """Several agents in ONE reference TaskEnvironment (shared goals, one episode): every agent's reward total
+    (bit-exact) and cache size, the shared list, the terminal flag and the episode table, replayed from the
+    recorded positions."""
+    g = gu.load(fname)
+    env = orc.EnvSpec(walls=g["user_walls"])
+    n = int(g["reset_n_goals"])
+    T, A = g["pos"].shape[:2]
+    W = orc.TaskWorld(env, g["goal_table"], A, str(g["goalorder"]), float(g["terminate_delay"]))
+    W.reset(0.0, range(n))
+    t = 0.0
+    for k in range(T):
+        t = t + float(g["dt"])
+        totals, term = W.step(g["pos"][k], t)
+        assert np.array_equal(totals, g["reward"][k]), k
+        left = int(g["goals_left"][k])
+        assert W.goal_list == g["goal_list"][k, :left].tolist(), k
+        assert [len(L.rewards) for L in W.lanes] == g["n_rewards"][k].tolist(), k
+        assert term == (left == 0)
+        if not g["late"][k]:
+            assert term == bool(g["terminal"][k]), k
+        if g["reset"][k]:
+            W.reset(t, range(n))
+    mine = np.array(W.finished).reshape(-1, 4)
+    np.testing.assert_allclose(mine, g["episodes"][:len(mine)], rtol=0, atol=0)
+    assert len(mine) == int(g["reset"].sum())
+    assert W.late_completions == int(g["late"].sum())
+
+
 def test_reset_draws_are_permutation_prefixes():
     for lane in range(50):
         d = orc.task_reset_draws(seed=7, counter=3, lane_id=lane, n_pool=9, n_select=6)
