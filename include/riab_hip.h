@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RIAB_ABI_VERSION 6
+#define RIAB_ABI_VERSION 7
 #define RIAB_MAX_WALLS 64     /* walls staged in LDS by the motion / BVC / line-of-sight kernels */
 #define RIAB_MAX_TEST_ANGLES 360
 #define RIAB_STATE_ROWS 12    /* rows of the agent state matrix, see below */
@@ -580,6 +580,53 @@ int riab_task_reset(const RiabEnv* env, const RiabTask* task, double* task_state
                     uint64_t counter, int32_t teleport, const double* new_x, const double* new_y, double* pos_x,
                     double* pos_y, float* hist_x, float* hist_y, double* ep_log, int64_t ep_log_cap,
                     int32_t* ep_count, int32_t* diag, riab_stream_t stream);
+
+/* ---- the other batching of the task: the lanes are the agents of ONE world ----------------------------
+ * The reference's TaskEnvironment with several Agents and agentmode = "interact" (its default,
+ * contribs/TaskEnvironment.py:1030): one clock, one episode, and — because GoalCache.pop removes a satisfied
+ * goal from every agent's list (:1165-1172) while reset / append fill all lists alike (:1204-1211, :1250-1252)
+ * — ONE shared goal list; every agent keeps its own reward cache (rows RIAB_TS_N_REWARDS, RIAB_TS_STEPS_*,
+ * RIAB_TS_R_*, RIAB_TS_RW_* of task_state; its goal / episode rows are unused).  GoalCache.check (:1076-1152)
+ * gives the agents their turns in agent order against the list as the earlier agents of the pass left it: a
+ * goal goes to the FIRST agent, in that order, found inside it; in a nonsequential turn the goal that slides
+ * into a popped slot is skipped by that agent and left to the later ones (:1141); in sequential order every
+ * agent looks at the head once per pass, so several heads can go in one pass.
+ * Shared state: device float64 [RIAB_TW_ROWS]. */
+enum {
+  RIAB_TW_N_GOALS = 0,      /* length of the shared goal list */
+  RIAB_TW_DELAYED = 1,      /* episode_state["delayed_term"] */
+  RIAB_TW_PAD_START = 2,    /* start_time of the termination-delay goal */
+  RIAB_TW_EPISODE = 3,      /* TaskEnvironment.episode */
+  RIAB_TW_EP_START = 4,     /* episodes["start"][-1] */
+  RIAB_TW_EP_ANY_ENDED = 5, /* an episode of non-zero duration has ended before */
+  RIAB_TW_STARTED = 6,      /* len(episodes["start"]) > 0 */
+  RIAB_TW_GOAL_LIST = 8,    /* [RIAB_TASK_MAX_GOALS] pool index of list entry i; RIAB_GOAL_TIME_ELAPSED = delay goal */
+  RIAB_TW_ROWS = 24
+};
+/* One TaskEnvironment.step (:410-449) of the world after the agents have moved; arguments as riab_task_step.
+ * One launch: every lane decays its own rewards and works out which goals of the list it stands in; the
+ * workgroup that finishes last (ticket: device int32, zero before the first call; the kernel leaves it zero)
+ * walks the step's check passes over the shared list, appends the awards to the winners' caches in award
+ * order and totals every agent's rewards.  met_scratch: device uint64 [B].  terminal_out [B] holds the world's
+ * flag for every agent ("no goals left" after the step's last pass, as riab_task_step).  No workgroup waits
+ * for another: capturable, nothing has to be co-resident. */
+int riab_task_world_step(const RiabEnv* env, const RiabTask* task, double* task_state, double* world,
+                         const double* pos_x, const double* pos_y, int64_t B, double t_env, double* reward_out,
+                         uint8_t* terminal_out, uint64_t* met_scratch, int32_t* ticket, int32_t* diag,
+                         riab_stream_t stream);
+/* TaskEnvironment.reset (:307-351) of the world: the episode is closed once (ep_log row: lane id -1), the
+ * shared list refilled with n_select goals of the pool (the first ones when `ordered`, else a sample drawn
+ * from Philox(seed; counter, id 0xFFFFFFFF)), every agent teleported when `teleport` (to (new_x, new_y)[b] or
+ * its own draw, as riab_task_reset).  No mask: there is one episode. */
+int riab_task_world_reset(const RiabEnv* env, const RiabTask* task, double* task_state, double* world, int64_t B,
+                          int64_t agent_id0, double t_env, int32_t n_select, int32_t ordered, uint64_t seed,
+                          uint64_t counter, int32_t teleport, const double* new_x, const double* new_y,
+                          double* pos_x, double* pos_y, float* hist_x, float* hist_y, double* ep_log,
+                          int64_t ep_log_cap, int32_t* ep_count, int32_t* diag, riab_stream_t stream);
+/* get_goal_vector (:1555-1584) of every agent against the shared list (arguments as riab_task_goal_vector). */
+int riab_task_world_goal_vector(const RiabEnv* env, const RiabTask* task, double* task_state, const double* world,
+                                const double* pos_x, const double* pos_y, int64_t B, double scale, double* out_x,
+                                double* out_y, riab_stream_t stream);
 
 /* Attach a task (riab_task_*) to the plan: every plan step then is one TaskEnvironment.step —
  * [scripted_speed > 0: drift <- scripted_speed * unit goal vector, written to the plan's drift buffer]

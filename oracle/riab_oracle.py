@@ -1025,9 +1025,9 @@ class TaskWorld:
 
     def _pass(self, pos, t_env):
         def met(a, entry):
-            L = self.lanes[a]
-            L.pad_start = self.pad_start
-            return L._met(entry, pos[a], t_env)
+            if entry == GOAL_TIME_ELAPSED:    # TimeElapsedGoal.check (:1271-1278): whoever looks
+                return t_env - self.pad_start >= self.terminate_delay
+            return bool(self._inside[a, entry])
         awards = world_check_pass(self.goal_list, _Met(self.n_agents, met), self.sequential)
         for a, entry in awards:           # _is_terminal_state (:283-285): appended in award order
             self.lanes[a]._award(entry)
@@ -1036,6 +1036,10 @@ class TaskWorld:
     def step(self, pos, t_env):
         """-> (reward totals [n_agents], terminal).  `pos` [n_agents, 2] after the agents' updates."""
         pos = np.asarray(pos, float).reshape(self.n_agents, 2)
+        # SpatialGoal._in_goal_radius (:1319-1332) of every agent for every goal of the pool, once per step (the passes ask
+        # about the same goals at the same positions)
+        G = self.lanes[0].goals
+        self._inside = env_distances(self.lanes[0].env, pos, G[:, 0:2], "line_of_sight") < G[None, :, 2]
         for L in self.lanes:              # RewardCache.update of every agent (:406-408)
             L._rewards_update()
         self._pass(pos, t_env)

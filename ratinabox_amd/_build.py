@@ -14,7 +14,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libriab_hip.so")
 SOURCES = ["riab_rates.hip", "riab_agent.hip", "riab_bvc.hip", "riab_ff.hip", "riab_ovc.hip", "riab_plan.hip",
-           "riab_task.hip", "riab_env.hip", "riab_simulate.hip", "riab_step1.hip"]
+           "riab_task.hip", "riab_task_world.hip", "riab_env.hip", "riab_simulate.hip", "riab_step1.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 
 from . import _build
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_WALLS = 64
 STATE_ROWS = 12
 HIST_ROWS = 8
@@ -103,6 +103,9 @@ GOAL_TIME_ELAPSED = -2
 DECAYS = {"constant": 0, "linear": 1, "exponential": 2, "none": 3}
 GOALORDERS = {"nonsequential": 0, "sequential": 1}
 TD_REWARD_OVERFLOW, TD_LATE_COMPLETIONS, TD_EPLOG_OVERFLOW, TD_RESETS = range(4)
+# rows of the shared state of a task whose lanes are the agents of one world (RIAB_TW_*)
+TW_N_GOALS, TW_DELAYED, TW_PAD_START, TW_EPISODE, TW_EP_START, TW_EP_ANY_ENDED, TW_STARTED = range(7)
+TW_GOAL_LIST, TW_ROWS = 8, 24
 
 POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4, "ff": 5, "velocity": 6, "speed": 7, "random_spatial": 8}
 EINVAL = -1
@@ -204,6 +207,15 @@ PROTOTYPES = {
                                   C.c_double, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "riab_task_world_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    "riab_task_world_reset": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                        C.c_double, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "riab_task_world_goal_vector": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_streamer_create": (C.c_void_p, []),
     "riab_streamer_destroy": (None, [C.c_void_p]),
     "riab_simulate": (C.c_int, [C.c_void_p, C.POINTER(RiabSimulate), C.c_void_p]),

@@ -19,8 +19,13 @@ Same names and constructor arguments as the reference: `TaskEnvironment`, `Spati
 `reward_default`, `no_reward_default`.  Outside the accelerated path (raise NotImplementedError):
 rendering, custom python decay / external-drive functions on rewards, user `TimeElapsedGoal`s in
 the pool, several Agent objects (put the agents in one batched Agent).  `goalorder="custom"` behaves as in the
-reference: accepted by the constructor, `ValueError("Unknown mode: custom")` from the first step's goal check.  `agentmode` is accepted for
-compatibility: with one agent per replica "interact" and "noninteract" coincide."""
+reference: accepted by the constructor, `ValueError("Unknown mode: custom")` from the first step's goal check.
+
+Two batchings (`lanes=`).  "replicas" (default): as above — with one agent per replica `agentmode` "interact" and
+"noninteract" coincide.  "agents": the lanes are the agents of ONE world, the reference's multi-agent TaskEnvironment
+with `agentmode="interact"` (its default, TaskEnvironment.py:1030): one episode, one SHARED goal list — a goal is
+consumed for everybody by the first agent, in agent order, found inside it (GoalCache.check / pop, :1076-1172) — and a
+reward cache per agent (`riab_task_world_step` / `_reset`, csrc/riab_task_world.hip)."""
 import copy
 import random
 import warnings
@@ -183,7 +188,10 @@ class GoalCache:
         return self.env._goal_lists()
 
     def __len__(self):
-        """Pending goals summed over the lanes (synchronises)."""
+        """Pending goals summed over the lanes — of the one shared list when the lanes are the agents of one world, like
+        the reference's `len(goal_cache)` (synchronises)."""
+        if self.env._shared:
+            return int(self.env.goals_left[0].item())
         return int(self.env.goals_left.sum().item())
 
 
@@ -223,10 +231,17 @@ class TaskEnvironment(Environment):
     def __init__(self, *pos, dt=0.01, render_mode="none", render_every=None, render_every_framestep=2,
                  teleport_on_reset=False, save_expired_rewards=False, goals=[], goalcachekws=dict(),
                  rewardcachekws=dict(), episode_terminate_delay=0, verbose=False, seed=0,
-                 episode_log_capacity=1 << 20, **kws):
+                 episode_log_capacity=1 << 20, lanes="replicas", **kws):
         super().__init__(*pos, **kws)
+        if lanes not in ("replicas", "agents"):
+            raise ValueError("lanes must be 'replicas' (every lane its own copy of the task) or 'agents' (one shared world)")
+        self.lanes = lanes
+        self._shared = lanes == "agents"
         self.Ags = {}
         self.goal_cache = GoalCache(self, **goalcachekws)
+        if self._shared and self.goal_cache.agentmode != "interact":
+            raise NotImplementedError("lanes='agents' shares the goals between the agents: agentmode='interact' "
+                                      "(the reference's default); use lanes='replicas' for independent goal lists")
         self.goal_cache.reset_goals = goals if isinstance(goals, list) else [goals]
         self.t = 0
         self.dt = dt
@@ -305,6 +320,10 @@ class TaskEnvironment(Environment):
         self._diag = torch.zeros(4, dtype=torch.int32, device=dev)
         self._ep_log = torch.zeros((self._ep_cap, 5), dtype=torch.float64, device=dev)
         self._ep_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self._shared:   # the world's own state, the lanes' "stands inside" masks, the last-workgroup ticket
+            self._world = torch.zeros(_L.TW_ROWS, dtype=torch.float64, device=dev)
+            self._met = torch.zeros(self._B, dtype=torch.int64, device=dev)
+            self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.reset()
 
     def remove_agents(self, agents=None):
@@ -382,6 +401,8 @@ class TaskEnvironment(Environment):
         if n_sel > _L.TASK_MAX_GOALS - 1:
             raise ValueError(f"at most {_L.TASK_MAX_GOALS - 1} goals per episode, got {n_sel}")
         m = None
+        if self._shared and mask is not None:
+            raise ValueError("lanes='agents': the agents share one episode, reset() takes no mask")
         if mask is not None:
             m = torch.as_tensor(mask, device=dev).to(torch.uint8).reshape(-1)
             assert m.shape[0] == self._B, "mask must have one entry per agent of the batch"
@@ -397,6 +418,24 @@ class TaskEnvironment(Environment):
         hist_row = getattr(ag, "_last_row", None)  # newest fp32 row [8, B_padded]: what the rate kernels read
         st = ag.state_tensor
         self._reset_counter += 1
+        if self._shared:
+            rc = _L.lib.riab_task_world_reset(env_s, task, _L.ptr(self.task_state), _L.ptr(self._world), self._B,
+                                              int(ag.agent_id0), float(self.t), int(n_sel), int(ordered), self._task_seed,
+                                              self._reset_counter, int(teleport),
+                                              _L.ptr(None if newpos is None else newpos[0]),
+                                              _L.ptr(None if newpos is None else newpos[1]), _L.ptr(st[0]), _L.ptr(st[1]),
+                                              _L.ptr(None if hist_row is None else hist_row[0]),
+                                              _L.ptr(None if hist_row is None else hist_row[1]),
+                                              _L.ptr(self._ep_log), self._ep_cap, _L.ptr(self._ep_count), _L.ptr(self._diag),
+                                              _L.current_stream())
+            _L.check(rc, "riab_task_world_reset")
+            self._keep = (newpos, walls, task, self._pool_dev)
+            if goal_selection is not None:   # one list for everybody: (n,) pool indices
+                sel = torch.as_tensor(np.asarray(goal_selection), device=dev).to(torch.float64).reshape(-1)
+                assert sel.shape[0] == n_sel, f"goal_selection must name {n_sel} goals"
+                self._world[_L.TW_GOAL_LIST:_L.TW_GOAL_LIST + n_sel].copy_(sel)
+            self.agents = copy.copy(self.agent_names)
+            return self.get_observation(), self.infos
         rc = _L.lib.riab_task_reset(env_s, task, _L.ptr(self.task_state), _L.ptr(m), self._B, int(ag.agent_id0),
                                     float(self.t), int(n_sel), int(ordered), self._task_seed, self._reset_counter,
                                     int(teleport), _L.ptr(None if newpos is None else newpos[0]),
@@ -454,10 +493,17 @@ class TaskEnvironment(Environment):
         env_s, walls = self.device_tables(dev)
         task = self._task_struct()
         st = ag.state_tensor
-        rc = _L.lib.riab_task_step(env_s, task, _L.ptr(self.task_state), _L.ptr(st[0]), _L.ptr(st[1]), self._B,
-                                   float(self.t), _L.ptr(self._reward), _L.ptr(self._terminal), _L.ptr(self._diag),
-                                   _L.current_stream())
-        _L.check(rc, "riab_task_step")
+        if self._shared:
+            rc = _L.lib.riab_task_world_step(env_s, task, _L.ptr(self.task_state), _L.ptr(self._world), _L.ptr(st[0]),
+                                             _L.ptr(st[1]), self._B, float(self.t), _L.ptr(self._reward),
+                                             _L.ptr(self._terminal), _L.ptr(self._met), _L.ptr(self._ticket),
+                                             _L.ptr(self._diag), _L.current_stream())
+            _L.check(rc, "riab_task_world_step")
+        else:
+            rc = _L.lib.riab_task_step(env_s, task, _L.ptr(self.task_state), _L.ptr(st[0]), _L.ptr(st[1]), self._B,
+                                       float(self.t), _L.ptr(self._reward), _L.ptr(self._terminal), _L.ptr(self._diag),
+                                       _L.current_stream())
+            _L.check(rc, "riab_task_step")
         self._keep_step = (walls, task)
         return (self.get_observation(), self._reward, self._terminal.bool(), self._truncated, self.infos)
 
@@ -465,6 +511,9 @@ class TaskEnvironment(Environment):
         """The whole closed-loop step as ONE native call (plan.py, riab_plan_*): `plan.step(1, drift_velocity=
         actions)` == `env.step(actions)` + `Neurons.update()` of every population (+ `env.reset(mask=terminal)`
         when `auto_reset`).  Read `env.get_reward()`, `env.terminal`, `env.get_observation()` afterwards."""
+        if self._shared:
+            raise NotImplementedError("step plans carry the per-lane task (lanes='replicas'); a shared world steps through "
+                                      "env.step()")
         plan = self._agent.make_step_plan(neurons, capacity)
         return plan.attach_task(self, auto_reset=auto_reset, scripted_speed=scripted_speed)
 
@@ -504,11 +553,15 @@ class TaskEnvironment(Environment):
 
     @property
     def goals_left(self):
+        if self._shared:   # (one list: the same count for every agent)
+            return self._world[_L.TW_N_GOALS].long().expand(self._B)
         return self.task_state[_L.TS_N_GOALS, :self._B].long()
 
     @property
     def episode(self):
-        """Episode counter per lane (device int tensor); the reference's scalar when B == 1."""
+        """Episode counter per lane (device int tensor); the reference's scalar when B == 1 or the lanes share one world."""
+        if self._shared:
+            return int(self._world[_L.TW_EPISODE].item())
         e = self.task_state[_L.TS_EPISODE, :self._B].long()
         return int(e[0].item()) if self._B == 1 else e
 
@@ -517,13 +570,24 @@ class TaskEnvironment(Environment):
         out = torch.empty((2, self._B), dtype=torch.float64, device=st.device)
         env_s, walls = self.device_tables(st.device)
         task = self._task_struct()
-        rc = _L.lib.riab_task_goal_vector(env_s, task, _L.ptr(self.task_state), _L.ptr(st[0]), _L.ptr(st[1]), self._B,
-                                          float(scale), _L.ptr(out[0]), _L.ptr(out[1]), _L.current_stream())
+        if self._shared:
+            rc = _L.lib.riab_task_world_goal_vector(env_s, task, _L.ptr(self.task_state), _L.ptr(self._world), _L.ptr(st[0]),
+                                                    _L.ptr(st[1]), self._B, float(scale), _L.ptr(out[0]), _L.ptr(out[1]),
+                                                    _L.current_stream())
+        else:
+            rc = _L.lib.riab_task_goal_vector(env_s, task, _L.ptr(self.task_state), _L.ptr(st[0]), _L.ptr(st[1]), self._B,
+                                              float(scale), _L.ptr(out[0]), _L.ptr(out[1]), _L.current_stream())
         _L.check(rc, "riab_task_goal_vector")
         self._keep_gv = (walls, task)
         return out.t()
 
     def _goal_lists(self):
+        if self._shared:   # every agent's list is the shared one
+            w = self._world.cpu().numpy()
+            row = np.full(_L.TASK_MAX_GOALS, -1)
+            n = int(w[_L.TW_N_GOALS])
+            row[:n] = w[_L.TW_GOAL_LIST:_L.TW_GOAL_LIST + n].astype(int)
+            return np.tile(row, (self._B, 1))
         ts = self.task_state[:, :self._B].cpu().numpy()
         n = ts[_L.TS_N_GOALS].astype(int)
         L = ts[_L.TS_GOAL_LIST:_L.TS_GOAL_LIST + _L.TASK_MAX_GOALS].T.astype(int)

@@ -340,9 +340,9 @@ struct ResetDraw {
   double x, y;
   u128 list;
 };
-__device__ __forceinline__ ResetDraw reset_draw(const TaskArgs& a, const ResetArgs& r, int64_t b) {
+// (`id`: the global agent id — or RIAB_WORLD_STREAM_ID for what a whole world draws once, riab_task_world.hip)
+__device__ __forceinline__ ResetDraw reset_draw_id(const TaskArgs& a, const ResetArgs& r, uint64_t id) {
   ResetDraw d = {0.0, 0.0, 0};
-  const uint64_t id = (uint64_t)(r.agent_id0 + b);
   if (r.teleport && !r.new_x) {  // sample_positions(1), "uniform_jitter": the centre of the box +- 0.45 * scale (Philox block 0)
     const u32x4 rnd = philox4x32_10((uint32_t)r.counter, (uint32_t)(r.counter >> 32), (uint32_t)id, RIAB_TAG_TASK,
                                     (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
@@ -381,6 +381,9 @@ __device__ __forceinline__ ResetDraw reset_draw(const TaskArgs& a, const ResetAr
   }
   d.list = list;
   return d;
+}
+__device__ __forceinline__ ResetDraw reset_draw(const TaskArgs& a, const ResetArgs& r, int64_t b) {
+  return reset_draw_id(a, r, (uint64_t)(r.agent_id0 + b));
 }
 struct EpisodeRecord {  // write_end_episode's row, on its way into the table
   bool pending;

@@ -1,0 +1,317 @@
+// TaskEnvironment whose lanes are the agents of ONE world, agentmode = "interact" (the reference's default,
+// contribs/TaskEnvironment.py:1030): one clock, one episode, ONE goal list — a goal is consumed for everybody by the
+// first agent, in agent order, found inside it (GoalCache.check :1076-1152 with GoalCache.pop :1165-1172) — and a
+// reward cache per agent.  (riab_task.hip is the other batching: every lane a single-agent replica of the task.)
+//
+// The reference's check is serial over the agents: each takes its turn against the list as the agents before it left
+// it.  What can be done per agent without looking at the others is done by every lane at once (phase A); the serial
+// remainder is a handful of turns — only an agent standing in a goal of the list changes anything, and every such turn
+// consumes at least one of the <= 16 entries — found by min-reductions over the lanes' "stands inside" masks (phase B).
+//
+//   phase A, all workgroups: RewardCache.update of the lane (:913-927), its mask of the list's goals it stands in
+//     (SpatialGoal.check :1337-1360: line-of-sight distance < radius), the surviving rewards' total;
+//   phase B, the workgroup that finishes LAST (a ticket counter; no workgroup waits for another: nothing has to be
+//     resident together, capturable): the step's check passes (:418-440) over the shared list, the awards appended to
+//     the winners' caches in award order, every lane's total (:929-939), the terminal flag, the shared state.
+//
+// Float64 like the reference; contraction off (riab_task_kernel.h).
+#include "riab_task_kernel.h"
+#include "riab_task_world_logic.h"
+
+#pragma clang fp contract(off)
+
+#define RIAB_WORLD_STREAM_ID 0xFFFFFFFFull  // Philox "agent id" of what the world draws once (its goal selection)
+
+namespace riab {
+
+constexpr int WORLD_BLOCK = 256;
+
+struct WorldShared {  // phase B's state, in LDS
+  uint8_t list[RIAB_TASK_MAX_GOALS];
+  int n;
+  WorldAward awards[RIAB_WL_MAX_AWARDS];
+  int n_awards;
+  int next_agent;  // min-reduction slot
+  unsigned long long any;
+  int last;
+};
+
+// One GoalCache.check(remove_finished=True) over all agents, by the whole workgroup (uniform control flow).
+// Returns the number of goals consumed.
+__device__ int world_pass(WorldShared& S, const uint64_t* met, int64_t B, uint64_t any, bool pad_elapsed, bool sequential) {
+  const int tid = (int)threadIdx.x;
+  int64_t a_next = 0;
+  int done = 0;
+  for (;;) {
+    __syncthreads();  // (the list as the last turn left it)
+    WorldList l = {S.list, S.n};
+    bool looks_at_pad;
+    const uint64_t mask = world_turn_mask(l, sequential, looks_at_pad);
+    const bool pad_now = looks_at_pad && pad_elapsed;
+    if (l.n == 0 || a_next >= B || (!(any & mask) && !pad_now)) break;
+    int64_t cand;
+    if (pad_now) {
+      cand = a_next;  // whoever's turn it is takes the termination-delay goal
+    } else {
+      if (tid == 0) S.next_agent = 0x7FFFFFFF;
+      __syncthreads();
+      for (int64_t i = a_next + tid; i < B; i += WORLD_BLOCK)
+        if (met[i] & mask) {
+          atomicMin(&S.next_agent, (int)i);
+          break;
+        }
+      __syncthreads();
+      if (S.next_agent == 0x7FFFFFFF) break;
+      cand = S.next_agent;
+    }
+    const int before = S.n;
+    __syncthreads();  // (everybody has read the slot and the list)
+    if (tid == 0) {
+      WorldList w = {S.list, S.n};
+      world_agent_turn(w, met[cand], pad_now, sequential, (int)cand, S.awards, S.n_awards);
+      S.n = w.n;
+    }
+    __syncthreads();
+    done += before - S.n;
+    a_next = cand + 1;
+  }
+  return done;
+}
+
+__global__ __launch_bounds__(WORLD_BLOCK) void task_world_step_kernel(TaskArgs a, double* world, const double* pos_x,
+                                                                       const double* pos_y, double t_env, double* reward_out,
+                                                                       uint8_t* terminal_out, uint64_t* met, int32_t* ticket,
+                                                                       int32_t* diag) {
+  __shared__ double s_goals[RIAB_TASK_MAX_POOL * RIAB_GOAL_COLS];
+  __shared__ WorldShared S;
+  const int tid = (int)threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x * WORLD_BLOCK + tid;
+  const bool live = b < a.B;
+  // ---- phase A
+  task_stage_goals(a, s_goals, tid, WORLD_BLOCK);
+  if (tid < RIAB_TASK_MAX_GOALS) S.list[tid] = (uint8_t)((int)world[RIAB_TW_GOAL_LIST + tid] & 0xFF);
+  if (tid == 0) S.n = (int)world[RIAB_TW_N_GOALS];
+  RewardsIn rin;
+  double px = 0.0, py = 0.0;
+  if (live) {
+    rin = load_rewards_in(a, b);
+    px = pos_x[b];
+    py = pos_y[b];
+  }
+  __syncthreads();
+  const lds_f64_ptr goals = (lds_f64_ptr)s_goals;
+  if (live) {
+    const RewardsOut ro = rewards_step(a, goals, b, rin);
+    if (ro.n_rw != rin.n_rw) ts_at(a, RIAB_TS_N_REWARDS, b) = (double)ro.n_rw;
+    uint64_t m = 0;
+    for (int g = 0; g < S.n; ++g) {
+      const int v = S.list[g];
+      if (v != (int)RIAB_WL_PAD && in_goal_radius(a, px, py, goals + v * RIAB_GOAL_COLS)) m |= 1ull << v;
+    }
+    met[b] = m;
+    reward_out[b] = ro.total;  // (the survivors' sum; phase B adds this step's awards and the default level)
+  }
+  // ---- the last workgroup to get here goes on
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) S.last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!S.last) return;
+  __threadfence();
+  // ---- phase B
+  uint64_t any = 0;
+  for (int64_t i = tid; i < a.B; i += WORLD_BLOCK) any |= met[i];
+  if (tid == 0) {
+    S.any = 0;
+    S.n_awards = 0;
+  }
+  __syncthreads();
+  if (any) atomicOr(&S.any, (unsigned long long)any);
+  __syncthreads();
+  any = S.any;
+  const bool sequential = a.goalorder == RIAB_GOALORDER_SEQUENTIAL;
+  const int n0 = S.n;
+  bool delayed = world[RIAB_TW_DELAYED] != 0.0;
+  const bool delayed0 = delayed;
+  double pad_start = world[RIAB_TW_PAD_START];
+  // _is_terminal_state (:278-290) as step() calls it (:418-440)
+  world_pass(S, met, a.B, any, t_env - pad_start >= a.terminate_delay, sequential);
+  bool terminal = S.n == 0;
+  if (terminal && a.terminate_delay != 0.0 && !delayed) {  // :421-434: one unrewarded TimeElapsedGoal pads the episode
+    delayed = true;
+    pad_start = t_env;
+    __syncthreads();
+    if (tid == 0) {
+      S.list[0] = (uint8_t)RIAB_WL_PAD;
+      S.n = 1;
+    }
+    world_pass(S, met, a.B, any, t_env - pad_start >= a.terminate_delay, sequential);
+    terminal = S.n == 0;
+  }
+  const int late = world_pass(S, met, a.B, any, t_env - pad_start >= a.terminate_delay, sequential);  // :438
+  const bool terminal_last = S.n == 0;
+  if (tid == 0) {
+    if (late > 0 && terminal_last && !terminal) atomicAdd(diag + RIAB_TD_LATE_COMPLETIONS, 1);
+    // _is_terminal_state :284-285 — RewardCache.append (:902-911) in award order
+    for (int i = 0; i < S.n_awards; ++i) {
+      const int64_t w = S.awards[i].agent;
+      const int src = S.awards[i].entry == (int)RIAB_WL_PAD ? RIAB_GOAL_TIME_ELAPSED : S.awards[i].entry;
+      const int n_rw = (int)ts_at(a, RIAB_TS_N_REWARDS, w);
+      if (n_rw >= RIAB_TASK_MAX_REWARDS) {
+        atomicAdd(diag + RIAB_TD_REWARD_OVERFLOW, 1);
+        continue;
+      }
+      const RewardTpl r = reward_of(a, goals, src);
+      ts_at(a, RIAB_TS_RW_STATE + n_rw, w) = r.init;
+      ts_at(a, RIAB_TS_RW_EXPIRE + n_rw, w) = r.expire;
+      ts_at(a, RIAB_TS_RW_SRC + n_rw, w) = (double)src;
+      ts_at(a, RIAB_TS_N_REWARDS, w) = (double)(n_rw + 1);
+      reward_out[w] = reward_out[w] + r.init;  // python sum(): left to right, the new rewards last
+    }
+    // the shared state
+    if (S.n != n0) world[RIAB_TW_N_GOALS] = (double)S.n;
+    if (delayed != delayed0) {
+      world[RIAB_TW_DELAYED] = 1.0;
+      world[RIAB_TW_PAD_START] = pad_start;
+    }
+    if (S.n != n0 || delayed != delayed0)
+      for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i)
+        world[RIAB_TW_GOAL_LIST + i] = i < S.n ? (S.list[i] == RIAB_WL_PAD ? (double)RIAB_GOAL_TIME_ELAPSED : (double)S.list[i]) : 0.0;
+    *ticket = 0;  // (the next launch is ordered behind this one)
+  }
+  __syncthreads();
+  // RewardCache.get_total (:929-939) and stats of every agent; the terminal flag is the world's
+  for (int64_t i = tid; i < a.B; i += WORLD_BLOCK) {
+    double total = reward_out[i];
+    total = total + a.default_level;
+    if (total > ts_at(a, RIAB_TS_R_MAX, i)) ts_at(a, RIAB_TS_R_MAX, i) = total;
+    if (total < ts_at(a, RIAB_TS_R_MIN, i)) ts_at(a, RIAB_TS_R_MIN, i) = total;
+    reward_out[i] = total;
+    terminal_out[i] = terminal_last ? 1 : 0;
+  }
+}
+
+// TaskEnvironment.reset (:307-351) of the world: the episode table and the goal selection once (workgroup 0's first
+// thread), teleport_on_reset for every agent (:323-330).
+__global__ __launch_bounds__(WORLD_BLOCK) void task_world_reset_kernel(TaskArgs a, ResetArgs r, double* world, double t_env,
+                                                                        int32_t* diag) {
+  const int64_t b = (int64_t)blockIdx.x * WORLD_BLOCK + threadIdx.x;
+  if (b < a.B && r.teleport) {
+    ResetDraw d = {0.0, 0.0, 0};
+    if (!r.new_x) d = reset_draw_id(a, r, (uint64_t)(r.agent_id0 + b));
+    Lane L;
+    reset_lane_teleport(r, b, L, d);
+  }
+  if (b != 0) return;
+  atomicAdd(diag + RIAB_TD_RESETS, 1);
+  // write_end_episode (:536-539), the episode counter (:333-338)
+  bool zero_duration = false;
+  bool any_ended = world[RIAB_TW_EP_ANY_ENDED] != 0.0;
+  const double episode = world[RIAB_TW_EPISODE], ep_start = world[RIAB_TW_EP_START];
+  if (world[RIAB_TW_STARTED] != 0.0) {
+    const double duration = t_env - ep_start;
+    zero_duration = duration == 0.0;
+    if (!zero_duration) {  // a zero-duration episode is popped again right away (:333-335)
+      any_ended = true;
+      world[RIAB_TW_EP_ANY_ENDED] = 1.0;
+      if (r.ep_log) {
+        const int slot = atomicAdd(r.ep_count, 1);
+        if (slot < r.ep_log_cap) {
+          double* e = r.ep_log + (int64_t)slot * 5;
+          e[0] = -1.0;  // (no lane: the world's episode)
+          e[1] = episode;
+          e[2] = ep_start;
+          e[3] = t_env;
+          e[4] = duration;
+        } else {
+          atomicAdd(diag + RIAB_TD_EPLOG_OVERFLOW, 1);
+        }
+      }
+    }
+  }
+  if (!zero_duration) world[RIAB_TW_EPISODE] = episode + 1.0;
+  world[RIAB_TW_STARTED] = 1.0;
+  world[RIAB_TW_EP_START] = any_ended ? t_env : 0.0;  // _current_episode_start (:526-527)
+  // GoalCache.reset (:1218-1252): one selection, appended to every agent's list — the shared list
+  const ResetDraw d = reset_draw_id(a, r, RIAB_WORLD_STREAM_ID);
+  const int n = r.n_select < a.n_pool ? r.n_select : a.n_pool;
+  for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i) world[RIAB_TW_GOAL_LIST + i] = i < n ? (double)list_get(d.list, i) : 0.0;
+  world[RIAB_TW_N_GOALS] = (double)n;
+  world[RIAB_TW_DELAYED] = 0.0;
+}
+
+// get_goal_vector (:1555-1584) of every agent against the shared list
+__global__ __launch_bounds__(WORLD_BLOCK) void task_world_goal_vector_kernel(TaskArgs a, const double* world, const double* pos_x,
+                                                                              const double* pos_y, double scale, double* out_x,
+                                                                              double* out_y) {
+  __shared__ double s_goals[RIAB_TASK_MAX_POOL * RIAB_GOAL_COLS];
+  const int64_t b = (int64_t)blockIdx.x * WORLD_BLOCK + threadIdx.x;
+  task_stage_goals(a, s_goals, (int)threadIdx.x, WORLD_BLOCK);
+  Lane L;
+  L.n_goals = (int)world[RIAB_TW_N_GOALS];
+  u128 l = 0;
+  for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i)
+    if (i < L.n_goals) l |= (u128)(uint32_t)((int)world[RIAB_TW_GOAL_LIST + i] & 0xFF) << (8 * i);
+  L.list = l;
+  __syncthreads();
+  if (b >= a.B) return;
+  L.px = pos_x[b];
+  L.py = pos_y[b];
+  double vx, vy;
+  goal_vector(a, (lds_f64_ptr)s_goals, L, scale, vx, vy);
+  out_x[b] = vx;
+  out_y[b] = vy;
+}
+
+static int fill_world_args(TaskArgs& a, const RiabEnv* env, const RiabTask* task, double* task_state, double* world, int64_t B) {
+  if (!world) return RIAB_EINVAL;
+  if (B > 0x7FFFFFFF) return RIAB_ETOOBIG;
+  return fill_args(a, env, task, task_state, B);
+}
+
+}  // namespace riab
+
+using namespace riab;
+
+extern "C" int riab_task_world_step(const RiabEnv* env, const RiabTask* task, double* task_state, double* world,
+                                    const double* pos_x, const double* pos_y, int64_t B, double t_env, double* reward_out,
+                                    uint8_t* terminal_out, uint64_t* met_scratch, int32_t* ticket, int32_t* diag,
+                                    riab_stream_t stream) {
+  TaskArgs a;
+  const int rc = fill_world_args(a, env, task, task_state, world, B);
+  if (rc) return rc;
+  if (!pos_x || !pos_y || !reward_out || !terminal_out || !met_scratch || !ticket || !diag) return RIAB_EINVAL;
+  hipLaunchKernelGGL(task_world_step_kernel, dim3((unsigned)((B + WORLD_BLOCK - 1) / WORLD_BLOCK)), dim3(WORLD_BLOCK), 0,
+                     (hipStream_t)stream, a, world, pos_x, pos_y, t_env, reward_out, terminal_out, met_scratch, ticket, diag);
+  return (int)hipGetLastError();
+}
+
+extern "C" int riab_task_world_reset(const RiabEnv* env, const RiabTask* task, double* task_state, double* world, int64_t B,
+                                     int64_t agent_id0, double t_env, int32_t n_select, int32_t ordered, uint64_t seed,
+                                     uint64_t counter, int32_t teleport, const double* new_x, const double* new_y,
+                                     double* pos_x, double* pos_y, float* hist_x, float* hist_y, double* ep_log,
+                                     int64_t ep_log_cap, int32_t* ep_count, int32_t* diag, riab_stream_t stream) {
+  TaskArgs a;
+  int rc = fill_world_args(a, env, task, task_state, world, B);
+  if (rc) return rc;
+  if (!diag) return RIAB_EINVAL;
+  ResetArgs r;
+  rc = fill_reset(r, env, agent_id0, n_select, ordered, seed, counter, teleport, new_x, new_y, pos_x, pos_y, hist_x, hist_y,
+                  ep_log, ep_log_cap, ep_count);
+  if (rc) return rc;
+  hipLaunchKernelGGL(task_world_reset_kernel, dim3((unsigned)((B + WORLD_BLOCK - 1) / WORLD_BLOCK)), dim3(WORLD_BLOCK), 0,
+                     (hipStream_t)stream, a, r, world, t_env, diag);
+  return (int)hipGetLastError();
+}
+
+extern "C" int riab_task_world_goal_vector(const RiabEnv* env, const RiabTask* task, double* task_state, const double* world,
+                                           const double* pos_x, const double* pos_y, int64_t B, double scale, double* out_x,
+                                           double* out_y, riab_stream_t stream) {
+  TaskArgs a;
+  const int rc = fill_world_args(a, env, task, task_state, const_cast<double*>(world), B);
+  if (rc) return rc;
+  if (!pos_x || !pos_y || !out_x || !out_y) return RIAB_EINVAL;
+  hipLaunchKernelGGL(task_world_goal_vector_kernel, dim3((unsigned)((B + WORLD_BLOCK - 1) / WORLD_BLOCK)), dim3(WORLD_BLOCK), 0,
+                     (hipStream_t)stream, a, world, pos_x, pos_y, scale, out_x, out_y);
+  return (int)hipGetLastError();
+}

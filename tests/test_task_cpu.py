@@ -88,6 +88,63 @@ def test_task_world_oracle_vs_reference(fname):
     assert W.late_completions == int(g["late"].sum())
 
 
+@pytest.fixture(scope="module")
+def world_logic(tmp_path_factory):
+    """csrc/riab_task_world_logic.h — the text the kernel compiles — built for the host with g++ behind a serial driver."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path_factory.mktemp("world_logic") / "world_logic_host.so")
+    subprocess.run(["g++", "-O1", "-shared", "-fPIC", "-std=c++17", "-I", os.path.join(root, "ratinabox_amd", "csrc"),
+                    os.path.join(root, "tests", "native", "world_logic_host.cpp"), "-o", so], check=True)
+    lib = C.CDLL(so)
+    lib.world_pass_host.restype = C.c_int
+
+    def run(lst, met_bits, pad_elapsed, sequential):
+        buf = (C.c_uint8 * 16)(*lst)
+        n = C.c_int(len(lst))
+        met = (C.c_uint64 * len(met_bits))(*met_bits)
+        aa, ae = (C.c_int * 32)(), (C.c_int * 32)()
+        k = lib.world_pass_host(buf, C.byref(n), met, len(met_bits), int(pad_elapsed), int(sequential), aa, ae)
+        return [(aa[i], ae[i]) for i in range(k)], list(buf[:n.value])
+    return run
+
+
+def test_kernel_list_logic_vs_reference(world_logic):
+    """The kernel's list logic (turns only for agents that stand in a goal the turn looks at) against the reference's
+    GoalCache.check on the recorded tables, three passes each."""
+    g = gu.load("taskworld_list_logic.npz")
+    for c in range(g["met"].shape[0]):
+        na, ng, seq = (int(x) for x in g["dims"][c])
+        bits = [int(sum(1 << e for e in range(ng) if g["met"][c, a, e])) for a in range(na)]
+        lst = list(range(ng))
+        for p in range(g["award_agent"].shape[1]):
+            awards, lst = world_logic(lst, bits, False, seq)
+            n = int((g["award_agent"][c, p] >= 0).sum())
+            assert awards == list(zip(g["award_agent"][c, p, :n].tolist(), g["award_goal"][c, p, :n].tolist())), (c, p)
+            assert lst == g["left_after"][c, p, :len(lst)].tolist() and (g["left_after"][c, p, len(lst):] == -1).all(), (c, p)
+
+
+def test_kernel_list_logic_vs_oracle_with_the_delay_goal(world_logic):
+    """... and against the oracle's walk on random lists that contain the termination-delay goal (pool indices up to 63,
+    up to 200 agents, elapsed or not)."""
+    rs = np.random.RandomState(5)
+    PAD = 0xFE
+    for c in range(600):
+        na, n = int(rs.randint(1, 200)), int(rs.randint(0, 17))
+        lst = rs.choice(64, size=n, replace=False).tolist()
+        if n and rs.rand() < 0.5:
+            lst[int(rs.randint(n))] = PAD
+        dens = rs.choice([0.002, 0.02, 0.3])
+        met = rs.random_sample((na, 64)) < dens
+        bits = [int(sum(1 << e for e in np.nonzero(met[a])[0])) for a in range(na)]
+        elapsed, seq = bool(rs.rand() < 0.5), bool(c % 2)
+        ref_list = list(lst)
+        ref = orc.world_check_pass(ref_list, orc._Met(na, lambda a, e: elapsed if e == PAD else bool(met[a, e])), seq)
+        awards, left = world_logic(lst, bits, elapsed, seq)
+        assert awards == ref and left == ref_list, c
+
+
 def test_reset_draws_are_permutation_prefixes():
     for lane in range(50):
         d = orc.task_reset_draws(seed=7, counter=3, lane_id=lane, n_pool=9, n_select=6)
@@ -153,3 +210,16 @@ def test_task_abi_argument_errors():
     assert L.lib.riab_task_reset(env, task, p, None, 4, 0, 0.0, 16, 1, 0, 0, 0, None, None, None, None, None, None, None, 0, None, p, None) == -3
     assert L.lib.riab_task_reset(env, task, p, None, 4, 0, 0.0, 2, 1, 0, 0, 1, None, None, None, None, None, None, None, 0, None, p, None) == -1
     assert C.sizeof(L.RiabTask) == 8 + 4 + 4 + 8 + 5 * 8 + 8
+    # the one-world entry points: the shared state, the scratch and the ticket are required
+    task.n_pool, task.goals = 2, 64
+    W = L.lib.riab_task_world_step
+    assert W(env, task, p, None, p, p, 4, 0.0, p, p, p, p, p, None) == -1
+    assert W(env, task, p, p, p, p, 4, 0.0, p, p, None, p, p, None) == -1
+    assert W(env, task, p, p, p, p, 4, 0.0, p, p, p, None, p, None) == -1
+    assert W(env, task, p, p, p, p, 1 << 31, 0.0, p, p, p, p, p, None) == -3
+    assert L.lib.riab_task_world_reset(env, task, p, None, 4, 0, 0.0, 2, 1, 0, 0, 0, None, None, None, None, None, None, None, 0,
+                                       None, p, None) == -1
+    assert L.lib.riab_task_world_reset(env, task, p, p, 4, 0, 0.0, 16, 1, 0, 0, 0, None, None, None, None, None, None, None, 0,
+                                       None, p, None) == -3
+    assert L.lib.riab_task_world_goal_vector(env, task, p, p, p, p, 4, 0.0, None, p, None) == -1
+    assert L.TW_ROWS == 24 and L.TW_GOAL_LIST + L.TASK_MAX_GOALS == L.TW_ROWS
