@@ -600,20 +600,23 @@ enum {
   RIAB_TW_EP_START = 4,     /* episodes["start"][-1] */
   RIAB_TW_EP_ANY_ENDED = 5, /* an episode of non-zero duration has ended before */
   RIAB_TW_STARTED = 6,      /* len(episodes["start"]) > 0 */
+  RIAB_TW_TERMINAL = 7,     /* the flag the last step left in terminal_out */
   RIAB_TW_GOAL_LIST = 8,    /* [RIAB_TASK_MAX_GOALS] pool index of list entry i; RIAB_GOAL_TIME_ELAPSED = delay goal */
   RIAB_TW_ROWS = 24
 };
 /* One TaskEnvironment.step (:410-449) of the world after the agents have moved; arguments as riab_task_step.
- * One launch: every lane decays its own rewards and works out which goals of the list it stands in; the
- * workgroup that finishes last (ticket: device int32, zero before the first call; the kernel leaves it zero)
- * walks the step's check passes over the shared list, appends the awards to the winners' caches in award
- * order and totals every agent's rewards.  met_scratch: device uint64 [B].  terminal_out [B] holds the world's
- * flag for every agent ("no goals left" after the step's last pass, as riab_task_step).  No workgroup waits
- * for another: capturable, nothing has to be co-resident. */
+ * One launch.  Every lane decays its own rewards and works out which goals of the list it stands in; a lane that
+ * stands in none totals its rewards and is done, the others put themselves on a work list (cand_scratch: device
+ * int32 [B]; met_scratch: device uint64 [B]).  The workgroup that finishes last (ctl: device int32 [2] — ticket,
+ * work-list length — zero before the first call; the kernel leaves them zero) walks the step's check passes over
+ * the shared list among the listed lanes, appends the awards to the winners' caches in award order and totals
+ * those lanes.  terminal_out [B] holds the world's flag for every agent ("no goals left" after the step's last
+ * pass, as riab_task_step); the column is rewritten only when the flag changes (RIAB_TW_TERMINAL remembers it):
+ * hand in the same array every step.  No workgroup waits for another: capturable, nothing has to be co-resident. */
 int riab_task_world_step(const RiabEnv* env, const RiabTask* task, double* task_state, double* world,
                          const double* pos_x, const double* pos_y, int64_t B, double t_env, double* reward_out,
-                         uint8_t* terminal_out, uint64_t* met_scratch, int32_t* ticket, int32_t* diag,
-                         riab_stream_t stream);
+                         uint8_t* terminal_out, uint64_t* met_scratch, int32_t* cand_scratch, int32_t* ctl,
+                         int32_t* diag, riab_stream_t stream);
 /* TaskEnvironment.reset (:307-351) of the world: the episode is closed once (ep_log row: lane id -1), the
  * shared list refilled with n_select goals of the pool (the first ones when `ordered`, else a sample drawn
  * from Philox(seed; counter, id 0xFFFFFFFF)), every agent teleported when `teleport` (to (new_x, new_y)[b] or

@@ -105,7 +105,7 @@ GOALORDERS = {"nonsequential": 0, "sequential": 1}
 TD_REWARD_OVERFLOW, TD_LATE_COMPLETIONS, TD_EPLOG_OVERFLOW, TD_RESETS = range(4)
 # rows of the shared state of a task whose lanes are the agents of one world (RIAB_TW_*)
 TW_N_GOALS, TW_DELAYED, TW_PAD_START, TW_EPISODE, TW_EP_START, TW_EP_ANY_ENDED, TW_STARTED = range(7)
-TW_GOAL_LIST, TW_ROWS = 8, 24
+TW_TERMINAL, TW_GOAL_LIST, TW_ROWS = 7, 8, 24
 
 POP_KINDS = {"place": 0, "grid": 1, "hdc": 2, "bvc": 3, "ovc": 4, "ff": 5, "velocity": 6, "speed": 7, "random_spatial": 8}
 EINVAL = -1
@@ -209,7 +209,7 @@ PROTOTYPES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_task_world_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_void_p]),
+                                       C.c_void_p, C.c_void_p]),
     "riab_task_world_reset": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                         C.c_double, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

@@ -323,7 +323,8 @@ class TaskEnvironment(Environment):
         if self._shared:   # the world's own state, the lanes' "stands inside" masks, the last-workgroup ticket
             self._world = torch.zeros(_L.TW_ROWS, dtype=torch.float64, device=dev)
             self._met = torch.zeros(self._B, dtype=torch.int64, device=dev)
-            self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._cand = torch.zeros(self._B, dtype=torch.int32, device=dev)
+            self._ticket = torch.zeros(2, dtype=torch.int32, device=dev)
         self.reset()
 
     def remove_agents(self, agents=None):
@@ -496,8 +497,8 @@ class TaskEnvironment(Environment):
         if self._shared:
             rc = _L.lib.riab_task_world_step(env_s, task, _L.ptr(self.task_state), _L.ptr(self._world), _L.ptr(st[0]),
                                              _L.ptr(st[1]), self._B, float(self.t), _L.ptr(self._reward),
-                                             _L.ptr(self._terminal), _L.ptr(self._met), _L.ptr(self._ticket),
-                                             _L.ptr(self._diag), _L.current_stream())
+                                             _L.ptr(self._terminal), _L.ptr(self._met), _L.ptr(self._cand),
+                                             _L.ptr(self._ticket), _L.ptr(self._diag), _L.current_stream())
             _L.check(rc, "riab_task_world_step")
         else:
             rc = _L.lib.riab_task_step(env_s, task, _L.ptr(self.task_state), _L.ptr(st[0]), _L.ptr(st[1]), self._B,

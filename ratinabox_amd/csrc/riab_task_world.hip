@@ -9,10 +9,12 @@
 // consumes at least one of the <= 16 entries — found by min-reductions over the lanes' "stands inside" masks (phase B).
 //
 //   phase A, all workgroups: RewardCache.update of the lane (:913-927), its mask of the list's goals it stands in
-//     (SpatialGoal.check :1337-1360: line-of-sight distance < radius), the surviving rewards' total;
+//     (SpatialGoal.check :1337-1360: line-of-sight distance < radius); a lane that stands in none is done — total
+//     (:929-939), statistics —, the others ("candidates") put themselves on a work list;
 //   phase B, the workgroup that finishes LAST (a ticket counter; no workgroup waits for another: nothing has to be
-//     resident together, capturable): the step's check passes (:418-440) over the shared list, the awards appended to
-//     the winners' caches in award order, every lane's total (:929-939), the terminal flag, the shared state.
+//     resident together, capturable): the step's check passes (:418-440) over the shared list among the candidates, the
+//     awards appended to the winners' caches in award order, the candidates' totals, the shared state.  A quiet step —
+//     nobody stands in anything — finds an empty work list: a ticket, three empty passes, nothing stored.
 //
 // Float64 like the reference; contraction off (riab_task_kernel.h).
 #include "riab_task_kernel.h"
@@ -32,13 +34,15 @@ struct WorldShared {  // phase B's state, in LDS
   WorldAward awards[RIAB_WL_MAX_AWARDS];
   int n_awards;
   int next_agent;  // min-reduction slot
-  unsigned long long any;
   int last;
 };
 
-// One GoalCache.check(remove_finished=True) over all agents, by the whole workgroup (uniform control flow).
-// Returns the number of goals consumed.
-__device__ int world_pass(WorldShared& S, const uint64_t* met, int64_t B, uint64_t any, bool pad_elapsed, bool sequential) {
+// One GoalCache.check(remove_finished=True) over all agents, by the whole workgroup (uniform control flow).  Only the
+// step's CANDIDATES can take a turn that changes anything: the lanes that stand in a goal of the list as the step found
+// it (the list only shrinks within a step) — phase A left their indices in `cand` — and, for a termination-delay goal whose
+// time has elapsed, whoever's turn comes first.  Returns the number of goals consumed.
+__device__ int world_pass(WorldShared& S, const uint64_t* met, const int32_t* cand, int n_cand, int64_t B, bool pad_elapsed,
+                          bool sequential) {
   const int tid = (int)threadIdx.x;
   int64_t a_next = 0;
   int done = 0;
@@ -48,55 +52,70 @@ __device__ int world_pass(WorldShared& S, const uint64_t* met, int64_t B, uint64
     bool looks_at_pad;
     const uint64_t mask = world_turn_mask(l, sequential, looks_at_pad);
     const bool pad_now = looks_at_pad && pad_elapsed;
-    if (l.n == 0 || a_next >= B || (!(any & mask) && !pad_now)) break;
-    int64_t cand;
+    if (l.n == 0 || a_next >= B || ((n_cand == 0 || mask == 0) && !pad_now)) break;
+    int64_t who;
     if (pad_now) {
-      cand = a_next;  // whoever's turn it is takes the termination-delay goal
+      who = a_next;  // whoever's turn it is takes the termination-delay goal
     } else {
       if (tid == 0) S.next_agent = 0x7FFFFFFF;
       __syncthreads();
-      for (int64_t i = a_next + tid; i < B; i += WORLD_BLOCK)
-        if (met[i] & mask) {
-          atomicMin(&S.next_agent, (int)i);
-          break;
-        }
+      int mine = 0x7FFFFFFF;
+      for (int i = tid; i < n_cand; i += WORLD_BLOCK) {  // (the candidates are in no particular order)
+        const int c = cand[i];
+        if (c >= a_next && c < mine && (met[c] & mask)) mine = c;
+      }
+      if (mine != 0x7FFFFFFF) atomicMin(&S.next_agent, mine);
       __syncthreads();
       if (S.next_agent == 0x7FFFFFFF) break;
-      cand = S.next_agent;
+      who = S.next_agent;
     }
     const int before = S.n;
     __syncthreads();  // (everybody has read the slot and the list)
     if (tid == 0) {
       WorldList w = {S.list, S.n};
-      world_agent_turn(w, met[cand], pad_now, sequential, (int)cand, S.awards, S.n_awards);
+      world_agent_turn(w, met[who], pad_now, sequential, (int)who, S.awards, S.n_awards);
       S.n = w.n;
     }
     __syncthreads();
     done += before - S.n;
-    a_next = cand + 1;
+    a_next = who + 1;
   }
   return done;
 }
 
+// RewardCache.get_total (:929-939) and the cache's statistics of one agent, from the python sum() of its rewards
+__device__ __forceinline__ void world_lane_total(const TaskArgs& a, int64_t b, double sum, double rmax, double rmin,
+                                                 double* reward_out) {
+  const double total = sum + a.default_level;
+  if (total > rmax) ts_at(a, RIAB_TS_R_MAX, b) = total;
+  if (total < rmin) ts_at(a, RIAB_TS_R_MIN, b) = total;
+  reward_out[b] = total;
+}
+
+// ctl: [0] ticket of the workgroups, [1] number of candidates (both zero between launches)
 __global__ __launch_bounds__(WORLD_BLOCK) void task_world_step_kernel(TaskArgs a, double* world, const double* pos_x,
                                                                        const double* pos_y, double t_env, double* reward_out,
-                                                                       uint8_t* terminal_out, uint64_t* met, int32_t* ticket,
-                                                                       int32_t* diag) {
+                                                                       uint8_t* terminal_out, uint64_t* met, int32_t* cand,
+                                                                       int32_t* ctl, int32_t* diag) {
   __shared__ double s_goals[RIAB_TASK_MAX_POOL * RIAB_GOAL_COLS];
   __shared__ WorldShared S;
   const int tid = (int)threadIdx.x;
   const int64_t b = (int64_t)blockIdx.x * WORLD_BLOCK + tid;
   const bool live = b < a.B;
-  // ---- phase A
+  // ---- phase A: what an agent's step needs of nobody else
   task_stage_goals(a, s_goals, tid, WORLD_BLOCK);
   if (tid < RIAB_TASK_MAX_GOALS) S.list[tid] = (uint8_t)((int)world[RIAB_TW_GOAL_LIST + tid] & 0xFF);
   if (tid == 0) S.n = (int)world[RIAB_TW_N_GOALS];
+  const double pad_start0 = world[RIAB_TW_PAD_START];
+  const uint8_t terminal_prev = world[RIAB_TW_TERMINAL] != 0.0 ? 1 : 0;
   RewardsIn rin;
-  double px = 0.0, py = 0.0;
-  if (live) {
+  double px = 0.0, py = 0.0, rmax = 0.0, rmin = 0.0;
+  if (live) {  // (one batch of independent loads)
     rin = load_rewards_in(a, b);
     px = pos_x[b];
     py = pos_y[b];
+    rmax = ts_at(a, RIAB_TS_R_MAX, b);
+    rmin = ts_at(a, RIAB_TS_R_MIN, b);
   }
   __syncthreads();
   const lds_f64_ptr goals = (lds_f64_ptr)s_goals;
@@ -104,38 +123,40 @@ __global__ __launch_bounds__(WORLD_BLOCK) void task_world_step_kernel(TaskArgs a
     const RewardsOut ro = rewards_step(a, goals, b, rin);
     if (ro.n_rw != rin.n_rw) ts_at(a, RIAB_TS_N_REWARDS, b) = (double)ro.n_rw;
     uint64_t m = 0;
+    bool pad_in_list = false;
     for (int g = 0; g < S.n; ++g) {
       const int v = S.list[g];
-      if (v != (int)RIAB_WL_PAD && in_goal_radius(a, px, py, goals + v * RIAB_GOAL_COLS)) m |= 1ull << v;
+      if (v == (int)RIAB_WL_PAD) pad_in_list = true;
+      else if (in_goal_radius(a, px, py, goals + v * RIAB_GOAL_COLS)) m |= 1ull << v;
     }
     met[b] = m;
-    reward_out[b] = ro.total;  // (the survivors' sum; phase B adds this step's awards and the default level)
+    // a termination-delay goal whose time has elapsed goes to the first agent (its pass starts with agent 0)
+    const bool candidate = m != 0 || (b == 0 && pad_in_list && t_env - pad_start0 >= a.terminate_delay);
+    if (candidate) {
+      reward_out[b] = ro.total;  // (the survivors' sum: phase B adds this step's awards, then totals)
+      cand[atomicAdd(ctl + 1, 1)] = (int32_t)b;
+    } else {
+      world_lane_total(a, b, ro.total, rmax, rmin, reward_out);
+    }
+    terminal_out[b] = terminal_prev;  // (the world's flag; phase B rewrites the column when it changes)
   }
   // ---- the last workgroup to get here goes on
   __threadfence();
   __syncthreads();
-  if (tid == 0) S.last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+  if (tid == 0) S.last = atomicAdd(ctl, 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (!S.last) return;
   __threadfence();
-  // ---- phase B
-  uint64_t any = 0;
-  for (int64_t i = tid; i < a.B; i += WORLD_BLOCK) any |= met[i];
-  if (tid == 0) {
-    S.any = 0;
-    S.n_awards = 0;
-  }
-  __syncthreads();
-  if (any) atomicOr(&S.any, (unsigned long long)any);
-  __syncthreads();
-  any = S.any;
+  // ---- phase B: the step's check passes over the shared list
+  const int n_cand = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) S.n_awards = 0;
   const bool sequential = a.goalorder == RIAB_GOALORDER_SEQUENTIAL;
   const int n0 = S.n;
   bool delayed = world[RIAB_TW_DELAYED] != 0.0;
   const bool delayed0 = delayed;
-  double pad_start = world[RIAB_TW_PAD_START];
+  double pad_start = pad_start0;
   // _is_terminal_state (:278-290) as step() calls it (:418-440)
-  world_pass(S, met, a.B, any, t_env - pad_start >= a.terminate_delay, sequential);
+  world_pass(S, met, cand, n_cand, a.B, t_env - pad_start >= a.terminate_delay, sequential);
   bool terminal = S.n == 0;
   if (terminal && a.terminate_delay != 0.0 && !delayed) {  // :421-434: one unrewarded TimeElapsedGoal pads the episode
     delayed = true;
@@ -145,10 +166,10 @@ __global__ __launch_bounds__(WORLD_BLOCK) void task_world_step_kernel(TaskArgs a
       S.list[0] = (uint8_t)RIAB_WL_PAD;
       S.n = 1;
     }
-    world_pass(S, met, a.B, any, t_env - pad_start >= a.terminate_delay, sequential);
+    world_pass(S, met, cand, n_cand, a.B, t_env - pad_start >= a.terminate_delay, sequential);
     terminal = S.n == 0;
   }
-  const int late = world_pass(S, met, a.B, any, t_env - pad_start >= a.terminate_delay, sequential);  // :438
+  const int late = world_pass(S, met, cand, n_cand, a.B, t_env - pad_start >= a.terminate_delay, sequential);  // :438
   const bool terminal_last = S.n == 0;
   if (tid == 0) {
     if (late > 0 && terminal_last && !terminal) atomicAdd(diag + RIAB_TD_LATE_COMPLETIONS, 1);
@@ -177,18 +198,17 @@ __global__ __launch_bounds__(WORLD_BLOCK) void task_world_step_kernel(TaskArgs a
     if (S.n != n0 || delayed != delayed0)
       for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i)
         world[RIAB_TW_GOAL_LIST + i] = i < S.n ? (S.list[i] == RIAB_WL_PAD ? (double)RIAB_GOAL_TIME_ELAPSED : (double)S.list[i]) : 0.0;
-    *ticket = 0;  // (the next launch is ordered behind this one)
+    if ((terminal_last ? 1 : 0) != terminal_prev) world[RIAB_TW_TERMINAL] = terminal_last ? 1.0 : 0.0;
+    ctl[0] = 0;  // (the next launch is ordered behind this one)
+    ctl[1] = 0;
   }
   __syncthreads();
-  // RewardCache.get_total (:929-939) and stats of every agent; the terminal flag is the world's
-  for (int64_t i = tid; i < a.B; i += WORLD_BLOCK) {
-    double total = reward_out[i];
-    total = total + a.default_level;
-    if (total > ts_at(a, RIAB_TS_R_MAX, i)) ts_at(a, RIAB_TS_R_MAX, i) = total;
-    if (total < ts_at(a, RIAB_TS_R_MIN, i)) ts_at(a, RIAB_TS_R_MIN, i) = total;
-    reward_out[i] = total;
-    terminal_out[i] = terminal_last ? 1 : 0;
+  for (int i = tid; i < n_cand; i += WORLD_BLOCK) {  // the candidates' totals, with what they were awarded
+    const int64_t c = cand[i];
+    world_lane_total(a, c, reward_out[c], ts_at(a, RIAB_TS_R_MAX, c), ts_at(a, RIAB_TS_R_MIN, c), reward_out);
   }
+  if ((terminal_last ? 1 : 0) != terminal_prev)
+    for (int64_t i = tid; i < a.B; i += WORLD_BLOCK) terminal_out[i] = terminal_last ? 1 : 0;
 }
 
 // TaskEnvironment.reset (:307-351) of the world: the episode table and the goal selection once (workgroup 0's first
@@ -238,6 +258,7 @@ __global__ __launch_bounds__(WORLD_BLOCK) void task_world_reset_kernel(TaskArgs 
   for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i) world[RIAB_TW_GOAL_LIST + i] = i < n ? (double)list_get(d.list, i) : 0.0;
   world[RIAB_TW_N_GOALS] = (double)n;
   world[RIAB_TW_DELAYED] = 0.0;
+  world[RIAB_TW_TERMINAL] = 0.0;
 }
 
 // get_goal_vector (:1555-1584) of every agent against the shared list
@@ -275,14 +296,15 @@ using namespace riab;
 
 extern "C" int riab_task_world_step(const RiabEnv* env, const RiabTask* task, double* task_state, double* world,
                                     const double* pos_x, const double* pos_y, int64_t B, double t_env, double* reward_out,
-                                    uint8_t* terminal_out, uint64_t* met_scratch, int32_t* ticket, int32_t* diag,
-                                    riab_stream_t stream) {
+                                    uint8_t* terminal_out, uint64_t* met_scratch, int32_t* cand_scratch, int32_t* ctl,
+                                    int32_t* diag, riab_stream_t stream) {
   TaskArgs a;
   const int rc = fill_world_args(a, env, task, task_state, world, B);
   if (rc) return rc;
-  if (!pos_x || !pos_y || !reward_out || !terminal_out || !met_scratch || !ticket || !diag) return RIAB_EINVAL;
+  if (!pos_x || !pos_y || !reward_out || !terminal_out || !met_scratch || !cand_scratch || !ctl || !diag) return RIAB_EINVAL;
   hipLaunchKernelGGL(task_world_step_kernel, dim3((unsigned)((B + WORLD_BLOCK - 1) / WORLD_BLOCK)), dim3(WORLD_BLOCK), 0,
-                     (hipStream_t)stream, a, world, pos_x, pos_y, t_env, reward_out, terminal_out, met_scratch, ticket, diag);
+                     (hipStream_t)stream, a, world, pos_x, pos_y, t_env, reward_out, terminal_out, met_scratch, cand_scratch,
+                     ctl, diag);
   return (int)hipGetLastError();
 }
 

@@ -213,10 +213,11 @@ def test_task_abi_argument_errors():
     # the one-world entry points: the shared state, the scratch and the ticket are required
     task.n_pool, task.goals = 2, 64
     W = L.lib.riab_task_world_step
-    assert W(env, task, p, None, p, p, 4, 0.0, p, p, p, p, p, None) == -1
-    assert W(env, task, p, p, p, p, 4, 0.0, p, p, None, p, p, None) == -1
-    assert W(env, task, p, p, p, p, 4, 0.0, p, p, p, None, p, None) == -1
-    assert W(env, task, p, p, p, p, 1 << 31, 0.0, p, p, p, p, p, None) == -3
+    assert W(env, task, p, None, p, p, 4, 0.0, p, p, p, p, p, p, None) == -1
+    assert W(env, task, p, p, p, p, 4, 0.0, p, p, None, p, p, p, None) == -1
+    assert W(env, task, p, p, p, p, 4, 0.0, p, p, p, None, p, p, None) == -1
+    assert W(env, task, p, p, p, p, 4, 0.0, p, p, p, p, None, p, None) == -1
+    assert W(env, task, p, p, p, p, 1 << 31, 0.0, p, p, p, p, p, p, None) == -3
     assert L.lib.riab_task_world_reset(env, task, p, None, 4, 0, 0.0, 2, 1, 0, 0, 0, None, None, None, None, None, None, None, 0,
                                        None, p, None) == -1
     assert L.lib.riab_task_world_reset(env, task, p, p, 4, 0, 0.0, 16, 1, 0, 0, 0, None, None, None, None, None, None, None, 0,

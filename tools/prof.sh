@@ -1,7 +1,7 @@
 # The round's profiles (run on the GPU box through gpurun: `gpurun --timeout 900 -- 'bash tools/prof.sh r05'`): the DRIVER's
 # bench command plain and under rocprofv3 (kernel trace + stats), PMC traffic of its dominant kernel (one counter per pass, as
 # MI355X_MICROARCH.md prescribes; never together with a trace domain), the closed-loop forms (one kernel per step), cfg 3 /
-# cfg 5.  Everything lands in gpurun_out/<round>_*; the summaries that are judged are copied to profiles/ by hand.
+# cfg 5; with a second argument `world`: only the one-world task's kernels.  Everything lands in gpurun_out/<round>_*; the summaries that are judged are copied to profiles/ by hand.
 R=${1:-r05}
 exec </dev/null
 O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
@@ -24,6 +24,13 @@ run_pmc() {  # name, counter, bench args...
   f=$(first /tmp/c_${name}_$ctr "*counter_collection.csv"); [ -n "$f" ] && cp "$f" $O/${R}_${name}_pmc_${ctr}.csv
   echo "== pmc $name $ctr: $( [ -f $O/${R}_${name}_pmc_${ctr}.csv ] && wc -l < $O/${R}_${name}_pmc_${ctr}.csv ) rows"
 }
+if [ "$2" = "world" ]; then  # only the one-world task (`bash tools/prof.sh r05 world`): tools/task_world_time.py under the kernel trace
+  rm -rf /tmp/p_world
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_world -- python $GRAFT_REPO_ROOT/tools/task_world_time.py > $O/${R}_task_world_time_under_rocprof.txt 2>&1
+  f=$(first /tmp/p_world "*kernel_stats.csv"); [ -n "$f" ] && cp "$f" $O/${R}_task_world_kernel_stats.csv
+  cut -d, -f1-7 $O/${R}_task_world_kernel_stats.csv | cut -c1-170 | sed -n 1,8p
+  exit 0
+fi
 timeout 400 python $B --gpus 1 --steps 20 --warmup 5 > $O/${R}_driver_bench_line.json 2> /dev/null
 run_trace driver --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline
 run_pmc driver WRITE_SIZE --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary

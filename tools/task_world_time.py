@@ -29,7 +29,7 @@ for B in (4096, 65536):
     def launch(t_env):
         rc = L.lib.riab_task_world_step(env_s, task, L.ptr(env.task_state), L.ptr(env._world), L.ptr(st[0]), L.ptr(st[1]), B,
                                         float(t_env), L.ptr(env._reward), L.ptr(env._terminal), L.ptr(env._met),
-                                        L.ptr(env._ticket), L.ptr(env._diag), L.current_stream())
+                                        L.ptr(env._cand), L.ptr(env._ticket), L.ptr(env._diag), L.current_stream())
         assert rc == 0
 
     # the first launch consumes what the agents stand in; the following ones are quiet steps
