@@ -427,7 +427,7 @@ class TaskEnvironment(Environment):
                                               _L.ptr(None if newpos is None else newpos[1]), _L.ptr(st[0]), _L.ptr(st[1]),
                                               _L.ptr(None if hist_row is None else hist_row[0]),
                                               _L.ptr(None if hist_row is None else hist_row[1]),
-                                              _L.ptr(self._ep_log), self._ep_cap, _L.ptr(self._ep_count), _L.ptr(self._diag),
+                                              _L.ptr(self._ep_log), self._ep_cap, _L.ptr(self._ep_count), 0, _L.ptr(self._diag),
                                               _L.current_stream())
             _L.check(rc, "riab_task_world_reset")
             self._keep = (newpos, walls, task, self._pool_dev)
@@ -511,10 +511,9 @@ class TaskEnvironment(Environment):
     def make_step_plan(self, neurons=None, capacity=1024, auto_reset=True, scripted_speed=None):
         """The whole closed-loop step as ONE native call (plan.py, riab_plan_*): `plan.step(1, drift_velocity=
         actions)` == `env.step(actions)` + `Neurons.update()` of every population (+ `env.reset(mask=terminal)`
-        when `auto_reset`).  Read `env.get_reward()`, `env.terminal`, `env.get_observation()` afterwards."""
-        if self._shared:
-            raise NotImplementedError("step plans carry the per-lane task (lanes='replicas'); a shared world steps through "
-                                      "env.step()")
+        when `auto_reset`).  Read `env.get_reward()`, `env.terminal`, `env.get_observation()` afterwards.  With
+        `lanes="agents"` the step's pieces (goal vector, motion, the world's step, its reset when the episode ended — decided
+        on the device —, the populations) are one launch each inside the one native call."""
         plan = self._agent.make_step_plan(neurons, capacity)
         return plan.attach_task(self, auto_reset=auto_reset, scripted_speed=scripted_speed)
 

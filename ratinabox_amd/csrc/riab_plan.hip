@@ -71,6 +71,11 @@ struct RiabPlan {
   int64_t ep_log_cap;
   int32_t* ep_count;
   double scripted_speed;
+  // ... whose lanes are the agents of one world (riab_plan_set_task_world); null: every lane its own replica
+  double* world;
+  uint64_t* world_met;
+  int32_t* world_cand;
+  int32_t* world_ctl;
   bool action_ready;  // the drift buffer holds the scripted action of the coming step
   // the one-launch step (riab_plan_set_fused)
   uint32_t* sync_words;
@@ -121,6 +126,7 @@ static int fused_task_step(RiabPlan* p, int lead, float* row, hipStream_t s, boo
 static int plan_lead(RiabPlan* p, bool whole_step = false) {
   if (!p->sync_words || riab::g_options[RIAB_OPT_FUSED_STEP] == 0 || p->forced) return -1;
   if (p->has_task && (!whole_step || riab::g_options[RIAB_OPT_FUSED_TASK] == 0)) return -1;
+  if (p->has_task && p->world) return -1;  // (the world's step is a launch of its own)
   if (p->lead == -2) {
     int best = -1;
     int64_t best_bytes = 0;
@@ -180,6 +186,7 @@ extern "C" RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* moti
   p->row_scratch = row_scratch;
   p->diag = diag;
   p->has_task = false;
+  p->world = nullptr;
   p->action_ready = false;
   p->sync_words = nullptr;
   p->epoch = 0u;
@@ -281,6 +288,7 @@ extern "C" int riab_plan_set_task(RiabPlan* p, const RiabTask* task, double* tas
                                   int32_t* ep_count, double scripted_speed) {
   if (!p) return RIAB_EINVAL;
   p->lead = -2;  // (a task's lead carries no spikes)
+  p->world = nullptr;
   if (!task) {
     p->has_task = false;
     return RIAB_OK;
@@ -308,6 +316,17 @@ extern "C" int riab_plan_set_task(RiabPlan* p, const RiabTask* task, double* tas
   p->ep_count = ep_count;
   p->scripted_speed = scripted_speed;
   p->action_ready = false;
+  return RIAB_OK;
+}
+
+extern "C" int riab_plan_set_task_world(RiabPlan* p, double* world, uint64_t* met_scratch, int32_t* cand_scratch, int32_t* ctl) {
+  if (!p || !p->has_task) return RIAB_EINVAL;
+  if (world && (!met_scratch || !cand_scratch || !ctl)) return RIAB_EINVAL;
+  p->world = world;
+  p->world_met = met_scratch;
+  p->world_cand = cand_scratch;
+  p->world_ctl = ctl;
+  p->lead = -2;
   return RIAB_OK;
 }
 
@@ -496,6 +515,40 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
     int rc;
     const bool scripted = p->has_task && p->scripted_speed > 0.0;
     double* act = const_cast<double*>(p->drift);
+    if (p->has_task && p->world) {  // the lanes are the agents of ONE world: the step's pieces, one launch each
+      if (scripted) {
+        if (!act || !p->motion.has_drift) return RIAB_EINVAL;
+        rc = riab_task_world_goal_vector(&p->env, &p->task, p->task_state, p->world, pos_x, pos_y, p->task_B, p->scripted_speed,
+                                         act, act + p->B, s);
+        if (rc) return rc;
+        p->launches += 1;
+      }
+      rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr, nullptr,
+                           p->seed, p->step, 1, row, p->diag, s);
+      if (rc) return rc;
+      p->step += 1;
+      if (p->hist_base) p->hist_fill += 1;
+      p->t_env += p->dt_env;
+      rc = riab_task_world_step(&p->env, &p->task, p->task_state, p->world, pos_x, pos_y, p->task_B, p->t_env, p->reward_out,
+                                p->terminal_out, p->world_met, p->world_cand, p->world_ctl, p->task_diag, s);
+      if (rc) return rc;
+      p->launches += 2;
+      if (p->auto_reset) {  // the caller's `if terminal: env.reset()`, decided on the device
+        p->reset_counter += 1;
+        rc = riab_task_world_reset(&p->env, &p->task, p->task_state, p->world, p->task_B, p->agent_id0, p->t_env, p->n_select,
+                                   p->ordered, p->task_seed, p->reset_counter, p->teleport, nullptr, nullptr, pos_x, pos_y,
+                                   row + (int64_t)RIAB_H_POS_X * p->B, row + (int64_t)RIAB_H_POS_Y * p->B, p->ep_log,
+                                   p->ep_log_cap, p->ep_count, 1, p->task_diag, s);
+        if (rc) return rc;
+        p->launches += 1;
+      }
+      for (size_t i = 0; i < p->pops.size(); ++i) {
+        rc = launch_population(p, i, row, s);
+        if (rc) return rc;
+        if (p->pops[i].capacity_rows > 0) p->pop_fill[i] += 1;
+      }
+      continue;
+    }
     if (scripted) {
       if (!act || !p->motion.has_drift) return RIAB_EINVAL;
       if (!p->action_ready) {  // first step: later ones get their action from the previous step's fused task kernel

@@ -213,9 +213,13 @@ __global__ __launch_bounds__(WORLD_BLOCK) void task_world_step_kernel(TaskArgs a
 
 // TaskEnvironment.reset (:307-351) of the world: the episode table and the goal selection once (workgroup 0's first
 // thread), teleport_on_reset for every agent (:323-330).
+// `only_if_terminal`: the caller's `if terminal: env.reset()` without a host round trip — nothing happens unless the last
+// step left the world's flag set.  (No reset touches RIAB_TW_TERMINAL — here other workgroups are still reading it —: it
+// stays "what the last step wrote into terminal_out", and the next step's last workgroup rewrites both.)
 __global__ __launch_bounds__(WORLD_BLOCK) void task_world_reset_kernel(TaskArgs a, ResetArgs r, double* world, double t_env,
-                                                                        int32_t* diag) {
+                                                                        int only_if_terminal, int32_t* diag) {
   const int64_t b = (int64_t)blockIdx.x * WORLD_BLOCK + threadIdx.x;
+  if (only_if_terminal && world[RIAB_TW_TERMINAL] == 0.0) return;
   if (b < a.B && r.teleport) {
     ResetDraw d = {0.0, 0.0, 0};
     if (!r.new_x) d = reset_draw_id(a, r, (uint64_t)(r.agent_id0 + b));
@@ -258,7 +262,6 @@ __global__ __launch_bounds__(WORLD_BLOCK) void task_world_reset_kernel(TaskArgs 
   for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i) world[RIAB_TW_GOAL_LIST + i] = i < n ? (double)list_get(d.list, i) : 0.0;
   world[RIAB_TW_N_GOALS] = (double)n;
   world[RIAB_TW_DELAYED] = 0.0;
-  world[RIAB_TW_TERMINAL] = 0.0;
 }
 
 // get_goal_vector (:1555-1584) of every agent against the shared list
@@ -312,7 +315,8 @@ extern "C" int riab_task_world_reset(const RiabEnv* env, const RiabTask* task, d
                                      int64_t agent_id0, double t_env, int32_t n_select, int32_t ordered, uint64_t seed,
                                      uint64_t counter, int32_t teleport, const double* new_x, const double* new_y,
                                      double* pos_x, double* pos_y, float* hist_x, float* hist_y, double* ep_log,
-                                     int64_t ep_log_cap, int32_t* ep_count, int32_t* diag, riab_stream_t stream) {
+                                     int64_t ep_log_cap, int32_t* ep_count, int32_t only_if_terminal, int32_t* diag,
+                                     riab_stream_t stream) {
   TaskArgs a;
   int rc = fill_world_args(a, env, task, task_state, world, B);
   if (rc) return rc;
@@ -322,7 +326,7 @@ extern "C" int riab_task_world_reset(const RiabEnv* env, const RiabTask* task, d
                   ep_log, ep_log_cap, ep_count);
   if (rc) return rc;
   hipLaunchKernelGGL(task_world_reset_kernel, dim3((unsigned)((B + WORLD_BLOCK - 1) / WORLD_BLOCK)), dim3(WORLD_BLOCK), 0,
-                     (hipStream_t)stream, a, r, world, t_env, diag);
+                     (hipStream_t)stream, a, r, world, t_env, (int)only_if_terminal, diag);
   return (int)hipGetLastError();
 }
 

@@ -184,6 +184,9 @@ class StepPlan:
                                        env._reset_counter, int(bool(env.teleport_on_reset)), _L.ptr(env._ep_log), env._ep_cap,
                                        _L.ptr(env._ep_count), float(scripted_speed or 0.0))
         _L.check(rc, "riab_plan_set_task")
+        if env._shared:   # the lanes are the agents of one world: the shared state and the step kernel's scratch
+            _L.check(_L.lib.riab_plan_set_task_world(self._h, _L.ptr(env._world), _L.ptr(env._met), _L.ptr(env._cand),
+                                                     _L.ptr(env._ticket)), "riab_plan_set_task_world")
         self._drift_key = None
         return self
 

@@ -149,7 +149,7 @@ def test_task_world_many_agents_vs_oracle(riab, goalorder, B, delay):
 
 def test_task_world_is_capturable_and_refuses_what_it_cannot_do(riab):
     """The world step inside a captured graph (no workgroup waits for another; the ticket returns to zero) replays like the
-    eager calls; masks, step plans and agentmode='noninteract' are refused."""
+    eager calls; masks and agentmode='noninteract' are refused."""
     from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
     np.random.seed(0)
     with pytest.raises(NotImplementedError):
@@ -168,8 +168,6 @@ def test_task_world_is_capturable_and_refuses_what_it_cannot_do(riab):
     env, Ag = world()
     with pytest.raises(ValueError):
         env.reset(mask=np.ones(700, bool))
-    with pytest.raises(NotImplementedError):
-        env.make_step_plan()
     L = riab._lib
     env_s, walls = env.device_tables(Ag.state_tensor.device)
     task = env._task_struct()
@@ -205,3 +203,52 @@ def test_task_world_is_capturable_and_refuses_what_it_cannot_do(riab):
     torch.cuda.synchronize()
     assert torch.equal(env2._reward, want[0]) and torch.equal(env2._world, want[1]) and torch.equal(env2.task_state, want[2])
     assert not env2._ticket.any().item() and len(env2.goal_cache) < 3
+
+
+@pytest.mark.parametrize("goalorder,B,auto_reset", [("nonsequential", 1030, True), ("sequential", 300, True), ("nonsequential", 64, False)])
+def test_task_world_step_plan_equals_eager_loop(riab, goalorder, B, auto_reset):
+    """env.make_step_plan(auto_reset, scripted_speed) of a one-world task: one native call per step (goal vector, motion, the
+    world's step, its reset when the episode ended — decided on the device —, the populations) == the eager loop
+    `a = speed * goal direction; env.step(a); if terminal: env.reset(); PCs.update()` bit for bit."""
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
+    T, speed = 160, 11.0 * 0.08
+
+    def build():
+        np.random.seed(2)
+        env = SpatialGoalEnvironment(params={"walls": [[[0.5, 0.3], [0.5, 0.7]]]},
+                                     possible_goal_positions=[[0.2, 0.25], [0.8, 0.7], [0.5, 0.1], [0.1, 0.9], [0.9, 0.1]],
+                                     goalcachekws=dict(reset_n_goals=3, goalorder=goalorder), goalkws={"goal_radius": 0.03},
+                                     episode_terminate_delay=0.03, teleport_on_reset=True, seed=11, lanes="agents")
+        Ag = riab.Agent(env, {"dt": 0.01, "n_agents": B, "seed": 4})
+        PCs = riab.PlaceCells(Ag, {"n": 40})
+        env.add_agents(Ag)
+        return env, Ag, PCs
+
+    e1, A1, P1 = build()
+    e2, A2, P2 = build()
+    plan = e2.make_step_plan(auto_reset=auto_reset, scripted_speed=speed)
+    c0 = e1._reset_counter
+    resets = 0
+    for k in range(T):
+        a = e1._goal_vector(speed)
+        obs, rew, term, trunc, info = e1.step(a)
+        rew, term = rew.clone(), term.clone()
+        if auto_reset and bool(term[0].item()):
+            e1._reset_counter = c0 + k     # (the plan advances its reset counter every step, reset or not)
+            e1.reset()
+            resets += 1
+        P1.update()
+        plan.step(1)
+        assert torch.equal(e2.get_reward(), rew), k
+        assert torch.equal(e2.terminal, term), k
+        assert torch.equal(e1._world, e2._world), k
+    assert np.array_equal(A1.pos, A2.pos) and np.array_equal(P1.firingrate, P2.firingrate)
+    assert torch.equal(e1.task_state, e2.task_state)
+    assert e1.episodes == e2.episodes and len(e1.episodes["episode"]) == resets
+    assert resets >= (2 if auto_reset else 0)
+    d1, d2 = e1.diagnostics, e2.diagnostics
+    assert d1 == d2, (d1, d2)
+    assert np.array_equal(A1.history["pos"], A2.history["pos"])
+    assert np.array_equal(P1.history["firingrate"], P2.history["firingrate"])
+    info = plan.info()
+    assert info["launches"] == T * (4 + int(auto_reset)) and info["fused_steps"] == 0

@@ -1,7 +1,8 @@
 """What a step of the one-world task (`lanes="agents"`, csrc/riab_task_world.hip) costs at the cfg 2 batch: the world step
 kernel alone (HIP events around back-to-back launches at fixed positions — the decay and the "stands inside" masks of every
 lane, the last workgroup's walk of the shared list) for a quiet step and for a step in which goals are consumed, and the eager
-closed loop `a = goal vector; env.step(a); PCs.update()` with the reset when the world's episode ends."""
+closed loop `a = goal vector; env.step(a); PCs.update()` with the reset when the world's episode ends, and the same loop as a
+step plan (`env.make_step_plan(auto_reset=True, scripted_speed=...)`)."""
 import os
 import sys
 import time
@@ -51,7 +52,7 @@ for B in (4096, 65536):
     env.reset()
     speed = 11 * ag.speed_mean
     N = 400
-    ag.preallocate_history(3 * N + 64)
+    ag.preallocate_history(5 * N + 64)
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -67,3 +68,14 @@ for B in (4096, 65536):
         dt = time.perf_counter() - t0
         print(f"B={B}: eager loop (goal vector + motion + world step + 1024 place cells): {dt / N * 1e6:6.1f} us per step "
               f"= {B * N / dt / 1e6:6.1f} M agent-steps/s, {resets} resets")
+    plan = env.make_step_plan(capacity=N, auto_reset=True, scripted_speed=speed)
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0, l0 = time.perf_counter(), plan.info()['launches']
+        for _ in range(N // 2):
+            plan.step(1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"B={B}: the same as a step plan (one native call per step, the reset decided on the device; "
+              f"{(plan.info()['launches'] - l0) // (N // 2)} launches per step): {dt / (N // 2) * 1e6:6.1f} us per step "
+              f"= {B * (N // 2) / dt / 1e6:6.1f} M agent-steps/s")
