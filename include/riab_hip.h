@@ -621,14 +621,16 @@ int riab_task_world_step(const RiabEnv* env, const RiabTask* task, double* task_
  * shared list refilled with n_select goals of the pool (the first ones when `ordered`, else a sample drawn
  * from Philox(seed; counter, id 0xFFFFFFFF)), every agent teleported when `teleport` (to (new_x, new_y)[b] or
  * its own draw, as riab_task_reset).  No mask: there is one episode.  only_if_terminal != 0: the caller's
- * `if terminal: env.reset()` decided on the device — nothing happens unless the last riab_task_world_step left
- * the world's flag set. */
+ * `if terminal: env.reset()` decided on the device — nothing is reset unless the last riab_task_world_step left
+ * the world's flag set.  gv_x / gv_y (or NULL): every agent's goal vector AFTER the reset-or-not, as
+ * riab_task_world_goal_vector(scale = gv_scale) would write it — a step plan's next scripted action in the same
+ * launch (needs pos_x / pos_y). */
 int riab_task_world_reset(const RiabEnv* env, const RiabTask* task, double* task_state, double* world, int64_t B,
                           int64_t agent_id0, double t_env, int32_t n_select, int32_t ordered, uint64_t seed,
                           uint64_t counter, int32_t teleport, const double* new_x, const double* new_y,
                           double* pos_x, double* pos_y, float* hist_x, float* hist_y, double* ep_log,
-                          int64_t ep_log_cap, int32_t* ep_count, int32_t only_if_terminal, int32_t* diag,
-                          riab_stream_t stream);
+                          int64_t ep_log_cap, int32_t* ep_count, int32_t only_if_terminal, double gv_scale,
+                          double* gv_x, double* gv_y, int32_t* diag, riab_stream_t stream);
 /* get_goal_vector (:1555-1584) of every agent against the shared list (arguments as riab_task_goal_vector). */
 int riab_task_world_goal_vector(const RiabEnv* env, const RiabTask* task, double* task_state, const double* world,
                                 const double* pos_x, const double* pos_y, int64_t B, double scale, double* out_x,
@@ -647,9 +649,10 @@ int riab_plan_set_task(RiabPlan* plan, const RiabTask* task, double* task_state,
                        int32_t* ep_count, double scripted_speed);
 double riab_plan_task_clock(const RiabPlan* plan);
 /* ... of the kind whose lanes are the agents of ONE world (riab_task_world_*; call after riab_plan_set_task with the
- * same task): a plan step then is [scripted_speed > 0: riab_task_world_goal_vector into the drift buffer] Agent.update,
- * clock += dt_env, riab_task_world_step, [auto_reset: riab_task_world_reset(only_if_terminal = 1), the reset counter
- * advanced every step], then the populations — one launch each, stream-ordered.  world == NULL: back to per-lane. */
+ * same task): a plan step then is [scripted_speed > 0: the goal vectors into the drift buffer — a launch of its own
+ * on the first step and when auto_reset is off], Agent.update + clock += dt_env + riab_task_world_step (ONE launch),
+ * [auto_reset: riab_task_world_reset(only_if_terminal = 1, with the next step's scripted action), the reset counter
+ * advanced every step], then the populations.  world == NULL: back to per-lane. */
 int riab_plan_set_task_world(RiabPlan* plan, double* world, uint64_t* met_scratch, int32_t* cand_scratch, int32_t* ctl);
 
 /* ---- the open-loop path as ONE native call: flag-coupled trajectory + firing-rate kernels -------

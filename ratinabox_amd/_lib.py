@@ -213,7 +213,7 @@ PROTOTYPES = {
     "riab_task_world_reset": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                         C.c_double, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                        C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_plan_set_task_world": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "riab_task_world_goal_vector": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),

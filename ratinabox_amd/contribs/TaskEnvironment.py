@@ -427,7 +427,8 @@ class TaskEnvironment(Environment):
                                               _L.ptr(None if newpos is None else newpos[1]), _L.ptr(st[0]), _L.ptr(st[1]),
                                               _L.ptr(None if hist_row is None else hist_row[0]),
                                               _L.ptr(None if hist_row is None else hist_row[1]),
-                                              _L.ptr(self._ep_log), self._ep_cap, _L.ptr(self._ep_count), 0, _L.ptr(self._diag),
+                                              _L.ptr(self._ep_log), self._ep_cap, _L.ptr(self._ep_count), 0, 0.0, None, None,
+                                              _L.ptr(self._diag),
                                               _L.current_stream())
             _L.check(rc, "riab_task_world_reset")
             self._keep = (newpos, walls, task, self._pool_dev)
@@ -512,8 +513,8 @@ class TaskEnvironment(Environment):
         """The whole closed-loop step as ONE native call (plan.py, riab_plan_*): `plan.step(1, drift_velocity=
         actions)` == `env.step(actions)` + `Neurons.update()` of every population (+ `env.reset(mask=terminal)`
         when `auto_reset`).  Read `env.get_reward()`, `env.terminal`, `env.get_observation()` afterwards.  With
-        `lanes="agents"` the step's pieces (goal vector, motion, the world's step, its reset when the episode ended — decided
-        on the device —, the populations) are one launch each inside the one native call."""
+        `lanes="agents"` a step is three launches inside the one native call: motion + the world's step, its reset when the
+        episode ended (decided on the device) + the next scripted action, the populations."""
         plan = self._agent.make_step_plan(neurons, capacity)
         return plan.attach_task(self, auto_reset=auto_reset, scripted_speed=scripted_speed)
 

@@ -26,6 +26,10 @@ int launch_motion_task(const AgentArgs& ma, const RiabEnv* env, const RiabTask* 
                        uint64_t counter, int32_t teleport, float* hist_x, float* hist_y, double* ep_log,
                        int64_t ep_log_cap, int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y, hipStream_t s);
 
+int launch_motion_world(const AgentArgs& ma, const RiabEnv* env, const RiabTask* task, double* task_state, double* world,
+                        const double* pos_x, const double* pos_y, int64_t task_B, double t_env, double* reward_out,
+                        uint8_t* terminal_out, uint64_t* met, int32_t* cand, int32_t* ctl, int32_t* diag, hipStream_t s);
+
 // the one-launch step (riab_step1.hip)
 int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
 int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
@@ -515,32 +519,38 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
     int rc;
     const bool scripted = p->has_task && p->scripted_speed > 0.0;
     double* act = const_cast<double*>(p->drift);
-    if (p->has_task && p->world) {  // the lanes are the agents of ONE world: the step's pieces, one launch each
+    if (p->has_task && p->world) {  // the lanes are the agents of ONE world
       if (scripted) {
         if (!act || !p->motion.has_drift) return RIAB_EINVAL;
-        rc = riab_task_world_goal_vector(&p->env, &p->task, p->task_state, p->world, pos_x, pos_y, p->task_B, p->scripted_speed,
-                                         act, act + p->B, s);
-        if (rc) return rc;
-        p->launches += 1;
+        if (!p->action_ready) {  // first step / no auto-reset: later ones get their action from the previous step's reset launch
+          rc = riab_task_world_goal_vector(&p->env, &p->task, p->task_state, p->world, pos_x, pos_y, p->task_B,
+                                           p->scripted_speed, act, act + p->B, s);
+          if (rc) return rc;
+          p->launches += 1;
+        }
       }
-      rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr, nullptr,
-                           p->seed, p->step, 1, row, p->diag, s);
+      riab::AgentArgs ma;  // Agent.update and the world's step in one launch
+      rc = riab::fill_agent_args(ma, &p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr,
+                                 p->seed, p->step, 1, row, p->diag);
       if (rc) return rc;
       p->step += 1;
       if (p->hist_base) p->hist_fill += 1;
       p->t_env += p->dt_env;
-      rc = riab_task_world_step(&p->env, &p->task, p->task_state, p->world, pos_x, pos_y, p->task_B, p->t_env, p->reward_out,
-                                p->terminal_out, p->world_met, p->world_cand, p->world_ctl, p->task_diag, s);
+      rc = riab::launch_motion_world(ma, &p->env, &p->task, p->task_state, p->world, pos_x, pos_y, p->task_B, p->t_env,
+                                     p->reward_out, p->terminal_out, p->world_met, p->world_cand, p->world_ctl, p->task_diag, s);
       if (rc) return rc;
-      p->launches += 2;
-      if (p->auto_reset) {  // the caller's `if terminal: env.reset()`, decided on the device
+      p->launches += 1;
+      p->action_ready = false;
+      if (p->auto_reset) {  // the caller's `if terminal: env.reset()`, decided on the device, and the next scripted action
         p->reset_counter += 1;
         rc = riab_task_world_reset(&p->env, &p->task, p->task_state, p->world, p->task_B, p->agent_id0, p->t_env, p->n_select,
                                    p->ordered, p->task_seed, p->reset_counter, p->teleport, nullptr, nullptr, pos_x, pos_y,
                                    row + (int64_t)RIAB_H_POS_X * p->B, row + (int64_t)RIAB_H_POS_Y * p->B, p->ep_log,
-                                   p->ep_log_cap, p->ep_count, 1, p->task_diag, s);
+                                   p->ep_log_cap, p->ep_count, 1, p->scripted_speed, scripted ? act : nullptr,
+                                   scripted ? act + p->B : nullptr, p->task_diag, s);
         if (rc) return rc;
         p->launches += 1;
+        p->action_ready = scripted;
       }
       for (size_t i = 0; i < p->pops.size(); ++i) {
         rc = launch_population(p, i, row, s);

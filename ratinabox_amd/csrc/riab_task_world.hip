@@ -17,7 +17,8 @@
 //     nobody stands in anything — finds an empty work list: a ticket, three empty passes, nothing stored.
 //
 // Float64 like the reference; contraction off (riab_task_kernel.h).
-#include "riab_task_kernel.h"
+#include "riab_agent_kernel.h"  // (the motion step: the plan launches it and the world step as one kernel)
+#include "riab_task_kernel.h"   // (after it: this header turns fp contraction off for its own code)
 #include "riab_task_world_logic.h"
 
 #pragma clang fp contract(off)
@@ -41,6 +42,7 @@ struct WorldShared {  // phase B's state, in LDS
 // step's CANDIDATES can take a turn that changes anything: the lanes that stand in a goal of the list as the step found
 // it (the list only shrinks within a step) — phase A left their indices in `cand` — and, for a termination-delay goal whose
 // time has elapsed, whoever's turn comes first.  Returns the number of goals consumed.
+template <int BLOCK>
 __device__ int world_pass(WorldShared& S, const uint64_t* met, const int32_t* cand, int n_cand, int64_t B, bool pad_elapsed,
                           bool sequential) {
   const int tid = (int)threadIdx.x;
@@ -60,7 +62,7 @@ __device__ int world_pass(WorldShared& S, const uint64_t* met, const int32_t* ca
       if (tid == 0) S.next_agent = 0x7FFFFFFF;
       __syncthreads();
       int mine = 0x7FFFFFFF;
-      for (int i = tid; i < n_cand; i += WORLD_BLOCK) {  // (the candidates are in no particular order)
+      for (int i = tid; i < n_cand; i += BLOCK) {  // (the candidates are in no particular order)
         const int c = cand[i];
         if (c >= a_next && c < mine && (met[c] & mask)) mine = c;
       }
@@ -92,18 +94,20 @@ __device__ __forceinline__ void world_lane_total(const TaskArgs& a, int64_t b, d
   reward_out[b] = total;
 }
 
-// ctl: [0] ticket of the workgroups, [1] number of candidates (both zero between launches)
-__global__ __launch_bounds__(WORLD_BLOCK) void task_world_step_kernel(TaskArgs a, double* world, const double* pos_x,
-                                                                       const double* pos_y, double t_env, double* reward_out,
-                                                                       uint8_t* terminal_out, uint64_t* met, int32_t* cand,
-                                                                       int32_t* ctl, int32_t* diag) {
+// ctl: [0] ticket of the workgroups, [1] number of candidates (both zero between launches).  The body of the step for
+// workgroups of BLOCK lanes: the stand-alone kernel (256) and the plan's motion + world step launch (64, behind the
+// motion step's body) run the same code.
+template <int BLOCK>
+__device__ __forceinline__ void world_step_body(const TaskArgs& a, double* world, const double* pos_x, const double* pos_y,
+                                                double t_env, double* reward_out, uint8_t* terminal_out, uint64_t* met,
+                                                int32_t* cand, int32_t* ctl, int32_t* diag) {
   __shared__ double s_goals[RIAB_TASK_MAX_POOL * RIAB_GOAL_COLS];
   __shared__ WorldShared S;
   const int tid = (int)threadIdx.x;
-  const int64_t b = (int64_t)blockIdx.x * WORLD_BLOCK + tid;
+  const int64_t b = (int64_t)blockIdx.x * BLOCK + tid;
   const bool live = b < a.B;
   // ---- phase A: what an agent's step needs of nobody else
-  task_stage_goals(a, s_goals, tid, WORLD_BLOCK);
+  task_stage_goals(a, s_goals, tid, BLOCK);
   if (tid < RIAB_TASK_MAX_GOALS) S.list[tid] = (uint8_t)((int)world[RIAB_TW_GOAL_LIST + tid] & 0xFF);
   if (tid == 0) S.n = (int)world[RIAB_TW_N_GOALS];
   const double pad_start0 = world[RIAB_TW_PAD_START];
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(WORLD_BLOCK) void task_world_step_kernel(TaskArgs a
   const bool delayed0 = delayed;
   double pad_start = pad_start0;
   // _is_terminal_state (:278-290) as step() calls it (:418-440)
-  world_pass(S, met, cand, n_cand, a.B, t_env - pad_start >= a.terminate_delay, sequential);
+  world_pass<BLOCK>(S, met, cand, n_cand, a.B, t_env - pad_start >= a.terminate_delay, sequential);
   bool terminal = S.n == 0;
   if (terminal && a.terminate_delay != 0.0 && !delayed) {  // :421-434: one unrewarded TimeElapsedGoal pads the episode
     delayed = true;
@@ -166,10 +170,10 @@ __global__ __launch_bounds__(WORLD_BLOCK) void task_world_step_kernel(TaskArgs a
       S.list[0] = (uint8_t)RIAB_WL_PAD;
       S.n = 1;
     }
-    world_pass(S, met, cand, n_cand, a.B, t_env - pad_start >= a.terminate_delay, sequential);
+    world_pass<BLOCK>(S, met, cand, n_cand, a.B, t_env - pad_start >= a.terminate_delay, sequential);
     terminal = S.n == 0;
   }
-  const int late = world_pass(S, met, cand, n_cand, a.B, t_env - pad_start >= a.terminate_delay, sequential);  // :438
+  const int late = world_pass<BLOCK>(S, met, cand, n_cand, a.B, t_env - pad_start >= a.terminate_delay, sequential);  // :438
   const bool terminal_last = S.n == 0;
   if (tid == 0) {
     if (late > 0 && terminal_last && !terminal) atomicAdd(diag + RIAB_TD_LATE_COMPLETIONS, 1);
@@ -203,30 +207,83 @@ __global__ __launch_bounds__(WORLD_BLOCK) void task_world_step_kernel(TaskArgs a
     ctl[1] = 0;
   }
   __syncthreads();
-  for (int i = tid; i < n_cand; i += WORLD_BLOCK) {  // the candidates' totals, with what they were awarded
+  for (int i = tid; i < n_cand; i += BLOCK) {  // the candidates' totals, with what they were awarded
     const int64_t c = cand[i];
     world_lane_total(a, c, reward_out[c], ts_at(a, RIAB_TS_R_MAX, c), ts_at(a, RIAB_TS_R_MIN, c), reward_out);
   }
   if ((terminal_last ? 1 : 0) != terminal_prev)
-    for (int64_t i = tid; i < a.B; i += WORLD_BLOCK) terminal_out[i] = terminal_last ? 1 : 0;
+    for (int64_t i = tid; i < a.B; i += BLOCK) terminal_out[i] = terminal_last ? 1 : 0;
+}
+
+__global__ __launch_bounds__(WORLD_BLOCK) void task_world_step_kernel(TaskArgs a, double* world, const double* pos_x,
+                                                                       const double* pos_y, double t_env, double* reward_out,
+                                                                       uint8_t* terminal_out, uint64_t* met, int32_t* cand,
+                                                                       int32_t* ctl, int32_t* diag) {
+  world_step_body<WORLD_BLOCK>(a, world, pos_x, pos_y, t_env, reward_out, terminal_out, met, cand, ctl, diag);
+}
+
+// Agent.update and the world's step in ONE launch (the step plan): each one-wave workgroup moves its 64 agents (the
+// stand-alone motion kernel's body), reads back the positions it has just written and goes on with the world's step; the
+// last of them to finish walks the shared list.  What is saved is one dependent dispatch per step.
+__global__ __launch_bounds__(64) void motion_world_kernel(const AgentArgs ma, TaskArgs a, double* world, const double* pos_x,
+                                                          const double* pos_y, double t_env, double* reward_out,
+                                                          uint8_t* terminal_out, uint64_t* met, int32_t* cand, int32_t* ctl,
+                                                          int32_t* diag) {
+  agent_step_body<double, 0, false>(ma);
+  world_step_body<64>(a, world, pos_x, pos_y, t_env, reward_out, terminal_out, met, cand, ctl, diag);
 }
 
 // TaskEnvironment.reset (:307-351) of the world: the episode table and the goal selection once (workgroup 0's first
 // thread), teleport_on_reset for every agent (:323-330).
-// `only_if_terminal`: the caller's `if terminal: env.reset()` without a host round trip — nothing happens unless the last
+// `only_if_terminal`: the caller's `if terminal: env.reset()` without a host round trip — nothing is reset unless the last
 // step left the world's flag set.  (No reset touches RIAB_TW_TERMINAL — here other workgroups are still reading it —: it
 // stays "what the last step wrote into terminal_out", and the next step's last workgroup rewrites both.)
+// `gv_x`: the goal vector / scripted action of every agent AFTER the reset-or-not (the step plan's next action, in the
+// same launch).  What the world draws at a reset is a function of (seed, counter) alone: every lane that needs the new
+// list works it out for itself instead of waiting for the thread that stores it.
 __global__ __launch_bounds__(WORLD_BLOCK) void task_world_reset_kernel(TaskArgs a, ResetArgs r, double* world, double t_env,
-                                                                        int only_if_terminal, int32_t* diag) {
+                                                                        int only_if_terminal, double gv_scale, double* gv_x,
+                                                                        double* gv_y, int32_t* diag) {
+  __shared__ double s_goals[RIAB_TASK_MAX_POOL * RIAB_GOAL_COLS];
   const int64_t b = (int64_t)blockIdx.x * WORLD_BLOCK + threadIdx.x;
-  if (only_if_terminal && world[RIAB_TW_TERMINAL] == 0.0) return;
-  if (b < a.B && r.teleport) {
-    ResetDraw d = {0.0, 0.0, 0};
-    if (!r.new_x) d = reset_draw_id(a, r, (uint64_t)(r.agent_id0 + b));
-    Lane L;
-    reset_lane_teleport(r, b, L, d);
+  const bool gv = gv_x != nullptr;
+  const bool reset = !only_if_terminal || world[RIAB_TW_TERMINAL] != 0.0;
+  if (!reset && !gv) return;
+  if (gv) task_stage_goals(a, s_goals, (int)threadIdx.x, WORLD_BLOCK);
+  Lane L;
+  L.px = L.py = 0.0;
+  ResetDraw world_draw = {0.0, 0.0, 0};
+  if (reset) {  // GoalCache.reset (:1218-1252): one selection, appended to every agent's list — the shared list
+    if (gv || b == 0) world_draw = reset_draw_id(a, r, RIAB_WORLD_STREAM_ID);
+    L.list = world_draw.list;
+    L.n_goals = r.n_select < a.n_pool ? r.n_select : a.n_pool;
+  } else {
+    L.n_goals = (int)world[RIAB_TW_N_GOALS];
+    u128 l = 0;
+    for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i)
+      if (i < L.n_goals) l |= (u128)(uint32_t)((int)world[RIAB_TW_GOAL_LIST + i] & 0xFF) << (8 * i);
+    L.list = l;
   }
-  if (b != 0) return;
+  if (b < a.B) {
+    if (reset && r.teleport) {
+      ResetDraw d = {0.0, 0.0, 0};
+      if (!r.new_x) d = reset_draw_id(a, r, (uint64_t)(r.agent_id0 + b));
+      reset_lane_teleport(r, b, L, d);
+    } else if (gv) {
+      L.px = r.pos_x[b];
+      L.py = r.pos_y[b];
+    }
+  }
+  if (gv) {
+    __syncthreads();
+    if (b < a.B) {
+      double vx, vy;
+      goal_vector(a, (lds_f64_ptr)s_goals, L, gv_scale, vx, vy);
+      gv_x[b] = vx;
+      gv_y[b] = vy;
+    }
+  }
+  if (b != 0 || !reset) return;
   atomicAdd(diag + RIAB_TD_RESETS, 1);
   // write_end_episode (:536-539), the episode counter (:333-338)
   bool zero_duration = false;
@@ -256,11 +313,8 @@ __global__ __launch_bounds__(WORLD_BLOCK) void task_world_reset_kernel(TaskArgs 
   if (!zero_duration) world[RIAB_TW_EPISODE] = episode + 1.0;
   world[RIAB_TW_STARTED] = 1.0;
   world[RIAB_TW_EP_START] = any_ended ? t_env : 0.0;  // _current_episode_start (:526-527)
-  // GoalCache.reset (:1218-1252): one selection, appended to every agent's list — the shared list
-  const ResetDraw d = reset_draw_id(a, r, RIAB_WORLD_STREAM_ID);
-  const int n = r.n_select < a.n_pool ? r.n_select : a.n_pool;
-  for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i) world[RIAB_TW_GOAL_LIST + i] = i < n ? (double)list_get(d.list, i) : 0.0;
-  world[RIAB_TW_N_GOALS] = (double)n;
+  for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i) world[RIAB_TW_GOAL_LIST + i] = i < L.n_goals ? (double)list_get(L.list, i) : 0.0;
+  world[RIAB_TW_N_GOALS] = (double)L.n_goals;
   world[RIAB_TW_DELAYED] = 0.0;
 }
 
@@ -293,6 +347,19 @@ static int fill_world_args(TaskArgs& a, const RiabEnv* env, const RiabTask* task
   return fill_args(a, env, task, task_state, B);
 }
 
+// the step plan's motion + world step launch (riab_plan.hip); `ma`: the motion step of the plan's (padded) batch
+int launch_motion_world(const AgentArgs& ma, const RiabEnv* env, const RiabTask* task, double* task_state, double* world,
+                        const double* pos_x, const double* pos_y, int64_t task_B, double t_env, double* reward_out,
+                        uint8_t* terminal_out, uint64_t* met, int32_t* cand, int32_t* ctl, int32_t* diag, hipStream_t s) {
+  TaskArgs a;
+  const int rc = fill_world_args(a, env, task, task_state, world, task_B);
+  if (rc) return rc;
+  if (!pos_x || !pos_y || !reward_out || !terminal_out || !met || !cand || !ctl || !diag) return RIAB_EINVAL;
+  hipLaunchKernelGGL(motion_world_kernel, dim3((unsigned)((ma.B + 63) / 64)), dim3(64), 0, s, ma, a, world, pos_x, pos_y, t_env,
+                     reward_out, terminal_out, met, cand, ctl, diag);
+  return (int)hipGetLastError();
+}
+
 }  // namespace riab
 
 using namespace riab;
@@ -315,18 +382,18 @@ extern "C" int riab_task_world_reset(const RiabEnv* env, const RiabTask* task, d
                                      int64_t agent_id0, double t_env, int32_t n_select, int32_t ordered, uint64_t seed,
                                      uint64_t counter, int32_t teleport, const double* new_x, const double* new_y,
                                      double* pos_x, double* pos_y, float* hist_x, float* hist_y, double* ep_log,
-                                     int64_t ep_log_cap, int32_t* ep_count, int32_t only_if_terminal, int32_t* diag,
-                                     riab_stream_t stream) {
+                                     int64_t ep_log_cap, int32_t* ep_count, int32_t only_if_terminal, double gv_scale,
+                                     double* gv_x, double* gv_y, int32_t* diag, riab_stream_t stream) {
   TaskArgs a;
   int rc = fill_world_args(a, env, task, task_state, world, B);
   if (rc) return rc;
-  if (!diag) return RIAB_EINVAL;
+  if (!diag || (gv_x == nullptr) != (gv_y == nullptr) || (gv_x && (!pos_x || !pos_y))) return RIAB_EINVAL;
   ResetArgs r;
   rc = fill_reset(r, env, agent_id0, n_select, ordered, seed, counter, teleport, new_x, new_y, pos_x, pos_y, hist_x, hist_y,
                   ep_log, ep_log_cap, ep_count);
   if (rc) return rc;
   hipLaunchKernelGGL(task_world_reset_kernel, dim3((unsigned)((B + WORLD_BLOCK - 1) / WORLD_BLOCK)), dim3(WORLD_BLOCK), 0,
-                     (hipStream_t)stream, a, r, world, t_env, (int)only_if_terminal, diag);
+                     (hipStream_t)stream, a, r, world, t_env, (int)only_if_terminal, gv_scale, gv_x, gv_y, diag);
   return (int)hipGetLastError();
 }
 

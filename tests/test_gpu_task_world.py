@@ -207,8 +207,8 @@ def test_task_world_is_capturable_and_refuses_what_it_cannot_do(riab):
 
 @pytest.mark.parametrize("goalorder,B,auto_reset", [("nonsequential", 1030, True), ("sequential", 300, True), ("nonsequential", 64, False)])
 def test_task_world_step_plan_equals_eager_loop(riab, goalorder, B, auto_reset):
-    """env.make_step_plan(auto_reset, scripted_speed) of a one-world task: one native call per step (goal vector, motion, the
-    world's step, its reset when the episode ended — decided on the device —, the populations) == the eager loop
+    """env.make_step_plan(auto_reset, scripted_speed) of a one-world task: one native call per step (motion + the world's
+    step, its reset when the episode ended — decided on the device — + the next action, the populations) == the eager loop
     `a = speed * goal direction; env.step(a); if terminal: env.reset(); PCs.update()` bit for bit."""
     from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
     T, speed = 160, 11.0 * 0.08
@@ -251,4 +251,4 @@ def test_task_world_step_plan_equals_eager_loop(riab, goalorder, B, auto_reset):
     assert np.array_equal(A1.history["pos"], A2.history["pos"])
     assert np.array_equal(P1.history["firingrate"], P2.history["firingrate"])
     info = plan.info()
-    assert info["launches"] == T * (4 + int(auto_reset)) and info["fused_steps"] == 0
+    assert info["launches"] == 3 * T + int(auto_reset) and info["fused_steps"] == 0   # (motion + world step, reset + action / action, rates)

@@ -219,9 +219,11 @@ def test_task_abi_argument_errors():
     assert W(env, task, p, p, p, p, 4, 0.0, p, p, p, p, None, p, None) == -1
     assert W(env, task, p, p, p, p, 1 << 31, 0.0, p, p, p, p, p, p, None) == -3
     assert L.lib.riab_task_world_reset(env, task, p, None, 4, 0, 0.0, 2, 1, 0, 0, 0, None, None, None, None, None, None, None, 0,
-                                       None, 0, p, None) == -1
+                                       None, 0, 0.0, None, None, p, None) == -1
     assert L.lib.riab_task_world_reset(env, task, p, p, 4, 0, 0.0, 16, 1, 0, 0, 0, None, None, None, None, None, None, None, 0,
-                                       None, 1, p, None) == -3
+                                       None, 1, 0.0, None, None, p, None) == -3
+    assert L.lib.riab_task_world_reset(env, task, p, p, 4, 0, 0.0, 2, 1, 0, 0, 0, None, None, None, None, None, None, None, 0,
+                                       None, 1, 1.0, p, p, p, None) == -1      # a goal vector needs the positions
     assert L.lib.riab_plan_set_task_world(None, p, p, p, p) == -1
     assert L.lib.riab_task_world_goal_vector(env, task, p, p, p, p, 4, 0.0, None, p, None) == -1
     assert L.TW_ROWS == 24 and L.TW_GOAL_LIST + L.TASK_MAX_GOALS == L.TW_ROWS
