@@ -87,14 +87,17 @@ def bytes_per_agent_step(cfg):
     return 4 * n + (n if cfg["spikes"] else 0) + 112
 
 
-def build_world(riab, cfg, rank, seed=1234, task=False):
+def build_world(riab, cfg, rank, seed=1234, task=False, one_world=False):
     import numpy as np
     np.random.seed(1000 + rank)
     if task:  # the same world inside a goal-directed task (closed loop: contribs/TaskEnvironment.py)
         from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
+        # (one_world: the rank's agents share ONE task — the reference's multi-agent environment, agentmode="interact":
+        # small goals, or 4096 agents empty the list on the spot)
+        kw = dict(lanes="agents", goalkws={"goal_radius": 0.005}) if one_world else {}
         env = SpatialGoalEnvironment(params={"walls": cfg["walls"]}, possible_goal_positions="random_8",
-                                     goalcachekws=dict(reset_n_goals=2), teleport_on_reset=True,
-                                     episode_terminate_delay=0.05, seed=seed)
+                                     goalcachekws=dict(reset_n_goals=4 if one_world else 2), teleport_on_reset=True,
+                                     episode_terminate_delay=0.05, seed=seed, **kw)
     else:
         env = riab.Environment({"walls": cfg["walls"]})
     B = cfg["agents"]
@@ -351,7 +354,8 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
             sys.exit(2)
         cfg["agents"] = per
     args.plan = args.plan or args.task
-    env, ag, pops = build_world(riab, cfg, rank, task=args.task)
+    one_world = bool(getattr(args, "task_world", False))
+    env, ag, pops = build_world(riab, cfg, rank, task=args.task, one_world=one_world)
     # the full rate history of K steps must fit in HBM next to the warmup's; otherwise stream
     # through ring buffers (every byte is still written, the oldest rows are overwritten)
     n_cells = sum(int(p.n) for p in pops)
@@ -678,6 +682,8 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
                     "kernel": ("step1_task_kernel<%s> (Agent.update + the rest of TaskEnvironment.step + auto-reset + next action + "
                                "Neurons.update in one launch)" % type(dominant).__name__) if one and args.task
                     else ("step1_kernel<%s> (Agent.update + Neurons.update in one launch)" % type(dominant).__name__) if one
+                    else ("motion_world_kernel (Agent.update + the shared world's TaskEnvironment.step) + task_world_reset_kernel "
+                          "(device-decided reset + next action) + rate_kernel_wide<%s> per step" % type(dominant).__name__) if one_world
                     else ("motion_task_kernel + rate_kernel_wide<%s> per step" % type(dominant).__name__) if args.task
                     else "agent_step_kernel + rate_kernel_wide<%s> per step" % type(dominant).__name__,
                     "launches": None, "avg_launch_ms": round(step_s * 1e3, 6), "units_per_launch": B,
@@ -707,7 +713,9 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
 
     out = None
     if rank == 0:
-        api = ("TaskEnvironment step plan: action, Agent.update, rewards/goals, auto-reset, rates; one native call per step"
+        api = ("TaskEnvironment(lanes='agents') step plan — the rank's agents in ONE world, agentmode='interact': Agent.update, "
+               "shared goal list / rewards, device-decided reset, next action, rates; one native call per step" if one_world else
+               "TaskEnvironment step plan: action, Agent.update, rewards/goals, auto-reset, rates; one native call per step"
                if args.task else "step plan (one native call per step)" if args.plan else "per-step update()"
                if args.per_step else "simulate(): trajectory kernel + rate stage running concurrently, coupled by flags in device memory, one native call"
                if fused_mode else "simulate(): trajectory kernel + every population's kernels per chunk of rows behind gates, "
@@ -769,6 +777,9 @@ def main():
     ap.add_argument("--task", action="store_true",
                     help="closed loop through the batched TaskEnvironment: goal-seeking actions, rewards, goal checks "
                          "and per-lane auto-reset every step (implies --plan)")
+    ap.add_argument("--task-world", action="store_true",
+                    help="as --task, but each rank's agents share ONE task world (TaskEnvironment(lanes='agents'): the "
+                         "reference's multi-agent environment with agentmode='interact')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: the config's agents are the TOTAL, split over the ranks (default: weak scaling, "
@@ -787,6 +798,7 @@ def main():
                     help="time the one-kernel rate stage with HIP start / stop events on its launch instead of the "
                          "device clock stamps")
     args = ap.parse_args()
+    args.task = args.task or args.task_world
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(relaunch_as_ranks(args))
@@ -894,16 +906,18 @@ def main():
         saved = args.no_history
         # ... and the CLOSED-LOOP forms of cfg2 (the reference's per-step API, Agent.py:160-242 + Neurons.py:145-171, and
         # its TaskEnvironment.step, contribs/TaskEnvironment.py:361-453): an explicit step plan (one native call per
-        # step), the unchanged `Ag.update(); PCs.update()` loop, a task plan — 256 steps after 32, five repeats each
+        # step), the unchanged `Ag.update(); PCs.update()` loop, a task plan (every agent its own replica of the task; all
+        # agents of the rank in ONE task world) — 256 steps after 32, five repeats each
         runs = [("cfg2_T1024", "cfg2", 128, None)] + ([("cfg3", "cfg3", 32, None)] if world == 1 else []) + \
             [("cfg4", "cfg4", 32, None), ("cfg5", "cfg5", 32, None),
              ("cfg2_closed_loop_plan", "cfg2", 32, "plan"), ("cfg2_closed_loop_per_step", "cfg2", 32, "per_step"),
-             ("cfg2_closed_loop_task", "cfg2", 32, "task")]
+             ("cfg2_closed_loop_task", "cfg2", 32, "task"), ("cfg2_closed_loop_task_world", "cfg2", 32, "task_world")]
         for key, name, warm, mode in runs:
             if key == "cfg2_T1024" and args.steps == SECONDARY_STEPS:
                 continue   # (the headline run IS that run)
             args.no_history = False
-            args.plan, args.per_step, args.task = mode in ("plan", "task"), mode == "per_step", mode == "task"
+            args.plan, args.per_step = mode in ("plan", "task", "task_world"), mode == "per_step"
+            args.task, args.task_world = mode in ("task", "task_world"), mode == "task_world"
             state["running"] = key
             t0 = time.perf_counter()
             try:
@@ -913,7 +927,7 @@ def main():
                 secondary[key] = {"error": f"{type(e).__name__}: {e}"}
                 continue
             finally:
-                args.plan = args.per_step = args.task = False
+                args.plan = args.per_step = args.task = args.task_world = False
             torch.cuda.empty_cache()   # (tens of GB of history per configuration: give them back before the next one)
             if o is None:
                 continue

@@ -791,13 +791,13 @@ def test_bench_launches_its_own_ranks(riab):
     assert [x["rank"] for x in per] == [0, 1] and all(0 < x["min"] <= x["median"] <= x["max"] for x in per)
     assert out["timed_region_ms"]["median"] >= max(x["min"] for x in per)
     sec = out["secondary"]
-    closed = {"cfg2_closed_loop_plan", "cfg2_closed_loop_per_step", "cfg2_closed_loop_task"}
+    closed = {"cfg2_closed_loop_plan", "cfg2_closed_loop_per_step", "cfg2_closed_loop_task", "cfg2_closed_loop_task_world"}
     assert set(sec) == {"cfg2_T1024", "cfg4", "cfg5"} | closed, sec.keys()
     for name, blk in sec.items():
         assert "error" not in blk, blk
         assert blk["n_gpus"] == 2 and blk["value"] > 1e6 and len(blk["timed_region_ms_per_rank"]) == 2
         assert blk["diagnostics"].get("pipeline_timeouts", 0) == 0
-        if name in closed and name != "cfg2_closed_loop_task":   # the one-launch step served the loop
+        if name in closed and "task" not in name:   # the one-launch step served the loop
             assert blk["plan"]["fused_steps"] > 0, blk["plan"]
         assert 0 < blk["frac_whole_path"] < 1 and blk["roofline"]["frac"] > 0
     # the driver's region length with two ranks on the chip: neither rank's pipeline serialised or timed out, and every

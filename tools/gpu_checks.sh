@@ -18,4 +18,5 @@ echo "== default"; timeout 300 python bench.py --no-cpu-baseline --no-secondary 
 echo "== per-step"; timeout 300 python bench.py --per-step --steps 1024 --warmup 64 --no-cpu-baseline 2>/dev/null | summ
 echo "== plan"; timeout 300 python bench.py --plan --steps 512 --warmup 64 --no-cpu-baseline 2>/dev/null | summ
 echo "== task"; timeout 300 python bench.py --task --steps 512 --warmup 64 --no-cpu-baseline 2>/dev/null | summ
+echo "== task, one world"; timeout 300 python bench.py --task-world --steps 512 --warmup 64 --no-cpu-baseline 2>/dev/null | summ
 for c in cfg3 cfg4 cfg5; do echo "== $c"; timeout 300 python bench.py --config $c --no-cpu-baseline 2>/dev/null | summ; done
