@@ -806,8 +806,9 @@ def test_bench_launches_its_own_ranks(riab):
                    {"RIAB_BENCH_SHARE_GPU": "1"}, timeout=400)
     for x in short["timed_region_ms_per_rank"]:
         # (two processes on ONE chip delay each other's dispatches: a rate stage that finds every row published then is
-        # contention, not a shared hardware queue — seen on 4 of ~30 calls here; queue sharing shows on EVERY call)
-        assert x["pipeline_timeouts"] == 0 and x["pipeline_serialised"] <= 10, x
+        # contention, not a shared hardware queue — seen on 4 to 11 of the rank's 31+ calls here, box by box; queue sharing
+        # shows on EVERY call)
+        assert x["pipeline_timeouts"] == 0 and x["pipeline_serialised"] <= 20, x
         assert set(x["host_us"]) == {"python_before_native_call", "in_native_call", "call_return_to_synchronised"}
         assert 0 < x["host_us"]["in_native_call"] < 1000
     strong = _bench(["--gpus", "2", "--strong", "--steps", "64", "--warmup", "8", "--no-cpu-baseline"],
