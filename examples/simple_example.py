@@ -67,3 +67,16 @@ for _ in range(300):
     total += reward
     env.reset(mask=terminal)
 print("task: %d episodes finished, mean return per lane %.2f" % (len(env.episodes["episode"]), float(total.mean())))
+
+# ---- 6. ... and the same 1024 agents in ONE world (the reference's multi-agent task, agentmode="interact") -----
+# one episode, one shared goal list: a goal is consumed for everybody by the first agent found inside it
+world = SpatialGoalEnvironment(possible_goal_positions="random_5", goalcachekws=dict(reset_n_goals=3), goalkws={"goal_radius": 0.01},
+                               teleport_on_reset=True, lanes="agents")
+Ag4 = Agent(world, params={"dt": 0.01, "n_agents": 1024})
+world.add_agents(Ag4)
+plan = world.make_step_plan(capacity=300, auto_reset=True, scripted_speed=0.5)   # three launches per step, one native call
+total = torch.zeros(1024, dtype=torch.float64, device="cuda")
+for _ in range(300):
+    plan.step(1)
+    total += world.get_reward()
+print("one world: %d episodes finished, %d of 1024 agents were rewarded" % (len(world.episodes["episode"]), int((total > 0).sum())))

@@ -185,6 +185,12 @@ def test_goal_cache_validation_and_pool():
     assert env2.goal_cache.get_goals()[1] == [0.3, 0.4]
     with pytest.raises(ValueError):
         SpatialGoalEnvironment(possible_goal_positions="grid_4")
+    # the two batchings: every lane its own replica of the task / the lanes as the agents of one world (interact only)
+    assert env2.lanes == "replicas" and SpatialGoalEnvironment(lanes="agents").goal_cache.agentmode == "interact"
+    with pytest.raises(ValueError):
+        SpatialGoalEnvironment(lanes="herd")
+    with pytest.raises(NotImplementedError):
+        SpatialGoalEnvironment(lanes="agents", goalcachekws=dict(agentmode="noninteract"))
     with pytest.raises(NotImplementedError):
         env2.render()
 
