@@ -6,7 +6,7 @@
 // The reference's check is serial over the agents: each takes its turn against the list as the agents before it left
 // it.  What can be done per agent without looking at the others is done by every lane at once (phase A); the serial
 // remainder is a handful of turns — only an agent standing in a goal of the list changes anything, and every such turn
-// consumes at least one of the <= 16 entries — found by min-reductions over the lanes' "stands inside" masks (phase B).
+// consumes at least one of the <= 16 entries — found by min-reductions over the work list of such agents (phase B).
 //
 //   phase A, all workgroups: RewardCache.update of the lane (:913-927), its mask of the list's goals it stands in
 //     (SpatialGoal.check :1337-1360: line-of-sight distance < radius); a lane that stands in none is done — total
