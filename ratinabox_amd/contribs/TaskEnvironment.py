@@ -613,7 +613,8 @@ class TaskEnvironment(Environment):
     @property
     def episodes(self):
         """Finished episodes of all lanes (synchronises): lists like the reference's `episodes` dict
-        (TaskEnvironment.py:130-136) plus the global `lane` id each belongs to."""
+        (TaskEnvironment.py:130-136) plus the global `lane` id each belongs to (-1: the one episode table of a world
+        whose lanes are its agents, `lanes="agents"`)."""
         n = min(int(self._ep_count.item()), self._ep_cap) if self._agent is not None else 0
         log = self._ep_log[:n].cpu().numpy() if n else np.zeros((0, 5))
         order = np.lexsort((log[:, 0], log[:, 3])) if n else []
