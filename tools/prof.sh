@@ -1,7 +1,7 @@
 # The round's profiles (run on the GPU box through gpurun: `gpurun --timeout 900 -- 'bash tools/prof.sh r05'`): the DRIVER's
 # bench command plain and under rocprofv3 (kernel trace + stats), PMC traffic of its dominant kernel (one counter per pass, as
 # MI355X_MICROARCH.md prescribes; never together with a trace domain), the closed-loop forms (one kernel per step), cfg 3 /
-# cfg 5; with a second argument `world`: only the one-world task's kernels.  Everything lands in gpurun_out/<round>_*; the summaries that are judged are copied to profiles/ by hand.
+# cfg 5; with a second argument `world`: only the one-world task's kernels, `driver`: only the driver's command.  Everything lands in gpurun_out/<round>_*; the summaries that are judged are copied to profiles/ by hand.
 R=${1:-r05}
 exec </dev/null
 O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
@@ -35,6 +35,11 @@ timeout 400 python $B --gpus 1 --steps 20 --warmup 5 > $O/${R}_driver_bench_line
 run_trace driver --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline
 run_pmc driver WRITE_SIZE --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary
 run_pmc driver FETCH_SIZE --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary
+if [ "$2" = "driver" ]; then  # only the driver's command (`bash tools/prof.sh r05 driver`): line, trace, PMC traffic
+  cd $GRAFT_REPO_ROOT
+  python tools/pmc_summary.py $O/${R}_driver_pmc_WRITE_SIZE.csv $O/${R}_driver_pmc_FETCH_SIZE.csv --kernel rate_kernel_gated --units-per-launch 81920 --out $O/${R}_pmc_traffic_driver.json > /dev/null 2>&1 && grep -E '"(hbm_bytes_per_unit|traffic_over_algorithmic_kernel|grid_threads)"' $O/${R}_pmc_traffic_driver.json
+  exit 0
+fi
 run_trace plan --plan --steps 256 --warmup 32 --no-cpu-baseline --no-secondary
 run_pmc plan WRITE_SIZE --plan --steps 256 --warmup 32 --no-cpu-baseline --no-secondary --repeats 3
 run_pmc plan FETCH_SIZE --plan --steps 256 --warmup 32 --no-cpu-baseline --no-secondary --repeats 3
