@@ -612,7 +612,8 @@ enum {
  * the shared list among the listed lanes, appends the awards to the winners' caches in award order and totals
  * those lanes.  terminal_out [B] holds the world's flag for every agent ("no goals left" after the step's last
  * pass, as riab_task_step); the column is rewritten only when the flag changes (RIAB_TW_TERMINAL remembers it):
- * hand in the same array every step.  No workgroup waits for another: capturable, nothing has to be co-resident. */
+ * hand in the same array every step.  No workgroup waits for another: capturable, nothing has to be co-resident.
+ * One launch at a time per world (the scratch and ctl belong to the launch in flight): stream-ordered calls only. */
 int riab_task_world_step(const RiabEnv* env, const RiabTask* task, double* task_state, double* world,
                          const double* pos_x, const double* pos_y, int64_t B, double t_env, double* reward_out,
                          uint8_t* terminal_out, uint64_t* met_scratch, int32_t* cand_scratch, int32_t* ctl,

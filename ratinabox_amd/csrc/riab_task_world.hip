@@ -138,7 +138,8 @@ __device__ __forceinline__ void world_step_body(const TaskArgs& a, double* world
     const bool candidate = m != 0 || (b == 0 && pad_in_list && t_env - pad_start0 >= a.terminate_delay);
     if (candidate) {
       reward_out[b] = ro.total;  // (the survivors' sum: phase B adds this step's awards, then totals)
-      cand[atomicAdd(ctl + 1, 1)] = (int32_t)b;
+      const int slot = atomicAdd(ctl + 1, 1);
+      if (slot < a.B) cand[slot] = (int32_t)b;  // (always, unless the caller's counter did not start at zero)
     } else {
       world_lane_total(a, b, ro.total, rmax, rmin, reward_out);
     }
@@ -152,7 +153,8 @@ __device__ __forceinline__ void world_step_body(const TaskArgs& a, double* world
   if (!S.last) return;
   __threadfence();
   // ---- phase B: the step's check passes over the shared list
-  const int n_cand = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int n_cand = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (n_cand > a.B) n_cand = (int)a.B;
   if (tid == 0) S.n_awards = 0;
   const bool sequential = a.goalorder == RIAB_GOALORDER_SEQUENTIAL;
   const int n0 = S.n;
