@@ -684,7 +684,10 @@ def get_goal_vector(Ag=None):
     """Vector from every lane's position to its goal: the head of the lane's list when goals are
     sequential, the nearest pending goal otherwise; zeros where a lane has no spatial goal pending
     (reference get_goal_vector, TaskEnvironment.py:1555-1584).  (B,2) float64 device tensor."""
-    if not isinstance(Ag, Agent):
-        raise TypeError("Unknown input type")
-    env = Ag.Environment
-    return env._goal_vector(0.0)
+    if isinstance(Ag, Agent):
+        return Ag.Environment._goal_vector(0.0)
+    if isinstance(Ag, list) and Ag and isinstance(Ag[0], Agent):   # (the reference's list / dict forms, :1575-1582)
+        return {a.name: get_goal_vector(a) for a in Ag}
+    if isinstance(Ag, dict):
+        return {name: get_goal_vector(a) for name, a in Ag.items()}
+    raise TypeError("Unknown input type")

@@ -114,6 +114,10 @@ def test_task_world_many_agents_vs_oracle(riab, goalorder, B, delay):
             want = pend[0] - pos if goalorder == "sequential" else \
                 (pend[None] - pos[:, None])[np.arange(B), np.argmin(np.linalg.norm(pend[None] - pos[:, None], axis=2), axis=1)]
             np.testing.assert_allclose(gv.cpu().numpy(), want, rtol=1e-12, atol=1e-15)
+        if k == 0:   # the reference's list / dict forms of the call
+            assert torch.equal(get_goal_vector([Ag])[Ag.name], gv) and torch.equal(get_goal_vector(env.Ags)[Ag.name], gv)
+            with pytest.raises(TypeError):
+                get_goal_vector(3)
         nrm = torch.linalg.norm(gv, dim=1, keepdim=True)
         act = torch.where(nrm > 0, 0.9 * gv / nrm.clamp_min(1e-300), torch.zeros_like(gv))
         obs, rew, term, trunc, info = env.step(act)
