@@ -447,6 +447,11 @@ int riab_plan_step(RiabPlan* plan, int32_t n_steps, riab_stream_t stream);
  * riab_plan_step.  RIAB_EFULL when the object's history chunk is exhausted (attach a new one).  Not with a task. */
 int riab_plan_step_agent(RiabPlan* plan, riab_stream_t stream);
 int riab_plan_step_population(RiabPlan* plan, int32_t index, riab_stream_t stream);
+/* The row riab_plan_step_agent wrote ahead for the fused population is stale — something that population reads was
+ * edited between the two calls of the step (contribs/TaskEnvironment.py:323-330: a reset teleports agents and patches
+ * agent.history["pos"][-1]): it is not claimed; riab_plan_step_population launches the population's own kernel on the
+ * edited row instead. */
+int riab_plan_discard_ahead(RiabPlan* plan);
 
 /* The closed-loop step in ONE launch (csrc/riab_step1.hip).  Replaces, per step, the reference's
  * `Agent.update()` (Agent.py:160-242) + `Neurons.update()` (Neurons.py:145-171) of ONE population — the pair

@@ -194,6 +194,7 @@ PROTOTYPES = {
     "riab_plan_step_agent": (C.c_int, [C.c_void_p, C.c_void_p]),
     "riab_plan_step_population": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "riab_plan_set_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "riab_plan_discard_ahead": (C.c_int, [C.c_void_p]),
     "riab_plan_info": (C.c_int64, [C.c_void_p, C.c_int32]),
     "riab_task_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -419,6 +419,10 @@ class TaskEnvironment(Environment):
         hist_row = getattr(ag, "_last_row", None)  # newest fp32 row [8, B_padded]: what the rate kernels read
         st = ag.state_tensor
         self._reset_counter += 1
+        if teleport and ag._plan is not None and hasattr(ag._plan, "discard_ahead"):
+            # the unchanged per-step loop served natively: this step's Agent.update() may have written its population's row
+            # ahead, at the positions the agents are now teleported away from — that population's update() recomputes it
+            ag._plan.discard_ahead()
         if self._shared:
             rc = _L.lib.riab_task_world_reset(env_s, task, _L.ptr(self.task_state), _L.ptr(self._world), self._B,
                                               int(ag.agent_id0), float(self.t), int(n_sel), int(ordered), self._task_seed,

@@ -472,6 +472,15 @@ extern "C" int riab_plan_step_agent(RiabPlan* p, riab_stream_t stream) {
   return RIAB_OK;
 }
 
+// Something the lead population reads was edited after riab_plan_step_agent wrote its row ahead (a TaskEnvironment reset
+// teleported agents and patched the newest history row): the row is not claimed — the population's own call launches its
+// kernel on the edited row, which overwrites it.  Not a miss: the loop does update the population.
+extern "C" int riab_plan_discard_ahead(RiabPlan* p) {
+  if (!p) return RIAB_EINVAL;
+  p->pre_pending = false;
+  return RIAB_OK;
+}
+
 // Neurons.update() of population `index` on the agent's newest history row
 extern "C" int riab_plan_step_population(RiabPlan* p, int32_t index, riab_stream_t stream) {
   if (!p || p->has_task || index < 0 || index >= (int)p->pops.size()) return RIAB_EINVAL;

@@ -478,6 +478,11 @@ class AutoStepper:
         else:
             buf.copy_(ag._as_device_f64(x, 2))
 
+    def discard_ahead(self):
+        """The positions were edited on the device after this step's Agent.update() (TaskEnvironment.reset teleported agents):
+        the row the one-launch step wrote ahead for its population is stale — its update() recomputes it."""
+        _L.check(_L.lib.riab_plan_discard_ahead(self._h), "riab_plan_discard_ahead")
+
     def step_population(self, N):
         """N.update() with no arguments, N one of the recorded populations with unchanged tables."""
         i = self._index.get(N)

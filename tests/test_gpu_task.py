@@ -659,3 +659,49 @@ def test_one_launch_task_step_only_where_its_grid_is_resident_at_once(riab, B, f
     assert (info["fused_steps"] == 6) == fits, info
     plan.close()                      # (raises if a workgroup of a one-launch step gave up waiting)
     assert np.isfinite(np.asarray(P.firingrate)).all()
+
+
+
+@pytest.mark.parametrize("lanes", ["replicas", "agents"])
+def test_eager_task_loop_sees_teleports_when_the_update_pair_is_one_launch(riab, lanes):
+    """`env.step(a); env.reset(...); PCs.update()` — the reference's order: the population is evaluated AFTER a reset has
+    teleported agents (contribs/TaskEnvironment.py:323-330).  With whole 256-agent segments the unchanged loop's
+    Agent.update() is the one-launch step, which writes the population's row ahead: a reset in between must make
+    PCs.update() recompute it.  Against the same loop with the one-launch step switched off: bit-identical rates."""
+    import os
+    from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
+    B, T, speed = 256, 80, 11.0 * 0.08
+
+    def run(fused):
+        if not fused:
+            os.environ["RIAB_NO_FUSED_STEP"] = "1"
+        try:
+            np.random.seed(2)
+            env = SpatialGoalEnvironment(possible_goal_positions=[[0.2, 0.25], [0.8, 0.7], [0.5, 0.1]],
+                                         goalcachekws=dict(reset_n_goals=2), goalkws={"goal_radius": 0.15},
+                                         teleport_on_reset=True, seed=11, lanes=lanes)
+            Ag = riab.Agent(env, {"dt": 0.01, "n_agents": B, "seed": 4})
+            PCs = riab.PlaceCells(Ag, {"n": 64})
+            env.add_agents(Ag)
+            resets = fused_steps = 0
+            for k in range(T):
+                a = env._goal_vector(speed)
+                obs, rew, term, trunc, info = env.step(a)
+                if lanes == "replicas":
+                    env.reset(mask=term)
+                    resets += int(term.sum().item())
+                elif bool(term[0].item()):
+                    env.reset()
+                    resets += 1
+                PCs.update()
+                if Ag._plan is not None and k == T - 1:
+                    fused_steps = Ag._plan.info()["fused_steps"]
+            return np.array(PCs.history["firingrate"]), np.array(Ag.history["pos"]), resets, fused_steps
+        finally:
+            os.environ.pop("RIAB_NO_FUSED_STEP", None)
+
+    fr1, pos1, resets1, fused1 = run(True)
+    fr0, pos0, resets0, fused0 = run(False)
+    assert resets1 == resets0 and resets1 >= 3 and fused1 > 0 and fused0 == 0, (resets1, resets0, fused1, fused0)
+    assert np.array_equal(pos1, pos0)
+    assert np.array_equal(fr1, fr0), np.nonzero((fr1 != fr0).any(axis=(1, 2)))[0]
