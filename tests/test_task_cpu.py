@@ -230,6 +230,6 @@ def test_task_abi_argument_errors():
                                        None, 1, 0.0, None, None, p, None) == -3
     assert L.lib.riab_task_world_reset(env, task, p, p, 4, 0, 0.0, 2, 1, 0, 0, 0, None, None, None, None, None, None, None, 0,
                                        None, 1, 1.0, p, p, p, None) == -1      # a goal vector needs the positions
-    assert L.lib.riab_plan_set_task_world(None, p, p, p, p) == -1
+    assert L.lib.riab_plan_set_task_world(None, p, p, p, p) == -1 and L.lib.riab_plan_discard_ahead(None) == -1
     assert L.lib.riab_task_world_goal_vector(env, task, p, p, p, p, 4, 0.0, None, p, None) == -1
     assert L.TW_ROWS == 24 and L.TW_GOAL_LIST + L.TASK_MAX_GOALS == L.TW_ROWS
