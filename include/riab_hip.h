@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RIAB_ABI_VERSION 7
+#define RIAB_ABI_VERSION 8
 #define RIAB_MAX_WALLS 64     /* walls staged in LDS by the motion / BVC / line-of-sight kernels */
 #define RIAB_MAX_TEST_ANGLES 360
 #define RIAB_STATE_ROWS 12    /* rows of the agent state matrix, see below */
@@ -481,18 +481,35 @@ int riab_plan_discard_ahead(RiabPlan* plan);
  * task's books, the others learn from the mail which agents a reset moved and write those agents' rates again.  With the split entry points riab_plan_step_agent launches the fused kernel (the population's row is written
  * ahead of its update() call) and the population's riab_plan_step_population of the same step only advances the row
  * cursor; a plan whose populations are not updated after each agent step stops fusing.
- * riab_plan_info: 0 steps served by the one-launch kernel, 1 index of the fused population (-1: none), 2 kernels
- * launched by the plan so far, 3 non-zero when arrival words are attached. */
+ * riab_plan_info: 0 steps served by the one-launch kernel, 1 index of the first fused population (-1: none), 2 kernels
+ * launched by the plan so far, 3 non-zero when arrival words are attached, 4 how many populations ride in the launch,
+ * 5 the compute units the plan counts on, 8 .. 8 + RIAB_STEP1_MAX_POPS - 1 their indices (-1: unused). */
 #define RIAB_STEP1_SYNC_STRIDE 64
 #define RIAB_STEP1_SYNC_MAX_Y 64     /* workgroups per segment (arrival words 1 .. 63) */
 #define RIAB_STEP1_SYNC_TAIL 16
 #define RIAB_STEP1_SYNC_TIMEOUTS 0
+#define RIAB_STEP1_SYNC_FIRST_BAD 1  /* the first / last step a wait gave up in, as "agent steps taken once it was done" (0: none) */
+#define RIAB_STEP1_SYNC_LAST_BAD 2
 #define RIAB_STEP1_SYNC_WALLS_AT(B) ((((B) + 255) / 256) * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TAIL)
 #define RIAB_STEP1_SYNC_MAIL_AT(B) (RIAB_STEP1_SYNC_WALLS_AT(B) + 12 * RIAB_MAX_WALLS + 4)
 #define RIAB_STEP1_MAIL_STRIDE 1088  /* per segment, 8-byte entries (epoch << 32 | value): (at 0) 4 x 8 verdict entries = per mover wave its lane mask in halves and its first two movers' x, y; (at 64) x[256], y[256] */
 #define RIAB_STEP1_SYNC_WORDS(B) (RIAB_STEP1_SYNC_MAIL_AT(B) + (((B) + 255) / 256) * RIAB_STEP1_MAIL_STRIDE)
 int riab_plan_set_fused(RiabPlan* plan, uint32_t* sync_words, int64_t n_words);
 int64_t riab_plan_info(const RiabPlan* plan, int32_t which);
+/* How much of the device the plan's launches can occupy.  The one-launch step cuts its grid to ONE round of workgroups,
+ * and a task plan's form of it — whose workgroups wait for each other in both directions — is only used when that whole
+ * grid is resident at once: compute units x workgroups of the kernel per unit (asked of the runtime per instantiation:
+ * hipOccupancyMaxActiveBlocksPerMultiprocessor); otherwise the plan keeps its two launches per step.  n_cus = 0
+ * (default): hipDeviceAttributeMultiprocessorCount of the calling thread's device.  A caller that knows better says so:
+ * a process whose queues carry a CU mask (HSA_CU_MASK, ROC_GLOBAL_CU_MASK, hipExtStreamCreateWithCUMask) is reported
+ * the whole device by the runtime — riab_probe_compute_units counts what its workgroups really land on. */
+int riab_plan_set_compute_units(RiabPlan* plan, int32_t n_cus);
+/* Count the compute units the workgroups of `stream` land on: two launches on `stream` — every one-wave workgroup of a
+ * grid several times the device marks its unit (XCC_ID, HW_ID's SE / SH / CU fields) in scratch, a one-workgroup kernel
+ * counts the marks into scratch[RIAB_CU_PROBE_WORDS - 1].  scratch: device uint32 [RIAB_CU_PROBE_WORDS], ZEROED by the
+ * caller; no allocation, no synchronisation, no copy: the caller reads the last word once the stream has got there. */
+#define RIAB_CU_PROBE_WORDS 4097
+int riab_probe_compute_units(uint32_t* scratch, riab_stream_t stream);
 
 /* ---- batched TaskEnvironment (contribs/TaskEnvironment.py) ------------------------------------
  * The closed-loop caller of the path: `TaskEnvironment.step(actions)` = Agent.update(drift_velocity
@@ -878,9 +895,16 @@ int64_t riab_streamer_info(RiabStreamer* h, int32_t which);
  *                          48; 1 .. 127)
  *   RIAB_OPT_FUSED_STEP    1 (default) a plan that was given arrival words (riab_plan_set_fused) advances the agent and
  *                          its largest store-bound population in ONE launch per step; 2 the same with ordinary instead
- *                          of nontemporal stores; 0 the motion kernel and every population's kernel one after the other */
+ *                          of nontemporal stores; 0 the motion kernel and every population's kernel one after the other
+ *   RIAB_OPT_STEP1_SPIN    log2 of the polls (~0.3 us each) a wait of the one-launch step makes before it gives up
+ *                          (default 22: about a second; 0 .. 30.  Tests: 0 makes every wait that is not already
+ *                          satisfied give up, which the host layer must recover from)
+ *   RIAB_OPT_STEP1_RESIDENCY  1 (default) the one-launch step's grid follows the compute units the plan counts on
+ *                          (riab_plan_set_compute_units) and a task plan's form is refused where it would not be
+ *                          resident at once; 0 the grid of a whole, idle MI355X whatever the device (tests) */
 enum { RIAB_OPT_TRAJ_KERNEL = 0, RIAB_OPT_FUSED_TASK = 1, RIAB_OPT_BVC_BOX = 2, RIAB_OPT_NT_STORES = 3,
-       RIAB_OPT_PUB_SINGLE_ROWS = 4, RIAB_OPT_POLL_SLEEP = 5, RIAB_OPT_FUSED_STEP = 6, RIAB_OPT_COUNT = 7 };
+       RIAB_OPT_PUB_SINGLE_ROWS = 4, RIAB_OPT_POLL_SLEEP = 5, RIAB_OPT_FUSED_STEP = 6, RIAB_OPT_STEP1_SPIN = 7,
+       RIAB_OPT_STEP1_RESIDENCY = 8, RIAB_OPT_COUNT = 9 };
 int riab_set_option(int32_t option, int32_t value);
 
 /* Process-level host setting for latency-bound callers (one short simulate() per synchronisation, as in bench.py's

@@ -136,6 +136,8 @@ class Agent:
         self._recovered_runs = 0      # diagnostics["pipeline_recovered"]
         self._timeouts_recovered = 0
         self._recover_warned = False
+        self._step1_timeouts = 0           # waits of the one-launch step that gave up (plan.py: _settle_fused) ...
+        self._step1_recovered_steps = 0    # ... and the steps whose fused rows were recomputed
         self._time_rate_kernel = False
         self._timed_population = None
         self._serial_warned = False
@@ -260,7 +262,16 @@ class Agent:
                           f"{len(runs)} run(s) were recomputed from the complete trajectory with the stream-ordered kernels "
                           "(diagnostics['pipeline_recovered'])", RuntimeWarning)
 
+    def _settle_plan(self):
+        """Host reads (the accessors that copy to the host, which waits for the device anyway): has a wait of the
+        one-launch step given up since the last look?  (plan.py _settle_fused: recovered, counted.)  The accessors that
+        hand out DEVICE tensors do not look — that would synchronise a closed loop every step; the plan does when it
+        closes."""
+        if self._plan is not None:
+            self._plan.settle()
+
     def _download(self, row, width):
+        self._settle_plan()
         self._check_pipeline()
         a = self._state[row:row + width, :self._B].t().contiguous().cpu().numpy()
         return self._squeeze(a if width > 1 else a[:, 0])
@@ -296,9 +307,12 @@ class Agent:
     def diagnostics(self):
         """Counters accumulated by the kernel: bounces, bounce-loop saturations,
         boundary conditions applied, zero-displacement steps."""
+        self._settle_plan()
         d = self._diag.cpu().numpy()
         out = dict(bounces=int(d[0]), bounce_saturations=int(d[1]), boundary_conditions=int(d[2]),
                    zero_displacement=int(d[3]))
+        out["step1_timeouts_recovered"] = self._step1_timeouts
+        out["step1_recovered_steps"] = self._step1_recovered_steps
         if self._ctrl is not None:
             w = self._ctrl[:4].cpu()
             out["pipeline_timeouts"] = int(w[_L.CTRL_TIMEOUTS])  # waits of the flag-coupled pipeline that gave up: must be 0
@@ -1145,6 +1159,7 @@ class Agent:
 
     def _materialise_history(self):
         self._sync_plan()
+        self._settle_plan()
         self._check_pipeline()
         h = self._hist.stack()[:, :, :self._B].cpu().numpy()  # (T, 8, B)
         sq = (lambda a: a[:, 0]) if self._B == 1 else (lambda a: a)

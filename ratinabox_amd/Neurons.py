@@ -192,6 +192,7 @@ class Neurons:
     @property
     def firingrate(self):
         self.Agent._sync_plan()
+        self.Agent._settle_plan()
         self.Agent._check_pipeline()
         a = self._rates[:, :self._B].cpu().numpy().astype(np.float64)
         return a[:, 0] if self._B == 1 else a
@@ -465,6 +466,7 @@ class Neurons:
     # ---- history ---------------------------------------------------------------------------------
     def _materialise_history(self):
         self.Agent._sync_plan()
+        self.Agent._settle_plan()
         self.Agent._check_pipeline()
         fr = self._hist_fr.stack()[:, :, :self._B].cpu().numpy()
         sp = self._hist_sp.stack()[:, :, :self._B].cpu().numpy().astype(bool)

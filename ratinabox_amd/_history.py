@@ -103,6 +103,14 @@ class DeviceHistory:
             return torch.empty((0, *self.row_shape), dtype=self.dtype, device=self.device)
         return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
 
+    def row(self, k):
+        """Filled row k (0 = oldest), as a view."""
+        for c, f in zip(self.chunks, self.filled):
+            if k < f:
+                return c[k]
+            k -= f
+        raise IndexError("history row out of range")
+
     def last(self):
         for c, f in zip(reversed(self.chunks), reversed(self.filled)):
             if f:

@@ -13,7 +13,7 @@ import torch  # noqa: F401
 
 from . import _build
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_WALLS = 64
 STATE_ROWS = 12
 HIST_ROWS = 8
@@ -122,6 +122,9 @@ CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_SERIALISED, CTRL_STAMPS, CTRL_TRAJ
 
 
 STEP1_SYNC_STRIDE, STEP1_SYNC_TAIL, STEP1_SYNC_TIMEOUTS = 64, 16, 0   # riab_hip.h RIAB_STEP1_SYNC_*
+STEP1_SYNC_FIRST_BAD, STEP1_SYNC_LAST_BAD = 1, 2
+STEP1_MAX_POPS = 4                                                      # csrc/riab_device.h RIAB_STEP1_MAX_POPS
+CU_PROBE_WORDS = 4097                                                   # riab_hip.h RIAB_CU_PROBE_WORDS
 STEP1_MAIL_STRIDE = 1088                                                # riab_hip.h RIAB_STEP1_MAIL_STRIDE
 
 
@@ -195,6 +198,8 @@ PROTOTYPES = {
     "riab_plan_step_population": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "riab_plan_set_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "riab_plan_discard_ahead": (C.c_int, [C.c_void_p]),
+    "riab_plan_set_compute_units": (C.c_int, [C.c_void_p, C.c_int32]),
+    "riab_probe_compute_units": (C.c_int, [C.c_void_p, C.c_void_p]),
     "riab_plan_info": (C.c_int64, [C.c_void_p, C.c_int32]),
     "riab_task_step": (C.c_int, [C.POINTER(RiabEnv), C.POINTER(RiabTask), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -281,7 +286,7 @@ lib, LIB_PATH = _load()
 
 
 OPTIONS = {"traj_kernel": 0, "fused_task": 1, "bvc_box": 2, "nt_stores": 3, "pub_single_rows": 4, "poll_sleep": 5,
-           "fused_step": 6}   # riab_hip.h RIAB_OPT_*
+           "fused_step": 6, "step1_spin": 7, "step1_residency": 8}   # riab_hip.h RIAB_OPT_*
 
 
 def set_option(name, value):
@@ -298,7 +303,8 @@ for _name, _opt, _val in (("RIAB_NO_PC", "traj_kernel", 1), ("RIAB_TRAJ2", "traj
                           ("RIAB_NO_FUSED_STEP", "fused_step", 0), ("RIAB_FUSED_STEP_PLAIN_STORES", "fused_step", 2)):
     if os.environ.get(_name):
         set_option(_opt, _val)
-for _name, _opt in (("RIAB_PUB_SINGLE_ROWS", "pub_single_rows"), ("RIAB_POLL_SLEEP", "poll_sleep")):
+for _name, _opt in (("RIAB_PUB_SINGLE_ROWS", "pub_single_rows"), ("RIAB_POLL_SLEEP", "poll_sleep"),
+                    ("RIAB_STEP1_SPIN", "step1_spin"), ("RIAB_STEP1_RESIDENCY", "step1_residency")):
     if os.environ.get(_name):
         set_option(_opt, int(os.environ[_name]))
 
@@ -338,3 +344,28 @@ def current_stream():
     if raw is not None:
         return C.c_void_p(raw(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_COMPUTE_UNITS = {}
+
+
+def compute_units(device_index):
+    """The compute units this process's workgroups on torch's current stream of the device really land on
+    (riab_probe_compute_units), measured once per device: a process under HSA_CU_MASK / ROC_GLOBAL_CU_MASK, or on a
+    partition of the chip, is told the whole device by hipGetDeviceProperties.  `RIAB_COMPUTE_UNITS=n` skips the probe."""
+    n = _COMPUTE_UNITS.get(device_index)
+    if n is None:
+        import torch
+        forced = os.environ.get("RIAB_COMPUTE_UNITS")
+        if forced:
+            n = int(forced)
+        else:
+            with torch.cuda.device(device_index):
+                scratch = torch.zeros(CU_PROBE_WORDS, dtype=torch.int32, device=f"cuda:{device_index}")
+                check(lib.riab_probe_compute_units(ptr(scratch), current_stream()), "riab_probe_compute_units")
+                n = int(scratch[CU_PROBE_WORDS - 1].item())
+            props = torch.cuda.get_device_properties(device_index).multi_processor_count
+            if n < 1 or n > props:   # (a probe that makes no sense: what the runtime says)
+                n = props
+        _COMPUTE_UNITS[device_index] = n
+    return n

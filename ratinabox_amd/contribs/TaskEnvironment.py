@@ -419,7 +419,9 @@ class TaskEnvironment(Environment):
         hist_row = getattr(ag, "_last_row", None)  # newest fp32 row [8, B_padded]: what the rate kernels read
         st = ag.state_tensor
         self._reset_counter += 1
-        if teleport and ag._plan is not None and hasattr(ag._plan, "discard_ahead"):
+        # (a mask on the host that selects no lane moves nobody: the rows written ahead stay valid)
+        nobody = mask is not None and not (torch.is_tensor(mask) and mask.is_cuda) and not bool(np.any(np.asarray(mask)))
+        if teleport and not nobody and ag._plan is not None and hasattr(ag._plan, "discard_ahead"):
             # the unchanged per-step loop served natively: this step's Agent.update() may have written its population's row
             # ahead, at the positions the agents are now teleported away from — that population's update() recomputes it
             ag._plan.discard_ahead()

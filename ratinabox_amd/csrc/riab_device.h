@@ -17,6 +17,15 @@ namespace riab {
 // riab_set_option's storage (defined in riab_rates.hip): plain ints, read per call
 extern int g_options[RIAB_OPT_COUNT];
 
+// the one-launch closed-loop step (riab_step1.hip): a population whose update() rides in the agent step's launch, and
+// its rows of this step
+#define RIAB_STEP1_MAX_POPS 4
+struct Step1PopRef {
+  const RiabPopulation* pop;
+  float* rates_row;
+  uint8_t* spikes_row;
+};
+
 struct u32x4 {
   uint32_t x, y, z, w;
 };

@@ -32,14 +32,14 @@ int launch_motion_world(const AgentArgs& ma, const RiabEnv* env, const RiabTask*
 
 // the one-launch step (riab_step1.hip)
 int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
-int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
-                 uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, hipStream_t s);
-int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
-                      uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready,
-                      const RiabTask* task, double* task_state, int64_t task_B, double t_env, double* reward_out,
-                      uint8_t* terminal_out, int32_t* diag, bool auto_reset, int32_t n_select, int32_t ordered, uint64_t task_seed,
-                      uint64_t counter, int32_t teleport, double* ep_log, int64_t ep_log_cap, int32_t* ep_count, double gv_scale,
-                      double* gv_x, double* gv_y, hipStream_t s, bool query);
+int launch_step1(const AgentArgs& a, const RiabEnv* env, const Step1PopRef* refs, int n_pops, uint64_t seed, uint64_t step_after,
+                 uint32_t* sync_words, uint32_t epoch, bool* walls_ready, int n_cus, hipStream_t s);
+int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const Step1PopRef* refs, int n_pops, uint64_t seed,
+                      uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, int n_cus, const RiabTask* task,
+                      double* task_state, int64_t task_B, double t_env, double* reward_out, uint8_t* terminal_out, int32_t* diag,
+                      bool auto_reset, int32_t n_select, int32_t ordered, uint64_t task_seed, uint64_t counter, int32_t teleport,
+                      double* ep_log, int64_t ep_log_cap, int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y,
+                      hipStream_t s, bool query);
 }  // namespace riab
 
 struct RiabPlan {
@@ -85,18 +85,41 @@ struct RiabPlan {
   uint32_t* sync_words;
   uint32_t epoch;        // tag of the last one-launch step on sync_words
   bool walls_ready;      // the wall table behind sync_words has been prepared (the plan's first one-launch step does it)
-  int lead;              // population fused with the agent step; -2: not worked out yet
+  int n_cus;             // compute units the plan's launches can occupy (riab_plan_set_compute_units)
+  int fused_n;           // populations whose update() rides in the agent step's launch; -2: not worked out yet
+  int fused[RIAB_STEP1_MAX_POPS];  // ... their indices, in list order
+  bool fused_whole;      // ... worked out for whole-plan steps (riab_plan_step) / for the split entry points
   int64_t fused_steps, launches;
-  bool pre_pending;      // split entry points: the lead's row of step `pre_step` was written by riab_plan_step_agent
+  // split entry points: riab_plan_step_agent wrote the rows of step `pre_step` of the populations flagged in
+  // `pre_pending` ahead; a row nobody claimed (riab_plan_step_population) is a miss of its population
+  std::vector<char> pre_pending;  // per population
   uint64_t pre_step;
-  int pre_misses;        // ... and was not claimed by riab_plan_step_population that many times in a row
+  std::vector<int> pre_misses;    // per population, in a row
 };
 
-// the population the agent step is fused with: the store-bound one that writes most bytes per row (-1: none)
+// this step's rows of the plan's fused populations (split: those whose chunk has a free row); returns how many
+static int fused_refs(const RiabPlan* p, riab::Step1PopRef* refs, uint32_t* mask, bool need_free_row) {
+  int n = 0;
+  *mask = 0u;
+  for (int k = 0; k < p->fused_n; ++k) {
+    const int i = p->fused[k];
+    const RiabPopulation& q = p->pops[i];
+    if (need_free_row && q.capacity_rows > 0 && p->pop_fill[i] >= q.capacity_rows) continue;
+    const int64_t r = q.capacity_rows > 0 ? p->pop_fill[i] : 0;
+    const int64_t row_elems = (int64_t)q.n * p->B;
+    refs[n].pop = &q;
+    refs[n].rates_row = q.rates_base + r * row_elems;
+    refs[n].spikes_row = q.spikes_base ? q.spikes_base + r * row_elems : nullptr;
+    *mask |= 1u << k;
+    ++n;
+  }
+  return n;
+}
+
 // One closed-loop step of a plan with a task as ONE kernel: Agent.update(), the rest of TaskEnvironment.step (+ the caller's
-// `if terminal: reset()`, + the next scripted action) and population `lead`'s update().  The caller has advanced the
+// `if terminal: reset()`, + the next scripted action) and the fused populations' update().  The caller has advanced the
 // plan's step counter and clock.  `query`: nothing is launched; RIAB_OK when there is a kernel for this plan's step.
-static int fused_task_step(RiabPlan* p, int lead, float* row, hipStream_t s, bool query) {
+static int fused_task_step(RiabPlan* p, float* row, hipStream_t s, bool query) {
   riab::AgentArgs ma;
   const uint64_t step_before = query ? p->step : p->step - 1;
   int rc = riab::fill_agent_args(ma, &p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr, p->seed,
@@ -105,20 +128,20 @@ static int fused_task_step(RiabPlan* p, int lead, float* row, hipStream_t s, boo
   const bool scripted = p->scripted_speed > 0.0;
   double* act = const_cast<double*>(p->drift);
   if (scripted && (!act || !p->motion.has_drift)) return RIAB_EINVAL;
-  const RiabPopulation& q = p->pops[lead];
-  const int64_t r = q.capacity_rows > 0 ? p->pop_fill[lead] : 0;
-  const int64_t row_elems = (int64_t)q.n * p->B;
+  riab::Step1PopRef refs[RIAB_STEP1_MAX_POPS];
+  uint32_t mask;
+  const int n = fused_refs(p, refs, &mask, false);
   uint32_t epoch = 1u;
   if (!query) {
     p->epoch += 1u;
     if (p->epoch == 0u) p->epoch = 1u;
     epoch = p->epoch;
   }
-  rc = riab::launch_step1_task(ma, &p->env, &q, q.rates_base + r * row_elems, q.spikes_base ? q.spikes_base + r * row_elems : nullptr,
-                               p->seed, step_before + 1, p->sync_words, epoch, &p->walls_ready, &p->task, p->task_state, p->task_B,
-                               p->t_env, p->reward_out, p->terminal_out, p->task_diag, p->auto_reset != 0, p->n_select, p->ordered,
-                               p->task_seed, p->reset_counter, p->teleport, p->ep_log, p->ep_log_cap, p->ep_count,
-                               p->scripted_speed, scripted ? act : nullptr, scripted ? act + p->B : nullptr, s, query);
+  rc = riab::launch_step1_task(ma, &p->env, refs, n, p->seed, step_before + 1, p->sync_words, epoch, &p->walls_ready, p->n_cus,
+                               &p->task, p->task_state, p->task_B, p->t_env, p->reward_out, p->terminal_out, p->task_diag,
+                               p->auto_reset != 0, p->n_select, p->ordered, p->task_seed, p->reset_counter, p->teleport, p->ep_log,
+                               p->ep_log_cap, p->ep_count, p->scripted_speed, scripted ? act : nullptr,
+                               scripted ? act + p->B : nullptr, s, query);
   if (rc == RIAB_OK && !query) {
     p->fused_steps += 1;
     p->launches += 1;
@@ -126,42 +149,75 @@ static int fused_task_step(RiabPlan* p, int lead, float* row, hipStream_t s, boo
   return rc;
 }
 
-// (a plan with a task: whole-plan steps only, motion + task fused (RIAB_OPT_FUSED_TASK))
-static int plan_lead(RiabPlan* p, bool whole_step = false) {
-  if (!p->sync_words || riab::g_options[RIAB_OPT_FUSED_STEP] == 0 || p->forced) return -1;
-  if (p->has_task && (!whole_step || riab::g_options[RIAB_OPT_FUSED_TASK] == 0)) return -1;
-  if (p->has_task && p->world) return -1;  // (the world's step is a launch of its own)
-  if (p->lead == -2) {
-    int best = -1;
-    int64_t best_bytes = 0;
+// The populations whose update() rides in the agent step's launch: every store-bound one without additive noise the
+// one-launch step has a functor for (riab_step1.hip: step1_supported), up to RIAB_STEP1_MAX_POPS of them — the ones
+// that write most bytes per row —, in list order.  Returns how many (0: the step is launched kernel by kernel).
+// `whole_step`: for riab_plan_step; otherwise for the split entry points, where a population that keeps no history
+// (its one row is what `firingrate` shows until ITS update() call) and one the caller's loop does not update after
+// every agent step are left out.  (a plan with a task: whole-plan steps only, motion + task fused (RIAB_OPT_FUSED_TASK))
+static int plan_fused(RiabPlan* p, bool whole_step = false) {
+  if (!p->sync_words || riab::g_options[RIAB_OPT_FUSED_STEP] == 0 || p->forced) return 0;
+  if (p->has_task && (!whole_step || riab::g_options[RIAB_OPT_FUSED_TASK] == 0)) return 0;
+  if (p->has_task && p->world) return 0;  // (the world's step is a launch of its own)
+  if (p->fused_n == -2 || p->fused_whole != whole_step) {
+    p->fused_whole = whole_step;
+    p->pre_misses.resize(p->pops.size(), 0);
+    p->pre_pending.resize(p->pops.size(), 0);
+    if (p->n_cus <= 0) {  // (nobody said: the device's own count)
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 1;
+      p->n_cus = n;
+    }
+    int cand[RIAB_STEP1_MAX_POPS];
+    int64_t bytes[RIAB_STEP1_MAX_POPS];
+    int n = 0;
     for (size_t i = 0; i < p->pops.size(); ++i) {
       const RiabPopulation& q = p->pops[i];
       if (riab::step1_supported(&p->env, &q, p->B) != RIAB_OK) continue;
-      if (p->has_task && fused_task_step(p, (int)i, p->row_scratch, nullptr, true) != RIAB_OK) continue;
-      const int64_t bytes = (int64_t)q.n * (q.spikes_base ? 5 : 4);
-      if (bytes > best_bytes) {
-        best = (int)i;
-        best_bytes = bytes;
+      if (!whole_step && (q.capacity_rows == 0 || p->pre_misses[i] >= 2)) continue;
+      const int64_t b = (int64_t)q.n * (q.spikes_base ? 5 : 4);
+      if (n < RIAB_STEP1_MAX_POPS) {
+        cand[n] = (int)i;
+        bytes[n] = b;
+        ++n;
+        continue;
       }
+      int least = 0;  // (more candidates than slots: the smallest gives way; the list order of the others is kept)
+      for (int k = 1; k < n; ++k)
+        if (bytes[k] < bytes[least]) least = k;
+      if (bytes[least] >= b) continue;
+      for (int k = least; k + 1 < n; ++k) {
+        cand[k] = cand[k + 1];
+        bytes[k] = bytes[k + 1];
+      }
+      cand[n - 1] = (int)i;
+      bytes[n - 1] = b;
     }
-    p->lead = best;
+    p->fused_n = n;
+    for (int k = 0; k < n; ++k) p->fused[k] = cand[k];
+    if (n > 0 && p->has_task && fused_task_step(p, p->row_scratch, nullptr, true) != RIAB_OK) p->fused_n = 0;
   }
-  return p->lead;
+  return p->fused_n;
+}
+static bool is_fused(const RiabPlan* p, int index) {
+  for (int k = 0; k < p->fused_n; ++k)
+    if (p->fused[k] == index) return true;
+  return false;
 }
 
-// Agent.update() + the lead population's update() of the same step as one kernel; cursors are the caller's business
-static int fused_agent_step(RiabPlan* p, int lead, float* row, hipStream_t s) {
+// Agent.update() + the fused populations' update() of the same step as one kernel; cursors are the caller's business.
+// `mask`: which of the fused populations took part (split entry points: the ones with a free row).
+static int fused_agent_step(RiabPlan* p, float* row, hipStream_t s, bool need_free_row, uint32_t* mask) {
+  riab::Step1PopRef refs[RIAB_STEP1_MAX_POPS];
+  const int n = fused_refs(p, refs, mask, need_free_row);
+  if (n == 0) return RIAB_EUNSUPPORTED;
   riab::AgentArgs ma;
   int rc = riab::fill_agent_args(ma, &p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr,
                                  p->seed, p->step, 1, row, p->diag);
   if (rc) return rc;
-  const RiabPopulation& q = p->pops[lead];
-  const int64_t r = q.capacity_rows > 0 ? p->pop_fill[lead] : 0;
-  const int64_t row_elems = (int64_t)q.n * p->B;
   p->epoch += 1u;
   if (p->epoch == 0u) p->epoch = 1u;
-  rc = riab::launch_step1(ma, &p->env, &q, q.rates_base + r * row_elems, q.spikes_base ? q.spikes_base + r * row_elems : nullptr,
-                          p->seed, p->step + 1, p->sync_words, p->epoch, &p->walls_ready, s);
+  rc = riab::launch_step1(ma, &p->env, refs, n, p->seed, p->step + 1, p->sync_words, p->epoch, &p->walls_ready, p->n_cus, s);
   if (rc == RIAB_OK) {
     p->fused_steps += 1;
     p->launches += 1;
@@ -195,24 +251,31 @@ extern "C" RiabPlan* riab_plan_create(const RiabEnv* env, const RiabMotion* moti
   p->sync_words = nullptr;
   p->epoch = 0u;
   p->walls_ready = false;
-  p->lead = -2;
+  p->n_cus = 0;
+  p->fused_n = -2;
+  p->fused_whole = false;
   p->fused_steps = p->launches = 0;
-  p->pre_pending = false;
   p->pre_step = 0;
-  p->pre_misses = 0;
   return p;
 }
 
 extern "C" int riab_plan_set_fused(RiabPlan* p, uint32_t* sync_words, int64_t n_words) {
   if (!p || n_words < 0) return RIAB_EINVAL;
   if (sync_words && n_words < (int64_t)RIAB_STEP1_SYNC_WORDS(p->B)) return RIAB_EINVAL;
-  if (((uintptr_t)sync_words) & 3) return RIAB_EALIGN;
+  if (((uintptr_t)sync_words) & 7) return RIAB_EALIGN;  // (the mail's 8-byte entries, the prepared walls' float64)
   p->sync_words = sync_words;
   p->epoch = 0u;
   p->walls_ready = false;
-  p->lead = -2;
-  p->pre_pending = false;
-  p->pre_misses = 0;
+  p->fused_n = -2;
+  p->pre_pending.assign(p->pops.size(), 0);
+  p->pre_misses.assign(p->pops.size(), 0);
+  return RIAB_OK;
+}
+
+extern "C" int riab_plan_set_compute_units(RiabPlan* p, int32_t n_cus) {
+  if (!p || n_cus < 0) return RIAB_EINVAL;
+  p->n_cus = n_cus;  // (0: the device's own count, asked at the next one-launch step)
+  p->fused_n = -2;
   return RIAB_OK;
 }
 
@@ -220,10 +283,14 @@ extern "C" int64_t riab_plan_info(const RiabPlan* p, int32_t which) {
   if (!p) return 0;
   switch (which) {
     case 0: return p->fused_steps;
-    case 1: return p->lead < 0 ? -1 : p->lead;
+    case 1: return p->fused_n <= 0 ? -1 : p->fused[0];
     case 2: return p->launches;
     case 3: return p->sync_words ? 1 : 0;
-    default: return 0;
+    case 4: return p->fused_n < 0 ? 0 : p->fused_n;
+    case 5: return p->n_cus;
+    default:
+      if (which >= 8 && which < 8 + RIAB_STEP1_MAX_POPS) return which - 8 < p->fused_n ? p->fused[which - 8] : -1;
+      return 0;
   }
 }
 
@@ -267,7 +334,9 @@ extern "C" int riab_plan_add(RiabPlan* p, const RiabPopulation* pop) {
   }
   p->pops.push_back(*pop);
   p->pop_fill.push_back(0);
-  p->lead = -2;
+  p->pre_misses.push_back(0);
+  p->pre_pending.push_back(0);
+  p->fused_n = -2;
   return (int)p->pops.size() - 1;
 }
 
@@ -280,8 +349,8 @@ extern "C" int riab_plan_set_population_history(RiabPlan* p, int32_t index, floa
   q.spikes_base = spikes_base;
   q.capacity_rows = capacity_rows;
   p->pop_fill[index] = 0;
-  if (p->pre_pending && index == p->lead) p->pre_pending = false;  // (the row written ahead was in the old chunk)
-  p->lead = -2;  // (spikes or not changes the bytes a row takes)
+  p->pre_pending[index] = 0;  // (a row written ahead was in the old chunk)
+  p->fused_n = -2;            // (spikes or not changes the bytes a row takes)
   return RIAB_OK;
 }
 
@@ -291,7 +360,8 @@ extern "C" int riab_plan_set_task(RiabPlan* p, const RiabTask* task, double* tas
                                   uint64_t reset_counter, int32_t teleport, double* ep_log, int64_t ep_log_cap,
                                   int32_t* ep_count, double scripted_speed) {
   if (!p) return RIAB_EINVAL;
-  p->lead = -2;  // (a task's lead carries no spikes)
+  p->fused_n = -2;
+  p->pre_pending.assign(p->pops.size(), 0);
   p->world = nullptr;
   if (!task) {
     p->has_task = false;
@@ -330,7 +400,7 @@ extern "C" int riab_plan_set_task_world(RiabPlan* p, double* world, uint64_t* me
   p->world_met = met_scratch;
   p->world_cand = cand_scratch;
   p->world_ctl = ctl;
-  p->lead = -2;
+  p->fused_n = -2;
   return RIAB_OK;
 }
 
@@ -445,22 +515,27 @@ extern "C" int riab_plan_step_agent(RiabPlan* p, riab_stream_t stream) {
     forced = p->forced + p->forced_fill * 2 * p->B;
   }
   float* row = p->hist_base ? p->hist_base + p->hist_fill * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
-  // The one-launch step: the lead population's row of THIS step is written by the agent's launch, ahead of the
-  // population's own call, which then only moves its cursor (same inputs, same row, same bits).  A row written ahead
-  // that nobody claims (a loop that does not update the population after every agent step) switches this off.
-  if (p->pre_pending) {
-    p->pre_pending = false;
-    p->pre_misses += 1;
+  // The one-launch step: the fused populations' rows of THIS step are written by the agent's launch, ahead of the
+  // populations' own calls, which then only move their cursors (same inputs, same rows, same bits).  A row written ahead
+  // that nobody claims (a loop that does not update that population after every agent step) is a miss; two in a row
+  // leave the population out.
+  for (size_t i = 0; i < p->pre_pending.size(); ++i) {
+    if (!p->pre_pending[i]) continue;
+    p->pre_pending[i] = 0;
+    if (++p->pre_misses[i] == 2) p->fused_n = -2;
   }
-  const int lead = p->pre_misses < 2 ? plan_lead(p) : -1;
-  if (lead >= 0 && (p->pops[lead].capacity_rows == 0 || p->pop_fill[lead] < p->pops[lead].capacity_rows)) {
-    const int rc = fused_agent_step(p, lead, row, (hipStream_t)stream);
-    if (rc) return rc;
-    p->step += 1;
-    if (p->hist_base) p->hist_fill += 1;
-    p->pre_pending = true;
-    p->pre_step = p->step;
-    return RIAB_OK;
+  if (plan_fused(p) > 0) {
+    uint32_t mask = 0u;
+    const int rc = fused_agent_step(p, row, (hipStream_t)stream, true, &mask);
+    if (rc == RIAB_OK) {
+      p->step += 1;
+      if (p->hist_base) p->hist_fill += 1;
+      for (int k = 0; k < p->fused_n; ++k)
+        if (mask & (1u << k)) p->pre_pending[p->fused[k]] = 1;
+      p->pre_step = p->step;
+      return RIAB_OK;
+    }
+    if (rc != RIAB_EUNSUPPORTED) return rc;  // (no fused population has a free row: the plain agent step)
   }
   const int rc = riab_agent_step(&p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, forced, nullptr,
                                  p->seed, p->step, 1, row, p->diag, (hipStream_t)stream);
@@ -472,12 +547,18 @@ extern "C" int riab_plan_step_agent(RiabPlan* p, riab_stream_t stream) {
   return RIAB_OK;
 }
 
-// Something the lead population reads was edited after riab_plan_step_agent wrote its row ahead (a TaskEnvironment reset
-// teleported agents and patched the newest history row): the row is not claimed — the population's own call launches its
-// kernel on the edited row, which overwrites it.  Not a miss: the loop does update the population.
+// Something the fused populations read was edited after riab_plan_step_agent wrote their rows ahead (a TaskEnvironment
+// reset teleported agents and patched the newest history row): the rows are not claimed — each population's own call
+// launches its kernel on the edited row, which overwrites them.  Counted like a miss: a loop that discards every step
+// (`env.reset(mask)` after every step) pays the fused work AND the populations' kernels, so two in a row switch the
+// one-launch step off for them; one claimed row switches it on again.
 extern "C" int riab_plan_discard_ahead(RiabPlan* p) {
   if (!p) return RIAB_EINVAL;
-  p->pre_pending = false;
+  for (size_t i = 0; i < p->pre_pending.size(); ++i) {
+    if (!p->pre_pending[i]) continue;
+    p->pre_pending[i] = 0;
+    if (++p->pre_misses[i] == 2) p->fused_n = -2;
+  }
   return RIAB_OK;
 }
 
@@ -487,15 +568,19 @@ extern "C" int riab_plan_step_population(RiabPlan* p, int32_t index, riab_stream
   const size_t i = (size_t)index;
   if (p->pops[i].capacity_rows > 0 && p->pop_fill[i] >= p->pops[i].capacity_rows) return RIAB_EFULL;
   if (p->hist_base && p->hist_fill == 0) return RIAB_EINVAL;  // no agent row written into this chunk yet
-  if (p->pre_pending && index == p->lead && p->pre_step == p->step) {  // written by this step's riab_plan_step_agent
-    p->pre_pending = false;
-    p->pre_misses = 0;
+  if (i < p->pre_pending.size() && p->pre_pending[i] && p->pre_step == p->step) {  // written by this step's riab_plan_step_agent
+    p->pre_pending[i] = 0;
+    p->pre_misses[i] = 0;
     if (p->pops[i].capacity_rows > 0) p->pop_fill[i] += 1;
     return RIAB_OK;
   }
   const float* row = p->hist_base ? p->hist_base + (p->hist_fill - 1) * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
   const int rc = launch_population(p, i, row, (hipStream_t)stream);
   if (rc) return rc;
+  if (i < p->pre_misses.size() && p->pre_misses[i] >= 2 && ++p->pre_misses[i] >= 2 + 64) {  // (left out: looked at again every 64 updates)
+    p->pre_misses[i] = 0;
+    p->fused_n = -2;
+  }
   if (p->pops[i].capacity_rows > 0) p->pop_fill[i] += 1;
   return RIAB_OK;
 }
@@ -505,20 +590,21 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
   if (riab_plan_rows_free(p) < n_steps) return RIAB_EFULL;
   if (p->forced && (p->has_task || p->forced_rows - p->forced_fill < n_steps)) return p->has_task ? RIAB_EINVAL : RIAB_EFULL;
   hipStream_t s = (hipStream_t)stream;
-  p->pre_pending = false;
-  const int lead = plan_lead(p, true);
+  p->pre_pending.assign(p->pops.size(), 0);
+  const int n_fused = plan_fused(p, true);
   for (int32_t k = 0; k < n_steps; ++k) {
     float* row = p->hist_base ? p->hist_base + p->hist_fill * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
-    if (lead >= 0 && !p->has_task) {  // Agent.update() and the lead population's update() in one launch, the other populations after it
-      int rc = fused_agent_step(p, lead, row, s);
+    if (n_fused > 0 && !p->has_task) {  // Agent.update() and the fused populations' update() in one launch, the others after it
+      uint32_t mask;
+      int rc = fused_agent_step(p, row, s, false, &mask);
       if (rc) return rc;
       p->step += 1;
       if (p->hist_base) p->hist_fill += 1;
-      if (p->pops[lead].capacity_rows > 0) p->pop_fill[lead] += 1;
       for (size_t i = 0; i < p->pops.size(); ++i) {
-        if ((int)i == lead) continue;
-        rc = launch_population(p, i, row, s);
-        if (rc) return rc;
+        if (!is_fused(p, (int)i)) {
+          rc = launch_population(p, i, row, s);
+          if (rc) return rc;
+        }
         if (p->pops[i].capacity_rows > 0) p->pop_fill[i] += 1;
       }
       continue;
@@ -586,16 +672,15 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
       if (p->hist_base) p->hist_fill += 1;
       p->t_env += p->dt_env;
       if (p->auto_reset) p->reset_counter += 1;
-      if (lead >= 0) {  // ... and the lead population's update() as well: the whole closed-loop step is one kernel
-        const RiabPopulation& q = p->pops[lead];
-        rc = fused_task_step(p, lead, row, s, false);
+      if (n_fused > 0) {  // ... and the fused populations' update() as well: the whole closed-loop step is one kernel
+        rc = fused_task_step(p, row, s, false);
         if (rc) return rc;
         p->action_ready = scripted;
-        if (q.capacity_rows > 0) p->pop_fill[lead] += 1;
         for (size_t i = 0; i < p->pops.size(); ++i) {
-          if ((int)i == lead) continue;
-          rc = launch_population(p, i, row, s);
-          if (rc) return rc;
+          if (!is_fused(p, (int)i)) {
+            rc = launch_population(p, i, row, s);
+            if (rc) return rc;
+          }
           if (p->pops[i].capacity_rows > 0) p->pop_fill[i] += 1;
         }
         continue;

@@ -949,11 +949,11 @@ extern "C" int riab_fill(void* dst, int64_t bytes, float value, riab_stream_t st
 }
 
 namespace riab {
-int g_options[RIAB_OPT_COUNT] = {0, 1, 1, 0, 4, 48, 1};
+int g_options[RIAB_OPT_COUNT] = {0, 1, 1, 0, 4, 48, 1, 22, 1};
 }
 extern "C" int riab_set_option(int32_t option, int32_t value) {
-  static const int lo[RIAB_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0};
-  static const int hi[RIAB_OPT_COUNT] = {2, 1, 1, 1, 64, 127, 2};
+  static const int lo[RIAB_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0, 0, 0};
+  static const int hi[RIAB_OPT_COUNT] = {2, 1, 1, 1, 64, 127, 2, 30, 1};
   if (option < 0 || option >= RIAB_OPT_COUNT || value < lo[option] || value > hi[option]) return RIAB_EINVAL;
   const int old = riab::g_options[option];
   riab::g_options[option] = value;

@@ -44,6 +44,49 @@ struct Step1Sync {
   const Wall<double>* walls;  // [n_walls] the wall table as the kernels keep it, prepared once per plan (walls_prepare_kernel)
 };
 
+// The populations whose update() rides in the launch (round 6: every store-bound one of the plan, not only the
+// largest).  The cell-group axis of the grid runs over the populations one after the other: population i owns the global
+// groups [group0, group0 + n_groups), a group being `cpb` consecutive cells of it (cpb a compile-time property of the
+// population's functor, s1_cpb); a wave finds the population of each of its groups (wave-uniform) and switches into the
+// functor's pass — the same inlined code on the same operands as the population's own kernel, hence the same bits.
+// functor ids: PlaceCells 0 .. 7 = 4 * periodic + (gaussian 0, gaussian_threshold 1, diff_of_gaussians 2, top_hat 3);
+// GridCells 8 + description; HeadDirectionCells 10
+enum { S1_KIND_PC = 0, S1_KIND_GC = 8, S1_KIND_HDC = 10 };
+struct Step1Pop {
+  const float* tab;   // the population's parameter table [n][NP]
+  float* rates;       // its row of this step
+  uint8_t* spikes;    // ... or null
+  int32_t n, kind;
+  int32_t group0, n_groups;
+  float fr_scale, fr_min;
+  float p0, p1, p2;   // PlaceCells: scale, half_scale (periodic wrap), top_hat_w2; GridCells: f0, 1 / (1 - f0)
+  uint32_t tag;       // RIAB_TAG_SPIKES | pop_id
+};
+struct Step1Pops {
+  int32_t n_pops, total_groups;
+  int32_t needs_hd;      // a population reads the head direction: the movers leave it in LDS too
+  float dt;
+  uint32_t k0, k1;       // Philox key (seed)
+  uint32_t step0;        // agent steps taken once this one is done (Neurons.update's spike counter)
+  uint32_t quad0;        // agent_id0 / 4
+  Step1Pop pop[RIAB_STEP1_MAX_POPS];
+};
+// cells per group of a functor: as the row-following kernel, twice the wide kernel's where a wave's 64 lanes hold the
+// parameters; a task's step (15 of a segment's 16 workgroups write rates) a sixteenth more, so that a population that
+// filled one round of workgroups stays one round: cfg 2, 1024 cells: 114 groups of 9 on 15 x 8 waves instead of 128 of 8
+template <class Cell, bool TASK>
+struct S1Cpb {
+  static constexpr int BASE = (Cell::NP * 2 * Cell::CPB <= 64) ? 2 * Cell::CPB : Cell::CPB;
+  static constexpr int T16 = (BASE * 16 + 14) / 15;
+  static constexpr int value = (TASK && Cell::NP * T16 <= 64) ? T16 : BASE;
+};
+__host__ __device__ static inline int s1_cpb(int kind, bool task) {
+  if (kind < S1_KIND_GC) return task ? S1Cpb<PlaceCell<0, 0>, true>::value : S1Cpb<PlaceCell<0, 0>, false>::value;
+  if (kind < S1_KIND_HDC) return task ? S1Cpb<GridCell<0>, true>::value : S1Cpb<GridCell<0>, false>::value;
+  return task ? S1Cpb<HDCell<0>, true>::value : S1Cpb<HDCell<0>, false>::value;
+}
+__host__ __device__ static inline int s1_np(int kind) { return kind < S1_KIND_GC ? PlaceCell<0, 0>::NP : kind < S1_KIND_HDC ? GridCell<0>::NP : HDCell<0>::NP; }
+
 // Once per plan (its first one-launch step): Wall<double>[n_walls] from the plan's wall table — a wall costs two float64
 // divisions and a square root, which a staging wave would otherwise pay in front of every step's first barrier — and,
 // behind the walls, the verdict of the box fast path (make_motion_const's check of the first four walls, ~600
@@ -58,6 +101,16 @@ __global__ __launch_bounds__(64) void walls_prepare_kernel(const AgentArgs a, Wa
 }
 
 typedef __attribute__((address_space(1))) uint32_t s1_gu32;
+// A wait that gave up (one lane): counted, and the step it happened in remembered (first / last, as "agent steps taken
+// once the step is done") — the host recomputes the fused populations' rows of those steps from the history rows
+// (plan.py: settle_fused; what a give-up can leave wrong is rates only: the writer computes the state from its own
+// loads and waits for the others only before it STORES; nobody but a writer stores state, history or task rows)
+__device__ __forceinline__ void step1_note_timeout(const Step1Sync& sy, uint32_t step_after) {
+  uint32_t* const tail = sy.words + (int64_t)sy.n_segments * RIAB_STEP1_SYNC_STRIDE;
+  atomicAdd(tail + RIAB_STEP1_SYNC_TIMEOUTS, 1u);
+  atomicCAS(tail + RIAB_STEP1_SYNC_FIRST_BAD, 0u, step_after);
+  atomicMax(tail + RIAB_STEP1_SYNC_LAST_BAD, step_after);
+}
 // A workgroup barrier for hand-overs through LDS: __syncthreads() also waits for every global store and atomic the wave
 // has in flight (its fence covers global memory) — a round trip in the middle of the writer's dependent chain, where the
 // bookkeeping's stores and the episode table's atomic are meant to stay in flight.  Nothing in global memory is handed
@@ -130,14 +183,91 @@ struct Step1Task {
 #define RIAB_S1_WAVES_PER_EU 2
 #endif
 #define RIAB_S1_WAVES 8  // waves per workgroup: 0-3 advance the 256 agents, 4-7 draw their normals, all of them write rates
-template <class Cell, int SPK, int CPB, bool NT, int TASK>
-__device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& ra, const Cell& cell, const Step1Sync& sy,
+// one cell group of population `q` (functor `Cell`, CPB cells) for the lane's quad of agents: rate_kernel_wide's inner
+// loop.  `cur`: the group's parameters, one per lane (s1_group_params); `store`: the lanes that write their values.
+template <class Cell, int CPB, int SPK, bool NT>
+__device__ __forceinline__ void s1_group(const Cell& cell, const Step1Pops& ps, const Step1Pop& q, const int gl, const float cur,
+                                         const v4f rx, const v4f ry, const v4f rhx, const v4f rhy, const int64_t B,
+                                         const uint32_t quad, const bool store) {
+  constexpr int NP = Cell::NP;
+  static_assert(NP * CPB <= 64, "a cell group's parameters must fit one wave");
+  const typename Cell::Pos P = cell.from_rows(rx, ry, rhx, rhy);
+  const int c0 = gl * CPB;
+  int64_t off = (int64_t)c0 * B + 4 * (int64_t)quad;
+  RateArgs sa;  // (what spike_store reads)
+  sa.u_in = nullptr;
+  sa.spikes = q.spikes;
+  sa.tag = q.tag;
+  sa.k0 = ps.k0;
+  sa.k1 = ps.k1;
+  sa.dt = ps.dt;
+#pragma unroll
+  for (int j = 0; j < CPB; ++j) {
+    if (c0 + j < q.n) {  // wave-uniform
+      float p[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) p[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), j * NP + i));
+      v4f rr = cell.eval(p, P);
+      rr = finish_rate(rr * q.fr_scale + q.fr_min, P);  // [0,1] -> [min_fr, max_fr]
+      if (store) {
+        if (RIAB_S1_ABLATE & 2) {
+          if (rr.x == 123.0f) *reinterpret_cast<v4f*>(q.rates + off) = rr;
+        } else if (NT) __builtin_nontemporal_store(rr, reinterpret_cast<v4f*>(q.rates + off));
+        else *reinterpret_cast<v4f*>(q.rates + off) = rr;
+        if (SPK && q.spikes) spike_store<false>(sa, rr, off, ps.step0, (uint32_t)(c0 + j), ps.quad0 + quad);  // (wave-uniform)
+      }
+      off += B;
+    }
+  }
+}
+
+// ... switched into by the population's functor id (wave-uniform)
+template <int SPK, bool NT, bool TASK>
+__device__ __forceinline__ void s1_group_any(const Step1Pops& ps, const Step1Pop& q, const int gl, const float cur, const v4f rx,
+                                             const v4f ry, const v4f rhx, const v4f rhy, const int64_t B, const uint32_t quad,
+                                             const bool store) {
+#define RIAB_S1_PC(DESC, GX, ID)                                                                                        \
+  case ID: {                                                                                                            \
+    PlaceCell<DESC, GX> c;                                                                                              \
+    c.tab = q.tab; c.scale = q.p0; c.half_scale = q.p1; c.top_hat_w2 = q.p2;                                            \
+    c.walls = nullptr; c.n_internal = 0; c.lds = nullptr;                                                               \
+    s1_group<PlaceCell<DESC, GX>, S1Cpb<PlaceCell<DESC, GX>, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, rhx, rhy, B, quad, store); \
+    break;                                                                                                              \
+  }
+  switch (q.kind) {
+    RIAB_S1_PC(RIAB_PC_GAUSSIAN, 0, 0)
+    RIAB_S1_PC(RIAB_PC_GAUSSIAN_THRESHOLD, 0, 1)
+    RIAB_S1_PC(RIAB_PC_DIFF_OF_GAUSSIANS, 0, 2)
+    RIAB_S1_PC(RIAB_PC_TOP_HAT, 0, 3)
+    RIAB_S1_PC(RIAB_PC_GAUSSIAN, 3, 4)
+    RIAB_S1_PC(RIAB_PC_GAUSSIAN_THRESHOLD, 3, 5)
+    RIAB_S1_PC(RIAB_PC_DIFF_OF_GAUSSIANS, 3, 6)
+    RIAB_S1_PC(RIAB_PC_TOP_HAT, 3, 7)
+    case S1_KIND_GC + RIAB_GC_RECTIFIED: {
+      const GridCell<RIAB_GC_RECTIFIED> c{q.tab, q.p0, q.p1};
+      s1_group<GridCell<RIAB_GC_RECTIFIED>, S1Cpb<GridCell<RIAB_GC_RECTIFIED>, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, rhx, rhy, B, quad, store);
+      break;
+    }
+    case S1_KIND_GC + RIAB_GC_SHIFTED: {
+      const GridCell<RIAB_GC_SHIFTED> c{q.tab, q.p0, q.p1};
+      s1_group<GridCell<RIAB_GC_SHIFTED>, S1Cpb<GridCell<RIAB_GC_SHIFTED>, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, rhx, rhy, B, quad, store);
+      break;
+    }
+    default: {
+      const HDCell<0> c{q.tab, 0.0f, nullptr, nullptr};
+      s1_group<HDCell<0>, S1Cpb<HDCell<0>, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, rhx, rhy, B, quad, store);
+      break;
+    }
+  }
+#undef RIAB_S1_PC
+}
+
+template <int SPK, bool NT, int TASK>
+__device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& ps, const Step1Sync& sy,
                                            const int reps, const MotionConst<double>& hk, const TailConst<double>& tail_c,
                                            const Step1Task& tk) {
   RIAB_EXACT_FP
-  constexpr int NP = Cell::NP;
   constexpr int NT_ = 64 * RIAB_S1_WAVES;
-  static_assert(NP * CPB <= 64, "a cell group's parameters must fit one wave");
   __shared__ Wall<double> s_w[RIAB_MAX_WALLS];
   __shared__ double s_g[RIAB_G_SEGS * RIAB_G_STRIDE];
   __shared__ double s_h[RIAB_H_SEGS * RIAB_H_STRIDE];
@@ -203,9 +333,18 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
   // this wave's first cell group (task: the writer has none, the cell groups are dealt to the workgroups y >= 1)
   const bool rates_here = !(TASK && writer);
   const int g0 = (int)((blockIdx.y - (TASK ? 1u : 0u)) * (uint32_t)RIAB_S1_WAVES + (uint32_t)wave) * reps;
-  auto group_params = [&](int g) -> float {
-    const int pi = g * CPB * NP + lane;
-    return (lane < NP * CPB && pi < ra.n * NP) ? cell.tab[pi] : 0.0f;
+  auto pop_of = [&](int g) -> int {  // (wave-uniform) the population the global cell group g belongs to
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < RIAB_STEP1_MAX_POPS; ++k) pi += (k < ps.n_pops && g >= ps.pop[k].group0) ? 1 : 0;
+    return pi;
+  };
+  auto group_params = [&](int g) -> float {  // group g's parameters, one per lane
+    if (g >= ps.total_groups) return 0.0f;
+    const Step1Pop& q = ps.pop[pop_of(g)];
+    const int np = s1_np(q.kind), width = np * s1_cpb(q.kind, TASK != 0);
+    const int pi = (g - q.group0) * width + lane;
+    return (lane < width && pi < q.n * np) ? q.tab[pi] : 0.0f;
   };
   float mine = rates_here ? group_params(g0) : 0.0f;
   stage_rayleigh_tables<NT_>(s_g, s_h, tid);
@@ -442,7 +581,7 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
       __builtin_amdgcn_s_sleep(8);
       hseen = arrivals();
     }
-    if (late && lane == 0) atomicAdd(sy.words + (int64_t)sy.n_segments * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TIMEOUTS, 1u);
+    if (late && lane == 0) step1_note_timeout(sy, ps.step0);
     if (hlive) {
       tk.gv_x[b] = hx_;
       tk.gv_y[b] = hy_;
@@ -451,7 +590,7 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
   } else if (mover) {
     s_row[0][tid] = (float)px;
     s_row[1][tid] = (float)py;
-    if (Cell::NEEDS_HD) {
+    if (ps.needs_hd) {
       s_row[2][tid] = (float)hx;
       s_row[3][tid] = (float)hy;
     }
@@ -498,8 +637,7 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
       __builtin_amdgcn_s_sleep(8);
       seen = arrivals();
     }
-    if (timed_out && lane == 0)
-      atomicAdd(sy.words + (int64_t)sy.n_segments * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TIMEOUTS, 1u);
+    if (timed_out && lane == 0) step1_note_timeout(sy, ps.step0);
     RIAB_S1_STAMP(5)
     {
       st[0 * B] = px;
@@ -525,40 +663,20 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
 
   // ---- Neurons.update of the population: this wave's cell groups for the segment's 256 agents ----------------------
   // (`store`: the lanes that write their quad's values — all of them, but for the pass that follows a reset, below)
-  auto rates_pass = [&](const v4f rx, const v4f ry, float params, const bool store) {
+  auto rates_pass = [&](const v4f rx, const v4f ry, float params, const bool store) __attribute__((always_inline)) {
     v4f rhx = {0.0f, 0.0f, 0.0f, 0.0f}, rhy = rhx;
-    if (Cell::NEEDS_HD) {
+    if (ps.needs_hd) {
       rhx = *reinterpret_cast<const v4f*>(&s_row[2][4 * lane]);
       rhy = *reinterpret_cast<const v4f*>(&s_row[3][4 * lane]);
     }
-    const typename Cell::Pos P = cell.from_rows(rx, ry, rhx, rhy);
-    const uint32_t q = blockIdx.x * 64u + (uint32_t)lane;  // the lane's quad of agents within the row
-    const uint32_t group = ra.group0 + q;
+    const uint32_t quad = blockIdx.x * 64u + (uint32_t)lane;  // the lane's quad of agents within the row
     for (int r = 0; r < reps; ++r) {
-      const int c0 = (g0 + r) * CPB;
-      if (c0 >= ra.n) break;  // wave-uniform
+      const int g = g0 + r;
+      if (g >= ps.total_groups) break;  // wave-uniform
       const float cur = params;
-      if (r + 1 < reps) params = group_params(g0 + r + 1);  // (requested before this group's stores are issued)
-      int64_t off = (int64_t)c0 * B + 4 * (int64_t)q;
-#pragma unroll
-      for (int j = 0; j < CPB; ++j) {
-        if (c0 + j < ra.n) {  // wave-uniform
-          float p[NP];
-#pragma unroll
-          for (int i = 0; i < NP; ++i)
-            p[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), j * NP + i));
-          v4f rr = cell.eval(p, P);
-          rr = finish_rate(rr * ra.fr_scale + ra.fr_min, P);  // [0,1] -> [min_fr, max_fr]
-          if (store) {
-            if (RIAB_S1_ABLATE & 2) {
-              if (rr.x == 123.0f) *reinterpret_cast<v4f*>(ra.rates + off) = rr;
-            } else if (NT) __builtin_nontemporal_store(rr, reinterpret_cast<v4f*>(ra.rates + off));
-            else *reinterpret_cast<v4f*>(ra.rates + off) = rr;
-            if (SPK == 1) spike_store<false>(ra, rr, off, ra.step0, (uint32_t)(c0 + j), group);
-          }
-          off += B;
-        }
-      }
+      if (r + 1 < reps) params = group_params(g + 1);  // (requested before this group's stores are issued)
+      const Step1Pop& q = ps.pop[pop_of(g)];
+      s1_group_any<SPK, NT, TASK != 0>(ps, q, g - q.group0, cur, rx, ry, rhx, rhy, B, quad, store);
     }
   };
   if (rates_here)
@@ -570,7 +688,12 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
     RIAB_S1_STAMP(4)
   }
 #endif
-  if (TASK && !writer && Cell::NEEDS_POS && !(RIAB_S1_TASK_DROP & 8)) {
+  // (a wave whose groups are all HeadDirectionCells' writes nothing a reset can change: no wait at all)
+  bool wave_needs_pos = false;
+  if (TASK && !writer)
+    for (int r = 0; r < reps; ++r)
+      if (g0 + r < ps.total_groups) wave_needs_pos = wave_needs_pos || ps.pop[pop_of(g0 + r)].kind != S1_KIND_HDC;
+  if (TASK && !writer && wave_needs_pos && !(RIAB_S1_TASK_DROP & 8)) {
     // ---- did a reset move one of the segment's agents?  The writer's 4 x 6 verdict entries of this launch: one round
     // trip (they are usually there by now) says that they are posted, which agents moved and where (almost all of) them went.
     const s1_gu64* const mail64 = (const s1_gu64*)(uintptr_t)(tk.mail + (int64_t)blockIdx.x * RIAB_STEP1_MAIL_STRIDE);
@@ -662,7 +785,7 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
       rates_pass(rx, ry, reps == 1 ? mine : group_params(g0), mine_moved);  // (one group per wave: its parameters are still here)
     }
     RIAB_S1_STAMP(12)
-    if (stale && lane == 0) atomicAdd(sy.words + (int64_t)sy.n_segments * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TIMEOUTS, 1u);
+    if (stale && lane == 0) step1_note_timeout(sy, ps.step0);
   }
   if (wb) write_back();
   // (the ended episodes' rows, last: their slots in the table were asked for a write-back ago)
@@ -675,99 +798,45 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const RateArgs& r
 #endif
 }
 
-template <class Cell, int SPK, int CPB, bool NT>
-__global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_kernel(const AgentArgs a, const RateArgs ra, Cell cell,
+template <int SPK, bool NT>
+__global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_kernel(const AgentArgs a, const Step1Pops ps,
                                                                                            const Step1Sync sy, const int reps,
                                                                                            const MotionConst<double> hk,
                                                                                            const TailConst<double> tail_c) {
   const Step1Task none = {};
-  step1_body<Cell, SPK, CPB, NT, 0>(a, ra, cell, sy, reps, hk, tail_c, none);
+  step1_body<SPK, NT, 0>(a, ps, sy, reps, hk, tail_c, none);
 }
 
-template <class Cell, int SPK, int CPB, bool NT, int TASK>
-__global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_task_kernel(const AgentArgs a, const RateArgs ra,
-                                                                                                Cell cell, const Step1Sync sy,
-                                                                                                const int reps,
+template <int SPK, int TASK>
+__global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_task_kernel(const AgentArgs a, const Step1Pops ps,
+                                                                                                const Step1Sync sy, const int reps,
                                                                                                 const MotionConst<double> hk,
                                                                                                 const TailConst<double> tail_c,
                                                                                                 const Step1Task tk) {
-  step1_body<Cell, SPK, CPB, NT, TASK>(a, ra, cell, sy, reps, hk, tail_c, tk);
+  step1_body<SPK, true, TASK>(a, ps, sy, reps, hk, tail_c, tk);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
-// how a (B, n) problem is cut: `reps` cell groups per wave so that the grid is about one wave of workgroups (two per
-// compute unit: 512 on MI355X) — a second round of workgroups would run the motion step a second time — and a
-// segment's workgroups fit its line of arrival words
+// How a (B, groups) problem is cut: `reps` cell groups per wave so that the grid is one round of workgroups on the
+// compute units the plan's launches can occupy (`resident`: workgroups of this kernel the device holds at once — a
+// second round would run the motion step a second time, and a task's step must not have one at all, see below) and a
+// segment's workgroups fit its line of arrival words.
 // (task: one of a segment's workgroups — its writer — keeps the task's books instead of writing rates)
-static void step1_shape(int64_t B, int n, int cpb, bool task, dim3* grid, int* reps) {
+static int step1_shape(int64_t B, int64_t groups, bool task, int64_t resident, dim3* grid, int* reps) {
   const int64_t segs = B / 256;
-  const int64_t groups = (n + cpb - 1) / cpb;
-  int64_t want_y = (2048 / RIAB_S1_WAVES) / segs;  // workgroups per segment in one resident round (eight waves per compute unit)
+  int64_t want_y = resident / segs;  // workgroups per segment in one resident round
   if (want_y > RIAB_STEP1_SYNC_MAX_Y) want_y = RIAB_STEP1_SYNC_MAX_Y;
   if (task) want_y -= 1;
-  if (want_y < 1) want_y = 1;
+  if (want_y < 1) {
+    if (task) return RIAB_EUNSUPPORTED;  // (no room for a writer and a rate workgroup per segment: two launches)
+    want_y = 1;
+  }
   int64_t r = (groups + RIAB_S1_WAVES * want_y - 1) / (RIAB_S1_WAVES * want_y);
   if (r < 1) r = 1;
-  int64_t gy = (groups + RIAB_S1_WAVES * r - 1) / (RIAB_S1_WAVES * r);
+  const int64_t gy = (groups + RIAB_S1_WAVES * r - 1) / (RIAB_S1_WAVES * r);
   *reps = (int)r;
   *grid = dim3((unsigned)segs, (unsigned)(gy + (task ? 1 : 0)), 1);
-}
-
-template <class Cell>
-static int launch_step1_cell(const AgentArgs& a, const RateArgs& ra, const Cell& cell, const Step1Sync& sy, bool spikes,
-                             bool nt, hipStream_t s, const Step1Task* tk, int task_mode, bool query) {
-  constexpr int CPB = (Cell::NP * 2 * Cell::CPB <= 64) ? 2 * Cell::CPB : Cell::CPB;  // (as the row-following kernel)
-  // (task: 15 of a segment's 16 workgroups write rates — a cell group a sixteenth larger keeps a population that filled
-  // one round of workgroups in one round: cfg 2, 1024 cells: 114 groups of 9 on 15 x 8 waves instead of 128 of 8 on 16 x 8)
-  constexpr int CPB_T = (Cell::NP * ((CPB * 16 + 14) / 15) <= 64) ? (CPB * 16 + 14) / 15 : CPB;
-  dim3 grid;
-  int reps;
-  step1_shape(a.B, ra.n, tk ? CPB_T : CPB, tk != nullptr, &grid, &reps);
-  // the launch's scalar constants, once, here (float64 divisions the kernel would otherwise repeat per thread and step)
-  MotionConst<double> hk = {};
-  motion_const_scalars<double>(hk, a);
-  const TailConst<double> tc = {a.m.dt, hk.inv_dt, 1.0 - a.m.dt / a.m.hd_tau, a.m.dt / a.m.hd_tau, a.m.hd_tau <= a.m.dt};
-  const dim3 block(64 * RIAB_S1_WAVES);
-  if (tk) {  // (non-temporal stores; TASK = task_kernel's MODE)
-    // The task step's workgroups wait for each other in both directions (the writer for the others' arrival, the others
-    // for the writer's verdict), and its 160+ registers per lane allow one workgroup per compute unit: the whole grid must
-    // be resident at once.  step1_shape keeps it to one round wherever a segment has room for a second workgroup; where
-    // it has not (more than 128 segments: 32768 agents) the plan keeps its two launches.
-    if ((int64_t)grid.x * grid.y > 2048 / RIAB_S1_WAVES) return RIAB_EUNSUPPORTED;
-    // a kernel the register allocator gave a stack frame (a few bytes of spilled scalars, never touched) would have the
-    // dispatcher set scratch memory up for every launch — more than the fusion saves: such an instantiation is not used
-    auto launch = [&](auto kernel) -> int {
-      static int frame = -1;  // (per instantiation)
-      if (frame < 0) {
-        hipFuncAttributes fa;
-        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) != hipSuccess) return RIAB_EUNSUPPORTED;
-        frame = (int)fa.localSizeBytes;
-      }
-      if (frame > 0) return RIAB_EUNSUPPORTED;
-      if (query) return RIAB_OK;
-      hipLaunchKernelGGL(kernel, grid, block, 0, s, a, ra, cell, sy, reps, hk, tc, *tk);
-      return (int)hipGetLastError();
-    };
-#define RIAB_S1_TASK(MODE)                                                                     \
-  return spikes ? launch(step1_task_kernel<Cell, 1, CPB_T, true, MODE>) : launch(step1_task_kernel<Cell, 0, CPB_T, true, MODE>)
-    switch (task_mode) {
-      case 1: RIAB_S1_TASK(1);
-      case 3: RIAB_S1_TASK(3);
-      case 5: RIAB_S1_TASK(5);
-      case 7: RIAB_S1_TASK(7);
-      default: return RIAB_EINVAL;
-    }
-#undef RIAB_S1_TASK
-  }
-  if (query) return RIAB_OK;
-  if (spikes) {
-    if (nt) hipLaunchKernelGGL((step1_kernel<Cell, 1, CPB, true>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc);
-    else hipLaunchKernelGGL((step1_kernel<Cell, 1, CPB, false>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc);
-  } else {
-    if (nt) hipLaunchKernelGGL((step1_kernel<Cell, 0, CPB, true>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc);
-    else hipLaunchKernelGGL((step1_kernel<Cell, 0, CPB, false>), grid, block, 0, s, a, ra, cell, sy, reps, hk, tc);
-  }
-  return (int)hipGetLastError();
+  return RIAB_OK;
 }
 
 // 0 when the one-launch step covers this population (the store-bound kinds whose functor needs no LDS of its own)
@@ -786,106 +855,165 @@ int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B) {
   }
 }
 
-// one Agent.update() (the arguments of riab_agent_step(T = 1), Philox noise) + the population's update() on the row it
-// writes: `rates_row` / `spikes_row` are the population's rows of this step, `step_after` the number of agent steps
-// taken once this one is done (Neurons.update's spike counter, as riab_plan_step passes it)
-static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row,
-                             uint8_t* spikes_row, uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch,
-                             bool* walls_ready, hipStream_t s, const Step1Task* tk, int task_mode, bool query = false) {
-  const int rc = step1_supported(env, pop, a.B);
-  if (rc) return rc;
-  if (a.z_in || a.z_out || a.forced || a.T != 1 || !sync_words || !rates_row || epoch == 0u) return RIAB_EINVAL;
-  if ((((uintptr_t)rates_row) & 15) || (((uintptr_t)spikes_row) & 3) || a.agent_id0 % 4) return RIAB_EALIGN;
-  RateArgs ra;
-  ra.pos_x = ra.pos_y = ra.hd_x = ra.hd_y = nullptr;  // (the row comes through LDS)
-  ra.pos_ld = 0;
-  ra.qrow = a.B / 4;
-  ra.nquads = ra.qrow;
-  ra.B = a.B;
-  ra.rates = rates_row;
-  ra.spikes = spikes_row;
-  ra.u_in = nullptr;
-  ra.dt = (float)a.m.dt;
-  ra.fr_scale = pop->io.max_fr - pop->io.min_fr;
-  ra.fr_min = pop->io.min_fr;
-  ra.k0 = (uint32_t)seed;
-  ra.k1 = (uint32_t)(seed >> 32);
-  ra.step0 = (uint32_t)step_after;
-  ra.tag = RIAB_TAG_SPIKES | ((uint32_t)pop->io.pop_id & 0xFFu);
-  ra.group0 = (uint32_t)(a.agent_id0 / 4);
-  ra.n = pop->n;
-  ra.cells_per_block = 0;
+static int step1_fill_pop(Step1Pop& q, const RiabEnv* env, const Step1PopRef& ref, bool task, int32_t group0) {
+  const RiabPopulation* pop = ref.pop;
+  if (!ref.rates_row) return RIAB_EINVAL;
+  if ((((uintptr_t)ref.rates_row) & 15) || (((uintptr_t)ref.spikes_row) & 3)) return RIAB_EALIGN;
+  q.tab = pop->table;
+  q.rates = ref.rates_row;
+  q.spikes = ref.spikes_row;
+  q.n = pop->n;
+  q.fr_scale = pop->io.max_fr - pop->io.min_fr;
+  q.fr_min = pop->io.min_fr;
+  q.p0 = q.p1 = q.p2 = 0.0f;
+  q.tag = RIAB_TAG_SPIKES | ((uint32_t)pop->io.pop_id & 0xFFu);
+  switch (pop->kind) {
+    case RIAB_POP_PLACE: {
+      int d;
+      switch (pop->description) {
+        case RIAB_PC_GAUSSIAN: d = 0; break;
+        case RIAB_PC_GAUSSIAN_THRESHOLD: d = 1; break;
+        case RIAB_PC_DIFF_OF_GAUSSIANS: d = 2; break;
+        case RIAB_PC_TOP_HAT: d = 3; break;
+        default: return RIAB_EUNSUPPORTED;
+      }
+      q.kind = S1_KIND_PC + (env->periodic ? 4 : 0) + d;
+      q.p0 = (float)env->scale;
+      q.p1 = (float)(env->scale / 2);
+      q.p2 = pop->top_hat_width * pop->top_hat_width;
+      break;
+    }
+    case RIAB_POP_GRID:
+      q.kind = S1_KIND_GC + (pop->description == RIAB_GC_RECTIFIED ? RIAB_GC_RECTIFIED : RIAB_GC_SHIFTED);
+      q.p0 = pop->f0;
+      q.p1 = pop->description == RIAB_GC_RECTIFIED ? 1.0f / (1.0f - pop->f0) : 1.0f;
+      break;
+    case RIAB_POP_HDC: q.kind = S1_KIND_HDC; break;
+    default: return RIAB_EUNSUPPORTED;
+  }
+  const int cpb = s1_cpb(q.kind, task);
+  q.group0 = group0;
+  q.n_groups = (pop->n + cpb - 1) / cpb;
+  return RIAB_OK;
+}
+
+// one Agent.update() (the arguments of riab_agent_step(T = 1), Philox noise) + the update() of `n_pops` populations on the
+// row it writes: `refs[i].rates_row` / `spikes_row` are population i's rows of this step, `step_after` the number of agent
+// steps taken once this one is done (Neurons.update's spike counter, as riab_plan_step passes it).  `n_cus`: the compute
+// units the launch can occupy (riab_plan_set_compute_units).
+static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const Step1PopRef* refs, int n_pops, uint64_t seed,
+                             uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, int n_cus, hipStream_t s,
+                             const Step1Task* tk, int task_mode, bool query = false) {
+  if (n_pops < 1 || n_pops > RIAB_STEP1_MAX_POPS || !refs) return RIAB_EINVAL;
+  for (int i = 0; i < n_pops; ++i) {
+    const int rc = step1_supported(env, refs[i].pop, a.B);
+    if (rc) return rc;
+  }
+  if (a.z_in || a.z_out || a.forced || a.T != 1 || !sync_words || epoch == 0u || n_cus < 1) return RIAB_EINVAL;
+  if (a.agent_id0 % 4) return RIAB_EALIGN;
+  Step1Pops ps = {};
+  ps.n_pops = n_pops;
+  ps.dt = (float)a.m.dt;
+  ps.k0 = (uint32_t)seed;
+  ps.k1 = (uint32_t)(seed >> 32);
+  ps.step0 = (uint32_t)step_after;
+  ps.quad0 = (uint32_t)(a.agent_id0 / 4);
+  int32_t groups = 0;
+  bool spikes = false;
+  for (int i = 0; i < n_pops; ++i) {
+    const int rc = step1_fill_pop(ps.pop[i], env, refs[i], tk != nullptr, groups);
+    if (rc) return rc;
+    groups += ps.pop[i].n_groups;
+    spikes = spikes || refs[i].spikes_row != nullptr;
+    if (ps.pop[i].kind == S1_KIND_HDC) ps.needs_hd = 1;
+  }
+  ps.total_groups = groups;
   Step1Sync sy;
   sy.words = sync_words;
   sy.epoch = epoch;
-  sy.spin_limit = 1u << 22;  // x ~0.3 us: about a second
+  sy.spin_limit = g_options[RIAB_OPT_STEP1_SPIN] ? 1u << g_options[RIAB_OPT_STEP1_SPIN] : 0u;  // x ~0.3 us: about a second by default
   sy.n_segments = (uint32_t)(a.B / 256);
   Wall<double>* const gw = reinterpret_cast<Wall<double>*>(sync_words + RIAB_STEP1_SYNC_WALLS_AT(a.B));
   sy.walls = gw;
-  if (!query && walls_ready && !*walls_ready) {  // (the plan's first one-launch step, and the first after its motion parameters changed)
-    hipLaunchKernelGGL(walls_prepare_kernel, dim3(1), dim3(64), 0, s, a, gw);
-    *walls_ready = true;
+  // the launch's scalar constants, once, here (float64 divisions the kernel would otherwise repeat per thread and step)
+  MotionConst<double> hk = {};
+  motion_const_scalars<double>(hk, a);
+  const TailConst<double> tc = {a.m.dt, hk.inv_dt, 1.0 - a.m.dt / a.m.hd_tau, a.m.dt / a.m.hd_tau, a.m.hd_tau <= a.m.dt};
+  const dim3 block(64 * RIAB_S1_WAVES);
+  const bool check = g_options[RIAB_OPT_STEP1_RESIDENCY] != 0;  // (A/B, tests: 0 = the grid of a whole, idle MI355X whatever the device)
+  dim3 grid;
+  int reps = 1;
+  auto prepare_walls = [&]() {
+    if (walls_ready && !*walls_ready) {  // (the plan's first one-launch step, and the first after its motion parameters changed)
+      hipLaunchKernelGGL(walls_prepare_kernel, dim3(1), dim3(64), 0, s, a, gw);
+      *walls_ready = true;
+    }
+  };
+  if (tk) {  // (non-temporal stores; TASK = task_kernel's MODE)
+    // The task step's workgroups wait for each other in both directions (the writer for the others' arrival, the others
+    // for the writer's verdict): the whole grid must be resident at once.  How many of its workgroups a compute unit
+    // holds (one, at 160+ registers per lane) is asked of the runtime once per instantiation; how many compute units
+    // the plan's launches can occupy is the plan's (`n_cus`: the device's count unless the caller measured fewer — a
+    // CU-masked process, a partitioned device).  Where a segment has no room for a second workgroup the plan keeps its
+    // two launches.
+    // A kernel the register allocator gave a stack frame (a few bytes of spilled scalars, never touched) would have the
+    // dispatcher set scratch memory up for every launch — more than the fusion saves: such an instantiation is not used.
+    auto launch = [&](auto kernel) -> int {
+      static int frame = -1, per_cu = 0;  // (per instantiation)
+      if (frame < 0) {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) != hipSuccess) return RIAB_EUNSUPPORTED;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64 * RIAB_S1_WAVES, 0) != hipSuccess || nb < 1) nb = 1;
+        per_cu = nb;
+        frame = (int)fa.localSizeBytes;
+      }
+      if (frame > 0) return RIAB_EUNSUPPORTED;
+      const int64_t resident = check ? (int64_t)n_cus * per_cu : 2048 / RIAB_S1_WAVES;
+      const int rc = step1_shape(a.B, groups, true, resident, &grid, &reps);
+      if (rc) return rc;
+      if ((int64_t)grid.x * grid.y > resident) return RIAB_EUNSUPPORTED;
+      if (query) return RIAB_OK;
+      prepare_walls();
+      hipLaunchKernelGGL(kernel, grid, block, 0, s, a, ps, sy, reps, hk, tc, *tk);
+      return (int)hipGetLastError();
+    };
+#define RIAB_S1_TASK(MODE) return spikes ? launch(step1_task_kernel<1, MODE>) : launch(step1_task_kernel<0, MODE>)
+    switch (task_mode) {
+      case 1: RIAB_S1_TASK(1);
+      case 3: RIAB_S1_TASK(3);
+      case 5: RIAB_S1_TASK(5);
+      case 7: RIAB_S1_TASK(7);
+      default: return RIAB_EINVAL;
+    }
+#undef RIAB_S1_TASK
   }
-  const bool spikes = spikes_row != nullptr;
+  // (no workgroup of this form waits for one that waits: nothing has to be resident together — the shape only keeps the
+  // motion step from being run more often than the device has room for)
+  step1_shape(a.B, groups, false, check ? n_cus : 2048 / RIAB_S1_WAVES, &grid, &reps);
+  if (query) return RIAB_OK;
+  prepare_walls();
   const bool nt = g_options[RIAB_OPT_FUSED_STEP] != 2;
-  switch (pop->kind) {
-    case RIAB_POP_PLACE: {
-      PlaceCell<RIAB_PC_GAUSSIAN, 0> c;
-      c.tab = pop->table;
-      c.scale = (float)env->scale;
-      c.half_scale = (float)(env->scale / 2);
-      c.top_hat_w2 = pop->top_hat_width * pop->top_hat_width;
-      c.walls = env->walls;
-      c.n_internal = 0;
-      c.e0 = env->extent[0]; c.e1 = env->extent[1]; c.e2 = env->extent[2]; c.e3 = env->extent[3];
-      c.shape = make_env_shape(env);
-      c.lds = nullptr;
-      if (env->periodic) {
-        PlaceCell<RIAB_PC_GAUSSIAN, 3> w;
-        w.tab = c.tab; w.scale = c.scale; w.half_scale = c.half_scale; w.top_hat_w2 = c.top_hat_w2; w.walls = c.walls;
-        w.n_internal = 0; w.e0 = c.e0; w.e1 = c.e1; w.e2 = c.e2; w.e3 = c.e3; w.shape = c.shape; w.lds = nullptr;
-        switch (pop->description) {
-          case RIAB_PC_GAUSSIAN: return launch_step1_cell(a, ra, w, sy, spikes, nt, s, tk, task_mode, query);
-          case RIAB_PC_GAUSSIAN_THRESHOLD: return launch_step1_cell(a, ra, w.as<RIAB_PC_GAUSSIAN_THRESHOLD>(), sy, spikes, nt, s, tk, task_mode, query);
-          case RIAB_PC_DIFF_OF_GAUSSIANS: return launch_step1_cell(a, ra, w.as<RIAB_PC_DIFF_OF_GAUSSIANS>(), sy, spikes, nt, s, tk, task_mode, query);
-          case RIAB_PC_TOP_HAT: return launch_step1_cell(a, ra, w.as<RIAB_PC_TOP_HAT>(), sy, spikes, nt, s, tk, task_mode, query);
-          default: return RIAB_EUNSUPPORTED;
-        }
-      }
-      switch (pop->description) {
-        case RIAB_PC_GAUSSIAN: return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode, query);
-        case RIAB_PC_GAUSSIAN_THRESHOLD: return launch_step1_cell(a, ra, c.as<RIAB_PC_GAUSSIAN_THRESHOLD>(), sy, spikes, nt, s, tk, task_mode, query);
-        case RIAB_PC_DIFF_OF_GAUSSIANS: return launch_step1_cell(a, ra, c.as<RIAB_PC_DIFF_OF_GAUSSIANS>(), sy, spikes, nt, s, tk, task_mode, query);
-        case RIAB_PC_TOP_HAT: return launch_step1_cell(a, ra, c.as<RIAB_PC_TOP_HAT>(), sy, spikes, nt, s, tk, task_mode, query);
-        default: return RIAB_EUNSUPPORTED;
-      }
-    }
-    case RIAB_POP_GRID:
-      if (pop->description == RIAB_GC_RECTIFIED) {
-        GridCell<RIAB_GC_RECTIFIED> c{pop->table, pop->f0, 1.0f / (1.0f - pop->f0)};
-        return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode, query);
-      } else {
-        GridCell<RIAB_GC_SHIFTED> c{pop->table, pop->f0, 1.0f};
-        return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode, query);
-      }
-    case RIAB_POP_HDC: {
-      HDCell<0> c{pop->table, 0.0f, nullptr, nullptr};
-      return launch_step1_cell(a, ra, c, sy, spikes, nt, s, tk, task_mode, query);
-    }
-    default: return RIAB_EUNSUPPORTED;
+  if (spikes) {
+    if (nt) hipLaunchKernelGGL((step1_kernel<1, true>), grid, block, 0, s, a, ps, sy, reps, hk, tc);
+    else hipLaunchKernelGGL((step1_kernel<1, false>), grid, block, 0, s, a, ps, sy, reps, hk, tc);
+  } else {
+    if (nt) hipLaunchKernelGGL((step1_kernel<0, true>), grid, block, 0, s, a, ps, sy, reps, hk, tc);
+    else hipLaunchKernelGGL((step1_kernel<0, false>), grid, block, 0, s, a, ps, sy, reps, hk, tc);
   }
+  return (int)hipGetLastError();
 }
 
-int launch_step1(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
-                 uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, hipStream_t s) {
-  return launch_step1_impl(a, env, pop, rates_row, spikes_row, seed, step_after, sync_words, epoch, walls_ready, s, nullptr, 0);
+int launch_step1(const AgentArgs& a, const RiabEnv* env, const Step1PopRef* refs, int n_pops, uint64_t seed, uint64_t step_after,
+                 uint32_t* sync_words, uint32_t epoch, bool* walls_ready, int n_cus, hipStream_t s) {
+  return launch_step1_impl(a, env, refs, n_pops, seed, step_after, sync_words, epoch, walls_ready, n_cus, s, nullptr, 0);
 }
 
 // ... + the rest of TaskEnvironment.step for the first `task_B` lanes: the arguments of launch_motion_task (riab_agent.hip),
-// whose two stages this replaces together with the lead population's launch
+// whose two stages this replaces together with the fused populations' launches
 // (`query`: nothing is launched; RIAB_OK when this plan's step has a kernel to be launched with)
-int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const RiabPopulation* pop, float* rates_row, uint8_t* spikes_row,
-                      uint64_t seed, uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, const RiabTask* task,
+int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const Step1PopRef* refs, int n_pops, uint64_t seed,
+                      uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, int n_cus, const RiabTask* task,
                       double* task_state, int64_t task_B, double t_env, double* reward_out, uint8_t* terminal_out, int32_t* diag,
                       bool auto_reset, int32_t n_select, int32_t ordered, uint64_t task_seed, uint64_t counter, int32_t teleport,
                       double* ep_log, int64_t ep_log_cap, int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y,
@@ -910,7 +1038,39 @@ int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const RiabPopulati
   tk.diag = diag;
   tk.mail = sync_words + RIAB_STEP1_SYNC_MAIL_AT(a.B);
   const int mode = 1 | (auto_reset ? 2 : 0) | (gv_x ? 4 : 0);
-  return launch_step1_impl(a, env, pop, rates_row, spikes_row, seed, step_after, sync_words, epoch, walls_ready, s, &tk, mode, query);
+  return launch_step1_impl(a, env, refs, n_pops, seed, step_after, sync_words, epoch, walls_ready, n_cus, s, &tk, mode, query);
+}
+
+// The compute units a stream's workgroups land on, counted: every one-wave workgroup of a grid that fills any device
+// several times over marks the unit it runs on (XCC_ID and HW_ID's shader engine / array / unit fields); a second, tiny
+// kernel counts the marks into scratch[RIAB_CU_PROBE_WORDS - 1].  A process whose queues carry a CU mask (HSA_CU_MASK,
+// ROC_GLOBAL_CU_MASK, a stream made with hipExtStreamCreateWithCUMask) reports the full device through
+// hipGetDeviceProperties; this does not.
+__global__ __launch_bounds__(64) void cu_probe_kernel(uint32_t* seen) {
+  unsigned id, xc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc));
+  if (threadIdx.x == 0) seen[((xc & 15u) << 8) | ((id >> 8) & 0xFFu)] = 1u;  // HW_ID [15:8]: CU_ID, SH_ID, SE_ID
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // (100 MHz: stay ~4 us, so that the grid spreads)
+  while (__builtin_amdgcn_s_memrealtime() - t0 < 400ull) __builtin_amdgcn_s_sleep(16);
+}
+__global__ __launch_bounds__(256) void cu_probe_count_kernel(uint32_t* seen) {
+  __shared__ uint32_t total;
+  if (threadIdx.x == 0) total = 0u;
+  __syncthreads();
+  uint32_t mine = 0;
+  for (int i = (int)threadIdx.x; i < RIAB_CU_PROBE_WORDS - 1; i += 256) mine += seen[i] ? 1u : 0u;
+  atomicAdd(&total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) seen[RIAB_CU_PROBE_WORDS - 1] = total;
 }
 
 }  // namespace riab
+
+extern "C" int riab_probe_compute_units(uint32_t* scratch, riab_stream_t stream) {
+  if (!scratch) return RIAB_EINVAL;
+  if (((uintptr_t)scratch) & 3) return RIAB_EALIGN;
+  hipLaunchKernelGGL(riab::cu_probe_kernel, dim3(32768), dim3(64), 0, (hipStream_t)stream, scratch);
+  hipLaunchKernelGGL(riab::cu_probe_count_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch);
+  return (int)hipGetLastError();
+}

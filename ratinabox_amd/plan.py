@@ -23,22 +23,106 @@ _L = _lib
 
 def _attach_fused(plan, agent):
     """Arrival words for the one-launch step (riab_plan_set_fused, csrc/riab_step1.hip): whole 256-agent segments
-    only; the library decides per step whether the step qualifies."""
+    only; the library decides per step whether the step qualifies.  The plan is told how many compute units this
+    process's workgroups really land on (`_lib.compute_units`: measured once per device — a CU mask or a partition is
+    invisible to hipGetDeviceProperties): the one-launch step cuts its grid to that, and a task plan whose grid would
+    not be resident at once keeps its two launches."""
     plan._sync_words = None
+    plan._fused_seen = 0      # one-launch steps the plan had taken when its give-up counter was last looked at
     if agent._Bp % 256 == 0 and not _L.env("RIAB_NO_FUSED_STEP"):
         n = _L.step1_sync_words(agent._Bp)
         plan._sync_words = torch.zeros(n + 256, dtype=torch.int32, device=agent._device)   # (+ slack: tools/step1_profile.py)
         _L.check(_L.lib.riab_plan_set_fused(plan._h, _L.ptr(plan._sync_words), n), "riab_plan_set_fused")
+        _L.check(_L.lib.riab_plan_set_compute_units(plan._h, _L.compute_units(agent._device_index)),
+                 "riab_plan_set_compute_units")
 
 
-def _check_fused(plan):
-    """A workgroup of the one-launch step that gave up waiting — a writer for its segment's arrival words, or (task
-    plans) another workgroup for the writer's verdict on this step's resets; must never happen."""
+_FUSABLE = ("PlaceCells", "GridCells", "HeadDirectionCells")   # (what csrc/riab_step1.hip step1_supported admits)
+
+
+def _settle_fused(plan):
+    """A workgroup of the one-launch step that gave up waiting (bounded spins, ~1 s: a writer for its segment's arrival
+    words, or — task plans — another workgroup for the writer's verdict on this step's resets; a device shared with
+    something that kept part of the grid off it for that long).  Looked at wherever the host reads results anyway (the
+    first read after the steps synchronises) and when the plan closes.
+
+    What such a step leaves wrong is RATES only: a writer works the new state out from its own loads and waits for the
+    others only before it STORES; nobody but a writer stores state, history or task rows; a workgroup that comes late
+    may read a state, an action or a position that is already the next step's, and writes its tile of the populations'
+    rows from that.  The kernel remembers the first and the last step a wait gave up in: the fused populations' rows of
+    those steps are recomputed here from the agent's history rows with the populations' own kernels — what the
+    two-launch step runs, hence the bits it would have written — counted (`Agent.diagnostics["step1_recovered_steps"]`),
+    one warning.  What cannot be redone raises as before: rows whose agent row is gone (no agent history kept)."""
     w = getattr(plan, "_sync_words", None)
-    if w is not None and plan._h and _L.lib.riab_plan_info(plan._h, 0) > 0:
-        if int(w[_L.step1_sync_tail(plan.agent._Bp) + _L.STEP1_SYNC_TIMEOUTS].item()):
-            raise _L.RiabError("one-launch step: a workgroup gave up waiting for its segment's other workgroups; "
-                               "the agent state / the rates of that step are not trustworthy")
+    if w is None or not plan._h:
+        return
+    fused = int(_L.lib.riab_plan_info(plan._h, 0))
+    if fused == plan._fused_seen:
+        return
+    plan._fused_seen = fused
+    ag = plan.agent
+    tail = _L.step1_sync_tail(ag._Bp)
+    t = w[tail:tail + 3].cpu().numpy().astype(np.int64) & 0xFFFFFFFF     # (waits for the steps)
+    n = int(t[_L.STEP1_SYNC_TIMEOUTS])
+    if not n:
+        return
+    first, last = int(t[_L.STEP1_SYNC_FIRST_BAD]), int(t[_L.STEP1_SYNC_LAST_BAD])
+    torch.cuda.synchronize(ag._device)
+    w[tail:tail + 3] = 0
+    plan.sync()
+    now = int(ag._step_index)
+    if not (0 < first <= last <= now) or last - first >= 1 << 16:
+        raise _L.RiabError(f"one-launch step: {n} waits gave up in steps {first}..{last} (now {now}): not a range this plan took")
+    stream = _L.current_stream()
+    redone = 0
+    for s in range(first, last + 1):
+        back = now - s                       # rows from the newest one
+        if ag.save_history:
+            k = len(ag._times) - 1 - back
+            row = ag._hist.row(k) if k >= 0 else None
+            t_s = ag._times[k] if k >= 0 else None
+        else:
+            row, t_s = (ag._last_row if back == 0 else None), None
+        for N in plan.neurons:
+            if N.__class__.__name__ not in _FUSABLE or N.noise_std != 0:
+                continue
+            if N.save_history:
+                if row is None:
+                    raise _L.RiabError(f"one-launch step: a wait gave up in step {s} and the agent's row of that step is "
+                                       "not kept (save_history=False): the population's row cannot be recomputed")
+                kp = None if t_s is None else next((j for j in range(len(N._times) - 1, max(-1, len(N._times) - 3 - back), -1)
+                                                    if N._times[j] == t_s), None)
+                if kp is None:
+                    if back == 0 and hasattr(plan, "discard_ahead"):
+                        plan.discard_ahead()   # (written ahead, its update() not called yet: that call recomputes it)
+                    continue
+                fr = N._hist_fr.row(kp)
+                sp = N._hist_sp.row(kp) if N.save_spikes else None
+            elif back == 0 and row is not None:
+                fr, sp = N._rates, None
+            else:
+                continue                     # (a population without history: only its newest row exists)
+            N._launch(row[_L.H_POS_X], row[_L.H_POS_Y], row[N._H_DIR[0]], row[N._H_DIR[1]], pos_ld=ag._Bp, T=1, B=ag._Bp,
+                      rates=fr.unsqueeze(0), spikes=None if sp is None else sp.unsqueeze(0), u_in=None, dt=float(ag.dt),
+                      step0=s, stream=stream)
+            redone += 1
+    torch.cuda.synchronize(ag._device)
+    ag._step1_timeouts += n
+    ag._step1_recovered_steps += last - first + 1
+    if not getattr(ag, "_step1_warned", False):
+        ag._step1_warned = True
+        import warnings
+        warnings.warn(f"one-launch step: {n} waits of its workgroups gave up in steps {first}..{last} (something kept part "
+                      f"of the grid off the device for about a second); {redone} rows of the fused populations were "
+                      "recomputed from the agent's history rows with the populations' own kernels "
+                      "(diagnostics['step1_recovered_steps'])", RuntimeWarning)
+
+
+def _plan_info(h):
+    f = _L.lib.riab_plan_info
+    pops = [int(f(h, 8 + k)) for k in range(_L.STEP1_MAX_POPS)]
+    return {"fused_steps": int(f(h, 0)), "fused_population": int(f(h, 1)), "launches": int(f(h, 2)),
+            "fused_enabled": bool(f(h, 3)), "fused_populations": [i for i in pops if i >= 0], "compute_units": int(f(h, 5))}
 
 
 class _ForcedRows:
@@ -286,16 +370,18 @@ class StepPlan:
             self.agent._plan = None
         if self._h:
             try:
-                _check_fused(self)
+                _settle_fused(self)
             finally:
                 _L.lib.riab_plan_destroy(self._h)
                 self._h = None
 
+    def settle(self):
+        """Look at the one-launch step's give-up counter; recover (see _settle_fused)."""
+        _settle_fused(self)
+
     def info(self):
         """Launch accounting of the native plan (riab_plan_info)."""
-        f = _L.lib.riab_plan_info
-        return {"fused_steps": int(f(self._h, 0)), "fused_population": int(f(self._h, 1)), "launches": int(f(self._h, 2)),
-                "fused_enabled": bool(f(self._h, 3))}
+        return _plan_info(self._h)
 
     def __del__(self):
         try:
@@ -316,9 +402,13 @@ class AutoStepper:
     After `Agent.AUTO_AFTER` consecutive plain `Agent.update()` calls (no arguments) the Agent records itself and
     its populations in a native plan and serves the following plain `update()` calls — its own and its
     populations' — from it: the per-call host work drops from ~15 us (parameter resolution, struct filling, history
-    bookkeeping) to one ctypes transition and a staleness check.  The calls keep their meaning: every call launches
-    its own kernel at the time of the call, on the same rows, with the same arguments and RNG counters as the eager
-    path, so results are bit-identical; any call that is not plain (kwargs, drift, another dt), any host edit of the
+    bookkeeping) to one ctypes transition and a staleness check.  The calls keep their meaning: the same rows, arguments
+    and RNG counters as the eager path, so results are bit-identical.  With the one-launch step (csrc/riab_step1.hip)
+    `Agent.update()` launches ONE kernel that also writes this step's rows of the store-bound populations that keep a
+    history (PlaceCells / GridCells / HeadDirectionCells without noise) — rows that are not yet part of the history — and
+    each such population's `update()` only publishes its row; a population that keeps no history (its single row IS what
+    `firingrate` shows until its own update()) always launches its own kernel at the time of its call, as do the
+    populations the loop does not update after every agent step.  Any call that is not plain (kwargs, drift, another dt), any host edit of the
     agent state, `simulate()`, `reset_history()` or an explicit step plan closes the stepper and the eager path
     takes over (and re-engages later).  Attribute edits are caught by value: the motion parameters, the wall table
     and each population's tables are compared with what the plan was built from on every call.
@@ -550,15 +640,16 @@ class AutoStepper:
             ag._auto_after = ag.AUTO_AFTER
         if self._h:
             try:
-                _check_fused(self)
+                _settle_fused(self)
             finally:
                 _L.lib.riab_plan_destroy(self._h)
                 self._h = None
 
+    def settle(self):
+        _settle_fused(self)
+
     def info(self):
-        f = _L.lib.riab_plan_info
-        return {"fused_steps": int(f(self._h, 0)), "fused_population": int(f(self._h, 1)), "launches": int(f(self._h, 2)),
-                "fused_enabled": bool(f(self._h, 3))}
+        return _plan_info(self._h)
 
     def __del__(self):
         try:

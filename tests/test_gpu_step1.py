@@ -120,10 +120,10 @@ def test_one_launch_step_rates_match_the_oracle_on_its_own_rows(riab):
         np.testing.assert_allclose(out["fr0"][t][:, :512], ref, rtol=1e-5, atol=1e-30)
 
 
-def test_lead_population_is_the_largest_store_bound_one_and_the_others_follow(riab):
-    """Several populations: the agent step is fused with the largest covered one, every other population is launched
-    after it in list order (a FeedForwardLayer reads the lead's fresh row); populations the kernel does not cover
-    (line-of-sight place cells, additive noise) never lead."""
+def test_store_bound_populations_ride_in_the_launch_and_the_others_follow(riab):
+    """Several populations: every covered one rides in the agent step's launch, every other population is launched
+    after it in list order (a FeedForwardLayer reads the fused populations' fresh rows); populations the kernel does not
+    cover (line-of-sight place cells, additive noise, boundary vector cells) never do."""
     def make(riab):
         np.random.seed(5)
         env = riab.Environment({"walls": [[[0.5, 0.0], [0.5, 0.35]]]})
@@ -139,8 +139,59 @@ def test_lead_population_is_the_largest_store_bound_one_and_the_others_follow(ri
         return env, ag, pops
     a, ia = _plan_run(riab, True, make, 20, drift_from=8, capacity=7)   # (chunk rollovers in the middle)
     b, ib = _plan_run(riab, False, make, 20, drift_from=8, capacity=7)
-    assert ia["fused_population"] == 2 and ia["fused_steps"] == 20, ia
-    assert ia["launches"] == ib["launches"] - 20, (ia, ib)            # exactly one kernel less per step
+    assert ia["fused_populations"] == [1, 2] and ia["fused_steps"] == 20, ia
+    assert ia["launches"] == ib["launches"] - 2 * 20, (ia, ib)        # exactly two kernels less per step
+    _same(a, b)
+
+
+@pytest.mark.parametrize("batch", [1, 5])
+def test_cfg5_mix_is_one_launch_plus_the_boundary_vector_cells(riab, batch):
+    """BASELINE configs[4]'s mix (Place + Grid + BVC + HeadDirection cells with Poisson spikes; reference loop:
+    tests/test_advanced.py:159-176 updates every population after every agent step), at a small size: the three
+    store-bound populations are written by the agent step's kernel — their cell groups one after the other on the
+    grid's cell axis, ragged last groups included —, the boundary vector cells follow: two kernels per step.  Every
+    rate and spike against the kernel-by-kernel plan, bit for bit; the PlaceCells' rows against the oracle."""
+    def make(riab):
+        np.random.seed(31)
+        env = riab.Environment()
+        ag = riab.Agent(env, {"n_agents": 1024, "dt": 0.01, "seed": 77})
+        np.random.seed(32)
+        pops = [riab.PlaceCells(ag, {"n": 203, "wall_geometry": "euclidean", "save_spikes": True, "max_fr": 30}),
+                riab.GridCells(ag, {"n": 101, "save_spikes": True, "max_fr": 30}),
+                riab.BoundaryVectorCells(ag, {"n": 24, "save_spikes": True, "max_fr": 30}),
+                riab.HeadDirectionCells(ag, {"n": 37, "save_spikes": True, "max_fr": 30})]
+        return env, ag, pops
+    steps = 30
+    a, ia = _plan_run(riab, True, make, steps, drift_from=17, capacity=16, batch=batch)
+    b, ib = _plan_run(riab, False, make, steps, drift_from=17, capacity=16, batch=batch)
+    assert ia["fused_populations"] == [0, 1, 3] and ia["fused_steps"] == steps, ia
+    assert ia["launches"] == 2 * steps and ib["launches"] == 5 * steps, (ia, ib)
+    _same(a, b)
+    assert a["sp0"].any() and a["sp1"].any() and a["sp3"].any()
+    env, ag, pops = make(riab)
+    for t in (0, steps - 1):
+        pos = np.stack((a["traj"][t, 0, :1024], a["traj"][t, 1, :1024]), -1).astype(np.float64)
+        np.testing.assert_allclose(a["fr0"][t][:, :1024], 30 * orc.place_cells(orc.EnvSpec(), pos, pops[0].place_cell_centres, 0.2),
+                                   rtol=1e-5, atol=1e-30)
+
+
+def test_more_store_bound_populations_than_the_launch_has_room_for(riab):
+    """Five covered populations: the four that write most ride in the launch (list order kept), the smallest follows as
+    its own kernel."""
+    def make(riab):
+        np.random.seed(41)
+        env = riab.Environment({"boundary_conditions": "periodic"})
+        ag = riab.Agent(env, {"n_agents": 256, "dt": 0.02, "seed": 5})
+        np.random.seed(42)
+        pops = [riab.GridCells(ag, {"n": 40, "description": "shifted_cosines"}),
+                riab.HeadDirectionCells(ag, {"n": 6}),
+                riab.PlaceCells(ag, {"n": 90, "description": "gaussian_threshold"}),
+                riab.PlaceCells(ag, {"n": 50, "description": "top_hat", "save_spikes": True, "max_fr": 40}),
+                riab.GridCells(ag, {"n": 20})]
+        return env, ag, pops
+    a, ia = _plan_run(riab, True, make, 15)
+    b, ib = _plan_run(riab, False, make, 15)
+    assert ia["fused_populations"] == [0, 2, 3, 4] and ia["launches"] == 2 * 15 and ib["launches"] == 6 * 15, (ia, ib)
     _same(a, b)
 
 

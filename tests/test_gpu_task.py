@@ -601,7 +601,8 @@ def test_one_launch_task_step_with_other_populations_and_batches(riab, batch):
     a, ep_a, d_a, info_a = run(True)
     b, ep_b, d_b, info_b = run(False)
     steps = T // batch * batch
-    assert info_a["fused_steps"] == steps and info_a["fused_population"] == 1, info_a    # (the PlaceCells: most bytes per row)
+    assert info_a["fused_steps"] == steps and info_a["fused_populations"] == [0, 1, 3], info_a  # (all but the boundary vector cells)
+    assert info_a["launches"] == 2 * steps, info_a
     assert info_b["fused_steps"] == 0
     assert a.keys() == b.keys()
     for k in a:
