@@ -33,7 +33,7 @@ int launch_motion_world(const AgentArgs& ma, const RiabEnv* env, const RiabTask*
 // the one-launch step (riab_step1.hip)
 int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
 int launch_step1(const AgentArgs& a, const RiabEnv* env, const Step1PopRef* refs, int n_pops, uint64_t seed, uint64_t step_after,
-                 uint32_t* sync_words, uint32_t epoch, bool* walls_ready, int n_cus, hipStream_t s);
+                 uint32_t* sync_words, uint32_t epoch, bool* walls_ready, int n_cus, hipStream_t s, bool query);
 int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const Step1PopRef* refs, int n_pops, uint64_t seed,
                       uint64_t step_after, uint32_t* sync_words, uint32_t epoch, bool* walls_ready, int n_cus, const RiabTask* task,
                       double* task_state, int64_t task_B, double t_env, double* reward_out, uint8_t* terminal_out, int32_t* diag,
@@ -96,6 +96,8 @@ struct RiabPlan {
   uint64_t pre_step;
   std::vector<int> pre_misses;    // per population, in a row
 };
+
+static int fused_agent_step(RiabPlan* p, float* row, hipStream_t s, bool need_free_row, uint32_t* mask, bool query);
 
 // this step's rows of the plan's fused populations (split: those whose chunk has a free row); returns how many
 static int fused_refs(const RiabPlan* p, riab::Step1PopRef* refs, uint32_t* mask, bool need_free_row) {
@@ -195,7 +197,10 @@ static int plan_fused(RiabPlan* p, bool whole_step = false) {
     }
     p->fused_n = n;
     for (int k = 0; k < n; ++k) p->fused[k] = cand[k];
-    if (n > 0 && p->has_task && fused_task_step(p, p->row_scratch, nullptr, true) != RIAB_OK) p->fused_n = 0;
+    uint32_t mask;  // (is there a kernel and a grid for it on this device?)
+    if (n > 0 && (p->has_task ? fused_task_step(p, p->row_scratch, nullptr, true)
+                              : fused_agent_step(p, p->row_scratch, nullptr, false, &mask, true)) != RIAB_OK)
+      p->fused_n = 0;
   }
   return p->fused_n;
 }
@@ -207,7 +212,8 @@ static bool is_fused(const RiabPlan* p, int index) {
 
 // Agent.update() + the fused populations' update() of the same step as one kernel; cursors are the caller's business.
 // `mask`: which of the fused populations took part (split entry points: the ones with a free row).
-static int fused_agent_step(RiabPlan* p, float* row, hipStream_t s, bool need_free_row, uint32_t* mask) {
+// (`query`: nothing is launched; RIAB_OK when there is a kernel and a grid for this plan's step)
+static int fused_agent_step(RiabPlan* p, float* row, hipStream_t s, bool need_free_row, uint32_t* mask, bool query) {
   riab::Step1PopRef refs[RIAB_STEP1_MAX_POPS];
   const int n = fused_refs(p, refs, mask, need_free_row);
   if (n == 0) return RIAB_EUNSUPPORTED;
@@ -215,10 +221,14 @@ static int fused_agent_step(RiabPlan* p, float* row, hipStream_t s, bool need_fr
   int rc = riab::fill_agent_args(ma, &p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr,
                                  p->seed, p->step, 1, row, p->diag);
   if (rc) return rc;
-  p->epoch += 1u;
-  if (p->epoch == 0u) p->epoch = 1u;
-  rc = riab::launch_step1(ma, &p->env, refs, n, p->seed, p->step + 1, p->sync_words, p->epoch, &p->walls_ready, p->n_cus, s);
-  if (rc == RIAB_OK) {
+  uint32_t epoch = 1u;
+  if (!query) {
+    p->epoch += 1u;
+    if (p->epoch == 0u) p->epoch = 1u;
+    epoch = p->epoch;
+  }
+  rc = riab::launch_step1(ma, &p->env, refs, n, p->seed, p->step + 1, p->sync_words, epoch, &p->walls_ready, p->n_cus, s, query);
+  if (rc == RIAB_OK && !query) {
     p->fused_steps += 1;
     p->launches += 1;
   }
@@ -526,7 +536,7 @@ extern "C" int riab_plan_step_agent(RiabPlan* p, riab_stream_t stream) {
   }
   if (plan_fused(p) > 0) {
     uint32_t mask = 0u;
-    const int rc = fused_agent_step(p, row, (hipStream_t)stream, true, &mask);
+    const int rc = fused_agent_step(p, row, (hipStream_t)stream, true, &mask, false);
     if (rc == RIAB_OK) {
       p->step += 1;
       if (p->hist_base) p->hist_fill += 1;
@@ -596,7 +606,7 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
     float* row = p->hist_base ? p->hist_base + p->hist_fill * (int64_t)RIAB_HIST_ROWS * p->B : p->row_scratch;
     if (n_fused > 0 && !p->has_task) {  // Agent.update() and the fused populations' update() in one launch, the others after it
       uint32_t mask;
-      int rc = fused_agent_step(p, row, s, false, &mask);
+      int rc = fused_agent_step(p, row, s, false, &mask, false);
       if (rc) return rc;
       p->step += 1;
       if (p->hist_base) p->hist_fill += 1;
@@ -660,6 +670,7 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
         rc = riab_task_goal_vector(&p->env, &p->task, p->task_state, pos_x, pos_y, p->task_B, p->scripted_speed, act,
                                    act + p->B, s);
         if (rc) return rc;
+        p->launches += 1;
       }
     }
     const bool fused = p->has_task && riab::g_options[RIAB_OPT_FUSED_TASK] != 0;  // (A/B: 0 = motion and task launched separately)
@@ -692,6 +703,7 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
                                     p->ep_log_cap, p->ep_count, p->scripted_speed, scripted ? act : nullptr,
                                     scripted ? act + p->B : nullptr, s);
       if (rc) return rc;
+      p->launches += 1;
       p->action_ready = scripted;
     } else {
     const double* forced = p->forced ? p->forced + p->forced_fill * 2 * p->B : nullptr;
@@ -711,6 +723,7 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
                                    row + (int64_t)RIAB_H_POS_Y * p->B, p->ep_log, p->ep_log_cap, p->ep_count,
                                    p->scripted_speed, scripted ? act : nullptr, scripted ? act + p->B : nullptr, s);
       if (rc) return rc;
+      p->launches += 1;
       p->action_ready = scripted;
     }
     }

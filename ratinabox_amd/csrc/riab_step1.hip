@@ -182,6 +182,9 @@ struct Step1Task {
 #ifndef RIAB_S1_WAVES_PER_EU
 #define RIAB_S1_WAVES_PER_EU 2
 #endif
+#ifndef RIAB_S1_STAGE
+#define RIAB_S1_STAGE 8  // cell groups per wave, at most (the parameters of all but the first wait in LDS: 14 KB, a workgroup stays below 64 KB of LDS)
+#endif
 #define RIAB_S1_WAVES 8  // waves per workgroup: 0-3 advance the 256 agents, 4-7 draw their normals, all of them write rates
 // one cell group of population `q` (functor `Cell`, CPB cells) for the lane's quad of agents: rate_kernel_wide's inner
 // loop.  `cur`: the group's parameters, one per lane (s1_group_params); `store`: the lanes that write their values.
@@ -222,7 +225,8 @@ __device__ __forceinline__ void s1_group(const Cell& cell, const Step1Pops& ps, 
 }
 
 // ... switched into by the population's functor id (wave-uniform)
-template <int SPK, bool NT, bool TASK>
+// (KIND >= 0: the functor is known when the kernel is compiled — the plan's only population is of that kind)
+template <int SPK, bool NT, bool TASK, int KIND>
 __device__ __forceinline__ void s1_group_any(const Step1Pops& ps, const Step1Pop& q, const int gl, const float cur, const v4f rx,
                                              const v4f ry, const v4f rhx, const v4f rhy, const int64_t B, const uint32_t quad,
                                              const bool store) {
@@ -234,7 +238,7 @@ __device__ __forceinline__ void s1_group_any(const Step1Pops& ps, const Step1Pop
     s1_group<PlaceCell<DESC, GX>, S1Cpb<PlaceCell<DESC, GX>, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, rhx, rhy, B, quad, store); \
     break;                                                                                                              \
   }
-  switch (q.kind) {
+  switch (KIND >= 0 ? KIND : q.kind) {
     RIAB_S1_PC(RIAB_PC_GAUSSIAN, 0, 0)
     RIAB_S1_PC(RIAB_PC_GAUSSIAN_THRESHOLD, 0, 1)
     RIAB_S1_PC(RIAB_PC_DIFF_OF_GAUSSIANS, 0, 2)
@@ -255,24 +259,30 @@ __device__ __forceinline__ void s1_group_any(const Step1Pops& ps, const Step1Pop
     }
     default: {
       const HDCell<0> c{q.tab, 0.0f, nullptr, nullptr};
-      s1_group<HDCell<0>, S1Cpb<HDCell<0>, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, rhx, rhy, B, quad, store);
+      // (the head direction's normalisation — square roots, divisions — is loop-invariant and free of side effects: left
+      // alone, the compiler hoists it in front of the switch, where every wave of every population pays for it)
+      v4f hx = rhx, hy = rhy;
+      asm volatile("" : "+v"(hx.x), "+v"(hx.y), "+v"(hx.z), "+v"(hx.w), "+v"(hy.x), "+v"(hy.y), "+v"(hy.z), "+v"(hy.w));
+      s1_group<HDCell<0>, S1Cpb<HDCell<0>, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, hx, hy, B, quad, store);
       break;
     }
   }
 #undef RIAB_S1_PC
 }
 
-template <int SPK, bool NT, int TASK>
+template <int SPK, bool NT, int TASK, int KIND>
 __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& ps, const Step1Sync& sy,
                                            const int reps, const MotionConst<double>& hk, const TailConst<double>& tail_c,
                                            const Step1Task& tk) {
   RIAB_EXACT_FP
+  constexpr bool MULTI = KIND < 0;  // (several populations, or one of a kind without a kernel of its own)
   constexpr int NT_ = 64 * RIAB_S1_WAVES;
   __shared__ Wall<double> s_w[RIAB_MAX_WALLS];
   __shared__ double s_g[RIAB_G_SEGS * RIAB_G_STRIDE];
   __shared__ double s_h[RIAB_H_SEGS * RIAB_H_STRIDE];
   __shared__ __align__(16) float s_row[4][256];  // x, y, head direction x, y of the segment's agents as the history keeps them
   __shared__ float s_z[2][256];                  // the step's two standard normals per agent (drawn by waves 4-7)
+  __shared__ float s_par[RIAB_S1_WAVES][RIAB_S1_STAGE][64];  // each wave's cell groups' parameters, one per lane and group
   __shared__ double s_goals[TASK ? RIAB_TASK_MAX_POOL * RIAB_GOAL_COLS : 1];  // the task's goal pool (writer)
   // (writer) what its noise-drawing waves work out for the lanes' books while the movers move: the reward cache's update
   // (rewards alive, their total) and what a reset of the lane would draw (position, next episode's goals)
@@ -333,20 +343,65 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
   // this wave's first cell group (task: the writer has none, the cell groups are dealt to the workgroups y >= 1)
   const bool rates_here = !(TASK && writer);
   const int g0 = (int)((blockIdx.y - (TASK ? 1u : 0u)) * (uint32_t)RIAB_S1_WAVES + (uint32_t)wave) * reps;
-  auto pop_of = [&](int g) -> int {  // (wave-uniform) the population the global cell group g belongs to
+  // (wave-uniform) the population the global cell group g belongs to, and its record.  The records are read at STATIC
+  // offsets of the argument block — population 0's with the kernel's other arguments, a later one's only by a wave that
+  // has a group of it: a record picked by a computed index is fetched field by field, every field a scalar-memory round
+  // trip of its own at its first use (a microsecond in front of the first store when tried).
+  auto pop_of = [&](int g) -> int {
     int pi = 0;
+    if (MULTI) {
 #pragma unroll
-    for (int k = 1; k < RIAB_STEP1_MAX_POPS; ++k) pi += (k < ps.n_pops && g >= ps.pop[k].group0) ? 1 : 0;
+      for (int k = 1; k < RIAB_STEP1_MAX_POPS; ++k) pi += (k < ps.n_pops && g >= ps.pop[k].group0) ? 1 : 0;
+    }
     return pi;
   };
-  auto group_params = [&](int g) -> float {  // group g's parameters, one per lane
-    if (g >= ps.total_groups) return 0.0f;
-    const Step1Pop& q = ps.pop[pop_of(g)];
-    const int np = s1_np(q.kind), width = np * s1_cpb(q.kind, TASK != 0);
-    const int pi = (g - q.group0) * width + lane;
-    return (lane < width && pi < q.n * np) ? q.tab[pi] : 0.0f;
+  auto pick = [&](int pi) -> Step1Pop {  // (field by field: a record copied as a whole is given a home in scratch memory)
+    pi = __builtin_amdgcn_readfirstlane(pi);
+    Step1Pop q;
+    // (MULTI = false, one population — the closed loop of BASELINE configs[1] —: its record comes with the kernel's other
+    // arguments at entry; a pick among several is a second scalar-memory round trip, in front of the parameter loads at
+    // the top and in front of the first store after the motion step: 0.7 us per step when that was the only path — and
+    // a run-time test of n_pops does not help: the compiler turns it into the same select of addresses)
+#define RIAB_S1_FIELDS(F) F(tab) F(rates) F(spikes) F(n) F(kind) F(group0) F(n_groups) F(fr_scale) F(fr_min) F(p0) F(p1) F(p2) F(tag)
+    // (every field passes through a scalar register of its own: neighbouring fields copied together become a block copy
+    // into a private array, which the compiler then gives a home in LDS or scratch memory)
+#define RIAB_S1_FIELD0(f) { auto v_ = ps.pop[0].f; asm("" : "+s"(v_)); q.f = v_; }
+#define RIAB_S1_FIELD(f) { auto v_ = pi == 1 ? ps.pop[1].f : pi == 2 ? ps.pop[2].f : pi == 3 ? ps.pop[3].f : ps.pop[0].f; asm("" : "+s"(v_)); q.f = v_; }
+    if (!MULTI) {
+      RIAB_S1_FIELDS(RIAB_S1_FIELD0)
+    } else {
+      RIAB_S1_FIELDS(RIAB_S1_FIELD)
+    }
+#undef RIAB_S1_FIELD
+#undef RIAB_S1_FIELD0
+#undef RIAB_S1_FIELDS
+    static_assert(RIAB_STEP1_MAX_POPS == 4, "pick() spells the records out");
+    return q;
   };
-  float mine = rates_here ? group_params(g0) : 0.0f;
+  auto group_params = [&](const Step1Pop& q, int g) -> float {  // group g (of population q)'s parameters, one per lane
+    const int kind = KIND >= 0 ? KIND : q.kind;
+    const int np = s1_np(kind), width = np * s1_cpb(kind, TASK != 0);
+    const int pi = (g - q.group0) * width + lane;
+    return (g < ps.total_groups && lane < width && pi < q.n * np) ? q.tab[pi] : 0.0f;
+  };
+  // Every group's parameters come with the state, a whole motion step ahead of their use, and wait in LDS: a load issued
+  // between two groups' stores would have to be waited for with the one counter loads and stores share — in effect a
+  // drain of the wave's stores per group, and of the writer's before its write-back.  (step1_shape keeps reps within the
+  // staging's rows.)
+  // (without a task the first group's stay in a register, as they always did — most plans have one group per wave —; a
+  // task's step, whose rate workgroups may run their pass twice, measured faster with every group's in LDS)
+  constexpr bool MINE_REG = TASK == 0;
+  const int pi0 = pop_of(g0);
+  float mine = 0.0f;
+  if (rates_here) {
+    int pi = pi0;
+    Step1Pop q = pick(pi);
+    if (MINE_REG) mine = group_params(q, g0);
+    for (int r = MINE_REG ? 1 : 0; r < reps; ++r) {
+      if (MULTI && g0 + r >= q.group0 + q.n_groups && pi + 1 < ps.n_pops) q = pick(++pi);  // (a population has at least one group)
+      s_par[wave][r][lane] = group_params(q, g0 + r);
+    }
+  }
   stage_rayleigh_tables<NT_>(s_g, s_h, tid);
   for (int i = tid; i < a.n_walls * (int)(sizeof(Wall<double>) / sizeof(double)); i += NT_)
     reinterpret_cast<double*>(s_w)[i] = reinterpret_cast<const double*>(sy.walls)[i];
@@ -663,24 +718,27 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
 
   // ---- Neurons.update of the population: this wave's cell groups for the segment's 256 agents ----------------------
   // (`store`: the lanes that write their quad's values — all of them, but for the pass that follows a reset, below)
-  auto rates_pass = [&](const v4f rx, const v4f ry, float params, const bool store) __attribute__((always_inline)) {
+  auto rates_pass = [&](const v4f rx, const v4f ry, const bool store) __attribute__((always_inline)) {
     v4f rhx = {0.0f, 0.0f, 0.0f, 0.0f}, rhy = rhx;
     if (ps.needs_hd) {
       rhx = *reinterpret_cast<const v4f*>(&s_row[2][4 * lane]);
       rhy = *reinterpret_cast<const v4f*>(&s_row[3][4 * lane]);
     }
     const uint32_t quad = blockIdx.x * 64u + (uint32_t)lane;  // the lane's quad of agents within the row
+    float params = MINE_REG ? mine : s_par[wave][0][lane];
+    int pi = pi0;
+    Step1Pop q = pick(pi);
     for (int r = 0; r < reps; ++r) {
       const int g = g0 + r;
       if (g >= ps.total_groups) break;  // wave-uniform
       const float cur = params;
-      if (r + 1 < reps) params = group_params(g + 1);  // (requested before this group's stores are issued)
-      const Step1Pop& q = ps.pop[pop_of(g)];
-      s1_group_any<SPK, NT, TASK != 0>(ps, q, g - q.group0, cur, rx, ry, rhx, rhy, B, quad, store);
+      if (r + 1 < reps) params = s_par[wave][r + 1][lane];  // (asked for before this group's stores are issued)
+      if (MULTI && g >= q.group0 + q.n_groups && pi + 1 < ps.n_pops) q = pick(++pi);
+      s1_group_any<SPK, NT, TASK != 0, KIND>(ps, q, g - q.group0, cur, rx, ry, rhx, rhy, B, quad, store);
     }
   };
   if (rates_here)
-    rates_pass(*reinterpret_cast<const v4f*>(&s_row[0][4 * lane]), *reinterpret_cast<const v4f*>(&s_row[1][4 * lane]), mine, true);
+    rates_pass(*reinterpret_cast<const v4f*>(&s_row[0][4 * lane]), *reinterpret_cast<const v4f*>(&s_row[1][4 * lane]), true);
   RIAB_S1_STAMP(3)
 #ifdef RIAB_STEP1_PROFILE
   if (prof_slot >= 0) {
@@ -690,9 +748,12 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
 #endif
   // (a wave whose groups are all HeadDirectionCells' writes nothing a reset can change: no wait at all)
   bool wave_needs_pos = false;
-  if (TASK && !writer)
-    for (int r = 0; r < reps; ++r)
-      if (g0 + r < ps.total_groups) wave_needs_pos = wave_needs_pos || ps.pop[pop_of(g0 + r)].kind != S1_KIND_HDC;
+  if (TASK && !writer) {
+#pragma unroll
+    for (int k = 0; k < (MULTI ? RIAB_STEP1_MAX_POPS : 1); ++k)  // (a population other than HeadDirectionCells with a group in this wave's range)
+      wave_needs_pos = wave_needs_pos || (k < ps.n_pops && ps.pop[k].kind != S1_KIND_HDC && ps.pop[k].group0 < g0 + reps &&
+                                          ps.pop[k].group0 + ps.pop[k].n_groups > g0);
+  }
   if (TASK && !writer && wave_needs_pos && !(RIAB_S1_TASK_DROP & 8)) {
     // ---- did a reset move one of the segment's agents?  The writer's 4 x 6 verdict entries of this launch: one round
     // trip (they are usually there by now) says that they are posted, which agents moved and where (almost all of) them went.
@@ -782,7 +843,7 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
       // same instructions, hence the same bits as the population's own kernel gives on the patched history row — on
       // the row with the new positions in, stored by the lanes whose quad changed
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the values this wave stored for those quads a moment ago are in place)
-      rates_pass(rx, ry, reps == 1 ? mine : group_params(g0), mine_moved);  // (one group per wave: its parameters are still here)
+      rates_pass(rx, ry, mine_moved);
     }
     RIAB_S1_STAMP(12)
     if (stale && lane == 0) step1_note_timeout(sy, ps.step0);
@@ -798,22 +859,22 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
 #endif
 }
 
-template <int SPK, bool NT>
+template <int SPK, bool NT, int KIND>
 __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_kernel(const AgentArgs a, const Step1Pops ps,
                                                                                            const Step1Sync sy, const int reps,
                                                                                            const MotionConst<double> hk,
                                                                                            const TailConst<double> tail_c) {
   const Step1Task none = {};
-  step1_body<SPK, NT, 0>(a, ps, sy, reps, hk, tail_c, none);
+  step1_body<SPK, NT, 0, KIND>(a, ps, sy, reps, hk, tail_c, none);
 }
 
-template <int SPK, int TASK>
+template <int SPK, int TASK, int KIND>
 __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_task_kernel(const AgentArgs a, const Step1Pops ps,
                                                                                                 const Step1Sync sy, const int reps,
                                                                                                 const MotionConst<double> hk,
                                                                                                 const TailConst<double> tail_c,
                                                                                                 const Step1Task tk) {
-  step1_body<SPK, true, TASK>(a, ps, sy, reps, hk, tail_c, tk);
+  step1_body<SPK, true, TASK, KIND>(a, ps, sy, reps, hk, tail_c, tk);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
@@ -833,6 +894,7 @@ static int step1_shape(int64_t B, int64_t groups, bool task, int64_t resident, d
   }
   int64_t r = (groups + RIAB_S1_WAVES * want_y - 1) / (RIAB_S1_WAVES * want_y);
   if (r < 1) r = 1;
+  if (r > RIAB_S1_STAGE) return RIAB_EUNSUPPORTED;  // (a device this much smaller than the problem: kernel by kernel)
   const int64_t gy = (groups + RIAB_S1_WAVES * r - 1) / (RIAB_S1_WAVES * r);
   *reps = (int)r;
   *grid = dim3((unsigned)segs, (unsigned)(gy + (task ? 1 : 0)), 1);
@@ -940,6 +1002,12 @@ static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const Step1
   motion_const_scalars<double>(hk, a);
   const TailConst<double> tc = {a.m.dt, hk.inv_dt, 1.0 - a.m.dt / a.m.hd_tau, a.m.dt / a.m.hd_tau, a.m.hd_tau <= a.m.dt};
   const dim3 block(64 * RIAB_S1_WAVES);
+  // the plan's only population, gaussian PlaceCells in a solid room (BASELINE configs[1]'s closed loop): the kernel compiled
+  // for that functor, its record read at static offsets of the argument block; everything else: the generic kernel
+#ifndef RIAB_S1_FORCE_GENERIC
+#define RIAB_S1_FORCE_GENERIC 0
+#endif
+  const bool multi = n_pops > 1 || ps.pop[0].kind != S1_KIND_PC || RIAB_S1_FORCE_GENERIC;
   const bool check = g_options[RIAB_OPT_STEP1_RESIDENCY] != 0;  // (A/B, tests: 0 = the grid of a whole, idle MI355X whatever the device)
   dim3 grid;
   int reps = 1;
@@ -978,7 +1046,9 @@ static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const Step1
       hipLaunchKernelGGL(kernel, grid, block, 0, s, a, ps, sy, reps, hk, tc, *tk);
       return (int)hipGetLastError();
     };
-#define RIAB_S1_TASK(MODE) return spikes ? launch(step1_task_kernel<1, MODE>) : launch(step1_task_kernel<0, MODE>)
+#define RIAB_S1_TASK(MODE)                                                                                      \
+  return multi ? (spikes ? launch(step1_task_kernel<1, MODE, -1>) : launch(step1_task_kernel<0, MODE, -1>)) \
+               : (spikes ? launch(step1_task_kernel<1, MODE, 0>) : launch(step1_task_kernel<0, MODE, 0>))
     switch (task_mode) {
       case 1: RIAB_S1_TASK(1);
       case 3: RIAB_S1_TASK(3);
@@ -990,23 +1060,26 @@ static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const Step1
   }
   // (no workgroup of this form waits for one that waits: nothing has to be resident together — the shape only keeps the
   // motion step from being run more often than the device has room for)
-  step1_shape(a.B, groups, false, check ? n_cus : 2048 / RIAB_S1_WAVES, &grid, &reps);
+  const int rc_shape = step1_shape(a.B, groups, false, check ? n_cus : 2048 / RIAB_S1_WAVES, &grid, &reps);
+  if (rc_shape) return rc_shape;
   if (query) return RIAB_OK;
   prepare_walls();
   const bool nt = g_options[RIAB_OPT_FUSED_STEP] != 2;
+#define RIAB_S1_PLAIN(SPK, NT)                                                                              \
+  if (multi) hipLaunchKernelGGL((step1_kernel<SPK, NT, -1>), grid, block, 0, s, a, ps, sy, reps, hk, tc); \
+  else hipLaunchKernelGGL((step1_kernel<SPK, NT, 0>), grid, block, 0, s, a, ps, sy, reps, hk, tc)
   if (spikes) {
-    if (nt) hipLaunchKernelGGL((step1_kernel<1, true>), grid, block, 0, s, a, ps, sy, reps, hk, tc);
-    else hipLaunchKernelGGL((step1_kernel<1, false>), grid, block, 0, s, a, ps, sy, reps, hk, tc);
+    if (nt) { RIAB_S1_PLAIN(1, true); } else { RIAB_S1_PLAIN(1, false); }
   } else {
-    if (nt) hipLaunchKernelGGL((step1_kernel<0, true>), grid, block, 0, s, a, ps, sy, reps, hk, tc);
-    else hipLaunchKernelGGL((step1_kernel<0, false>), grid, block, 0, s, a, ps, sy, reps, hk, tc);
+    if (nt) { RIAB_S1_PLAIN(0, true); } else { RIAB_S1_PLAIN(0, false); }
   }
+#undef RIAB_S1_PLAIN
   return (int)hipGetLastError();
 }
 
 int launch_step1(const AgentArgs& a, const RiabEnv* env, const Step1PopRef* refs, int n_pops, uint64_t seed, uint64_t step_after,
-                 uint32_t* sync_words, uint32_t epoch, bool* walls_ready, int n_cus, hipStream_t s) {
-  return launch_step1_impl(a, env, refs, n_pops, seed, step_after, sync_words, epoch, walls_ready, n_cus, s, nullptr, 0);
+                 uint32_t* sync_words, uint32_t epoch, bool* walls_ready, int n_cus, hipStream_t s, bool query) {
+  return launch_step1_impl(a, env, refs, n_pops, seed, step_after, sync_words, epoch, walls_ready, n_cus, s, nullptr, 0, query);
 }
 
 // ... + the rest of TaskEnvironment.step for the first `task_B` lanes: the arguments of launch_motion_task (riab_agent.hip),
