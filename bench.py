@@ -69,6 +69,10 @@ CONFIGS = {
                  walls=[[[.2, 0], [.2, .4]], [[.4, 1], [.4, .6]], [[.6, 0], [.6, .4]], [[.8, 1], [.8, .6]],
                         [[.3, .5], [.7, .5]]],
                  desc="4096 agents x (1024 GridCells + 256 BVCs), 5 interior walls (BASELINE configs[2])"),
+    # cfg 3 in a wall-heavy room: a comb maze of 60 interior segments (RIAB_MAX_WALLS = 64 with the room's four): VERDICT
+    # r5 #5 — what the float64 wall loop of the motion step and stage A of the boundary vector cells cost at N_w = 64
+    "cfg3_64w": dict(agents=4096, place=0, grid=1024, bvc=256, hdc=0, spikes=False, walls="comb60",
+                     desc="4096 agents x (1024 GridCells + 256 BVCs), 60 interior walls (a comb maze: 64 wall segments)"),
     "cfg5": dict(agents=8192, place=1024, grid=512, bvc=256, hdc=256, walls=[], spikes=True,
                  desc="8192 agents/GPU x 2048 mixed cells with Poisson spikes (BASELINE configs[4] per-GPU shard)"),
 }
@@ -87,9 +91,27 @@ def bytes_per_agent_step(cfg):
     return 4 * n + (n if cfg["spikes"] else 0) + 112
 
 
+def comb_walls(n=60):
+    """n interior wall segments: teeth of two interleaved combs (from the floor and from the ceiling), every tooth in two
+    collinear pieces with a doorway — a room whose every position has several walls within the repel distance."""
+    walls, teeth = [], n // 2
+    for i in range(teeth):
+        x = (i + 1) / (teeth + 1)
+        if i % 2 == 0:   # from the floor: [0, 0.3] and [0.4, 0.7]
+            walls += [[[x, 0.0], [x, 0.3]], [[x, 0.4], [x, 0.7]]]
+        else:            # from the ceiling: [1, 0.7] and [0.6, 0.3]
+            walls += [[[x, 1.0], [x, 0.7]], [[x, 0.6], [x, 0.3]]]
+    return walls[:n]
+
+
+def resolve(cfg):
+    return dict(cfg, walls=comb_walls(60)) if cfg["walls"] == "comb60" else cfg
+
+
 def build_world(riab, cfg, rank, seed=1234, task=False, one_world=False):
     import numpy as np
     np.random.seed(1000 + rank)
+    cfg = resolve(cfg)
     if task:  # the same world inside a goal-directed task (closed loop: contribs/TaskEnvironment.py)
         from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
         # (one_world: the rank's agents share ONE task — the reference's multi-agent environment, agentmode="interact":
@@ -345,7 +367,7 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
     import numpy as np
     import torch
     import ratinabox_amd as riab
-    cfg = dict(CONFIGS[config])
+    cfg = resolve(dict(CONFIGS[config]))
     if args.strong and world > 1:   # (a fixed batch over more GPUs is launch-bound; labelled "strong")
         per = cfg["agents"] // world // 256 * 256
         if per <= 0:
@@ -367,6 +389,8 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
         ag.save_history = False
         for p in pops:
             p.save_history = False
+    if getattr(args, "strict", False):
+        ag.pipeline_mode(strict=True)
     B = cfg["agents"]
     R = repeats or max(3, min(20, 4096 // max(K, 1)))
     # the chunked two-stream path (several populations): about four chunks in flight for short runs so that the
@@ -721,6 +745,8 @@ def measure(args, config, K, W, repeats, rank, world, local, dist, ctrl_on_cpu, 
                if fused_mode else "simulate(): trajectory kernel + every population's kernels per chunk of rows behind gates, "
                "one native call (riab_simulate)" if native_mode
                else f"simulate(): chunked two-stream pipeline, {chunk} steps/launch")
+        if getattr(args, "strict", False) and native:
+            api += " — STRICT mode (riab_hip.h 'Two modes': nothing allocated / synchronised / queried / process-wide; the started gate always)"
         out = {
             "metric": metric_name(cfg),
             "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -780,6 +806,8 @@ def main():
     ap.add_argument("--task-world", action="store_true",
                     help="as --task, but each rank's agents share ONE task world (TaskEnvironment(lanes='agents'): the "
                          "reference's multi-agent environment with agentmode='interact')")
+    ap.add_argument("--strict", action="store_true",
+                    help="simulate() in the mode of riab_simulate that meets SURVEY 8(b2) to the letter (include/riab_hip.h 'Two modes')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: the config's agents are the TOTAL, split over the ranks (default: weak scaling, "
@@ -908,26 +936,35 @@ def main():
         # its TaskEnvironment.step, contribs/TaskEnvironment.py:361-453): an explicit step plan (one native call per
         # step), the unchanged `Ag.update(); PCs.update()` loop, a task plan (every agent its own replica of the task; all
         # agents of the rank in ONE task world) — 256 steps after 32, five repeats each
+        # ... the closed loops of cfg 3 / cfg 5 as well (the loop of the reference's tests/test_advanced.py:159-176: every
+        # population updated after every agent step; the store-bound populations ride in the agent step's launch, the
+        # boundary vector cells follow: two kernels per step), the headline workload in STRICT mode (what meeting SURVEY
+        # 8(b2) to the letter costs: at the driver's length and at 1024 steps), and cfg 3 in a room of 64 walls
         runs = [("cfg2_T1024", "cfg2", 128, None)] + ([("cfg3", "cfg3", 32, None)] if world == 1 else []) + \
             [("cfg4", "cfg4", 32, None), ("cfg5", "cfg5", 32, None),
              ("cfg2_closed_loop_plan", "cfg2", 32, "plan"), ("cfg2_closed_loop_per_step", "cfg2", 32, "per_step"),
-             ("cfg2_closed_loop_task", "cfg2", 32, "task"), ("cfg2_closed_loop_task_world", "cfg2", 32, "task_world")]
+             ("cfg2_closed_loop_task", "cfg2", 32, "task"), ("cfg2_closed_loop_task_world", "cfg2", 32, "task_world")] + \
+            ([("cfg3_closed_loop_plan", "cfg3", 32, "plan"), ("cfg5_closed_loop_plan", "cfg5", 32, "plan"),
+              ("cfg2_strict", "cfg2", args.warmup, "strict"), ("cfg2_strict_T1024", "cfg2", 128, "strict1024"),
+              ("cfg3_64w", "cfg3_64w", 32, None), ("cfg3_64w_closed_loop_plan", "cfg3_64w", 32, "plan")] if world == 1 else [])
         for key, name, warm, mode in runs:
             if key == "cfg2_T1024" and args.steps == SECONDARY_STEPS:
                 continue   # (the headline run IS that run)
             args.no_history = False
             args.plan, args.per_step = mode in ("plan", "task", "task_world"), mode == "per_step"
             args.task, args.task_world = mode in ("task", "task_world"), mode == "task_world"
+            args.strict = mode in ("strict", "strict1024")
             state["running"] = key
             t0 = time.perf_counter()
             try:
-                o, c = measure(args, name, 256 if mode else sec_steps, warm, 5, rank, world, local, dist,
+                steps_here = args.steps if mode == "strict" else 256 if mode in ("plan", "per_step", "task", "task_world") else sec_steps
+                o, c = measure(args, name, steps_here, warm, 0 if mode == "strict" else 5, rank, world, local, dist,
                                ctrl_on_cpu if dist is not None else False, control_plane, store_ceiling=False)
             except Exception as e:  # noqa: BLE001  (the headline line must not be lost to a secondary run)
                 secondary[key] = {"error": f"{type(e).__name__}: {e}"}
                 continue
             finally:
-                args.plan = args.per_step = args.task = args.task_world = False
+                args.plan = args.per_step = args.task = args.task_world = args.strict = False
             torch.cuda.empty_cache()   # (tens of GB of history per configuration: give them back before the next one)
             if o is None:
                 continue

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
       const int ci = min(4 * g + qi, n - 1);
       const int c = a.rows ? a.rows[ci] : ci;
       const uint64_t gid = (uint64_t)(a.agent_id0 + b);
-      blk = philox4x32_10(a.step0 + (uint32_t)t, (uint32_t)c, (uint32_t)(gid >> 2), a.tag, a.k0, a.k1);
+      blk = philox4x32_spikes(a.step0 + (uint32_t)t, (uint32_t)c, (uint32_t)(gid >> 2), a.tag, a.k0, a.k1);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

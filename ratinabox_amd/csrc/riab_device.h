@@ -33,10 +33,11 @@ struct u32x4 {
 // Philox4x32-10 (Salmon et al., SC'11).  32x32->64 products map to
 // v_mad_u64_u32 on gfx950.  Counter-based: no state, any (step, cell, agent)
 // can be regenerated on the host (oracle/riab_oracle.py: philox4x32_10).
-__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                               uint32_t k0, uint32_t k1) {
+template <int ROUNDS>
+__device__ __forceinline__ u32x4 philox4x32_r(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -48,6 +49,16 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     k1 += 0xBB67AE85u;
   }
   return {c0, c1, c2, c3};
+}
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  return philox4x32_r<10>(c0, c1, c2, c3, k0, k1);
+}
+// The spike streams: Philox4x32-7 — the smallest round count the generator's authors found to pass BigCrush (SC'11, table
+// 2; 10 is their default with a safety margin).  One call per (cell, four agents) in the epilogue of kernels that are
+// otherwise bound by their stores: at ten rounds the generator was two thirds of the epilogue's instructions and took a
+// PlaceCells kernel from 6.5 to 4.3 TB/s (round 6).  oracle/riab_oracle.py: spike_uniforms restates it.
+__device__ __forceinline__ u32x4 philox4x32_spikes(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  return philox4x32_r<7>(c0, c1, c2, c3, k0, k1);
 }
 
 // Read-only, wave-uniform tables: a pointer in the constant address space tells the compiler the

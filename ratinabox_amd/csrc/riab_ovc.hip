@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void ovc_kernel(const OvcArgs a) {
           u = a.u_in[off];
         } else {
           const uint64_t gid = (uint64_t)(a.agent_id0 + b);
-          const u32x4 w4 = philox4x32_10(a.step0 + (uint32_t)t, (uint32_t)c, (uint32_t)(gid >> 2), a.tag, a.k0, a.k1);
+          const u32x4 w4 = philox4x32_spikes(a.step0 + (uint32_t)t, (uint32_t)c, (uint32_t)(gid >> 2), a.tag, a.k0, a.k1);
           const uint32_t jj = (uint32_t)gid & 3u;
           u = u01_24(jj == 0 ? w4.x : (jj == 1 ? w4.y : (jj == 2 ? w4.z : w4.w)));
         }

@@ -68,7 +68,7 @@ __device__ __forceinline__ void spike_store(const RateArgs& a, v4f r, int64_t of
   if (EXPLICIT_U) {
     u = ldv4(a.u_in + off);
   } else {
-    const u32x4 w = philox4x32_10(step, c, group, a.tag, a.k0, a.k1);
+    const u32x4 w = philox4x32_spikes(step, c, group, a.tag, a.k0, a.k1);
     u = v4f{u01_24(w.x), u01_24(w.y), u01_24(w.z), u01_24(w.w)};
   }
   // one fp32 multiply, one fp32 compare: the exactly-specified spike rule

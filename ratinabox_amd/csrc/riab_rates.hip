@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void noise_kernel(float* noise, float* rates, 
     if (z_in) {
       z = ldv4(z_in + t * row + off);
     } else {
-      const u32x4 w = philox4x32_10(step0 + (uint32_t)t, (uint32_t)c, group0 + (uint32_t)q, tag, k0, k1);
+      const u32x4 w = philox4x32_spikes(step0 + (uint32_t)t, (uint32_t)c, group0 + (uint32_t)q, tag, k0, k1);
       // two Box-Muller pairs in fp32
       const float u0 = ((float)(w.x >> 8) + 0.5f) * 0x1.0p-24f, u1 = (float)(w.y >> 8) * 0x1.0p-24f;
       const float u2 = ((float)(w.z >> 8) + 0.5f) * 0x1.0p-24f, u3 = (float)(w.w >> 8) * 0x1.0p-24f;

@@ -1192,16 +1192,62 @@ def make_helpers():
     np.savez_compressed(os.path.join(HERE, "helpers.npz"), **out)
 
 
+def comb_walls(n=60):
+    """bench.py's wall-heavy room (cfg3_64w): n interior segments, the teeth of two interleaved combs with doorways."""
+    walls, teeth = [], n // 2
+    for i in range(teeth):
+        x = (i + 1) / (teeth + 1)
+        if i % 2 == 0:
+            walls += [[[x, 0.0], [x, 0.3]], [[x, 0.4], [x, 0.7]]]
+        else:
+            walls += [[[x, 1.0], [x, 0.7]], [[x, 0.6], [x, 0.3]]]
+    return walls[:n]
+
+
+def make_walls64():
+    """A room at RIAB_MAX_WALLS (60 interior segments + the box's four): motion steps — every position has
+    several walls within the repel distance, collisions are frequent —, boundary vector cells over 64 walls, line-of-sight
+    PlaceCells over 60 internal walls."""
+    _section("64 walls")
+    comb = comb_walls(60)
+    motion_records("comb60_dt10ms", {"walls": comb}, {"dt": 0.01}, 16, 250, seed=31)
+    motion_records("comb60_fast", {"walls": comb}, {"dt": 0.05, "speed_mean": 0.3, "thigmotaxis": 0.8}, 16, 150, seed=32)
+    np.random.seed(33)
+    out = {"walls": np.array(comb, float)}
+    rs = np.random.RandomState(34)
+    pos = np.stack((rs.uniform(0, 1, 128), rs.uniform(0, 1, 128)), -1)
+    pos[:16, 0] = np.round(pos[:16, 0] * 31) / 31 + rs.choice([-1e-3, 1e-3], 16)   # next to a tooth
+    pos[:, 0] = np.clip(pos[:, 0], 1e-3, 1 - 1e-3)
+    pos = f32exact(pos)
+    out["pos"] = pos
+    Env = Environment({"walls": comb})
+    Ag = Agent(Env)
+    assert len(Env.walls) == 64
+    B = BoundaryVectorCells(Ag, {"n": 24, "min_fr": 0.0, "max_fr": 1.0})
+    for k in ["tuning_distances", "tuning_angles", "sigma_distances", "sigma_angles", "cell_fr_norm"]:
+        out[f"bvc_{k}"] = np.array(getattr(B, k), float)
+    out["bvc_rates"] = B.get_state(evaluate_at=None, pos=pos)
+    PCs = PlaceCells(Ag, {"n": 40, "widths": 0.12, "wall_geometry": "line_of_sight"})
+    PCs.place_cell_centres = f32exact(PCs.place_cell_centres)
+    out["pc_los_centres"] = PCs.place_cell_centres
+    out["pc_los_rates"] = PCs.get_state(evaluate_at=None, pos=pos)
+    out["ref_walls"] = np.array(Env.walls, float)
+    out["vectors_from_walls"] = np.array([Env.vectors_from_walls(p) for p in pos[:32]])
+    np.savez_compressed(os.path.join(HERE, "walls64.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task", "task_world", "polygon", "cfg1", "stats", "helpers"]
+    which = sys.argv[1:] or ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task", "task_world", "polygon", "cfg1", "stats", "helpers", "walls64"]
     if "--out" in which:  # write somewhere else (tools/check_golden.py regenerates into a temporary directory)
         HERE = which[which.index("--out") + 1]
         which = [w for i, w in enumerate(which) if w != "--out" and (i == 0 or which[i - 1] != "--out")] or \
             ["motion", "rates", "update", "imported", "feedforward", "ovc", "avc", "velocity", "env", "random_spatial", "task",
-             "task_world", "polygon", "cfg1", "stats", "helpers"]
+             "task_world", "polygon", "cfg1", "stats", "helpers", "walls64"]
         os.makedirs(HERE, exist_ok=True)
     if "helpers" in which:
         make_helpers()
+    if "walls64" in which:
+        make_walls64()
     if "polygon" in which:
         make_polygon()
     if "cfg1" in which:

@@ -133,6 +133,28 @@ def test_bvc_allocentric_vs_reference(riab, tag):
     assert_rates(got, g[f"bvc_{tag}_rates"], floor=1.0)
 
 
+def test_sixty_four_walls_vs_reference(riab):
+    """a room at RIAB_MAX_WALLS — 60 interior segments of a comb maze + the box (reference fixture
+    walls64.npz): boundary vector cells over 64 walls, line-of-sight PlaceCells over 60 internal walls; one wall more is
+    refused.  (Its motion steps: motion_comb60_*.npz in test_motion_single_steps_vs_reference.)"""
+    g = gu.load("walls64.npz")
+    env = make_env(riab, g["walls"])
+    np.testing.assert_array_equal(np.asarray(env.walls, float), g["ref_walls"])
+    Ag = riab.Agent(env)
+    B = riab.BoundaryVectorCells(Ag, dict(tuning_distance=list(g["bvc_tuning_distances"]),
+                                          tuning_angle=list(np.degrees(g["bvc_tuning_angles"])),
+                                          sigma_distance=list(g["bvc_sigma_distances"]),
+                                          sigma_angle=list(np.degrees(g["bvc_sigma_angles"]))))
+    np.testing.assert_allclose(B.cell_fr_norm, g["bvc_cell_fr_norm"], rtol=1e-12)
+    assert_rates(B.get_state(evaluate_at=None, pos=g["pos"]), g["bvc_rates"], floor=1.0)
+    PCs = riab.PlaceCells(Ag, {"n": 40, "widths": 0.12, "wall_geometry": "line_of_sight",
+                               "place_cell_centres": g["pc_los_centres"]})
+    assert_rates(PCs.get_state(evaluate_at=None, pos=g["pos"]), g["pc_los_rates"])
+    with pytest.raises(Exception):
+        env.add_wall([[0.5, 0.45], [0.6, 0.45]])
+        riab.Agent(env).update()
+
+
 def test_bvc_egocentric_vs_reference(riab):
     g = gu.load("rates.npz")
     Ag = riab.Agent(make_env(riab, g["maze_walls"][4:]))

@@ -546,7 +546,8 @@ def test_one_launch_task_step_equals_the_two_launch_plan(riab, case):
 
     a, ep_a, d_a, ad_a, t_a, info_a = run(True)
     b, ep_b, d_b, ad_b, t_b, info_b = run(False)
-    assert info_a["fused_steps"] == T and info_a["launches"] == T, info_a      # one kernel per closed-loop step
+    # one kernel per closed-loop step (+ the launch that works out the plan's FIRST scripted action)
+    assert info_a["fused_steps"] == T and info_a["launches"] == T + int(scripted), info_a
     assert info_b["fused_steps"] == 0
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
@@ -602,7 +603,7 @@ def test_one_launch_task_step_with_other_populations_and_batches(riab, batch):
     b, ep_b, d_b, info_b = run(False)
     steps = T // batch * batch
     assert info_a["fused_steps"] == steps and info_a["fused_populations"] == [0, 1, 3], info_a  # (all but the boundary vector cells)
-    assert info_a["launches"] == 2 * steps, info_a
+    assert info_a["launches"] == 2 * steps + 1, info_a   # (+ the launch that works out the plan's first scripted action)
     assert info_b["fused_steps"] == 0
     assert a.keys() == b.keys()
     for k in a:

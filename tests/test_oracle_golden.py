@@ -107,6 +107,21 @@ def test_bvc_allocentric(tag):
     np.testing.assert_allclose(got, g[f"bvc_{tag}_rates"], rtol=1e-10, atol=1e-14)
 
 
+def test_sixty_four_walls():
+    """A room at RIAB_MAX_WALLS (tests/golden/make_golden.py make_walls64: a comb maze of 60 interior segments): boundary
+    vector cells, line-of-sight PlaceCells and the wall vectors of the oracle against the reference.  (The motion steps of
+    the same room are motion_comb60_*.npz: test_motion_single_steps / rollouts pick them up by name.)"""
+    g = gu.load("walls64.npz")
+    env = orc.EnvSpec(walls=g["walls"])
+    np.testing.assert_array_equal(env.walls, g["ref_walls"])
+    assert len(env.walls) == 64
+    got = orc.bvc(g["pos"], env.walls, g["bvc_tuning_distances"], g["bvc_tuning_angles"], g["bvc_sigma_distances"],
+                  g["bvc_sigma_angles"])
+    np.testing.assert_allclose(got, g["bvc_rates"], rtol=1e-10, atol=1e-14)
+    got = orc.place_cells(env, g["pos"], g["pc_los_centres"], 0.12, wall_geometry="line_of_sight")
+    np.testing.assert_allclose(got, g["pc_los_rates"], rtol=1e-11, atol=1e-13)
+
+
 def test_bvc_egocentric():
     g = _rates()
     got = orc.bvc(g["pos"][:48], g["maze_walls"], g["bvc_ego_tuning_distances"], g["bvc_ego_tuning_angles"],
