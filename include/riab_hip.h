@@ -490,6 +490,7 @@ int riab_plan_discard_ahead(RiabPlan* plan);
 #define RIAB_STEP1_SYNC_TIMEOUTS 0
 #define RIAB_STEP1_SYNC_FIRST_BAD 1  /* the first / last step a wait gave up in, as "agent steps taken once it was done" (0: none) */
 #define RIAB_STEP1_SYNC_LAST_BAD 2
+#define RIAB_STEP1_SYNC_FATAL 3      /* give-ups after which the STATE is not trustworthy (one-world task plans only: a writer that never saw the world's verdict) */
 #define RIAB_STEP1_SYNC_WALLS_AT(B) ((((B) + 255) / 256) * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_TAIL)
 #define RIAB_STEP1_SYNC_MAIL_AT(B) (RIAB_STEP1_SYNC_WALLS_AT(B) + 12 * RIAB_MAX_WALLS + 4)
 #define RIAB_STEP1_MAIL_STRIDE 1088  /* per segment, 8-byte entries (epoch << 32 | value): (at 0) 4 x 8 verdict entries = per mover wave its lane mask in halves and its first two movers' x, y; (at 64) x[256], y[256] */

@@ -122,7 +122,7 @@ CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_SERIALISED, CTRL_STAMPS, CTRL_TRAJ
 
 
 STEP1_SYNC_STRIDE, STEP1_SYNC_TAIL, STEP1_SYNC_TIMEOUTS = 64, 16, 0   # riab_hip.h RIAB_STEP1_SYNC_*
-STEP1_SYNC_FIRST_BAD, STEP1_SYNC_LAST_BAD = 1, 2
+STEP1_SYNC_FIRST_BAD, STEP1_SYNC_LAST_BAD, STEP1_SYNC_FATAL = 1, 2, 3
 STEP1_MAX_POPS = 4                                                      # csrc/riab_device.h RIAB_STEP1_MAX_POPS
 CU_PROBE_WORDS = 4097                                                   # riab_hip.h RIAB_CU_PROBE_WORDS
 STEP1_MAIL_STRIDE = 1088                                                # riab_hip.h RIAB_STEP1_MAIL_STRIDE

@@ -39,7 +39,7 @@ int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const Step1PopRef*
                       double* task_state, int64_t task_B, double t_env, double* reward_out, uint8_t* terminal_out, int32_t* diag,
                       bool auto_reset, int32_t n_select, int32_t ordered, uint64_t task_seed, uint64_t counter, int32_t teleport,
                       double* ep_log, int64_t ep_log_cap, int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y,
-                      hipStream_t s, bool query);
+                      double* world, uint64_t* world_met, int32_t* world_cand, int32_t* world_ctl, hipStream_t s, bool query);
 }  // namespace riab
 
 struct RiabPlan {
@@ -143,7 +143,7 @@ static int fused_task_step(RiabPlan* p, float* row, hipStream_t s, bool query) {
                                &p->task, p->task_state, p->task_B, p->t_env, p->reward_out, p->terminal_out, p->task_diag,
                                p->auto_reset != 0, p->n_select, p->ordered, p->task_seed, p->reset_counter, p->teleport, p->ep_log,
                                p->ep_log_cap, p->ep_count, p->scripted_speed, scripted ? act : nullptr,
-                               scripted ? act + p->B : nullptr, s, query);
+                               scripted ? act + p->B : nullptr, p->world, p->world_met, p->world_cand, p->world_ctl, s, query);
   if (rc == RIAB_OK && !query) {
     p->fused_steps += 1;
     p->launches += 1;
@@ -160,7 +160,6 @@ static int fused_task_step(RiabPlan* p, float* row, hipStream_t s, bool query) {
 static int plan_fused(RiabPlan* p, bool whole_step = false) {
   if (!p->sync_words || riab::g_options[RIAB_OPT_FUSED_STEP] == 0 || p->forced) return 0;
   if (p->has_task && (!whole_step || riab::g_options[RIAB_OPT_FUSED_TASK] == 0)) return 0;
-  if (p->has_task && p->world) return 0;  // (the world's step is a launch of its own)
   if (p->fused_n == -2 || p->fused_whole != whole_step) {
     p->fused_whole = whole_step;
     p->pre_misses.resize(p->pops.size(), 0);
@@ -633,6 +632,23 @@ extern "C" int riab_plan_step(RiabPlan* p, int32_t n_steps, riab_stream_t stream
           if (rc) return rc;
           p->launches += 1;
         }
+      }
+      if (n_fused > 0) {  // Agent.update, the world's step, its reset when the episode ended, the next action and the fused
+        p->step += 1;     // populations' update(): ONE kernel (riab_step1.hip, TASK & 8)
+        if (p->hist_base) p->hist_fill += 1;
+        p->t_env += p->dt_env;
+        if (p->auto_reset) p->reset_counter += 1;
+        rc = fused_task_step(p, row, s, false);
+        if (rc) return rc;
+        p->action_ready = scripted;
+        for (size_t i = 0; i < p->pops.size(); ++i) {
+          if (!is_fused(p, (int)i)) {
+            rc = launch_population(p, i, row, s);
+            if (rc) return rc;
+          }
+          if (p->pops[i].capacity_rows > 0) p->pop_fill[i] += 1;
+        }
+        continue;
       }
       riab::AgentArgs ma;  // Agent.update and the world's step in one launch
       rc = riab::fill_agent_args(ma, &p->env, &p->motion, p->state, p->B, p->agent_id0, p->drift, nullptr, nullptr, nullptr,

@@ -32,7 +32,7 @@
 // DESIGN.md 3.9, docs/EXPERIMENTS.md r05.
 #include "riab_agent_kernel.h"
 #include "riab_rate_cells.h"
-#include "riab_task_kernel.h"  // (last: it turns fp contraction off for its own code)
+#include "riab_task_world_kernel.h"  // (last: riab_task_kernel.h, which it includes, turns fp contraction off for its own code)
 
 namespace riab {
 
@@ -152,6 +152,11 @@ struct Step1Task {
   double* gv_y;
   int32_t* diag;
   uint32_t* mail;  // [segments][RIAB_STEP1_MAIL_STRIDE]
+  // the lanes are the agents of ONE world (TASK & 8; riab_task_world.hip): its shared state, the step's scratch
+  double* world;
+  uint64_t* met;
+  int32_t* cand;
+  int32_t* ctl;
 };
 
 // tools/step1_profile.py (a -DRIAB_STEP1_PROFILE build): three workgroups — the first writer, its segment's second
@@ -283,15 +288,19 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
   __shared__ __align__(16) float s_row[4][256];  // x, y, head direction x, y of the segment's agents as the history keeps them
   __shared__ float s_z[2][256];                  // the step's two standard normals per agent (drawn by waves 4-7)
   __shared__ float s_par[RIAB_S1_WAVES][RIAB_S1_STAGE][64];  // each wave's cell groups' parameters, one per lane and group
+  // TASK & 8: the lanes are the agents of ONE world (the writers keep the world's books, below); otherwise every lane is
+  // its own replica of the task.  RT / WT: the mode bits of the one or the other (0: not that kind of task)
+  constexpr int RT = (TASK & 8) ? 0 : TASK, WT = (TASK & 8) ? (TASK & 7) : 0;
+  __shared__ WorldShared s_world;
   __shared__ double s_goals[TASK ? RIAB_TASK_MAX_POOL * RIAB_GOAL_COLS : 1];  // the task's goal pool (writer)
   // (writer) what its noise-drawing waves work out for the lanes' books while the movers move: the reward cache's update
   // (rewards alive, their total) and what a reset of the lane would draw (position, next episode's goals)
-  __shared__ double s_rw_total[TASK ? 256 : 1];
-  __shared__ int s_rw_n[TASK ? 256 : 1];
-  __shared__ double s_draw_xy[2][(TASK & 6) ? 256 : 1];
-  __shared__ unsigned long long s_draw_list[2][(TASK & 6) ? 256 : 1];
+  __shared__ double s_rw_total[RT ? 256 : 1];
+  __shared__ int s_rw_n[RT ? 256 : 1];
+  __shared__ double s_draw_xy[2][(RT & 6) ? 256 : 1];
+  __shared__ unsigned long long s_draw_list[2][(RT & 6) ? 256 : 1];
   // ... and, the same arrays later, what the movers hand BACK for the next action (TASK & 4): the lane's list and position
-  __shared__ int s_fin_n[(TASK & 4) ? 256 : 1];
+  __shared__ int s_fin_n[(RT & 4) ? 256 : 1];
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -329,14 +338,25 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
   // are the helper waves' (4-7, idle once the normals are drawn), lane for lane beside the movers' second half; the
   // movers keep what needs the new position — the goal checks, the reset itself, the next action.
   // (dealing the lanes to all eight waves, 32 each, was tried: no faster — docs/EXPERIMENTS.md r05-5)
-  const bool tlive = TASK && writer && mover && b < tk.a.B;
-  const bool hlive = TASK && writer && !mover && b < tk.a.B;
+  const bool tlive = RT && writer && mover && b < tk.a.B;
+  const bool hlive = RT && writer && !mover && b < tk.a.B;
+  const bool wlive = WT && writer && mover && b < tk.a.B;  // (one world: a mover lane keeps its agent's books)
   LaneIn tin;
   RewardsIn trin;
+  WorldLaneIn win;
+  double w_pad_start0 = 0.0;
+  uint8_t w_terminal_prev = 0;
   if (TASK) {
-    if (tlive) tin = task_lane_load<TASK & ~RIAB_S1_TASK_DROP>(tk.a, b);  // (TM, declared below)
-    if (hlive && (TASK & 1)) trin = load_rewards_in(tk.a, b);
+    if (tlive) tin = task_lane_load<RT & ~RIAB_S1_TASK_DROP>(tk.a, b);  // (TM, declared below)
+    if (hlive && (RT & 1)) trin = load_rewards_in(tk.a, b);
     if (writer) task_stage_goals(tk.a, s_goals, tid, NT_);
+    if (WT && writer) {  // the world's list as this step finds it, the lane's reward rows: one batch with the state
+      if (tid < RIAB_TASK_MAX_GOALS) s_world.list[tid] = (uint8_t)((int)tk.world[RIAB_TW_GOAL_LIST + tid] & 0xFF);
+      if (tid == 0) s_world.n = (int)tk.world[RIAB_TW_N_GOALS];
+      w_pad_start0 = tk.world[RIAB_TW_PAD_START];
+      w_terminal_prev = tk.world[RIAB_TW_TERMINAL] != 0.0 ? 1 : 0;
+      if (wlive) win = world_lane_load(tk.a, b);
+    }
   }
   // (the box fast path's verdict, worked out once per plan by walls_prepare_kernel)
   const uint32_t box_word = *reinterpret_cast<const uint32_t*>(sy.walls + RIAB_MAX_WALLS);
@@ -466,8 +486,8 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
   tr.new_x = tr.new_y = nullptr;  // none stored by the lane's reset itself)
   tr.pos_x = tr.pos_y = nullptr;
   tr.hist_x = tr.hist_y = nullptr;
-  constexpr int TM = TASK & ~RIAB_S1_TASK_DROP;
-  if (TASK && writer && !mover) {  // (wave-uniform) the helper waves' share of the lanes' books, see above
+  constexpr int TM = RT & ~RIAB_S1_TASK_DROP;
+  if (RT && writer && !mover) {  // (wave-uniform) the helper waves' share of the lanes' books, see above
     if (hlive && (TM & 1)) {
       const RewardsOut ro = rewards_step(tk.a, (lds_f64_ptr)s_goals, b, trin);
       s_rw_n[tid & 255] = ro.n_rw;
@@ -541,7 +561,116 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
   const bool wb = writer && mover && !(RIAB_S1_ABLATE & 4);  // (wave-uniform)
   uint32_t seen = sy.epoch;
   LaneMid tmid = {0, 0, false, false, {false, 0, 0.0, 0.0, 0.0}, 0};
-  if (TASK && writer && mover) {
+  // a wait for the segment's other workgroups (their state / action loads have returned), bounded
+  auto wait_arrivals = [&]() {
+    bool timed_out = false;
+    for (uint32_t spins = 0; __builtin_amdgcn_ballot_w64(seen != sy.epoch) != 0; ++spins) {
+      if (spins >= sy.spin_limit) {  // (a workgroup of this grid that never ran: nothing sane to do but to say so)
+        timed_out = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+      seen = arrivals();
+    }
+    if (timed_out && lane == 0) step1_note_timeout(sy, ps.step0);
+  };
+  // The world's verdict on this step: five 8-byte entries at the head of the mail region, each tagged with the launch's
+  // epoch (epoch << 32 | value): [0] bit 0 = the episode ended and the world was reset (the caller's `if terminal:
+  // env.reset()`, decided here), bits 8.. = the length of the list the NEXT step finds; [1..4] that list, four entries
+  // a word.  Posted by the writer workgroup that took the last ticket; read by every wave that needs it (lanes 0-4).
+  auto world_verdict = [&](bool& stale) -> unsigned long long {  // -> lane l: entry l's value (lanes 0-4), once all are fresh
+    const s1_gu64* const mail64 = (const s1_gu64*)(uintptr_t)tk.mail;
+    unsigned long long e = (unsigned long long)sy.epoch << 32;
+    const bool polls = lane < 5;
+    if (polls) e = __hip_atomic_load((s1_gu64*)(mail64 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stale = false;
+    for (uint32_t spins = 0; __builtin_amdgcn_ballot_w64((uint32_t)(e >> 32) != sy.epoch) != 0; ++spins) {
+      if (spins >= sy.spin_limit) {
+        stale = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+      if (polls) e = __hip_atomic_load((s1_gu64*)(mail64 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return e;
+  };
+  if (WT && writer) {
+    // ---- ONE world (contribs/TaskEnvironment.py:1030, 1076-1172; riab_task_world.hip): every writer keeps the books of
+    // its 256 agents (phase A), takes a ticket; the writer with the last ticket walks the shared list for everybody
+    // (phase B), resets the world when its episode ended, and posts the verdict; every writer then teleports its agents
+    // (a reset's draws are functions of (seed, counter, agent) alone), works out their next action against the list the
+    // verdict carries and stores what it is handed back.  All eight waves take the barriers.
+    const lds_f64_ptr goals = (lds_f64_ptr)s_goals;
+    if (wb) seen = arrivals();
+    if (wlive)
+      world_phase_a(tk.a, goals, s_world, b, px, py, win, tk.t_env, w_pad_start0, w_terminal_prev, tk.reward_out, tk.terminal_out,
+                    tk.met, tk.cand, tk.ctl);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_world.last = atomicAdd(tk.ctl, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (s_world.last) {  // (workgroup-uniform)
+      __threadfence();
+      const bool terminal_last = world_phase_b<NT_>(tk.a, goals, s_world, tk.world, tk.t_env, w_pad_start0, w_terminal_prev,
+                                                    tk.reward_out, tk.terminal_out, tk.met, tk.cand, tk.ctl, tk.diag);
+      const bool reset = (WT & 2) && terminal_last;
+      __syncthreads();
+      if (tid == 0) {
+        if (reset) {  // GoalCache.reset (:1218-1252): one selection — the shared list —, the world's episode table
+          const ResetDraw d = reset_draw_id(tk.a, tk.r, RIAB_WORLD_STREAM_ID);
+          Lane nl;
+          nl.list = d.list;
+          nl.n_goals = tk.r.n_select < tk.a.n_pool ? tk.r.n_select : tk.a.n_pool;
+          world_reset_books(tk.a, tk.r, tk.world, tk.t_env, nl, tk.diag);
+          for (int i = 0; i < RIAB_TASK_MAX_GOALS; ++i) s_world.list[i] = (uint8_t)list_get(nl.list, i);
+          s_world.n = nl.n_goals;
+        }
+        s_world.next_agent = reset ? 1 : 0;
+      }
+      __syncthreads();
+      if (tid < 5) {
+        uint32_t v;
+        if (tid == 0) v = (uint32_t)s_world.next_agent | ((uint32_t)s_world.n << 8);
+        else v = (uint32_t)s_world.list[4 * tid - 4] | ((uint32_t)s_world.list[4 * tid - 3] << 8) |
+                 ((uint32_t)s_world.list[4 * tid - 2] << 16) | ((uint32_t)s_world.list[4 * tid - 1] << 24);
+        __hip_atomic_store((s1_gu64*)(uintptr_t)tk.mail + tid, ((unsigned long long)sy.epoch << 32) | v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (mover) {
+      bool stale;
+      const unsigned long long e = world_verdict(stale);
+      if (stale && lane == 0) {  // (a writer that does not learn whether the world was reset cannot keep its agents' state right)
+        step1_note_timeout(sy, ps.step0);
+        atomicAdd(sy.words + (int64_t)sy.n_segments * RIAB_STEP1_SYNC_STRIDE + RIAB_STEP1_SYNC_FATAL, 1u);
+      }
+      const int lo = (int)(uint32_t)e;
+      const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane(lo, 0);
+      const bool reset = !stale && (flags & 1u);
+      Lane L;
+      L.n_goals = (int)((flags >> 8) & 0xFFu);
+      L.list = (u128)(uint32_t)__builtin_amdgcn_readlane(lo, 1) | ((u128)(uint32_t)__builtin_amdgcn_readlane(lo, 2) << 32) |
+               ((u128)(uint32_t)__builtin_amdgcn_readlane(lo, 3) << 64) | ((u128)(uint32_t)__builtin_amdgcn_readlane(lo, 4) << 96);
+      if (wlive && reset && tk.r.teleport) {  // teleport_on_reset (:323-330)
+        const ResetDraw d = reset_draw_id(tk.a, tk.r, (uint64_t)(tk.r.agent_id0 + b));
+        px = d.x;
+        py = d.y;
+      }
+      if (WT & 4) {  // the coming step's action (get_goal_vector, :1555-1584), into the drift buffer: behind the arrival words
+        double gx = 0.0, gy = 0.0;
+        if (wlive) {
+          L.px = px;
+          L.py = py;
+          goal_vector(tk.a, goals, L, tk.gv_scale, gx, gy);
+        }
+        wait_arrivals();
+        if (wlive) {
+          tk.gv_x[b] = gx;
+          tk.gv_y[b] = gy;
+        }
+      }
+    }
+  } else if (RT && writer && mover) {
     // ---- the rest of TaskEnvironment.step for the writer's lanes (contribs/TaskEnvironment.py:410-449), the caller's
     // reset of the lanes that ended an episode, the next scripted action: task_kernel's lane, on the position just made
     if (wb) seen = arrivals();
@@ -613,7 +742,7 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
       py = qy;
     }
     RIAB_S1_STAMP(15)
-  } else if (TASK && (TM & 4) && writer) {
+  } else if (RT && (TM & 4) && writer) {
     // ---- the helper waves' last share: the coming step's action of every lane (get_goal_vector, :1555-1584), into the
     // drift buffer — which every workgroup of the segment read at the top: behind the arrival words, like the state
     uint32_t hseen = arrivals();
@@ -683,16 +812,7 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
 
   if (wb && !TASK) seen = arrivals();
   auto write_back = [&]() {
-    bool timed_out = false;
-    for (uint32_t spins = 0; __builtin_amdgcn_ballot_w64(seen != sy.epoch) != 0; ++spins) {
-      if (spins >= sy.spin_limit) {  // (a workgroup of this grid that never ran: nothing sane to do but to say so)
-        timed_out = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-      seen = arrivals();
-    }
-    if (timed_out && lane == 0) step1_note_timeout(sy, ps.step0);
+    wait_arrivals();
     RIAB_S1_STAMP(5)
     {
       st[0 * B] = px;
@@ -754,7 +874,34 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
       wave_needs_pos = wave_needs_pos || (k < ps.n_pops && ps.pop[k].kind != S1_KIND_HDC && ps.pop[k].group0 < g0 + reps &&
                                           ps.pop[k].group0 + ps.pop[k].n_groups > g0);
   }
-  if (TASK && !writer && wave_needs_pos && !(RIAB_S1_TASK_DROP & 8)) {
+  if (WT && (WT & 2) && !writer && wave_needs_pos) {
+    // ---- did the world's episode end?  Then every agent was teleported (where to is a function of (seed, counter,
+    // agent) alone: this lane's quad works it out for itself) and the wave runs its pass again on the new row
+    bool stale;
+    const unsigned long long e = world_verdict(stale);
+    const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, 0);
+    if (stale) {
+      if (lane == 0) step1_note_timeout(sy, ps.step0);
+    } else if ((flags & 1u) && tk.r.teleport) {
+      v4f rx = *reinterpret_cast<const v4f*>(&s_row[0][4 * lane]), ry = *reinterpret_cast<const v4f*>(&s_row[1][4 * lane]);
+      const int64_t b4 = (int64_t)blockIdx.x * 256 + 4 * lane;
+      float nx[4], ny[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const ResetDraw d = reset_draw_id(tk.a, tk.r, (uint64_t)(tk.r.agent_id0 + b4 + k));
+        nx[k] = (float)d.x;
+        ny[k] = (float)d.y;
+      }
+      const bool l0 = b4 + 0 < tk.a.B, l1 = b4 + 1 < tk.a.B, l2 = b4 + 2 < tk.a.B, l3 = b4 + 3 < tk.a.B;  // (lanes of the task)
+      rx.x = l0 ? nx[0] : rx.x; ry.x = l0 ? ny[0] : ry.x;
+      rx.y = l1 ? nx[1] : rx.y; ry.y = l1 ? ny[1] : ry.y;
+      rx.z = l2 ? nx[2] : rx.z; ry.z = l2 ? ny[2] : ry.z;
+      rx.w = l3 ? nx[3] : rx.w; ry.w = l3 ? ny[3] : ry.w;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the values this wave stored a moment ago are in place)
+      rates_pass(rx, ry, true);
+    }
+  }
+  if (RT && !writer && wave_needs_pos && !(RIAB_S1_TASK_DROP & 8)) {
     // ---- did a reset move one of the segment's agents?  The writer's 4 x 6 verdict entries of this launch: one round
     // trip (they are usually there by now) says that they are posted, which agents moved and where (almost all of) them went.
     const s1_gu64* const mail64 = (const s1_gu64*)(uintptr_t)(tk.mail + (int64_t)blockIdx.x * RIAB_STEP1_MAIL_STRIDE);
@@ -1054,6 +1201,10 @@ static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const Step1
       case 3: RIAB_S1_TASK(3);
       case 5: RIAB_S1_TASK(5);
       case 7: RIAB_S1_TASK(7);
+      case 9: RIAB_S1_TASK(9);  // (| 8: the lanes are the agents of one world)
+      case 11: RIAB_S1_TASK(11);
+      case 13: RIAB_S1_TASK(13);
+      case 15: RIAB_S1_TASK(15);
       default: return RIAB_EINVAL;
     }
 #undef RIAB_S1_TASK
@@ -1090,11 +1241,16 @@ int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const Step1PopRef*
                       double* task_state, int64_t task_B, double t_env, double* reward_out, uint8_t* terminal_out, int32_t* diag,
                       bool auto_reset, int32_t n_select, int32_t ordered, uint64_t task_seed, uint64_t counter, int32_t teleport,
                       double* ep_log, int64_t ep_log_cap, int32_t* ep_count, double gv_scale, double* gv_x, double* gv_y,
-                      hipStream_t s, bool query) {
+                      double* world, uint64_t* world_met, int32_t* world_cand, int32_t* world_ctl, hipStream_t s, bool query) {
   Step1Task tk = {};
   int rc = fill_args(tk.a, env, task, task_state, task_B);
   if (rc) return rc;
   if (task_B > a.B || !reward_out || !terminal_out || !diag || !sync_words) return RIAB_EINVAL;
+  if (world && (!world_met || !world_cand || !world_ctl || task_B > 0x7FFFFFFF)) return RIAB_EINVAL;
+  tk.world = world;  // (non-null: the lanes are the agents of ONE world)
+  tk.met = world_met;
+  tk.cand = world_cand;
+  tk.ctl = world_ctl;
   if (auto_reset) {
     double* const pos_x = a.state + (int64_t)RIAB_S_POS_X * a.B;
     rc = fill_reset(tk.r, env, a.agent_id0, n_select, ordered, task_seed, counter, teleport, nullptr, nullptr, pos_x, pos_x + a.B,
@@ -1110,7 +1266,7 @@ int launch_step1_task(const AgentArgs& a, const RiabEnv* env, const Step1PopRef*
   tk.gv_y = gv_y;
   tk.diag = diag;
   tk.mail = sync_words + RIAB_STEP1_SYNC_MAIL_AT(a.B);
-  const int mode = 1 | (auto_reset ? 2 : 0) | (gv_x ? 4 : 0);
+  const int mode = 1 | (auto_reset ? 2 : 0) | (gv_x ? 4 : 0) | (world ? 8 : 0);
   return launch_step1_impl(a, env, refs, n_pops, seed, step_after, sync_words, epoch, walls_ready, n_cus, s, &tk, mode, query);
 }
 

@@ -62,13 +62,16 @@ def _settle_fused(plan):
     plan._fused_seen = fused
     ag = plan.agent
     tail = _L.step1_sync_tail(ag._Bp)
-    t = w[tail:tail + 3].cpu().numpy().astype(np.int64) & 0xFFFFFFFF     # (waits for the steps)
+    t = w[tail:tail + 4].cpu().numpy().astype(np.int64) & 0xFFFFFFFF     # (waits for the steps)
     n = int(t[_L.STEP1_SYNC_TIMEOUTS])
     if not n:
         return
     first, last = int(t[_L.STEP1_SYNC_FIRST_BAD]), int(t[_L.STEP1_SYNC_LAST_BAD])
     torch.cuda.synchronize(ag._device)
-    w[tail:tail + 3] = 0
+    w[tail:tail + 4] = 0
+    if int(t[_L.STEP1_SYNC_FATAL]):   # (one-world task plans: a writer never learnt whether the world was reset)
+        raise _L.RiabError(f"one-launch step of a one-world task: {int(t[_L.STEP1_SYNC_FATAL])} writer workgroups gave up waiting "
+                           f"for the world's verdict in steps {first}..{last}; the agent state of those steps is not trustworthy")
     plan.sync()
     now = int(ag._step_index)
     if not (0 < first <= last <= now) or last - first >= 1 << 16:

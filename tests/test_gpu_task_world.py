@@ -209,11 +209,15 @@ def test_task_world_is_capturable_and_refuses_what_it_cannot_do(riab):
     assert not env2._ticket.any().item() and len(env2.goal_cache) < 3
 
 
-@pytest.mark.parametrize("goalorder,B,auto_reset", [("nonsequential", 1030, True), ("sequential", 300, True), ("nonsequential", 64, False)])
+@pytest.mark.parametrize("goalorder,B,auto_reset", [("nonsequential", 1030, True), ("sequential", 300, True), ("nonsequential", 64, False),
+                                                    ("nonsequential", 1024, True), ("sequential", 512, True), ("nonsequential", 256, False),
+                                                    ("sequential", 2048, True)])
 def test_task_world_step_plan_equals_eager_loop(riab, goalorder, B, auto_reset):
     """env.make_step_plan(auto_reset, scripted_speed) of a one-world task: one native call per step (motion + the world's
     step, its reset when the episode ended — decided on the device — + the next action, the populations) == the eager loop
-    `a = speed * goal direction; env.step(a); if terminal: env.reset(); PCs.update()` bit for bit."""
+    `a = speed * goal direction; env.step(a); if terminal: env.reset(); PCs.update()` bit for bit.  Whole 256-agent
+    segments: the step is ONE kernel (csrc/riab_step1.hip, TASK & 8: the writer workgroups keep the world's books, the one
+    with the last ticket walks the shared list and posts the verdict); other batches: three launches."""
     from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
     T, speed = 160, 11.0 * 0.08
 
@@ -255,4 +259,8 @@ def test_task_world_step_plan_equals_eager_loop(riab, goalorder, B, auto_reset):
     assert np.array_equal(A1.history["pos"], A2.history["pos"])
     assert np.array_equal(P1.history["firingrate"], P2.history["firingrate"])
     info = plan.info()
-    assert info["launches"] == 3 * T + int(auto_reset) and info["fused_steps"] == 0   # (motion + world step, reset + action / action, rates)
+    if B % 256 == 0:
+        assert info["fused_steps"] == T and info["launches"] == T + 1, info            # (+ the plan's first scripted action)
+        assert dict(A2.diagnostics)["step1_timeouts_recovered"] == 0
+    else:
+        assert info["launches"] == 3 * T + int(auto_reset) and info["fused_steps"] == 0   # (motion + world step, reset + action / action, rates)
