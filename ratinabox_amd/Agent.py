@@ -211,7 +211,9 @@ class Agent:
         kernels — the same functors on the same fp32 rows: the bits the pipeline would have written — counted in
         diagnostics["pipeline_recovered"], and the caller gets a warning instead of an exception.  What cannot be
         redone raises as before: a trajectory kernel that itself gave up, populations with additive OU noise (their
-        noise state has advanced), more unchecked runs than are remembered."""
+        noise state has advanced), more unchecked runs than are remembered, a population whose tuning parameters were
+        edited between the run and this read.  (Replays of a captured graph are not remembered: their rows are not
+        recoverable — a capture runs in strict mode, whose rate stage starts behind a gate and does not give up in practice.)"""
         if not self._pipeline_unchecked:
             return
         self._pipeline_unchecked = False
@@ -238,12 +240,19 @@ class Agent:
             why = f"more than {self.MAX_UNCHECKED_RUNS} runs since the last host read"
         elif any(N.noise_std != 0 for r in runs for N in r[5]):
             why = "a population with additive OU noise took part (its noise state has advanced)"
+        else:
+            for r in runs:
+                for N, (tabs, lo, hi) in zip(r[5], r[7]):
+                    N._auto_key()   # (brings the content-keyed tables up to date with the host arrays as they are NOW)
+                    if N._table_cache.get("t") is not tabs or float(N.min_fr) != lo or float(N.max_fr) != hi:
+                        why = (f"the parameters of {type(N).__name__} were edited between that run and this read: its rows "
+                               "would be recomputed with other tables than the run used")
         if why is not None:
             raise _L.RiabError(f"the flag-coupled simulate() pipeline was aborted ({n} waits timed out) and its rows cannot "
                                f"be recomputed: {why}; the rows of that run are incomplete (RIAB_NO_NATIVE=1 selects the "
                                "Python-driven chunk pipeline)")
         stream = _L.current_stream()
-        for traj_c, traj_s, n_steps, step0, dt, neurons, ats in runs:
+        for traj_c, traj_s, n_steps, step0, dt, neurons, ats, _tables in runs:
             traj = traj_c[traj_s:traj_s + n_steps]
             outs = [N._rows_views(at, n_steps) for N, at in zip(neurons, ats)]
             self._sim_outs = dict(zip(neurons, outs))   # (FeedForwardLayers read their inputs' rows of the same piece)
@@ -877,7 +886,11 @@ class Agent:
         if len(runs) >= self.MAX_UNCHECKED_RUNS:
             del runs[0]
             self._unchecked_lost = True
-        runs.append((traj_c, traj_s, n_steps, self._step_index, dt, neurons, ats))
+        # (+ what each population's kernels read, as it was for THIS run: its device tables — content-keyed: a new object
+        # when a tuning array was edited — and its rate scaling; a recovery with other parameters would not rewrite the
+        # bits the run would have written)
+        runs.append((traj_c, traj_s, n_steps, self._step_index, dt, neurons, ats,
+                     tuple((N._table_cache.get("t"), float(N.min_fr), float(N.max_fr)) for N in neurons)))
         traj = traj_c[traj_s:traj_s + n_steps]
         self._keep = (keep, outs)
         self._last_row = traj[n_steps - 1]

@@ -223,7 +223,16 @@ class RewardCache:
 
 # ------------------------------------------------------------------------------------------------
 class TaskEnvironment(Environment):
-    """Environment with task structure (reference TaskEnvironment.py:30-145), one replica per lane."""
+    """Environment with task structure (reference TaskEnvironment.py:30-145), one replica per lane — or, with
+    `lanes="agents"`, the batch as the agents of ONE world (the reference with several Agents, agentmode="interact").
+
+    One deliberate deviation, in both forms, counted in `diagnostics["late_completions"]`: the reference's `step()` calls
+    `_is_terminal_state()` a third time (:438, while it prunes `self.agents`) and throws that call's verdict away — a goal
+    the agents complete in THAT pass (overlapping goals, nonsequential order) empties the list without the step
+    reporting `terminal`, and the next step appends the `episode_terminate_delay` padding goal.  Here the flag handed
+    back (`terminal`, `RIAB_TW_TERMINAL`) is the list's state after that third pass: such a step reports the end of the
+    episode at once, and a device-decided reset (`auto_reset`) fires in the same step, without the padding goal.  Reward
+    totals are unaffected (the third pass's awards are appended either way)."""
 
     default_params = {}
     metadata = {"render_modes": ["none"], "name": "TaskEnvironment-RiaB"}
@@ -519,8 +528,11 @@ class TaskEnvironment(Environment):
         """The whole closed-loop step as ONE native call (plan.py, riab_plan_*): `plan.step(1, drift_velocity=
         actions)` == `env.step(actions)` + `Neurons.update()` of every population (+ `env.reset(mask=terminal)`
         when `auto_reset`).  Read `env.get_reward()`, `env.terminal`, `env.get_observation()` afterwards.  With
-        `lanes="agents"` a step is three launches inside the one native call: motion + the world's step, its reset when the
-        episode ended (decided on the device) + the next scripted action, the populations."""
+        `lanes="agents"` and whole 256-agent segments the step is ONE kernel as well (csrc/riab_step1.hip, TASK & 8: the
+        writer workgroups keep the world's books, the one that takes the last ticket walks the shared list, resets the world
+        when its episode ended and posts the verdict; the store-bound populations ride along); other batches take three
+        launches inside the one native call: motion + the world's step, its reset when the episode ended (decided on the
+        device) + the next scripted action, the populations."""
         plan = self._agent.make_step_plan(neurons, capacity)
         return plan.attach_task(self, auto_reset=auto_reset, scripted_speed=scripted_speed)
 

@@ -605,12 +605,10 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
     if (wlive)
       world_phase_a(tk.a, goals, s_world, b, px, py, win, tk.t_env, w_pad_start0, w_terminal_prev, tk.reward_out, tk.terminal_out,
                     tk.met, tk.cand, tk.ctl);
-    __threadfence();
-    __syncthreads();
+    __syncthreads();  // (phase A's write-through stores have been acknowledged)
     if (tid == 0) s_world.last = atomicAdd(tk.ctl, 1) == (int)gridDim.x - 1;
     __syncthreads();
     if (s_world.last) {  // (workgroup-uniform)
-      __threadfence();
       const bool terminal_last = world_phase_b<NT_>(tk.a, goals, s_world, tk.world, tk.t_env, w_pad_start0, w_terminal_prev,
                                                     tk.reward_out, tk.terminal_out, tk.met, tk.cand, tk.ctl, tk.diag);
       const bool reset = (WT & 2) && terminal_last;

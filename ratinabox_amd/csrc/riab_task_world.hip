@@ -54,13 +54,12 @@ __device__ __forceinline__ void world_step_body(const TaskArgs& a, double* world
   __syncthreads();
   const lds_f64_ptr goals = (lds_f64_ptr)s_goals;
   if (live) world_phase_a(a, goals, S, b, px, py, in, t_env, pad_start0, terminal_prev, reward_out, terminal_out, met, cand, ctl);
-  // ---- the last workgroup to get here goes on
-  __threadfence();
+  // ---- the last workgroup to get here goes on (what phase B reads of the others' phase A was written through and has
+  // been acknowledged: the barrier waits for every wave's stores — riab_task_world_kernel.h)
   __syncthreads();
   if (tid == 0) S.last = atomicAdd(ctl, 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (!S.last) return;
-  __threadfence();
   // ---- phase B: the step's check passes over the shared list
   world_phase_b<BLOCK>(a, goals, S, world, t_env, pad_start0, terminal_prev, reward_out, terminal_out, met, cand, ctl, diag);
 }

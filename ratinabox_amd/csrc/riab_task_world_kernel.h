@@ -11,6 +11,31 @@
 
 namespace riab {
 
+// What phase A hands to phase B across workgroups — a candidate's "stands inside" mask, its place on the work list, the
+// survivors' sum of its rewards, the length of its reward cache — travels write-through and is read past the reader's
+// L1 (relaxed agent-scope accesses: global_store / global_load ... sc1), the writer having waited for its stores'
+// acknowledgement before it takes its ticket.  Two __threadfence() — a write-back of the L2's dirty lines on one side, an
+// invalidation on the other, 3-7 us between them on this chip — used to stand where the ticket is taken; a quiet step
+// (no candidate: nothing to hand over but the counter) paid them all the same.
+__device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) {
+  __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(uintptr_t)p, (unsigned long long)v, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) {
+  return (uint64_t)__hip_atomic_load((__attribute__((address_space(1))) unsigned long long*)(uintptr_t)p, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(int32_t* p, int32_t v) {
+  __hip_atomic_store((__attribute__((address_space(1))) int*)(uintptr_t)p, (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int32_t ld_agent(const int32_t* p) {
+  return (int32_t)__hip_atomic_load((__attribute__((address_space(1))) int*)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(double* p, double v) { st_agent(reinterpret_cast<uint64_t*>(p), (uint64_t)__double_as_longlong(v)); }
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __longlong_as_double((long long)ld_agent(reinterpret_cast<const uint64_t*>(p)));
+}
+
 struct WorldShared {  // phase B's state, in LDS
   uint8_t list[RIAB_TASK_MAX_GOALS];
   int n;
@@ -45,8 +70,8 @@ __device__ int world_pass(WorldShared& S, const uint64_t* met, const int32_t* ca
       __syncthreads();
       int mine = 0x7FFFFFFF;
       for (int i = tid; i < n_cand; i += BLOCK) {  // (the candidates are in no particular order)
-        const int c = cand[i];
-        if (c >= a_next && c < mine && (met[c] & mask)) mine = c;
+        const int c = ld_agent(cand + i);
+        if (c >= a_next && c < mine && (ld_agent(met + c) & mask)) mine = c;
       }
       if (mine != 0x7FFFFFFF) atomicMin(&S.next_agent, mine);
       __syncthreads();
@@ -57,7 +82,7 @@ __device__ int world_pass(WorldShared& S, const uint64_t* met, const int32_t* ca
     __syncthreads();  // (everybody has read the slot and the list)
     if (tid == 0) {
       WorldList w = {S.list, S.n};
-      world_agent_turn(w, met[who], pad_now, sequential, (int)who, S.awards, S.n_awards);
+      world_agent_turn(w, ld_agent(met + who), pad_now, sequential, (int)who, S.awards, S.n_awards);
       S.n = w.n;
     }
     __syncthreads();
@@ -96,7 +121,7 @@ __device__ __forceinline__ void world_phase_a(const TaskArgs& a, lds_f64_ptr goa
                                               uint8_t terminal_prev, double* reward_out, uint8_t* terminal_out, uint64_t* met,
                                               int32_t* cand, int32_t* ctl) {
   const RewardsOut ro = rewards_step(a, goals, b, in.rin);
-  if (ro.n_rw != in.rin.n_rw) ts_at(a, RIAB_TS_N_REWARDS, b) = (double)ro.n_rw;
+  if (ro.n_rw != in.rin.n_rw) st_agent(&ts_at(a, RIAB_TS_N_REWARDS, b), (double)ro.n_rw);  // (phase B appends behind it)
   uint64_t m = 0;
   bool pad_in_list = false;
   for (int g = 0; g < S.n; ++g) {
@@ -104,17 +129,20 @@ __device__ __forceinline__ void world_phase_a(const TaskArgs& a, lds_f64_ptr goa
     if (v == (int)RIAB_WL_PAD) pad_in_list = true;
     else if (in_goal_radius(a, px, py, goals + v * RIAB_GOAL_COLS)) m |= 1ull << v;
   }
-  met[b] = m;
+  st_agent(met + b, m);
   // a termination-delay goal whose time has elapsed goes to the first agent (its pass starts with agent 0)
   const bool candidate = m != 0 || (b == 0 && pad_in_list && t_env - pad_start0 >= a.terminate_delay);
   if (candidate) {
-    reward_out[b] = ro.total;  // (the survivors' sum: phase B adds this step's awards, then totals)
+    st_agent(reward_out + b, ro.total);  // (the survivors' sum: phase B adds this step's awards, then totals)
     const int slot = atomicAdd(ctl + 1, 1);
-    if (slot < a.B) cand[slot] = (int32_t)b;  // (always, unless the caller's counter did not start at zero)
+    if (slot < a.B) st_agent(cand + slot, (int32_t)b);  // (always, unless the caller's counter did not start at zero)
   } else {
     world_lane_total(a, b, ro.total, in.rmax, in.rmin, reward_out);
   }
-  terminal_out[b] = terminal_prev;  // (the world's flag; phase B rewrites the column when it changes)
+  // (the world's flag; phase B rewrites the column when it changes — from another workgroup, possibly behind another L2:
+  // written through here, so that the rewrite, which comes after this store's acknowledgement, is what stays)
+  __hip_atomic_store((__attribute__((address_space(1))) uint8_t*)(uintptr_t)(terminal_out + b), terminal_prev, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- phase B, by the whole workgroup that took the last ticket: the step's check passes over the shared list, the
@@ -155,7 +183,7 @@ __device__ bool world_phase_b(const TaskArgs& a, lds_f64_ptr goals, WorldShared&
     for (int i = 0; i < S.n_awards; ++i) {
       const int64_t w = S.awards[i].agent;
       const int src = S.awards[i].entry == (int)RIAB_WL_PAD ? RIAB_GOAL_TIME_ELAPSED : S.awards[i].entry;
-      const int n_rw = (int)ts_at(a, RIAB_TS_N_REWARDS, w);
+      const int n_rw = (int)ld_agent(&ts_at(a, RIAB_TS_N_REWARDS, w));
       if (n_rw >= RIAB_TASK_MAX_REWARDS) {
         atomicAdd(diag + RIAB_TD_REWARD_OVERFLOW, 1);
         continue;
@@ -164,8 +192,8 @@ __device__ bool world_phase_b(const TaskArgs& a, lds_f64_ptr goals, WorldShared&
       ts_at(a, RIAB_TS_RW_STATE + n_rw, w) = r.init;
       ts_at(a, RIAB_TS_RW_EXPIRE + n_rw, w) = r.expire;
       ts_at(a, RIAB_TS_RW_SRC + n_rw, w) = (double)src;
-      ts_at(a, RIAB_TS_N_REWARDS, w) = (double)(n_rw + 1);
-      reward_out[w] = reward_out[w] + r.init;  // python sum(): left to right, the new rewards last
+      st_agent(&ts_at(a, RIAB_TS_N_REWARDS, w), (double)(n_rw + 1));
+      st_agent(reward_out + w, ld_agent(reward_out + w) + r.init);  // python sum(): left to right, the new rewards last
     }
     // the shared state
     if (S.n != n0) world[RIAB_TW_N_GOALS] = (double)S.n;
@@ -182,8 +210,8 @@ __device__ bool world_phase_b(const TaskArgs& a, lds_f64_ptr goals, WorldShared&
   }
   __syncthreads();
   for (int i = tid; i < n_cand; i += BLOCK) {  // the candidates' totals, with what they were awarded
-    const int64_t c = cand[i];
-    world_lane_total(a, c, reward_out[c], ts_at(a, RIAB_TS_R_MAX, c), ts_at(a, RIAB_TS_R_MIN, c), reward_out);
+    const int64_t c = ld_agent(cand + i);
+    world_lane_total(a, c, ld_agent(reward_out + c), ts_at(a, RIAB_TS_R_MAX, c), ts_at(a, RIAB_TS_R_MIN, c), reward_out);
   }
   if ((terminal_last ? 1 : 0) != terminal_prev)
     for (int64_t i = tid; i < a.B; i += BLOCK) terminal_out[i] = terminal_last ? 1 : 0;

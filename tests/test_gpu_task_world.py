@@ -228,7 +228,8 @@ def test_task_world_step_plan_equals_eager_loop(riab, goalorder, B, auto_reset):
                                      goalcachekws=dict(reset_n_goals=3, goalorder=goalorder), goalkws={"goal_radius": 0.03},
                                      episode_terminate_delay=0.03, teleport_on_reset=True, seed=11, lanes="agents")
         Ag = riab.Agent(env, {"dt": 0.01, "n_agents": B, "seed": 4})
-        PCs = riab.PlaceCells(Ag, {"n": 40})
+        # (whole segments: a population the one-launch step covers — the default geometry is geodesic in a room with a wall)
+        PCs = riab.PlaceCells(Ag, {"n": 40, "wall_geometry": "euclidean"} if B % 256 == 0 else {"n": 40})
         env.add_agents(Ag)
         return env, Ag, PCs
 
