@@ -167,7 +167,7 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
           const int k = kk[i];
           const float d = (float)((best[i] < INFINITY) ? best[i] : fallback[i]);
           s_d[k * 64 + lane] = d;
-          if (a.ray_out && live) a.ray_out[(t * K + k) * a.B + b] = d;
+          if (a.ray_out && live && blockIdx.y == 0) a.ray_out[(t * K + k) * a.B + b] = d;
         }
       }
     }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
           const float dn = (float)((bneg[i] < INFINITY) ? bneg[i] : -fallback[i]);
           s_d[k * 64 + lane] = dp;
           s_d[(k + m) * 64 + lane] = dn;
-          if (a.ray_out && live) {
+          if (a.ray_out && live && blockIdx.y == 0) {
             a.ray_out[(t * K + k) * a.B + b] = dp;
             a.ray_out[(t * K + k + m) * a.B + b] = dn;
           }
@@ -271,7 +271,9 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
   }
   const int n = a.n, Kp = a.Kp;
   const int n_groups = (n + 3) >> 2;
-  for (int g = wave; g < n_groups; g += 8) {
+  // (gridDim.y > 1: a launch of few tiles — one row of a closed loop — deals its cell groups to several workgroups per
+  // tile, each of which has cast the tile's rays for itself: see the launch)
+  for (int g = wave + 8 * (int)blockIdx.y; g < n_groups; g += 8 * (int)gridDim.y) {
     float aa[4], nmu[4], kap[4];
     const_f32_ptr tc[4];
     const_f32_ptr ts[4];
@@ -444,7 +446,16 @@ extern "C" int riab_boundary_vector_cells_windowed(const RiabEnv* env, const Ria
   a.rect_room = (!env->polygon && !env->hole_mask && !env->periodic && g_options[RIAB_OPT_BVC_BOX]) ? 1 : 0;
   const size_t lds = sizeof(float) * (size_t)((K + 3) / 4 * 4) * 64;
   if (lds > 160 * 1024) return RIAB_ETOOBIG;
-  const dim3 grid((unsigned)((a.P + 63) / 64));
+  // One workgroup per tile of 64 positions is the throughput shape (many rows per launch: every compute unit has tiles
+  // to spare).  ONE row of a closed loop is 64 tiles at 4096 agents — a quarter of the chip, each workgroup walking all
+  // of its cell groups alone: such a launch deals the cell groups of a tile to up to eight workgroups (grid.y), every one
+  // of which casts the tile's rays for itself (stage A: ~5-15 % of a tile's work) — what counts there is the row's
+  // latency.  [MI355X] cfg 3's closed-loop step 110 -> see DESIGN.md 3.2.
+  const int64_t tiles = (a.P + 63) / 64;
+  const int n_groups = (n + 3) / 4;
+  int split = 1;
+  while (split < 8 && tiles * split * 2 <= 512 && split * 2 * 8 <= n_groups) split *= 2;
+  const dim3 grid((unsigned)tiles, (unsigned)split);
   hipStream_t s = (hipStream_t)stream;
   if (egocentric) {
     if (lds > 64 * 1024)
