@@ -855,6 +855,12 @@ int riab_streamer_configure(RiabStreamer* h, int32_t option, int32_t value);
  *    riab_streamer_warmup(h, stream) once beforehand — outside any capture —, which creates that stream and the events
  *    and also performs the default mode's screening for `stream`; without it a strict call returns RIAB_EUNSUPPORTED
  *    (nothing launched).  Same rows, bit for bit, in either mode.
+ *  Which mode a call takes: RIAB_STREAMER_OPT_STRICT = 2 (the default of a new streamer): STRICT for runs of more than
+ *    256 steps once riab_streamer_warmup has been called — two launches more are 0.2 % of such a call [MI355X, cfg 2,
+ *    1024 steps: 1.423 against 1.426 G agent-steps/s] —, DEFAULT below (the 20 steps of the driver's bench command: 846
+ *    against 1016 M agent-steps/s); 1: always STRICT; 0: never (but for captures).  A THIRD-PARTY BINDING should call
+ *    riab_streamer_warmup once per (streamer, stream) at set-up and leave the option at 2 — or set 1 if it must never
+ *    touch process-wide state, at the price above for short calls.
  * The per-kernel entry points above and the step-plan entry points conform unconditionally. */
 int riab_streamer_warmup(RiabStreamer* h, riab_stream_t stream);
 int riab_simulate(RiabStreamer* h, const RiabSimulate* run, riab_stream_t stream);

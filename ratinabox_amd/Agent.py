@@ -654,14 +654,15 @@ class Agent:
         if _L.env("RIAB_STRICT") == "1":
             self.pipeline_mode(strict=True)
 
-    def pipeline_mode(self, strict):
+    def pipeline_mode(self, strict=None):
         """`strict=True`: native simulate() calls of this agent take the mode of riab_simulate that conforms to the C ABI's
         contract (include/riab_hip.h "Two modes": nothing allocated, synchronised, queried or shared; capturable; two
-        more launches per call); `False` (the default): the mode tuned for one short call per synchronisation.  Calls on
-        a stream that is being captured are strict whatever this says.  Same rows either way."""
+        more launches per call); `False`: the mode tuned for one short call per synchronisation; `None` (the default of
+        a new Agent): strict for runs of more than 256 steps, where it costs nothing measurable, the short-call mode below.
+        Calls on a stream that is being captured are strict whatever this says.  Same rows either way."""
         if self._streamer is None:
             self._make_streamer()
-        _L.check(_L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_STRICT, 1 if strict else 0),
+        _L.check(_L.lib.riab_streamer_configure(self._streamer, _L.STREAMER_OPT_STRICT, 2 if strict is None else 1 if strict else 0),
                  "riab_streamer_configure")
 
     # ---- the open-loop run as ONE native call (riab_simulate) -----------------------------------------------------------

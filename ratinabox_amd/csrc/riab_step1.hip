@@ -1181,7 +1181,9 @@ static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const Step1
         per_cu = nb;
         frame = (int)fa.localSizeBytes;
       }
+#ifndef RIAB_STEP1_PROFILE  // (a profiling build's extra stores may cost an instantiation its frame: the phases are what it is for)
       if (frame > 0) return RIAB_EUNSUPPORTED;
+#endif
       const int64_t resident = check ? (int64_t)n_cus * per_cu : 2048 / RIAB_S1_WAVES;
       const int rc = step1_shape(a.B, groups, true, resident, &grid, &reps);
       if (rc) return rc;

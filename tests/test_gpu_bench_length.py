@@ -123,8 +123,8 @@ def test_bench_length_run_native_against_comparator_and_oracle(riab, name, form)
                 info = ag.pipeline_info()
                 if len(pops) > 1:
                     assert info["form_selection"]["measured"], "the form was chosen without the measured step time"
-                else:   # one store-bound population from an idle stream: the reserving twelve-wave shape, two launches
-                    assert info["launches_last_call"] == 2, info
+                else:   # one store-bound population, more than 256 steps: the strict mode by default (opening kernel, started
+                    assert info["strict_last_call"] and info["launches_last_call"] == 4, info   # gate, trajectory, rate kernel)
                 B = cfg["agents"]
                 sel = np.arange(0, B, B // 32) + 5
                 # rows of the whole history (warm-up call first): the first row, the long call's first row, both sides of a
