@@ -116,7 +116,19 @@ typedef struct RiabMotion {
   double wall_repel_distance_kw;
   double thigmotaxis_kw;
   double hd_tau;              /* head_direction_smoothing_timescale (attribute) */
+  /* Optional broad phase for rooms with many walls (NULL: every wall is looked at every step).  A grid of
+   * wall_grid_n x wall_grid_n cells over the extent; per cell two 64-bit masks of walls: [0] every wall that can be the
+   * NEAREST wall of, or within wall_grid_wd of, a point of the cell; [1] every wall within wall_grid_lmax of the cell
+   * (the walls a step of at most that length from a point of the cell can cross).  Conservative supersets, built by
+   * the caller (ratinabox_amd/Environment.py: wall_grid): the motion step evaluates its per-wall arithmetic for the
+   * walls of the mask only — the minimum, the near set and the first-hit wall are the same, bit for bit.  Ignored when
+   * wall_repel_distance_kw > wall_grid_wd; a step longer than wall_grid_lmax looks at every wall. */
+  const uint64_t* wall_grid;  /* device uint64 [wall_grid_n * wall_grid_n][2], cell (ix, iy) at iy * wall_grid_n + ix */
+  int32_t wall_grid_n;        /* <= RIAB_WALL_GRID_MAX */
+  double wall_grid_wd;
+  double wall_grid_lmax;
 } RiabMotion;
+#define RIAB_WALL_GRID_MAX 16
 
 /* T fused Agent.update() steps for B independent agents.
  * Replaces Agent.update (Agent.py:160-242) = _stochastic_velocity_update

@@ -351,14 +351,17 @@ class Agent:
         the reference takes from kwargs and which from attributes (Agent.py:280-285,
         310, 340, 353-355, 375, 439, 489)."""
         key = None
+        g = kwargs.get
+        # (wall-heavy rooms: the broad phase of the step's wall loops, Environment.wall_grid — None below 13 walls)
+        grid = self.Environment.wall_grid(self._device, float(g("wall_repel_distance", self.wall_repel_distance))) \
+            if self._device.type == "cuda" else None
         if not kwargs:
             key = (dt, has_drift, ratio, self.rotational_velocity_std, self.rotational_velocity_coherence_time,
                    self.speed_coherence_time, self.speed_mean, self.speed_std, self.wall_repel_strength,
                    self.wall_repel_distance, self.thigmotaxis, self.head_direction_smoothing_timescale)
             hit = getattr(self, "_motion_cache", None)
-            if hit is not None and hit[0] == key:
+            if hit is not None and hit[0] == key and hit[2] is grid:
                 return hit[1]
-        g = kwargs.get
         m = _L.RiabMotion()
         rot_std = g("rotational_velocity_std", self.rotational_velocity_std)
         rot_tau = g("rotational_velocity_coherence_time", self.rotational_velocity_coherence_time)
@@ -378,8 +381,11 @@ class Agent:
         m.wall_repel_distance_kw = float(g("wall_repel_distance", self.wall_repel_distance))
         m.thigmotaxis_kw = float(g("thigmotaxis", self.thigmotaxis))
         m.hd_tau = float(self.head_direction_smoothing_timescale)
+        if grid is not None:
+            m.wall_grid, m.wall_grid_n, m.wall_grid_wd, m.wall_grid_lmax = grid[0].data_ptr(), grid[1], grid[2], grid[3]
+            m._keep_grid = grid
         if key is not None:
-            self._motion_cache = (key, m)
+            self._motion_cache = (key, m, grid)
         return m
 
     def _motion_key_now(self, dt, has_drift=False, ratio=1):

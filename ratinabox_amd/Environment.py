@@ -362,6 +362,46 @@ class Environment:
         return flags.cpu().numpy() == 1
 
     # -- device tables --------------------------------------------------------------------
+    WALL_GRID_FROM = 13     # walls from which the motion step gets a broad phase (include/riab_hip.h RiabMotion.wall_grid)
+
+    def wall_grid(self, device, wd, lmax=0.02):
+        """The broad phase of the motion step for wall-heavy rooms (include/riab_hip.h: RiabMotion.wall_grid): per cell of
+        a 16 x 16 grid over the extent, [0] the walls that can be the nearest wall of, or lie within `wd` (the wall repel
+        distance) of, a point of the cell, [1] the walls within `lmax` of the cell — the only ones a step of at most that
+        length can cross.  Conservative supersets from float64 NumPy: a cell is treated as the disc around its centre
+        that contains it (+ 1e-6), `dist(centre, wall) -/+ radius` bound the distance of its points from below / above.
+        -> (device int64 tensor [G * G, 2], G, wd, lmax), or None for rooms with fewer than WALL_GRID_FROM walls; cached
+        on the wall table and wd."""
+        import torch
+        from . import _lib
+        walls = np.asarray(self.walls, dtype=np.float64).reshape(-1, 4)
+        if len(walls) < self.WALL_GRID_FROM or len(walls) > _lib.MAX_WALLS or _lib.env("RIAB_NO_WALL_GRID") == "1":
+            return None   # (RIAB_NO_WALL_GRID=1: A/B and the tests' comparator — every wall, every step)
+        slot = ("wall_grid", str(device))
+        key = (walls.tobytes(), tuple(float(e) for e in self.extent), float(wd), float(lmax))
+        hit = self._device_cache.get(slot)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        G = _lib.WALL_GRID_MAX
+        e0, e1, e2, e3 = (float(e) for e in self.extent)
+        cw, ch = (e1 - e0) / G, (e3 - e2) / G
+        cx = e0 + (np.arange(G) + 0.5) * cw
+        cy = e2 + (np.arange(G) + 0.5) * ch
+        C = np.stack(np.meshgrid(cx, cy, indexing="xy"), -1).reshape(-1, 2)            # cell iy * G + ix
+        a, s_ = walls[:, :2], walls[:, 2:] - walls[:, :2]
+        ss = np.maximum((s_ ** 2).sum(1), 1e-300)
+        lam = np.clip(((C[:, None, :] - a[None]) * s_[None]).sum(-1) / ss[None], 0.0, 1.0)
+        d = np.linalg.norm(C[:, None, :] - (a[None] + lam[..., None] * s_[None]), axis=-1)   # [cells, walls]
+        r = 0.5 * np.hypot(cw, ch) * (1 + 1e-6) + 1e-6 * max(e1 - e0, e3 - e2)
+        upper = (d + r).min(1, keepdims=True)                       # some wall is at most this far from every point of the cell
+        near = (d - r) <= np.maximum(upper, wd * (1 + 1e-5)) + 1e-9
+        coll = (d - r) <= lmax + 1e-9
+        bits = (1 << np.arange(len(walls), dtype=np.uint64))
+        tab = np.stack(((near * bits).sum(1, dtype=np.uint64), (coll * bits).sum(1, dtype=np.uint64)), -1)
+        out = (torch.from_numpy(tab.view(np.int64).copy()).to(device), G, float(wd), float(lmax))
+        self._device_cache[slot] = (key, out)
+        return out
+
     def device_tables(self, device):
         """(RiabEnv struct, walls tensor): device copy of the wall table in the
         layout include/riab_hip.h documents.  Rebuilt when `walls` changed."""

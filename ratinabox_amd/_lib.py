@@ -38,7 +38,9 @@ class RiabMotion(C.Structure):
                 ("rot_drift_kw", C.c_double), ("speed_theta_kw", C.c_double), ("speed_sigma_kw", C.c_double),
                 ("speed_mean_kw", C.c_double), ("speed_mean", C.c_double), ("speed_std_is_zero", C.c_int32),
                 ("has_drift", C.c_int32), ("drift_theta", C.c_double), ("wall_repel_strength_kw", C.c_double),
-                ("wall_repel_distance_kw", C.c_double), ("thigmotaxis_kw", C.c_double), ("hd_tau", C.c_double)]
+                ("wall_repel_distance_kw", C.c_double), ("thigmotaxis_kw", C.c_double), ("hd_tau", C.c_double),
+                ("wall_grid", C.c_void_p), ("wall_grid_n", C.c_int32), ("wall_grid_wd", C.c_double),
+                ("wall_grid_lmax", C.c_double)]
 
 
 class RiabRateIO(C.Structure):
@@ -124,6 +126,7 @@ CTRL_STARTED, CTRL_TIMEOUTS, CTRL_ABORT, CTRL_SERIALISED, CTRL_STAMPS, CTRL_TRAJ
 STEP1_SYNC_STRIDE, STEP1_SYNC_TAIL, STEP1_SYNC_TIMEOUTS = 64, 16, 0   # riab_hip.h RIAB_STEP1_SYNC_*
 STEP1_SYNC_FIRST_BAD, STEP1_SYNC_LAST_BAD, STEP1_SYNC_FATAL = 1, 2, 3
 STEP1_MAX_POPS = 4                                                      # csrc/riab_device.h RIAB_STEP1_MAX_POPS
+WALL_GRID_MAX = 16                                                      # riab_hip.h RIAB_WALL_GRID_MAX
 CU_PROBE_WORDS = 4097                                                   # riab_hip.h RIAB_CU_PROBE_WORDS
 STEP1_MAIL_STRIDE = 1088                                                # riab_hip.h RIAB_STEP1_MAIL_STRIDE
 

@@ -438,7 +438,43 @@ struct MotionConst {
   R bxl, bxr, byb, byt;  // box fast path: the room's edges
   int nw;
   Wall<R> w4[4];         // the first four walls (the box itself when boundaries are solid), in registers
+  // the broad phase of the wall loops (RiabMotion.wall_grid), staged in LDS by the kernel; null: every wall, every step
+  const uint64_t* grid;
+  int gn;
+  R g_ix, g_iy, g_lmax2;
 };
+#define RIAB_WALL_GRID_WORDS (2 * RIAB_WALL_GRID_MAX * RIAB_WALL_GRID_MAX)
+
+// RiabMotion.wall_grid -> LDS (4 KB), by `nthreads` threads; the caller's barrier follows
+__device__ __forceinline__ void stage_wall_grid(const AgentArgs& a, uint64_t* s_grid, int tid, int nthreads) {
+  if (!a.m.wall_grid) return;
+  const int n = 2 * a.m.wall_grid_n * a.m.wall_grid_n;
+  for (int i = tid; i < n && i < RIAB_WALL_GRID_WORDS; i += nthreads) s_grid[i] = a.m.wall_grid[i];
+}
+// ... and into the step's constants (after motion_const_scalars): used only where it is valid for this launch — float64
+// steps, a repel distance the masks were built for, a solid (non-periodic-wrapping is fine: walls do not wrap) extent
+template <class R>
+__device__ __forceinline__ void motion_const_grid(MotionConst<R>& k, const AgentArgs& a, const uint64_t* s_grid) {
+  const bool ok = sizeof(R) == 8 && s_grid && a.m.wall_grid && a.m.wall_grid_n > 0 && a.m.wall_grid_n <= RIAB_WALL_GRID_MAX &&
+                  (double)k.wd <= a.m.wall_grid_wd && k.nw > 4;  // (the masks' margin covers the near test's own: wd2 = wd^2 * 1.000001)
+  k.grid = ok ? s_grid : nullptr;
+  k.gn = a.m.wall_grid_n;
+  k.g_ix = (R)((double)a.m.wall_grid_n / (a.e1 - a.e0));
+  k.g_iy = (R)((double)a.m.wall_grid_n / (a.e3 - a.e2));
+  k.g_lmax2 = (R)(a.m.wall_grid_lmax * a.m.wall_grid_lmax);
+}
+// the walls cell (px, py)'s mask `which` names (0: nearest / within the repel distance, 1: within a short step); a point
+// outside the extent (or NaN): every wall
+template <class R>
+__device__ __forceinline__ uint64_t wall_grid_mask(const MotionConst<R>& k, R px, R py, int which) {
+  const uint64_t all = k.nw >= 64 ? ~0ull : ((1ull << k.nw) - 1ull);
+  const bool inside = px >= k.e0 && px <= k.e1 && py >= k.e2 && py <= k.e3;
+  int ix = (int)((px - k.e0) * k.g_ix), iy = (int)((py - k.e2) * k.g_iy);
+  ix = ix < 0 ? 0 : (ix >= k.gn ? k.gn - 1 : ix);
+  iy = iy < 0 ? 0 : (iy >= k.gn ? k.gn - 1 : iy);
+  const uint64_t m = k.grid[2 * (iy * k.gn + ix) + which];
+  return inside ? (m & all) : all;
+}
 
 // The constants of a launch in two parts: the scalars, functions of the motion parameters and the extent alone — also
 // evaluated on the HOST for the one-launch step (riab_step1.hip), where a per-thread evaluation would be paid on every
@@ -466,6 +502,9 @@ __host__ __device__ __forceinline__ void motion_const_scalars(MotionConst<R>& k,
   // divisions by loop constants become multiplications (<= 1 ulp from the reference's quotient)
   k.inv_dt = (R)(1.0 / m.dt);
   k.wd2 = k.wd * k.wd * (R)1.000001;
+  k.grid = nullptr;
+  k.gn = 0;
+  k.g_ix = k.g_iy = k.g_lmax2 = (R)0;
 }
 
 template <class R>
@@ -511,10 +550,11 @@ __device__ __forceinline__ void motion_const_walls(MotionConst<R>& k, const Agen
 }
 
 template <class R>
-__device__ __forceinline__ MotionConst<R> make_motion_const(const AgentArgs& a, const Wall<R>* s_w) {
+__device__ __forceinline__ MotionConst<R> make_motion_const(const AgentArgs& a, const Wall<R>* s_w, const uint64_t* s_grid = nullptr) {
   MotionConst<R> k;
   motion_const_scalars<R>(k, a);
   motion_const_walls<R>(k, a, s_w);
+  motion_const_grid<R>(k, a, s_grid);
   return k;
 }
 
@@ -599,7 +639,24 @@ __device__ __forceinline__ NearWalls<R> walls_pass1(const MotionConst<R>& k, con
     };
     // the first four walls (the box itself when boundaries are solid) live in registers for the
     // whole launch: no LDS round trip per step for the common open-box case
-    if (k.box_fast) {
+    if (k.grid) {
+      // Wall-heavy rooms (RiabMotion.wall_grid): only the walls that can be the nearest one of, or within the repel
+      // distance of, a point of this lane's cell — a lane walks the set bits of ITS mask in ascending order (its wall from
+      // LDS by a per-lane index); the minimum and the near set are those of the full loop, bit for bit (a minimum and a
+      // union do not depend on the order, and the walls left out can contribute to neither).
+      uint64_t m = wall_grid_mask<R>(k, px, py, 0);
+      if (k.box_fast) {
+        box_pass1<R>(k, px, py, n);
+        m &= ~0xFull;
+      }
+      while (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+        if (m) {
+          const int w = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          pass1(s_w[w], w);
+        }
+      }
+    } else if (k.box_fast) {
       box_pass1<R>(k, px, py, n);
       for (int w = 4; w < nw; ++w) pass1(s_w[w], w);
     } else if (nw >= 4) {  // one uniform test instead of four (each a spilled 64-bit mask read back per step)
@@ -675,8 +732,8 @@ __device__ __forceinline__ void handle_collisions(const MotionConst<R>& k, const
     for (; it < RIAB_MAX_BOUNCES; ++it) {
       const R sbx = px - ppx, sby = py - ppy;  // the step (list b), walls are list a
       int hit = -1;
-      for (int w = 0; w < nw; ++w) {
-        const Wall<R> W = s_w[w];
+      auto crosses = [&](const Wall<R>& W) -> bool {
+        RIAB_EXACT_FP
         const R d0x = ppx - W.ax, d0y = ppy - W.ay;
         const R den_a = r_fma(W.sx, -sby, W.sy * sbx);
         const R num_a = r_fma(d0x, -sby, d0y * sbx);
@@ -685,7 +742,22 @@ __device__ __forceinline__ void handle_collisions(const MotionConst<R>& k, const
         // 0 < num/den < 1 by sign logic (den == 0: +-inf / NaN in NumPy -> no hit)
         const bool ia = (den_a > 0) ? (num_a > 0 && num_a < den_a) : (den_a < 0 ? (num_a < 0 && num_a > den_a) : false);
         const bool ib = (den_b > 0) ? (num_b > 0 && num_b < den_b) : (den_b < 0 ? (num_b < 0 && num_b > den_b) : false);
-        if (ia && ib && hit < 0) hit = w;  // first colliding wall = lowest index
+        return ia && ib;
+      };
+      if (k.grid) {
+        // (wall-heavy rooms: a step of at most the masks' length from prev_pos can only cross the walls of prev_pos's
+        // cell's second mask; a longer step looks at every wall.  Ascending order: the first hit IS the lowest index)
+        uint64_t m = norm2(sbx, sby) <= k.g_lmax2 ? wall_grid_mask<R>(k, ppx, ppy, 1) : (nw >= 64 ? ~0ull : ((1ull << nw) - 1ull));
+        while (__builtin_amdgcn_ballot_w64(m != 0 && hit < 0) != 0) {
+          if (m != 0 && hit < 0) {
+            const int w = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (crosses(s_w[w])) hit = w;
+          }
+        }
+      } else {
+        for (int w = 0; w < nw; ++w)
+          if (crosses(s_w[w]) && hit < 0) hit = w;  // first colliding wall = lowest index
       }
       if (hit < 0) break;
       const Wall<R> W = s_w[hit];
@@ -951,6 +1023,8 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
   const lds_cf64_ptr lds_g = (lds_cf64_ptr)s_g, lds_h = (lds_cf64_ptr)s_h;
   const glb_cf64_ptr glb_g = (glb_cf64_ptr)&riab_g_table[0][0], glb_h = (glb_cf64_ptr)&riab_h_table[0][0];
   stage_walls<R>(a, s_w, lane, 64);
+  __shared__ uint64_t s_grid[RIAB_WALL_GRID_WORDS];  // (wall-heavy rooms: RiabMotion.wall_grid)
+  stage_wall_grid(a, s_grid, lane, 64);
   __syncthreads();
   const int64_t b = (int64_t)blockIdx.x * 64 + lane;
   if (b >= a.B) return;
@@ -984,7 +1058,7 @@ __device__ __forceinline__ void agent_step_body(const AgentArgs& a) {
   const uint32_t aid = (uint32_t)(a.agent_id0 + b);
 
   // constants of the step
-  const MotionConst<R> K = make_motion_const<R>(a, s_w);
+  const MotionConst<R> K = make_motion_const<R>(a, s_w, s_grid);
   const R sm_kw = K.sm_kw;
   const R inv_2s2 = K.inv_2s2;
   const double inv_sm = K.inv_sm;

@@ -287,6 +287,7 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
   __shared__ double s_h[RIAB_H_SEGS * RIAB_H_STRIDE];
   __shared__ __align__(16) float s_row[4][256];  // x, y, head direction x, y of the segment's agents as the history keeps them
   __shared__ float s_z[2][256];                  // the step's two standard normals per agent (drawn by waves 4-7)
+  __shared__ uint64_t s_grid[RIAB_WALL_GRID_WORDS];  // (wall-heavy rooms: RiabMotion.wall_grid)
   __shared__ float s_par[RIAB_S1_WAVES][RIAB_S1_STAGE][64];  // each wave's cell groups' parameters, one per lane and group
   // TASK & 8: the lanes are the agents of ONE world (the writers keep the world's books, below); otherwise every lane is
   // its own replica of the task.  RT / WT: the mode bits of the one or the other (0: not that kind of task)
@@ -425,6 +426,7 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
   stage_rayleigh_tables<NT_>(s_g, s_h, tid);
   for (int i = tid; i < a.n_walls * (int)(sizeof(Wall<double>) / sizeof(double)); i += NT_)
     reinterpret_cast<double*>(s_w)[i] = reinterpret_cast<const double*>(sy.walls)[i];
+  stage_wall_grid(a, s_grid, tid, NT_);
   __syncthreads();
 #ifdef RIAB_STEP1_PROFILE
   if (prof_slot >= 0) {  // (the state must have arrived: its first use would otherwise be timed with the motion step)
@@ -457,6 +459,7 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
     const lds_cf64_ptr lds_g = (lds_cf64_ptr)s_g;
 #pragma unroll
     for (int w = 0; w < 4; ++w) K.w4[w] = s_w[w < K.nw ? w : 0];
+    motion_const_grid<double>(K, a, s_grid);
     K.box_fast = __builtin_amdgcn_readfirstlane((int)box_word) != 0;  // motion_const_walls' verdict ...
     K.bxl = K.box_fast ? K.e0 : 0.0;                                   // ... and its edges: the extent itself when it holds
     K.bxr = K.box_fast ? K.e1 : 0.0;

@@ -170,6 +170,8 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
   // ---- staging by all four waves, one barrier ----
   stage_rayleigh_tables<256>(s_g, s_h, tid);
   stage_walls<R>(a, s_w, tid, 256);
+  __shared__ uint64_t s_grid[RIAB_WALL_GRID_WORDS];  // (wall-heavy rooms: RiabMotion.wall_grid)
+  stage_wall_grid(a, s_grid, tid, 256);
   if (tid < 64) {
     s_v2[tid] = RIAB_T4_SENT;
     s_f[tid] = RIAB_T4_SENT;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void traj4_kernel(const AgentArgs a) {
 
   if (wave == 0) {
     // ================================ wave G: position and velocity ================================================
-    const MotionConst<R> K = make_motion_const<R>(a, s_w);
+    const MotionConst<R> K = make_motion_const<R>(a, s_w, s_grid);
     const R dt = K.dt;
     R px = pre0, py = pre1;
     R vx = pre2, vy = pre3;

@@ -155,6 +155,48 @@ def test_sixty_four_walls_vs_reference(riab):
         riab.Agent(env).update()
 
 
+@pytest.mark.parametrize("path", ["update", "simulate", "plan"])
+def test_wall_grid_broad_phase_changes_no_bit(riab, path):
+    """Rooms of 13 walls and more: the motion kernels look only at the walls their cell's masks name (RiabMotion.wall_grid,
+    Environment.wall_grid).  Against the same kernels looking at every wall (RIAB_NO_WALL_GRID=1): state, history,
+    diagnostics — every bit, through the per-step kernel, the four-wave trajectory kernel and the one-launch step; the
+    comb maze of bench.py's cfg3_64w, fast agents (long steps: some beyond the masks' step length), a drift towards walls."""
+    import os
+    import bench
+
+    def run(no_grid):
+        if no_grid:
+            os.environ["RIAB_NO_WALL_GRID"] = "1"
+        try:
+            np.random.seed(3)
+            env = riab.Environment({"walls": bench.comb_walls(60)})
+            ag = riab.Agent(env, {"n_agents": 1024, "dt": 0.02, "seed": 12, "speed_mean": 0.35, "thigmotaxis": 0.2})
+            pcs = riab.PlaceCells(ag, {"n": 32, "wall_geometry": "euclidean"})
+            drift = np.tile(np.array([[0.6, 0.1]]), (1024, 1))
+            if path == "update":
+                for t in range(60):
+                    ag.update(drift_velocity=drift if t % 3 == 0 else None)
+                    pcs.update()
+            elif path == "simulate":
+                ag.simulate(300)
+            else:
+                plan = ag.make_step_plan(capacity=128)
+                for t in range(100):
+                    plan.step(1, drift_velocity=drift if t % 4 == 0 else None)
+                assert plan.info()["fused_steps"] == 100
+                plan.close()
+            torch.cuda.synchronize()
+            return ag.state_tensor.cpu().numpy(), ag.get_history_tensor().cpu().numpy(), dict(ag.diagnostics), \
+                pcs.get_history_tensors()[0].cpu().numpy()
+        finally:
+            os.environ.pop("RIAB_NO_WALL_GRID", None)
+
+    a, b = run(False), run(True)
+    assert a[2] == b[2] and a[2]["bounces"] > 50, a[2]
+    for x, y in zip((a[0], a[1], a[3]), (b[0], b[1], b[3])):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_bvc_egocentric_vs_reference(riab):
     g = gu.load("rates.npz")
     Ag = riab.Agent(make_env(riab, g["maze_walls"][4:]))

@@ -463,3 +463,39 @@ def test_bench_pins_ranks_to_their_gpus_numa_node(tmp_path, monkeypatch):
     assert bench.bind_rank_to_gpu_numa(0, 1, str(sysfs), apply=False)["binding"] == "none"
     assert bench.bind_rank_to_gpu_numa(0, 1, str(tmp_path / "nothing"), apply=False)["binding"] == "none"
     assert bench._parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11] and bench._format_cpulist([3, 1, 2, 7]) == "1-3,7"
+
+
+def test_wall_grid_masks_are_supersets_of_what_a_step_can_need():
+    """Environment.wall_grid (the broad phase of the motion step in wall-heavy rooms, include/riab_hip.h RiabMotion.wall_grid):
+    for random points of a 64-wall comb maze and of a room of random walls, the cell's first mask holds the nearest wall
+    and every wall within the repel distance, its second mask every wall a step of at most `lmax` from the point crosses —
+    brute force over all walls in float64."""
+    import ratinabox_amd as riab
+    import bench
+    rs = np.random.RandomState(5)
+    rooms = [bench.comb_walls(60), [[list(rs.uniform(0, 1, 2)), list(rs.uniform(0, 1, 2))] for _ in range(40)]]
+    for walls in rooms:
+        env = riab.Environment({"walls": walls})
+        wd, lmax = 0.1, 0.02
+        tab, G, wd_, lmax_ = env.wall_grid("cpu", wd, lmax)
+        tab = tab.numpy().view(np.uint64)
+        W = np.asarray(env.walls, float).reshape(-1, 4)
+        assert tab.shape == (G * G, 2) and (wd_, lmax_) == (wd, lmax) and len(W) <= 64
+        P = rs.uniform(0, 1, (4000, 2))
+        P[:500] = np.clip(np.round(P[:500] * G) / G + rs.choice([-1e-12, 0, 1e-12], (500, 2)), 0, 1)   # on the cell borders
+        a, s_ = W[:, :2], W[:, 2:] - W[:, :2]
+        lam = np.clip(((P[:, None] - a[None]) * s_[None]).sum(-1) / (s_ ** 2).sum(1)[None], 0, 1)
+        d = np.linalg.norm(P[:, None] - (a[None] + lam[..., None] * s_[None]), axis=-1)
+        ix = np.clip((P[:, 0] * G).astype(int), 0, G - 1)
+        iy = np.clip((P[:, 1] * G).astype(int), 0, G - 1)
+        near, coll = tab[iy * G + ix, 0], tab[iy * G + ix, 1]
+        bit = lambda m, w: (m >> np.uint64(w)) & np.uint64(1)   # noqa: E731
+        nearest = d.argmin(1)
+        assert all(bit(near[i], nearest[i]) for i in range(len(P)))
+        for w in range(len(W)):
+            inside = d[:, w] <= wd * (1 + 1e-6)
+            assert bit(near[inside], w).all(), w
+            assert bit(coll[d[:, w] <= lmax], w).all(), w      # (a step of length <= lmax can only cross a wall that close)
+        # the masks do cull: far fewer walls than the room has
+        assert np.mean([bin(int(m)).count("1") for m in near]) < 0.6 * len(W)
+        assert np.mean([bin(int(m)).count("1") for m in coll]) < 0.35 * len(W)
