@@ -39,7 +39,7 @@ def test_library_is_in_tree(L):
 def test_struct_layouts_match_header(L):
     # natural C layout of the three ABI structs on LP64
     assert C.sizeof(L.RiabEnv) == 4 * 8 + 8 + 4 + 4 + 8 + 4 * 4 and L.RiabEnv.polygon.offset == 56
-    assert C.sizeof(L.RiabMotion) == 8 * 8 + 4 + 4 + 5 * 8
+    assert C.sizeof(L.RiabMotion) == 8 * 8 + 4 + 4 + 5 * 8 + 8 + 4 + 4 + 2 * 8 and L.RiabMotion.wall_grid.offset == 112   # (+ wall_grid, n + padding, wd, lmax)
     assert L.RiabRateIO.pos_ld.offset == 32 and L.RiabRateIO.rates.offset == 56
     assert L.RiabRateIO.dt.offset == 80 and L.RiabRateIO.seed.offset == 96
     assert C.sizeof(L.RiabRateIO) == 128

@@ -2,7 +2,7 @@
 # bench command plain and under rocprofv3 (kernel trace + stats), PMC traffic of its dominant kernel (one counter per pass, as
 # MI355X_MICROARCH.md prescribes; never together with a trace domain), the closed-loop forms (one kernel per step), cfg 3 /
 # cfg 5; with a second argument `world`: only the one-world task's kernels, `driver`: only the driver's command.  Everything lands in gpurun_out/<round>_*; the summaries that are judged are copied to profiles/ by hand.
-R=${1:-r05}
+R=${1:-r06}
 exec </dev/null
 O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -48,6 +48,14 @@ run_pmc task WRITE_SIZE --task --steps 256 --warmup 32 --no-cpu-baseline --no-se
 run_pmc task FETCH_SIZE --task --steps 256 --warmup 32 --no-cpu-baseline --no-secondary --repeats 3
 run_trace cfg3 --config cfg3 --no-cpu-baseline --steps 256 --warmup 32
 run_trace cfg5 --config cfg5 --no-cpu-baseline --steps 256 --warmup 32
+# (round 6) the closed loops of cfg 3 / cfg 5 (one step1 kernel + the boundary vector cells per step), the one-world task
+# (one step1_task_kernel per step), cfg 3 in the 64-wall room at 1024 steps (the trajectory kernel's wall loops)
+run_trace cfg3_plan --config cfg3 --plan --no-cpu-baseline --no-secondary --steps 256 --warmup 32
+run_trace cfg5_plan --config cfg5 --plan --no-cpu-baseline --no-secondary --steps 256 --warmup 32
+run_trace task_world --task-world --no-cpu-baseline --no-secondary --steps 256 --warmup 32
+run_trace cfg3_64w --config cfg3_64w --no-cpu-baseline --no-secondary --steps 1024 --warmup 32
+run_trace cfg3_1024 --config cfg3 --no-cpu-baseline --no-secondary --steps 1024 --warmup 32
+run_trace cfg5_1024 --config cfg5 --no-cpu-baseline --no-secondary --steps 1024 --warmup 32
 cd $GRAFT_REPO_ROOT
 python tools/pmc_summary.py $O/${R}_driver_pmc_WRITE_SIZE.csv $O/${R}_driver_pmc_FETCH_SIZE.csv --kernel rate_kernel_gated --units-per-launch 81920 --out $O/${R}_pmc_traffic_driver.json > /dev/null 2>&1 && grep -E '"(hbm_bytes_per_unit|traffic_over_algorithmic_kernel|grid_threads)"' $O/${R}_pmc_traffic_driver.json
 python tools/pmc_summary.py $O/${R}_plan_pmc_WRITE_SIZE.csv $O/${R}_plan_pmc_FETCH_SIZE.csv --kernel step1_kernel --units-per-launch 4096 --out $O/${R}_pmc_traffic_plan.json > /dev/null 2>&1 && grep -E '"(hbm_bytes_per_unit|traffic_over_algorithmic_kernel|grid_threads)"' $O/${R}_pmc_traffic_plan.json
