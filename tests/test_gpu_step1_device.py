@@ -139,3 +139,51 @@ def test_give_ups_in_this_process_are_recovered_on_the_first_host_read(riab):
     assert d2["step1_timeouts_recovered"] == 0
     for a, b in zip(got2, ref):
         np.testing.assert_array_equal(a, b)
+
+
+def test_give_ups_in_the_unchanged_per_step_loop_are_recovered(riab):
+    """The split entry points (the reference's `Ag.update(); PCs.update(); GCs.update()` loop served by the automatic
+    stepper): Agent.update() writes the populations' rows AHEAD; a give-up noticed by a host read BETWEEN the two calls finds
+    rows that are not yet part of the histories — they are discarded, and the populations' own calls recompute them.  Against
+    the eager loop (no plan at all): every row."""
+    import os
+    L = riab._lib
+
+    def loop(auto, spoil):
+        os.environ["RIAB_NO_AUTO_PLAN"] = "0" if auto else "1"
+        old = L.set_option("step1_spin", 22)
+        try:
+            np.random.seed(21)
+            env = riab.Environment()
+            ag = riab.Agent(env, {"n_agents": 4096, "dt": 0.01, "seed": 5})
+            np.random.seed(22)
+            pcs = riab.PlaceCells(ag, {"n": 2048, "wall_geometry": "euclidean"})
+            gcs = riab.GridCells(ag, {"n": 256, "save_spikes": True, "max_fr": 20})
+            reads = []
+            for t in range(40):
+                ag.update()
+                if spoil and t == 20 and ag._plan is not None:   # from here on: an oversized grid and no patience
+                    L.check(L.lib.riab_plan_set_compute_units(ag._plan._h, 8192), "riab_plan_set_compute_units")
+                    L.set_option("step1_spin", 0)
+                if t in (25, 31):
+                    reads.append(np.array(ag.pos))               # a host read between Agent.update() and the populations'
+                pcs.update()
+                gcs.update()
+                if t == 33:
+                    reads.append(np.array(gcs.firingrate))
+            d = ag.diagnostics
+            out = [ag.get_history_tensor().cpu().numpy()] + [x.cpu().numpy() for p in (pcs, gcs) for x in p.get_history_tensors()] + reads
+            fused = ag._plan.info()["fused_steps"] if ag._plan is not None and hasattr(ag._plan, "info") else 0
+            return out, d, fused
+        finally:
+            L.set_option("step1_spin", old)
+            os.environ.pop("RIAB_NO_AUTO_PLAN", None)
+
+    ref, d0, f0 = loop(False, False)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        got, d1, f1 = loop(True, True)
+    assert f0 == 0 and f1 >= 30, (f0, f1)
+    assert d1["step1_timeouts_recovered"] > 0, d1
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
