@@ -410,6 +410,12 @@ typedef struct RiabPopulation {
   const float* inv_norm;     /* bvc */
   const int32_t* cell_rows;  /* bvc direction windows (riab_boundary_vector_cells_windowed) or NULL */
   const int32_t* windows;    /* bvc */
+  /* bvc, step plans only, optional (NULL: none): scratch for the ray exchange of a one-row launch — the workgroups that
+   * share a tile of 64 positions each cast a share of its K rays and read the others' (csrc/riab_bvc.hip).  bvc_xch:
+   * device float32 [B / 64 rounded up][K rounded up to 4][64]; bvc_xch_count: device uint32 [B / 64 rounded up], ZEROED by
+   * the caller when the plan is created (the plan counts its launches against it) */
+  float* bvc_xch;
+  uint32_t* bvc_xch_count;
   const float* objects;      /* ovc */
   const int32_t* object_types; /* ovc */
   int32_t n_objects;         /* ovc */

@@ -170,6 +170,10 @@ class Neurons:
             pop.noise_sigma_dt = float(np.sqrt((2 * float(self.noise_std) ** 2) / (tau * dt))) * dt
         return pop
 
+    def _plan_scratch(self, pop):
+        """What a step plan needs of this population besides its tables (called once per plan, with the plan's
+        RiabPopulation): nothing by default."""
+
     def return_list_of_neurons(self, chosen_neurons="all"):
         """Indices of a selection of cells: "all", an int or digit string (that many, evenly spread),
         "<k>rand" (k at random), or an explicit list / array (reference Neurons.py:779-810)."""
@@ -888,6 +892,17 @@ class BoundaryVectorCells(VectorCells):
                                                         _L.ptr(vm_t), _L.ptr(inv_t), n, 1 if ego else 0, None,
                                                         _L.ptr(rows_t), _L.ptr(win_t), stream)
         _L.check(rc, "riab_boundary_vector_cells")
+
+    def _plan_scratch(self, pop):
+        """A step plan's one-row launches: scratch for the ray exchange between the workgroups that share a tile (riab_hip.h
+        RiabPopulation.bvc_xch); the arrival counters start at zero with every plan."""
+        tiles, Kp = (self._Bp + 63) // 64, (int(pop.K) + 3) // 4 * 4
+        if getattr(self, "_bvc_xch", None) is None or tuple(self._bvc_xch.shape) != (tiles, Kp, 64):
+            self._bvc_xch = torch.empty((tiles, Kp, 64), dtype=torch.float32, device=self._device)
+            self._bvc_xch_count = torch.zeros(tiles, dtype=torch.int32, device=self._device)
+        else:
+            self._bvc_xch_count.zero_()
+        pop.bvc_xch, pop.bvc_xch_count = self._bvc_xch.data_ptr(), self._bvc_xch_count.data_ptr()
 
     def _state_op(self, d):
         from . import ops  # noqa: F401  (registers torch.ops.riab.*)

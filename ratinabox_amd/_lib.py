@@ -61,6 +61,7 @@ class RiabPopulation(C.Structure):
                 ("description", C.c_int32), ("geometry", C.c_int32), ("top_hat_width", C.c_float), ("f0", C.c_float),
                 ("test_dirs", C.c_void_p), ("ray_rden", C.c_void_p), ("K", C.c_int32), ("egocentric", C.c_int32),
                 ("vm_table", C.c_void_p), ("inv_norm", C.c_void_p), ("cell_rows", C.c_void_p), ("windows", C.c_void_p),
+                ("bvc_xch", C.c_void_p), ("bvc_xch_count", C.c_void_p),
                 ("objects", C.c_void_p),
                 ("object_types", C.c_void_p), ("n_objects", C.c_int32), ("walls_occlude", C.c_int32),
                 ("one_sigma_speed", C.c_float), ("targets", C.c_void_p), ("n_anchors", C.c_int32),

@@ -51,6 +51,12 @@ struct BvcArgs {
   const int* win;
   double e0, e1, e2, e3;  // extent
   int rect_room;          // solid rectangular boundary, no holes: the first four walls may be the room's own edges
+  // ray exchange between the workgroups of a tile (gridDim.y > 1; a step plan's one-row launches): null = everybody casts
+  // every ray.  xch: float [tiles][Kp][64]; xch_count: uint32 [tiles], counts arrivals over all launches; xch_target:
+  // the count at which this launch's gridDim.y workgroups of a tile have all published their share
+  float* xch;
+  uint32_t* xch_count;
+  uint32_t xch_target;
 };
 
 typedef const __attribute__((address_space(4))) double* const_f64_ptr;
@@ -120,14 +126,23 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
     box4 = ok && __builtin_amdgcn_ballot_w64(live && !inside) == 0;  // (wave-uniform; the same in every wave of the tile)
   }
   const int w_full = box4 ? 4 : 0;  // walls from here on take the full (l_a, l_b) test
+  // Which rays THIS workgroup casts: all of them — or, where the tile's gridDim.y workgroups exchange their rays (a.xch),
+  // every gridDim.y-th batch: `vw` of `nvw` virtual waves.  (The whole of stage A is the lambda `cast_rays`; a workgroup
+  // whose partners do not show up casts the rest itself.)
+  auto cast_rays = [&](const int vw, const int nvw, const bool publish) {
+  float* const xrow = publish ? a.xch + (int64_t)blockIdx.x * a.Kp * 64 + lane : nullptr;
+  auto put = [&](int k, float d) {
+    s_d[k * 64 + lane] = d;
+    if (publish) __hip_atomic_store((__attribute__((address_space(1))) float*)(uintptr_t)(xrow + k * 64), d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   // rays without a partner (see below), `count` of them: table index 0 for t = 0, t + off otherwise
   auto cast_single = [&](int count, int off) {
-    for (int t0 = wave; t0 < count; t0 += 8 * KB) {
+    for (int t0 = vw; t0 < count; t0 += nvw * KB) {
       double ux[KB], uy[KB], best[KB], fallback[KB];
       int kk[KB];
 #pragma unroll
       for (int i = 0; i < KB; ++i) {
-        const int t = min(t0 + 8 * i, count - 1);  // (wave-uniform; a clamped duplicate is computed but not stored)
+        const int t = min(t0 + nvw * i, count - 1);  // (wave-uniform; a clamped duplicate is computed but not stored)
         kk[i] = t == 0 ? 0 : t + off;
         ux[i] = dirs[2 * kk[i]];
         uy[i] = dirs[2 * kk[i] + 1];
@@ -163,11 +178,11 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < KB; ++i) {
-        if (t0 + 8 * i < count) {
+        if (t0 + nvw * i < count) {
           const int k = kk[i];
           const float d = (float)((best[i] < INFINITY) ? best[i] : fallback[i]);
-          s_d[k * 64 + lane] = d;
-          if (a.ray_out && live && blockIdx.y == 0) a.ray_out[(t * K + k) * a.B + b] = d;
+          put(k, d);
+          if (a.ray_out && live && (publish || blockIdx.y == 0)) a.ray_out[(t * K + k) * a.B + b] = d;
         }
       }
     }
@@ -191,12 +206,12 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
     paired = __builtin_amdgcn_ballot_w64(!ok) == 0;  // (wave-uniform, and the same in every wave)
   }
   if (paired) {
-    for (int q0 = wave; q0 < np; q0 += 8 * KB) {
+    for (int q0 = vw; q0 < np; q0 += nvw * KB) {
       double ux[KB], uy[KB], bpos[KB], bneg[KB], fallback[KB];
       int jj[KB];
 #pragma unroll
       for (int i = 0; i < KB; ++i) {
-        jj[i] = 1 + min(q0 + 8 * i, np - 1);
+        jj[i] = 1 + min(q0 + nvw * i, np - 1);
         ux[i] = dirs[2 * jj[i]];
         uy[i] = dirs[2 * jj[i] + 1];
         bpos[i] = INFINITY;  // nearest hit along +u ...
@@ -236,13 +251,13 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < KB; ++i) {
-        if (q0 + 8 * i < np) {
+        if (q0 + nvw * i < np) {
           const int k = jj[i];
           const float dp = (float)((bpos[i] < INFINITY) ? bpos[i] : fallback[i]);
           const float dn = (float)((bneg[i] < INFINITY) ? bneg[i] : -fallback[i]);
-          s_d[k * 64 + lane] = dp;
-          s_d[(k + m) * 64 + lane] = dn;
-          if (a.ray_out && live && blockIdx.y == 0) {
+          put(k, dp);
+          put(k + m, dn);
+          if (a.ray_out && live && (publish || blockIdx.y == 0)) {
             a.ray_out[(t * K + k) * a.B + b] = dp;
             a.ray_out[(t * K + k + m) * a.B + b] = dn;
           }
@@ -252,6 +267,48 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
     cast_single(1 + (m - np), np);  // table index 0 (the duplicated first direction) and np + 1 .. m
   } else {
     cast_single(K, 0);
+  }
+  };  // cast_rays
+  const bool exchange = a.xch != nullptr && gridDim.y > 1;
+  if (!exchange) {
+    cast_rays(wave, 8, false);
+  } else {
+    // ---- a tile's workgroups share stage A: each casts every gridDim.y-th batch of rays, publishes them write-through,
+    // announces itself on the tile's counter, and waits — a few tens of microseconds at most — until all have: then the
+    // whole tile comes from the exchange rows (past L1).  Partners that do not show up in time (a device that does not
+    // hold the whole grid at once): this workgroup casts every ray itself — the same values either way.
+    cast_rays(wave + 8 * (int)blockIdx.y, 8 * (int)gridDim.y, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's rows have been acknowledged)
+    __syncthreads();
+    __shared__ int s_all_here;
+    if (tid == 0) {
+      typedef __attribute__((address_space(1))) uint32_t gu32;
+      gu32* const cnt = (gu32*)(uintptr_t)(a.xch_count + blockIdx.x);
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int ok = 0;
+      for (int spins = 0; spins < 256; ++spins) {  // (~0.3 us per poll)
+        if ((int32_t)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.xch_target) >= 0) {
+          ok = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      s_all_here = ok;
+    }
+    __syncthreads();
+    if (s_all_here) {
+      const float* const x = a.xch + (int64_t)blockIdx.x * a.Kp * 64;
+      for (int i = tid; i < K * 16; i += 512) {  // 16 bytes per thread and pass
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
+        gu64* const g = (gu64*)(uintptr_t)(x + 4 * i);
+        const unsigned long long lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<unsigned long long*>(s_d + 4 * i) = lo;
+        *reinterpret_cast<unsigned long long*>(s_d + 4 * i + 2) = hi;
+      }
+    } else {
+      cast_rays(wave, 8, false);
+    }
   }
   // pad rows: an infinite distance makes the term exp2(-inf) = 0 for any (finite or -inf) table entry
   for (int k = K + wave; k < a.Kp; k += 8) s_d[k * 64 + lane] = INFINITY;
@@ -384,6 +441,11 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
   }
 }
 
+int launch_bvc(const RiabEnv* env, const RiabRateIO* io, const double* test_dirs, const double* ray_rden, int32_t K,
+               const float* cells, const float* vm_table, const float* inv_norm, int32_t n, int32_t egocentric,
+               float* ray_out, const int32_t* cell_rows, const int32_t* windows, float* xch, uint32_t* xch_count,
+               uint32_t* xch_arrivals, int n_cus, hipStream_t stream);
+
 }  // namespace riab
 
 using namespace riab;
@@ -400,6 +462,16 @@ extern "C" int riab_boundary_vector_cells_windowed(const RiabEnv* env, const Ria
                                                    const float* vm_table, const float* inv_norm, int32_t n,
                                                    int32_t egocentric, float* ray_out, const int32_t* cell_rows,
                                                    const int32_t* windows, riab_stream_t stream) {
+  return riab::launch_bvc(env, io, test_dirs, ray_rden, K, cells, vm_table, inv_norm, n, egocentric, ray_out, cell_rows, windows,
+                          nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+}
+
+// ... + the ray exchange of a step plan's one-row launches (RiabPopulation.bvc_xch): `xch_launches` counts the plan's
+// launches on `xch_count` (incremented here when the exchange is used), `n_cus` the compute units the plan counts on
+int riab::launch_bvc(const RiabEnv* env, const RiabRateIO* io, const double* test_dirs, const double* ray_rden, int32_t K,
+                     const float* cells, const float* vm_table, const float* inv_norm, int32_t n, int32_t egocentric,
+                     float* ray_out, const int32_t* cell_rows, const int32_t* windows, float* xch, uint32_t* xch_count,
+                     uint32_t* xch_arrivals, int n_cus, hipStream_t stream) {
   if ((cell_rows == nullptr) != (windows == nullptr)) return RIAB_EINVAL;
   if (windows && (egocentric || K % 4 != 0)) return RIAB_EUNSUPPORTED;
   if (!env || !io || !test_dirs || !ray_rden || !cells || !vm_table || !inv_norm || n <= 0 || K <= 0) return RIAB_EINVAL;
@@ -456,6 +528,26 @@ extern "C" int riab_boundary_vector_cells_windowed(const RiabEnv* env, const Ria
   int split = 1;
   while (split < 8 && tiles * split * 2 <= 512 && split * 2 * 8 <= n_groups) split *= 2;
   const dim3 grid((unsigned)tiles, (unsigned)split);
+  // The exchange: the tile's workgroups each cast every split-th batch of rays and read the others' — in a room of many
+  // walls stage A is most of a one-row launch and was cast `split` times over.
+  // Only where the whole grid is resident at once (three of these workgroups fit a compute unit; a workgroup whose partners
+  // do not show up within ~50 us casts everything itself, so a wrong guess costs time, not correctness).
+  a.xch = nullptr;
+  a.xch_count = nullptr;
+  a.xch_target = 0u;
+  // (not inside a stream capture: a replayed launch would meet a counter that has already passed its target)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = xch && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  // ... and only in rooms with interior walls: in an open box stage A is the four edges' fast path and the exchange costs more
+  // than it saves ([MI355X] closed-loop step, with / without: cfg 5 (4 walls) 88.6 / 83.4 us, cfg 3 (9 walls) 55.9 / 58.0,
+  // cfg3_64w (64 walls) 95 / 184)
+  if (xch && xch_count && xch_arrivals && !capturing && split > 1 && io->T == 1 && n_cus > 0 && env->n_walls >= 8 &&
+      tiles * split <= 2 * (int64_t)n_cus) {
+    *xch_arrivals += (uint32_t)split;
+    a.xch = xch;
+    a.xch_count = xch_count;
+    a.xch_target = *xch_arrivals;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (egocentric) {
     if (lds > 64 * 1024)

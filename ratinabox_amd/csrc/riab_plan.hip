@@ -30,6 +30,12 @@ int launch_motion_world(const AgentArgs& ma, const RiabEnv* env, const RiabTask*
                         const double* pos_x, const double* pos_y, int64_t task_B, double t_env, double* reward_out,
                         uint8_t* terminal_out, uint64_t* met, int32_t* cand, int32_t* ctl, int32_t* diag, hipStream_t s);
 
+// boundary vector cells with the ray exchange of one-row launches (riab_bvc.hip)
+int launch_bvc(const RiabEnv* env, const RiabRateIO* io, const double* test_dirs, const double* ray_rden, int32_t K,
+               const float* cells, const float* vm_table, const float* inv_norm, int32_t n, int32_t egocentric,
+               float* ray_out, const int32_t* cell_rows, const int32_t* windows, float* xch, uint32_t* xch_count,
+               uint32_t* xch_arrivals, int n_cus, hipStream_t stream);
+
 // the one-launch step (riab_step1.hip)
 int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B);
 int launch_step1(const AgentArgs& a, const RiabEnv* env, const Step1PopRef* refs, int n_pops, uint64_t seed, uint64_t step_after,
@@ -92,6 +98,7 @@ struct RiabPlan {
   int64_t fused_steps, launches;
   // split entry points: riab_plan_step_agent wrote the rows of step `pre_step` of the populations flagged in
   // `pre_pending` ahead; a row nobody claimed (riab_plan_step_population) is a miss of its population
+  std::vector<uint32_t> xch_arrivals;  // per population: arrivals its ray-exchange launches have asked of bvc_xch_count so far
   std::vector<char> pre_pending;  // per population
   uint64_t pre_step;
   std::vector<int> pre_misses;    // per population, in a row
@@ -473,10 +480,17 @@ static int launch_population(RiabPlan* p, size_t i, const float* row, hipStream_
     case RIAB_POP_RANDOM_SPATIAL:
       rc = riab_random_spatial_neurons(&p->env, &io, q.table, q.n_anchors, q.targets, q.n, q.geometry, s);
       break;
-    case RIAB_POP_BVC:
-      rc = riab_boundary_vector_cells_windowed(&p->env, &io, q.test_dirs, q.ray_rden, q.K, q.table, q.vm_table,
-                                               q.inv_norm, q.n, q.egocentric, nullptr, q.cell_rows, q.windows, s);
+    case RIAB_POP_BVC: {
+      if (p->n_cus <= 0) {  // (nobody said: the device's own count)
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 1;
+        p->n_cus = n;
+      }
+      if (p->xch_arrivals.size() < p->pops.size()) p->xch_arrivals.resize(p->pops.size(), 0u);
+      rc = riab::launch_bvc(&p->env, &io, q.test_dirs, q.ray_rden, q.K, q.table, q.vm_table, q.inv_norm, q.n, q.egocentric,
+                            nullptr, q.cell_rows, q.windows, q.bvc_xch, q.bvc_xch_count, &p->xch_arrivals[i], p->n_cus, s);
       break;
+    }
     case RIAB_POP_OVC:
       rc = riab_object_vector_cells(&p->env, &io, q.objects, q.object_types, q.n_objects, q.table, q.n, q.walls_occlude,
                                     q.egocentric, s);

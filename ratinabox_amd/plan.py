@@ -195,6 +195,7 @@ class StepPlan:
         index = {}
         for N in self.neurons:
             pop = N._population(index)
+            N._plan_scratch(pop)
             index[N] = len(index)
             idx = _L.lib.riab_plan_add(self._h, pop)
             if idx < 0:
@@ -445,6 +446,7 @@ class AutoStepper:
         self._index, self._pops, self._keys = {}, [], []
         for N in self.neurons:
             pop = N._population(self._index)          # (raises NotImplementedError for populations a plan cannot hold)
+            N._plan_scratch(pop)
             idx = _L.lib.riab_plan_add(self._h, pop)
             if idx < 0:
                 raise _L.RiabError(f"riab_plan_add failed: {_L.strerror(idx)}")

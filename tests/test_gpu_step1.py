@@ -319,3 +319,44 @@ def test_cfg2_shape_one_launch_per_step(riab):
     _same(a, b)
     assert (a["traj"][:, :2] > 0).all() and (a["traj"][:, :2] < 1).all()
     assert a["fr0"].min() >= 0 and a["fr0"].max() <= 1
+
+
+@pytest.mark.parametrize("walls", ["maze", "comb"])
+def test_boundary_vector_cells_ray_exchange_in_a_plan_changes_no_bit(riab, walls):
+    """A step plan's one-row BVC launches in rooms with interior walls: the workgroups that share a tile each cast a share of
+    its rays and read the others' through the exchange rows (csrc/riab_bvc.hip, RiabPopulation.bvc_xch).  Against the eager
+    per-step loop (`Ag.update(); N.update()` with the automatic plan off: every workgroup casts every ray): every rate."""
+    import os
+    import bench
+
+    def run(plan):
+        os.environ["RIAB_NO_AUTO_PLAN"] = "1"
+        try:
+            np.random.seed(8)
+            env = riab.Environment({"walls": MAZE if walls == "maze" else bench.comb_walls(60)})
+            ag = riab.Agent(env, {"n_agents": 1024, "dt": 0.01, "seed": 3})
+            np.random.seed(9)
+            pops = [riab.GridCells(ag, {"n": 64}), riab.BoundaryVectorCells(ag, {"n": 96, "save_spikes": True, "max_fr": 20}),
+                    riab.BoundaryVectorCells(ag, {"n": 40, "reference_frame": "egocentric"})]
+            if plan:
+                p = ag.make_step_plan(capacity=16)
+                for _ in range(40):
+                    p.step()
+                p.close()
+                p = ag.make_step_plan(capacity=16)       # (a second plan on the same scratch: its counters start over)
+                for _ in range(10):
+                    p.step()
+                p.close()
+            else:
+                for _ in range(50):
+                    ag.update()
+                    for q in pops:
+                        q.update()
+            torch.cuda.synchronize()
+            return [x.cpu().numpy() for q in pops for x in q.get_history_tensors()] + [ag.get_history_tensor().cpu().numpy()]
+        finally:
+            os.environ.pop("RIAB_NO_AUTO_PLAN", None)
+
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
