@@ -184,6 +184,9 @@ struct Step1Task {
 #ifndef RIAB_S1_TASK_DROP
 #define RIAB_S1_TASK_DROP 0
 #endif
+#ifndef RIAB_S1_FEW
+#define RIAB_S1_FEW 1  // a task's second pass over the quads a reset moved: s1_group_few (0: the whole pass again, stored by those quads)
+#endif
 #ifndef RIAB_S1_WAVES_PER_EU
 #define RIAB_S1_WAVES_PER_EU 2
 #endif
@@ -228,19 +231,81 @@ __device__ __forceinline__ void s1_group(const Cell& cell, const Step1Pops& ps, 
     }
   }
 }
+// ... for a FEW of the segment's quads only (a task's reset has moved an agent or two of the segment: the quads `mq`, a
+// wave-uniform mask): the other way round — a lane takes ONE cell of the group and one of those quads, 64 / CPB quads to
+// a round, instead of every lane all CPB cells for a quad nobody moved.  The same functor on the same operands, element
+// for element: the same bits (the cell's parameters arrive in a vector register instead of a scalar one).  `rows`: the
+// segment's row in LDS (x, y, head direction x, y: 256 values each) with the moved agents' new positions in;
+// `quad0`: the segment's first quad within the history row.
+// (The quads' positions come from LDS, not from the lanes that hold them: four v_readlane of the elements of one vector
+// value inside this loop came out of the compiler — ROCm 7.2 — as four copies of the first element.)
+typedef const __attribute__((address_space(3))) float* lds_cf32_ptr;
+template <class Cell, int CPB, int SPK, bool NT>
+__device__ __forceinline__ void s1_group_few(const Cell& cell, const Step1Pops& ps, const Step1Pop& q, const int gl, const float cur,
+                                             const lds_cf32_ptr rows, const int64_t B, const uint32_t quad0, unsigned long long mq) {
+  constexpr int NP = Cell::NP;
+  constexpr int QPR = 64 / CPB;  // quads per round
+  typedef const __attribute__((address_space(3))) v4f* lds_cv4f_ptr;
+  const int lane = (int)__lane_id();
+  const int slot = lane / CPB, j = lane - slot * CPB;  // the lane's quad of the round, its cell of the group
+  float p[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+    p[i] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (j * NP + i), __builtin_bit_cast(int, cur)));
+  const int c = gl * CPB + j;
+  RateArgs sa;
+  sa.u_in = nullptr;
+  sa.spikes = q.spikes;
+  sa.tag = q.tag;
+  sa.k0 = ps.k0;
+  sa.k1 = ps.k1;
+  sa.dt = ps.dt;
+  while (mq) {  // (wave-uniform) a round of up to QPR quads
+    int my_quad = -1;
+    for (int t = 0; t < QPR && mq; ++t) {
+      const int l = __ffsll((long long)mq) - 1;
+      mq &= mq - 1;
+      my_quad = (slot == t) ? l : my_quad;
+    }
+    const int rq = my_quad < 0 ? 0 : my_quad;
+    const v4f cx = *(lds_cv4f_ptr)(rows + 4 * rq), cy = *(lds_cv4f_ptr)(rows + 256 + 4 * rq);
+    v4f chx = {1.0f, 1.0f, 1.0f, 1.0f}, chy = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ps.needs_hd) {
+      chx = *(lds_cv4f_ptr)(rows + 512 + 4 * rq);
+      chy = *(lds_cv4f_ptr)(rows + 768 + 4 * rq);
+    }
+    const typename Cell::Pos P = cell.from_rows(cx, cy, chx, chy);
+    v4f rr = cell.eval(p, P);
+    rr = finish_rate(rr * q.fr_scale + q.fr_min, P);
+    if (my_quad >= 0 && c < q.n) {
+      const uint32_t quad = quad0 + (uint32_t)my_quad;
+      const int64_t off = (int64_t)c * B + 4 * (int64_t)quad;
+      if (NT) __builtin_nontemporal_store(rr, reinterpret_cast<v4f*>(q.rates + off));
+      else *reinterpret_cast<v4f*>(q.rates + off) = rr;
+      if (SPK && q.spikes) spike_store<false>(sa, rr, off, ps.step0, (uint32_t)c, ps.quad0 + quad);
+    }
+  }
+}
 
 // ... switched into by the population's functor id (wave-uniform)
 // (KIND >= 0: the functor is known when the kernel is compiled — the plan's only population is of that kind)
-template <int SPK, bool NT, bool TASK, int KIND>
+// (FEW: `quad` is the segment's first quad, `mq` the quads to evaluate, `rows` the segment's row in LDS — s1_group_few;
+// otherwise the lane's own quad, its row values and whether it stores)
+template <int SPK, bool NT, bool TASK, int KIND, bool FEW = false>
 __device__ __forceinline__ void s1_group_any(const Step1Pops& ps, const Step1Pop& q, const int gl, const float cur, const v4f rx,
                                              const v4f ry, const v4f rhx, const v4f rhy, const int64_t B, const uint32_t quad,
-                                             const bool store) {
+                                             const bool store, const unsigned long long mq = 0ull,
+                                             const lds_cf32_ptr rows = nullptr) {
+#define RIAB_S1_RUN(CELL, c, hx_, hy_)                                                                                   \
+  if (FEW) s1_group_few<CELL, S1Cpb<CELL, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rows, B, quad, mq);                    \
+  else s1_group<CELL, S1Cpb<CELL, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, hx_, hy_, B, quad, store);
 #define RIAB_S1_PC(DESC, GX, ID)                                                                                        \
   case ID: {                                                                                                            \
-    PlaceCell<DESC, GX> c;                                                                                              \
+    typedef PlaceCell<DESC, GX> CellT;                                                                                  \
+    CellT c;                                                                                                            \
     c.tab = q.tab; c.scale = q.p0; c.half_scale = q.p1; c.top_hat_w2 = q.p2;                                            \
     c.walls = nullptr; c.n_internal = 0; c.lds = nullptr;                                                               \
-    s1_group<PlaceCell<DESC, GX>, S1Cpb<PlaceCell<DESC, GX>, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, rhx, rhy, B, quad, store); \
+    RIAB_S1_RUN(CellT, c, rhx, rhy)                                                                                     \
     break;                                                                                                              \
   }
   switch (KIND >= 0 ? KIND : q.kind) {
@@ -253,26 +318,30 @@ __device__ __forceinline__ void s1_group_any(const Step1Pops& ps, const Step1Pop
     RIAB_S1_PC(RIAB_PC_DIFF_OF_GAUSSIANS, 3, 6)
     RIAB_S1_PC(RIAB_PC_TOP_HAT, 3, 7)
     case S1_KIND_GC + RIAB_GC_RECTIFIED: {
-      const GridCell<RIAB_GC_RECTIFIED> c{q.tab, q.p0, q.p1};
-      s1_group<GridCell<RIAB_GC_RECTIFIED>, S1Cpb<GridCell<RIAB_GC_RECTIFIED>, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, rhx, rhy, B, quad, store);
+      typedef GridCell<RIAB_GC_RECTIFIED> CellT;
+      const CellT c{q.tab, q.p0, q.p1};
+      RIAB_S1_RUN(CellT, c, rhx, rhy)
       break;
     }
     case S1_KIND_GC + RIAB_GC_SHIFTED: {
-      const GridCell<RIAB_GC_SHIFTED> c{q.tab, q.p0, q.p1};
-      s1_group<GridCell<RIAB_GC_SHIFTED>, S1Cpb<GridCell<RIAB_GC_SHIFTED>, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, rhx, rhy, B, quad, store);
+      typedef GridCell<RIAB_GC_SHIFTED> CellT;
+      const CellT c{q.tab, q.p0, q.p1};
+      RIAB_S1_RUN(CellT, c, rhx, rhy)
       break;
     }
     default: {
-      const HDCell<0> c{q.tab, 0.0f, nullptr, nullptr};
+      typedef HDCell<0> CellT;
+      const CellT c{q.tab, 0.0f, nullptr, nullptr};
       // (the head direction's normalisation — square roots, divisions — is loop-invariant and free of side effects: left
       // alone, the compiler hoists it in front of the switch, where every wave of every population pays for it)
       v4f hx = rhx, hy = rhy;
       asm volatile("" : "+v"(hx.x), "+v"(hx.y), "+v"(hx.z), "+v"(hx.w), "+v"(hy.x), "+v"(hy.y), "+v"(hy.z), "+v"(hy.w));
-      s1_group<HDCell<0>, S1Cpb<HDCell<0>, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, hx, hy, B, quad, store);
+      RIAB_S1_RUN(CellT, c, hx, hy)
       break;
     }
   }
 #undef RIAB_S1_PC
+#undef RIAB_S1_RUN
 }
 
 template <int SPK, bool NT, int TASK, int KIND>
@@ -858,6 +927,27 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
       s1_group_any<SPK, NT, TASK != 0, KIND>(ps, q, g - q.group0, cur, rx, ry, rhx, rhy, B, quad, store);
     }
   };
+  // (a task's step) this wave's cell groups again, for the quads `mq` of the segment alone (s1_group_few) — whose new
+  // positions the lanes that hold them (`moved`) put into the row in LDS first: every wave of the workgroup writes the
+  // same values there, and reads what it wrote itself
+  auto rates_few = [&](const v4f rx, const v4f ry, const bool moved) __attribute__((always_inline)) {
+    const unsigned long long mq = __builtin_amdgcn_ballot_w64(moved);
+    if (moved) {
+      *reinterpret_cast<v4f*>(&s_row[0][4 * lane]) = rx;
+      *reinterpret_cast<v4f*>(&s_row[1][4 * lane]) = ry;
+    }
+    const v4f none = {0.0f, 0.0f, 0.0f, 0.0f};
+    int pi = pi0;
+    Step1Pop q = pick(pi);
+    for (int r = 0; r < reps; ++r) {
+      const int g = g0 + r;
+      if (g >= ps.total_groups) break;  // wave-uniform
+      const float cur = (MINE_REG && r == 0) ? mine : s_par[wave][r][lane];
+      if (MULTI && g >= q.group0 + q.n_groups && pi + 1 < ps.n_pops) q = pick(++pi);
+      s1_group_any<SPK, NT, TASK != 0, KIND, true>(ps, q, g - q.group0, cur, none, none, none, none, B, blockIdx.x * 64u, false, mq,
+                                                   (lds_cf32_ptr)&s_row[0][0]);
+    }
+  };
   if (rates_here)
     rates_pass(*reinterpret_cast<const v4f*>(&s_row[0][4 * lane]), *reinterpret_cast<const v4f*>(&s_row[1][4 * lane]), true);
   RIAB_S1_STAMP(3)
@@ -990,8 +1080,12 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
       // (wave-uniform) this wave's cell groups again for the quads an agent of which was moved: the same pass — the
       // same instructions, hence the same bits as the population's own kernel gives on the patched history row — on
       // the row with the new positions in, stored by the lanes whose quad changed
+      // (... by lanes that take one cell and one moved quad each — usually there is one, seldom more than three — instead
+      // of every lane running all its cells for a quad that did not move: the pass, and the wave's wait for the writer, are
+      // the tail of the step's critical path)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the values this wave stored for those quads a moment ago are in place)
-      rates_pass(rx, ry, mine_moved);
+      if (RIAB_S1_FEW) rates_few(rx, ry, mine_moved);
+      else rates_pass(rx, ry, mine_moved);
     }
     RIAB_S1_STAMP(12)
     if (stale && lane == 0) step1_note_timeout(sy, ps.step0);
@@ -1006,6 +1100,53 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
   }
 #endif
 }
+
+// The kernel's arguments are ~1.4 KB (the populations' records, the motion step's constants, the task's tables): 23
+// lines of the scalar cache, cold at every launch.  Left to the compiler, a workgroup meets them in five or six
+// DEPENDENT rounds of scalar loads in front of its first barrier (load what the next test needs, wait, branch, load
+// ...), each round with a miss in it; one word of every line asked for at entry makes that one round.  [MI355X] a task's
+// step (whose writer reads the most of them): 13.15 -> 12.87 us; the plain step, which meets fewer: + 0.08 us — not there.
+#ifndef RIAB_S1_KERNARG_WARM
+#define RIAB_S1_KERNARG_WARM 1
+#endif
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+#if RIAB_S1_KERNARG_WARM
+  // (ONE statement: the loads' target is a register the compiler may hand to somebody else only behind the wait; the
+  // values are not used — loads that return out of order into the same register harm nobody)
+  static_assert(BYTES > 64 && BYTES <= 26 * 64, "one load per line of the argument block");
+  const auto ka = __builtin_amdgcn_kernarg_segment_ptr();  // (a pointer into the constant address space: a scalar pair)
+  uint32_t t;
+#define RIAB_KA_OFF(i) "i"((64 * (i) < BYTES - 4) ? 64 * (i) : BYTES - 4)
+  asm volatile(
+      "s_load_dword %0, %1, %2\n s_load_dword %0, %1, %3\n s_load_dword %0, %1, %4\n s_load_dword %0, %1, %5\n"
+      "s_load_dword %0, %1, %6\n s_load_dword %0, %1, %7\n s_load_dword %0, %1, %8\n s_load_dword %0, %1, %9\n"
+      "s_load_dword %0, %1, %10\n s_load_dword %0, %1, %11\n s_load_dword %0, %1, %12\n s_load_dword %0, %1, %13\n"
+      "s_load_dword %0, %1, %14\n s_load_dword %0, %1, %15\n s_load_dword %0, %1, %16\n s_load_dword %0, %1, %17\n"
+      "s_load_dword %0, %1, %18\n s_load_dword %0, %1, %19\n s_load_dword %0, %1, %20\n s_load_dword %0, %1, %21\n"
+      "s_load_dword %0, %1, %22\n s_load_dword %0, %1, %23\n s_load_dword %0, %1, %24\n s_load_dword %0, %1, %25\n"
+      "s_load_dword %0, %1, %26\n s_load_dword %0, %1, %27\n s_waitcnt lgkmcnt(0)"
+      : "=&s"(t)
+      : "s"(ka), RIAB_KA_OFF(0), RIAB_KA_OFF(1), RIAB_KA_OFF(2), RIAB_KA_OFF(3), RIAB_KA_OFF(4), RIAB_KA_OFF(5), RIAB_KA_OFF(6),
+        RIAB_KA_OFF(7), RIAB_KA_OFF(8), RIAB_KA_OFF(9), RIAB_KA_OFF(10), RIAB_KA_OFF(11), RIAB_KA_OFF(12), RIAB_KA_OFF(13),
+        RIAB_KA_OFF(14), RIAB_KA_OFF(15), RIAB_KA_OFF(16), RIAB_KA_OFF(17), RIAB_KA_OFF(18), RIAB_KA_OFF(19), RIAB_KA_OFF(20),
+        RIAB_KA_OFF(21), RIAB_KA_OFF(22), RIAB_KA_OFF(23), RIAB_KA_OFF(24), RIAB_KA_OFF(25)
+      : "memory");
+#undef RIAB_KA_OFF
+#endif
+}
+struct Step1KernArgs {  // (the argument block of step1_kernel as the ABI lays it out)
+  AgentArgs a;
+  Step1Pops ps;
+  Step1Sync sy;
+  int reps;
+  MotionConst<double> hk;
+  TailConst<double> tail_c;
+};
+struct Step1TaskKernArgs {
+  Step1KernArgs k;
+  Step1Task tk;
+};
 
 template <int SPK, bool NT, int KIND>
 __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step1_kernel(const AgentArgs a, const Step1Pops ps,
@@ -1022,6 +1163,7 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
                                                                                                 const MotionConst<double> hk,
                                                                                                 const TailConst<double> tail_c,
                                                                                                 const Step1Task tk) {
+  kernarg_warm<(int)sizeof(Step1TaskKernArgs) + 32>();  // (+ the grid's size, the first of the implicit arguments)
   step1_body<SPK, true, TASK, KIND>(a, ps, sy, reps, hk, tail_c, tk);
 }
 

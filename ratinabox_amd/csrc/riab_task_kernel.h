@@ -94,8 +94,10 @@ struct Lane {
   uint64_t met;      // bit `pool index`: the lane stands inside that goal's radius (goals_met, once per step)
 };
 
-// (16 rows are asked for — the count arrives with them — but only as many as the longest list of the wave are packed /
-// written back: a step is one dependent instruction stream, every instruction it does not issue is time)
+// (only as many rows as the longest list of the wave are packed / written back: a step is one dependent instruction
+// stream, every instruction it does not issue is time.  The compiler sinks each row's load behind the test that guards
+// its use — a chain of round trips as long as that list, two entries in the benchmark's task; forcing all 16 loads into
+// ONE batch in front of the loop measured SLOWER, 12.9 -> 13.25 us per one-launch step: docs/EXPERIMENTS.md r06-9)
 __device__ __forceinline__ void load_list(const TaskArgs& a, int64_t b, Lane& L) {
   double rows[RIAB_TASK_MAX_GOALS];
 #pragma unroll
