@@ -431,7 +431,9 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
         float r = (acc2[j].x + acc2[j].y) * a.inv_norm[ci];
         r = r * a.fr_scale + a.fr_min;
         const int64_t off = (t * n + c) * a.B + b;
-        a.rates[off] = r;
+        // (a launch of one row — the closed loop's — writes its values through: riab_device.h, store_stream)
+        if (a.P == a.B) asm volatile("global_store_dword %0, %1, off " RIAB_WT_BITS ::"v"(a.rates + off), "v"(r) : "memory");
+        else a.rates[off] = r;
         if (a.spikes) {
           const float u = a.u_in ? a.u_in[off] : u01_24(word);
           a.spikes[off] = (u < a.dt * r) ? 1 : 0;

@@ -61,6 +61,43 @@ __device__ __forceinline__ u32x4 philox4x32_spikes(uint32_t c0, uint32_t c1, uin
   return philox4x32_r<7>(c0, c1, c2, c3, k0, k1);
 }
 
+// Rows that are written once and not read again by the call that writes them (rates, spikes): streamed.  POLICY
+// RIAB_STORE_NT: nontemporal stores — the lines pass through the L2 marked for early eviction, write-combined there, but
+// what is still dirty when the kernel ends is written back by the dispatch's closing release before the next kernel may
+// start; RIAB_STORE_WT: write-through as well (sc1) — the lines leave for memory while the kernel still runs and nothing
+// is left to flush.  [MI355X, round 6] a kernel that runs for microseconds and is followed by one that needs its results
+// (the one-launch closed-loop step: 16.8 MB of rates in 1.5 us, then the next step) gains 12 % from WT (9.67 -> 8.50 us
+// per step); a kernel that streams for milliseconds (rate_kernel_gated, 1024 rows) loses 9 % to it (1.45 -> 1.32 G
+// agent-steps/s: the L2 no longer combines the lanes' quads into full lines ahead of the memory channel).
+#ifndef RIAB_WT_MODE
+#define RIAB_WT_MODE 3
+#endif
+#if RIAB_WT_MODE == 1
+#define RIAB_WT_BITS "sc1"
+#elif RIAB_WT_MODE == 2
+#define RIAB_WT_BITS "sc0 sc1"
+#else
+#define RIAB_WT_BITS "sc1 nt"
+#endif
+#define RIAB_STORE_NT 0
+#define RIAB_STORE_WT 1
+typedef float riab_v4f __attribute__((ext_vector_type(4)));
+template <int POLICY>
+__device__ __forceinline__ void store_stream(float* p, riab_v4f v) {
+  // (s_nop BEHIND the store: a vector instruction must not write the data registers of a store of more than 64 bits in
+  // the two wait states behind it — the store reads them late.  The compiler pads its own stores and cannot see inside an
+  // asm statement: without the padding the z and w elements of a quad went to memory as whatever the next instruction
+  // made of their registers — tests/test_gpu_parity.py, spike shapes, and test_gpu_fused.py caught it.)
+  if (POLICY == RIAB_STORE_WT)
+    asm volatile("global_store_dwordx4 %0, %1, off " RIAB_WT_BITS "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else __builtin_nontemporal_store(v, reinterpret_cast<riab_v4f*>(p));
+}
+template <int POLICY>
+__device__ __forceinline__ void store_stream(uint32_t* p, uint32_t v) {
+  if (POLICY == RIAB_STORE_WT) asm volatile("global_store_dword %0, %1, off " RIAB_WT_BITS ::"v"(p), "v"(v) : "memory");
+  else __builtin_nontemporal_store(v, p);
+}
+
 // Read-only, wave-uniform tables: a pointer in the constant address space tells the compiler the
 // memory is invariant, so uniform-index reads become scalar loads (s_load_dwordx4 -> SGPR operands)
 // instead of per-lane vector loads.

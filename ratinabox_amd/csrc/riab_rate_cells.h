@@ -61,7 +61,7 @@ template <class P_>
 __device__ __forceinline__ v4f finish_rate(v4f r, const P_&) { return r; }
 
 // ---- spike epilogue: Neurons.save_to_history (reference Neurons.py:681-687) -------------
-template <bool EXPLICIT_U>
+template <bool EXPLICIT_U, int POLICY = RIAB_STORE_NT>
 __device__ __forceinline__ void spike_store(const RateArgs& a, v4f r, int64_t off, uint32_t step, uint32_t c,
                                             uint32_t group) {
   v4f u;
@@ -74,7 +74,7 @@ __device__ __forceinline__ void spike_store(const RateArgs& a, v4f r, int64_t of
   // one fp32 multiply, one fp32 compare: the exactly-specified spike rule
   const uint32_t s = (u.x < a.dt * r.x ? 1u : 0u) | (u.y < a.dt * r.y ? 0x100u : 0u) |
                      (u.z < a.dt * r.z ? 0x10000u : 0u) | (u.w < a.dt * r.w ? 0x1000000u : 0u);
-  __builtin_nontemporal_store(s, reinterpret_cast<uint32_t*>(a.spikes + off));
+  store_stream<POLICY>(reinterpret_cast<uint32_t*>(a.spikes + off), s);
 }
 
 // ---- PlaceCells (reference Neurons.py:936-981, Environment.py:677-779) -------------------

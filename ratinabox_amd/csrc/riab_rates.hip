@@ -23,6 +23,13 @@
 
 #include "riab_device.h"
 #include "riab_rate_cells.h"
+// how the spike bytes of the open-loop kernels are stored (riab_device.h: store_stream)
+#ifndef RIAB_SPIKE_POLICY_GATED
+#define RIAB_SPIKE_POLICY_GATED RIAB_STORE_NT
+#endif
+#ifndef RIAB_SPIKE_POLICY_WIDE
+#define RIAB_SPIKE_POLICY_WIDE RIAB_STORE_NT
+#endif
 
 namespace riab {
 
@@ -59,10 +66,13 @@ __global__ __launch_bounds__(256) void rate_kernel_wide(const RateArgs a, Cell c
       v4f r = cell.eval(p, P);
       r = finish_rate(r * a.fr_scale + a.fr_min, P);  // [0,1] -> [min_fr, max_fr]
       if (live) {
-        if (NT) __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(a.rates + off));
+        // (NT: a launch of ONE row — a population's update() inside a closed loop, kernels that need the result behind it:
+        // streamed and written through, nothing left for the dispatch's closing release to flush, riab_device.h; the
+        // many-row launches of an open-loop run keep ordinary stores: - 4 % at 1024 steps with nontemporal ones)
+        if (NT) store_stream<RIAB_STORE_WT>(a.rates + off, r);
         else *reinterpret_cast<v4f*>(a.rates + off) = r;
-        if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)(c0 + j), group);
-        if (SPK == 2) spike_store<true>(a, r, off, step, (uint32_t)(c0 + j), group);
+        if (SPK == 1) spike_store<false, NT ? RIAB_STORE_WT : RIAB_SPIKE_POLICY_WIDE>(a, r, off, step, (uint32_t)(c0 + j), group);
+        if (SPK == 2) spike_store<true, NT ? RIAB_STORE_WT : RIAB_SPIKE_POLICY_WIDE>(a, r, off, step, (uint32_t)(c0 + j), group);
       }
       off += a.B;
     }
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(256) void rate_kernel_generic(const RateArgs a, Cel
       v4f r = cell.eval(p, P);
       r = finish_rate(r * a.fr_scale + a.fr_min, P);
       if (live) {
-        __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(a.rates + off));
+        store_stream<RIAB_STORE_NT>(a.rates + off, r);
         if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)(cb + j), group);
         if (SPK == 2) spike_store<true>(a, r, off, step, (uint32_t)(cb + j), group);
       }
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(256) void place_one_hot_kernel(const RateArgs a, Pl
     v4f r = {arg[0] == c ? 1.0f : 0.0f, arg[1] == c ? 1.0f : 0.0f, arg[2] == c ? 1.0f : 0.0f,
              arg[3] == c ? 1.0f : 0.0f};
     r = r * a.fr_scale + a.fr_min;
-    __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(a.rates + off));
+    store_stream<RIAB_STORE_NT>(a.rates + off, r);
     if (a.spikes) {
       if (a.u_in) spike_store<true>(a, r, off, step, (uint32_t)c, group);
       else spike_store<false>(a, r, off, step, (uint32_t)c, group);
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) void random_spatial_kernel(const RateArgs a, P
   for (int j = 0; j < RS_CH; ++j) {
     if (c0 + j < a.n) {
       const v4f r = acc[j] / den;  // no position in range of any anchor: 0/0 = NaN, like the reference
-      __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(a.rates + off));
+      store_stream<RIAB_STORE_NT>(a.rates + off, r);
       if (a.spikes) {
         if (a.u_in) spike_store<true>(a, r, off, step, (uint32_t)(c0 + j), group);
         else spike_store<false>(a, r, off, step, (uint32_t)(c0 + j), group);
@@ -396,8 +406,8 @@ __global__ __launch_bounds__(64 * WAVES) void rate_kernel_gated(const RateArgs a
       // write back when the kernel ends.  [MI355X] cfg 2 against ordinary stores: 20 steps: the kernel 57.9 -> 54.4 us,
       // the region 102-104 -> 98-100 us; 64 / 256 steps + 5 / + 6 %.  (The ungated rate_kernel_wide is the other way
       // round: - 4 % at 1024 steps, - 6 % at cfg 4 with nontemporal stores — RIAB_OPT_NT_STORES.)
-      __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(a.rates + off));
-      if (SPK == 1) spike_store<false>(a, r, off, step, (uint32_t)(c0 + j), group);
+      store_stream<RIAB_STORE_NT>(a.rates + off, r);
+      if (SPK == 1) spike_store<false, RIAB_SPIKE_POLICY_GATED>(a, r, off, step, (uint32_t)(c0 + j), group);
       off += a.B;
     }
   }
@@ -529,7 +539,7 @@ static int launch_rate(const RiabRateIO* io, int n, const Cell& cell, hipStream_
   if (a.qrow >= 256 && io->T <= 65535 && (n + kCellsPerGroup - 1) / kCellsPerGroup <= 65535) {
     // address-ordered wide kernel
     const dim3 g((unsigned)((a.qrow + 255) / 256), (unsigned)((n + kCellsPerGroup - 1) / kCellsPerGroup), (unsigned)io->T);
-    if (g_options[RIAB_OPT_NT_STORES]) {  // (A/B: nontemporal stores in the ungated kernel too: slower, see rate_kernel_gated)
+    if (g_options[RIAB_OPT_NT_STORES] || io->T == 1) {  // (streamed, written-through stores: one-row launches; the option: A/B at any length)
       if (!io->spikes) hipLaunchKernelGGL((rate_kernel_wide<Cell, 0, kCellsPerGroup, true>), g, dim3(256), 0, s, a, cell);
       else if (!io->u_in) hipLaunchKernelGGL((rate_kernel_wide<Cell, 1, kCellsPerGroup, true>), g, dim3(256), 0, s, a, cell);
       else hipLaunchKernelGGL((rate_kernel_wide<Cell, 2, kCellsPerGroup, true>), g, dim3(256), 0, s, a, cell);

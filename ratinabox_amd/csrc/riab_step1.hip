@@ -223,9 +223,9 @@ __device__ __forceinline__ void s1_group(const Cell& cell, const Step1Pops& ps, 
       if (store) {
         if (RIAB_S1_ABLATE & 2) {
           if (rr.x == 123.0f) *reinterpret_cast<v4f*>(q.rates + off) = rr;
-        } else if (NT) __builtin_nontemporal_store(rr, reinterpret_cast<v4f*>(q.rates + off));
+        } else if (NT) store_stream<RIAB_STORE_WT>(q.rates + off, rr);
         else *reinterpret_cast<v4f*>(q.rates + off) = rr;
-        if (SPK && q.spikes) spike_store<false>(sa, rr, off, ps.step0, (uint32_t)(c0 + j), ps.quad0 + quad);  // (wave-uniform)
+        if (SPK && q.spikes) spike_store<false, RIAB_STORE_WT>(sa, rr, off, ps.step0, (uint32_t)(c0 + j), ps.quad0 + quad);  // (wave-uniform)
       }
       off += B;
     }
@@ -280,9 +280,9 @@ __device__ __forceinline__ void s1_group_few(const Cell& cell, const Step1Pops& 
     if (my_quad >= 0 && c < q.n) {
       const uint32_t quad = quad0 + (uint32_t)my_quad;
       const int64_t off = (int64_t)c * B + 4 * (int64_t)quad;
-      if (NT) __builtin_nontemporal_store(rr, reinterpret_cast<v4f*>(q.rates + off));
+      if (NT) store_stream<RIAB_STORE_WT>(q.rates + off, rr);
       else *reinterpret_cast<v4f*>(q.rates + off) = rr;
-      if (SPK && q.spikes) spike_store<false>(sa, rr, off, ps.step0, (uint32_t)c, ps.quad0 + quad);
+      if (SPK && q.spikes) spike_store<false, RIAB_STORE_WT>(sa, rr, off, ps.step0, (uint32_t)c, ps.quad0 + quad);
     }
   }
 }
