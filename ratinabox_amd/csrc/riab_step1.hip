@@ -74,16 +74,25 @@ struct Step1Pops {
 // cells per group of a functor: as the row-following kernel, twice the wide kernel's where a wave's 64 lanes hold the
 // parameters; a task's step (15 of a segment's 16 workgroups write rates) a sixteenth more, so that a population that
 // filled one round of workgroups stays one round: cfg 2, 1024 cells: 114 groups of 9 on 15 x 8 waves instead of 128 of 8
-template <class Cell, bool TASK>
+// (SPK — the kernel draws spikes —: a cell then costs its Philox block whatever its functor costs, and a wave's time is its
+// CELLS: HeadDirectionCells, 32 to a group where only stores count, would make the waves that hold them four times as long
+// as a wave of PlaceCells groups — the step kernel of BASELINE configs[4]'s closed loop ran 31.9 us for that —: 8)
+template <class Cell, bool TASK, bool SPK>
 struct S1Cpb {
-  static constexpr int BASE = (Cell::NP * 2 * Cell::CPB <= 64) ? 2 * Cell::CPB : Cell::CPB;
+  static constexpr int WIDE = (Cell::NP * 2 * Cell::CPB <= 64) ? 2 * Cell::CPB : Cell::CPB;
+  static constexpr int BASE = (SPK && WIDE > 8) ? 8 : WIDE;
   static constexpr int T16 = (BASE * 16 + 14) / 15;
   static constexpr int value = (TASK && Cell::NP * T16 <= 64) ? T16 : BASE;
 };
-__host__ __device__ static inline int s1_cpb(int kind, bool task) {
-  if (kind < S1_KIND_GC) return task ? S1Cpb<PlaceCell<0, 0>, true>::value : S1Cpb<PlaceCell<0, 0>, false>::value;
-  if (kind < S1_KIND_HDC) return task ? S1Cpb<GridCell<0>, true>::value : S1Cpb<GridCell<0>, false>::value;
-  return task ? S1Cpb<HDCell<0>, true>::value : S1Cpb<HDCell<0>, false>::value;
+template <class Cell>
+__host__ __device__ static inline int s1_cpb_of(bool task, bool spk) {
+  return task ? (spk ? S1Cpb<Cell, true, true>::value : S1Cpb<Cell, true, false>::value)
+              : (spk ? S1Cpb<Cell, false, true>::value : S1Cpb<Cell, false, false>::value);
+}
+__host__ __device__ static inline int s1_cpb(int kind, bool task, bool spk) {
+  if (kind < S1_KIND_GC) return s1_cpb_of<PlaceCell<0, 0>>(task, spk);
+  if (kind < S1_KIND_HDC) return s1_cpb_of<GridCell<0>>(task, spk);
+  return s1_cpb_of<HDCell<0>>(task, spk);
 }
 __host__ __device__ static inline int s1_np(int kind) { return kind < S1_KIND_GC ? PlaceCell<0, 0>::NP : kind < S1_KIND_HDC ? GridCell<0>::NP : HDCell<0>::NP; }
 
@@ -297,8 +306,8 @@ __device__ __forceinline__ void s1_group_any(const Step1Pops& ps, const Step1Pop
                                              const bool store, const unsigned long long mq = 0ull,
                                              const lds_cf32_ptr rows = nullptr) {
 #define RIAB_S1_RUN(CELL, c, hx_, hy_)                                                                                   \
-  if (FEW) s1_group_few<CELL, S1Cpb<CELL, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rows, B, quad, mq);                    \
-  else s1_group<CELL, S1Cpb<CELL, TASK>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, hx_, hy_, B, quad, store);
+  if (FEW) s1_group_few<CELL, S1Cpb<CELL, TASK, SPK != 0>::value, SPK, NT>(c, ps, q, gl, cur, rows, B, quad, mq);          \
+  else s1_group<CELL, S1Cpb<CELL, TASK, SPK != 0>::value, SPK, NT>(c, ps, q, gl, cur, rx, ry, hx_, hy_, B, quad, store);
 #define RIAB_S1_PC(DESC, GX, ID)                                                                                        \
   case ID: {                                                                                                            \
     typedef PlaceCell<DESC, GX> CellT;                                                                                  \
@@ -470,7 +479,7 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
   };
   auto group_params = [&](const Step1Pop& q, int g) -> float {  // group g (of population q)'s parameters, one per lane
     const int kind = KIND >= 0 ? KIND : q.kind;
-    const int np = s1_np(kind), width = np * s1_cpb(kind, TASK != 0);
+    const int np = s1_np(kind), width = np * s1_cpb(kind, TASK != 0, SPK != 0);
     const int pi = (g - q.group0) * width + lane;
     return (g < ps.total_groups && lane < width && pi < q.n * np) ? q.tab[pi] : 0.0f;
   };
@@ -1207,7 +1216,7 @@ int step1_supported(const RiabEnv* env, const RiabPopulation* pop, int64_t B) {
   }
 }
 
-static int step1_fill_pop(Step1Pop& q, const RiabEnv* env, const Step1PopRef& ref, bool task, int32_t group0) {
+static int step1_fill_pop(Step1Pop& q, const RiabEnv* env, const Step1PopRef& ref, bool task, bool spikes, int32_t group0) {
   const RiabPopulation* pop = ref.pop;
   if (!ref.rates_row) return RIAB_EINVAL;
   if ((((uintptr_t)ref.rates_row) & 15) || (((uintptr_t)ref.spikes_row) & 3)) return RIAB_EALIGN;
@@ -1243,7 +1252,7 @@ static int step1_fill_pop(Step1Pop& q, const RiabEnv* env, const Step1PopRef& re
     case RIAB_POP_HDC: q.kind = S1_KIND_HDC; break;
     default: return RIAB_EUNSUPPORTED;
   }
-  const int cpb = s1_cpb(q.kind, task);
+  const int cpb = s1_cpb(q.kind, task, spikes);  // (`spikes`: of the LAUNCH — the kernel's SPK — not of this population)
   q.group0 = group0;
   q.n_groups = (pop->n + cpb - 1) / cpb;
   return RIAB_OK;
@@ -1272,11 +1281,11 @@ static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const Step1
   ps.quad0 = (uint32_t)(a.agent_id0 / 4);
   int32_t groups = 0;
   bool spikes = false;
+  for (int i = 0; i < n_pops; ++i) spikes = spikes || refs[i].spikes_row != nullptr;
   for (int i = 0; i < n_pops; ++i) {
-    const int rc = step1_fill_pop(ps.pop[i], env, refs[i], tk != nullptr, groups);
+    const int rc = step1_fill_pop(ps.pop[i], env, refs[i], tk != nullptr, spikes, groups);
     if (rc) return rc;
     groups += ps.pop[i].n_groups;
-    spikes = spikes || refs[i].spikes_row != nullptr;
     if (ps.pop[i].kind == S1_KIND_HDC) ps.needs_hd = 1;
   }
   ps.total_groups = groups;
