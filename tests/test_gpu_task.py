@@ -561,11 +561,14 @@ def test_one_launch_task_step_equals_the_two_launch_plan(riab, case):
         assert jumps > 0.05
 
 
-@pytest.mark.parametrize("batch", [1, 7])
-def test_one_launch_task_step_with_other_populations_and_batches(riab, batch):
-    """The lead population rides in the task step's kernel, the others (a smaller store-bound one, boundary vector
-    cells) follow as their own kernels on the row the reset patched; `plan.step(batch)` issues `batch` such steps from
-    one native call.  Against the two-launch plan, every population, bit for bit."""
+@pytest.mark.parametrize("batch,radius,all_spikes", [(1, None, False), (7, None, False), (1, 0.3, True), (3, 0.35, True)])
+def test_one_launch_task_step_with_other_populations_and_batches(riab, batch, radius, all_spikes):
+    """The store-bound populations ride in the task step's kernel, the others (boundary vector cells) follow as their own
+    kernels on the row the reset patched; `plan.step(batch)` issues `batch` such steps from one native call.  Against the
+    two-launch plan, every population, bit for bit.
+    `radius`: one goal a third of the room wide per episode, no delay — dozens of lanes of a segment end an episode in the same step, so the rate
+    workgroups' second pass (one cell and one moved quad to a lane, seven quads to a round: s1_group_few) runs several
+    rounds; `all_spikes`: every population draws spikes (the kernel's groups are then eight cells for every functor)."""
     from ratinabox_amd.contribs.TaskEnvironment import SpatialGoalEnvironment
     T, speed = 210, 11.0 * 0.08
 
@@ -574,13 +577,14 @@ def test_one_launch_task_step_with_other_populations_and_batches(riab, batch):
         try:
             np.random.seed(21)
             env = SpatialGoalEnvironment(params={"walls": [[[0.4, 0.0], [0.4, 0.5]]]}, possible_goal_positions="random_6",
-                                         goalcachekws=dict(reset_n_goals=3, goalorder="nonsequential"),
-                                         episode_terminate_delay=0.02, teleport_on_reset=True, seed=3)
+                                         goalcachekws=dict(reset_n_goals=3 if radius is None else 1, goalorder="nonsequential"),
+                                         goalkws=dict() if radius is None else dict(goal_radius=radius),
+                                         episode_terminate_delay=0.02 if radius is None else 0.0, teleport_on_reset=True, seed=3)
             Ag = riab.Agent(env, {"dt": 0.01, "n_agents": 512, "seed": 9})
-            pops = [riab.HeadDirectionCells(Ag, {"n": 12, "save_spikes": False}),
+            pops = [riab.HeadDirectionCells(Ag, {"n": 12 if not all_spikes else 41, "save_spikes": all_spikes, "max_fr": 20}),
                     riab.PlaceCells(Ag, {"n": 150, "wall_geometry": "euclidean", "save_spikes": True, "max_fr": 25}),
                     riab.BoundaryVectorCells(Ag, {"n": 20, "save_spikes": False}),
-                    riab.GridCells(Ag, {"n": 30, "save_spikes": False})]
+                    riab.GridCells(Ag, {"n": 30, "save_spikes": all_spikes, "max_fr": 15})]
             env.add_agents(Ag)
             plan = env.make_step_plan(neurons=pops, capacity=256, auto_reset=True, scripted_speed=speed)
             for _ in range(T // batch):
@@ -609,6 +613,11 @@ def test_one_launch_task_step_with_other_populations_and_batches(riab, batch):
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     assert ep_a == ep_b and d_a == d_b and len(ep_a["episode"]) > 3
+    if radius is not None:   # (many lanes reset per step: more than one round of seven quads in a segment's second pass)
+        jumps = np.abs(np.diff(a["traj"][:, 0:2, :512], axis=0)).max(1) > 0.05
+        assert jumps.sum(1).max() > 16, int(jumps.sum(1).max())
+    if all_spikes:
+        assert all(a[f"sp{i}"].any() for i in (0, 1, 3))
 
 
 def test_one_launch_task_step_in_a_captured_graph(riab):
