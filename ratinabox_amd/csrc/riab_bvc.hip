@@ -14,8 +14,12 @@
 //   stage B  wave w owns the 4-cell groups g = w (mod 8); per group the K-loop reads d[k][lane]
 //            (conflict-free ds_read_b32) and the wave-uniform angular table entry (scalar
 //            load), one fused exponent per term: exp2(-(a d - a mu)^2 + T[c][k]).
+#include <type_traits>
 #include "riab_device.h"
 
+#ifndef RIAB_BVC_XCH_KB
+#define RIAB_BVC_XCH_KB 1  // pairs of rays per pass over the walls in a workgroup that exchanges its rays (see cast_rays)
+#endif
 namespace riab {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -85,7 +89,10 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
   const const_f64_ptr dirs = (const_f64_ptr)(const void*)a.test_dirs;
   const const_f64_ptr rden = (const_f64_ptr)(const void*)a.ray_rden;
 
-  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+  // (the tile's workgroups have ids `tiles` apart — on one XCD when the tiles are a multiple of eight; giving them
+  // neighbouring ids instead, so that they are dispatched together, measured slower: 41.4 -> 42.8 us per row at cfg 3)
+  const int tile = (int)blockIdx.x, part = (int)blockIdx.y, nparts = (int)gridDim.y;
+  const int64_t p = (int64_t)tile * 64 + lane;
   const bool live = p < a.P;
   const int64_t pc = live ? p : 0;
   const int64_t t = pc / a.B;
@@ -98,7 +105,6 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
   //   l_a = (d0 . sb_p) / (sa . sb_p),  l_b = (-d0 . sa_p) / (sb . sa_p),  sb . sa_p = -(sa . sb_p)
   // Four test directions per pass over the walls: the wall-only quantities (d0, its cross product
   // with the wall) are computed once per wall and pass, leaving 1 + 3 multiply-adds per (ray, wall).
-  constexpr int KB = 4;
   // Box fast path.  When the first four walls are the edges of the rectangular room (checked here on the wall table
   // itself: axis-aligned, on the extent, spanning it) and every position of the tile is strictly inside it, a ray
   // leaves the room through the edge whose LINE it crosses first: the nearest positive l_a over the four edges is
@@ -129,8 +135,12 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
   // Which rays THIS workgroup casts: all of them — or, where the tile's gridDim.y workgroups exchange their rays (a.xch),
   // every gridDim.y-th batch: `vw` of `nvw` virtual waves.  (The whole of stage A is the lambda `cast_rays`; a workgroup
   // whose partners do not show up casts the rest itself.)
-  auto cast_rays = [&](const int vw, const int nvw, const bool publish) {
-  float* const xrow = publish ? a.xch + (int64_t)blockIdx.x * a.Kp * 64 + lane : nullptr;
+  // (KB_: test directions / pairs of them per pass over the walls — four where a wave has many passes; a wave of an
+  // exchanging workgroup has one or two pairs in all, and a pass of four computes two or three it then throws away:
+  // [MI355X] the row with four / two / one per pass: cfg 3 (9 walls) 41.4 / 41.3 / 39.5 us, 64 walls 80.2 / 62.8 / 58.5)
+  auto cast_rays = [&](auto KB_, const int vw, const int nvw, const bool publish) {
+  constexpr int KB = decltype(KB_)::value;
+  float* const xrow = publish ? a.xch + (int64_t)tile * a.Kp * 64 + lane : nullptr;
   auto put = [&](int k, float d) {
     s_d[k * 64 + lane] = d;
     if (publish) __hip_atomic_store((__attribute__((address_space(1))) float*)(uintptr_t)(xrow + k * 64), d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
           const int k = kk[i];
           const float d = (float)((best[i] < INFINITY) ? best[i] : fallback[i]);
           put(k, d);
-          if (a.ray_out && live && (publish || blockIdx.y == 0)) a.ray_out[(t * K + k) * a.B + b] = d;
+          if (a.ray_out && live && (publish || part == 0)) a.ray_out[(t * K + k) * a.B + b] = d;
         }
       }
     }
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
           const float dn = (float)((bneg[i] < INFINITY) ? bneg[i] : -fallback[i]);
           put(k, dp);
           put(k + m, dn);
-          if (a.ray_out && live && (publish || blockIdx.y == 0)) {
+          if (a.ray_out && live && (publish || part == 0)) {
             a.ray_out[(t * K + k) * a.B + b] = dp;
             a.ray_out[(t * K + k + m) * a.B + b] = dn;
           }
@@ -269,21 +279,21 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
     cast_single(K, 0);
   }
   };  // cast_rays
-  const bool exchange = a.xch != nullptr && gridDim.y > 1;
+  const bool exchange = a.xch != nullptr && nparts > 1;
   if (!exchange) {
-    cast_rays(wave, 8, false);
+    cast_rays(std::integral_constant<int, 4>{}, wave, 8, false);
   } else {
     // ---- a tile's workgroups share stage A: each casts every gridDim.y-th batch of rays, publishes them write-through,
     // announces itself on the tile's counter, and waits — a few tens of microseconds at most — until all have: then the
     // whole tile comes from the exchange rows (past L1).  Partners that do not show up in time (a device that does not
     // hold the whole grid at once): this workgroup casts every ray itself — the same values either way.
-    cast_rays(wave + 8 * (int)blockIdx.y, 8 * (int)gridDim.y, true);
+    cast_rays(std::integral_constant<int, RIAB_BVC_XCH_KB>{}, wave + 8 * part, 8 * nparts, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's rows have been acknowledged)
     __syncthreads();
     __shared__ int s_all_here;
     if (tid == 0) {
       typedef __attribute__((address_space(1))) uint32_t gu32;
-      gu32* const cnt = (gu32*)(uintptr_t)(a.xch_count + blockIdx.x);
+      gu32* const cnt = (gu32*)(uintptr_t)(a.xch_count + tile);
       __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int ok = 0;
       for (int spins = 0; spins < 256; ++spins) {  // (~0.3 us per poll)
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
     }
     __syncthreads();
     if (s_all_here) {
-      const float* const x = a.xch + (int64_t)blockIdx.x * a.Kp * 64;
+      const float* const x = a.xch + (int64_t)tile * a.Kp * 64;
       for (int i = tid; i < K * 16; i += 512) {  // 16 bytes per thread and pass
         typedef __attribute__((address_space(1))) unsigned long long gu64;
         gu64* const g = (gu64*)(uintptr_t)(x + 4 * i);
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
         *reinterpret_cast<unsigned long long*>(s_d + 4 * i + 2) = hi;
       }
     } else {
-      cast_rays(wave, 8, false);
+      cast_rays(std::integral_constant<int, 4>{}, wave, 8, false);
     }
   }
   // pad rows: an infinite distance makes the term exp2(-inf) = 0 for any (finite or -inf) table entry
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(512) void bvc_kernel(const BvcArgs a) {
   const int n_groups = (n + 3) >> 2;
   // (gridDim.y > 1: a launch of few tiles — one row of a closed loop — deals its cell groups to several workgroups per
   // tile, each of which has cast the tile's rays for itself: see the launch)
-  for (int g = wave + 8 * (int)blockIdx.y; g < n_groups; g += 8 * (int)gridDim.y) {
+  for (int g = wave + 8 * part; g < n_groups; g += 8 * nparts) {
     float aa[4], nmu[4], kap[4];
     const_f32_ptr tc[4];
     const_f32_ptr ts[4];
@@ -542,7 +552,7 @@ int riab::launch_bvc(const RiabEnv* env, const RiabRateIO* io, const double* tes
   const bool capturing = xch && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
   // ... and only in rooms with interior walls: in an open box stage A is the four edges' fast path and the exchange costs more
   // than it saves ([MI355X] closed-loop step, with / without: cfg 5 (4 walls) 88.6 / 83.4 us, cfg 3 (9 walls) 55.9 / 58.0,
-  // cfg3_64w (64 walls) 95 / 184)
+  // cfg3_64w (64 walls) 95 / 184; with one pair per pass in the exchanging workgroups 74 — and still nothing in the open box: 78.2 / 77.7)
   if (xch && xch_count && xch_arrivals && !capturing && split > 1 && io->T == 1 && n_cus > 0 && env->n_walls >= 8 &&
       tiles * split <= 2 * (int64_t)n_cus) {
     *xch_arrivals += (uint32_t)split;
