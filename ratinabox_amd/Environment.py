@@ -362,7 +362,11 @@ class Environment:
         return flags.cpu().numpy() == 1
 
     # -- device tables --------------------------------------------------------------------
-    WALL_GRID_FROM = 13     # walls from which the motion step gets a broad phase (include/riab_hip.h RiabMotion.wall_grid)
+    # walls from which the motion step gets a broad phase (include/riab_hip.h RiabMotion.wall_grid): any room with an interior
+    # wall.  (Built for rooms of dozens of walls — 10.1 -> 3.8 us per step at 64 —; at the nine walls of BASELINE configs[2]
+    # the throughput kernel neither gains nor loses (196-198 M either way), the latency-bound one-launch step gains 2 us
+    # (closed loop 52.7 -> 50.7 us per step): from 13 walls until that was measured.)
+    WALL_GRID_FROM = 5
 
     def wall_grid(self, device, wd, lmax=0.02):
         """The broad phase of the motion step for wall-heavy rooms (include/riab_hip.h: RiabMotion.wall_grid): per cell of

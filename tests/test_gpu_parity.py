@@ -155,12 +155,14 @@ def test_sixty_four_walls_vs_reference(riab):
         riab.Agent(env).update()
 
 
+@pytest.mark.parametrize("room", ["comb60", "maze5"])
 @pytest.mark.parametrize("path", ["update", "simulate", "plan"])
-def test_wall_grid_broad_phase_changes_no_bit(riab, path):
-    """Rooms of 13 walls and more: the motion kernels look only at the walls their cell's masks name (RiabMotion.wall_grid,
+def test_wall_grid_broad_phase_changes_no_bit(riab, path, room):
+    """Rooms with interior walls: the motion kernels look only at the walls their cell's masks name (RiabMotion.wall_grid,
     Environment.wall_grid).  Against the same kernels looking at every wall (RIAB_NO_WALL_GRID=1): state, history,
     diagnostics — every bit, through the per-step kernel, the four-wave trajectory kernel and the one-launch step; the
-    comb maze of bench.py's cfg3_64w, fast agents (long steps: some beyond the masks' step length), a drift towards walls."""
+    comb maze of bench.py's cfg3_64w and the five-wall maze of its cfg 3, fast agents (long steps: some beyond the masks' step
+    length), a drift towards walls."""
     import os
     import bench
 
@@ -169,7 +171,8 @@ def test_wall_grid_broad_phase_changes_no_bit(riab, path):
             os.environ["RIAB_NO_WALL_GRID"] = "1"
         try:
             np.random.seed(3)
-            env = riab.Environment({"walls": bench.comb_walls(60)})
+            env = riab.Environment({"walls": bench.comb_walls(60) if room == "comb60" else bench.CONFIGS["cfg3"]["walls"]})
+            assert (env.wall_grid("cuda", 0.1) is None) == no_grid   # (any room with an interior wall has the grid)
             ag = riab.Agent(env, {"n_agents": 1024, "dt": 0.02, "seed": 12, "speed_mean": 0.35, "thigmotaxis": 0.2})
             pcs = riab.PlaceCells(ag, {"n": 32, "wall_geometry": "euclidean"})
             drift = np.tile(np.array([[0.6, 0.1]]), (1024, 1))
