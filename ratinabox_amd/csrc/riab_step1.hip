@@ -30,6 +30,9 @@
 // rate_kernel_wide evaluates them.  Bit-identical to the two-launch step (tests/test_gpu_step1.py).
 // [MI355X] cfg 2 (4096 agents x 1024 PlaceCells): 9.0-9.2 us per step against 13.7; where it goes and what was tried:
 // DESIGN.md 3.9, docs/EXPERIMENTS.md r05.
+#include <map>
+#include <mutex>
+#include <utility>
 #include "riab_agent_kernel.h"
 #include "riab_rate_cells.h"
 #include "riab_task_world_kernel.h"  // (last: riab_task_kernel.h, which it includes, turns fp contraction off for its own code)
@@ -193,6 +196,9 @@ struct Step1Task {
 #ifndef RIAB_S1_TASK_DROP
 #define RIAB_S1_TASK_DROP 0
 #endif
+#ifndef RIAB_S1_STORE
+#define RIAB_S1_STORE RIAB_STORE_WT
+#endif
 #ifndef RIAB_S1_FEW
 #define RIAB_S1_FEW 1  // a task's second pass over the quads a reset moved: s1_group_few (0: the whole pass again, stored by those quads)
 #endif
@@ -232,9 +238,9 @@ __device__ __forceinline__ void s1_group(const Cell& cell, const Step1Pops& ps, 
       if (store) {
         if (RIAB_S1_ABLATE & 2) {
           if (rr.x == 123.0f) *reinterpret_cast<v4f*>(q.rates + off) = rr;
-        } else if (NT) store_stream<RIAB_STORE_WT>(q.rates + off, rr);
+        } else if (NT) store_stream<RIAB_S1_STORE>(q.rates + off, rr);
         else *reinterpret_cast<v4f*>(q.rates + off) = rr;
-        if (SPK && q.spikes) spike_store<false, RIAB_STORE_WT>(sa, rr, off, ps.step0, (uint32_t)(c0 + j), ps.quad0 + quad);  // (wave-uniform)
+        if (SPK && q.spikes) spike_store<false, RIAB_S1_STORE>(sa, rr, off, ps.step0, (uint32_t)(c0 + j), ps.quad0 + quad);  // (wave-uniform)
       }
       off += B;
     }
@@ -289,9 +295,9 @@ __device__ __forceinline__ void s1_group_few(const Cell& cell, const Step1Pops& 
     if (my_quad >= 0 && c < q.n) {
       const uint32_t quad = quad0 + (uint32_t)my_quad;
       const int64_t off = (int64_t)c * B + 4 * (int64_t)quad;
-      if (NT) store_stream<RIAB_STORE_WT>(q.rates + off, rr);
+      if (NT) store_stream<RIAB_S1_STORE>(q.rates + off, rr);
       else *reinterpret_cast<v4f*>(q.rates + off) = rr;
-      if (SPK && q.spikes) spike_store<false, RIAB_STORE_WT>(sa, rr, off, ps.step0, (uint32_t)c, ps.quad0 + quad);
+      if (SPK && q.spikes) spike_store<false, RIAB_S1_STORE>(sa, rr, off, ps.step0, (uint32_t)c, ps.quad0 + quad);
     }
   }
 }
@@ -686,7 +692,12 @@ __device__ __forceinline__ void step1_body(const AgentArgs& a, const Step1Pops& 
     if (wlive)
       world_phase_a(tk.a, goals, s_world, b, px, py, win, tk.t_env, w_pad_start0, w_terminal_prev, tk.reward_out, tk.terminal_out,
                     tk.met, tk.cand, tk.ctl);
-    __syncthreads();  // (phase A's write-through stores have been acknowledged)
+    // (phase A's write-through stores must have been ACKNOWLEDGED before the ticket is taken: the workgroup with the last
+    // ticket reads them.  A barrier does not wait for them — the compiler puts `lgkmcnt(0)` in front of it, a workgroup's
+    // waves need no more of each other —: without this wait the last workgroup read, once in some millions of steps
+    // beside a foreign load, a row that had not arrived yet; tools/task_world_soak.py found it)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (an asm statement with a memory clobber here costs one instantiation a stack frame)
+    __syncthreads();
     if (tid == 0) s_world.last = atomicAdd(tk.ctl, 1) == (int)gridDim.x - 1;
     __syncthreads();
     if (s_world.last) {  // (workgroup-uniform)
@@ -1172,7 +1183,9 @@ __global__ __launch_bounds__(64 * RIAB_S1_WAVES, RIAB_S1_WAVES_PER_EU) void step
                                                                                                 const MotionConst<double> hk,
                                                                                                 const TailConst<double> tail_c,
                                                                                                 const Step1Task tk) {
-  kernarg_warm<(int)sizeof(Step1TaskKernArgs) + 32>();  // (+ the grid's size, the first of the implicit arguments)
+  // (not where the kernel draws spikes: there the statement's registers cost one instantiation — the one-world step of
+  // PlaceCells with spikes, `<1, 15, 0>` — a 36-byte stack frame, and a kernel with a frame is not used at all)
+  if (SPK == 0) kernarg_warm<(int)sizeof(Step1TaskKernArgs) + 32>();  // (+ the grid's size, the first of the implicit arguments)
   step1_body<SPK, true, TASK, KIND>(a, ps, sy, reps, hk, tail_c, tk);
 }
 
@@ -1326,7 +1339,14 @@ static int launch_step1_impl(const AgentArgs& a, const RiabEnv* env, const Step1
     // A kernel the register allocator gave a stack frame (a few bytes of spilled scalars, never touched) would have the
     // dispatcher set scratch memory up for every launch — more than the fusion saves: such an instantiation is not used.
     auto launch = [&](auto kernel) -> int {
-      static int frame = -1, per_cu = 0;  // (per instantiation)
+      // (per KERNEL: the lambda's own statics would be shared by every instantiation — they all have one function type —
+      // and the first kernel asked about would answer for all of them)
+      static std::mutex info_lock;
+      static std::map<const void*, std::pair<int, int>> info;
+      std::lock_guard<std::mutex> guard(info_lock);
+      std::pair<int, int>& fi = info.emplace(reinterpret_cast<const void*>(kernel), std::make_pair(-1, 0)).first->second;
+      int& frame = fi.first;
+      int& per_cu = fi.second;
       if (frame < 0) {
         hipFuncAttributes fa;
         if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) != hipSuccess) return RIAB_EUNSUPPORTED;

@@ -54,8 +54,10 @@ __device__ __forceinline__ void world_step_body(const TaskArgs& a, double* world
   __syncthreads();
   const lds_f64_ptr goals = (lds_f64_ptr)s_goals;
   if (live) world_phase_a(a, goals, S, b, px, py, in, t_env, pad_start0, terminal_prev, reward_out, terminal_out, met, cand, ctl);
-  // ---- the last workgroup to get here goes on (what phase B reads of the others' phase A was written through and has
-  // been acknowledged: the barrier waits for every wave's stores — riab_task_world_kernel.h)
+  // ---- the last workgroup to get here goes on: what phase B reads of the others' phase A was written through and has
+  // been acknowledged — waited for HERE, wave by wave (a barrier alone does not wait for global stores: the compiler puts
+  // `lgkmcnt(0)` in front of it)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) S.last = atomicAdd(ctl, 1) == (int)gridDim.x - 1;
   __syncthreads();
